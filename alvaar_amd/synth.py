@@ -1,0 +1,204 @@
+"""Seeded synthetic inputs shared by tests and bench.py.
+
+Identical bytes go to the HIP path, the oracle restatement and the compiled
+reference.  Pure numpy; nothing here touches oracle/ or the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def texture_canvas(width: int, height: int, seed: int = 7, margin: int = 400) -> np.ndarray:
+    """Random filled squares on black: (H+margin) x (W+margin) u8.
+
+    W*H/100 squares, side 4 + r%12, gray r%256, uniform positions
+    (recipe of SURVEY.md §8(d); our own RNG stream).
+    """
+    rng = np.random.RandomState(seed)
+    ch, cw = height + margin, width + margin
+    canvas = np.zeros((ch, cw), np.uint8)
+    n = (width * height) // 100
+    xs = rng.randint(0, cw, n)
+    ys = rng.randint(0, ch, n)
+    sides = 4 + rng.randint(0, 12, n)
+    grays = rng.randint(0, 256, n)
+    for x, y, s, g in zip(xs, ys, sides, grays):
+        canvas[y:y + s, x:x + s] = g
+    return canvas
+
+
+def frame_gray(canvas: np.ndarray, k: int, width: int, height: int, noise_seed: int | None = None) -> np.ndarray:
+    """Frame k = crop of the canvas at offset (2k, k); optional +-5 gray noise."""
+    x0, y0 = 2 * k, k
+    g = canvas[y0:y0 + height, x0:x0 + width].copy()
+    if noise_seed is not None:
+        rng = np.random.RandomState(noise_seed + k)
+        g = np.clip(g.astype(np.int16) + rng.randint(-5, 6, g.shape), 0, 255).astype(np.uint8)
+    return g
+
+
+def gray_to_rgba(gray: np.ndarray, seed: int | None = None) -> np.ndarray:
+    """RGBA = (g, g, g, 255); with a seed, R/G/B get independent +-3 jitter so the
+    colour weights of the gray conversion are actually exercised."""
+    h, w = gray.shape
+    rgba = np.empty((h, w, 4), np.uint8)
+    if seed is None:
+        rgba[..., 0] = gray
+        rgba[..., 1] = gray
+        rgba[..., 2] = gray
+    else:
+        rng = np.random.RandomState(seed)
+        for c in range(3):
+            rgba[..., c] = np.clip(gray.astype(np.int16) + rng.randint(-3, 4, gray.shape), 0, 255)
+    rgba[..., 3] = 255
+    return rgba
+
+
+def random_rgba(width: int, height: int, seed: int) -> np.ndarray:
+    return np.random.RandomState(seed).randint(0, 256, (height, width, 4)).astype(np.uint8)
+
+
+def stream_rgba(width: int, height: int, n_frames: int, seed: int = 7, noise: bool = False) -> np.ndarray:
+    canvas = texture_canvas(width, height, seed)
+    out = np.empty((n_frames, height, width, 4), np.uint8)
+    for k in range(n_frames):
+        out[k] = gray_to_rgba(frame_gray(canvas, k, width, height, 11 if noise else None))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# SE3 helpers (Sophus conventions: tangent = (upsilon, omega), T <- Exp(d) * T)
+def so3_exp(w: np.ndarray) -> np.ndarray:
+    th = float(np.linalg.norm(w))
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], float)
+    if th < 1e-10:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def se3_exp(xi: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    v, w = np.asarray(xi[:3], float), np.asarray(xi[3:], float)
+    th = float(np.linalg.norm(w))
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], float)
+    R = so3_exp(w)
+    if th < 1e-10:
+        V = np.eye(3) + 0.5 * K
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return R, V @ v
+
+
+def rot_to_quat_xyzw(R: np.ndarray) -> np.ndarray:
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def quat_xyzw_to_rot(q: np.ndarray) -> np.ndarray:
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def pose7(R: np.ndarray, t: np.ndarray) -> np.ndarray:
+    """[tx,ty,tz,qx,qy,qz,qw] -- memory order of the reference's PoseParametersBlock
+    (ceres_parametrization.hpp:64-71; Eigen coeffs() order x,y,z,w)."""
+    return np.concatenate([np.asarray(t, float), rot_to_quat_xyzw(R)])
+
+
+def make_pnp_problem(n: int, seed: int = 3, fx: float = 579.4, fy: float = 579.4, cx: float = 320.0,
+                     cy: float = 240.0, width: int = 640, height: int = 480, noise_px: float = 0.5,
+                     outlier_frac: float = 0.1, pose_noise: float = 0.01):
+    """World points = back-projected pixels at depths U(3,9) under a ground-truth Twc;
+    returns dict(uv, bv, wpt, pose_gt, pose_init)."""
+    rng = np.random.RandomState(seed)
+    R, t = se3_exp(np.array([0.3, -0.1, 0.2, 0.05, -0.03, 0.02]))
+    uv = np.stack([rng.uniform(20, width - 20, n), rng.uniform(20, height - 20, n)], 1)
+    z = rng.uniform(3, 9, n)
+    pc = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+    wpt = pc @ R.T + t  # X_w = R_wc X_c + t_wc
+    uvn = uv + rng.normal(0, noise_px, uv.shape)
+    nout = int(outlier_frac * n)
+    if nout:
+        idx = rng.choice(n, nout, replace=False)
+        uvn[idx] += rng.uniform(-60, 60, (nout, 2))
+    bv = np.stack([(uvn[:, 0] - cx) / fx, (uvn[:, 1] - cy) / fy, np.ones(n)], 1)
+    bv /= np.linalg.norm(bv, axis=1, keepdims=True)
+    Rn, tn = se3_exp(rng.normal(0, pose_noise, 6))
+    Ri, ti = Rn @ R, Rn @ t + tn
+    return dict(uv=uvn, bv=bv, wpt=wpt, pose_gt=pose7(R, t), pose_init=pose7(Ri, ti),
+                K=(fx, fy, cx, cy))
+
+
+def make_ba_problem(n_kf: int = 20, n_pt: int = 3000, seed: int = 42, fx: float = 579.4, fy: float = 579.4,
+                    cx: float = 320.0, cy: float = 240.0, width: int = 640, height: int = 480,
+                    px_noise: float = 0.5, pose_noise: float = 0.005, invdepth_noise: float = 0.02,
+                    n_fixed: int = 2):
+    """Local-BA instance of SURVEY.md §8(d): poses exp([0.08k,0.01k,0,0.002k,0.01k,0]), points
+    U([-3,5]x[-2.5,2.5]x[3,9]), pixel noise N(0,0.5^2), pose perturbation N(0,0.005^2) on KFs >= n_fixed,
+    inverse-depth noise 2 %, first n_fixed KFs constant.  Anchored inverse depth: the first observer
+    (lowest kf index) is the anchor and contributes no residual (optimizer.cpp:186-201)."""
+    rng = np.random.RandomState(seed)
+    K = np.array([fx, fy, cx, cy])
+    Rs, ts = [], []
+    for k in range(n_kf):
+        R, t = se3_exp(np.array([0.08 * k, 0.01 * k, 0.0, 0.002 * k, 0.01 * k, 0.0]))
+        Rs.append(R)
+        ts.append(t)
+    pts = np.stack([rng.uniform(-3, 5, n_pt), rng.uniform(-2.5, 2.5, n_pt), rng.uniform(3, 9, n_pt)], 1)
+    poses_gt = np.stack([pose7(R, t) for R, t in zip(Rs, ts)])
+    poses = poses_gt.copy()
+    for k in range(n_fixed, n_kf):
+        Rn, tn = se3_exp(rng.normal(0, pose_noise, 6))
+        poses[k] = pose7(Rn @ Rs[k], Rn @ ts[k] + tn)
+    anchor_kf = np.full(n_pt, -1, np.int32)
+    anchor_uv = np.zeros((n_pt, 2))
+    inv_depth = np.zeros(n_pt)
+    obs_kf, obs_pt, obs_uv = [], [], []
+    for p in range(n_pt):
+        for k in range(n_kf):
+            pc = Rs[k].T @ (pts[p] - ts[k])
+            if pc[2] <= 0.5:
+                continue
+            u = fx * pc[0] / pc[2] + cx
+            v = fy * pc[1] / pc[2] + cy
+            if not (0 <= u < width and 0 <= v < height):
+                continue
+            un = u + rng.normal(0, px_noise)
+            vn = v + rng.normal(0, px_noise)
+            if anchor_kf[p] < 0:
+                anchor_kf[p] = k
+                anchor_uv[p] = (un, vn)
+                inv_depth[p] = (1.0 / pc[2]) * (1.0 + rng.normal(0, invdepth_noise))
+            else:
+                obs_kf.append(k)
+                obs_pt.append(p)
+                obs_uv.append((un, vn))
+    # keep only points with an anchor and >=1 residual; re-index densely
+    obs_kf = np.asarray(obs_kf, np.int32)
+    obs_pt = np.asarray(obs_pt, np.int32)
+    obs_uv = np.asarray(obs_uv, float).reshape(-1, 2)
+    used = np.zeros(n_pt, bool)
+    used[obs_pt] = True
+    remap = -np.ones(n_pt, np.int32)
+    remap[used] = np.arange(int(used.sum()), dtype=np.int32)
+    kf_const = np.zeros(n_kf, np.uint8)
+    kf_const[:n_fixed] = 1
+    return dict(poses=poses, poses_gt=poses_gt, kf_const=kf_const, calib=K,
+                anchor_kf=anchor_kf[used].copy(), anchor_uv=anchor_uv[used].copy(), inv_depth=inv_depth[used].copy(),
+                pts_gt=pts[used].copy(), obs_kf=obs_kf, obs_pt=remap[obs_pt].copy(), obs_uv=obs_uv)

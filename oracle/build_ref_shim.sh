@@ -1,0 +1,55 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE ONLY.  Compiles, with plain g++ and no -march flag
+# (portable to the GPU box's host CPU, one Eigen alignment ABI everywhere):
+#   * OpenGV 1.0 sources    (/root/reference/src/libs/opengv/src/**/*.cpp)
+#   * AlvaAR slam sources   (/root/reference/src/slam/src/*.cpp minus embind.cpp)
+#   * oracle/ref_shim.cpp   (our extern "C" marshalling layer)
+# from where they lie, and links them with the static OpenCV/Ceres built by
+# build_ref_libs.sh into oracle/_ref/libalva_ref.so.  Objects are cached under
+# oracle/_ref/build/obj and only rebuilt when the source is newer.
+set -euo pipefail
+REF=${ALVA_REFERENCE_ROOT:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+P="$OUT/prefix"
+OBJ="$OUT/build/obj"
+J=${ALVA_REF_JOBS:-$(nproc)}
+if [ ! -d "$REF/src/slam/src" ]; then
+  echo "reference tree not present at $REF; keeping prebuilt $OUT/libalva_ref.so" >&2
+  exit 0
+fi
+"$HERE/build_ref_libs.sh"
+mkdir -p "$OBJ/opengv" "$OBJ/slam"
+L="$REF/src/libs"
+INC="-I$REF/src/slam/src -I$P/include/opencv4 -I$L/opencv/modules/highgui/include -I$L/opencv/modules/imgcodecs/include \
+ -I$L/opencv/modules/videoio/include -I$L/eigen -I$L/eigen/unsupported -I$L/Sophus -I$L/opengv/include -I$P/include -I$P/include/ceres/internal/miniglog"
+CXXFLAGS="-O2 -fPIC -w -DNDEBUG"
+
+compile() { # src obj std
+  if [ ! -f "$2" ] || [ "$1" -nt "$2" ]; then
+    echo "g++ -std=$3 $CXXFLAGS $INC -c '$1' -o '$2'"
+  fi
+}
+{
+  while IFS= read -r f; do
+    o="$OBJ/opengv/$(echo "${f#$L/opengv/src/}" | tr '/' '_' | sed 's/\.cpp$/.o/')"
+    compile "$f" "$o" c++17
+  done < <(find "$L/opengv/src" -name '*.cpp' | sort)
+  for f in "$REF"/src/slam/src/*.cpp; do
+    b=$(basename "$f" .cpp)
+    [ "$b" = embind ] && continue
+    std=c++17
+    # system.cpp calls duration_cast<> unqualified: needs C++20 ADL on template-ids (SURVEY.md §8c gotcha i)
+    [ "$b" = system ] && std=c++20
+    compile "$f" "$OBJ/slam/$b.o" $std
+  done
+  compile "$HERE/ref_shim.cpp" "$OBJ/ref_shim.o" c++17
+} > "$OBJ/cmds.txt"
+if [ -s "$OBJ/cmds.txt" ]; then
+  xargs -P "$J" -I{} bash -c '{}' < "$OBJ/cmds.txt"
+fi
+g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
+  -Wl,--start-group "$P/lib/libopencv_video.a" "$P/lib/libopencv_calib3d.a" "$P/lib/libopencv_features2d.a" \
+  "$P/lib/libopencv_flann.a" "$P/lib/libopencv_imgproc.a" "$P/lib/libopencv_core.a" -Wl,--end-group \
+  "$P/lib/libceres.a" "$P"/lib/opencv4/3rdparty/libzlib.a -lpthread -ldl -Wl,--exclude-libs,ALL
+echo "built $OUT/libalva_ref.so"

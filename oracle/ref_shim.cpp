@@ -1,0 +1,461 @@
+// TEST INFRASTRUCTURE ONLY — never linked into, imported by, or called from the
+// product path (alvaar_amd/).  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load the library built from this file.
+//
+// ref_shim.cpp: a thin extern "C" surface over the REAL reference code, compiled
+// from the sources where they lie under /root/reference (nothing copied):
+//   * src/slam/src/*.cpp (minus embind.cpp)            -- AlvaAR's own L1 stages
+//   * vendored OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV 1.0 -- the arithmetic
+// Output: oracle/_ref/libalva_ref.so (git-ignored, travels to the GPU box).
+//
+// Everything here is marshalling: flat arrays in, flat arrays out.  Determinism
+// switches: cv::setNumThreads(1); OpenGV doRandom=false;
+// Ceres wall-clock caps removed in the *_nocap entry points (the capped
+// reference methods are also exposed unchanged).
+#include <sstream>
+#include <string>
+#include "frame.hpp"
+#include <opencv2/imgproc.hpp>
+#include <opencv2/highgui.hpp>
+#define private public  // read FeatureExtractor::maxQuality_ (stateful across calls, feature_extractor.cpp:138-145)
+#include "feature_extractor.hpp"
+#undef private
+#include "feature_tracker.hpp"
+#include "multi_view_geometry.hpp"
+#include "ceres_parametrization.hpp"
+
+#include <opencv2/core.hpp>
+#include <opencv2/imgproc.hpp>
+#include <opencv2/features2d.hpp>
+#include <opencv2/video/tracking.hpp>
+
+#include <ceres/ceres.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <memory>
+#include <unordered_map>
+
+extern cv::Ptr<cv::DescriptorExtractor> descriptor_;  // feature_extractor.cpp:5 (global)
+
+namespace {
+struct Init {
+    Init() { cv::setNumThreads(1); }
+} g_init;
+
+inline cv::Mat wrapGray(const uint8_t *gray, int w, int h) {
+    return cv::Mat(h, w, CV_8UC1, const_cast<uint8_t *>(gray));
+}
+}  // namespace
+
+extern "C" {
+
+const char *ref_build_info() {
+    static std::string s = cv::getBuildInformation();
+    return s.c_str();
+}
+
+// a2: system.cpp:111-112  cv::cvtColor(RGBA2GRAY)
+int ref_rgba2gray(const uint8_t *rgba, int w, int h, uint8_t *gray) {
+    cv::Mat src(h, w, CV_8UC4, const_cast<uint8_t *>(rgba));
+    cv::Mat dst(h, w, CV_8UC1, gray);
+    cv::cvtColor(src, dst, cv::COLOR_RGBA2GRAY);
+    return dst.data == gray ? 0 : -1;
+}
+
+// a3: visual_frontend.cpp:696 cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), maxLevel)
+// Outputs, per level l (0..ret): padded gray (h_l+2win)x(w_l+2win) u8 at gray_out[l],
+// padded deriv (h_l+2win)x(w_l+2win)x2 i16 at deriv_out[l]; dims[l] = {w_l,h_l}.
+// Returns number of levels built - 1 (OpenCV convention) or <0 on error.
+int ref_build_pyramid(const uint8_t *gray, int w, int h, int win, int maxLevel,
+                      uint8_t **gray_out, int16_t **deriv_out, int *dims /*[2*(maxLevel+1)]*/) {
+    std::vector<cv::Mat> pyr;
+    int lv = cv::buildOpticalFlowPyramid(wrapGray(gray, w, h), pyr, cv::Size(win, win), maxLevel);
+    for (int l = 0; l <= lv; l++) {
+        cv::Mat g = pyr[2 * l], d = pyr[2 * l + 1];
+        dims[2 * l] = g.cols;
+        dims[2 * l + 1] = g.rows;
+        g.adjustROI(win, win, win, win);
+        d.adjustROI(win, win, win, win);
+        if (gray_out && gray_out[l]) {
+            cv::Mat dstg(g.rows, g.cols, CV_8UC1, gray_out[l]);
+            g.copyTo(dstg);
+        }
+        if (deriv_out && deriv_out[l]) {
+            cv::Mat dstd(d.rows, d.cols, CV_16SC2, deriv_out[l]);
+            d.copyTo(dstd);
+        }
+    }
+    return lv;
+}
+
+// a4: FeatureTracker::fbKltTracking (feature_tracker.cpp:5-111) on two gray images.
+// pts[N][2] read-only; prior[N][2] in/out; status[N] out (1 = tracked).
+int ref_fbklt(const uint8_t *prevGray, const uint8_t *currGray, int w, int h,
+              int win, int pyrLevelsBuilt, int numLevels, float errThresh, float fbDist,
+              int maxIters, float eps, const float *pts, float *prior, uint8_t *status, int n) {
+    std::vector<cv::Mat> pp, cp;
+    cv::buildOpticalFlowPyramid(wrapGray(prevGray, w, h), pp, cv::Size(win, win), pyrLevelsBuilt);
+    cv::buildOpticalFlowPyramid(wrapGray(currGray, w, h), cp, cv::Size(win, win), pyrLevelsBuilt);
+    FeatureTracker tracker(maxIters, eps);
+    std::vector<cv::Point2f> vp(n), vq(n);
+    for (int i = 0; i < n; i++) {
+        vp[i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+        vq[i] = cv::Point2f(prior[2 * i], prior[2 * i + 1]);
+    }
+    std::vector<bool> st;
+    tracker.fbKltTracking(pp, cp, win, numLevels, errThresh, fbDist, vp, vq, st);
+    for (int i = 0; i < n; i++) {
+        prior[2 * i] = vq[i].x;
+        prior[2 * i + 1] = vq[i].y;
+        status[i] = (i < (int) st.size() && st[i]) ? 1 : 0;
+    }
+    return 0;
+}
+
+// Raw single-direction cv::calcOpticalFlowPyrLK (lkpyramid.cpp:1239-1404) with the flags the
+// reference uses (USE_INITIAL_FLOW + LK_GET_MIN_EIGENVALS); exposes status + err for finer tests.
+int ref_lk(const uint8_t *prevGray, const uint8_t *currGray, int w, int h, int win, int pyrLevelsBuilt,
+           int numLevels, int maxIters, float eps, const float *pts, float *next, uint8_t *status, float *err, int n) {
+    std::vector<cv::Mat> pp, cp;
+    cv::buildOpticalFlowPyramid(wrapGray(prevGray, w, h), pp, cv::Size(win, win), pyrLevelsBuilt);
+    cv::buildOpticalFlowPyramid(wrapGray(currGray, w, h), cp, cv::Size(win, win), pyrLevelsBuilt);
+    std::vector<cv::Point2f> vp(n), vq(n);
+    for (int i = 0; i < n; i++) {
+        vp[i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+        vq[i] = cv::Point2f(next[2 * i], next[2 * i + 1]);
+    }
+    std::vector<uchar> st;
+    std::vector<float> er;
+    cv::calcOpticalFlowPyrLK(pp, cp, vp, vq, st, er, cv::Size(win, win), numLevels,
+                             cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, maxIters, eps),
+                             cv::OPTFLOW_USE_INITIAL_FLOW + cv::OPTFLOW_LK_GET_MIN_EIGENVALS);
+    for (int i = 0; i < n; i++) {
+        next[2 * i] = vq[i].x;
+        next[2 * i + 1] = vq[i].y;
+        status[i] = st[i];
+        err[i] = er[i];
+    }
+    return 0;
+}
+
+// a5: FeatureExtractor::detectFeaturePoints (feature_extractor.cpp:11-158).
+// maxQuality is in/out (the reference adapts it per call).  Returns #points (<= cap).
+int ref_detect_grid(const uint8_t *gray, int w, int h, int cellSize, const float *occupied, int nOcc,
+                    int roiX, int roiY, int roiW, int roiH, double *maxQuality, float *outPts, int cap) {
+    FeatureExtractor fx(*maxQuality);
+    std::vector<cv::Point2f> occ(nOcc);
+    for (int i = 0; i < nOcc; i++) occ[i] = cv::Point2f(occupied[2 * i], occupied[2 * i + 1]);
+    std::vector<cv::Point2f> r = fx.detectFeaturePoints(wrapGray(gray, w, h), cellSize, occ, cv::Rect(roiX, roiY, roiW, roiH));
+    *maxQuality = fx.maxQuality_;
+    int n = std::min<int>(cap, r.size());
+    for (int i = 0; i < n; i++) {
+        outPts[2 * i] = r[i].x;
+        outPts[2 * i + 1] = r[i].y;
+    }
+    return (int) r.size();
+}
+
+// Pieces of a5 for stage-level tests: GaussianBlur(3x3) of an ROI view + cornerMinEigenVal(3,3) of the stand-alone result.
+int ref_cell_mineig(const uint8_t *gray, int w, int h, int x, int y, int cell, uint8_t *blurOut, float *eigOut) {
+    cv::Mat img = wrapGray(gray, w, h);
+    cv::Mat filtered, hmap;
+    cv::GaussianBlur(img(cv::Rect(x, y, cell, cell)), filtered, cv::Size(3, 3), 0.);
+    cv::cornerMinEigenVal(filtered, hmap, 3, 3);
+    if (blurOut) filtered.copyTo(cv::Mat(cell, cell, CV_8UC1, blurOut));
+    if (eigOut) hmap.copyTo(cv::Mat(cell, cell, CV_32FC1, eigOut));
+    return 0;
+}
+
+int ref_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n) {
+    std::vector<cv::Point2f> v(n);
+    for (int i = 0; i < n; i++) v[i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+    cv::cornerSubPix(wrapGray(gray, w, h), v, cv::Size(3, 3), cv::Size(-1, -1),
+                     cv::TermCriteria(cv::TermCriteria::EPS + cv::TermCriteria::MAX_ITER, 30, 0.01));
+    for (int i = 0; i < n; i++) {
+        pts[2 * i] = v[i].x;
+        pts[2 * i + 1] = v[i].y;
+    }
+    return 0;
+}
+
+// a6: FeatureExtractor::describeFeaturePoints (feature_extractor.cpp:160-214).
+// desc[N][32]; valid[i]=0 where the reference returns an empty Mat.
+int ref_describe(const uint8_t *gray, int w, int h, const float *pts, int n, uint8_t *desc, uint8_t *valid) {
+    FeatureExtractor fx(0.001);
+    std::vector<cv::Point2f> v(n);
+    for (int i = 0; i < n; i++) v[i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+    std::vector<cv::Mat> d = fx.describeFeaturePoints(wrapGray(gray, w, h), v);
+    for (int i = 0; i < n; i++) {
+        bool ok = i < (int) d.size() && !d[i].empty();
+        valid[i] = ok;
+        if (ok) std::memcpy(desc + 32 * i, d[i].ptr<uint8_t>(0), 32);
+        else std::memset(desc + 32 * i, 0, 32);
+    }
+    return 0;
+}
+
+// 7x7 sigma=2 Gaussian exactly as ORB applies it (orb.cpp:1188) to a border-32 REFLECT_101 copy.
+int ref_orb_blur(const uint8_t *gray, int w, int h, int border, uint8_t *out /* (h+2b)x(w+2b) */) {
+    cv::Mat ext;
+    cv::copyMakeBorder(wrapGray(gray, w, h), ext, border, border, border, border, cv::BORDER_REFLECT_101 + cv::BORDER_ISOLATED);
+    cv::Mat working = ext(cv::Rect(border, border, w, h));
+    cv::GaussianBlur(working, working, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+    ext.copyTo(cv::Mat(ext.rows, ext.cols, CV_8UC1, out));
+    return 0;
+}
+
+// a5': cv::FAST (fast.cpp:56-292) threshold t, NMS on, TYPE_9_16.  out: x,y (int), score (u8 response)
+int ref_fast(const uint8_t *gray, int w, int h, int threshold, int nms, int *xy, int *score, int cap) {
+    std::vector<cv::KeyPoint> kps;
+    cv::FAST(wrapGray(gray, w, h), kps, threshold, nms != 0, cv::FastFeatureDetector::TYPE_9_16);
+    int n = std::min<int>(cap, kps.size());
+    for (int i = 0; i < n; i++) {
+        xy[2 * i] = (int) kps[i].pt.x;
+        xy[2 * i + 1] = (int) kps[i].pt.y;
+        score[i] = (int) kps[i].response;
+    }
+    return (int) kps.size();
+}
+
+// a5': cv::ORB::create(nfeatures, scale, nlevels, 31, 0, 2, HARRIS_SCORE, 31, fastThr)->detectAndCompute
+// kp[i] = {x, y, size, angle, response, octave}; desc[i][32].  Returns count.
+int ref_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures, float scaleFactor, int nlevels,
+                               int fastThreshold, int doDescribe, float *kp, uint8_t *desc, int cap) {
+    cv::Ptr<cv::ORB> orb = cv::ORB::create(nfeatures, scaleFactor, nlevels, 31, 0, 2, cv::ORB::HARRIS_SCORE, 31, fastThreshold);
+    std::vector<cv::KeyPoint> kps;
+    cv::Mat d;
+    if (doDescribe) orb->detectAndCompute(wrapGray(gray, w, h), cv::noArray(), kps, d);
+    else orb->detect(wrapGray(gray, w, h), kps);
+    int n = std::min<int>(cap, kps.size());
+    for (int i = 0; i < n; i++) {
+        kp[6 * i + 0] = kps[i].pt.x;
+        kp[6 * i + 1] = kps[i].pt.y;
+        kp[6 * i + 2] = kps[i].size;
+        kp[6 * i + 3] = kps[i].angle;
+        kp[6 * i + 4] = kps[i].response;
+        kp[6 * i + 5] = (float) kps[i].octave;
+        if (doDescribe && desc) std::memcpy(desc + 32 * i, d.ptr<uint8_t>(i), 32);
+    }
+    return (int) kps.size();
+}
+
+// a7: cv::BFMatcher(NORM_HAMMING).match (batch_distance.cpp:199-251): per query best train idx + distance.
+int ref_bf_match_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist) {
+    cv::Mat mq(nq, 32, CV_8UC1, const_cast<uint8_t *>(q)), mt(nt, 32, CV_8UC1, const_cast<uint8_t *>(t));
+    cv::BFMatcher matcher(cv::NORM_HAMMING, false);
+    std::vector<cv::DMatch> m;
+    matcher.match(mq, mt, m);
+    for (int i = 0; i < nq; i++) {
+        idx[i] = -1;
+        dist[i] = -1;
+    }
+    for (const auto &dm: m) {
+        idx[dm.queryIdx] = dm.trainIdx;
+        dist[dm.queryIdx] = (int) dm.distance;
+    }
+    return (int) m.size();
+}
+
+// a7: cv::norm(a,b,NORM_HAMMING) as called at map_point.cpp:106,158,212
+int ref_hamming(const uint8_t *a, const uint8_t *b) {
+    cv::Mat ma(1, 32, CV_8UC1, const_cast<uint8_t *>(a)), mb(1, 32, CV_8UC1, const_cast<uint8_t *>(b));
+    return (int) cv::norm(ma, mb, cv::NORM_HAMMING);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a8: MultiViewGeometry::p3pRansac (multi_view_geometry.cpp:24-127): OpenGV LMedS + Kneip P3P.
+// bv[N][3] unit bearings, wpt[N][3]; out Twc as R(3x3 row-major)+t, outliers list.
+// Returns 1 on success, 0 on failure.
+int ref_p3p_lmeds(const double *bv, const double *wpt, int n, int maxIterations, float errorThreshold,
+                  int doRandom, float fx, float fy, double *R_out, double *t_out, int *outliers, int *nOutliers) {
+    std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> vb(n), vw(n);
+    for (int i = 0; i < n; i++) {
+        vb[i] = Eigen::Vector3d(bv[3 * i], bv[3 * i + 1], bv[3 * i + 2]);
+        vw[i] = Eigen::Vector3d(wpt[3 * i], wpt[3 * i + 1], wpt[3 * i + 2]);
+    }
+    Sophus::SE3d Twc;
+    std::vector<int> out;
+    bool ok = MultiViewGeometry::p3pRansac(vb, vw, maxIterations, errorThreshold, false, doRandom != 0, fx, fy, Twc, out);
+    Eigen::Matrix3d R = Twc.rotationMatrix();
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) R_out[3 * r + c] = R(r, c);
+    for (int r = 0; r < 3; r++) t_out[r] = Twc.translation()(r);
+    *nOutliers = (int) out.size();
+    for (size_t i = 0; i < out.size(); i++) outliers[i] = out[i];
+    return ok ? 1 : 0;
+}
+
+// a9: MultiViewGeometry::ceresPnP exactly as shipped (includes the 5 ms wall-clock cap, :185).
+// pose7 = [tx,ty,tz,qx,qy,qz,qw] in/out.
+int ref_ceres_pnp_shipped(const double *uv, const double *wpt, int n, double *pose7, int maxIterations, float chi2th,
+                          int useRobust, int applyL2AfterRobust, float fx, float fy, float cx, float cy,
+                          int *outliers, int *nOutliers) {
+    std::vector<Eigen::Vector2d, Eigen::aligned_allocator<Eigen::Vector2d>> vk(n);
+    std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> vw(n);
+    for (int i = 0; i < n; i++) {
+        vk[i] = Eigen::Vector2d(uv[2 * i], uv[2 * i + 1]);
+        vw[i] = Eigen::Vector3d(wpt[3 * i], wpt[3 * i + 1], wpt[3 * i + 2]);
+    }
+    Eigen::Map<Eigen::Vector3d> t(pose7);
+    Eigen::Map<Eigen::Quaterniond> q(pose7 + 3);
+    Sophus::SE3d Twc(q, t);
+    std::vector<int> out;
+    bool ok = MultiViewGeometry::ceresPnP(vk, vw, Twc, maxIterations, chi2th, useRobust != 0, applyL2AfterRobust != 0, fx, fy, cx, cy, out);
+    PoseParametersBlock pb(0, Twc);
+    std::memcpy(pose7, pb.values(), 7 * sizeof(double));
+    *nOutliers = (int) out.size();
+    for (size_t i = 0; i < out.size(); i++) outliers[i] = out[i];
+    return ok ? 1 : 0;
+}
+
+// a9 with the wall-clock cap removed: same problem construction as multi_view_geometry.cpp:143-218,
+// using the reference's own cost function / parameterization classes; only
+// options.max_solver_time_in_seconds is left at its default.  Extra outputs for parity:
+// iteration count of both solves, final cost of both solves.
+int ref_ceres_pnp_nocap(const double *uv, const double *wpt, int n, double *pose7, int maxIterations, float chi2th,
+                        int useRobust, int applyL2AfterRobust, float fx, float fy, float cx, float cy,
+                        int *outliers, int *nOutliers, double *info /*[8]*/) {
+    ceres::Problem problem;
+    double chi2ThresholdSqrt = std::sqrt(chi2th);
+    auto *lossFunction = new ceres::LossFunctionWrapper(new ceres::HuberLoss(chi2ThresholdSqrt), ceres::TAKE_OWNERSHIP);
+    if (!useRobust) lossFunction->Reset(NULL, ceres::TAKE_OWNERSHIP);
+    ceres::LocalParameterization *lp = new SE3Parameterization();
+    Eigen::Map<Eigen::Vector3d> t(pose7);
+    Eigen::Map<Eigen::Quaterniond> q(pose7 + 3);
+    PoseParametersBlock posepar(0, Sophus::SE3d(q, t));
+    problem.AddParameterBlock(posepar.values(), 7, lp);
+    std::vector<DirectSE3::ReprojectionErrorSE3 *> verr;
+    std::vector<ceres::ResidualBlockId> vrid;
+    for (int i = 0; i < n; i++) {
+        auto *f = new DirectSE3::ReprojectionErrorSE3(uv[2 * i], uv[2 * i + 1], fx, fy, cx, cy,
+                                                       Eigen::Vector3d(wpt[3 * i], wpt[3 * i + 1], wpt[3 * i + 2]), 1.0);
+        vrid.push_back(problem.AddResidualBlock(f, lossFunction, posepar.values()));
+        verr.push_back(f);
+    }
+    ceres::Solver::Options options;
+    options.linear_solver_type = ceres::DENSE_QR;
+    options.trust_region_strategy_type = ceres::LEVENBERG_MARQUARDT;
+    options.num_threads = 1;
+    options.max_num_iterations = maxIterations;
+    options.function_tolerance = 1.e-3;
+    options.minimizer_progress_to_stdout = false;
+    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+    if (info) {
+        info[0] = (double) summary.iterations.size();
+        info[1] = summary.initial_cost;
+        info[2] = summary.final_cost;
+        info[3] = (double) summary.num_successful_steps;
+    }
+    int nbad = 0;
+    *nOutliers = 0;
+    for (int i = 0; i < n; i++) {
+        if (verr[i]->chi2err_ > chi2th || !verr[i]->isDepthPositive_) {
+            if (applyL2AfterRobust) problem.RemoveResidualBlock(vrid[i]);
+            outliers[(*nOutliers)++] = i;
+            nbad++;
+        }
+    }
+    if (nbad == n) return 0;
+    if (applyL2AfterRobust && nbad > 0) {
+        lossFunction->Reset(NULL, ceres::TAKE_OWNERSHIP);
+        ceres::Solve(options, &problem, &summary);
+        if (info) {
+            info[4] = (double) summary.iterations.size();
+            info[5] = summary.initial_cost;
+            info[6] = summary.final_cost;
+            info[7] = (double) summary.num_successful_steps;
+        }
+    }
+    std::memcpy(pose7, posepar.values(), 7 * sizeof(double));
+    return summary.IsSolutionUsable() ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10-a13: local bundle adjustment on a flat problem description, built with the reference's own
+// parameter blocks, SE3Parameterization, anchored-inverse-depth / XYZ cost functions and the solver
+// options of optimizer.cpp:251-262 -- minus the 10 ms cap, and with caller-chosen
+// max_num_iterations / function_tolerance (5 iterations, tolerance 0 for the bench).
+//
+//   poses[nKf][7]      [t, qx,qy,qz,qw] Twc, in/out
+//   kfConst[nKf]       1 = constant
+//   calib[4]           fx,fy,cx,cy (constant block)
+//   inverse-depth mode (invDepth=1): ptAnchorKf[nPt], ptAnchorUv[nPt][2], ptParam[nPt] (= 1/z_anchor) in/out
+//   xyz mode (invDepth=0): ptParam[nPt][3] in/out
+//   obs: obsKf[nObs], obsPt[nObs], obsUv[nObs][2]  (anchor observations are NOT listed in inv-depth mode)
+// Outputs: chi2[nObs], depthPos[nObs] (cost-function side outputs after the solve, optimizer.cpp:275-289),
+//          info[0]=#iterations summaries, [1]=initial cost, [2]=final cost, [3]=#successful steps,
+//          [4]=jacobian eval s, [5]=residual eval s, [6]=linear solver s, [7]=total s, [8]=preprocessor s
+int ref_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *calib, int invDepth,
+                 int nPt, const int *ptAnchorKf, const double *ptAnchorUv, double *ptParam,
+                 int nObs, const int *obsKf, const int *obsPt, const double *obsUv,
+                 int maxIterations, double functionTolerance, double huberChi2,
+                 double *chi2, uint8_t *depthPos, double *info) {
+    ceres::Problem problem;
+    auto *lossFunction = new ceres::LossFunctionWrapper(new ceres::HuberLoss(std::sqrt(huberChi2)), ceres::TAKE_OWNERSHIP);
+    auto ordering = new ceres::ParameterBlockOrdering;
+    double calibv[4] = {calib[0], calib[1], calib[2], calib[3]};
+    problem.AddParameterBlock(calibv, 4);
+    ordering->AddElementToGroup(calibv, 1);
+    problem.SetParameterBlockConstant(calibv);
+    for (int k = 0; k < nKf; k++) {
+        problem.AddParameterBlock(poses + 7 * k, 7, new SE3Parameterization());
+        ordering->AddElementToGroup(poses + 7 * k, 1);
+        if (kfConst[k]) problem.SetParameterBlockConstant(poses + 7 * k);
+    }
+    int pdim = invDepth ? 1 : 3;
+    for (int p = 0; p < nPt; p++) {
+        problem.AddParameterBlock(ptParam + pdim * p, pdim);
+        ordering->AddElementToGroup(ptParam + pdim * p, 0);
+    }
+    std::vector<ceres::CostFunction *> fs(nObs);
+    for (int o = 0; o < nObs; o++) {
+        int k = obsKf[o], p = obsPt[o];
+        if (invDepth) {
+            auto *f = new DirectSE3::ReprojectionErrorKSE3AnchInvDepth(obsUv[2 * o], obsUv[2 * o + 1], ptAnchorUv[2 * p], ptAnchorUv[2 * p + 1], 1.0);
+            problem.AddResidualBlock(f, lossFunction, calibv, poses + 7 * ptAnchorKf[p], poses + 7 * k, ptParam + p);
+            fs[o] = f;
+        } else {
+            auto *f = new DirectSE3::ReprojectionErrorKSE3XYZ(obsUv[2 * o], obsUv[2 * o + 1], 1.0);
+            problem.AddResidualBlock(f, lossFunction, calibv, poses + 7 * k, ptParam + 3 * p);
+            fs[o] = f;
+        }
+    }
+    ceres::Solver::Options options;
+    options.linear_solver_ordering.reset(ordering);
+    options.linear_solver_type = ceres::SPARSE_SCHUR;
+    options.trust_region_strategy_type = ceres::LEVENBERG_MARQUARDT;
+    options.num_threads = 1;
+    options.max_num_iterations = maxIterations;
+    options.function_tolerance = functionTolerance;
+    options.minimizer_progress_to_stdout = false;
+    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+    for (int o = 0; o < nObs; o++) {
+        if (invDepth) {
+            auto *e = static_cast<DirectSE3::ReprojectionErrorKSE3AnchInvDepth *>(fs[o]);
+            chi2[o] = e->chi2err_;
+            depthPos[o] = e->isDepthPositive_;
+        } else {
+            auto *e = static_cast<DirectSE3::ReprojectionErrorKSE3XYZ *>(fs[o]);
+            chi2[o] = e->chi2err_;
+            depthPos[o] = e->isDepthPositive_;
+        }
+    }
+    if (info) {
+        info[0] = (double) summary.iterations.size();
+        info[1] = summary.initial_cost;
+        info[2] = summary.final_cost;
+        info[3] = (double) summary.num_successful_steps;
+        info[4] = summary.jacobian_evaluation_time_in_seconds;
+        info[5] = summary.residual_evaluation_time_in_seconds;
+        info[6] = summary.linear_solver_time_in_seconds;
+        info[7] = summary.total_time_in_seconds;
+        info[8] = summary.preprocessor_time_in_seconds;
+    }
+    return summary.IsSolutionUsable() ? 1 : 0;
+}
+
+}  // extern "C"
