@@ -1,0 +1,172 @@
+"""ctypes binding of include/alvaar_hip.h.  Device buffers are torch CUDA tensors."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+# torch first: it ships its own ROCm runtime (torch/lib/libamdhip64.so).  Loading our library before
+# torch would bind it to /opt/rocm's copy and leave two HIP runtimes in one process.
+import torch  # noqa: F401  (plumbing: device memory + streams)
+
+_LIB_PATH = Path(__file__).resolve().parent / "libalvaar_hip.so"
+
+
+class AlvaError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not _LIB_PATH.exists():
+        raise AlvaError(
+            f"{_LIB_PATH} is missing: build it with `python -m alvaar_amd.build` "
+            "(there is deliberately no CPU fallback)")
+    return C.CDLL(str(_LIB_PATH))
+
+
+lib = _load()
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+
+class PyrLevel(C.Structure):
+    _fields_ = [("width", _i), ("height", _i), ("d_gray", _vp), ("gray_pitch", _sz),
+                ("d_deriv", _vp), ("deriv_pitch", _sz)]
+
+
+def _sig(name, argtypes, restype=_i):
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+_sig("alva_last_error", [], C.c_char_p)
+_sig("alva_version", [], C.c_char_p)
+_sig("alva_ctx_create", [_i, _vp, _i, C.POINTER(_vp)])
+_sig("alva_ctx_destroy", [_vp], None)
+_sig("alva_ctx_sync", [_vp])
+_sig("alva_rgba2gray", [_vp, _vp, _sz, _i, _i, _vp, _sz])
+_sig("alva_pyramid_create", [_vp, _i, _i, _i, _i, C.POINTER(_vp)])
+_sig("alva_pyramid_destroy", [_vp], None)
+_sig("alva_pyramid_num_levels", [_vp])
+_sig("alva_pyramid_level", [_vp, _i, C.POINTER(PyrLevel)])
+_sig("alva_pyramid_build_from_gray", [_vp, _vp, _vp, _sz])
+_sig("alva_pyramid_download_level", [_vp, _vp, _i, _vp, _vp])
+_sig("alva_pyramid_build_from_rgba", [_vp, _vp, _vp, _sz, _vp, _sz])
+_sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
+_sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
+_sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise AlvaError(f"alvaar_hip error {rc}: {lib.alva_last_error().decode()}")
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class Context:
+    """One HIP stream on one device (alva_ctx).  By default enqueues on torch's current stream so
+    torch.cuda.synchronize()/Events see the work."""
+
+    def __init__(self, device: int = 0, stream: int | None = None, own_stream: bool = False):
+        if not torch.cuda.is_available():
+            raise AlvaError("no HIP device visible: the alvaar_amd hot path has no CPU fallback")
+        self.device = device
+        if stream is None and not own_stream:
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = _vp()
+        check(lib.alva_ctx_create(device, _vp(stream or 0), 1 if own_stream else 0, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.alva_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        check(lib.alva_ctx_sync(self.h))
+
+    # a2
+    def rgba2gray(self, rgba, out=None):
+        h, w, c = rgba.shape
+        assert c == 4 and rgba.dtype == torch.uint8 and rgba.is_contiguous()
+        if out is None:
+            out = torch.empty((h, w), dtype=torch.uint8, device=rgba.device)
+        check(lib.alva_rgba2gray(self.h, _ptr(rgba), w * 4, w, h, _ptr(out), out.stride(0)))
+        return out
+
+
+    # a6
+    def orb_blur(self, gray):
+        h, w = gray.shape
+        out = torch.empty((h, w), dtype=torch.uint8, device=gray.device)
+        check(lib.alva_orb_blur(self.h, _ptr(gray), gray.stride(0), w, h, _ptr(out), out.stride(0)))
+        return out
+
+    def describe(self, gray, pts):
+        """FeatureExtractor::describeFeaturePoints: returns (desc [n,32] u8, valid [n] u8)."""
+        h, w = gray.shape
+        n = pts.shape[0]
+        assert pts.dtype == torch.float32 and pts.is_contiguous()
+        desc = torch.empty((n, 32), dtype=torch.uint8, device=gray.device)
+        valid = torch.empty(n, dtype=torch.uint8, device=gray.device)
+        check(lib.alva_describe(self.h, _ptr(gray), gray.stride(0), w, h, _ptr(pts), n, _ptr(desc), _ptr(valid)))
+        return desc, valid
+
+    # a7
+    def bf_match_hamming(self, query, train):
+        nq, nt = query.shape[0], train.shape[0]
+        assert query.dtype == torch.uint8 and query.shape[1] == 32 and query.is_contiguous()
+        assert train.dtype == torch.uint8 and train.shape[1] == 32 and train.is_contiguous()
+        idx = torch.empty(nq, dtype=torch.int32, device=query.device)
+        dist = torch.empty(nq, dtype=torch.int32, device=query.device)
+        check(lib.alva_bf_match_hamming(self.h, _ptr(query), nq, _ptr(train), nt, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+
+class Pyramid:
+    """alva_pyramid: padded gray + Scharr-derivative levels resident in HBM."""
+
+    def __init__(self, ctx: Context, width: int, height: int, win: int = 9, max_level: int = 3):
+        self.ctx = ctx
+        self.win = win
+        self.width, self.height = width, height
+        h = _vp()
+        check(lib.alva_pyramid_create(ctx.h, width, height, win, max_level, C.byref(h)))
+        self.h = h
+        self.num_levels = lib.alva_pyramid_num_levels(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.alva_pyramid_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def build_from_gray(self, gray):
+        check(lib.alva_pyramid_build_from_gray(self.ctx.h, self.h, _ptr(gray), gray.stride(0)))
+
+    def build_from_rgba(self, rgba, gray_out=None):
+        h, w, _ = rgba.shape
+        check(lib.alva_pyramid_build_from_rgba(self.ctx.h, self.h, _ptr(rgba), w * 4, _ptr(gray_out),
+                                               0 if gray_out is None else gray_out.stride(0)))
+
+    def level(self, l: int) -> PyrLevel:
+        info = PyrLevel()
+        check(lib.alva_pyramid_level(self.h, l, C.byref(info)))
+        return info
+
+    def download_level(self, l: int):
+        """Returns (gray_padded u8 [H+2w, W+2w], deriv_padded i16 [H+2w, W+2w, 2]) as numpy (tests)."""
+        import numpy as np
+        info = self.level(l)
+        W, H = info.width + 2 * self.win, info.height + 2 * self.win
+        g = np.empty((H, W), np.uint8)
+        d = np.empty((H, W, 2), np.int16)
+        check(lib.alva_pyramid_download_level(self.ctx.h, self.h, l, g.ctypes.data, d.ctypes.data))
+        return g, d

@@ -1,0 +1,66 @@
+// Internal definitions shared by the HIP translation units of libalvaar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/alvaar_hip.h"
+
+void alva_set_error(const char *fmt, ...);
+
+#define ALVA_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            alva_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return ALVA_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+#define ALVA_ARG(cond)                                                            \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            alva_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+            return ALVA_ERR_ARG;                                                  \
+        }                                                                         \
+    } while (0)
+
+#define ALVA_LAUNCH_CHECK() ALVA_HIP(hipGetLastError())
+
+// Growable device scratch owned by the context (no hipMalloc on the per-frame path once warm).
+struct alva_scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct alva_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    alva_scratch scratch[8];
+    void *pinned = nullptr;  // small pinned host staging (counters, results)
+    size_t pinned_bytes = 0;
+};
+
+int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out);
+
+static inline int alva_divup(int a, int b) { return (a + b - 1) / b; }
+
+struct alva_level {
+    int w = 0, h = 0;
+    uint8_t *gray_base = nullptr;   // allocation base
+    uint8_t *gray = nullptr;        // interior (0,0)
+    size_t gray_pitch = 0;
+    int16_t *deriv_base = nullptr;
+    int16_t *deriv = nullptr;       // interior (0,0)
+    size_t deriv_pitch = 0;         // bytes
+};
+
+struct alva_pyramid {
+    int device = 0;
+    int win = 0;
+    int nlevels = 0;
+    alva_level lv[8];
+};

@@ -1,0 +1,85 @@
+// Context, error reporting, scratch management.
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void alva_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *alva_last_error(void) { return g_err; }
+extern "C" const char *alva_version(void) { return "alvaar_hip 0.1 (gfx950)"; }
+
+extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out) {
+    ALVA_ARG(out != nullptr);
+    int ndev = 0;
+    ALVA_HIP(hipGetDeviceCount(&ndev));
+    ALVA_ARG(device >= 0 && device < ndev);
+    ALVA_HIP(hipSetDevice(device));
+    alva_ctx *c = new alva_ctx();
+    c->device = device;
+    if (!own_stream) {
+        c->stream = (hipStream_t) hip_stream;  // NULL = legacy default stream
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            alva_set_error("hipStreamCreate: %s", hipGetErrorString(e));
+            return ALVA_ERR_HIP;
+        }
+        c->owns_stream = true;
+    }
+    c->pinned_bytes = 1 << 16;
+    hipError_t e = hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (c->owns_stream) (void) hipStreamDestroy(c->stream);
+        delete c;
+        alva_set_error("hipHostMalloc: %s", hipGetErrorString(e));
+        return ALVA_ERR_NOMEM;
+    }
+    *out = c;
+    return ALVA_OK;
+}
+
+extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (auto &s: ctx->scratch)
+        if (s.ptr) (void) hipFree(s.ptr);
+    if (ctx->pinned) (void) hipHostFree(ctx->pinned);
+    if (ctx->owns_stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int alva_ctx_sync(alva_ctx *ctx) {
+    ALVA_ARG(ctx != nullptr);
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    return ALVA_OK;
+}
+
+extern "C" void *alva_ctx_stream(alva_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out) {
+    ALVA_ARG(slot >= 0 && slot < 8);
+    alva_scratch &s = ctx->scratch[slot];
+    if (s.bytes < bytes) {
+        // growing frees the old block: wait for work that may still read it
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        if (s.ptr) ALVA_HIP(hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.bytes = 0;
+        size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e != hipSuccess) {
+            alva_set_error("hipMalloc(%zu): %s", want, hipGetErrorString(e));
+            return ALVA_ERR_NOMEM;
+        }
+        s.bytes = want;
+    }
+    *out = s.ptr;
+    return ALVA_OK;
+}

@@ -1,0 +1,140 @@
+// a6: ORB description of supplied points = 7x7 sigma=2 Gaussian + 256-bit steered BRIEF.
+//
+// Restates (reference paths relative to /root/reference/src/libs/opencv/modules):
+//   * GaussianBlur(level, level, Size(7,7), 2, 2, BORDER_REFLECT_101)   features2d/src/orb.cpp:1188
+//     -> sepFilter2D float path: row  RowFilter<uchar,float>  s = k0*p0; s += k_i*p_i (i ascending)
+//                                col  SymmColumnFilter<float,uchar>  s = c0*r0; s += c_j*(r[+j] + r[-j])
+//        (imgproc/src/filter.simd.hpp:468-507,1163-1209,2446-2488), result cvRound + saturate.
+//        One IEEE rounding per written operation, no FMA (this TU is built with -ffp-contract=off).
+//        Taps = cv::getGaussianKernel(7, 2, CV_32F) (bit patterns below, taken from the reference build).
+//   * computeOrbDescriptors                                               features2d/src/orb.cpp:219-284
+//        sample = center + (cvRound(x*a - y*b), cvRound(x*b + y*a)),  bit = I(p) < I(q)
+//   * describeFeaturePoints keeps a point iff Rect(31,31,w-62,h-62).contains(Point(cvRound(pt)))
+//        (features2d/src/keypoint.cpp:105-117; src/slam/src/feature_extractor.cpp:191-209); angle is the
+//        constant -1 degree because KeyPoint::convert sets angle = -1 (core/src/types.cpp:93-101).
+#include "common.hpp"
+#include <cmath>
+
+namespace {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+// cv::getGaussianKernel(7, 2.0, CV_32F): 0.07015932 0.13107488 0.19071282 0.21610594 (symmetric)
+__device__ __forceinline__ float gk(int i) {
+    const uint32_t bits[4] = {0x3d8fafb1u, 0x3e06387eu, 0x3e434a39u, 0x3e5d4ae0u};
+    return __uint_as_float(bits[i > 3 ? 6 - i : i]);
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    // single reflection is enough for |overshoot| <= 3 on images wider than 3 px
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+}
+
+constexpr int BT_W = 64, BT_H = 16;
+
+// One block: BT_W x BT_H outputs.  LDS: u8 tile with 3 px halo, then row-filtered floats.
+__global__ void __launch_bounds__(256) k_blur7(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h,
+                                               uint8_t *__restrict__ dst, size_t dst_pitch) {
+    __shared__ uint8_t s_px[BT_H + 6][BT_W + 8];
+    __shared__ float s_row[BT_H + 6][BT_W + 1];
+    const int tx = threadIdx.x % BT_W, ty = threadIdx.x / BT_W;  // 64 x 4
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        int ly = i / (BT_W + 6), lx = i % (BT_W + 6);
+        int gx = reflect101(x0 + lx - 3, w), gy = reflect101(y0 + ly - 3, h);
+        gx = min(max(gx, 0), w - 1);
+        gy = min(max(gy, 0), h - 1);
+        s_px[ly][lx] = src[(size_t) gy * src_pitch + gx];
+    }
+    __syncthreads();
+    for (int ly = ty; ly < BT_H + 6; ly += 4) {
+        float s = gk(0) * (float) s_px[ly][tx];
+#pragma unroll
+        for (int k = 1; k < 7; k++) s += gk(k) * (float) s_px[ly][tx + k];
+        s_row[ly][tx] = s;
+    }
+    __syncthreads();
+    const int gx = x0 + tx;
+    for (int ly = ty; ly < BT_H; ly += 4) {
+        int gy = y0 + ly;
+        float s = gk(3) * s_row[ly + 3][tx];
+#pragma unroll
+        for (int k = 1; k <= 3; k++) s += gk(3 + k) * (s_row[ly + 3 + k][tx] + s_row[ly + 3 - k][tx]);
+        int v = __float2int_rn(s);  // cvRound: round half to even
+        v = min(max(v, 0), 255);
+        if (gx < w && gy < h) dst[(size_t) gy * dst_pitch + gx] = (uint8_t) v;
+    }
+}
+
+// 32 lanes per keypoint: lane = descriptor byte = 8 tests = 16 samples.
+__global__ void __launch_bounds__(256) k_brief(const uint8_t *__restrict__ img, size_t pitch, int w, int h,
+                                               const float *__restrict__ pts, int n, float a, float b,
+                                               uint8_t *__restrict__ desc, uint8_t *__restrict__ valid) {
+    const int kp = blockIdx.x * 8 + threadIdx.x / 32;
+    const int byte = threadIdx.x % 32;
+    if (kp >= n) return;
+    const float px = pts[2 * kp], py = pts[2 * kp + 1];
+    const int cx = __float2int_rn(px), cy = __float2int_rn(py);
+    const bool ok = cx >= 31 && cx < w - 31 && cy >= 31 && cy < h - 31;
+    if (byte == 0 && valid) valid[kp] = ok ? 1 : 0;
+    uint32_t val = 0;
+    if (ok) {
+        const uint8_t *center = img + (size_t) cy * pitch + cx;
+        const int8_t *pat = c_pattern + byte * 32;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            float x0 = (float) pat[4 * t], y0 = (float) pat[4 * t + 1], x1 = (float) pat[4 * t + 2], y1 = (float) pat[4 * t + 3];
+            int ix0 = __float2int_rn(x0 * a - y0 * b), iy0 = __float2int_rn(x0 * b + y0 * a);
+            int ix1 = __float2int_rn(x1 * a - y1 * b), iy1 = __float2int_rn(x1 * b + y1 * a);
+            int t0 = center[(ptrdiff_t) iy0 * (ptrdiff_t) pitch + ix0];
+            int t1 = center[(ptrdiff_t) iy1 * (ptrdiff_t) pitch + ix1];
+            val |= (uint32_t) (t0 < t1) << t;
+        }
+    }
+    desc[(size_t) kp * 32 + byte] = (uint8_t) val;
+}
+
+}  // namespace
+
+int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int w, int h, uint8_t *d_dst, size_t dst_pitch) {
+    hipLaunchKernelGGL(k_blur7, dim3(alva_divup(w, BT_W), alva_divup(h, BT_H)), dim3(256), 0, ctx->stream, d_src, src_pitch, w, h,
+                       d_dst, dst_pitch);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+int alva_brief_launch(alva_ctx *ctx, const uint8_t *d_blur, size_t pitch, int w, int h, const float *d_pts, int n, float a, float b,
+                      uint8_t *d_desc, uint8_t *d_valid) {
+    if (n <= 0) return ALVA_OK;
+    hipLaunchKernelGGL(k_brief, dim3(alva_divup(n, 8)), dim3(256), 0, ctx->stream, d_blur, pitch, w, h, d_pts, n, a, b, d_desc, d_valid);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+extern "C" int alva_orb_blur(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, uint8_t *d_out,
+                             size_t out_pitch) {
+    ALVA_ARG(ctx && d_gray && d_out && width > 6 && height > 6 && gray_pitch >= (size_t) width && out_pitch >= (size_t) width);
+    return alva_blur7_launch(ctx, d_gray, gray_pitch, width, height, d_out, out_pitch);
+}
+
+extern "C" int alva_describe(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, const float *d_pts,
+                             int n, uint8_t *d_desc, uint8_t *d_valid) {
+    ALVA_ARG(ctx && d_gray && n >= 0 && width > 62 && height > 62 && gray_pitch >= (size_t) width);
+    if (n == 0) return ALVA_OK;
+    ALVA_ARG(d_pts && d_desc);
+    uint8_t *blur = nullptr;
+    size_t pitch = ((size_t) width + 63) / 64 * 64;
+    int rc = alva_ctx_scratch(ctx, 1, pitch * height, (void **) &blur);
+    if (rc) return rc;
+    rc = alva_blur7_launch(ctx, d_gray, gray_pitch, width, height, blur, pitch);
+    if (rc) return rc;
+    // orb.cpp:232-235: angle (float, degrees) *= (float)(CV_PI/180.f); a = (float)cos(angle), b = (float)sin(angle)
+    float angle = -1.0f;
+    angle *= (float) (3.1415926535897932384626433832795 / 180.f);
+    float a = (float) std::cos((double) angle), b = (float) std::sin((double) angle);
+    return alva_brief_launch(ctx, blur, pitch, width, height, d_pts, n, a, b, d_desc, d_valid);
+}

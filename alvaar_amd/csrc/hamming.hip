@@ -1,0 +1,92 @@
+// a7: brute-force Hamming matcher for 256-bit descriptors.
+//
+// Replaces cv::BFMatcher(NORM_HAMMING).match (core/src/batch_distance.cpp:199-251; norm.cpp:99-):
+// per query the minimum popcount(q ^ t) over all train rows, LOWEST train index on ties (strict '<'
+// at batch_distance.cpp:238).  Integer, bit-exact.
+//
+// This stage is VALU-bound, not HBM-bound (32(N+M)+8N bytes vs 24 N M ops), so the
+// layout is about issue slots: one wave = 64 queries held in registers (8 dwords/lane); a chunk of
+// 64 train descriptors is staged once in LDS and read back as wave-uniform (broadcast) b128 reads;
+// per pair 8 v_xor + 8 v_bcnt (popcount-accumulate).  The N x M rectangle is cut into
+// ceil(N/64) x ceil(M/64) single-wave workgroups (>= 1024 at 2000 x 2000) so all 256 CUs get work;
+// each writes one packed key (dist << 20 | train_idx) per query, and a second tiny kernel takes the
+// min over chunks -- min of the packed key is exactly "smallest distance, then lowest index".
+#include "common.hpp"
+
+namespace {
+
+constexpr int QT = 64;  // queries per workgroup (one wave)
+constexpr int TC = 64;  // train descriptors per chunk
+
+__global__ void __launch_bounds__(QT) k_bf_partial(const uint4 *__restrict__ q, int nq, const uint4 *__restrict__ t, int nt,
+                                                   uint32_t *__restrict__ partial /* [chunks][nq_pad] */, int nq_pad) {
+    __shared__ uint4 s_t[TC * 2];
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x * QT + lane;
+    const int t0 = blockIdx.y * TC;
+    const int tcount = min(TC, nt - t0);
+    if (lane < tcount) {
+        s_t[2 * lane] = t[2 * (size_t) (t0 + lane)];
+        s_t[2 * lane + 1] = t[2 * (size_t) (t0 + lane) + 1];
+    }
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (qi < nq) {
+        qa = q[2 * (size_t) qi];
+        qb = q[2 * (size_t) qi + 1];
+    }
+    __syncthreads();
+    uint32_t best = 0xffffffffu;
+    for (int j = 0; j < tcount; j++) {
+        const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
+        uint32_t d = __popc(qa.x ^ ta.x);
+        d += __popc(qa.y ^ ta.y);
+        d += __popc(qa.z ^ ta.z);
+        d += __popc(qa.w ^ ta.w);
+        d += __popc(qb.x ^ tb.x);
+        d += __popc(qb.y ^ tb.y);
+        d += __popc(qb.z ^ tb.z);
+        d += __popc(qb.w ^ tb.w);
+        uint32_t key = (d << 20) | (uint32_t) (t0 + j);
+        best = min(best, key);
+    }
+    if (qi < nq) partial[(size_t) blockIdx.y * nq_pad + qi] = best;
+}
+
+__global__ void __launch_bounds__(256) k_bf_final(const uint32_t *__restrict__ partial, int chunks, int nq, int nq_pad,
+                                                  int *__restrict__ idx, int *__restrict__ dist) {
+    int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t best = 0xffffffffu;
+    for (int c = 0; c < chunks; c++) best = min(best, partial[(size_t) c * nq_pad + qi]);
+    if (best == 0xffffffffu) {
+        idx[qi] = -1;
+        dist[qi] = -1;
+    } else {
+        idx[qi] = (int) (best & 0xfffffu);
+        dist[qi] = (int) (best >> 20);
+    }
+}
+
+}  // namespace
+
+extern "C" int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int n_query, const uint8_t *d_train,
+                                     int n_train, int *d_idx, int *d_dist) {
+    ALVA_ARG(ctx && d_idx && d_dist && n_query >= 0 && n_train >= 0 && n_train < (1 << 20));
+    if (n_query == 0) return ALVA_OK;
+    ALVA_ARG(d_query && ((uintptr_t) d_query % 16) == 0);
+    ALVA_ARG(n_train == 0 || (d_train && ((uintptr_t) d_train % 16) == 0));
+    int chunks = alva_divup(n_train, TC);
+    int nq_pad = alva_divup(n_query, QT) * QT;
+    uint32_t *partial = nullptr;
+    if (chunks > 0) {
+        int rc = alva_ctx_scratch(ctx, 0, (size_t) chunks * nq_pad * sizeof(uint32_t), (void **) &partial);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_bf_partial, dim3(nq_pad / QT, chunks), dim3(QT), 0, ctx->stream, (const uint4 *) d_query, n_query,
+                           (const uint4 *) d_train, n_train, partial, nq_pad);
+        ALVA_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_bf_final, dim3(alva_divup(n_query, 256)), dim3(256), 0, ctx->stream, partial, chunks, n_query, nq_pad,
+                       d_idx, d_dist);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}

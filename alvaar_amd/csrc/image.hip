@@ -1,0 +1,314 @@
+// a2 + a3: RGBA -> gray and the LK pyramid (padded gray levels + Scharr derivative levels).
+//
+// Arithmetic restated from the reference's vendored OpenCV (all integer, bit-exact):
+//   gray     Y = (9798 R + 19235 G + 3735 B + 16384) >> 15       imgproc/src/color_rgb.simd.hpp:646-664
+//   pyrDown  separable [1 4 6 4 1], (sum + 128) >> 8, REFLECT_101 imgproc/src/pyramids.cpp:746-
+//   Scharr   Ix = d/dx of (3,10,3)-smoothed rows, Iy likewise     video/src/lkpyramid.cpp:70-151
+//   borders  gray REFLECT_101 by `win`, deriv constant 0          video/src/lkpyramid.cpp:726-822
+//
+// HBM layout: every level lives in its own padded 2-D buffer whose interior column 0 is 16-byte
+// aligned (so the interior is written with 4/16-byte stores); the REFLECT_101 border of a gray
+// level is written by the same threads that produce the mirrored interior pixels, so a level is
+// complete after ONE launch.  Launch plan for an L-level pyramid: 1 + L launches
+//   [gray L0 (+border)] , [scharr(l) | pyrDown(l -> l+1) (+border)] for l = 0..L-2 , [scharr(L-1)]
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ uint32_t gray_of(uint32_t rgba) {
+    uint32_t r = rgba & 0xff, g = (rgba >> 8) & 0xff, b = (rgba >> 16) & 0xff;
+    return (9798u * r + 19235u * g + 3735u * b + 16384u) >> 15;
+}
+
+// Writes v at (x,y) of a padded gray level and at every REFLECT_101 mirror image of (x,y) inside
+// the `win` border.  Interior store is done by the caller (vectorised); this handles mirrors only.
+__device__ __forceinline__ void store_mirrors(uint8_t *g, size_t pitch, int w, int h, int win, int x, int y, uint8_t v) {
+    int xs[3], ys[3];
+    int nx = 0, ny = 0;
+    xs[nx++] = x;
+    if (x >= 1 && x <= win) xs[nx++] = -x;
+    if (x <= w - 2 && x >= w - 1 - win) xs[nx++] = 2 * (w - 1) - x;
+    ys[ny++] = y;
+    if (y >= 1 && y <= win) ys[ny++] = -y;
+    if (y <= h - 2 && y >= h - 1 - win) ys[ny++] = 2 * (h - 1) - y;
+    if (nx == 1 && ny == 1) return;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++)
+            if (i | j) g[(ptrdiff_t) ys[j] * (ptrdiff_t) pitch + xs[i]] = v;
+}
+
+// Level 0 from RGBA (SRC_RGBA) or from a gray image: 4 pixels per thread.
+template<bool SRC_RGBA>
+__global__ void __launch_bounds__(256) k_level0(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, int win,
+                                                uint8_t *__restrict__ dst, size_t dst_pitch,
+                                                uint8_t *__restrict__ gray_out, size_t gray_out_pitch) {
+    int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= w || y >= h) return;
+    uint32_t packed;
+    if (SRC_RGBA) {
+        const uint4 p = *reinterpret_cast<const uint4 *>(src + (size_t) y * src_pitch + (size_t) x4 * 4);
+        packed = gray_of(p.x) | (gray_of(p.y) << 8) | (gray_of(p.z) << 16) | (gray_of(p.w) << 24);
+    } else {
+        packed = *reinterpret_cast<const uint32_t *>(src + (size_t) y * src_pitch + x4);
+    }
+    *reinterpret_cast<uint32_t *>(dst + (size_t) y * dst_pitch + x4) = packed;
+    if (gray_out) *reinterpret_cast<uint32_t *>(gray_out + (size_t) y * gray_out_pitch + x4) = packed;
+    bool edge_y = (y <= win) || (y >= h - 1 - win);
+    bool edge_x = (x4 <= win) || (x4 + 3 >= w - 1 - win);
+    if (edge_x || edge_y) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) store_mirrors(dst, dst_pitch, w, h, win, x4 + k, y, (uint8_t) (packed >> (8 * k)));
+    }
+}
+
+struct StageArgs {
+    // Scharr part: level l
+    const uint8_t *g;  // interior (0,0) of padded gray level l
+    size_t g_pitch;
+    int w, h;
+    int16_t *d;  // interior (0,0) of deriv level l
+    size_t d_pitch;
+    int scharr_bx, scharr_blocks;  // blocks per row of tiles, total scharr blocks
+    // pyrDown part: level l -> l+1 (dw == 0: none)
+    uint8_t *ng;
+    size_t ng_pitch;
+    int dw, dh, win;
+    int down_bx;
+};
+
+__device__ __forceinline__ void scharr_tile(const StageArgs &a, int bid) {
+    int bx = bid % a.scharr_bx, by = bid / a.scharr_bx;
+    int x4 = (bx * 64 + threadIdx.x) * 4;
+    int y = by * 4 + threadIdx.y;
+    if (x4 >= a.w || y >= a.h) return;
+    // rows y-1..y+1, bytes x4-4 .. x4+7 via three aligned u32 loads per row (the padding is
+    // REFLECT_101, which is exactly the border rule of ScharrDerivInvoker, lkpyramid.cpp:83-121)
+    int t0[6], t1[6];
+    {
+        uint32_t r[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint8_t *row = a.g + (ptrdiff_t) (y - 1 + j) * (ptrdiff_t) a.g_pitch + x4;
+            r[j][0] = *reinterpret_cast<const uint32_t *>(row - 4);
+            r[j][1] = *reinterpret_cast<const uint32_t *>(row);
+            r[j][2] = *reinterpret_cast<const uint32_t *>(row + 4);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            // column x4-1+c
+            int p0, p1, p2;
+            if (c == 0) {
+                p0 = r[0][0] >> 24; p1 = r[1][0] >> 24; p2 = r[2][0] >> 24;
+            } else if (c == 5) {
+                p0 = r[0][2] & 0xff; p1 = r[1][2] & 0xff; p2 = r[2][2] & 0xff;
+            } else {
+                int sh = 8 * (c - 1);
+                p0 = (r[0][1] >> sh) & 0xff; p1 = (r[1][1] >> sh) & 0xff; p2 = (r[2][1] >> sh) & 0xff;
+            }
+            t0[c] = (p0 + p2) * 3 + p1 * 10;
+            t1[c] = p2 - p0;
+        }
+    }
+    short out[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        out[2 * k] = (short) (t0[k + 2] - t0[k]);
+        out[2 * k + 1] = (short) ((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10);
+    }
+    int16_t *drow = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(a.d) + (size_t) y * a.d_pitch) + 2 * x4;
+    if (x4 + 3 < a.w) {
+        uint4 v;
+        v.x = (uint16_t) out[0] | ((uint32_t) (uint16_t) out[1] << 16);
+        v.y = (uint16_t) out[2] | ((uint32_t) (uint16_t) out[3] << 16);
+        v.z = (uint16_t) out[4] | ((uint32_t) (uint16_t) out[5] << 16);
+        v.w = (uint16_t) out[6] | ((uint32_t) (uint16_t) out[7] << 16);
+        *reinterpret_cast<uint4 *>(drow) = v;
+    } else {
+        for (int k = 0; k < 4 && x4 + k < a.w; k++) {
+            drow[2 * k] = out[2 * k];
+            drow[2 * k + 1] = out[2 * k + 1];
+        }
+    }
+}
+
+__device__ __forceinline__ void pyrdown_tile(const StageArgs &a, int bid) {
+    int bx = bid % a.down_bx, by = bid / a.down_bx;
+    int x = bx * 64 + threadIdx.x;
+    int y = by * 4 + threadIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    // 5x5 binomial around (2x, 2y) of level l; out-of-image taps read the REFLECT_101 padding
+    // (identical to borderInterpolate on the level size, pyramids.cpp:760-775, because win >= 2)
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint8_t *row = a.g + (ptrdiff_t) (2 * y - 2 + j) * (ptrdiff_t) a.g_pitch + (2 * x - 2);
+        int s = row[0] + row[4] + 4 * (row[1] + row[3]) + 6 * row[2];
+        const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+        acc += wj * s;
+    }
+    uint8_t v = (uint8_t) ((acc + 128) >> 8);
+    a.ng[(size_t) y * a.ng_pitch + x] = v;
+    store_mirrors(a.ng, a.ng_pitch, a.dw, a.dh, a.win, x, y, v);
+}
+
+__global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
+    int bid = blockIdx.x;
+    if (bid < a.scharr_blocks) scharr_tile(a, bid);
+    else pyrdown_tile(a, bid - a.scharr_blocks);
+}
+
+__global__ void __launch_bounds__(256) k_rgba2gray(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h,
+                                                   uint8_t *__restrict__ dst, size_t dst_pitch) {
+    int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= w || y >= h) return;
+    const uint4 p = *reinterpret_cast<const uint4 *>(src + (size_t) y * src_pitch + (size_t) x4 * 4);
+    uint32_t packed = gray_of(p.x) | (gray_of(p.y) << 8) | (gray_of(p.z) << 16) | (gray_of(p.w) << 24);
+    *reinterpret_cast<uint32_t *>(dst + (size_t) y * dst_pitch + x4) = packed;
+}
+
+static size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" int alva_rgba2gray(alva_ctx *ctx, const uint8_t *d_rgba, size_t rgba_pitch, int width, int height,
+                              uint8_t *d_gray, size_t gray_pitch) {
+    ALVA_ARG(ctx && d_rgba && d_gray);
+    ALVA_ARG(width > 0 && height > 0 && width % 4 == 0);
+    ALVA_ARG(rgba_pitch % 16 == 0 && rgba_pitch >= (size_t) width * 4 && ((uintptr_t) d_rgba % 16) == 0);
+    ALVA_ARG(gray_pitch % 4 == 0 && gray_pitch >= (size_t) width && ((uintptr_t) d_gray % 4) == 0);
+    dim3 block(64, 4), grid(alva_divup(width, 256), alva_divup(height, 4));
+    hipLaunchKernelGGL(k_rgba2gray, grid, block, 0, ctx->stream, d_rgba, rgba_pitch, width, height, d_gray, gray_pitch);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+extern "C" int alva_pyramid_create(alva_ctx *ctx, int width, int height, int win, int max_level, alva_pyramid **out) {
+    ALVA_ARG(ctx && out);
+    ALVA_ARG(width > 0 && height > 0 && width % 4 == 0 && win > 2 && win <= 15 && max_level >= 0 && max_level < 8);
+    ALVA_HIP(hipSetDevice(ctx->device));
+    alva_pyramid *p = new alva_pyramid();
+    p->device = ctx->device;
+    p->win = win;
+    int w = width, h = height;
+    for (int l = 0; l <= max_level; l++) {
+        alva_level &L = p->lv[l];
+        L.w = w;
+        L.h = h;
+        size_t xoff = (16 - win % 16) % 16;
+        L.gray_pitch = round_up(xoff + (size_t) w + 2 * win + 8, 64);
+        size_t gbytes = L.gray_pitch * (size_t) (h + 2 * win) + 64;
+        size_t xoffd = (4 - win % 4) % 4;
+        L.deriv_pitch = round_up((xoffd + (size_t) w + 2 * win) * 4 + 16, 64);
+        size_t dbytes = L.deriv_pitch * (size_t) (h + 2 * win) + 64;
+        if (hipMalloc((void **) &L.gray_base, gbytes) != hipSuccess || hipMalloc((void **) &L.deriv_base, dbytes) != hipSuccess) {
+            alva_pyramid_destroy(p);
+            alva_set_error("alva_pyramid_create: hipMalloc failed at level %d", l);
+            return ALVA_ERR_NOMEM;
+        }
+        // zero once: the derivative border is CONSTANT 0 and is never written afterwards
+        (void) hipMemsetAsync(L.gray_base, 0, gbytes, ctx->stream);
+        (void) hipMemsetAsync(L.deriv_base, 0, dbytes, ctx->stream);
+        L.gray = L.gray_base + (size_t) win * L.gray_pitch + xoff + win;
+        L.deriv = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.deriv_base) + (size_t) win * L.deriv_pitch + (xoffd + win) * 4);
+        p->nlevels = l + 1;
+        // lkpyramid.cpp:811-816: stop when the next level would be <= win in either dimension
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        if (w <= win || h <= win) break;
+    }
+    *out = p;
+    return ALVA_OK;
+}
+
+extern "C" void alva_pyramid_destroy(alva_pyramid *pyr) {
+    if (!pyr) return;
+    (void) hipSetDevice(pyr->device);
+    for (int l = 0; l < 8; l++) {
+        if (pyr->lv[l].gray_base) (void) hipFree(pyr->lv[l].gray_base);
+        if (pyr->lv[l].deriv_base) (void) hipFree(pyr->lv[l].deriv_base);
+    }
+    delete pyr;
+}
+
+extern "C" int alva_pyramid_num_levels(const alva_pyramid *pyr) { return pyr ? pyr->nlevels : 0; }
+
+extern "C" int alva_pyramid_level(const alva_pyramid *pyr, int level, alva_pyr_level *out) {
+    ALVA_ARG(pyr && out && level >= 0 && level < pyr->nlevels);
+    const alva_level &L = pyr->lv[level];
+    out->width = L.w;
+    out->height = L.h;
+    out->d_gray = L.gray;
+    out->gray_pitch = L.gray_pitch;
+    out->d_deriv = L.deriv;
+    out->deriv_pitch = L.deriv_pitch;
+    return ALVA_OK;
+}
+
+extern "C" int alva_pyramid_download_level(alva_ctx *ctx, const alva_pyramid *pyr, int level, uint8_t *h_gray, int16_t *h_deriv) {
+    ALVA_ARG(ctx && pyr && level >= 0 && level < pyr->nlevels);
+    const alva_level &L = pyr->lv[level];
+    const int win = pyr->win;
+    const size_t W = (size_t) L.w + 2 * win, H = (size_t) L.h + 2 * win;
+    if (h_gray)
+        ALVA_HIP(hipMemcpy2DAsync(h_gray, W, L.gray - (size_t) win * L.gray_pitch - win, L.gray_pitch, W, H, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_deriv)
+        ALVA_HIP(hipMemcpy2DAsync(h_deriv, W * 4, reinterpret_cast<const uint8_t *>(L.deriv) - (size_t) win * L.deriv_pitch - (size_t) win * 4,
+                                  L.deriv_pitch, W * 4, H, hipMemcpyDeviceToHost, ctx->stream));
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    return ALVA_OK;
+}
+
+static int build_rest(alva_ctx *ctx, alva_pyramid *p) {
+    for (int l = 0; l < p->nlevels; l++) {
+        const alva_level &L = p->lv[l];
+        StageArgs a{};
+        a.g = L.gray;
+        a.g_pitch = L.gray_pitch;
+        a.w = L.w;
+        a.h = L.h;
+        a.d = L.deriv;
+        a.d_pitch = L.deriv_pitch;
+        a.scharr_bx = alva_divup(L.w, 256);
+        a.scharr_blocks = a.scharr_bx * alva_divup(L.h, 4);
+        a.win = p->win;
+        int down_blocks = 0;
+        if (l + 1 < p->nlevels) {
+            const alva_level &N = p->lv[l + 1];
+            a.ng = N.gray;
+            a.ng_pitch = N.gray_pitch;
+            a.dw = N.w;
+            a.dh = N.h;
+            a.down_bx = alva_divup(N.w, 64);
+            down_blocks = a.down_bx * alva_divup(N.h, 4);
+        }
+        hipLaunchKernelGGL(k_pyr_stage, dim3(a.scharr_blocks + down_blocks), dim3(64, 4), 0, ctx->stream, a);
+        ALVA_LAUNCH_CHECK();
+    }
+    return ALVA_OK;
+}
+
+extern "C" int alva_pyramid_build_from_gray(alva_ctx *ctx, alva_pyramid *pyr, const uint8_t *d_gray, size_t gray_pitch) {
+    ALVA_ARG(ctx && pyr && d_gray && gray_pitch % 4 == 0 && ((uintptr_t) d_gray % 4) == 0);
+    const alva_level &L = pyr->lv[0];
+    ALVA_ARG(gray_pitch >= (size_t) L.w);
+    dim3 block(64, 4), grid(alva_divup(L.w, 256), alva_divup(L.h, 4));
+    hipLaunchKernelGGL(k_level0<false>, grid, block, 0, ctx->stream, d_gray, gray_pitch, L.w, L.h, pyr->win, L.gray,
+                       L.gray_pitch, (uint8_t *) nullptr, (size_t) 0);
+    ALVA_LAUNCH_CHECK();
+    return build_rest(ctx, pyr);
+}
+
+extern "C" int alva_pyramid_build_from_rgba(alva_ctx *ctx, alva_pyramid *pyr, const uint8_t *d_rgba, size_t rgba_pitch,
+                                            uint8_t *d_gray_out, size_t gray_out_pitch) {
+    ALVA_ARG(ctx && pyr && d_rgba && rgba_pitch % 16 == 0 && ((uintptr_t) d_rgba % 16) == 0);
+    const alva_level &L = pyr->lv[0];
+    ALVA_ARG(rgba_pitch >= (size_t) L.w * 4);
+    if (d_gray_out) ALVA_ARG(gray_out_pitch % 4 == 0 && gray_out_pitch >= (size_t) L.w && ((uintptr_t) d_gray_out % 4) == 0);
+    dim3 block(64, 4), grid(alva_divup(L.w, 256), alva_divup(L.h, 4));
+    hipLaunchKernelGGL(k_level0<true>, grid, block, 0, ctx->stream, d_rgba, rgba_pitch, L.w, L.h, pyr->win, L.gray, L.gray_pitch,
+                       d_gray_out, gray_out_pitch);
+    ALVA_LAUNCH_CHECK();
+    return build_rest(ctx, pyr);
+}

@@ -1,0 +1,192 @@
+/*
+ * alvaar_hip.h -- C ABI of the MI355X (gfx950) hot path of AlvaAR's visual-SLAM
+ * front-end and local bundle adjustment.
+ *
+ * This is the drop-in seam: each entry point replaces one L1 -> L0 call of the
+ * reference (array in / array out, SURVEY.md §8(a), §8(b) "internal seam for
+ * HIP").  Plain pointers and sizes only; no C++/torch types.  Pointers named
+ * d_* are DEVICE pointers (HBM, on the context's device); h_* are host
+ * pointers.  All work is enqueued on the context's HIP stream; functions that
+ * return results through h_* pointers synchronise that stream before returning,
+ * all others are asynchronous.
+ *
+ * Return value: ALVA_OK (0) or a negative ALVA_ERR_* code; alva_last_error()
+ * gives a thread-local message.  There is NO CPU fallback anywhere behind this
+ * header: if no gfx950 device is usable the calls fail.
+ */
+#ifndef ALVAAR_HIP_H
+#define ALVAAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ALVA_OK = 0,
+    ALVA_ERR_ARG = -1,   /* bad argument */
+    ALVA_ERR_HIP = -2,   /* HIP runtime error (see alva_last_error) */
+    ALVA_ERR_NOMEM = -3, /* allocation failed */
+    ALVA_ERR_STATE = -4  /* object not in a usable state */
+};
+
+typedef struct alva_ctx alva_ctx;
+typedef struct alva_pyramid alva_pyramid;
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* own_stream != 0: the context creates and owns a non-blocking stream (hip_stream ignored).
+ * own_stream == 0: enqueue on the caller's hipStream_t `hip_stream` as given -- NULL is the
+ * legacy default stream (e.g. torch's current stream handle, which is 0 for the default stream). */
+int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out);
+void alva_ctx_destroy(alva_ctx *ctx);
+int alva_ctx_sync(alva_ctx *ctx);
+void *alva_ctx_stream(alva_ctx *ctx);
+const char *alva_last_error(void);
+const char *alva_version(void);
+
+/* ---- a2: RGBA -> gray ------------------------------------------------------------------------
+ * Replaces cv::cvtColor(image, image, COLOR_RGBA2GRAY) at src/slam/src/system.cpp:112
+ * (Y = (9798 R + 19235 G + 3735 B + 16384) >> 15; imgproc/src/color_rgb.simd.hpp:646-664).
+ * Pitches in bytes; rgba_pitch % 16 == 0, gray_pitch % 4 == 0, width % 4 == 0. */
+int alva_rgba2gray(alva_ctx *ctx, const uint8_t *d_rgba, size_t rgba_pitch, int width, int height,
+                   uint8_t *d_gray, size_t gray_pitch);
+
+/* ---- a3: LK pyramid with Scharr derivatives --------------------------------------------------
+ * Replaces cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), max_level) at
+ * src/slam/src/visual_frontend.cpp:696 (video/src/lkpyramid.cpp:726-822; pyrDown
+ * imgproc/src/pyramids.cpp:746-; ScharrDerivInvoker lkpyramid.cpp:70-151).
+ * Every level is stored padded by `win` pixels on each side: gray REFLECT_101, derivatives
+ * (interleaved int16 Ix,Iy) constant 0 -- the layout the LK tracker reads. */
+typedef struct alva_pyr_level {
+    int width, height;   /* interior size of this level */
+    uint8_t *d_gray;     /* device pointer to interior pixel (0,0); valid for x,y in [-win, size+win) */
+    size_t gray_pitch;   /* bytes */
+    int16_t *d_deriv;    /* device pointer to interior element (0,0), 2 x int16 per pixel */
+    size_t deriv_pitch;  /* bytes */
+} alva_pyr_level;
+
+int alva_pyramid_create(alva_ctx *ctx, int width, int height, int win, int max_level, alva_pyramid **out);
+void alva_pyramid_destroy(alva_pyramid *pyr);
+/* number of levels actually built (OpenCV stops when the next level would be <= win in either
+ * dimension, lkpyramid.cpp:811-816) */
+int alva_pyramid_num_levels(const alva_pyramid *pyr);
+int alva_pyramid_level(const alva_pyramid *pyr, int level, alva_pyr_level *out);
+int alva_pyramid_build_from_gray(alva_ctx *ctx, alva_pyramid *pyr, const uint8_t *d_gray, size_t gray_pitch);
+/* Copies one padded level to host (synchronises): h_gray (h+2win) x (w+2win) u8 contiguous,
+ * h_deriv same x 2 int16.  Either may be NULL. */
+int alva_pyramid_download_level(alva_ctx *ctx, const alva_pyramid *pyr, int level, uint8_t *h_gray, int16_t *h_deriv);
+/* fused a2+a3: level 0 is converted straight from the RGBA frame (also the entry of
+ * System::findCameraPose, system.cpp:106-112).  d_gray_out may be NULL. */
+int alva_pyramid_build_from_rgba(alva_ctx *ctx, alva_pyramid *pyr, const uint8_t *d_rgba, size_t rgba_pitch,
+                                 uint8_t *d_gray_out, size_t gray_out_pitch);
+
+/* ---- a4: forward-backward pyramidal KLT ------------------------------------------------------
+ * alva_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, pts, next, status, err,
+ * Size(win,win), num_levels, {COUNT+EPS,max_iters,eps}, USE_INITIAL_FLOW|LK_GET_MIN_EIGENVALS)
+ * (video/src/lkpyramid.cpp:183-724,1239-1404).  d_next is in/out (initial flow), d_status u8,
+ * d_err = min eigenvalue (float).
+ * alva_fbklt_track replaces FeatureTracker::fbKltTracking (src/slam/src/feature_tracker.cpp:5-111):
+ * forward LK on num_levels, gate (status && err <= err_thresh && inBorder), backward LK on level 0
+ * only, keep if |p - back| <= fb_dist.  d_prior in/out, d_status out (1 = tracked). */
+int alva_lk_track(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *next, int num_levels,
+                  int max_iters, float eps, const float *d_pts, float *d_next, uint8_t *d_status,
+                  float *d_err, int n);
+int alva_fbklt_track(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels,
+                     float err_thresh, float fb_dist, int max_iters, float eps, const float *d_pts,
+                     float *d_prior, uint8_t *d_status, int n);
+
+/* ---- a6: 256-bit steered-BRIEF (ORB) description of given points ------------------------------
+ * Replaces FeatureExtractor::describeFeaturePoints (src/slam/src/feature_extractor.cpp:160-214) =
+ * cv::ORB::create(500,1.,0)->compute(): border-32 REFLECT_101 copy, 7x7 sigma=2 Gaussian
+ * (features2d/src/orb.cpp:1188), 256 tests at round(R(angle) * pattern) with angle = -1 deg
+ * (orb.cpp:219-284; core/src/types.cpp:93-101).  Points within 31 px of the image edge get
+ * d_valid[i] = 0 and a zero descriptor (the reference returns an empty Mat for them).
+ * d_desc: n x 32 bytes. */
+int alva_describe(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height,
+                  const float *d_pts, int n, uint8_t *d_desc, uint8_t *d_valid);
+/* The blurred border-32 image ORB samples from (for stage-level parity tests):
+ * d_out is (height+64) x (width+64), pitch out_pitch. */
+int alva_orb_blur(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height,
+                  uint8_t *d_out, size_t out_pitch);
+
+/* ---- a5': FAST-9/16 + NMS, and the full ORB detector -------------------------------------------
+ * alva_fast replaces cv::FAST(img, kps, threshold, true, TYPE_9_16) (features2d/src/fast.cpp:56-292,
+ * score fast_score.cpp:120-): keypoints are emitted in row-major order; d_xy int32 x,y pairs,
+ * d_score int32.  *h_count receives the total found (may exceed cap; only cap are written). */
+int alva_fast(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int threshold,
+              int *d_xy, int *d_score, int cap, int *h_count);
+
+typedef struct alva_orb alva_orb;
+/* Replaces cv::ORB::create(nfeatures, scale, nlevels, 31, 0, 2, HARRIS_SCORE, 31, fast_threshold)
+ * ->detectAndCompute (features2d/src/orb.cpp:784-1218). */
+int alva_orb_create(alva_ctx *ctx, int width, int height, int nfeatures, float scale_factor, int nlevels,
+                    int fast_threshold, alva_orb **out);
+void alva_orb_destroy(alva_orb *orb);
+/* d_kp: cap x 6 floats {x, y, size, angle, response, octave}; d_desc: cap x 32 bytes (may be NULL for
+ * detect-only).  Keypoint ORDER within a level is canonical (row-major by y then x) rather than
+ * nth_element's unspecified order; the SET equals the reference's (SURVEY.md §8a a5'). */
+int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch,
+                                float *d_kp, uint8_t *d_desc, int cap, int *h_count);
+
+/* ---- a5: the reference's grid Shi-Tomasi detector ---------------------------------------------
+ * Replaces FeatureExtractor::detectFeaturePoints (src/slam/src/feature_extractor.cpp:11-158).
+ * h_max_quality is the detector's adaptive threshold, in/out (stateful across calls, :138-145).
+ * d_occupied: n_occ x 2 floats (already-tracked keypoints).  d_out_pts: cap x 2 floats,
+ * sub-pixel refined (cornerSubPix win 3, 30 it, eps 0.01).  *h_count = number of points. */
+int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height,
+                     int cell_size, const float *d_occupied, int n_occ, int roi_x, int roi_y, int roi_w,
+                     int roi_h, double *h_max_quality, float *d_out_pts, int cap, int *h_count);
+
+/* ---- a7: Hamming brute-force matcher ----------------------------------------------------------
+ * Replaces cv::BFMatcher(NORM_HAMMING).match(query, train) (core/src/batch_distance.cpp:199-251,
+ * norm.cpp:99-): per query the smallest distance, LOWEST train index on ties.
+ * Descriptors are 32 bytes each, rows 32-byte aligned. */
+int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int n_query, const uint8_t *d_train,
+                          int n_train, int *d_idx, int *d_dist);
+
+/* ---- a8: P3P + LMedS absolute pose ------------------------------------------------------------
+ * Replaces MultiViewGeometry::p3pRansac(obs, wpts, max_iters, err_thr, optimize=false, doRandom,
+ * fx, fy, Twc, outliers) (src/slam/src/multi_view_geometry.cpp:24-127) = opengv::sac::Lmeds<
+ * AbsolutePoseSacProblem(KNEIP)> (opengv/sac/implementation/Lmeds.hpp:43-195).
+ * h_samples: max_iters x 4 int32 sample indices, drawn by the host with the reference's sampler
+ * (alva_p3p_draw_samples reproduces SampleConsensusProblem.hpp:65-120 with std::mt19937).
+ * Outputs (host): R row-major 3x3 + t (Twc), outlier index list.  Returns 1 in *h_ok on success. */
+int alva_p3p_draw_samples(int n_points, int max_iters, int do_random, uint32_t seed, int *h_samples);
+int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters,
+                   float err_threshold, const int *h_samples, float fx, float fy, double *h_R, double *h_t,
+                   int *h_outliers, int *h_n_outliers, int *h_ok);
+
+/* ---- a9: robust PnP refinement (motion-only BA) -----------------------------------------------
+ * Replaces MultiViewGeometry::ceresPnP (src/slam/src/multi_view_geometry.cpp:129-223): Huber LM on
+ * the 6-DoF pose (Ceres trust_region_minimizer.cc / levenberg_marquardt_strategy.cc semantics,
+ * wall-clock cap removed), chi2 outlier sweep, optional L2 re-solve.
+ * h_pose7 = [tx,ty,tz,qx,qy,qz,qw] (Twc) in/out.  h_info[8]: iterations/cost of both solves. */
+int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *d_wpts, int n, double *h_pose7,
+                    int max_iters, float chi2_th, int use_robust, int apply_l2_after_robust, float fx,
+                    float fy, float cx, float cy, int *h_outliers, int *h_n_outliers, double *h_info,
+                    int *h_ok);
+
+/* ---- a10-a13: local bundle adjustment ---------------------------------------------------------
+ * Replaces the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262 on the problem
+ * built at :20-247): Levenberg-Marquardt + Huber, Schur complement on the point blocks,
+ * anchored-inverse-depth (inv_depth=1, state.hpp:74 default) or XYZ points; cost functions
+ * src/slam/src/ceres_parametrization.cpp:6-94,157-268.  Flat problem description (host arrays):
+ *   h_poses[n_kf][7] in/out, h_kf_const[n_kf], h_calib[4],
+ *   inv_depth=1: h_pt_anchor_kf[n_pt], h_pt_anchor_uv[n_pt][2], h_pt_param[n_pt]    in/out
+ *   inv_depth=0: h_pt_param[n_pt][3] in/out
+ *   h_obs_kf[n_obs], h_obs_pt[n_obs], h_obs_uv[n_obs][2]
+ * Outputs: h_chi2[n_obs], h_depth_pos[n_obs] at the last evaluated point (what the reference's
+ * outlier sweep reads, optimizer.cpp:266-309), h_info[0..3] = {#iterations, initial cost, final cost,
+ * #successful steps}. */
+int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib,
+                  int inv_depth, int n_pt, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv,
+                  double *h_pt_param, int n_obs, const int *h_obs_kf, const int *h_obs_pt,
+                  const double *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2,
+                  double *h_chi2, uint8_t *h_depth_pos, double *h_info, int *h_ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALVAAR_HIP_H */

@@ -1,0 +1,31 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference hot path (see oracle/README.md).
+ * Parity status: PINNED against oracle/_ref/libalva_ref.so (the compiled reference) by
+ * tests/test_oracle_vs_ref.py and against tests/golden/ fixtures generated from it. */
+#ifndef ALVA_ORACLE_H
+#define ALVA_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a2 */
+void orc_rgba2gray(const uint8_t *rgba, int w, int h, uint8_t *gray);
+
+/* a3: level sizes; returns number of levels built (OpenCV stops early, lkpyramid.cpp:811-816) */
+int orc_pyramid_dims(int w, int h, int win, int max_level, int *dims /* [2*(max_level+1)] */);
+/* gray_out[l]: (h_l+2win) x (w_l+2win) u8 contiguous; deriv_out[l]: same x 2 int16 */
+int orc_build_pyramid(const uint8_t *gray, int w, int h, int win, int max_level, uint8_t **gray_out, int16_t **deriv_out);
+
+/* a6 */
+void orc_orb_blur(const uint8_t *gray, int w, int h, uint8_t *out /* w*h */);
+void orc_describe(const uint8_t *gray, int w, int h, const float *pts, int n, uint8_t *desc /* n*32 */, uint8_t *valid);
+
+/* a7 */
+int orc_hamming256(const uint8_t *a, const uint8_t *b);
+void orc_bf_match_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

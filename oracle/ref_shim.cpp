@@ -206,6 +206,13 @@ int ref_orb_blur(const uint8_t *gray, int w, int h, int border, uint8_t *out /* 
     return 0;
 }
 
+// cv::getGaussianKernel(n, sigma, CV_32F) -- the taps GaussianBlur feeds the float separable filter.
+int ref_gaussian_kernel(int n, double sigma, float *out) {
+    cv::Mat k = cv::getGaussianKernel(n, sigma, CV_32F);
+    for (int i = 0; i < n; i++) out[i] = k.at<float>(i);
+    return 0;
+}
+
 // a5': cv::FAST (fast.cpp:56-292) threshold t, NMS on, TYPE_9_16.  out: x,y (int), score (u8 response)
 int ref_fast(const uint8_t *gray, int w, int h, int threshold, int nms, int *xy, int *score, int cap) {
     std::vector<cv::KeyPoint> kps;

@@ -1,0 +1,159 @@
+"""TEST INFRASTRUCTURE: numpy-facing loaders for the two CPU oracles.
+
+  orc  = oracle/libalva_oracle.so   (plain-C restatement)
+  ref  = oracle/_ref/libalva_ref.so (the compiled reference itself)
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORC_PATH = ROOT / "oracle" / "libalva_oracle.so"
+REF_PATH = ROOT / "oracle" / "_ref" / "libalva_ref.so"
+
+_vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def ref_available() -> bool:
+    return REF_PATH.exists()
+
+
+_orc = None
+_ref = None
+
+
+def orc_lib():
+    global _orc
+    if _orc is None:
+        src = ROOT / "oracle" / "alva_oracle.c"
+        if not ORC_PATH.exists() or ORC_PATH.stat().st_mtime < src.stat().st_mtime:
+            subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
+        _orc = C.CDLL(str(ORC_PATH))
+    return _orc
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(str(REF_PATH))
+        _ref.ref_build_info.restype = C.c_char_p
+    return _ref
+
+
+def pyr_dims(w, h, win, max_level):
+    dims = np.zeros(2 * (max_level + 1), np.int32)
+    n = orc_lib().orc_pyramid_dims(w, h, win, max_level, _p(dims))
+    return [(int(dims[2 * l]), int(dims[2 * l + 1])) for l in range(n)]
+
+
+def _pyr_call(fn, gray, win, max_level, with_dims):
+    h, w = gray.shape
+    dims = pyr_dims(w, h, win, max_level)
+    gs = [np.zeros((lh + 2 * win, lw + 2 * win), np.uint8) for lw, lh in dims]
+    ds = [np.zeros((lh + 2 * win, lw + 2 * win, 2), np.int16) for lw, lh in dims]
+    nmax = max_level + 1
+    gp = (_vp * nmax)(*[g.ctypes.data for g in gs] + [None] * (nmax - len(gs)))
+    dp = (_vp * nmax)(*[d.ctypes.data for d in ds] + [None] * (nmax - len(ds)))
+    gray = np.ascontiguousarray(gray)
+    if with_dims:
+        od = np.zeros(2 * nmax, np.int32)
+        lv = fn(_p(gray), w, h, win, max_level, gp, dp, _p(od))
+        assert lv + 1 == len(dims), (lv, dims)
+    else:
+        n = fn(_p(gray), w, h, win, max_level, gp, dp)
+        assert n == len(dims)
+    return gs, ds
+
+
+class Orc:
+    """Plain-C restatement."""
+
+    @staticmethod
+    def rgba2gray(rgba):
+        h, w, _ = rgba.shape
+        out = np.empty((h, w), np.uint8)
+        orc_lib().orc_rgba2gray(_p(np.ascontiguousarray(rgba)), w, h, _p(out))
+        return out
+
+    @staticmethod
+    def build_pyramid(gray, win=9, max_level=3):
+        return _pyr_call(orc_lib().orc_build_pyramid, gray, win, max_level, False)
+
+    @staticmethod
+    def bf_match(q, t):
+        q = np.ascontiguousarray(q)
+        t = np.ascontiguousarray(t)
+        idx = np.empty(len(q), np.int32)
+        dist = np.empty(len(q), np.int32)
+        orc_lib().orc_bf_match_hamming(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+        return idx, dist
+
+
+    @staticmethod
+    def orb_blur(gray):
+        h, w = gray.shape
+        out = np.empty((h, w), np.uint8)
+        orc_lib().orc_orb_blur(_p(np.ascontiguousarray(gray)), w, h, _p(out))
+        return out
+
+    @staticmethod
+    def describe(gray, pts):
+        h, w = gray.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        n = len(pts)
+        desc = np.zeros((n, 32), np.uint8)
+        valid = np.zeros(n, np.uint8)
+        orc_lib().orc_describe(_p(np.ascontiguousarray(gray)), w, h, _p(pts), n, _p(desc), _p(valid))
+        return desc, valid
+
+
+class Ref:
+    """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
+
+    @staticmethod
+    def rgba2gray(rgba):
+        h, w, _ = rgba.shape
+        out = np.empty((h, w), np.uint8)
+        rc = ref_lib().ref_rgba2gray(_p(np.ascontiguousarray(rgba)), w, h, _p(out))
+        assert rc == 0
+        return out
+
+    @staticmethod
+    def build_pyramid(gray, win=9, max_level=3):
+        return _pyr_call(ref_lib().ref_build_pyramid, gray, win, max_level, True)
+
+    @staticmethod
+    def bf_match(q, t):
+        q = np.ascontiguousarray(q)
+        t = np.ascontiguousarray(t)
+        idx = np.empty(len(q), np.int32)
+        dist = np.empty(len(q), np.int32)
+        ref_lib().ref_bf_match_hamming(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+        return idx, dist
+
+    @staticmethod
+    def orb_blur(gray):
+        h, w = gray.shape
+        b = 32
+        out = np.empty((h + 2 * b, w + 2 * b), np.uint8)
+        ref_lib().ref_orb_blur(_p(np.ascontiguousarray(gray)), w, h, b, _p(out))
+        return out[b:b + h, b:b + w].copy()
+
+    @staticmethod
+    def describe(gray, pts):
+        h, w = gray.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        n = len(pts)
+        desc = np.zeros((n, 32), np.uint8)
+        valid = np.zeros(n, np.uint8)
+        ref_lib().ref_describe(_p(np.ascontiguousarray(gray)), w, h, _p(pts), n, _p(desc), _p(valid))
+        return desc, valid

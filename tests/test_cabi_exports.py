@@ -1,0 +1,32 @@
+"""CPU: the C-ABI library loads and exports every symbol include/alvaar_hip.h declares."""
+import ctypes
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "alvaar_hip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(alva_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(str(ROOT / "alvaar_amd" / "libalvaar_hip.so"))
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/alvaar_hip.h but not exported: {missing}"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    import alvaar_amd
+    if torch.cuda.is_available():
+        return
+    try:
+        alvaar_amd.Context(0)
+    except alvaar_amd.AlvaError:
+        return
+    raise AssertionError("Context() must fail loudly without a HIP device")

@@ -1,0 +1,101 @@
+"""GPU parity: a2 (gray), a3 (LK pyramid), a7 (Hamming brute force) -- HIP path through the C ABI
+vs the CPU oracle(s).  Integer stages: bit-exact."""
+import numpy as np
+import pytest
+
+from alvaar_amd import synth
+from oracles import Orc, Ref, ref_available
+
+pytestmark = pytest.mark.gpu
+
+
+def _checkers():
+    return [("orc", Orc)] + ([("ref", Ref)] if ref_available() else [])
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 1), (1280, 720, 2), (64, 48, 3), (4, 1, 4)])
+def test_rgba2gray_bit_exact(ctx, w, h, seed):
+    import torch
+    rgba = synth.random_rgba(w, h, seed)
+    out = ctx.rgba2gray(torch.from_numpy(rgba).cuda()).cpu().numpy()
+    for name, O in _checkers():
+        assert np.array_equal(out, O.rgba2gray(rgba)), name
+
+
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 3), (1280, 720, 3), (100, 76, 3), (52, 44, 3), (332, 201, 2)])
+def test_pyramid_bit_exact(ctx, w, h, levels):
+    import torch
+    import alvaar_amd
+    canvas = synth.texture_canvas(w, h, seed=w + h)
+    g = synth.frame_gray(canvas, 3, w, h, noise_seed=11)
+    pyr = alvaar_amd.Pyramid(ctx, w, h, 9, levels)
+    pyr.build_from_gray(torch.from_numpy(g).cuda())
+    for name, O in _checkers():
+        og, od = O.build_pyramid(g, 9, levels)
+        assert pyr.num_levels == len(og)
+        for l in range(pyr.num_levels):
+            hg, hd = pyr.download_level(l)
+            assert np.array_equal(hg, og[l]), f"{name}: gray level {l}"
+            assert np.array_equal(hd, od[l]), f"{name}: deriv level {l}"
+    # rebuilding with another frame must not leave stale border pixels
+    g2 = synth.frame_gray(canvas, 9, w, h, noise_seed=5)
+    pyr.build_from_gray(torch.from_numpy(g2).cuda())
+    og, od = Orc.build_pyramid(g2, 9, levels)
+    for l in range(pyr.num_levels):
+        hg, hd = pyr.download_level(l)
+        assert np.array_equal(hg, og[l]) and np.array_equal(hd, od[l])
+    pyr.close()
+
+
+def test_pyramid_from_rgba_fused(ctx):
+    import torch
+    import alvaar_amd
+    w, h = 640, 480
+    rgba = synth.gray_to_rgba(synth.frame_gray(synth.texture_canvas(w, h), 0, w, h), seed=5)
+    pyr = alvaar_amd.Pyramid(ctx, w, h, 9, 3)
+    gout = torch.empty((h, w), dtype=torch.uint8, device="cuda")
+    pyr.build_from_rgba(torch.from_numpy(rgba).cuda(), gout)
+    gray = Orc.rgba2gray(rgba)
+    assert np.array_equal(gout.cpu().numpy(), gray)
+    og, od = Orc.build_pyramid(gray, 9, 3)
+    for l in range(pyr.num_levels):
+        hg, hd = pyr.download_level(l)
+        assert np.array_equal(hg, og[l]) and np.array_equal(hd, od[l])
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(1, 1, 0), (17, 33, 1), (300, 257, 2), (2120, 2120, 3), (64, 0, 4)])
+def test_bf_match_bit_exact(ctx, nq, nt, seed):
+    import torch
+    rng = np.random.RandomState(seed)
+    q = rng.randint(0, 256, (nq, 32)).astype(np.uint8)
+    t = rng.randint(0, 256, (nt, 32)).astype(np.uint8)
+    if nt > 2:
+        t[nt // 2] = t[0]  # exact ties: the lowest train index must win
+        t[nt - 1] = t[1]
+        q[0] = t[0]
+        if nq > 5:
+            q[5] = t[1]
+    idx, dist = ctx.bf_match_hamming(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    if nt == 0:
+        assert (idx == -1).all() and (dist == -1).all()
+        return
+    oi, od = Orc.bf_match(q, t)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    if ref_available() and nq * nt < 10_000_000:
+        ri, rd = Ref.bf_match(q, t)
+        assert np.array_equal(idx, ri) and np.array_equal(dist, rd)
+
+
+def test_bf_match_full_size_properties(ctx):
+    """BASELINE config 3 size (4080 x 4080): self-match is the identity with distance 0, and the
+    result is invariant to how the train set is chunked (size-independent property)."""
+    import torch
+    rng = np.random.RandomState(9)
+    d = rng.randint(0, 256, (4080, 32)).astype(np.uint8)
+    dd = torch.from_numpy(d).cuda()
+    idx, dist = ctx.bf_match_hamming(dd, dd)
+    assert torch.equal(idx.cpu(), torch.arange(4080, dtype=torch.int32)) and int(dist.abs().sum()) == 0
+    perm = rng.permutation(4080)
+    idx2, dist2 = ctx.bf_match_hamming(dd, torch.from_numpy(d[perm]).cuda())
+    assert np.array_equal(perm[idx2.cpu().numpy()], np.arange(4080)) and int(dist2.abs().sum()) == 0
