@@ -53,6 +53,8 @@ _sig("alva_pyramid_level", [_vp, _i, C.POINTER(PyrLevel)])
 _sig("alva_pyramid_build_from_gray", [_vp, _vp, _vp, _sz])
 _sig("alva_pyramid_download_level", [_vp, _vp, _i, _vp, _vp])
 _sig("alva_pyramid_build_from_rgba", [_vp, _vp, _vp, _sz, _vp, _sz])
+_sig("alva_lk_track", [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i])
+_sig("alva_fbklt_track", [_vp, _vp, _vp, _i, _f, _f, _i, _f, _vp, _vp, _vp, _i])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -100,6 +102,25 @@ class Context:
         check(lib.alva_rgba2gray(self.h, _ptr(rgba), w * 4, w, h, _ptr(out), out.stride(0)))
         return out
 
+
+    # a4
+    def lk_track(self, prev: "Pyramid", nxt: "Pyramid", pts, init, num_levels=3, max_iters=30, eps=0.01):
+        n = pts.shape[0]
+        out = init.clone().contiguous()
+        status = torch.empty(n, dtype=torch.uint8, device=pts.device)
+        err = torch.empty(n, dtype=torch.float32, device=pts.device)
+        check(lib.alva_lk_track(self.h, prev.h, nxt.h, num_levels, max_iters, eps, _ptr(pts), _ptr(out), _ptr(status), _ptr(err), n))
+        return out, status, err
+
+    def fbklt_track(self, prev: "Pyramid", curr: "Pyramid", pts, prior, num_levels=3, err_thresh=30.0, fb_dist=0.5,
+                    max_iters=30, eps=0.01):
+        """FeatureTracker::fbKltTracking: returns (updated prior [n,2], status [n] u8)."""
+        n = pts.shape[0]
+        out = prior.clone().contiguous()
+        status = torch.empty(n, dtype=torch.uint8, device=pts.device)
+        check(lib.alva_fbklt_track(self.h, prev.h, curr.h, num_levels, err_thresh, fb_dist, max_iters, eps, _ptr(pts), _ptr(out),
+                                   _ptr(status), n))
+        return out, status
 
     # a6
     def orb_blur(self, gray):

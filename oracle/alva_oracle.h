@@ -17,6 +17,12 @@ int orc_pyramid_dims(int w, int h, int win, int max_level, int *dims /* [2*(max_
 /* gray_out[l]: (h_l+2win) x (w_l+2win) u8 contiguous; deriv_out[l]: same x 2 int16 */
 int orc_build_pyramid(const uint8_t *gray, int w, int h, int win, int max_level, uint8_t **gray_out, int16_t **deriv_out);
 
+/* a4 (win must be 9, the reference's constant kltWinSizeWH_) */
+int orc_lk(const uint8_t *prevGray, const uint8_t *nextGray, int w, int h, int win, int pyrLevelsBuilt, int numLevels,
+           int maxIters, float eps, const float *pts, float *next, uint8_t *status, float *err, int n);
+int orc_fbklt(const uint8_t *prevGray, const uint8_t *currGray, int w, int h, int win, int pyrLevelsBuilt, int numLevels,
+              float errThresh, float fbDist, int maxIters, float eps, const float *pts, float *prior, uint8_t *status, int n);
+
 /* a6 */
 void orc_orb_blur(const uint8_t *gray, int w, int h, uint8_t *out /* w*h */);
 void orc_describe(const uint8_t *gray, int w, int h, const float *pts, int n, uint8_t *desc /* n*32 */, uint8_t *valid);

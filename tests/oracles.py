@@ -76,6 +76,35 @@ def _pyr_call(fn, gray, win, max_level, with_dims):
 
 class Orc:
     """Plain-C restatement."""
+    _pfx = "orc_"
+    _lib = staticmethod(lambda: orc_lib())
+
+    @classmethod
+    def lk(cls, prev, curr, pts, init, num_levels=3, win=9, built=3, max_iters=30, eps=0.01):
+        h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        nxt = np.ascontiguousarray(init, np.float32).copy()
+        n = len(pts)
+        st = np.zeros(n, np.uint8)
+        er = np.zeros(n, np.float32)
+        fn = getattr(cls._lib(), cls._pfx + "lk")
+        rc = fn(_p(np.ascontiguousarray(prev)), _p(np.ascontiguousarray(curr)), w, h, win, built, num_levels, max_iters,
+                _f(eps), _p(pts), _p(nxt), _p(st), _p(er), n)
+        assert rc == 0
+        return nxt, st, er
+
+    @classmethod
+    def fbklt(cls, prev, curr, pts, prior, num_levels=3, win=9, built=3, err_thresh=30.0, fb_dist=0.5, max_iters=30, eps=0.01):
+        h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        pr = np.ascontiguousarray(prior, np.float32).copy()
+        n = len(pts)
+        st = np.zeros(n, np.uint8)
+        fn = getattr(cls._lib(), cls._pfx + "fbklt")
+        rc = fn(_p(np.ascontiguousarray(prev)), _p(np.ascontiguousarray(curr)), w, h, win, built, num_levels, _f(err_thresh),
+                _f(fb_dist), max_iters, _f(eps), _p(pts), _p(pr), _p(st), n)
+        assert rc == 0
+        return pr, st
 
     @staticmethod
     def rgba2gray(rgba):
@@ -118,6 +147,35 @@ class Orc:
 
 class Ref:
     """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
+    _pfx = "ref_"
+    _lib = staticmethod(lambda: ref_lib())
+
+    @classmethod
+    def lk(cls, prev, curr, pts, init, num_levels=3, win=9, built=3, max_iters=30, eps=0.01):
+        h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        nxt = np.ascontiguousarray(init, np.float32).copy()
+        n = len(pts)
+        st = np.zeros(n, np.uint8)
+        er = np.zeros(n, np.float32)
+        fn = getattr(cls._lib(), cls._pfx + "lk")
+        rc = fn(_p(np.ascontiguousarray(prev)), _p(np.ascontiguousarray(curr)), w, h, win, built, num_levels, max_iters,
+                _f(eps), _p(pts), _p(nxt), _p(st), _p(er), n)
+        assert rc == 0
+        return nxt, st, er
+
+    @classmethod
+    def fbklt(cls, prev, curr, pts, prior, num_levels=3, win=9, built=3, err_thresh=30.0, fb_dist=0.5, max_iters=30, eps=0.01):
+        h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        pr = np.ascontiguousarray(prior, np.float32).copy()
+        n = len(pts)
+        st = np.zeros(n, np.uint8)
+        fn = getattr(cls._lib(), cls._pfx + "fbklt")
+        rc = fn(_p(np.ascontiguousarray(prev)), _p(np.ascontiguousarray(curr)), w, h, win, built, num_levels, _f(err_thresh),
+                _f(fb_dist), max_iters, _f(eps), _p(pts), _p(pr), _p(st), n)
+        assert rc == 0
+        return pr, st
 
     @staticmethod
     def rgba2gray(rgba):

@@ -1,0 +1,66 @@
+"""GPU parity: a4 -- pyramidal LK and forward-backward KLT.  The HIP kernel replays the reference
+build's float accumulation order, so positions are compared BITWISE and status flags exactly."""
+import numpy as np
+import pytest
+
+from alvaar_amd import synth
+from oracles import Orc, Ref, ref_available
+from test_oracle_vs_ref import klt_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _pyrs(ctx, prev, curr, built=3):
+    import torch
+    import alvaar_amd
+    h, w = prev.shape
+    pp = alvaar_amd.Pyramid(ctx, w, h, 9, built)
+    cp = alvaar_amd.Pyramid(ctx, w, h, 9, built)
+    pp.build_from_gray(torch.from_numpy(prev).cuda())
+    cp.build_from_gray(torch.from_numpy(curr).cuda())
+    return pp, cp
+
+
+@pytest.mark.parametrize("w,h,n,levels,seed", [(640, 480, 600, 3, 1), (640, 480, 300, 1, 2), (640, 480, 300, 0, 3), (200, 152, 200, 3, 4)])
+def test_lk_bitwise(ctx, w, h, n, levels, seed):
+    import torch
+    prev, curr, pts, init = klt_case(w, h, n, seed)
+    pp, cp = _pyrs(ctx, prev, curr)
+    nx, st, er = ctx.lk_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(init).cuda(), levels)
+    nx, st, er = nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()
+    for name, O in [("orc", Orc)] + ([("ref", Ref)] if ref_available() else []):
+        on, os_, oe = O.lk(prev, curr, pts, init, levels)
+        assert np.array_equal(st, os_), name
+        assert np.array_equal(nx.view(np.uint32), on.view(np.uint32)), name
+        ok = os_.astype(bool)
+        assert np.array_equal(er[ok].view(np.uint32), oe[ok].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("w,h,n,levels,seed", [(640, 480, 2120, 3, 5), (640, 480, 400, 1, 6), (1280, 720, 4080, 3, 7)])
+def test_fbklt_bitwise(ctx, w, h, n, levels, seed):
+    import torch
+    prev, curr, pts, init = klt_case(w, h, n, seed)
+    pp, cp = _pyrs(ctx, prev, curr)
+    pr, st = ctx.fbklt_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(init).cuda(), levels)
+    pr, st = pr.cpu().numpy(), st.cpu().numpy()
+    for name, O in [("orc", Orc)] + ([("ref", Ref)] if ref_available() else []):
+        op, os_ = O.fbklt(prev, curr, pts, init, levels)
+        assert np.array_equal(st, os_), name
+        assert np.array_equal(pr.view(np.uint32), op.view(np.uint32)), name
+    assert 0.2 * n < st.sum() < n
+
+
+def test_fbklt_identity_property(ctx):
+    """Size-independent property at the full BASELINE size: tracking a frame against itself keeps every
+    interior textured point within the FB gate and moves it by < 0.01 px."""
+    import torch
+    w, h, n = 640, 480, 2120
+    canvas = synth.texture_canvas(w, h, 7)
+    g = synth.frame_gray(canvas, 0, w, h)
+    pp, cp = _pyrs(ctx, g, g)
+    rng = np.random.RandomState(0)
+    pts = np.stack([rng.uniform(20, w - 20, n), rng.uniform(20, h - 20, n)], 1).astype(np.float32)
+    pr, st = ctx.fbklt_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(), 3)
+    pr, st = pr.cpu().numpy(), st.cpu().numpy().astype(bool)
+    assert st.sum() > 0.5 * n
+    assert np.abs(pr[st] - pts[st]).max() < 0.01

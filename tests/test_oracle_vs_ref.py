@@ -64,3 +64,39 @@ def test_describe_bit_exact(w, h, n, seed):
     assert np.array_equal(ov, rv)
     assert np.array_equal(od, rd)
     assert 0 < ov.sum() < n
+
+
+def klt_case(w, h, n, seed, shift=(2, 1), noise=True):
+    canvas = synth.texture_canvas(w, h, seed)
+    prev = synth.frame_gray(canvas, 3, w, h, noise_seed=11 if noise else None)
+    curr = synth.frame_gray(canvas, 3 + 1, w, h, noise_seed=12 if noise else None)  # moves by (2,1)
+    rng = np.random.RandomState(seed)
+    pts = np.stack([rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)], 1).astype(np.float32)
+    pts[: n // 4] = np.round(pts[: n // 4])
+    pts[0] = (0.0, 0.0)
+    pts[1] = (w - 1.0, h - 1.0)
+    pts[2] = (-20.0, 5.0)   # far outside: window check
+    init = pts + rng.uniform(-1.5, 1.5, pts.shape).astype(np.float32)
+    return prev, curr, pts, init.astype(np.float32)
+
+
+@pytest.mark.parametrize("w,h,n,levels,seed", [(640, 480, 600, 3, 1), (640, 480, 300, 1, 2), (640, 480, 300, 0, 3), (200, 150, 200, 3, 4)])
+def test_lk_bit_exact(w, h, n, levels, seed):
+    prev, curr, pts, init = klt_case(w, h, n, seed)
+    on, os_, oe = Orc.lk(prev, curr, pts, init, levels)
+    rn, rs, re_ = Ref.lk(prev, curr, pts, init, levels)
+    assert np.array_equal(os_, rs)
+    assert np.array_equal(on.view(np.uint32), rn.view(np.uint32))
+    ok = rs.astype(bool)
+    assert np.array_equal(oe[ok].view(np.uint32), re_[ok].view(np.uint32))
+    assert 0.2 * n < ok.sum() < n
+
+
+@pytest.mark.parametrize("w,h,n,levels,seed", [(640, 480, 800, 3, 5), (640, 480, 400, 1, 6), (1280, 720, 500, 3, 7)])
+def test_fbklt_bit_exact(w, h, n, levels, seed):
+    prev, curr, pts, init = klt_case(w, h, n, seed)
+    op, os_ = Orc.fbklt(prev, curr, pts, init, levels)
+    rp, rs = Ref.fbklt(prev, curr, pts, init, levels)
+    assert np.array_equal(os_, rs)
+    assert np.array_equal(op.view(np.uint32), rp.view(np.uint32))
+    assert 0.2 * n < rs.sum() < n
