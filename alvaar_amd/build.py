@@ -20,7 +20,7 @@ LIB = PKG / "libalvaar_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the float32 stages (Gaussian 7x7, min-eigenvalue, LK) must round exactly like
 # the reference's non-FMA build ("RN, no FMA contraction").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",
          "-Wno-unused-function", f"-I{ROOT / 'include'}"]
 
 

@@ -55,6 +55,8 @@ _sig("alva_pyramid_download_level", [_vp, _vp, _i, _vp, _vp])
 _sig("alva_pyramid_build_from_rgba", [_vp, _vp, _vp, _sz, _vp, _sz])
 _sig("alva_lk_track", [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i])
 _sig("alva_fbklt_track", [_vp, _vp, _vp, _i, _f, _f, _i, _f, _vp, _vp, _vp, _i])
+_sig("alva_p3p_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
+_sig("alva_p3p_lmeds", [_vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _f, _f, _vp, _vp, _vp, _vp, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -121,6 +123,21 @@ class Context:
         check(lib.alva_fbklt_track(self.h, prev.h, curr.h, num_levels, err_thresh, fb_dist, max_iters, eps, _ptr(pts), _ptr(out),
                                    _ptr(status), n))
         return out, status
+
+    # a8
+    def p3p_lmeds(self, bearings, wpts, max_iters=100, err=3.0, fx=579.4, fy=579.4, do_random=False, seed=12345):
+        """MultiViewGeometry::p3pRansac: returns (ok, R [3,3] numpy, t [3] numpy, outlier indices numpy)."""
+        import numpy as np
+        n = bearings.shape[0]
+        assert bearings.dtype == torch.float64 and wpts.dtype == torch.float64
+        R = np.zeros((3, 3))
+        t = np.zeros(3)
+        out = np.zeros(max(n, 1), np.int32)
+        nout = C.c_int(0)
+        ok = C.c_int(0)
+        check(lib.alva_p3p_lmeds(self.h, _ptr(bearings), _ptr(wpts), n, max_iters, err, int(do_random), seed, fx, fy,
+                                 R.ctypes.data, t.ctypes.data, out.ctypes.data, C.byref(nout), C.byref(ok)))
+        return bool(ok.value), R, t, out[:nout.value].copy()
 
     # a6
     def orb_blur(self, gray):

@@ -150,13 +150,15 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     const float A11 = A[0], A12 = A[1], A22 = A[2];
     float D = A11 * A22 - A12 * A12;
     const float dA = A11 - A22;
-    const float minEig = __fdiv_rn((A22 + A11) - __fsqrt_rn(dA * dA + (4.f * A12) * A12), (float) (2 * WIN * WIN));
+    // sqrtf and '/' are IEEE correctly rounded here (-fhip-fp32-correctly-rounded-divide-sqrt); the __fsqrt_rn
+    // intrinsic is NOT (it lowers to the native approximate v_sqrt_f32)
+    const float minEig = ((A22 + A11) - sqrtf(dA * dA + (4.f * A12) * A12)) / (float) (2 * WIN * WIN);
     err = minEig;
     if (minEig < minEigThreshold || D < 1.1920928955078125e-07f) {
         if (level == 0) status = 0;
         return;
     }
-    D = __fdiv_rn(1.f, D);
+    D = 1.f / D;
     nextx -= halfWin;
     nexty -= halfWin;
     float pdx = 0.f, pdy = 0.f;

@@ -1,0 +1,416 @@
+// a8: P3P (Kneip) + least-median-of-squares absolute pose, hypothesis-parallel, FP64.
+//
+// Replaces MultiViewGeometry::p3pRansac (src/slam/src/multi_view_geometry.cpp:24-127) =
+// opengv::sac::Lmeds<AbsolutePoseSacProblem(KNEIP)>::computeModel
+// (src/libs/opengv/include/opengv/sac/implementation/Lmeds.hpp:43-195), with
+//   sampling   SampleConsensusProblem.hpp:40-120 (std::mt19937 + prefix Fisher-Yates; done on the HOST with
+//              the same libstdc++ classes, so the index stream is the reference's by construction)
+//   model      AbsolutePoseSacProblem.cpp:35-163 (Kneip P3P on samples 0..2, disambiguate on the 4th)
+//   p3p        src/absolute_pose/modules/main.cpp:50-205, quartic src/math/roots.cpp:88-135
+//   score      AbsolutePoseSacProblem.cpp:165-199  (1 - f . normalize(R^T (X - t)))
+//
+// The reference evaluates hypotheses one after another; they are independent, so here
+//   k_hyp      one thread per drawn sample   -> model + valid flag
+//   k_median   one workgroup per hypothesis  -> N squared scores into LDS, bitonic sort, median
+//   k_select   one workgroup                 -> replay the sequential "first max_iters valid, strict <"
+//                                               scan, then classify inliers of the winner
+// FP64 VALU work (100 x N x ~40 flop); bytes are negligible (48 N read once per hypothesis,
+// L2-resident).  No MFMA: nothing here is GEMM-shaped.
+#include "common.hpp"
+#include <cmath>
+#include <ctime>
+#include <random>
+
+namespace {
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx C_(double r, double i) { return cplx{r, i}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return C_(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return C_(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return C_(a.re * s, a.im * s); }
+__device__ __forceinline__ cplx cdivc(cplx a, cplx b) {
+    double den = b.re * b.re + b.im * b.im;
+    return C_((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+}
+__device__ cplx csqrt_(cplx z) {
+    double m = hypot(z.re, z.im);
+    if (m == 0) return C_(0, z.im);
+    if (z.re >= 0) {
+        double t = sqrt(0.5 * (m + z.re));
+        return C_(t, z.im / (2 * t));
+    }
+    double t = sqrt(0.5 * (m - z.re));
+    return C_(fabs(z.im) / (2 * t), z.im < 0 ? -t : t);
+}
+// std::pow(std::complex<double>, double) as libstdc++ evaluates it (principal branch via log/polar)
+__device__ cplx cpow_(cplx x, double y) {
+    if (x.im == 0 && x.re > 0) return C_(pow(x.re, y), 0);
+    double lr = log(hypot(x.re, x.im)), th = atan2(x.im, x.re);
+    double r = exp(y * lr), a = y * th;
+    return C_(r * cos(a), r * sin(a));
+}
+
+__device__ void o4_roots(const double f[5], double roots[4]) {
+    const double A = f[0], B = f[1], C = f[2], D = f[3], E = f[4];
+    const double A2 = A * A, B2 = B * B, A3 = A2 * A, B3 = B2 * B, A4 = A3 * A, B4 = B3 * B;
+    const double alpha = -3 * B2 / (8 * A2) + C / A;
+    const double beta = B3 / (8 * A3) - B * C / (2 * A2) + D / A;
+    const double gamma = -3 * B4 / (256 * A4) + B2 * C / (16 * A3) - B * D / (4 * A2) + E / A;
+    const double alpha2 = alpha * alpha, alpha3 = alpha2 * alpha;
+    const cplx P = C_(-alpha2 / 12 - gamma, 0);
+    const cplx Q = C_(-alpha3 / 108 + alpha * gamma / 3 - beta * beta / 8, 0);
+    const cplx R = cadd(cscale(Q, -0.5), csqrt_(cadd(cscale(cpow_(Q, 2.0), 0.25), cscale(cpow_(P, 3.0), 1.0 / 27.0))));
+    const cplx U = cpow_(R, 1.0 / 3.0);
+    cplx y;
+    if (U.re == 0) y = csub(C_(-5.0 * alpha / 6.0, 0), cpow_(Q, 1.0 / 3.0));
+    else y = cadd(csub(C_(-5.0 * alpha / 6.0, 0), cdivc(P, cscale(U, 3.0))), U);
+    const cplx w = csqrt_(cadd(C_(alpha, 0), cscale(y, 2.0)));
+    const cplx base = cadd(C_(3.0 * alpha, 0), cscale(y, 2.0));
+    const cplx bw = cdivc(C_(2.0 * beta, 0), w);
+    const cplx s1 = csqrt_(cscale(cadd(base, bw), -1.0)), s2 = csqrt_(cscale(csub(base, bw), -1.0));
+    const double off = -B / (4.0 * A);
+    roots[0] = off + 0.5 * (w.re + s1.re);
+    roots[1] = off + 0.5 * (w.re - s1.re);
+    roots[2] = off + 0.5 * (-w.re + s2.re);
+    roots[3] = off + 0.5 * (-w.re - s2.re);
+}
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ V3 divs(V3 a, double s) { return V3{a.x / s, a.y / s, a.z / s}; }
+struct M3 {
+    V3 r0, r1, r2;  // rows
+};
+__device__ __forceinline__ V3 mul(const M3 &M, V3 v) { return V3{dot(M.r0, v), dot(M.r1, v), dot(M.r2, v)}; }
+__device__ __forceinline__ V3 mulT(const M3 &M, V3 v) {
+    return V3{M.r0.x * v.x + M.r1.x * v.y + M.r2.x * v.z, M.r0.y * v.x + M.r1.y * v.y + M.r2.y * v.z,
+              M.r0.z * v.x + M.r1.z * v.y + M.r2.z * v.z};
+}
+
+// model = {R row-major (cam->world) [9], t [3]}
+__device__ __forceinline__ double p3p_score(const double *m, V3 wp, V3 bv) {
+    // inverse = [R^T | -R^T t] applied to the homogeneous point (AbsolutePoseSacProblem.cpp:171-190)
+    const V3 t = ld3(m + 9);
+    const V3 c0{m[0], m[3], m[6]}, c1{m[1], m[4], m[7]}, c2{m[2], m[5], m[8]};  // columns of R = rows of R^T
+    const V3 nRt{-dot(c0, t), -dot(c1, t), -dot(c2, t)};
+    V3 r{dot(c0, wp) + nRt.x, dot(c1, wp) + nRt.y, dot(c2, wp) + nRt.z};
+    r = divs(r, norm(r));
+    return 1.0 - dot(r, bv);
+}
+
+__device__ int p3p_kneip(const V3 f[3], const V3 p[3], double sol[4][12]) {
+    V3 P1 = p[0], P2 = p[1], P3 = p[2];
+    const V3 t1 = sub(P2, P1), t2 = sub(P3, P1);
+    if (norm(cross(t1, t2)) == 0) return 0;
+    V3 f1 = f[0], f2 = f[1], f3;
+    M3 T;
+    for (int pass = 0; pass < 2; pass++) {
+        const V3 e1 = f1;
+        V3 e3 = cross(f1, f2);
+        e3 = divs(e3, norm(e3));
+        const V3 e2 = cross(e3, e1);
+        T = M3{e1, e2, e3};
+        f3 = mul(T, f[2]);
+        if (pass == 0 && f3.z > 0) {
+            f1 = f[1];
+            f2 = f[0];
+            P1 = p[1];
+            P2 = p[0];
+            P3 = p[2];
+            continue;
+        }
+        break;
+    }
+    V3 n1 = sub(P2, P1);
+    n1 = divs(n1, norm(n1));
+    const V3 d = sub(P3, P1);
+    V3 n3 = cross(n1, d);
+    n3 = divs(n3, norm(n3));
+    const V3 n2 = cross(n3, n1);
+    const M3 N{n1, n2, n3};
+    const V3 P3n = mul(N, d);
+    const double d_12 = norm(t1);
+    const double f_1 = f3.x / f3.z, f_2 = f3.y / f3.z, p_1 = P3n.x, p_2 = P3n.y;
+    const double cos_beta = dot(f1, f2);
+    double b = 1 / (1 - cos_beta * cos_beta) - 1;
+    b = cos_beta < 0 ? -sqrt(b) : sqrt(b);
+    const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2, p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+    const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2, d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+    double fac[5];
+    fac[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+    fac[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+    fac[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw4 +
+             p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12 + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2 +
+             2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+    fac[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * p_1 * p_2 * d_12_pw2 * b;
+    fac[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2 +
+             f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
+             f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+    double roots[4];
+    o4_roots(fac, roots);
+    for (int i = 0; i < 4; i++) {
+        const double cot_alpha = (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
+        const double cos_theta = roots[i], sin_theta = sqrt(1 - roots[i] * roots[i]);
+        const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
+        double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
+        if (cot_alpha < 0) cos_alpha = -cos_alpha;
+        const double k = d_12 * (sin_alpha * b + cos_alpha);
+        const V3 Cv{cos_alpha * k, cos_theta * sin_alpha * k, sin_theta * sin_alpha * k};
+        const V3 Cw = add(P1, mulT(N, Cv));
+        const M3 R{V3{-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta}, V3{sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta},
+                   V3{0.0, -sin_theta, cos_theta}};
+        // Rout = N^T R^T T : column j of (R^T T) = R^T * (column j of T)
+        const V3 Tc[3] = {V3{T.r0.x, T.r1.x, T.r2.x}, V3{T.r0.y, T.r1.y, T.r2.y}, V3{T.r0.z, T.r1.z, T.r2.z}};
+        for (int j = 0; j < 3; j++) {
+            const V3 col = mulT(N, mulT(R, Tc[j]));
+            sol[i][j] = col.x;
+            sol[i][3 + j] = col.y;
+            sol[i][6 + j] = col.z;
+        }
+        sol[i][9] = Cw.x;
+        sol[i][10] = Cw.y;
+        sol[i][11] = Cw.z;
+    }
+    return 4;
+}
+
+__global__ void __launch_bounds__(64) k_hyp(const double *__restrict__ bv, const double *__restrict__ wpt, const int *__restrict__ samples,
+                                            int H, double *__restrict__ models, int *__restrict__ valid) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    const int *s = samples + 4 * h;
+    V3 f[3], p[3];
+    for (int k = 0; k < 3; k++) {
+        f[k] = ld3(bv + 3 * (size_t) s[k]);
+        p[k] = ld3(wpt + 3 * (size_t) s[k]);
+    }
+    double sol[4][12];
+    const int ns = p3p_kneip(f, p, sol);
+    double minScore = 1000000.0;
+    int minIndex = -1;
+    const V3 w4 = ld3(wpt + 3 * (size_t) s[3]), b4 = ld3(bv + 3 * (size_t) s[3]);
+    for (int i = 0; i < ns; i++) {
+        const double sc = p3p_score(sol[i], w4, b4);
+        if (sc < minScore) {
+            minScore = sc;
+            minIndex = i;
+        }
+    }
+    valid[h] = minIndex >= 0;
+    if (minIndex >= 0)
+        for (int k = 0; k < 12; k++) models[12 * (size_t) h + k] = sol[minIndex][k];
+}
+
+// One workgroup per hypothesis: squared clipped scores -> LDS -> bitonic sort -> median (Lmeds.hpp:96-130).
+__global__ void __launch_bounds__(256) k_median(const double *__restrict__ bv, const double *__restrict__ wpt, int n, int np2,
+                                                const double *__restrict__ models, const int *__restrict__ valid,
+                                                double *__restrict__ penalty) {
+    extern __shared__ double s_d[];
+    const int h = blockIdx.x;
+    if (!valid[h]) {
+        if (threadIdx.x == 0) penalty[h] = INFINITY;
+        return;
+    }
+    __shared__ double s_m[12];
+    if (threadIdx.x < 12) s_m[threadIdx.x] = models[12 * (size_t) h + threadIdx.x];
+    __syncthreads();
+    for (int i = threadIdx.x; i < np2; i += 256) {
+        double v = INFINITY;
+        if (i < n) {
+            double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
+            if (d < 0) d = 0;
+            v = d * d;
+            if (v != v) v = INFINITY;  // NaN scores sort last (std::sort's behaviour with NaN is unspecified)
+        }
+        s_d[i] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const double a = s_d[i], b = s_d[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s_d[i] = b;
+                        s_d[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        const int mid = n / 2;
+        penalty[h] = (n % 2 == 0) ? (s_d[mid - 1] + s_d[mid]) / 2 : s_d[mid];
+    }
+}
+
+struct SelectOut {
+    double model[12];
+    int best, n_valid_used, n_inliers, have_model;
+};
+
+__global__ void __launch_bounds__(256) k_select(const double *__restrict__ bv, const double *__restrict__ wpt, int n, int H, int max_iters,
+                                                const double *__restrict__ models, const int *__restrict__ valid,
+                                                const double *__restrict__ penalty, double threshold, SelectOut *__restrict__ out,
+                                                uint8_t *__restrict__ inlier) {
+    __shared__ int s_best, s_cnt;
+    __shared__ double s_m[12];
+    if (threadIdx.x == 0) {
+        double best = 1.7976931348623157e308;
+        int bi = -1, used = 0;
+        for (int h = 0; h < H && used < max_iters; h++) {
+            if (!valid[h]) continue;
+            if (penalty[h] < best) {
+                best = penalty[h];
+                bi = h;
+            }
+            used++;
+        }
+        s_best = bi;
+        s_cnt = 0;
+        out->best = bi;
+        out->n_valid_used = used;
+        out->have_model = bi >= 0;
+    }
+    __syncthreads();
+    const int bi = s_best;
+    if (bi < 0) {
+        if (threadIdx.x == 0) out->n_inliers = 0;
+        return;
+    }
+    if (threadIdx.x < 12) {
+        s_m[threadIdx.x] = models[12 * (size_t) bi + threadIdx.x];
+        out->model[threadIdx.x] = s_m[threadIdx.x];
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
+        const bool in = d <= threshold;  // Lmeds.hpp:180-183 (raw, unsquared distance)
+        inlier[i] = in;
+        cnt += in;
+    }
+    atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) out->n_inliers = s_cnt;
+}
+
+// SampleConsensusProblem<M>: rng_dist_ = uniform_int_distribution<>(0, INT_MAX), rng_alg_ = std::mt19937
+// seeded 12345u (or time+clock), shuffled_indices_ persists across draws (SampleConsensusProblem.hpp:40-84).
+struct Sampler {
+    std::mt19937 alg;
+    std::uniform_int_distribution<> dist{0, std::numeric_limits<int>::max()};
+    std::vector<int> shuffled;
+    Sampler(int n, bool random_seed, uint32_t seed) : shuffled((size_t) n) {
+        if (random_seed) alg.seed(static_cast<unsigned>(time(0)) + static_cast<unsigned>(clock()));
+        else alg.seed(seed);
+        for (int i = 0; i < n; i++) shuffled[(size_t) i] = i;
+    }
+    void draw(int *out4) {
+        const size_t index_size = shuffled.size();
+        for (unsigned i = 0; i < 4; ++i) std::swap(shuffled[i], shuffled[i + ((size_t) dist(alg) % (index_size - i))]);
+        for (int i = 0; i < 4; i++) out4[i] = shuffled[(size_t) i];
+    }
+};
+
+}  // namespace
+
+extern "C" int alva_p3p_draw_samples(int n_points, int count, int do_random, uint32_t seed, int *h_samples) {
+    ALVA_ARG(n_points >= 4 && count >= 0 && h_samples);
+    Sampler s(n_points, do_random != 0, seed);
+    for (int k = 0; k < count; k++) s.draw(h_samples + 4 * k);
+    return ALVA_OK;
+}
+
+extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
+                              int do_random, uint32_t seed, float fx, float fy, double *h_R, double *h_t, int *h_outliers,
+                              int *h_n_outliers, int *h_ok) {
+    ALVA_ARG(ctx && h_R && h_t && h_outliers && h_n_outliers && h_ok && max_iters > 0);
+    *h_ok = 0;
+    *h_n_outliers = 0;
+    if (n < 4) return ALVA_OK;  // multi_view_geometry.cpp:41-44
+    ALVA_ARG(d_bearings && d_wpts);
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    ALVA_ARG((size_t) np2 * sizeof(double) <= 64 * 1024);  // LDS-resident median; n <= 8192 3-D keypoints
+    float focal = fx + fy;  // :72-76
+    focal /= 2.f;
+    const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
+
+    // draw max_iters + slack samples up front; hypotheses whose model fails do not count as an iteration in
+    // the reference (Lmeds.hpp:88-92), so on the rare shortfall re-draw a longer prefix of the same stream.
+    const int max_draws = max_iters + max_iters * 10;  // max_skip = 10 x max_iterations (Lmeds.hpp:67)
+    int H = std::min(max_draws, max_iters + 28);
+    SelectOut res{};
+    uint8_t *d_inlier = nullptr;
+    for (;;) {
+        std::vector<int> samples((size_t) H * 4);
+        {
+            Sampler smp(n, do_random != 0, seed);
+            for (int k = 0; k < H; k++) smp.draw(samples.data() + 4 * k);
+        }
+        // scratch layout: samples | models | valid | penalty | SelectOut | inlier mask
+        size_t off_models = (size_t) H * 4 * sizeof(int);
+        off_models = (off_models + 63) / 64 * 64;
+        size_t off_valid = off_models + (size_t) H * 12 * sizeof(double);
+        size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
+        size_t off_out = off_pen + (size_t) H * sizeof(double);
+        size_t off_inl = (off_out + sizeof(SelectOut) + 63) / 64 * 64;
+        size_t total = off_inl + (size_t) n;
+        uint8_t *base = nullptr;
+        int rc = alva_ctx_scratch(ctx, 2, total, (void **) &base);
+        if (rc) return rc;
+        int *d_samples = (int *) base;
+        double *d_models = (double *) (base + off_models);
+        int *d_valid = (int *) (base + off_valid);
+        double *d_pen = (double *) (base + off_pen);
+        SelectOut *d_out = (SelectOut *) (base + off_out);
+        d_inlier = base + off_inl;
+        ALVA_HIP(hipMemcpyAsync(d_samples, samples.data(), (size_t) H * 4 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, d_samples, H, d_models, d_valid);
+        ALVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) np2 * sizeof(double), ctx->stream, d_bearings, d_wpts, n, np2, d_models,
+                           d_valid, d_pen);
+        ALVA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, d_bearings, d_wpts, n, H, max_iters, d_models, d_valid, d_pen,
+                           threshold, d_out, d_inlier);
+        ALVA_LAUNCH_CHECK();
+        ALVA_HIP(hipMemcpyAsync(&res, d_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        if (res.n_valid_used >= max_iters || H >= max_draws) break;
+        H = std::min(max_draws, H * 2);
+    }
+    if (!res.have_model) return ALVA_OK;
+    if (res.n_inliers < 5) return ALVA_OK;  // multi_view_geometry.cpp:82-85
+    // Sophus::isOrthogonal(R): ||R R^T - I||_F < 1e-10 (:88-91; sophus/rotation_matrix.hpp:17-27)
+    const double *R = res.model;
+    double e = 0;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double v = R[3 * r] * R[3 * c] + R[3 * r + 1] * R[3 * c + 1] + R[3 * r + 2] * R[3 * c + 2] - (r == c ? 1.0 : 0.0);
+            e += v * v;
+        }
+    if (!(std::sqrt(e) < 1e-10)) return ALVA_OK;
+    std::vector<uint8_t> inl((size_t) n);
+    ALVA_HIP(hipMemcpyAsync(inl.data(), d_inlier, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 9; k++) h_R[k] = R[k];
+    for (int k = 0; k < 3; k++) h_t[k] = res.model[9 + k];
+    int no = 0;
+    for (int i = 0; i < n; i++)
+        if (!inl[(size_t) i]) h_outliers[no++] = i;  // :109-124: outliers = complement of the inlier list
+    *h_n_outliers = no;
+    *h_ok = 1;
+    return ALVA_OK;
+}

@@ -150,13 +150,16 @@ int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int n_query, co
  * Replaces MultiViewGeometry::p3pRansac(obs, wpts, max_iters, err_thr, optimize=false, doRandom,
  * fx, fy, Twc, outliers) (src/slam/src/multi_view_geometry.cpp:24-127) = opengv::sac::Lmeds<
  * AbsolutePoseSacProblem(KNEIP)> (opengv/sac/implementation/Lmeds.hpp:43-195).
- * h_samples: max_iters x 4 int32 sample indices, drawn by the host with the reference's sampler
- * (alva_p3p_draw_samples reproduces SampleConsensusProblem.hpp:65-120 with std::mt19937).
- * Outputs (host): R row-major 3x3 + t (Twc), outlier index list.  Returns 1 in *h_ok on success. */
-int alva_p3p_draw_samples(int n_points, int max_iters, int do_random, uint32_t seed, int *h_samples);
+ * Sampling runs on the host with the reference's own sampler classes (std::mt19937 +
+ * std::uniform_int_distribution, prefix Fisher-Yates; SampleConsensusProblem.hpp:40-120): do_random = 0
+ * seeds with `seed` (the reference's fixed seed is 12345u), do_random != 0 seeds from the clock like
+ * the reference's default.  alva_p3p_draw_samples exposes that index stream (count x 4 int32).
+ * Outputs (host): R row-major 3x3 + t (Twc), outlier index list (capacity n); *h_ok = 1 on success
+ * (>= 5 inliers and an orthogonal R, multi_view_geometry.cpp:82-91).  n <= 8192. */
+int alva_p3p_draw_samples(int n_points, int count, int do_random, uint32_t seed, int *h_samples);
 int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters,
-                   float err_threshold, const int *h_samples, float fx, float fy, double *h_R, double *h_t,
-                   int *h_outliers, int *h_n_outliers, int *h_ok);
+                   float err_threshold, int do_random, uint32_t seed, float fx, float fy, double *h_R,
+                   double *h_t, int *h_outliers, int *h_n_outliers, int *h_ok);
 
 /* ---- a9: robust PnP refinement (motion-only BA) -----------------------------------------------
  * Replaces MultiViewGeometry::ceresPnP (src/slam/src/multi_view_geometry.cpp:129-223): Huber LM on

@@ -3,6 +3,7 @@
  * (paths relative to /root/reference). */
 #include "alva_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -528,4 +529,635 @@ int orc_fbklt(const uint8_t *prevGray, const uint8_t *currGray, int w, int h, in
         free(pg[l]); free(cg[l]); free(pd[l]); free(cd[l]);
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a8 -- MultiViewGeometry::p3pRansac (src/slam/src/multi_view_geometry.cpp:24-127):
+ * opengv::sac::Lmeds<AbsolutePoseSacProblem(KNEIP)> (src/libs/opengv/include/opengv/sac/implementation/Lmeds.hpp:43-195).
+ * FP64 throughout.  Complex arithmetic follows libstdc++'s std::complex<double> semantics where they
+ * matter (pow via log/polar, principal branches). */
+typedef struct { double re, im; } cplx;
+static cplx c_(double r, double i) { cplx z = {r, i}; return z; }
+static cplx cadd(cplx a, cplx b) { return c_(a.re + b.re, a.im + b.im); }
+static cplx csub(cplx a, cplx b) { return c_(a.re - b.re, a.im - b.im); }
+static cplx cscale(cplx a, double s) { return c_(a.re * s, a.im * s); }
+static cplx cmul(cplx a, cplx b) { return c_(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+static cplx cdivc(cplx a, cplx b) {
+    double den = b.re * b.re + b.im * b.im;
+    return c_((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+}
+static cplx csqrt_(cplx z) { /* principal square root */
+    double m = hypot(z.re, z.im);
+    if (m == 0) return c_(0, z.im);
+    double t;
+    if (z.re >= 0) {
+        t = sqrt(0.5 * (m + z.re));
+        return c_(t, z.im / (2 * t));
+    }
+    t = sqrt(0.5 * (m - z.re));
+    return c_(fabs(z.im) / (2 * t), z.im < 0 ? -t : t);
+}
+/* std::pow(complex<double>, double), libstdc++ <complex>: real fast path for positive reals, else
+ * polar(exp(y*log|x|), y*arg(x)) */
+static cplx cpow_(cplx x, double y) {
+    if (x.im == 0 && x.re > 0) return c_(pow(x.re, y), 0);
+    double lr = log(hypot(x.re, x.im)), th = atan2(x.im, x.re);
+    double r = exp(y * lr), a = y * th;
+    return c_(r * cos(a), r * sin(a));
+}
+
+/* opengv::math::o4_roots -- src/libs/opengv/src/math/roots.cpp:88-135 (Ferrari; real parts returned) */
+static void o4_roots(const double f[5], double roots[4]) {
+    double A = f[0], B = f[1], C = f[2], D = f[3], E = f[4];
+    double A2 = A * A, B2 = B * B, A3 = A2 * A, B3 = B2 * B, A4 = A3 * A, B4 = B3 * B;
+    double alpha = -3 * B2 / (8 * A2) + C / A;
+    double beta = B3 / (8 * A3) - B * C / (2 * A2) + D / A;
+    double gamma = -3 * B4 / (256 * A4) + B2 * C / (16 * A3) - B * D / (4 * A2) + E / A;
+    double alpha2 = alpha * alpha, alpha3 = alpha2 * alpha;
+    cplx P = c_(-alpha2 / 12 - gamma, 0);
+    cplx Q = c_(-alpha3 / 108 + alpha * gamma / 3 - pow(beta, 2) / 8, 0);
+    cplx R = cadd(cscale(Q, -0.5), csqrt_(cadd(cscale(cpow_(Q, 2.0), 0.25), cscale(cpow_(P, 3.0), 1.0 / 27.0))));
+    cplx U = cpow_(R, 1.0 / 3.0);
+    cplx y;
+    if (U.re == 0) y = csub(c_(-5.0 * alpha / 6.0, 0), cpow_(Q, 1.0 / 3.0));
+    else y = cadd(csub(c_(-5.0 * alpha / 6.0, 0), cdivc(P, cscale(U, 3.0))), U);
+    cplx w = csqrt_(cadd(c_(alpha, 0), cscale(y, 2.0)));
+    cplx base = cadd(c_(3.0 * alpha, 0), cscale(y, 2.0));
+    cplx bw = cdivc(c_(2.0 * beta, 0), w);
+    cplx s1 = csqrt_(cscale(cadd(base, bw), -1.0)), s2 = csqrt_(cscale(csub(base, bw), -1.0));
+    double off = -B / (4.0 * A);
+    roots[0] = off + 0.5 * (w.re + s1.re);
+    roots[1] = off + 0.5 * (w.re - s1.re);
+    roots[2] = off + 0.5 * (-w.re + s2.re);
+    roots[3] = off + 0.5 * (-w.re - s2.re);
+}
+
+static void v3sub(const double *a, const double *b, double *o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static void v3cross(const double *a, const double *b, double *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double v3dot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v3norm(const double *a) { return sqrt(v3dot(a, a)); }
+static void m3v(const double M[9], const double *v, double *o) { /* row-major */
+    for (int r = 0; r < 3; r++) o[r] = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2];
+}
+static void m3tv(const double M[9], const double *v, double *o) {
+    for (int c = 0; c < 3; c++) o[c] = M[c] * v[0] + M[3 + c] * v[1] + M[6 + c] * v[2];
+}
+
+/* opengv::absolute_pose::modules::p3p_kneip_main -- src/libs/opengv/src/absolute_pose/modules/main.cpp:50-205.
+ * f: 3 bearings, p: 3 world points.  Writes up to 4 solutions {R row-major (cam->world), C}. Returns count (0 or 4). */
+static int p3p_kneip(const double f[3][3], const double p[3][3], double sol[4][12]) {
+    double P1[3], P2[3], P3[3], t1[3], t2[3], cr[3];
+    memcpy(P1, p[0], 24); memcpy(P2, p[1], 24); memcpy(P3, p[2], 24);
+    v3sub(P2, P1, t1); v3sub(P3, P1, t2); v3cross(t1, t2, cr);
+    if (v3norm(cr) == 0) return 0;
+    double f1[3], f2[3], f3[3], e1[3], e2[3], e3[3], T[9];
+    memcpy(f1, f[0], 24); memcpy(f2, f[1], 24); memcpy(f3, f[2], 24);
+    for (int pass = 0; pass < 2; pass++) {
+        memcpy(e1, f1, 24);
+        v3cross(f1, f2, e3);
+        double n = v3norm(e3);
+        e3[0] /= n; e3[1] /= n; e3[2] /= n;
+        v3cross(e3, e1, e2);
+        memcpy(T, e1, 24); memcpy(T + 3, e2, 24); memcpy(T + 6, e3, 24);
+        double tf[3];
+        m3v(T, f[2], tf);
+        memcpy(f3, tf, 24);
+        if (pass == 0 && f3[2] > 0) {
+            memcpy(f1, f[1], 24); memcpy(f2, f[0], 24);
+            memcpy(P1, p[1], 24); memcpy(P2, p[0], 24); memcpy(P3, p[2], 24);
+            continue;
+        }
+        break;
+    }
+    double n1[3], n2[3], n3[3], d[3], N[9];
+    v3sub(P2, P1, n1);
+    double nn = v3norm(n1);
+    n1[0] /= nn; n1[1] /= nn; n1[2] /= nn;
+    v3sub(P3, P1, d);
+    v3cross(n1, d, n3);
+    nn = v3norm(n3);
+    n3[0] /= nn; n3[1] /= nn; n3[2] /= nn;
+    v3cross(n3, n1, n2);
+    memcpy(N, n1, 24); memcpy(N + 3, n2, 24); memcpy(N + 6, n3, 24);
+    double P3n[3];
+    m3v(N, d, P3n);
+    double d_12 = v3norm(t1);
+    double f_1 = f3[0] / f3[2], f_2 = f3[1] / f3[2], p_1 = P3n[0], p_2 = P3n[1];
+    double cos_beta = v3dot(f1, f2);
+    double b = 1 / (1 - pow(cos_beta, 2)) - 1;
+    b = cos_beta < 0 ? -sqrt(b) : sqrt(b);
+    double f_1_pw2 = pow(f_1, 2), f_2_pw2 = pow(f_2, 2), p_1_pw2 = pow(p_1, 2), p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+    double p_2_pw2 = pow(p_2, 2), p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2, d_12_pw2 = pow(d_12, 2), b_pw2 = pow(b, 2);
+    double fac[5];
+    fac[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+    fac[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+    fac[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw4
+             + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12 + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2
+             + 2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+    fac[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * p_1 * p_2 * d_12_pw2 * b;
+    fac[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2
+             + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2
+             + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+    double roots[4];
+    o4_roots(fac, roots);
+    for (int i = 0; i < 4; i++) {
+        double cot_alpha = (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
+        double cos_theta = roots[i], sin_theta = sqrt(1 - pow(roots[i], 2));
+        double sin_alpha = sqrt(1 / (pow(cot_alpha, 2) + 1)), cos_alpha = sqrt(1 - pow(sin_alpha, 2));
+        if (cot_alpha < 0) cos_alpha = -cos_alpha;
+        double Cv[3] = {d_12 * cos_alpha * (sin_alpha * b + cos_alpha), cos_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha),
+                        sin_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha)};
+        double NtC[3];
+        m3tv(N, Cv, NtC);
+        double R[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta, sin_alpha, -cos_alpha * cos_theta,
+                       -cos_alpha * sin_theta, 0.0, -sin_theta, cos_theta};
+        /* R = N^T * R^T * T */
+        double RtT[9], out[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) RtT[3 * r + c] = R[r] * T[c] + R[3 + r] * T[3 + c] + R[6 + r] * T[6 + c];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) out[3 * r + c] = N[r] * RtT[c] + N[3 + r] * RtT[3 + c] + N[6 + r] * RtT[6 + c];
+        memcpy(sol[i], out, 72);
+        sol[i][9] = P1[0] + NtC[0]; sol[i][10] = P1[1] + NtC[1]; sol[i][11] = P1[2] + NtC[2];
+    }
+    return 4;
+}
+
+/* score of one point under model {R cam->world, t}: 1 - f . normalize(R^T (p - t))
+ * (AbsolutePoseSacProblem::getSelectedDistancesToModel, AbsolutePoseSacProblem.cpp:165-199) */
+static double p3p_score(const double m[12], const double *wp, const double *bv) {
+    double d[3] = {wp[0] - m[9], wp[1] - m[10], wp[2] - m[11]}, r[3];
+    /* the reference forms inverse = [R^T | -R^T t] and applies it to the homogeneous point */
+    double Rt_t[3];
+    m3tv(m, m + 9, Rt_t);
+    (void) d;
+    for (int c = 0; c < 3; c++) r[c] = (m[c] * wp[0] + m[3 + c] * wp[1] + m[6 + c] * wp[2]) + (-Rt_t[c]) * 1.0;
+    double n = v3norm(r);
+    r[0] /= n; r[1] /= n; r[2] /= n;
+    return 1.0 - v3dot(r, bv);
+}
+
+/* computeModelCoefficients, AbsolutePoseSacProblem.cpp:35-163 (KNEIP): P3P on samples 0..2, pick by 4th */
+static int p3p_model(const double *bv, const double *wpt, const int s[4], double model[12]) {
+    double f[3][3], p[3][3], sol[4][12];
+    for (int k = 0; k < 3; k++) {
+        memcpy(f[k], bv + 3 * s[k], 24);
+        memcpy(p[k], wpt + 3 * s[k], 24);
+    }
+    int ns = p3p_kneip(f, p, sol);
+    double minScore = 1000000.0;
+    int minIndex = -1;
+    for (int i = 0; i < ns; i++) {
+        double sc = p3p_score(sol[i], wpt + 3 * s[3], bv + 3 * s[3]);
+        if (sc < minScore) {
+            minScore = sc;
+            minIndex = i;
+        }
+    }
+    if (minIndex < 0) return 0;
+    memcpy(model, sol[minIndex], 96);
+    return 1;
+}
+
+/* std::mt19937 */
+typedef struct { uint32_t mt[624]; int idx; } orc_mt;
+static void mt_seed(orc_mt *g, uint32_t s) {
+    g->mt[0] = s;
+    for (int i = 1; i < 624; i++) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t) i;
+    g->idx = 624;
+}
+static uint32_t mt_next(orc_mt *g) {
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+/* rnd() = std::uniform_int_distribution<int>(0, INT_MAX)(mt19937): with libstdc++ >= 10 (Lemire's
+ * nearly-divisionless path for a 32-bit generator and range 2^31) this is exactly mt() >> 1.
+ * SampleConsensusProblem.hpp:40-49 (seed 12345u when !randomSeed), :65-84 (prefix Fisher-Yates). */
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *) a, y = *(const double *) b;
+    return (x > y) - (x < y);
+}
+
+int orc_p3p_lmeds(const double *bv, const double *wpt, int n, int maxIterations, float errorThreshold, uint32_t seed, float fx,
+                  float fy, double *R_out, double *t_out, int *outliers, int *nOutliers) {
+    *nOutliers = 0;
+    if (n < 4) return 0; /* multi_view_geometry.cpp:41-44 */
+    float focal = fx + fy; /* :72-76 */
+    focal /= 2.f;
+    double threshold = 1.0 - cos(atan((double) (errorThreshold / focal)));
+    orc_mt g;
+    mt_seed(&g, seed);
+    int *shuf = (int *) malloc(sizeof(int) * (size_t) n);
+    for (int i = 0; i < n; i++) shuf[i] = i;
+    double *dist = (double *) malloc(sizeof(double) * (size_t) n);
+    double best = 1.7976931348623157e308, bestModel[12];
+    int haveModel = 0, iterations = 0;
+    unsigned skipped = 0, maxSkip = (unsigned) maxIterations * 10u;
+    while (iterations < maxIterations && skipped < maxSkip) {
+        int s[4];
+        for (int i = 0; i < 4; i++) { /* drawIndexSample */
+            int r = (int) (mt_next(&g) >> 1);
+            int j = i + (int) ((unsigned) r % (unsigned) (n - i));
+            int tmp = shuf[i]; shuf[i] = shuf[j]; shuf[j] = tmp;
+        }
+        memcpy(s, shuf, sizeof(s));
+        double model[12];
+        if (!p3p_model(bv, wpt, s, model)) {
+            skipped++;
+            continue;
+        }
+        for (int i = 0; i < n; i++) {
+            double d = p3p_score(model, wpt + 3 * i, bv + 3 * i);
+            if (d < 0) d = 0;
+            dist[i] = d * d;
+        }
+        qsort(dist, (size_t) n, sizeof(double), cmp_double);
+        int mid = n / 2;
+        double pen = (n % 2 == 0) ? (dist[mid - 1] + dist[mid]) / 2 : dist[mid];
+        if (pen < best) {
+            best = pen;
+            memcpy(bestModel, model, sizeof(model));
+            haveModel = 1;
+        }
+        iterations++;
+    }
+    int ok = 0;
+    if (haveModel) {
+        uint8_t *inl = (uint8_t *) calloc((size_t) n, 1);
+        int ninl = 0;
+        for (int i = 0; i < n; i++)
+            if (p3p_score(bestModel, wpt + 3 * i, bv + 3 * i) <= threshold) {
+                inl[i] = 1;
+                ninl++;
+            }
+        /* :82-91: >= 5 inliers and Sophus::isOrthogonal(R): ||R R^T - I||_F < 1e-10 */
+        double e = 0;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) {
+                double v = bestModel[3 * r] * bestModel[3 * c] + bestModel[3 * r + 1] * bestModel[3 * c + 1] + bestModel[3 * r + 2] * bestModel[3 * c + 2] - (r == c);
+                e += v * v;
+            }
+        if (ninl >= 5 && sqrt(e) < 1e-10) {
+            ok = 1;
+            memcpy(R_out, bestModel, 72);
+            memcpy(t_out, bestModel + 9, 24);
+            for (int i = 0; i < n; i++)
+                if (!inl[i]) outliers[(*nOutliers)++] = i;
+        }
+        free(inl);
+    }
+    free(shuf);
+    free(dist);
+    return ok;
+}
+
+int orc_p3p_draw_samples(int n, int count, uint32_t seed, int *samples) {
+    orc_mt g;
+    mt_seed(&g, seed);
+    int *shuf = (int *) malloc(sizeof(int) * (size_t) n);
+    for (int i = 0; i < n; i++) shuf[i] = i;
+    for (int k = 0; k < count; k++) {
+        for (int i = 0; i < 4; i++) {
+            int r = (int) (mt_next(&g) >> 1);
+            int j = i + (int) ((unsigned) r % (unsigned) (n - i));
+            int tmp = shuf[i]; shuf[i] = shuf[j]; shuf[j] = tmp;
+        }
+        memcpy(samples + 4 * k, shuf, 4 * sizeof(int));
+    }
+    free(shuf);
+    return 0;
+}
+
+/* ================================================================================================
+ * a9 / a10-a13 -- Ceres-style Levenberg-Marquardt, restated.
+ *
+ * Control flow: src/libs/ceres-solver/internal/ceres/trust_region_minimizer.cc:67-136 (loop),
+ * :244-311 (evaluate, Jacobi scaling 1/(1+sqrt(||col||^2)) computed ONCE at iteration 0), :377-451
+ * (step, model cost change), :744-829 (tolerances, step quality, accept);
+ * levenberg_marquardt_strategy.cc:66-160 (D = sqrt(clamp(diag JtJ,1e-6,1e32)/radius), radius update);
+ * robust loss residual_block.cc + corrector.cc:41-110 + loss_function.cc:48-62 (Huber => scale r and J
+ * by sqrt(rho')); defaults from include/ceres/solver.h (radius0 1e4, max 1e16, min 1e-32,
+ * min_relative_decrease 1e-3, gradient_tolerance 1e-10, parameter_tolerance 1e-8).
+ * The linear solve is done on the normal equations (the reference uses DENSE_QR for PnP and
+ * SPARSE_SCHUR for BA; same minimiser of ||J y - r||^2 + ||D y||^2 up to FP64 rounding). */
+typedef struct { double q[4]; double t[3]; double R[9]; } orc_se3; /* q = x,y,z,w ; R row-major world<-cam */
+
+static void quat_to_R(const double q[4], double R[9]) { /* Eigen::Quaternion::toRotationMatrix */
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x,
+           tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+static void se3_from_pose7(const double *p, orc_se3 *T) { /* Sophus::SE3d(q, t): normalises q */
+    double n = sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+    for (int i = 0; i < 4; i++) T->q[i] = p[3 + i] / n;
+    memcpy(T->t, p, 24);
+    quat_to_R(T->q, T->R);
+}
+/* SE3Parameterization::Plus: T <- Exp(delta) * T, delta = (upsilon, omega)
+ * (src/slam/src/ceres_parametrization.hpp:224-240; Sophus se3.hpp:763-784, so3.hpp:585-621, :329-343) */
+static void se3_plus(const double *x7, const double *d6, double *out7) {
+    orc_se3 T;
+    se3_from_pose7(x7, &T);
+    const double *u = d6, *w = d6 + 3;
+    double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], theta, imag, real;
+    if (th2 < 1e-10 * 1e-10) {
+        theta = 0;
+        double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+    } else {
+        theta = sqrt(th2);
+        double h = 0.5 * theta;
+        imag = sin(h) / theta;
+        real = cos(h);
+    }
+    double qd[4] = {imag * w[0], imag * w[1], imag * w[2], real}, Rd[9];
+    quat_to_R(qd, Rd);
+    double V[9];
+    if (theta < 1e-10) memcpy(V, Rd, sizeof(V));
+    else {
+        double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, O2[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) O2[3 * r + c] = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
+        double a = (1 - cos(theta)) / th2, b = (theta - sin(theta)) / (th2 * theta);
+        for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+    }
+    double td[3];
+    m3v(V, u, td);
+    /* product: q = qd * qT (normalised), t = td + Rd * tT */
+    const double *a4 = qd, *b4 = T.q;
+    double qn[4] = {a4[3] * b4[0] + a4[0] * b4[3] + a4[1] * b4[2] - a4[2] * b4[1],
+                    a4[3] * b4[1] + a4[1] * b4[3] + a4[2] * b4[0] - a4[0] * b4[2],
+                    a4[3] * b4[2] + a4[2] * b4[3] + a4[0] * b4[1] - a4[1] * b4[0],
+                    a4[3] * b4[3] - a4[0] * b4[0] - a4[1] * b4[1] - a4[2] * b4[2]};
+    double n = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    double Rt[3];
+    m3v(Rd, T.t, Rt);
+    for (int i = 0; i < 3; i++) out7[i] = td[i] + Rt[i];
+    for (int i = 0; i < 4; i++) out7[3 + i] = qn[i] / n;
+}
+
+/* Cholesky solve of a dense SPD system (n x n, row-major), in place; returns 0 on failure */
+static int chol_solve(double *A, double *b, int n) {
+    for (int j = 0; j < n; j++) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= A[i * n + k] * b[k];
+        b[i] = s / A[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= A[k * n + i] * b[k];
+        b[i] = s / A[i * n + i];
+    }
+    return 1;
+}
+
+static void huber(double s, double a, int robust, double *rho0, double *rho1) {
+    double b = a * a;
+    if (robust && s > b) {
+        double r = sqrt(s);
+        *rho0 = 2.0 * a * r - b;
+        double v = a / r;
+        *rho1 = v > 2.2250738585072014e-308 ? v : 2.2250738585072014e-308;
+    } else {
+        *rho0 = s;
+        *rho1 = 1.0;
+    }
+}
+
+/* projection residual + the 2x3 block J_pi * R_cw shared by all the reference's cost functions
+ * (src/slam/src/ceres_parametrization.cpp:6-94, 96-155, 157-268) */
+static void reproj(const orc_se3 *Twc, const double K[4], const double X[3], const double uv[2], double r[2], double JR[6],
+                   double *chi2, int *depthPos) {
+    double d[3] = {X[0] - Twc->t[0], X[1] - Twc->t[1], X[2] - Twc->t[2]}, c[3];
+    m3tv(Twc->R, d, c); /* camera point = R_wc^T (X - t_wc) */
+    double iz = 1.0 / c[2];
+    r[0] = K[0] * c[0] * iz + K[2] - uv[0];
+    r[1] = K[1] * c[1] * iz + K[3] - uv[1];
+    *chi2 = r[0] * r[0] + r[1] * r[1];
+    *depthPos = c[2] > 0;
+    if (JR) {
+        double iz2 = iz * iz;
+        double Jp[6] = {iz * K[0], 0, -c[0] * iz2 * K[0], 0, iz * K[1], -c[1] * iz2 * K[1]};
+        for (int rr = 0; rr < 2; rr++)
+            for (int cc = 0; cc < 3; cc++) /* R_cw = R_wc^T */
+                JR[3 * rr + cc] = Jp[3 * rr] * Twc->R[3 * cc] + Jp[3 * rr + 1] * Twc->R[3 * cc + 1] + Jp[3 * rr + 2] * Twc->R[3 * cc + 2];
+    }
+}
+/* 2x3 times hat(X) */
+static void times_hat(const double JR[6], const double X[3], double out[6]) {
+    for (int r = 0; r < 2; r++) {
+        const double *j = JR + 3 * r;
+        out[3 * r + 0] = j[1] * X[2] - j[2] * X[1];
+        out[3 * r + 1] = j[2] * X[0] - j[0] * X[2];
+        out[3 * r + 2] = j[0] * X[1] - j[1] * X[0];
+    }
+}
+
+typedef struct {
+    double radius, decrease_factor;
+    int reuse_diagonal;
+} orc_lm;
+
+/* ---- a9: MultiViewGeometry::ceresPnP (src/slam/src/multi_view_geometry.cpp:129-223), wall-clock cap removed ---- */
+typedef struct {
+    const double *uv, *wpt;
+    const uint8_t *active;
+    int n;
+    double K[4], huber_a;
+    int robust;
+    double *chi2;
+    uint8_t *depth;
+} pnp_prob;
+
+/* cost (+ H = J^T J (36), g = J^T r (6) when H != NULL) at pose x7 */
+static double pnp_eval(const pnp_prob *P, const double *x7, double *H, double *g) {
+    orc_se3 T;
+    se3_from_pose7(x7, &T);
+    double cost = 0;
+    if (H) {
+        memset(H, 0, 36 * sizeof(double));
+        memset(g, 0, 6 * sizeof(double));
+    }
+    for (int i = 0; i < P->n; i++) {
+        if (!P->active[i]) continue;
+        double r[2], JR[6], JH[6], chi2;
+        int dp;
+        reproj(&T, P->K, P->wpt + 3 * i, P->uv + 2 * i, r, H ? JR : NULL, &chi2, &dp);
+        P->chi2[i] = chi2;
+        P->depth[i] = (uint8_t) dp;
+        double rho0, rho1;
+        huber(chi2, P->huber_a, P->robust, &rho0, &rho1);
+        cost += 0.5 * rho0;
+        if (H) {
+            times_hat(JR, P->wpt + 3 * i, JH);
+            double s = sqrt(rho1), J[12];
+            for (int rr = 0; rr < 2; rr++)
+                for (int c = 0; c < 3; c++) {
+                    J[6 * rr + c] = -JR[3 * rr + c] * s;
+                    J[6 * rr + 3 + c] = JH[3 * rr + c] * s;
+                }
+            double rs[2] = {r[0] * s, r[1] * s};
+            for (int a = 0; a < 6; a++) {
+                g[a] += J[a] * rs[0] + J[6 + a] * rs[1];
+                for (int b = 0; b < 6; b++) H[6 * a + b] += J[a] * J[b] + J[6 + a] * J[6 + b];
+            }
+        }
+    }
+    return cost;
+}
+
+static int pnp_solve(const pnp_prob *P, double *pose7, int maxIterations, double functionTolerance, double *info) {
+    double x[7], cand[7], H[36], g[6], scale[6], diag[6];
+    memcpy(x, pose7, sizeof(x));
+    orc_lm lm = {1e4, 2.0, 0};
+    double x_cost = pnp_eval(P, x, H, g);
+    for (int i = 0; i < 6; i++) scale[i] = 1.0 / (1.0 + sqrt(H[7 * i]));
+    double gmax = 0;
+    for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+    double x_norm = -1; /* trust_region_minimizer.cc:187 */
+    int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1;
+    double initial = x_cost;
+    while (1) {
+        if (iteration >= maxIterations) break;
+        if (gmax <= 1e-10) break;
+        if (lm.radius <= 1e-32) break;
+        iteration++;
+        /* ComputeStep */
+        double Hs[36], gs[6], A[36], y[6];
+        for (int a = 0; a < 6; a++) {
+            gs[a] = g[a] * scale[a];
+            for (int b = 0; b < 6; b++) Hs[6 * a + b] = H[6 * a + b] * scale[a] * scale[b];
+        }
+        if (!lm.reuse_diagonal)
+            for (int a = 0; a < 6; a++) diag[a] = fmin(fmax(Hs[7 * a], 1e-6), 1e32);
+        memcpy(A, Hs, sizeof(A));
+        for (int a = 0; a < 6; a++) A[7 * a] += diag[a] / lm.radius;
+        memcpy(y, gs, sizeof(y));
+        int okstep = chol_solve(A, y, 6);
+        lm.reuse_diagonal = 1;
+        double step[6], mcc = 0;
+        if (okstep) {
+            for (int a = 0; a < 6; a++) step[a] = -y[a];
+            double sg = 0, sHs = 0;
+            for (int a = 0; a < 6; a++) {
+                sg += step[a] * gs[a];
+                for (int b = 0; b < 6; b++) sHs += step[a] * Hs[6 * a + b] * step[b];
+            }
+            mcc = -sg - 0.5 * sHs;
+        }
+        if (!okstep || !(mcc > 0)) { /* HandleInvalidStep */
+            if (++invalid >= 5) return 0;
+            lm.radius /= lm.decrease_factor;
+            lm.decrease_factor *= 2;
+            lm.reuse_diagonal = 1;
+            nsummaries++;
+            continue;
+        }
+        invalid = 0;
+        double delta[6];
+        for (int a = 0; a < 6; a++) delta[a] = step[a] * scale[a];
+        se3_plus(x, delta, cand);
+        double cand_cost = pnp_eval(P, cand, NULL, NULL);
+        double sn = 0;
+        for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+        if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) break; /* ParameterToleranceReached */
+        if (fabs(x_cost - cand_cost) <= functionTolerance * x_cost) break; /* FunctionToleranceReached */
+        double rel = (x_cost - cand_cost) / mcc;
+        if (getenv("ALVA_ORC_VERBOSE")) fprintf(stderr, "it %d x_cost %.6e cand %.6e mcc %.6e rel %.3f radius %.3e\n", iteration, x_cost, cand_cost, mcc, rel, lm.radius);
+        if (rel > 1e-3) {
+            memcpy(x, cand, sizeof(x));
+            x_norm = 0;
+            for (int i = 0; i < 7; i++) x_norm += x[i] * x[i];
+            x_norm = sqrt(x_norm);
+            x_cost = pnp_eval(P, x, H, g);
+            gmax = 0;
+            for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(g[i]));
+            lm.radius = lm.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+            lm.radius = fmin(1e16, lm.radius);
+            lm.decrease_factor = 2.0;
+            lm.reuse_diagonal = 0;
+            nsucc++;
+        } else {
+            lm.radius /= lm.decrease_factor;
+            lm.decrease_factor *= 2;
+            lm.reuse_diagonal = 1;
+        }
+        nsummaries++;
+    }
+    memcpy(pose7, x, sizeof(x));
+    if (info) {
+        info[0] = nsummaries;
+        info[1] = initial;
+        info[2] = x_cost;
+        info[3] = nsucc;
+    }
+    return 1;
+}
+
+int orc_pnp_refine(const double *uv, const double *wpt, int n, double *pose7, int maxIterations, float chi2th, int useRobust,
+                   int applyL2AfterRobust, float fx, float fy, float cx, float cy, int *outliers, int *nOutliers, double *info) {
+    pnp_prob P;
+    P.uv = uv;
+    P.wpt = wpt;
+    P.n = n;
+    P.K[0] = fx; P.K[1] = fy; P.K[2] = cx; P.K[3] = cy;
+    P.huber_a = (double) sqrtf(chi2th); /* :135 std::sqrt(float) -> float */
+    P.robust = useRobust;
+    uint8_t *active = (uint8_t *) malloc((size_t) n + 1);
+    memset(active, 1, (size_t) n);
+    P.active = active;
+    P.chi2 = (double *) calloc((size_t) n + 1, sizeof(double));
+    P.depth = (uint8_t *) calloc((size_t) n + 1, 1);
+    if (info) memset(info, 0, 8 * sizeof(double));
+    *nOutliers = 0;
+    int ok = pnp_solve(&P, pose7, maxIterations, 1e-3, info);
+    int nbad = 0;
+    for (int i = 0; i < n; i++)
+        if (P.chi2[i] > (double) chi2th || !P.depth[i]) { /* multi_view_geometry.cpp:194-207 */
+            if (applyL2AfterRobust) active[i] = 0;
+            outliers[(*nOutliers)++] = i;
+            nbad++;
+        }
+    int ret;
+    if (nbad == n) ret = 0;
+    else {
+        if (applyL2AfterRobust && nbad > 0) { /* :214-218 */
+            P.robust = 0;
+            ok = pnp_solve(&P, pose7, maxIterations, 1e-3, info ? info + 4 : NULL);
+        }
+        ret = ok;
+    }
+    free(active);
+    free(P.chi2);
+    free(P.depth);
+    return ret;
 }

@@ -31,6 +31,15 @@ void orc_describe(const uint8_t *gray, int w, int h, const float *pts, int n, ui
 int orc_hamming256(const uint8_t *a, const uint8_t *b);
 void orc_bf_match_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist);
 
+/* a8 */
+int orc_p3p_lmeds(const double *bv, const double *wpt, int n, int maxIterations, float errorThreshold, uint32_t seed, float fx,
+                  float fy, double *R_out /*9, row-major*/, double *t_out, int *outliers, int *nOutliers);
+int orc_p3p_draw_samples(int n, int count, uint32_t seed, int *samples /* count*4 */);
+
+/* a9 */
+int orc_pnp_refine(const double *uv, const double *wpt, int n, double *pose7, int maxIterations, float chi2th, int useRobust,
+                   int applyL2AfterRobust, float fx, float fy, float cx, float cy, int *outliers, int *nOutliers, double *info /*[8]*/);
+
 #ifdef __cplusplus
 }
 #endif

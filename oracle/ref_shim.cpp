@@ -347,7 +347,7 @@ int ref_ceres_pnp_nocap(const double *uv, const double *wpt, int n, double *pose
     options.num_threads = 1;
     options.max_num_iterations = maxIterations;
     options.function_tolerance = 1.e-3;
-    options.minimizer_progress_to_stdout = false;
+    options.minimizer_progress_to_stdout = getenv("ALVA_REF_VERBOSE") != nullptr;
     ceres::Solver::Summary summary;
     ceres::Solve(options, &problem, &summary);
     if (info) {
@@ -401,7 +401,7 @@ int ref_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *c
                  int maxIterations, double functionTolerance, double huberChi2,
                  double *chi2, uint8_t *depthPos, double *info) {
     ceres::Problem problem;
-    auto *lossFunction = new ceres::LossFunctionWrapper(new ceres::HuberLoss(std::sqrt(huberChi2)), ceres::TAKE_OWNERSHIP);
+    auto *lossFunction = new ceres::LossFunctionWrapper(new ceres::HuberLoss(std::sqrt((float) huberChi2)) /* optimizer.cpp:22: sqrt of a float */, ceres::TAKE_OWNERSHIP);
     auto ordering = new ceres::ParameterBlockOrdering;
     double calibv[4] = {calib[0], calib[1], calib[2], calib[3]};
     problem.AddParameterBlock(calibv, 4);

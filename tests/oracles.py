@@ -77,6 +77,21 @@ def _pyr_call(fn, gray, win, max_level, with_dims):
 class Orc:
     """Plain-C restatement."""
     _pfx = "orc_"
+    _pnp = "orc_pnp_refine"
+
+    @classmethod
+    def pnp_refine(cls, uv, wpt, pose7, K, max_iters=5, chi2th=5.9915, robust=True, l2=True):
+        uv = np.ascontiguousarray(uv, np.float64)
+        wpt = np.ascontiguousarray(wpt, np.float64)
+        n = len(uv)
+        pose = np.ascontiguousarray(pose7, np.float64).copy()
+        out = np.zeros(max(n, 1), np.int32)
+        nout = C.c_int(0)
+        info = np.zeros(8)
+        fn = getattr(cls._lib(), cls._pnp)
+        ok = fn(_p(uv), _p(wpt), n, _p(pose), max_iters, _f(chi2th), int(robust), int(l2), _f(K[0]), _f(K[1]), _f(K[2]), _f(K[3]),
+                _p(out), C.byref(nout), _p(info))
+        return bool(ok), pose, out[:nout.value].copy(), info
     _lib = staticmethod(lambda: orc_lib())
 
     @classmethod
@@ -128,6 +143,19 @@ class Orc:
 
 
     @staticmethod
+    def p3p_lmeds(bv, wpt, max_iters=100, err=3.0, fx=579.4, fy=579.4, seed=12345):
+        bv = np.ascontiguousarray(bv, np.float64)
+        wpt = np.ascontiguousarray(wpt, np.float64)
+        n = len(bv)
+        R = np.zeros((3, 3))
+        t = np.zeros(3)
+        out = np.zeros(n, np.int32)
+        nout = C.c_int(0)
+        ok = orc_lib().orc_p3p_lmeds(_p(bv), _p(wpt), n, max_iters, _f(err), C.c_uint32(seed), _f(fx), _f(fy), _p(R), _p(t), _p(out),
+                                     C.byref(nout))
+        return bool(ok), R, t, out[:nout.value].copy()
+
+    @staticmethod
     def orb_blur(gray):
         h, w = gray.shape
         out = np.empty((h, w), np.uint8)
@@ -148,6 +176,21 @@ class Orc:
 class Ref:
     """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
     _pfx = "ref_"
+    _pnp = "ref_ceres_pnp_nocap"
+
+    @classmethod
+    def pnp_refine(cls, uv, wpt, pose7, K, max_iters=5, chi2th=5.9915, robust=True, l2=True):
+        uv = np.ascontiguousarray(uv, np.float64)
+        wpt = np.ascontiguousarray(wpt, np.float64)
+        n = len(uv)
+        pose = np.ascontiguousarray(pose7, np.float64).copy()
+        out = np.zeros(max(n, 1), np.int32)
+        nout = C.c_int(0)
+        info = np.zeros(8)
+        fn = getattr(cls._lib(), cls._pnp)
+        ok = fn(_p(uv), _p(wpt), n, _p(pose), max_iters, _f(chi2th), int(robust), int(l2), _f(K[0]), _f(K[1]), _f(K[2]), _f(K[3]),
+                _p(out), C.byref(nout), _p(info))
+        return bool(ok), pose, out[:nout.value].copy(), info
     _lib = staticmethod(lambda: ref_lib())
 
     @classmethod
@@ -215,3 +258,16 @@ class Ref:
         valid = np.zeros(n, np.uint8)
         ref_lib().ref_describe(_p(np.ascontiguousarray(gray)), w, h, _p(pts), n, _p(desc), _p(valid))
         return desc, valid
+
+    @staticmethod
+    def p3p_lmeds(bv, wpt, max_iters=100, err=3.0, fx=579.4, fy=579.4, do_random=False):
+        bv = np.ascontiguousarray(bv, np.float64)
+        wpt = np.ascontiguousarray(wpt, np.float64)
+        n = len(bv)
+        R = np.zeros((3, 3))
+        t = np.zeros(3)
+        out = np.zeros(n, np.int32)
+        nout = C.c_int(0)
+        ok = ref_lib().ref_p3p_lmeds(_p(bv), _p(wpt), n, max_iters, _f(err), int(do_random), _f(fx), _f(fy), _p(R), _p(t), _p(out),
+                                     C.byref(nout))
+        return bool(ok), R, t, out[:nout.value].copy()

@@ -100,3 +100,30 @@ def test_fbklt_bit_exact(w, h, n, levels, seed):
     assert np.array_equal(os_, rs)
     assert np.array_equal(op.view(np.uint32), rp.view(np.uint32))
     assert 0.2 * n < rs.sum() < n
+
+
+@pytest.mark.parametrize("n,seed,outl", [(2000, 3, 0.1), (192, 4, 0.3), (12, 5, 0.0), (501, 6, 0.45)])
+def test_p3p_lmeds(n, seed, outl):
+    pb = synth.make_pnp_problem(n, seed, outlier_frac=outl)
+    ok1, R1, t1, o1 = Orc.p3p_lmeds(pb["bv"], pb["wpt"])
+    ok2, R2, t2, o2 = Ref.p3p_lmeds(pb["bv"], pb["wpt"])
+    assert ok1 == ok2 and ok2
+    # FP64 restatement vs OpenGV/Eigen: same hypothesis wins, pose equal to rounding noise
+    assert np.abs(t1 - t2).max() < 1e-8 and np.abs(R1 - R2).max() < 1e-8
+    assert np.array_equal(o1, o2)
+    from alvaar_amd.synth import quat_xyzw_to_rot
+    Rgt = quat_xyzw_to_rot(pb["pose_gt"][3:])
+    assert np.abs(R2 - Rgt).max() < 0.05
+
+
+@pytest.mark.parametrize("n,seed,outl,noise", [(2000, 3, 0.1, 0.01), (192, 4, 0.3, 0.02), (30, 5, 0.0, 0.005), (500, 6, 0.2, 0.05)])
+def test_pnp_refine(n, seed, outl, noise):
+    pb = synth.make_pnp_problem(n, seed, outlier_frac=outl, pose_noise=noise)
+    ok1, p1, o1, i1 = Orc.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"])
+    ok2, p2, o2, i2 = Ref.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"])
+    assert ok1 == ok2
+    assert np.array_equal(o1, o2)
+    assert i1[0] == i2[0] and i1[4] == i2[4], (i1, i2)          # same number of LM iterations in both solves
+    assert np.allclose(i1[[1, 2, 5, 6]], i2[[1, 2, 5, 6]], rtol=1e-9)  # initial / final costs
+    assert np.abs(p1 - p2).max() < 1e-9
+    assert np.abs(p2[:3] - pb["pose_gt"][:3]).max() < 0.05
