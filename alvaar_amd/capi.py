@@ -57,6 +57,7 @@ _sig("alva_lk_track", [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i])
 _sig("alva_fbklt_track", [_vp, _vp, _vp, _i, _f, _f, _i, _f, _vp, _vp, _vp, _i])
 _sig("alva_p3p_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
 _sig("alva_p3p_lmeds", [_vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _f, _f, _vp, _vp, _vp, _vp, _vp])
+_sig("alva_pnp_refine", [_vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -138,6 +139,21 @@ class Context:
         check(lib.alva_p3p_lmeds(self.h, _ptr(bearings), _ptr(wpts), n, max_iters, err, int(do_random), seed, fx, fy,
                                  R.ctypes.data, t.ctypes.data, out.ctypes.data, C.byref(nout), C.byref(ok)))
         return bool(ok.value), R, t, out[:nout.value].copy()
+
+    # a9
+    def pnp_refine(self, uv, wpts, pose7, K, max_iters=5, chi2th=5.9915, robust=True, l2=True):
+        """MultiViewGeometry::ceresPnP: returns (ok, pose7 numpy, outlier indices numpy, info[8])."""
+        import numpy as np
+        n = uv.shape[0]
+        assert uv.dtype == torch.float64 and wpts.dtype == torch.float64
+        pose = np.ascontiguousarray(pose7, np.float64).copy()
+        out = np.zeros(max(n, 1), np.int32)
+        nout = C.c_int(0)
+        ok = C.c_int(0)
+        info = np.zeros(8)
+        check(lib.alva_pnp_refine(self.h, _ptr(uv), _ptr(wpts), n, pose.ctypes.data, max_iters, chi2th, int(robust), int(l2),
+                                  K[0], K[1], K[2], K[3], out.ctypes.data, C.byref(nout), info.ctypes.data, C.byref(ok)))
+        return bool(ok.value), pose, out[:nout.value].copy(), info
 
     # a6
     def orb_blur(self, gray):

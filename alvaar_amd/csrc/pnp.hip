@@ -1,0 +1,334 @@
+// a9: robust PnP refinement (motion-only bundle adjustment) -- the whole Levenberg-Marquardt loop in
+// ONE persistent workgroup.
+//
+// Replaces MultiViewGeometry::ceresPnP (src/slam/src/multi_view_geometry.cpp:129-223): Ceres LM +
+// Huber on the 6-DoF pose with cost ReprojectionErrorSE3 (ceres_parametrization.cpp:96-155), chi2 /
+// depth outlier sweep, optional L2 re-solve.  The minimiser control flow is Ceres 2.0's
+// (trust_region_minimizer.cc:67-136, 244-311, 377-451, 744-829; levenberg_marquardt_strategy.cc:66-160)
+// with the reference's 5 ms wall-clock cap removed (it makes the reference non-deterministic).
+//
+// Why one workgroup: the problem is N <= a few thousand 2x6 Jacobian rows and a 6x6 solve per iteration;
+// a multi-launch version would pay ~10 dependent kernel boundaries + host round trips (~1.5-5 us each,
+// MI355X_MICROARCH "boundary" row) for ~1 us of FP64 work per evaluation.  Here 1024 threads evaluate
+// residuals/Jacobians and reduce the 28 normal-equation scalars (21 of J^T J, 6 of J^T r, cost) through
+// wave shuffles + LDS; lane 0 does the 6x6 Cholesky and the trust-region bookkeeping; nothing leaves
+// the CU until the pose is final.  FP64 throughout (the reference is all double).
+#include "common.hpp"
+#include "lm_device.hpp"
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int NW = NT / 64;
+constexpr int NACC = 28;  // H upper triangle (21) | g (6) | cost (1)
+
+struct PnpArgs {
+    const double *uv, *wpt;
+    int n;
+    double K[4];
+    double huber_a;
+    double chi2_th;
+    int use_robust, apply_l2, max_iters;
+    double ftol;
+};
+
+struct PnpOut {
+    double pose[7];
+    double info[8];
+    int ok, n_bad;
+};
+
+struct PnpShared {
+    double part[NW][NACC];
+    double acc[NACC];
+    double x[7], cand[7];
+    int flag;
+};
+
+enum { F_DONE = 0, F_EVAL_CAND = 1, F_RETRY = 2, F_ACCEPT = 3, F_FAIL = 4 };
+
+__device__ __forceinline__ int tri(int a, int b) {  // index of (a,b), a <= b, in the packed upper triangle of a 6x6
+    return a * 6 - a * (a - 1) / 2 + (b - a);
+}
+
+// Block-wide evaluation at pose p7: cost (+ packed J^T J and J^T r when WANT_J) into sh.acc.
+template<bool WANT_J>
+__device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robust, const uint8_t *active, double *chi2_out,
+                     uint8_t *depth_out) {
+    Se3 T;
+    se3_from_pose7(p7, T);
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < A.n; i += NT) {
+        if (!active[i]) continue;
+        const double X[3] = {A.wpt[3 * i], A.wpt[3 * i + 1], A.wpt[3 * i + 2]};
+        double r[2], JR[6], chi2;
+        int dp;
+        reproj<WANT_J>(T, A.K, X, A.uv[2 * i], A.uv[2 * i + 1], r, JR, chi2, dp);
+        chi2_out[i] = chi2;
+        depth_out[i] = (uint8_t) dp;
+        double rho0, rho1;
+        huber_rho(chi2, A.huber_a, robust, rho0, rho1);
+        acc[27] += 0.5 * rho0;
+        if (WANT_J) {
+            double JH[6];
+            times_hat(JR, X, JH);
+            const double s = sqrt(rho1);
+            double J[12];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    J[6 * rr + c] = -JR[3 * rr + c] * s;
+                    J[6 * rr + 3 + c] = JH[3 * rr + c] * s;
+                }
+            const double r0 = r[0] * s, r1 = r[1] * s;
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+#pragma unroll
+                for (int b = a; b < 6; b++) acc[t++] += J[a] * J[b] + J[6 + a] * J[6 + b];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; k++) {
+        if (!WANT_J && k != 27) continue;
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sh.part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double v = 0;
+        for (int w = 0; w < NW; w++) v += sh.part[w][threadIdx.x];
+        sh.acc[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+// One ceres::Solve on the pose in sh.x.  Returns (block-uniformly) 1 = usable, 0 = failure.
+__device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *active, double *chi2, uint8_t *depth, double *info) {
+    // thread-0 private minimiser state
+    double H[36], g[6], scale[6], diag[6], x_cost = 0, gmax = 0, x_norm = -1, initial = 0, mcc = 0;
+    LmState lm;
+    int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1;
+
+    eval<true>(sh, A, sh.x, robust, active, chi2, depth);
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
+        for (int a = 0; a < 6; a++) g[a] = sh.acc[21 + a];
+        x_cost = initial = sh.acc[27];
+        for (int a = 0; a < 6; a++) {
+            scale[a] = 1.0 / (1.0 + sqrt(H[7 * a]));  // trust_region_minimizer.cc:266-275, iteration 0 only
+            gmax = fmax(gmax, fabs(g[a]));
+        }
+    }
+    int result = 1;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int flag;
+            if (iteration >= A.max_iters || gmax <= 1e-10 || lm.radius <= 1e-32) {
+                flag = F_DONE;
+            } else {
+                iteration++;
+                double Hs[36], gs[6], M[36], y[6];
+                for (int a = 0; a < 6; a++) {
+                    gs[a] = g[a] * scale[a];
+                    for (int b = 0; b < 6; b++) Hs[6 * a + b] = H[6 * a + b] * scale[a] * scale[b];
+                }
+                if (!lm.reuse_diagonal)
+                    for (int a = 0; a < 6; a++) diag[a] = fmin(fmax(Hs[7 * a], 1e-6), 1e32);
+                for (int k = 0; k < 36; k++) M[k] = Hs[k];
+                for (int a = 0; a < 6; a++) {
+                    M[7 * a] += diag[a] / lm.radius;
+                    y[a] = gs[a];
+                }
+                const bool okstep = chol_solve_dense(M, y, 6);
+                lm.reuse_diagonal = 1;
+                double step[6];
+                mcc = 0;
+                if (okstep) {
+                    double sg = 0, sHs = 0;
+                    for (int a = 0; a < 6; a++) {
+                        step[a] = -y[a];
+                        sg += step[a] * gs[a];
+                    }
+                    for (int a = 0; a < 6; a++)
+                        for (int b = 0; b < 6; b++) sHs += step[a] * Hs[6 * a + b] * step[b];
+                    mcc = -sg - 0.5 * sHs;  // = -(J s)'(f + J s / 2), trust_region_minimizer.cc:419-431
+                }
+                if (!okstep || !(mcc > 0)) {
+                    if (++invalid >= 5) flag = F_FAIL;
+                    else {
+                        lm.rejected();
+                        nsummaries++;
+                        flag = F_RETRY;
+                    }
+                } else {
+                    invalid = 0;
+                    double delta[6];
+                    for (int a = 0; a < 6; a++) delta[a] = step[a] * scale[a];
+                    se3_plus(sh.x, delta, sh.cand);
+                    flag = F_EVAL_CAND;
+                }
+            }
+            sh.flag = flag;
+        }
+        __syncthreads();
+        int flag = sh.flag;
+        if (flag == F_DONE) break;
+        if (flag == F_FAIL) {
+            result = 0;
+            break;
+        }
+        if (flag == F_RETRY) continue;
+        eval<false>(sh, A, sh.cand, robust, active, chi2, depth);
+        if (threadIdx.x == 0) {
+            const double cand_cost = sh.acc[27];
+            double sn = 0;
+            for (int i = 0; i < 7; i++) sn += (sh.x[i] - sh.cand[i]) * (sh.x[i] - sh.cand[i]);
+            if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) flag = F_DONE;                       // ParameterToleranceReached
+            else if (fabs(x_cost - cand_cost) <= A.ftol * x_cost) flag = F_DONE;        // FunctionToleranceReached
+            else {
+                const double rel = (x_cost - cand_cost) / mcc;
+                if (rel > 1e-3) {
+                    double nn = 0;
+                    for (int i = 0; i < 7; i++) {
+                        sh.x[i] = sh.cand[i];
+                        nn += sh.x[i] * sh.x[i];
+                    }
+                    x_norm = sqrt(nn);
+                    lm.accepted(rel);
+                    nsucc++;
+                    flag = F_ACCEPT;
+                } else {
+                    lm.rejected();
+                    nsummaries++;
+                    flag = F_RETRY;
+                }
+            }
+            sh.flag = flag;
+        }
+        __syncthreads();
+        flag = sh.flag;
+        if (flag == F_DONE) break;
+        if (flag == F_ACCEPT) {
+            // HandleSuccessfulStep re-evaluates with Jacobians at the accepted point (:809-829)
+            eval<true>(sh, A, sh.x, robust, active, chi2, depth);
+            if (threadIdx.x == 0) {
+                for (int a = 0; a < 6; a++)
+                    for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
+                gmax = 0;
+                for (int a = 0; a < 6; a++) {
+                    g[a] = sh.acc[21 + a];
+                    gmax = fmax(gmax, fabs(g[a]));
+                }
+                x_cost = sh.acc[27];
+                nsummaries++;
+            }
+        }
+    }
+    if (threadIdx.x == 0 && info) {
+        info[0] = nsummaries;
+        info[1] = initial;
+        info[2] = x_cost;
+        info[3] = nsucc;
+    }
+    __syncthreads();
+    return result;
+}
+
+__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict__ pose_in, uint8_t *__restrict__ active,
+                                            double *__restrict__ chi2, uint8_t *__restrict__ depth, uint8_t *__restrict__ bad,
+                                            PnpOut *__restrict__ out) {
+    __shared__ PnpShared sh;
+    __shared__ int s_nbad;
+    if (threadIdx.x < 7) sh.x[threadIdx.x] = pose_in[threadIdx.x];
+    if (threadIdx.x < 8) out->info[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nbad = 0;
+    for (int i = threadIdx.x; i < A.n; i += NT) active[i] = 1;
+    __syncthreads();
+    {
+        // normalise like PoseParametersBlock(0, Sophus::SE3d(q, t)) does before the solve
+        if (threadIdx.x == 0) {
+            Se3 T;
+            se3_from_pose7(sh.x, T);
+            for (int i = 0; i < 4; i++) sh.x[3 + i] = T.q[i];
+        }
+        __syncthreads();
+    }
+    int ok = solve(sh, A, A.use_robust, active, chi2, depth, out->info);
+    int nb = 0;
+    for (int i = threadIdx.x; i < A.n; i += NT) {
+        const bool b = chi2[i] > A.chi2_th || !depth[i];  // multi_view_geometry.cpp:194-207
+        bad[i] = b;
+        if (b) {
+            nb++;
+            if (A.apply_l2) active[i] = 0;
+        }
+    }
+    atomicAdd(&s_nbad, nb);
+    __syncthreads();
+    const int nbad = s_nbad;
+    if (nbad == A.n) ok = 0;
+    else if (A.apply_l2 && nbad > 0) ok = solve(sh, A, 0, active, chi2, depth, out->info + 4);  // :214-218
+    if (threadIdx.x < 7) out->pose[threadIdx.x] = sh.x[threadIdx.x];
+    if (threadIdx.x == 0) {
+        out->ok = ok;
+        out->n_bad = nbad;
+    }
+}
+
+}  // namespace
+
+extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *d_wpts, int n, double *h_pose7, int max_iters,
+                               float chi2_th, int use_robust, int apply_l2_after_robust, float fx, float fy, float cx, float cy,
+                               int *h_outliers, int *h_n_outliers, double *h_info, int *h_ok) {
+    ALVA_ARG(ctx && h_pose7 && h_outliers && h_n_outliers && h_ok && n >= 0 && max_iters >= 0);
+    *h_ok = 0;
+    *h_n_outliers = 0;
+    if (h_info) memset(h_info, 0, 8 * sizeof(double));
+    if (n == 0) return ALVA_OK;  // nbad == numKeyPoints -> false (:209-212)
+    ALVA_ARG(d_uv && d_wpts);
+    PnpArgs A{};
+    A.uv = d_uv;
+    A.wpt = d_wpts;
+    A.n = n;
+    A.K[0] = fx; A.K[1] = fy; A.K[2] = cx; A.K[3] = cy;
+    A.huber_a = (double) sqrtf(chi2_th);  // :135 std::sqrt(float)
+    A.chi2_th = (double) chi2_th;
+    A.use_robust = use_robust;
+    A.apply_l2 = apply_l2_after_robust;
+    A.max_iters = max_iters;
+    A.ftol = 1.e-3;  // :186
+    // scratch: pose_in(7) | out | chi2(n) | active(n) | depth(n) | bad(n)
+    size_t off_out = 64, off_chi2 = off_out + ((sizeof(PnpOut) + 63) / 64) * 64;
+    size_t off_act = off_chi2 + (size_t) n * 8, off_dep = off_act + (size_t) n, off_bad = off_dep + (size_t) n;
+    uint8_t *base = nullptr;
+    int rc = alva_ctx_scratch(ctx, 3, off_bad + (size_t) n, (void **) &base);
+    if (rc) return rc;
+    ALVA_HIP(hipMemcpyAsync(base, h_pose7, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, (const double *) base, base + off_act, (double *) (base + off_chi2),
+                       base + off_dep, base + off_bad, (PnpOut *) (base + off_out));
+    ALVA_LAUNCH_CHECK();
+    PnpOut res;
+    std::vector<uint8_t> bad((size_t) n);
+    ALVA_HIP(hipMemcpyAsync(&res, base + off_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    ALVA_HIP(hipMemcpyAsync(bad.data(), base + off_bad, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    int no = 0;
+    for (int i = 0; i < n; i++)
+        if (bad[(size_t) i]) h_outliers[no++] = i;
+    *h_n_outliers = no;
+    if (h_info) memcpy(h_info, res.info, sizeof(res.info));
+    if (no == n) return ALVA_OK;
+    memcpy(h_pose7, res.pose, sizeof(res.pose));
+    *h_ok = res.ok;
+    return ALVA_OK;
+}

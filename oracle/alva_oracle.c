@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* cv::borderInterpolate(BORDER_REFLECT_101): src/libs/opencv/modules/core/src/copy.cpp */
@@ -1160,4 +1161,319 @@ int orc_pnp_refine(const double *uv, const double *wpt, int n, double *pose7, in
     free(P.chi2);
     free(P.depth);
     return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a10-a13 -- the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262) on a flat problem:
+ * LM + Huber, SPARSE_SCHUR == Schur complement on the point blocks
+ * (ceres schur_eliminator_impl.h:177-375: S = F'F + D_f^2 - sum_p (F'E)(E'E + D_e^2)^-1 (E'F); back-substitution
+ * :330-375), cost functions ReprojectionErrorKSE3AnchInvDepth / ...KSE3XYZ
+ * (src/slam/src/ceres_parametrization.cpp:157-268 / :6-94).  Constant blocks (calibration, constant
+ * keyframes) are not part of the reduced program (ceres program.cc RemoveFixedBlocks). */
+typedef struct {
+    int nKf, nPt, nObs, invDepth, pdim;
+    const uint8_t *kfConst;
+    const double *calib;
+    const int *ancKf;
+    const double *ancUv;
+    const int *obsKf, *obsPt;
+    const double *obsUv;
+    double huber_a;
+    int nc;      /* free keyframes */
+    int *cidx;   /* kf -> free index or -1 */
+    double *chi2;
+    uint8_t *depth;
+    /* normal equations (unscaled) */
+    double *Hcc, *gc;     /* (6nc)^2, 6nc */
+    double *Hpp, *gp;     /* nPt*pdim*pdim, nPt*pdim */
+    double *W;            /* nPt * nc * 6 * pdim : W[p][c] = sum F^T E */
+} ba_prob;
+
+static void ba_accum_block(ba_prob *B, int p, const double *Jc[2], const int cids[2], const double *Je, const double r[2]) {
+    int dp = B->pdim, n6 = 6 * B->nc;
+    for (int a = 0; a < dp; a++) {
+        B->gp[p * dp + a] += Je[a] * r[0] + Je[dp + a] * r[1];
+        for (int b = 0; b < dp; b++) B->Hpp[(p * dp + a) * dp + b] += Je[a] * Je[b] + Je[dp + a] * Je[dp + b];
+    }
+    for (int s = 0; s < 2; s++) {
+        if (cids[s] < 0) continue;
+        const double *J = Jc[s];
+        int c = cids[s];
+        for (int a = 0; a < 6; a++) {
+            B->gc[6 * c + a] += J[a] * r[0] + J[6 + a] * r[1];
+            for (int b = 0; b < dp; b++) B->W[(((size_t) p * B->nc + c) * 6 + a) * dp + b] += J[a] * Je[b] + J[6 + a] * Je[dp + b];
+        }
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (cids[s2] < 0) continue;
+            const double *J2 = Jc[s2];
+            int c2 = cids[s2];
+            for (int a = 0; a < 6; a++)
+                for (int b = 0; b < 6; b++) B->Hcc[(size_t) (6 * c + a) * n6 + 6 * c2 + b] += J[a] * J2[b] + J[6 + a] * J2[6 + b];
+        }
+    }
+}
+
+static double ba_eval(ba_prob *B, const double *poses, const double *pts, int wantJ) {
+    int dp = B->pdim, n6 = 6 * B->nc;
+    if (wantJ) {
+        memset(B->Hcc, 0, sizeof(double) * (size_t) n6 * n6);
+        memset(B->gc, 0, sizeof(double) * (size_t) n6);
+        memset(B->Hpp, 0, sizeof(double) * (size_t) B->nPt * dp * dp);
+        memset(B->gp, 0, sizeof(double) * (size_t) B->nPt * dp);
+        memset(B->W, 0, sizeof(double) * (size_t) B->nPt * B->nc * 6 * dp);
+    }
+    orc_se3 *T = (orc_se3 *) malloc(sizeof(orc_se3) * (size_t) B->nKf);
+    for (int k = 0; k < B->nKf; k++) se3_from_pose7(poses + 7 * k, &T[k]);
+    const double *K = B->calib;
+    double cost = 0;
+    for (int o = 0; o < B->nObs; o++) {
+        int k = B->obsKf[o], p = B->obsPt[o];
+        double X[3], r[2], JR[6], chi2, dJl[3] = {0, 0, 0};
+        int dpz, a = -1;
+        if (B->invDepth) {
+            a = B->ancKf[p];
+            double zanch = 1.0 / pts[p];
+            /* anchpt = zanch * K^-1 * (ua, va, 1) */
+            double ap[3] = {zanch * ((B->ancUv[2 * p] - K[2]) / K[0]), zanch * ((B->ancUv[2 * p + 1] - K[3]) / K[1]), zanch};
+            double Ra[3];
+            m3v(T[a].R, ap, Ra);
+            X[0] = Ra[0] + T[a].t[0]; X[1] = Ra[1] + T[a].t[1]; X[2] = Ra[2] + T[a].t[2];
+            dJl[0] = -zanch * Ra[0]; dJl[1] = -zanch * Ra[1]; dJl[2] = -zanch * Ra[2]; /* J_lambda, :262 */
+        } else {
+            memcpy(X, pts + 3 * p, 24);
+        }
+        reproj(&T[k], K, X, B->obsUv + 2 * o, r, wantJ ? JR : NULL, &chi2, &dpz);
+        B->chi2[o] = chi2;
+        B->depth[o] = (uint8_t) dpz;
+        double rho0, rho1;
+        huber(chi2, B->huber_a, 1, &rho0, &rho1);
+        cost += 0.5 * rho0;
+        if (!wantJ) continue;
+        double s = sqrt(rho1), JH[6], Jobs[12], Janc[12], Je[6], rs[2] = {r[0] * s, r[1] * s};
+        times_hat(JR, X, JH);
+        for (int rr = 0; rr < 2; rr++)
+            for (int c = 0; c < 3; c++) {
+                Jobs[6 * rr + c] = -JR[3 * rr + c] * s;
+                Jobs[6 * rr + 3 + c] = JH[3 * rr + c] * s;
+                Janc[6 * rr + c] = JR[3 * rr + c] * s;
+                Janc[6 * rr + 3 + c] = -JH[3 * rr + c] * s;
+            }
+        if (B->invDepth) {
+            Je[0] = (JR[0] * dJl[0] + JR[1] * dJl[1] + JR[2] * dJl[2]) * s;
+            Je[1] = (JR[3] * dJl[0] + JR[4] * dJl[1] + JR[5] * dJl[2]) * s;
+        } else {
+            for (int rr = 0; rr < 2; rr++)
+                for (int c = 0; c < 3; c++) Je[3 * rr + c] = JR[3 * rr + c] * s;
+        }
+        const double *Jc[2] = {Jobs, Janc};
+        int cids[2] = {B->cidx[k], (B->invDepth ? B->cidx[a] : -1)};
+        ba_accum_block(B, p, Jc, cids, Je, rs);
+    }
+    free(T);
+    return cost;
+}
+
+int orc_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *calib, int invDepth, int nPt, const int *ptAnchorKf,
+                 const double *ptAnchorUv, double *ptParam, int nObs, const int *obsKf, const int *obsPt, const double *obsUv,
+                 int maxIterations, double functionTolerance, double huberChi2, double *chi2, uint8_t *depthPos, double *info) {
+    ba_prob B;
+    memset(&B, 0, sizeof(B));
+    B.nKf = nKf; B.nPt = nPt; B.nObs = nObs; B.invDepth = invDepth; B.pdim = invDepth ? 1 : 3;
+    B.kfConst = kfConst; B.calib = calib; B.ancKf = ptAnchorKf; B.ancUv = ptAnchorUv;
+    B.obsKf = obsKf; B.obsPt = obsPt; B.obsUv = obsUv;
+    B.huber_a = (double) sqrtf((float) huberChi2); /* optimizer.cpp:22: std::sqrt(float) */
+    B.chi2 = chi2; B.depth = depthPos;
+    B.cidx = (int *) malloc(sizeof(int) * (size_t) nKf);
+    for (int k = 0; k < nKf; k++) B.cidx[k] = kfConst[k] ? -1 : B.nc++;
+    int dp = B.pdim, nc = B.nc, n6 = 6 * nc, np = nPt * dp;
+    B.Hcc = (double *) malloc(sizeof(double) * (size_t) (n6 * n6 + 1));
+    B.gc = (double *) malloc(sizeof(double) * (size_t) (n6 + 1));
+    B.Hpp = (double *) malloc(sizeof(double) * (size_t) (np * dp + 1));
+    B.gp = (double *) malloc(sizeof(double) * (size_t) (np + 1));
+    B.W = (double *) malloc(sizeof(double) * ((size_t) nPt * nc * 6 * dp + 1));
+    double *x_p = (double *) malloc(sizeof(double) * 7 * (size_t) nKf), *c_p = (double *) malloc(sizeof(double) * 7 * (size_t) nKf);
+    double *x_t = (double *) malloc(sizeof(double) * (size_t) (np + 1)), *c_t = (double *) malloc(sizeof(double) * (size_t) (np + 1));
+    for (int k = 0; k < nKf; k++) { /* PoseParametersBlock(id, SE3d): unit quaternion */
+        orc_se3 T;
+        se3_from_pose7(poses + 7 * k, &T);
+        memcpy(x_p + 7 * k, T.t, 24);
+        memcpy(x_p + 7 * k + 3, T.q, 32);
+    }
+    memcpy(x_t, ptParam, sizeof(double) * (size_t) np);
+    double *sc = (double *) malloc(sizeof(double) * (size_t) (n6 + 1)), *sp = (double *) malloc(sizeof(double) * (size_t) (np + 1));
+    double *dc = (double *) malloc(sizeof(double) * (size_t) (n6 + 1)), *dpd = (double *) malloc(sizeof(double) * (size_t) (np + 1));
+    double *S = (double *) malloc(sizeof(double) * (size_t) (n6 * n6 + 1)), *rhs = (double *) malloc(sizeof(double) * (size_t) (n6 + 1));
+    double *yp = (double *) malloc(sizeof(double) * (size_t) (np + 1)), *Hinv = (double *) malloc(sizeof(double) * (size_t) (np * dp + 1));
+    orc_lm lm = {1e4, 2.0, 0};
+    double x_cost = ba_eval(&B, x_p, x_t, 1), initial = x_cost, x_norm = -1;
+    for (int i = 0; i < n6; i++) sc[i] = 1.0 / (1.0 + sqrt(B.Hcc[(size_t) i * n6 + i]));
+    for (int p = 0; p < nPt; p++)
+        for (int a = 0; a < dp; a++) sp[p * dp + a] = 1.0 / (1.0 + sqrt(B.Hpp[(p * dp + a) * dp + a]));
+    double gmax = 0;
+    for (int i = 0; i < n6; i++) gmax = fmax(gmax, fabs(B.gc[i]));
+    for (int i = 0; i < np; i++) gmax = fmax(gmax, fabs(B.gp[i]));
+    int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1, ok = 1;
+    while (1) {
+        if (iteration >= maxIterations || gmax <= 1e-10 || lm.radius <= 1e-32) break;
+        iteration++;
+        if (!lm.reuse_diagonal) {
+            for (int i = 0; i < n6; i++) dc[i] = fmin(fmax(B.Hcc[(size_t) i * n6 + i] * sc[i] * sc[i], 1e-6), 1e32);
+            for (int p = 0; p < nPt; p++)
+                for (int a = 0; a < dp; a++) dpd[p * dp + a] = fmin(fmax(B.Hpp[(p * dp + a) * dp + a] * sp[p * dp + a] * sp[p * dp + a], 1e-6), 1e32);
+        }
+        lm.reuse_diagonal = 1;
+        /* scaled Schur complement */
+        for (int i = 0; i < n6; i++) {
+            rhs[i] = B.gc[i] * sc[i];
+            for (int j = 0; j < n6; j++) S[(size_t) i * n6 + j] = B.Hcc[(size_t) i * n6 + j] * sc[i] * sc[j];
+            S[(size_t) i * n6 + i] += dc[i] / lm.radius;
+        }
+        int okstep = 1;
+        for (int p = 0; p < nPt && okstep; p++) {
+            double M[9], Mi[9];
+            for (int a = 0; a < dp; a++)
+                for (int b = 0; b < dp; b++)
+                    M[a * dp + b] = B.Hpp[(p * dp + a) * dp + b] * sp[p * dp + a] * sp[p * dp + b] + (a == b ? dpd[p * dp + a] / lm.radius : 0.0);
+            if (dp == 1) Mi[0] = 1.0 / M[0];
+            else { /* 3x3 SPD inverse via Cholesky solves of the identity */
+                for (int c = 0; c < 3; c++) {
+                    double A3[9], e[3] = {c == 0, c == 1, c == 2};
+                    memcpy(A3, M, sizeof(A3));
+                    if (!chol_solve(A3, e, 3)) { okstep = 0; break; }
+                    for (int rr = 0; rr < 3; rr++) Mi[rr * 3 + c] = e[rr];
+                }
+            }
+            memcpy(Hinv + (size_t) p * dp * dp, Mi, sizeof(double) * (size_t) dp * dp);
+            /* t = Hinv * gp_s ; for each cam pair accumulate */
+            double tg[3] = {0, 0, 0};
+            for (int a = 0; a < dp; a++)
+                for (int b = 0; b < dp; b++) tg[a] += Mi[a * dp + b] * B.gp[p * dp + b] * sp[p * dp + b];
+            for (int c = 0; c < nc; c++) {
+                const double *Wc = B.W + (((size_t) p * nc + c) * 6) * dp;
+                int nz = 0;
+                for (int i = 0; i < 6 * dp; i++) nz |= (Wc[i] != 0);
+                if (!nz) continue;
+                double WH[18]; /* (W_s Hinv) 6 x dp */
+                for (int a = 0; a < 6; a++)
+                    for (int b = 0; b < dp; b++) {
+                        double v = 0;
+                        for (int m = 0; m < dp; m++) v += Wc[a * dp + m] * sc[6 * c + a] * sp[p * dp + m] * Mi[m * dp + b];
+                        WH[a * dp + b] = v;
+                    }
+                for (int a = 0; a < 6; a++) {
+                    double v = 0;
+                    for (int b = 0; b < dp; b++) v += Wc[a * dp + b] * sc[6 * c + a] * sp[p * dp + b] * tg[b];
+                    rhs[6 * c + a] -= v;
+                }
+                for (int c2 = 0; c2 < nc; c2++) {
+                    const double *W2 = B.W + (((size_t) p * nc + c2) * 6) * dp;
+                    int nz2 = 0;
+                    for (int i = 0; i < 6 * dp; i++) nz2 |= (W2[i] != 0);
+                    if (!nz2) continue;
+                    for (int a = 0; a < 6; a++)
+                        for (int b = 0; b < 6; b++) {
+                            double v = 0;
+                            for (int m = 0; m < dp; m++) v += WH[a * dp + m] * W2[b * dp + m] * sc[6 * c2 + b] * sp[p * dp + m];
+                            S[(size_t) (6 * c + a) * n6 + 6 * c2 + b] -= v;
+                        }
+                }
+            }
+        }
+        if (okstep && n6 > 0) okstep = chol_solve(S, rhs, n6); /* rhs <- y_c */
+        double mcc = 0;
+        if (okstep) {
+            /* back-substitute y_p = Hinv (gp_s - W_s^T y_c); then step = -y, model cost change */
+            double sg = 0, sHs = 0;
+            for (int p = 0; p < nPt; p++) {
+                double t[3];
+                for (int a = 0; a < dp; a++) {
+                    double v = B.gp[p * dp + a] * sp[p * dp + a];
+                    for (int c = 0; c < nc; c++) {
+                        const double *Wc = B.W + (((size_t) p * nc + c) * 6) * dp;
+                        for (int i = 0; i < 6; i++) v -= Wc[i * dp + a] * sc[6 * c + i] * sp[p * dp + a] * rhs[6 * c + i];
+                    }
+                    t[a] = v;
+                }
+                for (int a = 0; a < dp; a++) {
+                    double v = 0;
+                    for (int b = 0; b < dp; b++) v += Hinv[(size_t) p * dp * dp + a * dp + b] * t[b];
+                    yp[p * dp + a] = v;
+                }
+            }
+            for (int i = 0; i < n6; i++) sg += -rhs[i] * B.gc[i] * sc[i];
+            for (int i = 0; i < np; i++) sg += -yp[i] * B.gp[i] * sp[i];
+            for (int i = 0; i < n6; i++)
+                for (int j = 0; j < n6; j++) sHs += rhs[i] * B.Hcc[(size_t) i * n6 + j] * sc[i] * sc[j] * rhs[j];
+            for (int p = 0; p < nPt; p++) {
+                for (int a = 0; a < dp; a++)
+                    for (int b = 0; b < dp; b++) sHs += yp[p * dp + a] * B.Hpp[(p * dp + a) * dp + b] * sp[p * dp + a] * sp[p * dp + b] * yp[p * dp + b];
+                for (int c = 0; c < nc; c++) {
+                    const double *Wc = B.W + (((size_t) p * nc + c) * 6) * dp;
+                    for (int i = 0; i < 6; i++)
+                        for (int a = 0; a < dp; a++) sHs += 2 * rhs[6 * c + i] * Wc[i * dp + a] * sc[6 * c + i] * sp[p * dp + a] * yp[p * dp + a];
+                }
+            }
+            mcc = -sg - 0.5 * sHs;
+        }
+        if (!okstep || !(mcc > 0)) {
+            if (++invalid >= 5) { ok = 0; break; }
+            lm.radius /= lm.decrease_factor;
+            lm.decrease_factor *= 2;
+            nsummaries++;
+            continue;
+        }
+        invalid = 0;
+        double sn = 0;
+        memcpy(c_p, x_p, sizeof(double) * 7 * (size_t) nKf);
+        for (int k = 0; k < nKf; k++) {
+            int c = B.cidx[k];
+            if (c < 0) continue;
+            double d6[6];
+            for (int i = 0; i < 6; i++) d6[i] = -rhs[6 * c + i] * sc[6 * c + i];
+            se3_plus(x_p + 7 * k, d6, c_p + 7 * k);
+            for (int i = 0; i < 7; i++) sn += (x_p[7 * k + i] - c_p[7 * k + i]) * (x_p[7 * k + i] - c_p[7 * k + i]);
+        }
+        for (int i = 0; i < np; i++) {
+            c_t[i] = x_t[i] + (-yp[i] * sp[i]);
+            sn += (x_t[i] - c_t[i]) * (x_t[i] - c_t[i]);
+        }
+        double cand_cost = ba_eval(&B, c_p, c_t, 0);
+        if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) break;
+        if (fabs(x_cost - cand_cost) <= functionTolerance * x_cost) break;
+        double rel = (x_cost - cand_cost) / mcc;
+        if (getenv("ALVA_ORC_VERBOSE")) fprintf(stderr, "ba it %d x_cost %.9e cand %.9e mcc %.6e rel %.4f radius %.3e\n", iteration, x_cost, cand_cost, mcc, rel, lm.radius);
+        if (rel > 1e-3) {
+            memcpy(x_p, c_p, sizeof(double) * 7 * (size_t) nKf);
+            memcpy(x_t, c_t, sizeof(double) * (size_t) np);
+            x_norm = 0;
+            for (int k = 0; k < nKf; k++)
+                if (B.cidx[k] >= 0)
+                    for (int i = 0; i < 7; i++) x_norm += x_p[7 * k + i] * x_p[7 * k + i];
+            for (int i = 0; i < np; i++) x_norm += x_t[i] * x_t[i];
+            x_norm = sqrt(x_norm);
+            x_cost = ba_eval(&B, x_p, x_t, 1);
+            gmax = 0;
+            for (int i = 0; i < n6; i++) gmax = fmax(gmax, fabs(B.gc[i]));
+            for (int i = 0; i < np; i++) gmax = fmax(gmax, fabs(B.gp[i]));
+            lm.radius = lm.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+            lm.radius = fmin(1e16, lm.radius);
+            lm.decrease_factor = 2.0;
+            lm.reuse_diagonal = 0;
+            nsucc++;
+        } else {
+            lm.radius /= lm.decrease_factor;
+            lm.decrease_factor *= 2;
+            lm.reuse_diagonal = 1;
+        }
+        nsummaries++;
+    }
+    for (int k = 0; k < nKf; k++)
+        if (B.cidx[k] >= 0) memcpy(poses + 7 * k, x_p + 7 * k, 56);
+    memcpy(ptParam, x_t, sizeof(double) * (size_t) np);
+    if (info) {
+        info[0] = nsummaries; info[1] = initial; info[2] = x_cost; info[3] = nsucc;
+    }
+    free(B.cidx); free(B.Hcc); free(B.gc); free(B.Hpp); free(B.gp); free(B.W); free(x_p); free(c_p); free(x_t); free(c_t);
+    free(sc); free(sp); free(dc); free(dpd); free(S); free(rhs); free(yp); free(Hinv);
+    return ok;
 }

@@ -40,6 +40,11 @@ int orc_p3p_draw_samples(int n, int count, uint32_t seed, int *samples /* count*
 int orc_pnp_refine(const double *uv, const double *wpt, int n, double *pose7, int maxIterations, float chi2th, int useRobust,
                    int applyL2AfterRobust, float fx, float fy, float cx, float cy, int *outliers, int *nOutliers, double *info /*[8]*/);
 
+/* a10-a13 (same flat description as ref_local_ba in ref_shim.cpp / alva_local_ba in include/alvaar_hip.h) */
+int orc_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *calib, int invDepth, int nPt, const int *ptAnchorKf,
+                 const double *ptAnchorUv, double *ptParam, int nObs, const int *obsKf, const int *obsPt, const double *obsUv,
+                 int maxIterations, double functionTolerance, double huberChi2, double *chi2, uint8_t *depthPos, double *info /*[9]*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,27 @@ class Orc:
     _pnp = "orc_pnp_refine"
 
     @classmethod
+    def local_ba(cls, pb, max_iters=5, ftol=0.0, huber_chi2=5.9915, inv_depth=True):
+        """pb: dict from synth.make_ba_problem (or make_ba_problem_xyz).  Returns dict(poses, pts, chi2, depth, info, ok)."""
+        poses = np.ascontiguousarray(pb["poses"], np.float64).copy()
+        kfc = np.ascontiguousarray(pb["kf_const"], np.uint8)
+        calib = np.ascontiguousarray(pb["calib"], np.float64)
+        akf = np.ascontiguousarray(pb["anchor_kf"], np.int32)
+        auv = np.ascontiguousarray(pb["anchor_uv"], np.float64)
+        pts = np.ascontiguousarray(pb["inv_depth"] if inv_depth else pb["pts_xyz"], np.float64).copy()
+        okf = np.ascontiguousarray(pb["obs_kf"], np.int32)
+        opt = np.ascontiguousarray(pb["obs_pt"], np.int32)
+        ouv = np.ascontiguousarray(pb["obs_uv"], np.float64)
+        nobs = len(okf)
+        chi2 = np.zeros(nobs)
+        depth = np.zeros(nobs, np.uint8)
+        info = np.zeros(9)
+        fn = getattr(cls._lib(), cls._pfx + "local_ba")
+        ok = fn(len(poses), _p(poses), _p(kfc), _p(calib), int(inv_depth), len(akf), _p(akf), _p(auv), _p(pts), nobs, _p(okf), _p(opt),
+                _p(ouv), max_iters, _d(ftol), _d(huber_chi2), _p(chi2), _p(depth), _p(info))
+        return dict(ok=bool(ok), poses=poses, pts=pts, chi2=chi2, depth=depth, info=info)
+
+    @classmethod
     def pnp_refine(cls, uv, wpt, pose7, K, max_iters=5, chi2th=5.9915, robust=True, l2=True):
         uv = np.ascontiguousarray(uv, np.float64)
         wpt = np.ascontiguousarray(wpt, np.float64)
@@ -177,6 +198,27 @@ class Ref:
     """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
     _pfx = "ref_"
     _pnp = "ref_ceres_pnp_nocap"
+
+    @classmethod
+    def local_ba(cls, pb, max_iters=5, ftol=0.0, huber_chi2=5.9915, inv_depth=True):
+        """pb: dict from synth.make_ba_problem (or make_ba_problem_xyz).  Returns dict(poses, pts, chi2, depth, info, ok)."""
+        poses = np.ascontiguousarray(pb["poses"], np.float64).copy()
+        kfc = np.ascontiguousarray(pb["kf_const"], np.uint8)
+        calib = np.ascontiguousarray(pb["calib"], np.float64)
+        akf = np.ascontiguousarray(pb["anchor_kf"], np.int32)
+        auv = np.ascontiguousarray(pb["anchor_uv"], np.float64)
+        pts = np.ascontiguousarray(pb["inv_depth"] if inv_depth else pb["pts_xyz"], np.float64).copy()
+        okf = np.ascontiguousarray(pb["obs_kf"], np.int32)
+        opt = np.ascontiguousarray(pb["obs_pt"], np.int32)
+        ouv = np.ascontiguousarray(pb["obs_uv"], np.float64)
+        nobs = len(okf)
+        chi2 = np.zeros(nobs)
+        depth = np.zeros(nobs, np.uint8)
+        info = np.zeros(9)
+        fn = getattr(cls._lib(), cls._pfx + "local_ba")
+        ok = fn(len(poses), _p(poses), _p(kfc), _p(calib), int(inv_depth), len(akf), _p(akf), _p(auv), _p(pts), nobs, _p(okf), _p(opt),
+                _p(ouv), max_iters, _d(ftol), _d(huber_chi2), _p(chi2), _p(depth), _p(info))
+        return dict(ok=bool(ok), poses=poses, pts=pts, chi2=chi2, depth=depth, info=info)
 
     @classmethod
     def pnp_refine(cls, uv, wpt, pose7, K, max_iters=5, chi2th=5.9915, robust=True, l2=True):

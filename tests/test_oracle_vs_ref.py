@@ -127,3 +127,23 @@ def test_pnp_refine(n, seed, outl, noise):
     assert np.allclose(i1[[1, 2, 5, 6]], i2[[1, 2, 5, 6]], rtol=1e-9)  # initial / final costs
     assert np.abs(p1 - p2).max() < 1e-9
     assert np.abs(p2[:3] - pb["pose_gt"][:3]).max() < 0.05
+
+
+def ba_compare(a, b, pose_tol=1e-8, pt_tol=1e-7):
+    assert a["ok"] == b["ok"]
+    assert a["info"][0] == b["info"][0] and a["info"][3] == b["info"][3], (a["info"], b["info"])
+    assert np.allclose(a["info"][1:3], b["info"][1:3], rtol=1e-8), (a["info"], b["info"])
+    assert np.abs(a["poses"] - b["poses"]).max() < pose_tol
+    assert np.abs(a["pts"] - b["pts"]).max() < pt_tol
+    assert np.array_equal(a["depth"], b["depth"])
+    assert np.allclose(a["chi2"], b["chi2"], rtol=1e-6, atol=1e-8)
+    assert np.array_equal(a["chi2"] > 5.9915, b["chi2"] > 5.9915)
+
+
+@pytest.mark.parametrize("nkf,npt,seed,iters,ftol", [(6, 200, 1, 5, 0.0), (20, 600, 42, 5, 0.0), (8, 300, 2, 5, 1e-3), (5, 80, 3, 2, 0.0)])
+def test_local_ba_invdepth(nkf, npt, seed, iters, ftol):
+    pb = synth.make_ba_problem(nkf, npt, seed)
+    a = Orc.local_ba(pb, iters, ftol)
+    b = Ref.local_ba(pb, iters, ftol)
+    ba_compare(a, b)
+    assert b["info"][2] < 0.2 * b["info"][1]
