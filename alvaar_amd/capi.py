@@ -58,6 +58,7 @@ _sig("alva_fbklt_track", [_vp, _vp, _vp, _i, _f, _f, _i, _f, _vp, _vp, _vp, _i])
 _sig("alva_p3p_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
 _sig("alva_p3p_lmeds", [_vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _f, _f, _vp, _vp, _vp, _vp, _vp])
 _sig("alva_pnp_refine", [_vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
+_sig("alva_local_ba", [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -154,6 +155,30 @@ class Context:
         check(lib.alva_pnp_refine(self.h, _ptr(uv), _ptr(wpts), n, pose.ctypes.data, max_iters, chi2th, int(robust), int(l2),
                                   K[0], K[1], K[2], K[3], out.ctypes.data, C.byref(nout), info.ctypes.data, C.byref(ok)))
         return bool(ok.value), pose, out[:nout.value].copy(), info
+
+    # a10-a13
+    def local_ba(self, pb, max_iters=5, ftol=0.0, huber_chi2=5.9915, inv_depth=True):
+        """The solve of Optimizer::localBA on a flat problem dict (see synth.make_ba_problem)."""
+        import numpy as np
+        poses = np.ascontiguousarray(pb["poses"], np.float64).copy()
+        kfc = np.ascontiguousarray(pb["kf_const"], np.uint8)
+        calib = np.ascontiguousarray(pb["calib"], np.float64)
+        akf = np.ascontiguousarray(pb["anchor_kf"], np.int32)
+        auv = np.ascontiguousarray(pb["anchor_uv"], np.float64)
+        pts = np.ascontiguousarray(pb["inv_depth"] if inv_depth else pb["pts_xyz"], np.float64).copy()
+        okf = np.ascontiguousarray(pb["obs_kf"], np.int32)
+        opt = np.ascontiguousarray(pb["obs_pt"], np.int32)
+        ouv = np.ascontiguousarray(pb["obs_uv"], np.float64)
+        nobs = len(okf)
+        chi2 = np.zeros(max(nobs, 1))
+        depth = np.zeros(max(nobs, 1), np.uint8)
+        info = np.zeros(9)
+        ok = C.c_int(0)
+        check(lib.alva_local_ba(self.h, len(poses), poses.ctypes.data, kfc.ctypes.data, calib.ctypes.data, int(inv_depth), len(akf),
+                                akf.ctypes.data, auv.ctypes.data, pts.ctypes.data, nobs, okf.ctypes.data, opt.ctypes.data,
+                                ouv.ctypes.data, max_iters, ftol, huber_chi2, chi2.ctypes.data, depth.ctypes.data, info.ctypes.data,
+                                C.byref(ok)))
+        return dict(ok=bool(ok.value), poses=poses, pts=pts, chi2=chi2[:nobs], depth=depth[:nobs], info=info)
 
     # a6
     def orb_blur(self, gray):

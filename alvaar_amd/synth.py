@@ -199,6 +199,13 @@ def make_ba_problem(n_kf: int = 20, n_pt: int = 3000, seed: int = 42, fx: float 
     remap[used] = np.arange(int(used.sum()), dtype=np.int32)
     kf_const = np.zeros(n_kf, np.uint8)
     kf_const[:n_fixed] = 1
+    akf, auv, rho = anchor_kf[used].copy(), anchor_uv[used].copy(), inv_depth[used].copy()
+    # XYZ parameterisation of the same (noisy) initial points: X = T_w,anchor * (K^-1 [u,v,1] / rho)
+    pts_xyz = np.empty((len(rho), 3))
+    for i in range(len(rho)):
+        pa = np.array([(auv[i, 0] - cx) / fx, (auv[i, 1] - cy) / fy, 1.0]) / rho[i]
+        Ra = quat_xyzw_to_rot(poses[akf[i], 3:])
+        pts_xyz[i] = Ra @ pa + poses[akf[i], :3]
     return dict(poses=poses, poses_gt=poses_gt, kf_const=kf_const, calib=K,
-                anchor_kf=anchor_kf[used].copy(), anchor_uv=anchor_uv[used].copy(), inv_depth=inv_depth[used].copy(),
+                anchor_kf=akf, anchor_uv=auv, inv_depth=rho, pts_xyz=pts_xyz,
                 pts_gt=pts[used].copy(), obs_kf=obs_kf, obs_pt=remap[obs_pt].copy(), obs_uv=obs_uv)

@@ -147,3 +147,22 @@ def test_local_ba_invdepth(nkf, npt, seed, iters, ftol):
     b = Ref.local_ba(pb, iters, ftol)
     ba_compare(a, b)
     assert b["info"][2] < 0.2 * b["info"][1]
+
+
+def xyz_problem(nkf, npt, seed):
+    """XYZ mode has a residual for EVERY observation (no anchor): add the anchor observations back."""
+    pb = synth.make_ba_problem(nkf, npt, seed)
+    n = len(pb["anchor_kf"])
+    pb = dict(pb)
+    pb["obs_kf"] = np.concatenate([pb["anchor_kf"], pb["obs_kf"]]).astype(np.int32)
+    pb["obs_pt"] = np.concatenate([np.arange(n, dtype=np.int32), pb["obs_pt"]]).astype(np.int32)
+    pb["obs_uv"] = np.concatenate([pb["anchor_uv"], pb["obs_uv"]])
+    return pb
+
+
+@pytest.mark.parametrize("nkf,npt,seed", [(6, 150, 5), (12, 400, 6)])
+def test_local_ba_xyz(nkf, npt, seed):
+    pb = xyz_problem(nkf, npt, seed)
+    a = Orc.local_ba(pb, 5, 0.0, inv_depth=False)
+    b = Ref.local_ba(pb, 5, 0.0, inv_depth=False)
+    ba_compare(a, b, pt_tol=1e-6)
