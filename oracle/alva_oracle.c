@@ -1477,3 +1477,323 @@ int orc_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *c
     free(sc); free(sp); free(dc); free(dpd); free(S); free(rhs); free(yp); free(Hinv);
     return ok;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * a5 -- FeatureExtractor::detectFeaturePoints (src/slam/src/feature_extractor.cpp:11-158): the reference's
+ * per-grid-cell Shi-Tomasi detector.  Cells are visited in row-major order and share one float mask, so the
+ * visiting order is part of the semantics. */
+
+/* cv::circle(mask, c, r, 0, FILLED): imgproc/src/drawing.cpp:1477-1617 (Circle(), fill) -- half-width of the
+ * filled midpoint circle per |dy| */
+static void circle_halfwidths(int radius, int *hw /* [radius+1] */) {
+    for (int i = 0; i <= radius; i++) hw[i] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > hw[dy]) hw[dy] = dx;
+        if (dy > hw[dx]) hw[dx] = dy;
+        dy++;
+        err += plus;
+        plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+static void draw_zero_circle(uint8_t *mask, int w, int h, int cx, int cy, int radius, const int *hw) {
+    for (int dy = -radius; dy <= radius; dy++) {
+        int y = cy + dy, half = hw[dy < 0 ? -dy : dy];
+        if (y < 0 || y >= h || half < 0) continue;
+        int x0 = cx - half, x1 = cx + half;
+        if (x0 < 0) x0 = 0;
+        if (x1 > w - 1) x1 = w - 1;
+        for (int x = x0; x <= x1; x++) mask[(size_t) y * w + x] = 0;
+    }
+}
+
+static float cov_at(const float *dx, const float *dy, int cell, int y, int x, int ch) {
+    volatile float fx = dx[y * cell + x], fy = dy[y * cell + x];
+    volatile float v = ch == 0 ? fx * fx : (ch == 1 ? fx * fy : fy * fy);
+    return v;
+}
+
+/* One cell: GaussianBlur(image(roi), 3x3, sigma 0) -- integer sum [1 2 1;2 4 2;1 2 1] p / 16 (rounding: see the column pass note)
+ * reading real neighbours, REFLECT_101 only at the image border (imgproc/src/smooth.dispatch.cpp:654,754;
+ * filter.dispatch.cpp:336-363) -- then cornerMinEigenVal(block 3, Sobel 3) on the STAND-ALONE blurred cell
+ * (imgproc/src/corner.cpp:237-316): scale s = (float)(1/3060);
+ *   Dx: row (c - a), column (r0 + r2)*s + r1*(2s)        (deriv.cpp:427-439; filter.simd.hpp:2806-2911)
+ *   Dy: row s*a + 2s*b + s*c (left to right), column r2 - r0   (filter.simd.hpp:2446-2488, :2915-2937)
+ *   cov = (dx*dx, dx*dy, dy*dy); 3x3 box sum accumulated in double, cast to float once (box_filter.simd.hpp);
+ *   lambda = (a/2 + c/2) - sqrt((a/2 - c/2)^2 + b*b)       (corner.cpp:52-102)          all REFLECT_101 at the cell edge. */
+void orc_cell_mineig(const uint8_t *gray, int w, int h, int x0, int y0, int cell, uint8_t *blurOut, float *eig) {
+    uint8_t *B = (uint8_t *) malloc((size_t) cell * cell);
+    float *dx = (float *) malloc(sizeof(float) * (size_t) cell * cell), *dy = (float *) malloc(sizeof(float) * (size_t) cell * cell);
+    for (int y = 0; y < cell; y++)
+        for (int x = 0; x < cell; x++) {
+            static const int k3[3] = {1, 2, 1};
+            int acc = 0;
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++)
+                    acc += k3[j + 1] * k3[i + 1] * gray[(size_t) reflect101(y0 + y + j, h) * w + reflect101(x0 + x + i, w)];
+            /* column pass: the vector part (SymmColumnVec_32s8u, filter.simd.hpp:1010-1099) evaluates acc/16 exactly in
+             * float and rounds HALF-TO-EVEN (v_round); the scalar tail x >= (cell & ~3) uses FixedPtCastEx = (v + 2^15) >> 16,
+             * i.e. half-up.  (128-bit universal intrinsics: chunks of 16, then 8, then 4 columns.) */
+            int q = acc >> 4, rem = acc & 15, v;
+            if (x < (cell & ~3)) v = rem > 8 ? q + 1 : (rem < 8 ? q : (q + (q & 1)));
+            else v = (acc + 8) >> 4;
+            B[y * cell + x] = (uint8_t) (v > 255 ? 255 : v);
+        }
+    const float s = (float) (1.0 / (4.0 * 3.0 * 255.0));
+    volatile float s2 = 2.0f * s;
+#define BP(yy, xx) ((float) B[reflect101(yy, cell) * cell + reflect101(xx, cell)])
+    for (int y = 0; y < cell; y++)
+        for (int x = 0; x < cell; x++) {
+            /* Dx */
+            volatile float r0 = BP(y - 1, x + 1) - BP(y - 1, x - 1), r1 = BP(y, x + 1) - BP(y, x - 1), r2 = BP(y + 1, x + 1) - BP(y + 1, x - 1);
+            volatile float t0 = r0 + r2;
+            volatile float t1 = t0 * s, t2 = r1 * s2;
+            dx[y * cell + x] = t1 + t2;
+            /* Dy: row-filtered rows y-1 and y+1 */
+            volatile float ua = s * BP(y - 1, x - 1), ub = s2 * BP(y - 1, x), uc = s * BP(y - 1, x + 1);
+            volatile float u01 = ua + ub;
+            volatile float up = u01 + uc;
+            volatile float da = s * BP(y + 1, x - 1), db = s2 * BP(y + 1, x), dc = s * BP(y + 1, x + 1);
+            volatile float d01 = da + db;
+            volatile float dn = d01 + dc;
+            dy[y * cell + x] = dn - up;
+        }
+#undef BP
+    /* boxFilter(cov, cov, CV_32F, 3x3, normalize=false): RowSum<float,double> then ColumnSum<double,float>
+     * (imgproc/src/box_filter.simd.hpp:65-84,176-270): SLIDING sums in double -- s += new - old along x, and
+     * SUM = (SUM + R[y+1]) -> out, SUM -= R[y-1] down y -- so the rounding history is part of the result. */
+    double *R = (double *) malloc(sizeof(double) * 3 * (size_t) cell * cell);
+    for (int y = 0; y < cell; y++)
+        for (int ch = 0; ch < 3; ch++) {
+#define COV(xx) cov_at(dx, dy, cell, y, reflect101(xx, cell), ch)
+            double sacc = 0;
+            sacc += (double) COV(-1);
+            sacc += (double) COV(0);
+            sacc += (double) COV(1);
+            R[((size_t) y * cell + 0) * 3 + ch] = sacc;
+            for (int x = 1; x < cell; x++) {
+                sacc += (double) COV(x + 1) - (double) COV(x - 2);
+                R[((size_t) y * cell + x) * 3 + ch] = sacc;
+            }
+#undef COV
+        }
+    for (int x = 0; x < cell; x++) {
+        double SUM[3] = {0, 0, 0};
+        for (int ch = 0; ch < 3; ch++) {
+            SUM[ch] += R[((size_t) reflect101(-1, cell) * cell + x) * 3 + ch];
+            SUM[ch] += R[((size_t) 0 * cell + x) * 3 + ch];
+        }
+        for (int y = 0; y < cell; y++) {
+            float box[3];
+            for (int ch = 0; ch < 3; ch++) {
+                double s0 = SUM[ch] + R[((size_t) reflect101(y + 1, cell) * cell + x) * 3 + ch];
+                box[ch] = (float) s0;
+                SUM[ch] = s0 - R[((size_t) reflect101(y - 1, cell) * cell + x) * 3 + ch];
+            }
+            volatile float a = box[0] * 0.5f, b = box[1], c = box[2] * 0.5f;
+            volatile float t = a - c;
+            volatile float tt = t * t, bb = b * b;
+            volatile float sum = bb + tt;
+            volatile float sq = sqrtf(sum);
+            volatile float ac = a + c;
+            eig[y * cell + x] = ac - sq;
+        }
+    }
+    free(R);
+    if (blurOut) memcpy(blurOut, B, (size_t) cell * cell);
+    free(B); free(dx); free(dy);
+}
+
+/* cv::getRectSubPix(8U -> 32F), imgproc/src/samplers.cpp:219-268 (+ generic border branch :129-216) */
+static void rect_subpix_8u32f(const uint8_t *src, int w, int h, int ww, int wh, float cx, float cy, float *dst) {
+    cx -= (ww - 1) * 0.5f;
+    cy -= (wh - 1) * 0.5f;
+    int ipx = (int) floorf(cx), ipy = (int) floorf(cy);
+    if (0 <= ipx && ipx + ww < w && 0 <= ipy && ipy + wh < h) {
+        volatile float a = cx - ipx, b = cy - ipy;
+        if (a < 0.0001f) a = 0.0001f;
+        volatile float omb = 1.f - b;
+        volatile float a12 = a * omb, a22 = a * b, b1 = omb, b2 = b, oma = 1 - a;
+        double s = (1. - a) / a;
+        const uint8_t *p = src + (size_t) ipy * w + ipx;
+        for (int i = 0; i < wh; i++, p += w, dst += ww) {
+            volatile float e0 = b1 * p[0], e1 = b2 * p[w];
+            volatile float e = e0 + e1;
+            volatile float prev = oma * e;
+            for (int j = 0; j < ww; j++) {
+                volatile float t0 = a12 * p[j + 1], t1 = a22 * p[j + 1 + w];
+                volatile float t = t0 + t1;
+                dst[j] = prev + t;
+                prev = (float) (t * s);
+            }
+        }
+        return;
+    }
+    /* generic branch with adjustRect (samplers.cpp:43-110) */
+    volatile float a = cx - ipx, b = cy - ipy;
+    volatile float oma = 1.f - a, omb = 1.f - b;
+    volatile float a11 = oma * omb, a12 = a * omb, a21 = oma * b, a22 = a * b, b1 = omb, b2 = b;
+    int rx, ry, rw, rh;
+    const uint8_t *p = src;
+    if (ipx >= 0) { p += ipx; rx = 0; } else { rx = -ipx; if (rx > ww) rx = ww; }
+    if (ipx < w - ww) rw = ww; else { rw = w - ipx - 1; if (rw < 0) { p += rw; rw = 0; } }
+    if (ipy >= 0) { p += (size_t) ipy * w; ry = 0; } else ry = -ipy;
+    if (ipy < h - wh) rh = wh; else { rh = h - ipy - 1; if (rh < 0) { p += (ptrdiff_t) rh * w; rh = 0; } }
+    p -= rx;
+    for (int i = 0; i < wh; i++, dst += ww) {
+        const uint8_t *p2 = p + w;
+        if (i < ry || i >= rh) p2 -= w;
+        volatile float q0 = p[rx] * b1, q1 = p2[rx] * b2;
+        float s0 = q0 + q1;
+        for (int j = 0; j < rx; j++) dst[j] = s0;
+        q0 = p[rw] * b1; q1 = p2[rw] * b2;
+        s0 = q0 + q1;
+        for (int j = rw; j < ww; j++) dst[j] = s0;
+        for (int j = rx; j < rw; j++) {
+            volatile float m0 = p[j] * a11, m1 = p[j + 1] * a12, m2 = p2[j] * a21, m3 = p2[j + 1] * a22;
+            volatile float m01 = m0 + m1;
+            volatile float m012 = m01 + m2;
+            dst[j] = m012 + m3;
+        }
+        if (i < rh) p = p2;
+    }
+}
+
+/* cv::cornerSubPix(image, pts, Size(3,3), Size(-1,-1), {EPS+MAX_ITER, 30, 0.01}): imgproc/src/cornersubpix.cpp:44-156 */
+void orc_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n) {
+    enum { WINH = 3, WW = 7 };
+    float mask[WW * WW], buf[(WW + 2) * (WW + 2)];
+    for (int i = 0; i < WW; i++) {
+        float y = (float) (i - WINH) / WINH;
+        float vy = expf(-y * y);
+        for (int j = 0; j < WW; j++) {
+            float x = (float) (j - WINH) / WINH;
+            mask[i * WW + j] = (float) (vy * expf(-x * x));
+        }
+    }
+    const int max_iters = 30;
+    double eps = 0.01;
+    eps *= eps;
+    for (int pi = 0; pi < n; pi++) {
+        float cTx = pts[2 * pi], cTy = pts[2 * pi + 1], cIx = cTx, cIy = cTy;
+        int iter = 0;
+        double err = 0;
+        do {
+            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            rect_subpix_8u32f(gray, w, h, WW + 2, WW + 2, cIx, cIy, buf);
+            const float *sp = buf + (WW + 2) + 1;
+            for (int i = 0, k = 0; i < WW; i++, sp += WW + 2) {
+                double py = i - WINH;
+                for (int j = 0; j < WW; j++, k++) {
+                    double m = mask[k];
+                    volatile float fgx = sp[j + 1] - sp[j - 1], fgy = sp[j + WW + 2] - sp[j - WW - 2];
+                    double tgx = fgx, tgy = fgy;
+                    double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m, px = j - WINH;
+                    a += gxx;
+                    b += gxy;
+                    c += gyy;
+                    bb1 += gxx * px + gxy * py;
+                    bb2 += gxy * px + gyy * py;
+                }
+            }
+            double det = a * c - b * b;
+            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+            double scale = 1.0 / det;
+            float nx = (float) (cIx + c * scale * bb1 - b * scale * bb2);
+            float ny = (float) (cIy - b * scale * bb1 + a * scale * bb2);
+            volatile float ex = nx - cIx, ey = ny - cIy;
+            volatile float ex2 = ex * ex, ey2 = ey * ey;
+            volatile float e = ex2 + ey2;
+            err = e;
+            cIx = nx;
+            cIy = ny;
+            if (cIx < 0 || cIx >= w || cIy < 0 || cIy >= h) break;
+        } while (++iter < max_iters && err > eps);
+        if (fabs((double) (cIx - cTx)) > WINH || fabs((double) (cIy - cTy)) > WINH) {
+            cIx = cTx;
+            cIy = cTy;
+        }
+        pts[2 * pi] = cIx;
+        pts[2 * pi + 1] = cIy;
+    }
+}
+
+/* returns the number of points written (<= cap); *maxQuality is updated like FeatureExtractor::maxQuality_ */
+int orc_detect_grid(const uint8_t *gray, int w, int h, int cell, const float *occupied, int nOcc, int roiX, int roiY, int roiW,
+                    int roiH, double *maxQuality, float *outPts, int cap) {
+    int radius = cell / 4, nCH = h / cell, nCW = w / cell, nCells = nCH * nCW;
+    int *hw = (int *) malloc(sizeof(int) * (size_t) (radius + 1));
+    circle_halfwidths(radius, hw);
+    uint8_t *mask = (uint8_t *) malloc((size_t) w * h), *occ = (uint8_t *) calloc((size_t) (nCH + 1) * (nCW + 1), 1);
+    memset(mask, 1, (size_t) w * h);
+    for (int i = 0; i < nOcc; i++) { /* :30-36 */
+        float px = occupied[2 * i], py = occupied[2 * i + 1];
+        occ[(size_t) (py / cell) * (nCW + 1) + (size_t) (px / cell)] = 1;
+        draw_zero_circle(mask, w, h, cv_round_f(px), cv_round_f(py), radius, hw);
+    }
+    float *eig = (float *) malloc(sizeof(float) * (size_t) cell * cell);
+    float *prim = (float *) malloc(sizeof(float) * 2 * (size_t) nCells), *sec = (float *) malloc(sizeof(float) * 2 * (size_t) nCells);
+    uint8_t *hasP = (uint8_t *) calloc((size_t) nCells, 1), *hasS = (uint8_t *) calloc((size_t) nCells, 1);
+    size_t numOccupied = 0;
+    for (int i = 0; i < nCells; i++) {
+        int r = i / nCW, c = i % nCW;
+        if (occ[(size_t) r * (nCW + 1) + c]) {
+            numOccupied++;
+            continue;
+        }
+        int x = c * cell, y = r * cell;
+        if (!(x + cell < w - 1 && y + cell < h - 1)) continue; /* :62 */
+        orc_cell_mineig(gray, w, h, x, y, cell, NULL, eig);
+        for (int pass = 0; pass < 2; pass++) {
+            float best = -3.402823466e+38f;
+            int bi = 0;
+            for (int k = 0; k < cell * cell; k++) { /* hMap.mul(mask(roi)) + minMaxLoc: first maximum */
+                volatile float v = eig[k] * (float) mask[(size_t) (y + k / cell) * w + x + k % cell];
+                if (v > best) {
+                    best = v;
+                    bi = k;
+                }
+            }
+            int mx = x + bi % cell, my = y + bi / cell;
+            if (mx < roiX || my < roiY || mx >= roiX + roiW || my >= roiY + roiH) break; /* `continue` of the cell loop, :78-81, :93-96 */
+            if ((double) best >= *maxQuality) {
+                float *dst = pass == 0 ? prim : sec;
+                dst[2 * i] = (float) mx;
+                dst[2 * i + 1] = (float) my;
+                (pass == 0 ? hasP : hasS)[i] = 1;
+                draw_zero_circle(mask, w, h, mx, my, radius, hw);
+            }
+        }
+    }
+    int n = 0;
+    float *all = (float *) malloc(sizeof(float) * 4 * (size_t) nCells + 8);
+    for (int i = 0; i < nCells; i++)
+        if (hasP[i]) {
+            all[2 * n] = prim[2 * i];
+            all[2 * n + 1] = prim[2 * i + 1];
+            n++;
+        }
+    size_t numKeypoints = (size_t) n;
+    if (numKeypoints + numOccupied < (size_t) nCells) { /* :117-134 */
+        size_t numSec = (size_t) nCells - (numKeypoints + numOccupied), k = 0;
+        for (int i = 0; i < nCells; i++)
+            if (hasS[i]) {
+                all[2 * n] = sec[2 * i];
+                all[2 * n + 1] = sec[2 * i + 1];
+                n++;
+                if (++k == numSec) break;
+            }
+    }
+    numKeypoints = (size_t) n;
+    if ((double) numKeypoints < 0.33 * (double) ((size_t) nCells - numOccupied)) *maxQuality *= 0.5; /* :138-145 */
+    else if ((double) numKeypoints > 0.9 * (double) ((size_t) nCells - numOccupied)) *maxQuality *= 1.5;
+    if (n > 0) orc_corner_subpix(gray, w, h, all, n);
+    int m = n < cap ? n : cap;
+    memcpy(outPts, all, sizeof(float) * 2 * (size_t) m);
+    free(hw); free(mask); free(occ); free(eig); free(prim); free(sec); free(hasP); free(hasS); free(all);
+    return n;
+}

@@ -23,6 +23,12 @@ int orc_lk(const uint8_t *prevGray, const uint8_t *nextGray, int w, int h, int w
 int orc_fbklt(const uint8_t *prevGray, const uint8_t *currGray, int w, int h, int win, int pyrLevelsBuilt, int numLevels,
               float errThresh, float fbDist, int maxIters, float eps, const float *pts, float *prior, uint8_t *status, int n);
 
+/* a5 */
+void orc_cell_mineig(const uint8_t *gray, int w, int h, int x0, int y0, int cell, uint8_t *blurOut, float *eig);
+void orc_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n);
+int orc_detect_grid(const uint8_t *gray, int w, int h, int cell, const float *occupied, int nOcc, int roiX, int roiY, int roiW,
+                    int roiH, double *maxQuality, float *outPts, int cap);
+
 /* a6 */
 void orc_orb_blur(const uint8_t *gray, int w, int h, uint8_t *out /* w*h */);
 void orc_describe(const uint8_t *gray, int w, int h, const float *pts, int n, uint8_t *desc /* n*32 */, uint8_t *valid);

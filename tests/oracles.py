@@ -80,6 +80,33 @@ class Orc:
     _pnp = "orc_pnp_refine"
 
     @classmethod
+    def cell_mineig(cls, gray, x, y, cell):
+        h, w = gray.shape
+        blur = np.zeros((cell, cell), np.uint8)
+        eig = np.zeros((cell, cell), np.float32)
+        getattr(cls._lib(), cls._pfx + "cell_mineig")(_p(np.ascontiguousarray(gray)), w, h, x, y, cell, _p(blur), _p(eig))
+        return blur, eig
+
+    @classmethod
+    def corner_subpix(cls, gray, pts):
+        h, w = gray.shape
+        p = np.ascontiguousarray(pts, np.float32).copy()
+        getattr(cls._lib(), cls._pfx + "corner_subpix")(_p(np.ascontiguousarray(gray)), w, h, _p(p), len(p))
+        return p
+
+    @classmethod
+    def detect_grid(cls, gray, cell, occupied=None, roi=None, max_quality=0.001, cap=20000):
+        h, w = gray.shape
+        occ = np.zeros((0, 2), np.float32) if occupied is None else np.ascontiguousarray(occupied, np.float32)
+        if roi is None:
+            roi = (20, 20, w - 40, h - 40)
+        mq = C.c_double(max_quality)
+        out = np.zeros((cap, 2), np.float32)
+        n = getattr(cls._lib(), cls._pfx + "detect_grid")(_p(np.ascontiguousarray(gray)), w, h, cell, _p(occ), len(occ), roi[0], roi[1],
+                                                          roi[2], roi[3], C.byref(mq), _p(out), cap)
+        return out[:n].copy(), mq.value
+
+    @classmethod
     def local_ba(cls, pb, max_iters=5, ftol=0.0, huber_chi2=5.9915, inv_depth=True):
         """pb: dict from synth.make_ba_problem (or make_ba_problem_xyz).  Returns dict(poses, pts, chi2, depth, info, ok)."""
         poses = np.ascontiguousarray(pb["poses"], np.float64).copy()
@@ -198,6 +225,33 @@ class Ref:
     """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
     _pfx = "ref_"
     _pnp = "ref_ceres_pnp_nocap"
+
+    @classmethod
+    def cell_mineig(cls, gray, x, y, cell):
+        h, w = gray.shape
+        blur = np.zeros((cell, cell), np.uint8)
+        eig = np.zeros((cell, cell), np.float32)
+        getattr(cls._lib(), cls._pfx + "cell_mineig")(_p(np.ascontiguousarray(gray)), w, h, x, y, cell, _p(blur), _p(eig))
+        return blur, eig
+
+    @classmethod
+    def corner_subpix(cls, gray, pts):
+        h, w = gray.shape
+        p = np.ascontiguousarray(pts, np.float32).copy()
+        getattr(cls._lib(), cls._pfx + "corner_subpix")(_p(np.ascontiguousarray(gray)), w, h, _p(p), len(p))
+        return p
+
+    @classmethod
+    def detect_grid(cls, gray, cell, occupied=None, roi=None, max_quality=0.001, cap=20000):
+        h, w = gray.shape
+        occ = np.zeros((0, 2), np.float32) if occupied is None else np.ascontiguousarray(occupied, np.float32)
+        if roi is None:
+            roi = (20, 20, w - 40, h - 40)
+        mq = C.c_double(max_quality)
+        out = np.zeros((cap, 2), np.float32)
+        n = getattr(cls._lib(), cls._pfx + "detect_grid")(_p(np.ascontiguousarray(gray)), w, h, cell, _p(occ), len(occ), roi[0], roi[1],
+                                                          roi[2], roi[3], C.byref(mq), _p(out), cap)
+        return out[:n].copy(), mq.value
 
     @classmethod
     def local_ba(cls, pb, max_iters=5, ftol=0.0, huber_chi2=5.9915, inv_depth=True):

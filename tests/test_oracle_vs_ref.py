@@ -166,3 +166,41 @@ def test_local_ba_xyz(nkf, npt, seed):
     a = Orc.local_ba(pb, 5, 0.0, inv_depth=False)
     b = Ref.local_ba(pb, 5, 0.0, inv_depth=False)
     ba_compare(a, b, pt_tol=1e-6)
+
+
+def _img(w, h, seed, noise=True, k=2):
+    return synth.frame_gray(synth.texture_canvas(w, h, seed), k, w, h, noise_seed=seed if noise else None)
+
+
+@pytest.mark.parametrize("cell,x,y,seed", [(12, 24, 36, 1), (40, 0, 0, 2), (15, 600, 450, 3), (35, 70, 35, 4)])
+def test_cell_mineig_bit_exact(cell, x, y, seed):
+    g = _img(640, 480, seed)
+    ob, oe = Orc.cell_mineig(g, x, y, cell)
+    rb, re_ = Ref.cell_mineig(g, x, y, cell)
+    assert np.array_equal(ob, rb)
+    assert np.array_equal(oe.view(np.uint32), re_.view(np.uint32))
+
+
+def test_corner_subpix_bit_exact():
+    g = _img(640, 480, 5)
+    rng = np.random.RandomState(0)
+    pts = np.stack([rng.uniform(0, 640, 600), rng.uniform(0, 480, 600)], 1).astype(np.float32)
+    pts[:100] = np.round(pts[:100])
+    pts[100:110] = [[2, 2], [637, 477], [0, 0], [639, 479], [4, 100], [5, 100], [634, 100], [300, 3], [300, 475], [6.5, 6.5]]
+    assert np.array_equal(Orc.corner_subpix(g, pts).view(np.uint32), Ref.corner_subpix(g, pts).view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,cell,seed,nocc", [(640, 480, 12, 1, 0), (640, 480, 40, 2, 30), (1280, 720, 15, 3, 200), (640, 480, 35, 4, 0),
+                                               (200, 160, 12, 5, 10)])
+def test_detect_grid_bit_exact(w, h, cell, seed, nocc):
+    g = _img(w, h, seed)
+    rng = np.random.RandomState(seed)
+    occ = np.stack([rng.uniform(0, w - 1, nocc), rng.uniform(0, h - 1, nocc)], 1).astype(np.float32)
+    mq = 0.001
+    for rep in range(3):  # the adaptive threshold carries over between calls
+        op, omq = Orc.detect_grid(g, cell, occ, max_quality=mq)
+        rp, rmq = Ref.detect_grid(g, cell, occ, max_quality=mq)
+        assert omq == rmq
+        assert op.shape == rp.shape and len(rp) > 0
+        assert np.array_equal(op.view(np.uint32), rp.view(np.uint32))
+        mq = rmq
