@@ -59,6 +59,7 @@ _sig("alva_p3p_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
 _sig("alva_p3p_lmeds", [_vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _f, _f, _vp, _vp, _vp, _vp, _vp])
 _sig("alva_pnp_refine", [_vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
 _sig("alva_local_ba", [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp])
+_sig("alva_detect_grid", [_vp, _vp, _sz, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -179,6 +180,22 @@ class Context:
                                 ouv.ctypes.data, max_iters, ftol, huber_chi2, chi2.ctypes.data, depth.ctypes.data, info.ctypes.data,
                                 C.byref(ok)))
         return dict(ok=bool(ok.value), poses=poses, pts=pts, chi2=chi2[:nobs], depth=depth[:nobs], info=info)
+
+    # a5
+    def detect_grid(self, gray, cell, occupied=None, roi=None, max_quality=0.001, cap=None):
+        """FeatureExtractor::detectFeaturePoints: returns (pts [n,2] float32 cuda tensor, new max_quality)."""
+        h, w = gray.shape
+        if roi is None:
+            roi = (20, 20, w - 40, h - 40)
+        if cap is None:
+            cap = 2 * (w // cell) * (h // cell) + 1
+        nocc = 0 if occupied is None else occupied.shape[0]
+        out = torch.zeros((cap, 2), dtype=torch.float32, device=gray.device)
+        mq = C.c_double(max_quality)
+        cnt = C.c_int(0)
+        check(lib.alva_detect_grid(self.h, _ptr(gray), gray.stride(0), w, h, cell, _ptr(occupied) if nocc else None, nocc,
+                                   roi[0], roi[1], roi[2], roi[3], C.byref(mq), _ptr(out), cap, C.byref(cnt)))
+        return out[:min(cnt.value, cap)], mq.value
 
     # a6
     def orb_blur(self, gray):

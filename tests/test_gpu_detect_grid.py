@@ -1,0 +1,46 @@
+"""GPU parity: a5 -- the reference's grid Shi-Tomasi detector (FeatureExtractor::detectFeaturePoints), bit-exact:
+the detected point list (order included), the sub-pixel positions (float bits) and the adaptive threshold."""
+import numpy as np
+import pytest
+
+from alvaar_amd import synth
+from oracles import Orc, Ref, ref_available
+from test_oracle_vs_ref import _img
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,cell,seed,nocc", [(640, 480, 12, 1, 0), (640, 480, 40, 2, 30), (1280, 720, 15, 3, 200), (640, 480, 35, 4, 0),
+                                               (200, 160, 12, 5, 10), (640, 480, 13, 6, 5)])
+def test_detect_grid_bit_exact(ctx, w, h, cell, seed, nocc):
+    import torch
+    g = _img(w, h, seed)
+    rng = np.random.RandomState(seed)
+    occ = np.stack([rng.uniform(0, w - 1, nocc), rng.uniform(0, h - 1, nocc)], 1).astype(np.float32)
+    gd = torch.from_numpy(g).cuda()
+    od = torch.from_numpy(occ).cuda() if nocc else None
+    mq = 0.001
+    O = Ref if ref_available() else Orc
+    for rep in range(3):
+        pts, nmq = ctx.detect_grid(gd, cell, od, max_quality=mq)
+        rp, rmq = O.detect_grid(g, cell, occ, max_quality=mq)
+        pts = pts.cpu().numpy()
+        assert nmq == rmq
+        assert pts.shape == rp.shape and len(rp) > 0
+        assert np.array_equal(pts.view(np.uint32), rp.view(np.uint32))
+        mq = rmq
+
+
+def test_detect_grid_properties_full_size(ctx):
+    """BASELINE sizes: 2120 / 4080 cells; at most one primary + one secondary per cell, all inside the roi before
+    refinement (|refined - integer| <= 3 px), and the call is idempotent for a fixed threshold."""
+    import torch
+    for (w, h, cell) in [(640, 480, 12), (1280, 720, 15)]:
+        g = torch.from_numpy(_img(w, h, 7, noise=False, k=0)).cuda()
+        a, q1 = ctx.detect_grid(g, cell, max_quality=0.001)
+        b, q2 = ctx.detect_grid(g, cell, max_quality=0.001)
+        assert torch.equal(a, b) and q1 == q2
+        n = a.shape[0]
+        assert 0.5 * (w // cell) * (h // cell) < n <= (w // cell) * (h // cell)
+        a = a.cpu().numpy()
+        assert (a[:, 0] >= 20 - 3).all() and (a[:, 0] < w - 20 + 3).all() and (a[:, 1] >= 20 - 3).all() and (a[:, 1] < h - 20 + 3).all()
