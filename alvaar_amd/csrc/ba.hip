@@ -235,14 +235,13 @@ __device__ __forceinline__ int tri6(int x, int y) {
 __global__ void __launch_bounds__(256) k_assemble(BaDev B, int first) {
     const int n6 = B.n6, nKf = B.nKf;
     __shared__ double s_red[256];
+    __shared__ int s_kf[256];  // free index -> keyframe id
+    for (int k = threadIdx.x; k < nKf; k += 256)
+        if (B.cidx[k] >= 0 && B.cidx[k] < 256) s_kf[B.cidx[k]] = k;
+    __syncthreads();
     for (int e = threadIdx.x; e < n6 * n6; e += 256) {
         const int r = e / n6, c = e % n6, cr = r / 6, cc = c / 6, x = r % 6, y = c % 6;
-        // map free index -> kf id
-        int kr = -1, kc = -1;
-        for (int k = 0; k < nKf; k++) {
-            if (B.cidx[k] == cr) kr = k;
-            if (B.cidx[k] == cc) kc = k;
-        }
+        const int kr = s_kf[cr], kc = s_kf[cc];
         double v = 0;
         const int t = tri6(x, y);
         if (B.inv) {
@@ -258,9 +257,7 @@ __global__ void __launch_bounds__(256) k_assemble(BaDev B, int first) {
     }
     for (int r = threadIdx.x; r < n6; r += 256) {
         const int cr = r / 6, x = r % 6;
-        int kr = -1;
-        for (int k = 0; k < nKf; k++)
-            if (B.cidx[k] == cr) kr = k;
+        const int kr = s_kf[cr];
         double v = 0;
         if (B.inv) {
             for (int k = 0; k < nKf; k++) v += B.M[(size_t) (kr * nKf + k) * 27 + 21 + x] - B.M[(size_t) (k * nKf + kr) * 27 + 21 + x];
@@ -393,17 +390,20 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 }
 
 // S = S_c F'F S_c + D_c^2/radius - G ; rhs = S_c F'r - G[:, n6] ; dense Cholesky; y_c.  One workgroup.
+template<bool IN_LDS>
 __global__ void __launch_bounds__(256) k_solve(BaDev B, double radius) {
+    extern __shared__ double s_S[];
     const int n = B.n6;
     __shared__ double s_piv;
     __shared__ int s_ok;
+    double *S = IN_LDS ? s_S : B.S;  // the reduced camera matrix lives in LDS (n <= 140: n^2 * 8 B <= 157 KB)
     for (int e = threadIdx.x; e < n * n; e += 256) {
         const int r = e / n, c = e % n;
         double g = 0;
         for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + c];
         double v = B.Hcc[e] * B.sc[r] * B.sc[c] - g;
         if (r == c) v += B.dc[r] / radius;
-        B.S[e] = v;
+        S[e] = v;
     }
     for (int r = threadIdx.x; r < n; r += 256) {
         double g = 0;
@@ -412,41 +412,47 @@ __global__ void __launch_bounds__(256) k_solve(BaDev B, double radius) {
     }
     if (threadIdx.x == 0) s_ok = 1;
     __syncthreads();
-    // right-looking Cholesky, lower triangle in place
+    // right-looking Cholesky, lower triangle in place; the solve phases run on one wave with the running sums
+    // spread over lanes (forward: column sweep, backward: row sweep)
     for (int j = 0; j < n; j++) {
         if (threadIdx.x == 0) {
-            const double d = B.S[(size_t) j * n + j];
+            const double d = S[(size_t) j * n + j];
             if (!(d > 0)) s_ok = 0;
             s_piv = sqrt(d);
-            B.S[(size_t) j * n + j] = s_piv;
+            S[(size_t) j * n + j] = s_piv;
         }
         __syncthreads();
         if (!s_ok) break;
         const double piv = s_piv;
-        for (int i = j + 1 + threadIdx.x; i < n; i += 256) B.S[(size_t) i * n + j] /= piv;
+        for (int i = j + 1 + threadIdx.x; i < n; i += 256) S[(size_t) i * n + j] /= piv;
         __syncthreads();
         const int m = n - j - 1;
+        // trailing update of the lower triangle: element (a, b), b <= a
         for (int e = threadIdx.x; e < m * m; e += 256) {
             const int a = j + 1 + e / m, b = j + 1 + e % m;
-            if (b <= a) B.S[(size_t) a * n + b] -= B.S[(size_t) a * n + j] * B.S[(size_t) b * n + j];
+            if (b <= a) S[(size_t) a * n + b] -= S[(size_t) a * n + j] * S[(size_t) b * n + j];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        if (s_ok) {
-            for (int i = 0; i < n; i++) {
-                double s = B.yc[i];
-                for (int k = 0; k < i; k++) s -= B.S[(size_t) i * n + k] * B.yc[k];
-                B.yc[i] = s / B.S[(size_t) i * n + i];
-            }
-            for (int i = n - 1; i >= 0; i--) {
-                double s = B.yc[i];
-                for (int k = i + 1; k < n; k++) s -= B.S[(size_t) k * n + i] * B.yc[k];
-                B.yc[i] = s / B.S[(size_t) i * n + i];
-            }
+    if (s_ok) {
+        // forward substitution L z = rhs (column-oriented: after z_i is final, every lane updates its rows)
+        for (int i = 0; i < n; i++) {
+            if (threadIdx.x == 0) B.yc[i] = B.yc[i] / S[(size_t) i * n + i];
+            __syncthreads();
+            const double zi = B.yc[i];
+            for (int k = i + 1 + threadIdx.x; k < n; k += 256) B.yc[k] -= S[(size_t) k * n + i] * zi;
+            __syncthreads();
         }
-        B.scal[5] = s_ok ? 1.0 : 0.0;
+        // backward substitution L' y = z
+        for (int i = n - 1; i >= 0; i--) {
+            if (threadIdx.x == 0) B.yc[i] = B.yc[i] / S[(size_t) i * n + i];
+            __syncthreads();
+            const double yi = B.yc[i];
+            for (int k = threadIdx.x; k < i; k += 256) B.yc[k] -= S[(size_t) i * n + k] * yi;
+            __syncthreads();
+        }
     }
+    if (threadIdx.x == 0) B.scal[5] = s_ok ? 1.0 : 0.0;
 }
 
 // per point: y_p = hinv (g_s - (S_c W S_p)' y_c); candidate point; partials for the model cost change
@@ -677,6 +683,9 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     ALVA_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope / are reused
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
+    const bool solve_in_lds = n6 * n6 * sizeof(double) <= 156 * 1024;
+    if (solve_in_lds && n6 * n6 * sizeof(double) > 48 * 1024)
+        ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     auto eval = [&](const double *xp, const double *xt, bool wantJ, bool first) -> int {
         if (n_pt > 0) {
             if (inv_depth) {
@@ -723,7 +732,8 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         const int tiles = B.NP / 16;
         hipLaunchKernelGGL(k_gemm, dim3((unsigned) (tiles * tiles), KSPLIT), dim3(64), 0, st, B);
-        hipLaunchKernelGGL(k_solve, dim3(1), blk, 0, st, B, lm.radius);
+        if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), blk, n6 * n6 * sizeof(double), st, B, lm.radius);
+        else hipLaunchKernelGGL(k_solve<false>, dim3(1), blk, 0, st, B, lm.radius);
         if (n_pt > 0) {
             if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
             else hipLaunchKernelGGL(k_backsub<3>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);

@@ -11,7 +11,7 @@
 //
 // The reference evaluates hypotheses one after another; they are independent, so here
 //   k_hyp      one thread per drawn sample   -> model + valid flag
-//   k_median   one workgroup per hypothesis  -> N squared scores into LDS, bitonic sort, median
+//   k_median   one workgroup per hypothesis  -> N squared scores into LDS, radix-select of the median
 //   k_select   one workgroup                 -> replay the sequential "first max_iters valid, strict <"
 //                                               scan, then classify inliers of the winner
 // FP64 VALU work (100 x N x ~40 flop); bytes are negligible (48 N read once per hypothesis,
@@ -210,48 +210,105 @@ __global__ void __launch_bounds__(64) k_hyp(const double *__restrict__ bv, const
         for (int k = 0; k < 12; k++) models[12 * (size_t) h + k] = sol[minIndex][k];
 }
 
-// One workgroup per hypothesis: squared clipped scores -> LDS -> bitonic sort -> median (Lmeds.hpp:96-130).
+// One workgroup per hypothesis: squared clipped scores -> LDS, then the median by MSB-first radix SELECT on the
+// IEEE bit patterns (non-negative doubles order like their uint64 bits) instead of the reference's full std::sort
+// (Lmeds.hpp:96-130 only ever reads distances[mid-1] and distances[mid]): 8 passes of a 256-bin LDS histogram.
+__device__ unsigned long long radix_select(const unsigned long long *keys, int n, int k, unsigned int *hist, int *s_bin, int *s_k) {
+    unsigned long long prefix = 0, mask = 0;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;  // 256 threads == 256 bins
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const unsigned long long key = keys[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned) (key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const unsigned c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+            const unsigned tot = c0 + c1 + c2 + c3;
+            unsigned incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(incl, off);
+                if (l >= off) incl += v;
+            }
+            const unsigned excl = incl - tot;
+            if ((unsigned) k >= excl && (unsigned) k < incl) {
+                unsigned r = (unsigned) k - excl;
+                int b;
+                if (r < c0) b = 0;
+                else if (r < c0 + c1) { b = 1; r -= c0; }
+                else if (r < c0 + c1 + c2) { b = 2; r -= c0 + c1; }
+                else { b = 3; r -= c0 + c1 + c2; }
+                *s_bin = 4 * l + b;
+                *s_k = (int) r;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long) (unsigned) *s_bin << shift;
+        mask |= 0xffull << shift;
+        k = *s_k;
+        __syncthreads();
+    }
+    return prefix;
+}
+
 __global__ void __launch_bounds__(256) k_median(const double *__restrict__ bv, const double *__restrict__ wpt, int n, int np2,
                                                 const double *__restrict__ models, const int *__restrict__ valid,
                                                 double *__restrict__ penalty) {
-    extern __shared__ double s_d[];
+    extern __shared__ unsigned long long s_keys[];
+    __shared__ unsigned int s_hist[256];
+    __shared__ int s_bin, s_k;
+    __shared__ unsigned long long s_min[256];
+    __shared__ unsigned int s_cnt[256];
+    __shared__ double s_m[12];
+    (void) np2;
     const int h = blockIdx.x;
     if (!valid[h]) {
         if (threadIdx.x == 0) penalty[h] = INFINITY;
         return;
     }
-    __shared__ double s_m[12];
     if (threadIdx.x < 12) s_m[threadIdx.x] = models[12 * (size_t) h + threadIdx.x];
     __syncthreads();
-    for (int i = threadIdx.x; i < np2; i += 256) {
-        double v = INFINITY;
-        if (i < n) {
-            double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
-            if (d < 0) d = 0;
-            v = d * d;
-            if (v != v) v = INFINITY;  // NaN scores sort last (std::sort's behaviour with NaN is unspecified)
-        }
-        s_d[i] = v;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
+        if (d < 0) d = 0;
+        double v = d * d;
+        if (v != v) v = INFINITY;  // NaN scores order last (std::sort's behaviour with NaN is unspecified)
+        s_keys[i] = (unsigned long long) __double_as_longlong(v);
     }
     __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const double a = s_d[i], b = s_d[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        s_d[i] = b;
-                        s_d[l] = a;
-                    }
-                }
-            }
-            __syncthreads();
+    const int mid = n / 2;
+    const unsigned long long kmid = radix_select(s_keys, n, mid, s_hist, &s_bin, &s_k);
+    if (n % 2 != 0) {
+        if (threadIdx.x == 0) penalty[h] = __longlong_as_double((long long) kmid);
+        return;
+    }
+    // even n: also need the (mid-1)-th smallest = max{x : x < kmid} unless kmid is duplicated below rank mid
+    unsigned long long below = 0;
+    unsigned int cnt_lt = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long key = s_keys[i];
+        if (key < kmid) {
+            cnt_lt++;
+            below = key > below ? key : below;
         }
+    }
+    s_min[threadIdx.x] = below;
+    s_cnt[threadIdx.x] = cnt_lt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            s_min[threadIdx.x] = s_min[threadIdx.x] > s_min[threadIdx.x + s] ? s_min[threadIdx.x] : s_min[threadIdx.x + s];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        const int mid = n / 2;
-        penalty[h] = (n % 2 == 0) ? (s_d[mid - 1] + s_d[mid]) / 2 : s_d[mid];
+        // elements < kmid occupy ranks [0, cnt_lt); rank mid-1 is below kmid only if cnt_lt == mid
+        const unsigned long long klo = (s_cnt[0] == (unsigned) mid) ? s_min[0] : kmid;
+        penalty[h] = (__longlong_as_double((long long) klo) + __longlong_as_double((long long) kmid)) / 2;
     }
 }
 
@@ -343,7 +400,7 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
     ALVA_ARG(d_bearings && d_wpts);
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    ALVA_ARG((size_t) np2 * sizeof(double) <= 64 * 1024);  // LDS-resident median; n <= 8192 3-D keypoints
+    ALVA_ARG(n <= 7168);  // LDS-resident median select (n * 8 B + histogram < 64 KB)
     float focal = fx + fy;  // :72-76
     focal /= 2.f;
     const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
@@ -354,6 +411,7 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
     int H = std::min(max_draws, max_iters + 28);
     SelectOut res{};
     uint8_t *d_inlier = nullptr;
+    std::vector<uint8_t> inl;
     for (;;) {
         std::vector<int> samples((size_t) H * 4);
         {
@@ -380,13 +438,15 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
         ALVA_HIP(hipMemcpyAsync(d_samples, samples.data(), (size_t) H * 4 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, d_samples, H, d_models, d_valid);
         ALVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) np2 * sizeof(double), ctx->stream, d_bearings, d_wpts, n, np2, d_models,
+        hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) n * sizeof(double), ctx->stream, d_bearings, d_wpts, n, np2, d_models,
                            d_valid, d_pen);
         ALVA_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, d_bearings, d_wpts, n, H, max_iters, d_models, d_valid, d_pen,
                            threshold, d_out, d_inlier);
         ALVA_LAUNCH_CHECK();
         ALVA_HIP(hipMemcpyAsync(&res, d_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+        inl.resize((size_t) n);
+        ALVA_HIP(hipMemcpyAsync(inl.data(), d_inlier, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
         ALVA_HIP(hipStreamSynchronize(ctx->stream));
         if (res.n_valid_used >= max_iters || H >= max_draws) break;
         H = std::min(max_draws, H * 2);
@@ -402,9 +462,6 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
             e += v * v;
         }
     if (!(std::sqrt(e) < 1e-10)) return ALVA_OK;
-    std::vector<uint8_t> inl((size_t) n);
-    ALVA_HIP(hipMemcpyAsync(inl.data(), d_inlier, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
-    ALVA_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 9; k++) h_R[k] = R[k];
     for (int k = 0; k < 3; k++) h_t[k] = res.model[9 + k];
     int no = 0;

@@ -43,6 +43,8 @@ struct PnpShared {
     double acc[NACC];
     double x[7], cand[7];
     int flag;
+    // minimiser state (touched by lane 0 only; kept in LDS so that dynamic indexing never goes to scratch memory)
+    double H[36], g[6], scale[6], diag[6], Hs[36], gs[6], M[36], y[6], step[6], delta[6];
 };
 
 enum { F_DONE = 0, F_EVAL_CAND = 1, F_RETRY = 2, F_ACCEPT = 3, F_FAIL = 4 };
@@ -113,8 +115,8 @@ __device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robu
 
 // One ceres::Solve on the pose in sh.x.  Returns (block-uniformly) 1 = usable, 0 = failure.
 __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *active, double *chi2, uint8_t *depth, double *info) {
-    // thread-0 private minimiser state
-    double H[36], g[6], scale[6], diag[6], x_cost = 0, gmax = 0, x_norm = -1, initial = 0, mcc = 0;
+    double *H = sh.H, *g = sh.g, *scale = sh.scale, *diag = sh.diag;
+    double x_cost = 0, gmax = 0, x_norm = -1, initial = 0, mcc = 0;
     LmState lm;
     int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1;
 
@@ -137,7 +139,7 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
                 flag = F_DONE;
             } else {
                 iteration++;
-                double Hs[36], gs[6], M[36], y[6];
+                double *Hs = sh.Hs, *gs = sh.gs, *M = sh.M, *y = sh.y;
                 for (int a = 0; a < 6; a++) {
                     gs[a] = g[a] * scale[a];
                     for (int b = 0; b < 6; b++) Hs[6 * a + b] = H[6 * a + b] * scale[a] * scale[b];
@@ -151,7 +153,7 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
                 }
                 const bool okstep = chol_solve_dense(M, y, 6);
                 lm.reuse_diagonal = 1;
-                double step[6];
+                double *step = sh.step;
                 mcc = 0;
                 if (okstep) {
                     double sg = 0, sHs = 0;
@@ -172,7 +174,7 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
                     }
                 } else {
                     invalid = 0;
-                    double delta[6];
+                    double *delta = sh.delta;
                     for (int a = 0; a < 6; a++) delta[a] = step[a] * scale[a];
                     se3_plus(sh.x, delta, sh.cand);
                     flag = F_EVAL_CAND;

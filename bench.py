@@ -5,7 +5,7 @@ A "step" is one pass of the per-frame hot path (BASELINE.json configs[1]: 640x48
 per frame) over one synthetic frame whose RGBA bytes are ALREADY resident in HBM:
     RGBA -> gray -> LK pyramid (+Scharr)        (a2, a3; one fused chain of launches)
     forward-backward KLT of the previous frame's keypoints, 3 pyramid levels        (a4)
-    [keypoint detection on the new frame -- see config.stages for whether it is in the timed region]
+    grid Shi-Tomasi detection of ~2120 keypoints on the new frame (the reference's detector, cell 12)   (a5)
     256-bit ORB description of the keypoints                                        (a6)
     brute-force Hamming match against the previous frame's descriptors             (a7)
     P3P + LMedS (100 hypotheses) and robust PnP refinement (5 LM iterations) on ~2000 3-D/2-D pairs (a8, a9)
@@ -67,10 +67,20 @@ class FrameJob:
         self.K = pb["K"]
         self.pose0 = pb["pose_init"]
         self.k = 0
+        self.maxq = 0.001
+        self._det = torch.zeros((NKP, 2), dtype=torch.float32, device=self.dev)
         # prime: frame 0 pyramid + descriptors
         self.pyr[0].build_from_rgba(self.frames[0], self.gray)
         self.prev_desc, _ = self.ctx.describe(self.gray, self.pts)
         torch.cuda.synchronize(self.dev)
+
+    def det_buf(self, det):
+        """fixed-size keypoint buffer for the describe/match stages (detections, padded with the grid points)"""
+        n = min(det.shape[0], NKP)
+        self._det[:n] = det[:n]
+        if n < NKP:
+            self._det[n:] = self.pts[n:]
+        return self._det
 
     def step(self):
         ctx = self.ctx
@@ -78,7 +88,8 @@ class FrameJob:
         cur, prev = self.pyr[self.k % 2], self.pyr[(self.k - 1) % 2]
         cur.build_from_rgba(self.frames[self.k % RING], self.gray)                    # a2 + a3
         tracked, status = ctx.fbklt_track(prev, cur, self.pts, self.pts, 3)           # a4
-        desc, valid = ctx.describe(self.gray, tracked)                                 # a6
+        det, self.maxq = ctx.detect_grid(self.gray, 12, max_quality=self.maxq)         # a5 (count -> host)
+        desc, valid = ctx.describe(self.gray, self.det_buf(det))                       # a6
         idx, dist = ctx.bf_match_hamming(desc, self.prev_desc)                         # a7
         ok, R, t, outl = ctx.p3p_lmeds(self.bv, self.wpt, 100, 3.0, self.K[0], self.K[1])   # a8 (host result)
         ok2, pose, outl2, info = ctx.pnp_refine(self.uv, self.wpt, self.pose0, self.K)       # a9 (host result)
@@ -93,6 +104,7 @@ class FrameJob:
         tracked, _ = ctx.fbklt_track(prev, cur, self.pts, self.pts, 3)
         desc, _ = ctx.describe(self.gray, tracked)
         stages = {
+            "detect_grid": lambda: ctx.detect_grid(self.gray, 12, max_quality=0.001),
             "gray+pyramid": lambda: cur.build_from_rgba(self.frames[2], self.gray),
             "fbklt": lambda: ctx.fbklt_track(prev, cur, self.pts, self.pts, 3),
             "describe(blur7+brief)": lambda: ctx.describe(self.gray, tracked),
@@ -146,7 +158,10 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
         k = 1 + n % 3
         g = O.rgba2gray(frames[k])
         tracked, st = O.fbklt(prev, g, pts, pts, 3)        # builds both pyramids internally (the reference reuses prev's)
-        desc, _ = O.describe(g, tracked)
+        det, _ = O.detect_grid(g, 12)
+        dpts = pts.copy()
+        dpts[:min(len(det), NKP)] = det[:NKP]
+        desc, _ = O.describe(g, dpts)
         O.bf_match(desc, prev_desc)
         O.p3p_lmeds(pb["bv"], pb["wpt"])
         O.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"])
@@ -159,7 +174,7 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
     r = O.local_ba(pbba, 5, 0.0)
     dtb = time.perf_counter() - t1
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{n} frames of the same 640x480 / {NKP}-keypoint step (gray, 2 LK pyramids, fb-KLT 3 lvl, ORB describe, "
+            "sample": f"{n} frames of the same 640x480 / {NKP}-keypoint step (gray, 2 LK pyramids, fb-KLT 3 lvl, grid detect cell 12, ORB describe, "
                       f"BF Hamming {NKP}^2, P3P-LMedS 100 it, Ceres PnP) + 1 local-BA solve",
             "local_ba_residual_block_iters_per_s": len(pbba["obs_kf"]) * (int(r["info"][0]) - 1) / dtb,
             "local_ba_ms": dtb * 1e3}
@@ -208,9 +223,9 @@ def main():
         ba, _ = bench_ba(job.ctx)
         P = W * H
         # ALGORITHMIC bytes per launch chain: rgba->gray 5P + pyramid/Scharr 6.64P
-        alg_bytes = {"gray+pyramid": (4 + 1 + 6.64) * P, "describe(blur7+brief)": 2 * P + 40 * NKP,
+        alg_bytes = {"detect_grid": P + 4 * P + 8 * NKP, "gray+pyramid": (4 + 1 + 6.64) * P, "describe(blur7+brief)": 2 * P + 40 * NKP,
                      "fbklt": 2 * 6.64 * P + 24 * NKP, "bf_hamming": 32 * 2 * NKP + 8 * NKP}
-        dom = max(("gray+pyramid", "fbklt", "describe(blur7+brief)", "bf_hamming"), key=lambda k: stage_us[k])
+        dom = max(("detect_grid", "gray+pyramid", "fbklt", "describe(blur7+brief)", "bf_hamming"), key=lambda k: stage_us[k])
         achieved = alg_bytes[dom] / (stage_us[dom] * 1e-6) / 1e9
         out = {
             "metric": "frames/sec @640x480 2000kp; local-BA residuals/sec (20KFx3k pts)",
@@ -218,9 +233,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 image stages, f32 KLT, f64 pose+BA", "data": "synthetic",
             "config": {"workload": "c640_track: 640x480 RGBA stream, 2120 kp/frame",
-                       "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels)", "orb_describe", "bf_hamming 2120x2120",
-                                  "p3p_lmeds(100)", "pnp_refine(5 it)"],
-                       "not_in_timed_region": ["keypoint detection (grid Shi-Tomasi / FAST-ORB): not implemented yet in this commit"],
+                       "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels)", "detect_grid(cell 12)+cornerSubPix", "orb_describe",
+                                  "bf_hamming 2120x2120", "p3p_lmeds(100)", "pnp_refine(5 it)"],
+                       "not_in_timed_region": [],
                        "parallelism": f"{world} independent streams, one per GPU, no collective"},
             "local_ba": ba,
             "stage_us": stage_us,
