@@ -232,39 +232,44 @@ __device__ __forceinline__ int tri6(int x, int y) {
 }
 
 // F'F, F'r from the pair sums; Jacobi scaling at iteration 0; gradient max-norm; cost.
+// With M[c][a] = sum over observations (cam c, anchor a) of [J'J (21) | J'r (6)]:
+//   F'F(c,c) = sum_a M[c][a] + sum_c' M[c'][c]      F'F(c,a) = -(M[c][a] + M[a][c])  (c != a)
+//   F'r(c)   = sum_a m[c][a] - sum_c' m[c'][c]       (J_anchor = -J_obs).  XYZ mode: only M[c][c].
 __global__ void __launch_bounds__(256) k_assemble(BaDev B, int first) {
     const int n6 = B.n6, nKf = B.nKf;
+    extern __shared__ double s_sum[];  // [nKf][27] row sums | [nKf][27] column sums
     __shared__ double s_red[256];
     __shared__ int s_kf[256];  // free index -> keyframe id
+    double *rowsum = s_sum, *colsum = s_sum + nKf * 27;
     for (int k = threadIdx.x; k < nKf; k += 256)
         if (B.cidx[k] >= 0 && B.cidx[k] < 256) s_kf[B.cidx[k]] = k;
+    for (int e = threadIdx.x; e < nKf * 27; e += 256) {
+        const int k = e / 27, t = e % 27;
+        double rs = 0, cs = 0;
+        for (int j = 0; j < nKf; j++) {
+            rs += B.M[(size_t) (k * nKf + j) * 27 + t];
+            cs += B.M[(size_t) (j * nKf + k) * 27 + t];
+        }
+        rowsum[e] = rs;
+        colsum[e] = cs;
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < n6 * n6; e += 256) {
         const int r = e / n6, c = e % n6, cr = r / 6, cc = c / 6, x = r % 6, y = c % 6;
         const int kr = s_kf[cr], kc = s_kf[cc];
-        double v = 0;
         const int t = tri6(x, y);
+        double v = 0;
         if (B.inv) {
-            if (kr == kc) {
-                for (int k = 0; k < nKf; k++) v += B.M[(size_t) (kr * nKf + k) * 27 + t] + B.M[(size_t) (k * nKf + kr) * 27 + t];
-            } else {
-                v = -(B.M[(size_t) (kr * nKf + kc) * 27 + t] + B.M[(size_t) (kc * nKf + kr) * 27 + t]);
-            }
+            if (kr == kc) v = rowsum[kr * 27 + t] + colsum[kr * 27 + t];
+            else v = -(B.M[(size_t) (kr * nKf + kc) * 27 + t] + B.M[(size_t) (kc * nKf + kr) * 27 + t]);
         } else {
             if (kr == kc) v = B.M[(size_t) (kr * nKf + kr) * 27 + t];
         }
         B.Hcc[e] = v;
     }
     for (int r = threadIdx.x; r < n6; r += 256) {
-        const int cr = r / 6, x = r % 6;
-        const int kr = s_kf[cr];
-        double v = 0;
-        if (B.inv) {
-            for (int k = 0; k < nKf; k++) v += B.M[(size_t) (kr * nKf + k) * 27 + 21 + x] - B.M[(size_t) (k * nKf + kr) * 27 + 21 + x];
-        } else {
-            v = B.M[(size_t) (kr * nKf + kr) * 27 + 21 + x];
-        }
-        B.gc[r] = v;
+        const int kr = s_kf[r / 6], x = r % 6;
+        B.gc[r] = B.inv ? rowsum[kr * 27 + 21 + x] - colsum[kr * 27 + 21 + x] : B.M[(size_t) (kr * nKf + kr) * 27 + 21 + x];
     }
     __syncthreads();
     if (first) {
@@ -390,14 +395,15 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 }
 
 // S = S_c F'F S_c + D_c^2/radius - G ; rhs = S_c F'r - G[:, n6] ; dense Cholesky; y_c.  One workgroup.
+constexpr int SOLVE_NT = 1024;
 template<bool IN_LDS>
-__global__ void __launch_bounds__(256) k_solve(BaDev B, double radius) {
+__global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
     extern __shared__ double s_S[];
     const int n = B.n6;
     __shared__ double s_piv;
     __shared__ int s_ok;
     double *S = IN_LDS ? s_S : B.S;  // the reduced camera matrix lives in LDS (n <= 140: n^2 * 8 B <= 157 KB)
-    for (int e = threadIdx.x; e < n * n; e += 256) {
+    for (int e = threadIdx.x; e < n * n; e += SOLVE_NT) {
         const int r = e / n, c = e % n;
         double g = 0;
         for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + c];
@@ -405,7 +411,7 @@ __global__ void __launch_bounds__(256) k_solve(BaDev B, double radius) {
         if (r == c) v += B.dc[r] / radius;
         S[e] = v;
     }
-    for (int r = threadIdx.x; r < n; r += 256) {
+    for (int r = threadIdx.x; r < n; r += SOLVE_NT) {
         double g = 0;
         for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + n];
         B.yc[r] = B.gc[r] * B.sc[r] - g;
@@ -424,33 +430,57 @@ __global__ void __launch_bounds__(256) k_solve(BaDev B, double radius) {
         __syncthreads();
         if (!s_ok) break;
         const double piv = s_piv;
-        for (int i = j + 1 + threadIdx.x; i < n; i += 256) S[(size_t) i * n + j] /= piv;
+        for (int i = j + 1 + threadIdx.x; i < n; i += SOLVE_NT) S[(size_t) i * n + j] /= piv;
         __syncthreads();
-        const int m = n - j - 1;
-        // trailing update of the lower triangle: element (a, b), b <= a
-        for (int e = threadIdx.x; e < m * m; e += 256) {
-            const int a = j + 1 + e / m, b = j + 1 + e % m;
-            if (b <= a) S[(size_t) a * n + b] -= S[(size_t) a * n + j] * S[(size_t) b * n + j];
+        // trailing update of the lower triangle on a 32 x 32 thread grid (no integer division in the loop)
+        const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+        for (int a = j + 1 + ty; a < n; a += 32) {
+            const double la = S[(size_t) a * n + j];
+            for (int b = j + 1 + tx; b <= a; b += 32) S[(size_t) a * n + b] -= la * S[(size_t) b * n + j];
         }
         __syncthreads();
     }
-    if (s_ok) {
-        // forward substitution L z = rhs (column-oriented: after z_i is final, every lane updates its rows)
-        for (int i = 0; i < n; i++) {
-            if (threadIdx.x == 0) B.yc[i] = B.yc[i] / S[(size_t) i * n + i];
-            __syncthreads();
-            const double zi = B.yc[i];
-            for (int k = i + 1 + threadIdx.x; k < n; k += 256) B.yc[k] -= S[(size_t) k * n + i] * zi;
-            __syncthreads();
+    if (s_ok && threadIdx.x < 64) {
+        // triangular solves on ONE wave, no barriers: y lives in registers (lane l owns rows l, l+64, ...), each row
+        // is a lane-parallel dot product against L (read-only now) followed by a wave reduction
+        constexpr int OWN = 4;  // n <= 256
+        const int lane = threadIdx.x;
+        double y[OWN];
+#pragma unroll
+        for (int q = 0; q < OWN; q++) y[q] = (lane + 64 * q < n) ? B.yc[lane + 64 * q] : 0.0;
+        for (int i = 0; i < n; i++) {  // L z = rhs
+            double part = 0;
+#pragma unroll
+            for (int q = 0; q < OWN; q++) {
+                const int k = lane + 64 * q;
+                if (k < i) part += S[(size_t) i * n + k] * y[q];
+            }
+            const double sum = wave_sum(part);
+            const int qi = i >> 6;
+            const double rhs_i = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63);
+            const double zi = (rhs_i - sum) / S[(size_t) i * n + i];
+#pragma unroll
+            for (int q = 0; q < OWN; q++)
+                if (q == qi && lane == (i & 63)) y[q] = zi;
         }
-        // backward substitution L' y = z
-        for (int i = n - 1; i >= 0; i--) {
-            if (threadIdx.x == 0) B.yc[i] = B.yc[i] / S[(size_t) i * n + i];
-            __syncthreads();
-            const double yi = B.yc[i];
-            for (int k = threadIdx.x; k < i; k += 256) B.yc[k] -= S[(size_t) i * n + k] * yi;
-            __syncthreads();
+        for (int i = n - 1; i >= 0; i--) {  // L' y = z
+            double part = 0;
+#pragma unroll
+            for (int q = 0; q < OWN; q++) {
+                const int k = lane + 64 * q;
+                if (k > i && k < n) part += S[(size_t) k * n + i] * y[q];
+            }
+            const double sum = wave_sum(part);
+            const int qi = i >> 6;
+            const double zi = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63);
+            const double yi = (zi - sum) / S[(size_t) i * n + i];
+#pragma unroll
+            for (int q = 0; q < OWN; q++)
+                if (q == qi && lane == (i & 63)) y[q] = yi;
         }
+#pragma unroll
+        for (int q = 0; q < OWN; q++)
+            if (lane + 64 * q < n) B.yc[lane + 64 * q] = y[q];
     }
     if (threadIdx.x == 0) B.scal[5] = s_ok ? 1.0 : 0.0;
 }
@@ -699,7 +729,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         hipLaunchKernelGGL(k_sum_cost, dim3(1), blk, 0, st, B);
         if (wantJ) {
             hipLaunchKernelGGL(k_pairs, dim3((unsigned) alva_divup(n_kf * n_kf, 4)), blk, 0, st, B);
-            hipLaunchKernelGGL(k_assemble, dim3(1), blk, 0, st, B, first ? 1 : 0);
+            hipLaunchKernelGGL(k_assemble, dim3(1), blk, (size_t) n_kf * 27 * 2 * sizeof(double), st, B, first ? 1 : 0);
         }
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
@@ -732,8 +762,8 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         const int tiles = B.NP / 16;
         hipLaunchKernelGGL(k_gemm, dim3((unsigned) (tiles * tiles), KSPLIT), dim3(64), 0, st, B);
-        if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), blk, n6 * n6 * sizeof(double), st, B, lm.radius);
-        else hipLaunchKernelGGL(k_solve<false>, dim3(1), blk, 0, st, B, lm.radius);
+        if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_NT), n6 * n6 * sizeof(double), st, B, lm.radius);
+        else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_NT), 0, st, B, lm.radius);
         if (n_pt > 0) {
             if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
             else hipLaunchKernelGGL(k_backsub<3>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);

@@ -173,27 +173,56 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     __syncthreads();
     const int cell = A.cell, n2 = cell * cell;
     const int T = (A.nCW - 1) + 2 * (A.nCH - 1);
-    for (int t = 0; t <= T; t++) {
-        // cells (r, c) with c + 2r == t
+    constexpr int PER_LANE = (MAX_CELL * MAX_CELL + 63) / 64;  // 25 values per lane at cell 40
+    float pre[PER_LANE];
+    // the cells a wave will visit are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16k), so
+    // the lambda_min values of the NEXT cell are fetched from HBM/L2 before the barrier that releases it: inside the
+    // dependent section only registers and the LDS mask are touched.
+    auto cell_of = [&](int t, int slot, int &r, int &c) -> bool {
         const int rmin = max(0, (t - (A.nCW - 1) + 1) / 2), rmax = min(A.nCH - 1, t / 2);
-        for (int r = rmin + wave; r <= rmax; r += nwaves) {
-            const int c = t - 2 * r;
-            if (c < 0 || c >= A.nCW) continue;
+        r = rmin + wave + slot * nwaves;
+        c = t - 2 * r;
+        return r <= rmax && c >= 0 && c < A.nCW;
+    };
+    auto usable = [&](int r, int c) -> bool {
+        const int ci = r * A.nCW + c;
+        return !A.cellOcc[ci] && (c * cell + cell < A.w - 1 && r * cell + cell < A.h - 1);
+    };
+    auto prefetch = [&](int r, int c) {
+        const float *eig = A.eig + (size_t) (r * A.nCW + c) * n2;
+#pragma unroll
+        for (int q = 0; q < PER_LANE; q++) {
+            const int k = lane + 64 * q;
+            pre[q] = k < n2 ? eig[k] : 0.f;
+        }
+    };
+    {
+        int r, c;
+        if (cell_of(0, 0, r, c) && usable(r, c)) prefetch(r, c);
+    }
+    for (int t = 0; t <= T; t++) {
+        for (int slot = 0;; slot++) {
+            int r, c;
+            if (!cell_of(t, slot, r, c)) break;
             const int ci = r * A.nCW + c;
             int prim = -1, sec = -1;
             const int x0 = c * cell, y0 = r * cell;
-            if (!A.cellOcc[ci] && (x0 + cell < A.w - 1 && y0 + cell < A.h - 1)) {
-                const float *eig = A.eig + (size_t) ci * n2;
+            if (usable(r, c)) {
+                if (slot > 0) prefetch(r, c);  // more than 16 cells on this wavefront: fetch late (rare: only for nCH > 32)
                 for (int pass = 0; pass < 2; pass++) {
                     float best = -3.402823466e+38f;
                     int bi = 0x7fffffff;
-                    for (int k = lane; k < n2; k += 64) {
-                        const int x = x0 + k % cell, y = y0 + k / cell;
-                        const float m = (float) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
-                        const float v = eig[k] * m;
-                        if (v > best) {
-                            best = v;
-                            bi = k;
+#pragma unroll
+                    for (int q = 0; q < PER_LANE; q++) {
+                        const int k = lane + 64 * q;
+                        if (k < n2) {
+                            const int x = x0 + k % cell, y = y0 + k / cell;
+                            const float m = (float) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
+                            const float v = pre[q] * m;
+                            if (v > best) {
+                                best = v;
+                                bi = k;
+                            }
                         }
                     }
                     // wave arg-max: largest value, then smallest index (= first maximum of the row-major scan)
@@ -222,6 +251,11 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
                 A.prim[ci] = prim;
                 A.sec[ci] = sec;
             }
+        }
+        // prefetch this wave's first cell of the next wavefront while the others finish
+        {
+            int r, c;
+            if (t < T && cell_of(t + 1, 0, r, c) && usable(r, c)) prefetch(r, c);
         }
         __syncthreads();
     }
@@ -373,6 +407,7 @@ __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray,
     constexpr int WINH = 3, WW = 7, BW = WW + 2;
     __shared__ float s_buf[BW * BW];
     __shared__ float s_mask[WW * WW];
+    __shared__ double s_term[5][WW * WW + 1];
     const int lane = threadIdx.x;
     // exp(-(k/3)^2), k = 0..3, as glibc's expf returns them (the reference computes the mask with std::exp(float))
     const uint32_t ebits[4] = {0x3f800000u, 0x3f651430u, 0x3f242466u, 0x3ebc5ab2u};
@@ -391,24 +426,26 @@ __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray,
         __syncthreads();
         for (int e = lane; e < BW * BW; e += 64) s_buf[e] = subpix_at(g, gray, pitch, e / BW, e % BW, BW);
         __syncthreads();
-        // five sequential double accumulators, one lane each: a, b, c, bb1, bb2
+        // the 49 per-pixel terms are evaluated lane-parallel (one term per lane) into LDS; lanes 0..4 then replay the
+        // reference's five sequential double accumulations a, b, c, bb1, bb2 in row-major order
+        if (lane < WW * WW) {
+            const int i = lane / WW, j = lane % WW;
+            const float *sp = s_buf + (i + 1) * BW + 1;
+            const double m = s_mask[lane];
+            const double tgx = (double) (sp[j + 1] - sp[j - 1]);
+            const double tgy = (double) (sp[j + BW] - sp[j - BW]);
+            const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m, px = j - WINH, py = i - WINH;
+            s_term[0][lane] = gxx;
+            s_term[1][lane] = gxy;
+            s_term[2][lane] = gyy;
+            s_term[3][lane] = gxx * px + gxy * py;
+            s_term[4][lane] = gxy * px + gyy * py;
+        }
+        __syncthreads();
         double acc = 0;
         if (lane < 5) {
-            for (int i = 0, k = 0; i < WW; i++) {
-                const float *sp = s_buf + (i + 1) * BW + 1;
-                const double py = i - WINH;
-                for (int j = 0; j < WW; j++, k++) {
-                    const double m = s_mask[k];
-                    const double tgx = (double) (sp[j + 1] - sp[j - 1]);
-                    const double tgy = (double) (sp[j + BW] - sp[j - BW]);
-                    const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m, px = j - WINH;
-                    if (lane == 0) acc += gxx;
-                    else if (lane == 1) acc += gxy;
-                    else if (lane == 2) acc += gyy;
-                    else if (lane == 3) acc += gxx * px + gxy * py;
-                    else acc += gxy * px + gyy * py;
-                }
-            }
+#pragma unroll 7
+            for (int k = 0; k < WW * WW; k++) acc += s_term[lane][k];
         }
         const double a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2), bb1 = __shfl(acc, 3), bb2 = __shfl(acc, 4);
         const double det = a * c - b * b;

@@ -149,6 +149,42 @@ ALVA_HD bool chol_solve_dense(double *A, double *b, int n) {
     return true;
 }
 
+// Fixed-size variant with every loop unrolled so that A and b stay in registers (no scratch / LDS round trips).
+template<int N>
+ALVA_HD bool chol_solve_fixed(double (&A)[N * N], double (&b)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = A[j * N + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j * N + k] * A[j * N + k];
+        if (!(d > 0)) return false;
+        d = sqrt(d);
+        A[j * N + j] = d;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double s = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i * N + k] * A[j * N + k];
+            A[i * N + j] = s / d;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= A[i * N + k] * b[k];
+        b[i] = s / A[i * N + i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) s -= A[k * N + i] * b[k];
+        b[i] = s / A[i * N + i];
+    }
+    return true;
+}
+
 // Ceres LevenbergMarquardtStrategy state (levenberg_marquardt_strategy.cc:48-160)
 struct LmState {
     double radius = 1e4, decrease_factor = 2.0;

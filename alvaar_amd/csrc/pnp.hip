@@ -139,30 +139,42 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
                 flag = F_DONE;
             } else {
                 iteration++;
-                double *Hs = sh.Hs, *gs = sh.gs, *M = sh.M, *y = sh.y;
+                // everything below is straight-line code on registers (all loops unrolled, constant indices)
+                double Hr[36], gr[6], sc[6], Mr[36], yr[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++) sc[a] = scale[a];
+#pragma unroll
                 for (int a = 0; a < 6; a++) {
-                    gs[a] = g[a] * scale[a];
-                    for (int b = 0; b < 6; b++) Hs[6 * a + b] = H[6 * a + b] * scale[a] * scale[b];
+                    gr[a] = g[a] * sc[a];
+#pragma unroll
+                    for (int b = 0; b < 6; b++) Hr[6 * a + b] = H[6 * a + b] * sc[a] * sc[b];
                 }
-                if (!lm.reuse_diagonal)
-                    for (int a = 0; a < 6; a++) diag[a] = fmin(fmax(Hs[7 * a], 1e-6), 1e32);
-                for (int k = 0; k < 36; k++) M[k] = Hs[k];
+                if (!lm.reuse_diagonal) {
+#pragma unroll
+                    for (int a = 0; a < 6; a++) diag[a] = fmin(fmax(Hr[7 * a], 1e-6), 1e32);
+                }
+#pragma unroll
+                for (int k = 0; k < 36; k++) Mr[k] = Hr[k];
+#pragma unroll
                 for (int a = 0; a < 6; a++) {
-                    M[7 * a] += diag[a] / lm.radius;
-                    y[a] = gs[a];
+                    Mr[7 * a] += diag[a] / lm.radius;
+                    yr[a] = gr[a];
                 }
-                const bool okstep = chol_solve_dense(M, y, 6);
+                const bool okstep = chol_solve_fixed<6>(Mr, yr);
                 lm.reuse_diagonal = 1;
                 double *step = sh.step;
                 mcc = 0;
                 if (okstep) {
                     double sg = 0, sHs = 0;
+#pragma unroll
                     for (int a = 0; a < 6; a++) {
-                        step[a] = -y[a];
-                        sg += step[a] * gs[a];
+                        step[a] = -yr[a];
+                        sg += -yr[a] * gr[a];
                     }
+#pragma unroll
                     for (int a = 0; a < 6; a++)
-                        for (int b = 0; b < 6; b++) sHs += step[a] * Hs[6 * a + b] * step[b];
+#pragma unroll
+                        for (int b = 0; b < 6; b++) sHs += yr[a] * Hr[6 * a + b] * yr[b];
                     mcc = -sg - 0.5 * sHs;  // = -(J s)'(f + J s / 2), trust_region_minimizer.cc:419-431
                 }
                 if (!okstep || !(mcc > 0)) {
