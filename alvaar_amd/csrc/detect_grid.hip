@@ -159,11 +159,14 @@ __device__ __forceinline__ void clear_circle(uint32_t *mask, int wordsPerRow, in
     }
 }
 
+template<int PER_LANE>
 __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     extern __shared__ uint32_t smask[];
     const int wordsPerRow = (A.w + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = 16;
+    uint8_t *s_occ = reinterpret_cast<uint8_t *>(smask + wordsPerRow * A.h);  // per-cell occupied flags, LDS copy
     for (int i = threadIdx.x; i < wordsPerRow * A.h; i += 1024) smask[i] = 0xffffffffu;
+    for (int i = threadIdx.x; i < A.nCW * A.nCH; i += 1024) s_occ[i] = A.cellOcc[i];
     __syncthreads();
     // pre-zero circles of the occupied keypoints, centre = Point(cvRound(px)) (:32-36)
     for (int k = wave; k < A.nOcc; k += nwaves) {
@@ -173,8 +176,14 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     __syncthreads();
     const int cell = A.cell, n2 = cell * cell;
     const int T = (A.nCW - 1) + 2 * (A.nCH - 1);
-    constexpr int PER_LANE = (MAX_CELL * MAX_CELL + 63) / 64;  // 25 values per lane at cell 40
+    // PER_LANE = ceil(cell^2 / 64) values per lane (3 at cell 12, 25 at cell 40); their in-cell offsets are fixed
     float pre[PER_LANE];
+    int offs[PER_LANE];  // (dy << 8) | dx of element lane + 64 q, or -1 past the end of the cell
+#pragma unroll
+    for (int q = 0; q < PER_LANE; q++) {
+        const int k = lane + 64 * q;
+        offs[q] = k < n2 ? (((k / cell) << 8) | (k % cell)) : -1;
+    }
     // the cells a wave will visit are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16k), so
     // the lambda_min values of the NEXT cell are fetched from HBM/L2 before the barrier that releases it: inside the
     // dependent section only registers and the LDS mask are touched.
@@ -186,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     };
     auto usable = [&](int r, int c) -> bool {
         const int ci = r * A.nCW + c;
-        return !A.cellOcc[ci] && (c * cell + cell < A.w - 1 && r * cell + cell < A.h - 1);
+        return !s_occ[ci] && (c * cell + cell < A.w - 1 && r * cell + cell < A.h - 1);
     };
     auto prefetch = [&](int r, int c) {
         const float *eig = A.eig + (size_t) (r * A.nCW + c) * n2;
@@ -214,14 +223,13 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
                     int bi = 0x7fffffff;
 #pragma unroll
                     for (int q = 0; q < PER_LANE; q++) {
-                        const int k = lane + 64 * q;
-                        if (k < n2) {
-                            const int x = x0 + k % cell, y = y0 + k / cell;
+                        if (offs[q] >= 0) {
+                            const int x = x0 + (offs[q] & 255), y = y0 + (offs[q] >> 8);
                             const float m = (float) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
                             const float v = pre[q] * m;
                             if (v > best) {
                                 best = v;
-                                bi = k;
+                                bi = lane + 64 * q;
                             }
                         }
                     }
@@ -485,8 +493,6 @@ void circle_halfwidths(int radius, int *hw) {  // drawing.cpp:1477-1617 (Circle,
     }
 }
 
-bool g_attr_set = false;
-
 }  // namespace
 
 extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int cell_size,
@@ -528,13 +534,22 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     if (n_occ > 0) hipLaunchKernelGGL(k_mark_occupied, dim3(alva_divup(n_occ, 256)), dim3(256), 0, st, A);
     const size_t lds_eig = (size_t) n2 * (4 + 4 + 8 + 12 + 1) + (size_t) (cell_size + 2) * (cell_size + 2) + 64;
     hipLaunchKernelGGL(k_cell_eig, dim3(nCells), dim3(256), lds_eig, st, A);
-    const size_t lds_mask = (size_t) ((width + 31) / 32) * height * 4;
+    const size_t lds_mask = (size_t) ((width + 31) / 32) * height * 4 + (size_t) nCells + 16;
     ALVA_ARG(lds_mask <= 160 * 1024 - 1024);
-    if (!g_attr_set || lds_mask > 48 * 1024) {
-        ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        g_attr_set = true;
-    }
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_mask, st, A);
+    const int per_lane = (n2 + 63) / 64;
+#define ALVA_SELECT(PL)                                                                                                          \
+    do {                                                                                                                         \
+        if (lds_mask > 48 * 1024)                                                                                                \
+            ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select<PL>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         160 * 1024 - 1024));                                                                   \
+        hipLaunchKernelGGL(k_select<PL>, dim3(1), dim3(1024), lds_mask, st, A);                                                  \
+    } while (0)
+    if (per_lane <= 3) ALVA_SELECT(3);
+    else if (per_lane <= 4) ALVA_SELECT(4);
+    else if (per_lane <= 9) ALVA_SELECT(9);
+    else if (per_lane <= 16) ALVA_SELECT(16);
+    else ALVA_SELECT(25);
+#undef ALVA_SELECT
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, A, d_out_pts, cap, d_cnt);
     ALVA_LAUNCH_CHECK();
     // one wave per candidate slot; the kernel reads the actual count from device memory (no host round trip before it)
