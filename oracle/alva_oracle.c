@@ -1797,3 +1797,305 @@ int orc_detect_grid(const uint8_t *gray, int w, int h, int cell, const float *oc
     free(hw); free(mask); free(occ); free(eig); free(prim); free(sec); free(hasP); free(hasS); free(all);
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * a5' -- cv::FAST (TYPE_9_16, NMS) and cv::ORB::detectAndCompute, the north_star-named detector.
+ * FAST: src/libs/opencv/modules/features2d/src/fast.cpp:56-292; score: fast_score.cpp:120-;
+ * ORB: orb.cpp:784-959 (computeKeyPoints), :130-177 (HarrisResponses), :181-215 (ICAngles),
+ * :970-1218 (detectAndCompute), keypoint.cpp:55-117 (retainBest, runByImageBorder),
+ * imgproc/src/resize.cpp:733-900 (INTER_LINEAR_EXACT), core/src/mathfuncs_core.simd.hpp:34-71 (fastAtan2,
+ * polynomial form -- the wasm build substitutes libm atan2, mathfuncs_core.simd.hpp:39-48). */
+static const int fast_off16[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                                      {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+/* returns 0 if not a corner at `threshold`, else the FAST score (max threshold keeping it a corner), >= 1 */
+static int fast_corner_score(const uint8_t *p, int stride, int threshold) {
+    int d[25], v = p[0];
+    for (int k = 0; k < 25; k++) d[k] = v - p[fast_off16[k % 16][0] + fast_off16[k % 16][1] * stride];
+    int is = 0;
+    for (int dir = 0; dir < 2 && !is; dir++) {
+        int count = 0;
+        for (int k = 0; k < 25; k++) {
+            int c = dir == 0 ? (d[k] > threshold) : (d[k] < -threshold); /* darker ring (x < v - t) or brighter ring */
+            if (c) {
+                if (++count > 8) { is = 1; break; }
+            } else count = 0;
+        }
+    }
+    if (!is) return 0;
+    /* cornerScore<16>: max over the 16 arcs of 9 of min(d) and of min(-d), floor at threshold, minus 1 */
+    int a0 = threshold;
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+        for (int j = 1; j < 9; j++) {
+            int e = d[(k + j) % 16];
+            if (e < mn) mn = e;
+            if (e > mx) mx = e;
+        }
+        if (mn > a0) a0 = mn;
+        if (-mx > a0) a0 = -mx;
+    }
+    return a0 - 1;
+}
+
+/* score map (0 = no corner) for rows/cols 3..size-4, then 3x3 strict NMS; keypoints in row-major order */
+static int fast_detect(const uint8_t *img, int stride, int w, int h, int threshold, int *xy, int *score, int cap, uint8_t *scratch) {
+    uint8_t *sc = scratch;
+    memset(sc, 0, (size_t) w * h);
+    if (threshold < 0) threshold = 0;
+    if (threshold > 255) threshold = 255;
+    for (int y = 3; y < h - 3; y++)
+        for (int x = 3; x < w - 3; x++) sc[(size_t) y * w + x] = (uint8_t) fast_corner_score(img + (size_t) y * stride + x, stride, threshold);
+    int n = 0;
+    for (int y = 3; y < h - 3; y++)
+        for (int x = 3; x < w - 3; x++) {
+            int s = sc[(size_t) y * w + x];
+            if (!s) continue;
+            const uint8_t *q = sc + (size_t) y * w + x;
+            if (s > q[-1] && s > q[1] && s > q[-w - 1] && s > q[-w] && s > q[-w + 1] && s > q[w - 1] && s > q[w] && s > q[w + 1]) {
+                if (n < cap) {
+                    xy[2 * n] = x;
+                    xy[2 * n + 1] = y;
+                    score[n] = s;
+                }
+                n++;
+            }
+        }
+    return n;
+}
+
+int orc_fast(const uint8_t *gray, int w, int h, int threshold, int *xy, int *score, int cap) {
+    uint8_t *scratch = (uint8_t *) malloc((size_t) w * h);
+    int n = fast_detect(gray, w, w, h, threshold, xy, score, cap, scratch);
+    free(scratch);
+    return n;
+}
+
+/* resize(prev, cur, sz, 0, 0, INTER_LINEAR_EXACT) for 8UC1: ufixedpoint16 (8 fractional bits) taps from
+ * fval = scale*(d + 0.5) - 0.5 in IEEE double (softdouble), rows then columns, (v + 2^15) >> 16 */
+static void resize_linear_exact(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh) {
+    int *xo = (int *) malloc(sizeof(int) * (size_t) dw), *yo = (int *) malloc(sizeof(int) * (size_t) dh);
+    int *xc = (int *) malloc(sizeof(int) * (size_t) dw), *yc = (int *) malloc(sizeof(int) * (size_t) dh);
+    for (int pass = 0; pass < 2; pass++) {
+        int dn = pass ? dh : dw, sn = pass ? sh : sw, *o = pass ? yo : xo, *c = pass ? yc : xc;
+        double inv_scale = (double) dn / sn;
+        volatile double scale = 1.0 / inv_scale;
+        for (int d = 0; d < dn; d++) {
+            volatile double t = (double) d + 0.5;
+            volatile double m = scale * t;
+            volatile double fval = m - 0.5;
+            int ival = (int) floor(fval);
+            if (ival >= 0 && sn > 1) {
+                if (ival < sn - 1) {
+                    o[d] = ival;
+                    volatile double fr = fval - (double) ival;
+                    c[d] = (int) lrint(fr * 256.0); /* coeffs[1]; coeffs[0] = 256 - coeffs[1] */
+                } else {
+                    o[d] = sn - 1;
+                    c[d] = -2; /* >= max: copies the last source element */
+                }
+            } else {
+                o[d] = 0;
+                c[d] = -1; /* < min: copies the first source element */
+            }
+        }
+    }
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int rows[2], nr = 0, rc[2];
+            if (yc[y] == -1) { rows[0] = 0; rc[0] = 256; nr = 1; }
+            else if (yc[y] == -2) { rows[0] = sh - 1; rc[0] = 256; nr = 1; }
+            else { rows[0] = yo[y]; rows[1] = yo[y] + 1; rc[0] = 256 - yc[y]; rc[1] = yc[y]; nr = 2; }
+            unsigned acc = 0;
+            for (int k = 0; k < nr; k++) {
+                const uint8_t *r = src + (size_t) rows[k] * sw;
+                unsigned hv; /* ufixedpoint16 raw */
+                if (xc[x] == -1) hv = (unsigned) r[0] << 8;
+                else if (xc[x] == -2) hv = (unsigned) r[sw - 1] << 8;
+                else hv = (unsigned) (256 - xc[x]) * r[xo[x]] + (unsigned) xc[x] * r[xo[x] + 1];
+                acc += (unsigned) rc[k] * hv;
+            }
+            unsigned v = (acc + 32768u) >> 16;
+            dst[(size_t) y * dw + x] = (uint8_t) (v > 255 ? 255 : v);
+        }
+    free(xo); free(yo); free(xc); free(yc);
+}
+
+static float fast_atan2f(float y, float x) { /* core/src/mathfuncs_core.simd.hpp:34-71 */
+    const float s = (float) (180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    volatile float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    const float eps = (float) 2.2204460492503131e-16;
+    if (ax >= ay) {
+        volatile float den = ax + eps;
+        c = ay / den;
+        c2 = c * c;
+        volatile float t = p7 * c2; t = t + p5; t = t * c2; t = t + p3; t = t * c2; t = t + p1;
+        a = t * c;
+    } else {
+        volatile float den = ay + eps;
+        c = ax / den;
+        c2 = c * c;
+        volatile float t = p7 * c2; t = t + p5; t = t * c2; t = t + p3; t = t * c2; t = t + p1;
+        volatile float u = t * c;
+        a = 90.f - u;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+typedef struct { int x, y; float resp; } orc_cand;
+
+/* retainBest: keep everything with response >= the n-th largest (keypoint.cpp:69-90); stable order */
+static int retain_best(orc_cand *c, int n, int keep) {
+    if (keep < 0 || n <= keep) return n;
+    if (keep == 0) return 0;
+    float *tmp = (float *) malloc(sizeof(float) * (size_t) n);
+    for (int i = 0; i < n; i++) tmp[i] = c[i].resp;
+    /* n-th largest by simple selection (test infrastructure: clarity over speed) */
+    for (int i = 0; i < keep; i++) {
+        int b = i;
+        for (int j = i + 1; j < n; j++)
+            if (tmp[j] > tmp[b]) b = j;
+        float t = tmp[i]; tmp[i] = tmp[b]; tmp[b] = t;
+    }
+    float thr = tmp[keep - 1];
+    free(tmp);
+    int m = 0;
+    for (int i = 0; i < n; i++)
+        if (c[i].resp >= thr) c[m++] = c[i];
+    return m;
+}
+
+int orc_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures, float scaleFactorF, int nlevels, int fastThreshold,
+                               int doDescribe, float *kp /* [cap][6] */, uint8_t *desc, int cap) {
+    double scaleFactor = (double) scaleFactorF;
+    /* orb.cpp:799-813 */
+    int *nPer = (int *) malloc(sizeof(int) * (size_t) nlevels);
+    {
+        float factor = (float) (1.0 / scaleFactor);
+        volatile float num = (float) nfeatures * (1 - factor);
+        volatile float den = 1 - (float) pow((double) factor, (double) nlevels);
+        float nd = num / den;
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; l++) {
+            nPer[l] = cv_round_f(nd);
+            sum += nPer[l];
+            volatile float t = nd * factor;
+            nd = t;
+        }
+        nPer[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    }
+    /* umax, :819-834 */
+    int umax[17];
+    {
+        const int hp = 15;
+        int vmax = (int) floorf(hp * sqrtf(2.f) / 2 + 1), vmin = (int) ceilf(hp * sqrtf(2.f) / 2);
+        for (int v = 0; v <= vmax; v++) umax[v] = (int) lrint(sqrt((double) hp * hp - v * v));
+        for (int v = hp, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+    }
+    uint8_t **lv = (uint8_t **) calloc((size_t) nlevels, sizeof(uint8_t *));
+    int *lw = (int *) malloc(sizeof(int) * (size_t) nlevels), *lh = (int *) malloc(sizeof(int) * (size_t) nlevels);
+    float *lscale = (float *) malloc(sizeof(float) * (size_t) nlevels);
+    for (int l = 0; l < nlevels; l++) { /* :1041-1058, :1070-1112 */
+        lscale[l] = (float) pow(scaleFactor, (double) l);
+        float inv = 1.0f / lscale[l];
+        lw[l] = cv_round_f((float) w * inv);
+        lh[l] = cv_round_f((float) h * inv);
+        lv[l] = (uint8_t *) malloc((size_t) lw[l] * lh[l]);
+        if (l == 0) memcpy(lv[0], gray, (size_t) w * h);
+        else resize_linear_exact(lv[l - 1], lw[l - 1], lh[l - 1], lv[l], lw[l], lh[l]);
+    }
+    int total = 0;
+    const float hk = 0.04f;
+    volatile float hscale = 1.f / ((1 << 2) * 7 * 255.f);
+    volatile float hs2 = hscale * hscale;
+    volatile float hs3 = hs2 * hscale;
+    const float scale_sq_sq = hs3 * hscale;
+    for (int l = 0; l < nlevels; l++) {
+        int W = lw[l], H = lh[l], capL = W * H / 4 + 16;
+        int *xy = (int *) malloc(sizeof(int) * 2 * (size_t) capL), *sc = (int *) malloc(sizeof(int) * (size_t) capL);
+        uint8_t *scratch = (uint8_t *) malloc((size_t) W * H);
+        int n = fast_detect(lv[l], W, W, H, fastThreshold, xy, sc, capL, scratch);
+        if (n > capL) n = capL;
+        orc_cand *c = (orc_cand *) malloc(sizeof(orc_cand) * (size_t) (n + 1));
+        int m = 0;
+        if (H > 62 && W > 62)
+            for (int i = 0; i < n; i++) /* runByImageBorder(31) */
+                if (xy[2 * i] >= 31 && xy[2 * i] < W - 31 && xy[2 * i + 1] >= 31 && xy[2 * i + 1] < H - 31) {
+                    c[m].x = xy[2 * i];
+                    c[m].y = xy[2 * i + 1];
+                    c[m].resp = (float) sc[i];
+                    m++;
+                }
+        m = retain_best(c, m, 2 * nPer[l]);
+        for (int i = 0; i < m; i++) { /* HarrisResponses, block 7 */
+            int a = 0, b = 0, cc = 0;
+            for (int k = 0; k < 49; k++) {
+                const uint8_t *p = lv[l] + (size_t) (c[i].y - 3 + k / 7) * W + (c[i].x - 3 + k % 7);
+                int Ix = (p[1] - p[-1]) * 2 + (p[-W + 1] - p[-W - 1]) + (p[W + 1] - p[W - 1]);
+                int Iy = (p[W] - p[-W]) * 2 + (p[W - 1] - p[-W - 1]) + (p[W + 1] - p[-W + 1]);
+                a += Ix * Ix;
+                b += Iy * Iy;
+                cc += Ix * Iy;
+            }
+            volatile float fa = (float) a, fb = (float) b, fc = (float) cc;
+            volatile float t1 = fa * fb, t2 = fc * fc, s = fa + fb;
+            volatile float t3 = hk * s;
+            volatile float t4 = t3 * s;
+            volatile float d1 = t1 - t2;
+            volatile float d2 = d1 - t4;
+            c[i].resp = d2 * scale_sq_sq;
+        }
+        m = retain_best(c, m, nPer[l]);
+        uint8_t *blur = NULL;
+        if (doDescribe && m > 0) {
+            blur = (uint8_t *) malloc((size_t) W * H);
+            orc_orb_blur(lv[l], W, H, blur);
+        }
+        for (int i = 0; i < m; i++) {
+            const uint8_t *ctr = lv[l] + (size_t) c[i].y * W + c[i].x;
+            int m01 = 0, m10 = 0;
+            for (int u = -15; u <= 15; u++) m10 += u * ctr[u];
+            for (int v = 1; v <= 15; v++) {
+                int vs = 0, d = umax[v];
+                for (int u = -d; u <= d; u++) {
+                    int vp = ctr[u + v * W], vm = ctr[u - v * W];
+                    vs += vp - vm;
+                    m10 += u * (vp + vm);
+                }
+                m01 += v * vs;
+            }
+            float angle = fast_atan2f((float) m01, (float) m10);
+            if (total < cap) {
+                float *o = kp + 6 * (size_t) total;
+                volatile float sx = (float) c[i].x * lscale[l], sy = (float) c[i].y * lscale[l];
+                o[0] = sx;
+                o[1] = sy;
+                o[2] = 31 * lscale[l];
+                o[3] = angle;
+                o[4] = c[i].resp;
+                o[5] = (float) l;
+                if (doDescribe) {
+                    float inv = 1.f / lscale[l];
+                    volatile float bx = o[0] * inv, by = o[1] * inv;
+                    int cx = cv_round_f(bx), cy = cv_round_f(by);
+                    float ang = angle;
+                    ang *= (float) (3.1415926535897932384626433832795 / 180.f);
+                    float ca = (float) cos((double) ang), sa = (float) sin((double) ang);
+                    brief256(blur, W, cx, cy, ca, sa, desc + 32 * (size_t) total);
+                }
+            }
+            total++;
+        }
+        free(xy); free(sc); free(scratch); free(c); free(blur);
+    }
+    for (int l = 0; l < nlevels; l++) free(lv[l]);
+    free(lv); free(lw); free(lh); free(lscale); free(nPer);
+    return total;
+}

@@ -29,6 +29,11 @@ void orc_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n);
 int orc_detect_grid(const uint8_t *gray, int w, int h, int cell, const float *occupied, int nOcc, int roiX, int roiY, int roiW,
                     int roiH, double *maxQuality, float *outPts, int cap);
 
+/* a5' */
+int orc_fast(const uint8_t *gray, int w, int h, int threshold, int *xy, int *score, int cap);
+int orc_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures, float scaleFactor, int nlevels, int fastThreshold,
+                               int doDescribe, float *kp /* [cap][6] */, uint8_t *desc, int cap);
+
 /* a6 */
 void orc_orb_blur(const uint8_t *gray, int w, int h, uint8_t *out /* w*h */);
 void orc_describe(const uint8_t *gray, int w, int h, const float *pts, int n, uint8_t *desc /* n*32 */, uint8_t *valid);

@@ -80,6 +80,27 @@ class Orc:
     _pnp = "orc_pnp_refine"
 
     @classmethod
+    def fast(cls, gray, threshold=20, cap=200000):
+        h, w = gray.shape
+        xy = np.zeros((cap, 2), np.int32)
+        sc = np.zeros(cap, np.int32)
+        g = np.ascontiguousarray(gray)
+        if cls._pfx == "ref_":
+            n = ref_lib().ref_fast(_p(g), w, h, threshold, 1, _p(xy), _p(sc), cap)
+        else:
+            n = orc_lib().orc_fast(_p(g), w, h, threshold, _p(xy), _p(sc), cap)
+        return xy[:n].copy(), sc[:n].copy()
+
+    @classmethod
+    def orb(cls, gray, nfeatures=2000, scale=1.2, nlevels=8, fast_thr=20, describe=True, cap=20000):
+        h, w = gray.shape
+        kp = np.zeros((cap, 6), np.float32)
+        desc = np.zeros((cap, 32), np.uint8)
+        fn = getattr(cls._lib(), cls._pfx + "orb_detect_and_compute")
+        n = fn(_p(np.ascontiguousarray(gray)), w, h, nfeatures, _f(scale), nlevels, fast_thr, int(describe), _p(kp), _p(desc), cap)
+        return kp[:n].copy(), desc[:n].copy()
+
+    @classmethod
     def cell_mineig(cls, gray, x, y, cell):
         h, w = gray.shape
         blur = np.zeros((cell, cell), np.uint8)
@@ -225,6 +246,27 @@ class Ref:
     """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
     _pfx = "ref_"
     _pnp = "ref_ceres_pnp_nocap"
+
+    @classmethod
+    def fast(cls, gray, threshold=20, cap=200000):
+        h, w = gray.shape
+        xy = np.zeros((cap, 2), np.int32)
+        sc = np.zeros(cap, np.int32)
+        g = np.ascontiguousarray(gray)
+        if cls._pfx == "ref_":
+            n = ref_lib().ref_fast(_p(g), w, h, threshold, 1, _p(xy), _p(sc), cap)
+        else:
+            n = orc_lib().orc_fast(_p(g), w, h, threshold, _p(xy), _p(sc), cap)
+        return xy[:n].copy(), sc[:n].copy()
+
+    @classmethod
+    def orb(cls, gray, nfeatures=2000, scale=1.2, nlevels=8, fast_thr=20, describe=True, cap=20000):
+        h, w = gray.shape
+        kp = np.zeros((cap, 6), np.float32)
+        desc = np.zeros((cap, 32), np.uint8)
+        fn = getattr(cls._lib(), cls._pfx + "orb_detect_and_compute")
+        n = fn(_p(np.ascontiguousarray(gray)), w, h, nfeatures, _f(scale), nlevels, fast_thr, int(describe), _p(kp), _p(desc), cap)
+        return kp[:n].copy(), desc[:n].copy()
 
     @classmethod
     def cell_mineig(cls, gray, x, y, cell):

@@ -204,3 +204,28 @@ def test_detect_grid_bit_exact(w, h, cell, seed, nocc):
         assert op.shape == rp.shape and len(rp) > 0
         assert np.array_equal(op.view(np.uint32), rp.view(np.uint32))
         mq = rmq
+
+
+@pytest.mark.parametrize("w,h,seed,thr", [(640, 480, 1, 20), (200, 120, 2, 10), (1280, 720, 3, 20), (64, 48, 4, 5)])
+def test_fast_bit_exact(w, h, seed, thr):
+    g = _img(w, h, seed)
+    oxy, osc = Orc.fast(g, thr)
+    rxy, rsc = Ref.fast(g, thr)
+    assert len(rxy) > 0
+    assert np.array_equal(oxy, rxy) and np.array_equal(osc, rsc)
+
+
+def orb_key(kp):
+    """canonical order: (octave, y, x) -- cv::ORB's own order within a level comes from std::nth_element"""
+    return np.lexsort((kp[:, 0], kp[:, 1], kp[:, 5]))
+
+
+@pytest.mark.parametrize("w,h,seed,nf", [(640, 480, 1, 2000), (1280, 720, 3, 4000), (320, 240, 5, 300)])
+def test_orb_detect_and_compute_set_exact(w, h, seed, nf):
+    g = _img(w, h, seed, noise=False)
+    okp, od = Orc.orb(g, nf)
+    rkp, rd = Ref.orb(g, nf)
+    assert len(okp) == len(rkp) and len(rkp) > 0.3 * nf
+    oi, ri = orb_key(okp), orb_key(rkp)
+    assert np.array_equal(okp[oi].view(np.uint32), rkp[ri].view(np.uint32))   # x, y, size, angle, response, octave: bitwise
+    assert np.array_equal(od[oi], rd[ri])
