@@ -60,6 +60,10 @@ _sig("alva_p3p_lmeds", [_vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _f, _f, _vp, 
 _sig("alva_pnp_refine", [_vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
 _sig("alva_local_ba", [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp])
 _sig("alva_detect_grid", [_vp, _vp, _sz, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp])
+_sig("alva_fast", [_vp, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _vp])
+_sig("alva_orb_create", [_vp, _i, _i, _i, _f, _i, _i, C.POINTER(_vp)])
+_sig("alva_orb_destroy", [_vp], None)
+_sig("alva_orb_detect_and_compute", [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -197,6 +201,17 @@ class Context:
                                    roi[0], roi[1], roi[2], roi[3], C.byref(mq), _ptr(out), cap, C.byref(cnt)))
         return out[:min(cnt.value, cap)], mq.value
 
+    # a5'
+    def fast(self, gray, threshold=20, cap=200000):
+        """cv::FAST(TYPE_9_16, NMS): returns (xy [n,2] int32, score [n] int32) cuda tensors, row-major order."""
+        h, w = gray.shape
+        xy = torch.zeros((cap, 2), dtype=torch.int32, device=gray.device)
+        sc = torch.zeros(cap, dtype=torch.int32, device=gray.device)
+        cnt = C.c_int(0)
+        check(lib.alva_fast(self.h, _ptr(gray), gray.stride(0), w, h, threshold, _ptr(xy), _ptr(sc), cap, C.byref(cnt)))
+        n = min(cnt.value, cap)
+        return xy[:n], sc[:n]
+
     # a6
     def orb_blur(self, gray):
         h, w = gray.shape
@@ -266,3 +281,33 @@ class Pyramid:
         d = np.empty((H, W, 2), np.int16)
         check(lib.alva_pyramid_download_level(self.ctx.h, self.h, l, g.ctypes.data, d.ctypes.data))
         return g, d
+
+
+class Orb:
+    """alva_orb: cv::ORB::create(nfeatures, scale, nlevels, 31, 0, 2, HARRIS_SCORE, 31, fast_threshold)."""
+
+    def __init__(self, ctx: Context, width: int, height: int, nfeatures: int = 2000, scale: float = 1.2, nlevels: int = 8,
+                 fast_threshold: int = 20):
+        self.ctx = ctx
+        self.nfeatures = nfeatures
+        h = _vp()
+        check(lib.alva_orb_create(ctx.h, width, height, nfeatures, scale, nlevels, fast_threshold, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.alva_orb_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def detect_and_compute(self, gray, describe=True, cap=None):
+        """returns (kp [n,6] float32 {x,y,size,angle,response,octave}, desc [n,32] u8) cuda tensors"""
+        if cap is None:
+            cap = 4 * self.nfeatures + 1024
+        kp = torch.zeros((cap, 6), dtype=torch.float32, device=gray.device)
+        desc = torch.zeros((cap, 32), dtype=torch.uint8, device=gray.device) if describe else None
+        cnt = C.c_int(0)
+        check(lib.alva_orb_detect_and_compute(self.ctx.h, self.h, _ptr(gray), gray.stride(0), _ptr(kp), _ptr(desc), cap, C.byref(cnt)))
+        n = min(cnt.value, cap)
+        return kp[:n], (desc[:n] if describe else None)

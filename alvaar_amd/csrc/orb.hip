@@ -1,0 +1,697 @@
+// a5': FAST-9/16 + NMS, and the full ORB detector (8-level pyramid, Harris ranking, IC angle, rBRIEF).
+//
+// Replaces cv::FAST(img, kps, thr, true, TYPE_9_16) (features2d/src/fast.cpp:56-292; score fast_score.cpp:120-) and
+// cv::ORB::create(n, s, L, 31, 0, 2, HARRIS_SCORE, 31, thr)->detectAndCompute (features2d/src/orb.cpp:784-1218):
+//   pyramid   resize(prev, cur, INTER_LINEAR_EXACT): 8-bit fixed-point taps from fval = scale (d + .5) - .5 in IEEE double
+//             (imgproc/src/resize.cpp:733-900); the tap tables are built on the host, the pixels on the device
+//   FAST      9 contiguous of 16 brighter/darker by > t; score = largest t that keeps it a corner; strict 3x3 NMS
+//   cull      border 31, keep response >= (2 n_l)-th largest FAST score (keypoint.cpp:69-90: ties at the cut all kept),
+//             Harris 7x7 (orb.cpp:130-177), keep response >= n_l-th largest Harris
+//   angle     intensity centroid over the radius-15 disc, OpenCV's polynomial fastAtan2 (mathfuncs_core.simd.hpp:34-71)
+//   describe  7x7 sigma-2 Gaussian of each level + 256 steered BRIEF tests (describe.hip)
+// Everything up to the angle is integer (or float with a fixed operation order) => bit-exact.  cv::ORB's keypoint ORDER
+// inside a level comes from std::nth_element; this implementation emits the same SET in row-major order per level.
+//
+// HBM traffic: the 8 levels total 3.27 P pixels; each is written once (resize), read once by the score
+// kernel through an LDS tile (+3 px halo), scores written once (u8) and re-read by the two row kernels: ~6.5 P bytes
+// algorithmic per frame.  All levels are processed by ONE launch per stage (blockIdx.y = level) so that a 640x480 frame
+// (3.3 k tiles) fills the 256 CUs; candidate lists stay ordered without a sort by counting per row, scanning, emitting.
+#include "common.hpp"
+#include <cmath>
+
+int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int w, int h, uint8_t *d_dst, size_t dst_pitch);
+
+namespace {
+
+constexpr int MAXLV = 12;
+
+struct Level {
+    int w, h, pitch;       // pitch in bytes (multiple of 64)
+    size_t img, score, blur;  // byte offsets into the image pool
+    int rowOff;            // offset of this level's rows in the row-count arrays
+    int candOff, candCap;  // region of this level in the candidate arrays
+    int nKeep;             // n_l
+    int border;            // 31 for ORB, 0 for plain FAST
+    float scale;           // layerScale
+    int tabOff;            // offset of this level's resize taps (x then y) in the tap arrays
+};
+
+struct OrbDev {
+    int nlevels, threshold;
+    Level lv[MAXLV];
+    uint8_t *pool;          // images | scores | blurred
+    int *rowCnt, *rowStart; // per row survivors / exclusive offsets (per level)
+    int *n1, *n2, *n3;      // per level counts after NMS, after FAST cull, after Harris cull
+    int *hist;              // [nlevels][256] FAST score histogram
+    int *c1x, *c1y, *c1s;   // NMS survivors (row-major per level)
+    int *c2x, *c2y;         // after the FAST-score cull
+    float *c2r;             // Harris responses
+    int *c3x, *c3y;         // after the Harris cull
+    float *c3r;
+    const int *tapOfs;      // resize tap source offsets
+    const int *tapCoef;     // resize tap coefficient (second tap, 0..256), -1 = clamp to first, -2 = clamp to last
+    int umax[17];
+};
+
+__device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int threshold) {
+    // ring in the order of makeOffsets (fast_score.cpp:50-80)
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * stride];
+    d[1] = v - p[3 * stride + 1];
+    d[2] = v - p[2 * stride + 2];
+    d[3] = v - p[stride + 3];
+    d[4] = v - p[3];
+    d[5] = v - p[-stride + 3];
+    d[6] = v - p[-2 * stride + 2];
+    d[7] = v - p[-3 * stride + 1];
+    d[8] = v - p[-3 * stride];
+    d[9] = v - p[-3 * stride - 1];
+    d[10] = v - p[-2 * stride - 2];
+    d[11] = v - p[-stride - 3];
+    d[12] = v - p[-3];
+    d[13] = v - p[stride - 3];
+    d[14] = v - p[2 * stride - 2];
+    d[15] = v - p[3 * stride - 1];
+    // bit k set <=> ring pixel k darker than v - t  /  brighter than v + t
+    unsigned dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        dark |= (unsigned) (d[k] > threshold) << k;
+        bright |= (unsigned) (d[k] < -threshold) << k;
+    }
+    auto has9 = [](unsigned m) -> bool {  // 9 contiguous set bits on the 16-ring
+        m |= m << 16;
+        unsigned r = m & (m >> 1);
+        r &= r >> 2;
+        r &= r >> 4;       // runs of 8
+        r &= m >> 8;       // runs of 9
+        return (r & 0xffffu) != 0;
+    };
+    if (!has9(dark) && !has9(bright)) return 0;
+    // cornerScore<16>: max over the 16 arcs of 9 of min(d) and min(-d), floored at threshold, minus 1
+    int a0 = threshold;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int j = 1; j < 9; j++) {
+            const int e = d[(k + j) & 15];
+            mn = min(mn, e);
+            mx = max(mx, e);
+        }
+        a0 = max(a0, max(mn, -mx));
+    }
+    return a0 - 1;
+}
+
+// resize level l from level l-1 (INTER_LINEAR_EXACT)
+__global__ void __launch_bounds__(256) k_resize(OrbDev D, int l) {
+    const Level &S = D.lv[l - 1], &T = D.lv[l];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= T.w || y >= T.h) return;
+    const int *xo = D.tapOfs + T.tabOff, *xc = D.tapCoef + T.tabOff, *yo = xo + T.w, *yc = xc + T.w;
+    const uint8_t *src = D.pool + S.img;
+    int rows[2], rc[2], nr;
+    const int cy = yc[y];
+    if (cy == -1) { rows[0] = 0; rc[0] = 256; nr = 1; }
+    else if (cy == -2) { rows[0] = S.h - 1; rc[0] = 256; nr = 1; }
+    else { rows[0] = yo[y]; rows[1] = yo[y] + 1; rc[0] = 256 - cy; rc[1] = cy; nr = 2; }
+    const int cx = xc[x], ox = xo[x];
+    unsigned acc = 0;
+    for (int k = 0; k < nr; k++) {
+        const uint8_t *r = src + (size_t) rows[k] * S.pitch;
+        unsigned hv;
+        if (cx == -1) hv = (unsigned) r[0] << 8;
+        else if (cx == -2) hv = (unsigned) r[S.w - 1] << 8;
+        else hv = (unsigned) (256 - cx) * r[ox] + (unsigned) cx * r[ox + 1];
+        acc += (unsigned) rc[k] * hv;
+    }
+    const unsigned v = (acc + 32768u) >> 16;
+    D.pool[T.img + (size_t) y * T.pitch + x] = (uint8_t) min(v, 255u);
+}
+
+// FAST score map of every level: 64x16 tile + 3 px halo staged in LDS
+constexpr int FT_W = 64, FT_H = 16;
+__global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
+    const Level &L = D.lv[blockIdx.y];
+    const int tilesX = (L.w + FT_W - 1) / FT_W, tilesY = (L.h + FT_H - 1) / FT_H;
+    if ((int) blockIdx.x >= tilesX * tilesY) return;
+    const int x0 = (blockIdx.x % tilesX) * FT_W, y0 = (blockIdx.x / tilesX) * FT_H;
+    __shared__ uint8_t s[(FT_H + 6) * (FT_W + 8)];
+    constexpr int SW = FT_W + 8;
+    const uint8_t *img = D.pool + L.img;
+    for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
+        const int ly = i / (FT_W + 6), lx = i % (FT_W + 6);
+        const int gx = min(max(x0 + lx - 3, 0), L.w - 1), gy = min(max(y0 + ly - 3, 0), L.h - 1);
+        s[ly * SW + lx] = img[(size_t) gy * L.pitch + gx];
+    }
+    __syncthreads();
+    uint8_t *sc = D.pool + L.score;
+    for (int i = threadIdx.x; i < FT_W * FT_H; i += 256) {
+        const int ly = i / FT_W, lx = i % FT_W, gx = x0 + lx, gy = y0 + ly;
+        if (gx >= L.w || gy >= L.h) continue;
+        int v = 0;
+        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) v = fast_score_at(s + (ly + 3) * SW + lx + 3, SW, D.threshold);
+        sc[(size_t) gy * L.pitch + gx] = (uint8_t) v;
+    }
+}
+
+__device__ __forceinline__ bool nms_keep(const uint8_t *sc, int pitch, int x, int y, const Level &L) {
+    if (x < 3 || x >= L.w - 3 || y < 3 || y >= L.h - 3) return false;
+    const uint8_t *q = sc + (size_t) y * pitch + x;
+    const int s = q[0];
+    if (!s) return false;
+    if (!(s > q[-1] && s > q[1] && s > q[-pitch - 1] && s > q[-pitch] && s > q[-pitch + 1] && s > q[pitch - 1] && s > q[pitch] && s > q[pitch + 1]))
+        return false;
+    if (L.border > 0)  // KeyPointsFilter::runByImageBorder (keypoint.cpp:105-117)
+        if (!(L.w > 2 * L.border && L.h > 2 * L.border && x >= L.border && x < L.w - L.border && y >= L.border && y < L.h - L.border)) return false;
+    return true;
+}
+
+// one wave per image row: EMIT = false counts the NMS survivors, EMIT = true writes them in x order
+template<bool EMIT>
+__global__ void __launch_bounds__(256) k_fast_rows(OrbDev D) {
+    const Level &L = D.lv[blockIdx.y];
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (y >= L.h) return;
+    const uint8_t *sc = D.pool + L.score;
+    int base = EMIT ? D.rowStart[L.rowOff + y] : 0;
+    int count = 0;
+    for (int x0 = 0; x0 < L.w; x0 += 64) {
+        const int x = x0 + lane;
+        const bool keep = x < L.w && nms_keep(sc, L.pitch, x, y, L);
+        const unsigned long long m = __ballot(keep);
+        if (EMIT && keep) {
+            const int pos = base + count + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < L.candCap) {
+                const int s = sc[(size_t) y * L.pitch + x];
+                D.c1x[L.candOff + pos] = x;
+                D.c1y[L.candOff + pos] = y;
+                D.c1s[L.candOff + pos] = s;
+                atomicAdd(&D.hist[blockIdx.y * 256 + s], 1);
+            }
+        }
+        count += __popcll(m);
+    }
+    if (!EMIT && lane == 0) D.rowCnt[L.rowOff + y] = count;
+}
+
+// exclusive scan of the per-row counts of one level (one workgroup per level)
+__global__ void __launch_bounds__(1024) k_scan_rows(OrbDev D) {
+    const Level &L = D.lv[blockIdx.x];
+    __shared__ int s[1024];
+    int carry = 0;
+    for (int b = 0; b < L.h; b += 1024) {
+        const int y = b + threadIdx.x;
+        const int v = y < L.h ? D.rowCnt[L.rowOff + y] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (y < L.h) D.rowStart[L.rowOff + y] = carry + s[threadIdx.x] - v;
+        carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) D.n1[blockIdx.x] = min(carry, L.candCap);
+}
+
+// ordered compaction helper: keep[i] decided by the caller's predicate; one workgroup, chunks of 1024
+template<typename Pred, typename Emit>
+__device__ int compact_ordered(int n, Pred pred, Emit emit) {
+    __shared__ int s[1024];
+    int carry = 0;
+    for (int b = 0; b < n; b += 1024) {
+        const int i = b + threadIdx.x;
+        const int k = (i < n && pred(i)) ? 1 : 0;
+        s[threadIdx.x] = k;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (k) emit(i, carry + s[threadIdx.x] - 1);
+        carry += s[1023];
+        __syncthreads();
+    }
+    return carry;
+}
+
+// cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept), preserving order
+__global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) {
+    const Level &L = D.lv[blockIdx.x];
+    const int n = D.n1[blockIdx.x], keepN = 2 * L.nKeep;
+    __shared__ int s_thr;
+    if (threadIdx.x == 0) {
+        int thr = 0;
+        if (keepN == 0) thr = 1 << 30;
+        else if (n > keepN) {
+            int acc = 0;
+            for (int v = 255; v >= 0; v--) {
+                acc += D.hist[blockIdx.x * 256 + v];
+                if (acc >= keepN) {
+                    thr = v;
+                    break;
+                }
+            }
+        }
+        s_thr = thr;
+    }
+    __syncthreads();
+    const int thr = s_thr;
+    const int o = L.candOff;
+    const int m = compact_ordered(
+        n, [&](int i) { return D.c1s[o + i] >= thr; },
+        [&](int i, int pos) {
+            D.c2x[o + pos] = D.c1x[o + i];
+            D.c2y[o + pos] = D.c1y[o + i];
+        });
+    if (threadIdx.x == 0) D.n2[blockIdx.x] = m;
+}
+
+// Harris response of every surviving candidate (orb.cpp:130-177), one thread each
+__global__ void __launch_bounds__(256) k_harris(OrbDev D) {
+    const Level &L = D.lv[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D.n2[blockIdx.y]) return;
+    const int x = D.c2x[L.candOff + i], y = D.c2y[L.candOff + i], W = L.pitch;
+    const uint8_t *img = D.pool + L.img;
+    int a = 0, b = 0, c = 0;
+    for (int k = 0; k < 49; k++) {
+        const uint8_t *p = img + (size_t) (y - 3 + k / 7) * W + (x - 3 + k % 7);
+        const int Ix = (p[1] - p[-1]) * 2 + (p[-W + 1] - p[-W - 1]) + (p[W + 1] - p[W - 1]);
+        const int Iy = (p[W] - p[-W]) * 2 + (p[W - 1] - p[-W - 1]) + (p[W + 1] - p[-W + 1]);
+        a += Ix * Ix;
+        b += Iy * Iy;
+        c += Ix * Iy;
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    const float fa = (float) a, fb = (float) b, fc = (float) c;
+    D.c2r[L.candOff + i] = ((fa * fb - fc * fc) - (0.04f * (fa + fb)) * (fa + fb)) * scale_sq_sq;
+}
+
+__device__ __forceinline__ unsigned f2key(float f) {  // order-preserving map float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// cull by Harris: keep response >= the n_l-th largest, preserving order (radix select on the float keys)
+__global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) {
+    const Level &L = D.lv[blockIdx.x];
+    const int n = D.n2[blockIdx.x], keepN = L.nKeep, o = L.candOff;
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_prefix, s_k;
+    unsigned thrKey = 0;
+    if (keepN == 0) thrKey = 0xffffffffu;
+    else if (n > keepN) {
+        // the keepN-th largest = element of rank (n - keepN) in ascending order
+        unsigned prefix = 0, mask = 0;
+        unsigned k = (unsigned) (n - keepN);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += 1024) {
+                const unsigned key = f2key(D.c2r[o + i]);
+                if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned acc = 0;
+                int b = 0;
+                for (; b < 256; b++) {
+                    if (k < acc + s_hist[b]) break;
+                    acc += s_hist[b];
+                }
+                s_prefix = prefix | ((unsigned) b << shift);
+                s_k = k - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            k = s_k;
+            mask |= 0xffu << shift;
+            __syncthreads();
+        }
+        thrKey = prefix;
+    }
+    const int m = compact_ordered(
+        n, [&](int i) { return f2key(D.c2r[o + i]) >= thrKey; },
+        [&](int i, int pos) {
+            D.c3x[o + pos] = D.c2x[o + i];
+            D.c3y[o + pos] = D.c2y[o + i];
+            D.c3r[o + pos] = D.c2r[o + i];
+        });
+    if (threadIdx.x == 0) D.n3[blockIdx.x] = m;
+}
+
+__device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_core.simd.hpp:34-71
+    const float s = (float) (180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float eps = (float) 2.2204460492503131e-16;
+    float a;
+    if (ax >= ay) {
+        const float c = ay / (ax + eps), c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        const float c = ax / (ay + eps), c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// IC angle + output record, one wave per kept keypoint (orb.cpp:181-215, :952-958)
+__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) {
+    const int l = blockIdx.y;
+    const Level &L = D.lv[l];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int base = 0;
+    for (int q = 0; q < l; q++) base += D.n3[q];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && l == D.nlevels - 1) *total = base + D.n3[l];
+    if (i >= D.n3[l]) return;
+    const int x = D.c3x[L.candOff + i], y = D.c3y[L.candOff + i], W = L.pitch;
+    const uint8_t *ctr = D.pool + L.img + (size_t) y * W + x;
+    // rows v = -15..15 spread over lanes 0..30; integer sums => any order is exact
+    int m01 = 0, m10 = 0;
+    if (lane < 31) {
+        const int v = lane - 15, av = v < 0 ? -v : v, d = av == 0 ? 15 : D.umax[av];
+        int rs = 0, ms = 0;
+        for (int u = -d; u <= d; u++) {
+            const int val = ctr[u + v * W];
+            rs += val;
+            ms += u * val;
+        }
+        m10 = ms;
+        m01 = v * rs;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m01 += __shfl_down(m01, off);
+        m10 += __shfl_down(m10, off);
+    }
+    if (lane == 0 && base + i < cap) {
+        float *o = kp + 6 * (size_t) (base + i);
+        o[0] = (float) x * L.scale;
+        o[1] = (float) y * L.scale;
+        o[2] = 31 * L.scale;
+        o[3] = fast_atan2f((float) m01, (float) m10);
+        o[4] = D.c3r[L.candOff + i];
+        o[5] = (float) l;
+    }
+}
+
+__constant__ int8_t c_pattern_orb[1024] = {
+#include "orb_pattern.inc"
+};
+
+// steered BRIEF of the ORB keypoints on their (blurred) pyramid level; 32 lanes per keypoint (orb.cpp:219-284)
+__global__ void __launch_bounds__(256) k_brief_orb(OrbDev D, const float *__restrict__ kp, const int *__restrict__ total, int cap,
+                                                   uint8_t *__restrict__ desc) {
+    const int n = min(*total, cap);
+    const int k = blockIdx.x * 8 + threadIdx.x / 32, byte = threadIdx.x % 32;
+    if (k >= n) return;
+    const float *rec = kp + 6 * (size_t) k;
+    const int l = (int) rec[5];
+    const Level &L = D.lv[l];
+    const float inv = 1.f / L.scale;
+    const int cx = __float2int_rn(rec[0] * inv), cy = __float2int_rn(rec[1] * inv);
+    float angle = rec[3];
+    angle *= (float) (3.1415926535897932384626433832795 / 180.f);
+    const float a = (float) cos((double) angle), b = (float) sin((double) angle);
+    const uint8_t *center = D.pool + L.blur + (size_t) cy * L.pitch + cx;
+    const int8_t *pat = c_pattern_orb + byte * 32;
+    unsigned val = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float x0 = (float) pat[4 * t], y0 = (float) pat[4 * t + 1], x1 = (float) pat[4 * t + 2], y1 = (float) pat[4 * t + 3];
+        const int ix0 = __float2int_rn(x0 * a - y0 * b), iy0 = __float2int_rn(x0 * b + y0 * a);
+        const int ix1 = __float2int_rn(x1 * a - y1 * b), iy1 = __float2int_rn(x1 * b + y1 * a);
+        const int t0 = center[(ptrdiff_t) iy0 * L.pitch + ix0], t1 = center[(ptrdiff_t) iy1 * L.pitch + ix1];
+        val |= (unsigned) (t0 < t1) << t;
+    }
+    desc[(size_t) k * 32 + byte] = (uint8_t) val;
+}
+
+__global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) {
+    const Level &L = D.lv[0];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < L.w && y < L.h) D.pool[L.img + (size_t) y * L.pitch + x] = src[(size_t) y * pitch + x];
+}
+
+int cv_round_f(float v) { return (int) lrintf(v); }
+
+}  // namespace
+
+struct alva_orb {
+    int device = 0;
+    OrbDev D{};
+    void *d_block = nullptr;
+    int maxRows = 0, maxTiles = 0, candTotal = 0;
+    int *d_total = nullptr;
+    bool fast_only = false;
+};
+
+static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float scale_factor, int nlevels, int fast_threshold, int border,
+                     alva_orb **out) {
+    ALVA_ARG(ctx && out && width >= 16 && height >= 16 && nlevels >= 1 && nlevels <= MAXLV && nfeatures >= 0);
+    ALVA_HIP(hipSetDevice(ctx->device));
+    alva_orb *o = new alva_orb();
+    o->device = ctx->device;
+    OrbDev &D = o->D;
+    D.nlevels = nlevels;
+    D.threshold = std::min(std::max(fast_threshold, 0), 255);
+    const double scaleFactor = (double) scale_factor;
+    // features per level (orb.cpp:799-813)
+    {
+        const float factor = (float) (1.0 / scaleFactor);
+        float nd = (float) nfeatures * (1 - factor) / (1 - (float) std::pow((double) factor, (double) nlevels));
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; l++) {
+            D.lv[l].nKeep = cv_round_f(nd);
+            sum += D.lv[l].nKeep;
+            nd *= factor;
+        }
+        D.lv[nlevels - 1].nKeep = std::max(nfeatures - sum, 0);
+    }
+    // umax (orb.cpp:819-834)
+    {
+        const int hp = 15;
+        const int vmax = (int) std::floor(hp * std::sqrt(2.f) / 2 + 1), vmin = (int) std::ceil(hp * std::sqrt(2.f) / 2);
+        for (int v = 0; v <= vmax; v++) D.umax[v] = (int) std::lrint(std::sqrt((double) hp * hp - v * v));
+        for (int v = hp, v0 = 0; v >= vmin; --v) {
+            while (D.umax[v0] == D.umax[v0 + 1]) ++v0;
+            D.umax[v] = v0;
+            ++v0;
+        }
+    }
+    // level geometry + resize taps (orb.cpp:1041-1058; resize.cpp:733-770)
+    std::vector<int> tapOfs, tapCoef;
+    size_t pool = 0;
+    int rows = 0, cands = 0;
+    for (int l = 0; l < nlevels; l++) {
+        Level &L = D.lv[l];
+        L.scale = (float) std::pow(scaleFactor, (double) l);
+        const float inv = 1.0f / L.scale;
+        L.w = cv_round_f((float) width * inv);
+        L.h = cv_round_f((float) height * inv);
+        if (L.w < 8 || L.h < 8) {
+            delete o;
+            alva_set_error("alva_orb_create: level %d would be %dx%d", l, L.w, L.h);
+            return ALVA_ERR_ARG;
+        }
+        L.pitch = (L.w + 63) / 64 * 64;
+        L.border = border;
+        L.rowOff = rows;
+        rows += L.h;
+        L.candOff = cands;
+        L.candCap = L.w * L.h / 4 + 64;
+        cands += L.candCap;
+        o->maxRows = std::max(o->maxRows, L.h);
+        o->maxTiles = std::max(o->maxTiles, ((L.w + FT_W - 1) / FT_W) * ((L.h + FT_H - 1) / FT_H));
+        L.tabOff = (int) tapOfs.size();
+        if (l > 0) {
+            const Level &S = D.lv[l - 1];
+            for (int pass = 0; pass < 2; pass++) {
+                const int dn = pass ? L.h : L.w, sn = pass ? S.h : S.w;
+                const double inv_scale = (double) dn / sn;
+                const double scale = 1.0 / inv_scale;
+                for (int d = 0; d < dn; d++) {
+                    const double fval = scale * ((double) d + 0.5) - 0.5;
+                    const int ival = (int) std::floor(fval);
+                    if (ival >= 0 && sn > 1) {
+                        if (ival < sn - 1) {
+                            tapOfs.push_back(ival);
+                            tapCoef.push_back((int) std::lrint((fval - (double) ival) * 256.0));
+                        } else {
+                            tapOfs.push_back(sn - 1);
+                            tapCoef.push_back(-2);
+                        }
+                    } else {
+                        tapOfs.push_back(0);
+                        tapCoef.push_back(-1);
+                    }
+                }
+            }
+        } else {
+            tapOfs.resize(tapOfs.size() + L.w + L.h, 0);
+            tapCoef.resize(tapCoef.size() + L.w + L.h, 0);
+        }
+    }
+    for (int l = 0; l < nlevels; l++) {
+        Level &L = D.lv[l];
+        const size_t bytes = (size_t) L.pitch * L.h;
+        L.img = pool; pool += bytes + 256;
+        L.score = pool; pool += bytes + 256;
+        L.blur = pool; pool += bytes + 256;
+    }
+    o->candTotal = cands;
+    // one allocation, carved
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
+    const size_t o_pool = take(pool), o_rowCnt = take((size_t) rows * 4), o_rowStart = take((size_t) rows * 4), o_n = take(3 * MAXLV * 4),
+                 o_hist = take((size_t) MAXLV * 256 * 4), o_c1 = take((size_t) cands * 12), o_c2 = take((size_t) cands * 12),
+                 o_c3 = take((size_t) cands * 12), o_tap = take(tapOfs.size() * 8), o_total = take(64);
+    hipError_t e = hipMalloc(&o->d_block, off);
+    if (e != hipSuccess) {
+        delete o;
+        alva_set_error("alva_orb_create: hipMalloc(%zu): %s", off, hipGetErrorString(e));
+        return ALVA_ERR_NOMEM;
+    }
+    uint8_t *b = (uint8_t *) o->d_block;
+    D.pool = b + o_pool;
+    D.rowCnt = (int *) (b + o_rowCnt);
+    D.rowStart = (int *) (b + o_rowStart);
+    D.n1 = (int *) (b + o_n);
+    D.n2 = D.n1 + MAXLV;
+    D.n3 = D.n2 + MAXLV;
+    D.hist = (int *) (b + o_hist);
+    D.c1x = (int *) (b + o_c1); D.c1y = D.c1x + cands; D.c1s = D.c1y + cands;
+    D.c2x = (int *) (b + o_c2); D.c2y = D.c2x + cands; D.c2r = (float *) (D.c2y + cands);
+    D.c3x = (int *) (b + o_c3); D.c3y = D.c3x + cands; D.c3r = (float *) (D.c3y + cands);
+    int *d_tap = (int *) (b + o_tap);
+    D.tapOfs = d_tap;
+    D.tapCoef = d_tap + tapOfs.size();
+    o->d_total = (int *) (b + o_total);
+    ALVA_HIP(hipMemcpyAsync(d_tap, tapOfs.data(), tapOfs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ALVA_HIP(hipMemcpyAsync(d_tap + tapOfs.size(), tapCoef.data(), tapCoef.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    *out = o;
+    return ALVA_OK;
+}
+
+extern "C" int alva_orb_create(alva_ctx *ctx, int width, int height, int nfeatures, float scale_factor, int nlevels, int fast_threshold,
+                               alva_orb **out) {
+    return orb_build(ctx, width, height, nfeatures, scale_factor, nlevels, fast_threshold, 31, out);
+}
+
+extern "C" void alva_orb_destroy(alva_orb *orb) {
+    if (!orb) return;
+    (void) hipSetDevice(orb->device);
+    if (orb->d_block) (void) hipFree(orb->d_block);
+    delete orb;
+}
+
+// levels -> FAST -> NMS survivors (row-major per level) with counts in n1
+static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, size_t gray_pitch) {
+    OrbDev &D = o->D;
+    hipStream_t st = ctx->stream;
+    const Level &L0 = D.lv[0];
+    hipLaunchKernelGGL(k_copy_level0, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4)), dim3(256), 0, st, D, d_gray, gray_pitch);
+    for (int l = 1; l < D.nlevels; l++)
+        hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
+    ALVA_HIP(hipMemsetAsync(D.hist, 0, (size_t) MAXLV * 256 * 4, st));
+    hipLaunchKernelGGL(k_fast_score, dim3(o->maxTiles, D.nlevels), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_fast_rows<false>, dim3(alva_divup(o->maxRows, 4), D.nlevels), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_scan_rows, dim3(D.nlevels), dim3(1024), 0, st, D);
+    hipLaunchKernelGGL(k_fast_rows<true>, dim3(alva_divup(o->maxRows, 4), D.nlevels), dim3(256), 0, st, D);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch, float *d_kp,
+                                           uint8_t *d_desc, int cap, int *h_count) {
+    ALVA_ARG(ctx && orb && d_gray && d_kp && h_count && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
+    OrbDev &D = orb->D;
+    hipStream_t st = ctx->stream;
+    int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cull_fast, dim3(D.nlevels), dim3(1024), 0, st, D);
+    int maxC = 0;
+    for (int l = 0; l < D.nlevels; l++) maxC = std::max(maxC, D.lv[l].candCap);
+    hipLaunchKernelGGL(k_harris, dim3(alva_divup(maxC, 256), D.nlevels), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_cull_harris, dim3(D.nlevels), dim3(1024), 0, st, D);
+    int maxKeep = 0;
+    for (int l = 0; l < D.nlevels; l++) maxKeep = std::max(maxKeep, std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024)));
+    // ties at the Harris cut are rare (float responses): 4 n_l + 64 waves per level is a generous bound; if a level ever had
+    // more survivors than that the extra ones would be dropped silently, so the bound is checked below.
+    hipLaunchKernelGGL(k_angle_emit, dim3(alva_divup(maxKeep, 4), D.nlevels), dim3(256), 0, st, D, d_kp, cap, orb->d_total);
+    ALVA_LAUNCH_CHECK();
+    if (d_desc) {
+        for (int l = 0; l < D.nlevels; l++) {
+            const Level &L = D.lv[l];
+            rc = alva_blur7_launch(ctx, D.pool + L.img, L.pitch, L.w, L.h, D.pool + L.blur, L.pitch);
+            if (rc) return rc;
+        }
+        int nmax = 0;
+        for (int l = 0; l < D.nlevels; l++) nmax += std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024));
+        nmax = std::min(nmax, cap);
+        if (nmax > 0) hipLaunchKernelGGL(k_brief_orb, dim3(alva_divup(nmax, 8)), dim3(256), 0, st, D, (const float *) d_kp, (const int *) orb->d_total, cap, d_desc);
+        ALVA_LAUNCH_CHECK();
+    }
+    int n3[MAXLV], total = 0;
+    ALVA_HIP(hipMemcpyAsync(n3, D.n3, sizeof(n3), hipMemcpyDeviceToHost, st));
+    ALVA_HIP(hipStreamSynchronize(st));
+    for (int l = 0; l < D.nlevels; l++) {
+        if (n3[l] > std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024))) {
+            alva_set_error("alva_orb_detect_and_compute: level %d kept %d keypoints, above the launch bound", l, n3[l]);
+            return ALVA_ERR_STATE;
+        }
+        total += n3[l];
+    }
+    *h_count = total;
+    return ALVA_OK;
+}
+
+// plain FAST on one image (no border cull): a one-level "orb" object cached in the context would avoid the allocation; the
+// function is a parity/utility entry point, so it simply builds and tears down its buffers.
+extern "C" int alva_fast(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int threshold, int *d_xy,
+                         int *d_score, int cap, int *h_count) {
+    ALVA_ARG(ctx && d_gray && d_xy && d_score && h_count && cap >= 0);
+    alva_orb *o = nullptr;
+    int rc = orb_build(ctx, width, height, 0, 1.0f, 1, threshold, 0, &o);
+    if (rc) return rc;
+    rc = run_fast_stages(ctx, o, d_gray, gray_pitch);
+    int n = 0;
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(&n, o->D.n1, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && n > 0) {
+            const int m = std::min(n, cap);
+            // interleave x,y
+            std::vector<int> xs((size_t) m), ys((size_t) m), xy((size_t) 2 * m);
+            e = hipMemcpy(xs.data(), o->D.c1x, (size_t) m * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(ys.data(), o->D.c1y, (size_t) m * 4, hipMemcpyDeviceToHost);
+            for (int i = 0; i < m; i++) {
+                xy[2 * (size_t) i] = xs[(size_t) i];
+                xy[2 * (size_t) i + 1] = ys[(size_t) i];
+            }
+            if (e == hipSuccess) e = hipMemcpy(d_xy, xy.data(), (size_t) 2 * m * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_score, o->D.c1s, (size_t) m * 4, hipMemcpyDeviceToDevice);
+        }
+        if (e != hipSuccess) {
+            alva_set_error("alva_fast: %s", hipGetErrorString(e));
+            rc = ALVA_ERR_HIP;
+        }
+    }
+    alva_orb_destroy(o);
+    *h_count = n;
+    return rc;
+}

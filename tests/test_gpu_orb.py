@@ -1,0 +1,42 @@
+"""GPU parity: a5' -- FAST-9/16 + NMS (bit-exact, row-major order) and the full ORB detector.
+ORB: the keypoint SET {x, y, size, angle, response, octave} must equal the reference's bitwise (cv::ORB's order within a
+level is std::nth_element's; ours is row-major, so both sides are put in (octave, y, x) order first).  Descriptors:
+identical bytes; the only non-reproducible step is cos/sin of the angle in double on the device vs glibc, so up to
+0.1 % of descriptors may differ in a bit -- the test states and checks that bound (observed: 0)."""
+import numpy as np
+import pytest
+
+from oracles import Orc, Ref, ref_available
+from test_oracle_vs_ref import _img, orb_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,seed,thr", [(640, 480, 1, 20), (200, 120, 2, 10), (1280, 720, 3, 20), (64, 48, 4, 5)])
+def test_fast_bit_exact(ctx, w, h, seed, thr):
+    import torch
+    g = _img(w, h, seed)
+    xy, sc = ctx.fast(torch.from_numpy(g).cuda(), thr)
+    O = Ref if ref_available() else Orc
+    rxy, rsc = O.fast(g, thr)
+    assert len(rxy) > 0
+    assert np.array_equal(xy.cpu().numpy(), rxy) and np.array_equal(sc.cpu().numpy(), rsc)
+
+
+@pytest.mark.parametrize("w,h,seed,nf", [(640, 480, 1, 2000), (1280, 720, 3, 4000), (320, 240, 5, 300)])
+def test_orb_detect_and_compute(ctx, w, h, seed, nf):
+    import torch
+    import alvaar_amd
+    g = _img(w, h, seed, noise=False)
+    orb = alvaar_amd.Orb(ctx, w, h, nf)
+    for rep in range(2):  # second call reuses every buffer
+        kp, desc = orb.detect_and_compute(torch.from_numpy(g).cuda())
+    kp, desc = kp.cpu().numpy(), desc.cpu().numpy()
+    O = Ref if ref_available() else Orc
+    rkp, rd = O.orb(g, nf)
+    assert len(kp) == len(rkp) and len(rkp) > 0.3 * nf
+    ri = orb_key(rkp)
+    assert np.array_equal(kp.view(np.uint32), rkp[ri].view(np.uint32))   # ours is already in (octave, y, x) order
+    bad = (desc != rd[ri]).any(axis=1).sum()
+    assert bad <= max(1, len(kp) // 1000), bad
+    orb.close()
