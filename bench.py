@@ -188,17 +188,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
-    if dist:
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from alvaar_amd import multi
+    import torch.distributed as td
+    shard = multi.shard_from_env()
+    rank, world, local = shard.rank, shard.world, shard.local_rank
     torch.cuda.set_device(local)
+    dist = multi.init_process_group(shard, "nccl")   # "nccl" IS RCCL on ROCm; only used for the barrier + timing reduction
 
-    job = FrameJob(local, seed=7 + rank)
+    job = FrameJob(local, seed=shard.stream_seed)
     for _ in range(args.warmup):
         job.step()
     torch.cuda.synchronize()
@@ -211,10 +208,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = multi.max_over_ranks(dt, torch.device("cuda", local))
         td.barrier()
-        dt = float(tmax.item())
     torch.cuda.synchronize()
 
     if rank == 0:

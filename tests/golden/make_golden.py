@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libalva_ref.so = AlvaAR's slam sources +
+vendored OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV, built by oracle/build_ref_shim.sh in the container that has
+/root/reference).  The reference has no golden vectors of its own; these are outputs of the
+reference itself on small seeded inputs, committed so that the restatement oracle and the HIP path stay pinned on
+machines where the reference library is absent.  Re-run: `python tests/golden/make_golden.py`."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from alvaar_amd import synth  # noqa: E402
+from oracles import Ref, ref_lib  # noqa: E402
+from test_oracle_vs_ref import klt_case, _test_points, xyz_problem  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def img(w, h, seed, k=2, noise=True):
+    return synth.frame_gray(synth.texture_canvas(w, h, seed), k, w, h, noise_seed=seed if noise else None)
+
+
+def main():
+    info = ref_lib().ref_build_info().decode()
+    base = [l.strip() for l in info.splitlines() if "Baseline" in l or "Version control" in l]
+    # image stages, 160x120
+    w, h = 160, 120
+    rgba = synth.random_rgba(w, h, 1)
+    g = img(w, h, 2)
+    gp, dp = Ref.build_pyramid(g, 9, 3)
+    pts = _test_points(w, h, 64, 3)
+    desc, valid = Ref.describe(g, pts)
+    prev, curr, kpts, kinit = klt_case(w, h, 120, 4)
+    lk_next, lk_st, lk_err = Ref.lk(prev, curr, kpts, kinit, 3)
+    fb_prior, fb_st = Ref.fbklt(prev, curr, kpts, kinit, 3)
+    det_pts, det_q = Ref.detect_grid(g, 12)
+    fxy, fsc = Ref.fast(g, 20)
+    g2 = img(320, 240, 5, noise=False)
+    okp, odesc = Ref.orb(g2, 300)
+    rng = np.random.RandomState(6)
+    q = rng.randint(0, 256, (40, 32)).astype(np.uint8)
+    t = rng.randint(0, 256, (50, 32)).astype(np.uint8)
+    t[25] = t[3]
+    q[7] = t[3]
+    bf_idx, bf_dist = Ref.bf_match(q, t)
+    np.savez_compressed(OUT / "image_stages.npz", rgba=rgba, gray_of_rgba=Ref.rgba2gray(rgba), g=g,
+                        pyr_gray0=gp[0], pyr_gray1=gp[1], pyr_gray2=gp[2], pyr_gray3=gp[3],
+                        pyr_deriv0=dp[0], pyr_deriv1=dp[1], pyr_deriv2=dp[2], pyr_deriv3=dp[3],
+                        blur=Ref.orb_blur(g), pts=pts, desc=desc, valid=valid,
+                        klt_prev=prev, klt_curr=curr, klt_pts=kpts, klt_init=kinit, lk_next=lk_next, lk_status=lk_st, lk_err=lk_err,
+                        fb_prior=fb_prior, fb_status=fb_st, det_pts=det_pts, det_q=np.float64(det_q), fast_xy=fxy, fast_score=fsc,
+                        orb_img=g2, orb_kp=okp, orb_desc=odesc, bf_q=q, bf_t=t, bf_idx=bf_idx, bf_dist=bf_dist,
+                        ref_build=np.array(base))
+    # pose + BA
+    pb = synth.make_pnp_problem(150, 7, outlier_frac=0.2, pose_noise=0.02)
+    ok, R, tt, outl = Ref.p3p_lmeds(pb["bv"], pb["wpt"])
+    ok2, pose, outl2, pinfo = Ref.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"])
+    ba = synth.make_ba_problem(6, 120, 9)
+    rb = Ref.local_ba(ba, 5, 0.0)
+    bx = xyz_problem(5, 80, 10)
+    rx = Ref.local_ba(bx, 5, 0.0, inv_depth=False)
+    np.savez_compressed(OUT / "pose_ba.npz", p3p_ok=ok, p3p_R=R, p3p_t=tt, p3p_outliers=outl, pnp_ok=ok2, pnp_pose=pose, pnp_outliers=outl2,
+                        pnp_info=pinfo, ba_poses=rb["poses"], ba_pts=rb["pts"], ba_chi2=rb["chi2"], ba_depth=rb["depth"], ba_info=rb["info"][:4],
+                        bax_poses=rx["poses"], bax_pts=rx["pts"], bax_info=rx["info"][:4])
+    print("wrote", [p.name for p in OUT.glob("*.npz")])
+
+
+if __name__ == "__main__":
+    main()
