@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int MAX_CELL = 40;
+constexpr int NCAND = 256;  // sorted candidates kept per cell (4 per lane of the selecting wave)
 
 __device__ __forceinline__ int refl(int p, int len) {
     if (len == 1) return 0;
@@ -43,6 +44,8 @@ struct GridArgs {
     const float *occupied;
     int nOcc;
     float *eig;       // [nCells][cell*cell]
+    float *candVal;   // [nCells][NCAND] lambda_min of the cell's best pixels, sorted (value desc, index asc)
+    int *candIdx;     // [nCells][NCAND] their in-cell index, -1 = none
     uint8_t *cellOcc; // [nCells] 1 = occupied (skipped and counted)
     int *prim;        // [nCells] packed (y << 16 | x) or -1
     int *sec;         // [nCells]
@@ -140,10 +143,52 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
         __syncthreads();
     }
     float *out = A.eig + (size_t) ci * n2;
-    for (int i = threadIdx.x; i < n2; i += 256) {
-        const float a = sbox[i] * 0.5f, b = sbox[n2 + i], cc = sbox[2 * n2 + i] * 0.5f;
-        const float t = a - cc;
-        out[i] = (a + cc) - sqrtf(b * b + t * t);
+    // sort keys (value desc, index asc) -> 64-bit key sorted descending: [orderable float bits | ~index]
+    unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem + ((29 * n2 + gw * gw + 15) & ~15));
+    int np2 = 256;
+    while (np2 < n2) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += 256) {
+        unsigned long long key = 0;
+        if (i < n2) {
+            const float a = sbox[i] * 0.5f, b = sbox[n2 + i], cc = sbox[2 * n2 + i] * 0.5f;
+            const float t = a - cc;
+            const float e = (a + cc) - sqrtf(b * b + t * t);
+            out[i] = e;
+            const unsigned u = __float_as_uint(e);
+            const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            key = ((unsigned long long) ord << 32) | (unsigned long long) (0xffffffffu - (unsigned) i);
+        }
+        skey[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = skey[i], y = skey[l];
+                    const bool desc = (i & k) == 0;
+                    if ((x < y) == desc) {
+                        skey[i] = y;
+                        skey[l] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x < NCAND) {
+        const int i = threadIdx.x;
+        float v = 0.f;
+        int idx = -1;
+        if (i < n2) {
+            const unsigned long long key = skey[i];
+            const unsigned ord = (unsigned) (key >> 32);
+            const unsigned u = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+            v = __uint_as_float(u);
+            idx = (int) (0xffffffffu - (unsigned) (key & 0xffffffffu));
+        }
+        A.candVal[(size_t) ci * NCAND + i] = v;
+        A.candIdx[(size_t) ci * NCAND + i] = idx;
     }
 }
 
@@ -159,7 +204,6 @@ __device__ __forceinline__ void clear_circle(uint32_t *mask, int wordsPerRow, in
     }
 }
 
-template<int PER_LANE>
 __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     extern __shared__ uint32_t smask[];
     const int wordsPerRow = (A.w + 31) / 32;
@@ -176,17 +220,11 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     __syncthreads();
     const int cell = A.cell, n2 = cell * cell;
     const int T = (A.nCW - 1) + 2 * (A.nCH - 1);
-    // PER_LANE = ceil(cell^2 / 64) values per lane (3 at cell 12, 25 at cell 40); their in-cell offsets are fixed
-    float pre[PER_LANE];
-    int offs[PER_LANE];  // (dy << 8) | dx of element lane + 64 q, or -1 past the end of the cell
-#pragma unroll
-    for (int q = 0; q < PER_LANE; q++) {
-        const int k = lane + 64 * q;
-        offs[q] = k < n2 ? (((k / cell) << 8) | (k % cell)) : -1;
-    }
-    // the cells a wave will visit are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16k), so
-    // the lambda_min values of the NEXT cell are fetched from HBM/L2 before the barrier that releases it: inside the
-    // dependent section only registers and the LDS mask are touched.
+    // Each wave's cells are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16 k), so the sorted
+    // candidate list of the NEXT cell (4 per lane) is fetched before the barrier that releases it; inside the dependent
+    // section a pass is: one LDS mask bit per candidate, one ballot, one circle of LDS atomics.
+    float cv[4];
+    int cx[4], cy[4], ck[4];
     auto cell_of = [&](int t, int slot, int &r, int &c) -> bool {
         const int rmin = max(0, (t - (A.nCW - 1) + 1) / 2), rmax = min(A.nCH - 1, t / 2);
         r = rmin + wave + slot * nwaves;
@@ -198,11 +236,14 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
         return !s_occ[ci] && (c * cell + cell < A.w - 1 && r * cell + cell < A.h - 1);
     };
     auto prefetch = [&](int r, int c) {
-        const float *eig = A.eig + (size_t) (r * A.nCW + c) * n2;
+        const size_t base = (size_t) (r * A.nCW + c) * NCAND;
 #pragma unroll
-        for (int q = 0; q < PER_LANE; q++) {
-            const int k = lane + 64 * q;
-            pre[q] = k < n2 ? eig[k] : 0.f;
+        for (int q = 0; q < 4; q++) {
+            const int k = A.candIdx[base + lane + 64 * q];
+            cv[q] = A.candVal[base + lane + 64 * q];
+            ck[q] = k;
+            cx[q] = k >= 0 ? c * cell + k % cell : 0;
+            cy[q] = k >= 0 ? r * cell + k / cell : 0;
         }
     };
     {
@@ -217,35 +258,50 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
             int prim = -1, sec = -1;
             const int x0 = c * cell, y0 = r * cell;
             if (usable(r, c)) {
-                if (slot > 0) prefetch(r, c);  // more than 16 cells on this wavefront: fetch late (rare: only for nCH > 32)
+                if (slot > 0) prefetch(r, c);  // more than 16 cells on this wavefront (nCH > 32): fetch late
                 for (int pass = 0; pass < 2; pass++) {
-                    float best = -3.402823466e+38f;
-                    int bi = 0x7fffffff;
+                    // first unmasked candidate with a positive value, in sorted order = the reference's masked arg-max
+                    float best = 0.f;
+                    int bi = -1;
 #pragma unroll
-                    for (int q = 0; q < PER_LANE; q++) {
-                        if (offs[q] >= 0) {
-                            const int x = x0 + (offs[q] & 255), y = y0 + (offs[q] >> 8);
+                    for (int q = 0; q < 4; q++) {
+                        if (bi >= 0) break;
+                        bool hit = false;
+                        if (ck[q] >= 0 && cv[q] > 0.f) hit = (smask[cy[q] * wordsPerRow + (cx[q] >> 5)] >> (cx[q] & 31)) & 1u;
+                        const unsigned long long m = __ballot(hit);
+                        if (m) {
+                            const int src = __ffsll((long long) m) - 1;
+                            best = __shfl(cv[q], src);
+                            bi = __shfl(ck[q], src);
+                        }
+                    }
+                    if (bi < 0) {
+                        // rare: every listed candidate is masked (or <= 0): exact full scan of eig * mask, first maximum
+                        const float *eig = A.eig + (size_t) ci * n2;
+                        best = -3.402823466e+38f;
+                        bi = 0x7fffffff;
+                        for (int k = lane; k < n2; k += 64) {
+                            const int x = x0 + k % cell, y = y0 + k / cell;
                             const float m = (float) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
-                            const float v = pre[q] * m;
+                            const float v = eig[k] * m;
                             if (v > best) {
                                 best = v;
-                                bi = lane + 64 * q;
+                                bi = k;
                             }
                         }
-                    }
-                    // wave arg-max: largest value, then smallest index (= first maximum of the row-major scan)
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const float ob = __shfl_down(best, off);
-                        const int oi = __shfl_down(bi, off);
-                        if (ob > best || (ob == best && oi < bi)) {
-                            best = ob;
-                            bi = oi;
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const float ob = __shfl_down(best, off);
+                            const int oi = __shfl_down(bi, off);
+                            if (ob > best || (ob == best && oi < bi)) {
+                                best = ob;
+                                bi = oi;
+                            }
                         }
+                        best = __shfl(best, 0);
+                        bi = __shfl(bi, 0);
+                        if (bi == 0x7fffffff) bi = 0;  // nothing exceeded -FLT_MAX: minMaxLoc reports index 0
                     }
-                    best = __shfl(best, 0);
-                    bi = __shfl(bi, 0);
-                    if (bi == 0x7fffffff) bi = 0;  // nothing exceeded the initial -FLT_MAX: minMaxLoc reports index 0
                     const int mx = x0 + bi % cell, my = y0 + bi / cell;
                     if (mx < A.roiX || my < A.roiY || mx >= A.roiX + A.roiW || my >= A.roiY + A.roiH) break;  // `continue` of the cell loop
                     if ((double) best >= A.maxQuality) {
@@ -260,7 +316,6 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
                 A.sec[ci] = sec;
             }
         }
-        // prefetch this wave's first cell of the next wavefront while the others finish
         {
             int r, c;
             if (t < T && cell_of(t + 1, 0, r, c) && usable(r, c)) prefetch(r, c);
@@ -520,7 +575,8 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     const int nCells = A.nCW * A.nCH, n2 = cell_size * cell_size;
     if (nCells == 0) return ALVA_OK;
     size_t off_occ = (size_t) nCells * n2 * 4, off_prim = (off_occ + nCells + 63) / 64 * 64, off_sec = off_prim + (size_t) nCells * 4,
-           off_out = off_sec + (size_t) nCells * 4;
+           off_cv = (off_sec + (size_t) nCells * 4 + 63) / 64 * 64, off_ci = off_cv + (size_t) nCells * NCAND * 4,
+           off_out = off_ci + (size_t) nCells * NCAND * 4;
     uint8_t *base = nullptr;
     int rc = alva_ctx_scratch(ctx, 5, off_out + 64, (void **) &base);
     if (rc) return rc;
@@ -528,28 +584,22 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     A.cellOcc = base + off_occ;
     A.prim = (int *) (base + off_prim);
     A.sec = (int *) (base + off_sec);
+    A.candVal = (float *) (base + off_cv);
+    A.candIdx = (int *) (base + off_ci);
     CompactOut *d_cnt = (CompactOut *) (base + off_out);
     hipStream_t st = ctx->stream;
     ALVA_HIP(hipMemsetAsync(A.cellOcc, 0, (size_t) nCells, st));
     if (n_occ > 0) hipLaunchKernelGGL(k_mark_occupied, dim3(alva_divup(n_occ, 256)), dim3(256), 0, st, A);
-    const size_t lds_eig = (size_t) n2 * (4 + 4 + 8 + 12 + 1) + (size_t) (cell_size + 2) * (cell_size + 2) + 64;
+    int np2 = 256;
+    while (np2 < n2) np2 <<= 1;
+    const size_t lds_eig = (size_t) n2 * (4 + 4 + 8 + 12 + 1) + (size_t) (cell_size + 2) * (cell_size + 2) + 32 + (size_t) np2 * 8;
+    ALVA_ARG(lds_eig <= 64 * 1024);
     hipLaunchKernelGGL(k_cell_eig, dim3(nCells), dim3(256), lds_eig, st, A);
     const size_t lds_mask = (size_t) ((width + 31) / 32) * height * 4 + (size_t) nCells + 16;
     ALVA_ARG(lds_mask <= 160 * 1024 - 1024);
-    const int per_lane = (n2 + 63) / 64;
-#define ALVA_SELECT(PL)                                                                                                          \
-    do {                                                                                                                         \
-        if (lds_mask > 48 * 1024)                                                                                                \
-            ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select<PL>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         160 * 1024 - 1024));                                                                   \
-        hipLaunchKernelGGL(k_select<PL>, dim3(1), dim3(1024), lds_mask, st, A);                                                  \
-    } while (0)
-    if (per_lane <= 3) ALVA_SELECT(3);
-    else if (per_lane <= 4) ALVA_SELECT(4);
-    else if (per_lane <= 9) ALVA_SELECT(9);
-    else if (per_lane <= 16) ALVA_SELECT(16);
-    else ALVA_SELECT(25);
-#undef ALVA_SELECT
+    if (lds_mask > 48 * 1024)
+        ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_mask, st, A);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, A, d_out_pts, cap, d_cnt);
     ALVA_LAUNCH_CHECK();
     // one wave per candidate slot; the kernel reads the actual count from device memory (no host round trip before it)
