@@ -50,6 +50,8 @@ struct GridArgs {
     int *prim;        // [nCells] packed (y << 16 | x) or -1
     int *sec;         // [nCells]
     int hw[MAX_CELL / 4 + 1];  // filled-circle half widths
+    int dbg;
+    long long *dbgbuf;  // optional cycle counters (ALVA_DBG_SELECT=5)
 };
 
 __global__ void __launch_bounds__(256) k_mark_occupied(GridArgs A) {
@@ -193,95 +195,141 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void clear_circle(uint32_t *mask, int wordsPerRow, int w, int h, int cx, int cy, int radius, const int *hw,
-                                             int lane, int nlanes) {
-    const int side = 2 * radius + 1;
-    for (int i = lane; i < side * side; i += nlanes) {
-        const int dy = i / side - radius, dx = i % side - radius;
-        const int half = hw[dy < 0 ? -dy : dy];
-        const int x = cx + dx, y = cy + dy;
-        if ((dx < 0 ? -dx : dx) <= half && x >= 0 && x < w && y >= 0 && y < h) atomicAnd(&mask[y * wordsPerRow + (x >> 5)], ~(1u << (x & 31)));
-    }
-}
-
 __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
     extern __shared__ uint32_t smask[];
-    const int wordsPerRow = (A.w + 31) / 32;
+    // kernel arguments live in the kernarg segment: copy what the dependent loop needs into registers once, so that no
+    // scalar load (and its wait) sits on the per-wavefront critical path
+    const int IW = A.w, IH = A.h, NCW = A.nCW, NCH = A.nCH, RX0 = A.roiX, RY0 = A.roiY, RX1 = A.roiX + A.roiW, RY1 = A.roiY + A.roiH;
+    const int DBG = A.dbg, RAD = A.radius;
+    const double MAXQ = A.maxQuality;
+    const float *const EIG = A.eig;
+    const float *const CANDV = A.candVal;
+    const int *const CANDI = A.candIdx;
+    const int wordsPerRow = (IW + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = 16;
-    uint8_t *s_occ = reinterpret_cast<uint8_t *>(smask + wordsPerRow * A.h);  // per-cell occupied flags, LDS copy
-    for (int i = threadIdx.x; i < wordsPerRow * A.h; i += 1024) smask[i] = 0xffffffffu;
-    for (int i = threadIdx.x; i < A.nCW * A.nCH; i += 1024) s_occ[i] = A.cellOcc[i];
-    __syncthreads();
-    // pre-zero circles of the occupied keypoints, centre = Point(cvRound(px)) (:32-36)
-    for (int k = wave; k < A.nOcc; k += nwaves) {
-        const float px = A.occupied[2 * k], py = A.occupied[2 * k + 1];
-        clear_circle(smask, wordsPerRow, A.w, A.h, __float2int_rn(px), __float2int_rn(py), A.radius, A.hw, lane, 64);
+    const int cell = A.cell, n2 = cell * cell, side = 2 * RAD + 1;
+    uint8_t *s_occ = reinterpret_cast<uint8_t *>(smask + wordsPerRow * IH);   // per-cell occupied flags
+    uint16_t *s_xy = reinterpret_cast<uint16_t *>(s_occ + ((NCW * NCH + 15) & ~15));  // in-cell index -> (dy << 8) | dx
+    uint16_t *s_circ = s_xy + ((n2 + 7) & ~7);  // filled-circle pixels: ((dy + 128) << 8) | (dx + 128), 0xffff = outside
+    // results stay in LDS until the end: on CDNA4 vmcnt also counts stores, so a global store per step would sit on the
+    // critical path of the next step's candidate-load wait
+    int *s_prim = reinterpret_cast<int *>(s_circ + ((side * side + 7) & ~7));
+    int *s_sec = s_prim + NCW * NCH;
+    for (int i = threadIdx.x; i < NCW * NCH; i += 1024) {
+        s_prim[i] = -1;
+        s_sec[i] = -1;
+    }
+    for (int i = threadIdx.x; i < wordsPerRow * IH; i += 1024) smask[i] = 0xffffffffu;
+    for (int i = threadIdx.x; i < NCW * NCH; i += 1024) s_occ[i] = A.cellOcc[i];
+    for (int i = threadIdx.x; i < n2; i += 1024) s_xy[i] = (uint16_t) (((i / cell) << 8) | (i % cell));
+    for (int i = threadIdx.x; i < side * side; i += 1024) {
+        const int dy = i / side - RAD, dx = i % side - RAD;
+        const int half = A.hw[dy < 0 ? -dy : dy];
+        s_circ[i] = (dx < 0 ? -dx : dx) <= half ? (uint16_t) (((dy + 128) << 8) | (dx + 128)) : (uint16_t) 0xffff;
     }
     __syncthreads();
-    const int cell = A.cell, n2 = cell * cell;
-    const int T = (A.nCW - 1) + 2 * (A.nCH - 1);
-    // Each wave's cells are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16 k), so the sorted
-    // candidate list of the NEXT cell (4 per lane) is fetched before the barrier that releases it; inside the dependent
-    // section a pass is: one LDS mask bit per candidate, one ballot, one circle of LDS atomics.
-    float cv[4];
-    int cx[4], cy[4], ck[4];
-    auto cell_of = [&](int t, int slot, int &r, int &c) -> bool {
-        const int rmin = max(0, (t - (A.nCW - 1) + 1) / 2), rmax = min(A.nCH - 1, t / 2);
-        r = rmin + wave + slot * nwaves;
-        c = t - 2 * r;
-        return r <= rmax && c >= 0 && c < A.nCW;
-    };
-    auto usable = [&](int r, int c) -> bool {
-        const int ci = r * A.nCW + c;
-        return !s_occ[ci] && (c * cell + cell < A.w - 1 && r * cell + cell < A.h - 1);
-    };
-    auto prefetch = [&](int r, int c) {
-        const size_t base = (size_t) (r * A.nCW + c) * NCAND;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int k = A.candIdx[base + lane + 64 * q];
-            cv[q] = A.candVal[base + lane + 64 * q];
-            ck[q] = k;
-            cx[q] = k >= 0 ? c * cell + k % cell : 0;
-            cy[q] = k >= 0 ? r * cell + k / cell : 0;
+    const unsigned circ0 = lane < side * side ? s_circ[lane] : 0xffffu;  // this lane's circle pixel (radius <= 3: all of them)
+    auto clear = [&](int cx, int cy) {
+        for (int i = lane; i < side * side; i += 64) {
+            const unsigned e = i == lane ? circ0 : s_circ[i];
+            if (e == 0xffffu) continue;
+            const int x = cx + (int) (e & 255u) - 128, y = cy + (int) (e >> 8) - 128;
+            if (x >= 0 && x < IW && y >= 0 && y < IH) atomicAnd(&smask[y * wordsPerRow + (x >> 5)], ~(1u << (x & 31)));
         }
     };
+    // pre-zero circles of the occupied keypoints, centre = Point(cvRound(px)) (:32-36)
+    for (int k = wave; k < A.nOcc; k += nwaves) clear(__float2int_rn(A.occupied[2 * k]), __float2int_rn(A.occupied[2 * k + 1]));
+    __syncthreads();
+    const int T = (NCW - 1) + 2 * (NCH - 1);
+    // Each wave's cells are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16 k).  The sorted
+    // candidate list of the NEXT wavefront's cell (4 per lane) is requested from HBM/L2 at the START of a step and first
+    // touched after the barrier that ends it, so the load latency hides behind the current cell + the barrier; inside
+    // the dependent section a pass is: one LDS mask bit per candidate, one ballot, one circle of LDS atomics.
+    constexpr int SLOTS = 3;  // cells per wave per wavefront whose candidates are prefetched (16 waves x 3 = 48 cells)
+    float cv[SLOTS][4], nv[SLOTS][4];
+    int ck[SLOTS][4], nk[SLOTS][4];
+    auto cell_of = [&](int t, int slot, int &r, int &c) -> bool {
+        const int rmin = max(0, (t - (NCW - 1) + 1) / 2), rmax = min(NCH - 1, t / 2);
+        r = rmin + wave + slot * nwaves;
+        c = t - 2 * r;
+        return r <= rmax && c >= 0 && c < NCW;
+    };
+    auto usable = [&](int r, int c) -> bool {
+        const int ci = r * NCW + c;
+        return !s_occ[ci] && (c * cell + cell < IW - 1 && r * cell + cell < IH - 1);
+    };
+#define ALVA_LOAD_CANDS(V, K, r, c)                                                   \
+    do {                                                                              \
+        const size_t base_ = (size_t) ((r) * NCW + (c)) * NCAND;                     \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                               \
+            K[q] = CANDI[base_ + lane + 64 * q];                                  \
+            V[q] = CANDV[base_ + lane + 64 * q];                                  \
+        }                                                                             \
+    } while (0)
     {
         int r, c;
-        if (cell_of(0, 0, r, c) && usable(r, c)) prefetch(r, c);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++)
+            if (cell_of(0, sl, r, c) && usable(r, c)) ALVA_LOAD_CANDS(cv[sl], ck[sl], r, c);
     }
+    long long c_pre = 0, c_work = 0, c_bar = 0, c_rot = 0, c0 = 0, c1 = 0;
     for (int t = 0; t <= T; t++) {
-        for (int slot = 0;; slot++) {
+        if (DBG == 5) c0 = wall_clock64();
+        {
             int r, c;
-            if (!cell_of(t, slot, r, c)) break;
-            const int ci = r * A.nCW + c;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; sl++)
+                if (t < T && cell_of(t + 1, sl, r, c) && usable(r, c)) ALVA_LOAD_CANDS(nv[sl], nk[sl], r, c);
+        }
+        if (DBG == 5) { c1 = wall_clock64(); c_pre += c1 - c0; c0 = c1; }
+#pragma unroll
+        for (int slot = 0; slot < SLOTS + 1; slot++) {
+          // slots 0..SLOTS-1 use prefetched registers; slot SLOTS loops over any remaining cells with late fetches
+          for (int sl2 = slot;; sl2 += 1) {
+            int r, c;
+            if (!cell_of(t, sl2, r, c)) break;
+            float (&CV)[4] = cv[slot < SLOTS ? slot : 0];
+            int (&CK)[4] = ck[slot < SLOTS ? slot : 0];
+            const int ci = r * NCW + c;
             int prim = -1, sec = -1;
             const int x0 = c * cell, y0 = r * cell;
-            if (usable(r, c)) {
-                if (slot > 0) prefetch(r, c);  // more than 16 cells on this wavefront (nCH > 32): fetch late
-                for (int pass = 0; pass < 2; pass++) {
+            if (usable(r, c) && DBG != 1) {
+                if (slot >= SLOTS) ALVA_LOAD_CANDS(CV, CK, r, c);  // more than 48 cells on this wavefront: fetch late
+                // absolute pixel of each candidate (one batch of independent LDS reads per cell, not per pass)
+                int cxy[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned e = CK[q] >= 0 ? s_xy[CK[q]] : 0u;
+                    cxy[q] = ((y0 + (int) (e >> 8)) << 16) | (x0 + (int) (e & 255u));
+                }
+                for (int pass = 0; pass < (DBG == 2 ? 1 : 2); pass++) {
                     // first unmasked candidate with a positive value, in sorted order = the reference's masked arg-max
                     float best = 0.f;
-                    int bi = -1;
+                    int bi = -1, bxy = 0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         if (bi >= 0) break;
                         bool hit = false;
-                        if (ck[q] >= 0 && cv[q] > 0.f) hit = (smask[cy[q] * wordsPerRow + (cx[q] >> 5)] >> (cx[q] & 31)) & 1u;
+                        if (CK[q] >= 0 && CV[q] > 0.f) {
+                            const int x = cxy[q] & 0xffff, y = cxy[q] >> 16;
+                            hit = DBG == 4 ? true : (bool) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
+                        }
                         const unsigned long long m = __ballot(hit);
                         if (m) {
-                            const int src = __ffsll((long long) m) - 1;
-                            best = __shfl(cv[q], src);
-                            bi = __shfl(ck[q], src);
+                            const int src = __ffsll((long long) m) - 1;  // wave-uniform -> v_readlane, no LDS crossbar
+                            best = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(CV[q]), src));
+                            bi = __builtin_amdgcn_readlane(CK[q], src);
+                            bxy = __builtin_amdgcn_readlane(cxy[q], src);
                         }
                     }
                     if (bi < 0) {
                         // rare: every listed candidate is masked (or <= 0): exact full scan of eig * mask, first maximum
-                        const float *eig = A.eig + (size_t) ci * n2;
+                        const float *eig = EIG + (size_t) ci * n2;
                         best = -3.402823466e+38f;
                         bi = 0x7fffffff;
                         for (int k = lane; k < n2; k += 64) {
-                            const int x = x0 + k % cell, y = y0 + k / cell;
+                            const unsigned e = s_xy[k];
+                            const int x = x0 + (int) (e & 255u), y = y0 + (int) (e >> 8);
                             const float m = (float) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
                             const float v = eig[k] * m;
                             if (v > best) {
@@ -301,27 +349,48 @@ __global__ void __launch_bounds__(1024) k_select(GridArgs A) {
                         best = __shfl(best, 0);
                         bi = __shfl(bi, 0);
                         if (bi == 0x7fffffff) bi = 0;  // nothing exceeded -FLT_MAX: minMaxLoc reports index 0
+                        const unsigned eb = s_xy[bi];
+                        bxy = ((y0 + (int) (eb >> 8)) << 16) | (x0 + (int) (eb & 255u));
                     }
-                    const int mx = x0 + bi % cell, my = y0 + bi / cell;
-                    if (mx < A.roiX || my < A.roiY || mx >= A.roiX + A.roiW || my >= A.roiY + A.roiH) break;  // `continue` of the cell loop
-                    if ((double) best >= A.maxQuality) {
+                    const int mx = bxy & 0xffff, my = bxy >> 16;
+                    if (mx < RX0 || my < RY0 || mx >= RX1 || my >= RY1) break;  // `continue` of the cell loop
+                    if ((double) best >= MAXQ) {
                         if (pass == 0) prim = (my << 16) | mx;
                         else sec = (my << 16) | mx;
-                        clear_circle(smask, wordsPerRow, A.w, A.h, mx, my, A.radius, A.hw, lane, 64);
+                        if (DBG != 3) clear(mx, my);
                     }
                 }
             }
             if (lane == 0) {
-                A.prim[ci] = prim;
-                A.sec[ci] = sec;
+                s_prim[ci] = prim;
+                s_sec[ci] = sec;
             }
+            if (slot < SLOTS) break;  // prefetched slots handle exactly one cell each
+          }
         }
-        {
-            int r, c;
-            if (t < T && cell_of(t + 1, 0, r, c) && usable(r, c)) prefetch(r, c);
-        }
+        if (DBG == 5) { c1 = wall_clock64(); c_work += c1 - c0; c0 = c1; }
         __syncthreads();
+        if (DBG == 5) { c1 = wall_clock64(); c_bar += c1 - c0; c0 = c1; }
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                cv[sl][q] = nv[sl][q];
+                ck[sl][q] = nk[sl][q];
+            }
+        if (DBG == 5) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = wall_clock64(); c_rot += c1 - c0; }
     }
+    if (DBG == 5 && A.dbgbuf && lane == 0) {
+        A.dbgbuf[4 * wave + 0] = c_pre;
+        A.dbgbuf[4 * wave + 1] = c_work;
+        A.dbgbuf[4 * wave + 2] = c_bar;
+        A.dbgbuf[4 * wave + 3] = c_rot;
+    }
+    for (int i = threadIdx.x; i < NCW * NCH; i += 1024) {
+        A.prim[i] = s_prim[i];
+        A.sec[i] = s_sec[i];
+    }
+#undef ALVA_LOAD_CANDS
 }
 
 struct CompactOut {
@@ -572,6 +641,13 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     A.occupied = d_occupied;
     A.nOcc = n_occ;
     circle_halfwidths(A.radius, A.hw);
+    A.dbg = getenv("ALVA_DBG_SELECT") ? atoi(getenv("ALVA_DBG_SELECT")) : 0;
+    A.dbgbuf = nullptr;
+    if (A.dbg == 5) {
+        static long long *dbg_dev = nullptr;
+        if (!dbg_dev) (void) hipMalloc((void **) &dbg_dev, 64 * 8);
+        A.dbgbuf = dbg_dev;
+    }
     const int nCells = A.nCW * A.nCH, n2 = cell_size * cell_size;
     if (nCells == 0) return ALVA_OK;
     size_t off_occ = (size_t) nCells * n2 * 4, off_prim = (off_occ + nCells + 63) / 64 * 64, off_sec = off_prim + (size_t) nCells * 4,
@@ -595,7 +671,8 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     const size_t lds_eig = (size_t) n2 * (4 + 4 + 8 + 12 + 1) + (size_t) (cell_size + 2) * (cell_size + 2) + 32 + (size_t) np2 * 8;
     ALVA_ARG(lds_eig <= 64 * 1024);
     hipLaunchKernelGGL(k_cell_eig, dim3(nCells), dim3(256), lds_eig, st, A);
-    const size_t lds_mask = (size_t) ((width + 31) / 32) * height * 4 + (size_t) nCells + 16;
+    const int side = 2 * A.radius + 1;
+    const size_t lds_mask = (size_t) ((width + 31) / 32) * height * 4 + (size_t) nCells + 16 + (size_t) (n2 + 8) * 2 + (size_t) (side * side + 8) * 2 + (size_t) nCells * 8 + 64;
     ALVA_ARG(lds_mask <= 160 * 1024 - 1024);
     if (lds_mask > 48 * 1024)
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
@@ -609,6 +686,14 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     CompactOut res;
     ALVA_HIP(hipMemcpyAsync(&res, d_cnt, sizeof(res), hipMemcpyDeviceToHost, st));
     ALVA_HIP(hipStreamSynchronize(st));
+    if (A.dbg == 5 && A.dbgbuf) {
+        long long hb[64];
+        (void) hipMemcpy(hb, A.dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
+        static int once = 0;
+        if (once++ == 3)
+            for (int wv = 0; wv < 16; wv++)
+                fprintf(stderr, "[select dbg] wave %2d: prefetch %lld work %lld barrier %lld rotate %lld (100 MHz ticks)\n", wv, hb[4 * wv], hb[4 * wv + 1], hb[4 * wv + 2], hb[4 * wv + 3]);
+    }
     *h_count = res.n_total;
     // adaptive threshold (:138-145)
     const double freeCells = (double) ((size_t) nCells - (size_t) res.n_occupied);

@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- hot-path throughput on MI355X, one JSON line (see the driver contract).
 
-A "step" is one pass of the per-frame hot path (BASELINE.json configs[1]: 640x480 stream, ~2000 keypoints
-per frame) over one synthetic frame whose RGBA bytes are ALREADY resident in HBM:
-    RGBA -> gray -> LK pyramid (+Scharr)        (a2, a3; one fused chain of launches)
+A "step" is one pass of the per-frame hot path of BASELINE.json configs[1] ("640x480 stream, 2000 kp/frame, FAST+ORB+
+Hamming match+PnP full track") over one synthetic frame whose RGBA bytes are ALREADY resident in HBM:
+    RGBA -> gray -> LK pyramid (+Scharr)                                            (a2, a3; one fused chain of launches)
     forward-backward KLT of the previous frame's keypoints, 3 pyramid levels        (a4)
-    grid Shi-Tomasi detection of ~2120 keypoints on the new frame (the reference's detector, cell 12)   (a5)
-    256-bit ORB description of the keypoints                                        (a6)
-    brute-force Hamming match against the previous frame's descriptors             (a7)
+    FAST-pyramid + ORB detectAndCompute, nfeatures 2000, 8 levels (the north_star-named detector)   (a5', a6)
+    brute-force Hamming match of the new descriptors against the previous frame's  (a7)
     P3P + LMedS (100 hypotheses) and robust PnP refinement (5 LM iterations) on ~2000 3-D/2-D pairs (a8, a9)
 `value` = frames/s over all ranks (streams are independent: one per GPU, no collective on the data path).
+The same loop with the REFERENCE-ACTUAL detector (grid Shi-Tomasi, cell 12 => 2120 keypoints, + cornerSubPix + ORB
+description of those points; a5 + a6) is timed as well and reported as "ref_detector_variant".
 The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3000 pts, 5 LM iterations), is
 measured in the same run and reported under "local_ba".
 
@@ -67,6 +68,7 @@ class FrameJob:
         self.K = pb["K"]
         self.pose0 = pb["pose_init"]
         self.k = 0
+        self.orb = alvaar_amd.Orb(self.ctx, W, H, 2000)
         self.maxq = 0.001
         self._det = torch.zeros((NKP, 2), dtype=torch.float32, device=self.dev)
         # prime: frame 0 pyramid + descriptors
@@ -82,14 +84,17 @@ class FrameJob:
             self._det[n:] = self.pts[n:]
         return self._det
 
-    def step(self):
+    def step(self, grid_detector: bool = False):
         ctx = self.ctx
         self.k += 1
         cur, prev = self.pyr[self.k % 2], self.pyr[(self.k - 1) % 2]
         cur.build_from_rgba(self.frames[self.k % RING], self.gray)                    # a2 + a3
         tracked, status = ctx.fbklt_track(prev, cur, self.pts, self.pts, 3)           # a4
-        det, self.maxq = ctx.detect_grid(self.gray, 12, max_quality=self.maxq)         # a5 (count -> host)
-        desc, valid = ctx.describe(self.gray, self.det_buf(det))                       # a6
+        if grid_detector:
+            det, self.maxq = ctx.detect_grid(self.gray, 12, max_quality=self.maxq)     # a5 (count -> host)
+            desc, valid = ctx.describe(self.gray, self.det_buf(det))                   # a6
+        else:
+            kp, desc = self.orb.detect_and_compute(self.gray)                          # a5' + a6 (count -> host)
         idx, dist = ctx.bf_match_hamming(desc, self.prev_desc)                         # a7
         ok, R, t, outl = ctx.p3p_lmeds(self.bv, self.wpt, 100, 3.0, self.K[0], self.K[1])   # a8 (host result)
         ok2, pose, outl2, info = ctx.pnp_refine(self.uv, self.wpt, self.pose0, self.K)       # a9 (host result)
@@ -104,6 +109,7 @@ class FrameJob:
         tracked, _ = ctx.fbklt_track(prev, cur, self.pts, self.pts, 3)
         desc, _ = ctx.describe(self.gray, tracked)
         stages = {
+            "orb_detect_and_compute": lambda: self.orb.detect_and_compute(self.gray),
             "detect_grid": lambda: ctx.detect_grid(self.gray, 12, max_quality=0.001),
             "gray+pyramid": lambda: cur.build_from_rgba(self.frames[2], self.gray),
             "fbklt": lambda: ctx.fbklt_track(prev, cur, self.pts, self.pts, 3),
@@ -152,16 +158,13 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
     pts = make_keypoints(NKP, seed)
     pb = synth.make_pnp_problem(NKP, seed, outlier_frac=0.1, pose_noise=0.01)
     prev = O.rgba2gray(frames[0])
-    prev_desc, _ = O.describe(prev, pts)
+    _, prev_desc = O.orb(prev, 2000)
     n, t0 = 0, time.perf_counter()
     while True:
         k = 1 + n % 3
         g = O.rgba2gray(frames[k])
         tracked, st = O.fbklt(prev, g, pts, pts, 3)        # builds both pyramids internally (the reference reuses prev's)
-        det, _ = O.detect_grid(g, 12)
-        dpts = pts.copy()
-        dpts[:min(len(det), NKP)] = det[:NKP]
-        desc, _ = O.describe(g, dpts)
+        kp, desc = O.orb(g, 2000)
         O.bf_match(desc, prev_desc)
         O.p3p_lmeds(pb["bv"], pb["wpt"])
         O.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"])
@@ -174,8 +177,8 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
     r = O.local_ba(pbba, 5, 0.0)
     dtb = time.perf_counter() - t1
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{n} frames of the same 640x480 / {NKP}-keypoint step (gray, 2 LK pyramids, fb-KLT 3 lvl, grid detect cell 12, ORB describe, "
-                      f"BF Hamming {NKP}^2, P3P-LMedS 100 it, Ceres PnP) + 1 local-BA solve",
+            "sample": f"{n} frames of the same 640x480 / {NKP}-keypoint step (gray, 2 LK pyramids, fb-KLT 3 lvl, cv::ORB detectAndCompute 2000, "
+                      f"BF Hamming, P3P-LMedS 100 it, Ceres PnP) + 1 local-BA solve",
             "local_ba_residual_block_iters_per_s": len(pbba["obs_kf"]) * (int(r["info"][0]) - 1) / dtb,
             "local_ba_ms": dtb * 1e3}
 
@@ -212,26 +215,40 @@ def main():
         td.barrier()
     torch.cuda.synchronize()
 
+    # secondary: the same loop with the reference-actual detector
+    for _ in range(3):
+        job.step(grid_detector=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step(grid_detector=True)
+    torch.cuda.synchronize()
+    dt_grid = time.perf_counter() - t1
+    if dist:
+        dt_grid = multi.max_over_ranks(dt_grid, torch.device("cuda", local))
+        td.barrier()
     if rank == 0:
         fps = world * args.steps / dt
         stage_us = job.stage_times()
         ba, _ = bench_ba(job.ctx)
         P = W * H
         # ALGORITHMIC bytes per launch chain: rgba->gray 5P + pyramid/Scharr 6.64P
-        alg_bytes = {"detect_grid": P + 4 * P + 8 * NKP, "gray+pyramid": (4 + 1 + 6.64) * P, "describe(blur7+brief)": 2 * P + 40 * NKP,
+        alg_bytes = {"orb_detect_and_compute": 6.5 * P + 2 * 3.27 * P + 44 * 2000, "detect_grid": P + 4 * P + 8 * NKP, "gray+pyramid": (4 + 1 + 6.64) * P, "describe(blur7+brief)": 2 * P + 40 * NKP,
                      "fbklt": 2 * 6.64 * P + 24 * NKP, "bf_hamming": 32 * 2 * NKP + 8 * NKP}
-        dom = max(("detect_grid", "gray+pyramid", "fbklt", "describe(blur7+brief)", "bf_hamming"), key=lambda k: stage_us[k])
+        dom = max(("orb_detect_and_compute", "gray+pyramid", "fbklt", "bf_hamming"), key=lambda k: stage_us[k])
         achieved = alg_bytes[dom] / (stage_us[dom] * 1e-6) / 1e9
         out = {
             "metric": "frames/sec @640x480 2000kp; local-BA residuals/sec (20KFx3k pts)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 image stages, f32 KLT, f64 pose+BA", "data": "synthetic",
-            "config": {"workload": "c640_track: 640x480 RGBA stream, 2120 kp/frame",
-                       "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels)", "detect_grid(cell 12)+cornerSubPix", "orb_describe",
-                                  "bf_hamming 2120x2120", "p3p_lmeds(100)", "pnp_refine(5 it)"],
+            "config": {"workload": "configs[1]: 640x480 RGBA stream, ORB 2000 kp/frame, FAST+ORB+Hamming match+KLT+PnP full track",
+                       "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels, 2120 pts)", "orb_detect_and_compute(2000, 1.2, 8)",
+                                  "bf_hamming ~2000x2000", "p3p_lmeds(100 it, 2120 pts)", "pnp_refine(5 it, 2120 pts)"],
                        "not_in_timed_region": [],
                        "parallelism": f"{world} independent streams, one per GPU, no collective"},
+            "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,
+                                     "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
             "local_ba": ba,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
