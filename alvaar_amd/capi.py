@@ -64,6 +64,7 @@ _sig("alva_fast", [_vp, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _vp])
 _sig("alva_orb_create", [_vp, _i, _i, _i, _f, _i, _i, C.POINTER(_vp)])
 _sig("alva_orb_destroy", [_vp], None)
 _sig("alva_orb_detect_and_compute", [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp])
+_sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
@@ -211,6 +212,19 @@ class Context:
         check(lib.alva_fast(self.h, _ptr(gray), gray.stride(0), w, h, threshold, _ptr(xy), _ptr(sc), cap, C.byref(cnt)))
         n = min(cnt.value, cap)
         return xy[:n], sc[:n]
+
+    # a8 + a9 chained
+    def compute_pose(self, bearings, uv, wpts, K, p3p_iters=100, p3p_err=3.0, pnp_iters=5, chi2th=5.9915, do_random=False, seed=12345):
+        """VisualFrontend::computePose: returns (status 0/1/2, pose7, p3p_outlier mask, pnp_outlier mask)."""
+        import numpy as np
+        n = bearings.shape[0]
+        pose = np.zeros(7)
+        m1 = np.zeros(max(n, 1), np.uint8)
+        m2 = np.zeros(max(n, 1), np.uint8)
+        st = C.c_int(0)
+        check(lib.alva_compute_pose(self.h, _ptr(bearings), _ptr(uv), _ptr(wpts), n, p3p_iters, p3p_err, int(do_random), seed, pnp_iters,
+                                    chi2th, K[0], K[1], K[2], K[3], pose.ctypes.data, m1.ctypes.data, m2.ctypes.data, C.byref(st)))
+        return st.value, pose, m1[:n].astype(bool), m2[:n].astype(bool)
 
     # a6
     def orb_blur(self, gray):

@@ -13,6 +13,7 @@
 //        (features2d/src/keypoint.cpp:105-117; src/slam/src/feature_extractor.cpp:191-209); angle is the
 //        constant -1 degree because KeyPoint::convert sets angle = -1 (core/src/types.cpp:93-101).
 #include "common.hpp"
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -37,12 +38,12 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 constexpr int BT_W = 64, BT_H = 16;
 
 // One block: BT_W x BT_H outputs.  LDS: u8 tile with 3 px halo, then row-filtered floats.
-__global__ void __launch_bounds__(256) k_blur7(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h,
-                                               uint8_t *__restrict__ dst, size_t dst_pitch) {
+__device__ __forceinline__ void blur7_tile(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, uint8_t *__restrict__ dst,
+                                           size_t dst_pitch, int bx, int by) {
     __shared__ uint8_t s_px[BT_H + 6][BT_W + 8];
     __shared__ float s_row[BT_H + 6][BT_W + 1];
     const int tx = threadIdx.x % BT_W, ty = threadIdx.x / BT_W;  // 64 x 4
-    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const int x0 = bx * BT_W, y0 = by * BT_H;
     for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
         int ly = i / (BT_W + 6), lx = i % (BT_W + 6);
         int gx = reflect101(x0 + lx - 3, w), gy = reflect101(y0 + ly - 3, h);
@@ -68,6 +69,25 @@ __global__ void __launch_bounds__(256) k_blur7(const uint8_t *__restrict__ src, 
         v = min(max(v, 0), 255);
         if (gx < w && gy < h) dst[(size_t) gy * dst_pitch + gx] = (uint8_t) v;
     }
+}
+
+__global__ void __launch_bounds__(256) k_blur7(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h,
+                                               uint8_t *__restrict__ dst, size_t dst_pitch) {
+    blur7_tile(src, src_pitch, w, h, dst, dst_pitch, blockIdx.x, blockIdx.y);
+}
+
+struct BlurBatch {
+    const uint8_t *src[12];
+    uint8_t *dst[12];
+    int w[12], h[12], pitch[12];
+};
+
+// all pyramid levels in ONE launch (blockIdx.y = level, blockIdx.x = tile)
+__global__ void __launch_bounds__(256) k_blur7_batch(BlurBatch B) {
+    const int l = blockIdx.y;
+    const int tilesX = (B.w[l] + BT_W - 1) / BT_W, tilesY = (B.h[l] + BT_H - 1) / BT_H;
+    if ((int) blockIdx.x >= tilesX * tilesY) return;
+    blur7_tile(B.src[l], (size_t) B.pitch[l], B.w[l], B.h[l], B.dst[l], (size_t) B.pitch[l], blockIdx.x % tilesX, blockIdx.x / tilesX);
 }
 
 // 32 lanes per keypoint: lane = descriptor byte = 8 tests = 16 samples.
@@ -103,6 +123,23 @@ __global__ void __launch_bounds__(256) k_brief(const uint8_t *__restrict__ img, 
 int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int w, int h, uint8_t *d_dst, size_t dst_pitch) {
     hipLaunchKernelGGL(k_blur7, dim3(alva_divup(w, BT_W), alva_divup(h, BT_H)), dim3(256), 0, ctx->stream, d_src, src_pitch, w, h,
                        d_dst, dst_pitch);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h,
+                            const int *pitch) {
+    BlurBatch B{};
+    int maxTiles = 0;
+    for (int l = 0; l < n && l < 12; l++) {
+        B.src[l] = src[l];
+        B.dst[l] = dst[l];
+        B.w[l] = w[l];
+        B.h[l] = h[l];
+        B.pitch[l] = pitch[l];
+        maxTiles = std::max(maxTiles, alva_divup(w[l], BT_W) * alva_divup(h[l], BT_H));
+    }
+    hipLaunchKernelGGL(k_blur7_batch, dim3(maxTiles, n), dim3(256), 0, ctx->stream, B);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

@@ -19,7 +19,8 @@
 #include "common.hpp"
 #include <cmath>
 
-int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int w, int h, uint8_t *d_dst, size_t dst_pitch);
+int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h,
+                            const int *pitch);
 
 namespace {
 
@@ -635,11 +636,19 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     hipLaunchKernelGGL(k_angle_emit, dim3(alva_divup(maxKeep, 4), D.nlevels), dim3(256), 0, st, D, d_kp, cap, orb->d_total);
     ALVA_LAUNCH_CHECK();
     if (d_desc) {
+        const uint8_t *bs[MAXLV];
+        uint8_t *bd[MAXLV];
+        int bw[MAXLV], bh[MAXLV], bp[MAXLV];
         for (int l = 0; l < D.nlevels; l++) {
             const Level &L = D.lv[l];
-            rc = alva_blur7_launch(ctx, D.pool + L.img, L.pitch, L.w, L.h, D.pool + L.blur, L.pitch);
-            if (rc) return rc;
+            bs[l] = D.pool + L.img;
+            bd[l] = D.pool + L.blur;
+            bw[l] = L.w;
+            bh[l] = L.h;
+            bp[l] = L.pitch;
         }
+        rc = alva_blur7_batch_launch(ctx, D.nlevels, bs, bd, bw, bh, bp);
+        if (rc) return rc;
         int nmax = 0;
         for (int l = 0; l < D.nlevels; l++) nmax += std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024));
         nmax = std::min(nmax, cap);

@@ -17,6 +17,7 @@
 // FP64 VALU work (100 x N x ~40 flop); bytes are negligible (48 N read once per hypothesis,
 // L2-resident).  No MFMA: nothing here is GEMM-shaped.
 #include "common.hpp"
+#include "pose_internal.hpp"
 #include <cmath>
 #include <ctime>
 #include <random>
@@ -312,10 +313,7 @@ __global__ void __launch_bounds__(256) k_median(const double *__restrict__ bv, c
     }
 }
 
-struct SelectOut {
-    double model[12];
-    int best, n_valid_used, n_inliers, have_model;
-};
+using SelectOut = P3pSelectOut;
 
 __global__ void __launch_bounds__(256) k_select(const double *__restrict__ bv, const double *__restrict__ wpt, int n, int H, int max_iters,
                                                 const double *__restrict__ models, const int *__restrict__ valid,
@@ -390,6 +388,49 @@ extern "C" int alva_p3p_draw_samples(int n_points, int count, int do_random, uin
     return ALVA_OK;
 }
 
+int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
+                     int do_random, uint32_t seed, float fx, float fy, int H, P3pSelectOut **d_out_p, uint8_t **d_inlier_p) {
+    ALVA_ARG(n >= 4 && n <= 7168);  // LDS-resident median select (n * 8 B + histogram < 64 KB)
+    float focal = fx + fy;          // multi_view_geometry.cpp:72-76
+    focal /= 2.f;
+    const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
+    std::vector<int> samples((size_t) H * 4);
+    {
+        Sampler smp(n, do_random != 0, seed);
+        for (int k = 0; k < H; k++) smp.draw(samples.data() + 4 * k);
+    }
+    // scratch layout: samples | models | valid | penalty | SelectOut | inlier mask
+    size_t off_models = (size_t) H * 4 * sizeof(int);
+    off_models = (off_models + 63) / 64 * 64;
+    size_t off_valid = off_models + (size_t) H * 12 * sizeof(double);
+    size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
+    size_t off_out = off_pen + (size_t) H * sizeof(double);
+    size_t off_inl = (off_out + sizeof(SelectOut) + 63) / 64 * 64;
+    size_t total = off_inl + (size_t) n;
+    uint8_t *base = nullptr;
+    int rc = alva_ctx_scratch(ctx, 2, total, (void **) &base);
+    if (rc) return rc;
+    int *d_samples = (int *) base;
+    double *d_models = (double *) (base + off_models);
+    int *d_valid = (int *) (base + off_valid);
+    double *d_pen = (double *) (base + off_pen);
+    SelectOut *d_out = (SelectOut *) (base + off_out);
+    uint8_t *d_inlier = base + off_inl;
+    // pageable source: the runtime stages the bytes before returning, so `samples` may go out of scope afterwards
+    ALVA_HIP(hipMemcpyAsync(d_samples, samples.data(), (size_t) H * 4 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, d_samples, H, d_models, d_valid);
+    ALVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) n * sizeof(double), ctx->stream, d_bearings, d_wpts, n, 0, d_models, d_valid,
+                       d_pen);
+    ALVA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, d_bearings, d_wpts, n, H, max_iters, d_models, d_valid, d_pen,
+                       threshold, d_out, d_inlier);
+    ALVA_LAUNCH_CHECK();
+    *d_out_p = d_out;
+    *d_inlier_p = d_inlier;
+    return ALVA_OK;
+}
+
 extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
                               int do_random, uint32_t seed, float fx, float fy, double *h_R, double *h_t, int *h_outliers,
                               int *h_n_outliers, int *h_ok) {
@@ -398,54 +439,18 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
     *h_n_outliers = 0;
     if (n < 4) return ALVA_OK;  // multi_view_geometry.cpp:41-44
     ALVA_ARG(d_bearings && d_wpts);
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    ALVA_ARG(n <= 7168);  // LDS-resident median select (n * 8 B + histogram < 64 KB)
-    float focal = fx + fy;  // :72-76
-    focal /= 2.f;
-    const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
-
     // draw max_iters + slack samples up front; hypotheses whose model fails do not count as an iteration in
     // the reference (Lmeds.hpp:88-92), so on the rare shortfall re-draw a longer prefix of the same stream.
     const int max_draws = max_iters + max_iters * 10;  // max_skip = 10 x max_iterations (Lmeds.hpp:67)
     int H = std::min(max_draws, max_iters + 28);
     SelectOut res{};
-    uint8_t *d_inlier = nullptr;
-    std::vector<uint8_t> inl;
+    std::vector<uint8_t> inl((size_t) n);
     for (;;) {
-        std::vector<int> samples((size_t) H * 4);
-        {
-            Sampler smp(n, do_random != 0, seed);
-            for (int k = 0; k < H; k++) smp.draw(samples.data() + 4 * k);
-        }
-        // scratch layout: samples | models | valid | penalty | SelectOut | inlier mask
-        size_t off_models = (size_t) H * 4 * sizeof(int);
-        off_models = (off_models + 63) / 64 * 64;
-        size_t off_valid = off_models + (size_t) H * 12 * sizeof(double);
-        size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
-        size_t off_out = off_pen + (size_t) H * sizeof(double);
-        size_t off_inl = (off_out + sizeof(SelectOut) + 63) / 64 * 64;
-        size_t total = off_inl + (size_t) n;
-        uint8_t *base = nullptr;
-        int rc = alva_ctx_scratch(ctx, 2, total, (void **) &base);
+        SelectOut *d_out = nullptr;
+        uint8_t *d_inlier = nullptr;
+        int rc = alva_p3p_enqueue(ctx, d_bearings, d_wpts, n, max_iters, err_threshold, do_random, seed, fx, fy, H, &d_out, &d_inlier);
         if (rc) return rc;
-        int *d_samples = (int *) base;
-        double *d_models = (double *) (base + off_models);
-        int *d_valid = (int *) (base + off_valid);
-        double *d_pen = (double *) (base + off_pen);
-        SelectOut *d_out = (SelectOut *) (base + off_out);
-        d_inlier = base + off_inl;
-        ALVA_HIP(hipMemcpyAsync(d_samples, samples.data(), (size_t) H * 4 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, d_samples, H, d_models, d_valid);
-        ALVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) n * sizeof(double), ctx->stream, d_bearings, d_wpts, n, np2, d_models,
-                           d_valid, d_pen);
-        ALVA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, d_bearings, d_wpts, n, H, max_iters, d_models, d_valid, d_pen,
-                           threshold, d_out, d_inlier);
-        ALVA_LAUNCH_CHECK();
         ALVA_HIP(hipMemcpyAsync(&res, d_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
-        inl.resize((size_t) n);
         ALVA_HIP(hipMemcpyAsync(inl.data(), d_inlier, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
         ALVA_HIP(hipStreamSynchronize(ctx->stream));
         if (res.n_valid_used >= max_iters || H >= max_draws) break;

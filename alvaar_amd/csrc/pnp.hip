@@ -15,6 +15,9 @@
 // the CU until the pose is final.  FP64 throughout (the reference is all double).
 #include "common.hpp"
 #include "lm_device.hpp"
+#include "pose_internal.hpp"
+#include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -36,6 +39,7 @@ struct PnpOut {
     double pose[7];
     double info[8];
     int ok, n_bad;
+    int p3p_ok, n_active;  // chained mode: P3P verdict and the number of points handed to the refinement
 };
 
 struct PnpShared {
@@ -258,15 +262,77 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
     return result;
 }
 
+// p3p / inlier0 non-null = chained mode (VisualFrontend::computePose, visual_frontend.cpp:300-375): the initial pose is the
+// P3P-LMedS model and only its inliers are refined; the P3P acceptance tests of multi_view_geometry.cpp:82-91 run here.
 __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict__ pose_in, uint8_t *__restrict__ active,
                                             double *__restrict__ chi2, uint8_t *__restrict__ depth, uint8_t *__restrict__ bad,
-                                            PnpOut *__restrict__ out) {
+                                            PnpOut *__restrict__ out, const P3pSelectOut *__restrict__ p3p,
+                                            const uint8_t *__restrict__ inlier0) {
     __shared__ PnpShared sh;
-    __shared__ int s_nbad;
-    if (threadIdx.x < 7) sh.x[threadIdx.x] = pose_in[threadIdx.x];
+    __shared__ int s_nbad, s_p3p_ok, s_nact;
     if (threadIdx.x < 8) out->info[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_nbad = 0;
-    for (int i = threadIdx.x; i < A.n; i += NT) active[i] = 1;
+    if (threadIdx.x == 0) {
+        s_nbad = 0;
+        s_nact = 0;
+        s_p3p_ok = 1;
+        if (p3p) {
+            const double *R = p3p->model;
+            double e = 0;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    const double v = R[3 * r] * R[3 * c] + R[3 * r + 1] * R[3 * c + 1] + R[3 * r + 2] * R[3 * c + 2] - (r == c ? 1.0 : 0.0);
+                    e += v * v;
+                }
+            s_p3p_ok = p3p->have_model && p3p->n_inliers >= 5 && sqrt(e) < 1e-10;
+            if (s_p3p_ok) {
+                // rotation matrix -> unit quaternion (Sophus::SE3d::setRotationMatrix -> Eigen::Quaternion(R))
+                double q[4];
+                const double tr = R[0] + R[4] + R[8];
+                if (tr > 0) {
+                    double t = sqrt(tr + 1.0);
+                    q[3] = 0.5 * t;
+                    t = 0.5 / t;
+                    q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+                } else {
+                    int i = R[4] > R[0] ? 1 : 0;
+                    if (R[8] > R[4 * i]) i = 2;
+                    const int j = (i + 1) % 3, k = (i + 2) % 3;
+                    double t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+                    q[i] = 0.5 * t;
+                    t = 0.5 / t;
+                    q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+                    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+                    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+                }
+                for (int c = 0; c < 3; c++) sh.x[c] = p3p->model[9 + c];
+                for (int c = 0; c < 4; c++) sh.x[3 + c] = q[c];
+            }
+        } else {
+            for (int c = 0; c < 7; c++) sh.x[c] = pose_in[c];
+        }
+    }
+    __syncthreads();
+    if (!s_p3p_ok) {
+        if (threadIdx.x == 0) {
+            out->ok = 0;
+            out->p3p_ok = 0;
+            out->n_bad = 0;
+            out->n_active = 0;
+        }
+        for (int i = threadIdx.x; i < A.n; i += NT) bad[i] = 0;
+        return;
+    }
+    {
+        int na = 0;
+        for (int i = threadIdx.x; i < A.n; i += NT) {
+            const uint8_t a = inlier0 ? inlier0[i] : (uint8_t) 1;
+            active[i] = a;
+            chi2[i] = 0.0;
+            depth[i] = 1;
+            na += a;
+        }
+        atomicAdd(&s_nact, na);
+    }
     __syncthreads();
     {
         // normalise like PoseParametersBlock(0, Sophus::SE3d(q, t)) does before the solve
@@ -278,9 +344,10 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict_
         __syncthreads();
     }
     int ok = solve(sh, A, A.use_robust, active, chi2, depth, out->info);
+    const int nact = s_nact;
     int nb = 0;
     for (int i = threadIdx.x; i < A.n; i += NT) {
-        const bool b = chi2[i] > A.chi2_th || !depth[i];  // multi_view_geometry.cpp:194-207
+        const bool b = active[i] && (chi2[i] > A.chi2_th || !depth[i]);  // multi_view_geometry.cpp:194-207
         bad[i] = b;
         if (b) {
             nb++;
@@ -290,12 +357,14 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict_
     atomicAdd(&s_nbad, nb);
     __syncthreads();
     const int nbad = s_nbad;
-    if (nbad == A.n) ok = 0;
+    if (nbad == nact) ok = 0;
     else if (A.apply_l2 && nbad > 0) ok = solve(sh, A, 0, active, chi2, depth, out->info + 4);  // :214-218
     if (threadIdx.x < 7) out->pose[threadIdx.x] = sh.x[threadIdx.x];
     if (threadIdx.x == 0) {
         out->ok = ok;
         out->n_bad = nbad;
+        out->p3p_ok = 1;
+        out->n_active = nact;
     }
 }
 
@@ -329,7 +398,7 @@ extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *
     if (rc) return rc;
     ALVA_HIP(hipMemcpyAsync(base, h_pose7, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, (const double *) base, base + off_act, (double *) (base + off_chi2),
-                       base + off_dep, base + off_bad, (PnpOut *) (base + off_out));
+                       base + off_dep, base + off_bad, (PnpOut *) (base + off_out), (const P3pSelectOut *) nullptr, (const uint8_t *) nullptr);
     ALVA_LAUNCH_CHECK();
     PnpOut res;
     std::vector<uint8_t> bad((size_t) n);
@@ -344,5 +413,66 @@ extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *
     if (no == n) return ALVA_OK;
     memcpy(h_pose7, res.pose, sizeof(res.pose));
     *h_ok = res.ok;
+    return ALVA_OK;
+}
+
+// VisualFrontend::computePose (src/slam/src/visual_frontend.cpp:245-417) as ONE device-side chain and ONE host
+// synchronisation: P3P-LMedS -> acceptance tests -> drop its outliers -> robust PnP on the inliers -> acceptance tests.
+extern "C" int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n, int p3p_iters,
+                                 float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx, float fy, float cx,
+                                 float cy, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier, int *h_status) {
+    ALVA_ARG(ctx && h_pose7 && h_status && n >= 0 && p3p_iters > 0 && pnp_iters >= 0);
+    *h_status = 0;
+    if (n < 4) return ALVA_OK;  // visual_frontend.cpp:249-257
+    ALVA_ARG(d_bearings && d_uv && d_wpts);
+    const int max_draws = p3p_iters + p3p_iters * 10;
+    int H = std::min(max_draws, p3p_iters + 28);
+    PnpArgs A{};
+    A.uv = d_uv;
+    A.wpt = d_wpts;
+    A.n = n;
+    A.K[0] = fx; A.K[1] = fy; A.K[2] = cx; A.K[3] = cy;
+    A.huber_a = (double) sqrtf(chi2_th);
+    A.chi2_th = (double) chi2_th;
+    A.use_robust = 1;   // visual_frontend.cpp:361
+    A.apply_l2 = 1;     // state.hpp:76 robustCostRefineWithL2_
+    A.max_iters = pnp_iters;
+    A.ftol = 1.e-3;
+    size_t off_out = 64, off_chi2 = off_out + ((sizeof(PnpOut) + 63) / 64) * 64;
+    size_t off_act = off_chi2 + (size_t) n * 8, off_dep = off_act + (size_t) n, off_bad = off_dep + (size_t) n;
+    uint8_t *base = nullptr;
+    int rc = alva_ctx_scratch(ctx, 3, off_bad + (size_t) n, (void **) &base);
+    if (rc) return rc;
+    PnpOut res{};
+    P3pSelectOut sel{};
+    std::vector<uint8_t> bad((size_t) n), inl((size_t) n);
+    for (;;) {
+        P3pSelectOut *d_sel = nullptr;
+        uint8_t *d_inl = nullptr;
+        rc = alva_p3p_enqueue(ctx, d_bearings, d_wpts, n, p3p_iters, p3p_err, do_random, seed, fx, fy, H, &d_sel, &d_inl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, (const double *) nullptr, base + off_act, (double *) (base + off_chi2),
+                           base + off_dep, base + off_bad, (PnpOut *) (base + off_out), (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl);
+        ALVA_LAUNCH_CHECK();
+        ALVA_HIP(hipMemcpyAsync(&res, base + off_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+        ALVA_HIP(hipMemcpyAsync(&sel, d_sel, sizeof(sel), hipMemcpyDeviceToHost, ctx->stream));
+        ALVA_HIP(hipMemcpyAsync(bad.data(), base + off_bad, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+        ALVA_HIP(hipMemcpyAsync(inl.data(), d_inl, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        if (sel.n_valid_used >= p3p_iters || H >= max_draws) break;
+        H = std::min(max_draws, H * 2);   // rare: too many degenerate samples, redo with a longer prefix of the stream
+    }
+    for (int i = 0; i < n; i++) {
+        if (h_p3p_outlier) h_p3p_outlier[i] = res.p3p_ok ? !inl[(size_t) i] : 0;
+        if (h_pnp_outlier) h_pnp_outlier[i] = bad[(size_t) i];
+    }
+    if (!res.p3p_ok) return ALVA_OK;                                   // :318-330 -> resetFrame, false
+    *h_status = 1;                                                      // P3P pose accepted
+    if (res.n_bad == res.n_active) return ALVA_OK;                      // ceresPnP returns false before writing the pose
+    memcpy(h_pose7, res.pose, sizeof(res.pose));
+    const int inliers = res.n_active - res.n_bad;
+    bool finite = true;
+    for (int c = 0; c < 3; c++) finite = finite && std::isfinite(res.pose[c]);
+    if (res.ok && inliers >= 5 && res.n_bad <= 0.5 * res.n_active && finite) *h_status = 2;   // :383-399
     return ALVA_OK;
 }

@@ -51,11 +51,14 @@ def make_keypoints(n: int, seed: int) -> np.ndarray:
 class FrameJob:
     """Everything one stream needs, resident on one GPU."""
 
-    def __init__(self, device: int, seed: int):
+    def __init__(self, device: int, seed: int, own_stream: bool = False):
         import alvaar_amd
         from alvaar_amd import synth
         self.dev = torch.device("cuda", device)
-        self.ctx = alvaar_amd.Context(device)
+        self.tstream = torch.cuda.Stream(device) if own_stream else None
+        if own_stream:
+            torch.cuda.set_stream(self.tstream)   # per-thread current stream: torch allocations/copies follow it
+        self.ctx = alvaar_amd.Context(device, stream=self.tstream.cuda_stream if own_stream else None)
         frames = synth.stream_rgba(W, H, RING, seed=seed, noise=True)
         self.frames = torch.from_numpy(frames).to(self.dev)
         self.pyr = [alvaar_amd.Pyramid(self.ctx, W, H, 9, 3) for _ in range(2)]
@@ -96,10 +99,10 @@ class FrameJob:
         else:
             kp, desc = self.orb.detect_and_compute(self.gray)                          # a5' + a6 (count -> host)
         idx, dist = ctx.bf_match_hamming(desc, self.prev_desc)                         # a7
-        ok, R, t, outl = ctx.p3p_lmeds(self.bv, self.wpt, 100, 3.0, self.K[0], self.K[1])   # a8 (host result)
-        ok2, pose, outl2, info = ctx.pnp_refine(self.uv, self.wpt, self.pose0, self.K)       # a9 (host result)
+        # a8 + a9 as VisualFrontend::computePose chains them (P3P -> drop outliers -> PnP), one host sync
+        st, pose, m1, m2 = ctx.compute_pose(self.bv, self.uv, self.wpt, self.K)
         self.prev_desc = desc
-        return ok and ok2
+        return st == 2
 
     # ---- per-stage HIP-event timing (not part of the timed region) ----
     def stage_times(self, reps: int = 20):
@@ -117,6 +120,7 @@ class FrameJob:
             "bf_hamming": lambda: ctx.bf_match_hamming(desc, self.prev_desc),
             "p3p_lmeds": lambda: ctx.p3p_lmeds(self.bv, self.wpt, 100, 3.0, self.K[0], self.K[1]),
             "pnp_refine": lambda: ctx.pnp_refine(self.uv, self.wpt, self.pose0, self.K),
+            "compute_pose(p3p->pnp)": lambda: ctx.compute_pose(self.bv, self.uv, self.wpt, self.K),
         }
         out = {}
         for name, fn in stages.items():
@@ -130,6 +134,40 @@ class FrameJob:
             torch.cuda.synchronize(self.dev)
             out[name] = e0.elapsed_time(e1) / reps * 1e3  # us
         return out
+
+
+def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5):
+    """S independent camera streams on ONE GPU, each with its own HIP stream and host thread (the C ABI calls release
+    the GIL).  Every stage of a single stream is latency-bound at these sizes, so concurrent streams fill the idle CUs."""
+    import threading
+    jobs = [None] * n_streams
+    barrier = threading.Barrier(n_streams + 1)
+    times = [0.0] * n_streams
+
+    def worker(i):
+        torch.cuda.set_device(device)
+        jobs[i] = FrameJob(device, seed=7 + i, own_stream=True)
+        for _ in range(warmup):
+            jobs[i].step()
+        jobs[i].tstream.synchronize()
+        barrier.wait()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            jobs[i].step()
+        jobs[i].tstream.synchronize()
+        times[i] = time.perf_counter() - t0
+        barrier.wait()
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
+    for t in th:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    wall = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    return {"streams": n_streams, "frames_per_s": n_streams * steps / wall, "ms_per_frame_per_stream": wall / steps * 1e3}
 
 
 def bench_ba(ctx, reps: int = 3):
@@ -151,6 +189,7 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
     """Reference CPU path (1 thread) on a bounded sample of the same workload."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracles
+    from scipy.spatial.transform import Rotation
     from alvaar_amd import synth
     use_ref = oracles.ref_available()
     O = oracles.Ref if use_ref else oracles.Orc
@@ -166,8 +205,10 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
         tracked, st = O.fbklt(prev, g, pts, pts, 3)        # builds both pyramids internally (the reference reuses prev's)
         kp, desc = O.orb(g, 2000)
         O.bf_match(desc, prev_desc)
-        O.p3p_lmeds(pb["bv"], pb["wpt"])
-        O.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"])
+        ok, R, t, outl = O.p3p_lmeds(pb["bv"], pb["wpt"], fx=pb["K"][0], fy=pb["K"][1])
+        keep = np.setdiff1d(np.arange(NKP), outl)            # computePose: refine the P3P inliers only
+        q = Rotation.from_matrix(R).as_quat()
+        O.pnp_refine(pb["uv"][keep], pb["wpt"][keep], np.concatenate([t, q]), pb["K"])
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 40:
             break
@@ -189,6 +230,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams-per-gpu", type=int, default=0,
+                    help="also time S concurrent independent streams on rank 0's GPU (reported under multi_stream; not part of value)")
     args = ap.parse_args()
 
     from alvaar_amd import multi
@@ -255,6 +298,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": "stage-level HIP-event time over its launch chain; per-kernel numbers in profiles/"},
         }
+        if args.streams_per_gpu > 1:
+            out["multi_stream"] = bench_multi_stream(local, args.streams_per_gpu, max(20, args.steps // 2))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(7)
         print(json.dumps(out))

@@ -171,6 +171,17 @@ int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *d_wpts, int
                     float fy, float cx, float cy, int *h_outliers, int *h_n_outliers, double *h_info,
                     int *h_ok);
 
+/* ---- a8 + a9 chained: VisualFrontend::computePose (src/slam/src/visual_frontend.cpp:245-417) -----------------
+ * P3P-LMedS, its acceptance tests, removal of its outliers and the robust PnP refinement of the inliers run as one
+ * device-side chain with ONE host synchronisation.  d_uv are the undistorted pixel observations of the same n points.
+ * Outputs: h_pose7 (written when *h_status >= 1 and PnP produced a pose), per-point masks in the caller's
+ * indexing (either may be NULL), *h_status: 0 = P3P rejected (the reference resets the frame), 1 = P3P pose accepted
+ * but the refinement failed its checks (:383-399), 2 = refined pose accepted. */
+int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
+                      int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th,
+                      float fx, float fy, float cx, float cy, double *h_pose7, uint8_t *h_p3p_outlier,
+                      uint8_t *h_pnp_outlier, int *h_status);
+
 /* ---- a10-a13: local bundle adjustment ---------------------------------------------------------
  * Replaces the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262 on the problem
  * built at :20-247): Levenberg-Marquardt + Huber, Schur complement on the point blocks,
