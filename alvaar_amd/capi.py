@@ -64,6 +64,8 @@ _sig("alva_fast", [_vp, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _vp])
 _sig("alva_orb_create", [_vp, _i, _i, _i, _f, _i, _i, C.POINTER(_vp)])
 _sig("alva_orb_destroy", [_vp], None)
 _sig("alva_orb_detect_and_compute", [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp])
+_sig("alva_ctx_wait", [_vp, _vp])
+_sig("alva_orb_collect", [_vp, _vp, _vp])
 _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
@@ -213,6 +215,10 @@ class Context:
         n = min(cnt.value, cap)
         return xy[:n], sc[:n]
 
+    def wait_for(self, producer: "Context"):
+        """stream-order dependency on another context's enqueued work (no host wait)"""
+        check(lib.alva_ctx_wait(self.h, producer.h))
+
     # a8 + a9 chained
     def compute_pose(self, bearings, uv, wpts, K, p3p_iters=100, p3p_err=3.0, pnp_iters=5, chi2th=5.9915, do_random=False, seed=12345):
         """VisualFrontend::computePose: returns (status 0/1/2, pose7, p3p_outlier mask, pnp_outlier mask)."""
@@ -314,6 +320,20 @@ class Orb:
             self.h = None
 
     __del__ = close
+
+    def enqueue(self, gray, kp_buf, desc_buf, ctx=None):
+        """detectAndCompute without the host wait, into caller-owned buffers (kp_buf [cap,6] f32, desc_buf [cap,32] u8)."""
+        self._pending = (ctx or self.ctx, kp_buf, desc_buf)
+        check(lib.alva_orb_detect_and_compute(self._pending[0].h, self.h, _ptr(gray), gray.stride(0), _ptr(kp_buf), _ptr(desc_buf),
+                                              kp_buf.shape[0], None))
+
+    def collect(self):
+        """wait for enqueue(): returns (kp[:n], desc[:n]) views of the caller's buffers"""
+        ctx, kp, desc = self._pending
+        cnt = C.c_int(0)
+        check(lib.alva_orb_collect(ctx.h, self.h, C.byref(cnt)))
+        n = min(cnt.value, kp.shape[0])
+        return kp[:n], (desc[:n] if desc is not None else None)
 
     def detect_and_compute(self, gray, describe=True, cap=None):
         """returns (kp [n,6] float32 {x,y,size,angle,response,octave}, desc [n,32] u8) cuda tensors"""

@@ -42,6 +42,7 @@ struct alva_ctx {
     alva_scratch scratch[8];
     void *pinned = nullptr;  // small pinned host staging (counters, results)
     size_t pinned_bytes = 0;
+    hipEvent_t fence = nullptr;  // lazily created; alva_ctx_wait records it on this context's stream
 };
 
 int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out);

@@ -51,6 +51,7 @@ extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
     for (auto &s: ctx->scratch)
         if (s.ptr) (void) hipFree(s.ptr);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
+    if (ctx->fence) (void) hipEventDestroy(ctx->fence);
     if (ctx->owns_stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -58,6 +59,17 @@ extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
 extern "C" int alva_ctx_sync(alva_ctx *ctx) {
     ALVA_ARG(ctx != nullptr);
     ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    return ALVA_OK;
+}
+
+// Work enqueued on `ctx` after this call starts only after everything enqueued so far on `producer` has finished.
+// No host synchronisation.  Lets one frame run independent stages (detection vs tracking + pose) on two HIP streams.
+extern "C" int alva_ctx_wait(alva_ctx *ctx, alva_ctx *producer) {
+    ALVA_ARG(ctx && producer && ctx->device == producer->device);
+    if (ctx->stream == producer->stream) return ALVA_OK;
+    if (!producer->fence) ALVA_HIP(hipEventCreateWithFlags(&producer->fence, hipEventDisableTiming));
+    ALVA_HIP(hipEventRecord(producer->fence, producer->stream));
+    ALVA_HIP(hipStreamWaitEvent(ctx->stream, producer->fence, 0));
     return ALVA_OK;
 }
 

@@ -617,9 +617,11 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
     return ALVA_OK;
 }
 
+extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
+
 extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch, float *d_kp,
                                            uint8_t *d_desc, int cap, int *h_count) {
-    ALVA_ARG(ctx && orb && d_gray && d_kp && h_count && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
+    ALVA_ARG(ctx && orb && d_gray && d_kp && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
     OrbDev &D = orb->D;
     hipStream_t st = ctx->stream;
     int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch);
@@ -655,6 +657,14 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
         if (nmax > 0) hipLaunchKernelGGL(k_brief_orb, dim3(alva_divup(nmax, 8)), dim3(256), 0, st, D, (const float *) d_kp, (const int *) orb->d_total, cap, d_desc);
         ALVA_LAUNCH_CHECK();
     }
+    if (!h_count) return ALVA_OK;  // enqueue only; alva_orb_collect() fetches the count later
+    return alva_orb_collect(ctx, orb, h_count);
+}
+
+extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count) {
+    ALVA_ARG(ctx && orb && h_count);
+    OrbDev &D = orb->D;
+    hipStream_t st = ctx->stream;
     int n3[MAXLV], total = 0;
     ALVA_HIP(hipMemcpyAsync(n3, D.n3, sizeof(n3), hipMemcpyDeviceToHost, st));
     ALVA_HIP(hipStreamSynchronize(st));

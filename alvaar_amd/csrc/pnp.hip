@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int NT = 1024;
+constexpr int NT = 512;   // 8 waves: 256 VGPRs per lane keep the unrolled 6x6 minimiser step and the 28 accumulators out of scratch
 constexpr int NW = NT / 64;
 constexpr int NACC = 28;  // H upper triangle (21) | g (6) | cost (1)
 
@@ -200,13 +200,16 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
         }
         __syncthreads();
         int flag = sh.flag;
+        __syncthreads();  // everyone has read the flag before thread 0 may overwrite it
         if (flag == F_DONE) break;
         if (flag == F_FAIL) {
             result = 0;
             break;
         }
         if (flag == F_RETRY) continue;
-        eval<false>(sh, A, sh.cand, robust, active, chi2, depth);
+        // The candidate is evaluated WITH its Jacobian: when the step is accepted Ceres re-evaluates at the same point
+        // (HandleSuccessfulStep, trust_region_minimizer.cc:809-829), which would produce exactly these sums again.
+        eval<true>(sh, A, sh.cand, robust, active, chi2, depth);
         if (threadIdx.x == 0) {
             const double cand_cost = sh.acc[27];
             double sn = 0;
@@ -225,6 +228,15 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
                     lm.accepted(rel);
                     nsucc++;
                     flag = F_ACCEPT;
+                    for (int a = 0; a < 6; a++)
+                        for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
+                    gmax = 0;
+                    for (int a = 0; a < 6; a++) {
+                        g[a] = sh.acc[21 + a];
+                        gmax = fmax(gmax, fabs(g[a]));
+                    }
+                    x_cost = cand_cost;
+                    nsummaries++;
                 } else {
                     lm.rejected();
                     nsummaries++;
@@ -235,22 +247,8 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
         }
         __syncthreads();
         flag = sh.flag;
+        __syncthreads();
         if (flag == F_DONE) break;
-        if (flag == F_ACCEPT) {
-            // HandleSuccessfulStep re-evaluates with Jacobians at the accepted point (:809-829)
-            eval<true>(sh, A, sh.x, robust, active, chi2, depth);
-            if (threadIdx.x == 0) {
-                for (int a = 0; a < 6; a++)
-                    for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
-                gmax = 0;
-                for (int a = 0; a < 6; a++) {
-                    g[a] = sh.acc[21 + a];
-                    gmax = fmax(gmax, fabs(g[a]));
-                }
-                x_cost = sh.acc[27];
-                nsummaries++;
-            }
-        }
     }
     if (threadIdx.x == 0 && info) {
         info[0] = nsummaries;

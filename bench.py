@@ -72,6 +72,12 @@ class FrameJob:
         self.pose0 = pb["pose_init"]
         self.k = 0
         self.orb = alvaar_amd.Orb(self.ctx, W, H, 2000)
+        # second lane (own non-blocking HIP stream) for the detector: it only needs the gray image, not the tracker's output
+        self.lane_b = alvaar_amd.Context(device, own_stream=True)
+        cap = 4 * 2000 + 1024
+        self.kp_buf = [torch.zeros((cap, 6), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.desc_buf = [torch.zeros((cap, 32), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.match = None
         self.maxq = 0.001
         self._det = torch.zeros((NKP, 2), dtype=torch.float32, device=self.dev)
         # prime: frame 0 pyramid + descriptors
@@ -86,6 +92,21 @@ class FrameJob:
         if n < NKP:
             self._det[n:] = self.pts[n:]
         return self._det
+
+    def step_overlapped(self):
+        """Same work as step(): ORB + matching run on lane B while fb-KLT + pose run on lane A (one frame, two HIP streams)."""
+        ctx, lb = self.ctx, self.lane_b
+        self.k += 1
+        cur, prev = self.pyr[self.k % 2], self.pyr[(self.k - 1) % 2]
+        cur.build_from_rgba(self.frames[self.k % RING], self.gray)                    # a2 + a3   (lane A)
+        lb.wait_for(ctx)
+        self.orb.enqueue(self.gray, self.kp_buf[self.k % 2], self.desc_buf[self.k % 2], ctx=lb)   # a5' + a6 (lane B, no host wait)
+        tracked, status = ctx.fbklt_track(prev, cur, self.pts, self.pts, 3)           # a4        (lane A)
+        st, pose, m1, m2 = ctx.compute_pose(self.bv, self.uv, self.wpt, self.K)       # a8 + a9   (lane A, host result)
+        kp, desc = self.orb.collect()                                                  # count -> host (lane B)
+        self.match = lb.bf_match_hamming(desc, self.prev_desc)                         # a7        (lane B)
+        self.prev_desc = desc   # (double-buffered; lane B orders the next frame's detector after this match)
+        return st == 2
 
     def step(self, grid_detector: bool = False):
         ctx = self.ctx
@@ -230,6 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="headline number on one HIP stream (no detector/tracker overlap)")
     ap.add_argument("--streams-per-gpu", type=int, default=0,
                     help="also time S concurrent independent streams on rank 0's GPU (reported under multi_stream; not part of value)")
     args = ap.parse_args()
@@ -242,34 +264,30 @@ def main():
     dist = multi.init_process_group(shard, "nccl")   # "nccl" IS RCCL on ROCm; only used for the barrier + timing reduction
 
     job = FrameJob(local, seed=shard.stream_seed)
-    for _ in range(args.warmup):
-        job.step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        dt = multi.max_over_ranks(dt, torch.device("cuda", local))
-        td.barrier()
-    torch.cuda.synchronize()
 
-    # secondary: the same loop with the reference-actual detector
-    for _ in range(3):
-        job.step(grid_detector=True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step(grid_detector=True)
-    torch.cuda.synchronize()
-    dt_grid = time.perf_counter() - t1
-    if dist:
-        dt_grid = multi.max_over_ranks(dt_grid, torch.device("cuda", local))
-        td.barrier()
+    def timed(fn, warmup, steps):
+        """W untimed + exactly K timed steps, barrier + device sync on both sides, MAX over ranks"""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            el = multi.max_over_ranks(el, torch.device("cuda", local))
+            td.barrier()
+        torch.cuda.synchronize()
+        return el
+
+    dt = timed(job.step if args.serial else job.step_overlapped, args.warmup, args.steps)
+    # secondary: every stage back-to-back on ONE HIP stream, and the same with the reference-actual detector
+    dt_serial = timed(job.step, 3, args.steps)
+    dt_grid = timed(lambda: job.step(grid_detector=True), 3, args.steps)
     if rank == 0:
         fps = world * args.steps / dt
         stage_us = job.stage_times()
@@ -289,7 +307,10 @@ def main():
                        "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels, 2120 pts)", "orb_detect_and_compute(2000, 1.2, 8)",
                                   "bf_hamming ~2000x2000", "p3p_lmeds(100 it, 2120 pts)", "pnp_refine(5 it, 2120 pts)"],
                        "not_in_timed_region": [],
-                       "parallelism": f"{world} independent streams, one per GPU, no collective"},
+                       "parallelism": f"{world} independent camera streams, one per GPU, no collective; within a frame the detector "
+                                      "(ORB + match) and the tracker (fb-KLT + pose) run on two HIP streams" + (" [disabled: --serial]" if args.serial else "")},
+            "one_hip_stream": {"frames_per_s": world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3,
+                               "stages": "same work, every stage back-to-back on one HIP stream"},
             "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,
                                      "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
             "local_ba": ba,

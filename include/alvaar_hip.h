@@ -42,6 +42,10 @@ typedef struct alva_pyramid alva_pyramid;
 int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out);
 void alva_ctx_destroy(alva_ctx *ctx);
 int alva_ctx_sync(alva_ctx *ctx);
+/* Stream-order dependency without a host wait: work enqueued on `ctx` after this call starts only after everything
+ * enqueued so far on `producer` has completed.  (The reference is single-threaded; this is what lets one frame run
+ * detection and tracking+pose on two HIP streams.) */
+int alva_ctx_wait(alva_ctx *ctx, alva_ctx *producer);
 void *alva_ctx_stream(alva_ctx *ctx);
 const char *alva_last_error(void);
 const char *alva_version(void);
@@ -129,6 +133,8 @@ void alva_orb_destroy(alva_orb *orb);
  * nth_element's unspecified order; the SET equals the reference's (SURVEY.md §8a a5'). */
 int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch,
                                 float *d_kp, uint8_t *d_desc, int cap, int *h_count);
+/* h_count == NULL above only enqueues the work (no host wait); this call then waits for it and returns the count. */
+int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
 
 /* ---- a5: the reference's grid Shi-Tomasi detector ---------------------------------------------
  * Replaces FeatureExtractor::detectFeaturePoints (src/slam/src/feature_extractor.cpp:11-158).
