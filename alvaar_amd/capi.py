@@ -66,6 +66,8 @@ _sig("alva_orb_destroy", [_vp], None)
 _sig("alva_orb_detect_and_compute", [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp])
 _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_compute_pose_enqueue", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f])
+_sig("alva_compute_pose_collect", [_vp, _vp, _vp, _vp, _vp])
 _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
@@ -230,6 +232,24 @@ class Context:
         st = C.c_int(0)
         check(lib.alva_compute_pose(self.h, _ptr(bearings), _ptr(uv), _ptr(wpts), n, p3p_iters, p3p_err, int(do_random), seed, pnp_iters,
                                     chi2th, K[0], K[1], K[2], K[3], pose.ctypes.data, m1.ctypes.data, m2.ctypes.data, C.byref(st)))
+        return st.value, pose, m1[:n].astype(bool), m2[:n].astype(bool)
+
+    def compute_pose_enqueue(self, bearings, uv, wpts, K, p3p_iters=100, p3p_err=3.0, pnp_iters=5, chi2th=5.9915, do_random=False,
+                             seed=12345):
+        self._pose_n = bearings.shape[0]
+        self._pose_keep = (bearings, uv, wpts)
+        check(lib.alva_compute_pose_enqueue(self.h, _ptr(bearings), _ptr(uv), _ptr(wpts), self._pose_n, p3p_iters, p3p_err, int(do_random),
+                                            seed, pnp_iters, chi2th, K[0], K[1], K[2], K[3]))
+
+    def compute_pose_collect(self):
+        import numpy as np
+        n = self._pose_n
+        pose = np.zeros(7)
+        m1 = np.zeros(max(n, 1), np.uint8)
+        m2 = np.zeros(max(n, 1), np.uint8)
+        st = C.c_int(0)
+        check(lib.alva_compute_pose_collect(self.h, pose.ctypes.data, m1.ctypes.data, m2.ctypes.data, C.byref(st)))
+        self._pose_keep = None
         return st.value, pose, m1[:n].astype(bool), m2[:n].astype(bool)
 
     # a6

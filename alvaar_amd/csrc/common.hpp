@@ -43,9 +43,15 @@ struct alva_ctx {
     void *pinned = nullptr;  // small pinned host staging (counters, results)
     size_t pinned_bytes = 0;
     hipEvent_t fence = nullptr;  // lazily created; alva_ctx_wait records it on this context's stream
+    void *pose_pending = nullptr;  // alva_compute_pose_enqueue -> _collect hand-over (pnp.hip)
+    void (*pose_pending_free)(void *) = nullptr;
 };
 
 int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out);
+// Pinned, device-visible host staging of at least `bytes` (grown on demand; growing waits for the stream).  Kernels read
+// small inputs from it and write small results into it directly, so a call needs no copy commands, only the final
+// stream synchronisation.
+int alva_ctx_pinned(alva_ctx *ctx, size_t bytes, void **out);
 
 static inline int alva_divup(int a, int b) { return (a + b - 1) / b; }
 

@@ -52,6 +52,7 @@ extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
         if (s.ptr) (void) hipFree(s.ptr);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
     if (ctx->fence) (void) hipEventDestroy(ctx->fence);
+    if (ctx->pose_pending && ctx->pose_pending_free) ctx->pose_pending_free(ctx->pose_pending);
     if (ctx->owns_stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -74,6 +75,24 @@ extern "C" int alva_ctx_wait(alva_ctx *ctx, alva_ctx *producer) {
 }
 
 extern "C" void *alva_ctx_stream(alva_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+int alva_ctx_pinned(alva_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_bytes < bytes) {
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) ALVA_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        const size_t want = bytes + bytes / 2;
+        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            alva_set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+            return ALVA_ERR_NOMEM;
+        }
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return ALVA_OK;
+}
 
 int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out) {
     ALVA_ARG(slot >= 0 && slot < 8);

@@ -398,7 +398,8 @@ struct CompactOut {
 };
 
 // ordered compaction: primaries in cell order, then up to numSec secondaries in cell order (:107-134)
-__global__ void __launch_bounds__(1024) k_compact(GridArgs A, float *__restrict__ pts, int cap, CompactOut *__restrict__ out) {
+__global__ void __launch_bounds__(1024) k_compact(GridArgs A, float *__restrict__ pts, int cap, CompactOut *__restrict__ out,
+                                                  CompactOut *__restrict__ host_out) {
     __shared__ int s_cnt[1024];
     __shared__ int s_base;
     const int nCells = A.nCW * A.nCH;
@@ -452,6 +453,8 @@ __global__ void __launch_bounds__(1024) k_compact(GridArgs A, float *__restrict_
     if (threadIdx.x == 0) {
         out->n_total = total;
         out->n_occupied = nocc;
+        host_out->n_total = total;  // pinned host mirror: the host reads it after the stream sync, no copy command
+        host_out->n_occupied = nocc;
     }
     (void) s_base;
 }
@@ -677,15 +680,17 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     if (lds_mask > 48 * 1024)
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_mask, st, A);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, A, d_out_pts, cap, d_cnt);
+    CompactOut *h_cnt = nullptr;
+    rc = alva_ctx_pinned(ctx, sizeof(CompactOut), (void **) &h_cnt);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, A, d_out_pts, cap, d_cnt, h_cnt);
     ALVA_LAUNCH_CHECK();
     // one wave per candidate slot; the kernel reads the actual count from device memory (no host round trip before it)
     const int maxPts = std::min(cap, 2 * nCells);
     if (maxPts > 0) hipLaunchKernelGGL(k_subpix, dim3(maxPts), dim3(64), 0, st, d_gray, gray_pitch, width, height, d_out_pts, d_cnt, cap);
     ALVA_LAUNCH_CHECK();
-    CompactOut res;
-    ALVA_HIP(hipMemcpyAsync(&res, d_cnt, sizeof(res), hipMemcpyDeviceToHost, st));
     ALVA_HIP(hipStreamSynchronize(st));
+    const CompactOut res = *h_cnt;
     if (A.dbg == 5 && A.dbgbuf) {
         long long hb[64];
         (void) hipMemcpy(hb, A.dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);

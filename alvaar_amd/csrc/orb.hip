@@ -51,6 +51,7 @@ struct OrbDev {
     float *c3r;
     const int *tapOfs;      // resize tap source offsets
     const int *tapCoef;     // resize tap coefficient (second tap, 0..256), -1 = clamp to first, -2 = clamp to last
+    int *h_n3;              // pinned host mirror of n3, written by k_angle_emit (the host reads it after the stream sync)
     int umax[17];
 };
 
@@ -376,7 +377,10 @@ __global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict_
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     int base = 0;
     for (int q = 0; q < l; q++) base += D.n3[q];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && l == D.nlevels - 1) *total = base + D.n3[l];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        D.h_n3[l] = D.n3[l];
+        if (l == D.nlevels - 1) *total = base + D.n3[l];
+    }
     if (i >= D.n3[l]) return;
     const int x = D.c3x[L.candOff + i], y = D.c3y[L.candOff + i], W = L.pitch;
     const uint8_t *ctr = D.pool + L.img + (size_t) y * W + x;
@@ -445,6 +449,9 @@ __global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t 
     const Level &L = D.lv[0];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < L.w && y < L.h) D.pool[L.img + (size_t) y * L.pitch + x] = src[(size_t) y * pitch + x];
+    // first launch of the chain: clear the FAST-score histograms here instead of a separate fill command
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int k = threadIdx.x; k < MAXLV * 256; k += 256) D.hist[k] = 0;
 }
 
 int cv_round_f(float v) { return (int) lrintf(v); }
@@ -581,6 +588,14 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     D.tapOfs = d_tap;
     D.tapCoef = d_tap + tapOfs.size();
     o->d_total = (int *) (b + o_total);
+    e = hipHostMalloc((void **) &D.h_n3, MAXLV * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void) hipFree(o->d_block);
+        delete o;
+        alva_set_error("alva_orb_create: hipHostMalloc: %s", hipGetErrorString(e));
+        return ALVA_ERR_NOMEM;
+    }
+    memset(D.h_n3, 0, MAXLV * sizeof(int));
     ALVA_HIP(hipMemcpyAsync(d_tap, tapOfs.data(), tapOfs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ALVA_HIP(hipMemcpyAsync(d_tap + tapOfs.size(), tapCoef.data(), tapCoef.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ALVA_HIP(hipStreamSynchronize(ctx->stream));
@@ -597,6 +612,7 @@ extern "C" void alva_orb_destroy(alva_orb *orb) {
     if (!orb) return;
     (void) hipSetDevice(orb->device);
     if (orb->d_block) (void) hipFree(orb->d_block);
+    if (orb->D.h_n3) (void) hipHostFree(orb->D.h_n3);
     delete orb;
 }
 
@@ -608,7 +624,6 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
     hipLaunchKernelGGL(k_copy_level0, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4)), dim3(256), 0, st, D, d_gray, gray_pitch);
     for (int l = 1; l < D.nlevels; l++)
         hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
-    ALVA_HIP(hipMemsetAsync(D.hist, 0, (size_t) MAXLV * 256 * 4, st));
     hipLaunchKernelGGL(k_fast_score, dim3(o->maxTiles, D.nlevels), dim3(256), 0, st, D);
     hipLaunchKernelGGL(k_fast_rows<false>, dim3(alva_divup(o->maxRows, 4), D.nlevels), dim3(256), 0, st, D);
     hipLaunchKernelGGL(k_scan_rows, dim3(D.nlevels), dim3(1024), 0, st, D);
@@ -666,8 +681,8 @@ extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count) {
     OrbDev &D = orb->D;
     hipStream_t st = ctx->stream;
     int n3[MAXLV], total = 0;
-    ALVA_HIP(hipMemcpyAsync(n3, D.n3, sizeof(n3), hipMemcpyDeviceToHost, st));
     ALVA_HIP(hipStreamSynchronize(st));
+    memcpy(n3, D.h_n3, sizeof(n3));
     for (int l = 0; l < D.nlevels; l++) {
         if (n3[l] > std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024))) {
             alva_set_error("alva_orb_detect_and_compute: level %d kept %d keypoints, above the launch bound", l, n3[l]);

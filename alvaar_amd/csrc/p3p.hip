@@ -389,45 +389,34 @@ extern "C" int alva_p3p_draw_samples(int n_points, int count, int do_random, uin
 }
 
 int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
-                     int do_random, uint32_t seed, float fx, float fy, int H, P3pSelectOut **d_out_p, uint8_t **d_inlier_p) {
+                     int do_random, uint32_t seed, float fx, float fy, int H, int *pin_samples, P3pSelectOut *out, uint8_t *inlier) {
     ALVA_ARG(n >= 4 && n <= 7168);  // LDS-resident median select (n * 8 B + histogram < 64 KB)
     float focal = fx + fy;          // multi_view_geometry.cpp:72-76
     focal /= 2.f;
     const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
-    std::vector<int> samples((size_t) H * 4);
     {
         Sampler smp(n, do_random != 0, seed);
-        for (int k = 0; k < H; k++) smp.draw(samples.data() + 4 * k);
+        for (int k = 0; k < H; k++) smp.draw(pin_samples + 4 * k);
     }
-    // scratch layout: samples | models | valid | penalty | SelectOut | inlier mask
-    size_t off_models = (size_t) H * 4 * sizeof(int);
-    off_models = (off_models + 63) / 64 * 64;
-    size_t off_valid = off_models + (size_t) H * 12 * sizeof(double);
+    // scratch layout: models | valid | penalty
+    size_t off_valid = (size_t) H * 12 * sizeof(double);
     size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
-    size_t off_out = off_pen + (size_t) H * sizeof(double);
-    size_t off_inl = (off_out + sizeof(SelectOut) + 63) / 64 * 64;
-    size_t total = off_inl + (size_t) n;
+    size_t total = off_pen + (size_t) H * sizeof(double);
     uint8_t *base = nullptr;
     int rc = alva_ctx_scratch(ctx, 2, total, (void **) &base);
     if (rc) return rc;
-    int *d_samples = (int *) base;
-    double *d_models = (double *) (base + off_models);
+    double *d_models = (double *) base;
     int *d_valid = (int *) (base + off_valid);
     double *d_pen = (double *) (base + off_pen);
-    SelectOut *d_out = (SelectOut *) (base + off_out);
-    uint8_t *d_inlier = base + off_inl;
-    // pageable source: the runtime stages the bytes before returning, so `samples` may go out of scope afterwards
-    ALVA_HIP(hipMemcpyAsync(d_samples, samples.data(), (size_t) H * 4 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, d_samples, H, d_models, d_valid);
+    hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, (const int *) pin_samples, H, d_models,
+                       d_valid);
     ALVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) n * sizeof(double), ctx->stream, d_bearings, d_wpts, n, 0, d_models, d_valid,
                        d_pen);
     ALVA_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, d_bearings, d_wpts, n, H, max_iters, d_models, d_valid, d_pen,
-                       threshold, d_out, d_inlier);
+                       threshold, out, inlier);
     ALVA_LAUNCH_CHECK();
-    *d_out_p = d_out;
-    *d_inlier_p = d_inlier;
     return ALVA_OK;
 }
 
@@ -444,15 +433,19 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
     const int max_draws = max_iters + max_iters * 10;  // max_skip = 10 x max_iterations (Lmeds.hpp:67)
     int H = std::min(max_draws, max_iters + 28);
     SelectOut res{};
-    std::vector<uint8_t> inl((size_t) n);
+    const uint8_t *inl = nullptr;
     for (;;) {
-        SelectOut *d_out = nullptr;
-        uint8_t *d_inlier = nullptr;
-        int rc = alva_p3p_enqueue(ctx, d_bearings, d_wpts, n, max_iters, err_threshold, do_random, seed, fx, fy, H, &d_out, &d_inlier);
+        // pinned: samples | SelectOut | inlier mask -- the kernels read / write it directly, no copy commands
+        const size_t off_out = ((size_t) H * 16 + 255) / 256 * 256, off_inl = off_out + 256;
+        uint8_t *pin = nullptr;
+        int rc = alva_ctx_pinned(ctx, off_inl + (size_t) n, (void **) &pin);
         if (rc) return rc;
-        ALVA_HIP(hipMemcpyAsync(&res, d_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
-        ALVA_HIP(hipMemcpyAsync(inl.data(), d_inlier, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+        rc = alva_p3p_enqueue(ctx, d_bearings, d_wpts, n, max_iters, err_threshold, do_random, seed, fx, fy, H, (int *) pin,
+                              (SelectOut *) (pin + off_out), pin + off_inl);
+        if (rc) return rc;
         ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(&res, pin + off_out, sizeof(res));
+        inl = pin + off_inl;
         if (res.n_valid_used >= max_iters || H >= max_draws) break;
         H = std::min(max_draws, H * 2);
     }
@@ -471,7 +464,7 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
     for (int k = 0; k < 3; k++) h_t[k] = res.model[9 + k];
     int no = 0;
     for (int i = 0; i < n; i++)
-        if (!inl[(size_t) i]) h_outliers[no++] = i;  // :109-124: outliers = complement of the inlier list
+        if (!inl[i]) h_outliers[no++] = i;  // :109-124: outliers = complement of the inlier list
     *h_n_outliers = no;
     *h_ok = 1;
     return ALVA_OK;

@@ -33,6 +33,7 @@ struct PnpArgs {
     double chi2_th;
     int use_robust, apply_l2, max_iters;
     double ftol;
+    double pose0[7];  // initial pose (ignored in chained mode)
 };
 
 struct PnpOut {
@@ -40,6 +41,7 @@ struct PnpOut {
     double info[8];
     int ok, n_bad;
     int p3p_ok, n_active;  // chained mode: P3P verdict and the number of points handed to the refinement
+    int p3p_n_valid_used, pad;
 };
 
 struct PnpShared {
@@ -262,13 +264,15 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
 
 // p3p / inlier0 non-null = chained mode (VisualFrontend::computePose, visual_frontend.cpp:300-375): the initial pose is the
 // P3P-LMedS model and only its inliers are refined; the P3P acceptance tests of multi_view_geometry.cpp:82-91 run here.
-__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict__ pose_in, uint8_t *__restrict__ active,
-                                            double *__restrict__ chi2, uint8_t *__restrict__ depth, uint8_t *__restrict__ bad,
-                                            PnpOut *__restrict__ out, const P3pSelectOut *__restrict__ p3p,
-                                            const uint8_t *__restrict__ inlier0) {
+// `out`, `bad` and `p3p_outlier` may live in pinned host memory (written once, at the end).
+__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ active, double *__restrict__ chi2,
+                                            uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
+                                            const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
+                                            uint8_t *__restrict__ p3p_outlier) {
     __shared__ PnpShared sh;
     __shared__ int s_nbad, s_p3p_ok, s_nact;
-    if (threadIdx.x < 8) out->info[threadIdx.x] = 0;
+    __shared__ double s_info[8];
+    if (threadIdx.x < 8) s_info[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         s_nbad = 0;
         s_nact = 0;
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict_
                 for (int c = 0; c < 4; c++) sh.x[3 + c] = q[c];
             }
         } else {
-            for (int c = 0; c < 7; c++) sh.x[c] = pose_in[c];
+            for (int c = 0; c < 7; c++) sh.x[c] = A.pose0[c];
         }
     }
     __syncthreads();
@@ -316,8 +320,13 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict_
             out->p3p_ok = 0;
             out->n_bad = 0;
             out->n_active = 0;
+            out->p3p_n_valid_used = p3p->n_valid_used;
         }
-        for (int i = threadIdx.x; i < A.n; i += NT) bad[i] = 0;
+        if (threadIdx.x < 8) out->info[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < A.n; i += NT) {
+            bad[i] = 0;
+            if (p3p_outlier) p3p_outlier[i] = 0;
+        }
         return;
     }
     {
@@ -341,12 +350,13 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict_
         }
         __syncthreads();
     }
-    int ok = solve(sh, A, A.use_robust, active, chi2, depth, out->info);
+    int ok = solve(sh, A, A.use_robust, active, chi2, depth, s_info);
     const int nact = s_nact;
     int nb = 0;
     for (int i = threadIdx.x; i < A.n; i += NT) {
         const bool b = active[i] && (chi2[i] > A.chi2_th || !depth[i]);  // multi_view_geometry.cpp:194-207
         bad[i] = b;
+        if (p3p_outlier) p3p_outlier[i] = !inlier0[i];
         if (b) {
             nb++;
             if (A.apply_l2) active[i] = 0;
@@ -356,13 +366,15 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, const double *__restrict_
     __syncthreads();
     const int nbad = s_nbad;
     if (nbad == nact) ok = 0;
-    else if (A.apply_l2 && nbad > 0) ok = solve(sh, A, 0, active, chi2, depth, out->info + 4);  // :214-218
+    else if (A.apply_l2 && nbad > 0) ok = solve(sh, A, 0, active, chi2, depth, s_info + 4);  // :214-218
     if (threadIdx.x < 7) out->pose[threadIdx.x] = sh.x[threadIdx.x];
+    if (threadIdx.x < 8) out->info[threadIdx.x] = s_info[threadIdx.x];
     if (threadIdx.x == 0) {
         out->ok = ok;
         out->n_bad = nbad;
         out->p3p_ok = 1;
         out->n_active = nact;
+        out->p3p_n_valid_used = p3p ? p3p->n_valid_used : 0;
     }
 }
 
@@ -388,24 +400,25 @@ extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *
     A.apply_l2 = apply_l2_after_robust;
     A.max_iters = max_iters;
     A.ftol = 1.e-3;  // :186
-    // scratch: pose_in(7) | out | chi2(n) | active(n) | depth(n) | bad(n)
-    size_t off_out = 64, off_chi2 = off_out + ((sizeof(PnpOut) + 63) / 64) * 64;
-    size_t off_act = off_chi2 + (size_t) n * 8, off_dep = off_act + (size_t) n, off_bad = off_dep + (size_t) n;
-    uint8_t *base = nullptr;
-    int rc = alva_ctx_scratch(ctx, 3, off_bad + (size_t) n, (void **) &base);
+    memcpy(A.pose0, h_pose7, sizeof(A.pose0));
+    // device scratch: chi2(n) | active(n) | depth(n);  pinned (written by the kernel, read after the sync): out | bad(n)
+    const size_t off_act = (size_t) n * 8, off_dep = off_act + (size_t) n;
+    uint8_t *base = nullptr, *pin = nullptr;
+    int rc = alva_ctx_scratch(ctx, 3, off_dep + (size_t) n, (void **) &base);
     if (rc) return rc;
-    ALVA_HIP(hipMemcpyAsync(base, h_pose7, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, (const double *) base, base + off_act, (double *) (base + off_chi2),
-                       base + off_dep, base + off_bad, (PnpOut *) (base + off_out), (const P3pSelectOut *) nullptr, (const uint8_t *) nullptr);
+    rc = alva_ctx_pinned(ctx, 256 + (size_t) n, (void **) &pin);
+    if (rc) return rc;
+    static_assert(sizeof(PnpOut) <= 256, "pinned layout");
+    hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, base + off_act, (double *) base, base + off_dep, pin + 256,
+                       (PnpOut *) pin, (const P3pSelectOut *) nullptr, (const uint8_t *) nullptr, (uint8_t *) nullptr);
     ALVA_LAUNCH_CHECK();
-    PnpOut res;
-    std::vector<uint8_t> bad((size_t) n);
-    ALVA_HIP(hipMemcpyAsync(&res, base + off_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
-    ALVA_HIP(hipMemcpyAsync(bad.data(), base + off_bad, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
     ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    PnpOut res;
+    memcpy(&res, pin, sizeof(res));
+    const uint8_t *bad = pin + 256;
     int no = 0;
     for (int i = 0; i < n; i++)
-        if (bad[(size_t) i]) h_outliers[no++] = i;
+        if (bad[i]) h_outliers[no++] = i;
     *h_n_outliers = no;
     if (h_info) memcpy(h_info, res.info, sizeof(res.info));
     if (no == n) return ALVA_OK;
@@ -416,16 +429,69 @@ extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *
 
 // VisualFrontend::computePose (src/slam/src/visual_frontend.cpp:245-417) as ONE device-side chain and ONE host
 // synchronisation: P3P-LMedS -> acceptance tests -> drop its outliers -> robust PnP on the inliers -> acceptance tests.
-extern "C" int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n, int p3p_iters,
-                                 float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx, float fy, float cx,
-                                 float cy, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier, int *h_status) {
-    ALVA_ARG(ctx && h_pose7 && h_status && n >= 0 && p3p_iters > 0 && pnp_iters >= 0);
-    *h_status = 0;
+// Split in enqueue / collect so that a caller can put other work (the detector, on a second stream) between the two.
+struct alva_pose_pending {
+    const double *bearings, *wpts;
+    PnpArgs A;
+    int n, p3p_iters, do_random, H, max_draws;
+    float p3p_err, fx, fy;
+    uint32_t seed;
+    size_t poff_out, poff_bad, poff_po;
+    uint8_t *pin;
+    bool active;
+};
+
+static void pose_pending_free(void *p) { delete (alva_pose_pending *) p; }
+
+static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
+    const int n = P.n;
+    const size_t off_act = (size_t) n * 8, off_dep = off_act + (size_t) n, off_sel = (off_dep + (size_t) n + 63) / 64 * 64;
+    const size_t off_inl = off_sel + 256;
+    uint8_t *base = nullptr;
+    int rc = alva_ctx_scratch(ctx, 3, off_inl + (size_t) n, (void **) &base);
+    if (rc) return rc;
+    // pinned: samples | PnpOut | bad(n) | p3p outlier(n): read / written by the kernels directly, no copy commands
+    P.poff_out = ((size_t) P.H * 16 + 255) / 256 * 256;
+    P.poff_bad = P.poff_out + 256;
+    P.poff_po = P.poff_bad + (size_t) n;
+    rc = alva_ctx_pinned(ctx, P.poff_po + (size_t) n, (void **) &P.pin);
+    if (rc) return rc;
+    P3pSelectOut *d_sel = (P3pSelectOut *) (base + off_sel);
+    uint8_t *d_inl = base + off_inl;
+    rc = alva_p3p_enqueue(ctx, P.bearings, P.wpts, n, P.p3p_iters, P.p3p_err, P.do_random, P.seed, P.fx, P.fy, P.H, (int *) P.pin, d_sel,
+                          d_inl);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad,
+                       (PnpOut *) (P.pin + P.poff_out), (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
+                                         int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx,
+                                         float fy, float cx, float cy) {
+    ALVA_ARG(ctx && n >= 0 && p3p_iters > 0 && pnp_iters >= 0);
+    if (!ctx->pose_pending) {
+        ctx->pose_pending = new alva_pose_pending();
+        ctx->pose_pending_free = pose_pending_free;
+    }
+    alva_pose_pending &P = *(alva_pose_pending *) ctx->pose_pending;
+    P.active = true;
+    P.n = n;
     if (n < 4) return ALVA_OK;  // visual_frontend.cpp:249-257
     ALVA_ARG(d_bearings && d_uv && d_wpts);
-    const int max_draws = p3p_iters + p3p_iters * 10;
-    int H = std::min(max_draws, p3p_iters + 28);
-    PnpArgs A{};
+    P.bearings = d_bearings;
+    P.wpts = d_wpts;
+    P.p3p_iters = p3p_iters;
+    P.p3p_err = p3p_err;
+    P.do_random = do_random;
+    P.seed = seed;
+    P.fx = fx;
+    P.fy = fy;
+    P.max_draws = p3p_iters + p3p_iters * 10;
+    P.H = std::min(P.max_draws, p3p_iters + 28);
+    PnpArgs &A = P.A;
+    A = PnpArgs{};
     A.uv = d_uv;
     A.wpt = d_wpts;
     A.n = n;
@@ -436,33 +502,34 @@ extern "C" int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const 
     A.apply_l2 = 1;     // state.hpp:76 robustCostRefineWithL2_
     A.max_iters = pnp_iters;
     A.ftol = 1.e-3;
-    size_t off_out = 64, off_chi2 = off_out + ((sizeof(PnpOut) + 63) / 64) * 64;
-    size_t off_act = off_chi2 + (size_t) n * 8, off_dep = off_act + (size_t) n, off_bad = off_dep + (size_t) n;
-    uint8_t *base = nullptr;
-    int rc = alva_ctx_scratch(ctx, 3, off_bad + (size_t) n, (void **) &base);
-    if (rc) return rc;
-    PnpOut res{};
-    P3pSelectOut sel{};
-    std::vector<uint8_t> bad((size_t) n), inl((size_t) n);
-    for (;;) {
-        P3pSelectOut *d_sel = nullptr;
-        uint8_t *d_inl = nullptr;
-        rc = alva_p3p_enqueue(ctx, d_bearings, d_wpts, n, p3p_iters, p3p_err, do_random, seed, fx, fy, H, &d_sel, &d_inl);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, (const double *) nullptr, base + off_act, (double *) (base + off_chi2),
-                           base + off_dep, base + off_bad, (PnpOut *) (base + off_out), (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl);
-        ALVA_LAUNCH_CHECK();
-        ALVA_HIP(hipMemcpyAsync(&res, base + off_out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
-        ALVA_HIP(hipMemcpyAsync(&sel, d_sel, sizeof(sel), hipMemcpyDeviceToHost, ctx->stream));
-        ALVA_HIP(hipMemcpyAsync(bad.data(), base + off_bad, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
-        ALVA_HIP(hipMemcpyAsync(inl.data(), d_inl, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
-        ALVA_HIP(hipStreamSynchronize(ctx->stream));
-        if (sel.n_valid_used >= p3p_iters || H >= max_draws) break;
-        H = std::min(max_draws, H * 2);   // rare: too many degenerate samples, redo with a longer prefix of the stream
+    return pose_launch(ctx, P);
+}
+
+extern "C" int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier, int *h_status) {
+    ALVA_ARG(ctx && h_pose7 && h_status);
+    alva_pose_pending *pp = (alva_pose_pending *) ctx->pose_pending;
+    if (!pp || !pp->active) {
+        alva_set_error("alva_compute_pose_collect: nothing enqueued on this context");
+        return ALVA_ERR_STATE;
     }
+    alva_pose_pending &P = *pp;
+    P.active = false;
+    *h_status = 0;
+    const int n = P.n;
+    if (n < 4) return ALVA_OK;
+    PnpOut res{};
+    for (;;) {
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(&res, P.pin + P.poff_out, sizeof(res));
+        if (res.p3p_n_valid_used >= P.p3p_iters || P.H >= P.max_draws) break;
+        P.H = std::min(P.max_draws, P.H * 2);   // rare: too many degenerate samples, redo with a longer prefix of the stream
+        int rc = pose_launch(ctx, P);
+        if (rc) return rc;
+    }
+    const uint8_t *bad = P.pin + P.poff_bad, *p3p_out = P.pin + P.poff_po;
     for (int i = 0; i < n; i++) {
-        if (h_p3p_outlier) h_p3p_outlier[i] = res.p3p_ok ? !inl[(size_t) i] : 0;
-        if (h_pnp_outlier) h_pnp_outlier[i] = bad[(size_t) i];
+        if (h_p3p_outlier) h_p3p_outlier[i] = p3p_out[i];
+        if (h_pnp_outlier) h_pnp_outlier[i] = bad[i];
     }
     if (!res.p3p_ok) return ALVA_OK;                                   // :318-330 -> resetFrame, false
     *h_status = 1;                                                      // P3P pose accepted
@@ -473,4 +540,14 @@ extern "C" int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const 
     for (int c = 0; c < 3; c++) finite = finite && std::isfinite(res.pose[c]);
     if (res.ok && inliers >= 5 && res.n_bad <= 0.5 * res.n_active && finite) *h_status = 2;   // :383-399
     return ALVA_OK;
+}
+
+extern "C" int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n, int p3p_iters,
+                                 float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx, float fy, float cx,
+                                 float cy, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier, int *h_status) {
+    ALVA_ARG(ctx && h_pose7 && h_status);
+    int rc = alva_compute_pose_enqueue(ctx, d_bearings, d_uv, d_wpts, n, p3p_iters, p3p_err, do_random, seed, pnp_iters, chi2_th, fx, fy,
+                                       cx, cy);
+    if (rc) return rc;
+    return alva_compute_pose_collect(ctx, h_pose7, h_p3p_outlier, h_pnp_outlier, h_status);
 }

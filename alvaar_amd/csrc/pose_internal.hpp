@@ -8,7 +8,10 @@ struct P3pSelectOut {
     int best, n_valid_used, n_inliers, have_model;
 };
 
-// Enqueues the P3P-LMedS kernels on ctx->stream WITHOUT synchronising.  On return *d_out / *d_inlier point into context
-// scratch (slot 2): the selection result and the per-point inlier mask (n bytes).
+// Enqueues the P3P-LMedS kernels on ctx->stream WITHOUT synchronising and without copy commands.
+//   pin_samples : H*4 ints of PINNED host memory (alva_ctx_pinned); filled here, read by the hypothesis kernel over the bus
+//   out/inlier  : where the selection result and the n-byte inlier mask are written: context scratch when another kernel
+//                 consumes them (alva_compute_pose), pinned host memory when the host does (alva_p3p_lmeds)
 int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
-                     int do_random, uint32_t seed, float fx, float fy, int n_draws, P3pSelectOut **d_out, uint8_t **d_inlier);
+                     int do_random, uint32_t seed, float fx, float fy, int n_draws, int *pin_samples, P3pSelectOut *out,
+                     uint8_t *inlier);

@@ -100,9 +100,10 @@ class FrameJob:
         cur, prev = self.pyr[self.k % 2], self.pyr[(self.k - 1) % 2]
         cur.build_from_rgba(self.frames[self.k % RING], self.gray)                    # a2 + a3   (lane A)
         lb.wait_for(ctx)
-        self.orb.enqueue(self.gray, self.kp_buf[self.k % 2], self.desc_buf[self.k % 2], ctx=lb)   # a5' + a6 (lane B, no host wait)
         tracked, status = ctx.fbklt_track(prev, cur, self.pts, self.pts, 3)           # a4        (lane A)
-        st, pose, m1, m2 = ctx.compute_pose(self.bv, self.uv, self.wpt, self.K)       # a8 + a9   (lane A, host result)
+        ctx.compute_pose_enqueue(self.bv, self.uv, self.wpt, self.K)                  # a8 + a9   (lane A, no host wait)
+        self.orb.enqueue(self.gray, self.kp_buf[self.k % 2], self.desc_buf[self.k % 2], ctx=lb)   # a5' + a6 (lane B, no host wait)
+        st, pose, m1, m2 = ctx.compute_pose_collect()                                  # host result (lane A)
         kp, desc = self.orb.collect()                                                  # count -> host (lane B)
         self.match = lb.bf_match_hamming(desc, self.prev_desc)                         # a7        (lane B)
         self.prev_desc = desc   # (double-buffered; lane B orders the next frame's detector after this match)

@@ -187,6 +187,13 @@ int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const double *d_u
                       int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th,
                       float fx, float fy, float cx, float cy, double *h_pose7, uint8_t *h_p3p_outlier,
                       uint8_t *h_pnp_outlier, int *h_status);
+/* The same in two halves: _enqueue launches the chain without waiting, _collect waits and returns the results.  No other
+ * call may be made on `ctx` in between (other contexts / streams are free to run: that is the point). */
+int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
+                              int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th,
+                              float fx, float fy, float cx, float cy);
+int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
+                              int *h_status);
 
 /* ---- a10-a13: local bundle adjustment ---------------------------------------------------------
  * Replaces the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262 on the problem

@@ -132,3 +132,15 @@ def test_compute_pose_too_few(ctx):
     st, pose, m1, m2 = ctx.compute_pose(torch.from_numpy(pb["bv"]).cuda(), torch.from_numpy(pb["uv"]).cuda(),
                                         torch.from_numpy(pb["wpt"]).cuda(), pb["K"])
     assert st == 0
+
+
+def test_compute_pose_enqueue_collect_equals_blocking_call(ctx):
+    import torch
+    pb = synth.make_pnp_problem(700, 11, outlier_frac=0.2)
+    bv, uv, wp = (torch.from_numpy(pb[k]).cuda() for k in ("bv", "uv", "wpt"))
+    a = ctx.compute_pose(bv, uv, wp, pb["K"])
+    ctx.compute_pose_enqueue(bv, uv, wp, pb["K"])
+    b = ctx.compute_pose_collect()
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    with pytest.raises(Exception):
+        ctx.compute_pose_collect()   # nothing pending
