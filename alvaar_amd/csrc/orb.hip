@@ -55,10 +55,9 @@ struct OrbDev {
     int umax[17];
 };
 
-__device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int threshold) {
+__device__ __forceinline__ void fast_ring(const uint8_t *p, int stride, int d[16]) {
     // ring in the order of makeOffsets (fast_score.cpp:50-80)
     const int v = p[0];
-    int d[16];
     d[0] = v - p[3 * stride];
     d[1] = v - p[3 * stride + 1];
     d[2] = v - p[2 * stride + 2];
@@ -75,7 +74,10 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int t
     d[13] = v - p[stride - 3];
     d[14] = v - p[2 * stride - 2];
     d[15] = v - p[3 * stride - 1];
-    // bit k set <=> ring pixel k darker than v - t  /  brighter than v + t
+}
+
+// 9 contiguous ring pixels darker than v - t or brighter than v + t (fast.cpp:56-292)
+__device__ __forceinline__ bool fast_is_corner(const int d[16], int threshold) {
     unsigned dark = 0, bright = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -90,21 +92,38 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int t
         r &= m >> 8;       // runs of 9
         return (r & 0xffffu) != 0;
     };
-    if (!has9(dark) && !has9(bright)) return 0;
-    // cornerScore<16>: max over the 16 arcs of 9 of min(d) and min(-d), floored at threshold, minus 1
+    return has9(dark) || has9(bright);
+}
+
+// cornerScore<16> (fast_score.cpp:120-): max over the 16 arcs of 9 of min(d) and min(-d), floored at threshold, minus 1.
+// The arc minima / maxima come from doubling windows (2, 4, 8, then +1): min and max are exact in any association.
+__device__ __forceinline__ int fast_corner_score(const int d[16], int threshold) {
+    int n2[16], x2[16], n4[16], x4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        n2[k] = min(d[k], d[(k + 1) & 15]);
+        x2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        n4[k] = min(n2[k], n2[(k + 2) & 15]);
+        x4[k] = max(x2[k], x2[(k + 2) & 15]);
+    }
     int a0 = threshold;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        int mn = d[k], mx = d[k];
-#pragma unroll
-        for (int j = 1; j < 9; j++) {
-            const int e = d[(k + j) & 15];
-            mn = min(mn, e);
-            mx = max(mx, e);
-        }
+        const int mn = min(min(n4[k], n4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int mx = max(max(x4[k], x4[(k + 4) & 15]), d[(k + 8) & 15]);
         a0 = max(a0, max(mn, -mx));
     }
     return a0 - 1;
+}
+
+__device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int threshold) {
+    int d[16];
+    fast_ring(p, stride, d);
+    if (!fast_is_corner(d, threshold)) return 0;
+    return fast_corner_score(d, threshold);
 }
 
 // resize level l from level l-1 (INTER_LINEAR_EXACT)
@@ -156,6 +175,106 @@ __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
         int v = 0;
         if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) v = fast_score_at(s + (ly + 3) * SW + lx + 3, SW, D.threshold);
         sc[(size_t) gy * L.pitch + gx] = (uint8_t) v;
+    }
+}
+
+// FAST + strict 3x3 non-maximum suppression fused over an LDS tile (the ORB path): gray tile with a 4-px halo in LDS,
+// corner test for every pixel of the tile + 1, the few corners are then packed (wave ballot) so that the score is
+// computed with dense lanes, scores stay in LDS, NMS survivors are packed per row by ballot and appended to the level's
+// candidate list with ONE atomic per tile.  No score map in HBM, no count/scan/emit passes.  The list order depends on
+// tile completion order; every later stage is order-free (threshold culls) and k_cull_harris finally sorts by position.
+__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
+    const Level &L = D.lv[blockIdx.y];
+    const int tilesX = (L.w + FT_W - 1) / FT_W, tilesY = (L.h + FT_H - 1) / FT_H;
+    if ((int) blockIdx.x >= tilesX * tilesY) return;
+    const int x0 = (blockIdx.x % tilesX) * FT_W, y0 = (blockIdx.x / tilesX) * FT_H;
+    // candidates live in [border, dim - border): tiles wholly outside (+1 px for the NMS neighbours) have nothing to do
+    const int lo = max(L.border, 3), hx = L.w - lo, hy = L.h - lo;
+    if (x0 >= hx || x0 + FT_W <= lo || y0 >= hy || y0 + FT_H <= lo) return;
+    constexpr int GW = FT_W + 8, GH = FT_H + 8, SW = FT_W + 4, SH = FT_H + 2;   // gray tile (halo 4), score tile (halo 1)
+    __shared__ uint8_t g[GH * GW];
+    __shared__ uint8_t sc[SH * SW];
+    __shared__ unsigned short list[SH * (FT_W + 2)];
+    __shared__ int s_n, s_row[FT_H], s_base;
+    const uint8_t *img = D.pool + L.img;
+    if (threadIdx.x == 0) s_n = 0;
+    for (int i = threadIdx.x; i < GH * GW; i += 256) {
+        const int ly = i / GW, lx = i % GW;
+        const int gx = min(max(x0 + lx - 4, 0), L.w - 1), gy = min(max(y0 + ly - 4, 0), L.h - 1);
+        g[i] = img[(size_t) gy * L.pitch + gx];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // corner test on the (FT_H + 2) x (FT_W + 2) region; pack the corners
+    for (int i0 = 0; i0 < SH * (FT_W + 2); i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool corner = false;
+        int ly = 0, lx = 0;
+        if (i < SH * (FT_W + 2)) {
+            ly = i / (FT_W + 2);
+            lx = i % (FT_W + 2);
+            const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+            if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) {
+                int d[16];
+                fast_ring(g + (ly + 3) * GW + lx + 3, GW, d);
+                corner = fast_is_corner(d, D.threshold);
+            }
+            sc[ly * SW + lx] = 0;
+        }
+        const unsigned long long m = __ballot(corner);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+        base = __shfl(base, 0);
+        if (corner) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short) (ly * 256 + lx);
+    }
+    __syncthreads();
+    const int nc = s_n;
+    for (int j = threadIdx.x; j < nc; j += 256) {
+        const int ly = list[j] >> 8, lx = list[j] & 255;
+        int d[16];
+        fast_ring(g + (ly + 3) * GW + lx + 3, GW, d);
+        sc[ly * SW + lx] = (uint8_t) fast_corner_score(d, D.threshold);
+    }
+    __syncthreads();
+    // NMS: wave w takes rows w, w + 4, ...; one lane per column
+    const int wave = threadIdx.x >> 6;
+    unsigned long long keepm[FT_H / 4];
+    int myscore[FT_H / 4];
+#pragma unroll
+    for (int it = 0; it < FT_H / 4; it++) {
+        const int r = it * 4 + wave, gx = x0 + lane, gy = y0 + r;
+        const uint8_t *q = sc + (r + 1) * SW + lane + 1;
+        const int v = q[0];
+        bool keep = v > 0 && gx >= lo && gx < hx && gy >= lo && gy < hy;
+        keep = keep && v > q[-1] && v > q[1] && v > q[-SW - 1] && v > q[-SW] && v > q[-SW + 1] && v > q[SW - 1] && v > q[SW] && v > q[SW + 1];
+        if (L.border > 0) keep = keep && L.w > 2 * L.border && L.h > 2 * L.border;   // KeyPointsFilter::runByImageBorder
+        keepm[it] = __ballot(keep);
+        myscore[it] = v;
+        if (lane == 0) s_row[r] = __popcll(keepm[it]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int r = 0; r < FT_H; r++) {
+            const int c = s_row[r];
+            s_row[r] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(&D.n1[blockIdx.y], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FT_H / 4; it++) {
+        if ((keepm[it] >> lane) & 1ull) {
+            const int r = it * 4 + wave;
+            const int pos = s_base + s_row[r] + __popcll(keepm[it] & ((1ull << lane) - 1ull));
+            if (pos < L.candCap) {
+                D.c1x[L.candOff + pos] = x0 + lane;
+                D.c1y[L.candOff + pos] = y0 + r;
+                D.c1s[L.candOff + pos] = myscore[it];
+                atomicAdd(&D.hist[blockIdx.y * 256 + myscore[it]], 1);
+            }
+        }
     }
 }
 
@@ -222,24 +341,53 @@ __global__ void __launch_bounds__(1024) k_scan_rows(OrbDev D) {
     if (threadIdx.x == 0) D.n1[blockIdx.x] = min(carry, L.candCap);
 }
 
+// Wave-0 helper for the culls: first bin b (in the order given by `load`) whose inclusive prefix sum exceeds k.
+// 256 bins, 4 per lane; returns through LDS words (bin, k - exclusive prefix).  Call with threadIdx.x < 64.
+template<typename Load>
+__device__ __forceinline__ void wave_find_bin(Load load, unsigned k, unsigned *s_bin, unsigned *s_rem) {
+    const int l = threadIdx.x;
+    const unsigned c0 = load(4 * l), c1 = load(4 * l + 1), c2 = load(4 * l + 2), c3 = load(4 * l + 3);
+    const unsigned tot = c0 + c1 + c2 + c3;
+    unsigned incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off);
+        if (l >= off) incl += v;
+    }
+    const unsigned excl = incl - tot;
+    if (k >= excl && k < incl) {
+        unsigned r = k - excl;
+        int b;
+        if (r < c0) b = 0;
+        else if (r < c0 + c1) { b = 1; r -= c0; }
+        else if (r < c0 + c1 + c2) { b = 2; r -= c0 + c1; }
+        else { b = 3; r -= c0 + c1 + c2; }
+        *s_bin = (unsigned) (4 * l + b);
+        *s_rem = r;
+    }
+}
+
 // ordered compaction helper: keep[i] decided by the caller's predicate; one workgroup, chunks of 1024
 template<typename Pred, typename Emit>
 __device__ int compact_ordered(int n, Pred pred, Emit emit) {
-    __shared__ int s[1024];
+    __shared__ int s_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int carry = 0;
     for (int b = 0; b < n; b += 1024) {
         const int i = b + threadIdx.x;
-        const int k = (i < n && pred(i)) ? 1 : 0;
-        s[threadIdx.x] = k;
+        const bool k = i < n && pred(i);
+        const unsigned long long m = __ballot(k);   // position inside the wave from the ballot, wave offsets from 16 LDS words
+        if (lane == 0) s_w[wave] = __popcll(m);
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int c = s_w[w];
+            before += w < wave ? c : 0;
+            tot += c;
         }
-        if (k) emit(i, carry + s[threadIdx.x] - 1);
-        carry += s[1023];
+        if (k) emit(i, carry + before + __popcll(m & ((1ull << lane) - 1ull)));
+        carry += tot;
         __syncthreads();
     }
     return carry;
@@ -248,25 +396,17 @@ __device__ int compact_ordered(int n, Pred pred, Emit emit) {
 // cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept), preserving order
 __global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) {
     const Level &L = D.lv[blockIdx.x];
-    const int n = D.n1[blockIdx.x], keepN = 2 * L.nKeep;
-    __shared__ int s_thr;
-    if (threadIdx.x == 0) {
-        int thr = 0;
-        if (keepN == 0) thr = 1 << 30;
-        else if (n > keepN) {
-            int acc = 0;
-            for (int v = 255; v >= 0; v--) {
-                acc += D.hist[blockIdx.x * 256 + v];
-                if (acc >= keepN) {
-                    thr = v;
-                    break;
-                }
-            }
-        }
-        s_thr = thr;
+    const int n = min(D.n1[blockIdx.x], L.candCap), keepN = 2 * L.nKeep;
+    __shared__ unsigned s_bin, s_rem;
+    int thr = 0;
+    if (keepN == 0) thr = 1 << 30;
+    else if (n > keepN) {
+        // largest score v with #{score >= v} >= keepN: prefix sums over the bins in DESCENDING score order
+        const int *hist = D.hist + blockIdx.x * 256;
+        if (threadIdx.x < 64) wave_find_bin([&](int b) { return (unsigned) hist[255 - b]; }, (unsigned) (keepN - 1), &s_bin, &s_rem);
+        __syncthreads();
+        thr = 255 - (int) s_bin;
     }
-    __syncthreads();
-    const int thr = s_thr;
     const int o = L.candOff;
     const int m = compact_ordered(
         n, [&](int i) { return D.c1s[o + i] >= thr; },
@@ -277,26 +417,36 @@ __global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) {
     if (threadIdx.x == 0) D.n2[blockIdx.x] = m;
 }
 
-// Harris response of every surviving candidate (orb.cpp:130-177), one thread each
+// Harris response of every surviving candidate (orb.cpp:130-177): one wave each, the 49 block positions spread over the
+// lanes.  a, b, c are INTEGER sums in the reference, so the cross-lane reduction order cannot change them.
 __global__ void __launch_bounds__(256) k_harris(OrbDev D) {
     const Level &L = D.lv[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= D.n2[blockIdx.y]) return;
-    const int x = D.c2x[L.candOff + i], y = D.c2y[L.candOff + i], W = L.pitch;
+    const int lane = threadIdx.x & 63, n2 = D.n2[blockIdx.y], W = L.pitch;
     const uint8_t *img = D.pool + L.img;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n2; i += gridDim.x * 4) {
+    const int x = D.c2x[L.candOff + i], y = D.c2y[L.candOff + i];
     int a = 0, b = 0, c = 0;
-    for (int k = 0; k < 49; k++) {
-        const uint8_t *p = img + (size_t) (y - 3 + k / 7) * W + (x - 3 + k % 7);
+    if (lane < 49) {
+        const uint8_t *p = img + (size_t) (y - 3 + lane / 7) * W + (x - 3 + lane % 7);
         const int Ix = (p[1] - p[-1]) * 2 + (p[-W + 1] - p[-W - 1]) + (p[W + 1] - p[W - 1]);
         const int Iy = (p[W] - p[-W]) * 2 + (p[W - 1] - p[-W - 1]) + (p[W + 1] - p[-W + 1]);
-        a += Ix * Ix;
-        b += Iy * Iy;
-        c += Ix * Iy;
+        a = Ix * Ix;
+        b = Iy * Iy;
+        c = Ix * Iy;
     }
-    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-    const float scale_sq_sq = scale * scale * scale * scale;
-    const float fa = (float) a, fb = (float) b, fc = (float) c;
-    D.c2r[L.candOff + i] = ((fa * fb - fc * fc) - (0.04f * (fa + fb)) * (fa + fb)) * scale_sq_sq;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+        c += __shfl_down(c, off);
+    }
+    if (lane == 0) {
+        const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+        const float scale_sq_sq = scale * scale * scale * scale;
+        const float fa = (float) a, fb = (float) b, fc = (float) c;
+        D.c2r[L.candOff + i] = ((fa * fb - fc * fc) - (0.04f * (fa + fb)) * (fa + fb)) * scale_sq_sq;
+    }
+    }
 }
 
 __device__ __forceinline__ unsigned f2key(float f) {  // order-preserving map float -> uint
@@ -324,18 +474,9 @@ __global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) {
                 if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned acc = 0;
-                int b = 0;
-                for (; b < 256; b++) {
-                    if (k < acc + s_hist[b]) break;
-                    acc += s_hist[b];
-                }
-                s_prefix = prefix | ((unsigned) b << shift);
-                s_k = k - acc;
-            }
+            if (threadIdx.x < 64) wave_find_bin([&](int b) { return s_hist[b]; }, k, &s_prefix, &s_k);
             __syncthreads();
-            prefix = s_prefix;
+            prefix |= s_prefix << shift;
             k = s_k;
             mask |= 0xffu << shift;
             __syncthreads();
@@ -350,6 +491,37 @@ __global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) {
             D.c3r[o + pos] = D.c2r[o + i];
         });
     if (threadIdx.x == 0) D.n3[blockIdx.x] = m;
+    // Deterministic output order: row-major by position inside the level (positions are unique).  Rank sort: every element
+    // counts the keys below its own from an LDS copy (broadcast reads, no barriers in the loop); m is ~n_l (a few hundred).
+    constexpr int SORT_CAP = 4096;
+    __shared__ unsigned s_key[SORT_CAP];
+    if (m > SORT_CAP) return;  // pathological tie at the Harris cut: the set is still right, the order is as compacted
+    __syncthreads();
+    int ex[4], ey[4];
+    float er[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = threadIdx.x + q * 1024;
+        if (i < m) {
+            ex[q] = D.c3x[o + i];
+            ey[q] = D.c3y[o + i];
+            er[q] = D.c3r[o + i];
+            s_key[i] = ((unsigned) ey[q] << 16) | (unsigned) ex[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = threadIdx.x + q * 1024;
+        if (i < m) {
+            const unsigned mine = ((unsigned) ey[q] << 16) | (unsigned) ex[q];
+            int rank = 0;
+            for (int j = 0; j < m; j++) rank += s_key[j] < mine;
+            D.c3x[o + rank] = ex[q];
+            D.c3y[o + rank] = ey[q];
+            D.c3r[o + rank] = er[q];
+        }
+    }
 }
 
 __device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_core.simd.hpp:34-71
@@ -450,8 +622,10 @@ __global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t 
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < L.w && y < L.h) D.pool[L.img + (size_t) y * L.pitch + x] = src[(size_t) y * pitch + x];
     // first launch of the chain: clear the FAST-score histograms here instead of a separate fill command
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int k = threadIdx.x; k < MAXLV * 256; k += 256) D.hist[k] = 0;
+        if (threadIdx.x < MAXLV) D.n1[threadIdx.x] = 0;   // k_fast_nms appends with atomics
+    }
 }
 
 int cv_round_f(float v) { return (int) lrintf(v); }
@@ -617,13 +791,19 @@ extern "C" void alva_orb_destroy(alva_orb *orb) {
 }
 
 // levels -> FAST -> NMS survivors (row-major per level) with counts in n1
-static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, size_t gray_pitch) {
+static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, size_t gray_pitch, bool fused) {
     OrbDev &D = o->D;
     hipStream_t st = ctx->stream;
     const Level &L0 = D.lv[0];
     hipLaunchKernelGGL(k_copy_level0, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4)), dim3(256), 0, st, D, d_gray, gray_pitch);
     for (int l = 1; l < D.nlevels; l++)
         hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
+    if (fused) {
+        // ORB: candidate order is irrelevant downstream (k_cull_harris re-sorts by position), so FAST + NMS is one launch
+        hipLaunchKernelGGL(k_fast_nms, dim3(o->maxTiles, D.nlevels), dim3(256), 0, st, D);
+        ALVA_LAUNCH_CHECK();
+        return ALVA_OK;
+    }
     hipLaunchKernelGGL(k_fast_score, dim3(o->maxTiles, D.nlevels), dim3(256), 0, st, D);
     hipLaunchKernelGGL(k_fast_rows<false>, dim3(alva_divup(o->maxRows, 4), D.nlevels), dim3(256), 0, st, D);
     hipLaunchKernelGGL(k_scan_rows, dim3(D.nlevels), dim3(1024), 0, st, D);
@@ -639,12 +819,10 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     ALVA_ARG(ctx && orb && d_gray && d_kp && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
     OrbDev &D = orb->D;
     hipStream_t st = ctx->stream;
-    int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch);
+    int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cull_fast, dim3(D.nlevels), dim3(1024), 0, st, D);
-    int maxC = 0;
-    for (int l = 0; l < D.nlevels; l++) maxC = std::max(maxC, D.lv[l].candCap);
-    hipLaunchKernelGGL(k_harris, dim3(alva_divup(maxC, 256), D.nlevels), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_harris, dim3(256, D.nlevels), dim3(256), 0, st, D);   // wave-strided over the level's candidates
     hipLaunchKernelGGL(k_cull_harris, dim3(D.nlevels), dim3(1024), 0, st, D);
     int maxKeep = 0;
     for (int l = 0; l < D.nlevels; l++) maxKeep = std::max(maxKeep, std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024)));
@@ -702,7 +880,7 @@ extern "C" int alva_fast(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch
     alva_orb *o = nullptr;
     int rc = orb_build(ctx, width, height, 0, 1.0f, 1, threshold, 0, &o);
     if (rc) return rc;
-    rc = run_fast_stages(ctx, o, d_gray, gray_pitch);
+    rc = run_fast_stages(ctx, o, d_gray, gray_pitch, false);
     int n = 0;
     if (!rc) {
         hipError_t e = hipMemcpyAsync(&n, o->D.n1, 4, hipMemcpyDeviceToHost, ctx->stream);
