@@ -25,6 +25,10 @@ namespace {
 constexpr int WIN = 9;
 constexpr int NPX = WIN * WIN;  // 81
 constexpr int MAXL = 8;
+// The iteration loop is a chain of dependent steps, and the slowest keypoint (30 iterations on every level) sets the
+// kernel time, so its latency is what matters: the searched image is read through a 16x16 LDS tile (the 10x10 bilinear
+// footprint + 3 px of travel each way) that is re-staged from L2 only when the window leaves it.
+constexpr int TR = 3, TW = WIN + 1 + 2 * TR;
 
 struct LkLevel {
     const uint8_t *gray;
@@ -39,12 +43,15 @@ struct LkPyr {
 };
 
 struct LkShared {
-    short I[NPX + 3];
-    short dIx[NPX + 3];
-    short dIy[NPX + 3];
-    int px[NPX + 3];  // diff * Ix
-    int py[NPX + 3];  // diff * Iy
+    short2 dxy[NPX + 3];  // (Ix, Iy) of the template window
+    int2 pxy[NPX + 3];    // (diff * Ix, diff * Iy) of the current iteration
+    uint8_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level)
 };
+
+// value of lane k (compile-time constant) for every lane: v_readlane, no LDS crossbar round trip
+__device__ __forceinline__ float lane_bcast(float v, int k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
@@ -93,59 +100,56 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     }
     Weights wt = bilinear_weights(prevx - (float) ipx, prevy - (float) ipy);
 
-    // ---- patch extraction: pixel p -> lane p (and p+64 for lanes < 17) ------------------------------
+    // ---- patch extraction: pixel p -> lane p, pixels 64..80 -> lanes 0..16 (the other lanes redo pixel 80: no branch) ----
     short rI[2], rIx[2], rIy[2];
+    int toff[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const int p = lane + 64 * r;
-        rI[r] = rIx[r] = rIy[r] = 0;
-        if (p < NPX) {
-            const int y = p / WIN, x = p - y * WIN;
-            const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
-            const int ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
-            const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
-            const short2 d00 = *reinterpret_cast<const short2 *>(drow);
-            const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
-            const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
-            const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
-            const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
-            const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
-            rI[r] = (short) ival;
-            rIx[r] = (short) ixval;
-            rIy[r] = (short) iyval;
-            sh.dIx[p] = (short) ixval;
-            sh.dIy[p] = (short) iyval;
-        }
+        const int p = min(lane + 64 * r, NPX - 1);
+        const int y = p / WIN, x = p - y * WIN;
+        toff[r] = y * TW + x;
+        const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
+        const int ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
+        const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
+        const short2 d00 = *reinterpret_cast<const short2 *>(drow);
+        const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
+        const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
+        const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
+        const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
+        const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+        rI[r] = (short) ival;
+        rIx[r] = (short) ixval;
+        rIy[r] = (short) iyval;
+        sh.dxy[p] = make_short2((short) ixval, (short) iyval);
     }
     __syncthreads();
-    // ---- A = sum of dI dI^T in the reference's SIMD128 order (15 chains on lanes 0..14) ---------------
+    // ---- A = sum of dI dI^T in the reference's SIMD128 order: 15 chains on lanes 0..14 = (component, vector lane 0..3 |
+    // scalar pixel 8).  Branch-free: every lane runs the same 18 adds (the scalar chain adds +0.f for its missing half;
+    // lanes >= 15 repeat lane 14).  (float) ix * (float) iy == (float) (ix * iy): both round the same exact product.
     float acc = 0.f;
-    if (lane < 15) {
-        const int comp = lane / 5, ch = lane - comp * 5;
-        for (int y = 0; y < WIN; y++) {
-            if (ch < 4) {
+    {
+        const int l15 = min(lane, 14), comp = l15 / 5, ch = l15 - comp * 5;
+        const bool two = ch < 4;
+        const int qa = two ? ch : 8, qb = two ? ch + 4 : 8;
 #pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int p = y * WIN + ch + 4 * half;
-                    const float fx = (float) sh.dIx[p], fy = (float) sh.dIy[p];
-                    const float prod = comp == 0 ? fx * fx : (comp == 1 ? fx * fy : fy * fy);
-                    acc = prod + acc;
-                }
-            } else {
-                const int p = y * WIN + 8;
-                const int ix = sh.dIx[p], iy = sh.dIy[p];
-                const int prod = comp == 0 ? ix * ix : (comp == 1 ? ix * iy : iy * iy);
-                acc += (float) prod;
-            }
+        for (int y = 0; y < WIN; y++) {
+            const short2 da = sh.dxy[y * WIN + qa], db = sh.dxy[y * WIN + qb];
+            const float fxa = (float) da.x, fya = (float) da.y, fxb = (float) db.x, fyb = (float) db.y;
+            const float p1 = (comp == 2 ? fya : fxa) * (comp == 0 ? fxa : fya);
+            float p2 = (comp == 2 ? fyb : fxb) * (comp == 0 ? fxb : fyb);
+            p2 = two ? p2 : 0.f;
+            acc = p1 + acc;
+            acc = p2 + acc;
         }
     }
     float A[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const float q0 = __shfl(acc, 5 * k + 0), q1 = __shfl(acc, 5 * k + 1), q2 = __shfl(acc, 5 * k + 2), q3 = __shfl(acc, 5 * k + 3);
-        float s = __shfl(acc, 5 * k + 4);
-        s += (q0 + q2) + (q1 + q3);
-        A[k] = s * (1.f / (1 << 20));
+        const float q0 = lane_bcast(acc, 5 * k + 0), q1 = lane_bcast(acc, 5 * k + 1), q2 = lane_bcast(acc, 5 * k + 2),
+                    q3 = lane_bcast(acc, 5 * k + 3);
+        float sres = lane_bcast(acc, 5 * k + 4);
+        sres += (q0 + q2) + (q1 + q3);
+        A[k] = sres * (1.f / (1 << 20));
     }
     const float A11 = A[0], A12 = A[1], A22 = A[2];
     float D = A11 * A22 - A12 * A12;
@@ -162,6 +166,7 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     nextx -= halfWin;
     nexty -= halfWin;
     float pdx = 0.f, pdy = 0.f;
+    int tx0 = 0x40000000, ty0 = 0x40000000;  // tile origin in image coordinates (invalid: staged on first use)
     for (int j = 0; j < maxCount; j++) {
         const int inx = (int) floorf(nextx), iny = (int) floorf(nexty);
         if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
@@ -169,41 +174,53 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
             break;
         }
         wt = bilinear_weights(nextx - (float) inx, nexty - (float) iny);
-        __syncthreads();  // previous iteration's chain reads are done before px/py are overwritten
+        if (inx < tx0 || inx > tx0 + 2 * TR || iny < ty0 || iny > ty0 + 2 * TR) {  // wave-uniform
+            tx0 = inx - TR;
+            ty0 = iny - TR;
+            __syncthreads();
+            // lane -> row lane/4, 4 consecutive columns; coordinates clamped to the padded level (the window itself
+            // never leaves it, lkpyramid.cpp:518-523, so clamped bytes are never used)
+            const int row = lane >> 2, c0 = (lane & 3) * 4;
+            const int gy = min(max(ty0 + row, -WIN), J.h + WIN - 1);
+            const uint8_t *srow = J.gray + (ptrdiff_t) gy * J.gpitch;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sh.jt[row * TW + c0 + k] = srow[min(max(tx0 + c0 + k, -WIN), J.w + WIN - 1)];
+        }
+        __syncthreads();  // tile staged; previous iteration's chain reads are done before px/py are overwritten
+        const int tbase = (iny - ty0) * TW + (inx - tx0);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const int p = lane + 64 * r;
-            if (p < NPX) {
-                const int y = p / WIN, x = p - y * WIN;
-                const uint8_t *src = J.gray + (ptrdiff_t) (y + iny) * J.gpitch + (x + inx);
-                const int jval = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[J.gpitch] * wt.w10 + src[J.gpitch + 1] * wt.w11, 9);
-                const int diff = (int) (short) (jval - rI[r]);
-                sh.px[p] = diff * rIx[r];
-                sh.py[p] = diff * rIy[r];
-            }
+            const int p = min(lane + 64 * r, NPX - 1);
+            const uint8_t *src = sh.jt + toff[r] + tbase;
+            const int jval = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[TW] * wt.w10 + src[TW + 1] * wt.w11, 9);
+            const int diff = (int) (short) (jval - rI[r]);
+            sh.pxy[p] = make_int2(diff * rIx[r], diff * rIy[r]);
         }
         __syncthreads();
-        // b chains (lkpyramid.cpp:553-562, 628-646): lanes 0..7 = (pixel pair (q, q+4), component),
-        // lanes 8,9 = scalar pixel 8
+        // b chains (lkpyramid.cpp:553-562, 628-646): lanes 0..7 = (vector lane q: pixels q and q+4, component),
+        // lanes 8,9 = scalar pixel 8; branch-free like the A chains
         float bacc = 0.f;
-        if (lane < 10) {
-            const int comp = lane & 1;
-            const int *src = comp ? sh.py : sh.px;
-            if (lane < 8) {
-                const int q = lane >> 1;
-                for (int y = 0; y < WIN; y++) bacc += (float) (src[y * WIN + q] + src[y * WIN + q + 4]);
-            } else {
-                for (int y = 0; y < WIN; y++) bacc += (float) src[y * WIN + 8];
+        {
+            const int l10 = min(lane, 9), comp = l10 & 1, q = l10 >> 1;
+            const bool two = q < 4;
+            const int qa = two ? q : 8, qb = two ? q + 4 : 8;
+            const int *src = reinterpret_cast<const int *>(sh.pxy) + comp;
+#pragma unroll
+            for (int y = 0; y < WIN; y++) {
+                const int va = src[2 * (y * WIN + qa)];
+                int vb = src[2 * (y * WIN + qb)];
+                vb = two ? vb : 0;
+                bacc += (float) (va + vb);
             }
         }
         float ib[2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const float s0 = __shfl(bacc, 0 + c) + __shfl(bacc, 4 + c);  // qb0[0|1] + qb1[0|1]
-            const float s2 = __shfl(bacc, 2 + c) + __shfl(bacc, 6 + c);  // qb0[2|3] + qb1[2|3]
-            float s = __shfl(bacc, 8 + c);
-            s += (s0 + 0.f) + (s2 + 0.f);
-            ib[c] = s;
+            const float s0 = lane_bcast(bacc, 0 + c) + lane_bcast(bacc, 4 + c);  // qb0[0|1] + qb1[0|1]
+            const float s2 = lane_bcast(bacc, 2 + c) + lane_bcast(bacc, 6 + c);  // qb0[2|3] + qb1[2|3]
+            float sres = lane_bcast(bacc, 8 + c);
+            sres += (s0 + 0.f) + (s2 + 0.f);
+            ib[c] = sres;
         }
         const float b1 = ib[0] * (1.f / (1 << 20)), b2 = ib[1] * (1.f / (1 << 20));
         const float dx = (A12 * b2 - A22 * b1) * D;
