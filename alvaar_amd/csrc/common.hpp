@@ -42,6 +42,7 @@ struct alva_ctx {
     alva_scratch scratch[8];
     void *pinned = nullptr;  // small pinned host staging (counters, results)
     size_t pinned_bytes = 0;
+    int *d_counters = nullptr;  // 64 device ints, zero between launches (inter-workgroup arrival counters)
     hipEvent_t fence = nullptr;  // lazily created; alva_ctx_wait records it on this context's stream
     void *pose_pending = nullptr;  // alva_compute_pose_enqueue -> _collect hand-over (pnp.hip)
     void (*pose_pending_free)(void *) = nullptr;

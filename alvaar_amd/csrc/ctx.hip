@@ -40,6 +40,15 @@ extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alv
         alva_set_error("hipHostMalloc: %s", hipGetErrorString(e));
         return ALVA_ERR_NOMEM;
     }
+    e = hipMalloc((void **) &c->d_counters, 64 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 64 * sizeof(int));
+    if (e != hipSuccess) {
+        (void) hipHostFree(c->pinned);
+        if (c->owns_stream) (void) hipStreamDestroy(c->stream);
+        delete c;
+        alva_set_error("hipMalloc(counters): %s", hipGetErrorString(e));
+        return ALVA_ERR_NOMEM;
+    }
     *out = c;
     return ALVA_OK;
 }
@@ -51,6 +60,7 @@ extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
     for (auto &s: ctx->scratch)
         if (s.ptr) (void) hipFree(s.ptr);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
+    if (ctx->d_counters) (void) hipFree(ctx->d_counters);
     if (ctx->fence) (void) hipEventDestroy(ctx->fence);
     if (ctx->pose_pending && ctx->pose_pending_free) ctx->pose_pending_free(ctx->pose_pending);
     if (ctx->owns_stream) (void) hipStreamDestroy(ctx->stream);

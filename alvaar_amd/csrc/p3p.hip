@@ -10,10 +10,9 @@
 //   score      AbsolutePoseSacProblem.cpp:165-199  (1 - f . normalize(R^T (X - t)))
 //
 // The reference evaluates hypotheses one after another; they are independent, so here
-//   k_hyp      one thread per drawn sample   -> model + valid flag
-//   k_median   one workgroup per hypothesis  -> N squared scores into LDS, radix-select of the median
-//   k_select   one workgroup                 -> replay the sequential "first max_iters valid, strict <"
-//                                               scan, then classify inliers of the winner
+//   k_p3p      ONE launch, one workgroup per drawn sample: hypothesis (4 lanes = 4 quartic roots) -> N squared scores
+//              into LDS, radix-select of the median -> the last workgroup to finish replays the sequential
+//              "first max_iters valid, strict <" selection and classifies the winner's inliers
 // FP64 VALU work (100 x N x ~40 flop); bytes are negligible (48 N read once per hypothesis,
 // L2-resident).  No MFMA: nothing here is GEMM-shaped.
 #include "common.hpp"
@@ -23,6 +22,8 @@
 #include <random>
 
 namespace {
+
+using SelectOut = P3pSelectOut;
 
 struct cplx {
     double re, im;
@@ -108,7 +109,9 @@ __device__ __forceinline__ double p3p_score(const double *m, V3 wp, V3 bv) {
     return 1.0 - dot(r, bv);
 }
 
-__device__ int p3p_kneip(const V3 f[3], const V3 p[3], double sol[4][12]) {
+// Kneip P3P (opengv p3p_kneip): the quartic is shared, solution `which` (0..3) is back-substituted into sol[12].
+// Four lanes of a wave each take one root; returns 0 for a degenerate (collinear) world triple.
+__device__ int p3p_kneip(const V3 f[3], const V3 p[3], int which, double sol[12]) {
     V3 P1 = p[0], P2 = p[1], P3 = p[2];
     const V3 t1 = sub(P2, P1), t2 = sub(P3, P1);
     if (norm(cross(t1, t2)) == 0) return 0;
@@ -158,9 +161,10 @@ __device__ int p3p_kneip(const V3 f[3], const V3 p[3], double sol[4][12]) {
              f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
     double roots[4];
     o4_roots(fac, roots);
-    for (int i = 0; i < 4; i++) {
-        const double cot_alpha = (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
-        const double cos_theta = roots[i], sin_theta = sqrt(1 - roots[i] * roots[i]);
+    {
+        const double root = which == 0 ? roots[0] : (which == 1 ? roots[1] : (which == 2 ? roots[2] : roots[3]));
+        const double cot_alpha = (-f_1 * p_1 / f_2 - root * p_2 + d_12 * b) / (-f_1 * root * p_2 / f_2 + p_1 - d_12);
+        const double cos_theta = root, sin_theta = sqrt(1 - root * root);
         const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
         double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
         if (cot_alpha < 0) cos_alpha = -cos_alpha;
@@ -173,47 +177,26 @@ __device__ int p3p_kneip(const V3 f[3], const V3 p[3], double sol[4][12]) {
         const V3 Tc[3] = {V3{T.r0.x, T.r1.x, T.r2.x}, V3{T.r0.y, T.r1.y, T.r2.y}, V3{T.r0.z, T.r1.z, T.r2.z}};
         for (int j = 0; j < 3; j++) {
             const V3 col = mulT(N, mulT(R, Tc[j]));
-            sol[i][j] = col.x;
-            sol[i][3 + j] = col.y;
-            sol[i][6 + j] = col.z;
+            sol[j] = col.x;
+            sol[3 + j] = col.y;
+            sol[6 + j] = col.z;
         }
-        sol[i][9] = Cw.x;
-        sol[i][10] = Cw.y;
-        sol[i][11] = Cw.z;
+        sol[9] = Cw.x;
+        sol[10] = Cw.y;
+        sol[11] = Cw.z;
     }
     return 4;
 }
 
-__global__ void __launch_bounds__(64) k_hyp(const double *__restrict__ bv, const double *__restrict__ wpt, const int *__restrict__ samples,
-                                            int H, double *__restrict__ models, int *__restrict__ valid) {
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= H) return;
-    const int *s = samples + 4 * h;
-    V3 f[3], p[3];
-    for (int k = 0; k < 3; k++) {
-        f[k] = ld3(bv + 3 * (size_t) s[k]);
-        p[k] = ld3(wpt + 3 * (size_t) s[k]);
-    }
-    double sol[4][12];
-    const int ns = p3p_kneip(f, p, sol);
-    double minScore = 1000000.0;
-    int minIndex = -1;
-    const V3 w4 = ld3(wpt + 3 * (size_t) s[3]), b4 = ld3(bv + 3 * (size_t) s[3]);
-    for (int i = 0; i < ns; i++) {
-        const double sc = p3p_score(sol[i], w4, b4);
-        if (sc < minScore) {
-            minScore = sc;
-            minIndex = i;
-        }
-    }
-    valid[h] = minIndex >= 0;
-    if (minIndex >= 0)
-        for (int k = 0; k < 12; k++) models[12 * (size_t) h + k] = sol[minIndex][k];
-}
-
-// One workgroup per hypothesis: squared clipped scores -> LDS, then the median by MSB-first radix SELECT on the
-// IEEE bit patterns (non-negative doubles order like their uint64 bits) instead of the reference's full std::sort
-// (Lmeds.hpp:96-130 only ever reads distances[mid-1] and distances[mid]): 8 passes of a 256-bin LDS histogram.
+// ---------------------------------------------------------------------------------------------------------------
+// ONE launch for the whole LMedS loop (Lmeds.hpp:60-190): one workgroup per drawn sample
+//   1. hypothesis: 4 lanes back-substitute the 4 quartic roots, the 4th point picks the solution
+//      (AbsolutePoseSacProblem.cpp:41-110)
+//   2. penalty: squared clipped scores of all n points -> LDS, median by MSB-first radix SELECT on the IEEE bit patterns
+//      (non-negative doubles order like their uint64 bits) instead of the reference's full std::sort (Lmeds.hpp:96-130
+//      only ever reads distances[mid-1] and distances[mid]): 8 passes of a 256-bin LDS histogram
+//   3. the workgroup that finishes LAST (device-scope counter) picks the best of the first max_iters valid hypotheses
+//      and classifies the inliers of the winner (Lmeds.hpp:150-190)
 __device__ unsigned long long radix_select(const unsigned long long *keys, int n, int k, unsigned int *hist, int *s_bin, int *s_k) {
     unsigned long long prefix = 0, mask = 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
@@ -255,110 +238,187 @@ __device__ unsigned long long radix_select(const unsigned long long *keys, int n
     return prefix;
 }
 
-__global__ void __launch_bounds__(256) k_median(const double *__restrict__ bv, const double *__restrict__ wpt, int n, int np2,
-                                                const double *__restrict__ models, const int *__restrict__ valid,
-                                                double *__restrict__ penalty) {
+
+struct P3pArgs {
+    const double *bv, *wpt;
+    const int *samples;     // H x 4 (pinned host memory, read once)
+    int n, H, max_iters;
+    double threshold;
+    double *models;         // H x 12
+    int *valid;             // H
+    double *penalty;        // H
+    int *counter;           // device-scope arrival counter (zero between launches)
+    SelectOut *out;
+    uint8_t *inlier;
+};
+
+__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) {
     extern __shared__ unsigned long long s_keys[];
     __shared__ unsigned int s_hist[256];
-    __shared__ int s_bin, s_k;
+    __shared__ int s_bin, s_k, s_valid, s_last;
     __shared__ unsigned long long s_min[256];
     __shared__ unsigned int s_cnt[256];
     __shared__ double s_m[12];
-    (void) np2;
-    const int h = blockIdx.x;
-    if (!valid[h]) {
-        if (threadIdx.x == 0) penalty[h] = INFINITY;
-        return;
-    }
-    if (threadIdx.x < 12) s_m[threadIdx.x] = models[12 * (size_t) h + threadIdx.x];
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
-        double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
-        if (d < 0) d = 0;
-        double v = d * d;
-        if (v != v) v = INFINITY;  // NaN scores order last (std::sort's behaviour with NaN is unspecified)
-        s_keys[i] = (unsigned long long) __double_as_longlong(v);
-    }
-    __syncthreads();
-    const int mid = n / 2;
-    const unsigned long long kmid = radix_select(s_keys, n, mid, s_hist, &s_bin, &s_k);
-    if (n % 2 != 0) {
-        if (threadIdx.x == 0) penalty[h] = __longlong_as_double((long long) kmid);
-        return;
-    }
-    // even n: also need the (mid-1)-th smallest = max{x : x < kmid} unless kmid is duplicated below rank mid
-    unsigned long long below = 0;
-    unsigned int cnt_lt = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const unsigned long long key = s_keys[i];
-        if (key < kmid) {
-            cnt_lt++;
-            below = key > below ? key : below;
+    const int h = blockIdx.x, n = A.n;
+    const double *bv = A.bv, *wpt = A.wpt;
+    // ---- 1. hypothesis -------------------------------------------------------------------------------------------
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x & 3;  // only lanes 0..3 matter; the rest of the wave mirrors them
+        const int *smp = A.samples + 4 * h;
+        const int i0 = smp[0], i1 = smp[1], i2 = smp[2], i3 = smp[3];
+        V3 f[3] = {ld3(bv + 3 * (size_t) i0), ld3(bv + 3 * (size_t) i1), ld3(bv + 3 * (size_t) i2)};
+        V3 p[3] = {ld3(wpt + 3 * (size_t) i0), ld3(wpt + 3 * (size_t) i1), ld3(wpt + 3 * (size_t) i2)};
+        double sol[12];
+        const int ns = p3p_kneip(f, p, which, sol);
+        // the solution closest to the 4th correspondence, first one on ties (strict <, initial 1e6)
+        double sc = ns ? p3p_score(sol, ld3(wpt + 3 * (size_t) i3), ld3(bv + 3 * (size_t) i3)) : 2000000.0;
+        if (!(sc < 1000000.0)) sc = 2000000.0;  // NaN or too large: never selected
+        double best = sc;
+        int bi = which;
+#pragma unroll
+        for (int off = 1; off < 4; off <<= 1) {
+            const double o = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (o < best || (o == best && oi < bi)) {
+                best = o;
+                bi = oi;
+            }
+        }
+        const int ok = best < 1000000.0;
+        if (threadIdx.x < 4 && ok && bi == which) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                s_m[k] = sol[k];
+                A.models[12 * (size_t) h + k] = sol[k];
+            }
+        }
+        if (threadIdx.x == 0) {
+            s_valid = ok;
+            A.valid[h] = ok;
         }
     }
-    s_min[threadIdx.x] = below;
-    s_cnt[threadIdx.x] = cnt_lt;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            s_min[threadIdx.x] = s_min[threadIdx.x] > s_min[threadIdx.x + s] ? s_min[threadIdx.x] : s_min[threadIdx.x + s];
-            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + s];
+    // ---- 2. LMedS penalty ----------------------------------------------------------------------------------------
+    double pen = INFINITY;
+    if (s_valid) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
+            if (d < 0) d = 0;
+            double v = d * d;
+            if (v != v) v = INFINITY;  // NaN scores order last (std::sort's behaviour with NaN is unspecified)
+            s_keys[i] = (unsigned long long) __double_as_longlong(v);
         }
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        // elements < kmid occupy ranks [0, cnt_lt); rank mid-1 is below kmid only if cnt_lt == mid
-        const unsigned long long klo = (s_cnt[0] == (unsigned) mid) ? s_min[0] : kmid;
-        penalty[h] = (__longlong_as_double((long long) klo) + __longlong_as_double((long long) kmid)) / 2;
-    }
-}
-
-using SelectOut = P3pSelectOut;
-
-__global__ void __launch_bounds__(256) k_select(const double *__restrict__ bv, const double *__restrict__ wpt, int n, int H, int max_iters,
-                                                const double *__restrict__ models, const int *__restrict__ valid,
-                                                const double *__restrict__ penalty, double threshold, SelectOut *__restrict__ out,
-                                                uint8_t *__restrict__ inlier) {
-    __shared__ int s_best, s_cnt;
-    __shared__ double s_m[12];
-    if (threadIdx.x == 0) {
-        double best = 1.7976931348623157e308;
-        int bi = -1, used = 0;
-        for (int h = 0; h < H && used < max_iters; h++) {
-            if (!valid[h]) continue;
-            if (penalty[h] < best) {
-                best = penalty[h];
-                bi = h;
+        const int mid = n / 2;
+        const unsigned long long kmid = radix_select(s_keys, n, mid, s_hist, &s_bin, &s_k);
+        if (n % 2 != 0) {
+            pen = __longlong_as_double((long long) kmid);
+        } else {
+            // even n: also need the (mid-1)-th smallest = max{x : x < kmid} unless kmid is duplicated below rank mid
+            unsigned long long below = 0;
+            unsigned int cnt_lt = 0;
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const unsigned long long key = s_keys[i];
+                if (key < kmid) {
+                    cnt_lt++;
+                    below = key > below ? key : below;
+                }
             }
-            used++;
+            s_min[threadIdx.x] = below;
+            s_cnt[threadIdx.x] = cnt_lt;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (threadIdx.x < st) {
+                    s_min[threadIdx.x] = s_min[threadIdx.x] > s_min[threadIdx.x + st] ? s_min[threadIdx.x] : s_min[threadIdx.x + st];
+                    s_cnt[threadIdx.x] += s_cnt[threadIdx.x + st];
+                }
+                __syncthreads();
+            }
+            // elements < kmid occupy ranks [0, cnt_lt); rank mid-1 is below kmid only if cnt_lt == mid
+            const unsigned long long klo = (s_cnt[0] == (unsigned) mid) ? s_min[0] : kmid;
+            pen = (__longlong_as_double((long long) klo) + __longlong_as_double((long long) kmid)) / 2;
         }
-        s_best = bi;
-        s_cnt = 0;
-        out->best = bi;
-        out->n_valid_used = used;
-        out->have_model = bi >= 0;
+    }
+    // ---- 3. last workgroup selects -------------------------------------------------------------------------------
+    if (threadIdx.x == 0) {
+        A.penalty[h] = pen;
+        __threadfence();
+        s_last = atomicAdd(A.counter, 1) == A.H - 1;
     }
     __syncthreads();
-    const int bi = s_best;
-    if (bi < 0) {
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) *A.counter = 0;  // ready for the next launch (stream order)
+    const volatile int *vvalid = A.valid;
+    const volatile double *vpen = A.penalty, *vmodels = A.models;
+    // first max_iters VALID hypotheses in draw order (failed models do not count as iterations, Lmeds.hpp:88-92);
+    // smallest penalty, earliest on ties (strict <)
+    __shared__ int s_wcnt[4];
+    double *s_bp = reinterpret_cast<double *>(s_min);
+    int *s_bidx = reinterpret_cast<int *>(s_cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int used = 0, bestI = -1;
+    double bestP = 1.7976931348623157e308;
+    for (int base = 0; base < A.H && used < A.max_iters; base += 256) {
+        const int hh = base + threadIdx.x;
+        const bool v = hh < A.H && vvalid[hh] != 0;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = used, tot = 0;
+        for (int w = 0; w < 4; w++) {
+            before += w < wave ? s_wcnt[w] : 0;
+            tot += s_wcnt[w];
+        }
+        before += __popcll(m & ((1ull << lane) - 1ull));
+        const bool ok = v && before < A.max_iters;
+        s_bp[threadIdx.x] = ok ? vpen[hh] : INFINITY;
+        s_bidx[threadIdx.x] = ok ? hh : 0x7fffffff;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                const double o = s_bp[threadIdx.x + st];
+                const int oi = s_bidx[threadIdx.x + st];
+                if (o < s_bp[threadIdx.x] || (o == s_bp[threadIdx.x] && oi < s_bidx[threadIdx.x])) {
+                    s_bp[threadIdx.x] = o;
+                    s_bidx[threadIdx.x] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (s_bidx[0] != 0x7fffffff && s_bp[0] < bestP) {
+            bestP = s_bp[0];
+            bestI = s_bidx[0];
+        }
+        used = min(used + tot, A.max_iters);
+        __syncthreads();
+    }
+    SelectOut *out = A.out;
+    if (threadIdx.x == 0) {
+        out->best = bestI;
+        out->n_valid_used = used;
+        out->have_model = bestI >= 0;
+        s_k = 0;
+    }
+    if (bestI < 0) {
         if (threadIdx.x == 0) out->n_inliers = 0;
         return;
     }
     if (threadIdx.x < 12) {
-        s_m[threadIdx.x] = models[12 * (size_t) bi + threadIdx.x];
+        s_m[threadIdx.x] = vmodels[12 * (size_t) bestI + threadIdx.x];
         out->model[threadIdx.x] = s_m[threadIdx.x];
     }
     __syncthreads();
     int cnt = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
         const double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
-        const bool in = d <= threshold;  // Lmeds.hpp:180-183 (raw, unsquared distance)
-        inlier[i] = in;
+        const bool in = d <= A.threshold;  // Lmeds.hpp:180-183 (raw, unsquared distance)
+        A.inlier[i] = in;
         cnt += in;
     }
-    atomicAdd(&s_cnt, cnt);
+    atomicAdd(&s_k, cnt);
     __syncthreads();
-    if (threadIdx.x == 0) out->n_inliers = s_cnt;
+    if (threadIdx.x == 0) out->n_inliers = s_k;
 }
 
 // SampleConsensusProblem<M>: rng_dist_ = uniform_int_distribution<>(0, INT_MAX), rng_alg_ = std::mt19937
@@ -405,17 +465,21 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     uint8_t *base = nullptr;
     int rc = alva_ctx_scratch(ctx, 2, total, (void **) &base);
     if (rc) return rc;
-    double *d_models = (double *) base;
-    int *d_valid = (int *) (base + off_valid);
-    double *d_pen = (double *) (base + off_pen);
-    hipLaunchKernelGGL(k_hyp, dim3(alva_divup(H, 64)), dim3(64), 0, ctx->stream, d_bearings, d_wpts, (const int *) pin_samples, H, d_models,
-                       d_valid);
-    ALVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_median, dim3(H), dim3(256), (size_t) n * sizeof(double), ctx->stream, d_bearings, d_wpts, n, 0, d_models, d_valid,
-                       d_pen);
-    ALVA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, d_bearings, d_wpts, n, H, max_iters, d_models, d_valid, d_pen,
-                       threshold, out, inlier);
+    P3pArgs A{};
+    A.bv = d_bearings;
+    A.wpt = d_wpts;
+    A.samples = pin_samples;
+    A.n = n;
+    A.H = H;
+    A.max_iters = max_iters;
+    A.threshold = threshold;
+    A.models = (double *) base;
+    A.valid = (int *) (base + off_valid);
+    A.penalty = (double *) (base + off_pen);
+    A.counter = ctx->d_counters;  // slot 0: zero between launches (the last workgroup resets it)
+    A.out = out;
+    A.inlier = inlier;
+    hipLaunchKernelGGL(k_p3p, dim3(H), dim3(256), (size_t) n * sizeof(double), ctx->stream, A);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }
