@@ -9,11 +9,16 @@
 //
 // Why one workgroup: the problem is N <= a few thousand 2x6 Jacobian rows and a 6x6 solve per iteration;
 // a multi-launch version would pay ~10 dependent kernel boundaries + host round trips (~1.5-5 us each,
-// MI355X_MICROARCH "boundary" row) for ~1 us of FP64 work per evaluation.  Here 1024 threads evaluate
+// MI355X_MICROARCH "boundary" row) for ~1 us of FP64 work per evaluation.  Here 512 threads evaluate
 // residuals/Jacobians and reduce the 28 normal-equation scalars (21 of J^T J, 6 of J^T r, cost) through
-// wave shuffles + LDS; lane 0 does the 6x6 Cholesky and the trust-region bookkeeping; nothing leaves
-// the CU until the pose is final.  FP64 throughout (the reference is all double).
+// a butterfly reduce-scatter + LDS; lane 0 does the 6x6 Cholesky and the trust-region bookkeeping; nothing
+// leaves the CU until the pose is final.  FP64 throughout (the reference is all double).
+//
+// An evaluation is FP64-issue bound on the one CU (~13 k wave instructions for 2 k points), so this translation unit
+// allows fused multiply-add contraction: the normal-equation accumulation is half the instructions as FMAs.  Results
+// are compared with the reference under a tolerance (FP64 sums in a different order anyway), not bitwise.
 #include "common.hpp"
+#pragma clang fp contract(fast)
 #include "lm_device.hpp"
 #include "pose_internal.hpp"
 #include <algorithm>
@@ -102,16 +107,33 @@ __device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robu
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (WANT_J) {
+        // butterfly reduce-scatter over the wave: at distance d each lane keeps half of its values and adds the partner's
+        // copy of that half (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges instead of 28 x 6); lane l ends with the total of
+        // value l >> 1
+        double v[32];
 #pragma unroll
-    for (int k = 0; k < NACC; k++) {
-        if (!WANT_J && k != 27) continue;
-        double v = acc[k];
+        for (int k = 0; k < 32; k++) v[k] = k < NACC ? acc[k] : 0.0;
+#pragma unroll
+        for (int half = 16; half >= 1; half >>= 1) {
+            const bool hi = (lane & (2 * half)) != 0;
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                const double send = hi ? v[k] : v[k + half];
+                const double keep = hi ? v[k + half] : v[k];
+                v[k] = keep + __shfl_xor(send, 2 * half);
+            }
+        }
+        v[0] += __shfl_xor(v[0], 1);
+        if (!(lane & 1) && (lane >> 1) < NACC) sh.part[wave][lane >> 1] = v[0];
+    } else {
+        double v = acc[27];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sh.part[wave][k] = v;
+        if (lane == 0) sh.part[wave][27] = v;
     }
     __syncthreads();
-    if (threadIdx.x < NACC) {
+    if (threadIdx.x < NACC && (WANT_J || threadIdx.x == 27)) {
         double v = 0;
         for (int w = 0; w < NW; w++) v += sh.part[w][threadIdx.x];
         sh.acc[threadIdx.x] = v;
