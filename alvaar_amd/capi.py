@@ -66,6 +66,11 @@ _sig("alva_orb_destroy", [_vp], None)
 _sig("alva_orb_detect_and_compute", [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp])
 _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_frontend_create", [_i, _i, _i, _i, _i, C.POINTER(_vp)])
+_sig("alva_frontend_destroy", [_vp], None)
+_sig("alva_frontend_track", [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp])
+_sig("alva_frontend_results", [_vp] + [C.POINTER(_vp)] * 6)
+_sig("alva_frontend_sync", [_vp])
 _sig("alva_compute_pose_enqueue", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f])
 _sig("alva_compute_pose_collect", [_vp, _vp, _vp, _vp, _vp])
 _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
@@ -365,3 +370,58 @@ class Orb:
         check(lib.alva_orb_detect_and_compute(self.ctx.h, self.h, _ptr(gray), gray.stride(0), _ptr(kp), _ptr(desc), cap, C.byref(cnt)))
         n = min(cnt.value, cap)
         return kp[:n], (desc[:n] if describe else None)
+
+
+class Frontend:
+    """alva_frontend: native per-frame driver (VisualFrontend::trackMono order) over two HIP streams."""
+
+    def __init__(self, device: int, width: int, height: int, max_tracked: int, orb_features: int = 2000):
+        import numpy as np
+        h = _vp()
+        check(lib.alva_frontend_create(device, width, height, max_tracked, orb_features, C.byref(h)))
+        self.h = h
+        self.device = device
+        self.cap = 4 * orb_features + 1024
+        self.max_tracked = max_tracked
+        self._pose = np.zeros(7)
+        self._st = C.c_int(0)
+        self._nkp = C.c_int(0)
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.alva_frontend_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def track(self, rgba, pts, bearings, uv, wpts, K):
+        """returns (pose status 0/1/2, pose7 numpy (a view, overwritten by the next call), number of ORB keypoints)"""
+        check(lib.alva_frontend_track(self.h, _ptr(rgba), rgba.stride(0), _ptr(pts), pts.shape[0], _ptr(bearings), _ptr(uv), _ptr(wpts),
+                                      bearings.shape[0], K[0], K[1], K[2], K[3], self._pose.ctypes.data, C.byref(self._st),
+                                      C.byref(self._nkp)))
+        self._npts = pts.shape[0]
+        return self._st.value, self._pose, self._nkp.value
+
+    def sync(self):
+        check(lib.alva_frontend_sync(self.h))
+
+    def results(self):
+        """dict of torch views (no copy) of the device-resident results of the last track(); call sync() before reading"""
+        ptrs = [_vp() for _ in range(6)]
+        check(lib.alva_frontend_results(self.h, *[C.byref(p) for p in ptrs]))
+        n, m = self._npts, self._nkp.value
+
+        def view(ptr, shape, dtype):
+            import numpy as np
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            if nbytes == 0:
+                return torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+            class _W:
+                pass
+            w = _W()
+            typestr = {torch.float32: "<f4", torch.uint8: "|u1", torch.int32: "<i4"}[dtype]
+            w.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr.value, False), "version": 2}
+            return torch.as_tensor(w, device=f"cuda:{self.device}")
+        return {"tracked": view(ptrs[0], (n, 2), torch.float32), "status": view(ptrs[1], (n,), torch.uint8),
+                "keypoints": view(ptrs[2], (m, 6), torch.float32), "descriptors": view(ptrs[3], (m, 32), torch.uint8),
+                "match_idx": view(ptrs[4], (m,), torch.int32), "match_dist": view(ptrs[5], (m,), torch.int32)}

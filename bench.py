@@ -78,6 +78,7 @@ class FrameJob:
         self.kp_buf = [torch.zeros((cap, 6), dtype=torch.float32, device=self.dev) for _ in range(2)]
         self.desc_buf = [torch.zeros((cap, 32), dtype=torch.uint8, device=self.dev) for _ in range(2)]
         self.match = None
+        self.fe = alvaar_amd.Frontend(device, W, H, NKP, 2000)   # native per-frame driver (same stages, host side in C++)
         self.maxq = 0.001
         self._det = torch.zeros((NKP, 2), dtype=torch.float32, device=self.dev)
         # prime: frame 0 pyramid + descriptors
@@ -92,6 +93,12 @@ class FrameJob:
         if n < NKP:
             self._det[n:] = self.pts[n:]
         return self._det
+
+    def step_native(self):
+        """The frame through alva_frontend_track: the same stage calls as step_overlapped(), issued from C++."""
+        self.k += 1
+        st, pose, nkp = self.fe.track(self.frames[self.k % RING], self.pts, self.bv, self.uv, self.wpt, self.K)
+        return st == 2
 
     def step_overlapped(self):
         """Same work as step(): ORB + matching run on lane B while fb-KLT + pose run on lane A (one frame, two HIP streams)."""
@@ -252,6 +259,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--python-host", action="store_true", help="headline number with the stage calls issued from Python")
     ap.add_argument("--serial", action="store_true", help="headline number on one HIP stream (no detector/tracker overlap)")
     ap.add_argument("--streams-per-gpu", type=int, default=0,
                     help="also time S concurrent independent streams on rank 0's GPU (reported under multi_stream; not part of value)")
@@ -285,7 +293,9 @@ def main():
         torch.cuda.synchronize()
         return el
 
-    dt = timed(job.step if args.serial else job.step_overlapped, args.warmup, args.steps)
+    headline = job.step if args.serial else (job.step_overlapped if args.python_host else job.step_native)
+    dt = timed(headline, args.warmup, args.steps)
+    dt_py = timed(job.step_overlapped, 3, args.steps)
     # secondary: every stage back-to-back on ONE HIP stream, and the same with the reference-actual detector
     dt_serial = timed(job.step, 3, args.steps)
     dt_grid = timed(lambda: job.step(grid_detector=True), 3, args.steps)
@@ -310,6 +320,8 @@ def main():
                        "not_in_timed_region": [],
                        "parallelism": f"{world} independent camera streams, one per GPU, no collective; within a frame the detector "
                                       "(ORB + match) and the tracker (fb-KLT + pose) run on two HIP streams" + (" [disabled: --serial]" if args.serial else "")},
+            "python_host_two_streams": {"frames_per_s": world * args.steps / dt_py, "ms_per_step": dt_py / args.steps * 1e3,
+                                        "stages": "same work and overlap, stage calls issued from Python (ctypes) instead of alva_frontend_track"},
             "one_hip_stream": {"frames_per_s": world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3,
                                "stages": "same work, every stage back-to-back on one HIP stream"},
             "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,

@@ -195,6 +195,29 @@ int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const dou
 int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
                               int *h_status);
 
+/* ---- per-frame driver: the caller of a2-a9 -------------------------------------------------------------------
+ * Mirrors the order of VisualFrontend::trackMono (src/slam/src/visual_frontend.cpp:83-150): preprocessImage (:672-698)
+ * -> kltTracking (:152-243) -> computePose (:245-417), plus the keyframe branch's feature work
+ * (MapManager::extractKeypoints, map_manager.cpp:196-231, with the detector the north_star names, and BFMatcher
+ * matching against the previous frame, map_point.cpp:106-212).  The reference runs them back to back on one CPU
+ * thread; here the detector + matcher run on a second HIP stream while the first tracks and solves the pose.  One host
+ * wait for the pose, one for the keypoint count.  All inputs are device pointers: d_rgba the frame; d_pts n_pts x 2
+ * float keypoints to track from the previous frame; d_bearings / d_uv / d_wpts n_corr 2-D/3-D correspondences for the
+ * pose (doubles, as alva_compute_pose).  *h_pose_status as alva_compute_pose. */
+typedef struct alva_frontend alva_frontend;
+int alva_frontend_create(int device, int width, int height, int max_tracked, int orb_features, alva_frontend **out);
+void alva_frontend_destroy(alva_frontend *fe);
+int alva_frontend_track(alva_frontend *fe, const uint8_t *d_rgba, size_t rgba_pitch, const float *d_pts, int n_pts,
+                        const double *d_bearings, const double *d_uv, const double *d_wpts, int n_corr, float fx,
+                        float fy, float cx, float cy, double *h_pose7, int *h_pose_status, int *h_n_keypoints);
+/* Device-resident results of the last alva_frontend_track: tracked positions (n_pts x 2) + status, ORB keypoints
+ * (n x 6) + descriptors (n x 32), matches of the n descriptors against the previous frame's.  Any may be NULL.
+ * Call alva_frontend_sync first if anything but later alva_frontend_* calls is going to read them. */
+int alva_frontend_results(alva_frontend *fe, const float **d_tracked, const uint8_t **d_track_status,
+                          const float **d_keypoints, const uint8_t **d_descriptors, const int **d_match_idx,
+                          const int **d_match_dist);
+int alva_frontend_sync(alva_frontend *fe);
+
 /* ---- a10-a13: local bundle adjustment ---------------------------------------------------------
  * Replaces the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262 on the problem
  * built at :20-247): Levenberg-Marquardt + Huber, Schur complement on the point blocks,
