@@ -65,6 +65,8 @@ _sig("alva_orb_create", [_vp, _i, _i, _i, _f, _i, _i, C.POINTER(_vp)])
 _sig("alva_orb_destroy", [_vp], None)
 _sig("alva_orb_detect_and_compute", [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp])
 _sig("alva_ctx_wait", [_vp, _vp])
+_sig("alva_prof_enable", [_i])
+_sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
 _sig("alva_frontend_create", [_i, _i, _i, _i, _i, C.POINTER(_vp)])
 _sig("alva_frontend_destroy", [_vp], None)
@@ -425,3 +427,20 @@ class Frontend:
         return {"tracked": view(ptrs[0], (n, 2), torch.float32), "status": view(ptrs[1], (n,), torch.uint8),
                 "keypoints": view(ptrs[2], (m, 6), torch.float32), "descriptors": view(ptrs[3], (m, 32), torch.uint8),
                 "match_idx": view(ptrs[4], (m,), torch.int32), "match_dist": view(ptrs[5], (m,), torch.int32)}
+
+
+def kernel_times(fn, reps: int):
+    """Run fn() reps times with per-kernel HIP-event timing on; returns {kernel: (launches, average microseconds)}."""
+    check(lib.alva_prof_enable(1))
+    try:
+        for _ in range(reps):
+            fn()
+    finally:
+        check(lib.alva_prof_enable(0))
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.alva_prof_report(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, us = line.split("\t")
+        out[name] = (int(calls), float(us))
+    return out

@@ -10,6 +10,18 @@
 
 void alva_set_error(const char *fmt, ...);
 
+// Optional per-kernel timing (alva_prof_enable / alva_prof_report): every launch of this library goes through the
+// macro below; with profiling on it is bracketed by two HIP events recorded on the launch stream.  Off = one load.
+extern int g_alva_prof_on;
+void alva_prof_mark(hipStream_t stream, const char *kernel, int end);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)            \
+    do {                                                                                             \
+        if (g_alva_prof_on) alva_prof_mark((streamId), #kernelName, 0);                              \
+        (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);         \
+        if (g_alva_prof_on) alva_prof_mark((streamId), #kernelName, 1);                              \
+    } while (0)
+
 #define ALVA_HIP(expr)                                                                         \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \

@@ -13,6 +13,97 @@ void alva_set_error(const char *fmt, ...) {
 extern "C" const char *alva_last_error(void) { return g_err; }
 extern "C" const char *alva_version(void) { return "alvaar_hip 0.1 (gfx950)"; }
 
+// ---- per-kernel event timing ---------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <string>
+int g_alva_prof_on = 0;
+namespace {
+struct ProfRec {
+    const char *name;
+    hipEvent_t e0, e1;
+};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+std::map<std::string, std::pair<long, double>> g_prof_acc;  // kernel -> (launches, total ms)
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+
+// waits for every recorded pair and folds it into the per-kernel totals (caller holds the mutex)
+void prof_drain() {
+    for (ProfRec &r: g_prof_recs) {
+        if (!r.e0 || !r.e1) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            std::string key(r.name);
+            if (!key.empty() && key.front() == '(' && key.back() == ')') key = key.substr(1, key.size() - 2);  // (k<a, b>) -> k<a, b>
+            auto &a = g_prof_acc[key];
+            a.first++;
+            a.second += ms;
+        }
+        g_prof_pool.push_back(r.e0);
+        g_prof_pool.push_back(r.e1);
+    }
+    g_prof_recs.clear();
+}
+}  // namespace
+
+void alva_prof_mark(hipStream_t stream, const char *kernel, int end) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!end) {
+        if (g_prof_recs.size() >= 8192) prof_drain();
+        ProfRec r{kernel, prof_event(), nullptr};
+        if (r.e0) (void) hipEventRecord(r.e0, stream);
+        g_prof_recs.push_back(r);
+    } else {
+        // the matching begin is the last record of this kernel name without an end (launches of one host thread nest trivially)
+        for (size_t i = g_prof_recs.size(); i-- > 0;)
+            if (g_prof_recs[i].name == kernel && !g_prof_recs[i].e1) {
+                g_prof_recs[i].e1 = prof_event();
+                if (g_prof_recs[i].e1) (void) hipEventRecord(g_prof_recs[i].e1, stream);
+                break;
+            }
+    }
+}
+
+extern "C" int alva_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on && !g_alva_prof_on) {
+        prof_drain();
+        g_prof_acc.clear();
+    }
+    g_alva_prof_on = on ? 1 : 0;
+    return ALVA_OK;
+}
+
+extern "C" int alva_prof_report(char *buf, size_t cap) {
+    ALVA_ARG(buf && cap > 0);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain();
+    std::string out;
+    char line[256];
+    for (auto &kv: g_prof_acc) {
+        snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", kv.first.c_str(), kv.second.first, kv.second.second * 1e3 / (double) kv.second.first);
+        out += line;
+    }
+    if (out.size() + 1 > cap) {
+        alva_set_error("alva_prof_report: buffer too small (%zu needed)", out.size() + 1);
+        return ALVA_ERR_ARG;
+    }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return ALVA_OK;
+}
+
 extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out) {
     ALVA_ARG(out != nullptr);
     int ndev = 0;

@@ -247,7 +247,11 @@ __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxL
                                             float fbDist, const float *__restrict__ pts, float *__restrict__ nextio,
                                             uint8_t *__restrict__ status_out, float *__restrict__ err_out, int n) {
     __shared__ LkShared sh;
-    const int kp = blockIdx.x;
+    // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Giving every XCD one CONTIGUOUS
+    // eighth of the keypoint list (callers keep keypoints in spatial / grid order) keeps an image region in one L2
+    // instead of pulling the whole pyramid through all eight.
+    const int per = gridDim.x >> 3;
+    const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (kp >= n) return;
     const float ptx = pts[2 * kp], pty = pts[2 * kp + 1];
     float nx = nextio[2 * kp], ny = nextio[2 * kp + 1];
@@ -318,7 +322,7 @@ int launch(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, in
     double epsilon = (double) eps;
     epsilon = epsilon < 0 ? 0 : (epsilon > 10 ? 10 : epsilon);
     epsilon *= epsilon;  // :1365
-    hipLaunchKernelGGL(k_klt, dim3(n), dim3(64), 0, ctx->stream, P, C, mode, maxLevel, maxCount, epsilon, err_thresh, fb_dist, d_pts,
+    hipLaunchKernelGGL(k_klt, dim3(8 * alva_divup(n, 8)), dim3(64), 0, ctx->stream, P, C, mode, maxLevel, maxCount, epsilon, err_thresh, fb_dist, d_pts,
                        d_nextio, d_status, d_err, n);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;

@@ -42,6 +42,11 @@ typedef struct alva_pyramid alva_pyramid;
 int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out);
 void alva_ctx_destroy(alva_ctx *ctx);
 int alva_ctx_sync(alva_ctx *ctx);
+/* Per-kernel timing for bench.py's roofline line: while enabled every kernel launch of the library is bracketed by two
+ * HIP events on its own stream.  alva_prof_report waits for them and writes one line per kernel,
+ * "name<TAB>launches<TAB>average microseconds", into buf.  (Measurement plumbing; no reference counterpart.) */
+int alva_prof_enable(int on);
+int alva_prof_report(char *buf, size_t cap);
 /* Stream-order dependency without a host wait: work enqueued on `ctx` after this call starts only after everything
  * enqueued so far on `producer` has completed.  (The reference is single-threaded; this is what lets one frame run
  * detection and tracking+pose on two HIP streams.) */
