@@ -13,11 +13,12 @@
 //   k_cell_eig   one workgroup per grid cell, everything in LDS: blur -> Sobel -> products -> sliding box sums
 //                (one lane per row, then one lane per column: the rounding history of the running sums is part of
 //                the result) -> lambda_min written once to HBM (4 B/px).  Algorithmic HBM traffic: read P, write 4P.
-//   k_select     the cells share one mask and are visited in row-major order in the reference; a circle reaches only
-//                the 4 already-visited neighbours, so cells on the anti-diagonal wavefront t = c + 2r are
-//                independent.  ONE workgroup walks the wavefronts with the whole mask as a bit-plane in LDS
-//                (640x480: 38 KB, 1280x720: 113 KB of the CU's 160 KB), one wave per cell: masked arg-max (first
-//                maximum), accept, clear the circle with LDS atomics, second arg-max.
+//   selection    the cells share one mask and are visited in row-major order in the reference; a circle (radius cell/4)
+//                reaches only the 4 already-visited neighbours, so the result is the fixed point of a DAG recurrence.
+//                k_cell_eig also makes every cell's speculative pick (no neighbour circles), k_round repairs the cells
+//                whose pick lies under a neighbour's circle (one wave per cell on all CUs, Jacobi rounds, one launch
+//                each), k_select finishes in one workgroup in the rare case that 4 rounds were not enough.  See the
+//                comment above SelView.
 //   k_compact    ordered compaction of primaries + secondaries, the reference's top-up rule (:117-134).
 //   k_subpix     one wave per detected corner: 9x9 bilinear patch lane-parallel, the five double accumulators
 //                replayed sequentially (one lane each) so the float result is bit-identical.
@@ -27,7 +28,8 @@
 namespace {
 
 constexpr int MAX_CELL = 40;
-constexpr int NCAND = 256;  // sorted candidates kept per cell (4 per lane of the selecting wave)
+// per-cell stride of the sorted candidate lists (uint16 entries): all n2 pixels, padded to 8, + one terminator chunk
+__host__ __device__ inline int cand_stride(int n2) { return ((n2 + 7) & ~7) + 8; }
 
 __device__ __forceinline__ int refl(int p, int len) {
     if (len == 1) return 0;
@@ -44,22 +46,47 @@ struct GridArgs {
     const float *occupied;
     int nOcc;
     float *eig;       // [nCells][cell*cell]
-    float *candVal;   // [nCells][NCAND] lambda_min of the cell's best pixels, sorted (value desc, index asc)
-    int *candIdx;     // [nCells][NCAND] their in-cell index, -1 = none
+    uint16_t *cand;   // [nCells][cand_stride] in-cell index of the cell's pixels, sorted (lambda_min desc, index asc); 0xffff
+                      // ends the list (no more pixels with a positive value)
     uint8_t *cellOcc; // [nCells] 1 = occupied (skipped and counted)
-    int *prim;        // [nCells] packed (y << 16 | x) or -1
-    int *sec;         // [nCells]
+    uint32_t *maskBits;  // static part of the reference's mask as a bit-plane [h][(w+31)/32]: 0 under the circles of the
+                         // tracked keypoints (:32-36), 1 elsewhere
+    uint8_t *needFull;   // [nCells] 1 = the speculative pick could not be made (only when maxQuality <= 0)
+    int maskInLds;       // k_select keeps a copy of maskBits in LDS (when it fits next to the per-cell arrays)
+    int *nGood;          // [nCells] length of the list prefix whose lambda_min >= maxQuality (the list is sorted)
+    int *prim;        // [2][nCells] packed (y << 16 | x) or -1: double buffer of the fixed-point rounds
+    int *sec;         // [2][nCells]
+    uint8_t *dirty;   // [2][nCells] cell has to be looked at in the round that reads this buffer
+    uint8_t *infl;    // [nCells] last evaluation met a neighbour's circle (or must be exact: needFull)
+    int *roundCnt;    // [8] number of cells changed by round k
     int hw[MAX_CELL / 4 + 1];  // filled-circle half widths
-    int dbg;
-    long long *dbgbuf;  // optional cycle counters (ALVA_DBG_SELECT=5)
 };
 
+__device__ __forceinline__ int hw_of(const GridArgs &A, int dy) { return A.hw[dy < 0 ? -dy : dy]; }
+
+// mask = ones, no cell occupied (one launch instead of two fill commands)
+__global__ void __launch_bounds__(256) k_prepare(GridArgs A) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int words = ((A.w + 31) / 32) * A.h;
+    if (i < words) A.maskBits[i] = 0xffffffffu;
+    if (i < A.nCW * A.nCH) A.cellOcc[i] = 0;
+    if (i < 8) A.roundCnt[i] = 0;
+}
+
+// one wave per tracked keypoint: mark its cell, zero its filled circle (centre = Point(cvRound(px)), :32-36)
 __global__ void __launch_bounds__(256) k_mark_occupied(GridArgs A) {
-    int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= A.nOcc) return;
-    float px = A.occupied[2 * i], py = A.occupied[2 * i + 1];
-    int cy = (int) (py / (float) A.cell), cx = (int) (px / (float) A.cell);  // occupiedCells[px.y / cellSize][px.x / cellSize] (:32)
-    if (cy >= 0 && cy < A.nCH && cx >= 0 && cx < A.nCW) A.cellOcc[cy * A.nCW + cx] = 1;
+    const float px = A.occupied[2 * i], py = A.occupied[2 * i + 1];
+    const int cy = (int) (py / (float) A.cell), cx = (int) (px / (float) A.cell);  // occupiedCells[px.y / cellSize][px.x / cellSize] (:32)
+    if (lane == 0 && cy >= 0 && cy < A.nCH && cx >= 0 && cx < A.nCW) A.cellOcc[cy * A.nCW + cx] = 1;
+    const int mx = __float2int_rn(px), my = __float2int_rn(py), R = A.radius, side = 2 * R + 1, wpr = (A.w + 31) / 32;
+    for (int k = lane; k < side * side; k += 64) {
+        const int dy = k / side - R, dx = k % side - R;
+        if ((dx < 0 ? -dx : dx) > hw_of(A, dy)) continue;
+        const int x = mx + dx, y = my + dy;
+        if (x >= 0 && x < A.w && y >= 0 && y < A.h) atomicAnd(&A.maskBits[y * wpr + (x >> 5)], ~(1u << (x & 31)));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -69,8 +96,18 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
     const int ci = blockIdx.x;
     const int r = ci / A.nCW, c = ci % A.nCW;
     const int x0 = c * cell, y0 = r * cell;
-    if (A.cellOcc[ci]) return;
-    if (!(x0 + cell < A.w - 1 && y0 + cell < A.h - 1)) return;  // feature_extractor.cpp:62
+    if (A.cellOcc[ci] || !(x0 + cell < A.w - 1 && y0 + cell < A.h - 1)) {  // feature_extractor.cpp:50-54, :62
+        if (threadIdx.x == 0) {
+            A.prim[ci] = -1;
+            A.sec[ci] = -1;
+            A.needFull[ci] = 0;
+            A.nGood[ci] = 0;
+            A.infl[ci] = 0;
+            A.dirty[ci] = 0;
+            A.dirty[A.nCW * A.nCH + ci] = 0;
+        }
+        return;
+    }
     // LDS carve
     float *sdx = reinterpret_cast<float *>(smem);
     float *sdy = sdx + n2;
@@ -178,219 +215,451 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
             }
             __syncthreads();
         }
-    if (threadIdx.x < NCAND) {
-        const int i = threadIdx.x;
-        float v = 0.f;
-        int idx = -1;
+    // the whole sorted list (index only; 0xffff from the first non-positive value on, and as terminator chunk), and the
+    // length of its prefix that passes the quality threshold (the only thing the selection needs the values for)
+    const int stride = cand_stride(n2);
+    __shared__ int s_good;
+    if (threadIdx.x == 0) s_good = 0;
+    __syncthreads();
+    int good = 0;
+    for (int i = threadIdx.x; i < stride; i += 256) {
+        uint16_t o = 0xffff;
         if (i < n2) {
             const unsigned long long key = skey[i];
             const unsigned ord = (unsigned) (key >> 32);
             const unsigned u = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
-            v = __uint_as_float(u);
-            idx = (int) (0xffffffffu - (unsigned) (key & 0xffffffffu));
+            const float v = __uint_as_float(u);
+            if (v > 0.f) o = (uint16_t) (0xffffffffu - (unsigned) (key & 0xffffffffu));
+            good += (double) v >= A.maxQuality;
         }
-        A.candVal[(size_t) ci * NCAND + i] = v;
-        A.candIdx[(size_t) ci * NCAND + i] = idx;
+        A.cand[(size_t) ci * stride + i] = o;
+    }
+    if (good) atomicAdd(&s_good, good);
+    __syncthreads();
+    if (threadIdx.x == 0) A.nGood[ci] = s_good;
+    // Speculative pick of this cell, as if no other cell had drawn a circle yet (k_select then repairs the few cells whose
+    // pick lies under a neighbour's circle): wave 0 walks the sorted list 64 entries at a time; "first free entry" is one
+    // ballot.  Pass 0 = primary; pass 1 continues behind it with the primary's own circle masked as well.
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, wpr = (A.w + 31) / 32, R = A.radius;
+        const int RX1 = A.roiX + A.roiW, RY1 = A.roiY + A.roiH;
+        int prim = -1, sec = -1, need = 0, pos = 0, own = -1;
+        for (int pass = 0; pass < 2; pass++) {
+            int fxy = -1;
+            float fv = 0.f;
+            while (pos < n2) {
+                const int i = pos + lane;
+                bool ok = false, nonpos = false;
+                float v = 0.f;
+                int xy = 0;
+                if (i < n2) {
+                    const unsigned long long key = skey[i];
+                    const unsigned ord = (unsigned) (key >> 32);
+                    v = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
+                    const int idx = (int) (0xffffffffu - (unsigned) (key & 0xffffffffu));
+                    const int x = x0 + idx % cell, y = y0 + idx / cell;
+                    xy = (y << 16) | x;
+                    nonpos = !(v > 0.f);
+                    if (!nonpos) {
+                        ok = (A.maskBits[y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+                        if (ok && own >= 0) {
+                            int dy = y - (own >> 16), dx = x - (own & 0xffff);
+                            dy = dy < 0 ? -dy : dy;
+                            dx = dx < 0 ? -dx : dx;
+                            if (dy <= R && dx <= A.hw[dy]) ok = false;
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(ok), mz = __ballot(nonpos);
+                // the list is sorted: an entry counts only if it comes before the first non-positive one
+                const int firstOk = m ? __ffsll((long long) m) - 1 : 64, firstZ = mz ? __ffsll((long long) mz) - 1 : 64;
+                if (firstOk < firstZ) {
+                    fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), firstOk));
+                    fxy = __builtin_amdgcn_readlane(xy, firstOk);
+                    pos += firstOk + 1;
+                    break;
+                }
+                if (mz) {
+                    pos = n2;  // nothing positive left
+                    break;
+                }
+                pos += 64;
+            }
+            if (fxy < 0) {
+                if (!(A.maxQuality > 0.0)) need = 1;  // the exact arg-max over non-positive values is left to k_select
+                break;
+            }
+            const int mx = fxy & 0xffff, my = fxy >> 16;
+            if (mx < A.roiX || my < A.roiY || mx >= RX1 || my >= RY1) break;
+            if (!((double) fv >= A.maxQuality)) break;
+            if (pass == 0) {
+                prim = fxy;
+                own = fxy;
+            } else {
+                sec = fxy;
+            }
+        }
+        if (lane == 0) {
+            A.prim[ci] = need ? -1 : prim;
+            A.sec[ci] = need ? -1 : sec;
+            A.needFull[ci] = (uint8_t) need;
+            A.infl[ci] = (uint8_t) need;
+            A.dirty[ci] = 1;   // round 0 looks at every cell
+            A.dirty[A.nCW * A.nCH + ci] = 0;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_select(GridArgs A) {
-    extern __shared__ uint32_t smask[];
-    // kernel arguments live in the kernarg segment: copy what the dependent loop needs into registers once, so that no
-    // scalar load (and its wait) sits on the per-wavefront critical path
-    const int IW = A.w, IH = A.h, NCW = A.nCW, NCH = A.nCH, RX0 = A.roiX, RY0 = A.roiY, RX1 = A.roiX + A.roiW, RY1 = A.roiY + A.roiH;
-    const int DBG = A.dbg, RAD = A.radius;
-    const double MAXQ = A.maxQuality;
-    const float *const EIG = A.eig;
-    const float *const CANDV = A.candVal;
-    const int *const CANDI = A.candIdx;
-    const int wordsPerRow = (IW + 31) / 32;
+// Selection.  The reference visits the cells in row-major order and every accepted point zeroes a filled circle of
+// radius cell/4 in a mask shared by all cells, so cell i sees the circles of cells j < i -- of its four already-visited
+// neighbours only, because the radius is smaller than a cell.  That is a recurrence v_i = f_i(v_j, j < i) on a DAG, and
+// its solution is the unique fixed point of "every cell re-evaluates f_i on the current values of its neighbours".
+// So instead of walking the 2r + c wavefronts one after another (133 dependent steps for 640x480 / cell 12):
+//   * k_cell_eig already made every cell's SPECULATIVE pick (no neighbour circles at all), in parallel on all CUs;
+//   * each round, one thread per cell checks whether the cell has to be re-evaluated: neighbours' circles can only
+//     REMOVE candidates, so a pick made without any candidate being rejected by a neighbour stands unless a present
+//     circle covers the primary or the secondary itself; a pick that did meet a neighbour's circle (`influenced`) is
+//     re-evaluated whenever a predecessor changed;
+//   * the (few) cells that need it are re-evaluated by one WAVE each: 64 entries of the cell's sorted candidate list
+//     (value desc, index asc = the reference's "first maximum") per step, "first free entry" = one ballot; free = not
+//     under a static circle (tracked keypoints, bit-plane), one of <= 8 neighbour circles or the own primary's;
+//   * a changed cell marks its four successors for the next round; a round without change is the fixed point, i.e.
+//     exactly the sequential result (at most longest-dependency-path + 1 rounds; 3 on the bench frames).
+struct SelView {
+    const uint32_t *smask;    // static bit-plane (LDS copy), only read when hasStatic
+    unsigned long long hwp;   // filled-circle half widths, 4 bits per |dy| (radius <= 10)
+    int wordsPerRow, cell, inv, n2, R, hasStatic;
+    int RX0, RY0, RX1, RY1;
+    double MAXQ;
+};
+
+__device__ __forceinline__ bool sel_covered(int x, int y, int cxy, const SelView &V) {
+    int dy = y - (cxy >> 16);  // cxy = -1 (no circle) gives dx far outside any radius
+    dy = dy < 0 ? -dy : dy;
+    int dx = x - (cxy & 0xffff);
+    dx = dx < 0 ? -dx : dx;
+    const int hw = (int) ((V.hwp >> (4 * min(dy, 15))) & 15ull);
+    return cxy >= 0 && dy <= V.R && dx <= hw;
+}
+
+// the <= 8 circles of the four predecessors of cell (r, c); those that cannot reach the cell are dropped (-1)
+__device__ __forceinline__ void sel_circles(const int *s_prim, const int *s_sec, int ci, int r, int c, int NCW, int cell, int R, int circ[8]) {
+    const bool up = r > 0, lf = c > 0, rt = c + 1 < NCW;
+    const int n0 = up && lf ? ci - NCW - 1 : -1, n1 = up ? ci - NCW : -1, n2i = up && rt ? ci - NCW + 1 : -1, n3 = lf ? ci - 1 : -1;
+    circ[0] = n0 >= 0 ? s_prim[n0] : -1;
+    circ[1] = n0 >= 0 ? s_sec[n0] : -1;
+    circ[2] = n1 >= 0 ? s_prim[n1] : -1;
+    circ[3] = n1 >= 0 ? s_sec[n1] : -1;
+    circ[4] = n2i >= 0 ? s_prim[n2i] : -1;
+    circ[5] = n2i >= 0 ? s_sec[n2i] : -1;
+    circ[6] = n3 >= 0 ? s_prim[n3] : -1;
+    circ[7] = n3 >= 0 ? s_sec[n3] : -1;
+    const int x0 = c * cell, y0 = r * cell;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int cx = circ[q] & 0xffff, cy = circ[q] >> 16;
+        if (circ[q] >= 0 && (cx + R < x0 || cx - R >= x0 + cell || cy + R < y0 || cy - R >= y0 + cell)) circ[q] = -1;
+    }
+}
+
+// f_i by one wave: (primary, secondary) of one cell given its predecessors' circles.  `pre` = entries 0..63 of the cell's
+// sorted list (prefetched), influenced = some candidate was rejected by a neighbour's circle.  All results wave-uniform.
+__device__ void sel_eval_wave(const SelView &V, int x0, int y0, unsigned pre0, unsigned pre1, const uint16_t *cand, int stride, int nGood,
+                              const float *eig, const int circ[8], int &prim, int &sec, int &influenced) {
+    const int lane = threadIdx.x & 63;
+    prim = -1;
+    sec = -1;
+    influenced = 0;
+    int own = -1, pos = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int fxy = -1, fpos = 0;
+        while (pos < stride) {
+            // the 64-entry chunk that contains pos (chunks 0 and 1 were prefetched); entries before pos are already consumed
+            const int base = pos & ~63, i = base + lane;
+            unsigned idx = 0xffffu;
+            if (i < stride) idx = base == 0 ? pre0 : (base == 64 ? pre1 : (unsigned) cand[i]);
+            const bool live = i >= pos;
+            const bool end = live && idx == 0xffffu;
+            bool ok = false, byNb = false;
+            int xy = 0;
+            if (live && !end) {
+                const int dyc = (int) ((idx * (unsigned) V.inv) >> 16), dxc = (int) idx - dyc * V.cell;
+                const int x = x0 + dxc, y = y0 + dyc;
+                xy = (y << 16) | x;
+                ok = !sel_covered(x, y, own, V);
+                if (ok) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (circ[q] >= 0) byNb = byNb || sel_covered(x, y, circ[q], V);
+                    ok = !byNb;
+                    if (ok && V.hasStatic) ok = (V.smask[y * V.wordsPerRow + (x >> 5)] >> (x & 31)) & 1u;
+                }
+            }
+            const unsigned long long m = __ballot(ok), me = __ballot(end), mn = __ballot(byNb);
+            const int firstOk = m ? __ffsll((long long) m) - 1 : 64, firstEnd = me ? __ffsll((long long) me) - 1 : 64;
+            const int upto = min(firstOk, firstEnd);  // entries actually examined by the sequential scan
+            if (mn & (upto >= 64 ? ~0ull : ((1ull << upto) - 1ull))) influenced = 1;
+            if (firstOk < firstEnd) {
+                fxy = __builtin_amdgcn_readlane(xy, firstOk);
+                fpos = base + firstOk;
+                pos = fpos + 1;  // entries before it stay masked in the second pass, this one by its own circle
+                break;
+            }
+            if (me) {
+                pos = stride;  // nothing positive left
+                break;
+            }
+            pos = base + 64;
+        }
+        bool accept;
+        if (fxy >= 0) {
+            accept = fpos < nGood;  // lambda_min >= maxQuality: the sorted list's first nGood entries
+        } else {
+            // No free pixel with a positive value: the masked arg-max is <= 0.  With a positive quality threshold (always, in
+            // the reference: maxQuality_ starts at 0.001 and only halves) nothing can be accepted, whatever the ROI test says.
+            if (V.MAXQ > 0.0) break;
+            // general case: exact scan of eig * mask, first maximum (minMaxLoc)
+            float best = -3.402823466e+38f;
+            int bi = 0x7fffffff;
+            for (int q = lane; q < V.n2; q += 64) {
+                const int dyc = (int) (((unsigned) q * (unsigned) V.inv) >> 16), dxc = q - dyc * V.cell;
+                const int x = x0 + dxc, y = y0 + dyc;
+                bool fr = !sel_covered(x, y, own, V);
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    if (circ[t] >= 0) fr = fr && !sel_covered(x, y, circ[t], V);
+                if (fr && V.hasStatic) fr = (V.smask[y * V.wordsPerRow + (x >> 5)] >> (x & 31)) & 1u;
+                const float v = eig[q] * (fr ? 1.f : 0.f);
+                if (v > best) {
+                    best = v;
+                    bi = q;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ob > best || (ob == best && oi < bi)) {
+                    best = ob;
+                    bi = oi;
+                }
+            }
+            if (bi == 0x7fffffff) bi = 0;  // nothing exceeded -FLT_MAX: minMaxLoc reports index 0
+            const int dyc = (int) (((unsigned) bi * (unsigned) V.inv) >> 16), dxc = bi - dyc * V.cell;
+            fxy = ((y0 + dyc) << 16) | (x0 + dxc);
+            influenced = 1;  // exact path: always re-evaluate when a predecessor changes
+            accept = (double) best >= V.MAXQ;
+        }
+        const int mx = fxy & 0xffff, my = fxy >> 16;
+        if (mx < V.RX0 || my < V.RY0 || mx >= V.RX1 || my >= V.RY1) break;  // `continue` of the cell loop (:76-79, :90-93)
+        if (!accept) break;  // no circle drawn: the second arg-max finds the same pixel and rejects it too
+        if (pass == 0) {
+            prim = fxy;
+            own = fxy;
+        } else {
+            sec = fxy;
+        }
+    }
+}
+
+// One Jacobi round on all CUs: one wave per cell, reads buffer `src`, writes buffer `src ^ 1`.
+__global__ void __launch_bounds__(256) k_round(GridArgs A, int src, int round) {
+    const int NCW = A.nCW, NCH = A.nCH, nCells = NCW * NCH, cell = A.cell, RAD = A.radius;
+    const int lane = threadIdx.x & 63, ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= nCells) return;
+    const int dst = src ^ 1;
+    const int *Ps = A.prim + (size_t) src * nCells, *Ss = A.sec + (size_t) src * nCells;
+    uint8_t *dS = A.dirty + (size_t) src * nCells, *dD = A.dirty + (size_t) dst * nCells;
+    const int p0 = Ps[ci], q0 = Ss[ci];
+    int p = p0, q = q0;
+    if (dS[ci]) {  // wave-uniform
+        const int r = ci / NCW, c = ci - r * NCW;
+        SelView V;
+        V.smask = A.maskBits;
+        unsigned long long hwp = 0;
+        for (int d = 0; d <= RAD; d++) hwp |= (unsigned long long) (A.hw[d] & 15) << (4 * d);
+        V.hwp = hwp;
+        V.wordsPerRow = (A.w + 31) / 32;
+        V.cell = cell;
+        V.inv = (65536 + cell - 1) / cell;
+        V.n2 = cell * cell;
+        V.R = RAD;
+        V.hasStatic = A.nOcc > 0;
+        V.RX0 = A.roiX;
+        V.RY0 = A.roiY;
+        V.RX1 = A.roiX + A.roiW;
+        V.RY1 = A.roiY + A.roiH;
+        V.MAXQ = A.maxQuality;
+        int circ[8];
+        sel_circles(Ps, Ss, ci, r, c, NCW, cell, RAD, circ);
+        bool need = A.infl[ci];
+        if (!need) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                if (p0 >= 0) need = need || sel_covered(p0 & 0xffff, p0 >> 16, circ[t], V);
+                if (q0 >= 0) need = need || sel_covered(q0 & 0xffff, q0 >> 16, circ[t], V);
+            }
+        }
+        if (need) {
+            const int cstride = cand_stride(V.n2);
+            const uint16_t *l = A.cand + (size_t) ci * cstride;
+            const unsigned pre0 = lane < cstride ? (unsigned) l[lane] : 0xffffu;
+            const unsigned pre1 = 64 + lane < cstride ? (unsigned) l[64 + lane] : 0xffffu;
+            int infl;
+            sel_eval_wave(V, c * cell, r * cell, pre0, pre1, l, cstride, A.nGood[ci], A.eig + (size_t) ci * V.n2, circ, p, q, infl);
+            if (lane == 0) A.infl[ci] = (uint8_t) (infl | A.needFull[ci]);
+        }
+        if (lane == 0) {
+            dS[ci] = 0;  // this buffer is the next round's destination: leave it clean
+            if (p != p0 || q != q0) {
+                atomicAdd(&A.roundCnt[round], 1);
+                // successors in visiting order: right, below-left, below, below-right (cells that do not take part ignore it)
+                if (c + 1 < NCW) dD[ci + 1] = 1;
+                if (r + 1 < NCH) {
+                    if (c > 0) dD[ci + NCW - 1] = 1;
+                    dD[ci + NCW] = 1;
+                    if (c + 1 < NCW) dD[ci + NCW + 1] = 1;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        A.prim[(size_t) dst * nCells + ci] = p;
+        A.sec[(size_t) dst * nCells + ci] = q;
+    }
+}
+
+// Finishes the iteration in ONE workgroup (Gauss-Seidel order, no launch per round) when the Jacobi rounds above did not
+// reach the fixed point yet; returns at once when the last of them changed nothing.
+__global__ void __launch_bounds__(1024) k_select(GridArgs A, int buf, int lastRound) {
+    extern __shared__ int s_prim[];
+    if (A.roundCnt[lastRound] == 0) return;  // the last Jacobi round changed nothing: buffer `buf` is the fixed point
+    const int IW = A.w, IH = A.h, NCW = A.nCW, NCH = A.nCH, nCells = NCW * NCH;
+    const int cell = A.cell, n2 = cell * cell, RAD = A.radius;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = 16;
-    const int cell = A.cell, n2 = cell * cell, side = 2 * RAD + 1;
-    uint8_t *s_occ = reinterpret_cast<uint8_t *>(smask + wordsPerRow * IH);   // per-cell occupied flags
-    uint16_t *s_xy = reinterpret_cast<uint16_t *>(s_occ + ((NCW * NCH + 15) & ~15));  // in-cell index -> (dy << 8) | dx
-    uint16_t *s_circ = s_xy + ((n2 + 7) & ~7);  // filled-circle pixels: ((dy + 128) << 8) | (dx + 128), 0xffff = outside
-    // results stay in LDS until the end: on CDNA4 vmcnt also counts stores, so a global store per step would sit on the
-    // critical path of the next step's candidate-load wait
-    int *s_prim = reinterpret_cast<int *>(s_circ + ((side * side + 7) & ~7));
-    int *s_sec = s_prim + NCW * NCH;
-    for (int i = threadIdx.x; i < NCW * NCH; i += 1024) {
-        s_prim[i] = -1;
-        s_sec[i] = -1;
+    const int pad = (nCells + 15) & ~15;
+    int *s_sec = s_prim + nCells;
+    int *s_list = s_sec + nCells;                                    // cells to re-evaluate this round
+    uint8_t *s_use = reinterpret_cast<uint8_t *>(s_list + nCells);   // cell takes part (not occupied, not at the border)
+    uint8_t *s_dirty0 = s_use + pad;
+    uint8_t *s_dirty1 = s_dirty0 + pad;
+    uint8_t *s_infl = s_dirty1 + pad;   // last evaluation met a neighbour's circle (or must be exact: needFull)
+    uint8_t *s_need = s_infl + pad;
+    int *s_good = reinterpret_cast<int *>(s_need + pad);
+    uint32_t *smask = reinterpret_cast<uint32_t *>(s_good + nCells);  // static bit-plane, only when there are tracked keypoints
+    __shared__ int s_flag[2], s_n;
+    const int hasStatic = A.nOcc > 0;
+    const int wordsPerRow = (IW + 31) / 32;
+    for (int i = threadIdx.x; i < nCells; i += 1024) {
+        s_need[i] = A.needFull[i];
+        s_infl[i] = A.infl[i];
+        s_good[i] = A.nGood[i];
+        s_prim[i] = A.prim[(size_t) buf * nCells + i];
+        s_sec[i] = A.sec[(size_t) buf * nCells + i];
+        const int r = i / NCW, c = i - r * NCW;
+        const bool use = !A.cellOcc[i] && (c * cell + cell < IW - 1 && r * cell + cell < IH - 1);  // :50-54, :62
+        s_use[i] = use;
+        s_dirty0[i] = use && A.dirty[(size_t) buf * nCells + i];
+        s_dirty1[i] = 0;
     }
-    for (int i = threadIdx.x; i < wordsPerRow * IH; i += 1024) smask[i] = 0xffffffffu;
-    for (int i = threadIdx.x; i < NCW * NCH; i += 1024) s_occ[i] = A.cellOcc[i];
-    for (int i = threadIdx.x; i < n2; i += 1024) s_xy[i] = (uint16_t) (((i / cell) << 8) | (i % cell));
-    for (int i = threadIdx.x; i < side * side; i += 1024) {
-        const int dy = i / side - RAD, dx = i % side - RAD;
-        const int half = A.hw[dy < 0 ? -dy : dy];
-        s_circ[i] = (dx < 0 ? -dx : dx) <= half ? (uint16_t) (((dy + 128) << 8) | (dx + 128)) : (uint16_t) 0xffff;
-    }
+    if (hasStatic && A.maskInLds)
+        for (int i = threadIdx.x; i < wordsPerRow * IH; i += 1024) smask[i] = A.maskBits[i];
+    unsigned long long hwp = 0;
+    for (int d = 0; d <= RAD; d++) hwp |= (unsigned long long) (A.hw[d] & 15) << (4 * d);
+    if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const unsigned circ0 = lane < side * side ? s_circ[lane] : 0xffffu;  // this lane's circle pixel (radius <= 3: all of them)
-    auto clear = [&](int cx, int cy) {
-        for (int i = lane; i < side * side; i += 64) {
-            const unsigned e = i == lane ? circ0 : s_circ[i];
-            if (e == 0xffffu) continue;
-            const int x = cx + (int) (e & 255u) - 128, y = cy + (int) (e >> 8) - 128;
-            if (x >= 0 && x < IW && y >= 0 && y < IH) atomicAnd(&smask[y * wordsPerRow + (x >> 5)], ~(1u << (x & 31)));
-        }
-    };
-    // pre-zero circles of the occupied keypoints, centre = Point(cvRound(px)) (:32-36)
-    for (int k = wave; k < A.nOcc; k += nwaves) clear(__float2int_rn(A.occupied[2 * k]), __float2int_rn(A.occupied[2 * k + 1]));
-    __syncthreads();
-    const int T = (NCW - 1) + 2 * (NCH - 1);
-    // Each wave's cells are known in advance (cell (r, c) on wavefront t = c + 2r, r = rmin + wave + 16 k).  The sorted
-    // candidate list of the NEXT wavefront's cell (4 per lane) is requested from HBM/L2 at the START of a step and first
-    // touched after the barrier that ends it, so the load latency hides behind the current cell + the barrier; inside
-    // the dependent section a pass is: one LDS mask bit per candidate, one ballot, one circle of LDS atomics.
-    constexpr int SLOTS = 3;  // cells per wave per wavefront whose candidates are prefetched (16 waves x 3 = 48 cells)
-    float cv[SLOTS][4], nv[SLOTS][4];
-    int ck[SLOTS][4], nk[SLOTS][4];
-    auto cell_of = [&](int t, int slot, int &r, int &c) -> bool {
-        const int rmin = max(0, (t - (NCW - 1) + 1) / 2), rmax = min(NCH - 1, t / 2);
-        r = rmin + wave + slot * nwaves;
-        c = t - 2 * r;
-        return r <= rmax && c >= 0 && c < NCW;
-    };
-    auto usable = [&](int r, int c) -> bool {
-        const int ci = r * NCW + c;
-        return !s_occ[ci] && (c * cell + cell < IW - 1 && r * cell + cell < IH - 1);
-    };
-#define ALVA_LOAD_CANDS(V, K, r, c)                                                   \
-    do {                                                                              \
-        const size_t base_ = (size_t) ((r) * NCW + (c)) * NCAND;                     \
-        _Pragma("unroll") for (int q = 0; q < 4; q++) {                               \
-            K[q] = CANDI[base_ + lane + 64 * q];                                  \
-            V[q] = CANDV[base_ + lane + 64 * q];                                  \
-        }                                                                             \
-    } while (0)
-    {
-        int r, c;
+    SelView V;
+    V.smask = A.maskInLds ? smask : A.maskBits;
+    V.hwp = hwp;
+    V.wordsPerRow = wordsPerRow;
+    V.cell = cell;
+    V.inv = (65536 + cell - 1) / cell;   // idx / cell == (idx * inv) >> 16 for idx < cell^2 <= 1600 (checked exhaustively)
+    V.n2 = n2;
+    V.R = RAD;
+    V.hasStatic = hasStatic;
+    V.RX0 = A.roiX;
+    V.RY0 = A.roiY;
+    V.RX1 = A.roiX + A.roiW;
+    V.RY1 = A.roiY + A.roiH;
+    V.MAXQ = A.maxQuality;
+    const int cstride = cand_stride(n2);
+    const int maxRounds = NCW + 2 * NCH + 4;  // longest dependency path (the 2r + c wavefront count) + slack
+    uint8_t *dcur = s_dirty0, *dnext = s_dirty1;
+    for (int round = 0; round < maxRounds; round++) {
+        // ---- A: one thread per marked cell decides whether it has to be re-evaluated --------------------------------------
+        for (int ci = threadIdx.x; ci < nCells; ci += 1024) {
+            if (!dcur[ci]) continue;
+            dcur[ci] = 0;
+            bool need = s_infl[ci];
+            if (!need) {
+                const int r = ci / NCW, c = ci - r * NCW;
+                int circ[8];
+                sel_circles(s_prim, s_sec, ci, r, c, NCW, cell, RAD, circ);
+                const int p0 = s_prim[ci], q0 = s_sec[ci];
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; sl++)
-            if (cell_of(0, sl, r, c) && usable(r, c)) ALVA_LOAD_CANDS(cv[sl], ck[sl], r, c);
-    }
-    long long c_pre = 0, c_work = 0, c_bar = 0, c_rot = 0, c0 = 0, c1 = 0;
-    for (int t = 0; t <= T; t++) {
-        if (DBG == 5) c0 = wall_clock64();
-        {
-            int r, c;
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; sl++)
-                if (t < T && cell_of(t + 1, sl, r, c) && usable(r, c)) ALVA_LOAD_CANDS(nv[sl], nk[sl], r, c);
-        }
-        if (DBG == 5) { c1 = wall_clock64(); c_pre += c1 - c0; c0 = c1; }
-#pragma unroll
-        for (int slot = 0; slot < SLOTS + 1; slot++) {
-          // slots 0..SLOTS-1 use prefetched registers; slot SLOTS loops over any remaining cells with late fetches
-          for (int sl2 = slot;; sl2 += 1) {
-            int r, c;
-            if (!cell_of(t, sl2, r, c)) break;
-            float (&CV)[4] = cv[slot < SLOTS ? slot : 0];
-            int (&CK)[4] = ck[slot < SLOTS ? slot : 0];
-            const int ci = r * NCW + c;
-            int prim = -1, sec = -1;
-            const int x0 = c * cell, y0 = r * cell;
-            if (usable(r, c) && DBG != 1) {
-                if (slot >= SLOTS) ALVA_LOAD_CANDS(CV, CK, r, c);  // more than 48 cells on this wavefront: fetch late
-                // absolute pixel of each candidate (one batch of independent LDS reads per cell, not per pass)
-                int cxy[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned e = CK[q] >= 0 ? s_xy[CK[q]] : 0u;
-                    cxy[q] = ((y0 + (int) (e >> 8)) << 16) | (x0 + (int) (e & 255u));
-                }
-                for (int pass = 0; pass < (DBG == 2 ? 1 : 2); pass++) {
-                    // first unmasked candidate with a positive value, in sorted order = the reference's masked arg-max
-                    float best = 0.f;
-                    int bi = -1, bxy = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (bi >= 0) break;
-                        bool hit = false;
-                        if (CK[q] >= 0 && CV[q] > 0.f) {
-                            const int x = cxy[q] & 0xffff, y = cxy[q] >> 16;
-                            hit = DBG == 4 ? true : (bool) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
-                        }
-                        const unsigned long long m = __ballot(hit);
-                        if (m) {
-                            const int src = __ffsll((long long) m) - 1;  // wave-uniform -> v_readlane, no LDS crossbar
-                            best = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(CV[q]), src));
-                            bi = __builtin_amdgcn_readlane(CK[q], src);
-                            bxy = __builtin_amdgcn_readlane(cxy[q], src);
-                        }
-                    }
-                    if (bi < 0) {
-                        // rare: every listed candidate is masked (or <= 0): exact full scan of eig * mask, first maximum
-                        const float *eig = EIG + (size_t) ci * n2;
-                        best = -3.402823466e+38f;
-                        bi = 0x7fffffff;
-                        for (int k = lane; k < n2; k += 64) {
-                            const unsigned e = s_xy[k];
-                            const int x = x0 + (int) (e & 255u), y = y0 + (int) (e >> 8);
-                            const float m = (float) ((smask[y * wordsPerRow + (x >> 5)] >> (x & 31)) & 1u);
-                            const float v = eig[k] * m;
-                            if (v > best) {
-                                best = v;
-                                bi = k;
-                            }
-                        }
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const float ob = __shfl_down(best, off);
-                            const int oi = __shfl_down(bi, off);
-                            if (ob > best || (ob == best && oi < bi)) {
-                                best = ob;
-                                bi = oi;
-                            }
-                        }
-                        best = __shfl(best, 0);
-                        bi = __shfl(bi, 0);
-                        if (bi == 0x7fffffff) bi = 0;  // nothing exceeded -FLT_MAX: minMaxLoc reports index 0
-                        const unsigned eb = s_xy[bi];
-                        bxy = ((y0 + (int) (eb >> 8)) << 16) | (x0 + (int) (eb & 255u));
-                    }
-                    const int mx = bxy & 0xffff, my = bxy >> 16;
-                    if (mx < RX0 || my < RY0 || mx >= RX1 || my >= RY1) break;  // `continue` of the cell loop
-                    if ((double) best >= MAXQ) {
-                        if (pass == 0) prim = (my << 16) | mx;
-                        else sec = (my << 16) | mx;
-                        if (DBG != 3) clear(mx, my);
-                    }
+                for (int q = 0; q < 8; q++) {
+                    if (p0 >= 0) need = need || sel_covered(p0 & 0xffff, p0 >> 16, circ[q], V);
+                    if (q0 >= 0) need = need || sel_covered(q0 & 0xffff, q0 >> 16, circ[q], V);
                 }
             }
-            if (lane == 0) {
-                s_prim[ci] = prim;
-                s_sec[ci] = sec;
-            }
-            if (slot < SLOTS) break;  // prefetched slots handle exactly one cell each
-          }
+            if (need) s_list[atomicAdd(&s_n, 1)] = ci;
         }
-        if (DBG == 5) { c1 = wall_clock64(); c_work += c1 - c0; c0 = c1; }
         __syncthreads();
-        if (DBG == 5) { c1 = wall_clock64(); c_bar += c1 - c0; c0 = c1; }
-#pragma unroll
-        for (int sl = 0; sl < SLOTS; sl++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                cv[sl][q] = nv[sl][q];
-                ck[sl][q] = nk[sl][q];
+        // ---- B: one wave per listed cell ----------------------------------------------------------------------------
+        const int nList = s_n;
+        int changed = 0;
+        unsigned pre0 = 0xffffu, pre1 = 0xffffu;
+        auto fetch = [&](int cell_index) {
+            const uint16_t *l = A.cand + (size_t) cell_index * cstride;
+            pre0 = lane < cstride ? (unsigned) l[lane] : 0xffffu;
+            pre1 = 64 + lane < cstride ? (unsigned) l[64 + lane] : 0xffffu;
+        };
+        if (wave < nList) fetch(s_list[wave]);
+        for (int e = wave; e < nList; e += nwaves) {
+            const int ci = s_list[e];
+            const unsigned cur0 = pre0, cur1 = pre1;
+            if (e + nwaves < nList) fetch(s_list[e + nwaves]);  // next cell's first 128 entries, in flight during this cell
+            const int r = ci / NCW, c = ci - r * NCW;
+            int circ[8];
+            sel_circles(s_prim, s_sec, ci, r, c, NCW, cell, RAD, circ);
+            int prim, sec, infl;
+            sel_eval_wave(V, c * cell, r * cell, cur0, cur1, A.cand + (size_t) ci * cstride, cstride, s_good[ci], A.eig + (size_t) ci * n2, circ, prim,
+                          sec, infl);
+            if (lane == 0) {
+                s_infl[ci] = (uint8_t) (infl | s_need[ci]);
+                if (prim != s_prim[ci] || sec != s_sec[ci]) {
+                    s_prim[ci] = prim;
+                    s_sec[ci] = sec;
+                    changed = 1;
+                    // successors in visiting order: right, below-left, below, below-right
+                    if (c + 1 < NCW && s_use[ci + 1]) dnext[ci + 1] = 1;
+                    if (r + 1 < NCH) {
+                        if (c > 0 && s_use[ci + NCW - 1]) dnext[ci + NCW - 1] = 1;
+                        if (s_use[ci + NCW]) dnext[ci + NCW] = 1;
+                        if (c + 1 < NCW && s_use[ci + NCW + 1]) dnext[ci + NCW + 1] = 1;
+                    }
+                }
             }
-        if (DBG == 5) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = wall_clock64(); c_rot += c1 - c0; }
+        }
+        if (changed) s_flag[round & 1] = 1;
+        __syncthreads();
+        const int any = s_flag[round & 1];
+        if (threadIdx.x == 0) {
+            s_flag[(round + 1) & 1] = 0;
+            s_n = 0;
+        }
+        if (!any) break;
+        uint8_t *t = dcur;
+        dcur = dnext;
+        dnext = t;
+        __syncthreads();
     }
-    if (DBG == 5 && A.dbgbuf && lane == 0) {
-        A.dbgbuf[4 * wave + 0] = c_pre;
-        A.dbgbuf[4 * wave + 1] = c_work;
-        A.dbgbuf[4 * wave + 2] = c_bar;
-        A.dbgbuf[4 * wave + 3] = c_rot;
+    for (int i = threadIdx.x; i < nCells; i += 1024) {
+        A.prim[(size_t) buf * nCells + i] = s_prim[i];
+        A.sec[(size_t) buf * nCells + i] = s_sec[i];
     }
-    for (int i = threadIdx.x; i < NCW * NCH; i += 1024) {
-        A.prim[i] = s_prim[i];
-        A.sec[i] = s_sec[i];
-    }
-#undef ALVA_LOAD_CANDS
 }
 
 struct CompactOut {
@@ -644,46 +913,58 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     A.occupied = d_occupied;
     A.nOcc = n_occ;
     circle_halfwidths(A.radius, A.hw);
-    A.dbg = getenv("ALVA_DBG_SELECT") ? atoi(getenv("ALVA_DBG_SELECT")) : 0;
-    A.dbgbuf = nullptr;
-    if (A.dbg == 5) {
-        static long long *dbg_dev = nullptr;
-        if (!dbg_dev) (void) hipMalloc((void **) &dbg_dev, 64 * 8);
-        A.dbgbuf = dbg_dev;
-    }
     const int nCells = A.nCW * A.nCH, n2 = cell_size * cell_size;
     if (nCells == 0) return ALVA_OK;
-    size_t off_occ = (size_t) nCells * n2 * 4, off_prim = (off_occ + nCells + 63) / 64 * 64, off_sec = off_prim + (size_t) nCells * 4,
-           off_cv = (off_sec + (size_t) nCells * 4 + 63) / 64 * 64, off_ci = off_cv + (size_t) nCells * NCAND * 4,
-           off_out = off_ci + (size_t) nCells * NCAND * 4;
+    size_t off_occ = (size_t) nCells * n2 * 4, off_prim = (off_occ + nCells + 63) / 64 * 64, off_sec = off_prim + (size_t) nCells * 8,
+           off_cv = (off_sec + (size_t) nCells * 8 + 63) / 64 * 64, off_out = (off_cv + (size_t) nCells * cand_stride(n2) * 2 + 63) / 64 * 64;
     uint8_t *base = nullptr;
-    int rc = alva_ctx_scratch(ctx, 5, off_out + 64, (void **) &base);
+    const size_t off_mask = off_out + 64, off_need = off_mask + (size_t) ((width + 31) / 32) * height * 4;
+    const size_t off_good = (off_need + (size_t) nCells + 63) / 64 * 64;
+    const size_t off_dirty = off_good + (size_t) nCells * 4, off_infl = off_dirty + 2 * (size_t) nCells;
+    const size_t off_rc = (off_infl + (size_t) nCells + 63) / 64 * 64;
+    int rc = alva_ctx_scratch(ctx, 5, off_rc + 64, (void **) &base);
     if (rc) return rc;
     A.eig = (float *) base;
     A.cellOcc = base + off_occ;
     A.prim = (int *) (base + off_prim);
     A.sec = (int *) (base + off_sec);
-    A.candVal = (float *) (base + off_cv);
-    A.candIdx = (int *) (base + off_ci);
+    A.cand = (uint16_t *) (base + off_cv);
+    A.maskBits = (uint32_t *) (base + off_mask);
+    A.needFull = base + off_need;
+    A.nGood = (int *) (base + off_good);
+    A.dirty = base + off_dirty;
+    A.infl = base + off_infl;
+    A.roundCnt = (int *) (base + off_rc);
     CompactOut *d_cnt = (CompactOut *) (base + off_out);
     hipStream_t st = ctx->stream;
-    ALVA_HIP(hipMemsetAsync(A.cellOcc, 0, (size_t) nCells, st));
-    if (n_occ > 0) hipLaunchKernelGGL(k_mark_occupied, dim3(alva_divup(n_occ, 256)), dim3(256), 0, st, A);
+    const int maskWords = ((width + 31) / 32) * height;
+    hipLaunchKernelGGL(k_prepare, dim3(alva_divup(std::max(maskWords, nCells), 256)), dim3(256), 0, st, A);
+    if (n_occ > 0) hipLaunchKernelGGL(k_mark_occupied, dim3(alva_divup(n_occ, 4)), dim3(256), 0, st, A);
     int np2 = 256;
     while (np2 < n2) np2 <<= 1;
     const size_t lds_eig = (size_t) n2 * (4 + 4 + 8 + 12 + 1) + (size_t) (cell_size + 2) * (cell_size + 2) + 32 + (size_t) np2 * 8;
     ALVA_ARG(lds_eig <= 64 * 1024);
     hipLaunchKernelGGL(k_cell_eig, dim3(nCells), dim3(256), lds_eig, st, A);
-    const int side = 2 * A.radius + 1;
-    const size_t lds_mask = (size_t) ((width + 31) / 32) * height * 4 + (size_t) nCells + 16 + (size_t) (n2 + 8) * 2 + (size_t) (side * side + 8) * 2 + (size_t) nCells * 8 + 64;
-    ALVA_ARG(lds_mask <= 160 * 1024 - 1024);
-    if (lds_mask > 48 * 1024)
+    size_t lds_sel = (size_t) nCells * 16 + 5 * (size_t) ((nCells + 15) & ~15) + 64;
+    ALVA_ARG(lds_sel <= 160 * 1024 - 1024);
+    const size_t mask_bytes = (size_t) ((width + 31) / 32) * height * 4;
+    A.maskInLds = n_occ > 0 && lds_sel + mask_bytes <= 160 * 1024 - 1024;
+    if (A.maskInLds) lds_sel += mask_bytes;
+    if (lds_sel > 48 * 1024)
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_mask, st, A);
+    // fixed-point rounds: K on all CUs (3 reach the fixed point on typical frames, the 4th confirms it), the rest -- if any --
+    // in one workgroup without further launches
+    constexpr int K_ROUNDS = 4;
+    for (int k = 0; k < K_ROUNDS; k++) hipLaunchKernelGGL(k_round, dim3(alva_divup(nCells, 4)), dim3(256), 0, st, A, k & 1, k);
+    const int fin = K_ROUNDS & 1;
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_sel, st, A, fin, K_ROUNDS - 1);
     CompactOut *h_cnt = nullptr;
     rc = alva_ctx_pinned(ctx, sizeof(CompactOut), (void **) &h_cnt);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, A, d_out_pts, cap, d_cnt, h_cnt);
+    GridArgs AF = A;  // the final buffer
+    AF.prim = A.prim + (size_t) fin * nCells;
+    AF.sec = A.sec + (size_t) fin * nCells;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, AF, d_out_pts, cap, d_cnt, h_cnt);
     ALVA_LAUNCH_CHECK();
     // one wave per candidate slot; the kernel reads the actual count from device memory (no host round trip before it)
     const int maxPts = std::min(cap, 2 * nCells);
@@ -691,14 +972,6 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     ALVA_LAUNCH_CHECK();
     ALVA_HIP(hipStreamSynchronize(st));
     const CompactOut res = *h_cnt;
-    if (A.dbg == 5 && A.dbgbuf) {
-        long long hb[64];
-        (void) hipMemcpy(hb, A.dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
-        static int once = 0;
-        if (once++ == 3)
-            for (int wv = 0; wv < 16; wv++)
-                fprintf(stderr, "[select dbg] wave %2d: prefetch %lld work %lld barrier %lld rotate %lld (100 MHz ticks)\n", wv, hb[4 * wv], hb[4 * wv + 1], hb[4 * wv + 2], hb[4 * wv + 3]);
-    }
     *h_count = res.n_total;
     // adaptive threshold (:138-145)
     const double freeCells = (double) ((size_t) nCells - (size_t) res.n_occupied);
