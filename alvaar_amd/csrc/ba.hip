@@ -27,6 +27,8 @@
 //   k_point<cost only> on the candidate; the host reads three scalars and applies Ceres' accept/reject logic.
 #include "common.hpp"
 #include "lm_device.hpp"
+#include <chrono>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -47,6 +49,8 @@ struct BaDev {
     const int *ancKf;       // [nPt]
     const double *ancUv;    // [nPt][2]
     const int *cidx;        // [nKf] free index or -1
+    double *rowcol;         // [2][nKf][27] row / column sums of M
+    const int *kfOf;        // [nc] free camera index -> keyframe id
     const int *pairPerm;    // [nObs] observation ids grouped by pair key
     const int *pairPtr;     // [nKf*nKf+1]
     // work
@@ -195,13 +199,16 @@ __global__ void __launch_bounds__(256) k_point(BaDev B, const double *__restrict
 
 // One wave per (observing kf, anchor kf) pair: sums of J_obs'J_obs (21) and J_obs' r (6).
 __global__ void __launch_bounds__(256) k_pairs(BaDev B) {
-    const int lane = threadIdx.x & 63;
-    const int key = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (key >= B.nKf * B.nKf) return;
-    double acc[27];
+    // one WORKGROUP per (observing kf, anchor kf) pair: the big pairs (thousands of observations) set the kernel time, so
+    // their observations are spread over 256 lanes; lane partials -> butterfly reduce-scatter per wave -> 4 waves in LDS
+    // (fixed order: bit-reproducible)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int key = blockIdx.x;
+    __shared__ double s_part[4][28];
+    double v[32];
 #pragma unroll
-    for (int i = 0; i < 27; i++) acc[i] = 0;
-    for (int q = B.pairPtr[key] + lane; q < B.pairPtr[key + 1]; q += 64) {
+    for (int i = 0; i < 32; i++) v[i] = 0;
+    for (int q = B.pairPtr[key] + threadIdx.x; q < B.pairPtr[key + 1]; q += 256) {
         const int o = B.pairPerm[q];
         double J[12];
 #pragma unroll
@@ -210,16 +217,26 @@ __global__ void __launch_bounds__(256) k_pairs(BaDev B) {
         int t = 0;
 #pragma unroll
         for (int x = 0; x < 6; x++) {
-            acc[21 + x] += J[x] * r0 + J[6 + x] * r1;
+            v[21 + x] += J[x] * r0 + J[6 + x] * r1;
 #pragma unroll
-            for (int y = x; y < 6; y++) acc[t++] += J[x] * J[y] + J[6 + x] * J[6 + y];
+            for (int y = x; y < 6; y++) v[t++] += J[x] * J[y] + J[6 + x] * J[6 + y];
         }
     }
+    // at distance d each lane keeps half of its values and adds the partner's copy of that half; lane l ends with value l >> 1
 #pragma unroll
-    for (int i = 0; i < 27; i++) {
-        const double v = wave_sum(acc[i]);
-        if (lane == 0) B.M[(size_t) key * 27 + i] = v;
+    for (int half = 16; half >= 1; half >>= 1) {
+        const bool hi = (lane & (2 * half)) != 0;
+#pragma unroll
+        for (int k = 0; k < half; k++) {
+            const double send = hi ? v[k] : v[k + half];
+            const double keep = hi ? v[k + half] : v[k];
+            v[k] = keep + __shfl_xor(send, 2 * half);
+        }
     }
+    v[0] += __shfl_xor(v[0], 1);
+    if (!(lane & 1) && (lane >> 1) < 27) s_part[wave][lane >> 1] = v[0];
+    __syncthreads();
+    if (threadIdx.x < 27) B.M[(size_t) key * 27 + threadIdx.x] = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
 }
 
 __device__ __forceinline__ int tri6(int x, int y) {
@@ -235,28 +252,30 @@ __device__ __forceinline__ int tri6(int x, int y) {
 // With M[c][a] = sum over observations (cam c, anchor a) of [J'J (21) | J'r (6)]:
 //   F'F(c,c) = sum_a M[c][a] + sum_c' M[c'][c]      F'F(c,a) = -(M[c][a] + M[a][c])  (c != a)
 //   F'r(c)   = sum_a m[c][a] - sum_c' m[c'][c]       (J_anchor = -J_obs).  XYZ mode: only M[c][c].
-__global__ void __launch_bounds__(256) k_assemble(BaDev B, int first) {
-    const int n6 = B.n6, nKf = B.nKf;
-    extern __shared__ double s_sum[];  // [nKf][27] row sums | [nKf][27] column sums
-    __shared__ double s_red[256];
-    __shared__ int s_kf[256];  // free index -> keyframe id
-    double *rowsum = s_sum, *colsum = s_sum + nKf * 27;
-    for (int k = threadIdx.x; k < nKf; k += 256)
-        if (B.cidx[k] >= 0 && B.cidx[k] < 256) s_kf[B.cidx[k]] = k;
-    for (int e = threadIdx.x; e < nKf * 27; e += 256) {
-        const int k = e / 27, t = e % 27;
-        double rs = 0, cs = 0;
-        for (int j = 0; j < nKf; j++) {
-            rs += B.M[(size_t) (k * nKf + j) * 27 + t];
-            cs += B.M[(size_t) (j * nKf + k) * 27 + t];
-        }
-        rowsum[e] = rs;
-        colsum[e] = cs;
+// Assembly of the camera block H_cc / g_c from the per-pair sums, in three small launches instead of one single-workgroup
+// kernel (which spent 34 us walking 11.6 k dependent index computations + loads with 256 threads):
+//   k_rowcol   per keyframe: row and column sums of the pair sums
+//   k_hcc      every element of H_cc, g_c, and (first evaluation) the Jacobi scaling of the cameras
+//   k_gmax     (first evaluation) the Jacobi scaling of the points; max |gradient| -> scal[3]
+__global__ void __launch_bounds__(64) k_rowcol(BaDev B) {
+    const int k = blockIdx.x, t = threadIdx.x, nKf = B.nKf;
+    if (t >= 27) return;
+    double rs = 0, cs = 0;
+    for (int j = 0; j < nKf; j++) {
+        rs += B.M[(size_t) (k * nKf + j) * 27 + t];
+        cs += B.M[(size_t) (j * nKf + k) * 27 + t];
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < n6 * n6; e += 256) {
-        const int r = e / n6, c = e % n6, cr = r / 6, cc = c / 6, x = r % 6, y = c % 6;
-        const int kr = s_kf[cr], kc = s_kf[cc];
+    B.rowcol[(size_t) k * 27 + t] = rs;
+    B.rowcol[(size_t) (nKf + k) * 27 + t] = cs;
+}
+
+__global__ void __launch_bounds__(256) k_hcc(BaDev B, int first) {
+    const int n6 = B.n6, nKf = B.nKf;
+    const double *rowsum = B.rowcol, *colsum = B.rowcol + (size_t) nKf * 27;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n6 * n6) {
+        const int r = e / n6, c = e - r * n6, cr = r / 6, cc = c / 6, x = r - 6 * cr, y = c - 6 * cc;
+        const int kr = B.kfOf[cr], kc = B.kfOf[cc];
         const int t = tri6(x, y);
         double v = 0;
         if (B.inv) {
@@ -266,26 +285,27 @@ __global__ void __launch_bounds__(256) k_assemble(BaDev B, int first) {
             if (kr == kc) v = B.M[(size_t) (kr * nKf + kr) * 27 + t];
         }
         B.Hcc[e] = v;
-    }
-    for (int r = threadIdx.x; r < n6; r += 256) {
-        const int kr = s_kf[r / 6], x = r % 6;
+        if (first && r == c) B.sc[r] = 1.0 / (1.0 + sqrt(v));
+    } else if (e < n6 * n6 + n6) {
+        const int r = e - n6 * n6, kr = B.kfOf[r / 6], x = r % 6;
         B.gc[r] = B.inv ? rowsum[kr * 27 + 21 + x] - colsum[kr * 27 + 21 + x] : B.M[(size_t) (kr * nKf + kr) * 27 + 21 + x];
     }
-    __syncthreads();
-    if (first) {
-        for (int r = threadIdx.x; r < n6; r += 256) B.sc[r] = 1.0 / (1.0 + sqrt(B.Hcc[(size_t) r * n6 + r]));
+}
+
+__global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
+    __shared__ double s_red[256];
+    if (first)
         for (int i = threadIdx.x; i < B.npd; i += 256) {
             const int p = i / B.dp, x = i % B.dp;
             B.sp[i] = 1.0 / (1.0 + sqrt(B.Hpp[(size_t) p * B.dp * B.dp + x * B.dp + x]));
         }
-    }
     double gm = 0;
-    for (int r = threadIdx.x; r < n6; r += 256) gm = fmax(gm, fabs(B.gc[r]));
+    for (int r = threadIdx.x; r < B.n6; r += 256) gm = fmax(gm, fabs(B.gc[r]));
     for (int i = threadIdx.x; i < B.npd; i += 256) gm = fmax(gm, fabs(B.gp[i]));
     s_red[threadIdx.x] = gm;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + s]);
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + s2]);
         __syncthreads();
     }
     if (threadIdx.x == 0) B.scal[3] = s_red[0];
@@ -395,92 +415,212 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 }
 
 // S = S_c F'F S_c + D_c^2/radius - G ; rhs = S_c F'r - G[:, n6] ; dense Cholesky; y_c.  One workgroup.
-constexpr int SOLVE_NT = 1024;
+//
+// Blocked right-looking Cholesky, block 16, the matrix padded with an identity to a multiple of 16 (no edge cases):
+//   diagonal block   wave 0, one row per lane IN REGISTERS, pivots / multipliers broadcast with v_readlane (no LDS, no barrier)
+//   panel            one thread per row below: x L11' = a, 136 FMAs against the (broadcast-read) diagonal block
+//   trailing update  4x4 register micro-tiles of A22 -= L21 L21'
+// = 3 barriers per 16 columns instead of 3 per column; the triangular solves are blocked the same way.  Row stride is
+// odd (padded size + 1) so that threads reading different rows hit different LDS banks.
+constexpr int SOLVE_NT = 256, NB = 16;
+
+// reduced camera system of this LM step, padded: S [np][np + 1] and the right-hand side [np] right behind it (all CUs)
+__global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius) {
+    const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < np * np) {
+        const int r = e / np, c = e - r * np;
+        double v = r == c ? 1.0 : 0.0;  // identity padding
+        if (r < n && c < n) {
+            double g = 0;
+#pragma unroll
+            for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + c];
+            v = B.Hcc[(size_t) r * n + c] * B.sc[r] * B.sc[c] - g;
+            if (r == c) v += B.dc[r] / radius;
+        }
+        B.S[(size_t) r * ld + c] = v;
+    } else if (e < np * np + np) {
+        const int r = e - np * np;
+        double v = 0;
+        if (r < n) {
+            double g = 0;
+#pragma unroll
+            for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + n];
+            v = B.gc[r] * B.sc[r] - g;
+        }
+        B.S[(size_t) np * ld + r] = v;
+    }
+}
+
+__device__ __forceinline__ double lane_get(double v, int lane) {  // value of `lane` (wave-uniform index) in every lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 template<bool IN_LDS>
 __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
     extern __shared__ double s_S[];
-    const int n = B.n6;
-    __shared__ double s_piv;
+    const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1, nb = np / NB;
+    __shared__ double s_inv[NB], s_z[NB];
     __shared__ int s_ok;
-    double *S = IN_LDS ? s_S : B.S;  // the reduced camera matrix lives in LDS (n <= 140: n^2 * 8 B <= 157 KB)
-    for (int e = threadIdx.x; e < n * n; e += SOLVE_NT) {
-        const int r = e / n, c = e % n;
-        double g = 0;
-        for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + c];
-        double v = B.Hcc[e] * B.sc[r] * B.sc[c] - g;
-        if (r == c) v += B.dc[r] / radius;
-        S[e] = v;
+    double *S = IN_LDS ? s_S : B.S;            // [np][ld]
+    double *y = IN_LDS ? s_S + (size_t) np * ld : B.S + (size_t) np * ld;  // [np] right-hand side / solution
+    if (IN_LDS) {  // matrix + right-hand side from k_reduced_system, one coalesced pass
+        const int total = np * ld + np;
+        for (int e = threadIdx.x; e < total; e += SOLVE_NT) s_S[e] = B.S[e];
     }
-    for (int r = threadIdx.x; r < n; r += SOLVE_NT) {
-        double g = 0;
-        for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + n];
-        B.yc[r] = B.gc[r] * B.sc[r] - g;
+    // micro-tile enumeration of a lower triangle, row by row: t -> (ta, tb), the same for every trailing size
+    __shared__ unsigned short s_tile[640];
+    for (int t = threadIdx.x; t < 640; t += SOLVE_NT) {
+        int ta = 0;
+        while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+        s_tile[t] = (unsigned short) ((ta << 8) | (t - ta * (ta + 1) / 2));
     }
     if (threadIdx.x == 0) s_ok = 1;
     __syncthreads();
-    // right-looking Cholesky, lower triangle in place; the solve phases run on one wave with the running sums
-    // spread over lanes (forward: column sweep, backward: row sweep)
-    for (int j = 0; j < n; j++) {
-        if (threadIdx.x == 0) {
-            const double d = S[(size_t) j * n + j];
-            if (!(d > 0)) s_ok = 0;
-            s_piv = sqrt(d);
-            S[(size_t) j * n + j] = s_piv;
+    const int lane = threadIdx.x & 63;
+    for (int kb = 0; kb < nb; kb++) {
+        const int base = kb * NB;
+
+        // ---- diagonal block: lane i (< 16) owns row i --------------------------------------------------------------
+        if (threadIdx.x < 64) {
+            double a[NB];
+            const int row = base + (lane & 15);
+#pragma unroll
+            for (int k = 0; k < NB; k++) a[k] = S[(size_t) row * ld + base + k];
+            int ok = 1;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const double d = lane_get(a[j], j);
+                if (!(d > 0)) ok = 0;
+                const double inv = rsqrt(d), piv = d * inv;
+                a[j] = (lane & 15) == j ? piv : a[j] * inv;  // rows above j hold garbage in column j: never read
+                if (lane == j) s_inv[j] = inv;
+#pragma unroll
+                for (int k = j + 1; k < NB; k++) {
+                    const double lkj = lane_get(a[j], k);
+                    a[k] -= a[j] * lkj;  // used for rows >= k only
+                }
+            }
+            if (lane < NB) {
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+                    if (k <= lane) S[(size_t) row * ld + base + k] = a[k];
+            }
+            if (lane == 0 && !ok) s_ok = 0;
         }
         __syncthreads();
         if (!s_ok) break;
-        const double piv = s_piv;
-        for (int i = j + 1 + threadIdx.x; i < n; i += SOLVE_NT) S[(size_t) i * n + j] /= piv;
+        // ---- panel: x L11' = a for every row below --------------------------------------------------------------------
+        const int m = np - base - NB;  // rows below the block
+        for (int r = threadIdx.x; r < m; r += SOLVE_NT) {
+            double *rowp = S + (size_t) (base + NB + r) * ld + base;
+            double x[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                double v = rowp[j];
+                const double *lj = S + (size_t) (base + j) * ld + base;
+#pragma unroll
+                for (int k = 0; k < j; k++) v -= x[k] * lj[k];
+                x[j] = v * s_inv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++) rowp[j] = x[j];
+        }
         __syncthreads();
-        // trailing update of the lower triangle on a 32 x 32 thread grid (no integer division in the loop)
-        const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
-        for (int a = j + 1 + ty; a < n; a += 32) {
-            const double la = S[(size_t) a * n + j];
-            for (int b = j + 1 + tx; b <= a; b += 32) S[(size_t) a * n + b] -= la * S[(size_t) b * n + j];
+        // ---- trailing update A22 -= L21 L21', lower triangle, 4x4 micro-tiles ----------------------------------------------
+        const int mt = m / 4, ntile = mt * (mt + 1) / 2;
+        for (int t = threadIdx.x; t < ntile; t += SOLVE_NT) {
+            const int ta = s_tile[t] >> 8, tb = s_tile[t] & 255;
+            const double *La = S + (size_t) (base + NB + 4 * ta) * ld + base, *Lb = S + (size_t) (base + NB + 4 * tb) * ld + base;
+            double acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < NB; k++) {
+                double la[4], lb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    la[i] = La[(size_t) i * ld + k];
+                    lb[i] = Lb[(size_t) i * ld + k];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] += la[i] * lb[j];
+            }
+            double *C = S + (size_t) (base + NB + 4 * ta) * ld + base + NB + 4 * tb;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ta != tb || j <= i) C[(size_t) i * ld + j] -= acc[i][j];
         }
         __syncthreads();
     }
-    if (s_ok && threadIdx.x < 64) {
-        // triangular solves on ONE wave, no barriers: y lives in registers (lane l owns rows l, l+64, ...), each row
-        // is a lane-parallel dot product against L (read-only now) followed by a wave reduction
-        constexpr int OWN = 4;  // n <= 256
-        const int lane = threadIdx.x;
-        double y[OWN];
+    if (s_ok) {
+        // ---- L z = rhs, blocked -----------------------------------------------------------------------------------------
+        for (int kb = 0; kb < nb; kb++) {
+            const int base = kb * NB;
+            if (threadIdx.x < 64) {
+                const int i = lane & 15;
+                double l[NB];
 #pragma unroll
-        for (int q = 0; q < OWN; q++) y[q] = (lane + 64 * q < n) ? B.yc[lane + 64 * q] : 0.0;
-        for (int i = 0; i < n; i++) {  // L z = rhs
-            double part = 0;
+                for (int k = 0; k < NB; k++) l[k] = S[(size_t) (base + i) * ld + base + k];
+                double yi = y[base + i];
 #pragma unroll
-            for (int q = 0; q < OWN; q++) {
-                const int k = lane + 64 * q;
-                if (k < i) part += S[(size_t) i * n + k] * y[q];
+                for (int j = 0; j < NB; j++) {
+                    const double zj = lane_get(yi, j) / lane_get(l[j], j);
+                    if (i == j) yi = zj;
+                    else if (i > j) yi -= l[j] * zj;
+                }
+                if (lane < NB) {
+                    y[base + i] = yi;
+                    s_z[i] = yi;
+                }
             }
-            const double sum = wave_sum(part);
-            const int qi = i >> 6;
-            const double rhs_i = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63);
-            const double zi = (rhs_i - sum) / S[(size_t) i * n + i];
+            __syncthreads();
+            for (int r = base + NB + threadIdx.x; r < np; r += SOLVE_NT) {
+                const double *lr = S + (size_t) r * ld + base;
+                double v = y[r];
 #pragma unroll
-            for (int q = 0; q < OWN; q++)
-                if (q == qi && lane == (i & 63)) y[q] = zi;
-        }
-        for (int i = n - 1; i >= 0; i--) {  // L' y = z
-            double part = 0;
-#pragma unroll
-            for (int q = 0; q < OWN; q++) {
-                const int k = lane + 64 * q;
-                if (k > i && k < n) part += S[(size_t) k * n + i] * y[q];
+                for (int k = 0; k < NB; k++) v -= lr[k] * s_z[k];
+                y[r] = v;
             }
-            const double sum = wave_sum(part);
-            const int qi = i >> 6;
-            const double zi = __shfl(qi == 0 ? y[0] : (qi == 1 ? y[1] : (qi == 2 ? y[2] : y[3])), i & 63);
-            const double yi = (zi - sum) / S[(size_t) i * n + i];
-#pragma unroll
-            for (int q = 0; q < OWN; q++)
-                if (q == qi && lane == (i & 63)) y[q] = yi;
+            __syncthreads();
         }
+        // ---- L' y = z, blocked, last block first ------------------------------------------------------------------------------
+        for (int kb = nb - 1; kb >= 0; kb--) {
+            const int base = kb * NB;
+            if (threadIdx.x < 64) {
+                const int i = lane & 15;
+                double lc[NB];  // column i of the diagonal block: lc[j] = L[base + j][base + i]
 #pragma unroll
-        for (int q = 0; q < OWN; q++)
-            if (lane + 64 * q < n) B.yc[lane + 64 * q] = y[q];
+                for (int j = 0; j < NB; j++) lc[j] = S[(size_t) (base + j) * ld + base + i];
+                double zi = y[base + i];
+#pragma unroll
+                for (int j = NB - 1; j >= 0; j--) {
+                    const double yj = lane_get(zi, j) / lane_get(lc[j], j);
+                    if (i == j) zi = yj;
+                    else if (i < j) zi -= lc[j] * yj;
+                }
+                if (lane < NB) {
+                    y[base + i] = zi;
+                    s_z[i] = zi;
+                }
+            }
+            __syncthreads();
+            for (int r = threadIdx.x; r < base; r += SOLVE_NT) {
+                double v = y[r];
+#pragma unroll
+                for (int k = 0; k < NB; k++) v -= S[(size_t) (base + k) * ld + r] * s_z[k];
+                y[r] = v;
+            }
+            __syncthreads();
+        }
+        for (int r = threadIdx.x; r < n; r += SOLVE_NT) B.yc[r] = y[r];
     }
     if (threadIdx.x == 0) B.scal[5] = s_ok ? 1.0 : 0.0;
 }
@@ -603,10 +743,16 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     int nc = 0;
     for (int k = 0; k < n_kf; k++) cidx[(size_t) k] = h_kf_const[k] ? -1 : nc++;
     for (int o = 0; o < n_obs; o++) ALVA_ARG(h_obs_kf[o] >= 0 && h_obs_kf[o] < n_kf && h_obs_pt[o] >= 0 && h_obs_pt[o] < n_pt);
-    std::vector<int> order((size_t) n_obs);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_obs_pt[a] < h_obs_pt[b]; });
-    std::vector<int> obsKf((size_t) n_obs), ptPtr((size_t) n_pt + 1, 0), pairKey((size_t) n_obs);
+    const auto t_begin = std::chrono::steady_clock::now();
+    // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
+    std::vector<int> order((size_t) n_obs), ptPtr((size_t) n_pt + 1, 0);
+    {
+        std::vector<int> cursor((size_t) n_pt + 1, 0);
+        for (int o = 0; o < n_obs; o++) cursor[(size_t) h_obs_pt[o] + 1]++;
+        for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];
+        for (int o = 0; o < n_obs; o++) order[(size_t) cursor[(size_t) h_obs_pt[o]]++] = o;
+    }
+    std::vector<int> obsKf((size_t) n_obs), pairKey((size_t) n_obs);
     std::vector<double> obsUv((size_t) n_obs * 2);
     for (int q = 0; q < n_obs; q++) {
         const int o = order[(size_t) q];
@@ -619,11 +765,15 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         pairKey[(size_t) q] = h_obs_kf[o] * n_kf + anc;
     }
     for (int p = 0; p < n_pt; p++) ptPtr[(size_t) p + 1] += ptPtr[(size_t) p];
+    // the same observations grouped by (observing kf, anchor kf) pair, stable: counting sort again
     std::vector<int> pairPerm((size_t) n_obs), pairPtr((size_t) n_kf * n_kf + 1, 0);
-    std::iota(pairPerm.begin(), pairPerm.end(), 0);
-    std::stable_sort(pairPerm.begin(), pairPerm.end(), [&](int a, int b) { return pairKey[(size_t) a] < pairKey[(size_t) b]; });
     for (int q = 0; q < n_obs; q++) pairPtr[(size_t) pairKey[(size_t) q] + 1]++;
     for (size_t i = 0; i + 1 < pairPtr.size(); i++) pairPtr[i + 1] += pairPtr[i];
+    {
+        std::vector<int> cursor(pairPtr.begin(), pairPtr.end() - 1);
+        for (int q = 0; q < n_obs; q++) pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
+    }
+    const auto t_built = std::chrono::steady_clock::now();
 
     BaDev B{};
     B.nKf = n_kf; B.nPt = n_pt; B.nObs = n_obs; B.inv = inv_depth; B.dp = dp; B.nc = nc; B.n6 = 6 * nc;
@@ -636,7 +786,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
 
     // ---- one scratch block, carved -------------------------------------------------------------------
     const size_t nObs = (size_t) n_obs, nPt = (size_t) n_pt, npd = (size_t) B.npd, n6 = (size_t) B.n6, NP = (size_t) B.NP;
-    int *d_obsKf, *d_ptPtr, *d_ancKf, *d_cidx, *d_pairPerm, *d_pairPtr;
+    int *d_obsKf, *d_ptPtr, *d_ancKf, *d_cidx, *d_pairPerm, *d_pairPtr, *d_kfOf;
     double *d_obsUv, *d_ancUv, *d_xp, *d_cp, *d_xt, *d_ct;
     auto layout = [&](uint8_t *base) -> size_t {
         uint8_t *cur = base;
@@ -646,6 +796,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         d_ancKf = carve<int>(cur, nPt);
         d_ancUv = carve<double>(cur, nPt * 2);
         d_cidx = carve<int>(cur, (size_t) n_kf);
+        d_kfOf = carve<int>(cur, (size_t) n_kf);
         d_pairPerm = carve<int>(cur, nObs);
         d_pairPtr = carve<int>(cur, (size_t) n_kf * n_kf + 1);
         B.Jobs = carve<double>(cur, nObs * 12);
@@ -657,6 +808,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         B.gp = carve<double>(cur, npd);
         B.Wt = carve<double>(cur, npd * NP);
         B.M = carve<double>(cur, (size_t) n_kf * n_kf * 27);
+        B.rowcol = carve<double>(cur, (size_t) n_kf * 27 * 2);
         B.Hcc = carve<double>(cur, n6 * n6);
         B.gc = carve<double>(cur, n6);
         B.sc = carve<double>(cur, n6);
@@ -666,7 +818,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         B.hinv = carve<double>(cur, npd * dp);
         B.Zt = carve<double>(cur, (size_t) B.kpad * NP);
         B.Gpart = carve<double>(cur, (size_t) KSPLIT * NP * NP);
-        B.S = carve<double>(cur, n6 * n6);
+        B.S = carve<double>(cur, (n6 + 16) * (n6 + 17) + n6 + 16);  // padded to a multiple of 16, odd row stride, + rhs
         B.yc = carve<double>(cur, NP);
         B.yp = carve<double>(cur, npd);
         B.scal = carve<double>(cur, 64);
@@ -682,7 +834,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     int rc = alva_ctx_scratch(ctx, 4, bytes, (void **) &base);
     if (rc) return rc;
     layout(base);
-    B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx;
+    B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
     B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
 
     hipStream_t st = ctx->stream;
@@ -703,6 +855,10 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         UP(d_ancUv, h_pt_anchor_uv, nPt * 16);
     }
     UP(d_cidx, cidx.data(), (size_t) n_kf * 4);
+    std::vector<int> kfOf((size_t) n_kf, 0);
+    for (int k = 0; k < n_kf; k++)
+        if (cidx[(size_t) k] >= 0) kfOf[(size_t) cidx[(size_t) k]] = k;
+    UP(d_kfOf, kfOf.data(), (size_t) n_kf * 4);
     UP(d_pairPerm, pairPerm.data(), nObs * 4);
     UP(d_pairPtr, pairPtr.data(), ((size_t) n_kf * n_kf + 1) * 4);
     UP(d_xp, poses0.data(), (size_t) n_kf * 56);
@@ -711,10 +867,12 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     ALVA_HIP(hipMemsetAsync(B.Wt, 0, npd * NP * 8, st));                     // sparsity pattern is fixed: zero once
     ALVA_HIP(hipMemsetAsync(B.Zt, 0, (size_t) B.kpad * NP * 8, st));         // K padding rows stay zero
     ALVA_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope / are reused
+    const auto t_up = std::chrono::steady_clock::now();
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
-    const bool solve_in_lds = n6 * n6 * sizeof(double) <= 156 * 1024;
-    if (solve_in_lds && n6 * n6 * sizeof(double) > 48 * 1024)
+    const size_t np16 = (n6 + 15) / 16 * 16, solve_lds = (np16 * (np16 + 1) + np16) * sizeof(double);
+    const bool solve_in_lds = solve_lds <= 156 * 1024;
+    if (solve_in_lds && solve_lds > 48 * 1024)
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     auto eval = [&](const double *xp, const double *xt, bool wantJ, bool first) -> int {
         if (n_pt > 0) {
@@ -728,16 +886,22 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         hipLaunchKernelGGL(k_sum_cost, dim3(1), blk, 0, st, B);
         if (wantJ) {
-            hipLaunchKernelGGL(k_pairs, dim3((unsigned) alva_divup(n_kf * n_kf, 4)), blk, 0, st, B);
-            hipLaunchKernelGGL(k_assemble, dim3(1), blk, (size_t) n_kf * 27 * 2 * sizeof(double), st, B, first ? 1 : 0);
+            hipLaunchKernelGGL(k_pairs, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, B);
+            hipLaunchKernelGGL(k_rowcol, dim3((unsigned) n_kf), dim3(64), 0, st, B);
+            hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
+            hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);
         }
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     };
     double scal[8];
+    double *pin_scal = nullptr;
+    rc = alva_ctx_pinned(ctx, 64, (void **) &pin_scal);
+    if (rc) return rc;
     auto read_scal = [&]() -> int {
-        ALVA_HIP(hipMemcpyAsync(scal, B.scal, sizeof(scal), hipMemcpyDeviceToHost, st));
+        ALVA_HIP(hipMemcpyAsync(pin_scal, B.scal, sizeof(scal), hipMemcpyDeviceToHost, st));  // pinned: a plain DMA, no staging
         ALVA_HIP(hipStreamSynchronize(st));
+        memcpy(scal, pin_scal, sizeof(scal));
         return ALVA_OK;
     };
 
@@ -762,7 +926,11 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         const int tiles = B.NP / 16;
         hipLaunchKernelGGL(k_gemm, dim3((unsigned) (tiles * tiles), KSPLIT), dim3(64), 0, st, B);
-        if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_NT), n6 * n6 * sizeof(double), st, B, lm.radius);
+        {
+            const int np16i = (int) np16;
+            hipLaunchKernelGGL(k_reduced_system, dim3((unsigned) alva_divup(np16i * np16i + np16i, 256)), blk, 0, st, B, lm.radius);
+        }
+        if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_NT), solve_lds, st, B, lm.radius);
         else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_NT), 0, st, B, lm.radius);
         if (n_pt > 0) {
             if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
@@ -807,6 +975,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         nsummaries++;
     }
+    const auto t_lm = std::chrono::steady_clock::now();
     // results: poses / points at the last accepted x; chi2 / depth flags of the LAST evaluation (what the
     // reference's outlier sweep reads from its cost-function objects, optimizer.cpp:266-309)
     std::vector<double> posesOut((size_t) n_kf * 7);
@@ -830,6 +999,13 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         h_info[1] = initial;
         h_info[2] = x_cost;
         h_info[3] = nsucc;
+    }
+    if (getenv("ALVA_BA_TIMING")) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return (double) std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3;
+        };
+        fprintf(stderr, "[alva_local_ba] host structure %.0f us | scratch + upload %.0f us | LM loop (%d summaries) %.0f us | download %.0f us\n",
+                us(t_begin, t_built), us(t_built, t_up), nsummaries, us(t_up, t_lm), us(t_lm, std::chrono::steady_clock::now()));
     }
     return ALVA_OK;
 }
