@@ -738,43 +738,12 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     *h_ok = 1;
     if (h_info) memset(h_info, 0, 4 * sizeof(double));
     const int dp = inv_depth ? 1 : 3;
-    // ---- host-side structure (the analogue of Ceres' program / block-structure build, done once) --------
+    // ---- sizes -----------------------------------------------------------------------------------------------
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<int> cidx((size_t) n_kf);
     int nc = 0;
     for (int k = 0; k < n_kf; k++) cidx[(size_t) k] = h_kf_const[k] ? -1 : nc++;
     for (int o = 0; o < n_obs; o++) ALVA_ARG(h_obs_kf[o] >= 0 && h_obs_kf[o] < n_kf && h_obs_pt[o] >= 0 && h_obs_pt[o] < n_pt);
-    const auto t_begin = std::chrono::steady_clock::now();
-    // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
-    std::vector<int> order((size_t) n_obs), ptPtr((size_t) n_pt + 1, 0);
-    {
-        std::vector<int> cursor((size_t) n_pt + 1, 0);
-        for (int o = 0; o < n_obs; o++) cursor[(size_t) h_obs_pt[o] + 1]++;
-        for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];
-        for (int o = 0; o < n_obs; o++) order[(size_t) cursor[(size_t) h_obs_pt[o]]++] = o;
-    }
-    std::vector<int> obsKf((size_t) n_obs), pairKey((size_t) n_obs);
-    std::vector<double> obsUv((size_t) n_obs * 2);
-    for (int q = 0; q < n_obs; q++) {
-        const int o = order[(size_t) q];
-        obsKf[(size_t) q] = h_obs_kf[o];
-        obsUv[2 * (size_t) q] = h_obs_uv[2 * o];
-        obsUv[2 * (size_t) q + 1] = h_obs_uv[2 * o + 1];
-        ptPtr[(size_t) h_obs_pt[o] + 1]++;
-        const int anc = inv_depth ? h_pt_anchor_kf[h_obs_pt[o]] : h_obs_kf[o];
-        ALVA_ARG(anc >= 0 && anc < n_kf);
-        pairKey[(size_t) q] = h_obs_kf[o] * n_kf + anc;
-    }
-    for (int p = 0; p < n_pt; p++) ptPtr[(size_t) p + 1] += ptPtr[(size_t) p];
-    // the same observations grouped by (observing kf, anchor kf) pair, stable: counting sort again
-    std::vector<int> pairPerm((size_t) n_obs), pairPtr((size_t) n_kf * n_kf + 1, 0);
-    for (int q = 0; q < n_obs; q++) pairPtr[(size_t) pairKey[(size_t) q] + 1]++;
-    for (size_t i = 0; i + 1 < pairPtr.size(); i++) pairPtr[i + 1] += pairPtr[i];
-    {
-        std::vector<int> cursor(pairPtr.begin(), pairPtr.end() - 1);
-        for (int q = 0; q < n_obs; q++) pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
-    }
-    const auto t_built = std::chrono::steady_clock::now();
-
     BaDev B{};
     B.nKf = n_kf; B.nPt = n_pt; B.nObs = n_obs; B.inv = inv_depth; B.dp = dp; B.nc = nc; B.n6 = 6 * nc;
     B.NP = (B.n6 + 1 + 15) / 16 * 16;
@@ -784,10 +753,11 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     for (int i = 0; i < 4; i++) B.K[i] = h_calib[i];
     B.huber_a = (double) sqrtf((float) huber_chi2);  // optimizer.cpp:22: std::sqrt of a float
 
-    // ---- one scratch block, carved -------------------------------------------------------------------
+    // ---- one scratch block, carved; the INPUT arrays come first and contiguous so that one copy uploads them ----------
     const size_t nObs = (size_t) n_obs, nPt = (size_t) n_pt, npd = (size_t) B.npd, n6 = (size_t) B.n6, NP = (size_t) B.NP;
     int *d_obsKf, *d_ptPtr, *d_ancKf, *d_cidx, *d_pairPerm, *d_pairPtr, *d_kfOf;
     double *d_obsUv, *d_ancUv, *d_xp, *d_cp, *d_xt, *d_ct;
+    size_t in_bytes = 0, off_res = 0;
     auto layout = [&](uint8_t *base) -> size_t {
         uint8_t *cur = base;
         d_obsKf = carve<int>(cur, nObs);
@@ -799,10 +769,14 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         d_kfOf = carve<int>(cur, (size_t) n_kf);
         d_pairPerm = carve<int>(cur, nObs);
         d_pairPtr = carve<int>(cur, (size_t) n_kf * n_kf + 1);
+        d_xp = carve<double>(cur, (size_t) n_kf * 7);
+        d_xt = carve<double>(cur, npd);
+        in_bytes = (size_t) (cur - base);
+        off_res = in_bytes;
+        B.chi2 = carve<double>(cur, nObs);   // results the host reads back: chi2 | depth flags, contiguous
+        B.depth = carve<uint8_t>(cur, nObs);
         B.Jobs = carve<double>(cur, nObs * 12);
         B.rs = carve<double>(cur, nObs * 2);
-        B.chi2 = carve<double>(cur, nObs);
-        B.depth = carve<uint8_t>(cur, nObs);
         B.ptCost = carve<double>(cur, nPt);
         B.Hpp = carve<double>(cur, npd * dp);
         B.gp = carve<double>(cur, npd);
@@ -823,9 +797,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         B.yp = carve<double>(cur, npd);
         B.scal = carve<double>(cur, 64);
         B.partial = carve<double>(cur, nPt * 3);
-        d_xp = carve<double>(cur, (size_t) n_kf * 7);
         d_cp = carve<double>(cur, (size_t) n_kf * 7);
-        d_xt = carve<double>(cur, npd);
         d_ct = carve<double>(cur, npd);
         return (size_t) (cur - base);
     };
@@ -833,40 +805,74 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     uint8_t *base = nullptr;
     int rc = alva_ctx_scratch(ctx, 4, bytes, (void **) &base);
     if (rc) return rc;
+    // pinned staging: [0, 256) the per-iteration scalars | the input block (mirror of the device layout) | results
+    const size_t res_bytes = (nObs * 9 + 511) / 256 * 256 + (size_t) n_kf * 56 + 256 + npd * 8 + 256;
+    uint8_t *pin = nullptr;
+    rc = alva_ctx_pinned(ctx, 256 + std::max(in_bytes, res_bytes), (void **) &pin);
+    if (rc) return rc;
+    uint8_t *stage = pin + 256;
+    layout(stage);  // host mirrors of the input arrays, written in place
+    int *h_obsKf = d_obsKf, *h_ptPtr = d_ptPtr, *h_ancKf = d_ancKf, *h_cidx = d_cidx, *h_kfOf = d_kfOf, *h_pairPerm = d_pairPerm,
+        *h_pairPtr = d_pairPtr;
+    double *h_obsUv = d_obsUv, *h_ancUv = d_ancUv, *h_xp = d_xp, *h_xt = d_xt;
     layout(base);
     B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
     B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
-
     hipStream_t st = ctx->stream;
+    ALVA_HIP(hipStreamSynchronize(st));  // nothing enqueued earlier may still be reading the staging area
+
+    // ---- host-side structure (the analogue of Ceres' program / block-structure build), built in the staging area ---------
+    // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
+    std::vector<int> order((size_t) n_obs), pairKey((size_t) n_obs);
+    for (size_t p2 = 0; p2 <= nPt; p2++) h_ptPtr[p2] = 0;
+    {
+        std::vector<int> cursor((size_t) n_pt + 1, 0);
+        for (int o = 0; o < n_obs; o++) cursor[(size_t) h_obs_pt[o] + 1]++;
+        for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];
+        for (int o = 0; o < n_obs; o++) order[(size_t) cursor[(size_t) h_obs_pt[o]]++] = o;
+    }
+    for (int q = 0; q < n_obs; q++) {
+        const int o = order[(size_t) q];
+        h_obsKf[q] = h_obs_kf[o];
+        h_obsUv[2 * (size_t) q] = h_obs_uv[2 * o];
+        h_obsUv[2 * (size_t) q + 1] = h_obs_uv[2 * o + 1];
+        h_ptPtr[(size_t) h_obs_pt[o] + 1]++;
+        const int anc = inv_depth ? h_pt_anchor_kf[h_obs_pt[o]] : h_obs_kf[o];
+        ALVA_ARG(anc >= 0 && anc < n_kf);
+        pairKey[(size_t) q] = h_obs_kf[o] * n_kf + anc;
+    }
+    for (int p2 = 0; p2 < n_pt; p2++) h_ptPtr[(size_t) p2 + 1] += h_ptPtr[(size_t) p2];
+    // the same observations grouped by (observing kf, anchor kf) pair, stable: counting sort again
+    const size_t nPairs = (size_t) n_kf * n_kf;
+    for (size_t i = 0; i <= nPairs; i++) h_pairPtr[i] = 0;
+    for (int q = 0; q < n_obs; q++) h_pairPtr[(size_t) pairKey[(size_t) q] + 1]++;
+    for (size_t i = 0; i < nPairs; i++) h_pairPtr[i + 1] += h_pairPtr[i];
+    {
+        std::vector<int> cursor(h_pairPtr, h_pairPtr + nPairs);
+        for (int q = 0; q < n_obs; q++) h_pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
+    }
+    if (inv_depth && n_pt > 0) {
+        memcpy(h_ancKf, h_pt_anchor_kf, nPt * 4);
+        memcpy(h_ancUv, h_pt_anchor_uv, nPt * 16);
+    }
+    for (int k = 0; k < n_kf; k++) {
+        h_cidx[k] = cidx[(size_t) k];
+        h_kfOf[k] = 0;
+    }
+    for (int k = 0; k < n_kf; k++)
+        if (cidx[(size_t) k] >= 0) h_kfOf[cidx[(size_t) k]] = k;
     // poses are stored the way PoseParametersBlock(id, SE3d) stores them: unit quaternion
-    std::vector<double> poses0((size_t) n_kf * 7);
     for (int k = 0; k < n_kf; k++) {
         Se3 T;
         se3_from_pose7(h_poses + 7 * k, T);
-        for (int i = 0; i < 3; i++) poses0[7 * (size_t) k + i] = T.t[i];
-        for (int i = 0; i < 4; i++) poses0[7 * (size_t) k + 3 + i] = T.q[i];
+        for (int i = 0; i < 3; i++) h_xp[7 * (size_t) k + i] = T.t[i];
+        for (int i = 0; i < 4; i++) h_xp[7 * (size_t) k + 3 + i] = T.q[i];
     }
-#define UP(dst, src, n) ALVA_HIP(hipMemcpyAsync(dst, src, (n), hipMemcpyHostToDevice, st))
-    UP(d_obsKf, obsKf.data(), nObs * 4);
-    UP(d_obsUv, obsUv.data(), nObs * 16);
-    UP(d_ptPtr, ptPtr.data(), (nPt + 1) * 4);
-    if (inv_depth) {
-        UP(d_ancKf, h_pt_anchor_kf, nPt * 4);
-        UP(d_ancUv, h_pt_anchor_uv, nPt * 16);
-    }
-    UP(d_cidx, cidx.data(), (size_t) n_kf * 4);
-    std::vector<int> kfOf((size_t) n_kf, 0);
-    for (int k = 0; k < n_kf; k++)
-        if (cidx[(size_t) k] >= 0) kfOf[(size_t) cidx[(size_t) k]] = k;
-    UP(d_kfOf, kfOf.data(), (size_t) n_kf * 4);
-    UP(d_pairPerm, pairPerm.data(), nObs * 4);
-    UP(d_pairPtr, pairPtr.data(), ((size_t) n_kf * n_kf + 1) * 4);
-    UP(d_xp, poses0.data(), (size_t) n_kf * 56);
-    UP(d_xt, h_pt_param, npd * 8);
-#undef UP
+    if (npd) memcpy(h_xt, h_pt_param, npd * 8);
+    const auto t_built = std::chrono::steady_clock::now();
+    ALVA_HIP(hipMemcpyAsync(base, stage, in_bytes, hipMemcpyHostToDevice, st));   // ONE upload from pinned memory
     ALVA_HIP(hipMemsetAsync(B.Wt, 0, npd * NP * 8, st));                     // sparsity pattern is fixed: zero once
     ALVA_HIP(hipMemsetAsync(B.Zt, 0, (size_t) B.kpad * NP * 8, st));         // K padding rows stay zero
-    ALVA_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope / are reused
     const auto t_up = std::chrono::steady_clock::now();
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
@@ -895,9 +901,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         return ALVA_OK;
     };
     double scal[8];
-    double *pin_scal = nullptr;
-    rc = alva_ctx_pinned(ctx, 64, (void **) &pin_scal);
-    if (rc) return rc;
+    double *pin_scal = reinterpret_cast<double *>(pin);
     auto read_scal = [&]() -> int {
         ALVA_HIP(hipMemcpyAsync(pin_scal, B.scal, sizeof(scal), hipMemcpyDeviceToHost, st));  // pinned: a plain DMA, no staging
         ALVA_HIP(hipStreamSynchronize(st));
@@ -978,18 +982,20 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     const auto t_lm = std::chrono::steady_clock::now();
     // results: poses / points at the last accepted x; chi2 / depth flags of the LAST evaluation (what the
     // reference's outlier sweep reads from its cost-function objects, optimizer.cpp:266-309)
-    std::vector<double> posesOut((size_t) n_kf * 7);
-    ALVA_HIP(hipMemcpyAsync(posesOut.data(), xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
-    if (npd) ALVA_HIP(hipMemcpyAsync(h_pt_param, xt, npd * 8, hipMemcpyDeviceToHost, st));
-    std::vector<double> chi2s(nObs);
-    std::vector<uint8_t> deps(nObs);
-    if (n_obs) {
-        ALVA_HIP(hipMemcpyAsync(chi2s.data(), B.chi2, nObs * 8, hipMemcpyDeviceToHost, st));
-        ALVA_HIP(hipMemcpyAsync(deps.data(), B.depth, nObs, hipMemcpyDeviceToHost, st));
-    }
+    // the input staging area is free again (its upload finished long ago): results land there, three DMA copies
+    uint8_t *r_chi = stage;
+    const size_t chi_bytes = (size_t) ((uint8_t *) B.depth - (uint8_t *) B.chi2) + nObs;   // chi2 | pad | depth, as carved
+    double *r_poses = reinterpret_cast<double *>(stage + (chi_bytes + 255) / 256 * 256);
+    double *r_pts = r_poses + (size_t) n_kf * 7 + 32;
+    if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, B.chi2, chi_bytes, hipMemcpyDeviceToHost, st));
+    ALVA_HIP(hipMemcpyAsync(r_poses, xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
+    if (npd) ALVA_HIP(hipMemcpyAsync(r_pts, xt, npd * 8, hipMemcpyDeviceToHost, st));
     ALVA_HIP(hipStreamSynchronize(st));
+    if (npd) memcpy(h_pt_param, r_pts, npd * 8);
+    const double *chi2s = reinterpret_cast<const double *>(r_chi);
+    const uint8_t *deps = r_chi + ((uint8_t *) B.depth - (uint8_t *) B.chi2);
     for (int k = 0; k < n_kf; k++)
-        if (cidx[(size_t) k] >= 0) memcpy(h_poses + 7 * k, posesOut.data() + 7 * (size_t) k, 56);
+        if (cidx[(size_t) k] >= 0) memcpy(h_poses + 7 * k, r_poses + 7 * (size_t) k, 56);
     for (int q = 0; q < n_obs; q++) {  // back to the caller's observation order
         if (h_chi2) h_chi2[order[(size_t) q]] = chi2s[(size_t) q];
         if (h_depth_pos) h_depth_pos[order[(size_t) q]] = deps[(size_t) q];
