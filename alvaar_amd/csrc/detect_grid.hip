@@ -90,7 +90,10 @@ __global__ void __launch_bounds__(256) k_mark_occupied(GridArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
+// NT = 64 for cells up to 16x16 (one wave per cell: the many phase barriers cost nothing and 4x more cells are in flight
+// per CU), 256 for larger cells.
+template<int NT>
+__global__ void __launch_bounds__(NT) k_cell_eig(GridArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int cell = A.cell, n2 = cell * cell;
     const int ci = blockIdx.x;
@@ -116,12 +119,12 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
     uint8_t *sB = reinterpret_cast<uint8_t *>(sbox + 3 * n2);
     uint8_t *sG = sB + n2;                                   // (cell+2)^2 gray with 1-px halo
     const int gw = cell + 2;
-    for (int i = threadIdx.x; i < gw * gw; i += 256) {
+    for (int i = threadIdx.x; i < gw * gw; i += NT) {
         int ly = i / gw, lx = i % gw;
         sG[i] = A.gray[(size_t) refl(y0 + ly - 1, A.h) * A.pitch + refl(x0 + lx - 1, A.w)];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n2; i += 256) {
+    for (int i = threadIdx.x; i < n2; i += NT) {
         int y = i / cell, x = i % cell;
         const uint8_t *g = sG + (y + 1) * gw + (x + 1);
         int acc = g[-gw - 1] + 2 * g[-gw] + g[-gw + 1] + 2 * g[-1] + 4 * g[0] + 2 * g[1] + g[gw - 1] + 2 * g[gw] + g[gw + 1];
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
     __syncthreads();
     const float s = (float) (1.0 / (4.0 * 3.0 * 255.0));
     const float s2 = 2.0f * s;
-    for (int i = threadIdx.x; i < n2; i += 256) {
+    for (int i = threadIdx.x; i < n2; i += NT) {
         int y = i / cell, x = i % cell;
         int ym = refl(y - 1, cell), yp = refl(y + 1, cell), xm = refl(x - 1, cell), xp = refl(x + 1, cell);
         float a0 = sB[ym * cell + xm], a1 = sB[ym * cell + x], a2 = sB[ym * cell + xp];
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
     unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem + ((29 * n2 + gw * gw + 15) & ~15));
     int np2 = 256;
     while (np2 < n2) np2 <<= 1;
-    for (int i = threadIdx.x; i < np2; i += 256) {
+    for (int i = threadIdx.x; i < np2; i += NT) {
         unsigned long long key = 0;
         if (i < n2) {
             const float a = sbox[i] * 0.5f, b = sbox[n2 + i], cc = sbox[2 * n2 + i] * 0.5f;
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += 256) {
+            for (int i = threadIdx.x; i < np2; i += NT) {
                 const int l = i ^ j;
                 if (l > i) {
                     const unsigned long long x = skey[i], y = skey[l];
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(256) k_cell_eig(GridArgs A) {
     if (threadIdx.x == 0) s_good = 0;
     __syncthreads();
     int good = 0;
-    for (int i = threadIdx.x; i < stride; i += 256) {
+    for (int i = threadIdx.x; i < stride; i += NT) {
         uint16_t o = 0xffff;
         if (i < n2) {
             const unsigned long long key = skey[i];
@@ -803,15 +806,38 @@ __device__ float subpix_at(const SubpixGeom &g, const uint8_t *src, size_t pitch
     return (((float) p[j] * g.a11 + (float) p[j + 1] * g.a12) + (float) p2[j] * g.a21) + (float) p2[j + 1] * g.a22;
 }
 
+// inside path of subpix_at with the source pixels in an LDS tile whose (0,0) is image pixel (tx0, ty0)
+__device__ __forceinline__ float subpix_at_tile(const SubpixGeom &g, const uint8_t *tile, int tpitch, int tx0, int ty0, int i, int j) {
+    const uint8_t *p = tile + (g.ipy + i - ty0) * tpitch + (g.ipx - tx0);
+    const float t = g.a12 * (float) p[j + 1] + g.a22 * (float) p[j + 1 + tpitch];
+    float prev;
+    if (j == 0) prev = g.oma * (g.b1 * (float) p[0] + g.b2 * (float) p[tpitch]);
+    else {
+        const float tp = g.a12 * (float) p[j] + g.a22 * (float) p[j + tpitch];
+        prev = (float) ((double) tp * g.s);
+    }
+    return prev + t;
+}
+
+__device__ __forceinline__ double lane_bcast_d(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// The slowest corner (30 iterations) sets the kernel time, so the iteration is kept short: the 10x10 source footprint of
+// the 9x9 patch is read from a 24x24 LDS tile (re-staged from L2 only when the window leaves it), broadcasts are v_readlane.
 __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray, size_t pitch, int w, int h, float *__restrict__ pts,
                                               const CompactOut *__restrict__ cnt, int cap) {
     const int n = min(cnt->n_total, cap);
     const int pi = blockIdx.x;
     if (pi >= n) return;
     constexpr int WINH = 3, WW = 7, BW = WW + 2;
+    constexpr int TS = 24, TM = (TS - BW - 1) / 2;  // tile side, margin around the footprint when staged
     __shared__ float s_buf[BW * BW];
     __shared__ float s_mask[WW * WW];
     __shared__ double s_term[5][WW * WW + 1];
+    __shared__ uint8_t s_tile[TS * TS];
+    int tx0 = 0x40000000, ty0 = 0x40000000;  // tile origin (invalid: staged on first use)
     const int lane = threadIdx.x;
     // exp(-(k/3)^2), k = 0..3, as glibc's expf returns them (the reference computes the mask with std::exp(float))
     const uint32_t ebits[4] = {0x3f800000u, 0x3f651430u, 0x3f242466u, 0x3ebc5ab2u};
@@ -828,7 +854,20 @@ __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray,
     do {
         const SubpixGeom g = subpix_geom(cIx, cIy, BW, BW, w, h);
         __syncthreads();
-        for (int e = lane; e < BW * BW; e += 64) s_buf[e] = subpix_at(g, gray, pitch, e / BW, e % BW, BW);
+        if (g.inside) {  // wave-uniform
+            if (g.ipx < tx0 || g.ipx + BW + 1 > tx0 + TS || g.ipy < ty0 || g.ipy + BW + 1 > ty0 + TS) {
+                tx0 = g.ipx - TM;
+                ty0 = g.ipy - TM;
+                for (int e = lane; e < TS * TS; e += 64) {
+                    const int yy = min(max(ty0 + e / TS, 0), h - 1), xx = min(max(tx0 + e % TS, 0), w - 1);  // clamped bytes are never used
+                    s_tile[e] = gray[(size_t) yy * pitch + xx];
+                }
+                __syncthreads();
+            }
+            for (int e = lane; e < BW * BW; e += 64) s_buf[e] = subpix_at_tile(g, s_tile, TS, tx0, ty0, e / BW, e % BW);
+        } else {
+            for (int e = lane; e < BW * BW; e += 64) s_buf[e] = subpix_at(g, gray, pitch, e / BW, e % BW, BW);
+        }
         __syncthreads();
         // the 49 per-pixel terms are evaluated lane-parallel (one term per lane) into LDS; lanes 0..4 then replay the
         // reference's five sequential double accumulations a, b, c, bb1, bb2 in row-major order
@@ -851,7 +890,8 @@ __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray,
 #pragma unroll 7
             for (int k = 0; k < WW * WW; k++) acc += s_term[lane][k];
         }
-        const double a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2), bb1 = __shfl(acc, 3), bb2 = __shfl(acc, 4);
+        const double a = lane_bcast_d(acc, 0), b = lane_bcast_d(acc, 1), c = lane_bcast_d(acc, 2), bb1 = lane_bcast_d(acc, 3),
+                     bb2 = lane_bcast_d(acc, 4);
         const double det = a * c - b * b;
         if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
         const double scale = 1.0 / det;
@@ -944,7 +984,8 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     while (np2 < n2) np2 <<= 1;
     const size_t lds_eig = (size_t) n2 * (4 + 4 + 8 + 12 + 1) + (size_t) (cell_size + 2) * (cell_size + 2) + 32 + (size_t) np2 * 8;
     ALVA_ARG(lds_eig <= 64 * 1024);
-    hipLaunchKernelGGL(k_cell_eig, dim3(nCells), dim3(256), lds_eig, st, A);
+    if (n2 <= 256) hipLaunchKernelGGL(k_cell_eig<64>, dim3(nCells), dim3(64), lds_eig, st, A);
+    else hipLaunchKernelGGL(k_cell_eig<256>, dim3(nCells), dim3(256), lds_eig, st, A);
     size_t lds_sel = (size_t) nCells * 16 + 5 * (size_t) ((nCells + 15) & ~15) + 64;
     ALVA_ARG(lds_sel <= 160 * 1024 - 1024);
     const size_t mask_bytes = (size_t) ((width + 31) / 32) * height * 4;
