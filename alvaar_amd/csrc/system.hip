@@ -235,61 +235,24 @@ extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgb
         ALVA_HIP(hipMemcpyAsync(s->d_bv, bv.data(), bv.size() * 8, hipMemcpyHostToDevice, st));
         ALVA_HIP(hipMemcpyAsync(s->d_wpt, wp.data(), wp.size() * 8, hipMemcpyHostToDevice, st));
         ALVA_HIP(hipMemcpyAsync(s->d_uv, uv.data(), uv.size() * 8, hipMemcpyHostToDevice, st));
-        double R[9], t[3];
-        std::vector<int> outl((size_t) n);
-        int nout = 0, ok = 0;
-        // p3pEnabled_ = true (system.cpp:19); multiViewRandomEnabled_ seeds from the clock in the reference -- fixed seed here
-        rc = alva_p3p_lmeds(s->ctx, s->d_bv, s->d_wpt, n, 100, 3.0f, 0, 12345u, (float) s->fx, (float) s->fy, R, t, outl.data(), &nout, &ok);
-        if (rc) return rc;
-        bool good = ok && (n - nout) >= 5;
+        // p3pEnabled_ = true (system.cpp:19): P3P-LMedS -> drop its outliers -> robust PnP on the inliers, chained on the
+        // device (visual_frontend.cpp:300-399).  multiViewRandomEnabled_ seeds from the clock in the reference -- fixed seed here.
         double pose7[7];
+        std::vector<uint8_t> outP3p((size_t) n), outPnp((size_t) n);
+        int pstat = 0;
+        rc = alva_compute_pose(s->ctx, s->d_bv, s->d_uv, s->d_wpt, n, 100, 3.0f, 0, 12345u, 5, 5.9915f, (float) s->fx, (float) s->fy,
+                               (float) s->cx, (float) s->cy, pose7, outP3p.data(), outPnp.data(), &pstat);
+        if (rc) return rc;
+        const bool good = pstat == 2;
         if (good) {
-            // rotation matrix -> unit quaternion (Sophus::SE3d::setRotationMatrix)
-            double q[4];
-            const double tr = R[0] + R[4] + R[8];
-            if (tr > 0) {
-                const double sq = std::sqrt(tr + 1.0) * 2;
-                q[3] = 0.25 * sq; q[0] = (R[7] - R[5]) / sq; q[1] = (R[2] - R[6]) / sq; q[2] = (R[3] - R[1]) / sq;
-            } else {
-                int i = R[4] > R[0] ? 1 : 0;
-                if (R[8] > R[4 * i]) i = 2;
-                const int j = (i + 1) % 3, k = (i + 2) % 3;
-                const double sq = std::sqrt(1.0 + R[4 * i] - R[4 * j] - R[4 * k]) * 2;
-                q[i] = 0.25 * sq; q[j] = (R[3 * j + i] + R[3 * i + j]) / sq; q[k] = (R[3 * k + i] + R[3 * i + k]) / sq;
-                q[3] = (R[3 * k + j] - R[3 * j + k]) / sq;
-            }
-            for (int c = 0; c < 3; c++) pose7[c] = t[c];
-            for (int c = 0; c < 4; c++) pose7[3 + c] = q[c];
-            // PnP refinement on the P3P inliers (visual_frontend.cpp:344-375): drop the outliers first
-            std::vector<uint8_t> isout((size_t) n, 0);
-            for (int k = 0; k < nout; k++) isout[(size_t) outl[(size_t) k]] = 1;
-            std::vector<double> uv2, wp2;
-            std::vector<int> map2;
+            // remove the observations P3P and ceresPnP flagged (visual_frontend.cpp:344-352, :411-414)
+            std::vector<uint8_t> drop(s->kps.size(), 0);
             for (int k = 0; k < n; k++)
-                if (!isout[(size_t) k]) {
-                    uv2.push_back(uv[2 * (size_t) k]); uv2.push_back(uv[2 * (size_t) k + 1]);
-                    for (int c = 0; c < 3; c++) wp2.push_back(wp[3 * (size_t) k + c]);
-                    map2.push_back(k);
-                }
-            const int m = (int) map2.size();
-            ALVA_HIP(hipMemcpyAsync(s->d_uv, uv2.data(), uv2.size() * 8, hipMemcpyHostToDevice, st));
-            ALVA_HIP(hipMemcpyAsync(s->d_wpt, wp2.data(), wp2.size() * 8, hipMemcpyHostToDevice, st));
-            std::vector<int> outl2((size_t) std::max(m, 1));
-            int nout2 = 0, ok2 = 0;
-            rc = alva_pnp_refine(s->ctx, s->d_uv, s->d_wpt, m, pose7, 5, 5.9915f, 1, 1, (float) s->fx, (float) s->fy, (float) s->cx,
-                                 (float) s->cy, outl2.data(), &nout2, nullptr, &ok2);
-            if (rc) return rc;
-            good = ok2 && (m - nout2) >= 5 && nout2 <= 0.5 * m;
-            if (good) {
-                // remove the observations ceresPnP flagged (visual_frontend.cpp:411-414)
-                std::vector<uint8_t> drop(s->kps.size(), 0);
-                for (int k = 0; k < nout; k++) drop[(size_t) idx3d[(size_t) outl[(size_t) k]]] = 1;
-                for (int k = 0; k < nout2; k++) drop[(size_t) idx3d[(size_t) map2[(size_t) outl2[(size_t) k]]]] = 1;
-                std::vector<Keypoint> kept;
-                for (size_t i = 0; i < s->kps.size(); i++)
-                    if (!drop[i]) kept.push_back(s->kps[i]);
-                s->kps.swap(kept);
-            }
+                if (outP3p[(size_t) k] || outPnp[(size_t) k]) drop[(size_t) idx3d[(size_t) k]] = 1;
+            std::vector<Keypoint> kept;
+            for (size_t i = 0; i < s->kps.size(); i++)
+                if (!drop[i]) kept.push_back(s->kps[i]);
+            s->kps.swap(kept);
         }
         if (good) {
             memcpy(s->pose, pose7, sizeof(pose7));

@@ -199,6 +199,47 @@ def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5)
     return {"streams": n_streams, "frames_per_s": n_streams * steps / wall, "ms_per_frame_per_stream": wall / steps * 1e3}
 
 
+def bench_720p(device: int, reps: int = 50):
+    """BASELINE configs[2]: 1280x720, ORB extract 4000 kp/frame + brute-force Hamming match (secondary line)."""
+    import alvaar_amd
+    from alvaar_amd import synth, capi
+    w, h = 1280, 720
+    ctx = alvaar_amd.Context(device)
+    frames = torch.from_numpy(synth.stream_rgba(w, h, 2, seed=11, noise=True)).to(f"cuda:{device}")
+    gray = [ctx.rgba2gray(frames[k]) for k in range(2)]
+    orb = alvaar_amd.Orb(ctx, w, h, 4000)
+    cap = 4 * 4000 + 1024
+    bufs = [(torch.zeros((cap, 6), dtype=torch.float32, device=gray[0].device), torch.zeros((cap, 32), dtype=torch.uint8, device=gray[0].device))
+            for _ in range(2)]
+    orb.enqueue(gray[0], *bufs[0])
+    _, prev = orb.collect()
+
+    def step(k=[0]):
+        k[0] += 1
+        orb.enqueue(gray[k[0] & 1], *bufs[k[0] & 1])
+        kp, desc = orb.collect()
+        step.match = ctx.bf_match_hamming(desc, step.prev)
+        step.prev = desc
+        step.n = desc.shape[0]
+    step.prev = prev
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kt = capi.kernel_times(step, 20)
+    P2 = w * h
+    algb = {"k_fast_nms": 3.27 * P2, "k_blur7_batch": 2 * 3.27 * P2, "k_bf_partial": 32 * 2 * step.n + 8 * step.n * ((step.n + 63) // 64)}
+    return {"workload": "configs[2]: 1280x720, cv::ORB detectAndCompute(4000, 1.2, 8) + BFMatcher(HAMMING) vs the previous frame",
+            "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "keypoints": int(step.n),
+            "kernels": {k: {"avg_us": round(v[1], 2), "launches_per_frame": round(v[0] / 20, 2),
+                            **({"GBps": round(algb[k] / (v[1] * 1e-6) / 1e9, 1)} if k in algb else {})}
+                        for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8]}}
+
+
 def bench_ba(ctx, reps: int = 3):
     from alvaar_amd import synth
     pb = synth.make_ba_problem(20, 3000, 42)
@@ -352,6 +393,7 @@ def main():
             "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,
                                      "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
             "local_ba": ba,
+            "config_1280x720": bench_720p(local),
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
