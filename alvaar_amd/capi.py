@@ -73,6 +73,7 @@ _sig("alva_frontend_destroy", [_vp], None)
 _sig("alva_frontend_track", [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp])
 _sig("alva_frontend_results", [_vp] + [C.POINTER(_vp)] * 6)
 _sig("alva_frontend_sync", [_vp])
+_sig("alva_frontend_run_many", [_vp, _i, _i, _i, _vp, _i, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp])
 _sig("alva_compute_pose_enqueue", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f])
 _sig("alva_compute_pose_collect", [_vp, _vp, _vp, _vp, _vp])
 _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
@@ -444,3 +445,18 @@ def kernel_times(fn, reps: int):
         name, calls, us = line.split("\t")
         out[name] = (int(calls), float(us))
     return out
+
+
+def frontend_run_many(fes, steps, warmup, frames, pts, bearings, uv, wpts, K):
+    """fes: list of Frontend; frames: list (per stream) of [ring,H,W,4] u8 cuda tensors; pts/bearings/uv/wpts: per-stream tensors.
+    Returns (seconds, accepted poses)."""
+    n = len(fes)
+    ring = frames[0].shape[0]
+    arr = lambda ptrs: (_vp * len(ptrs))(*ptrs)
+    a_fe = arr([f.h.value for f in fes])
+    a_fr = arr([frames[s][k].data_ptr() for s in range(n) for k in range(ring)])
+    a_pts, a_bv, a_uv, a_wp = (arr([t[s].data_ptr() for s in range(n)]) for t in (pts, bearings, uv, wpts))
+    secs, acc = C.c_double(0), C.c_int(0)
+    check(lib.alva_frontend_run_many(a_fe, n, steps, warmup, a_fr, ring, frames[0].stride(1), a_pts, pts[0].shape[0], a_bv, a_uv, a_wp,
+                                     bearings[0].shape[0], K[0], K[1], K[2], K[3], C.byref(secs), C.byref(acc)))
+    return secs.value, acc.value

@@ -146,3 +146,55 @@ extern "C" int alva_frontend_sync(alva_frontend *fe) {
     if (rc) return rc;
     return alva_ctx_sync(fe->B);
 }
+
+// ---- many independent camera streams on one GPU (measurement helper) -------------------------------------------
+// One host thread per stream, each driving its own alva_frontend (two HIP streams each).  A single 640x480 stream keeps
+// the GPU a few percent busy (every stage is a short dependent chain); independent streams fill the remaining CUs.
+// d_frames[s * ring + k] is frame k of stream s; the other inputs are per stream.  *h_seconds = wall time of
+// `steps` frames per stream, started together.
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+extern "C" int alva_frontend_run_many(alva_frontend **fes, int n_streams, int steps, int warmup, const uint8_t *const *d_frames, int ring,
+                                      size_t rgba_pitch, const float *const *d_pts, int n_pts, const double *const *d_bearings,
+                                      const double *const *d_uv, const double *const *d_wpts, int n_corr, float fx, float fy, float cx,
+                                      float cy, double *h_seconds, int *h_accepted) {
+    ALVA_ARG(fes && n_streams > 0 && steps > 0 && warmup >= 0 && d_frames && ring > 0 && d_pts && d_bearings && d_uv && d_wpts && h_seconds);
+    std::atomic<int> ready{0}, go{0}, failed{0}, accepted{0};
+    std::vector<std::thread> th;
+    std::vector<std::chrono::steady_clock::time_point> t_end((size_t) n_streams);
+    auto body = [&](int s) {
+        double pose[7];
+        int st = 0, nkp = 0, ok = 0;
+        auto one = [&](int k) {
+            const int rc = alva_frontend_track(fes[s], d_frames[(size_t) s * ring + (size_t) (k % ring)], rgba_pitch, d_pts[s], n_pts,
+                                               d_bearings[s], d_uv[s], d_wpts[s], n_corr, fx, fy, cx, cy, pose, &st, &nkp);
+            if (rc) failed.store(1);
+            ok += st == 2;
+        };
+        for (int k = 0; k < warmup; k++) one(k);
+        (void) alva_frontend_sync(fes[s]);
+        ok = 0;
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        for (int k = 0; k < steps; k++) one(warmup + k);
+        (void) alva_frontend_sync(fes[s]);
+        t_end[(size_t) s] = std::chrono::steady_clock::now();
+        accepted.fetch_add(ok);
+    };
+    for (int s = 0; s < n_streams; s++) th.emplace_back(body, s);
+    while (ready.load() < n_streams) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(1, std::memory_order_release);
+    for (auto &t: th) t.join();
+    auto t1 = t0;
+    for (auto &e: t_end) t1 = e > t1 ? e : t1;
+    *h_seconds = (double) std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-9;
+    if (h_accepted) *h_accepted = accepted.load();
+    if (failed.load()) {
+        alva_set_error("alva_frontend_run_many: a stream reported an error");
+        return ALVA_ERR_STATE;
+    }
+    return ALVA_OK;
+}

@@ -166,37 +166,29 @@ class FrameJob:
 
 
 def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5):
-    """S independent camera streams on ONE GPU, each with its own HIP stream and host thread (the C ABI calls release
-    the GIL).  Every stage of a single stream is latency-bound at these sizes, so concurrent streams fill the idle CUs."""
-    import threading
-    jobs = [None] * n_streams
-    barrier = threading.Barrier(n_streams + 1)
-    times = [0.0] * n_streams
-
-    def worker(i):
-        torch.cuda.set_device(device)
-        jobs[i] = FrameJob(device, seed=7 + i, own_stream=True)
-        for _ in range(warmup):
-            jobs[i].step()
-        jobs[i].tstream.synchronize()
-        barrier.wait()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            jobs[i].step()
-        jobs[i].tstream.synchronize()
-        times[i] = time.perf_counter() - t0
-        barrier.wait()
-
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
-    for t in th:
-        t.start()
-    barrier.wait()
-    t0 = time.perf_counter()
-    barrier.wait()
-    wall = time.perf_counter() - t0
-    for t in th:
-        t.join()
-    return {"streams": n_streams, "frames_per_s": n_streams * steps / wall, "ms_per_frame_per_stream": wall / steps * 1e3}
+    """S independent camera streams on ONE GPU, each with its own alva_frontend (two HIP streams) and its own host thread
+    inside the library (alva_frontend_run_many).  Every stage of a single stream is latency-bound at these sizes, so
+    concurrent streams fill the idle CUs."""
+    import alvaar_amd
+    from alvaar_amd import capi, synth
+    dev = torch.device("cuda", device)
+    fes, frames, pts, bv, uv, wp = [], [], [], [], [], []
+    K = None
+    for s in range(n_streams):
+        fes.append(alvaar_amd.Frontend(device, W, H, NKP, 2000))
+        frames.append(torch.from_numpy(synth.stream_rgba(W, H, RING, seed=7 + s, noise=True)).to(dev))
+        pts.append(torch.from_numpy(make_keypoints(NKP, 7 + s)).to(dev))
+        pb = synth.make_pnp_problem(NKP, 7 + s, outlier_frac=0.1, pose_noise=0.01)
+        bv.append(torch.from_numpy(pb["bv"]).to(dev))
+        uv.append(torch.from_numpy(pb["uv"]).to(dev))
+        wp.append(torch.from_numpy(pb["wpt"]).to(dev))
+        K = pb["K"]
+    torch.cuda.synchronize()
+    wall, accepted = capi.frontend_run_many(fes, steps, warmup, frames, pts, bv, uv, wp, K)
+    for f in fes:
+        f.close()
+    return {"streams": n_streams, "frames_per_s": n_streams * steps / wall, "ms_per_frame_per_stream": wall / steps * 1e3,
+            "poses_accepted": accepted, "frames": n_streams * steps}
 
 
 def bench_720p(device: int, reps: int = 50):

@@ -222,6 +222,13 @@ int alva_frontend_results(alva_frontend *fe, const float **d_tracked, const uint
                           const float **d_keypoints, const uint8_t **d_descriptors, const int **d_match_idx,
                           const int **d_match_dist);
 int alva_frontend_sync(alva_frontend *fe);
+/* Measurement helper: n_streams independent camera streams on one GPU, one host thread per stream, each running `steps`
+ * alva_frontend_track calls on its own alva_frontend (d_frames[s * ring + k] = frame k of stream s; the other inputs are
+ * per-stream arrays of device pointers).  *h_seconds = wall time from the common start to the last stream's finish. */
+int alva_frontend_run_many(alva_frontend **fes, int n_streams, int steps, int warmup, const uint8_t *const *d_frames,
+                           int ring, size_t rgba_pitch, const float *const *d_pts, int n_pts,
+                           const double *const *d_bearings, const double *const *d_uv, const double *const *d_wpts,
+                           int n_corr, float fx, float fy, float cx, float cy, double *h_seconds, int *h_accepted);
 
 /* ---- a10-a13: local bundle adjustment ---------------------------------------------------------
  * Replaces the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262 on the problem
