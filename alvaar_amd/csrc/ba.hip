@@ -894,7 +894,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         if (wantJ) {
             hipLaunchKernelGGL(k_pairs, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, B);
             hipLaunchKernelGGL(k_rowcol, dim3((unsigned) n_kf), dim3(64), 0, st, B);
-            hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
+            if (B.n6 > 0) hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
             hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);
         }
         ALVA_LAUNCH_CHECK();
@@ -930,7 +930,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         const int tiles = B.NP / 16;
         hipLaunchKernelGGL(k_gemm, dim3((unsigned) (tiles * tiles), KSPLIT), dim3(64), 0, st, B);
-        {
+        if (np16 > 0) {
             const int np16i = (int) np16;
             hipLaunchKernelGGL(k_reduced_system, dim3((unsigned) alva_divup(np16i * np16i + np16i, 256)), blk, 0, st, B, lm.radius);
         }

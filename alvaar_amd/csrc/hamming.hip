@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(256) k_bf_final(const uint32_t *__restrict__ p
 
 extern "C" int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int n_query, const uint8_t *d_train,
                                      int n_train, int *d_idx, int *d_dist) {
-    ALVA_ARG(ctx && d_idx && d_dist && n_query >= 0 && n_train >= 0 && n_train < (1 << 20));
-    if (n_query == 0) return ALVA_OK;
+    ALVA_ARG(ctx && n_query >= 0 && n_train >= 0 && n_train < (1 << 20));
+    if (n_query == 0) return ALVA_OK;  // nothing to match: output pointers may be NULL
+    ALVA_ARG(d_idx && d_dist);
     ALVA_ARG(d_query && ((uintptr_t) d_query % 16) == 0);
     ALVA_ARG(n_train == 0 || (d_train && ((uintptr_t) d_train % 16) == 0));
     int chunks = alva_divup(n_train, TC);

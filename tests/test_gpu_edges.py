@@ -1,0 +1,132 @@
+"""GPU: edge cases of the C ABI -- empty and tiny inputs, points on the image border, capacity limits, flat images,
+argument errors.  Wherever the oracle defines the answer it is compared; otherwise the documented contract is checked."""
+import numpy as np
+import pytest
+
+from alvaar_amd import synth
+from oracles import Orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _gray(w, h, seed=1):
+    return synth.frame_gray(synth.texture_canvas(w + 64, h + 64, seed), 3, w, h)
+
+
+def test_empty_inputs(ctx):
+    import torch
+    import alvaar_amd
+    g = torch.from_numpy(_gray(128, 96)).cuda()
+    pyr = alvaar_amd.Pyramid(ctx, 128, 96, 9, 3)
+    pyr.build_from_gray(g)
+    z2 = torch.zeros((0, 2), dtype=torch.float32, device="cuda")
+    out, st = ctx.fbklt_track(pyr, pyr, z2, z2, 3)
+    assert out.shape == (0, 2) and st.shape == (0,)
+    out, st, err = ctx.lk_track(pyr, pyr, z2, z2, 3)
+    assert out.shape == (0, 2)
+    desc, valid = ctx.describe(g, z2)
+    assert desc.shape == (0, 32)
+    q = torch.zeros((0, 32), dtype=torch.uint8, device="cuda")
+    t = torch.randint(0, 255, (10, 32), dtype=torch.uint8, device="cuda")
+    idx, dist = ctx.bf_match_hamming(q, t)
+    assert idx.shape == (0,)
+    bv = torch.zeros((0, 3), dtype=torch.float64, device="cuda")
+    ok, R, tt, outl = ctx.p3p_lmeds(bv, bv)
+    assert not ok
+    okp, pose, o2, info = ctx.pnp_refine(torch.zeros((0, 2), dtype=torch.float64, device="cuda"), bv, np.array([0, 0, 0, 0, 0, 0, 1.0]),
+                                         (500., 500., 64., 48.))
+    assert not okp and len(o2) == 0
+
+
+def test_bf_match_single_train_and_ties(ctx):
+    import torch
+    q = torch.randint(0, 255, (70, 32), dtype=torch.uint8, device="cuda")
+    t = q[:1].clone()
+    idx, dist = ctx.bf_match_hamming(q, t)
+    i2, d2 = Orc.bf_match(q.cpu().numpy(), t.cpu().numpy())
+    assert np.array_equal(idx.cpu().numpy(), i2) and np.array_equal(dist.cpu().numpy(), d2)
+    # every train row identical: the lowest index wins (BFMatcher keeps the first minimum)
+    t = q[:1].repeat(130, 1).contiguous()
+    idx, dist = ctx.bf_match_hamming(q, t)
+    assert int(idx.max()) == 0
+
+
+def test_describe_border_points_are_flagged(ctx):
+    import torch
+    w, h = 160, 120
+    g = _gray(w, h)
+    pts = np.array([[30.4, 60], [31.0, 60], [w - 31.6, 60], [w - 32, 60], [80, 30.49], [80, 31], [80, h - 31.4], [80, h - 32]], np.float32)
+    desc, valid = ctx.describe(torch.from_numpy(g).cuda(), torch.from_numpy(pts).cuda())
+    d2, v2 = Orc.describe(g, pts)
+    assert np.array_equal(valid.cpu().numpy().astype(bool), v2.astype(bool))
+    assert np.array_equal(desc.cpu().numpy(), d2)
+    assert not valid.cpu().numpy().all() and valid.cpu().numpy().any()
+
+
+def test_klt_points_near_and_outside_the_border(ctx):
+    import torch
+    import alvaar_amd
+    w, h = 200, 152
+    c = synth.texture_canvas(w + 64, h + 64, 3)
+    a, b = synth.frame_gray(c, 2, w, h), synth.frame_gray(c, 3, w, h)
+    pa, pb = alvaar_amd.Pyramid(ctx, w, h, 9, 3), alvaar_amd.Pyramid(ctx, w, h, 9, 3)
+    pa.build_from_gray(torch.from_numpy(a).cuda())
+    pb.build_from_gray(torch.from_numpy(b).cuda())
+    pts = np.array([[0.2, 0.3], [w - 1.0, h - 1.0], [3.9, 76], [w - 4.1, 76], [100, 4.0], [100, h - 4.5], [-6.0, 50], [w + 7.5, 50], [100, 76]], np.float32)
+    out, st = ctx.fbklt_track(pa, pb, torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(), 3)
+    o2, s2 = Orc.fbklt(a, b, pts, pts, 3)
+    assert np.array_equal(st.cpu().numpy(), s2)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), o2.view(np.uint32))
+
+
+def test_flat_image_yields_nothing(ctx):
+    import torch
+    import alvaar_amd
+    w, h = 320, 240
+    g = torch.full((h, w), 117, dtype=torch.uint8, device="cuda")
+    pts, maxq = ctx.detect_grid(g, 12, max_quality=0.001)
+    assert pts.shape[0] == 0 and maxq == 0.0005          # adaptive threshold halves (:138-141)
+    orb = alvaar_amd.Orb(ctx, w, h, 500)
+    kp, desc = orb.detect_and_compute(g)
+    assert kp.shape[0] == 0 and desc.shape[0] == 0
+    xy, sc = ctx.fast(g, 20)
+    assert xy.shape[0] == 0
+
+
+def test_orb_small_budget_and_capacity(ctx):
+    import torch
+    import alvaar_amd
+    w, h = 320, 240
+    g = _gray(w, h, 9)
+    gd = torch.from_numpy(g).cuda()
+    orb = alvaar_amd.Orb(ctx, w, h, 50)
+    kp, desc = orb.detect_and_compute(gd)
+    k2, d2 = Orc.orb(g, 50)
+    assert kp.shape[0] == len(k2)
+    # a capacity smaller than the result: only `cap` rows are written, the call still succeeds
+    kp_c, desc_c = orb.detect_and_compute(gd, cap=16)
+    assert kp_c.shape[0] == 16 and torch.equal(kp_c, kp[:16])
+
+
+def test_argument_errors_are_reported(ctx):
+    import torch
+    import alvaar_amd
+    with pytest.raises(alvaar_amd.AlvaError):
+        alvaar_amd.Pyramid(ctx, 130, 96, 9, 3)            # width must be a multiple of 4
+    with pytest.raises(alvaar_amd.AlvaError):
+        alvaar_amd.Pyramid(ctx, 128, 96, 2, 3)            # window too small
+    big = torch.zeros((7200, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(alvaar_amd.AlvaError):
+        ctx.p3p_lmeds(big, big)                           # LDS-resident median: n <= 7168
+    assert "7168" in alvaar_amd.lib.alva_last_error().decode() or "n <=" in alvaar_amd.lib.alva_last_error().decode()
+
+
+def test_ba_without_points_or_with_all_cameras_fixed(ctx):
+    pb = synth.make_ba_problem(4, 60, 3)
+    pb2 = dict(pb)
+    pb2["kf_const"] = np.ones_like(pb["kf_const"])
+    r = ctx.local_ba(pb2, 5, 0.0)                          # only the points move
+    r2 = Orc.local_ba(pb2, 5, 0.0)
+    assert np.abs(r["poses"] - r2["poses"]).max() < 1e-12
+    assert np.abs(r["pts"] - r2["pts"]).max() < 1e-7 * max(1.0, np.abs(r2["pts"]).max())
+    assert int(r["info"][0]) == int(r2["info"][0])
