@@ -68,6 +68,7 @@ _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_prof_enable", [_i])
 _sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_triangulate", [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _f, _vp, _vp, _vp, _vp, _vp])
 _sig("alva_frontend_create", [_i, _i, _i, _i, _i, C.POINTER(_vp)])
 _sig("alva_frontend_destroy", [_vp], None)
 _sig("alva_frontend_track", [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp])
@@ -224,6 +225,19 @@ class Context:
         check(lib.alva_fast(self.h, _ptr(gray), gray.stride(0), w, h, threshold, _ptr(xy), _ptr(sc), cap, C.byref(cnt)))
         n = min(cnt.value, cap)
         return xy[:n], sc[:n]
+
+    # f2a
+    def triangulate(self, T, group, bvl, bvr, unpxl, unpxr, K, max_reproj_err=3.0):
+        """Mapper::triangulateTemporal per keypoint: returns dict(lpt, wpt, inv_depth, status, parallax) of cuda tensors."""
+        n = bvl.shape[0]
+        dev = bvl.device
+        out = dict(lpt=torch.empty((n, 3), dtype=torch.float64, device=dev), wpt=torch.empty((n, 3), dtype=torch.float64, device=dev),
+                   inv_depth=torch.empty(n, dtype=torch.float64, device=dev), status=torch.empty(n, dtype=torch.uint8, device=dev),
+                   parallax=torch.empty(n, dtype=torch.float64, device=dev))
+        check(lib.alva_triangulate(self.h, n, _ptr(T), T.shape[0], _ptr(group), _ptr(bvl), _ptr(bvr), _ptr(unpxl), _ptr(unpxr),
+                                   K[0], K[1], K[2], K[3], max_reproj_err, _ptr(out["lpt"]), _ptr(out["wpt"]), _ptr(out["inv_depth"]),
+                                   _ptr(out["status"]), _ptr(out["parallax"])))
+        return out
 
     def wait_for(self, producer: "Context"):
         """stream-order dependency on another context's enqueued work (no host wait)"""

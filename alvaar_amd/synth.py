@@ -209,3 +209,49 @@ def make_ba_problem(n_kf: int = 20, n_pt: int = 3000, seed: int = 42, fx: float 
     return dict(poses=poses, poses_gt=poses_gt, kf_const=kf_const, calib=K,
                 anchor_kf=akf, anchor_uv=auv, inv_depth=rho, pts_xyz=pts_xyz,
                 pts_gt=pts[used].copy(), obs_kf=obs_kf, obs_pt=remap[obs_pt].copy(), obs_uv=obs_uv)
+
+
+def make_triangulation_problem(n: int, n_groups: int, seed: int, px_noise: float = 0.4, bad_frac: float = 0.15):
+    """A new keyframe + n_groups earlier keyframes observing n points: Twc poses (pose7), unit bearings, pixel observations,
+    group index per point.  A fraction of the points gets a gross pixel error or sits behind / very close to a camera, so that
+    all three status values occur."""
+    rng = np.random.RandomState(seed)
+    fx = fy = 520.0
+    cx, cy = 320.0, 240.0
+
+    def pose(center, yaw):
+        R = so3_exp(np.array([0.03 * rng.randn(), yaw, 0.02 * rng.randn()]))
+        q = _quat_from_R(R)
+        return np.concatenate([center, q]), R
+    pose_new, Rn = pose(np.array([0.6, 0.05, 0.1]), 0.05)
+    pose_kf, Rk = [], []
+    for g in range(n_groups):
+        p, R = pose(np.array([-0.3 - 0.25 * g, 0.02 * rng.randn(), 0.05 * rng.randn()]), -0.04 * g)
+        pose_kf.append(p)
+        Rk.append(R)
+    pose_kf = np.array(pose_kf)
+    group = rng.randint(0, n_groups, n).astype(np.int32)
+    X = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(2.5, 12, n)], 1)
+    bad = rng.rand(n) < bad_frac
+    bvl, bvr, ul, ur = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32)
+    for i in range(n):
+        g = group[i]
+        pl = Rk[g].T @ (X[i] - pose_kf[g][:3])
+        pr = Rn.T @ (X[i] - pose_new[:3])
+        for p, bv, u in ((pl, bvl, ul), (pr, bvr, ur)):
+            z = p[2] if abs(p[2]) > 1e-3 else 1e-3
+            px = np.array([fx * p[0] / z + cx, fy * p[1] / z + cy]) + px_noise * rng.randn(2)
+            if bad[i] and rng.rand() < 0.5:
+                px += rng.uniform(-25, 25, 2)
+            u[i] = px.astype(np.float32)
+            b = np.array([(u[i, 0] - cx) / fx, (u[i, 1] - cy) / fy, 1.0])
+            if bad[i] and rng.rand() < 0.15:
+                b[2] = -1.0     # a bearing that points backwards: triangulates behind the camera
+            bv[i] = b / np.linalg.norm(b)
+    return dict(pose_kf=pose_kf, pose_new=pose_new, group=group, bvl=bvl, bvr=bvr, unpxl=ul, unpxr=ur, K=(fx, fy, cx, cy))
+
+
+def _quat_from_R(R):
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(R).as_quat()
+    return q if q[3] >= 0 else -q

@@ -200,6 +200,21 @@ int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const dou
 int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
                               int *h_status);
 
+/* ---- f2a: triangulation of a new keyframe's 2-D keypoints -------------------------------------
+ * Replaces the per-keypoint arithmetic of Mapper::triangulateTemporal (src/slam/src/mapper.cpp:222-287):
+ * MultiViewGeometry::triangulate (= opengv::triangulation::triangulate2, opengv/src/triangulation/methods.cpp:67-90),
+ * the rotation-compensated parallax (:246-248), the cheirality gate z < 0.1 (:256) and the reprojection gate (:266-272).
+ * The caller groups the points by the keyframe that first observed them: d_T holds one block of 36 doubles per group,
+ * { R_lr[9], t_lr[3], R_rl[9], t_rl[3], R_wl[9], t_wl[3] } row-major (l = that keyframe, r = the new keyframe,
+ * w = world; T_lr = T_lw * T_wr, :226-228), d_group[i] selects the block of point i.  d_bv_*: unit bearings (n x 3 f64),
+ * d_unpx_*: undistorted pixels (n x 2 f32).  Outputs per point: point in the l camera, world point, inverse depth
+ * 1 / z_l, status (0 = accepted, 1 = behind a camera, 2 = reprojection error), parallax in pixels (the reference drops
+ * the observation of rejected points whose parallax exceeds 20, :258-262/:274-278 -- host bookkeeping).  Enqueue only. */
+int alva_triangulate(alva_ctx *ctx, int n, const double *d_T, int n_groups, const int *d_group, const double *d_bv_l,
+                     const double *d_bv_r, const float *d_unpx_l, const float *d_unpx_r, double fx, double fy, double cx,
+                     double cy, float max_reproj_err, double *d_lpt, double *d_wpt, double *d_inv_depth,
+                     uint8_t *d_status, double *d_parallax);
+
 /* ---- per-frame driver: the caller of a2-a9 -------------------------------------------------------------------
  * Mirrors the order of VisualFrontend::trackMono (src/slam/src/visual_frontend.cpp:83-150): preprocessImage (:672-698)
  * -> kltTracking (:152-243) -> computePose (:245-417), plus the keyframe branch's feature work

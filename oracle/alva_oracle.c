@@ -2099,3 +2099,63 @@ int orc_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures,
     free(lv); free(lw); free(lh); free(lscale); free(nPer);
     return total;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * f2a: triangulation of the 2-D keypoints of a new keyframe against their first observation
+ * (Mapper::triangulateTemporal, src/slam/src/mapper.cpp:246-287).  Pure per-point arithmetic in IEEE double, with the
+ * reference's float conversions where it returns cv::Point2f (CameraCalibration::projectCamToImage,
+ * camera_calibration.cpp:25-32) and cv::norm(Point2f) = sqrt of the double-promoted squares (core/types.hpp). */
+static void tri_matvec(const double *R, const double *v, double *o) {
+    for (int i = 0; i < 3; i++) o[i] = (R[3 * i] * v[0] + R[3 * i + 1] * v[1]) + R[3 * i + 2] * v[2];  /* Eigen 3-term redux order */
+}
+static double tri_dot(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static void tri_project(const double *p, double fx, double fy, double cx, double cy, float *u, float *v) {
+    const double iz = 1. / p[2], x = p[0] * iz, y = p[1] * iz;
+    *u = (float) (fx * x + cx);
+    *v = (float) (fy * y + cy);
+}
+static double tri_norm2f(float dx, float dy) { return sqrt((double) dx * (double) dx + (double) dy * (double) dy); }
+
+void orc_triangulate(int n, const double *T, const int *group, const double *bvl, const double *bvr, const float *unpxl,
+                     const float *unpxr, double fx, double fy, double cx, double cy, float maxReprojErr, double *lpt, double *wpt,
+                     double *invDepth, uint8_t *status, double *parallax) {
+    for (int i = 0; i < n; i++) {
+        const double *G = T + 36 * (size_t) group[i];
+        const double *Rlr = G, *tlr = G + 9, *Rrl = G + 12, *trl = G + 21, *Rwl = G + 24, *twl = G + 33;
+        const double *f1 = bvl + 3 * i, *f2 = bvr + 3 * i;
+        /* rotation-compensated parallax (:246-248) */
+        double f2u[3];
+        tri_matvec(Rlr, f2, f2u);
+        float ru, rv;
+        tri_project(f2u, fx, fy, cx, cy, &ru, &rv);
+        parallax[i] = tri_norm2f(unpxl[2 * i] - ru, unpxl[2 * i + 1] - rv);
+        /* opengv::triangulation::triangulate2 (methods.cpp:67-90), A.inverse() = Eigen's closed 2x2 form */
+        const double b0 = tri_dot(tlr, f1), b1 = tri_dot(tlr, f2u);
+        const double a00 = tri_dot(f1, f1), a10 = tri_dot(f1, f2u), a01 = -a10, a11 = -tri_dot(f2u, f2u);
+        const double invdet = 1.0 / (a00 * a11 - a10 * a01);
+        const double i00 = a11 * invdet, i10 = -a10 * invdet, i01 = -a01 * invdet, i11 = a00 * invdet;
+        const double l0 = i00 * b0 + i01 * b1, l1 = i10 * b0 + i11 * b1;
+        double lp[3], rp[3], wp[3], t[3];
+        for (int k = 0; k < 3; k++) lp[k] = (l0 * f1[k] + (tlr[k] + l1 * f2u[k])) / 2;
+        tri_matvec(Rrl, lp, t);
+        for (int k = 0; k < 3; k++) rp[k] = t[k] + trl[k];
+        tri_matvec(Rwl, lp, t);
+        for (int k = 0; k < 3; k++) wp[k] = t[k] + twl[k];
+        for (int k = 0; k < 3; k++) {
+            lpt[3 * i + k] = lp[k];
+            wpt[3 * i + k] = wp[k];
+        }
+        invDepth[i] = 1. / lp[2];
+        uint8_t st = 0;
+        if (lp[2] < 0.1 || rp[2] < 0.1) st = 1; /* :256 */
+        else {
+            float lu, lv, pu, pv;
+            tri_project(lp, fx, fy, cx, cy, &lu, &lv);
+            tri_project(rp, fx, fy, cx, cy, &pu, &pv);
+            const float lDist = (float) tri_norm2f(lu - unpxl[2 * i], lv - unpxl[2 * i + 1]);
+            const float rDist = (float) tri_norm2f(pu - unpxr[2 * i], pv - unpxr[2 * i + 1]);
+            if (lDist > maxReprojErr || rDist > maxReprojErr) st = 2; /* :272 */
+        }
+        status[i] = st;
+    }
+}

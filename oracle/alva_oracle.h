@@ -60,3 +60,11 @@ int orc_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *c
 }
 #endif
 #endif
+
+/* f2a: the numeric part of Mapper::triangulateTemporal per keypoint (mapper.cpp:246-287): OpenGV triangulate2
+ * (opengv/src/triangulation/methods.cpp:67-90), cheirality and reprojection gates.
+ * T: nGroups x 36 doubles = { R_lr[9], t_lr[3], R_rl[9], t_rl[3], R_wl[9], t_wl[3] } (row-major; l = the keyframe that first
+ * observed the point, r = the new keyframe, w = world).  status: 0 accepted, 1 behind a camera (z < 0.1), 2 reprojection error. */
+void orc_triangulate(int n, const double *T, const int *group, const double *bvl, const double *bvr, const float *unpxl,
+                     const float *unpxr, double fx, double fy, double cx, double cy, float maxReprojErr, double *lpt, double *wpt,
+                     double *invDepth, uint8_t *status, double *parallax);

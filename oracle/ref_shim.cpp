@@ -466,3 +466,55 @@ int ref_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *c
 }
 
 }  // extern "C"
+
+// f2a: the per-keypoint part of Mapper::triangulateTemporal (mapper.cpp:222-287) with the reference's own pieces:
+// Sophus for the relative motions, MultiViewGeometry::triangulate (= OpenGV triangulate2),
+// CameraCalibration::projectCamToImage for the projections.  poseKf: nGroups x 7 (Twc of the first-observing keyframes),
+// poseNew: 7 (Twc of the new keyframe).  Also exports the rotation matrices / translations it used (T: nGroups x 36).
+extern "C" void ref_triangulate(int n, int nGroups, const double *poseKf, const double *poseNew, const int *group, const double *bvl,
+                                const double *bvr, const float *unpxl, const float *unpxr, double fx, double fy, double cx, double cy,
+                                float maxReprojErr, double *T, double *lpt, double *wpt, double *invDepth, uint8_t *status,
+                                double *parallax) {
+    CameraCalibration cal(fx, fy, cx, cy, 0., 0., 0., 0., 640., 480., 1.);
+    auto se3 = [](const double *p) {
+        return Sophus::SE3d(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), Eigen::Vector3d(p[0], p[1], p[2]));
+    };
+    const Sophus::SE3d Twcj = se3(poseNew);
+    std::vector<Sophus::SE3d, Eigen::aligned_allocator<Sophus::SE3d>> Tlr(nGroups), Trl(nGroups), Twl(nGroups);
+    for (int g = 0; g < nGroups; g++) {
+        Twl[g] = se3(poseKf + 7 * g);
+        Tlr[g] = Twl[g].inverse() * Twcj;   // Tcicj = Tciw * Twcj (:226-227)
+        Trl[g] = Tlr[g].inverse();
+        const Sophus::SE3d *S[3] = {&Tlr[g], &Trl[g], &Twl[g]};
+        for (int k = 0; k < 3; k++) {
+            const Eigen::Matrix3d R = S[k]->rotationMatrix();
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) T[36 * g + 12 * k + 3 * r + c] = R(r, c);
+            for (int r = 0; r < 3; r++) T[36 * g + 12 * k + 9 + r] = S[k]->translation()(r);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const int g = group[i];
+        const Eigen::Vector3d f1(bvl[3 * i], bvl[3 * i + 1], bvl[3 * i + 2]), f2(bvr[3 * i], bvr[3 * i + 1], bvr[3 * i + 2]);
+        const cv::Point2f ul(unpxl[2 * i], unpxl[2 * i + 1]), ur(unpxr[2 * i], unpxr[2 * i + 1]);
+        const Eigen::Matrix3d Rcicj = Tlr[g].rotationMatrix();
+        const cv::Point2f rotPx = cal.projectCamToImage(Rcicj * f2);
+        parallax[i] = cv::norm(ul - rotPx);
+        const Eigen::Vector3d lPoint = MultiViewGeometry::triangulate(Tlr[g], f1, f2);
+        const Eigen::Vector3d rPoint = Trl[g] * lPoint;
+        const Eigen::Vector3d w = Twl[g] * lPoint;
+        for (int k = 0; k < 3; k++) {
+            lpt[3 * i + k] = lPoint(k);
+            wpt[3 * i + k] = w(k);
+        }
+        invDepth[i] = 1. / lPoint.z();
+        uint8_t st = 0;
+        if (lPoint.z() < 0.1 || rPoint.z() < 0.1) st = 1;
+        else {
+            const cv::Point2f lPx = cal.projectCamToImage(lPoint), rPx = cal.projectCamToImage(rPoint);
+            const float lDist = cv::norm(lPx - ul), rDist = cv::norm(rPx - ur);
+            if (lDist > maxReprojErr || rDist > maxReprojErr) st = 2;
+        }
+        status[i] = st;
+    }
+}

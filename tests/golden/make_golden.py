@@ -68,5 +68,14 @@ def main():
     print("wrote", [p.name for p in OUT.glob("*.npz")])
 
 
+def triangulation():
+    from oracles import ref_triangulate
+    pb = synth.make_triangulation_problem(200, 3, 11)
+    ref, T = ref_triangulate(pb["pose_kf"], pb["pose_new"], pb["group"], pb["bvl"], pb["bvr"], pb["unpxl"], pb["unpxr"], pb["K"])
+    np.savez_compressed(OUT / "triangulate.npz", T=T, group=pb["group"], bvl=pb["bvl"], bvr=pb["bvr"], unpxl=pb["unpxl"], unpxr=pb["unpxr"],
+                        K=np.array(pb["K"]), pose_kf=pb["pose_kf"], pose_new=pb["pose_new"], **{"out_" + k: v for k, v in ref.items()})
+
+
 if __name__ == "__main__":
+    triangulation()
     main()

@@ -242,6 +242,38 @@ class Orc:
         return desc, valid
 
 
+def _tri_out(n):
+    return dict(lpt=np.zeros((n, 3)), wpt=np.zeros((n, 3)), inv_depth=np.zeros(n), status=np.zeros(n, np.uint8), parallax=np.zeros(n))
+
+
+def orc_triangulate(T, group, bvl, bvr, unpxl, unpxr, K, max_err=3.0):
+    """oracle restatement of the per-keypoint part of Mapper::triangulateTemporal"""
+    n = len(bvl)
+    o = _tri_out(n)
+    T, group = np.ascontiguousarray(T, np.float64), np.ascontiguousarray(group, np.int32)
+    bvl, bvr = np.ascontiguousarray(bvl, np.float64), np.ascontiguousarray(bvr, np.float64)
+    unpxl, unpxr = np.ascontiguousarray(unpxl, np.float32), np.ascontiguousarray(unpxr, np.float32)
+    orc_lib().orc_triangulate(n, _p(T), _p(group), _p(bvl), _p(bvr), _p(unpxl), _p(unpxr), _d(K[0]), _d(K[1]), _d(K[2]), _d(K[3]),
+                              _f(max_err), _p(o["lpt"]), _p(o["wpt"]), _p(o["inv_depth"]), _p(o["status"]), _p(o["parallax"]))
+    return o
+
+
+def ref_triangulate(pose_kf, pose_new, group, bvl, bvr, unpxl, unpxr, K, max_err=3.0):
+    """the reference's own pieces (Sophus, MultiViewGeometry::triangulate, CameraCalibration); also returns the transform
+    blocks T [nGroups, 36] it used"""
+    n, ng = len(bvl), len(pose_kf)
+    o = _tri_out(n)
+    T = np.zeros((ng, 36))
+    pose_kf, pose_new = np.ascontiguousarray(pose_kf, np.float64), np.ascontiguousarray(pose_new, np.float64)
+    group = np.ascontiguousarray(group, np.int32)
+    bvl, bvr = np.ascontiguousarray(bvl, np.float64), np.ascontiguousarray(bvr, np.float64)
+    unpxl, unpxr = np.ascontiguousarray(unpxl, np.float32), np.ascontiguousarray(unpxr, np.float32)
+    ref_lib().ref_triangulate(n, ng, _p(pose_kf), _p(pose_new), _p(group), _p(bvl), _p(bvr), _p(unpxl), _p(unpxr), _d(K[0]), _d(K[1]),
+                              _d(K[2]), _d(K[3]), _f(max_err), _p(T), _p(o["lpt"]), _p(o["wpt"]), _p(o["inv_depth"]), _p(o["status"]),
+                              _p(o["parallax"]))
+    return o, T
+
+
 class Ref:
     """The compiled reference (OpenCV 4.5.5 / Ceres 2.0.0 / OpenGV / AlvaAR slam sources)."""
     _pfx = "ref_"
