@@ -68,6 +68,7 @@ _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_prof_enable", [_i])
 _sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_clahe", [_vp, _vp, _sz, _i, _i, C.c_double, _i, _i, _vp, _sz])
 _sig("alva_triangulate", [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _f, _vp, _vp, _vp, _vp, _vp])
 _sig("alva_frontend_create", [_i, _i, _i, _i, _i, C.POINTER(_vp)])
 _sig("alva_frontend_destroy", [_vp], None)
@@ -225,6 +226,15 @@ class Context:
         check(lib.alva_fast(self.h, _ptr(gray), gray.stride(0), w, h, threshold, _ptr(xy), _ptr(sc), cap, C.byref(cnt)))
         n = min(cnt.value, cap)
         return xy[:n], sc[:n]
+
+    # f4a
+    def clahe(self, gray, clip_limit=3.0, tiles=None, tile_size=50):
+        """cv::createCLAHE(clip, tiles)->apply; default grid = size / 50 as VisualFrontend builds it"""
+        h, w = gray.shape
+        tx, ty = tiles if tiles is not None else (w // tile_size, h // tile_size)
+        out = torch.empty_like(gray)
+        check(lib.alva_clahe(self.h, _ptr(gray), gray.stride(0), w, h, float(clip_limit), int(tx), int(ty), _ptr(out), out.stride(0)))
+        return out
 
     # f2a
     def triangulate(self, T, group, bvl, bvr, unpxl, unpxr, K, max_reproj_err=3.0):

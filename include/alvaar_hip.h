@@ -200,6 +200,15 @@ int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const dou
 int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
                               int *h_status);
 
+/* ---- f4a: CLAHE ------------------------------------------------------------------------------
+ * Replaces cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply(src, dst) for 8-bit images
+ * (imgproc/src/clahe.cpp:120-420), which VisualFrontend::preprocessImage runs when claheEnabled_
+ * (src/slam/src/visual_frontend.cpp:16-18 with clip 3 and tiles = size / 50, :678-681; off in the shipped
+ * configuration, system.cpp:17).  Bit-exact, including the REFLECT_101 extension for sizes that the grid does not divide.
+ * d_dst may not alias d_src.  Enqueue only. */
+int alva_clahe(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int width, int height, double clip_limit,
+               int tiles_x, int tiles_y, uint8_t *d_dst, size_t dst_pitch);
+
 /* ---- f2a: triangulation of a new keyframe's 2-D keypoints -------------------------------------
  * Replaces the per-keypoint arithmetic of Mapper::triangulateTemporal (src/slam/src/mapper.cpp:222-287):
  * MultiViewGeometry::triangulate (= opengv::triangulation::triangulate2, opengv/src/triangulation/methods.cpp:67-90),

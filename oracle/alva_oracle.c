@@ -2159,3 +2159,82 @@ void orc_triangulate(int n, const double *T, const int *group, const double *bvl
         status[i] = st;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * f4a: CLAHE, 8-bit (imgproc/src/clahe.cpp).  Integer histogram / clip / redistribution, LUT = saturate_cast<uchar>(sum *
+ * lutScale) (float product, round half to even), bilinear blend of the four neighbouring tile LUTs in float with the
+ * reference's operation order. */
+static int clahe_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+static uint8_t clahe_sat_u8(float v) {
+    int r = (int) lrintf(v); /* cvRound: round half to even (default rounding mode) */
+    return (uint8_t) (r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+void orc_clahe(const uint8_t *src, int w, int h, double clipLimitD, int tilesX, int tilesY, uint8_t *dst) {
+    int ew = w, eh = h; /* extended size (copyMakeBorder right / bottom, REFLECT_101) when not divisible (:364-384) */
+    if (!(w % tilesX == 0 && h % tilesY == 0)) {
+        ew = w + (tilesX - (w % tilesX));
+        eh = h + (tilesY - (h % tilesY));
+    }
+    const int tw = ew / tilesX, th = eh / tilesY, total = tw * th;
+    const float lutScale = (float) (256 - 1) / total;
+    int clipLimit = 0;
+    if (clipLimitD > 0.0) {
+        clipLimit = (int) (clipLimitD * total / 256);
+        if (clipLimit < 1) clipLimit = 1;
+    }
+    uint8_t *lut = (uint8_t *) malloc((size_t) tilesX * tilesY * 256);
+    for (int k = 0; k < tilesX * tilesY; k++) {
+        const int ty = k / tilesX, tx = k % tilesX;
+        int hist[256] = {0};
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < tw; x++) {
+                const int sx = clahe_reflect101(tx * tw + x, w), sy = clahe_reflect101(ty * th + y, h);
+                hist[src[(size_t) sy * w + sx]]++;
+            }
+        if (clipLimit > 0) {
+            int clipped = 0;
+            for (int i = 0; i < 256; i++)
+                if (hist[i] > clipLimit) {
+                    clipped += hist[i] - clipLimit;
+                    hist[i] = clipLimit;
+                }
+            const int batch = clipped / 256;
+            int residual = clipped - batch * 256;
+            for (int i = 0; i < 256; i++) hist[i] += batch;
+            if (residual != 0) {
+                int step = 256 / residual;
+                if (step < 1) step = 1;
+                for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+            }
+        }
+        int sum = 0;
+        for (int i = 0; i < 256; i++) {
+            sum += hist[i];
+            lut[(size_t) k * 256 + i] = clahe_sat_u8((float) sum * lutScale);
+        }
+    }
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    for (int y = 0; y < h; y++) {
+        const float tyf = y * inv_th - 0.5f;
+        int ty1 = (int) floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > tilesY - 1) ty2 = tilesY - 1;
+        for (int x = 0; x < w; x++) {
+            const float txf = x * inv_tw - 0.5f;
+            int tx1 = (int) floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > tilesX - 1) tx2 = tilesX - 1;
+            const int v = src[(size_t) y * w + x];
+            const uint8_t *p1 = lut + (size_t) (ty1 * tilesX) * 256, *p2 = lut + (size_t) (ty2 * tilesX) * 256;
+            const float res = (p1[tx1 * 256 + v] * xa1 + p1[tx2 * 256 + v] * xa) * ya1 + (p2[tx1 * 256 + v] * xa1 + p2[tx2 * 256 + v] * xa) * ya;
+            dst[(size_t) y * w + x] = clahe_sat_u8(res);
+        }
+    }
+    free(lut);
+}

@@ -68,3 +68,7 @@ int orc_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *c
 void orc_triangulate(int n, const double *T, const int *group, const double *bvl, const double *bvr, const float *unpxl,
                      const float *unpxr, double fx, double fy, double cx, double cy, float maxReprojErr, double *lpt, double *wpt,
                      double *invDepth, uint8_t *status, double *parallax);
+
+/* f4a: cv::createCLAHE(clipLimit, Size(tilesX, tilesY))->apply on an 8-bit image (imgproc/src/clahe.cpp:120-420), as
+ * VisualFrontend::preprocessImage calls it when claheEnabled_ (visual_frontend.cpp:16-18, :678-681). */
+void orc_clahe(const uint8_t *src, int w, int h, double clipLimit, int tilesX, int tilesY, uint8_t *dst);

@@ -518,3 +518,12 @@ extern "C" void ref_triangulate(int n, int nGroups, const double *poseKf, const 
         status[i] = st;
     }
 }
+
+// f4a: cv::createCLAHE(clipLimit, Size(tilesX, tilesY))->apply, as VisualFrontend's constructor / preprocessImage use it
+// (visual_frontend.cpp:16-18, :678-681).
+extern "C" void ref_clahe(const uint8_t *src, int w, int h, double clipLimit, int tilesX, int tilesY, uint8_t *dst) {
+    cv::Mat s(h, w, CV_8UC1, const_cast<uint8_t *>(src)), d;
+    cv::Ptr<cv::CLAHE> c = cv::createCLAHE(clipLimit, cv::Size(tilesX, tilesY));
+    c->apply(s, d);
+    for (int y = 0; y < h; y++) std::memcpy(dst + (size_t) y * w, d.ptr<uint8_t>(y), (size_t) w);
+}

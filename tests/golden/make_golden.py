@@ -76,6 +76,13 @@ def triangulation():
                         K=np.array(pb["K"]), pose_kf=pb["pose_kf"], pose_new=pb["pose_new"], **{"out_" + k: v for k, v in ref.items()})
 
 
+def clahe():
+    from oracles import ref_clahe
+    g = img(160, 120, 21)
+    np.savez_compressed(OUT / "clahe.npz", g=g, clip=np.float64(3.0), tiles=np.array([3, 2]), out=ref_clahe(g, 3.0, (3, 2)))
+
+
 if __name__ == "__main__":
     triangulation()
+    clahe()
     main()

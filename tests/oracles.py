@@ -242,6 +242,20 @@ class Orc:
         return desc, valid
 
 
+def orc_clahe(gray, clip=3.0, tiles=(12, 9)):
+    g = np.ascontiguousarray(gray)
+    out = np.empty_like(g)
+    orc_lib().orc_clahe(_p(g), g.shape[1], g.shape[0], _d(float(clip)), int(tiles[0]), int(tiles[1]), _p(out))
+    return out
+
+
+def ref_clahe(gray, clip=3.0, tiles=(12, 9)):
+    g = np.ascontiguousarray(gray)
+    out = np.empty_like(g)
+    ref_lib().ref_clahe(_p(g), g.shape[1], g.shape[0], _d(float(clip)), int(tiles[0]), int(tiles[1]), _p(out))
+    return out
+
+
 def _tri_out(n):
     return dict(lpt=np.zeros((n, 3)), wpt=np.zeros((n, 3)), inv_depth=np.zeros(n), status=np.zeros(n, np.uint8), parallax=np.zeros(n))
 
