@@ -15,6 +15,9 @@
 // stay resident; the frame and the correspondences are device pointers supplied by the caller.
 #include "common.hpp"
 
+int alva_fbklt_track_to(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
+                        int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, int n);
+
 struct alva_frontend {
     int device = 0, width = 0, height = 0, n_track = 0, cap = 0;
     alva_ctx *A = nullptr, *B = nullptr;
@@ -96,9 +99,8 @@ extern "C" int alva_frontend_track(alva_frontend *fe, const uint8_t *d_rgba, siz
     // lane A: kltTracking (prior = previous positions, feature_tracker.cpp:5-111) -- from the second frame on
     if (fe->frame > 0 && n_pts > 0) {
         ALVA_ARG(d_pts);
-        ALVA_HIP(hipMemcpyAsync(fe->d_prior, d_pts, (size_t) n_pts * 2 * sizeof(float), hipMemcpyDeviceToDevice, fe->A->stream));
-        rc = alva_fbklt_track(fe->A, fe->pyr[prv], fe->pyr[cur], fe->klt_levels, 30.f, 0.5f, 30, 0.01f, d_pts, fe->d_prior, fe->d_status,
-                              n_pts);  // state.hpp:55-59
+        rc = alva_fbklt_track_to(fe->A, fe->pyr[prv], fe->pyr[cur], fe->klt_levels, 30.f, 0.5f, 30, 0.01f, d_pts, d_pts, fe->d_prior,
+                                 fe->d_status, n_pts);  // state.hpp:55-59; prior = the previous positions, result in d_prior
         if (rc) return rc;
     }
     // lane A: computePose (state.hpp:64-76: 100 LMedS iterations, 3 px, chi2 5.9915, 5 LM iterations)

@@ -244,8 +244,9 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
 // mode 0: plain calcOpticalFlowPyrLK (next in/out, status, err).
 // mode 1: FeatureTracker::fbKltTracking (prior in/out, status).
 __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxLevel, int maxCount, double epsilon, float errThresh,
-                                            float fbDist, const float *__restrict__ pts, float *__restrict__ nextio,
-                                            uint8_t *__restrict__ status_out, float *__restrict__ err_out, int n) {
+                                            float fbDist, const float *__restrict__ pts, const float *init,
+                                            float *nextio, uint8_t *__restrict__ status_out, float *__restrict__ err_out,
+                                            int n) {
     __shared__ LkShared sh;
     // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Giving every XCD one CONTIGUOUS
     // eighth of the keypoint list (callers keep keypoints in spatial / grid order) keeps an image region in one L2
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxL
     const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (kp >= n) return;
     const float ptx = pts[2 * kp], pty = pts[2 * kp + 1];
-    float nx = nextio[2 * kp], ny = nextio[2 * kp + 1];
+    float nx = init[2 * kp], ny = init[2 * kp + 1];  // initial flow; may be the same buffer as the output
     int status = 1;
     float err = 0.f;
     for (int level = maxLevel; level >= 0; level--)
@@ -307,10 +308,10 @@ int fill_pyr(const alva_pyramid *p, LkPyr &out) {
 }
 
 int launch(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int mode, int num_levels, int max_iters, float eps,
-           float err_thresh, float fb_dist, const float *d_pts, float *d_nextio, uint8_t *d_status, float *d_err, int n) {
+           float err_thresh, float fb_dist, const float *d_pts, const float *d_init, float *d_nextio, uint8_t *d_status, float *d_err, int n) {
     ALVA_ARG(ctx && prev && curr && n >= 0 && num_levels >= 0);
     if (n == 0) return ALVA_OK;
-    ALVA_ARG(d_pts && d_nextio && d_status);
+    ALVA_ARG(d_pts && d_init && d_nextio && d_status);
     ALVA_ARG(prev->win == WIN && curr->win == WIN);  // kltWinSizeWH_ = 9 (state.hpp:53); the lane layout is specific to it
     ALVA_ARG(prev->nlevels == curr->nlevels && prev->lv[0].w == curr->lv[0].w && prev->lv[0].h == curr->lv[0].h);
     LkPyr P, C;
@@ -323,7 +324,7 @@ int launch(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, in
     epsilon = epsilon < 0 ? 0 : (epsilon > 10 ? 10 : epsilon);
     epsilon *= epsilon;  // :1365
     hipLaunchKernelGGL(k_klt, dim3(8 * alva_divup(n, 8)), dim3(64), 0, ctx->stream, P, C, mode, maxLevel, maxCount, epsilon, err_thresh, fb_dist, d_pts,
-                       d_nextio, d_status, d_err, n);
+                       d_init, d_nextio, d_status, d_err, n);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }
@@ -333,11 +334,18 @@ int launch(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, in
 extern "C" int alva_lk_track(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *next, int num_levels, int max_iters,
                              float eps, const float *d_pts, float *d_next, uint8_t *d_status, float *d_err, int n) {
     ALVA_ARG(n == 0 || d_err);
-    return launch(ctx, prev, next, 0, num_levels, max_iters, eps, 0.f, 0.f, d_pts, d_next, d_status, d_err, n);
+    return launch(ctx, prev, next, 0, num_levels, max_iters, eps, 0.f, 0.f, d_pts, d_next, d_next, d_status, d_err, n);
 }
 
 extern "C" int alva_fbklt_track(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh,
                                 float fb_dist, int max_iters, float eps, const float *d_pts, float *d_prior, uint8_t *d_status,
                                 int n) {
-    return launch(ctx, prev, curr, 1, num_levels, max_iters, eps, err_thresh, fb_dist, d_pts, d_prior, d_status, nullptr, n);
+    return launch(ctx, prev, curr, 1, num_levels, max_iters, eps, err_thresh, fb_dist, d_pts, d_prior, d_prior, d_status, nullptr, n);
+}
+
+// alva_fbklt_track with the prior read from one buffer and the result written to another (internal: the per-frame driver
+// tracks from the caller's keypoint buffer without first copying it)
+int alva_fbklt_track_to(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
+                        int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, int n) {
+    return launch(ctx, prev, curr, 1, num_levels, max_iters, eps, err_thresh, fb_dist, d_pts, d_prior_in, d_out, d_status, nullptr, n);
 }
