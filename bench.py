@@ -7,8 +7,12 @@ Hamming match+PnP full track") over one synthetic frame whose RGBA bytes are ALR
     forward-backward KLT of the previous frame's keypoints, 3 pyramid levels        (a4)
     FAST-pyramid + ORB detectAndCompute, nfeatures 2000, 8 levels (the north_star-named detector)   (a5', a6)
     brute-force Hamming match of the new descriptors against the previous frame's  (a7)
-    P3P + LMedS (100 hypotheses) and robust PnP refinement (5 LM iterations) on ~2000 3-D/2-D pairs (a8, a9)
-`value` = frames/s over all ranks (streams are independent: one per GPU, no collective on the data path).
+    P3P + LMedS (100 hypotheses) -> drop its outliers -> robust PnP refinement (5 LM iterations) on ~2000 3-D/2-D pairs,
+    chained as VisualFrontend::computePose chains them                                                    (a8, a9)
+The frame is issued by the native driver alva_frontend_track (C++ host loop in trackMono order): tracker + pose on one
+HIP stream, detector + matcher on a second one.  `value` = frames/s over all ranks (streams are independent: one per
+GPU, no collective on the data path).  The same frame issued call by call from Python ("python_host_two_streams") and
+on a single HIP stream ("one_hip_stream") is reported next to it.
 The same loop with the REFERENCE-ACTUAL detector (grid Shi-Tomasi, cell 12 => 2120 keypoints, + cornerSubPix + ORB
 description of those points; a5 + a6) is timed as well and reported as "ref_detector_variant".
 The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3000 pts, 5 LM iterations), is
@@ -374,7 +378,8 @@ def main():
             "dtype": "u8/i16 image stages, f32 KLT, f64 pose+BA", "data": "synthetic",
             "config": {"workload": "configs[1]: 640x480 RGBA stream, ORB 2000 kp/frame, FAST+ORB+Hamming match+KLT+PnP full track",
                        "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels, 2120 pts)", "orb_detect_and_compute(2000, 1.2, 8)",
-                                  "bf_hamming ~2000x2000", "p3p_lmeds(100 it, 2120 pts)", "pnp_refine(5 it, 2120 pts)"],
+                                  "bf_hamming ~2000x2000", "compute_pose = p3p_lmeds(100 it, 2120 pts) -> pnp_refine(5 it, inliers)"],
+                       "host": "alva_frontend_track (C++)" if not (args.serial or args.python_host) else "python ctypes",
                        "not_in_timed_region": [],
                        "parallelism": f"{world} independent camera streams, one per GPU, no collective; within a frame the detector "
                                       "(ORB + match) and the tracker (fb-KLT + pose) run on two HIP streams" + (" [disabled: --serial]" if args.serial else "")},
