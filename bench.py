@@ -390,7 +390,7 @@ def main():
             "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,
                                      "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
             "local_ba": ba,
-            "config_1280x720": bench_720p(local),
+            "config_1280x720": bench_720p(local) if world == 1 else None,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -403,7 +403,7 @@ def main():
         }
         if args.streams_per_gpu > 1:
             out["multi_stream"] = bench_multi_stream(local, args.streams_per_gpu, max(20, args.steps // 2))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the contract: reference CPU path timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(7)
         print(json.dumps(out))
     if dist:
