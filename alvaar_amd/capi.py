@@ -68,6 +68,8 @@ _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_prof_enable", [_i])
 _sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_undistort_points", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
+_sig("alva_project_dist", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
 _sig("alva_clahe", [_vp, _vp, _sz, _i, _i, C.c_double, _i, _i, _vp, _sz])
 _sig("alva_triangulate", [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _f, _vp, _vp, _vp, _vp, _vp])
 _sig("alva_frontend_create", [_i, _i, _i, _i, _i, C.POINTER(_vp)])
@@ -226,6 +228,19 @@ class Context:
         check(lib.alva_fast(self.h, _ptr(gray), gray.stride(0), w, h, threshold, _ptr(xy), _ptr(sc), cap, C.byref(cnt)))
         n = min(cnt.value, cap)
         return xy[:n], sc[:n]
+
+    # f4b
+    def undistort_points(self, px, K, dist):
+        """CameraCalibration::undistortImagePoint for n pixels [n,2] f32; K = (fx,fy,cx,cy), dist = (k1,k2,p1,p2)"""
+        out = torch.empty_like(px)
+        check(lib.alva_undistort_points(self.h, _ptr(px), px.shape[0], *[float(v) for v in K], *[float(v) for v in dist], _ptr(out)))
+        return out
+
+    def project_dist(self, cam_pts, K, dist):
+        """CameraCalibration::projectCamToImageDist for n camera-frame points [n,3] f64 -> [n,2] f32 pixels"""
+        out = torch.empty((cam_pts.shape[0], 2), dtype=torch.float32, device=cam_pts.device)
+        check(lib.alva_project_dist(self.h, _ptr(cam_pts), cam_pts.shape[0], *[float(v) for v in K], *[float(v) for v in dist], _ptr(out)))
+        return out
 
     # f4a
     def clahe(self, gray, clip_limit=3.0, tiles=None, tile_size=50):

@@ -209,6 +209,19 @@ int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_out
 int alva_clahe(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int width, int height, double clip_limit,
                int tiles_x, int tiles_y, uint8_t *d_dst, size_t dst_pitch);
 
+/* ---- f4b: lens distortion paths of CameraCalibration --------------------------------------
+ * alva_undistort_points replaces CameraCalibration::undistortImagePoint (src/slam/src/camera_calibration.cpp:56-72) =
+ * cv::undistortPoints(pts, out, K, D, R = K) with D = (k1, k2, p1, p2), 5 fixed iterations
+ * (calib3d/src/undistort.dispatch.cpp:384-556): pixel in, undistorted pixel out (n x 2 f32 each).
+ * alva_project_dist replaces CameraCalibration::projectCamToImageDist (:34-54) = cv::projectPoints of (x/z, y/z, 1)
+ * rounded to float, zero rvec / tvec (calib3d/src/calibration.cpp:522-): camera-frame points (n x 3 f64) in, distorted
+ * pixels (n x 2 f32) out.  Both bit-exact; both are used by the reference even when the coefficients are zero.
+ * Enqueue only. */
+int alva_undistort_points(alva_ctx *ctx, const float *d_px, int n, double fx, double fy, double cx, double cy, double k1,
+                          double k2, double p1, double p2, float *d_out);
+int alva_project_dist(alva_ctx *ctx, const double *d_cam_pts, int n, double fx, double fy, double cx, double cy,
+                      double k1, double k2, double p1, double p2, float *d_out);
+
 /* ---- f2a: triangulation of a new keyframe's 2-D keypoints -------------------------------------
  * Replaces the per-keypoint arithmetic of Mapper::triangulateTemporal (src/slam/src/mapper.cpp:222-287):
  * MultiViewGeometry::triangulate (= opengv::triangulation::triangulate2, opengv/src/triangulation/methods.cpp:67-90),

@@ -2238,3 +2238,47 @@ void orc_clahe(const uint8_t *src, int w, int h, double clipLimitD, int tilesX, 
     }
     free(lut);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * f4b: lens distortion paths of CameraCalibration (camera_calibration.cpp:34-72), k = (k1, k2, p1, p2). */
+void orc_undistort_points(const float *px, int n, double fx, double fy, double cx, double cy, const double *k, float *out) {
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        const double u = px[2 * i], v = px[2 * i + 1];
+        double x = (u - cx) * ifx, y = (v - cy) * ify;
+        const double x0 = x, y0 = y; /* the tilt matrices are identities: invProj * vec = the same values */
+        for (int j = 0; j < 5; j++) { /* TermCriteria(MAX_ITER, 5, 0.01): five iterations, no error test */
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((0 * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) {
+                x = (u - cx) * ifx;
+                y = (v - cy) * ify;
+                break;
+            }
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + 0 * r2 + 0 * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        /* R = K (the reference passes Kcv_ in the R slot): xx = fx x + 0 y + cx, ww = 1 / (0 x + 0 y + 1) */
+        const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+        out[2 * i] = (float) (xx * ww);
+        out[2 * i + 1] = (float) (yy * ww);
+    }
+}
+
+void orc_project_dist(const double *P, int n, double fx, double fy, double cx, double cy, const double *k, float *out) {
+    for (int i = 0; i < n; i++) {
+        const double iz = 1. / P[3 * i + 2];
+        const float Xf = (float) (P[3 * i] * iz), Yf = (float) (P[3 * i + 1] * iz); /* cv::Point3f cvPoint(x, y, 1.0) */
+        double x = (double) Xf, y = (double) Yf; /* R = I, t = 0, z = 1: exact */
+        const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+        const double cdist = 1 + k[0] * r2 + k[1] * r4 + 0 * r6;
+        const double icdist2 = 1. / (1 + 0 * r2 + 0 * r4 + 0 * r6);
+        const double xd0 = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + 0 * r2 + 0 * r4;
+        const double yd0 = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + 0 * r2 + 0 * r4;
+        out[2 * i] = (float) (xd0 * fx + cx);
+        out[2 * i + 1] = (float) (yd0 * fy + cy);
+    }
+}

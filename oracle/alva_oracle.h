@@ -72,3 +72,10 @@ void orc_triangulate(int n, const double *T, const int *group, const double *bvl
 /* f4a: cv::createCLAHE(clipLimit, Size(tilesX, tilesY))->apply on an 8-bit image (imgproc/src/clahe.cpp:120-420), as
  * VisualFrontend::preprocessImage calls it when claheEnabled_ (visual_frontend.cpp:16-18, :678-681). */
 void orc_clahe(const uint8_t *src, int w, int h, double clipLimit, int tilesX, int tilesY, uint8_t *dst);
+
+/* f4b: CameraCalibration::undistortImagePoint (camera_calibration.cpp:56-72) = cv::undistortPoints(pts, out, K, D, R = K)
+ * with D = (k1, k2, p1, p2), 5 fixed iterations (calib3d/src/undistort.dispatch.cpp:384-556), and
+ * CameraCalibration::projectCamToImageDist (:34-54) = cv::projectPoints of (x/z, y/z, 1) ROUNDED TO FLOAT with zero
+ * rvec / tvec (calib3d/src/calibration.cpp:522-). */
+void orc_undistort_points(const float *px, int n, double fx, double fy, double cx, double cy, const double *dist4, float *out);
+void orc_project_dist(const double *camPts, int n, double fx, double fy, double cx, double cy, const double *dist4, float *out);

@@ -527,3 +527,21 @@ extern "C" void ref_clahe(const uint8_t *src, int w, int h, double clipLimit, in
     c->apply(s, d);
     for (int y = 0; y < h; y++) std::memcpy(dst + (size_t) y * w, d.ptr<uint8_t>(y), (size_t) w);
 }
+
+// f4b: the reference's own CameraCalibration methods, point by point (camera_calibration.cpp:34-72)
+extern "C" void ref_undistort_points(const float *px, int n, double fx, double fy, double cx, double cy, const double *k, float *out) {
+    CameraCalibration cal(fx, fy, cx, cy, k[0], k[1], k[2], k[3], 640., 480., 1.);
+    for (int i = 0; i < n; i++) {
+        const cv::Point2f r = cal.undistortImagePoint(cv::Point2f(px[2 * i], px[2 * i + 1]));
+        out[2 * i] = r.x;
+        out[2 * i + 1] = r.y;
+    }
+}
+extern "C" void ref_project_dist(const double *P, int n, double fx, double fy, double cx, double cy, const double *k, float *out) {
+    CameraCalibration cal(fx, fy, cx, cy, k[0], k[1], k[2], k[3], 640., 480., 1.);
+    for (int i = 0; i < n; i++) {
+        const cv::Point2f r = cal.projectCamToImageDist(Eigen::Vector3d(P[3 * i], P[3 * i + 1], P[3 * i + 2]));
+        out[2 * i] = r.x;
+        out[2 * i + 1] = r.y;
+    }
+}

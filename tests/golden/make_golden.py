@@ -82,7 +82,18 @@ def clahe():
     np.savez_compressed(OUT / "clahe.npz", g=g, clip=np.float64(3.0), tiles=np.array([3, 2]), out=ref_clahe(g, 3.0, (3, 2)))
 
 
+def distortion():
+    from oracles import ref_undistort_points, ref_project_dist
+    rng = np.random.RandomState(31)
+    K, dist = np.array([520.0, 515.0, 318.5, 241.25]), np.array([-0.28, 0.07, 0.0002, -0.0003])
+    px = rng.uniform(-40, [680, 520], (500, 2)).astype(np.float32)
+    P = np.stack([rng.uniform(-3, 3, 500), rng.uniform(-2, 2, 500), rng.uniform(0.5, 9, 500)], 1)
+    np.savez_compressed(OUT / "distortion.npz", K=K, dist=dist, px=px, P=P, und=ref_undistort_points(px, K, dist),
+                        proj=ref_project_dist(P, K, dist))
+
+
 if __name__ == "__main__":
     triangulation()
     clahe()
+    distortion()
     main()

@@ -242,6 +242,30 @@ class Orc:
         return desc, valid
 
 
+def _dist_call(lib, name, arr, K, dist, shape):
+    a = np.ascontiguousarray(arr)
+    k = np.ascontiguousarray(dist, np.float64)
+    out = np.zeros(shape, np.float32)
+    getattr(lib, name)(_p(a), len(a), _d(float(K[0])), _d(float(K[1])), _d(float(K[2])), _d(float(K[3])), _p(k), _p(out))
+    return out
+
+
+def orc_undistort_points(px, K, dist):
+    return _dist_call(orc_lib(), "orc_undistort_points", np.asarray(px, np.float32), K, dist, (len(px), 2))
+
+
+def ref_undistort_points(px, K, dist):
+    return _dist_call(ref_lib(), "ref_undistort_points", np.asarray(px, np.float32), K, dist, (len(px), 2))
+
+
+def orc_project_dist(P, K, dist):
+    return _dist_call(orc_lib(), "orc_project_dist", np.asarray(P, np.float64), K, dist, (len(P), 2))
+
+
+def ref_project_dist(P, K, dist):
+    return _dist_call(ref_lib(), "ref_project_dist", np.asarray(P, np.float64), K, dist, (len(P), 2))
+
+
 def orc_clahe(gray, clip=3.0, tiles=(12, 9)):
     g = np.ascontiguousarray(gray)
     out = np.empty_like(g)
