@@ -27,6 +27,7 @@
 //   k_point<cost only> on the candidate; the host reads three scalars and applies Ceres' accept/reject logic.
 #include "common.hpp"
 #include "lm_device.hpp"
+#include "wave_utils.hpp"
 #include <chrono>
 #include <cstdlib>
 #include <algorithm>
@@ -222,18 +223,7 @@ __global__ void __launch_bounds__(256) k_pairs(BaDev B) {
             for (int y = x; y < 6; y++) v[t++] += J[x] * J[y] + J[6 + x] * J[6 + y];
         }
     }
-    // at distance d each lane keeps half of its values and adds the partner's copy of that half; lane l ends with value l >> 1
-#pragma unroll
-    for (int half = 16; half >= 1; half >>= 1) {
-        const bool hi = (lane & (2 * half)) != 0;
-#pragma unroll
-        for (int k = 0; k < half; k++) {
-            const double send = hi ? v[k] : v[k + half];
-            const double keep = hi ? v[k + half] : v[k];
-            v[k] = keep + __shfl_xor(send, 2 * half);
-        }
-    }
-    v[0] += __shfl_xor(v[0], 1);
+    wave_reduce_scatter32(v);  // lane l ends with the wave total of value l >> 1
     if (!(lane & 1) && (lane >> 1) < 27) s_part[wave][lane >> 1] = v[0];
     __syncthreads();
     if (threadIdx.x < 27) B.M[(size_t) key * 27 + threadIdx.x] = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
@@ -452,11 +442,6 @@ __global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius) 
     }
 }
 
-__device__ __forceinline__ double lane_get(double v, int lane) {  // value of `lane` (wave-uniform index) in every lane
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 template<bool IN_LDS>
 __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
     extern __shared__ double s_S[];
@@ -491,14 +476,14 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
             int ok = 1;
 #pragma unroll
             for (int j = 0; j < NB; j++) {
-                const double d = lane_get(a[j], j);
+                const double d = lane_bcast(a[j], j);
                 if (!(d > 0)) ok = 0;
                 const double inv = rsqrt(d), piv = d * inv;
                 a[j] = (lane & 15) == j ? piv : a[j] * inv;  // rows above j hold garbage in column j: never read
                 if (lane == j) s_inv[j] = inv;
 #pragma unroll
                 for (int k = j + 1; k < NB; k++) {
-                    const double lkj = lane_get(a[j], k);
+                    const double lkj = lane_bcast(a[j], k);
                     a[k] -= a[j] * lkj;  // used for rows >= k only
                 }
             }
@@ -572,7 +557,7 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
                 double yi = y[base + i];
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
-                    const double zj = lane_get(yi, j) / lane_get(l[j], j);
+                    const double zj = lane_bcast(yi, j) / lane_bcast(l[j], j);
                     if (i == j) yi = zj;
                     else if (i > j) yi -= l[j] * zj;
                 }
@@ -602,7 +587,7 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
                 double zi = y[base + i];
 #pragma unroll
                 for (int j = NB - 1; j >= 0; j--) {
-                    const double yj = lane_get(zi, j) / lane_get(lc[j], j);
+                    const double yj = lane_bcast(zi, j) / lane_bcast(lc[j], j);
                     if (i == j) zi = yj;
                     else if (i < j) zi -= lc[j] * yj;
                 }

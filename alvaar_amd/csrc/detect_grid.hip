@@ -24,6 +24,7 @@
 //                replayed sequentially (one lane each) so the float result is bit-identical.
 // This translation unit must be compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "wave_utils.hpp"
 
 namespace {
 
@@ -819,11 +820,6 @@ __device__ __forceinline__ float subpix_at_tile(const SubpixGeom &g, const uint8
     return prev + t;
 }
 
-__device__ __forceinline__ double lane_bcast_d(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 // The slowest corner (30 iterations) sets the kernel time, so the iteration is kept short: the 10x10 source footprint of
 // the 9x9 patch is read from a 24x24 LDS tile (re-staged from L2 only when the window leaves it), broadcasts are v_readlane.
 __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray, size_t pitch, int w, int h, float *__restrict__ pts,
@@ -890,8 +886,8 @@ __global__ void __launch_bounds__(64) k_subpix(const uint8_t *__restrict__ gray,
 #pragma unroll 7
             for (int k = 0; k < WW * WW; k++) acc += s_term[lane][k];
         }
-        const double a = lane_bcast_d(acc, 0), b = lane_bcast_d(acc, 1), c = lane_bcast_d(acc, 2), bb1 = lane_bcast_d(acc, 3),
-                     bb2 = lane_bcast_d(acc, 4);
+        const double a = lane_bcast(acc, 0), b = lane_bcast(acc, 1), c = lane_bcast(acc, 2), bb1 = lane_bcast(acc, 3),
+                     bb2 = lane_bcast(acc, 4);
         const double det = a * c - b * b;
         if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
         const double scale = 1.0 / det;

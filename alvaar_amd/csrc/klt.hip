@@ -19,6 +19,7 @@
 //
 // This translation unit must be compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "wave_utils.hpp"
 
 namespace {
 
@@ -47,11 +48,6 @@ struct LkShared {
     int2 pxy[NPX + 3];    // (diff * Ix, diff * Iy) of the current iteration
     uint8_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level)
 };
-
-// value of lane k (compile-time constant) for every lane: v_readlane, no LDS crossbar round trip
-__device__ __forceinline__ float lane_bcast(float v, int k) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
-}
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 

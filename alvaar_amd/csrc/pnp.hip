@@ -20,6 +20,7 @@
 #include "common.hpp"
 #pragma clang fp contract(fast)
 #include "lm_device.hpp"
+#include "wave_utils.hpp"
 #include "pose_internal.hpp"
 #include <algorithm>
 #include <cmath>
@@ -108,23 +109,10 @@ __device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robu
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (WANT_J) {
-        // butterfly reduce-scatter over the wave: at distance d each lane keeps half of its values and adds the partner's
-        // copy of that half (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges instead of 28 x 6); lane l ends with the total of
-        // value l >> 1
         double v[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) v[k] = k < NACC ? acc[k] : 0.0;
-#pragma unroll
-        for (int half = 16; half >= 1; half >>= 1) {
-            const bool hi = (lane & (2 * half)) != 0;
-#pragma unroll
-            for (int k = 0; k < half; k++) {
-                const double send = hi ? v[k] : v[k + half];
-                const double keep = hi ? v[k + half] : v[k];
-                v[k] = keep + __shfl_xor(send, 2 * half);
-            }
-        }
-        v[0] += __shfl_xor(v[0], 1);
+        wave_reduce_scatter32(v);  // lane l ends with the wave total of value l >> 1
         if (!(lane & 1) && (lane >> 1) < NACC) sh.part[wave][lane >> 1] = v[0];
     } else {
         double v = acc[27];

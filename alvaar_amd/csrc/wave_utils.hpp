@@ -1,0 +1,31 @@
+// Wave64 helpers shared by the kernels: broadcasts through v_readlane (no LDS crossbar round trip) and the butterfly
+// reduce-scatter used for the 27/28-value normal-equation sums.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// value held by `lane` (a wave-uniform index) delivered to every lane
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum of 32 per-lane values over the 64 lanes of a wave: at distance d each lane keeps half of its values and adds the
+// partner's copy of that half (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges instead of 32 x 6).  On return v[0] of lane l holds the
+// wave total of value (l >> 1).  The summation order is fixed (bit-reproducible).
+__device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int half = 16; half >= 1; half >>= 1) {
+        const bool hi = (lane & (2 * half)) != 0;
+#pragma unroll
+        for (int k = 0; k < half; k++) {
+            const double send = hi ? v[k] : v[k + half];
+            const double keep = hi ? v[k + half] : v[k];
+            v[k] = keep + __shfl_xor(send, 2 * half);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1);
+}
