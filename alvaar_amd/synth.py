@@ -255,3 +255,92 @@ def _quat_from_R(R):
     from scipy.spatial.transform import Rotation
     q = Rotation.from_matrix(R).as_quat()
     return q if q[3] >= 0 else -q
+
+
+def make_match_to_map_problem(n_points: int, seed: int, n_kf: int = 8, dist=(0.0, 0.0, 0.0, 0.0), dup_frac: float = 0.45, px_noise: float = 0.3,
+                              max_flips: int = 10, twin_frac: float = 0.0):
+    """A small consistent map for Mapper::matchToMap: n_kf keyframes (the last one is the frame being matched), map points with
+    per-keyframe pixel observations and descriptors.  A fraction of the world points exists TWICE in the map -- an old map
+    point seen in the first keyframes (local map) and a recent one tracked into the frame -- which is exactly what
+    matchToMap is there to find and merge; the rest are only-old or only-tracked points."""
+    rng = np.random.RandomState(seed)
+    fx = fy = 520.0
+    cx, cy, W, H = 320.0, 240.0, 640, 480
+    calib = np.array([fx, fy, cx, cy, *dist, W, H], np.float64)
+    poses, Rs, cs = [], [], []
+    for k in range(n_kf):
+        R = so3_exp(np.array([0.01 * rng.randn(), 0.02 * k + 0.01 * rng.randn(), 0.01 * rng.randn()]))
+        c = np.array([0.12 * k, 0.01 * rng.randn(), 0.02 * rng.randn()])
+        poses.append(np.concatenate([c, _quat_from_R(R)]))
+        Rs.append(R)
+        cs.append(c)
+    poses = np.array(poses)
+
+    def project(k, X):
+        p = Rs[k].T @ (X - cs[k])
+        x, y = p[0] / p[2], p[1] / p[2]
+        r2 = x * x + y * y
+        cd = 1 + dist[0] * r2 + dist[1] * r2 * r2
+        xd = x * cd + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)
+        yd = y * cd + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y
+        return np.array([fx * xd + cx, fy * yd + cy]), p[2]
+    last = n_kf - 1
+    mp_id, mp_wpt, mp_is3d, obs_ptr, obs_kf, obs_px, obs_desc = [], [], [], [0], [], [], []
+    kinds = []
+
+    def add_mp(idv, X, kfs, base, is3d=True):
+        rows = []
+        for k in kfs:
+            px, z = project(k, X)
+            if z < 0.3 or not (10 <= px[0] < W - 10 and 10 <= px[1] < H - 10):   # keypoints live inside the image
+                continue
+            d = base.copy()
+            for b in rng.randint(0, 256, rng.randint(2, max_flips)):
+                d[b >> 3] ^= np.uint8(1 << (b & 7))
+            rows.append((k, np.clip(px + px_noise * rng.randn(2), 1.0, [W - 2.0, H - 2.0]).astype(np.float32), d))
+        if not rows:
+            return False
+        mp_id.append(idv)
+        mp_wpt.append(X)
+        mp_is3d.append(1 if is3d else 0)
+        for k, px, d in rows:
+            obs_kf.append(k)
+            obs_px.append(px)
+            obs_desc.append(d)
+        obs_ptr.append(len(obs_kf))
+        return True
+    half = n_kf // 2
+    for j in range(n_points):
+        X = np.array([rng.uniform(-2.2, 3.0), rng.uniform(-1.8, 1.8), rng.uniform(3.0, 9.0)])
+        base = rng.randint(0, 256, 32).astype(np.uint8)
+        if j > 0 and rng.rand() < twin_frac:   # a look-alike right next to the previous point: exercises the 0.9 ratio test
+            X = prevX + np.array([0.004, 0.003, 0.0]) * rng.randn(3)
+            base = prevBase.copy()
+            for b in rng.randint(0, 256, 6):
+                base[b >> 3] ^= np.uint8(1 << (b & 7))
+        prevX, prevBase = X, base
+        u = rng.rand()
+        if u < dup_frac:          # the same physical point twice
+            add_mp(5000 + j, X + 0.002 * rng.randn(3), range(0, half), base)
+            add_mp(1000 + j, X, range(half + 1, n_kf), base, is3d=bool(rng.rand() < 0.7))
+            kinds.append("dup")
+        elif u < dup_frac + 0.3:  # only old (local map, nothing to match)
+            add_mp(5000 + j, X, range(0, half + 1), base)
+            kinds.append("old")
+        else:                     # only tracked
+            add_mp(1000 + j, X, range(rng.randint(half, last), n_kf), base)
+            kinds.append("new")
+    mp_id = np.array(mp_id, np.int32)
+    obs_ptr = np.array(obs_ptr, np.int32)
+    obs_kf = np.array(obs_kf, np.int32)
+    frame_obs = np.flatnonzero(obs_kf == last).astype(np.int32)
+    frame_kp_order = rng.permutation(frame_obs).astype(np.int32)
+    in_frame = np.zeros(len(mp_id), bool)
+    for m in range(len(mp_id)):
+        in_frame[m] = (obs_kf[obs_ptr[m]:obs_ptr[m + 1]] == last).any()
+    local = [int(i) for i in mp_id[~in_frame]] + [int(i) for i in mp_id[in_frame][:5]]   # a few observed ones: must be skipped
+    local = list(rng.permutation(local))
+    return dict(calib=calib, cell_size=35, kf_id=np.arange(10, 10 + n_kf, dtype=np.int32), kf_pose=poses, mp_id=mp_id,
+                mp_wpt=np.array(mp_wpt), mp_is3d=np.array(mp_is3d, np.uint8), obs_ptr=obs_ptr, obs_kf=obs_kf,
+                obs_px=np.array(obs_px, np.float32), obs_desc=np.array(obs_desc, np.uint8), frame_kp_order=frame_kp_order,
+                local=np.array(local, np.int32), num_kp3d=int(in_frame.sum()))

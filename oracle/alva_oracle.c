@@ -2282,3 +2282,115 @@ void orc_project_dist(const double *P, int n, double fx, double fy, double cx, d
         out[2 * i + 1] = (float) (yd0 * fy + cy);
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * f1: Mapper::matchToMap (mapper.cpp:354-588).  Sophus::SE3d * point = Eigen::Quaternion::_transformVector + translation
+ * (uv = q.vec x v; uv += uv; v + w uv + q.vec x uv), CameraCalibration::projectCamToImageDist (orc_project_dist), the 2x2-cell
+ * neighbourhood of Frame::getSurroundingKeypoints (frame.cpp:313-341), the two-minimum scan with <= and the 0.9 ratio test,
+ * and the per-keypoint arbitration in push order. */
+static void mtm_transform(const double *q, const double *t, const double *v, double *o) {
+    const double uv0 = q[1] * v[2] - q[2] * v[1], uv1 = q[2] * v[0] - q[0] * v[2], uv2 = q[0] * v[1] - q[1] * v[0];
+    const double u0 = uv0 + uv0, u1 = uv1 + uv1, u2 = uv2 + uv2;
+    const double c0 = q[1] * u2 - q[2] * u1, c1 = q[2] * u0 - q[0] * u2, c2 = q[0] * u1 - q[1] * u0;
+    o[0] = ((v[0] + q[3] * u0) + c0) + t[0];
+    o[1] = ((v[1] + q[3] * u1) + c1) + t[1];
+    o[2] = ((v[2] + q[3] * u2) + c2) + t[2];
+}
+
+int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridCells, const int *cellPtr, const int *cellMp, int nKf,
+                     const double *kfQ, const double *kfT, int nMp, const double *mpWpt, const uint8_t *mpIs3d, const int *obsPtr,
+                     const int *obsKf, const float *obsPx, const uint8_t *obsDesc, int frameKf, int numKeypoints3d, int nLocal,
+                     const int *local, float maxProjErr, float distRatio, int *matchOfMp) {
+    (void) nKf;
+    const double fx = calib[0], fy = calib[1], cx = calib[2], cy = calib[3], imgW = calib[8], imgH = calib[9];
+    const float fovV = 0.5 * imgH / fy, fovH = 0.5 * imgW / fx;
+    const float maxRadFov = fovH > fovV ? atanf(fovH) : atanf(fovV);
+    const float view_th = cosf(maxRadFov);
+    float maxPxDist = maxProjErr;
+    if (numKeypoints3d < 30) maxPxDist *= 2.;
+    int *frameObs = (int *) malloc(sizeof(int) * (size_t) nMp); /* observation of map point m in the frame, or -1 */
+    float *bestDistOfKp = (float *) malloc(sizeof(float) * (size_t) nMp);
+    for (int m = 0; m < nMp; m++) {
+        frameObs[m] = -1;
+        for (int o = obsPtr[m]; o < obsPtr[m + 1]; o++)
+            if (obsKf[o] == frameKf) frameObs[m] = o;
+        matchOfMp[m] = -1;
+        bestDistOfKp[m] = 1024;
+    }
+    int nMatches = 0;
+    for (int li = 0; li < nLocal; li++) {
+        const int M = local[li];
+        if (frameObs[M] >= 0) continue;                                /* frame.isObservingKeypoint (:393) */
+        if (!mpIs3d[M] || obsPtr[M] == obsPtr[M + 1]) continue;       /* !is3d_ || desc_.empty() (:404) */
+        const double *wpt = mpWpt + 3 * (size_t) M;
+        double campt[3];
+        mtm_transform(kfQ + 4 * (size_t) frameKf, kfT + 3 * (size_t) frameKf, wpt, campt);
+        if (campt[2] < 0.1) continue;
+        const float view_angle = (float) (campt[2] / sqrt((campt[0] * campt[0] + campt[1] * campt[1]) + campt[2] * campt[2]));
+        if (fabsf(view_angle) < view_th) continue;
+        float proj[2];
+        orc_project_dist(campt, 1, fx, fy, cx, cy, calib + 4, proj);
+        if (!(proj[0] >= 0 && proj[1] >= 0 && proj[0] < imgW && proj[1] < imgH)) continue;
+        const float minDist = 32 * distRatio * 8.;
+        int bestId = -1, secId = -1;
+        float bestDist = minDist, secDist = minDist;
+        const int rkp = (int) floorf(proj[1] / (float) cellSize), ckp = (int) floorf(proj[0] / (float) cellSize);
+        for (int r = rkp - 1; r < rkp + 1; r++)
+            for (int c = ckp - 1; c < ckp + 1; c++) {
+                const int idx = r * numCellsW + c;
+                if (r < 0 || c < 0 || idx > gridCells) continue;
+                for (int e = cellPtr[idx]; e < cellPtr[idx + 1]; e++) {
+                    const int K = cellMp[e], ko = frameObs[K];
+                    const float pxDist = (float) sqrt((double) (proj[0] - obsPx[2 * ko]) * (double) (proj[0] - obsPx[2 * ko]) +
+                                                      (double) (proj[1] - obsPx[2 * ko + 1]) * (double) (proj[1] - obsPx[2 * ko + 1]));
+                    if (pxDist > maxPxDist) continue;
+                    int cand = 1; /* never both observed in one keyframe (:474-485); both lists ascend */
+                    for (int a = obsPtr[K]; a < obsPtr[K + 1] && cand; a++)
+                        for (int b = obsPtr[M]; b < obsPtr[M + 1]; b++)
+                            if (obsKf[a] == obsKf[b]) {
+                                cand = 0;
+                                break;
+                            }
+                    if (!cand) continue;
+                    float coProj = 0.;
+                    size_t nCo = 0;
+                    for (int a = obsPtr[K]; a < obsPtr[K + 1]; a++) {
+                        double cp[3];
+                        float pp[2];
+                        mtm_transform(kfQ + 4 * (size_t) obsKf[a], kfT + 3 * (size_t) obsKf[a], wpt, cp);
+                        orc_project_dist(cp, 1, fx, fy, cx, cy, calib + 4, pp);
+                        const float dx = obsPx[2 * a] - pp[0], dy = obsPx[2 * a + 1] - pp[1];
+                        coProj += sqrt((double) dx * (double) dx + (double) dy * (double) dy);
+                        nCo++;
+                    }
+                    if (coProj / nCo > maxPxDist) continue;
+                    float dist = 1000.0;
+                    for (int a = obsPtr[M]; a < obsPtr[M + 1]; a++)
+                        for (int b = obsPtr[K]; b < obsPtr[K + 1]; b++) {
+                            const float d = (float) orc_hamming256(obsDesc + 32 * (size_t) a, obsDesc + 32 * (size_t) b);
+                            if (d < dist) dist = d;
+                        }
+                    if (dist <= bestDist) {
+                        secDist = bestDist;
+                        secId = bestId;
+                        bestDist = dist;
+                        bestId = K;
+                    } else if (dist <= secDist) {
+                        secDist = dist;
+                        secId = K;
+                    }
+                }
+            }
+        if (bestId != -1 && secId != -1)
+            if (0.9 * secDist < bestDist) bestId = -1;
+        if (bestId < 0) continue;
+        if (bestDist <= bestDistOfKp[bestId]) { /* arbitration per keypoint, in push order, <= (:563-578) */
+            if (matchOfMp[bestId] < 0) nMatches++;
+            bestDistOfKp[bestId] = bestDist;
+            matchOfMp[bestId] = M;
+        }
+    }
+    free(frameObs);
+    free(bestDistOfKp);
+    return nMatches;
+}

@@ -79,3 +79,15 @@ void orc_clahe(const uint8_t *src, int w, int h, double clipLimit, int tilesX, i
  * rvec / tvec (calib3d/src/calibration.cpp:522-). */
 void orc_undistort_points(const float *px, int n, double fx, double fy, double cx, double cy, const double *dist4, float *out);
 void orc_project_dist(const double *camPts, int n, double fx, double fy, double cx, double cy, const double *dist4, float *out);
+
+/* f1: Mapper::matchToMap (src/slam/src/mapper.cpp:354-588) on a flattened, CONSISTENT map (every keypoint id has its map point,
+ * every observing keyframe exists and holds the keypoint -- the reference's repair branches :459-463, :500-509 never fire).
+ *   calib[10] = fx fy cx cy k1 k2 p1 p2 imgW imgH ; the frame's keypoint grid as the reference stores it: cellPtr/cellMp (map point
+ *   INDEX of each stored keypoint, in stored order), numCellsW, gridCells ; keyframes' T_cw as unit quaternion (x y z w) + translation ;
+ *   map points: world point, is3d, observations obsPtr -> (obsKf ascending keyframe index, obsPx, obsDesc) ; frameKf = index of the
+ *   keyframe being matched ; local[] = map point indices in the iteration order of the reference's unordered_set.
+ * out: matchOfMp[m] = index of the local map point matched to the frame keypoint of map point m, or -1.  Returns #matches. */
+int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridCells, const int *cellPtr, const int *cellMp, int nKf,
+                     const double *kfQ, const double *kfT, int nMp, const double *mpWpt, const uint8_t *mpIs3d, const int *obsPtr,
+                     const int *obsKf, const float *obsPx, const uint8_t *obsDesc, int frameKf, int numKeypoints3d, int nLocal,
+                     const int *local, float maxProjErr, float distRatio, int *matchOfMp);

@@ -280,6 +280,50 @@ def ref_clahe(gray, clip=3.0, tiles=(12, 9)):
     return out
 
 
+def ref_match_to_map(pb, max_proj_err=2.0, dist_ratio=0.2, num_kp3d=None):
+    """The reference's own Mapper::matchToMap on a map built with its own classes.  Returns (matches {kpId: mpId}, aux) where
+    aux holds what the reference's containers determine: Tcw of the keyframes, the frame's keypoint grid, the iteration order of
+    the local-map unordered_set."""
+    nkf, nmp = len(pb["kf_id"]), len(pb["mp_id"])
+    kfQ, kfT = np.zeros((nkf, 4)), np.zeros((nkf, 3))
+    nfk = len(pb["frame_kp_order"])
+    gc, ncw = C.c_int(0), C.c_int(0)
+    cellPtr, cellKp = np.zeros(4096, np.int32), np.zeros(max(nfk, 1), np.int32)
+    nloc = len(pb["local"])
+    localOrder = np.zeros(max(nloc, 1), np.int32)
+    mk, mm = np.zeros(max(nfk, 1), np.int32), np.zeros(max(nfk, 1), np.int32)
+    a = {k: np.ascontiguousarray(v) for k, v in pb.items() if isinstance(v, np.ndarray)}
+    n = ref_lib().ref_match_to_map(_p(a["calib"]), int(pb["cell_size"]), nkf, _p(a["kf_id"]), _p(a["kf_pose"]), nmp, _p(a["mp_id"]),
+                                   _p(a["mp_wpt"]), _p(a["mp_is3d"]), _p(a["obs_ptr"]), _p(a["obs_kf"]), _p(a["obs_px"]), _p(a["obs_desc"]),
+                                   nfk, _p(a["frame_kp_order"]), int(pb["num_kp3d"] if num_kp3d is None else num_kp3d), nloc, _p(a["local"]),
+                                   _f(max_proj_err), _f(dist_ratio), _p(kfQ), _p(kfT), C.byref(gc), C.byref(ncw), _p(cellPtr), _p(cellKp),
+                                   _p(localOrder), _p(mk), _p(mm))
+    aux = dict(kf_q=kfQ, kf_t=kfT, grid_cells=gc.value, num_cells_w=ncw.value, cell_ptr=cellPtr[:gc.value + 1].copy(),
+               cell_kp=cellKp[:cellPtr[gc.value]].copy(), local_order=localOrder[:nloc].copy())
+    return {int(mk[i]): int(mm[i]) for i in range(n)}, aux
+
+
+def flatten_match_to_map(pb, aux):
+    """ids -> indices: what a host integration hands to the device path"""
+    idx_of = {int(v): i for i, v in enumerate(pb["mp_id"])}
+    cell_mp = np.array([idx_of[int(i)] for i in aux["cell_kp"]], np.int32)
+    local = np.array([idx_of[int(i)] for i in aux["local_order"]], np.int32)
+    return cell_mp, local
+
+
+def orc_match_to_map(pb, aux, max_proj_err=2.0, dist_ratio=0.2, num_kp3d=None):
+    cell_mp, local = flatten_match_to_map(pb, aux)
+    nmp = len(pb["mp_id"])
+    out = np.full(nmp, -1, np.int32)
+    a = {k: np.ascontiguousarray(v) for k, v in pb.items() if isinstance(v, np.ndarray)}
+    kfq, kft, cp = np.ascontiguousarray(aux["kf_q"]), np.ascontiguousarray(aux["kf_t"]), np.ascontiguousarray(aux["cell_ptr"], np.int32)
+    orc_lib().orc_match_to_map(_p(a["calib"]), int(pb["cell_size"]), int(aux["num_cells_w"]), int(aux["grid_cells"]), _p(cp), _p(cell_mp),
+                               len(pb["kf_id"]), _p(kfq), _p(kft), nmp, _p(a["mp_wpt"]), _p(a["mp_is3d"]), _p(a["obs_ptr"]), _p(a["obs_kf"]),
+                               _p(a["obs_px"]), _p(a["obs_desc"]), len(pb["kf_id"]) - 1, int(pb["num_kp3d"] if num_kp3d is None else num_kp3d),
+                               len(local), _p(local), _f(max_proj_err), _f(dist_ratio), _p(out))
+    return {int(pb["mp_id"][m]): int(pb["mp_id"][out[m]]) for m in range(nmp) if out[m] >= 0}
+
+
 def _tri_out(n):
     return dict(lpt=np.zeros((n, 3)), wpt=np.zeros((n, 3)), inv_depth=np.zeros(n), status=np.zeros(n, np.uint8), parallax=np.zeros(n))
 
