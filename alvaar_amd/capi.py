@@ -68,6 +68,7 @@ _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_prof_enable", [_i])
 _sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_match_to_map", [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _vp])
 _sig("alva_undistort_points", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
 _sig("alva_project_dist", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
 _sig("alva_clahe", [_vp, _vp, _sz, _i, _i, C.c_double, _i, _i, _vp, _sz])
@@ -228,6 +229,21 @@ class Context:
         check(lib.alva_fast(self.h, _ptr(gray), gray.stride(0), w, h, threshold, _ptr(xy), _ptr(sc), cap, C.byref(cnt)))
         n = min(cnt.value, cap)
         return xy[:n], sc[:n]
+
+    # f1
+    def match_to_map(self, calib10, cell_size, num_cells_w, grid_cells, cell_ptr, cell_mp, kf_q, kf_t, mp_wpt, mp_is3d, obs_ptr, obs_kf,
+                     obs_px, obs_desc, frame_kf, num_kp3d, local, max_proj_err=2.0, dist_ratio=0.2):
+        """Mapper::matchToMap on a flattened map (see include/alvaar_hip.h); all arrays cuda tensors, calib10 a host sequence.
+        Returns match_of_mp [n_mp] int32 (cuda)."""
+        import numpy as np
+        n_mp = mp_wpt.shape[0]
+        out = torch.empty(n_mp, dtype=torch.int32, device=mp_wpt.device)
+        cal = np.ascontiguousarray(calib10, np.float64)
+        check(lib.alva_match_to_map(self.h, cal.ctypes.data, int(cell_size), int(num_cells_w), int(grid_cells), _ptr(cell_ptr), _ptr(cell_mp),
+                                    kf_q.shape[0], _ptr(kf_q), _ptr(kf_t), n_mp, _ptr(mp_wpt), _ptr(mp_is3d), _ptr(obs_ptr), _ptr(obs_kf),
+                                    _ptr(obs_px), _ptr(obs_desc), int(frame_kf), int(num_kp3d), local.shape[0], _ptr(local),
+                                    float(max_proj_err), float(dist_ratio), _ptr(out)))
+        return out
 
     # f4b
     def undistort_points(self, px, K, dist):

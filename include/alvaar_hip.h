@@ -209,6 +209,27 @@ int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_out
 int alva_clahe(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int width, int height, double clip_limit,
                int tiles_x, int tiles_y, uint8_t *d_dst, size_t dst_pitch);
 
+/* ---- f1: Mapper::matchToMap on a flattened map ----------------------------------------------------
+ * Replaces the loops of Mapper::matchToMap(frame, maxProjectionError, distRatio, localMapPointIds)
+ * (src/slam/src/mapper.cpp:354-588; caller matchingToLocalMap :334 with state.hpp:62-63) for a consistent map.  The host
+ * flattens its containers once per keyframe:
+ *   h_calib10        fx fy cx cy k1 k2 p1 p2 imgWidth imgHeight (the shared CameraCalibration)
+ *   grid             the frame's keypoint grid as Frame stores it (frame.cpp:250-260, :313-341): cell_size, num_cells_w,
+ *                    grid_cells, d_cell_ptr[grid_cells + 1], d_cell_mp = map point INDEX of each stored keypoint, stored order
+ *   keyframes        d_kf_q[n_kf][4] (x y z w) and d_kf_t[n_kf][3]: T_cw of every keyframe; frame_kf = the one being matched
+ *   map points       d_mp_wpt[n_mp][3], d_mp_is3d[n_mp], observations d_obs_ptr[n_mp + 1] -> d_obs_kf (ascending keyframe
+ *                    index = MapPoint::observedKeyframeIds_ order), d_obs_px (the keypoint's px_ in that keyframe),
+ *                    d_obs_desc (32 B each, 16-B aligned: MapPoint::mapKeyframeDescriptors_)
+ *   d_local          indices of the local map points in the iteration order of frame.localMapPointIds_
+ * Output d_match_of_mp[n_mp]: for the map point m of a frame keypoint, the index of the local map point that
+ * matchToMap pairs with it (the reference's mapPrevIdNewId[keypointId] = mapPointId), else -1.  Enqueue only. */
+int alva_match_to_map(alva_ctx *ctx, const double *h_calib10, int cell_size, int num_cells_w, int grid_cells,
+                      const int *d_cell_ptr, const int *d_cell_mp, int n_kf, const double *d_kf_q, const double *d_kf_t,
+                      int n_mp, const double *d_mp_wpt, const uint8_t *d_mp_is3d, const int *d_obs_ptr,
+                      const int *d_obs_kf, const float *d_obs_px, const uint8_t *d_obs_desc, int frame_kf,
+                      int num_keypoints_3d, int n_local, const int *d_local, float max_proj_err, float dist_ratio,
+                      int *d_match_of_mp);
+
 /* ---- f4b: lens distortion paths of CameraCalibration --------------------------------------
  * alva_undistort_points replaces CameraCalibration::undistortImagePoint (src/slam/src/camera_calibration.cpp:56-72) =
  * cv::undistortPoints(pts, out, K, D, R = K) with D = (k1, k2, p1, p2), 5 fixed iterations

@@ -92,7 +92,25 @@ def distortion():
                         proj=ref_project_dist(P, K, dist))
 
 
+def match_to_map():
+    from oracles import ref_match_to_map
+    cases = [dict(n=250, seed=41), dict(n=300, seed=42, dist=(-0.2, 0.05, 0.001, -0.001), px_noise=0.8, max_flips=40, twin_frac=0.3),
+             dict(n=200, seed=43, px_noise=1.5, max_flips=70, twin_frac=0.6)]
+    out = {"count": np.int32(len(cases))}
+    for i, c in enumerate(cases):
+        kw = {k: v for k, v in c.items() if k not in ("n", "seed")}
+        pb = synth.make_match_to_map_problem(c["n"], c["seed"], **kw)
+        ref, aux = ref_match_to_map(pb)
+        for k, v in pb.items():
+            out[f"p{i}_{k}"] = np.asarray(v)
+        for k, v in aux.items():
+            out[f"p{i}_aux_{k}"] = np.asarray(v)
+        out[f"p{i}_exp"] = np.array(sorted(ref.items()), np.int32).reshape(-1, 2)
+    np.savez_compressed(OUT / "match_to_map.npz", **out)
+
+
 if __name__ == "__main__":
+    match_to_map()
     triangulation()
     clahe()
     distortion()

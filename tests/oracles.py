@@ -303,6 +303,31 @@ def ref_match_to_map(pb, max_proj_err=2.0, dist_ratio=0.2, num_kp3d=None):
     return {int(mk[i]): int(mm[i]) for i in range(n)}, aux
 
 
+def py_match_to_map_aux(pb):
+    """A stand-in for the reference-determined inputs when the reference is absent (GPU box): T_cw from the poses with numpy,
+    the keypoint grid filled in frame_kp_order like Frame::addKeypointToGrid, the local list in its given order.  Any such
+    choice is a valid input; oracle and HIP path must agree on it."""
+    from scipy.spatial.transform import Rotation
+    nkf = len(pb["kf_id"])
+    kfq, kft = np.zeros((nkf, 4)), np.zeros((nkf, 3))
+    for k in range(nkf):
+        R = Rotation.from_quat(pb["kf_pose"][k, 3:]).as_matrix()
+        q = Rotation.from_matrix(R.T).as_quat()
+        kfq[k] = q if q[3] >= 0 else -q
+        kft[k] = -R.T @ pb["kf_pose"][k, :3]
+    W, H, cs = pb["calib"][8], pb["calib"][9], pb["cell_size"]
+    ncw, nch = int(np.ceil(np.float32(W) / cs)), int(np.ceil(np.float32(H) / cs))
+    cells = [[] for _ in range(ncw * nch)]
+    owner = np.searchsorted(pb["obs_ptr"], pb["frame_kp_order"], side="right") - 1
+    for o, m in zip(pb["frame_kp_order"], owner):
+        px = pb["obs_px"][o]
+        cells[int(np.floor(px[1] / np.float32(cs))) * ncw + int(np.floor(px[0] / np.float32(cs)))].append(int(pb["mp_id"][m]))
+    cell_ptr = np.zeros(len(cells) + 1, np.int32)
+    cell_ptr[1:] = np.cumsum([len(c) for c in cells])
+    return dict(kf_q=kfq, kf_t=kft, grid_cells=len(cells), num_cells_w=ncw, cell_ptr=cell_ptr,
+                cell_kp=np.array([i for c in cells for i in c], np.int32), local_order=np.asarray(pb["local"], np.int32))
+
+
 def flatten_match_to_map(pb, aux):
     """ids -> indices: what a host integration hands to the device path"""
     idx_of = {int(v): i for i, v in enumerate(pb["mp_id"])}
