@@ -18,6 +18,10 @@
 int alva_fbklt_track_to(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
                         int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, int n);
 
+int alva_bf_match_hamming_devcount(alva_ctx *ctx, const uint8_t *d_query, const int *d_n_query, int cap_query, const uint8_t *d_train,
+                                   const int *d_n_train, int cap_train, int *d_idx, int *d_dist);
+const int *alva_orb_device_count(const alva_orb *orb);
+
 struct alva_frontend {
     int device = 0, width = 0, height = 0, n_track = 0, cap = 0;
     alva_ctx *A = nullptr, *B = nullptr;
@@ -29,6 +33,7 @@ struct alva_frontend {
     float *d_prior = nullptr;
     uint8_t *d_status = nullptr;
     int *d_match = nullptr;  // idx | dist
+    int *d_counts = nullptr; // [2] descriptor count of each buffer, device copy (the matcher reads them before the host does)
     int n_desc[2] = {0, 0};
     long frame = 0;
     int klt_levels = 3;  // state.hpp:54 kltPyramidLevels_
@@ -42,7 +47,7 @@ extern "C" void alva_frontend_destroy(alva_frontend *fe) {
     if (fe->orb) alva_orb_destroy(fe->orb);
     for (auto p: fe->pyr)
         if (p) alva_pyramid_destroy(p);
-    void *bufs[] = {fe->d_gray, fe->d_kp[0], fe->d_kp[1], fe->d_desc[0], fe->d_desc[1], fe->d_prior, fe->d_status, fe->d_match};
+    void *bufs[] = {fe->d_gray, fe->d_kp[0], fe->d_kp[1], fe->d_desc[0], fe->d_desc[1], fe->d_prior, fe->d_status, fe->d_match, fe->d_counts};
     for (void *b: bufs)
         if (b) (void) hipFree(b);
     if (fe->B) alva_ctx_destroy(fe->B);
@@ -77,6 +82,7 @@ extern "C" int alva_frontend_create(int device, int width, int height, int max_t
     dev_alloc((void **) &fe->d_prior, (size_t) max_tracked * 2 * sizeof(float));
     dev_alloc((void **) &fe->d_status, (size_t) max_tracked);
     dev_alloc((void **) &fe->d_match, (size_t) fe->cap * 2 * sizeof(int));
+    dev_alloc((void **) &fe->d_counts, 2 * sizeof(int));
     if (rc) {
         alva_frontend_destroy(fe);
         return rc;
@@ -109,6 +115,14 @@ extern "C" int alva_frontend_track(alva_frontend *fe, const uint8_t *d_rgba, siz
     // lane B: detector + descriptors of this frame
     rc = alva_orb_detect_and_compute(fe->B, fe->orb, fe->d_gray, (size_t) fe->width, fe->d_kp[cur], fe->d_desc[cur], fe->cap, nullptr);
     if (rc) return rc;
+    // lane B: match against the previous frame's descriptors, enqueued right behind the detector with both counts still on
+    // the device (nothing of it is left on the host's path between two frames)
+    ALVA_HIP(hipMemcpyAsync(fe->d_counts + cur, alva_orb_device_count(fe->orb), sizeof(int), hipMemcpyDeviceToDevice, fe->B->stream));
+    if (fe->frame > 0 && fe->n_desc[prv] > 0) {
+        rc = alva_bf_match_hamming_devcount(fe->B, fe->d_desc[cur], fe->d_counts + cur, fe->cap, fe->d_desc[prv], fe->d_counts + prv,
+                                            fe->n_desc[prv], fe->d_match, fe->d_match + fe->cap);
+        if (rc) return rc;
+    }
     // host results
     rc = alva_compute_pose_collect(fe->A, h_pose7, nullptr, nullptr, h_pose_status);
     if (rc) return rc;
@@ -116,11 +130,6 @@ extern "C" int alva_frontend_track(alva_frontend *fe, const uint8_t *d_rgba, siz
     rc = alva_orb_collect(fe->B, fe->orb, &nkp);
     if (rc) return rc;
     nkp = nkp < fe->cap ? nkp : fe->cap;
-    // lane B: match against the previous frame's descriptors
-    if (fe->frame > 0 && nkp > 0 && fe->n_desc[prv] > 0) {
-        rc = alva_bf_match_hamming(fe->B, fe->d_desc[cur], nkp, fe->d_desc[prv], fe->n_desc[prv], fe->d_match, fe->d_match + fe->cap);
-        if (rc) return rc;
-    }
     fe->n_desc[cur] = nkp;
     *h_n_keypoints = nkp;
     fe->frame++;

@@ -18,9 +18,17 @@ namespace {
 constexpr int QT = 64;  // queries per workgroup (one wave)
 constexpr int TC = 64;  // train descriptors per chunk
 
+// dnq / dnt non-null: the counts are read from device memory (clamped to the launch's nq / nt capacities), so that the match can
+// be enqueued before the host knows how many descriptors the detector produced
 __global__ void __launch_bounds__(QT) k_bf_partial(const uint4 *__restrict__ q, int nq, const uint4 *__restrict__ t, int nt,
-                                                   uint32_t *__restrict__ partial /* [chunks][nq_pad] */, int nq_pad) {
+                                                   uint32_t *__restrict__ partial /* [chunks][nq_pad] */, int nq_pad,
+                                                   const int *__restrict__ dnq, const int *__restrict__ dnt) {
     __shared__ uint4 s_t[TC * 2];
+    if (dnq) {
+        nq = min(nq, *dnq);
+        nt = min(nt, *dnt);
+        if ((int) blockIdx.x * QT >= nq || (int) blockIdx.y * TC >= nt) return;
+    }
     const int lane = threadIdx.x;
     const int qi = blockIdx.x * QT + lane;
     const int t0 = blockIdx.y * TC;
@@ -53,7 +61,12 @@ __global__ void __launch_bounds__(QT) k_bf_partial(const uint4 *__restrict__ q, 
 }
 
 __global__ void __launch_bounds__(256) k_bf_final(const uint32_t *__restrict__ partial, int chunks, int nq, int nq_pad,
-                                                  int *__restrict__ idx, int *__restrict__ dist) {
+                                                  int *__restrict__ idx, int *__restrict__ dist, const int *__restrict__ dnq,
+                                                  const int *__restrict__ dnt) {
+    if (dnq) {
+        nq = min(nq, *dnq);
+        chunks = min(chunks, (min(chunks * TC, *dnt) + TC - 1) / TC);
+    }
     int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
     uint32_t best = 0xffffffffu;
@@ -83,11 +96,29 @@ extern "C" int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int 
         int rc = alva_ctx_scratch(ctx, 0, (size_t) chunks * nq_pad * sizeof(uint32_t), (void **) &partial);
         if (rc) return rc;
         hipLaunchKernelGGL(k_bf_partial, dim3(nq_pad / QT, chunks), dim3(QT), 0, ctx->stream, (const uint4 *) d_query, n_query,
-                           (const uint4 *) d_train, n_train, partial, nq_pad);
+                           (const uint4 *) d_train, n_train, partial, nq_pad, (const int *) nullptr, (const int *) nullptr);
         ALVA_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_bf_final, dim3(alva_divup(n_query, 256)), dim3(256), 0, ctx->stream, partial, chunks, n_query, nq_pad,
-                       d_idx, d_dist);
+                       d_idx, d_dist, (const int *) nullptr, (const int *) nullptr);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+// The same match with the two counts still on the device (internal: the per-frame driver enqueues it right behind the detector).
+// cap_query / cap_train bound the counts; rows of d_idx / d_dist beyond the actual query count are left untouched.
+int alva_bf_match_hamming_devcount(alva_ctx *ctx, const uint8_t *d_query, const int *d_n_query, int cap_query, const uint8_t *d_train,
+                                   const int *d_n_train, int cap_train, int *d_idx, int *d_dist) {
+    ALVA_ARG(ctx && d_query && d_train && d_n_query && d_n_train && d_idx && d_dist && cap_query > 0 && cap_train > 0 && cap_train < (1 << 20));
+    ALVA_ARG(((uintptr_t) d_query % 16) == 0 && ((uintptr_t) d_train % 16) == 0);
+    const int chunks = alva_divup(cap_train, TC), nq_pad = alva_divup(cap_query, QT) * QT;
+    uint32_t *partial = nullptr;
+    int rc = alva_ctx_scratch(ctx, 0, (size_t) chunks * nq_pad * sizeof(uint32_t), (void **) &partial);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bf_partial, dim3(nq_pad / QT, chunks), dim3(QT), 0, ctx->stream, (const uint4 *) d_query, cap_query,
+                       (const uint4 *) d_train, cap_train, partial, nq_pad, d_n_query, d_n_train);
+    hipLaunchKernelGGL(k_bf_final, dim3(alva_divup(cap_query, 256)), dim3(256), 0, ctx->stream, partial, chunks, cap_query, nq_pad, d_idx,
+                       d_dist, d_n_query, d_n_train);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

@@ -814,6 +814,9 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
 
 extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
 
+// device-resident total of the last detect_and_compute (internal: lets the driver chain the matcher without a host round trip)
+const int *alva_orb_device_count(const alva_orb *orb) { return orb->d_total; }
+
 extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch, float *d_kp,
                                            uint8_t *d_desc, int cap, int *h_count) {
     ALVA_ARG(ctx && orb && d_gray && d_kp && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
