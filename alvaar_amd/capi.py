@@ -111,7 +111,7 @@ class Context:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:   # `lib` is already gone at interpreter shutdown
             lib.alva_ctx_destroy(self.h)
             self.h = None
 
@@ -356,7 +356,7 @@ class Pyramid:
         self.num_levels = lib.alva_pyramid_num_levels(self.h)
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.alva_pyramid_destroy(self.h)
             self.h = None
 
@@ -398,7 +398,7 @@ class Orb:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.alva_orb_destroy(self.h)
             self.h = None
 
