@@ -13,16 +13,17 @@
 //             into a dense [points x 6*cams(+pad)] matrix.  For anchored inverse depth J_anchor = -J_obs
 //             (ceres_parametrization.cpp:239-256), so only J_obs and the scaled residual are stored
 //             (112 B / residual block; inputs 60 B) for the camera-pair pass.
-//   k_pairs   one wave per (observing kf, anchor kf) pair: sum of J_obs' J_obs and J_obs' r over the pair's
+//   k_pairs   one workgroup per (observing kf, anchor kf) pair: sum of J_obs' J_obs and J_obs' r over the pair's
 //             observations (a permutation built once on the host) -- from these 27 numbers per pair every
 //             block of F'F and F'r follows by signs.
-//   k_assemble   F'F, F'r, Jacobi column scaling (iteration 0), gradient max-norm.
+//   k_rowcol, k_hcc, k_gmax   F'F, F'r, Jacobi column scaling (iteration 0), gradient max-norm.
 // Per LM step:
 //   k_prep    per point: (E'E + D^2)^-1, its Cholesky factor L, Z_p = S_c W_p S_p L  and v_p = L'(E'r)
 //   k_gemm    G = Z' Z with v appended as one more column: ONE dense [6*cams+1 x points*d]^2 FP64 GEMM on
 //             v_mfma_f64_16x16x4_f64 (the only GEMM-shaped piece of the whole path) --
 //             S = F'F + D^2 - G,  rhs = F'r - G[:, last]
-//   k_solve   dense Cholesky of the reduced camera system in one workgroup, back-substitution inputs
+//   k_reduced_system   S and the right-hand side, padded to a multiple of 16
+//   k_solve   blocked dense Cholesky of the reduced camera system in one workgroup + blocked triangular solves
 //   k_backsub per point: y_p, candidate point; model-cost-change and step-norm partials
 //   k_point<cost only> on the candidate; the host reads three scalars and applies Ceres' accept/reject logic.
 #include "common.hpp"

@@ -12,10 +12,11 @@
 // Everything up to the angle is integer (or float with a fixed operation order) => bit-exact.  cv::ORB's keypoint ORDER
 // inside a level comes from std::nth_element; this implementation emits the same SET in row-major order per level.
 //
-// HBM traffic: the 8 levels total 3.27 P pixels; each is written once (resize), read once by the score
-// kernel through an LDS tile (+3 px halo), scores written once (u8) and re-read by the two row kernels: ~6.5 P bytes
-// algorithmic per frame.  All levels are processed by ONE launch per stage (blockIdx.y = level) so that a 640x480 frame
-// (3.3 k tiles) fills the 256 CUs; candidate lists stay ordered without a sort by counting per row, scanning, emitting.
+// HBM traffic: the 8 levels total 3.27 P pixels; each is written once (resize) and read once by the fused
+// FAST + NMS kernel through an LDS tile (+4 px halo): the ORB path keeps no score map (plain alva_fast still uses the
+// score-map kernels, whose row-major emission order is part of cv::FAST's contract).  All levels are processed by ONE launch
+// per stage (blockIdx.y = level) so that a 640x480 frame (3.3 k tiles) fills the 256 CUs; candidates are appended per tile
+// with one atomic, every cull is a threshold (order-free), and the survivors are put in row-major order at the very end.
 #include "common.hpp"
 #include <cmath>
 
