@@ -456,9 +456,11 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
         for (int e = threadIdx.x; e < total; e += SOLVE_NT) s_S[e] = B.S[e];
     }
     // micro-tile enumeration of a lower triangle, row by row: t -> (ta, tb), the same for every trailing size
-    __shared__ unsigned short s_tile[640];
-    for (int t = threadIdx.x; t < 640; t += SOLVE_NT) {
-        int ta = 0;
+    constexpr int TILE_LUT = 2048;   // covers np <= 268 (44 free cameras); larger systems decode arithmetically
+    __shared__ unsigned short s_tile[TILE_LUT];
+    for (int t = threadIdx.x; t < TILE_LUT; t += SOLVE_NT) {
+        int ta = (int) ((sqrtf(8.f * (float) t + 1.f) - 1.f) * 0.5f);
+        while (ta * (ta + 1) / 2 > t) ta--;
         while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
         s_tile[t] = (unsigned short) ((ta << 8) | (t - ta * (ta + 1) / 2));
     }
@@ -517,7 +519,16 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
         // ---- trailing update A22 -= L21 L21', lower triangle, 4x4 micro-tiles ----------------------------------------------
         const int mt = m / 4, ntile = mt * (mt + 1) / 2;
         for (int t = threadIdx.x; t < ntile; t += SOLVE_NT) {
-            const int ta = s_tile[t] >> 8, tb = s_tile[t] & 255;
+            int ta, tb;
+            if (t < TILE_LUT) {
+                ta = s_tile[t] >> 8;
+                tb = s_tile[t] & 255;
+            } else {
+                ta = (int) ((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while (ta * (ta + 1) / 2 > t) ta--;
+                while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+                tb = t - ta * (ta + 1) / 2;
+            }
             const double *La = S + (size_t) (base + NB + 4 * ta) * ld + base, *Lb = S + (size_t) (base + NB + 4 * tb) * ld + base;
             double acc[4][4];
 #pragma unroll
@@ -863,9 +874,9 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
     const size_t np16 = (n6 + 15) / 16 * 16, solve_lds = (np16 * (np16 + 1) + np16) * sizeof(double);
-    const bool solve_in_lds = solve_lds <= 156 * 1024;
+    const bool solve_in_lds = solve_lds <= 152 * 1024;   // + ~5 KB of static LDS in k_solve stays under the CU's 160 KB
     if (solve_in_lds && solve_lds > 48 * 1024)
-        ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     auto eval = [&](const double *xp, const double *xt, bool wantJ, bool first) -> int {
         if (n_pt > 0) {
             if (inv_depth) {

@@ -47,3 +47,13 @@ def test_local_ba_full_size(ctx):
     g2 = ctx.local_ba(pb2, 5, 0.0)
     assert np.abs(g2["poses"] - g["poses"]).max() < 1e-10
     assert np.allclose(g2["chi2"], g["chi2"][perm], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("nkf,npt,seed", [(28, 900, 9), (40, 600, 10)])
+def test_local_ba_more_cameras_than_fit_in_lds(ctx, nkf, npt, seed):
+    """6 x (free cameras) > 136: the reduced camera system no longer fits the LDS and the blocked Cholesky runs on the
+    copy in device memory (k_solve<false>); same tolerances."""
+    pb = synth.make_ba_problem(nkf, npt, seed)
+    assert 6 * int((pb["kf_const"] == 0).sum()) > 136
+    g = ctx.local_ba(pb, 5, 0.0)
+    ba_compare(g, Orc.local_ba(pb, 5, 0.0))
