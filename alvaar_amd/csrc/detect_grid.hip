@@ -24,6 +24,7 @@
 //                replayed sequentially (one lane each) so the float result is bit-identical.
 // This translation unit must be compiled with -ffp-contract=off.
 #include "common.hpp"
+#include <cstdlib>
 #include "wave_utils.hpp"
 
 namespace {
@@ -991,7 +992,8 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     // fixed-point rounds: K on all CUs (3 reach the fixed point on typical frames, the 4th confirms it), the rest -- if any --
     // in one workgroup without further launches
-    constexpr int K_ROUNDS = 4;
+    int K_ROUNDS = 4;
+    if (const char *e = getenv("ALVA_GRID_ROUNDS")) K_ROUNDS = std::min(4, std::max(1, atoi(e)));   // test hook: leave work to the finisher
     for (int k = 0; k < K_ROUNDS; k++) hipLaunchKernelGGL(k_round, dim3(alva_divup(nCells, 4)), dim3(256), 0, st, A, k & 1, k);
     const int fin = K_ROUNDS & 1;
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_sel, st, A, fin, K_ROUNDS - 1);

@@ -44,3 +44,18 @@ def test_detect_grid_properties_full_size(ctx):
         assert 0.5 * (w // cell) * (h // cell) < n <= (w // cell) * (h // cell)
         a = a.cpu().numpy()
         assert (a[:, 0] >= 20 - 3).all() and (a[:, 0] < w - 20 + 3).all() and (a[:, 1] >= 20 - 3).all() and (a[:, 1] < h - 20 + 3).all()
+
+
+@pytest.mark.parametrize("rounds", ["1", "2"])
+def test_detect_grid_finisher_path(ctx, monkeypatch, rounds):
+    """With fewer multi-CU repair rounds than the fixed point needs, the single-workgroup finisher (k_select) has real work
+    left; the result must not change."""
+    import torch
+    w, h, cell = 640, 480, 12
+    g = synth.frame_gray(synth.texture_canvas(w, h, 1), 2, w, h, noise_seed=1)
+    occ = np.random.RandomState(3).uniform(20, [w - 20, h - 20], (150, 2)).astype(np.float32)
+    monkeypatch.setenv("ALVA_GRID_ROUNDS", rounds)
+    pts, q = ctx.detect_grid(torch.from_numpy(g).cuda(), cell, occupied=torch.from_numpy(occ).cuda())
+    monkeypatch.delenv("ALVA_GRID_ROUNDS")
+    ref_pts, ref_q = Orc.detect_grid(g, cell, occupied=occ)
+    assert q == ref_q and np.array_equal(pts.cpu().numpy().view(np.uint32), ref_pts.view(np.uint32))

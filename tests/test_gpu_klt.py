@@ -64,3 +64,28 @@ def test_fbklt_identity_property(ctx):
     pr, st = pr.cpu().numpy(), st.cpu().numpy().astype(bool)
     assert st.sum() > 0.5 * n
     assert np.abs(pr[st] - pts[st]).max() < 0.01
+
+
+@pytest.mark.parametrize("dx,dy,levels,seed", [(14, 9, 3, 21), (9, -6, 0, 22), (30, 18, 3, 23)])
+def test_klt_large_motion_restages_the_search_tile(ctx, dx, dy, levels, seed):
+    """Displacements far beyond the 3 px of travel the LDS tile of the searched image allows for: the window leaves the tile
+    (several times at level 0 without pyramid help) and the tile is re-staged; results stay bitwise equal to the oracle, also
+    with a poor initial guess that makes the iteration wander."""
+    import torch
+    w, h, n = 320, 240, 500
+    canvas = synth.texture_canvas(w + 64, h + 64, seed)
+    prev = canvas[32:32 + h, 32:32 + w].copy()
+    curr = canvas[32 - dy:32 - dy + h, 32 - dx:32 - dx + w].copy()     # content moves by (+dx, +dy)
+    rng = np.random.RandomState(seed)
+    pts = rng.uniform(12, [w - 12, h - 12], (n, 2)).astype(np.float32)
+    init = (pts + rng.uniform(-6, 6, pts.shape)).astype(np.float32)
+    pp, cp = _pyrs(ctx, prev, curr)
+    nx, st, er = ctx.lk_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(init).cuda(), levels)
+    on, os_, oe = Orc.lk(prev, curr, pts, init, levels)
+    assert np.array_equal(st.cpu().numpy(), os_)
+    assert np.array_equal(nx.cpu().numpy().view(np.uint32), on.view(np.uint32))
+    pr, fs = ctx.fbklt_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(init).cuda(), levels)
+    op, ofs = Orc.fbklt(prev, curr, pts, init, levels)
+    assert np.array_equal(fs.cpu().numpy(), ofs) and np.array_equal(pr.cpu().numpy().view(np.uint32), op.view(np.uint32))
+    moved = np.abs(on[os_.astype(bool)] - pts[os_.astype(bool)]).max()
+    assert moved > 4.0        # the windows really travelled

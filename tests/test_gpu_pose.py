@@ -144,3 +144,28 @@ def test_compute_pose_enqueue_collect_equals_blocking_call(ctx):
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     with pytest.raises(Exception):
         ctx.compute_pose_collect()   # nothing pending
+
+
+def test_p3p_many_degenerate_samples_force_a_redraw(ctx):
+    """Most world points coincide, so most drawn triples are degenerate and do not count as LMedS iterations
+    (Lmeds.hpp:88-92): the first batch of samples cannot supply 100 valid hypotheses and the call re-draws a longer prefix
+    of the same stream.  Same result as the oracle's one-by-one loop."""
+    import torch
+    pb = synth.make_pnp_problem(400, 31, outlier_frac=0.1)
+    wpt = pb["wpt"].copy()
+    bv = pb["bv"].copy()
+    rng = np.random.RandomState(5)
+    dup = rng.rand(400) < 0.7
+    wpt[dup] = wpt[0]                       # 70 % of the points are the same 3-D point
+    bv[dup] = bv[0]
+    ok, R, t, out = ctx.p3p_lmeds(torch.from_numpy(bv).cuda(), torch.from_numpy(wpt).cuda(), fx=pb["K"][0], fy=pb["K"][1])
+    ok2, R2, t2, out2 = Orc.p3p_lmeds(bv, wpt, fx=pb["K"][0], fy=pb["K"][1])
+    assert ok == ok2
+    if ok:
+        assert np.abs(R - R2).max() < P3P_TOL and np.abs(t - t2).max() < P3P_TOL and np.array_equal(out, out2)
+    st, pose, m1, m2 = ctx.compute_pose(torch.from_numpy(bv).cuda(), torch.from_numpy(pb["uv"]).cuda(), torch.from_numpy(wpt).cuda(), pb["K"])
+    assert (st >= 1) == bool(ok2)
+    if ok2:
+        mask = np.zeros(400, bool)
+        mask[out2] = True
+        assert np.array_equal(m1, mask)
