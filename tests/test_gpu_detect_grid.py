@@ -59,3 +59,17 @@ def test_detect_grid_finisher_path(ctx, monkeypatch, rounds):
     monkeypatch.delenv("ALVA_GRID_ROUNDS")
     ref_pts, ref_q = Orc.detect_grid(g, cell, occupied=occ)
     assert q == ref_q and np.array_equal(pts.cpu().numpy().view(np.uint32), ref_pts.view(np.uint32))
+
+
+@pytest.mark.parametrize("maxq", [0.0, -1.0, 1e-9, 10.0])
+def test_detect_grid_unusual_quality_thresholds(ctx, maxq):
+    """maxQuality <= 0 cannot occur in the reference (it starts at 0.001 and only halves) but the C ABI accepts it: the exact
+    masked arg-max path (non-positive values compete) has to agree with the oracle as well; a huge threshold rejects everything."""
+    import torch
+    w, h, cell = 320, 240, 12
+    g = synth.frame_gray(synth.texture_canvas(w, h, 4), 2, w, h, noise_seed=4)
+    g[60:120, 80:200] = 90       # a flat patch: lambda_min exactly 0 there
+    occ = np.random.RandomState(5).uniform(20, [w - 20, h - 20], (40, 2)).astype(np.float32)
+    pts, q = ctx.detect_grid(torch.from_numpy(g).cuda(), cell, occupied=torch.from_numpy(occ).cuda(), max_quality=maxq)
+    ref_pts, ref_q = Orc.detect_grid(g, cell, occupied=occ, max_quality=maxq)
+    assert q == ref_q and np.array_equal(pts.cpu().numpy().view(np.uint32), ref_pts.view(np.uint32))

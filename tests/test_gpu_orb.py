@@ -40,3 +40,30 @@ def test_orb_detect_and_compute(ctx, w, h, seed, nf):
     bad = (desc != rd[ri]).any(axis=1).sum()
     assert bad <= max(1, len(kp) // 1000), bad
     orb.close()
+
+
+@pytest.mark.parametrize("w,h,seed,nf,scale,nlevels,thr", [(640, 480, 7, 500, 1.5, 4, 20), (400, 300, 8, 1000, 1.2, 3, 7), (320, 240, 9, 200, 2.0, 2, 40),
+                                                           (256, 256, 10, 300, 1.2, 1, 20)])
+def test_orb_other_pyramid_parameters(ctx, w, h, seed, nf, scale, nlevels, thr):
+    """cv::ORB::create with other scale factors / level counts / FAST thresholds than the reference's defaults"""
+    import torch
+    import alvaar_amd
+    g = _img(w, h, seed, noise=True)
+    orb = alvaar_amd.Orb(ctx, w, h, nf, scale=scale, nlevels=nlevels, fast_threshold=thr)
+    kp, desc = orb.detect_and_compute(torch.from_numpy(g).cuda())
+    kp, desc = kp.cpu().numpy(), desc.cpu().numpy()
+    rkp, rd = Orc.orb(g, nf, scale=scale, nlevels=nlevels, fast_thr=thr)
+    assert len(kp) == len(rkp) and len(rkp) > 10
+    ri = orb_key(rkp)
+    assert np.array_equal(kp.view(np.uint32), rkp[ri].view(np.uint32))
+    assert (desc != rd[ri]).any(axis=1).sum() <= max(1, len(kp) // 1000)
+    orb.close()
+
+
+@pytest.mark.parametrize("thr", [1, 60, 120])
+def test_fast_threshold_extremes(ctx, thr):
+    import torch
+    g = _img(320, 240, 12)
+    xy, sc = ctx.fast(torch.from_numpy(g).cuda(), thr)
+    rxy, rsc = Orc.fast(g, thr)
+    assert np.array_equal(xy.cpu().numpy(), rxy) and np.array_equal(sc.cpu().numpy(), rsc)

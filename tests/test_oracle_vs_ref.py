@@ -229,3 +229,35 @@ def test_orb_detect_and_compute_set_exact(w, h, seed, nf):
     oi, ri = orb_key(okp), orb_key(rkp)
     assert np.array_equal(okp[oi].view(np.uint32), rkp[ri].view(np.uint32))   # x, y, size, angle, response, octave: bitwise
     assert np.array_equal(od[oi], rd[ri])
+
+
+@pytest.mark.parametrize("w,h,seed,nf,scale,nlevels,thr", [(640, 480, 7, 500, 1.5, 4, 20), (400, 300, 8, 1000, 1.2, 3, 7), (320, 240, 9, 200, 2.0, 2, 40),
+                                                           (256, 256, 10, 300, 1.2, 1, 20)])
+def test_orb_other_pyramid_parameters(w, h, seed, nf, scale, nlevels, thr):
+    g = _img(w, h, seed, noise=True)
+    okp, od = Orc.orb(g, nf, scale=scale, nlevels=nlevels, fast_thr=thr)
+    rkp, rd = Ref.orb(g, nf, scale=scale, nlevels=nlevels, fast_thr=thr)
+    assert len(okp) == len(rkp) and len(rkp) > 10
+    oi, ri = orb_key(okp), orb_key(rkp)
+    assert np.array_equal(okp[oi].view(np.uint32), rkp[ri].view(np.uint32))
+    assert (od[oi] != rd[ri]).any(axis=1).sum() <= max(1, len(okp) // 1000)
+
+
+@pytest.mark.parametrize("thr", [1, 60, 120])
+def test_fast_threshold_extremes(thr):
+    g = _img(320, 240, 12)
+    oxy, osc = Orc.fast(g, thr)
+    rxy, rsc = Ref.fast(g, thr)
+    assert np.array_equal(oxy, rxy) and np.array_equal(osc, rsc)
+
+
+@pytest.mark.parametrize("maxq", [0.0, -1.0, 1e-9, 10.0])
+def test_detect_grid_unusual_quality_thresholds(maxq):
+    from alvaar_amd import synth
+    w, h, cell = 320, 240, 12
+    g = synth.frame_gray(synth.texture_canvas(w, h, 4), 2, w, h, noise_seed=4)
+    g[60:120, 80:200] = 90
+    occ = np.random.RandomState(5).uniform(20, [w - 20, h - 20], (40, 2)).astype(np.float32)
+    op, oq = Orc.detect_grid(g, cell, occupied=occ, max_quality=maxq)
+    rp, rq = Ref.detect_grid(g, cell, occupied=occ, max_quality=maxq)
+    assert oq == rq and np.array_equal(op.view(np.uint32), rp.view(np.uint32))
