@@ -85,6 +85,14 @@ _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
+_sig("alva_relpose_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
+_sig("alva_relpose_hypotheses", [_vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _vp, _vp])
+_sig("alva_compute_5pt_essential", [_vp, _vp, _vp, _i, _i, _f, _i, _i, C.c_uint32, _f, _f, _vp, _vp, _vp, _vp, _vp])
+
+
+class RelposeInfo(C.Structure):
+    _fields_ = [("iterations", _i), ("n_inliers", _i), ("draws", _i), ("lm_iterations", _i), ("lm_status", _i), ("lm_nfev", _i),
+                ("ransac_model", C.c_double * 12)]
 
 
 def check(rc: int) -> None:
@@ -163,6 +171,33 @@ class Context:
         check(lib.alva_p3p_lmeds(self.h, _ptr(bearings), _ptr(wpts), n, max_iters, err, int(do_random), seed, fx, fy,
                                  R.ctypes.data, t.ctypes.data, out.ctypes.data, C.byref(nout), C.byref(ok)))
         return bool(ok.value), R, t, out[:nout.value].copy()
+
+    # f2b
+    def compute_5pt_essential(self, bv1, bv2, max_iters=100, err=3.0, optimize=True, fx=579.4, fy=579.4, do_random=False, seed=12345):
+        """MultiViewGeometry::compute5ptEssentialMatrix: returns (ok, Rwc [3,3], twc [3], inlier mask [n] bool, RelposeInfo)."""
+        import numpy as np
+        n = bv1.shape[0]
+        assert bv1.dtype == torch.float64 and bv2.dtype == torch.float64 and bv2.shape[0] == n
+        R = np.zeros((3, 3))
+        t = np.zeros(3)
+        mask = np.zeros(max(n, 1), np.uint8)
+        info = RelposeInfo()
+        ok = C.c_int(0)
+        check(lib.alva_compute_5pt_essential(self.h, _ptr(bv1), _ptr(bv2), n, int(max_iters), float(err), int(optimize), int(do_random),
+                                             int(seed), float(fx), float(fy), R.ctypes.data, t.ctypes.data, mask.ctypes.data,
+                                             C.addressof(info), C.addressof(ok)))
+        return bool(ok.value), R, t, mask[:n].astype(bool), info
+
+    def relpose_hypotheses(self, bv1, bv2, samples8, err=3.0, fx=579.4, fy=579.4):
+        """One RANSAC hypothesis per 8-index sample: returns (models [H,12] = R row-major | t, inlier counts [H], -1 = no model)."""
+        import numpy as np
+        s = np.ascontiguousarray(samples8, np.int32)
+        H = s.shape[0]
+        models = np.zeros((H, 12))
+        counts = np.zeros(H, np.int32)
+        check(lib.alva_relpose_hypotheses(self.h, _ptr(bv1), _ptr(bv2), bv1.shape[0], s.ctypes.data, H, float(err), float(fx), float(fy),
+                                          models.ctypes.data, counts.ctypes.data))
+        return models, counts
 
     # a9
     def pnp_refine(self, uv, wpts, pose7, K, max_iters=5, chi2th=5.9915, robust=True, l2=True):
@@ -483,6 +518,13 @@ class Frontend:
         return {"tracked": view(ptrs[0], (n, 2), torch.float32), "status": view(ptrs[1], (n,), torch.uint8),
                 "keypoints": view(ptrs[2], (m, 6), torch.float32), "descriptors": view(ptrs[3], (m, 32), torch.uint8),
                 "match_idx": view(ptrs[4], (m,), torch.int32), "match_dist": view(ptrs[5], (m,), torch.int32)}
+
+
+def relpose_draw_samples(n_points: int, count: int, do_random: bool = False, seed: int = 12345):
+    import numpy as np
+    s = np.zeros((count, 8), np.int32)
+    check(lib.alva_relpose_draw_samples(n_points, count, int(do_random), seed, s.ctypes.data))
+    return s
 
 
 def kernel_times(fn, reps: int):

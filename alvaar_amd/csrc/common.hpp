@@ -51,7 +51,7 @@ struct alva_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    alva_scratch scratch[8];
+    alva_scratch scratch[12];
     void *pinned = nullptr;  // small pinned host staging (counters, results)
     size_t pinned_bytes = 0;
     int *d_counters = nullptr;  // 64 device ints, zero between launches (inter-workgroup arrival counters)

@@ -196,7 +196,7 @@ int alva_ctx_pinned(alva_ctx *ctx, size_t bytes, void **out) {
 }
 
 int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out) {
-    ALVA_ARG(slot >= 0 && slot < 8);
+    ALVA_ARG(slot >= 0 && slot < 12);
     alva_scratch &s = ctx->scratch[slot];
     if (s.bytes < bytes) {
         // growing frees the old block: wait for work that may still read it

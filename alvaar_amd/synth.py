@@ -344,3 +344,27 @@ def make_match_to_map_problem(n_points: int, seed: int, n_kf: int = 8, dist=(0.0
                 mp_wpt=np.array(mp_wpt), mp_is3d=np.array(mp_is3d, np.uint8), obs_ptr=obs_ptr, obs_kf=obs_kf,
                 obs_px=np.array(obs_px, np.float32), obs_desc=np.array(obs_desc, np.uint8), frame_kp_order=frame_kp_order,
                 local=np.array(local, np.int32), num_kp3d=int(in_frame.sum()))
+
+
+def make_relpose_problem(n: int, seed: int, outlier_frac: float = 0.2, px_noise: float = 0.5, baseline: float = 0.5, fx: float = 579.4,
+                         fy: float = 579.4, cx: float = 320.0, cy: float = 240.0):
+    """Two views of n points for the map initialisation (previous keyframe = view 1, current frame = view 2): unit bearings
+    bv1 / bv2 built from noisy pixel observations, a fraction of gross mismatches, and the true relative pose
+    X1 = R12 X2 + t12 (|t12| = baseline)."""
+    rng = np.random.RandomState(seed)
+    R12 = so3_exp(np.array([0.04, -0.07, 0.02]) * (1 + 0.3 * rng.randn(3)))
+    t12 = np.array([1.0, 0.15 * rng.randn(), 0.2 * rng.randn()])
+    t12 = baseline * t12 / np.linalg.norm(t12)
+    X1 = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2.2, 2.2, n), rng.uniform(3, 9, n)], 1)
+    X2 = (X1 - t12) @ R12          # R12^T (X1 - t12)
+    bad = rng.rand(n) < outlier_frac
+
+    def bearings(X, shift):
+        px = np.stack([fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy], 1) + px_noise * rng.randn(n, 2)
+        if shift:
+            px[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2))
+        px = px.astype(np.float32).astype(np.float64)
+        b = np.stack([(px[:, 0] - cx) / fx, (px[:, 1] - cy) / fy, np.ones(n)], 1)
+        return b / np.linalg.norm(b, axis=1, keepdims=True)
+    return dict(bv1=np.ascontiguousarray(bearings(X1, False)), bv2=np.ascontiguousarray(bearings(X2, True)), R12=R12, t12=t12, bad=bad,
+                K=(fx, fy, cx, cy))

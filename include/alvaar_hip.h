@@ -200,6 +200,35 @@ int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const dou
 int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
                               int *h_status);
 
+/* ---- f2b: two-view map initialisation ----------------------------------------------------------------
+ * Replaces MultiViewGeometry::compute5ptEssentialMatrix(bvs1, bvs2, maxIterations, errorThreshold, optimize, doRandom, fx, fy,
+ * Rwc, twc, outliers) (src/slam/src/multi_view_geometry.cpp:225-320; caller VisualFrontend::checkReadyForInit,
+ * visual_frontend.cpp:517-528 with state.hpp:67-69: 100 iterations, 3 px, optimize = true): OpenGV RANSAC (99 % confidence,
+ * adaptive iteration count) over Nister's five-point solver with 8-index samples, then Levenberg-Marquardt refinement of
+ * (t, Cayley(R)) on the inliers.  d_bv1 / d_bv2: n x 3 unit bearings in the previous keyframe / the current frame (device);
+ * the model is X1 = R X2 + t.  Outputs (host): h_R (3 x 3 row-major), h_t (as the reference, NOT normalised), h_inlier[n]
+ * (1 = inlier; the reference's outlier list is its complement; may be NULL), *h_ok = the reference's return value
+ * (0: n < 8, no model, or fewer than 10 inliers).  do_random = 0 draws the reference's deterministic sample stream
+ * (std::mt19937 seeded 12345u when seed = 12345).  Synchronous.
+ * The refinement is a forward-difference optimiser working at its rounding-noise floor: the reference's own result moves by
+ * 1e-6 .. 1e-4 when one input changes by one ulp, and agreement with it is of that size. */
+typedef struct alva_relpose_info {
+    int iterations;      /* RANSAC iterations the reference would have run (Ransac::iterations_) */
+    int n_inliers;
+    int draws;           /* samples consumed (iterations + samples without a real root) */
+    int lm_iterations, lm_status, lm_nfev; /* Eigen::LevenbergMarquardt iter / status code / function evaluations */
+    double ransac_model[12]; /* R (row-major) | t before the refinement */
+} alva_relpose_info;
+int alva_compute_5pt_essential(alva_ctx *ctx, const double *d_bv1, const double *d_bv2, int n, int max_iters,
+                               float error_threshold, int optimize, int do_random, uint32_t seed, float fx, float fy,
+                               double *h_R, double *h_t, uint8_t *h_inlier, alva_relpose_info *h_info, int *h_ok);
+/* The sample stream (count x 8 int32, SampleConsensusProblem.hpp:65-84) and the hypothesis stage alone: one
+ * CentralRelativePoseSacProblem::computeModelCoefficients (CentralRelativePoseSacProblem.cpp:38-247) + countWithinDistance per
+ * sample; h_counts[k] = -1 when sample k has no model. */
+int alva_relpose_draw_samples(int n_points, int count, int do_random, uint32_t seed, int *h_samples8);
+int alva_relpose_hypotheses(alva_ctx *ctx, const double *d_bv1, const double *d_bv2, int n, const int *h_samples8, int n_samples,
+                            float error_threshold, float fx, float fy, double *h_models12, int *h_counts);
+
 /* ---- f4a: CLAHE ------------------------------------------------------------------------------
  * Replaces cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply(src, dst) for 8-bit images
  * (imgproc/src/clahe.cpp:120-420), which VisualFrontend::preprocessImage runs when claheEnabled_

@@ -56,6 +56,23 @@ int orc_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *c
                  const double *ptAnchorUv, double *ptParam, int nObs, const int *obsKf, const int *obsPt, const double *obsUv,
                  int maxIterations, double functionTolerance, double huberChi2, double *chi2, uint8_t *depthPos, double *info /*[9]*/);
 
+/* f2b: two-view map initialisation, MultiViewGeometry::compute5ptEssentialMatrix (multi_view_geometry.cpp:225-320) = OpenGV
+ * RANSAC over Nister's five-point solver + forward-difference Levenberg-Marquardt refinement; restated in
+ * alva_oracle_relpose.c (file:line citations there).  Models are R (row-major 3x3) followed by t: X1 = R X2 + t. */
+int orc_sturm_roots(const double *coeffs, int ncoef, double *roots);
+void orc_nister_compose_a(const double *EE /* [9][4] */, double *A /* [10][20] */);
+int orc_nister_nullspace(const double *bv1, const double *bv2, double *EE /* [9][4] */);
+int orc_fivept_nister(const double *bv1, const double *bv2, double *E /* [<=10][9] */);
+int orc_relpose_model(const double *bv1, const double *bv2, int n, const int *idx8, double *model12);
+void orc_relpose_scores(const double *bv1, const double *bv2, int n, const double *model12, double *scores);
+void orc_relpose_optimize(const double *bv1, const double *bv2, int n, const int *inliers, int nIn, const double *model12, double *out12,
+                          int *info3 /* LM outer iterations, status, function evaluations */);
+int orc_relpose_draw_samples(int n, int count, uint32_t seed, int *samples8);
+int orc_relpose_ransac(const double *bv1, const double *bv2, int n, int maxIterations, float errorThreshold, uint32_t seed, float fx,
+                       float fy, double *ransacModel12, uint8_t *inlierMask, int *info2 /* iterations, inliers */);
+int orc_compute_5pt(const double *bv1, const double *bv2, int n, int maxIterations, float errorThreshold, int optimize, uint32_t seed,
+                    float fx, float fy, double *R_out, double *t_out, int *outliers, int *nOutliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,7 @@
 # (portable to the GPU box's host CPU, one Eigen alignment ABI everywhere):
 #   * OpenGV 1.0 sources    (/root/reference/src/libs/opengv/src/**/*.cpp)
 #   * AlvaAR slam sources   (/root/reference/src/slam/src/*.cpp minus embind.cpp)
-#   * oracle/ref_shim.cpp, oracle/ref_shim_map.cpp   (our extern "C" marshalling layers)
+#   * oracle/ref_shim.cpp, oracle/ref_shim_map.cpp, oracle/ref_shim_relpose.cpp   (our extern "C" marshalling layers)
 # from where they lie, and links them with the static OpenCV/Ceres built by
 # build_ref_libs.sh into oracle/_ref/libalva_ref.so.  Objects are cached under
 # oracle/_ref/build/obj and only rebuilt when the source is newer.
@@ -45,11 +45,12 @@ compile() { # src obj std
   done
   compile "$HERE/ref_shim.cpp" "$OBJ/ref_shim.o" c++17
   compile "$HERE/ref_shim_map.cpp" "$OBJ/ref_shim_map.o" c++17
+  compile "$HERE/ref_shim_relpose.cpp" "$OBJ/ref_shim_relpose.o" c++17
 } > "$OBJ/cmds.txt"
 if [ -s "$OBJ/cmds.txt" ]; then
   xargs -P "$J" -I{} bash -c '{}' < "$OBJ/cmds.txt"
 fi
-g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
+g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ/ref_shim_relpose.o" "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
   -Wl,--start-group "$P/lib/libopencv_video.a" "$P/lib/libopencv_calib3d.a" "$P/lib/libopencv_features2d.a" \
   "$P/lib/libopencv_flann.a" "$P/lib/libopencv_imgproc.a" "$P/lib/libopencv_core.a" -Wl,--end-group \
   "$P/lib/libceres.a" "$P"/lib/opencv4/3rdparty/libzlib.a -lpthread -ldl -Wl,--exclude-libs,ALL

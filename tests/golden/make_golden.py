@@ -109,9 +109,24 @@ def match_to_map():
     np.savez_compressed(OUT / "match_to_map.npz", **out)
 
 
+def relpose():
+    import oracles as O
+    """f2b: the compiled reference's RANSAC stage (model, inlier set, iteration count) and refined pose on four two-view problems."""
+    out = {"n_cases": 4}
+    for k, (n, seed, of) in enumerate([(150, 31, 0.25), (400, 32, 0.4), (64, 33, 0.1), (9, 34, 0.0)]):
+        p = synth.make_relpose_problem(n, seed, of)
+        ok, R, t, mask, iters = O.relpose_ransac(p["bv1"], p["bv2"], which="ref")
+        ok2, Ropt, topt, outl = O.compute_5pt(p["bv1"], p["bv2"], which="ref")
+        assert ok == ok2
+        out.update({f"bv1_{k}": p["bv1"], f"bv2_{k}": p["bv2"], f"ok_{k}": ok, f"R_{k}": R, f"t_{k}": t, f"mask_{k}": mask, f"iters_{k}": iters,
+                    f"Ropt_{k}": Ropt, f"topt_{k}": topt})
+    np.savez_compressed(OUT / "relpose.npz", **out)
+
+
 if __name__ == "__main__":
     match_to_map()
     triangulation()
     clahe()
     distortion()
+    relpose()
     main()

@@ -34,8 +34,8 @@ _ref = None
 def orc_lib():
     global _orc
     if _orc is None:
-        src = ROOT / "oracle" / "alva_oracle.c"
-        if not ORC_PATH.exists() or ORC_PATH.stat().st_mtime < src.stat().st_mtime:
+        newest = max(f.stat().st_mtime for f in (ROOT / "oracle").glob("alva_oracle*.[ch]"))
+        if not ORC_PATH.exists() or ORC_PATH.stat().st_mtime < newest:
             subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
         _orc = C.CDLL(str(ORC_PATH))
     return _orc
@@ -548,3 +548,104 @@ class Ref:
         ok = ref_lib().ref_p3p_lmeds(_p(bv), _p(wpt), n, max_iters, _f(err), int(do_random), _f(fx), _f(fy), _p(R), _p(t), _p(out),
                                      C.byref(nout))
         return bool(ok), R, t, out[:nout.value].copy()
+
+
+# ---- f2b: two-view initialisation (compute5ptEssentialMatrix).  Models are (R 3x3, t 3): X1 = R X2 + t -------------------------------
+def _bv(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _split(m12):
+    return m12[:9].reshape(3, 3).copy(), m12[9:].copy()
+
+
+def _join(R, t):
+    return np.concatenate([np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()])
+
+
+def relpose_sturm_roots(coeffs, which="orc"):
+    c = np.ascontiguousarray(coeffs, np.float64)
+    r = np.zeros(len(c))
+    fn = orc_lib().orc_sturm_roots if which == "orc" else ref_lib().ref_sturm_roots
+    n = fn(_p(c), len(c), _p(r))
+    return r[:n].copy()
+
+
+def relpose_nullspace(bv1, bv2, which="orc"):
+    EE = np.zeros((9, 4))
+    (orc_lib().orc_nister_nullspace if which == "orc" else ref_lib().ref_nister_nullspace)(_p(_bv(bv1)), _p(_bv(bv2)), _p(EE))
+    return EE
+
+
+def relpose_compose_a(EE, which="orc"):
+    A = np.zeros((10, 20))
+    (orc_lib().orc_nister_compose_a if which == "orc" else ref_lib().ref_nister_compose_a)(_p(_bv(EE)), _p(A))
+    return A
+
+
+def relpose_fivept(bv1, bv2, which="orc"):
+    E = np.zeros((10, 9))
+    n = (orc_lib().orc_fivept_nister if which == "orc" else ref_lib().ref_fivept_nister)(_p(_bv(bv1)), _p(_bv(bv2)), _p(E))
+    return E[:n].reshape(n, 3, 3).copy()
+
+
+def relpose_model(bv1, bv2, idx8, which="orc"):
+    idx = np.ascontiguousarray(idx8, np.int32)
+    m = np.zeros(12)
+    fn = orc_lib().orc_relpose_model if which == "orc" else ref_lib().ref_relpose_model
+    ok = fn(_p(_bv(bv1)), _p(_bv(bv2)), len(bv1), _p(idx), _p(m))
+    return (bool(ok),) + _split(m)
+
+
+def relpose_scores(bv1, bv2, R, t, which="orc"):
+    n = len(bv1)
+    s = np.zeros(n)
+    (orc_lib().orc_relpose_scores if which == "orc" else ref_lib().ref_relpose_scores)(_p(_bv(bv1)), _p(_bv(bv2)), n, _p(_join(R, t)), _p(s))
+    return s
+
+
+def relpose_optimize(bv1, bv2, inliers, R, t, which="orc"):
+    inl = np.ascontiguousarray(inliers, np.int32)
+    o = np.zeros(12)
+    info = np.zeros(3, np.int32)
+    if which == "orc":
+        orc_lib().orc_relpose_optimize(_p(_bv(bv1)), _p(_bv(bv2)), len(bv1), _p(inl), len(inl), _p(_join(R, t)), _p(o), _p(info))
+    else:
+        ref_lib().ref_relpose_optimize(_p(_bv(bv1)), _p(_bv(bv2)), len(bv1), _p(inl), len(inl), _p(_join(R, t)), _p(o))
+    return _split(o) + (info,)
+
+
+def relpose_draw_samples(n, count, seed=12345):
+    s = np.zeros((count, 8), np.int32)
+    orc_lib().orc_relpose_draw_samples(n, count, C.c_uint32(seed), _p(s))
+    return s
+
+
+def relpose_ransac(bv1, bv2, max_iters=100, err=3.0, fx=579.4, fy=579.4, seed=12345, which="orc"):
+    """-> ok, R, t (RANSAC model before refinement), inlier mask, iterations"""
+    n = len(bv1)
+    m = np.zeros(12)
+    mask = np.zeros(n, np.uint8)
+    info = np.zeros(2, np.int32)
+    if which == "orc":
+        ok = orc_lib().orc_relpose_ransac(_p(_bv(bv1)), _p(_bv(bv2)), n, max_iters, _f(err), C.c_uint32(seed), _f(fx), _f(fy), _p(m), _p(mask),
+                                          _p(info))
+    else:
+        ok = ref_lib().ref_relpose_ransac(_p(_bv(bv1)), _p(_bv(bv2)), n, max_iters, _f(err), _f(fx), _f(fy), _p(m), _p(mask), _p(info))
+    return (bool(ok),) + _split(m) + (mask.astype(bool), int(info[0]))
+
+
+def compute_5pt(bv1, bv2, max_iters=100, err=3.0, optimize=True, fx=579.4, fy=579.4, seed=12345, which="orc"):
+    """MultiViewGeometry::compute5ptEssentialMatrix -> ok, Rwc, twc, outlier indices"""
+    n = len(bv1)
+    R = np.zeros((3, 3))
+    t = np.zeros(3)
+    out = np.zeros(max(n, 1), np.int32)
+    nout = C.c_int(0)
+    if which == "orc":
+        ok = orc_lib().orc_compute_5pt(_p(_bv(bv1)), _p(_bv(bv2)), n, max_iters, _f(err), int(optimize), C.c_uint32(seed), _f(fx), _f(fy), _p(R),
+                                       _p(t), _p(out), C.byref(nout))
+    else:
+        ok = ref_lib().ref_compute_5pt(_p(_bv(bv1)), _p(_bv(bv2)), n, max_iters, _f(err), int(optimize), _f(fx), _f(fy), _p(R), _p(t), _p(out),
+                                       C.byref(nout))
+    return bool(ok), R, t, out[:nout.value].copy()

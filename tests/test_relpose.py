@@ -1,0 +1,245 @@
+"""f2b: two-view map initialisation, MultiViewGeometry::compute5ptEssentialMatrix
+(src/slam/src/multi_view_geometry.cpp:225-320).
+
+CPU part: every stage of the restatement (oracle/alva_oracle_relpose.c) against the compiled reference (OpenGV / Eigen), and the
+committed golden fixture.  GPU part: alva_compute_5pt_essential / alva_relpose_hypotheses against the restatement.
+
+Tolerances.  Everything up to and including the RANSAC model is deterministic arithmetic: 1e-9 (the hypotheses whose
+10th-degree polynomial has nearly coincident roots are the exception: there Newton does not converge in the reference's five
+steps and the result is sensitive to the last bit of its input; they are counted, not compared).  The refinement is a
+forward-difference Levenberg-Marquardt working at its noise floor: the reference's OWN output moves by 1e-6 .. 1e-4 (rotation)
+and up to 1e-3 (translation direction) when one input bearing changes by one ulp (test_reference_refinement_noise_floor
+measures it), so the refined pose is compared at that scale and through the cost it reaches."""
+import numpy as np
+import pytest
+
+import oracles as O
+from alvaar_amd import synth
+
+needs_ref = pytest.mark.skipif(not O.ref_available(), reason="compiled reference not built")
+FX = 579.4
+
+
+def _tdir(t):
+    return t / np.linalg.norm(t)
+
+
+def _cost(p, inl, R, t):
+    return float(np.sum(O.relpose_scores(p["bv1"][inl], p["bv2"][inl], R, t) ** 2))
+
+
+PROBLEMS = [(200, 1, 0.2), (500, 2, 0.3), (1000, 3, 0.1), (60, 4, 0.2), (300, 5, 0.5), (120, 6, 0.35), (2000, 8, 0.25), (40, 9, 0.1)]
+
+
+@needs_ref
+def test_sturm_is_bit_exact():
+    rng = np.random.RandomState(1)
+    for _ in range(500):
+        c = rng.randn(11) * np.exp(rng.randn(11))
+        a, b = O.relpose_sturm_roots(c, "orc"), O.relpose_sturm_roots(c, "ref")
+        assert len(a) == len(b) and np.array_equal(a, b)
+
+
+@needs_ref
+def test_nullspace_basis_and_constraint_matrix():
+    worst = 0.0
+    for seed in range(400):
+        p = synth.make_relpose_problem(5, seed, 0.0)
+        e_ref = O.relpose_nullspace(p["bv1"], p["bv2"], "ref")
+        e_orc = O.relpose_nullspace(p["bv1"], p["bv2"], "orc")
+        assert np.abs(e_ref - e_orc).max() < 1e-11     # same pivot order => same basis, not just the same subspace
+        worst = max(worst, np.abs(O.relpose_compose_a(e_ref, "ref") - O.relpose_compose_a(e_ref, "orc")).max())
+    assert worst < 1e-13
+
+
+@needs_ref
+def test_five_point_solutions():
+    diffs = []
+    for seed in range(600):
+        p = synth.make_relpose_problem(5, seed, 0.0)
+        a, b = O.relpose_fivept(p["bv1"], p["bv2"], "orc"), O.relpose_fivept(p["bv1"], p["bv2"], "ref")
+        assert len(a) == len(b)
+        diffs += [np.abs(x - y).max() for x, y in zip(a, b)]
+    diffs = np.array(diffs)
+    assert len(diffs) > 2000 and np.quantile(diffs, 0.9) < 1e-11 and (diffs > 1e-7).mean() < 0.01
+
+
+@needs_ref
+def test_hypothesis_model_and_scores():
+    bad = 0
+    for seed in range(300):
+        p = synth.make_relpose_problem(8, seed, 0.0)
+        ok1, R1, t1 = O.relpose_model(p["bv1"], p["bv2"], np.arange(8), "orc")
+        ok2, R2, t2 = O.relpose_model(p["bv1"], p["bv2"], np.arange(8), "ref")
+        assert ok1 == ok2
+        if ok1 and max(np.abs(R1 - R2).max(), np.abs(t1 - t2).max()) > 1e-9:
+            bad += 1
+    assert bad <= 3
+    p = synth.make_relpose_problem(400, 7, 0.2)
+    ok, R, t = O.relpose_model(p["bv1"], p["bv2"], np.arange(8), "ref")
+    assert ok and np.array_equal(O.relpose_scores(p["bv1"], p["bv2"], R, t, "orc"), O.relpose_scores(p["bv1"], p["bv2"], R, t, "ref"))
+
+
+@needs_ref
+@pytest.mark.parametrize("n,seed,of", PROBLEMS + [(9, 10, 0.0), (8, 11, 0.0)])
+def test_ransac_stage_identical(n, seed, of):
+    p = synth.make_relpose_problem(n, seed, of)
+    a = O.relpose_ransac(p["bv1"], p["bv2"], which="orc")
+    b = O.relpose_ransac(p["bv1"], p["bv2"], which="ref")
+    assert a[0] == b[0] and a[4] == b[4]                       # success flag, iteration count
+    assert np.array_equal(a[3], b[3])                          # inlier set
+    assert np.abs(a[1] - b[1]).max() < 1e-9 and np.abs(a[2] - b[2]).max() < 1e-9
+
+
+@needs_ref
+@pytest.mark.parametrize("n,seed,of", PROBLEMS)
+def test_full_call_against_reference(n, seed, of):
+    p = synth.make_relpose_problem(n, seed, of)
+    ok1, R1, t1, out1 = O.compute_5pt(p["bv1"], p["bv2"], which="orc")
+    ok2, R2, t2, out2 = O.compute_5pt(p["bv1"], p["bv2"], which="ref")
+    assert ok1 and ok2 and np.array_equal(out1, out2)
+    inl = np.setdiff1d(np.arange(n), out2)
+    c1, c2 = _cost(p, inl, R1, t1), _cost(p, inl, R2, t2)
+    tolR, tolT, tolC = (5e-4, 5e-3, 2e-2) if n < 100 else (5e-5, 5e-4, 5e-3)
+    assert abs(c1 - c2) <= tolC * c2                           # both sit on the same flat minimum
+    assert np.abs(R1 - R2).max() < tolR and np.abs(_tdir(t1) - _tdir(t2)).max() < tolT
+    # and both recover the true motion
+    assert np.abs(R2 - p["R12"]).max() < 0.05 and np.abs(_tdir(t2) - _tdir(p["t12"])).max() < 0.15
+
+
+@needs_ref
+def test_reference_refinement_noise_floor():
+    """The reference's refined pose is only defined to ~1e-6..1e-4: one input moved by one ulp moves it that much."""
+    moved = []
+    for n, seed, of in PROBLEMS[:6]:
+        p = synth.make_relpose_problem(n, seed, of)
+        _, R0, t0, o0 = O.compute_5pt(p["bv1"], p["bv2"], which="ref")
+        b1 = p["bv1"].copy()
+        k = int(np.setdiff1d(np.arange(n), o0)[0])
+        b1[k, 0] = np.nextafter(b1[k, 0], 2.0)
+        _, R1, t1, o1 = O.compute_5pt(b1, p["bv2"], which="ref")
+        assert np.array_equal(o0, o1)
+        moved.append(np.abs(R0 - R1).max())
+    assert max(moved) > 1e-7      # far above the 1e-16 input change
+    assert max(moved) < 1e-3
+
+
+@needs_ref
+def test_too_few_points_or_inliers():
+    p = synth.make_relpose_problem(7, 3, 0.0)
+    assert not O.compute_5pt(p["bv1"], p["bv2"], which="orc")[0] and not O.compute_5pt(p["bv1"], p["bv2"], which="ref")[0]
+    p = synth.make_relpose_problem(9, 10, 0.0)     # 9 correspondences: a model, but fewer than 10 inliers
+    assert not O.compute_5pt(p["bv1"], p["bv2"], which="orc")[0] and not O.compute_5pt(p["bv1"], p["bv2"], which="ref")[0]
+    rng = np.random.RandomState(0)                 # unrelated bearings
+    a = rng.randn(60, 3) + [0, 0, 4]
+    b = rng.randn(60, 3) + [0, 0, 4]
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    r1, r2 = O.relpose_ransac(a, b, which="orc"), O.relpose_ransac(a, b, which="ref")
+    assert r1[0] == r2[0] and r1[4] == r2[4] and np.array_equal(r1[3], r2[3])
+
+
+def test_golden_fixture():
+    g = np.load(O.ROOT / "tests" / "golden" / "relpose.npz")
+    for k in range(int(g["n_cases"])):
+        bv1, bv2 = g[f"bv1_{k}"], g[f"bv2_{k}"]
+        ok, R, t, mask, iters = O.relpose_ransac(bv1, bv2, which="orc")
+        assert ok == bool(g[f"ok_{k}"]) and iters == int(g[f"iters_{k}"]) and np.array_equal(mask, g[f"mask_{k}"])
+        assert np.abs(R - g[f"R_{k}"]).max() < 1e-9 and np.abs(t - g[f"t_{k}"]).max() < 1e-9
+        ok2, R2, t2, out = O.compute_5pt(bv1, bv2, which="orc")
+        assert ok2 == bool(g[f"ok_{k}"])
+        if ok2:
+            assert np.array_equal(out, np.nonzero(~g[f"mask_{k}"])[0])
+            assert np.abs(R2 - g[f"Ropt_{k}"]).max() < 5e-4 and np.abs(_tdir(t2) - _tdir(g[f"topt_{k}"])).max() < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    import alvaar_amd
+    c = alvaar_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+def test_gpu_sample_stream():
+    from alvaar_amd import capi
+    for n in (8, 9, 57, 2000):
+        assert np.array_equal(capi.relpose_draw_samples(n, 150), O.relpose_draw_samples(n, 150))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,of", [(200, 1, 0.2), (60, 4, 0.2), (1000, 3, 0.1)])
+def test_gpu_hypotheses_vs_oracle(ctx, n, seed, of):
+    p = synth.make_relpose_problem(n, seed, of)
+    S = O.relpose_draw_samples(n, 128)
+    models, counts = ctx.relpose_hypotheses(_dev(p["bv1"]), _dev(p["bv2"]), S)
+    thr = 2.0 * (1.0 - np.cos(np.arctan(np.float64(np.float32(3.0) / np.float32(FX)))))   # multi_view_geometry.cpp:276, double libm calls
+    unstable = 0
+    for k in range(len(S)):
+        ok, R, t = O.relpose_model(p["bv1"], p["bv2"], S[k])
+        assert ok == (counts[k] >= 0)
+        if not ok:
+            continue
+        d = max(np.abs(models[k, :9].reshape(3, 3) - R).max(), np.abs(models[k, 9:] - t).max())
+        if d > 1e-9:
+            unstable += 1
+            continue
+        c = int((O.relpose_scores(p["bv1"], p["bv2"], R, t) < thr).sum())
+        assert int(counts[k]) == c
+    assert unstable <= 6      # of 128: hypotheses with nearly coincident roots (see the module docstring)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,of", PROBLEMS + [(9, 10, 0.0), (8, 11, 0.0), (7, 12, 0.0), (3000, 13, 0.3)])   # 3000: Jacobian beyond the LDS budget
+def test_gpu_compute_5pt_vs_oracle(ctx, n, seed, of):
+    p = synth.make_relpose_problem(n, seed, of)
+    ok, R, t, mask, info = ctx.compute_5pt_essential(_dev(p["bv1"]), _dev(p["bv2"]))
+    oko, Ro, to, masko, iters = O.relpose_ransac(p["bv1"], p["bv2"]) if n >= 8 else (False, None, None, np.zeros(n, bool), 0)
+    assert ok == oko and info.iterations == iters and np.array_equal(mask, masko)
+    if n >= 8 and info.n_inliers > 0:
+        m = np.array(info.ransac_model)
+        assert np.abs(m[:9].reshape(3, 3) - Ro).max() < 1e-9 and np.abs(m[9:] - to).max() < 1e-9
+    if not ok:
+        return
+    _, R2, t2, out2 = O.compute_5pt(p["bv1"], p["bv2"])
+    inl = np.nonzero(mask)[0]
+    assert np.array_equal(np.setdiff1d(np.arange(n), inl), out2)
+    c1, c2 = _cost(p, inl, R, t), _cost(p, inl, R2, t2)
+    tolR, tolT, tolC = (5e-4, 5e-3, 2e-2) if n < 100 else (5e-5, 5e-4, 5e-3)
+    assert abs(c1 - c2) <= tolC * c2
+    assert np.abs(R - R2).max() < tolR and np.abs(_tdir(t) - _tdir(t2)).max() < tolT
+    assert np.abs(R.T @ R - np.eye(3)).max() < 1e-12
+    assert info.lm_status in (1, 2, 3, 6, 7) and 2 <= info.lm_iterations < 150
+
+
+@pytest.mark.gpu
+def test_gpu_compute_5pt_without_refinement_and_pure_outliers(ctx):
+    p = synth.make_relpose_problem(300, 5, 0.5)
+    ok, R, t, mask, info = ctx.compute_5pt_essential(_dev(p["bv1"]), _dev(p["bv2"]), optimize=False)
+    oko, Ro, to, masko, iters = O.relpose_ransac(p["bv1"], p["bv2"])
+    assert ok and oko and info.iterations == iters and np.array_equal(mask, masko)
+    assert np.abs(R - Ro).max() < 1e-9 and np.abs(t - to).max() < 1e-9
+    rng = np.random.RandomState(0)
+    a = rng.randn(60, 3) + [0, 0, 4]
+    b = rng.randn(60, 3) + [0, 0, 4]
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    ok, R, t, mask, info = ctx.compute_5pt_essential(_dev(a), _dev(b))
+    r = O.relpose_ransac(a, b)
+    assert ok == r[0] and info.iterations == r[4] and np.array_equal(mask, r[3])
+
+
+@pytest.mark.gpu
+def test_gpu_other_thresholds_and_iteration_caps(ctx):
+    p = synth.make_relpose_problem(400, 21, 0.4, px_noise=1.0)
+    for iters, err in ((20, 3.0), (100, 1.0), (250, 6.0)):
+        ok, R, t, mask, info = ctx.compute_5pt_essential(_dev(p["bv1"]), _dev(p["bv2"]), max_iters=iters, err=err, optimize=False)
+        r = O.relpose_ransac(p["bv1"], p["bv2"], max_iters=iters, err=err)
+        assert ok == r[0] and info.iterations == r[4] and np.array_equal(mask, r[3])
