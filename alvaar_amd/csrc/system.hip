@@ -7,13 +7,20 @@
 // robust PnP on the keypoints that carry a 3-D map point (:245-417) -> constant-velocity motion model update; and on a
 // keyframe (:554-594, here: fewer than half of the cells still tracked)  MapManager::extractKeypoints
 // (map_manager.cpp:193-222): grid detection in the unoccupied cells + ORB description.
-// NOT mirrored yet: initialisation (5-pt essential matrix), triangulation, map matching,
-// local-BA scheduling, plane fitting -- the host graph logic around them is the reference's L2 layer.
+// Cold start (visual_frontend.cpp:33-71, :419-551; mapper.cpp:9-51, :144-291): the first frame becomes keyframe 0; while the map
+// is not initialised every frame checks checkReadyForInit (median / rotation-compensated average parallax against the keyframe
+// > 40 px, then the 5-point RANSAC of alva_compute_5pt_essential, translation normalised to 1); the frame that passes becomes
+// keyframe 1 and its 2-D keypoints are triangulated against the keyframe that first observed them (alva_triangulate).  Every
+// later keyframe (checkNewKeyframeRequired, :554-594) extracts new keypoints and triangulates the same way.
+// NOT mirrored (the reference's L2 map layer): matching to the local map, local-BA scheduling, keyframe / map-point culling,
+// plane fitting.  alva_local_ba and alva_match_to_map exist behind the C ABI; the graph bookkeeping that feeds them does not.
 #include "common.hpp"
 #include "lm_device.hpp"
 #include "../../include/alvaar_system.h"
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <set>
 #include <unordered_map>
 
 static thread_local char g_sys_err[256] = "";
@@ -25,6 +32,12 @@ struct Keypoint {
     float px, py;
     bool is3d;
     double X[3];
+    int kf_first = -1, kf_last = -1;  // keyframe that first observed it / latest keyframe that holds it
+    float fpx = 0, fpy = 0, lpx = 0, lpy = 0;  // its position in those keyframes
+};
+struct KeyframeRec {
+    double pose[7];  // Twc
+    int frame_id, n3d;
 };
 }  // namespace
 
@@ -37,6 +50,10 @@ struct alva_system {
     int cur = 0;
     bool have_prev = false, configured = false;
     uint8_t *d_rgba = nullptr, *d_gray = nullptr, *d_desc = nullptr, *d_status = nullptr, *d_valid = nullptr;
+    double *d_tri = nullptr;  // triangulation staging: T blocks | bv_l | bv_r | lpt | wpt | inv depth | parallax | unpx_l | unpx_r | group | status
+    std::vector<KeyframeRec> kfs;
+    bool ready = false;       // state_->slamReadyForInit_
+    bool external_map = false;
     uint8_t *h_rgba_pinned = nullptr;
     float *d_pts = nullptr, *d_prior = nullptr, *d_new = nullptr;
     double *d_bv = nullptr, *d_wpt = nullptr, *d_uv = nullptr;
@@ -69,7 +86,8 @@ static void sys_free(alva_system *s) {
         alva_pyramid_destroy(p);
         p = nullptr;
     }
-    void *bufs[] = {s->d_rgba, s->d_gray, s->d_desc, s->d_status, s->d_valid, s->d_pts, s->d_prior, s->d_new, s->d_bv, s->d_wpt, s->d_uv};
+    void *bufs[] = {s->d_rgba, s->d_gray, s->d_desc, s->d_status, s->d_valid, s->d_pts, s->d_prior, s->d_new, s->d_bv, s->d_wpt, s->d_uv, s->d_tri};
+    s->d_tri = nullptr;
     for (void *b: bufs)
         if (b) (void) hipFree(b);
     s->d_rgba = s->d_gray = s->d_desc = s->d_status = s->d_valid = nullptr;
@@ -125,6 +143,7 @@ extern "C" int alva_system_configure(alva_system *s, int width, int height, doub
     ALVA_HIP(hipMalloc((void **) &s->d_bv, c * 24));
     ALVA_HIP(hipMalloc((void **) &s->d_wpt, c * 24));
     ALVA_HIP(hipMalloc((void **) &s->d_uv, c * 16));
+    ALVA_HIP(hipMalloc((void **) &s->d_tri, 32 * 36 * 8 + c * (24 * 4 + 8 * 2 + 8 * 2 + 4 + 8)));
     for (auto &p: s->pyr) {
         int rc = alva_pyramid_create(s->ctx, width, height, 9, 3, &p);   // state.hpp:51-53: 3 levels, 9x9 window
         if (rc) return rc;
@@ -137,6 +156,9 @@ extern "C" int alva_system_configure(alva_system *s, int width, int height, doub
 extern "C" void alva_system_reset(alva_system *s) {  // system.cpp:42-55
     if (!s) return;
     s->kps.clear();
+    s->kfs.clear();
+    s->ready = false;
+    s->external_map = false;
     s->have_prev = false;
     s->pose_failures = 0;
     s->max_quality = 0.001;
@@ -177,6 +199,259 @@ static int extract_keypoints(alva_system *s) {
     return ALVA_OK;
 }
 
+static void bearing_of(const alva_system *s, float px, float py, double *bv) {  // Frame::computeKeypoint: K^-1 px, normalised
+    const double x = (px - s->cx) / s->fx, y = (py - s->cy) / s->fy, nn = std::sqrt(x * x + y * y + 1.0);
+    bv[0] = x / nn;
+    bv[1] = y / nn;
+    bv[2] = 1.0 / nn;
+}
+static void se3_inverse(const Se3 &T, Se3 &Ti) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Ti.R[3 * r + c] = T.R[3 * c + r];
+    for (int r = 0; r < 3; r++) Ti.t[r] = -(Ti.R[3 * r] * T.t[0] + Ti.R[3 * r + 1] * T.t[1] + Ti.R[3 * r + 2] * T.t[2]);
+}
+static void se3_mul(const Se3 &A, const Se3 &B, Se3 &C) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) C.R[3 * r + c] = A.R[3 * r] * B.R[c] + A.R[3 * r + 1] * B.R[3 + c] + A.R[3 * r + 2] * B.R[6 + c];
+    for (int r = 0; r < 3; r++) C.t[r] = A.R[3 * r] * B.t[0] + A.R[3 * r + 1] * B.t[1] + A.R[3 * r + 2] * B.t[2] + A.t[r];
+}
+static void rot_to_quat(const double *R, double *q) {  // x y z w
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        const double S = std::sqrt(tr + 1.0) * 2;
+        q[3] = 0.25 * S; q[0] = (R[7] - R[5]) / S; q[1] = (R[2] - R[6]) / S; q[2] = (R[3] - R[1]) / S;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        const double S = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+        q[3] = (R[7] - R[5]) / S; q[0] = 0.25 * S; q[1] = (R[1] + R[3]) / S; q[2] = (R[2] + R[6]) / S;
+    } else if (R[4] > R[8]) {
+        const double S = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+        q[3] = (R[2] - R[6]) / S; q[0] = (R[1] + R[3]) / S; q[1] = 0.25 * S; q[2] = (R[5] + R[7]) / S;
+    } else {
+        const double S = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+        q[3] = (R[3] - R[1]) / S; q[0] = (R[2] + R[6]) / S; q[1] = (R[5] + R[7]) / S; q[2] = 0.25 * S;
+    }
+}
+static int count3d(const alva_system *s) {
+    int n = 0;
+    for (const Keypoint &k: s->kps) n += k.is3d ? 1 : 0;
+    return n;
+}
+
+// VisualFrontend::computeParallax (visual_frontend.cpp:596-670) against the latest keyframe
+static float compute_parallax(const alva_system *s, bool unrotate, bool median) {
+    if (s->kfs.empty()) return 0.f;
+    const int kf = (int) s->kfs.size() - 1;
+    double Rkc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (unrotate) {
+        Se3 Tk, Tc;
+        se3_from_pose7(s->kfs[(size_t) kf].pose, Tk);
+        se3_from_pose7(s->pose, Tc);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Rkc[3 * r + c] = Tk.R[r] * Tc.R[c] + Tk.R[3 + r] * Tc.R[3 + c] + Tk.R[6 + r] * Tc.R[6 + c];  // Rkw * Rwc
+    }
+    float avg = 0.f;
+    int n = 0;
+    std::set<float> all;
+    for (const Keypoint &k: s->kps) {
+        if (k.kf_last != kf) continue;
+        float ux = k.px, uy = k.py;
+        if (unrotate) {
+            double bv[3], r[3];
+            bearing_of(s, k.px, k.py, bv);
+            for (int i = 0; i < 3; i++) r[i] = Rkc[3 * i] * bv[0] + Rkc[3 * i + 1] * bv[1] + Rkc[3 * i + 2] * bv[2];
+            ux = (float) (s->fx * r[0] / r[2] + s->cx);
+            uy = (float) (s->fy * r[1] / r[2] + s->cy);
+        }
+        const float p = (float) std::sqrt((double) (ux - k.lpx) * (ux - k.lpx) + (double) (uy - k.lpy) * (uy - k.lpy));
+        avg += p;
+        n++;
+        if (median) all.insert(p);
+    }
+    if (!n) return 0.f;
+    avg /= (float) n;
+    if (median) {
+        auto it = all.begin();
+        std::advance(it, all.size() / 2);
+        avg = *it;
+    }
+    return avg;
+}
+
+// Mapper::triangulateTemporal (mapper.cpp:144-291) for the keyframe just created: every 2-D keypoint that an earlier keyframe
+// observed first is triangulated against that keyframe
+static int triangulate_new_keyframe(alva_system *s) {
+    const int newKf = (int) s->kfs.size() - 1;
+    std::vector<int> sel, groupOf, kfOfGroup;
+    for (size_t i = 0; i < s->kps.size(); i++) {
+        const Keypoint &k = s->kps[i];
+        if (k.is3d || k.kf_first < 0 || k.kf_first == newKf) continue;
+        int g = -1;
+        for (size_t q = 0; q < kfOfGroup.size(); q++)
+            if (kfOfGroup[q] == k.kf_first) g = (int) q;
+        if (g < 0) {
+            if (kfOfGroup.size() >= 32) continue;  // staging holds 32 distinct first keyframes; the map keeps 30 (mapper.cpp:15-18)
+            g = (int) kfOfGroup.size();
+            kfOfGroup.push_back(k.kf_first);
+        }
+        sel.push_back((int) i);
+        groupOf.push_back(g);
+    }
+    const int n = (int) sel.size(), G = (int) kfOfGroup.size();
+    if (!n) return ALVA_OK;
+    std::vector<double> T((size_t) G * 36), bvl((size_t) n * 3), bvr((size_t) n * 3);
+    std::vector<float> ul((size_t) n * 2), ur((size_t) n * 2);
+    Se3 Twr;
+    se3_from_pose7(s->kfs[(size_t) newKf].pose, Twr);
+    for (int g = 0; g < G; g++) {
+        Se3 Twl, Tlw, Tlr, Trl;
+        se3_from_pose7(s->kfs[(size_t) kfOfGroup[(size_t) g]].pose, Twl);
+        se3_inverse(Twl, Tlw);
+        se3_mul(Tlw, Twr, Tlr);  // Tcicj = Tciw * Twcj (:226-228)
+        se3_inverse(Tlr, Trl);
+        double *o = &T[(size_t) g * 36];
+        memcpy(o, Tlr.R, 72); memcpy(o + 9, Tlr.t, 24);
+        memcpy(o + 12, Trl.R, 72); memcpy(o + 21, Trl.t, 24);
+        memcpy(o + 24, Twl.R, 72); memcpy(o + 33, Twl.t, 24);
+    }
+    for (int k = 0; k < n; k++) {
+        const Keypoint &kp = s->kps[(size_t) sel[(size_t) k]];
+        bearing_of(s, kp.fpx, kp.fpy, &bvl[3 * (size_t) k]);
+        bearing_of(s, kp.px, kp.py, &bvr[3 * (size_t) k]);
+        ul[2 * (size_t) k] = kp.fpx; ul[2 * (size_t) k + 1] = kp.fpy;
+        ur[2 * (size_t) k] = kp.px; ur[2 * (size_t) k + 1] = kp.py;
+    }
+    hipStream_t st = (hipStream_t) alva_ctx_stream(s->ctx);
+    const size_t c = (size_t) s->cap;
+    double *dT = s->d_tri, *dbl = dT + 32 * 36, *dbr = dbl + 3 * c, *dlp = dbr + 3 * c, *dwp = dlp + 3 * c, *dinv = dwp + 3 * c, *dpar = dinv + c;
+    float *dul = (float *) (dpar + c), *dur = dul + 2 * c;
+    int *dgrp = (int *) (dur + 2 * c);
+    uint8_t *dst = (uint8_t *) (dgrp + c);
+    ALVA_HIP(hipMemcpyAsync(dT, T.data(), T.size() * 8, hipMemcpyHostToDevice, st));
+    ALVA_HIP(hipMemcpyAsync(dbl, bvl.data(), bvl.size() * 8, hipMemcpyHostToDevice, st));
+    ALVA_HIP(hipMemcpyAsync(dbr, bvr.data(), bvr.size() * 8, hipMemcpyHostToDevice, st));
+    ALVA_HIP(hipMemcpyAsync(dul, ul.data(), ul.size() * 4, hipMemcpyHostToDevice, st));
+    ALVA_HIP(hipMemcpyAsync(dur, ur.data(), ur.size() * 4, hipMemcpyHostToDevice, st));
+    ALVA_HIP(hipMemcpyAsync(dgrp, groupOf.data(), groupOf.size() * 4, hipMemcpyHostToDevice, st));
+    int rc = alva_triangulate(s->ctx, n, dT, G, dgrp, dbl, dbr, dul, dur, s->fx, s->fy, s->cx, s->cy, 3.0f /* state.hpp:64 */, dlp, dwp, dinv,
+                              dst, dpar);
+    if (rc) return rc;
+    std::vector<double> wp((size_t) n * 3), par((size_t) n);
+    std::vector<uint8_t> stt((size_t) n);
+    ALVA_HIP(hipMemcpyAsync(wp.data(), dwp, wp.size() * 8, hipMemcpyDeviceToHost, st));
+    ALVA_HIP(hipMemcpyAsync(par.data(), dpar, par.size() * 8, hipMemcpyDeviceToHost, st));
+    ALVA_HIP(hipMemcpyAsync(stt.data(), dst, stt.size(), hipMemcpyDeviceToHost, st));
+    ALVA_HIP(hipStreamSynchronize(st));
+    std::vector<uint8_t> drop(s->kps.size(), 0);
+    for (int k = 0; k < n; k++) {
+        Keypoint &kp = s->kps[(size_t) sel[(size_t) k]];
+        if (stt[(size_t) k] == 0) {
+            kp.is3d = true;  // MapManager::updateMapPoint (:286)
+            for (int q = 0; q < 3; q++) kp.X[q] = wp[3 * (size_t) k + q];
+        } else if (par[(size_t) k] > 20.) {
+            drop[(size_t) sel[(size_t) k]] = 1;  // removeMapPointObs (:258-262, :274-278)
+        }
+    }
+    std::vector<Keypoint> kept;
+    for (size_t i = 0; i < s->kps.size(); i++)
+        if (!drop[i]) kept.push_back(s->kps[i]);
+    s->kps.swap(kept);
+    return ALVA_OK;
+}
+
+// MapManager::createKeyframe (map_manager.cpp:45-89) + Mapper::processNewKeyframe's triangulation (mapper.cpp:9-25)
+static int create_keyframe(alva_system *s) {
+    const size_t before = s->kps.size();
+    int rc = extract_keypoints(s);
+    if (rc) return rc;
+    KeyframeRec kf{};
+    memcpy(kf.pose, s->pose, sizeof(kf.pose));
+    kf.frame_id = s->frame_id;
+    s->kfs.push_back(kf);
+    const int id = (int) s->kfs.size() - 1;
+    for (size_t i = 0; i < s->kps.size(); i++) {
+        Keypoint &k = s->kps[i];
+        if (i >= before || k.kf_first < 0) {
+            k.kf_first = id;
+            k.fpx = k.px;
+            k.fpy = k.py;
+        }
+        k.kf_last = id;
+        k.lpx = k.px;
+        k.lpy = k.py;
+    }
+    if (id > 0) {
+        rc = triangulate_new_keyframe(s);
+        if (rc) return rc;
+    }
+    s->kfs.back().n3d = count3d(s);
+    return ALVA_OK;
+}
+
+// VisualFrontend::checkReadyForInit (visual_frontend.cpp:419-551)
+static int check_ready_for_init(alva_system *s, bool *ready) {
+    *ready = false;
+    if (compute_parallax(s, false, true) <= 40.f) return ALVA_OK;  // state.hpp:37 minAvgRotationParallax_
+    if (s->kps.size() < 8) return ALVA_OK;
+    const int kf = (int) s->kfs.size() - 1;
+    std::vector<int> sel;
+    std::vector<double> b1, b2;
+    float avg = 0.f;
+    for (size_t i = 0; i < s->kps.size(); i++) {
+        const Keypoint &k = s->kps[i];
+        if (k.kf_last != kf) continue;
+        double a[3], b[3];
+        bearing_of(s, k.lpx, k.lpy, a);
+        bearing_of(s, k.px, k.py, b);
+        b1.insert(b1.end(), a, a + 3);
+        b2.insert(b2.end(), b, b + 3);
+        sel.push_back((int) i);
+        avg += (float) std::sqrt((double) (k.px - k.lpx) * (k.px - k.lpx) + (double) (k.py - k.lpy) * (k.py - k.lpy));  // both poses are identity
+    }
+    const int n = (int) sel.size();
+    if (n < 8) return ALVA_OK;
+    if (avg / (float) n < 40.f) return ALVA_OK;
+    hipStream_t st = (hipStream_t) alva_ctx_stream(s->ctx);
+    ALVA_HIP(hipMemcpyAsync(s->d_bv, b1.data(), b1.size() * 8, hipMemcpyHostToDevice, st));
+    ALVA_HIP(hipMemcpyAsync(s->d_wpt, b2.data(), b2.size() * 8, hipMemcpyHostToDevice, st));
+    double R[9], t[3];
+    std::vector<uint8_t> inl((size_t) n);
+    int ok = 0;
+    // state.hpp:67-69: 100 iterations, 3 px, random sampling (a fixed seed here, as for the P3P stage)
+    int rc = alva_compute_5pt_essential(s->ctx, s->d_bv, s->d_wpt, n, 100, 3.0f, 1, 0, 12345u, (float) s->fx, (float) s->fy, R, t, inl.data(),
+                                        nullptr, &ok);
+    if (rc) return rc;
+    if (!ok) return ALVA_OK;
+    std::vector<uint8_t> drop(s->kps.size(), 0);
+    for (int k = 0; k < n; k++)
+        if (!inl[(size_t) k]) drop[(size_t) sel[(size_t) k]] = 1;  // :541-544
+    std::vector<Keypoint> kept;
+    for (size_t i = 0; i < s->kps.size(); i++)
+        if (!drop[i]) kept.push_back(s->kps[i]);
+    s->kps.swap(kept);
+    const double tn = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);  // :547 twc.normalize()
+    for (int q = 0; q < 3; q++) s->pose[q] = t[q] / tn;
+    rot_to_quat(R, s->pose + 3);
+    *ready = true;
+    return ALVA_OK;
+}
+
+// VisualFrontend::checkNewKeyframeRequired (visual_frontend.cpp:554-594)
+static bool new_keyframe_required(const alva_system *s) {
+    if (s->kfs.empty()) return false;
+    const KeyframeRec &kf = s->kfs.back();
+    const float med = compute_parallax(s, true, true);
+    const int idDiff = s->frame_id - kf.frame_id, n3d = count3d(s), cellsW = s->w / s->cell;
+    const int maxKp = cellsW * (s->h / s->cell);  // state.cpp:8-11 frameMaxNumKeypoints_
+    std::set<int> occ;
+    for (const Keypoint &k: s->kps) occ.insert((int) (k.py / (float) s->cell) * cellsW + (int) (k.px / (float) s->cell));
+    const int occupied = (int) occ.size();
+    if (idDiff >= 5 && occupied < 0.33 * maxKp) return true;
+    if (idDiff >= 2 && n3d < 20) return true;
+    if (idDiff < 2 && n3d > 0.5 * maxKp) return false;
+    const bool cx = med >= 40.f / 2., c0 = med >= 40.f, c1 = n3d < 0.75 * kf.n3d, c2 = occupied < 0.5 * maxKp && n3d < 0.85 * kf.n3d;
+    return (c0 || c1 || c2) && cx;
+}
+
 extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgba, float *h_pose) {
     if (!s || !s->configured || !h_rgba || !h_pose) return ALVA_ERR_ARG;
     hipStream_t st = (hipStream_t) alva_ctx_stream(s->ctx);
@@ -189,9 +464,21 @@ extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgb
     alva_pyramid *cur = s->pyr[s->cur], *prev = s->pyr[s->cur ^ 1];
     int rc = alva_pyramid_build_from_rgba(s->ctx, cur, s->d_rgba, (size_t) s->w * 4, s->d_gray, (size_t) s->w);  // system.cpp:111-112 + :696
     if (rc) return rc;
-    int status = 3;
+    auto reset_and_report = [&]() {  // slamResetRequested_ -> System::reset, status 2 (system.cpp:163-167)
+        alva_system_reset(s);
+        pose_to_array(s->pose, h_pose);
+        return 2;
+    };
+    // ---- first frame: keyframe 0 (visual_frontend.cpp:37-41) ---------------------------------------------------------
+    if (!s->have_prev) {
+        rc = create_keyframe(s);
+        if (rc) return rc;
+        s->have_prev = true;
+        pose_to_array(s->pose, h_pose);
+        return 3;
+    }
     // ---- KLT tracking of the frame's keypoints (visual_frontend.cpp:103-243) -------------------------------------
-    if (s->have_prev && !s->kps.empty()) {
+    if (!s->kps.empty()) {
         const int n = (int) s->kps.size();
         std::vector<float> pts((size_t) n * 2);
         for (int i = 0; i < n; i++) {
@@ -217,17 +504,34 @@ extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgb
             }
         s->kps.swap(kept);
     }
+    // ---- not initialised yet (visual_frontend.cpp:52-71) --------------------------------------------------------------
+    if (!s->ready) {
+        if ((int) s->kps.size() - count3d(s) < 50) return reset_and_report();
+        bool ready = false;
+        rc = check_ready_for_init(s, &ready);
+        if (rc) return rc;
+        if (!ready) {
+            pose_to_array(s->pose, h_pose);
+            return 3;
+        }
+        s->ready = true;
+        rc = create_keyframe(s);  // keyframe 1: new keypoints + triangulation of the tracked ones against keyframe 0
+        if (rc) return rc;
+        if (s->kfs.size() == 2 && s->kfs.back().n3d < 30) return reset_and_report();  // mapper.cpp:29-39 bad initialisation
+        pose_to_array(s->pose, h_pose);
+        return 1;
+    }
     // ---- pose from the 3-D keypoints (visual_frontend.cpp:245-417) ------------------------------------------------
     std::vector<int> idx3d;
     for (size_t i = 0; i < s->kps.size(); i++)
         if (s->kps[i].is3d) idx3d.push_back((int) i);
-    if (s->have_prev && idx3d.size() >= 4) {
+    bool good = false;
+    if (idx3d.size() >= 4) {
         const int n = (int) idx3d.size();
         std::vector<double> bv((size_t) n * 3), wp((size_t) n * 3), uv((size_t) n * 2);
         for (int k = 0; k < n; k++) {
             const Keypoint &kp = s->kps[(size_t) idx3d[(size_t) k]];
-            const double x = (kp.px - s->cx) / s->fx, y = (kp.py - s->cy) / s->fy, nn = std::sqrt(x * x + y * y + 1.0);
-            bv[3 * (size_t) k] = x / nn; bv[3 * (size_t) k + 1] = y / nn; bv[3 * (size_t) k + 2] = 1.0 / nn;
+            bearing_of(s, kp.px, kp.py, &bv[3 * (size_t) k]);
             for (int c = 0; c < 3; c++) wp[3 * (size_t) k + c] = kp.X[c];
             uv[2 * (size_t) k] = kp.px;
             uv[2 * (size_t) k + 1] = kp.py;
@@ -243,7 +547,7 @@ extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgb
         rc = alva_compute_pose(s->ctx, s->d_bv, s->d_uv, s->d_wpt, n, 100, 3.0f, 0, 12345u, 5, 5.9915f, (float) s->fx, (float) s->fy,
                                (float) s->cx, (float) s->cy, pose7, outP3p.data(), outPnp.data(), &pstat);
         if (rc) return rc;
-        const bool good = pstat == 2;
+        good = pstat == 2;
         if (good) {
             // remove the observations P3P and ceresPnP flagged (visual_frontend.cpp:344-352, :411-414)
             std::vector<uint8_t> drop(s->kps.size(), 0);
@@ -253,26 +557,25 @@ extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgb
             for (size_t i = 0; i < s->kps.size(); i++)
                 if (!drop[i]) kept.push_back(s->kps[i]);
             s->kps.swap(kept);
-        }
-        if (good) {
             memcpy(s->pose, pose7, sizeof(pose7));
             s->pose_failures = 0;
-            status = 1;
-        } else if (++s->pose_failures > 3) {   // visual_frontend.cpp:86-92 -> System::reset, status 2
-            alva_system_reset(s);
-            pose_to_array(s->pose, h_pose);
-            return 2;
         }
     }
-    // ---- keyframe: extract new keypoints when too few cells are still tracked ---------------------------------------
-    const int cells = (s->w / s->cell) * (s->h / s->cell);
-    if (!s->have_prev || (int) s->kps.size() < cells / 2) {
-        rc = extract_keypoints(s);
+    if (!good && ++s->pose_failures > 3) return reset_and_report();   // visual_frontend.cpp:73-87
+    // ---- keyframe decision + creation (visual_frontend.cpp:554-594, map_manager.cpp:45-89, mapper.cpp:9-25) --------------
+    bool keyframe;
+    if (s->external_map) {
+        const int cells = (s->w / s->cell) * (s->h / s->cell);
+        keyframe = (int) s->kps.size() < cells / 2;  // host-fed map: only refill the grid
+    } else
+        keyframe = new_keyframe_required(s);
+    if (keyframe) {
+        rc = create_keyframe(s);
         if (rc) return rc;
+        if (!s->external_map && s->kfs.size() < 11 && s->kfs.back().n3d < 3) return reset_and_report();  // mapper.cpp:41-50
     }
-    s->have_prev = true;
     pose_to_array(s->pose, h_pose);
-    return status;
+    return 1;  // system.cpp:169-174: 1 whenever the map is initialised
 }
 
 extern "C" int alva_system_find_camera_pose_with_imu(alva_system *s, const uint8_t *h_rgba, const double *h_imu, float *h_pose) {
@@ -354,6 +657,7 @@ extern "C" int alva_system_set_map_points(alva_system *s, const int *h_ids, cons
         for (int c = 0; c < 3; c++) kp.X[c] = h_xyz[3 * k + c];
         m++;
     }
+    if (m) s->ready = s->external_map = true;  // a host-fed map replaces the two-view initialisation
     return m;
 }
 

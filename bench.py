@@ -251,6 +251,26 @@ def bench_ba(ctx, reps: int = 3):
                 note="whole alva_local_ba call incl. host structure build, H2D of the problem and D2H of results"), pb
 
 
+def bench_two_view_init(ctx, reps: int = 10):
+    """§8f-2 secondary line: the map-initialisation call (compute5ptEssentialMatrix) on 2000 correspondences, 25 % mismatches."""
+    import torch
+    from alvaar_amd import synth, capi
+    p = synth.make_relpose_problem(2000, 8, 0.25)
+    b1, b2 = torch.from_numpy(p["bv1"]).cuda(), torch.from_numpy(p["bv2"]).cuda()
+    ctx.compute_5pt_essential(b1, b2)  # warm
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ok, R, t, mask, info = ctx.compute_5pt_essential(b1, b2)
+    dt = (time.perf_counter() - t0) / reps
+    kt = capi.kernel_times(lambda: ctx.compute_5pt_essential(b1, b2), 5)
+    return dict(correspondences=2000, ok=bool(ok), ransac_iterations=int(info.iterations), inliers=int(info.n_inliers),
+                lm_iterations=int(info.lm_iterations), ms_per_call=dt * 1e3, calls_per_s=1.0 / dt,
+                kernels={k: {"avg_us": round(v[1], 2), "launches_per_call": round(v[0] / 5, 2)} for k, v in kt.items()},
+                rotation_error_vs_truth=float(np.abs(R - p["R12"]).max()),
+                note="whole alva_compute_5pt_essential call: host sample draw, 112 five-point hypotheses, adaptive-loop replay, "
+                     "on-device Levenberg-Marquardt refinement, one stream synchronisation")
+
+
 def cpu_baseline(seed: int, budget_s: float = 12.0):
     """Reference CPU path (1 thread) on a bounded sample of the same workload."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -283,7 +303,13 @@ def cpu_baseline(seed: int, budget_s: float = 12.0):
     t1 = time.perf_counter()
     r = O.local_ba(pbba, 5, 0.0)
     dtb = time.perf_counter() - t1
+    prp = synth.make_relpose_problem(2000, 8, 0.25)
+    t2 = time.perf_counter()
+    for _ in range(3):
+        oracles.compute_5pt(prp["bv1"], prp["bv2"], which="ref" if use_ref else "orc")
+    dt5 = (time.perf_counter() - t2) / 3
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
+            "two_view_init_ms": dt5 * 1e3,
             "sample": f"{n} frames of the same 640x480 / {NKP}-keypoint step (gray, 2 LK pyramids, fb-KLT 3 lvl, cv::ORB detectAndCompute 2000, "
                       f"BF Hamming, P3P-LMedS 100 it, Ceres PnP) + 1 local-BA solve",
             "local_ba_residual_block_iters_per_s": len(pbba["obs_kf"]) * (int(r["info"][0]) - 1) / dtb,
@@ -391,6 +417,7 @@ def main():
             "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,
                                      "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
             "local_ba": ba,
+            "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
             "config_1280x720": bench_720p(local) if world == 1 else None,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

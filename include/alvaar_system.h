@@ -9,10 +9,14 @@
  * Pose layout (src/slam/src/utils.cpp:3-27): p[0..2] = R row 0, p[4..6] = R row 1, p[8..10] = R row 2,
  * p[12..14] = t, p[3] = p[7] = p[11] = 0, p[15] = 1 (Twc).
  *
- * Scope in this round (DESIGN.md "System surface"): the per-frame tracking loop of SURVEY.md §3.2 runs on the GPU
- * (gray -> pyramid -> fb-KLT -> P3P-LMedS -> PnP) together with keyframe keypoint extraction (§3.3: grid detector +
- * ORB description).  Map initialisation / triangulation / map matching are NOT built yet, so
- * 3-D map points are attached with alva_system_set_map_points until those rows land; without them the status stays 3.
+ * Scope (DESIGN.md "System surface"): the per-frame loop of SURVEY.md §3.2 runs on the GPU (gray -> pyramid -> fb-KLT ->
+ * P3P-LMedS -> PnP), and so does the cold start: keyframe 0 on the first frame, the parallax gate and the five-point
+ * initialisation of VisualFrontend::checkReadyForInit (unit baseline), triangulation of every new keyframe's 2-D keypoints
+ * against the keyframe that first saw them (Mapper::triangulateTemporal), new keyframes by checkNewKeyframeRequired with grid
+ * detection + ORB description in the free cells.  The reference's map layer above that (matching to the local map, local-BA
+ * scheduling, keyframe / map-point culling, the plane fit) is not mirrored: alva_local_ba / alva_match_to_map exist in
+ * alvaar_hip.h for a host that keeps that graph.  alva_system_set_map_points lets a host attach its own 3-D points instead of
+ * the two-view initialisation.
  */
 #ifndef ALVAAR_SYSTEM_H
 #define ALVAAR_SYSTEM_H

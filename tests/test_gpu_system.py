@@ -52,3 +52,35 @@ def test_imu_variant_and_plane_conventions():
     assert pose is not None and np.allclose(pose.reshape(4, 4)[:3, :3], np.eye(3)) and pose[15] == 1.0
     assert ar.findPlane() is None                                     # < 32 observed 3-D points -> 0 (system.cpp:181)
     ar.close()
+
+
+def test_cold_start_initialises_its_own_map():
+    """No host-fed map: keyframe 0, parallax gate, 5-point initialisation (unit baseline), triangulation of keyframe 1, then
+    P3P + PnP tracking and new keyframes by the reference's policy -- the path checkReadyForInit -> createKeyframe ->
+    triangulateTemporal -> computePose of the reference, on the same fronto-parallel scene as above."""
+    from alvaar_amd.system import AlvaAR
+    w, h = 640, 480
+    ar = AlvaAR.Initialize(w, h)
+    canvas = synth.texture_canvas(w, h, 7)
+    frame = lambda k: synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h))
+    statuses, poses = [], {}
+    for k in range(0, 60):
+        pose, status = ar.findCameraPose(frame(k))
+        statuses.append(status)
+        if status == 1:
+            poses[k] = pose
+        assert status in (1, 3), (k, status)
+    k0 = statuses.index(1)
+    assert statuses[:k0] == [3] * k0 and all(s == 1 for s in statuses[k0:])
+    assert 17 <= k0 <= 22                                   # (2, 1) px per frame => > 40 px of parallax after 18 frames
+    d = np.array([2.0, 1.0, 0.0]) / np.sqrt(5.0)
+    t0 = poses[k0][12:15]
+    assert abs(np.linalg.norm(t0) - 1.0) < 1e-6             # twc.normalize() (visual_frontend.cpp:547)
+    assert np.abs(t0 - d).max() < 0.03                      # direction of the true translation
+    ids, px, is3d = ar.keypoints()
+    assert is3d.sum() >= 30                                 # the initial map (mapper.cpp:29: fewer than 30 would reset)
+    for k, pose in poses.items():
+        R, t = pose.reshape(4, 4)[:3, :3], pose[12:15]
+        assert np.abs(R - np.eye(3)).max() < 0.02, k
+        assert np.abs(t - d * k / k0).max() < 0.06 * k / k0, (k, t)     # the map's scale is the first baseline
+    ar.close()
