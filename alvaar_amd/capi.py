@@ -76,6 +76,7 @@ _sig("alva_triangulate", [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_double,
 _sig("alva_frontend_create", [_i, _i, _i, _i, _i, C.POINTER(_vp)])
 _sig("alva_frontend_destroy", [_vp], None)
 _sig("alva_frontend_track", [_vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp])
+_sig("alva_frontend_track_ahead", [_vp, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp])
 _sig("alva_frontend_results", [_vp] + [C.POINTER(_vp)] * 6)
 _sig("alva_frontend_sync", [_vp])
 _sig("alva_frontend_run_many", [_vp, _i, _i, _i, _vp, _i, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp])
@@ -487,11 +488,12 @@ class Frontend:
 
     __del__ = close
 
-    def track(self, rgba, pts, bearings, uv, wpts, K):
-        """returns (pose status 0/1/2, pose7 numpy (a view, overwritten by the next call), number of ORB keypoints)"""
-        check(lib.alva_frontend_track(self.h, _ptr(rgba), rgba.stride(0), _ptr(pts), pts.shape[0], _ptr(bearings), _ptr(uv), _ptr(wpts),
-                                      bearings.shape[0], K[0], K[1], K[2], K[3], self._pose.ctypes.data, C.byref(self._st),
-                                      C.byref(self._nkp)))
+    def track(self, rgba, pts, bearings, uv, wpts, K, rgba_next=None):
+        """returns (pose status 0/1/2, pose7 numpy (a view, overwritten by the next call), number of ORB keypoints).
+        rgba_next: the frame the next call will pass as rgba (its gray + pyramid are built on a third stream meanwhile)."""
+        check(lib.alva_frontend_track_ahead(self.h, _ptr(rgba), rgba.stride(0), None if rgba_next is None else _ptr(rgba_next), _ptr(pts),
+                                            pts.shape[0], _ptr(bearings), _ptr(uv), _ptr(wpts), bearings.shape[0], K[0], K[1], K[2], K[3],
+                                            self._pose.ctypes.data, C.byref(self._st), C.byref(self._nkp)))
         self._npts = pts.shape[0]
         return self._st.value, self._pose, self._nkp.value
 

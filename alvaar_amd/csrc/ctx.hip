@@ -104,7 +104,7 @@ extern "C" int alva_prof_report(char *buf, size_t cap) {
     return ALVA_OK;
 }
 
-extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out) {
+static int ctx_create(int device, void *hip_stream, int own_stream, int priority_class, alva_ctx **out) {
     ALVA_ARG(out != nullptr);
     int ndev = 0;
     ALVA_HIP(hipGetDeviceCount(&ndev));
@@ -115,7 +115,10 @@ extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alv
     if (!own_stream) {
         c->stream = (hipStream_t) hip_stream;  // NULL = legacy default stream
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        int least = 0, greatest = 0;  // numerically: greatest priority <= least priority
+        (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int prio = priority_class < 0 ? greatest : (priority_class > 0 ? least : (least + greatest) / 2);
+        hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
         if (e != hipSuccess) {
             delete c;
             alva_set_error("hipStreamCreate: %s", hipGetErrorString(e));
@@ -142,6 +145,17 @@ extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alv
     }
     *out = c;
     return ALVA_OK;
+}
+
+extern "C" int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out) {
+    return ctx_create(device, hip_stream, own_stream, 0, out);
+}
+
+// Own non-blocking stream in one of the device's priority classes (-1 high, 0 normal, +1 low).  Besides the scheduling hint this
+// decides the hardware queue: the HIP runtime multiplexes the streams of one priority class onto a small pool of hardware
+// queues (GPU_MAX_HW_QUEUES, default 4), and two streams that share a queue execute strictly one after the other.
+extern "C" int alva_ctx_create_with_priority(int device, int priority_class, alva_ctx **out) {
+    return ctx_create(device, nullptr, 1, priority_class, out);
 }
 
 extern "C" void alva_ctx_destroy(alva_ctx *ctx) {

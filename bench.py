@@ -34,6 +34,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The HIP runtime multiplexes all streams of a priority class onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams
+# that share a queue serialise; the multi-camera measurement drives up to 16 x 3 streams.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -98,10 +101,13 @@ class FrameJob:
             self._det[n:] = self.pts[n:]
         return self._det
 
-    def step_native(self):
-        """The frame through alva_frontend_track: the same stage calls as step_overlapped(), issued from C++."""
+    def step_native(self, lookahead: bool = True):
+        """The frame through alva_frontend_track_ahead: the same stage calls as step_overlapped(), issued from C++.  With
+        look-ahead the NEXT frame of the resident ring has its gray image + pyramid built on a third stream meanwhile (every
+        step still builds exactly one pyramid)."""
         self.k += 1
-        st, pose, nkp = self.fe.track(self.frames[self.k % RING], self.pts, self.bv, self.uv, self.wpt, self.K)
+        nxt = self.frames[(self.k + 1) % RING] if lookahead else None
+        st, pose, nkp = self.fe.track(self.frames[self.k % RING], self.pts, self.bv, self.uv, self.wpt, self.K, rgba_next=nxt)
         return st == 2
 
     def step_overlapped(self):
@@ -359,6 +365,7 @@ def main():
 
     headline = job.step if args.serial else (job.step_overlapped if args.python_host else job.step_native)
     dt = timed(headline, args.warmup, args.steps)
+    dt_nola = timed(lambda: job.step_native(lookahead=False), 3, args.steps)
     dt_py = timed(job.step_overlapped, 3, args.steps)
     # secondary: every stage back-to-back on ONE HIP stream, and the same with the reference-actual detector
     dt_serial = timed(job.step, 3, args.steps)
@@ -406,10 +413,13 @@ def main():
             "config": {"workload": "configs[1]: 640x480 RGBA stream, ORB 2000 kp/frame, FAST+ORB+Hamming match+KLT+PnP full track",
                        "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels, 2120 pts)", "orb_detect_and_compute(2000, 1.2, 8)",
                                   "bf_hamming ~2000x2000", "compute_pose = p3p_lmeds(100 it, 2120 pts) -> pnp_refine(5 it, inliers)"],
-                       "host": "alva_frontend_track (C++)" if not (args.serial or args.python_host) else "python ctypes",
+                       "host": "alva_frontend_track_ahead (C++; the next resident frame's gray + pyramid are built on a third HIP stream)" if not (args.serial or args.python_host) else "python ctypes",
                        "not_in_timed_region": [],
+                       "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                        "parallelism": f"{world} independent camera streams, one per GPU, no collective; within a frame the detector "
                                       "(ORB + match) and the tracker (fb-KLT + pose) run on two HIP streams" + (" [disabled: --serial]" if args.serial else "")},
+            "no_lookahead": {"frames_per_s": world * args.steps / dt_nola, "ms_per_step": dt_nola / args.steps * 1e3,
+                             "stages": "alva_frontend_track: same work, the frame's own gray + pyramid built at the head of its tracker chain"},
             "python_host_two_streams": {"frames_per_s": world * args.steps / dt_py, "ms_per_step": dt_py / args.steps * 1e3,
                                         "stages": "same work and overlap, stage calls issued from Python (ctypes) instead of alva_frontend_track"},
             "one_hip_stream": {"frames_per_s": world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3,

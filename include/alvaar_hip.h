@@ -40,6 +40,11 @@ typedef struct alva_pyramid alva_pyramid;
  * own_stream == 0: enqueue on the caller's hipStream_t `hip_stream` as given -- NULL is the
  * legacy default stream (e.g. torch's current stream handle, which is 0 for the default stream). */
 int alva_ctx_create(int device, void *hip_stream, int own_stream, alva_ctx **out);
+/* Context with its own non-blocking stream in one of the device's priority classes: -1 high, 0 normal, +1 low.  The HIP runtime
+ * multiplexes the streams of a class onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); streams sharing a queue run
+ * strictly one after the other, so lanes that must overlap (alva_frontend's tracker / detector / look-ahead lanes) are
+ * created in different classes. */
+int alva_ctx_create_with_priority(int device, int priority_class, alva_ctx **out);
 void alva_ctx_destroy(alva_ctx *ctx);
 int alva_ctx_sync(alva_ctx *ctx);
 /* Per-kernel timing for bench.py's roofline line: while enabled every kernel launch of the library is bracketed by two
@@ -302,6 +307,14 @@ void alva_frontend_destroy(alva_frontend *fe);
 int alva_frontend_track(alva_frontend *fe, const uint8_t *d_rgba, size_t rgba_pitch, const float *d_pts, int n_pts,
                         const double *d_bearings, const double *d_uv, const double *d_wpts, int n_corr, float fx,
                         float fy, float cx, float cy, double *h_pose7, int *h_pose_status, int *h_n_keypoints);
+/* The same with one frame of look-ahead: d_rgba_next (may be NULL) is the frame the NEXT call will pass as d_rgba; its gray
+ * image and pyramid are built on a third HIP stream while this frame is tracked, so preprocessImage leaves the dependent chain
+ * pyramid -> KLT -> P3P -> PnP.  The buffer must not change until that call; a next call with any other d_rgba simply rebuilds.
+ * Results are identical to alva_frontend_track. */
+int alva_frontend_track_ahead(alva_frontend *fe, const uint8_t *d_rgba, size_t rgba_pitch, const uint8_t *d_rgba_next,
+                              const float *d_pts, int n_pts, const double *d_bearings, const double *d_uv, const double *d_wpts,
+                              int n_corr, float fx, float fy, float cx, float cy, double *h_pose7, int *h_pose_status,
+                              int *h_n_keypoints);
 /* Device-resident results of the last alva_frontend_track: tracked positions (n_pts x 2) + status, ORB keypoints
  * (n x 6) + descriptors (n x 32), matches of the n descriptors against the previous frame's.  Any may be NULL.
  * Call alva_frontend_sync first if anything but later alva_frontend_* calls is going to read them. */
