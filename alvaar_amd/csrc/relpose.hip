@@ -24,6 +24,7 @@
 #include "wave_utils.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <ctime>
 #include <limits>
 #include <random>
@@ -167,6 +168,15 @@ __device__ void rp_cpqr_9x5(double *A /* column-major 9 x 5 */, double *hc) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Eigen::LevenbergMarquardt pieces for N unknowns (lmpar.h:160-296, qrsolv.h:17-88, Jacobi.h makeGivens); all N x N
 // matrices column-major m[j][i] = M(i, j).
+// Jacobi.h makeGivens (real case).  Its two branches (|p| > |q| or not) both reduce to c = p / r, s = -q / r with r = |(p, q)|;
+// one reciprocal square root (hardware estimate + two Newton steps) replaces a division, a square root and a second division.
+// This algebra feeds a trust-region search that runs at its rounding-noise floor anyway (DESIGN.md, f2b note).
+__device__ __forceinline__ double rp_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
 __device__ __forceinline__ void rp_givens(double p, double q, double &c, double &s) {
     if (q == 0) {
         c = p < 0 ? -1 : 1;
@@ -174,18 +184,10 @@ __device__ __forceinline__ void rp_givens(double p, double q, double &c, double 
     } else if (p == 0) {
         c = 0;
         s = q < 0 ? 1 : -1;
-    } else if (fabs(p) > fabs(q)) {
-        const double t = q / p;
-        double u = sqrt(1 + t * t);
-        if (p < 0) u = -u;
-        c = 1 / u;
-        s = -t * c;
     } else {
-        const double t = p / q;
-        double u = sqrt(1 + t * t);
-        if (q < 0) u = -u;
-        s = -1 / u;
-        c = -t * s;
+        const double ir = rp_rsqrt(p * p + q * q);
+        c = p * ir;
+        s = -q * ir;
     }
 }
 template <int N> __device__ double rp_norm(const double (&v)[N]) {
@@ -1132,7 +1134,8 @@ struct RelposeSelectArgs {
     uint8_t *mask;                     // [n] pinned host
     int *inl;                          // [n] ordered inlier indices (device)
 };
-constexpr int RP_NT = 256;
+constexpr int RP_NT = 256;     // k_relpose_select
+constexpr int RP_LM_NT = 256;  // k_relpose_lm (512 threads measured slower: every barrier and the replicated 6 x 6 algebra cost more than the residual passes gain)
 
 __global__ __launch_bounds__(RP_NT) void k_relpose_select(const RelposeSelectArgs P) {
     __shared__ RelposeSelectOut so;
@@ -1209,6 +1212,7 @@ __global__ __launch_bounds__(RP_NT) void k_relpose_select(const RelposeSelectArg
 struct RelposeLmOut {
     double model[12];
     int iterations, status, nfev, ran;
+    long long cyc[6];  // wall_clock64 ticks (100 MHz): Jacobian passes | QR | trust-region algebra | trial passes | total | lmpar calls
 };
 struct RelposeLmArgs {
     const double *bv1, *bv2;
@@ -1257,7 +1261,7 @@ __device__ void rp_rot2cayley(const double *R, double *c) {  // cayley.cpp:74-88
 }
 // sum of K per-thread values over the workgroup, delivered to every thread in a fixed order; ONE barrier per call (the
 // staging buffer alternates, so the next call's writes cannot overtake this call's reads)
-template <int K> __device__ void rp_block_sum(double (&v)[K], double (*red)[4][8], int &parity) {
+template <int K> __device__ void rp_block_sum(double (&v)[K], double (*red)[RP_LM_NT / 64][8], int &parity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -1267,16 +1271,21 @@ template <int K> __device__ void rp_block_sum(double (&v)[K], double (*red)[4][8
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = ((red[parity][0][k] + red[parity][1][k]) + red[parity][2][k]) + red[parity][3][k];
+    for (int k = 0; k < K; k++) {
+        double t = red[parity][0][k];
+#pragma unroll
+        for (int w = 1; w < RP_LM_NT / 64; w++) t += red[parity][w][k];
+        v[k] = t;
+    }
     parity ^= 1;
 }
 
 // LDS = true: residuals, their working copy and the Jacobian (8 doubles per inlier) live in dynamic LDS (n <= RP_LDS_ROWS);
-// otherwise in the context's scratch.  Row i of every array belongs to thread i % RP_NT.
+// otherwise in the context's scratch.  Row i of every array belongs to thread i % RP_LM_NT.
 constexpr int RP_LDS_ROWS = 2368;  // 8 * 8 B * 2368 = 148 KB of the CU's 160 KB
-template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const RelposeLmArgs P) {
+template <bool LDS> __global__ __launch_bounds__(RP_LM_NT) void k_relpose_lm(const RelposeLmArgs P) {
     extern __shared__ double rp_dyn[];
-    __shared__ double red[2][4][8];
+    __shared__ double red[2][RP_LM_NT / 64][8];
     constexpr int N = 6;
     const int tid = threadIdx.x;
     const RelposeSelectOut *sel = P.sel;
@@ -1320,7 +1329,7 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
     {
         double R[9], sq[1] = {0};
         rp_cayley2rot(x + 3, R);
-        for (int i = tid; i < m; i += RP_NT) {
+        for (int i = tid; i < m; i += RP_LM_NT) {
             const double r = residual(R, x, i);
             fvec[i] = r;
             sq[0] += r * r;
@@ -1331,7 +1340,10 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
     double diag[N] = {0, 0, 0, 0, 0, 0};
     int status = 0;
     const double fdeps = sqrt(RP_EPS);
+    long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    const long long tAll = wall_clock64(), cAll = clock64();
     while (!status) {
+        long long tc = wall_clock64();
         // ---- forward-difference Jacobian (NumericalDiff.h:63-121): f(x) again (bit-identical to fvec) + one evaluation per unknown
         double colsq[N] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1343,13 +1355,13 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
             for (int q = 0; q < N; q++) xt[q] = x[q];
             xt[j] += h;
             rp_cayley2rot(xt + 3, R);
-            for (int i = tid; i < m; i += RP_NT) {
+            for (int i = tid; i < m; i += RP_LM_NT) {
                 const double d = (residual(R, xt, i) - fvec[i]) / h;
                 fjac[(size_t) j * ld + i] = d;
                 colsq[j] += d * d;
             }
         }
-        for (int i = tid; i < m; i += RP_NT) wa4[i] = fvec[i];
+        for (int i = tid; i < m; i += RP_LM_NT) wa4[i] = fvec[i];
         S.nfev += N + 1;
         rp_block_sum<N>(colsq, red, parity);
         double wa2[N];
@@ -1363,6 +1375,8 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
         int perm[N] = {0, 1, 2, 3, 4, 5};
         double nu[N], nd[N], Rm[N][N] = {}, qtf[N];
         double maxn = 0;
+        cyc[0] += wall_clock64() - tc;
+        tc = wall_clock64();
 #pragma unroll
         for (int j = 0; j < N; j++) {
             nu[j] = nd[j] = wa2[j];
@@ -1394,7 +1408,7 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
                 }
             double *colk = fjac + (size_t) perm[k] * ld;
             double acc[N + 1] = {0, 0, 0, 0, 0, 0, 0};  // [0] tail sum of squares, [j] . column j (j > k), [N] . residual copy
-            for (int i = tid; i < m; i += RP_NT)
+            for (int i = tid; i < m; i += RP_LM_NT)
                 if (i > k) {
                     const double e = colk[i];
                     acc[0] += e * e;
@@ -1427,7 +1441,7 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
             for (int j = k + 1; j < N; j++) Rm[j][k] = tau != 0 ? rowk[j] - tau * tmp[j] : rowk[j];
             qtf[k] = tau != 0 ? rowk[N] - tau * tmp[N] : rowk[N];
             if (tau != 0)
-                for (int i = tid; i < m; i += RP_NT)
+                for (int i = tid; i < m; i += RP_LM_NT)
                     if (i > k) {
                         const double e = tau * (colk[i] / denom);
 #pragma unroll
@@ -1453,7 +1467,7 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
             }
             if (any) {
                 double sq[N] = {0, 0, 0, 0, 0, 0};
-                for (int i = tid; i < m; i += RP_NT)  // own rows only: written by this thread just above
+                for (int i = tid; i < m; i += RP_LM_NT)  // own rows only: written by this thread just above
                     if (i > k) {
 #pragma unroll
                         for (int j = k + 1; j < N; j++)
@@ -1469,6 +1483,7 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
             }
         }
         int rank = 0;
+        cyc[1] += wall_clock64() - tc;
         {
             const double pm = maxpivot * (RP_EPS * (double) N);
 #pragma unroll
@@ -1507,7 +1522,11 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
         double ratio;
         do {
             double wa1[N], xn[N], t[N], R[9];
+            tc = wall_clock64();
             rp_lmpar<N>(Rm, rank, perm, diag, qtf, S.delta, S.par, wa1);
+            cyc[2] += wall_clock64() - tc;
+            cyc[5]++;
+            tc = wall_clock64();
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 wa1[j] = -wa1[j];
@@ -1518,13 +1537,14 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
             if (S.iter == 1) S.delta = fmin(S.delta, pnorm);
             double sq[1] = {0};
             rp_cayley2rot(xn + 3, R);
-            for (int i = tid; i < m; i += RP_NT) {  // wa4: each thread touches its own rows only from here on
+            for (int i = tid; i < m; i += RP_LM_NT) {  // wa4: each thread touches its own rows only from here on
                 const double r = residual(R, xn, i);
                 wa4[i] = r;
                 sq[0] += r * r;
             }
             S.nfev++;
             rp_block_sum<1>(sq, red, parity);
+            cyc[3] += wall_clock64() - tc;
             const double fnorm1 = sqrt(sq[0]);
             double actred, prered;
             rp_lm_ratio<N>(S, Rm, perm, wa1, pnorm, fnorm1, actred, prered, ratio);
@@ -1534,7 +1554,7 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
                     x[j] = xn[j];
                     t[j] = diag[j] * x[j];
                 }
-                for (int i = tid; i < m; i += RP_NT) fvec[i] = wa4[i];
+                for (int i = tid; i < m; i += RP_LM_NT) fvec[i] = wa4[i];
                 S.xnorm = rp_norm<N>(t);
                 S.fnorm = fnorm1;
                 S.iter++;
@@ -1551,6 +1571,9 @@ template <bool LDS> __global__ __launch_bounds__(RP_NT) void k_relpose_lm(const 
         P.out->status = status;
         P.out->nfev = S.nfev;
         P.out->ran = 1;
+        cyc[4] = wall_clock64() - tAll;
+        for (int q = 0; q < 6; q++) P.out->cyc[q] = cyc[q];
+        P.out->cyc[5] = clock64() - cAll;  // shader clock ticks over the same span
     }
 }
 
@@ -1655,9 +1678,9 @@ extern "C" int alva_compute_5pt_essential(alva_ctx *ctx, const double *d_bv1, co
                                                  RP_LDS_ROWS * 8 * (int) sizeof(double)));
                     attr_set = true;
                 }
-                hipLaunchKernelGGL(k_relpose_lm<true>, dim3(1), dim3(RP_NT), lds, ctx->stream, C);
+                hipLaunchKernelGGL(k_relpose_lm<true>, dim3(1), dim3(RP_LM_NT), lds, ctx->stream, C);
             } else
-                hipLaunchKernelGGL(k_relpose_lm<false>, dim3(1), dim3(RP_NT), 0, ctx->stream, C);
+                hipLaunchKernelGGL(k_relpose_lm<false>, dim3(1), dim3(RP_LM_NT), 0, ctx->stream, C);
             ALVA_LAUNCH_CHECK();
         }
         ALVA_HIP(hipStreamSynchronize(ctx->stream));
@@ -1667,6 +1690,11 @@ extern "C" int alva_compute_5pt_essential(alva_ctx *ctx, const double *d_bv1, co
         if (!sel.need_more || H >= max_draws) break;
         H = std::min(max_draws, H * 2);  // rare: many samples without a real root; redo with a longer prefix of the same stream
     }
+    if (optimize && sel.ok && getenv("ALVA_RP_PROFILE"))
+        fprintf(stderr, "[k_relpose_lm] us: jacobian %.1f | qr %.1f | lmpar %.1f (%lld calls) | trial passes %.1f | total %.1f | %d iterations\n",
+                lm.cyc[0] * 0.01, lm.cyc[1] * 0.01, lm.cyc[2] * 0.01, (long long) lm.nfev, lm.cyc[3] * 0.01, lm.cyc[4] * 0.01, lm.iterations);
+    if (optimize && sel.ok && getenv("ALVA_RP_PROFILE"))
+        fprintf(stderr, "[k_relpose_lm] shader clock over the kernel: %.0f MHz\n", (double) lm.cyc[5] / (lm.cyc[4] * 0.01));
     if (h_info) {
         h_info->iterations = sel.iterations;
         h_info->n_inliers = sel.n_inliers;
