@@ -1672,11 +1672,11 @@ extern "C" int alva_compute_5pt_essential(alva_ctx *ctx, const double *d_bv1, co
             RelposeLmArgs C{d_bv1, d_bv2, B.inl, B.out, f, f + n, f + 2 * (size_t) n, n, (RelposeLmOut *) (pin + off_lm)};
             if (n <= RP_LDS_ROWS) {
                 const size_t lds = (size_t) n * 8 * sizeof(double);
-                static bool attr_set = false;  // dynamic LDS beyond 64 KB has to be allowed once per process
-                if (!attr_set) {
+                static bool attr_set[64] = {};  // dynamic LDS beyond 64 KB has to be allowed once per device
+                if (ctx->device >= 64 || !attr_set[ctx->device]) {
                     ALVA_HIP(hipFuncSetAttribute((const void *) k_relpose_lm<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  RP_LDS_ROWS * 8 * (int) sizeof(double)));
-                    attr_set = true;
+                    if (ctx->device < 64) attr_set[ctx->device] = true;
                 }
                 hipLaunchKernelGGL(k_relpose_lm<true>, dim3(1), dim3(RP_LM_NT), lds, ctx->stream, C);
             } else
