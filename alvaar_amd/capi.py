@@ -86,6 +86,7 @@ _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _
 _sig("alva_describe", [_vp, _vp, _sz, _i, _i, _vp, _i, _vp, _vp])
 _sig("alva_orb_blur", [_vp, _vp, _sz, _i, _i, _vp, _sz])
 _sig("alva_bf_match_hamming", [_vp, _vp, _i, _vp, _i, _vp, _vp])
+_sig("alva_find_plane", [_vp, _vp, _i, _vp, _i, _i, C.c_uint32, _vp, _vp, _vp])
 _sig("alva_relpose_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
 _sig("alva_relpose_hypotheses", [_vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _vp, _vp])
 _sig("alva_compute_5pt_essential", [_vp, _vp, _vp, _i, _i, _f, _i, _i, C.c_uint32, _f, _f, _vp, _vp, _vp, _vp, _vp])
@@ -188,6 +189,19 @@ class Context:
                                              int(seed), float(fx), float(fy), R.ctypes.data, t.ctypes.data, mask.ctypes.data,
                                              C.addressof(info), C.addressof(ok)))
         return bool(ok.value), R, t, mask[:n].astype(bool), info
+
+    # f3 (parity unpinned)
+    def find_plane(self, points, pose7, num_iterations=250, samples3=None, do_random=False, seed=12345):
+        """The intended System::processPlane: returns the plane pose [16] float32 or None."""
+        import numpy as np
+        assert points.dtype == torch.float64
+        pose = np.ascontiguousarray(pose7, np.float64)
+        out = np.zeros(16, np.float32)
+        found = C.c_int(0)
+        s = None if samples3 is None else np.ascontiguousarray(samples3, np.int32)
+        check(lib.alva_find_plane(self.h, _ptr(points), points.shape[0], pose.ctypes.data, int(num_iterations if s is None else len(s)),
+                                  int(do_random), int(seed), None if s is None else s.ctypes.data, out.ctypes.data, C.addressof(found)))
+        return out if found.value else None
 
     def relpose_hypotheses(self, bv1, bv2, samples8, err=3.0, fx=579.4, fy=579.4):
         """One RANSAC hypothesis per 8-index sample: returns (models [H,12] = R row-major | t, inlier counts [H], -1 = no model)."""

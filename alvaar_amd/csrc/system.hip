@@ -12,8 +12,8 @@
 // > 40 px, then the 5-point RANSAC of alva_compute_5pt_essential, translation normalised to 1); the frame that passes becomes
 // keyframe 1 and its 2-D keypoints are triangulated against the keyframe that first observed them (alva_triangulate).  Every
 // later keyframe (checkNewKeyframeRequired, :554-594) extracts new keypoints and triangulates the same way.
-// NOT mirrored (the reference's L2 map layer): matching to the local map, local-BA scheduling, keyframe / map-point culling,
-// plane fitting.  alva_local_ba and alva_match_to_map exist behind the C ABI; the graph bookkeeping that feeds them does not.
+// findPlane runs the intended plane fit (alva_find_plane, parity unpinned) on the current frame's 3-D keypoints.
+// NOT mirrored (the reference's L2 map layer): matching to the local map, local-BA scheduling, keyframe / map-point culling.  alva_local_ba and alva_match_to_map exist behind the C ABI; the graph bookkeeping that feeds them does not.
 #include "common.hpp"
 #include "lm_device.hpp"
 #include "../../include/alvaar_system.h"
@@ -607,12 +607,21 @@ extern "C" int alva_system_find_camera_pose_with_imu(alva_system *s, const uint8
 }
 
 extern "C" int alva_system_find_plane(alva_system *s, float *h_pose, int num_iterations) {
-    (void) h_pose;
-    (void) num_iterations;
-    if (!s) return 0;
-    // System::processPlane (system.cpp:177-342) is SURVEY.md §8f row 3 ("next"); until it lands the call reports
-    // "no plane" exactly like the reference does with fewer than 32 observed 3-D points (:181,269).
-    return 0;
+    if (!s || !s->configured || !h_pose || num_iterations <= 0) return 0;
+    // System::findPlane (system.cpp:123-137) on MapManager::getCurrentFrameMapPoints (map_manager.cpp:340-357): the observed 3-D map
+    // points of the current frame.  The plane fit itself is the INTENDED algorithm of processPlane (parity unpinned).
+    std::vector<double> pts;
+    for (const Keypoint &k: s->kps)
+        if (k.is3d) pts.insert(pts.end(), k.X, k.X + 3);
+    const int n = (int) (pts.size() / 3);
+    if (n < 32) return 0;  // :181
+    if (hipSetDevice(s->device) != hipSuccess) return 0;
+    hipStream_t st = (hipStream_t) alva_ctx_stream(s->ctx);
+    if (hipMemcpyAsync(s->d_wpt, pts.data(), pts.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    int found = 0;
+    // the reference seeds a fresh generator from std::random_device in every iteration (:203)
+    if (alva_find_plane(s->ctx, s->d_wpt, n, s->pose, num_iterations, 1, 0u, nullptr, h_pose, &found) != ALVA_OK) return 0;
+    return found ? 1 : 0;
 }
 
 extern "C" int alva_system_get_frame_points(alva_system *s, int *h_points) {

@@ -234,6 +234,18 @@ int alva_relpose_draw_samples(int n_points, int count, int do_random, uint32_t s
 int alva_relpose_hypotheses(alva_ctx *ctx, const double *d_bv1, const double *d_bv2, int n, const int *h_samples8, int n_samples,
                             float error_threshold, float fx, float fy, double *h_models12, int *h_counts);
 
+/* ---- f3: plane under the map points -------------------------------------------------------------------
+ * The INTENDED algorithm of System::processPlane(mapPoints, Twc, numIterations) (src/slam/src/system.cpp:177-342, caller
+ * findPlane :123-137): RANSAC over planes through 3 sampled points (orientation test, k-th smallest distance as the score),
+ * inliers within 1.4 x the best score, least-squares refit, pose = [Rodrigues(...) Rodrigues((1,0,0)) | mean of the inliers]
+ * in the layout of Utils::toPoseArray(cv::Mat).  PARITY UNPINNED: the reference function has no defined behaviour to compare
+ * with; the CPU restatement oracle/alva_oracle_plane.c follows the same statements and is the test partner.
+ * d_points: n x 3 world points (device, f64); h_pose7_twc: current pose; h_samples3 (num_iterations x 3 int32, may be NULL):
+ * the sample indices, otherwise drawn from std::mt19937(seed) (clock-seeded when do_random).  *h_found = 0 when n < 32 or
+ * fewer than 32 inliers.  Synchronous. */
+int alva_find_plane(alva_ctx *ctx, const double *d_points, int n, const double *h_pose7_twc, int num_iterations, int do_random,
+                    uint32_t seed, const int *h_samples3, float *h_plane_pose16, int *h_found);
+
 /* ---- f4a: CLAHE ------------------------------------------------------------------------------
  * Replaces cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply(src, dst) for 8-bit images
  * (imgproc/src/clahe.cpp:120-420), which VisualFrontend::preprocessImage runs when claheEnabled_

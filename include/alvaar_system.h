@@ -14,9 +14,10 @@
  * initialisation of VisualFrontend::checkReadyForInit (unit baseline), triangulation of every new keyframe's 2-D keypoints
  * against the keyframe that first saw them (Mapper::triangulateTemporal), new keyframes by checkNewKeyframeRequired with grid
  * detection + ORB description in the free cells.  The reference's map layer above that (matching to the local map, local-BA
- * scheduling, keyframe / map-point culling, the plane fit) is not mirrored: alva_local_ba / alva_match_to_map exist in
+ * scheduling, keyframe / map-point culling) is not mirrored: alva_local_ba / alva_match_to_map exist in
  * alvaar_hip.h for a host that keeps that graph.  alva_system_set_map_points lets a host attach its own 3-D points instead of
- * the two-view initialisation.
+ * the two-view initialisation.  find_plane runs the plane fit the reference intends (alva_find_plane; the reference function itself
+ * computes on reinterpreted memory, so its parity is unpinned) on the current frame's 3-D keypoints.
  */
 #ifndef ALVAAR_SYSTEM_H
 #define ALVAAR_SYSTEM_H

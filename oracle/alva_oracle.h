@@ -73,6 +73,9 @@ int orc_relpose_ransac(const double *bv1, const double *bv2, int n, int maxItera
 int orc_compute_5pt(const double *bv1, const double *bv2, int n, int maxIterations, float errorThreshold, int optimize, uint32_t seed,
                     float fx, float fy, double *R_out, double *t_out, int *outliers, int *nOutliers);
 
+/* f3: the INTENDED algorithm of System::processPlane (system.cpp:177-342) -- PARITY UNPINNED, see alva_oracle_plane.c. */
+int orc_find_plane(const double *pts, int n, const double *pose7_twc, const int *samples3, int numIterations, float *out16);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,26 @@ def test_imu_variant_and_plane_conventions():
     ar.close()
 
 
+def test_find_plane_after_cold_start():
+    """findPlane on the map the cold start built: the scene IS a fronto-parallel plane, so the plane normal must come out along the
+    world z axis and the origin inside the triangulated points (the plane fit is the intended processPlane, parity unpinned)."""
+    from alvaar_amd.system import AlvaAR
+    w, h = 640, 480
+    ar = AlvaAR.Initialize(w, h)
+    canvas = synth.texture_canvas(w, h, 7)
+    for k in range(0, 30):
+        pose, status = ar.findCameraPose(synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)))
+    assert status == 1
+    plane = ar.findPlane()
+    assert plane is not None and plane[15] == 1.0
+    R = plane.reshape(4, 4)[:3, :3].T
+    Rx = np.array([[1, 0, 0], [0, np.cos(1.0), -np.sin(1.0)], [0, np.sin(1.0), np.cos(1.0)]])
+    n = (R @ Rx.T)[:, 0]
+    assert abs(abs(n[2]) - 1.0) < 0.02, n
+    assert plane[14] > 0.5                                             # in front of the first camera (unit-baseline scale)
+    ar.close()
+
+
 def test_cold_start_initialises_its_own_map():
     """No host-fed map: keyframe 0, parallax gate, 5-point initialisation (unit baseline), triangulation of keyframe 1, then
     P3P + PnP tracking and new keyframes by the reference's policy -- the path checkReadyForInit -> createKeyframe ->
