@@ -1178,6 +1178,7 @@ __global__ __launch_bounds__(RP_NT) void k_relpose_select(const RelposeSelectArg
     // inlier mask + ordered index list: each thread owns a contiguous chunk
     const int chunk = (P.n + RP_NT - 1) / RP_NT, i0 = tid * chunk, i1 = min(P.n, i0 + chunk);
     int cnt = 0;
+    unsigned long long mine = 0;  // this thread's inlier flags (chunk <= 64); the pinned host mask is write-only for the device
     if (so.have_model && !so.need_more) {
         double m[12];
 #pragma unroll
@@ -1187,6 +1188,7 @@ __global__ __launch_bounds__(RP_NT) void k_relpose_select(const RelposeSelectArg
             const double f2[3] = {P.bv2[3 * (size_t) i], P.bv2[3 * (size_t) i + 1], P.bv2[3 * (size_t) i + 2]};
             const bool in = rp_score(m, m + 9, f1, f2) < P.threshold;
             P.mask[i] = in ? 1 : 0;
+            if (in && i - i0 < 64) mine |= 1ull << (i - i0);
             cnt += in ? 1 : 0;
         }
     } else
@@ -1197,7 +1199,7 @@ __global__ __launch_bounds__(RP_NT) void k_relpose_select(const RelposeSelectArg
     for (int t = 0; t < tid; t++) base += s_cnt[t];
     if (so.have_model && !so.need_more)
         for (int i = i0; i < i1; i++)
-            if (P.mask[i]) P.inl[base++] = i;
+            if (i - i0 < 64 ? (mine >> (i - i0)) & 1ull : P.mask[i] != 0) P.inl[base++] = i;
     if (tid == RP_NT - 1) {
         so.n_inliers = base;  // the last thread's running total
         so.ok = so.have_model && !so.need_more && base >= 10;  // multi_view_geometry.cpp:281-285
