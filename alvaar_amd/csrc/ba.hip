@@ -16,7 +16,7 @@
 //   k_pairs   one workgroup per (observing kf, anchor kf) pair: sum of J_obs' J_obs and J_obs' r over the pair's
 //             observations (a permutation built once on the host) -- from these 27 numbers per pair every
 //             block of F'F and F'r follows by signs.
-//   k_rowcol, k_hcc, k_gmax   F'F, F'r, Jacobi column scaling (iteration 0), gradient max-norm.
+//   k_rowcol, k_hcc, k_gmax   F'F, F'r, Jacobi column scaling (iteration 0), gradient max-norm, total cost.
 // Per LM step:
 //   k_prep    per point: (E'E + D^2)^-1, its Cholesky factor L, Z_p = S_c W_p S_p L  and v_p = L'(E'r)
 //   k_gemm    G = Z' Z with v appended as one more column: ONE dense [6*cams+1 x points*d]^2 FP64 GEMM on
@@ -25,7 +25,10 @@
 //   k_reduced_system   S and the right-hand side, padded to a multiple of 16
 //   k_solve   blocked dense Cholesky of the reduced camera system in one workgroup + blocked triangular solves
 //   k_backsub per point: y_p, candidate point; model-cost-change and step-norm partials
-//   k_point<cost only> on the candidate; the host reads three scalars and applies Ceres' accept/reject logic.
+//   k_update  candidate poses, model cost change, step norm, candidate norm
+//   then the candidate is evaluated WITH its Jacobian (the first five kernels above): an accepted step -- the normal case --
+//   needs exactly that evaluation next (trust_region_minimizer.cc:809-829), so the host reads its scalars ONCE per LM
+//   iteration and applies Ceres' accept / reject logic; a rejected step re-evaluates at the previous point.
 #include "common.hpp"
 #include "lm_device.hpp"
 #include "wave_utils.hpp"
@@ -283,37 +286,32 @@ __global__ void __launch_bounds__(256) k_hcc(BaDev B, int first) {
     }
 }
 
+// max |gradient| (scal[3]) and, same single workgroup, the total cost (scal[0] = sum of the per-point costs of k_point)
 __global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
-    __shared__ double s_red[256];
+    __shared__ double s_red[256], s_cost[256];
     if (first)
         for (int i = threadIdx.x; i < B.npd; i += 256) {
             const int p = i / B.dp, x = i % B.dp;
             B.sp[i] = 1.0 / (1.0 + sqrt(B.Hpp[(size_t) p * B.dp * B.dp + x * B.dp + x]));
         }
-    double gm = 0;
+    double gm = 0, v = 0;
     for (int r = threadIdx.x; r < B.n6; r += 256) gm = fmax(gm, fabs(B.gc[r]));
     for (int i = threadIdx.x; i < B.npd; i += 256) gm = fmax(gm, fabs(B.gp[i]));
+    for (int p = threadIdx.x; p < B.nPt; p += 256) v += B.ptCost[p];
     s_red[threadIdx.x] = gm;
+    s_cost[threadIdx.x] = v;
     __syncthreads();
     for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + s2]);
+        if (threadIdx.x < s2) {
+            s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + s2]);
+            s_cost[threadIdx.x] += s_cost[threadIdx.x + s2];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) B.scal[3] = s_red[0];
-}
-
-// deterministic sum of the per-point costs -> scal[0]
-__global__ void __launch_bounds__(256) k_sum_cost(BaDev B) {
-    __shared__ double s_red[256];
-    double v = 0;
-    for (int p = threadIdx.x; p < B.nPt; p += 256) v += B.ptCost[p];
-    s_red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        B.scal[3] = s_red[0];
+        B.scal[0] = s_cost[0];
     }
-    if (threadIdx.x == 0) B.scal[0] = s_red[0];
 }
 
 // LM diagonal (levenberg_marquardt_strategy.cc:79-90), refreshed only after an accepted step.
@@ -657,9 +655,12 @@ __global__ void __launch_bounds__(256) k_backsub(BaDev B, double radius, const d
 }
 
 // candidate poses (SE3 Plus), camera part of mcc / step norm, and the final deterministic reductions.
-__global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p) {
-    __shared__ double s_a[256], s_b[256];
-    double mcc = 0, sn = 0;
+// candidate poses, model cost change (scal[1]), squared step norm (scal[2]) and the squared norm of the CANDIDATE (scal[4]: free
+// poses + point parameters c_t written by k_backsub), which becomes x_norm when the step is accepted
+__global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p,
+                                                const double *__restrict__ c_t) {
+    __shared__ double s_a[256], s_b[256], s_c[256];
+    double mcc = 0, sn = 0, xn = 0;
     for (int k = threadIdx.x; k < B.nKf; k += 256) {
         const int c = B.cidx[k];
         if (c < 0) {
@@ -674,46 +675,36 @@ __global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const do
         }
         se3_plus(x_p + 7 * k, d6, c_p + 7 * k);
         for (int i = 0; i < 7; i++) {
-            const double d = x_p[7 * k + i] - c_p[7 * k + i];
+            const double cv = c_p[7 * k + i], d = x_p[7 * k + i] - cv;
             sn += d * d;
+            xn += cv * cv;
         }
     }
     for (int p = threadIdx.x; p < B.nPt; p += 256) {
         mcc += B.partial[3 * (size_t) p];
         sn += B.partial[3 * (size_t) p + 1];
     }
+    for (int i = threadIdx.x; i < B.npd; i += 256) xn += c_t[i] * c_t[i];
     s_a[threadIdx.x] = mcc;
     s_b[threadIdx.x] = sn;
+    s_c[threadIdx.x] = xn;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             s_a[threadIdx.x] += s_a[threadIdx.x + s];
             s_b[threadIdx.x] += s_b[threadIdx.x + s];
+            s_c[threadIdx.x] += s_c[threadIdx.x + s];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         B.scal[1] = s_a[0];
         B.scal[2] = s_b[0];
+        B.scal[4] = s_c[0];
     }
 }
 
 // |x|^2 over the variable blocks (free poses in their 7-vector form + all point parameters) -> scal[4]
-__global__ void __launch_bounds__(256) k_xnorm(BaDev B, const double *__restrict__ x_p, const double *__restrict__ x_t) {
-    __shared__ double s_a[256];
-    double v = 0;
-    for (int k = threadIdx.x; k < B.nKf; k += 256)
-        if (B.cidx[k] >= 0)
-            for (int i = 0; i < 7; i++) v += x_p[7 * k + i] * x_p[7 * k + i];
-    for (int i = threadIdx.x; i < B.npd; i += 256) v += x_t[i] * x_t[i];
-    s_a[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) s_a[threadIdx.x] += s_a[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) B.scal[4] = s_a[0];
-}
 
 template<typename T>
 T *carve(uint8_t *&cur, size_t count) {
@@ -877,23 +868,16 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     const bool solve_in_lds = solve_lds <= 152 * 1024;   // + ~5 KB of static LDS in k_solve stays under the CU's 160 KB
     if (solve_in_lds && solve_lds > 48 * 1024)
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    auto eval = [&](const double *xp, const double *xt, bool wantJ, bool first) -> int {
+    // cost, Jacobian blocks, Schur products and gradient at (xp, xt); every evaluation carries its Jacobian (see the loop below)
+    auto eval = [&](const double *xp, const double *xt, bool first) -> int {
         if (n_pt > 0) {
-            if (inv_depth) {
-                if (wantJ) hipLaunchKernelGGL((k_point<true, true>), gPt, blk, 0, st, B, xp, xt);
-                else hipLaunchKernelGGL((k_point<true, false>), gPt, blk, 0, st, B, xp, xt);
-            } else {
-                if (wantJ) hipLaunchKernelGGL((k_point<false, true>), gPt, blk, 0, st, B, xp, xt);
-                else hipLaunchKernelGGL((k_point<false, false>), gPt, blk, 0, st, B, xp, xt);
-            }
+            if (inv_depth) hipLaunchKernelGGL((k_point<true, true>), gPt, blk, 0, st, B, xp, xt);
+            else hipLaunchKernelGGL((k_point<false, true>), gPt, blk, 0, st, B, xp, xt);
         }
-        hipLaunchKernelGGL(k_sum_cost, dim3(1), blk, 0, st, B);
-        if (wantJ) {
-            hipLaunchKernelGGL(k_pairs, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, B);
-            hipLaunchKernelGGL(k_rowcol, dim3((unsigned) n_kf), dim3(64), 0, st, B);
-            if (B.n6 > 0) hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
-            hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);
-        }
+        hipLaunchKernelGGL(k_pairs, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, B);
+        hipLaunchKernelGGL(k_rowcol, dim3((unsigned) n_kf), dim3(64), 0, st, B);
+        if (B.n6 > 0) hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
+        hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);  // also sums the cost
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     };
@@ -907,7 +891,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     };
 
     // ---- Ceres TrustRegionMinimizer::Minimize, restated (trust_region_minimizer.cc:67-136) -------------------
-    rc = eval(d_xp, d_xt, true, true);
+    rc = eval(d_xp, d_xt, true);
     if (rc) return rc;
     rc = read_scal();
     if (rc) return rc;
@@ -915,9 +899,16 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     LmState lm;
     int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1;
     double *xp = d_xp, *xt = d_xt, *cp = d_cp, *ct = d_ct;
+    bool need_restore = false;  // the Jacobian-derived state belongs to a rejected candidate (restored lazily: when the loop ends right
+                                // after a rejection, the last evaluation stays the candidate's, as in the reference)
     while (true) {
         if (iteration >= max_iters || gmax <= 1e-10 || lm.radius <= 1e-32) break;
         iteration++;
+        if (need_restore) {
+            rc = eval(xp, xt, false);
+            if (rc) return rc;
+            need_restore = false;
+        }
         const int ndiag = std::max(B.n6, B.npd);
         if (!lm.reuse_diagonal && ndiag > 0) hipLaunchKernelGGL(k_diag, dim3((unsigned) alva_divup(ndiag, 256)), blk, 0, st, B);
         lm.reuse_diagonal = 1;
@@ -937,9 +928,12 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
             if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
             else hipLaunchKernelGGL(k_backsub<3>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
         }
-        hipLaunchKernelGGL(k_update, dim3(1), blk, 0, st, B, lm.radius, (const double *) xp, cp);
+        hipLaunchKernelGGL(k_update, dim3(1), blk, 0, st, B, lm.radius, (const double *) xp, cp, (const double *) ct);
         ALVA_LAUNCH_CHECK();
-        rc = eval(cp, ct, false, false);
+        // The candidate is evaluated WITH its Jacobian and its norm straight away: when the step is accepted (the normal case) Ceres
+        // re-evaluates at the same point (HandleSuccessfulStep, trust_region_minimizer.cc:809-829) and would produce exactly these
+        // numbers again, so one host round trip per iteration disappears.  A rejected step costs one re-evaluation at x instead.
+        rc = eval(cp, ct, false);
         if (rc) return rc;
         rc = read_scal();
         if (rc) return rc;
@@ -952,6 +946,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
             }
             lm.rejected();
             nsummaries++;
+            need_restore = true;
             continue;
         }
         invalid = 0;
@@ -961,18 +956,14 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         if (rel > 1e-3) {
             std::swap(xp, cp);
             std::swap(xt, ct);
-            hipLaunchKernelGGL(k_xnorm, dim3(1), blk, 0, st, B, (const double *) xp, (const double *) xt);
-            rc = eval(xp, xt, true, false);
-            if (rc) return rc;
-            rc = read_scal();
-            if (rc) return rc;
-            x_cost = scal[0];
+            x_cost = cand_cost;
             gmax = scal[3];
             x_norm = std::sqrt(scal[4]);
             lm.accepted(rel);
             nsucc++;
         } else {
             lm.rejected();
+            need_restore = true;
         }
         nsummaries++;
     }
