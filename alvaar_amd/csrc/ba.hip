@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 // Blocked right-looking Cholesky, block 16, the matrix padded with an identity to a multiple of 16 (no edge cases):
 //   diagonal block   wave 0, one row per lane IN REGISTERS, pivots / multipliers broadcast with v_readlane (no LDS, no barrier)
 //   panel            one thread per row below: x L11' = a, 136 FMAs against the (broadcast-read) diagonal block
-//   trailing update  4x4 register micro-tiles of A22 -= L21 L21'
+//   trailing update  A22 -= L21 L21' as 16 x 16 tiles on v_mfma_f64_16x16x4_f64, one wavefront per tile
 // = 3 barriers per 16 columns instead of 3 per column; the triangular solves are blocked the same way.  Row stride is
 // odd (padded size + 1) so that threads reading different rows hit different LDS banks.
 constexpr int SOLVE_NT = 256, NB = 16;
@@ -449,12 +449,25 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
     __shared__ int s_ok;
     double *S = IN_LDS ? s_S : B.S;            // [np][ld]
     double *y = IN_LDS ? s_S + (size_t) np * ld : B.S + (size_t) np * ld;  // [np] right-hand side / solution
-    if (IN_LDS) {  // matrix + right-hand side from k_reduced_system, one coalesced pass
+    if (IN_LDS) {  // matrix + right-hand side from k_reduced_system: coalesced, eight loads in flight per thread (one load -> one
+                   // LDS store per trip took 14 us for the 100 KB of a 108-unknown system)
         const int total = np * ld + np;
-        for (int e = threadIdx.x; e < total; e += SOLVE_NT) s_S[e] = B.S[e];
+        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * SOLVE_NT) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * SOLVE_NT;
+                v[u] = e < total ? B.S[e] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * SOLVE_NT;
+                if (e < total) s_S[e] = v[u];
+            }
+        }
     }
     // micro-tile enumeration of a lower triangle, row by row: t -> (ta, tb), the same for every trailing size
-    constexpr int TILE_LUT = 2048;   // covers np <= 268 (44 free cameras); larger systems decode arithmetically
+    constexpr int TILE_LUT = 1024;   // 16 x 16 tiles: covers np <= 736; larger systems decode arithmetically
     __shared__ unsigned short s_tile[TILE_LUT];
     for (int t = threadIdx.x; t < TILE_LUT; t += SOLVE_NT) {
         int ta = (int) ((sqrtf(8.f * (float) t + 1.f) - 1.f) * 0.5f);
@@ -514,9 +527,12 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
             for (int j = 0; j < NB; j++) rowp[j] = x[j];
         }
         __syncthreads();
-        // ---- trailing update A22 -= L21 L21', lower triangle, 4x4 micro-tiles ----------------------------------------------
-        const int mt = m / 4, ntile = mt * (mt + 1) / 2;
-        for (int t = threadIdx.x; t < ntile; t += SOLVE_NT) {
+        // ---- trailing update A22 -= L21 L21': a rank-16 update, i.e. one 16 x 16 x 16 product per 16 x 16 tile of the lower triangle
+        //      = four v_mfma_f64_16x16x4_f64 per tile, one wavefront per tile (operand a: L[rowa + (lane & 15)][4c + (lane >> 4)],
+        //      operand b the same for rowb; result row (lane >> 4) + 4r, column lane & 15).  Diagonal tiles are updated in full: the
+        //      strict upper triangle is never read.
+        const int mt = m / NB, ntile = mt * (mt + 1) / 2;
+        for (int t = threadIdx.x >> 6; t < ntile; t += SOLVE_NT / 64) {
             int ta, tb;
             if (t < TILE_LUT) {
                 ta = s_tile[t] >> 8;
@@ -527,31 +543,14 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
                 while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
                 tb = t - ta * (ta + 1) / 2;
             }
-            const double *La = S + (size_t) (base + NB + 4 * ta) * ld + base, *Lb = S + (size_t) (base + NB + 4 * tb) * ld + base;
-            double acc[4][4];
+            const double *La = S + (size_t) (base + NB + NB * ta + (lane & 15)) * ld + base + (lane >> 4);
+            const double *Lb = S + (size_t) (base + NB + NB * tb + (lane & 15)) * ld + base + (lane >> 4);
+            double4_t acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int c = 0; c < NB / 4; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * c], Lb[4 * c], acc, 0, 0, 0);
+            double *C = S + (size_t) (base + NB + NB * ta + (lane >> 4)) * ld + base + NB + NB * tb + (lane & 15);
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < NB; k++) {
-                double la[4], lb[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    la[i] = La[(size_t) i * ld + k];
-                    lb[i] = Lb[(size_t) i * ld + k];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] += la[i] * lb[j];
-            }
-            double *C = S + (size_t) (base + NB + 4 * ta) * ld + base + NB + 4 * tb;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (ta != tb || j <= i) C[(size_t) i * ld + j] -= acc[i][j];
+            for (int r = 0; r < 4; r++) C[(size_t) (4 * r) * ld] -= acc[r];
         }
         __syncthreads();
     }
