@@ -394,7 +394,20 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
     double4_t acc = {0, 0, 0, 0};
     const double *Za = B.Zt + (size_t) (k0 + (lane >> 4)) * B.NP + ti * 16 + (lane & 15);
     const double *Zb = B.Zt + (size_t) (k0 + (lane >> 4)) * B.NP + tj * 16 + (lane & 15);
-    for (int k = 0; k < chunk; k += 4) {
+    // eight k-steps of operands in flight per trip: with one load pair per MFMA the loop ran at the latency of one L2 round trip
+    // per step (30 us for 94 steps)
+    int k = 0;
+    for (; k + 32 <= chunk; k += 32) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a[u] = Za[(size_t) (k + 4 * u) * B.NP];
+            b[u] = Zb[(size_t) (k + 4 * u) * B.NP];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k < chunk; k += 4) {
         const double a = Za[(size_t) k * B.NP], b = Zb[(size_t) k * B.NP];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
