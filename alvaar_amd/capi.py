@@ -43,6 +43,7 @@ def _sig(name, argtypes, restype=_i):
 _sig("alva_last_error", [], C.c_char_p)
 _sig("alva_version", [], C.c_char_p)
 _sig("alva_ctx_create", [_i, _vp, _i, C.POINTER(_vp)])
+_sig("alva_ctx_create_with_priority", [_i, _i, C.POINTER(_vp)])
 _sig("alva_ctx_destroy", [_vp], None)
 _sig("alva_ctx_sync", [_vp])
 _sig("alva_rgba2gray", [_vp, _vp, _sz, _i, _i, _vp, _sz])

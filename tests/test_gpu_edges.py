@@ -130,3 +130,72 @@ def test_ba_without_points_or_with_all_cameras_fixed(ctx):
     assert np.abs(r["poses"] - r2["poses"]).max() < 1e-12
     assert np.abs(r["pts"] - r2["pts"]).max() < 1e-7 * max(1.0, np.abs(r2["pts"]).max())
     assert int(r["info"][0]) == int(r2["info"][0])
+
+
+def test_new_entry_points_contracts(ctx):
+    """alva_compute_5pt_essential / alva_find_plane / priority contexts / the run-many helper: sizes below the reference's own
+    limits, capacity limits, NULL optional outputs, argument errors."""
+    import ctypes as C
+    import torch
+    import alvaar_amd
+    from alvaar_amd import capi
+    lib = capi.lib
+    p = synth.make_relpose_problem(300, 3, 0.2)
+    b1, b2 = torch.from_numpy(p["bv1"]).cuda(), torch.from_numpy(p["bv2"]).cuda()
+    R, t, ok = np.zeros(9), np.zeros(3), C.c_int(-1)
+    # optional outputs may be NULL
+    rc = lib.alva_compute_5pt_essential(ctx.h, capi._ptr(b1), capi._ptr(b2), 300, 100, 3.0, 1, 0, 12345, 579.4, 579.4, R.ctypes.data, t.ctypes.data,
+                                        None, None, C.addressof(ok))
+    assert rc == 0 and ok.value == 1 and abs(np.linalg.det(R.reshape(3, 3)) - 1.0) < 1e-9
+    # fewer than 8 correspondences: the reference returns false before touching anything (multi_view_geometry.cpp:242-245)
+    rc = lib.alva_compute_5pt_essential(ctx.h, None, None, 7, 100, 3.0, 1, 0, 12345, 579.4, 579.4, R.ctypes.data, t.ctypes.data, None, None,
+                                        C.addressof(ok))
+    assert rc == 0 and ok.value == 0
+    # argument errors
+    assert lib.alva_compute_5pt_essential(ctx.h, None, None, 50, 100, 3.0, 1, 0, 12345, 579.4, 579.4, R.ctypes.data, t.ctypes.data, None, None,
+                                          C.addressof(ok)) != 0
+    assert lib.alva_compute_5pt_essential(ctx.h, capi._ptr(b1), capi._ptr(b2), 300, 0, 3.0, 1, 0, 12345, 579.4, 579.4, R.ctypes.data, t.ctypes.data,
+                                          None, None, C.addressof(ok)) != 0
+    # plane: capacity limit of the LDS-resident distances, and too few points
+    big = torch.zeros((12289, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(alvaar_amd.AlvaError):
+        ctx.find_plane(big, np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    assert ctx.find_plane(big[:31], np.array([0, 0, 0, 0, 0, 0, 1.0])) is None
+    # a degenerate cloud (all points identical) must come back without a plane or with a finite one, never hang
+    out = ctx.find_plane(torch.ones((100, 3), dtype=torch.float64, device="cuda"), np.array([0, 0, 0, 0, 0, 0, 1.0]), num_iterations=20)
+    assert out is None or np.isfinite(out).all()
+    # contexts in the three priority classes run kernels like any other
+    for cls in (-1, 0, 1):
+        h = C.c_void_p()
+        assert lib.alva_ctx_create_with_priority(0, cls, C.byref(h)) == 0
+        g = torch.from_numpy(_gray(128, 96)).cuda()
+        out = torch.empty((96, 128), dtype=torch.uint8, device="cuda")
+        rgba = torch.from_numpy(synth.gray_to_rgba(_gray(128, 96))).cuda()
+        assert lib.alva_rgba2gray(h, capi._ptr(rgba), rgba.stride(0), 128, 96, capi._ptr(out), 128) == 0
+        assert lib.alva_ctx_sync(h) == 0 and torch.equal(out, g)
+        lib.alva_ctx_destroy(h)
+
+
+def test_run_many_helper(ctx):
+    """alva_frontend_run_many: one stream (look-ahead on) and two streams (off) process every frame and accept every pose."""
+    import torch
+    import alvaar_amd
+    from alvaar_amd import capi
+    W, H, N = 320, 240, 200
+    for streams in (1, 2):
+        fes, frames, pts, bv, uv, wp = [], [], [], [], [], []
+        for s in range(streams):
+            fes.append(alvaar_amd.Frontend(0, W, H, N, 300))
+            frames.append(torch.from_numpy(synth.stream_rgba(W, H, 4, seed=3 + s, noise=True)).cuda())
+            rng = np.random.RandomState(s)
+            pts.append(torch.from_numpy(rng.uniform(30, [W - 30, H - 30], (N, 2)).astype(np.float32)).cuda())
+            pb = synth.make_pnp_problem(N, 5 + s, outlier_frac=0.1)
+            bv.append(torch.from_numpy(pb["bv"]).cuda())
+            uv.append(torch.from_numpy(pb["uv"]).cuda())
+            wp.append(torch.from_numpy(pb["wpt"]).cuda())
+            K = pb["K"]
+        torch.cuda.synchronize()
+        wall, accepted = capi.frontend_run_many(fes, 12, 2, frames, pts, bv, uv, wp, K)
+        assert wall > 0 and accepted == 12 * streams
+        for f in fes:
+            f.close()
