@@ -54,6 +54,7 @@ _sig("alva_pyramid_level", [_vp, _i, C.POINTER(PyrLevel)])
 _sig("alva_pyramid_build_from_gray", [_vp, _vp, _vp, _sz])
 _sig("alva_pyramid_download_level", [_vp, _vp, _i, _vp, _vp])
 _sig("alva_pyramid_build_from_rgba", [_vp, _vp, _vp, _sz, _vp, _sz])
+_sig("alva_pyramid_build_from_rgba_batch", [_vp, _vp, _vp, _sz, _vp, _sz, _i])
 _sig("alva_lk_track", [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i])
 _sig("alva_fbklt_track", [_vp, _vp, _vp, _i, _f, _f, _i, _f, _vp, _vp, _vp, _i])
 _sig("alva_p3p_draw_samples", [_i, _i, _i, C.c_uint32, _vp])
@@ -535,6 +536,15 @@ class Frontend:
         return {"tracked": view(ptrs[0], (n, 2), torch.float32), "status": view(ptrs[1], (n,), torch.uint8),
                 "keypoints": view(ptrs[2], (m, 6), torch.float32), "descriptors": view(ptrs[3], (m, 32), torch.uint8),
                 "match_idx": view(ptrs[4], (m,), torch.int32), "match_dist": view(ptrs[5], (m,), torch.int32)}
+
+
+def build_pyramids_batch(ctx: "Context", pyrs, rgbas, grays=None):
+    """alva_pyramid_build_from_rgba_batch: all cameras' gray + LK pyramid in five launches."""
+    n = len(pyrs)
+    ph = (_vp * n)(*[p.h for p in pyrs])
+    pr = (_vp * n)(*[_ptr(r) for r in rgbas])
+    pg = None if grays is None else (_vp * n)(*[_ptr(g) for g in grays])
+    check(lib.alva_pyramid_build_from_rgba_batch(ctx.h, ph, pr, rgbas[0].stride(0), pg, 0 if grays is None else grays[0].stride(0), n))
 
 
 def relpose_draw_samples(n_points: int, count: int, do_random: bool = False, seed: int = 12345):

@@ -39,9 +39,9 @@ __device__ __forceinline__ void store_mirrors(uint8_t *g, size_t pitch, int w, i
 
 // Level 0 from RGBA (SRC_RGBA) or from a gray image: 4 pixels per thread.
 template<bool SRC_RGBA>
-__global__ void __launch_bounds__(256) k_level0(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, int win,
-                                                uint8_t *__restrict__ dst, size_t dst_pitch,
-                                                uint8_t *__restrict__ gray_out, size_t gray_out_pitch) {
+__device__ __forceinline__ void level0_body(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, int win,
+                                            uint8_t *__restrict__ dst, size_t dst_pitch, uint8_t *__restrict__ gray_out,
+                                            size_t gray_out_pitch) {
     int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     int y = blockIdx.y * 4 + threadIdx.y;
     if (x4 >= w || y >= h) return;
@@ -60,6 +60,23 @@ __global__ void __launch_bounds__(256) k_level0(const uint8_t *__restrict__ src,
 #pragma unroll
         for (int k = 0; k < 4; k++) store_mirrors(dst, dst_pitch, w, h, win, x4 + k, y, (uint8_t) (packed >> (8 * k)));
     }
+}
+template<bool SRC_RGBA>
+__global__ void __launch_bounds__(256) k_level0(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, int win,
+                                                uint8_t *__restrict__ dst, size_t dst_pitch,
+                                                uint8_t *__restrict__ gray_out, size_t gray_out_pitch) {
+    level0_body<SRC_RGBA>(src, src_pitch, w, h, win, dst, dst_pitch, gray_out, gray_out_pitch);
+}
+// The same for B cameras in one launch (blockIdx.z = camera): one frame is 1.2 MB and every launch of this file is bound by
+// launch latency, not by HBM; B frames per launch is what lets the same code run at memory speed.
+struct Level0Item {
+    const uint8_t *src;
+    uint8_t *dst, *gray_out;
+};
+__global__ void __launch_bounds__(256) k_level0_batch(const Level0Item *__restrict__ items, size_t src_pitch, int w, int h, int win,
+                                                      size_t dst_pitch, size_t gray_out_pitch) {
+    const Level0Item it = items[blockIdx.z];
+    level0_body<true>(it.src, src_pitch, w, h, win, it.dst, dst_pitch, it.gray_out, gray_out_pitch);
 }
 
 struct StageArgs {
@@ -153,6 +170,12 @@ __device__ __forceinline__ void pyrdown_tile(const StageArgs &a, int bid) {
 }
 
 __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
+    int bid = blockIdx.x;
+    if (bid < a.scharr_blocks) scharr_tile(a, bid);
+    else pyrdown_tile(a, bid - a.scharr_blocks);
+}
+__global__ void __launch_bounds__(256) k_pyr_stage_batch(const StageArgs *__restrict__ args) {
+    const StageArgs a = args[blockIdx.z];
     int bid = blockIdx.x;
     if (bid < a.scharr_blocks) scharr_tile(a, bid);
     else pyrdown_tile(a, bid - a.scharr_blocks);
@@ -260,30 +283,36 @@ extern "C" int alva_pyramid_download_level(alva_ctx *ctx, const alva_pyramid *py
     return ALVA_OK;
 }
 
+static int stage_args(const alva_pyramid *p, int l, StageArgs &a) {  // returns the number of workgroups of stage l
+    const alva_level &L = p->lv[l];
+    a = StageArgs{};
+    a.g = L.gray;
+    a.g_pitch = L.gray_pitch;
+    a.w = L.w;
+    a.h = L.h;
+    a.d = L.deriv;
+    a.d_pitch = L.deriv_pitch;
+    a.scharr_bx = alva_divup(L.w, 256);
+    a.scharr_blocks = a.scharr_bx * alva_divup(L.h, 4);
+    a.win = p->win;
+    int down_blocks = 0;
+    if (l + 1 < p->nlevels) {
+        const alva_level &N = p->lv[l + 1];
+        a.ng = N.gray;
+        a.ng_pitch = N.gray_pitch;
+        a.dw = N.w;
+        a.dh = N.h;
+        a.down_bx = alva_divup(N.w, 64);
+        down_blocks = a.down_bx * alva_divup(N.h, 4);
+    }
+    return a.scharr_blocks + down_blocks;
+}
+
 static int build_rest(alva_ctx *ctx, alva_pyramid *p) {
     for (int l = 0; l < p->nlevels; l++) {
-        const alva_level &L = p->lv[l];
-        StageArgs a{};
-        a.g = L.gray;
-        a.g_pitch = L.gray_pitch;
-        a.w = L.w;
-        a.h = L.h;
-        a.d = L.deriv;
-        a.d_pitch = L.deriv_pitch;
-        a.scharr_bx = alva_divup(L.w, 256);
-        a.scharr_blocks = a.scharr_bx * alva_divup(L.h, 4);
-        a.win = p->win;
-        int down_blocks = 0;
-        if (l + 1 < p->nlevels) {
-            const alva_level &N = p->lv[l + 1];
-            a.ng = N.gray;
-            a.ng_pitch = N.gray_pitch;
-            a.dw = N.w;
-            a.dh = N.h;
-            a.down_bx = alva_divup(N.w, 64);
-            down_blocks = a.down_bx * alva_divup(N.h, 4);
-        }
-        hipLaunchKernelGGL(k_pyr_stage, dim3(a.scharr_blocks + down_blocks), dim3(64, 4), 0, ctx->stream, a);
+        StageArgs a;
+        const int blocks = stage_args(p, l, a);
+        hipLaunchKernelGGL(k_pyr_stage, dim3(blocks), dim3(64, 4), 0, ctx->stream, a);
         ALVA_LAUNCH_CHECK();
     }
     return ALVA_OK;
@@ -311,4 +340,39 @@ extern "C" int alva_pyramid_build_from_rgba(alva_ctx *ctx, alva_pyramid *pyr, co
                        d_gray_out, gray_out_pitch);
     ALVA_LAUNCH_CHECK();
     return build_rest(ctx, pyr);
+}
+
+// B cameras of the same geometry in five launches (blockIdx.z = camera) instead of 5 B.  The per-camera arguments are staged in
+// pinned host memory and read by the workgroups directly.
+extern "C" int alva_pyramid_build_from_rgba_batch(alva_ctx *ctx, alva_pyramid *const *pyrs, const uint8_t *const *d_rgba, size_t rgba_pitch,
+                                                  uint8_t *const *d_gray_out, size_t gray_out_pitch, int count) {
+    ALVA_ARG(ctx && pyrs && d_rgba && count > 0 && count <= 65535 && rgba_pitch % 16 == 0);
+    const alva_pyramid *p0 = pyrs[0];
+    ALVA_ARG(p0);
+    const alva_level &L0 = p0->lv[0];
+    ALVA_ARG(rgba_pitch >= (size_t) L0.w * 4);
+    if (d_gray_out) ALVA_ARG(gray_out_pitch % 4 == 0 && gray_out_pitch >= (size_t) L0.w);
+    const size_t off_stage = ((size_t) count * sizeof(Level0Item) + 255) / 256 * 256;
+    uint8_t *pin = nullptr;
+    int rc = alva_ctx_pinned(ctx, off_stage + (size_t) count * p0->nlevels * sizeof(StageArgs), (void **) &pin);
+    if (rc) return rc;
+    Level0Item *items = (Level0Item *) pin;
+    StageArgs *st = (StageArgs *) (pin + off_stage);
+    int blocks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < count; c++) {
+        const alva_pyramid *p = pyrs[c];
+        ALVA_ARG(p && d_rgba[c] && ((uintptr_t) d_rgba[c] % 16) == 0 && p->nlevels == p0->nlevels && p->win == p0->win && p->lv[0].w == L0.w &&
+                 p->lv[0].h == L0.h && p->lv[0].gray_pitch == L0.gray_pitch);
+        items[c].src = d_rgba[c];
+        items[c].dst = p->lv[0].gray;
+        items[c].gray_out = d_gray_out ? d_gray_out[c] : nullptr;
+        if (d_gray_out) ALVA_ARG(d_gray_out[c] && ((uintptr_t) d_gray_out[c] % 4) == 0);
+        for (int l = 0; l < p->nlevels; l++) blocks[l] = stage_args(p, l, st[(size_t) l * count + c]);
+    }
+    hipLaunchKernelGGL(k_level0_batch, dim3(alva_divup(L0.w, 256), alva_divup(L0.h, 4), count), dim3(64, 4), 0, ctx->stream, (const Level0Item *) items,
+                       rgba_pitch, L0.w, L0.h, p0->win, L0.gray_pitch, gray_out_pitch);
+    for (int l = 0; l < p0->nlevels; l++)
+        hipLaunchKernelGGL(k_pyr_stage_batch, dim3(blocks[l], 1, count), dim3(64, 4), 0, ctx->stream, (const StageArgs *) (st + (size_t) l * count));
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
 }

@@ -257,6 +257,38 @@ def bench_ba(ctx, reps: int = 3):
                 note="whole alva_local_ba call incl. host structure build, H2D of the problem and D2H of results"), pb
 
 
+def bench_batched_preprocess(device: int, cameras: int = 64, reps: int = 20):
+    """Secondary line for the roofline discussion: gray + LK pyramid of `cameras` 640x480 frames in FIVE launches
+    (alva_pyramid_build_from_rgba_batch).  One frame per launch is launch-latency-bound (roofline.frac ~ 0.005); this shows what
+    the same kernels reach when a launch carries enough bytes.  Algorithmic bytes per camera: 5 P (RGBA -> gray) + 6.64 P
+    (pyramid + Scharr), SURVEY.md 8(d)."""
+    import alvaar_amd
+    from alvaar_amd import capi, synth
+    dev = torch.device("cuda", device)
+    ctx = alvaar_amd.Context(device, own_stream=True)
+    base = torch.from_numpy(synth.stream_rgba(W, H, 4, seed=5, noise=True)).to(dev)
+    frames = [base[c % 4].clone() for c in range(cameras)]
+    grays = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(cameras)]
+    pyrs = [alvaar_amd.Pyramid(ctx, W, H, 9, 3) for _ in range(cameras)]
+    capi.build_pyramids_batch(ctx, pyrs, frames, grays)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        capi.build_pyramids_batch(ctx, pyrs, frames, grays)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    kt = capi.kernel_times(lambda: capi.build_pyramids_batch(ctx, pyrs, frames, grays), 5)
+    ctx.sync()
+    kernel_us = sum(v[0] / 5 * v[1] for v in kt.values())
+    alg = cameras * (5 + 6.64) * W * H
+    for p in pyrs:
+        p.close()
+    return dict(cameras=cameras, launches=5, ms_per_batch=dt * 1e3, frames_per_s=cameras / dt, kernel_us_per_batch=kernel_us,
+                alg_bytes_per_batch=int(alg), achieved_GBps=alg / (kernel_us * 1e-6) / 1e9, hbm_frac=alg / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                kernels={k: {"avg_us": round(v[1], 2), "launches_per_batch": round(v[0] / 5, 2)} for k, v in kt.items()},
+                note="event-timed kernels of alva_pyramid_build_from_rgba_batch; achieved = algorithmic bytes / sum of kernel times")
+
+
 def bench_two_view_init(ctx, reps: int = 10):
     """§8f-2 secondary line: the map-initialisation call (compute5ptEssentialMatrix) on 2000 correspondences, 25 % mismatches."""
     import torch
@@ -428,6 +460,7 @@ def main():
                                      "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
             "local_ba": ba,
             "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
+            "batched_preprocess": bench_batched_preprocess(local) if world == 1 else None,
             "config_1280x720": bench_720p(local) if world == 1 else None,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

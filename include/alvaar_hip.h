@@ -95,6 +95,12 @@ int alva_pyramid_download_level(alva_ctx *ctx, const alva_pyramid *pyr, int leve
  * System::findCameraPose, system.cpp:106-112).  d_gray_out may be NULL. */
 int alva_pyramid_build_from_rgba(alva_ctx *ctx, alva_pyramid *pyr, const uint8_t *d_rgba, size_t rgba_pitch,
                                  uint8_t *d_gray_out, size_t gray_out_pitch);
+/* The same for `count` cameras of one geometry in FIVE launches (one grid layer per camera) instead of 5 x count: one 640x480
+ * frame is 1.2 MB and every launch above is bound by launch latency; many frames per launch is what lets the same kernels run at
+ * HBM speed (bench.py "batched_preprocess").  Results are identical to `count` calls of alva_pyramid_build_from_rgba.
+ * pyrs / d_rgba / d_gray_out (may be NULL) are HOST arrays of `count` handles / device pointers.  Enqueue only. */
+int alva_pyramid_build_from_rgba_batch(alva_ctx *ctx, alva_pyramid *const *pyrs, const uint8_t *const *d_rgba, size_t rgba_pitch,
+                                       uint8_t *const *d_gray_out, size_t gray_out_pitch, int count);
 
 /* ---- a4: forward-backward pyramidal KLT ------------------------------------------------------
  * alva_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, pts, next, status, err,

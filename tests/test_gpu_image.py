@@ -99,3 +99,29 @@ def test_bf_match_full_size_properties(ctx):
     perm = rng.permutation(4080)
     idx2, dist2 = ctx.bf_match_hamming(dd, torch.from_numpy(d[perm]).cuda())
     assert np.array_equal(perm[idx2.cpu().numpy()], np.arange(4080)) and int(dist2.abs().sum()) == 0
+
+
+def test_batched_pyramids_equal_single_builds(ctx):
+    """alva_pyramid_build_from_rgba_batch (one grid layer per camera) == one alva_pyramid_build_from_rgba per camera, bit for bit."""
+    import torch
+    import alvaar_amd
+    from alvaar_amd import capi
+    w, h, B = 320, 240, 5
+    frames = [torch.from_numpy(synth.gray_to_rgba(synth.frame_gray(synth.texture_canvas(w, h, 20 + c), c, w, h, noise_seed=c), seed=c)).cuda()
+              for c in range(B)]
+    single = [alvaar_amd.Pyramid(ctx, w, h, 9, 3) for _ in range(B)]
+    batch = [alvaar_amd.Pyramid(ctx, w, h, 9, 3) for _ in range(B)]
+    g1 = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in range(B)]
+    g2 = [torch.zeros((h, w), dtype=torch.uint8, device="cuda") for _ in range(B)]
+    for c in range(B):
+        single[c].build_from_rgba(frames[c], g1[c])
+    capi.build_pyramids_batch(ctx, batch, frames, g2)
+    ctx.sync()
+    for c in range(B):
+        assert torch.equal(g1[c], g2[c])
+        for l in range(single[c].num_levels):
+            a, b = single[c].download_level(l), batch[c].download_level(l)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (c, l)
+    capi.build_pyramids_batch(ctx, batch[:1], frames[:1])          # a batch of one, no gray output
+    ctx.sync()
+    assert np.array_equal(batch[0].download_level(2)[1], single[0].download_level(2)[1])
