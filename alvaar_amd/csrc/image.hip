@@ -369,10 +369,19 @@ extern "C" int alva_pyramid_build_from_rgba_batch(alva_ctx *ctx, alva_pyramid *c
         if (d_gray_out) ALVA_ARG(d_gray_out[c] && ((uintptr_t) d_gray_out[c] % 4) == 0);
         for (int l = 0; l < p->nlevels; l++) blocks[l] = stage_args(p, l, st[(size_t) l * count + c]);
     }
-    hipLaunchKernelGGL(k_level0_batch, dim3(alva_divup(L0.w, 256), alva_divup(L0.h, 4), count), dim3(64, 4), 0, ctx->stream, (const Level0Item *) items,
-                       rgba_pitch, L0.w, L0.h, p0->win, L0.gray_pitch, gray_out_pitch);
+    // the argument blocks go to device memory in one copy: tens of thousands of workgroups fetching them from pinned host memory
+    // would each start with a trip over the bus
+    const size_t arg_bytes = off_stage + (size_t) count * p0->nlevels * sizeof(StageArgs);
+    uint8_t *dev = nullptr;
+    rc = alva_ctx_scratch(ctx, 10, arg_bytes, (void **) &dev);
+    if (rc) return rc;
+    ALVA_HIP(hipMemcpyAsync(dev, pin, arg_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const Level0Item *d_items = (const Level0Item *) dev;
+    const StageArgs *d_st = (const StageArgs *) (dev + off_stage);
+    hipLaunchKernelGGL(k_level0_batch, dim3(alva_divup(L0.w, 256), alva_divup(L0.h, 4), count), dim3(64, 4), 0, ctx->stream, d_items, rgba_pitch, L0.w,
+                       L0.h, p0->win, L0.gray_pitch, gray_out_pitch);
     for (int l = 0; l < p0->nlevels; l++)
-        hipLaunchKernelGGL(k_pyr_stage_batch, dim3(blocks[l], 1, count), dim3(64, 4), 0, ctx->stream, (const StageArgs *) (st + (size_t) l * count));
+        hipLaunchKernelGGL(k_pyr_stage_batch, dim3(blocks[l], 1, count), dim3(64, 4), 0, ctx->stream, d_st + (size_t) l * count);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }
