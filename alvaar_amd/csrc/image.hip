@@ -149,24 +149,41 @@ __device__ __forceinline__ void scharr_tile(const StageArgs &a, int bid) {
     }
 }
 
+// pyrDown of level l into level l+1: FOUR output pixels per thread.  Their 5 x 5 binomial windows span input columns
+// 2x-2 .. 2x+8 (x a multiple of 4), i.e. the 16 bytes from 2x-4 on: four aligned dword loads per input row instead of 25 byte
+// loads per output pixel.  Out-of-image taps read the REFLECT_101 padding (identical to borderInterpolate on the level size,
+// pyramids.cpp:760-775, because win >= 2); the four bytes beyond 2x+8 are padding or interior too (pitch is a multiple of 64
+// and the window reaches at most 2 (dw - 1) + 11 <= w + 12 <= w + win + 3).
 __device__ __forceinline__ void pyrdown_tile(const StageArgs &a, int bid) {
-    int bx = bid % a.down_bx, by = bid / a.down_bx;
-    int x = bx * 64 + threadIdx.x;
-    int y = by * 4 + threadIdx.y;
+    const int bx = bid % a.down_bx, by = bid / a.down_bx;
+    const int x = (bx * 64 + threadIdx.x) * 4;
+    const int y = by * 4 + threadIdx.y;
     if (x >= a.dw || y >= a.dh) return;
-    // 5x5 binomial around (2x, 2y) of level l; out-of-image taps read the REFLECT_101 padding
-    // (identical to borderInterpolate on the level size, pyramids.cpp:760-775, because win >= 2)
-    int acc = 0;
+    int acc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-        const uint8_t *row = a.g + (ptrdiff_t) (2 * y - 2 + j) * (ptrdiff_t) a.g_pitch + (2 * x - 2);
-        int s = row[0] + row[4] + 4 * (row[1] + row[3]) + 6 * row[2];
+        const uint8_t *row = a.g + (ptrdiff_t) (2 * y - 2 + j) * (ptrdiff_t) a.g_pitch + (2 * x - 4);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(row);  // columns 2x-4 .. 2x+11; 2x - 4 is a multiple of 4 (not of 16)
+        const uint32_t w[4] = {rp[0], rp[1], rp[2], rp[3]};
+        auto px = [&](int c) -> int { return (int) ((w[c >> 2] >> (8 * (c & 3))) & 0xffu); };  // byte c of the 16, column 2x - 4 + c
         const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
-        acc += wj * s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c0 = 2 + 2 * k;  // window of output x + k starts at column 2 (x + k) - 2 = (2x - 4) + 2 + 2k
+            const int s = px(c0) + px(c0 + 4) + 4 * (px(c0 + 1) + px(c0 + 3)) + 6 * px(c0 + 2);
+            acc[k] += wj * s;
+        }
     }
-    uint8_t v = (uint8_t) ((acc + 128) >> 8);
-    a.ng[(size_t) y * a.ng_pitch + x] = v;
-    store_mirrors(a.ng, a.ng_pitch, a.dw, a.dh, a.win, x, y, v);
+    uint8_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (uint8_t) ((acc[k] + 128) >> 8);
+    uint8_t *dst = a.ng + (size_t) y * a.ng_pitch + x;
+    if (x + 3 < a.dw) {
+        *reinterpret_cast<uint32_t *>(dst) = (uint32_t) out[0] | ((uint32_t) out[1] << 8) | ((uint32_t) out[2] << 16) | ((uint32_t) out[3] << 24);
+    } else {
+        for (int k = 0; k < 4 && x + k < a.dw; k++) dst[k] = out[k];
+    }
+    for (int k = 0; k < 4 && x + k < a.dw; k++) store_mirrors(a.ng, a.ng_pitch, a.dw, a.dh, a.win, x + k, y, out[k]);
 }
 
 __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
@@ -302,7 +319,7 @@ static int stage_args(const alva_pyramid *p, int l, StageArgs &a) {  // returns 
         a.ng_pitch = N.gray_pitch;
         a.dw = N.w;
         a.dh = N.h;
-        a.down_bx = alva_divup(N.w, 64);
+        a.down_bx = alva_divup(N.w, 256);
         down_blocks = a.down_bx * alva_divup(N.h, 4);
     }
     return a.scharr_blocks + down_blocks;
