@@ -14,7 +14,7 @@ import re
 import sys
 from collections import defaultdict
 
-WIDE = ("k_level0", "k_bf_partial")   # kernels whose global reads are 16-B vectors per lane
+WIDE = ("k_level0", "k_level0_batch", "k_bf_partial")   # kernels whose global reads are 16-B vectors per lane
 
 
 def fold(path, counter):
