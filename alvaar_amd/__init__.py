@@ -5,7 +5,7 @@ The compute lives in `libalvaar_hip.so` (hand-written HIP for gfx950 behind the 
 bench.py; PyTorch is used only for device memory and streams.  There is no CPU fallback:
 touching any compute symbol fails loudly if the HIP library is missing.
 """
-_LAZY = ("lib", "AlvaError", "Context", "Pyramid", "Orb", "Frontend", "check")
+_LAZY = ("lib", "AlvaError", "Context", "Pyramid", "Orb", "Frontend", "TrackBatch", "check")
 
 
 def __getattr__(name):  # lazy so that `python -m alvaar_amd.build` works before the .so exists

@@ -82,6 +82,13 @@ _sig("alva_frontend_track_ahead", [_vp, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _
 _sig("alva_frontend_results", [_vp] + [C.POINTER(_vp)] * 6)
 _sig("alva_frontend_sync", [_vp])
 _sig("alva_frontend_run_many", [_vp, _i, _i, _i, _vp, _i, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp])
+_sig("alva_track_batch_create", [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)])
+_sig("alva_track_batch_destroy", [_vp], None)
+_sig("alva_track_batch_step", [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp])
+_sig("alva_track_batch_results", [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)])
+_sig("alva_track_batch_ctx", [_vp], _vp)
+_sig("alva_track_batch_stats", [_vp, _vp, _vp])
+_sig("alva_track_batch_set_klt_lanes", [_vp, _i])
 _sig("alva_compute_pose_enqueue", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f])
 _sig("alva_compute_pose_collect", [_vp, _vp, _vp, _vp, _vp])
 _sig("alva_compute_pose", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp])
@@ -536,6 +543,76 @@ class Frontend:
         return {"tracked": view(ptrs[0], (n, 2), torch.float32), "status": view(ptrs[1], (n,), torch.uint8),
                 "keypoints": view(ptrs[2], (m, 6), torch.float32), "descriptors": view(ptrs[3], (m, 32), torch.uint8),
                 "match_idx": view(ptrs[4], (m,), torch.int32), "match_dist": view(ptrs[5], (m,), torch.int32)}
+
+
+class TrackBatch:
+    """alva_track_batch: trackMono (preprocessImage -> kltTracking -> computePose) of B lock-step cameras, one launch per stage."""
+
+    def __init__(self, device: int, width: int, height: int, cameras: int, max_tracked: int, max_corr: int):
+        import numpy as np
+        h = _vp()
+        check(lib.alva_track_batch_create(device, width, height, cameras, max_tracked, max_corr, C.byref(h)))
+        self.h, self.device, self.B = h, device, cameras
+        self.poses = np.zeros((cameras, 7))
+        self.status = np.zeros(cameras, np.int32)
+        self._n_pts = [0] * cameras
+        self._args = None
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.alva_track_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def bind(self, pts, bearings, uv, wpts):
+        """pointer tables of the per-camera inputs that stay put between frames (lists of cuda tensors, one per camera)"""
+        B = self.B
+        arr = lambda ts: (_vp * B)(*[_ptr(t) if t is not None and t.numel() else None for t in ts])
+        self._args = (arr(pts), (_i * B)(*[0 if t is None else t.shape[0] for t in pts]), arr(bearings), arr(uv), arr(wpts),
+                      (_i * B)(*[0 if t is None else t.shape[0] for t in bearings]))
+        self._n_pts = [0 if t is None else t.shape[0] for t in pts]
+        self._keep = (pts, bearings, uv, wpts)
+
+    def step(self, rgbas, K):
+        """rgbas: list of B [H,W,4] u8 cuda tensors (same pitch).  Returns (status[B], poses[B,7]) -- views, overwritten by the next step."""
+        a_pts, a_np, a_bv, a_uv, a_wp, a_nc = self._args
+        fr = (_vp * self.B)(*[_ptr(r) for r in rgbas])
+        check(lib.alva_track_batch_step(self.h, fr, rgbas[0].stride(0), a_pts, a_np, a_bv, a_uv, a_wp, a_nc, K[0], K[1], K[2], K[3],
+                                        self.poses.ctypes.data, self.status.ctypes.data))
+        return self.status, self.poses
+
+    def results(self, cam: int):
+        """(tracked [n,2] f32, status [n] u8) of one camera: torch views of device memory, valid until the next step"""
+        p, q = _vp(), _vp()
+        check(lib.alva_track_batch_results(self.h, cam, C.byref(p), C.byref(q)))
+        n = self._n_pts[cam]
+        return _dev_view(p, (n, 2), torch.float32, self.device), _dev_view(q, (n,), torch.uint8, self.device)
+
+    def ctx_handle(self):
+        return lib.alva_track_batch_ctx(self.h)
+
+    def set_klt_lanes(self, lanes: int):
+        check(lib.alva_track_batch_set_klt_lanes(self.h, lanes))
+
+    def stats(self):
+        """(steps done, cameras re-solved through the single-camera call)"""
+        a, b = C.c_long(0), C.c_long(0)
+        check(lib.alva_track_batch_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def _dev_view(ptr, shape, dtype, device):
+    import numpy as np
+    if int(np.prod(shape)) == 0:
+        return torch.empty(shape, dtype=dtype, device=f"cuda:{device}")
+
+    class _W:
+        pass
+    w = _W()
+    typestr = {torch.float32: "<f4", torch.uint8: "|u1", torch.int32: "<i4"}[dtype]
+    w.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr.value, False), "version": 2}
+    return torch.as_tensor(w, device=f"cuda:{device}")
 
 
 def build_pyramids_batch(ctx: "Context", pyrs, rgbas, grays=None):

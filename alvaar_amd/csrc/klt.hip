@@ -20,6 +20,7 @@
 // This translation unit must be compiled with -ffp-contract=off.
 #include "common.hpp"
 #include "wave_utils.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -237,19 +238,12 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     __syncthreads();  // LDS reuse by the next level
 }
 
+// One keypoint through the whole pyramid (all arguments wave-uniform).
 // mode 0: plain calcOpticalFlowPyrLK (next in/out, status, err).
 // mode 1: FeatureTracker::fbKltTracking (prior in/out, status).
-__global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxLevel, int maxCount, double epsilon, float errThresh,
-                                            float fbDist, const float *__restrict__ pts, const float *init,
-                                            float *nextio, uint8_t *__restrict__ status_out, float *__restrict__ err_out,
-                                            int n) {
-    __shared__ LkShared sh;
-    // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Giving every XCD one CONTIGUOUS
-    // eighth of the keypoint list (callers keep keypoints in spatial / grid order) keeps an image region in one L2
-    // instead of pulling the whole pyramid through all eight.
-    const int per = gridDim.x >> 3;
-    const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (kp >= n) return;
+__device__ __forceinline__ void klt_point(LkShared &sh, const LkPyr &P, const LkPyr &C, int mode, int maxLevel, int maxCount, double epsilon,
+                                          float errThresh, float fbDist, const float *__restrict__ pts, const float *init, float *nextio,
+                                          uint8_t *__restrict__ status_out, float *__restrict__ err_out, int kp) {
     const float ptx = pts[2 * kp], pty = pts[2 * kp + 1];
     float nx = init[2 * kp], ny = init[2 * kp + 1];  // initial flow; may be the same buffer as the output
     int status = 1;
@@ -286,6 +280,519 @@ __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxL
         nextio[2 * kp] = nx;
         nextio[2 * kp + 1] = ny;
         status_out[kp] = (uint8_t) ok;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxLevel, int maxCount, double epsilon, float errThresh,
+                                            float fbDist, const float *__restrict__ pts, const float *init,
+                                            float *nextio, uint8_t *__restrict__ status_out, float *__restrict__ err_out,
+                                            int n) {
+    __shared__ LkShared sh;
+    // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Giving every XCD one CONTIGUOUS
+    // eighth of the keypoint list (callers keep keypoints in spatial / grid order) keeps an image region in one L2
+    // instead of pulling the whole pyramid through all eight.
+    const int per = gridDim.x >> 3;
+    const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (kp >= n) return;
+    klt_point(sh, P, C, mode, maxLevel, maxCount, epsilon, errThresh, fbDist, pts, init, nextio, status_out, err_out, kp);
+}
+
+// B cameras in one launch (fbKltTracking only): blockIdx.y = camera, each with its own pyramids, keypoint list and count.  The
+// per-camera block sits in device memory; it is wave-uniform, so the compiler reads it with scalar loads.  A camera's keypoints
+// keep the XCD-contiguous order of k_klt, so its pyramid still lives in the L2s of the XCDs that track into it.
+struct KltBatchItem {
+    LkPyr P, C;
+    const float *pts, *init;
+    float *out;
+    uint8_t *status;
+    int n, pad;
+};
+
+__global__ void __launch_bounds__(64) k_klt_batch(const KltBatchItem *__restrict__ items, int maxLevel, int maxCount, double epsilon,
+                                                  float errThresh, float fbDist) {
+    __shared__ LkShared sh;
+    const KltBatchItem &it = items[blockIdx.y];
+    const int per = gridDim.x >> 3;
+    const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (kp >= it.n) return;
+    klt_point(sh, it.P, it.C, 1, min(maxLevel, it.P.nlevels - 1), maxCount, epsilon, errThresh, fbDist, it.pts, it.init, it.out, it.status, nullptr,
+              kp);
+}
+
+// ---- throughput variant: 64 / L keypoints per wavefront ------------------------------------------------------------------------
+// One camera's launch of k_klt is a latency problem (the slowest keypoint sets the time), and a whole wave per keypoint is right
+// for it.  A batch of cameras is a THROUGHPUT problem: every SIMD has a queue of waves, and what counts is instructions issued per
+// keypoint.  With a wave per keypoint the window sums run on 15 / 10 of 64 lanes and every lane repeats the scalar update.  Here a
+// keypoint owns a group of L lanes (its 81 taps take ceil(81 / L) rounds), so one issued instruction advances 64 / L keypoints;
+// the arithmetic of a keypoint -- operand order of every float sum included -- is that of lk_level, so results are bit-identical.
+// Groups of a wave are neighbouring keypoints of one camera; a group that has left the loop (converged, out of the image) idles
+// until the last group of its wave is done.
+template <int L>
+struct LkSharedG {
+    short2 dxy[64 / L][NPX + 3];
+    int2 pxy[64 / L][NPX + 3];
+    uint8_t jt[64 / L][TW * TW];
+};
+
+template <int L>
+__device__ __forceinline__ float group_bcast(float v, int gbase, int k) {
+    return __shfl(v, gbase + k, 64);
+}
+
+template <int L>
+__device__ void lk_level_g(LkSharedG<L> &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
+                           float minEigThreshold, bool live, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
+    constexpr int R = (NPX + L - 1) / L;
+    const int lane = threadIdx.x, sub = lane & (L - 1), gbase = lane & ~(L - 1), g = lane / L;
+    const float halfWin = (WIN - 1) * 0.5f;
+    const float lscale = 1.0f / (float) (1 << level);
+    float prevx = ptx * lscale, prevy = pty * lscale;
+    float nextx, nexty;
+    if (level == maxLevel) {
+        nextx = nx * lscale;
+        nexty = ny * lscale;
+    } else {
+        nextx = nx * 2.f;
+        nexty = ny * 2.f;
+    }
+    if (live) {
+        nx = nextx;
+        ny = nexty;
+    }
+    prevx -= halfWin;
+    prevy -= halfWin;
+    const int ipx = (int) floorf(prevx), ipy = (int) floorf(prevy);
+    if (live && (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h)) {
+        if (level == 0) {
+            status = 0;
+            err = 0.f;
+        }
+        live = false;
+    }
+    Weights wt = bilinear_weights(prevx - (float) ipx, prevy - (float) ipy);
+    short rI[R], rIx[R], rIy[R];
+    int toff[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int p = min(sub + L * r, NPX - 1);
+        const int y = p / WIN, x = p - y * WIN;
+        toff[r] = y * TW + x;
+        rI[r] = rIx[r] = rIy[r] = 0;
+        if (live) {
+            const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
+            const int ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
+            const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
+            const short2 d00 = *reinterpret_cast<const short2 *>(drow);
+            const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
+            const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
+            const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
+            const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
+            const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+            rI[r] = (short) ival;
+            rIx[r] = (short) ixval;
+            rIy[r] = (short) iyval;
+            sh.dxy[g][p] = make_short2((short) ixval, (short) iyval);
+        }
+    }
+    __syncthreads();
+    float acc = 0.f;
+    {
+        const int l15 = min(sub, 14), comp = l15 / 5, ch = l15 - comp * 5;
+        const bool two = ch < 4;
+        const int qa = two ? ch : 8, qb = two ? ch + 4 : 8;
+#pragma unroll
+        for (int y = 0; y < WIN; y++) {
+            const short2 da = sh.dxy[g][y * WIN + qa], db = sh.dxy[g][y * WIN + qb];
+            const float fxa = (float) da.x, fya = (float) da.y, fxb = (float) db.x, fyb = (float) db.y;
+            const float p1 = (comp == 2 ? fya : fxa) * (comp == 0 ? fxa : fya);
+            float p2 = (comp == 2 ? fyb : fxb) * (comp == 0 ? fxb : fyb);
+            p2 = two ? p2 : 0.f;
+            acc = p1 + acc;
+            acc = p2 + acc;
+        }
+    }
+    float A[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float q0 = group_bcast<L>(acc, gbase, 5 * k + 0), q1 = group_bcast<L>(acc, gbase, 5 * k + 1),
+                    q2 = group_bcast<L>(acc, gbase, 5 * k + 2), q3 = group_bcast<L>(acc, gbase, 5 * k + 3);
+        float sres = group_bcast<L>(acc, gbase, 5 * k + 4);
+        sres += (q0 + q2) + (q1 + q3);
+        A[k] = sres * (1.f / (1 << 20));
+    }
+    const float A11 = A[0], A12 = A[1], A22 = A[2];
+    float D = A11 * A22 - A12 * A12;
+    const float dA = A11 - A22;
+    const float minEig = ((A22 + A11) - sqrtf(dA * dA + (4.f * A12) * A12)) / (float) (2 * WIN * WIN);
+    if (live) {
+        err = minEig;
+        if (minEig < minEigThreshold || D < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            live = false;
+        }
+    }
+    D = 1.f / D;
+    nextx -= halfWin;
+    nexty -= halfWin;
+    float pdx = 0.f, pdy = 0.f;
+    int tx0 = 0x40000000, ty0 = 0x40000000;
+    bool run = live;
+    for (int j = 0; j < maxCount; j++) {
+        if (!__any(run)) break;
+        const int inx = (int) floorf(nextx), iny = (int) floorf(nexty);
+        if (run && (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h)) {
+            if (level == 0) status = 0;
+            run = false;
+        }
+        wt = bilinear_weights(nextx - (float) inx, nexty - (float) iny);
+        const bool restage = run && (inx < tx0 || inx > tx0 + 2 * TR || iny < ty0 || iny > ty0 + 2 * TR);
+        if (__any(restage)) {
+            __syncthreads();
+            if (restage) {
+                tx0 = inx - TR;
+                ty0 = iny - TR;
+                constexpr int PER = TW * TW / L;  // bytes of the 16 x 16 tile each lane of the group stages
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    const int e = sub * PER + k, row = e / TW, col = e - row * TW;
+                    const int gy = min(max(ty0 + row, -WIN), J.h + WIN - 1);
+                    sh.jt[g][e] = J.gray[(ptrdiff_t) gy * J.gpitch + min(max(tx0 + col, -WIN), J.w + WIN - 1)];
+                }
+            }
+        }
+        __syncthreads();
+        const int tbase = run ? (iny - ty0) * TW + (inx - tx0) : 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int p = min(sub + L * r, NPX - 1);
+            const uint8_t *src = sh.jt[g] + toff[r] + tbase;
+            const int jval = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[TW] * wt.w10 + src[TW + 1] * wt.w11, 9);
+            const int diff = (int) (short) (jval - rI[r]);
+            sh.pxy[g][p] = make_int2(diff * rIx[r], diff * rIy[r]);
+        }
+        __syncthreads();
+        float bacc = 0.f;
+        {
+            const int l10 = min(sub, 9), comp = l10 & 1, q = l10 >> 1;
+            const bool two = q < 4;
+            const int qa = two ? q : 8, qb = two ? q + 4 : 8;
+            const int *src = reinterpret_cast<const int *>(sh.pxy[g]) + comp;
+#pragma unroll
+            for (int y = 0; y < WIN; y++) {
+                const int va = src[2 * (y * WIN + qa)];
+                int vb = src[2 * (y * WIN + qb)];
+                vb = two ? vb : 0;
+                bacc += (float) (va + vb);
+            }
+        }
+        float ib[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float s0 = group_bcast<L>(bacc, gbase, 0 + c) + group_bcast<L>(bacc, gbase, 4 + c);
+            const float s2 = group_bcast<L>(bacc, gbase, 2 + c) + group_bcast<L>(bacc, gbase, 6 + c);
+            float sres = group_bcast<L>(bacc, gbase, 8 + c);
+            sres += (s0 + 0.f) + (s2 + 0.f);
+            ib[c] = sres;
+        }
+        const float b1 = ib[0] * (1.f / (1 << 20)), b2 = ib[1] * (1.f / (1 << 20));
+        const float dx = (A12 * b2 - A22 * b1) * D;
+        const float dy = (A12 * b1 - A11 * b2) * D;
+        if (run) {
+            nextx += dx;
+            nexty += dy;
+            nx = nextx + halfWin;
+            ny = nexty + halfWin;
+            if ((double) dx * (double) dx + (double) dy * (double) dy <= epsilon) run = false;
+            else if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f;
+                ny -= dy * 0.5f;
+                run = false;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+    }
+    __syncthreads();
+}
+
+template <int L>
+__global__ void __launch_bounds__(64) k_klt_batch_g(const KltBatchItem *__restrict__ items, int maxLevelArg, int maxCount, double epsilon,
+                                                    float errThresh, float fbDist) {
+    __shared__ LkSharedG<L> sh;
+    constexpr int G = 64 / L;
+    const KltBatchItem &it = items[blockIdx.y];
+    const int per = gridDim.x >> 3;
+    const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-contiguous, as k_klt
+    if (w * G >= it.n) return;
+    const int kp = w * G + (int) threadIdx.x / L;
+    const bool has = kp < it.n;
+    const int kpc = has ? kp : it.n - 1;
+    const int maxLevel = min(maxLevelArg, it.P.nlevels - 1);
+    const float ptx = it.pts[2 * kpc], pty = it.pts[2 * kpc + 1];
+    float nx = it.init[2 * kpc], ny = it.init[2 * kpc + 1];
+    int status = 1;
+    float err = 0.f;
+    for (int level = maxLevel; level >= 0; level--)
+        lk_level_g<L>(sh, it.P.lv[level], it.C.lv[level], level, maxLevel, maxCount, epsilon, 1e-4f, has, ptx, pty, nx, ny, status, err);
+    // feature_tracker.cpp:48-73, as klt_point
+    int ok = status && !(err > errThresh);
+    const float fw = (float) it.C.lv[0].w, fh = (float) it.C.lv[0].h;
+    ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
+    float bx = ptx, by = pty;
+    int st2 = 1;
+    float err2 = 0.f;
+    lk_level_g<L>(sh, it.C.lv[0], it.P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, has && ok, nx, ny, bx, by, st2, err2);
+    if (ok) {
+        if (!st2) ok = 0;
+        else {
+            const float ddx = ptx - bx, ddy = pty - by;
+            const double nrm = sqrt((double) ddx * (double) ddx + (double) ddy * (double) ddy);
+            if (nrm > (double) fbDist) ok = 0;
+        }
+    }
+    if (has && (threadIdx.x & (L - 1)) == 0) {
+        it.out[2 * kp] = nx;
+        it.out[2 * kp + 1] = ny;
+        it.status[kp] = (uint8_t) ok;
+    }
+}
+
+// ---- throughput variant 2: a lane per column pair -----------------------------------------------------------------------------
+// PMC counters of the variants above on a 64-camera batch (profiles/): with a wave per keypoint the VALU is ~75 % busy
+// and the LDS array ~90 %; sharing the wave between four keypoints moves the bound to the LDS (bpermute broadcasts, four tiles on
+// the same banks).  Both costs come from the layout "pixel -> lane": every tap goes through LDS to reach the lane that owns its
+// reference sum.  Here the layout follows the reference's SUMMATION instead: its SIMD128 loop keeps, for vector lane q = 0..3, the
+// running sums of window columns q and q + 4, plus one scalar sum for column 8 (lkpyramid.cpp:553-562, 628-646).  A keypoint gets
+// GL lanes (5 used): lane q walks down its two columns (18 taps, 9 for the scalar lane), holds its part of the template in
+// registers, and adds its taps straight into its own float chains -- no tap ever goes through LDS.  Vertical neighbours share a row
+// of the searched image, so a lane reads each of its 10 rows once.  Only the 16 x 16 tile of the searched image is in LDS.  The
+// five partial sums of a keypoint meet in the reference's order through 8 bpermutes per iteration.  64 / GL keypoints per wave.
+constexpr int TPITCH = TW * TW + 4;  // LDS bytes per tile; +4 rotates the banks between the keypoints of a wave
+
+template <int GL>
+struct LkSharedQ {
+    uint8_t jt[64 / GL][TPITCH];
+};
+
+template <int GL>
+__device__ void lk_level_q(LkSharedQ<GL> &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
+                           float minEigThreshold, bool live, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
+    constexpr int NG = 64 / GL;
+    const int lane = threadIdx.x, g = min(lane / GL, NG - 1), sub = lane - (lane / GL) * GL, gbase = g * GL;
+    const int qq = min(sub, 4);
+    const bool two = qq < 4;
+    const int ca = two ? qq : 8, cb = two ? qq + 4 : 8;  // the scalar lane repeats column 8 and drops the copy
+    const float halfWin = (WIN - 1) * 0.5f;
+    const float lscale = 1.0f / (float) (1 << level);
+    float prevx = ptx * lscale, prevy = pty * lscale;
+    float nextx, nexty;
+    if (level == maxLevel) {
+        nextx = nx * lscale;
+        nexty = ny * lscale;
+    } else {
+        nextx = nx * 2.f;
+        nexty = ny * 2.f;
+    }
+    if (live) {
+        nx = nextx;
+        ny = nexty;
+    }
+    prevx -= halfWin;
+    prevy -= halfWin;
+    const int ipx = (int) floorf(prevx), ipy = (int) floorf(prevy);
+    if (live && (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h)) {
+        if (level == 0) {
+            status = 0;
+            err = 0.f;
+        }
+        live = false;
+    }
+    Weights wt = bilinear_weights(prevx - (float) ipx, prevy - (float) ipy);
+    // ---- template: this lane's two columns, all nine rows, in registers; A chains as it goes ----
+    short tI[2 * WIN], tIx[2 * WIN], tIy[2 * WIN];
+    float accA[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int y = 0; y < WIN; y++) {
+        float fx[2], fy[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int x = h ? cb : ca;
+            int ival = 0, ixval = 0, iyval = 0;
+            if (live) {
+                const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
+                ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
+                const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
+                const short2 d00 = *reinterpret_cast<const short2 *>(drow);
+                const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
+                const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
+                const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
+                ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
+                iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+            }
+            tI[2 * y + h] = (short) ival;
+            tIx[2 * y + h] = (short) ixval;
+            tIy[2 * y + h] = (short) iyval;
+            fx[h] = (float) (short) ixval;
+            fy[h] = (float) (short) iyval;
+        }
+        // comp 0: Ix Ix, 1: Ix Iy, 2: Iy Iy -- the operand order of lk_level's chains
+        const float pa[3] = {fx[0] * fx[0], fx[0] * fy[0], fy[0] * fy[0]};
+        const float pb[3] = {fx[1] * fx[1], fx[1] * fy[1], fy[1] * fy[1]};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            accA[c] = pa[c] + accA[c];
+            accA[c] = (two ? pb[c] : 0.f) + accA[c];
+        }
+    }
+    float A[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float q0 = __shfl(accA[k], gbase + 0, 64), q1 = __shfl(accA[k], gbase + 1, 64), q2 = __shfl(accA[k], gbase + 2, 64),
+                    q3 = __shfl(accA[k], gbase + 3, 64);
+        float sres = __shfl(accA[k], gbase + 4, 64);
+        sres += (q0 + q2) + (q1 + q3);
+        A[k] = sres * (1.f / (1 << 20));
+    }
+    const float A11 = A[0], A12 = A[1], A22 = A[2];
+    float D = A11 * A22 - A12 * A12;
+    const float dA = A11 - A22;
+    const float minEig = ((A22 + A11) - sqrtf(dA * dA + (4.f * A12) * A12)) / (float) (2 * WIN * WIN);
+    if (live) {
+        err = minEig;
+        if (minEig < minEigThreshold || D < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            live = false;
+        }
+    }
+    D = 1.f / D;
+    nextx -= halfWin;
+    nexty -= halfWin;
+    float pdx = 0.f, pdy = 0.f;
+    int tx0 = 0x40000000, ty0 = 0x40000000;
+    bool run = live && lane < NG * GL;
+    uint8_t *tile = sh.jt[g];
+    for (int j = 0; j < maxCount; j++) {
+        if (!__any(run)) break;
+        const int inx = (int) floorf(nextx), iny = (int) floorf(nexty);
+        if (run && (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h)) {
+            if (level == 0) status = 0;
+            run = false;
+        }
+        wt = bilinear_weights(nextx - (float) inx, nexty - (float) iny);
+        const bool restage = run && (inx < tx0 || inx > tx0 + 2 * TR || iny < ty0 || iny > ty0 + 2 * TR);
+        if (__any(restage)) {
+            __syncthreads();
+            if (restage) {
+                tx0 = inx - TR;
+                ty0 = iny - TR;
+                if (tx0 >= -WIN && ty0 >= -WIN && tx0 + TW <= J.w + WIN && ty0 + TW <= J.h + WIN) {
+                    // the whole tile lies inside the padded level: 64 dwords (the level's rows are not 4-byte aligned at tx0)
+                    for (int e = sub; e < TW * TW / 4; e += GL) {
+                        const int row = e >> 2, c4 = (e & 3) * 4;
+                        uint32_t v;
+                        __builtin_memcpy(&v, J.gray + (ptrdiff_t) (ty0 + row) * J.gpitch + (tx0 + c4), 4);
+                        *reinterpret_cast<uint32_t *>(tile + row * TW + c4) = v;
+                    }
+                } else {
+                    // coordinates clamped to the padded level, byte by byte (clamped bytes are never used, see lk_level)
+                    for (int e = sub; e < TW * TW; e += GL) {
+                        const int row = e / TW, col = e - row * TW;
+                        const int gy = min(max(ty0 + row, -WIN), J.h + WIN - 1);
+                        tile[e] = J.gray[(ptrdiff_t) gy * J.gpitch + min(max(tx0 + col, -WIN), J.w + WIN - 1)];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int tbase = run ? (iny - ty0) * TW + (inx - tx0) : 0;
+        float bx = 0.f, by = 0.f;
+        {
+            const uint8_t *sa = tile + tbase + ca, *sb = tile + tbase + cb;
+            // row r of the tile feeds the lower half of tap (r - 1) and the upper half of tap r
+            int topa = sa[0] * wt.w00 + sa[1] * wt.w01, topb = sb[0] * wt.w00 + sb[1] * wt.w01;
+#pragma unroll
+            for (int y = 0; y < WIN; y++) {
+                const int a0 = sa[(y + 1) * TW], a1 = sa[(y + 1) * TW + 1], b0 = sb[(y + 1) * TW], b1 = sb[(y + 1) * TW + 1];
+                const int ja = descale(topa + (a0 * wt.w10 + a1 * wt.w11), 9), jb = descale(topb + (b0 * wt.w10 + b1 * wt.w11), 9);
+                topa = a0 * wt.w00 + a1 * wt.w01;
+                topb = b0 * wt.w00 + b1 * wt.w01;
+                const int da = (int) (short) (ja - tI[2 * y]), db = (int) (short) (jb - tI[2 * y + 1]);
+                const int vxa = da * tIx[2 * y], vya = da * tIy[2 * y];
+                const int vxb = two ? db * tIx[2 * y + 1] : 0, vyb = two ? db * tIy[2 * y + 1] : 0;
+                bx += (float) (vxa + vxb);
+                by += (float) (vya + vyb);
+            }
+        }
+        float ib[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float v = c ? by : bx;
+            const float s0 = __shfl(v, gbase + 0, 64) + __shfl(v, gbase + 2, 64);
+            const float s2 = __shfl(v, gbase + 1, 64) + __shfl(v, gbase + 3, 64);
+            float sres = __shfl(v, gbase + 4, 64);
+            sres += (s0 + 0.f) + (s2 + 0.f);
+            ib[c] = sres;
+        }
+        const float b1 = ib[0] * (1.f / (1 << 20)), b2 = ib[1] * (1.f / (1 << 20));
+        const float dx = (A12 * b2 - A22 * b1) * D;
+        const float dy = (A12 * b1 - A11 * b2) * D;
+        if (run) {
+            nextx += dx;
+            nexty += dy;
+            nx = nextx + halfWin;
+            ny = nexty + halfWin;
+            if ((double) dx * (double) dx + (double) dy * (double) dy <= epsilon) run = false;
+            else if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f;
+                ny -= dy * 0.5f;
+                run = false;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+    }
+    __syncthreads();
+}
+
+template <int GL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_klt_batch_q(const KltBatchItem *__restrict__ items, int maxLevelArg, int maxCount, double epsilon,
+                                                    float errThresh, float fbDist) {
+    __shared__ LkSharedQ<GL> sh;
+    constexpr int NG = 64 / GL;
+    const KltBatchItem &it = items[blockIdx.y];
+    const int per = gridDim.x >> 3;
+    const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-contiguous, as k_klt
+    if (w * NG >= it.n) return;
+    const int grp = (int) threadIdx.x / GL;
+    const int kp = w * NG + grp;
+    const bool has = grp < NG && kp < it.n;
+    const int kpc = has ? kp : it.n - 1;
+    const int maxLevel = min(maxLevelArg, it.P.nlevels - 1);
+    const float ptx = it.pts[2 * kpc], pty = it.pts[2 * kpc + 1];
+    float nx = it.init[2 * kpc], ny = it.init[2 * kpc + 1];
+    int status = 1;
+    float err = 0.f;
+    for (int level = maxLevel; level >= 0; level--)
+        lk_level_q<GL>(sh, it.P.lv[level], it.C.lv[level], level, maxLevel, maxCount, epsilon, 1e-4f, has, ptx, pty, nx, ny, status, err);
+    int ok = status && !(err > errThresh);
+    const float fw = (float) it.C.lv[0].w, fh = (float) it.C.lv[0].h;
+    ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
+    float bx = ptx, by = pty;
+    int st2 = 1;
+    float err2 = 0.f;
+    lk_level_q<GL>(sh, it.C.lv[0], it.P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, has && ok, nx, ny, bx, by, st2, err2);
+    if (ok) {
+        if (!st2) ok = 0;
+        else {
+            const float ddx = ptx - bx, ddy = pty - by;
+            const double nrm = sqrt((double) ddx * (double) ddx + (double) ddy * (double) ddy);
+            if (nrm > (double) fbDist) ok = 0;
+        }
+    }
+    if (has && (int) threadIdx.x == grp * GL) {
+        it.out[2 * kp] = nx;
+        it.out[2 * kp + 1] = ny;
+        it.status[kp] = (uint8_t) ok;
     }
 }
 
@@ -344,4 +851,54 @@ extern "C" int alva_fbklt_track(alva_ctx *ctx, const alva_pyramid *prev, const a
 int alva_fbklt_track_to(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
                         int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, int n) {
     return launch(ctx, prev, curr, 1, num_levels, max_iters, eps, err_thresh, fb_dist, d_pts, d_prior_in, d_out, d_status, nullptr, n);
+}
+
+// ---- batch of cameras (internal: track_batch.hip) -------------------------------------------------------------------------
+size_t alva_klt_batch_item_size() { return sizeof(KltBatchItem); }
+
+int alva_klt_batch_item_fill(void *dst, const alva_pyramid *prev, const alva_pyramid *curr, const float *d_pts, const float *d_init,
+                             float *d_out, uint8_t *d_status, int n) {
+    ALVA_ARG(dst && prev && curr && n >= 0 && (n == 0 || (d_pts && d_init && d_out && d_status)));
+    ALVA_ARG(prev->win == WIN && curr->win == WIN);
+    ALVA_ARG(prev->nlevels == curr->nlevels && prev->lv[0].w == curr->lv[0].w && prev->lv[0].h == curr->lv[0].h);
+    KltBatchItem it{};
+    fill_pyr(prev, it.P);
+    fill_pyr(curr, it.C);
+    it.pts = d_pts;
+    it.init = d_init;
+    it.out = d_out;
+    it.status = d_status;
+    it.n = n;
+    memcpy(dst, &it, sizeof(it));
+    return ALVA_OK;
+}
+
+// fbKltTracking of `count` cameras, items already in device memory; n_max = the largest keypoint count among them
+// lanes = lanes of a wavefront per keypoint: 64 (k_klt's layout), 32 or 16 (2 / 4 keypoints per wave, see lk_level_g)
+int alva_fbklt_track_batch_enqueue(alva_ctx *ctx, const void *d_items, int count, int n_max, int num_levels, float err_thresh, float fb_dist,
+                                   int max_iters, float eps, int lanes) {
+    ALVA_ARG(ctx && d_items && count > 0 && count <= 65535 && n_max >= 0 && num_levels >= 0 && (lanes == 64 || lanes == 32 || lanes == 16 || lanes == 8 || lanes == 5));
+    if (n_max == 0) return ALVA_OK;
+    const int maxCount = max_iters < 0 ? 0 : (max_iters > 100 ? 100 : max_iters);
+    double epsilon = (double) eps;
+    epsilon = epsilon < 0 ? 0 : (epsilon > 10 ? 10 : epsilon);
+    epsilon *= epsilon;
+    const KltBatchItem *items = (const KltBatchItem *) d_items;
+    if (lanes == 64)
+        hipLaunchKernelGGL(k_klt_batch, dim3(8 * alva_divup(n_max, 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount, epsilon, err_thresh,
+                           fb_dist);
+    else if (lanes == 5)
+        hipLaunchKernelGGL(k_klt_batch_q<5>, dim3(8 * alva_divup(alva_divup(n_max, 12), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
+                           epsilon, err_thresh, fb_dist);
+    else if (lanes == 8)
+        hipLaunchKernelGGL(k_klt_batch_q<8>, dim3(8 * alva_divup(alva_divup(n_max, 8), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
+                           epsilon, err_thresh, fb_dist);
+    else if (lanes == 32)
+        hipLaunchKernelGGL(k_klt_batch_g<32>, dim3(8 * alva_divup(alva_divup(n_max, 2), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
+                           epsilon, err_thresh, fb_dist);
+    else
+        hipLaunchKernelGGL(k_klt_batch_g<16>, dim3(8 * alva_divup(alva_divup(n_max, 4), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
+                           epsilon, err_thresh, fb_dist);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
 }

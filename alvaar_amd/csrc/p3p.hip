@@ -252,14 +252,14 @@ struct P3pArgs {
     uint8_t *inlier;
 };
 
-__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) {
+__device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
     extern __shared__ unsigned long long s_keys[];
     __shared__ unsigned int s_hist[256];
     __shared__ int s_bin, s_k, s_valid, s_last;
     __shared__ unsigned long long s_min[256];
     __shared__ unsigned int s_cnt[256];
     __shared__ double s_m[12];
-    const int h = blockIdx.x, n = A.n;
+    const int n = A.n;
     const double *bv = A.bv, *wpt = A.wpt;
     // ---- 1. hypothesis -------------------------------------------------------------------------------------------
     if (threadIdx.x < 64) {
@@ -421,6 +421,16 @@ __global__ void __launch_bounds__(256) k_p3p(P3pArgs A) {
     if (threadIdx.x == 0) out->n_inliers = s_k;
 }
 
+__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) { p3p_block(A, blockIdx.x); }
+
+// B independent problems in one launch: blockIdx.y = problem (camera), each with its own correspondences, sample list, scratch
+// and arrival counter.  Dynamic LDS is sized for the largest problem.
+__global__ void __launch_bounds__(256) k_p3p_batch(const P3pArgs *__restrict__ args) {
+    const P3pArgs A = args[blockIdx.y];
+    if ((int) blockIdx.x >= A.H) return;
+    p3p_block(A, blockIdx.x);
+}
+
 // SampleConsensusProblem<M>: rng_dist_ = uniform_int_distribution<>(0, INT_MAX), rng_alg_ = std::mt19937
 // seeded 12345u (or time+clock), shuffled_indices_ persists across draws (SampleConsensusProblem.hpp:40-84).
 struct Sampler {
@@ -531,5 +541,48 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
         if (!inl[i]) h_outliers[no++] = i;  // :109-124: outliers = complement of the inlier list
     *h_n_outliers = no;
     *h_ok = 1;
+    return ALVA_OK;
+}
+
+// ---- batch of problems (internal: track_batch.hip) --------------------------------------------------------------------------
+size_t alva_p3p_batch_item_size() { return sizeof(P3pArgs); }
+
+// scratch bytes one problem with H hypotheses needs (models | valid | penalty), 64-byte granular
+size_t alva_p3p_batch_scratch_bytes(int H) {
+    const size_t off_valid = (size_t) H * 12 * sizeof(double);
+    const size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
+    return (off_pen + (size_t) H * sizeof(double) + 63) / 64 * 64;
+}
+
+int alva_p3p_batch_item_fill(void *dst, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold, float fx,
+                             float fy, int H, const int *d_samples, uint8_t *d_scratch, int *d_counter, P3pSelectOut *d_out,
+                             uint8_t *d_inlier) {
+    ALVA_ARG(dst && d_bearings && d_wpts && n >= 4 && n <= 7168 && H > 0 && d_samples && d_scratch && d_counter && d_out && d_inlier);
+    float focal = fx + fy;
+    focal /= 2.f;
+    P3pArgs A{};
+    A.bv = d_bearings;
+    A.wpt = d_wpts;
+    A.samples = d_samples;
+    A.n = n;
+    A.H = H;
+    A.max_iters = max_iters;
+    A.threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
+    const size_t off_valid = (size_t) H * 12 * sizeof(double);
+    const size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
+    A.models = (double *) d_scratch;
+    A.valid = (int *) (d_scratch + off_valid);
+    A.penalty = (double *) (d_scratch + off_pen);
+    A.counter = d_counter;
+    A.out = reinterpret_cast<SelectOut *>(d_out);
+    A.inlier = d_inlier;
+    memcpy(dst, &A, sizeof(A));
+    return ALVA_OK;
+}
+
+int alva_p3p_batch_enqueue(alva_ctx *ctx, const void *d_items, int count, int H_max, int n_max) {
+    ALVA_ARG(ctx && d_items && count > 0 && count <= 65535 && H_max > 0 && n_max >= 4 && n_max <= 7168);
+    hipLaunchKernelGGL(k_p3p_batch, dim3(H_max, count), dim3(256), (size_t) n_max * sizeof(double), ctx->stream, (const P3pArgs *) d_items);
+    ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

@@ -275,10 +275,10 @@ __device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t 
 // p3p / inlier0 non-null = chained mode (VisualFrontend::computePose, visual_frontend.cpp:300-375): the initial pose is the
 // P3P-LMedS model and only its inliers are refined; the P3P acceptance tests of multi_view_geometry.cpp:82-91 run here.
 // `out`, `bad` and `p3p_outlier` may live in pinned host memory (written once, at the end).
-__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ active, double *__restrict__ chi2,
-                                            uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
-                                            const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
-                                            uint8_t *__restrict__ p3p_outlier) {
+__device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict__ active, double *__restrict__ chi2,
+                                          uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
+                                          const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
+                                          uint8_t *__restrict__ p3p_outlier) {
     __shared__ PnpShared sh;
     __shared__ int s_nbad, s_p3p_ok, s_nact;
     __shared__ double s_info[8];
@@ -386,6 +386,30 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ act
         out->n_active = nact;
         out->p3p_n_valid_used = p3p ? p3p->n_valid_used : 0;
     }
+}
+
+__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ active, double *__restrict__ chi2,
+                                            uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
+                                            const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
+                                            uint8_t *__restrict__ p3p_outlier) {
+    pnp_block(A, active, chi2, depth, bad, out, p3p, inlier0, p3p_outlier);
+}
+
+// B chained P3P -> PnP problems in one launch, one workgroup each (blockIdx.x = camera).
+struct PnpBatchItem {
+    PnpArgs A;
+    uint8_t *active;
+    double *chi2;
+    uint8_t *depth, *bad;
+    PnpOut *out;
+    const P3pSelectOut *p3p;
+    const uint8_t *inlier0;
+    uint8_t *p3p_outlier;
+};
+
+__global__ void __launch_bounds__(NT) k_pnp_batch(const PnpBatchItem *__restrict__ items) {
+    const PnpBatchItem &it = items[blockIdx.x];
+    pnp_block(it.A, it.active, it.chi2, it.depth, it.bad, it.out, it.p3p, it.inlier0, it.p3p_outlier);
 }
 
 }  // namespace
@@ -560,4 +584,65 @@ extern "C" int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const 
                                        cx, cy);
     if (rc) return rc;
     return alva_compute_pose_collect(ctx, h_pose7, h_p3p_outlier, h_pnp_outlier, h_status);
+}
+
+// ---- batch of cameras (internal: track_batch.hip) -------------------------------------------------------------------------
+size_t alva_pnp_batch_item_size() { return sizeof(PnpBatchItem); }
+size_t alva_pnp_out_size() { return sizeof(PnpOut); }
+
+// device scratch one problem of n correspondences needs: chi2(n) | active(n) | depth(n) | bad(n) | p3p outlier(n)
+size_t alva_pnp_batch_scratch_bytes(int n) { return ((size_t) n * 12 + 63) / 64 * 64; }
+
+// computePose's PnP stage chained behind the P3P selection `d_sel` / inlier mask `d_inlier0` of the same camera
+int alva_pnp_batch_item_fill(void *dst, const double *d_uv, const double *d_wpts, int n, int pnp_iters, float chi2_th, float fx, float fy,
+                             float cx, float cy, uint8_t *d_scratch, void *out, const P3pSelectOut *d_sel, const uint8_t *d_inlier0) {
+    ALVA_ARG(dst && d_uv && d_wpts && n >= 4 && d_scratch && out && d_sel && d_inlier0);
+    PnpBatchItem it{};
+    PnpArgs &A = it.A;
+    A.uv = d_uv;
+    A.wpt = d_wpts;
+    A.n = n;
+    A.K[0] = fx; A.K[1] = fy; A.K[2] = cx; A.K[3] = cy;
+    A.huber_a = (double) sqrtf(chi2_th);
+    A.chi2_th = (double) chi2_th;
+    A.use_robust = 1;
+    A.apply_l2 = 1;
+    A.max_iters = pnp_iters;
+    A.ftol = 1.e-3;
+    it.chi2 = (double *) d_scratch;
+    it.active = d_scratch + (size_t) n * 8;
+    it.depth = it.active + n;
+    it.bad = it.depth + n;
+    it.p3p_outlier = it.bad + n;
+    it.out = (PnpOut *) out;
+    it.p3p = d_sel;
+    it.inlier0 = d_inlier0;
+    memcpy(dst, &it, sizeof(it));
+    return ALVA_OK;
+}
+
+int alva_pnp_batch_enqueue(alva_ctx *ctx, const void *d_items, int count) {
+    ALVA_ARG(ctx && d_items && count > 0);
+    hipLaunchKernelGGL(k_pnp_batch, dim3(count), dim3(NT), 0, ctx->stream, (const PnpBatchItem *) d_items);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+// the acceptance logic of alva_compute_pose_collect on one camera's PnpOut (status 0 / 1 / 2; pose written when the solver wrote one);
+// *needs_more_draws = the P3P stage ran short of valid hypotheses with H draws (the caller redoes that camera with a longer prefix)
+int alva_pnp_out_decode(const void *out, int p3p_iters, int H, int max_draws, double *h_pose7, int *h_status, int *needs_more_draws) {
+    PnpOut res;
+    memcpy(&res, out, sizeof(res));
+    *h_status = 0;
+    *needs_more_draws = !(res.p3p_n_valid_used >= p3p_iters || H >= max_draws);
+    if (*needs_more_draws) return ALVA_OK;
+    if (!res.p3p_ok) return ALVA_OK;
+    *h_status = 1;
+    if (res.n_bad == res.n_active) return ALVA_OK;
+    memcpy(h_pose7, res.pose, sizeof(res.pose));
+    const int inliers = res.n_active - res.n_bad;
+    bool finite = true;
+    for (int c = 0; c < 3; c++) finite = finite && std::isfinite(res.pose[c]);
+    if (res.ok && inliers >= 5 && res.n_bad <= 0.5 * res.n_active && finite) *h_status = 2;
+    return ALVA_OK;
 }

@@ -1,0 +1,256 @@
+// VisualFrontend::trackMono for B lock-step cameras: every stage is ONE launch that carries all cameras.
+//
+// The per-frame path of the reference (src/slam/src/visual_frontend.cpp:83-150) is preprocessImage -> kltTracking -> computePose;
+// the detector only runs when the mapper decides on a keyframe.  One 640x480 camera gives each of those stages a few microseconds
+// to a few tens of microseconds of work in a dependent chain, so a single stream cannot occupy 256 CUs, and threads driving
+// independent streams run into the launch path of the runtime.  A rig of cameras (or a server tracking many
+// sessions) has a data-parallel dimension the reference cannot use: here it becomes the grid's y / z dimension.
+//
+//   preprocessImage  x B   alva_pyramid_build_from_rgba_batch       5 launches   (image.hip)     image lane
+//   kltTracking      x B   k_klt_batch_g                            1 launch     (klt.hip)       image lane
+//   computePose      x B   k_p3p_batch -> k_pnp_batch               2 launches   (p3p.hip, pnp.hip)  pose lane (second HIP stream)
+//
+// and one host wait per lane for the B poses.  Every camera keeps its own pyramids, keypoints, correspondences and counts; the
+// device code of a camera is the single-camera code (klt_point / p3p_block / pnp_block), so results are bit-identical to B calls of
+// alva_frontend_track (tests/test_gpu_track_batch.py).
+#include "common.hpp"
+#include "pose_internal.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <unordered_map>
+
+size_t alva_klt_batch_item_size();
+int alva_klt_batch_item_fill(void *dst, const alva_pyramid *prev, const alva_pyramid *curr, const float *d_pts, const float *d_init,
+                             float *d_out, uint8_t *d_status, int n);
+int alva_fbklt_track_batch_enqueue(alva_ctx *ctx, const void *d_items, int count, int n_max, int num_levels, float err_thresh, float fb_dist,
+                                   int max_iters, float eps, int lanes);
+size_t alva_p3p_batch_item_size();
+size_t alva_p3p_batch_scratch_bytes(int H);
+int alva_p3p_batch_item_fill(void *dst, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold, float fx,
+                             float fy, int H, const int *d_samples, uint8_t *d_scratch, int *d_counter, P3pSelectOut *d_out,
+                             uint8_t *d_inlier);
+int alva_p3p_batch_enqueue(alva_ctx *ctx, const void *d_items, int count, int H_max, int n_max);
+size_t alva_pnp_batch_item_size();
+size_t alva_pnp_out_size();
+size_t alva_pnp_batch_scratch_bytes(int n);
+int alva_pnp_batch_item_fill(void *dst, const double *d_uv, const double *d_wpts, int n, int pnp_iters, float chi2_th, float fx, float fy,
+                             float cx, float cy, uint8_t *d_scratch, void *out, const P3pSelectOut *d_sel, const uint8_t *d_inlier0);
+int alva_pnp_batch_enqueue(alva_ctx *ctx, const void *d_items, int count);
+int alva_pnp_out_decode(const void *out, int p3p_iters, int H, int max_draws, double *h_pose7, int *h_status, int *needs_more_draws);
+
+namespace {
+constexpr int P3P_ITERS = 100;                 // state.hpp:64-76, as alva_frontend_track
+constexpr int P3P_DRAWS = P3P_ITERS + 28;      // first prefix of the sample stream (alva_compute_pose_enqueue)
+constexpr int P3P_MAX_DRAWS = P3P_ITERS * 11;  // Lmeds.hpp:67
+constexpr size_t OUT_STRIDE = 256;
+size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+}  // namespace
+
+struct alva_track_batch {
+    int device = 0, width = 0, height = 0, B = 0, n_track = 0, n_corr = 0, klt_levels = 3, klt_lanes = 5;
+    alva_ctx *ctx = nullptr, *pose = nullptr;  // image + tracking lane | pose lane (computePose reads nothing the tracker writes)
+    std::vector<alva_pyramid *> pyr[2];
+    uint8_t *slab = nullptr;      // per camera: tracked | status | p3p scratch | selection | inlier mask | pnp scratch; then counters
+    size_t cam_stride = 0, off_status = 0, off_p3p = 0, off_sel = 0, off_inl = 0, off_pnp = 0;
+    int *d_counters = nullptr;
+    uint8_t *d_items = nullptr, *h_items = nullptr;  // klt | p3p | pnp argument blocks (device copy, pinned staging)
+    size_t off_items_p3p = 0, off_items_pnp = 0, items_bytes = 0;
+    uint8_t *h_out = nullptr;     // pinned: PnpOut per camera, written by k_pnp_batch
+    std::unordered_map<int, int *> samples;  // n -> device copy of the first P3P_DRAWS samples of the fixed-seed stream
+    std::vector<int> slot;        // camera -> index among the cameras that solve a pose this frame (-1: fewer than 4 correspondences)
+    long frame = 0, fallbacks = 0;  // fallbacks: cameras re-solved by the single-camera call (P3P prefix too short)
+};
+
+extern "C" void alva_track_batch_destroy(alva_track_batch *tb) {
+    if (!tb) return;
+    (void) hipSetDevice(tb->device);
+    if (tb->ctx) (void) alva_ctx_sync(tb->ctx);
+    if (tb->pose && tb->pose != tb->ctx) (void) alva_ctx_sync(tb->pose);
+    for (auto &v: tb->pyr)
+        for (auto p: v)
+            if (p) alva_pyramid_destroy(p);
+    for (auto &kv: tb->samples) (void) hipFree(kv.second);
+    if (tb->slab) (void) hipFree(tb->slab);
+    if (tb->d_items) (void) hipFree(tb->d_items);
+    if (tb->h_items) (void) hipHostFree(tb->h_items);
+    if (tb->h_out) (void) hipHostFree(tb->h_out);
+    if (tb->pose && tb->pose != tb->ctx) alva_ctx_destroy(tb->pose);
+    if (tb->ctx) alva_ctx_destroy(tb->ctx);
+    delete tb;
+}
+
+extern "C" int alva_track_batch_create(int device, int width, int height, int cameras, int max_tracked, int max_corr, alva_track_batch **out) {
+    ALVA_ARG(out && width >= 64 && height >= 64 && width % 4 == 0 && cameras > 0 && cameras <= 4096 && max_tracked > 0 && max_corr >= 4 &&
+             max_corr <= 7168);
+    static_assert(sizeof(P3pSelectOut) <= 256, "selection slot");
+    if (alva_pnp_out_size() > OUT_STRIDE) {
+        alva_set_error("alva_track_batch_create: result slot too small");
+        return ALVA_ERR_STATE;
+    }
+    alva_track_batch *tb = new alva_track_batch();
+    tb->device = device;
+    tb->width = width;
+    tb->height = height;
+    tb->B = cameras;
+    tb->n_track = max_tracked;
+    tb->n_corr = max_corr;
+    tb->slot.assign((size_t) cameras, -1);
+    if (const char *e = std::getenv("ALVA_KLT_BATCH_LANES")) {
+        const int v = atoi(e);
+        if (v == 5 || v == 8 || v == 16 || v == 32 || v == 64) tb->klt_lanes = v;
+    }
+    int rc = alva_ctx_create(device, nullptr, 1, &tb->ctx);
+    // ALVA_TRACK_BATCH_ONE_LANE=1 (measurement): pose kernels on the image lane's stream, so per-kernel times are not inflated by overlap
+    if (std::getenv("ALVA_TRACK_BATCH_ONE_LANE")) tb->pose = tb->ctx;
+    else if (!rc) rc = alva_ctx_create(device, nullptr, 1, &tb->pose);
+    for (int k = 0; k < 2 && !rc; k++) {
+        tb->pyr[k].assign((size_t) cameras, nullptr);
+        for (int c = 0; c < cameras && !rc; c++) rc = alva_pyramid_create(tb->ctx, width, height, 9, 3, &tb->pyr[k][(size_t) c]);  // state.hpp:53-54
+    }
+    tb->off_status = up((size_t) max_tracked * 2 * sizeof(float), 64);
+    tb->off_p3p = tb->off_status + up((size_t) max_tracked, 64);
+    tb->off_sel = tb->off_p3p + alva_p3p_batch_scratch_bytes(P3P_DRAWS);
+    tb->off_inl = tb->off_sel + 256;
+    tb->off_pnp = tb->off_inl + up((size_t) max_corr, 64);
+    tb->cam_stride = up(tb->off_pnp + alva_pnp_batch_scratch_bytes(max_corr), 256);
+    const size_t slab_bytes = tb->cam_stride * (size_t) cameras + up((size_t) cameras * sizeof(int), 256);
+    tb->off_items_p3p = up(alva_klt_batch_item_size() * (size_t) cameras, 256);
+    tb->off_items_pnp = tb->off_items_p3p + up(alva_p3p_batch_item_size() * (size_t) cameras, 256);
+    tb->items_bytes = tb->off_items_pnp + up(alva_pnp_batch_item_size() * (size_t) cameras, 256);
+    auto check = [&](hipError_t e, const char *what) {
+        if (rc || e == hipSuccess) return;
+        alva_set_error("alva_track_batch_create: %s failed: %s", what, hipGetErrorString(e));
+        rc = ALVA_ERR_NOMEM;
+    };
+    if (!rc) check(hipMalloc((void **) &tb->slab, slab_bytes), "hipMalloc(slab)");
+    if (!rc) check(hipMemset(tb->slab, 0, slab_bytes), "hipMemset(slab)");
+    if (!rc) check(hipMalloc((void **) &tb->d_items, tb->items_bytes), "hipMalloc(items)");
+    if (!rc) check(hipHostMalloc((void **) &tb->h_items, tb->items_bytes, hipHostMallocDefault), "hipHostMalloc(items)");
+    if (!rc) check(hipHostMalloc((void **) &tb->h_out, OUT_STRIDE * (size_t) cameras, hipHostMallocDefault), "hipHostMalloc(results)");
+    if (rc) {
+        alva_track_batch_destroy(tb);
+        return rc;
+    }
+    tb->d_counters = (int *) (tb->slab + tb->cam_stride * (size_t) cameras);
+    *out = tb;
+    return ALVA_OK;
+}
+
+// the first P3P_DRAWS samples of SampleConsensusProblem's fixed-seed stream for n points (p3p.hip Sampler), resident on the device
+static int samples_for(alva_track_batch *tb, int n, const int **out) {
+    auto it = tb->samples.find(n);
+    if (it != tb->samples.end()) {
+        *out = it->second;
+        return ALVA_OK;
+    }
+    std::vector<int> h((size_t) P3P_DRAWS * 4);
+    int rc = alva_p3p_draw_samples(n, P3P_DRAWS, 0, 12345u, h.data());
+    if (rc) return rc;
+    int *d = nullptr;
+    ALVA_HIP(hipMalloc((void **) &d, h.size() * sizeof(int)));
+    ALVA_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+    tb->samples.emplace(n, d);
+    *out = d;
+    return ALVA_OK;
+}
+
+extern "C" int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const *d_rgba, size_t rgba_pitch, const float *const *d_pts,
+                                     const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
+                                     const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy, double *h_pose7,
+                                     int *h_pose_status) {
+    ALVA_ARG(tb && d_rgba && n_pts && n_corr && h_pose7 && h_pose_status);
+    ALVA_HIP(hipSetDevice(tb->device));
+    const int B = tb->B, cur = (int) (tb->frame & 1), prv = cur ^ 1;
+    alva_ctx *ctx = tb->ctx;
+    int n_pts_max = 0, n_corr_max = 0, n_pose = 0;
+    for (int c = 0; c < B; c++) {
+        ALVA_ARG(n_pts[c] >= 0 && n_pts[c] <= tb->n_track && n_corr[c] >= 0 && n_corr[c] <= tb->n_corr);
+        ALVA_ARG(n_pts[c] == 0 || tb->frame == 0 || (d_pts && d_pts[c]));
+        ALVA_ARG(n_corr[c] < 4 || (d_bearings && d_uv && d_wpts && d_bearings[c] && d_uv[c] && d_wpts[c]));
+    }
+    // argument blocks of the three launches behind the pyramids, one copy
+    int rc = ALVA_OK;
+    const size_t klt_sz = alva_klt_batch_item_size(), p3p_sz = alva_p3p_batch_item_size(), pnp_sz = alva_pnp_batch_item_size();
+    for (int c = 0; c < B; c++) {
+        uint8_t *cam = tb->slab + tb->cam_stride * (size_t) c;
+        const int np = tb->frame > 0 ? n_pts[c] : 0;
+        // kltTracking: prior = the previous positions (feature_tracker.cpp:5-111), result in the camera's own buffer
+        rc = alva_klt_batch_item_fill(tb->h_items + klt_sz * (size_t) c, tb->pyr[prv][(size_t) c], tb->pyr[cur][(size_t) c], np ? d_pts[c] : nullptr,
+                                      np ? d_pts[c] : nullptr, (float *) cam, cam + tb->off_status, np);
+        if (rc) return rc;
+        n_pts_max = std::max(n_pts_max, np);
+        h_pose_status[c] = 0;
+        tb->slot[(size_t) c] = -1;
+        if (n_corr[c] < 4) continue;  // visual_frontend.cpp:249-257
+        const int *d_samples = nullptr;
+        rc = samples_for(tb, n_corr[c], &d_samples);
+        if (rc) return rc;
+        P3pSelectOut *sel = (P3pSelectOut *) (cam + tb->off_sel);
+        rc = alva_p3p_batch_item_fill(tb->h_items + tb->off_items_p3p + p3p_sz * (size_t) n_pose, d_bearings[c], d_wpts[c], n_corr[c], P3P_ITERS, 3.0f,
+                                      fx, fy, P3P_DRAWS, d_samples, cam + tb->off_p3p, tb->d_counters + c, sel, cam + tb->off_inl);
+        if (!rc)
+            rc = alva_pnp_batch_item_fill(tb->h_items + tb->off_items_pnp + pnp_sz * (size_t) n_pose, d_uv[c], d_wpts[c], n_corr[c], 5, 5.9915f, fx, fy,
+                                          cx, cy, cam + tb->off_pnp, tb->h_out + OUT_STRIDE * (size_t) c, sel, cam + tb->off_inl);
+        if (rc) return rc;
+        tb->slot[(size_t) c] = n_pose++;
+        n_corr_max = std::max(n_corr_max, n_corr[c]);
+    }
+    ALVA_HIP(hipMemcpyAsync(tb->d_items, tb->h_items, tb->items_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pose lane: computePose of every camera.  Its inputs are the caller's correspondences, so it runs beside the image lane
+    // (the single pose workgroup per camera and the tracker's waves fill different CUs)
+    if (n_pose > 0) {
+        rc = alva_ctx_wait(tb->pose, ctx);  // the argument blocks
+        if (!rc) rc = alva_p3p_batch_enqueue(tb->pose, tb->d_items + tb->off_items_p3p, n_pose, P3P_DRAWS, n_corr_max);
+        if (!rc) rc = alva_pnp_batch_enqueue(tb->pose, tb->d_items + tb->off_items_pnp, n_pose);
+        if (rc) return rc;
+    }
+    // image lane: preprocessImage, then kltTracking, of every camera
+    rc = alva_pyramid_build_from_rgba_batch(ctx, tb->pyr[cur].data(), d_rgba, rgba_pitch, nullptr, 0, B);
+    if (rc) return rc;
+    rc = alva_fbklt_track_batch_enqueue(ctx, tb->d_items, B, n_pts_max, tb->klt_levels, 30.f, 0.5f, 30, 0.01f, tb->klt_lanes);  // state.hpp:55-59
+    if (rc) return rc;
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_pose > 0) ALVA_HIP(hipStreamSynchronize(tb->pose->stream));
+    for (int c = 0; c < B; c++) {
+        if (tb->slot[(size_t) c] < 0) continue;
+        int more = 0;
+        rc = alva_pnp_out_decode(tb->h_out + OUT_STRIDE * (size_t) c, P3P_ITERS, P3P_DRAWS, P3P_MAX_DRAWS, h_pose7 + 7 * (size_t) c, h_pose_status + c, &more);
+        if (rc) return rc;
+        if (more) {
+            tb->fallbacks++;
+            // rare: so many degenerate samples that the first prefix of the stream did not yield 100 models; that camera goes through the
+            // single-camera call, which extends the prefix (alva_compute_pose_collect)
+            rc = alva_compute_pose(ctx, d_bearings[c], d_uv[c], d_wpts[c], n_corr[c], P3P_ITERS, 3.0f, 0, 12345u, 5, 5.9915f, fx, fy, cx, cy,
+                                   h_pose7 + 7 * (size_t) c, nullptr, nullptr, h_pose_status + c);
+            if (rc) return rc;
+        }
+    }
+    tb->frame++;
+    return ALVA_OK;
+}
+
+// Device-resident kltTracking results of camera `cam` from the last step (valid until the next one).
+extern "C" int alva_track_batch_results(alva_track_batch *tb, int cam, const float **d_tracked, const uint8_t **d_track_status) {
+    ALVA_ARG(tb && cam >= 0 && cam < tb->B && tb->frame > 0);
+    const uint8_t *base = tb->slab + tb->cam_stride * (size_t) cam;
+    if (d_tracked) *d_tracked = (const float *) base;
+    if (d_track_status) *d_track_status = base + tb->off_status;
+    return ALVA_OK;
+}
+
+// lanes of a wavefront that share one keypoint in the tracking launch: 32 (default; two keypoints per wave), 16, or 64 (the
+// single-camera kernel's layout).  Results do not depend on it.
+extern "C" int alva_track_batch_set_klt_lanes(alva_track_batch *tb, int lanes) {
+    ALVA_ARG(tb && (lanes == 5 || lanes == 8 || lanes == 16 || lanes == 32 || lanes == 64));
+    tb->klt_lanes = lanes;
+    return ALVA_OK;
+}
+
+extern "C" int alva_track_batch_stats(alva_track_batch *tb, long *frames, long *single_camera_fallbacks) {
+    ALVA_ARG(tb);
+    if (frames) *frames = tb->frame;
+    if (single_camera_fallbacks) *single_camera_fallbacks = tb->fallbacks;
+    return ALVA_OK;
+}
+
+extern "C" alva_ctx *alva_track_batch_ctx(alva_track_batch *tb) { return tb ? tb->ctx : nullptr; }

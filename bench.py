@@ -289,6 +289,58 @@ def bench_batched_preprocess(device: int, cameras: int = 64, reps: int = 20):
                 note="event-timed kernels of alva_pyramid_build_from_rgba_batch; achieved = algorithmic bytes / sum of kernel times")
 
 
+def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed: int = 7):
+    """Secondary line: VisualFrontend::trackMono (preprocessImage -> kltTracking -> computePose; the detector belongs to the keyframe
+    branch) for `cameras` lock-step cameras through alva_track_batch_step -- 8 launches and one synchronisation for ALL cameras.
+    Every camera has its own frame ring (4 distinct synthetic streams, cycled), 2120 keypoints and 2120 correspondences.
+    Algorithmic HBM bytes per camera frame: 4P RGBA in + 7.64P pyramid/Scharr (no separate gray copy) + the KLT gathers, which stay
+    in L2 and are not counted => 11.64 P."""
+    import alvaar_amd
+    from alvaar_amd import capi, synth
+    dev = torch.device("cuda", device)
+    nsrc = min(cameras, 4)
+    rings = [torch.from_numpy(synth.stream_rgba(W, H, RING, seed=seed + s, noise=True)).to(dev) for s in range(nsrc)]
+    pts, bv, uv, wp = [], [], [], []
+    for s in range(nsrc):
+        pb = synth.make_pnp_problem(NKP, seed + s, outlier_frac=0.1, pose_noise=0.01)
+        pts.append(torch.from_numpy(make_keypoints(NKP, seed + s)).to(dev))
+        bv.append(torch.from_numpy(pb["bv"]).to(dev))
+        uv.append(torch.from_numpy(pb["uv"]).to(dev))
+        wp.append(torch.from_numpy(pb["wpt"]).to(dev))
+        K = pb["K"]
+    # every camera owns its frames (no two cameras read the same HBM lines)
+    frames = [rings[c % nsrc].clone() for c in range(cameras)]
+    tb = alvaar_amd.TrackBatch(device, W, H, cameras, NKP, NKP)
+    tb.bind([pts[c % nsrc] for c in range(cameras)], [bv[c % nsrc] for c in range(cameras)], [uv[c % nsrc] for c in range(cameras)],
+            [wp[c % nsrc] for c in range(cameras)])
+    k = 0
+
+    def step():
+        nonlocal k
+        k += 1
+        return tb.step([f[k % RING] for f in frames], K)
+    for _ in range(3):
+        st, _ = step()
+    torch.cuda.synchronize(dev)
+    ok = 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st, _ = step()
+        ok += int((st == 2).sum())
+    dt = (time.perf_counter() - t0) / reps
+    kt = capi.kernel_times(step, 3)
+    kernel_us = sum(v[0] / 3 * v[1] for v in kt.values())
+    alg = cameras * 11.64 * W * H
+    steps_done, fallbacks = tb.stats()
+    tb.close()
+    return dict(cameras=cameras, launches_per_step=8, ms_per_step=dt * 1e3, frames_per_s=cameras / dt, poses_accepted_frac=ok / (reps * cameras),
+                single_camera_fallbacks=fallbacks, kernel_us_per_step=kernel_us, alg_bytes_per_step=int(alg),
+                achieved_GBps=alg / dt / 1e9, hbm_frac=alg / dt / 1e9 / HBM_PEAK_GBS,
+                kernels={n: {"avg_us": round(v[1], 2), "launches_per_step": round(v[0] / 3, 2)} for n, v in kt.items()},
+                note="whole alva_track_batch_step calls (pointer tables, argument copy, 8 launches, one stream synchronisation, pose decode); "
+                     "achieved = algorithmic image bytes / wall time of the step, not / kernel time")
+
+
 def bench_two_view_init(ctx, reps: int = 10):
     """§8f-2 secondary line: the map-initialisation call (compute5ptEssentialMatrix) on 2000 correspondences, 25 % mismatches."""
     import torch
@@ -461,6 +513,7 @@ def main():
             "local_ba": ba,
             "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
             "batched_preprocess": bench_batched_preprocess(local) if world == 1 else None,
+            "track_mono_batch": [bench_track_mono_batch(local, c_) for c_ in (16, 64)] if world == 1 else None,
             "config_1280x720": bench_720p(local) if world == 1 else None,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

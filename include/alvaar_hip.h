@@ -348,6 +348,33 @@ int alva_frontend_run_many(alva_frontend **fes, int n_streams, int steps, int wa
                            const double *const *d_bearings, const double *const *d_uv, const double *const *d_wpts,
                            int n_corr, float fx, float fy, float cx, float cy, double *h_seconds, int *h_accepted);
 
+/* ---- a1 for a rig: VisualFrontend::trackMono of B lock-step cameras, one launch per stage for all of them ----------------
+ * The per-frame path of src/slam/src/visual_frontend.cpp:83-150 -- preprocessImage (:672-698), kltTracking (:152-243),
+ * computePose (:245-417); the detector is the keyframe branch's, not this path's -- for `cameras` independent cameras that deliver
+ * their frames together: 5 launches build all gray images + LK pyramids, 1 launch tracks every camera's keypoints, 2 launches solve
+ * every camera's P3P-LMedS -> PnP, and one host synchronisation returns the poses.  Each camera has its own frame, keypoints
+ * (n_pts[c] <= max_tracked), correspondences (n_corr[c] <= max_corr <= 7168) and state; results are identical to `cameras`
+ * alva_frontend_track calls.  d_rgba / d_pts / d_bearings / d_uv / d_wpts are host arrays of `cameras` device pointers;
+ * h_pose7 is [cameras][7] (written where status >= 1 and the solver produced a pose), h_pose_status [cameras] as alva_compute_pose. */
+typedef struct alva_track_batch alva_track_batch;
+int alva_track_batch_create(int device, int width, int height, int cameras, int max_tracked, int max_corr, alva_track_batch **out);
+void alva_track_batch_destroy(alva_track_batch *tb);
+int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const *d_rgba, size_t rgba_pitch, const float *const *d_pts,
+                          const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
+                          const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy, double *h_pose7,
+                          int *h_pose_status);
+/* device-resident kltTracking result of one camera from the last step: [n_pts][2] positions, [n_pts] status */
+int alva_track_batch_results(alva_track_batch *tb, int cam, const float **d_tracked, const uint8_t **d_track_status);
+/* Tuning knob of the tracking launch: lanes of a wavefront per keypoint, 32 (default: two keypoints per wave, the fastest on
+ * MI355X), 16 or 64 (the single-camera kernel's layout).  Results are identical for all three.  The environment variable
+ * ALVA_KLT_BATCH_LANES sets the default at creation. */
+int alva_track_batch_set_klt_lanes(alva_track_batch *tb, int lanes);
+/* steps done, and how often a camera had to be re-solved by the single-camera call because the first 128 samples of its P3P
+ * stream held fewer than 100 non-degenerate ones (the reference keeps drawing, Lmeds.hpp:67-92) */
+int alva_track_batch_stats(alva_track_batch *tb, long *frames, long *single_camera_fallbacks);
+/* the context (stream) the batch runs on, e.g. for alva_prof_* or alva_ctx_sync */
+alva_ctx *alva_track_batch_ctx(alva_track_batch *tb);
+
 /* ---- a10-a13: local bundle adjustment ---------------------------------------------------------
  * Replaces the solve inside Optimizer::localBA (src/slam/src/optimizer.cpp:251-262 on the problem
  * built at :20-247): Levenberg-Marquardt + Huber, Schur complement on the point blocks,
