@@ -68,6 +68,16 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     return w;
 }
 
+// The bilinear sums multiply 8-bit pixels / 13-bit derivatives by 15-bit weights: v_mul_i32_i24 / v_mad_i32_i24 are full-rate, the
+// 32-bit v_mul_lo_u32 the compiler must otherwise use is quarter-rate.  SIGNED 24-bit: w11 = 2^14 - w00 - w01 - w10 is -1 when the
+// three rounded weights add up to 2^14 + 1 (lkpyramid.cpp:236-239 has the same -1).
+__device__ __forceinline__ int bl_u8(int s00, int s01, int s10, int s11, const Weights &w) {
+    return __mul24(s00, w.w00) + __mul24(s01, w.w01) + __mul24(s10, w.w10) + __mul24(s11, w.w11);
+}
+__device__ __forceinline__ int bl_i16(int s00, int s01, int s10, int s11, const Weights &w) {
+    return __mul24(s00, w.w00) + __mul24(s01, w.w01) + __mul24(s10, w.w10) + __mul24(s11, w.w11);
+}
+
 // One point, one pyramid level (lkpyramid.cpp:199-680).  All arguments and results are wave-uniform.
 __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
                          float minEigThreshold, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
@@ -106,14 +116,14 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         const int y = p / WIN, x = p - y * WIN;
         toff[r] = y * TW + x;
         const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
-        const int ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
+        const int ival = descale(bl_u8(src[0], src[1], src[I.gpitch], src[I.gpitch + 1], wt), 9);
         const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
         const short2 d00 = *reinterpret_cast<const short2 *>(drow);
         const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
         const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
         const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
-        const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
-        const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+        const int ixval = descale(bl_i16(d00.x, d01.x, d10.x, d11.x, wt), 14);
+        const int iyval = descale(bl_i16(d00.y, d01.y, d10.y, d11.y, wt), 14);
         rI[r] = (short) ival;
         rIx[r] = (short) ixval;
         rIy[r] = (short) iyval;
@@ -189,7 +199,7 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         for (int r = 0; r < 2; r++) {
             const int p = min(lane + 64 * r, NPX - 1);
             const uint8_t *src = sh.jt + toff[r] + tbase;
-            const int jval = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[TW] * wt.w10 + src[TW + 1] * wt.w11, 9);
+            const int jval = descale(bl_u8(src[0], src[1], src[TW], src[TW + 1], wt), 9);
             const int diff = (int) (short) (jval - rI[r]);
             sh.pxy[p] = make_int2(diff * rIx[r], diff * rIy[r]);
         }
@@ -380,14 +390,14 @@ __device__ void lk_level_g(LkSharedG<L> &sh, const LkLevel &I, const LkLevel &J,
         rI[r] = rIx[r] = rIy[r] = 0;
         if (live) {
             const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
-            const int ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
+            const int ival = descale(bl_u8(src[0], src[1], src[I.gpitch], src[I.gpitch + 1], wt), 9);
             const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
             const short2 d00 = *reinterpret_cast<const short2 *>(drow);
             const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
             const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
             const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
-            const int ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
-            const int iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+            const int ixval = descale(bl_i16(d00.x, d01.x, d10.x, d11.x, wt), 14);
+            const int iyval = descale(bl_i16(d00.y, d01.y, d10.y, d11.y, wt), 14);
             rI[r] = (short) ival;
             rIx[r] = (short) ixval;
             rIy[r] = (short) iyval;
@@ -466,7 +476,7 @@ __device__ void lk_level_g(LkSharedG<L> &sh, const LkLevel &I, const LkLevel &J,
         for (int r = 0; r < R; r++) {
             const int p = min(sub + L * r, NPX - 1);
             const uint8_t *src = sh.jt[g] + toff[r] + tbase;
-            const int jval = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[TW] * wt.w10 + src[TW + 1] * wt.w11, 9);
+            const int jval = descale(bl_u8(src[0], src[1], src[TW], src[TW + 1], wt), 9);
             const int diff = (int) (short) (jval - rI[r]);
             sh.pxy[g][p] = make_int2(diff * rIx[r], diff * rIy[r]);
         }
@@ -620,14 +630,14 @@ __device__ void lk_level_q(LkSharedQ<GL> &sh, const LkLevel &I, const LkLevel &J
             int ival = 0, ixval = 0, iyval = 0;
             if (live) {
                 const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
-                ival = descale(src[0] * wt.w00 + src[1] * wt.w01 + src[I.gpitch] * wt.w10 + src[I.gpitch + 1] * wt.w11, 9);
+                ival = descale(bl_u8(src[0], src[1], src[I.gpitch], src[I.gpitch + 1], wt), 9);
                 const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
                 const short2 d00 = *reinterpret_cast<const short2 *>(drow);
                 const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
                 const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
                 const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
-                ixval = descale(d00.x * wt.w00 + d01.x * wt.w01 + d10.x * wt.w10 + d11.x * wt.w11, 14);
-                iyval = descale(d00.y * wt.w00 + d01.y * wt.w01 + d10.y * wt.w10 + d11.y * wt.w11, 14);
+                ixval = descale(bl_i16(d00.x, d01.x, d10.x, d11.x, wt), 14);
+                iyval = descale(bl_i16(d00.y, d01.y, d10.y, d11.y, wt), 14);
             }
             tI[2 * y + h] = (short) ival;
             tIx[2 * y + h] = (short) ixval;
@@ -709,13 +719,13 @@ __device__ void lk_level_q(LkSharedQ<GL> &sh, const LkLevel &I, const LkLevel &J
         {
             const uint8_t *sa = tile + tbase + ca, *sb = tile + tbase + cb;
             // row r of the tile feeds the lower half of tap (r - 1) and the upper half of tap r
-            int topa = sa[0] * wt.w00 + sa[1] * wt.w01, topb = sb[0] * wt.w00 + sb[1] * wt.w01;
+            int topa = __mul24(sa[0], wt.w00) + __mul24(sa[1], wt.w01), topb = __mul24(sb[0], wt.w00) + __mul24(sb[1], wt.w01);
 #pragma unroll
             for (int y = 0; y < WIN; y++) {
                 const int a0 = sa[(y + 1) * TW], a1 = sa[(y + 1) * TW + 1], b0 = sb[(y + 1) * TW], b1 = sb[(y + 1) * TW + 1];
-                const int ja = descale(topa + (a0 * wt.w10 + a1 * wt.w11), 9), jb = descale(topb + (b0 * wt.w10 + b1 * wt.w11), 9);
-                topa = a0 * wt.w00 + a1 * wt.w01;
-                topb = b0 * wt.w00 + b1 * wt.w01;
+                const int ja = descale(topa + (__mul24(a0, wt.w10) + __mul24(a1, wt.w11)), 9), jb = descale(topb + (__mul24(b0, wt.w10) + __mul24(b1, wt.w11)), 9);
+                topa = __mul24(a0, wt.w00) + __mul24(a1, wt.w01);
+                topb = __mul24(b0, wt.w00) + __mul24(b1, wt.w01);
                 const int da = (int) (short) (ja - tI[2 * y]), db = (int) (short) (jb - tI[2 * y + 1]);
                 const int vxa = da * tIx[2 * y], vya = da * tIy[2 * y];
                 const int vxb = two ? db * tIx[2 * y + 1] : 0, vyb = two ? db * tIy[2 * y + 1] : 0;
