@@ -82,6 +82,7 @@ _sig("alva_frontend_track_ahead", [_vp, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _
 _sig("alva_frontend_results", [_vp] + [C.POINTER(_vp)] * 6)
 _sig("alva_frontend_sync", [_vp])
 _sig("alva_frontend_run_many", [_vp, _i, _i, _i, _vp, _i, _sz, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp])
+_sig("alva_fbklt_track_batch", [_vp, _vp, _vp, _i, _i, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _i])
 _sig("alva_track_batch_create", [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)])
 _sig("alva_track_batch_destroy", [_vp], None)
 _sig("alva_track_batch_step", [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp])
@@ -543,6 +544,18 @@ class Frontend:
         return {"tracked": view(ptrs[0], (n, 2), torch.float32), "status": view(ptrs[1], (n,), torch.uint8),
                 "keypoints": view(ptrs[2], (m, 6), torch.float32), "descriptors": view(ptrs[3], (m, 32), torch.uint8),
                 "match_idx": view(ptrs[4], (m,), torch.int32), "match_dist": view(ptrs[5], (m,), torch.int32)}
+
+
+def fbklt_track_batch(ctx: "Context", prevs, currs, pts, priors, num_levels=3, lanes=5, err_thresh=30.0, fb_dist=0.5, max_iters=30, eps=0.01):
+    """alva_fbklt_track_batch: returns (list of tracked [n,2] f32 tensors, list of status [n] u8 tensors); priors are not modified."""
+    n = len(prevs)
+    outs = [p.clone() for p in priors]
+    sts = [torch.empty((p.shape[0],), dtype=torch.uint8, device=p.device) for p in pts]
+    arr = lambda v: (_vp * n)(*v)
+    check(lib.alva_fbklt_track_batch(ctx.h, arr([p.h for p in prevs]), arr([p.h for p in currs]), n, num_levels, err_thresh, fb_dist, max_iters, eps,
+                                     arr([_ptr(p) for p in pts]), arr([_ptr(o) for o in outs]), arr([_ptr(s_) for s_ in sts]),
+                                     (_i * n)(*[p.shape[0] for p in pts]), lanes))
+    return outs, sts
 
 
 class TrackBatch:

@@ -912,3 +912,23 @@ int alva_fbklt_track_batch_enqueue(alva_ctx *ctx, const void *d_items, int count
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }
+
+// fbKltTracking of `count` independent (previous, current) pyramid pairs in ONE launch -- the batched form of alva_fbklt_track
+// (pyramids may differ in size; d_prior[c] in/out as there).  Enqueue-only; the argument blocks are staged from pageable memory.
+extern "C" int alva_fbklt_track_batch(alva_ctx *ctx, const alva_pyramid *const *prev, const alva_pyramid *const *curr, int count, int num_levels,
+                                      float err_thresh, float fb_dist, int max_iters, float eps, const float *const *d_pts,
+                                      float *const *d_prior, uint8_t *const *d_status, const int *n, int lanes_per_keypoint) {
+    ALVA_ARG(ctx && prev && curr && count > 0 && count <= 65535 && d_pts && d_prior && d_status && n);
+    std::vector<KltBatchItem> items((size_t) count);
+    int n_max = 0;
+    for (int c = 0; c < count; c++) {
+        int rc = alva_klt_batch_item_fill(&items[(size_t) c], prev[c], curr[c], d_pts[c], d_prior[c], d_prior[c], d_status[c], n[c]);
+        if (rc) return rc;
+        n_max = n[c] > n_max ? n[c] : n_max;
+    }
+    void *dev = nullptr;
+    int rc = alva_ctx_scratch(ctx, 11, items.size() * sizeof(KltBatchItem), &dev);
+    if (rc) return rc;
+    ALVA_HIP(hipMemcpyAsync(dev, items.data(), items.size() * sizeof(KltBatchItem), hipMemcpyHostToDevice, ctx->stream));
+    return alva_fbklt_track_batch_enqueue(ctx, dev, count, n_max, num_levels, err_thresh, fb_dist, max_iters, eps, lanes_per_keypoint);
+}

@@ -348,6 +348,16 @@ int alva_frontend_run_many(alva_frontend **fes, int n_streams, int steps, int wa
                            const double *const *d_bearings, const double *const *d_uv, const double *const *d_wpts,
                            int n_corr, float fx, float fy, float cx, float cy, double *h_seconds, int *h_accepted);
 
+/* a4 for many cameras: FeatureTracker::fbKltTracking (src/slam/src/feature_tracker.cpp:5-111) of `count` independent
+ * (previous, current) pyramid pairs in ONE launch; arguments per pair as alva_fbklt_track (d_prior[c] in/out), pyramids may differ
+ * in size.  lanes_per_keypoint selects the wave layout: 5 (a lane per column pair of the 9x9 window, 12 keypoints per wave: the
+ * fastest for large batches), 8, 16, 32 or 64 (alva_fbklt_track's layout); results are bit-identical for all of them.
+ * Enqueue-only, like alva_fbklt_track. */
+int alva_fbklt_track_batch(alva_ctx *ctx, const alva_pyramid *const *prev, const alva_pyramid *const *curr, int count,
+                           int num_levels, float err_thresh, float fb_dist, int max_iters, float eps,
+                           const float *const *d_pts, float *const *d_prior, uint8_t *const *d_status, const int *n,
+                           int lanes_per_keypoint);
+
 /* ---- a1 for a rig: VisualFrontend::trackMono of B lock-step cameras, one launch per stage for all of them ----------------
  * The per-frame path of src/slam/src/visual_frontend.cpp:83-150 -- preprocessImage (:672-698), kltTracking (:152-243),
  * computePose (:245-417); the detector is the keyframe branch's, not this path's -- for `cameras` independent cameras that deliver
@@ -365,8 +375,7 @@ int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const *d_rgba, si
                           int *h_pose_status);
 /* device-resident kltTracking result of one camera from the last step: [n_pts][2] positions, [n_pts] status */
 int alva_track_batch_results(alva_track_batch *tb, int cam, const float **d_tracked, const uint8_t **d_track_status);
-/* Tuning knob of the tracking launch: lanes of a wavefront per keypoint, 32 (default: two keypoints per wave, the fastest on
- * MI355X), 16 or 64 (the single-camera kernel's layout).  Results are identical for all three.  The environment variable
+/* Tuning knob of the tracking launch: lanes of a wavefront per keypoint, 5 (default, see alva_fbklt_track_batch), 8, 16, 32 or 64 (the single-camera kernel's layout).  Results are identical for all three.  The environment variable
  * ALVA_KLT_BATCH_LANES sets the default at creation. */
 int alva_track_batch_set_klt_lanes(alva_track_batch *tb, int lanes);
 /* steps done, and how often a camera had to be re-solved by the single-camera call because the first 128 samples of its P3P

@@ -89,3 +89,22 @@ def test_klt_large_motion_restages_the_search_tile(ctx, dx, dy, levels, seed):
     assert np.array_equal(fs.cpu().numpy(), ofs) and np.array_equal(pr.cpu().numpy().view(np.uint32), op.view(np.uint32))
     moved = np.abs(on[os_.astype(bool)] - pts[os_.astype(bool)]).max()
     assert moved > 4.0        # the windows really travelled
+
+
+@pytest.mark.parametrize("lanes", [5, 8, 16, 32, 64])
+def test_fbklt_batch_bitwise(ctx, lanes):
+    """alva_fbklt_track_batch: three image pairs of two sizes in ONE launch, every wave layout, each pair bit-identical to the oracle
+    (and the compiled reference where present).  The 2120-point case contains taps whose fourth bilinear weight rounds to -1."""
+    import torch
+    from alvaar_amd import capi
+    cases = [klt_case(640, 480, 2120, 5), klt_case(640, 480, 401, 6), klt_case(1280, 720, 4080, 7)]
+    pyrs = [_pyrs(ctx, c[0], c[1]) for c in cases]
+    outs, sts = capi.fbklt_track_batch(ctx, [p[0] for p in pyrs], [p[1] for p in pyrs], [torch.from_numpy(c[2]).cuda() for c in cases],
+                                       [torch.from_numpy(c[3]).cuda() for c in cases], 3, lanes)
+    ctx.sync()
+    for (prev, curr, pts, init), pr, st in zip(cases, outs, sts):
+        pr, st = pr.cpu().numpy(), st.cpu().numpy()
+        for name, O in [("orc", Orc)] + ([("ref", Ref)] if ref_available() else []):
+            op, os_ = O.fbklt(prev, curr, pts, init, 3)
+            assert np.array_equal(st, os_), name
+            assert np.array_equal(pr.view(np.uint32), op.view(np.uint32)), name
