@@ -252,6 +252,44 @@ struct P3pArgs {
     uint8_t *inlier;
 };
 
+// ---- 1. hypothesis: Kneip P3P on one sample, on 4 lanes (one per candidate solution); the other lanes of the wave mirror them.
+// Returns whether a model was found; lanes 0..3 of the group have written it to A.models / A.valid.
+__device__ __forceinline__ int p3p_hypothesis(const P3pArgs &A, const int h, const int which, const bool writer, double *s_m) {
+    const double *bv = A.bv, *wpt = A.wpt;
+    const int *smp = A.samples + 4 * h;
+    const int i0 = smp[0], i1 = smp[1], i2 = smp[2], i3 = smp[3];
+    V3 f[3] = {ld3(bv + 3 * (size_t) i0), ld3(bv + 3 * (size_t) i1), ld3(bv + 3 * (size_t) i2)};
+    V3 p[3] = {ld3(wpt + 3 * (size_t) i0), ld3(wpt + 3 * (size_t) i1), ld3(wpt + 3 * (size_t) i2)};
+    double sol[12];
+    const int ns = p3p_kneip(f, p, which, sol);
+    // the solution closest to the 4th correspondence, first one on ties (strict <, initial 1e6)
+    double sc = ns ? p3p_score(sol, ld3(wpt + 3 * (size_t) i3), ld3(bv + 3 * (size_t) i3)) : 2000000.0;
+    if (!(sc < 1000000.0)) sc = 2000000.0;  // NaN or too large: never selected
+    double best = sc;
+    int bi = which;
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+        const double o = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (o < best || (o == best && oi < bi)) {
+            best = o;
+            bi = oi;
+        }
+    }
+    const int ok = best < 1000000.0;
+    if (writer && ok && bi == which) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            if (s_m) s_m[k] = sol[k];
+            A.models[12 * (size_t) h + k] = sol[k];
+        }
+    }
+    if (writer && which == 0) A.valid[h] = ok;
+    return ok;
+}
+
+// PRE = the hypotheses were computed by k_p3p_hyp_batch (models / valid already in memory)
+template <bool PRE>
 __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
     extern __shared__ unsigned long long s_keys[];
     __shared__ unsigned int s_hist[256];
@@ -261,41 +299,12 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
     __shared__ double s_m[12];
     const int n = A.n;
     const double *bv = A.bv, *wpt = A.wpt;
-    // ---- 1. hypothesis -------------------------------------------------------------------------------------------
-    if (threadIdx.x < 64) {
-        const int which = threadIdx.x & 3;  // only lanes 0..3 matter; the rest of the wave mirrors them
-        const int *smp = A.samples + 4 * h;
-        const int i0 = smp[0], i1 = smp[1], i2 = smp[2], i3 = smp[3];
-        V3 f[3] = {ld3(bv + 3 * (size_t) i0), ld3(bv + 3 * (size_t) i1), ld3(bv + 3 * (size_t) i2)};
-        V3 p[3] = {ld3(wpt + 3 * (size_t) i0), ld3(wpt + 3 * (size_t) i1), ld3(wpt + 3 * (size_t) i2)};
-        double sol[12];
-        const int ns = p3p_kneip(f, p, which, sol);
-        // the solution closest to the 4th correspondence, first one on ties (strict <, initial 1e6)
-        double sc = ns ? p3p_score(sol, ld3(wpt + 3 * (size_t) i3), ld3(bv + 3 * (size_t) i3)) : 2000000.0;
-        if (!(sc < 1000000.0)) sc = 2000000.0;  // NaN or too large: never selected
-        double best = sc;
-        int bi = which;
-#pragma unroll
-        for (int off = 1; off < 4; off <<= 1) {
-            const double o = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off);
-            if (o < best || (o == best && oi < bi)) {
-                best = o;
-                bi = oi;
-            }
-        }
-        const int ok = best < 1000000.0;
-        if (threadIdx.x < 4 && ok && bi == which) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                s_m[k] = sol[k];
-                A.models[12 * (size_t) h + k] = sol[k];
-            }
-        }
-        if (threadIdx.x == 0) {
-            s_valid = ok;
-            A.valid[h] = ok;
-        }
+    if (PRE) {
+        if (threadIdx.x < 12) s_m[threadIdx.x] = A.models[12 * (size_t) h + threadIdx.x];
+        if (threadIdx.x == 0) s_valid = A.valid[h];
+    } else if (threadIdx.x < 64) {
+        const int ok = p3p_hypothesis(A, h, threadIdx.x & 3, threadIdx.x < 4, s_m);
+        if (threadIdx.x == 0) s_valid = ok;
     }
     __syncthreads();
     // ---- 2. LMedS penalty ----------------------------------------------------------------------------------------
@@ -421,14 +430,23 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
     if (threadIdx.x == 0) out->n_inliers = s_k;
 }
 
-__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) { p3p_block(A, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) { p3p_block<false>(A, blockIdx.x); }
 
 // B independent problems in one launch: blockIdx.y = problem (camera), each with its own correspondences, sample list, scratch
 // and arrival counter.  Dynamic LDS is sized for the largest problem.
+// In a batch the Kneip solves get their own launch, 16 hypotheses per wave: inside k_p3p they occupy one wave of the four while the
+// other three wait, and their register need (120 VGPRs) would cap the scoring kernel at four workgroups per CU.
+__global__ void __launch_bounds__(256) k_p3p_hyp_batch(const P3pArgs *__restrict__ args) {
+    const P3pArgs A = args[blockIdx.y];
+    const int h = (int) (blockIdx.x * 64 + (threadIdx.x >> 2));
+    if (h >= A.H) return;  // whole groups of 4 lanes leave together (the xor shuffles stay inside a group)
+    (void) p3p_hypothesis(A, h, threadIdx.x & 3, true, nullptr);
+}
+
 __global__ void __launch_bounds__(256) k_p3p_batch(const P3pArgs *__restrict__ args) {
     const P3pArgs A = args[blockIdx.y];
     if ((int) blockIdx.x >= A.H) return;
-    p3p_block(A, blockIdx.x);
+    p3p_block<true>(A, blockIdx.x);
 }
 
 // SampleConsensusProblem<M>: rng_dist_ = uniform_int_distribution<>(0, INT_MAX), rng_alg_ = std::mt19937
@@ -582,6 +600,7 @@ int alva_p3p_batch_item_fill(void *dst, const double *d_bearings, const double *
 
 int alva_p3p_batch_enqueue(alva_ctx *ctx, const void *d_items, int count, int H_max, int n_max) {
     ALVA_ARG(ctx && d_items && count > 0 && count <= 65535 && H_max > 0 && n_max >= 4 && n_max <= 7168);
+    hipLaunchKernelGGL(k_p3p_hyp_batch, dim3(alva_divup(H_max, 64), count), dim3(256), 0, ctx->stream, (const P3pArgs *) d_items);
     hipLaunchKernelGGL(k_p3p_batch, dim3(H_max, count), dim3(256), (size_t) n_max * sizeof(double), ctx->stream, (const P3pArgs *) d_items);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
