@@ -197,19 +197,28 @@ __device__ int p3p_kneip(const V3 f[3], const V3 p[3], int which, double sol[12]
 //      only ever reads distances[mid-1] and distances[mid]): 8 passes of a 256-bin LDS histogram
 //   3. the workgroup that finishes LAST (device-scope counter) picks the best of the first max_iters valid hypotheses
 //      and classifies the inliers of the winner (Lmeds.hpp:150-190)
-__device__ unsigned long long radix_select(const unsigned long long *keys, int n, int k, unsigned int *hist, int *s_bin, int *s_k) {
+// k-th smallest of n 64-bit keys in LDS, 256 threads.  Most-significant-digit radix select, 8 bits per pass, with two histogram
+// buffers (the next pass's buffer is cleared while this pass counts: two barriers per pass instead of four) and an early exit: as
+// soon as the selected bin holds ONE key, that key is the answer and one scan fetches it (squared distances of a model differ
+// within their first 3-4 digits, so 3-4 passes instead of 8).  The barriers of this routine were the fixed cost of a workgroup:
+// with thousands of workgroups in flight (a batch of cameras) the kernel time did not depend on n.
+__device__ unsigned long long radix_select(const unsigned long long *keys, int n, int k, unsigned int *hist /* [512] */, int *s_bin, int *s_k,
+                                           int *s_binc, unsigned long long *s_key) {
     unsigned long long prefix = 0, mask = 0;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        hist[threadIdx.x] = 0;  // 256 threads == 256 bins
-        __syncthreads();
+    hist[threadIdx.x] = 0;  // 256 threads == 256 bins
+    __syncthreads();
+    int pass = 0;
+    for (int shift = 56; shift >= 0; shift -= 8, pass++) {
+        unsigned int *h = hist + 256 * (pass & 1);
+        hist[256 * ((pass + 1) & 1) + threadIdx.x] = 0;  // last read two barriers ago
         for (int i = threadIdx.x; i < n; i += 256) {
             const unsigned long long key = keys[i];
-            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned) (key >> shift) & 255u], 1u);
+            if ((key & mask) == prefix) atomicAdd(&h[(unsigned) (key >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
-            const unsigned c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+            const unsigned c0 = h[4 * l], c1 = h[4 * l + 1], c2 = h[4 * l + 2], c3 = h[4 * l + 3];
             const unsigned tot = c0 + c1 + c2 + c3;
             unsigned incl = tot;
 #pragma unroll
@@ -219,21 +228,32 @@ __device__ unsigned long long radix_select(const unsigned long long *keys, int n
             }
             const unsigned excl = incl - tot;
             if ((unsigned) k >= excl && (unsigned) k < incl) {
-                unsigned r = (unsigned) k - excl;
-                int b;
-                if (r < c0) b = 0;
-                else if (r < c0 + c1) { b = 1; r -= c0; }
-                else if (r < c0 + c1 + c2) { b = 2; r -= c0 + c1; }
-                else { b = 3; r -= c0 + c1 + c2; }
+                unsigned r = (unsigned) k - excl, c = c0;
+                int b = 0;
+                if (r >= c0) {
+                    r -= c0; b = 1; c = c1;
+                    if (r >= c1) {
+                        r -= c1; b = 2; c = c2;
+                        if (r >= c2) { r -= c2; b = 3; c = c3; }
+                    }
+                }
                 *s_bin = 4 * l + b;
                 *s_k = (int) r;
+                *s_binc = (int) c;
             }
         }
         __syncthreads();
         prefix |= (unsigned long long) (unsigned) *s_bin << shift;
         mask |= 0xffull << shift;
         k = *s_k;
-        __syncthreads();
+        if (*s_binc == 1 && shift > 0) {  // workgroup-uniform
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const unsigned long long key = keys[i];
+                if ((key & mask) == prefix) *s_key = key;  // exactly one key matches
+            }
+            __syncthreads();
+            return *s_key;
+        }
     }
     return prefix;
 }
@@ -288,28 +308,32 @@ __device__ __forceinline__ int p3p_hypothesis(const P3pArgs &A, const int h, con
     return ok;
 }
 
-// PRE = the hypotheses were computed by k_p3p_hyp_batch (models / valid already in memory)
-template <bool PRE>
+// MODE 0: the whole LMedS in one launch (hypothesis, penalty, and the workgroup that finishes last selects).
+// MODE 1 / 2: the batch's middle and last launch -- penalty of hypothesis h from the model k_p3p_hyp_batch left in memory | selection.
+// Between launches the kernel boundary orders the memory; inside one launch every workgroup pays a device-scope fence (an L2
+// write-back on a multi-XCD part) before it signals -- 8 192 of them per step for 64 cameras.
+template <int MODE>
 __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
     extern __shared__ unsigned long long s_keys[];
-    __shared__ unsigned int s_hist[256];
-    __shared__ int s_bin, s_k, s_valid, s_last;
+    __shared__ unsigned int s_hist[512];
+    __shared__ int s_bin, s_k, s_binc, s_valid, s_last;
+    __shared__ unsigned long long s_key;
     __shared__ unsigned long long s_min[256];
     __shared__ unsigned int s_cnt[256];
     __shared__ double s_m[12];
     const int n = A.n;
     const double *bv = A.bv, *wpt = A.wpt;
-    if (PRE) {
+    if (MODE == 1) {
         if (threadIdx.x < 12) s_m[threadIdx.x] = A.models[12 * (size_t) h + threadIdx.x];
         if (threadIdx.x == 0) s_valid = A.valid[h];
-    } else if (threadIdx.x < 64) {
+    } else if (MODE == 0 && threadIdx.x < 64) {
         const int ok = p3p_hypothesis(A, h, threadIdx.x & 3, threadIdx.x < 4, s_m);
         if (threadIdx.x == 0) s_valid = ok;
     }
     __syncthreads();
     // ---- 2. LMedS penalty ----------------------------------------------------------------------------------------
     double pen = INFINITY;
-    if (s_valid) {
+    if (MODE != 2 && s_valid) {
         for (int i = threadIdx.x; i < n; i += 256) {
             double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
             if (d < 0) d = 0;
@@ -319,7 +343,7 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
         }
         __syncthreads();
         const int mid = n / 2;
-        const unsigned long long kmid = radix_select(s_keys, n, mid, s_hist, &s_bin, &s_k);
+        const unsigned long long kmid = radix_select(s_keys, n, mid, s_hist, &s_bin, &s_k, &s_binc, &s_key);
         if (n % 2 != 0) {
             pen = __longlong_as_double((long long) kmid);
         } else {
@@ -349,15 +373,21 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
         }
     }
     // ---- 3. last workgroup selects -------------------------------------------------------------------------------
-    if (threadIdx.x == 0) {
-        A.penalty[h] = pen;
-        __threadfence();
-        s_last = atomicAdd(A.counter, 1) == A.H - 1;
+    if (MODE == 1) {
+        if (threadIdx.x == 0) A.penalty[h] = pen;
+        return;
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) *A.counter = 0;  // ready for the next launch (stream order)
+    if (MODE == 0) {
+        if (threadIdx.x == 0) {
+            A.penalty[h] = pen;
+            __threadfence();
+            s_last = atomicAdd(A.counter, 1) == A.H - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        if (threadIdx.x == 0) *A.counter = 0;  // ready for the next launch (stream order)
+    }
     const volatile int *vvalid = A.valid;
     const volatile double *vpen = A.penalty, *vmodels = A.models;
     // first max_iters VALID hypotheses in draw order (failed models do not count as iterations, Lmeds.hpp:88-92);
@@ -430,7 +460,7 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h) {
     if (threadIdx.x == 0) out->n_inliers = s_k;
 }
 
-__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) { p3p_block<false>(A, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_p3p(P3pArgs A) { p3p_block<0>(A, blockIdx.x); }
 
 // B independent problems in one launch: blockIdx.y = problem (camera), each with its own correspondences, sample list, scratch
 // and arrival counter.  Dynamic LDS is sized for the largest problem.
@@ -446,7 +476,12 @@ __global__ void __launch_bounds__(256) k_p3p_hyp_batch(const P3pArgs *__restrict
 __global__ void __launch_bounds__(256) k_p3p_batch(const P3pArgs *__restrict__ args) {
     const P3pArgs A = args[blockIdx.y];
     if ((int) blockIdx.x >= A.H) return;
-    p3p_block<true>(A, blockIdx.x);
+    p3p_block<1>(A, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) k_p3p_select_batch(const P3pArgs *__restrict__ args) {
+    const P3pArgs A = args[blockIdx.x];
+    p3p_block<2>(A, 0);
 }
 
 // SampleConsensusProblem<M>: rng_dist_ = uniform_int_distribution<>(0, INT_MAX), rng_alg_ = std::mt19937
@@ -602,6 +637,7 @@ int alva_p3p_batch_enqueue(alva_ctx *ctx, const void *d_items, int count, int H_
     ALVA_ARG(ctx && d_items && count > 0 && count <= 65535 && H_max > 0 && n_max >= 4 && n_max <= 7168);
     hipLaunchKernelGGL(k_p3p_hyp_batch, dim3(alva_divup(H_max, 64), count), dim3(256), 0, ctx->stream, (const P3pArgs *) d_items);
     hipLaunchKernelGGL(k_p3p_batch, dim3(H_max, count), dim3(256), (size_t) n_max * sizeof(double), ctx->stream, (const P3pArgs *) d_items);
+    hipLaunchKernelGGL(k_p3p_select_batch, dim3(count), dim3(256), 0, ctx->stream, (const P3pArgs *) d_items);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }
