@@ -595,6 +595,17 @@ class TrackBatch:
                                         self.poses.ctypes.data, self.status.ctypes.data))
         return self.status, self.poses
 
+    def frame_table(self, rgbas):
+        """pointer table of one set of B frames for step_table() (build once per resident frame set: a Python list comprehension
+        over 64 tensors costs more than the whole GPU step)"""
+        return (_vp * self.B)(*[_ptr(r) for r in rgbas]), rgbas[0].stride(0), rgbas
+
+    def step_table(self, table, K):
+        a_pts, a_np, a_bv, a_uv, a_wp, a_nc = self._args
+        check(lib.alva_track_batch_step(self.h, table[0], table[1], a_pts, a_np, a_bv, a_uv, a_wp, a_nc, K[0], K[1], K[2], K[3],
+                                        self.poses.ctypes.data, self.status.ctypes.data))
+        return self.status, self.poses
+
     def results(self, cam: int):
         """(tracked [n,2] f32, status [n] u8) of one camera: torch views of device memory, valid until the next step"""
         p, q = _vp(), _vp()

@@ -313,12 +313,13 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
     tb = alvaar_amd.TrackBatch(device, W, H, cameras, NKP, NKP)
     tb.bind([pts[c % nsrc] for c in range(cameras)], [bv[c % nsrc] for c in range(cameras)], [uv[c % nsrc] for c in range(cameras)],
             [wp[c % nsrc] for c in range(cameras)])
+    tables = [tb.frame_table([f[r] for f in frames]) for r in range(RING)]   # the resident frames' pointer tables, built once
     k = 0
 
     def step():
         nonlocal k
         k += 1
-        return tb.step([f[k % RING] for f in frames], K)
+        return tb.step_table(tables[k % RING], K)
     for _ in range(3):
         st, _ = step()
     torch.cuda.synchronize(dev)
