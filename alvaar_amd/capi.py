@@ -89,6 +89,13 @@ _sig("alva_track_batch_step", [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _f, 
 _sig("alva_track_batch_results", [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)])
 _sig("alva_track_batch_ctx", [_vp], _vp)
 _sig("alva_track_batch_stats", [_vp, _vp, _vp])
+_sig("alva_track_batch_enable_detector", [_vp, _i])
+_sig("alva_track_batch_step_detect", [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp])
+_sig("alva_track_batch_detections", [_vp, _i] + [C.POINTER(_vp)] * 4)
+_sig("alva_orb_detect_and_compute_batch", [_vp, _vp, _i, _vp, _sz, _vp, _vp, _i])
+_sig("alva_orb_collect_batch", [_vp, _vp, _i, _vp])
+_sig("alva_orb_device_count", [_vp], _vp)
+_sig("alva_bf_match_hamming_batch", [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i])
 _sig("alva_track_batch_set_klt_lanes", [_vp, _i])
 _sig("alva_compute_pose_enqueue", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f])
 _sig("alva_compute_pose_collect", [_vp, _vp, _vp, _vp, _vp])
@@ -591,9 +598,24 @@ class TrackBatch:
         """rgbas: list of B [H,W,4] u8 cuda tensors (same pitch).  Returns (status[B], poses[B,7]) -- views, overwritten by the next step."""
         a_pts, a_np, a_bv, a_uv, a_wp, a_nc = self._args
         fr = (_vp * self.B)(*[_ptr(r) for r in rgbas])
-        check(lib.alva_track_batch_step(self.h, fr, rgbas[0].stride(0), a_pts, a_np, a_bv, a_uv, a_wp, a_nc, K[0], K[1], K[2], K[3],
-                                        self.poses.ctypes.data, self.status.ctypes.data))
+        check(lib.alva_track_batch_step_detect(self.h, fr, rgbas[0].stride(0), a_pts, a_np, a_bv, a_uv, a_wp, a_nc, K[0], K[1], K[2], K[3],
+                                               self.poses.ctypes.data, self.status.ctypes.data,
+                                               self.nkp.ctypes.data if getattr(self, "nkp", None) is not None else None))
         return self.status, self.poses
+
+    def enable_detector(self, orb_features: int = 2000):
+        import numpy as np
+        check(lib.alva_track_batch_enable_detector(self.h, orb_features))
+        self.nkp = np.zeros(self.B, np.int32)
+        self.cap = 4 * orb_features + 1024
+
+    def detections(self, cam: int):
+        """dict of torch views of one camera's detector results of the last step (keypoints [n,6], descriptors [n,32], match idx/dist [n])"""
+        ptrs = [_vp() for _ in range(4)]
+        check(lib.alva_track_batch_detections(self.h, cam, *[C.byref(p) for p in ptrs]))
+        n = int(self.nkp[cam])
+        return {"keypoints": _dev_view(ptrs[0], (n, 6), torch.float32, self.device), "descriptors": _dev_view(ptrs[1], (n, 32), torch.uint8, self.device),
+                "match_idx": _dev_view(ptrs[2], (n,), torch.int32, self.device), "match_dist": _dev_view(ptrs[3], (n,), torch.int32, self.device)}
 
     def frame_table(self, rgbas):
         """pointer table of one set of B frames for step_table() (build once per resident frame set: a Python list comprehension
@@ -602,8 +624,9 @@ class TrackBatch:
 
     def step_table(self, table, K):
         a_pts, a_np, a_bv, a_uv, a_wp, a_nc = self._args
-        check(lib.alva_track_batch_step(self.h, table[0], table[1], a_pts, a_np, a_bv, a_uv, a_wp, a_nc, K[0], K[1], K[2], K[3],
-                                        self.poses.ctypes.data, self.status.ctypes.data))
+        check(lib.alva_track_batch_step_detect(self.h, table[0], table[1], a_pts, a_np, a_bv, a_uv, a_wp, a_nc, K[0], K[1], K[2], K[3],
+                                               self.poses.ctypes.data, self.status.ctypes.data,
+                                               self.nkp.ctypes.data if getattr(self, "nkp", None) is not None else None))
         return self.status, self.poses
 
     def results(self, cam: int):

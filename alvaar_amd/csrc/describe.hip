@@ -127,6 +127,38 @@ int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
     return ALVA_OK;
 }
 
+// ---- the same for several cameras: blockIdx.z = camera, one BlurBatch per camera in device memory ------------------------------
+__global__ void __launch_bounds__(256) k_blur7_multi(const BlurBatch *__restrict__ Bs) {
+    const BlurBatch &B = Bs[blockIdx.z];
+    const int l = blockIdx.y;
+    const int tilesX = (B.w[l] + BT_W - 1) / BT_W, tilesY = (B.h[l] + BT_H - 1) / BT_H;
+    if ((int) blockIdx.x >= tilesX * tilesY) return;
+    blur7_tile(B.src[l], (size_t) B.pitch[l], B.w[l], B.h[l], B.dst[l], (size_t) B.pitch[l], blockIdx.x % tilesX, blockIdx.x / tilesX);
+}
+
+size_t alva_blur7_batch_size() { return sizeof(BlurBatch); }
+
+int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h, const int *pitch) {
+    BlurBatch B{};
+    int maxTiles = 0;
+    for (int l = 0; l < n && l < 12; l++) {
+        B.src[l] = src[l];
+        B.dst[l] = dst[l];
+        B.w[l] = w[l];
+        B.h[l] = h[l];
+        B.pitch[l] = pitch[l];
+        maxTiles = std::max(maxTiles, alva_divup(w[l], BT_W) * alva_divup(h[l], BT_H));
+    }
+    memcpy(out, &B, sizeof(B));
+    return maxTiles;
+}
+
+int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int max_tiles) {
+    hipLaunchKernelGGL(k_blur7_multi, dim3(max_tiles, n_levels, count), dim3(256), 0, ctx->stream, (const BlurBatch *) d_batches);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
 int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h,
                             const int *pitch) {
     BlurBatch B{};

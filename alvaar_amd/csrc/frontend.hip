@@ -24,7 +24,6 @@ int alva_fbklt_track_to(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyra
 
 int alva_bf_match_hamming_devcount(alva_ctx *ctx, const uint8_t *d_query, const int *d_n_query, int cap_query, const uint8_t *d_train,
                                    const int *d_n_train, int cap_train, int *d_idx, int *d_dist);
-const int *alva_orb_device_count(const alva_orb *orb);
 
 struct alva_frontend {
     int device = 0, width = 0, height = 0, n_track = 0, cap = 0;

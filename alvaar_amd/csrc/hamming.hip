@@ -12,6 +12,7 @@
 // each writes one packed key (dist << 20 | train_idx) per query, and a second tiny kernel takes the
 // min over chunks -- min of the packed key is exactly "smallest distance, then lowest index".
 #include "common.hpp"
+#include <algorithm>
 
 namespace {
 
@@ -80,7 +81,120 @@ __global__ void __launch_bounds__(256) k_bf_final(const uint32_t *__restrict__ p
     }
 }
 
+// ---- several independent matches in one pair of launches (blockIdx.z = match) ------------------------------------------------
+// The query count of a match is only known on the device (the detector has just produced it), so the query blocks are covered by a
+// grid-stride loop instead of a grid sized for the capacity (tens of thousands of empty workgroups per camera otherwise).
+struct BfItem {
+    const uint4 *q, *t;
+    const int *dnq;      // device: number of queries
+    uint32_t *partial;   // [chunks][nq_pad]
+    int *idx, *dist;
+    int nq_cap, nt, nq_pad, chunks;
+};
+
+__global__ void __launch_bounds__(QT) k_bf_partial_b(const BfItem *__restrict__ items) {
+    __shared__ uint4 s_t[TC * 2];
+    const BfItem it = items[blockIdx.z];
+    const int nt = it.nt, t0 = blockIdx.y * TC;
+    if (t0 >= nt) return;  // also: a match without a train set (its count pointer may be null)
+    const int nq = min(it.nq_cap, *it.dnq);
+    const int lane = threadIdx.x;
+    const int tcount = min(TC, nt - t0);
+    if (lane < tcount) {
+        s_t[2 * lane] = it.t[2 * (size_t) (t0 + lane)];
+        s_t[2 * lane + 1] = it.t[2 * (size_t) (t0 + lane) + 1];
+    }
+    __syncthreads();
+    for (int qb = blockIdx.x; qb * QT < nq; qb += gridDim.x) {
+        const int qi = qb * QT + lane;
+        uint4 qa = make_uint4(0, 0, 0, 0), qb4 = qa;
+        if (qi < nq) {
+            qa = it.q[2 * (size_t) qi];
+            qb4 = it.q[2 * (size_t) qi + 1];
+        }
+        uint32_t best = 0xffffffffu;
+        for (int j = 0; j < tcount; j++) {
+            const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
+            uint32_t d = __popc(qa.x ^ ta.x);
+            d += __popc(qa.y ^ ta.y);
+            d += __popc(qa.z ^ ta.z);
+            d += __popc(qa.w ^ ta.w);
+            d += __popc(qb4.x ^ tb.x);
+            d += __popc(qb4.y ^ tb.y);
+            d += __popc(qb4.z ^ tb.z);
+            d += __popc(qb4.w ^ tb.w);
+            const uint32_t key = (d << 20) | (uint32_t) (t0 + j);
+            best = min(best, key);
+        }
+        if (qi < nq) it.partial[(size_t) blockIdx.y * it.nq_pad + qi] = best;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bf_final_b(const BfItem *__restrict__ items) {
+    const BfItem it = items[blockIdx.z];
+    if (it.nt == 0) return;
+    const int nq = min(it.nq_cap, *it.dnq);
+    for (int qi = blockIdx.x * 256 + threadIdx.x; qi < nq; qi += gridDim.x * 256) {
+        uint32_t best = 0xffffffffu;
+        for (int c = 0; c < it.chunks; c++) best = min(best, it.partial[(size_t) c * it.nq_pad + qi]);
+        if (best == 0xffffffffu) {
+            it.idx[qi] = -1;
+            it.dist[qi] = -1;
+        } else {
+            it.idx[qi] = (int) (best & 0xfffffu);
+            it.dist[qi] = (int) (best >> 20);
+        }
+    }
+}
+
 }  // namespace
+
+// `count` independent brute-force matches (cv::BFMatcher(NORM_HAMMING), batch_distance.cpp:199-251) in one pair of launches.
+// Match c: queries d_query[c] (their number is read from device memory, *d_n_query[c], clamped to cap_query), train set d_train[c]
+// with n_train[c] rows known to the host (0 = skip the match); rows of d_idx[c] / d_dist[c] beyond the query count stay untouched.
+// expected_queries sizes the grid (more queries are covered by a loop).  Enqueue-only.
+extern "C" int alva_bf_match_hamming_batch(alva_ctx *ctx, int count, const uint8_t *const *d_query, const int *const *d_n_query, int cap_query,
+                                           const uint8_t *const *d_train, const int *n_train, int *const *d_idx, int *const *d_dist,
+                                           int expected_queries) {
+    ALVA_ARG(ctx && count > 0 && count <= 65535 && d_query && d_n_query && d_train && n_train && d_idx && d_dist && cap_query > 0);
+    const int nq_pad = alva_divup(cap_query, QT) * QT;
+    int max_chunks = 0;
+    size_t partial_words = 0;
+    std::vector<BfItem> items((size_t) count);
+    for (int c = 0; c < count; c++) {
+        ALVA_ARG(n_train[c] >= 0 && n_train[c] < (1 << 20));
+        const int chunks = alva_divup(n_train[c], TC);
+        max_chunks = chunks > max_chunks ? chunks : max_chunks;
+        partial_words += (size_t) chunks * nq_pad;
+    }
+    if (max_chunks == 0) return ALVA_OK;
+    const size_t off_partial = (items.size() * sizeof(BfItem) + 255) / 256 * 256;
+    uint8_t *dev = nullptr;
+    int rc = alva_ctx_scratch(ctx, 0, off_partial + partial_words * sizeof(uint32_t), (void **) &dev);
+    if (rc) return rc;
+    uint32_t *partial = (uint32_t *) (dev + off_partial);
+    for (int c = 0; c < count; c++) {
+        BfItem &it = items[(size_t) c];
+        it.nt = n_train[c];
+        it.chunks = alva_divup(n_train[c], TC);
+        if (it.nt > 0) ALVA_ARG(d_query[c] && d_train[c] && d_n_query[c] && d_idx[c] && d_dist[c] && ((uintptr_t) d_query[c] % 16) == 0 && ((uintptr_t) d_train[c] % 16) == 0);
+        it.q = (const uint4 *) d_query[c];
+        it.t = (const uint4 *) d_train[c];
+        it.dnq = d_n_query[c];
+        it.partial = partial;
+        it.idx = d_idx[c];
+        it.dist = d_dist[c];
+        it.nq_cap = it.nt > 0 ? cap_query : 0;
+        it.nq_pad = nq_pad;
+        partial += (size_t) it.chunks * nq_pad;
+    }
+    ALVA_HIP(hipMemcpyAsync(dev, items.data(), items.size() * sizeof(BfItem), hipMemcpyHostToDevice, ctx->stream));
+    const int qblocks = std::max(1, std::min(alva_divup(cap_query, QT), alva_divup(std::max(expected_queries, 1), QT)));
+    hipLaunchKernelGGL(k_bf_partial_b, dim3(qblocks, max_chunks, count), dim3(QT), 0, ctx->stream, (const BfItem *) dev);
+    hipLaunchKernelGGL(k_bf_final_b, dim3(std::max(1, alva_divup(qblocks * QT, 256)), 1, count), dim3(256), 0, ctx->stream, (const BfItem *) dev);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
 
 extern "C" int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int n_query, const uint8_t *d_train,
                                      int n_train, int *d_idx, int *d_dist) {

@@ -23,6 +23,10 @@
 int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h,
                             const int *pitch);
 
+size_t alva_blur7_batch_size();
+int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h, const int *pitch);
+int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int max_tiles);
+
 namespace {
 
 constexpr int MAXLV = 12;
@@ -54,6 +58,17 @@ struct OrbDev {
     const int *tapCoef;     // resize tap coefficient (second tap, 0..256), -1 = clamp to first, -2 = clamp to last
     int *h_n3;              // pinned host mirror of n3, written by k_angle_emit (the host reads it after the stream sync)
     int umax[17];
+};
+
+// One camera of a batched launch (k_*_b: blockIdx.z = camera): the detector's own state plus the call's arguments.
+struct OrbItem {
+    OrbDev D;
+    const uint8_t *gray;
+    size_t gray_pitch;
+    float *kp;
+    uint8_t *desc;
+    int *total;
+    int cap, pad;
 };
 
 __device__ __forceinline__ void fast_ring(const uint8_t *p, int stride, int d[16]) {
@@ -128,7 +143,7 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int t
 }
 
 // resize level l from level l-1 (INTER_LINEAR_EXACT)
-__global__ void __launch_bounds__(256) k_resize(OrbDev D, int l) {
+__device__ __forceinline__ void resize_body(const OrbDev &D, int l) {
     const Level &S = D.lv[l - 1], &T = D.lv[l];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= T.w || y >= T.h) return;
@@ -152,6 +167,9 @@ __global__ void __launch_bounds__(256) k_resize(OrbDev D, int l) {
     const unsigned v = (acc + 32768u) >> 16;
     D.pool[T.img + (size_t) y * T.pitch + x] = (uint8_t) min(v, 255u);
 }
+
+__global__ void __launch_bounds__(256) k_resize(OrbDev D, int l) { resize_body(D, l); }
+__global__ void __launch_bounds__(256) k_resize_b(const OrbItem *__restrict__ items, int l) { resize_body(items[blockIdx.z].D, l); }
 
 // FAST score map of every level: 64x16 tile + 3 px halo staged in LDS
 constexpr int FT_W = 64, FT_H = 16;
@@ -184,7 +202,7 @@ __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
 // computed with dense lanes, scores stay in LDS, NMS survivors are packed per row by ballot and appended to the level's
 // candidate list with ONE atomic per tile.  No score map in HBM, no count/scan/emit passes.  The list order depends on
 // tile completion order; every later stage is order-free (threshold culls) and k_cull_harris finally sorts by position.
-__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
+__device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
     const Level &L = D.lv[blockIdx.y];
     const int tilesX = (L.w + FT_W - 1) / FT_W, tilesY = (L.h + FT_H - 1) / FT_H;
     if ((int) blockIdx.x >= tilesX * tilesY) return;
@@ -278,6 +296,9 @@ __global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
         }
     }
 }
+
+__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) { fast_nms_body(D); }
+__global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items) { fast_nms_body(items[blockIdx.z].D); }
 
 __device__ __forceinline__ bool nms_keep(const uint8_t *sc, int pitch, int x, int y, const Level &L) {
     if (x < 3 || x >= L.w - 3 || y < 3 || y >= L.h - 3) return false;
@@ -395,7 +416,7 @@ __device__ int compact_ordered(int n, Pred pred, Emit emit) {
 }
 
 // cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept), preserving order
-__global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) {
+__device__ __forceinline__ void cull_fast_body(const OrbDev &D) {
     const Level &L = D.lv[blockIdx.x];
     const int n = min(D.n1[blockIdx.x], L.candCap), keepN = 2 * L.nKeep;
     __shared__ unsigned s_bin, s_rem;
@@ -418,9 +439,12 @@ __global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) {
     if (threadIdx.x == 0) D.n2[blockIdx.x] = m;
 }
 
+__global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) { cull_fast_body(D); }
+__global__ void __launch_bounds__(1024) k_cull_fast_b(const OrbItem *__restrict__ items) { cull_fast_body(items[blockIdx.z].D); }
+
 // Harris response of every surviving candidate (orb.cpp:130-177): one wave each, the 49 block positions spread over the
 // lanes.  a, b, c are INTEGER sums in the reference, so the cross-lane reduction order cannot change them.
-__global__ void __launch_bounds__(256) k_harris(OrbDev D) {
+__device__ __forceinline__ void harris_body(const OrbDev &D) {
     const Level &L = D.lv[blockIdx.y];
     const int lane = threadIdx.x & 63, n2 = D.n2[blockIdx.y], W = L.pitch;
     const uint8_t *img = D.pool + L.img;
@@ -450,13 +474,16 @@ __global__ void __launch_bounds__(256) k_harris(OrbDev D) {
     }
 }
 
+__global__ void __launch_bounds__(256) k_harris(OrbDev D) { harris_body(D); }
+__global__ void __launch_bounds__(256) k_harris_b(const OrbItem *__restrict__ items) { harris_body(items[blockIdx.z].D); }
+
 __device__ __forceinline__ unsigned f2key(float f) {  // order-preserving map float -> uint
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
 // cull by Harris: keep response >= the n_l-th largest, preserving order (radix select on the float keys)
-__global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) {
+__device__ __forceinline__ void cull_harris_body(const OrbDev &D) {
     const Level &L = D.lv[blockIdx.x];
     const int n = D.n2[blockIdx.x], keepN = L.nKeep, o = L.candOff;
     __shared__ unsigned s_hist[256];
@@ -525,6 +552,9 @@ __global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) {
     }
 }
 
+__global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) { cull_harris_body(D); }
+__global__ void __launch_bounds__(1024) k_cull_harris_b(const OrbItem *__restrict__ items) { cull_harris_body(items[blockIdx.z].D); }
+
 __device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_core.simd.hpp:34-71
     const float s = (float) (180 / 3.1415926535897932384626433832795);
     const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
@@ -544,7 +574,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_c
 }
 
 // IC angle + output record, one wave per kept keypoint (orb.cpp:181-215, :952-958)
-__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) {
+__device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restrict__ kp, int cap, int *__restrict__ total) {
     const int l = blockIdx.y;
     const Level &L = D.lv[l];
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -586,13 +616,19 @@ __global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict_
     }
 }
 
+__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) { angle_emit_body(D, kp, cap, total); }
+__global__ void __launch_bounds__(256) k_angle_emit_b(const OrbItem *__restrict__ items) {
+    const OrbItem &it = items[blockIdx.z];
+    angle_emit_body(it.D, it.kp, it.cap, it.total);
+}
+
 __constant__ int8_t c_pattern_orb[1024] = {
 #include "orb_pattern.inc"
 };
 
 // steered BRIEF of the ORB keypoints on their (blurred) pyramid level; 32 lanes per keypoint (orb.cpp:219-284)
-__global__ void __launch_bounds__(256) k_brief_orb(OrbDev D, const float *__restrict__ kp, const int *__restrict__ total, int cap,
-                                                   uint8_t *__restrict__ desc) {
+__device__ __forceinline__ void brief_orb_body(const OrbDev &D, const float *__restrict__ kp, const int *__restrict__ total, int cap,
+                                               uint8_t *__restrict__ desc) {
     const int n = min(*total, cap);
     const int k = blockIdx.x * 8 + threadIdx.x / 32, byte = threadIdx.x % 32;
     if (k >= n) return;
@@ -618,7 +654,16 @@ __global__ void __launch_bounds__(256) k_brief_orb(OrbDev D, const float *__rest
     desc[(size_t) k * 32 + byte] = (uint8_t) val;
 }
 
-__global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) {
+__global__ void __launch_bounds__(256) k_brief_orb(OrbDev D, const float *__restrict__ kp, const int *__restrict__ total, int cap,
+                                                   uint8_t *__restrict__ desc) {
+    brief_orb_body(D, kp, total, cap, desc);
+}
+__global__ void __launch_bounds__(256) k_brief_orb_b(const OrbItem *__restrict__ items) {
+    const OrbItem &it = items[blockIdx.z];
+    brief_orb_body(it.D, it.kp, it.total, it.cap, it.desc);
+}
+
+__device__ __forceinline__ void copy_level0_body(const OrbDev &D, const uint8_t *__restrict__ src, size_t pitch) {
     const Level &L = D.lv[0];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < L.w && y < L.h) D.pool[L.img + (size_t) y * L.pitch + x] = src[(size_t) y * pitch + x];
@@ -627,6 +672,12 @@ __global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t 
         for (int k = threadIdx.x; k < MAXLV * 256; k += 256) D.hist[k] = 0;
         if (threadIdx.x < MAXLV) D.n1[threadIdx.x] = 0;   // k_fast_nms appends with atomics
     }
+}
+
+__global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) { copy_level0_body(D, src, pitch); }
+__global__ void k_copy_level0_b(const OrbItem *__restrict__ items) {
+    const OrbItem &it = items[blockIdx.z];
+    copy_level0_body(it.D, it.gray, it.gray_pitch);
 }
 
 int cv_round_f(float v) { return (int) lrintf(v); }
@@ -816,7 +867,7 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
 extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
 
 // device-resident total of the last detect_and_compute (internal: lets the driver chain the matcher without a host round trip)
-const int *alva_orb_device_count(const alva_orb *orb) { return orb->d_total; }
+extern "C" const int *alva_orb_device_count(const alva_orb *orb) { return orb ? orb->d_total : nullptr; }
 
 extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch, float *d_kp,
                                            uint8_t *d_desc, int cap, int *h_count) {
@@ -873,6 +924,95 @@ extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count) {
         total += n3[l];
     }
     *h_count = total;
+    return ALVA_OK;
+}
+
+// ---- cv::ORB::detectAndCompute of `count` cameras, one set of launches (blockIdx.z = camera) -----------------------------------
+// Every camera has its own detector object (image pool, candidate lists, counters); the objects must share one geometry.  The
+// kernels are the single-camera kernels' bodies, so every camera's keypoints and descriptors are those of its own
+// alva_orb_detect_and_compute.  Enqueue-only; alva_orb_collect_batch() waits and returns the counts.
+extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, const uint8_t *const *d_gray,
+                                                 size_t gray_pitch, float *const *d_kp, uint8_t *const *d_desc, int cap) {
+    ALVA_ARG(ctx && orbs && count > 0 && count <= 65535 && d_gray && d_kp && d_desc && cap >= 0 && orbs[0]);
+    const OrbDev &D0 = orbs[0]->D;
+    ALVA_ARG(gray_pitch >= (size_t) D0.lv[0].w);
+    hipStream_t st = ctx->stream;
+    const size_t blur_sz = alva_blur7_batch_size();
+    const size_t off_blur = ((size_t) count * sizeof(OrbItem) + 255) / 256 * 256, bytes = off_blur + (size_t) count * blur_sz;
+    std::vector<uint8_t> host(bytes);
+    int blurTiles = 0;
+    for (int c = 0; c < count; c++) {
+        const alva_orb *o = orbs[c];
+        ALVA_ARG(o && !o->fast_only && d_gray[c] && d_kp[c] && d_desc[c] && o->D.nlevels == D0.nlevels && o->maxTiles == orbs[0]->maxTiles);
+        for (int l = 0; l < D0.nlevels; l++)
+            ALVA_ARG(o->D.lv[l].w == D0.lv[l].w && o->D.lv[l].h == D0.lv[l].h && o->D.lv[l].nKeep == D0.lv[l].nKeep && o->D.lv[l].candCap == D0.lv[l].candCap);
+        OrbItem it{};
+        it.D = o->D;
+        it.gray = d_gray[c];
+        it.gray_pitch = gray_pitch;
+        it.kp = d_kp[c];
+        it.desc = d_desc[c];
+        it.total = o->d_total;
+        it.cap = cap;
+        memcpy(host.data() + (size_t) c * sizeof(OrbItem), &it, sizeof(it));
+        const uint8_t *bs[MAXLV];
+        uint8_t *bd[MAXLV];
+        int bw[MAXLV], bh[MAXLV], bp[MAXLV];
+        for (int l = 0; l < D0.nlevels; l++) {
+            const Level &L = o->D.lv[l];
+            bs[l] = o->D.pool + L.img;
+            bd[l] = o->D.pool + L.blur;
+            bw[l] = L.w;
+            bh[l] = L.h;
+            bp[l] = L.pitch;
+        }
+        blurTiles = alva_blur7_batch_fill(host.data() + off_blur + (size_t) c * blur_sz, D0.nlevels, bs, bd, bw, bh, bp);
+    }
+    uint8_t *dev = nullptr;
+    int rc = alva_ctx_scratch(ctx, 1, bytes, (void **) &dev);
+    if (rc) return rc;
+    ALVA_HIP(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, st));
+    const OrbItem *items = (const OrbItem *) dev;
+    const Level &L0 = D0.lv[0];
+    hipLaunchKernelGGL(k_copy_level0_b, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4), count), dim3(256), 0, st, items);
+    for (int l = 1; l < D0.nlevels; l++)
+        hipLaunchKernelGGL(k_resize_b, dim3(alva_divup(D0.lv[l].w, 64), alva_divup(D0.lv[l].h, 4), count), dim3(256), 0, st, items, l);
+    hipLaunchKernelGGL(k_fast_nms_b, dim3(orbs[0]->maxTiles, D0.nlevels, count), dim3(256), 0, st, items);
+    hipLaunchKernelGGL(k_cull_fast_b, dim3(D0.nlevels, 1, count), dim3(1024), 0, st, items);
+    hipLaunchKernelGGL(k_harris_b, dim3(256, D0.nlevels, count), dim3(256), 0, st, items);
+    hipLaunchKernelGGL(k_cull_harris_b, dim3(D0.nlevels, 1, count), dim3(1024), 0, st, items);
+    int maxKeep = 0, nmax = 0;
+    for (int l = 0; l < D0.nlevels; l++) {
+        const int bound = std::min(D0.lv[l].candCap, std::max(4 * D0.lv[l].nKeep + 64, 1024));
+        maxKeep = std::max(maxKeep, bound);
+        nmax += bound;
+    }
+    hipLaunchKernelGGL(k_angle_emit_b, dim3(alva_divup(maxKeep, 4), D0.nlevels, count), dim3(256), 0, st, items);
+    ALVA_LAUNCH_CHECK();
+    rc = alva_blur7_multi_launch(ctx, dev + off_blur, count, D0.nlevels, blurTiles);
+    if (rc) return rc;
+    nmax = std::min(nmax, cap);
+    if (nmax > 0) hipLaunchKernelGGL(k_brief_orb_b, dim3(alva_divup(nmax, 8), 1, count), dim3(256), 0, st, items);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+extern "C" int alva_orb_collect_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, int *h_counts) {
+    ALVA_ARG(ctx && orbs && count > 0 && h_counts);
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < count; c++) {
+        const OrbDev &D = orbs[c]->D;
+        int total = 0;
+        for (int l = 0; l < D.nlevels; l++) {
+            const int n3 = D.h_n3[l];
+            if (n3 > std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024))) {
+                alva_set_error("alva_orb_detect_and_compute_batch: camera %d level %d kept %d keypoints, above the launch bound", c, l, n3);
+                return ALVA_ERR_STATE;
+            }
+            total += n3;
+        }
+        h_counts[c] = total;
+    }
     return ALVA_OK;
 }
 

@@ -58,6 +58,14 @@ struct alva_track_batch {
     uint8_t *h_out = nullptr;     // pinned: PnpOut per camera, written by k_pnp_batch
     std::unordered_map<int, int *> samples;  // n -> device copy of the first P3P_DRAWS samples of the fixed-seed stream
     std::vector<int> slot;        // camera -> index among the cameras that solve a pose this frame (-1: fewer than 4 correspondences)
+    // keyframe branch's feature work (optional, alva_track_batch_enable_detector): cv::ORB + BFMatcher per camera on a third lane
+    alva_ctx *det = nullptr;
+    int orb_features = 0, cap = 0;
+    std::vector<alva_orb *> orbs;
+    uint8_t *det_slab = nullptr;  // per camera: gray | kp[2] | desc[2] | match idx + dist
+    size_t det_stride = 0, off_kp[2] = {0, 0}, off_desc[2] = {0, 0}, off_match = 0;
+    std::vector<uint8_t *> gray_ptrs;
+    std::vector<int> n_desc[2];
     long frame = 0, fallbacks = 0;  // fallbacks: cameras re-solved by the single-camera call (P3P prefix too short)
 };
 
@@ -69,6 +77,11 @@ extern "C" void alva_track_batch_destroy(alva_track_batch *tb) {
     for (auto &v: tb->pyr)
         for (auto p: v)
             if (p) alva_pyramid_destroy(p);
+    if (tb->det) (void) alva_ctx_sync(tb->det);
+    for (auto o: tb->orbs)
+        if (o) alva_orb_destroy(o);
+    if (tb->det_slab) (void) hipFree(tb->det_slab);
+    if (tb->det) alva_ctx_destroy(tb->det);
     for (auto &kv: tb->samples) (void) hipFree(kv.second);
     if (tb->slab) (void) hipFree(tb->slab);
     if (tb->d_items) (void) hipFree(tb->d_items);
@@ -154,11 +167,48 @@ static int samples_for(alva_track_batch *tb, int n, const int **out) {
     return ALVA_OK;
 }
 
-extern "C" int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const *d_rgba, size_t rgba_pitch, const float *const *d_pts,
-                                     const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
-                                     const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy, double *h_pose7,
-                                     int *h_pose_status) {
-    ALVA_ARG(tb && d_rgba && n_pts && n_corr && h_pose7 && h_pose_status);
+// The detector of every camera: cv::ORB::detectAndCompute(orb_features, 1.2, 8 levels, FAST 20) on the frame's gray image and a
+// brute-force Hamming match against the camera's previous descriptors, as alva_frontend_track does for one camera.  Call before
+// the first step.
+extern "C" int alva_track_batch_enable_detector(alva_track_batch *tb, int orb_features) {
+    ALVA_ARG(tb && orb_features > 0 && tb->frame == 0 && !tb->det);
+    ALVA_HIP(hipSetDevice(tb->device));
+    const int B = tb->B;
+    int rc = alva_ctx_create(tb->device, nullptr, 1, &tb->det);
+    if (rc) return rc;
+    tb->orb_features = orb_features;
+    tb->cap = 4 * orb_features + 1024;
+    tb->orbs.assign((size_t) B, nullptr);
+    for (int c = 0; c < B && !rc; c++) rc = alva_orb_create(tb->det, tb->width, tb->height, orb_features, 1.2f, 8, 20, &tb->orbs[(size_t) c]);
+    if (rc) return rc;
+    size_t off = up((size_t) tb->width * tb->height, 256);
+    for (int k = 0; k < 2; k++) {
+        tb->off_kp[k] = off;
+        off += up((size_t) tb->cap * 6 * sizeof(float), 256);
+    }
+    for (int k = 0; k < 2; k++) {
+        tb->off_desc[k] = off;
+        off += up((size_t) tb->cap * 32, 256);
+    }
+    tb->off_match = off;
+    off += up((size_t) tb->cap * 2 * sizeof(int), 256);
+    tb->det_stride = off;
+    if (hipMalloc((void **) &tb->det_slab, tb->det_stride * (size_t) B) != hipSuccess) {
+        alva_set_error("alva_track_batch_enable_detector: hipMalloc(%zu) failed", tb->det_stride * (size_t) B);
+        return ALVA_ERR_NOMEM;
+    }
+    tb->gray_ptrs.resize((size_t) B);
+    for (int c = 0; c < B; c++) tb->gray_ptrs[(size_t) c] = tb->det_slab + tb->det_stride * (size_t) c;
+    tb->n_desc[0].assign((size_t) B, 0);
+    tb->n_desc[1].assign((size_t) B, 0);
+    return ALVA_OK;
+}
+
+extern "C" int alva_track_batch_step_detect(alva_track_batch *tb, const uint8_t *const *d_rgba, size_t rgba_pitch, const float *const *d_pts,
+                                            const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
+                                            const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy,
+                                            double *h_pose7, int *h_pose_status, int *h_n_keypoints) {
+    ALVA_ARG(tb && d_rgba && n_pts && n_corr && h_pose7 && h_pose_status && (!tb->det || h_n_keypoints));
     ALVA_HIP(hipSetDevice(tb->device));
     const int B = tb->B, cur = (int) (tb->frame & 1), prv = cur ^ 1;
     alva_ctx *ctx = tb->ctx;
@@ -205,10 +255,50 @@ extern "C" int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const 
         if (rc) return rc;
     }
     // image lane: preprocessImage, then kltTracking, of every camera
-    rc = alva_pyramid_build_from_rgba_batch(ctx, tb->pyr[cur].data(), d_rgba, rgba_pitch, nullptr, 0, B);
+    rc = alva_pyramid_build_from_rgba_batch(ctx, tb->pyr[cur].data(), d_rgba, rgba_pitch, tb->det ? tb->gray_ptrs.data() : nullptr,
+                                            tb->det ? (size_t) tb->width : 0, B);
     if (rc) return rc;
+    if (tb->det) {
+        rc = alva_ctx_wait(tb->det, ctx);  // the gray images; recorded in front of the tracker's launch
+        if (rc) return rc;
+    }
     rc = alva_fbklt_track_batch_enqueue(ctx, tb->d_items, B, n_pts_max, tb->klt_levels, 30.f, 0.5f, 30, 0.01f, tb->klt_lanes);  // state.hpp:55-59
     if (rc) return rc;
+    if (tb->det) {
+        // detector lane: detect + describe every camera's frame, then match against the camera's previous descriptors with the new
+        // counts still on the device
+        std::vector<float *> kp((size_t) B);
+        std::vector<uint8_t *> desc((size_t) B);
+        std::vector<const uint8_t *> gray((size_t) B), query((size_t) B), train((size_t) B);
+        std::vector<const int *> dnq((size_t) B);
+        std::vector<int *> idx((size_t) B), dist((size_t) B);
+        int any_train = 0;
+        for (int c = 0; c < B; c++) {
+            uint8_t *base = tb->det_slab + tb->det_stride * (size_t) c;
+            gray[(size_t) c] = base;
+            kp[(size_t) c] = (float *) (base + tb->off_kp[cur]);
+            desc[(size_t) c] = base + tb->off_desc[cur];
+            query[(size_t) c] = desc[(size_t) c];
+            train[(size_t) c] = base + tb->off_desc[prv];
+            dnq[(size_t) c] = alva_orb_device_count(tb->orbs[(size_t) c]);
+            idx[(size_t) c] = (int *) (base + tb->off_match);
+            dist[(size_t) c] = idx[(size_t) c] + tb->cap;
+            if (tb->frame == 0) tb->n_desc[prv][(size_t) c] = 0;
+            any_train |= tb->n_desc[prv][(size_t) c] > 0;
+        }
+        rc = alva_orb_detect_and_compute_batch(tb->det, tb->orbs.data(), B, gray.data(), (size_t) tb->width, kp.data(), desc.data(), tb->cap);
+        if (!rc && any_train)
+            rc = alva_bf_match_hamming_batch(tb->det, B, query.data(), dnq.data(), tb->cap, train.data(), tb->n_desc[prv].data(), idx.data(), dist.data(),
+                                             tb->orb_features + 64);
+        if (rc) return rc;
+        // the detector lane's count first, as alva_frontend_track does (its short commands retire while the tracker still computes)
+        rc = alva_orb_collect_batch(tb->det, tb->orbs.data(), B, h_n_keypoints);
+        if (rc) return rc;
+        for (int c = 0; c < B; c++) {
+            h_n_keypoints[c] = std::min(h_n_keypoints[c], tb->cap);
+            tb->n_desc[cur][(size_t) c] = h_n_keypoints[c];
+        }
+    }
     ALVA_HIP(hipStreamSynchronize(ctx->stream));
     if (n_pose > 0) ALVA_HIP(hipStreamSynchronize(tb->pose->stream));
     for (int c = 0; c < B; c++) {
@@ -226,6 +316,31 @@ extern "C" int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const 
         }
     }
     tb->frame++;
+    return ALVA_OK;
+}
+
+extern "C" int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const *d_rgba, size_t rgba_pitch, const float *const *d_pts,
+                                     const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
+                                     const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy, double *h_pose7,
+                                     int *h_pose_status) {
+    ALVA_ARG(tb);
+    std::vector<int> nkp;
+    if (tb->det) nkp.resize((size_t) tb->B);
+    return alva_track_batch_step_detect(tb, d_rgba, rgba_pitch, d_pts, n_pts, d_bearings, d_uv, d_wpts, n_corr, fx, fy, cx, cy, h_pose7, h_pose_status,
+                                        tb->det ? nkp.data() : nullptr);
+}
+
+// Device-resident detector results of camera `cam` from the last step: keypoints [n][6] (x, y, size, angle, response, octave),
+// descriptors [n][32], and per keypoint the index / distance of its best match among the camera's PREVIOUS descriptors.
+extern "C" int alva_track_batch_detections(alva_track_batch *tb, int cam, const float **d_keypoints, const uint8_t **d_descriptors,
+                                           const int **d_match_idx, const int **d_match_dist) {
+    ALVA_ARG(tb && tb->det && cam >= 0 && cam < tb->B && tb->frame > 0);
+    const int last = (int) ((tb->frame - 1) & 1);
+    const uint8_t *base = tb->det_slab + tb->det_stride * (size_t) cam;
+    if (d_keypoints) *d_keypoints = (const float *) (base + tb->off_kp[last]);
+    if (d_descriptors) *d_descriptors = base + tb->off_desc[last];
+    if (d_match_idx) *d_match_idx = (const int *) (base + tb->off_match);
+    if (d_match_dist) *d_match_dist = (const int *) (base + tb->off_match) + tb->cap;
     return ALVA_OK;
 }
 

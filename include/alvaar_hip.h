@@ -151,6 +151,14 @@ int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_g
                                 float *d_kp, uint8_t *d_desc, int cap, int *h_count);
 /* h_count == NULL above only enqueues the work (no host wait); this call then waits for it and returns the count. */
 int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
+/* cv::ORB::detectAndCompute of `count` cameras in one set of launches (grid z = camera): every camera has its own detector object
+ * (all of one geometry), gray image, keypoint and descriptor buffer (each of capacity cap); each camera's output equals its own
+ * alva_orb_detect_and_compute.  Enqueue-only; alva_orb_collect_batch waits and returns the per-camera keypoint counts. */
+int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, const uint8_t *const *d_gray,
+                                      size_t gray_pitch, float *const *d_kp, uint8_t *const *d_desc, int cap);
+int alva_orb_collect_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, int *h_counts);
+/* device-resident keypoint count of the detector's last run (what alva_orb_collect copies to the host) */
+const int *alva_orb_device_count(const alva_orb *orb);
 
 /* ---- a5: the reference's grid Shi-Tomasi detector ---------------------------------------------
  * Replaces FeatureExtractor::detectFeaturePoints (src/slam/src/feature_extractor.cpp:11-158).
@@ -167,6 +175,13 @@ int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, in
  * Descriptors are 32 bytes each, rows 32-byte aligned. */
 int alva_bf_match_hamming(alva_ctx *ctx, const uint8_t *d_query, int n_query, const uint8_t *d_train,
                           int n_train, int *d_idx, int *d_dist);
+/* `count` independent matches in one pair of launches.  Match c: queries d_query[c], whose number is read from device memory
+ * (*d_n_query[c], clamped to cap_query) so that the call can be enqueued behind the detector that produces them; train set
+ * d_train[c] with n_train[c] rows (0 = skip that match); rows of d_idx[c] / d_dist[c] beyond the query count stay untouched.
+ * expected_queries sizes the grid (larger counts are covered by a loop).  Enqueue-only. */
+int alva_bf_match_hamming_batch(alva_ctx *ctx, int count, const uint8_t *const *d_query, const int *const *d_n_query,
+                                int cap_query, const uint8_t *const *d_train, const int *n_train, int *const *d_idx,
+                                int *const *d_dist, int expected_queries);
 
 /* ---- a8: P3P + LMedS absolute pose ------------------------------------------------------------
  * Replaces MultiViewGeometry::p3pRansac(obs, wpts, max_iters, err_thr, optimize=false, doRandom,
@@ -373,6 +388,18 @@ int alva_track_batch_step(alva_track_batch *tb, const uint8_t *const *d_rgba, si
                           const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
                           const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy, double *h_pose7,
                           int *h_pose_status);
+/* Optional: the keyframe branch's feature work for every camera, as alva_frontend_track does for one -- cv::ORB::detectAndCompute
+ * (orb_features, 1.2, 8 levels, FAST 20) on the frame's gray image and a brute-force Hamming match against the camera's previous
+ * descriptors, batched over the cameras on a third HIP stream (12 + 2 launches for all cameras).  Enable before the first step;
+ * alva_track_batch_step_detect then also returns the per-camera keypoint counts, alva_track_batch_detections the device-resident
+ * keypoints [n][6], descriptors [n][32] and matches (index / distance into the camera's previous descriptor set). */
+int alva_track_batch_enable_detector(alva_track_batch *tb, int orb_features);
+int alva_track_batch_step_detect(alva_track_batch *tb, const uint8_t *const *d_rgba, size_t rgba_pitch, const float *const *d_pts,
+                                 const int *n_pts, const double *const *d_bearings, const double *const *d_uv,
+                                 const double *const *d_wpts, const int *n_corr, float fx, float fy, float cx, float cy,
+                                 double *h_pose7, int *h_pose_status, int *h_n_keypoints);
+int alva_track_batch_detections(alva_track_batch *tb, int cam, const float **d_keypoints, const uint8_t **d_descriptors,
+                                const int **d_match_idx, const int **d_match_dist);
 /* device-resident kltTracking result of one camera from the last step: [n_pts][2] positions, [n_pts] status */
 int alva_track_batch_results(alva_track_batch *tb, int cam, const float **d_tracked, const uint8_t **d_track_status);
 /* Tuning knob of the tracking launch: lanes of a wavefront per keypoint, 5 (default, see alva_fbklt_track_batch), 8, 16, 32 or 64 (the single-camera kernel's layout).  Results are identical for all three.  The environment variable

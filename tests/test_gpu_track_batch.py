@@ -119,3 +119,38 @@ def test_batch_rejects_bad_arguments():
     with pytest.raises(alvaar_amd.AlvaError):
         tb.step([c["frames"][0]] * 2, K)
     tb.close()
+
+
+def test_batch_with_detector_equals_single_cameras(ctx):
+    """the detector lane (cv::ORB + Hamming match per camera, batched over the cameras) gives every camera the keypoints, descriptors
+    and matches of its own alva_frontend_track"""
+    import torch
+    import alvaar_amd
+    K = synth.make_pnp_problem(8, 1)["K"]
+    spec = [(300, 300), (120, 90), (0, 40), (500, 700), (64, 8)]
+    cams = [_camera(41 + i, a, b, frames=4) for i, (a, b) in enumerate(spec)]
+    B = len(cams)
+    tb = alvaar_amd.TrackBatch(0, W, H, B, 500, 700)
+    tb.enable_detector(500)
+    tb.bind([c["pts"] for c in cams], [c["bv"] for c in cams], [c["uv"] for c in cams], [c["wp"] for c in cams])
+    fes = [alvaar_amd.Frontend(0, W, H, 500, 500) for _ in range(B)]
+    empty_f = torch.empty((0, 2), dtype=torch.float32, device="cuda")
+    for k in range(4):
+        st, poses = tb.step([c["frames"][k] for c in cams], K)
+        st, poses, nkp = st.copy(), poses.copy(), tb.nkp.copy()
+        for i, c in enumerate(cams):
+            pts = c["pts"] if c["pts"] is not None else empty_f
+            st1, pose1, nkp1 = fes[i].track(c["frames"][k], pts, c["bv"], c["uv"], c["wp"], K)
+            assert st[i] == st1 and nkp[i] == nkp1 and nkp1 > 50, (k, i)
+            if st1 >= 1:
+                assert np.array_equal(poses[i], pose1), (k, i)
+            fes[i].sync()
+            r = fes[i].results()
+            d = tb.detections(i)
+            assert torch.equal(d["keypoints"], r["keypoints"]) and torch.equal(d["descriptors"], r["descriptors"]), (k, i)
+            if k > 0:
+                assert torch.equal(d["match_idx"], r["match_idx"]) and torch.equal(d["match_dist"], r["match_dist"]), (k, i)
+                assert int((d["match_dist"] >= 0).sum()) == nkp1
+    for f in fes:
+        f.close()
+    tb.close()
