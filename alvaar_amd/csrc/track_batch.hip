@@ -77,11 +77,11 @@ extern "C" void alva_track_batch_destroy(alva_track_batch *tb) {
     for (auto &v: tb->pyr)
         for (auto p: v)
             if (p) alva_pyramid_destroy(p);
-    if (tb->det) (void) alva_ctx_sync(tb->det);
+    if (tb->det && tb->det != tb->ctx) (void) alva_ctx_sync(tb->det);
     for (auto o: tb->orbs)
         if (o) alva_orb_destroy(o);
     if (tb->det_slab) (void) hipFree(tb->det_slab);
-    if (tb->det) alva_ctx_destroy(tb->det);
+    if (tb->det && tb->det != tb->ctx) alva_ctx_destroy(tb->det);
     for (auto &kv: tb->samples) (void) hipFree(kv.second);
     if (tb->slab) (void) hipFree(tb->slab);
     if (tb->d_items) (void) hipFree(tb->d_items);
@@ -174,7 +174,9 @@ extern "C" int alva_track_batch_enable_detector(alva_track_batch *tb, int orb_fe
     ALVA_ARG(tb && orb_features > 0 && tb->frame == 0 && !tb->det);
     ALVA_HIP(hipSetDevice(tb->device));
     const int B = tb->B;
-    int rc = alva_ctx_create(tb->device, nullptr, 1, &tb->det);
+    int rc = ALVA_OK;
+    if (std::getenv("ALVA_TRACK_BATCH_ONE_LANE")) tb->det = tb->ctx;
+    else rc = alva_ctx_create(tb->device, nullptr, 1, &tb->det);
     if (rc) return rc;
     tb->orb_features = orb_features;
     tb->cap = 4 * orb_features + 1024;

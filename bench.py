@@ -289,9 +289,12 @@ def bench_batched_preprocess(device: int, cameras: int = 64, reps: int = 20):
                 note="event-timed kernels of alva_pyramid_build_from_rgba_batch; achieved = algorithmic bytes / sum of kernel times")
 
 
-def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed: int = 7):
-    """Secondary line: VisualFrontend::trackMono (preprocessImage -> kltTracking -> computePose; the detector belongs to the keyframe
-    branch) for `cameras` lock-step cameras through alva_track_batch_step -- 10 launches and one synchronisation per lane for ALL cameras.
+def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed: int = 7, detector: bool = False):
+    """Secondary lines: `cameras` lock-step cameras through alva_track_batch_step.  detector=False ("track_mono_batch"):
+    VisualFrontend::trackMono (preprocessImage -> kltTracking -> computePose; the detector belongs to the keyframe branch).
+    detector=True ("frame_step_batch"): the headline's full stage list per camera -- the above plus cv::ORB detectAndCompute(2000) and
+    the Hamming match against the camera's previous descriptors -- i.e. B times the work of one alva_frontend_track.
+    Through alva_track_batch_step -- 10 launches and one synchronisation per lane for ALL cameras.
     Every camera has its own frame ring (4 distinct synthetic streams, cycled), 2120 keypoints and 2120 correspondences.
     Algorithmic HBM bytes per camera frame: 4P RGBA in + 7.64P pyramid/Scharr (no separate gray copy) + the KLT gathers, which stay
     in L2 and are not counted => 11.64 P."""
@@ -311,6 +314,8 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
     # every camera owns its frames (no two cameras read the same HBM lines)
     frames = [rings[c % nsrc].clone() for c in range(cameras)]
     tb = alvaar_amd.TrackBatch(device, W, H, cameras, NKP, NKP)
+    if detector:
+        tb.enable_detector(2000)   # + cv::ORB detectAndCompute(2000) and the Hamming match per camera: the headline's full stage list
     tb.bind([pts[c % nsrc] for c in range(cameras)], [bv[c % nsrc] for c in range(cameras)], [uv[c % nsrc] for c in range(cameras)],
             [wp[c % nsrc] for c in range(cameras)])
     tables = [tb.frame_table([f[r] for f in frames]) for r in range(RING)]   # the resident frames' pointer tables, built once
@@ -331,10 +336,10 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
     dt = (time.perf_counter() - t0) / reps
     kt = capi.kernel_times(step, 3)
     kernel_us = sum(v[0] / 3 * v[1] for v in kt.values())
-    alg = cameras * 11.64 * W * H
+    alg = cameras * (11.64 + (1 + 2 * 3.27 + 2 * 3.27 if detector else 0)) * W * H   # + gray copy, ORB pyramid w+r, blur r+w (L8 = 3.27 P)
     steps_done, fallbacks = tb.stats()
     tb.close()
-    return dict(cameras=cameras, launches_per_step=10, ms_per_step=dt * 1e3, frames_per_s=cameras / dt, poses_accepted_frac=ok / (reps * cameras),
+    return dict(cameras=cameras, detector=detector, launches_per_step=24 if detector else 10, ms_per_step=dt * 1e3, frames_per_s=cameras / dt, poses_accepted_frac=ok / (reps * cameras),
                 single_camera_fallbacks=fallbacks, kernel_us_per_step=kernel_us, alg_bytes_per_step=int(alg),
                 achieved_GBps=alg / dt / 1e9, hbm_frac=alg / dt / 1e9 / HBM_PEAK_GBS,
                 kernels={n: {"avg_us": round(v[1], 2), "launches_per_step": round(v[0] / 3, 2)} for n, v in kt.items()},
@@ -515,6 +520,7 @@ def main():
             "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
             "batched_preprocess": bench_batched_preprocess(local) if world == 1 else None,
             "track_mono_batch": [bench_track_mono_batch(local, c_) for c_ in (16, 64)] if world == 1 else None,
+            "frame_step_batch": [bench_track_mono_batch(local, c_, detector=True) for c_ in (16, 64)] if world == 1 else None,
             "config_1280x720": bench_720p(local) if world == 1 else None,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -7,7 +7,8 @@ sys.path.insert(0, ".")
 import torch  # noqa: F401,E402
 import bench  # noqa: E402
 
+det = os.environ.get("DETECTOR") == "1"
 for b in [int(a) for a in sys.argv[1:]] or [1, 4, 16, 64, 128]:
-    r = bench.bench_track_mono_batch(0, b, reps=6 if b >= 64 else 20)
+    r = bench.bench_track_mono_batch(0, b, reps=6 if b >= 64 else 20, detector=det)
     print(json.dumps({k: r[k] for k in ("cameras", "ms_per_step", "frames_per_s", "poses_accepted_frac", "single_camera_fallbacks",
                                         "kernel_us_per_step", "achieved_GBps")}), {n: v["avg_us"] for n, v in r["kernels"].items()}, flush=True)
