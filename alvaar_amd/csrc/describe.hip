@@ -128,12 +128,92 @@ int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
 }
 
 // ---- the same for several cameras: blockIdx.z = camera, one BlurBatch per camera in device memory ------------------------------
+// Throughput form of blur7_tile for the batched launch: the same 64 x 16 tile and the same float operations per pixel in the same
+// order, but four pixels per thread -- dword loads into the byte tile (per-byte reflection only in dwords that cross the image
+// border), v_cvt_f32_ubyteN unpacking, float4 LDS traffic, dword stores.  blur7_tile spends its time on byte-granular addressing
+// (0.24 TB/s on 64 cameras); one camera's launch is latency-bound and keeps it.  Needs 4-byte aligned rows (the ORB pool's are).
+__device__ __forceinline__ void blur7_tile4(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, uint8_t *__restrict__ dst,
+                                            size_t dst_pitch, int bx, int by) {
+    constexpr int PW = BT_W + 8, RW = BT_W + 4;                  // byte tile: columns x0 - 4 .. x0 + 67; float rows padded to 68
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[BT_H + 6][PW];
+    __shared__ __attribute__((aligned(16))) float s_row[BT_H + 6][RW];
+    const int x0 = bx * BT_W, y0 = by * BT_H;
+    for (int i = threadIdx.x; i < (BT_H + 6) * (PW / 4); i += 256) {
+        const int ly = i / (PW / 4), d = i - ly * (PW / 4);
+        int gy = reflect101(y0 + ly - 3, h);
+        gy = min(max(gy, 0), h - 1);
+        const int gx0 = x0 - 4 + 4 * d;
+        const uint8_t *row = src + (size_t) gy * src_pitch;
+        uint32_t v;
+        if (gx0 >= 0 && gx0 + 3 < w) {
+            v = *reinterpret_cast<const uint32_t *>(row + gx0);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int gx = reflect101(gx0 + k, w);
+                gx = min(max(gx, 0), w - 1);
+                v |= (uint32_t) row[gx] << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&s_px[ly][4 * d]) = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W / 4); i += 256) {
+        const int ly = i / (BT_W / 4), c = i - ly * (BT_W / 4);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(&s_px[ly][4 * c]);
+        const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2];
+        float p[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            p[k] = (float) ((d0 >> (8 * k)) & 0xffu);
+            p[4 + k] = (float) ((d1 >> (8 * k)) & 0xffu);
+            p[8 + k] = (float) ((d2 >> (8 * k)) & 0xffu);
+        }
+        float4 o;
+        float *op = &o.x;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float s_ = gk(0) * p[j + 1];
+#pragma unroll
+            for (int k = 1; k < 7; k++) s_ += gk(k) * p[j + 1 + k];
+            op[j] = s_;
+        }
+        *reinterpret_cast<float4 *>(&s_row[ly][4 * c]) = o;
+    }
+    __syncthreads();
+    {
+        const int ly = threadIdx.x / (BT_W / 4), c = threadIdx.x - ly * (BT_W / 4);  // 16 rows x 16 quads = 256 threads
+        float4 r[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) r[k] = *reinterpret_cast<const float4 *>(&s_row[ly + k][4 * c]);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float s_ = gk(3) * (&r[3].x)[j];
+#pragma unroll
+            for (int k = 1; k <= 3; k++) s_ += gk(3 + k) * ((&r[3 + k].x)[j] + (&r[3 - k].x)[j]);
+            int v = __float2int_rn(s_);
+            v = min(max(v, 0), 255);
+            packed |= (uint32_t) v << (8 * j);
+        }
+        const int gx = x0 + 4 * c, gy = y0 + ly;
+        if (gy < h) {
+            uint8_t *o = dst + (size_t) gy * dst_pitch + gx;
+            if (gx + 3 < w) *reinterpret_cast<uint32_t *>(o) = packed;
+            else
+                for (int j = 0; j < 4; j++)
+                    if (gx + j < w) o[j] = (uint8_t) (packed >> (8 * j));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_blur7_multi(const BlurBatch *__restrict__ Bs) {
     const BlurBatch &B = Bs[blockIdx.z];
     const int l = blockIdx.y;
     const int tilesX = (B.w[l] + BT_W - 1) / BT_W, tilesY = (B.h[l] + BT_H - 1) / BT_H;
     if ((int) blockIdx.x >= tilesX * tilesY) return;
-    blur7_tile(B.src[l], (size_t) B.pitch[l], B.w[l], B.h[l], B.dst[l], (size_t) B.pitch[l], blockIdx.x % tilesX, blockIdx.x / tilesX);
+    blur7_tile4(B.src[l], (size_t) B.pitch[l], B.w[l], B.h[l], B.dst[l], (size_t) B.pitch[l], blockIdx.x % tilesX, blockIdx.x / tilesX);
 }
 
 size_t alva_blur7_batch_size() { return sizeof(BlurBatch); }
@@ -147,6 +227,7 @@ int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *
         B.w[l] = w[l];
         B.h[l] = h[l];
         B.pitch[l] = pitch[l];
+        if (pitch[l] % 4 || ((uintptr_t) src[l] % 4) || ((uintptr_t) dst[l] % 4)) return -1;  // blur7_tile4 moves dwords
         maxTiles = std::max(maxTiles, alva_divup(w[l], BT_W) * alva_divup(h[l], BT_H));
     }
     memcpy(out, &B, sizeof(B));

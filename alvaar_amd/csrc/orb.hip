@@ -574,13 +574,13 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_c
 }
 
 // IC angle + output record, one wave per kept keypoint (orb.cpp:181-215, :952-958)
-__device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restrict__ kp, int cap, int *__restrict__ total) {
+__device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restrict__ kp, int cap, int *__restrict__ total, const int bx) {
     const int l = blockIdx.y;
     const Level &L = D.lv[l];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     int base = 0;
     for (int q = 0; q < l; q++) base += D.n3[q];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx == 0 && threadIdx.x == 0) {
         D.h_n3[l] = D.n3[l];
         if (l == D.nlevels - 1) *total = base + D.n3[l];
     }
@@ -616,10 +616,13 @@ __device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restri
     }
 }
 
-__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) { angle_emit_body(D, kp, cap, total); }
+__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) { angle_emit_body(D, kp, cap, total, blockIdx.x); }
 __global__ void __launch_bounds__(256) k_angle_emit_b(const OrbItem *__restrict__ items) {
+    // a level keeps a few hundred keypoints while the launch bound is >= 1024: a short grid that loops instead of ~130 k workgroups
+    // (for 64 cameras) of which three quarters find nothing to do
     const OrbItem &it = items[blockIdx.z];
-    angle_emit_body(it.D, it.kp, it.cap, it.total);
+    const int n3 = it.D.n3[blockIdx.y];
+    for (int bx = blockIdx.x; bx == 0 || bx * 4 < n3; bx += gridDim.x) angle_emit_body(it.D, it.kp, it.cap, it.total, bx);
 }
 
 __constant__ int8_t c_pattern_orb[1024] = {
@@ -967,6 +970,10 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
             bp[l] = L.pitch;
         }
         blurTiles = alva_blur7_batch_fill(host.data() + off_blur + (size_t) c * blur_sz, D0.nlevels, bs, bd, bw, bh, bp);
+        if (blurTiles < 0) {
+            alva_set_error("alva_orb_detect_and_compute_batch: image pool rows are not 4-byte aligned");
+            return ALVA_ERR_STATE;
+        }
     }
     uint8_t *dev = nullptr;
     int rc = alva_ctx_scratch(ctx, 1, bytes, (void **) &dev);
@@ -987,7 +994,7 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
         maxKeep = std::max(maxKeep, bound);
         nmax += bound;
     }
-    hipLaunchKernelGGL(k_angle_emit_b, dim3(alva_divup(maxKeep, 4), D0.nlevels, count), dim3(256), 0, st, items);
+    hipLaunchKernelGGL(k_angle_emit_b, dim3(std::min(64, alva_divup(maxKeep, 4)), D0.nlevels, count), dim3(256), 0, st, items);
     ALVA_LAUNCH_CHECK();
     rc = alva_blur7_multi_launch(ctx, dev + off_blur, count, D0.nlevels, blurTiles);
     if (rc) return rc;
