@@ -591,9 +591,17 @@ __device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restri
     int m01 = 0, m10 = 0;
     if (lane < 31) {
         const int v = lane - 15, av = v < 0 ? -v : v, d = av == 0 ? 15 : D.umax[av];
+        // the row's 31 bytes u = -15..15 (+1) as eight independent unaligned dword loads -- one round trip to L2 instead of a
+        // dependent load per pixel; the circular patch keeps |u| <= d (keypoints lie >= 31 px inside the level, so the full row exists)
+        const uint8_t *rowp = ctr + v * W - 15;
+        uint32_t dw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_memcpy(&dw[k], rowp + 4 * k, 4);
         int rs = 0, ms = 0;
-        for (int u = -d; u <= d; u++) {
-            const int val = ctr[u + v * W];
+#pragma unroll
+        for (int k = 0; k < 31; k++) {
+            const int u = k - 15;
+            const int val = (u >= -d && u <= d) ? (int) ((dw[k >> 2] >> (8 * (k & 3))) & 0xffu) : 0;
             rs += val;
             ms += u * val;
         }
