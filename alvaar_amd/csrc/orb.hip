@@ -213,10 +213,10 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
     constexpr int GW = FT_W + 8, GH = FT_H + 8, SW = FT_W + 4, SH = FT_H + 2;   // gray tile (halo 4), score tile (halo 1)
     __shared__ uint8_t g[GH * GW];
     __shared__ uint8_t sc[SH * SW];
-    __shared__ unsigned short list[SH * (FT_W + 2)];
-    __shared__ int s_n, s_row[FT_H], s_base;
+    __shared__ unsigned short list[SH * (FT_W + 2)], list2[SH * (FT_W + 2)];
+    __shared__ int s_n, s_n2, s_row[FT_H], s_base;
     const uint8_t *img = D.pool + L.img;
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) s_n = s_n2 = 0;
     for (int i = threadIdx.x; i < GH * GW; i += 256) {
         const int ly = i / GW, lx = i % GW;
         const int gx = min(max(x0 + lx - 4, 0), L.w - 1), gy = min(max(y0 + ly - 4, 0), L.h - 1);
@@ -224,27 +224,50 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    // corner test on the (FT_H + 2) x (FT_W + 2) region; pack the corners
+    // corner test on the (FT_H + 2) x (FT_W + 2) region, in two packed steps.  Step 1, every pixel: the high-speed test -- an arc of
+    // 9 on the ring of 16 contains k or k + 8 for every k, so a corner needs (ring 0 or 8) AND (ring 4 or 12) beyond the threshold
+    // on the same side (fast.cpp's quick rejection; a necessary condition, so the corner set is unchanged).  Step 2, the survivors
+    // only (a quarter of the pixels on textured frames), densely packed again: the full ring.
     for (int i0 = 0; i0 < SH * (FT_W + 2); i0 += 256) {
         const int i = i0 + threadIdx.x;
-        bool corner = false;
+        bool maybe = false;
         int ly = 0, lx = 0;
         if (i < SH * (FT_W + 2)) {
             ly = i / (FT_W + 2);
             lx = i % (FT_W + 2);
             const int gx = x0 + lx - 1, gy = y0 + ly - 1;
             if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) {
-                int d[16];
-                fast_ring(g + (ly + 3) * GW + lx + 3, GW, d);
-                corner = fast_is_corner(d, D.threshold);
+                const uint8_t *p = g + (ly + 3) * GW + lx + 3;
+                const int v = p[0], t = D.threshold;
+                const int d0 = v - p[3 * GW], d8 = v - p[-3 * GW], d4 = v - p[3], d12 = v - p[-3];
+                maybe = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
             }
             sc[ly * SW + lx] = 0;
+        }
+        const unsigned long long m = __ballot(maybe);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_n2, __popcll(m));
+        base = __shfl(base, 0);
+        if (maybe) list2[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short) (ly * 256 + lx);
+    }
+    __syncthreads();
+    const int n2 = s_n2;
+    for (int j0 = 0; j0 < n2; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        bool corner = false;
+        unsigned short code = 0;
+        if (j < n2) {
+            code = list2[j];
+            const int ly = code >> 8, lx = code & 255;
+            int d[16];
+            fast_ring(g + (ly + 3) * GW + lx + 3, GW, d);
+            corner = fast_is_corner(d, D.threshold);
         }
         const unsigned long long m = __ballot(corner);
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
         base = __shfl(base, 0);
-        if (corner) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short) (ly * 256 + lx);
+        if (corner) list[base + __popcll(m & ((1ull << lane) - 1ull))] = code;
     }
     __syncthreads();
     const int nc = s_n;
