@@ -211,16 +211,28 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
     const int lo = max(L.border, 3), hx = L.w - lo, hy = L.h - lo;
     if (x0 >= hx || x0 + FT_W <= lo || y0 >= hy || y0 + FT_H <= lo) return;
     constexpr int GW = FT_W + 8, GH = FT_H + 8, SW = FT_W + 4, SH = FT_H + 2;   // gray tile (halo 4), score tile (halo 1)
-    __shared__ uint8_t g[GH * GW];
+    __shared__ __attribute__((aligned(4))) uint8_t g[GH * GW];
     __shared__ uint8_t sc[SH * SW];
     __shared__ unsigned short list[SH * (FT_W + 2)], list2[SH * (FT_W + 2)];
     __shared__ int s_n, s_n2, s_row[FT_H], s_base;
     const uint8_t *img = D.pool + L.img;
     if (threadIdx.x == 0) s_n = s_n2 = 0;
-    for (int i = threadIdx.x; i < GH * GW; i += 256) {
-        const int ly = i / GW, lx = i % GW;
-        const int gx = min(max(x0 + lx - 4, 0), L.w - 1), gy = min(max(y0 + ly - 4, 0), L.h - 1);
-        g[i] = img[(size_t) gy * L.pitch + gx];
+    // gray tile, a dword per thread and step (x0 - 4 and the level's rows are 4-byte aligned); bytes are clamped one by one only in
+    // dwords that cross the image border
+    static_assert(GW % 4 == 0, "dword tile rows");
+    for (int i = threadIdx.x; i < GH * (GW / 4); i += 256) {
+        const int ly = i / (GW / 4), dq = i - ly * (GW / 4);
+        const int gy = min(max(y0 + ly - 4, 0), L.h - 1), gx0 = x0 - 4 + 4 * dq;
+        const uint8_t *row = img + (size_t) gy * L.pitch;
+        uint32_t v;
+        if (gx0 >= 0 && gx0 + 3 < L.w) {
+            v = *reinterpret_cast<const uint32_t *>(row + gx0);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t) row[min(max(gx0 + k, 0), L.w - 1)] << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(g + ly * GW + 4 * dq) = v;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
