@@ -10,11 +10,11 @@ pytestmark = pytest.mark.gpu
 W, H = 640, 480
 
 
-def _camera(seed, n_pts, n_corr, frames=3, outlier_frac=0.15):
+def _camera(seed, n_pts, n_corr, frames=3, outlier_frac=0.15, w=W, h=H):
     import torch
-    fr = torch.from_numpy(synth.stream_rgba(W, H, frames, seed=seed, noise=True)).cuda()
+    fr = torch.from_numpy(synth.stream_rgba(w, h, frames, seed=seed, noise=True)).cuda()
     rng = np.random.RandomState(seed)
-    pts = torch.from_numpy(rng.uniform(40, [W - 40, H - 40], (n_pts, 2)).astype(np.float32)).cuda() if n_pts else None
+    pts = torch.from_numpy(rng.uniform(40, [w - 40, h - 40], (n_pts, 2)).astype(np.float32)).cuda() if n_pts else None
     pb = synth.make_pnp_problem(max(n_corr, 8), seed + 100, outlier_frac=outlier_frac)
     bv, uv, wp = (torch.from_numpy(pb[k][:n_corr].copy()).cuda() for k in ("bv", "uv", "wpt"))
     return dict(frames=fr, pts=pts, bv=bv, uv=uv, wp=wp)
@@ -151,6 +151,35 @@ def test_batch_with_detector_equals_single_cameras(ctx):
             if k > 0:
                 assert torch.equal(d["match_idx"], r["match_idx"]) and torch.equal(d["match_dist"], r["match_dist"]), (k, i)
                 assert int((d["match_dist"] >= 0).sum()) == nkp1
+    for f in fes:
+        f.close()
+    tb.close()
+
+
+def test_batch_720p_with_detector(ctx):
+    """BASELINE configs[2] geometry (1280x720): two cameras, detector lane on, against their own alva_frontend_track"""
+    import torch
+    import alvaar_amd
+    w, h = 1280, 720
+    K = synth.make_pnp_problem(8, 1)["K"]
+    cams = [_camera(61 + i, 700, 500, frames=3, w=w, h=h) for i in range(2)]
+    tb = alvaar_amd.TrackBatch(0, w, h, 2, 700, 500)
+    tb.enable_detector(1000)
+    tb.bind([c["pts"] for c in cams], [c["bv"] for c in cams], [c["uv"] for c in cams], [c["wp"] for c in cams])
+    fes = [alvaar_amd.Frontend(0, w, h, 700, 1000) for _ in range(2)]
+    for k in range(3):
+        st, poses = tb.step([c["frames"][k] for c in cams], K)
+        st, poses, nkp = st.copy(), poses.copy(), tb.nkp.copy()
+        for i, c in enumerate(cams):
+            st1, pose1, nkp1 = fes[i].track(c["frames"][k], c["pts"], c["bv"], c["uv"], c["wp"], K)
+            assert st[i] == st1 == 2 and nkp[i] == nkp1 and np.array_equal(poses[i], pose1), (k, i)
+            fes[i].sync()
+            r, d = fes[i].results(), tb.detections(i)
+            assert torch.equal(d["keypoints"], r["keypoints"]) and torch.equal(d["descriptors"], r["descriptors"]), (k, i)
+            if k > 0:
+                tr, ok = tb.results(i)
+                assert torch.equal(tr, r["tracked"]) and torch.equal(ok, r["status"]), (k, i)
+                assert torch.equal(d["match_idx"], r["match_idx"]) and torch.equal(d["match_dist"], r["match_dist"]), (k, i)
     for f in fes:
         f.close()
     tb.close()
