@@ -339,8 +339,14 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
     alg = cameras * (11.64 + (1 + 2 * 3.27 + 2 * 3.27 if detector else 0)) * W * H   # + gray copy, ORB pyramid w+r, blur r+w (L8 = 3.27 P)
     steps_done, fallbacks = tb.stats()
     tb.close()
+    traffic = None   # HBM bytes per step from the PMC counters of the 64-camera step with the detector lane (two --pmc passes, tools/frame_step_pmc.py)
+    tfile = ROOT / "profiles" / "r02c_pmc_traffic_frame_step64.json"
+    if detector and cameras == 64 and tfile.exists():
+        per_step = {"k_pyr_stage_batch": 4, "k_resize_b": 7}
+        traffic = int(sum(v["hbm_bytes_per_launch"] * per_step.get(k, 1) for k, v in json.loads(tfile.read_text())["kernels"].items()
+                          if "rocclr" not in k))
     return dict(cameras=cameras, detector=detector, launches_per_step=24 if detector else 10, ms_per_step=dt * 1e3, frames_per_s=cameras / dt, poses_accepted_frac=ok / (reps * cameras),
-                single_camera_fallbacks=fallbacks, kernel_us_per_step=kernel_us, alg_bytes_per_step=int(alg),
+                single_camera_fallbacks=fallbacks, kernel_us_per_step=kernel_us, alg_bytes_per_step=int(alg), hbm_traffic_bytes_per_step_pmc=traffic,
                 achieved_GBps=alg / dt / 1e9, hbm_frac=alg / dt / 1e9 / HBM_PEAK_GBS,
                 kernels={n: {"avg_us": round(v[1], 2), "launches_per_step": round(v[0] / 3, 2)} for n, v in kt.items()},
                 note="whole alva_track_batch_step calls (pointer tables, argument copy, 10 launches on two streams, one synchronisation per stream, pose decode); "
