@@ -6,11 +6,12 @@
 // independent streams run into the launch path of the runtime.  A rig of cameras (or a server tracking many
 // sessions) has a data-parallel dimension the reference cannot use: here it becomes the grid's y / z dimension.
 //
-//   preprocessImage  x B   alva_pyramid_build_from_rgba_batch       5 launches   (image.hip)     image lane
-//   kltTracking      x B   k_klt_batch_g                            1 launch     (klt.hip)       image lane
-//   computePose      x B   k_p3p_batch -> k_pnp_batch               2 launches   (p3p.hip, pnp.hip)  pose lane (second HIP stream)
+//   preprocessImage  x B   alva_pyramid_build_from_rgba_batch                      5 launches   (image.hip)
+//   kltTracking      x B   k_klt_batch_q                                           1 launch     (klt.hip)
+//   computePose      x B   k_p3p_hyp_batch -> k_p3p_batch -> k_p3p_select_batch -> k_pnp_batch   4 launches   (p3p.hip, pnp.hip)
 //
-// and one host wait per lane for the B poses.  Every camera keeps its own pyramids, keypoints, correspondences and counts; the
+// in stream order on one HIP stream (the pose is solved from what the tracker has just moved), one host wait for the B poses; the
+// optional detector lane (cv::ORB + Hamming match per camera, 14 launches) runs on a second stream beside the tracker + pose chain.  Every camera keeps its own pyramids, keypoints, correspondences and counts; the
 // device code of a camera is the single-camera code (klt_point / p3p_block / pnp_block), so results are bit-identical to B calls of
 // alva_frontend_track (tests/test_gpu_track_batch.py).
 #include "common.hpp"
@@ -48,7 +49,7 @@ size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct alva_track_batch {
     int device = 0, width = 0, height = 0, B = 0, n_track = 0, n_corr = 0, klt_levels = 3, klt_lanes = 5;
-    alva_ctx *ctx = nullptr, *pose = nullptr;  // image + tracking lane | pose lane (computePose reads nothing the tracker writes)
+    alva_ctx *ctx = nullptr;  // tracker lane: pyramids -> KLT -> P3P -> PnP
     std::vector<alva_pyramid *> pyr[2];
     uint8_t *slab = nullptr;      // per camera: tracked | status | p3p scratch | selection | inlier mask | pnp scratch; then counters
     size_t cam_stride = 0, off_status = 0, off_p3p = 0, off_sel = 0, off_inl = 0, off_pnp = 0;
@@ -73,7 +74,6 @@ extern "C" void alva_track_batch_destroy(alva_track_batch *tb) {
     if (!tb) return;
     (void) hipSetDevice(tb->device);
     if (tb->ctx) (void) alva_ctx_sync(tb->ctx);
-    if (tb->pose && tb->pose != tb->ctx) (void) alva_ctx_sync(tb->pose);
     for (auto &v: tb->pyr)
         for (auto p: v)
             if (p) alva_pyramid_destroy(p);
@@ -87,7 +87,6 @@ extern "C" void alva_track_batch_destroy(alva_track_batch *tb) {
     if (tb->d_items) (void) hipFree(tb->d_items);
     if (tb->h_items) (void) hipHostFree(tb->h_items);
     if (tb->h_out) (void) hipHostFree(tb->h_out);
-    if (tb->pose && tb->pose != tb->ctx) alva_ctx_destroy(tb->pose);
     if (tb->ctx) alva_ctx_destroy(tb->ctx);
     delete tb;
 }
@@ -113,9 +112,6 @@ extern "C" int alva_track_batch_create(int device, int width, int height, int ca
         if (v == 5 || v == 8 || v == 16 || v == 32 || v == 64) tb->klt_lanes = v;
     }
     int rc = alva_ctx_create(device, nullptr, 1, &tb->ctx);
-    // ALVA_TRACK_BATCH_ONE_LANE=1 (measurement): pose kernels on the image lane's stream, so per-kernel times are not inflated by overlap
-    if (std::getenv("ALVA_TRACK_BATCH_ONE_LANE")) tb->pose = tb->ctx;
-    else if (!rc) rc = alva_ctx_create(device, nullptr, 1, &tb->pose);
     for (int k = 0; k < 2 && !rc; k++) {
         tb->pyr[k].assign((size_t) cameras, nullptr);
         for (int c = 0; c < cameras && !rc; c++) rc = alva_pyramid_create(tb->ctx, width, height, 9, 3, &tb->pyr[k][(size_t) c]);  // state.hpp:53-54
@@ -248,15 +244,7 @@ extern "C" int alva_track_batch_step_detect(alva_track_batch *tb, const uint8_t 
         n_corr_max = std::max(n_corr_max, n_corr[c]);
     }
     ALVA_HIP(hipMemcpyAsync(tb->d_items, tb->h_items, tb->items_bytes, hipMemcpyHostToDevice, ctx->stream));
-    // pose lane: computePose of every camera.  Its inputs are the caller's correspondences, so it runs beside the image lane
-    // (the single pose workgroup per camera and the tracker's waves fill different CUs)
-    if (n_pose > 0) {
-        rc = alva_ctx_wait(tb->pose, ctx);  // the argument blocks
-        if (!rc) rc = alva_p3p_batch_enqueue(tb->pose, tb->d_items + tb->off_items_p3p, n_pose, P3P_DRAWS, n_corr_max);
-        if (!rc) rc = alva_pnp_batch_enqueue(tb->pose, tb->d_items + tb->off_items_pnp, n_pose);
-        if (rc) return rc;
-    }
-    // image lane: preprocessImage, then kltTracking, of every camera
+    // tracker lane: preprocessImage, kltTracking, then computePose of every camera
     rc = alva_pyramid_build_from_rgba_batch(ctx, tb->pyr[cur].data(), d_rgba, rgba_pitch, tb->det ? tb->gray_ptrs.data() : nullptr,
                                             tb->det ? (size_t) tb->width : 0, B);
     if (rc) return rc;
@@ -266,6 +254,14 @@ extern "C" int alva_track_batch_step_detect(alva_track_batch *tb, const uint8_t 
     }
     rc = alva_fbklt_track_batch_enqueue(ctx, tb->d_items, B, n_pts_max, tb->klt_levels, 30.f, 0.5f, 30, 0.01f, tb->klt_lanes);  // state.hpp:55-59
     if (rc) return rc;
+    // computePose BEHIND the tracker in stream order, as in alva_frontend_track: in the reference the pose is solved from the keypoints
+    // kltTracking has just moved (visual_frontend.cpp:104-110), so the timed chain is the dependent one although the correspondence
+    // buffers are inputs of this call
+    if (n_pose > 0) {
+        rc = alva_p3p_batch_enqueue(ctx, tb->d_items + tb->off_items_p3p, n_pose, P3P_DRAWS, n_corr_max);
+        if (!rc) rc = alva_pnp_batch_enqueue(ctx, tb->d_items + tb->off_items_pnp, n_pose);
+        if (rc) return rc;
+    }
     if (tb->det) {
         // detector lane: detect + describe every camera's frame, then match against the camera's previous descriptors with the new
         // counts still on the device
@@ -302,7 +298,6 @@ extern "C" int alva_track_batch_step_detect(alva_track_batch *tb, const uint8_t 
         }
     }
     ALVA_HIP(hipStreamSynchronize(ctx->stream));
-    if (n_pose > 0) ALVA_HIP(hipStreamSynchronize(tb->pose->stream));
     for (int c = 0; c < B; c++) {
         if (tb->slot[(size_t) c] < 0) continue;
         int more = 0;

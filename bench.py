@@ -349,7 +349,7 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
                 single_camera_fallbacks=fallbacks, kernel_us_per_step=kernel_us, alg_bytes_per_step=int(alg), hbm_traffic_bytes_per_step_pmc=traffic,
                 achieved_GBps=alg / dt / 1e9, hbm_frac=alg / dt / 1e9 / HBM_PEAK_GBS,
                 kernels={n: {"avg_us": round(v[1], 2), "launches_per_step": round(v[0] / 3, 2)} for n, v in kt.items()},
-                note="whole alva_track_batch_step calls (pointer tables, argument copy, 10 launches on two streams, one synchronisation per stream, pose decode); "
+                note="whole alva_track_batch_step calls (pointer tables, argument copy, 10 launches in stream order (+ 14 of the detector lane on a second stream), one synchronisation per stream, pose decode); "
                      "achieved = algorithmic image bytes / wall time of the step, not / kernel time")
 
 
