@@ -376,8 +376,8 @@ int alva_fbklt_track_batch(alva_ctx *ctx, const alva_pyramid *const *prev, const
 /* ---- a1 for a rig: VisualFrontend::trackMono of B lock-step cameras, one launch per stage for all of them ----------------
  * The per-frame path of src/slam/src/visual_frontend.cpp:83-150 -- preprocessImage (:672-698), kltTracking (:152-243),
  * computePose (:245-417); the detector is the keyframe branch's, not this path's -- for `cameras` independent cameras that deliver
- * their frames together: 5 launches build all gray images + LK pyramids, 1 launch tracks every camera's keypoints, 2 launches solve
- * every camera's P3P-LMedS -> PnP, and one host synchronisation returns the poses.  Each camera has its own frame, keypoints
+ * their frames together: 5 launches build all gray images + LK pyramids, 1 launch tracks every camera's keypoints, 4 launches solve
+ * every camera's P3P-LMedS -> PnP behind it, and one host synchronisation returns the poses.  Each camera has its own frame, keypoints
  * (n_pts[c] <= max_tracked), correspondences (n_corr[c] <= max_corr <= 7168) and state; results are identical to `cameras`
  * alva_frontend_track calls.  d_rgba / d_pts / d_bearings / d_uv / d_wpts are host arrays of `cameras` device pointers;
  * h_pose7 is [cameras][7] (written where status >= 1 and the solver produced a pose), h_pose_status [cameras] as alva_compute_pose. */
