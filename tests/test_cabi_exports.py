@@ -30,3 +30,16 @@ def test_no_cpu_fallback_without_device():
     except alvaar_amd.AlvaError:
         return
     raise AssertionError("Context() must fail loudly without a HIP device")
+
+
+def test_batched_driver_has_no_cpu_fallback_either():
+    import torch
+    import alvaar_amd
+    if torch.cuda.is_available():
+        return
+    for make in (lambda: alvaar_amd.TrackBatch(0, 640, 480, 4, 100, 100), lambda: alvaar_amd.Frontend(0, 640, 480, 100, 500)):
+        try:
+            make()
+        except alvaar_amd.AlvaError:
+            continue
+        raise AssertionError("the drivers must fail loudly without a HIP device")
