@@ -208,12 +208,17 @@ __device__ __forceinline__ void blur7_tile4(const uint8_t *__restrict__ src, siz
     }
 }
 
-__global__ void __launch_bounds__(256) k_blur7_multi(const BlurBatch *__restrict__ Bs) {
+__global__ void __launch_bounds__(256) k_blur7_multi(const BlurBatch *__restrict__ Bs, int n_levels) {
     const BlurBatch &B = Bs[blockIdx.z];
-    const int l = blockIdx.y;
-    const int tilesX = (B.w[l] + BT_W - 1) / BT_W, tilesY = (B.h[l] + BT_H - 1) / BT_H;
-    if ((int) blockIdx.x >= tilesX * tilesY) return;
-    blur7_tile4(B.src[l], (size_t) B.pitch[l], B.w[l], B.h[l], B.dst[l], (size_t) B.pitch[l], blockIdx.x % tilesX, blockIdx.x / tilesX);
+    int t = blockIdx.x, l = 0, tilesX = 1;  // blockIdx.x runs over the tiles of all levels
+    for (; l < n_levels; l++) {
+        tilesX = (B.w[l] + BT_W - 1) / BT_W;
+        const int nt = tilesX * ((B.h[l] + BT_H - 1) / BT_H);
+        if (t < nt) break;
+        t -= nt;
+    }
+    if (l == n_levels) return;
+    blur7_tile4(B.src[l], (size_t) B.pitch[l], B.w[l], B.h[l], B.dst[l], (size_t) B.pitch[l], t % tilesX, t / tilesX);
 }
 
 size_t alva_blur7_batch_size() { return sizeof(BlurBatch); }
@@ -228,14 +233,14 @@ int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *
         B.h[l] = h[l];
         B.pitch[l] = pitch[l];
         if (pitch[l] % 4 || ((uintptr_t) src[l] % 4) || ((uintptr_t) dst[l] % 4)) return -1;  // blur7_tile4 moves dwords
-        maxTiles = std::max(maxTiles, alva_divup(w[l], BT_W) * alva_divup(h[l], BT_H));
+        maxTiles += alva_divup(w[l], BT_W) * alva_divup(h[l], BT_H);   // total over the levels
     }
     memcpy(out, &B, sizeof(B));
     return maxTiles;
 }
 
-int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int max_tiles) {
-    hipLaunchKernelGGL(k_blur7_multi, dim3(max_tiles, n_levels, count), dim3(256), 0, ctx->stream, (const BlurBatch *) d_batches);
+int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles) {
+    hipLaunchKernelGGL(k_blur7_multi, dim3(total_tiles, 1, count), dim3(256), 0, ctx->stream, (const BlurBatch *) d_batches, n_levels);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

@@ -25,7 +25,7 @@ int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uin
 
 size_t alva_blur7_batch_size();
 int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h, const int *pitch);
-int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int max_tiles);
+int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles);
 
 namespace {
 
@@ -260,11 +260,11 @@ __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
 // computed with dense lanes, scores stay in LDS, NMS survivors are packed per row by ballot and appended to the level's
 // candidate list with ONE atomic per tile.  No score map in HBM, no count/scan/emit passes.  The list order depends on
 // tile completion order; every later stage is order-free (threshold culls) and k_cull_harris finally sorts by position.
-__device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
-    const Level &L = D.lv[blockIdx.y];
+__device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, const int tile) {
+    const Level &L = D.lv[lvl];
     const int tilesX = (L.w + FT_W - 1) / FT_W, tilesY = (L.h + FT_H - 1) / FT_H;
-    if ((int) blockIdx.x >= tilesX * tilesY) return;
-    const int x0 = (blockIdx.x % tilesX) * FT_W, y0 = (blockIdx.x / tilesX) * FT_H;
+    if ((int) tile >= tilesX * tilesY) return;
+    const int x0 = (tile % tilesX) * FT_W, y0 = (tile / tilesX) * FT_H;
     // candidates live in [border, dim - border): tiles wholly outside (+1 px for the NMS neighbours) have nothing to do
     const int lo = max(L.border, 3), hx = L.w - lo, hy = L.h - lo;
     if (x0 >= hx || x0 + FT_W <= lo || y0 >= hy || y0 + FT_H <= lo) return;
@@ -372,7 +372,7 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
             s_row[r] = tot;
             tot += c;
         }
-        s_base = tot ? atomicAdd(&D.n1[blockIdx.y], tot) : 0;
+        s_base = tot ? atomicAdd(&D.n1[lvl], tot) : 0;
     }
     __syncthreads();
 #pragma unroll
@@ -384,14 +384,24 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D) {
                 D.c1x[L.candOff + pos] = x0 + lane;
                 D.c1y[L.candOff + pos] = y0 + r;
                 D.c1s[L.candOff + pos] = myscore[it];
-                atomicAdd(&D.hist[blockIdx.y * 256 + myscore[it]], 1);
+                atomicAdd(&D.hist[lvl * 256 + myscore[it]], 1);
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) { fast_nms_body(D); }
-__global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items) { fast_nms_body(items[blockIdx.z].D); }
+__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) { fast_nms_body(D, blockIdx.y, blockIdx.x); }
+// batched: blockIdx.x runs over the tiles of ALL levels (a grid sized for level 0 on every level would be 60 % empty workgroups)
+__global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items) {
+    const OrbDev &D = items[blockIdx.z].D;
+    int t = blockIdx.x, l = 0;
+    for (; l < D.nlevels; l++) {
+        const int nt = ((D.lv[l].w + FT_W - 1) / FT_W) * ((D.lv[l].h + FT_H - 1) / FT_H);
+        if (t < nt) break;
+        t -= nt;
+    }
+    if (l < D.nlevels) fast_nms_body(D, l, t);
+}
 
 __device__ __forceinline__ bool nms_keep(const uint8_t *sc, int pitch, int x, int y, const Level &L) {
     if (x < 3 || x >= L.w - 3 || y < 3 || y >= L.h - 3) return false;
@@ -1085,9 +1095,11 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
     hipLaunchKernelGGL(k_copy_level0_b, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4), count), dim3(256), 0, st, items);
     for (int l = 1; l < D0.nlevels; l++)
         hipLaunchKernelGGL(k_resize_b, dim3(alva_divup(D0.lv[l].w, 256), alva_divup(D0.lv[l].h, 4), count), dim3(256), 0, st, items, l);
-    hipLaunchKernelGGL(k_fast_nms_b, dim3(orbs[0]->maxTiles, D0.nlevels, count), dim3(256), 0, st, items);
+    int fastTiles = 0;
+    for (int l = 0; l < D0.nlevels; l++) fastTiles += alva_divup(D0.lv[l].w, FT_W) * alva_divup(D0.lv[l].h, FT_H);
+    hipLaunchKernelGGL(k_fast_nms_b, dim3(fastTiles, 1, count), dim3(256), 0, st, items);
     hipLaunchKernelGGL(k_cull_fast_b, dim3(D0.nlevels, 1, count), dim3(1024), 0, st, items);
-    hipLaunchKernelGGL(k_harris_b, dim3(256, D0.nlevels, count), dim3(256), 0, st, items);
+    hipLaunchKernelGGL(k_harris_b, dim3(64, D0.nlevels, count), dim3(256), 0, st, items);   // wave-strided loop, as k_harris
     hipLaunchKernelGGL(k_cull_harris_b, dim3(D0.nlevels, 1, count), dim3(1024), 0, st, items);
     int maxKeep = 0, nmax = 0;
     for (int l = 0; l < D0.nlevels; l++) {
