@@ -30,6 +30,14 @@ class Shard:
         return 7 + self.rank
 
 
+def rig_cameras(n_cameras: int, shard: Shard) -> range:
+    """cameras of a rig that this rank steps through alva_track_batch_* (block partition, first ranks one more when it does not
+    divide): the cameras are independent, so a rig shards over the GPUs like streams do -- no collective on the data path"""
+    base, extra = divmod(n_cameras, shard.world)
+    start = shard.rank * base + min(shard.rank, extra)
+    return range(start, start + base + (1 if shard.rank < extra else 0))
+
+
 def shard_from_env() -> Shard:
     return Shard(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
 

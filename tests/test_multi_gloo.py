@@ -64,3 +64,12 @@ def test_single_process_paths_need_no_process_group():
     assert multi.aggregate_rate(10, 2.0) == 5.0
     rec = multi.pack_records(0, np.arange(2, dtype=np.int32), np.zeros((2, 3)), np.zeros((2, 32), np.uint8), 4)
     assert multi.all_gather_map(rec) is rec
+
+
+def test_rig_cameras_partition():
+    from alvaar_amd import multi
+    for n in (1, 7, 8, 64, 100):
+        for world in (1, 2, 3, 8):
+            parts = [multi.rig_cameras(n, multi.Shard(r, world, r)) for r in range(world)]
+            assert [c for p in parts for c in p] == list(range(n))          # every camera exactly once, in order
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
