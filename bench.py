@@ -289,7 +289,7 @@ def bench_batched_preprocess(device: int, cameras: int = 64, reps: int = 20):
                 note="event-timed kernels of alva_pyramid_build_from_rgba_batch; achieved = algorithmic bytes / sum of kernel times")
 
 
-def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed: int = 7, detector: bool = False):
+def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed: int = 7, detector: bool = False, orb_features: int = 2000):
     """Secondary lines: `cameras` lock-step cameras through alva_track_batch_step.  detector=False ("track_mono_batch"):
     VisualFrontend::trackMono (preprocessImage -> kltTracking -> computePose; the detector belongs to the keyframe branch).
     detector=True ("frame_step_batch"): the headline's full stage list per camera -- the above plus cv::ORB detectAndCompute(2000) and
@@ -315,7 +315,7 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
     frames = [rings[c % nsrc].clone() for c in range(cameras)]
     tb = alvaar_amd.TrackBatch(device, W, H, cameras, NKP, NKP)
     if detector:
-        tb.enable_detector(2000)   # + cv::ORB detectAndCompute(2000) and the Hamming match per camera: the headline's full stage list
+        tb.enable_detector(orb_features)   # + cv::ORB detectAndCompute(2000) and the Hamming match per camera: the headline's full stage list
     tb.bind([pts[c % nsrc] for c in range(cameras)], [bv[c % nsrc] for c in range(cameras)], [uv[c % nsrc] for c in range(cameras)],
             [wp[c % nsrc] for c in range(cameras)])
     tables = [tb.frame_table([f[r] for f in frames]) for r in range(RING)]   # the resident frames' pointer tables, built once
