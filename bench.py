@@ -18,6 +18,12 @@ description of those points; a5 + a6) is timed as well and reported as "ref_dete
 The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3000 pts, 5 LM iterations), is
 measured in the same run and reported under "local_ba".
 
+Secondary lines for a RIG of lock-step cameras on the one GPU (alva_track_batch_*: one launch per stage for all cameras, every camera
+bit-identical to its own single-camera call): "track_mono_batch" (pyramid -> KLT -> pose per camera) and "frame_step_batch" (the
+stage list above per camera, i.e. B times the headline's work) at 16 and 64 cameras, with the PMC-measured HBM traffic of the
+64-camera step; "batched_preprocess" (gray + pyramid of 64 cameras in five launches).  `value` stays the ONE-stream rate: configs[1]
+is one stream per GPU.  --multi-stream adds the older measurement with 4 / 16 host threads driving independent streams.
+
 Also reported: "roofline" for the dominant kernel (HIP-event timed on the launch stream) and "cpu_baseline"
 (the compiled reference, oracle/_ref, timed on the host on a bounded sample of the same workload; falls back to
 the C restatement, kind "port", when the reference library is absent).
