@@ -30,10 +30,10 @@ struct MtmArgs {
     const double *kfQ, *kfT;
     int nMp;
     const double *mpWpt;
-    const uint8_t *mpIs3d;
+    const uint8_t *mpIs3d, *mpHasDesc;  // mpHasDesc / obsHasDesc may be NULL: every observation carries a descriptor
     const int *obsPtr, *obsKf;
     const float *obsPx;
-    const uint8_t *obsDesc;
+    const uint8_t *obsDesc, *obsHasDesc;
     int frameKf, nLocal;
     const int *local;
     float maxPxDist, minDist, viewTh;
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_match_local(MtmArgs A) {
     int outKp = -1;
     float outDist = 0.f;
     // wave-uniform gates (:393-433)
-    bool go = A.frameObs[M] < 0 && A.mpIs3d[M] && A.obsPtr[M] != A.obsPtr[M + 1];
+    bool go = A.frameObs[M] < 0 && A.mpIs3d[M] && (A.mpHasDesc ? A.mpHasDesc[M] != 0 : A.obsPtr[M] != A.obsPtr[M + 1]);
     double wpt[3] = {0, 0, 0}, campt[3];
     float pu = 0.f, pv = 0.f;
     if (go) {
@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(256) k_match_local(MtmArgs A) {
                 const int ko = A.frameObs[K];
                 const float pxDist = norm2f(pu - A.obsPx[2 * (size_t) ko], pv - A.obsPx[2 * (size_t) ko + 1]);
                 bool cand = !(pxDist > A.maxPxDist);
+                if (A.mpHasDesc && !A.mpHasDesc[K]) cand = false;  // kpMapPoint->desc_.empty() (:465-468)
                 const int ka = A.obsPtr[K], kb = A.obsPtr[K + 1], ma = A.obsPtr[M], mb = A.obsPtr[M + 1];
                 if (cand)  // never both observed in one keyframe (:474-485)
                     for (int a = ka; a < kb && cand; a++)
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(256) k_match_local(MtmArgs A) {
                     int dmin = 1000;
                     for (int a = ma; a < mb; a++)
                         for (int b = ka; b < kb; b++)
-                            dmin = min(dmin, hamming256(reinterpret_cast<const uint4 *>(A.obsDesc + 32 * (size_t) a),
+                            if (!A.obsHasDesc || (A.obsHasDesc[a] && A.obsHasDesc[b]))
+                                dmin = min(dmin, hamming256(reinterpret_cast<const uint4 *>(A.obsDesc + 32 * (size_t) a),
                                                         reinterpret_cast<const uint4 *>(A.obsDesc + 32 * (size_t) b)));
                     dist = (float) dmin;
                     valid = dist <= A.minDist;  // larger distances fail both `<=` tests of the scan (:519-531)
@@ -221,6 +223,17 @@ extern "C" int alva_match_to_map(alva_ctx *ctx, const double *h_calib10, int cel
                                  const uint8_t *d_mp_is3d, const int *d_obs_ptr, const int *d_obs_kf, const float *d_obs_px,
                                  const uint8_t *d_obs_desc, int frame_kf, int num_keypoints_3d, int n_local, const int *d_local,
                                  float max_proj_err, float dist_ratio, int *d_match_of_mp) {
+    return alva_match_to_map_flags(ctx, h_calib10, cell_size, num_cells_w, grid_cells, d_cell_ptr, d_cell_mp, n_kf, d_kf_q, d_kf_t, n_mp, d_mp_wpt,
+                                   d_mp_is3d, nullptr, d_obs_ptr, d_obs_kf, d_obs_px, d_obs_desc, nullptr, frame_kf, num_keypoints_3d, n_local,
+                                   d_local, max_proj_err, dist_ratio, d_match_of_mp);
+}
+
+extern "C" int alva_match_to_map_flags(alva_ctx *ctx, const double *h_calib10, int cell_size, int num_cells_w, int grid_cells,
+                                       const int *d_cell_ptr, const int *d_cell_mp, int n_kf, const double *d_kf_q, const double *d_kf_t, int n_mp,
+                                       const double *d_mp_wpt, const uint8_t *d_mp_is3d, const uint8_t *d_mp_has_desc, const int *d_obs_ptr,
+                                       const int *d_obs_kf, const float *d_obs_px, const uint8_t *d_obs_desc, const uint8_t *d_obs_has_desc,
+                                       int frame_kf, int num_keypoints_3d, int n_local, const int *d_local, float max_proj_err,
+                                       float dist_ratio, int *d_match_of_mp) {
     ALVA_ARG(ctx && h_calib10 && cell_size > 0 && num_cells_w > 0 && grid_cells > 0 && n_kf > 0 && n_mp >= 0 && n_local >= 0);
     ALVA_ARG(frame_kf >= 0 && frame_kf < n_kf);
     if (n_mp == 0) return ALVA_OK;
@@ -230,6 +243,7 @@ extern "C" int alva_match_to_map(alva_ctx *ctx, const double *h_calib10, int cel
     for (int i = 0; i < 10; i++) A.calib[i] = h_calib10[i];
     A.cellSize = cell_size; A.numCellsW = num_cells_w; A.gridCells = grid_cells;
     A.cellPtr = d_cell_ptr; A.cellMp = d_cell_mp; A.kfQ = d_kf_q; A.kfT = d_kf_t;
+    A.mpHasDesc = d_mp_has_desc; A.obsHasDesc = d_obs_has_desc;
     A.nMp = n_mp; A.mpWpt = d_mp_wpt; A.mpIs3d = d_mp_is3d; A.obsPtr = d_obs_ptr; A.obsKf = d_obs_kf; A.obsPx = d_obs_px; A.obsDesc = d_obs_desc;
     A.frameKf = frame_kf; A.nLocal = n_local; A.local = d_local;
     // thresholds exactly as the reference forms them (:364-387, :439): floats, atanf / cosf of the host libm

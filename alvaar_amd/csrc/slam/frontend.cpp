@@ -1,0 +1,397 @@
+// Per-frame state machine of the host-side map layer: the behaviour of System::processCameraPose (src/slam/src/system.cpp:156-175)
+// and VisualFrontend (src/slam/src/visual_frontend.cpp) of the reference, with every numeric stage behind `Stages`.
+#include "slam.hpp"
+#include <cmath>
+#include <cstring>
+
+namespace alva_slam {
+
+Slam::Slam(Stages *stages, const Camera &c, const Settings &s) : st(stages), cam(c), cfg(s) {
+    // State::State (state.cpp:3-12)
+    const float cw = std::ceil((float) cam.width / (float) cfg.cell_size), ch = std::ceil((float) cam.height / (float) cfg.cell_size);
+    cfg.max_keypoints = (int) (cw * ch);
+    // CameraCalibration: inverseK_ = K_.inverse() (camera_calibration.cpp:15) -- cofactor form of a 3x3 inverse
+    const double K[9] = {cam.fx, 0, cam.cx, 0, cam.fy, cam.cy, 0, 0, 1};
+    const double c00 = K[4] * K[8] - K[5] * K[7], c10 = K[5] * K[6] - K[3] * K[8], c20 = K[3] * K[7] - K[4] * K[6];
+    const double det = c00 * K[0] + c10 * K[1] + c20 * K[2], id = 1.0 / det;
+    invK[0] = c00 * id;
+    invK[1] = (K[2] * K[7] - K[1] * K[8]) * id;
+    invK[2] = (K[1] * K[5] - K[2] * K[4]) * id;
+    invK[3] = c10 * id;
+    invK[4] = (K[0] * K[8] - K[2] * K[6]) * id;
+    invK[5] = (K[2] * K[3] - K[0] * K[5]) * id;
+    invK[6] = c20 * id;
+    invK[7] = (K[1] * K[6] - K[0] * K[7]) * id;
+    invK[8] = (K[0] * K[4] - K[1] * K[3]) * id;
+    cur = std::make_shared<FrameRec>();
+    cur->init(&cam, (size_t) cfg.cell_size);
+}
+
+void Slam::reset() {  // System::reset (system.cpp:42-55)
+    cur->reset();
+    // VisualFrontend::reset (visual_frontend.cpp:716-727): images, pyramids, the failure counter -- p3pReq_ and the motion model stay
+    st->reset_images();
+    pose_failed = 0;
+    // MapManager::reset (map_manager.cpp:710-722)
+    next_mp_id = next_kf_id = n_map_points = n_keyframes = 0;
+    keyframes.clear();
+    map_points.clear();
+    // State::reset (state.cpp:14-18)
+    ready_for_init = false;
+    reset_requested = false;
+}
+
+int Slam::process_frame(const uint8_t *rgba, double timestamp) {  // system.cpp:156-175
+    err_ = 0;
+    cur->id++;
+    cur->timestamp = timestamp;
+    track(rgba, timestamp);
+    if (err_) return err_;
+    if (reset_requested) {
+        reset();
+        return 2;
+    }
+    if (!ready_for_init) return 3;
+    return 1;
+}
+
+bool Slam::track(const uint8_t *rgba, double timestamp) {  // visual_frontend.cpp:21-35
+    if (fail(st->new_frame(rgba))) return false;  // cvtColor (system.cpp:112) + preprocessImage (:672-698)
+    const bool kf_required = process(timestamp);
+    if (err_) return false;
+    if (kf_required) {
+        create_keyframe();
+        if (err_) return false;
+        if (!reset_requested && ready_for_init) process_new_keyframe(cur->kfid);
+    }
+    return true;
+}
+
+bool Slam::process(double timestamp) {  // visual_frontend.cpp:37-101
+    if (cur->id == 0) return true;
+    SE3 Twc = cur->Twc;
+    apply_motion_model(Twc, timestamp);
+    cur->set_Twc(Twc);
+    klt_from_motion_prior();
+    if (err_) return false;
+    if (!ready_for_init) {
+        if (cur->n_2d < 50) {
+            reset_requested = true;
+            return false;
+        }
+        if (check_ready_for_init()) {
+            ready_for_init = true;
+            return true;
+        }
+        return false;
+    }
+    const bool ok = compute_pose();
+    if (err_) return false;
+    if (!ok) {
+        pose_failed++;
+        if (pose_failed > 3) {
+            reset_requested = true;
+            return false;
+        }
+    }
+    update_motion_model(cur->Twc, timestamp);
+    return check_new_keyframe_required();
+}
+
+void Slam::apply_motion_model(SE3 &Twc, double time) {  // visual_frontend.hpp:17-31
+    if (mm_prev_time > 0) {
+        double xi[6];
+        se3_log(se3_mul(Twc, se3_inverse(mm_prev_Twc)), xi);
+        bool zero = true;  // Eigen's isZero(1e-5) on a 6-vector: every |x_i| <= 1e-5 (reference value 1)
+        for (double v: xi) zero = zero && std::fabs(v) <= 1e-5;
+        if (!zero) mm_prev_Twc = Twc;
+        const double dt = time - mm_prev_time;
+        double d[6];
+        for (int i = 0; i < 6; i++) d[i] = mm_log_rel[i] * dt;
+        Twc = se3_mul(Twc, se3_exp(d));
+    }
+}
+
+void Slam::update_motion_model(const SE3 &Twc, double time) {  // visual_frontend.hpp:33-58
+    if (mm_prev_time < 0.) {
+        mm_prev_time = time;
+        mm_prev_Twc = Twc;
+    } else {
+        const double dt = time - mm_prev_time;
+        mm_prev_time = time;
+        // the reference exits the process on dt < 0 (visual_frontend.hpp:46-50); a library must not: report a reset instead
+        if (dt < 0.) {
+            reset_requested = true;
+            return;
+        }
+        double xi[6];
+        se3_log(se3_mul(se3_inverse(mm_prev_Twc), Twc), xi);
+        for (int i = 0; i < 6; i++) mm_log_rel[i] = xi[i] / dt;
+        mm_prev_Twc = Twc;
+    }
+}
+
+void Slam::klt_from_motion_prior() {  // visual_frontend.cpp:103-243
+    std::vector<int> ids3d, ids;
+    std::vector<float> kps3d, priors3d, kps, priors;
+    // projections of the 3-D keypoints' map points with the predicted pose, in container order
+    std::vector<int> cand;
+    std::vector<double> cam_pts;
+    if (cfg.klt_use_prior) {
+        for (const auto &e: cur->kps) {
+            if (!e.second.is3d) continue;
+            const MapPt &mp = *map_points.at(e.second.id);
+            double pc[3];
+            se3_apply(cur->Tcw, mp.X, pc);
+            cand.push_back(e.second.id);
+            cam_pts.insert(cam_pts.end(), pc, pc + 3);
+        }
+    }
+    std::vector<float> proj(cand.size() * 2);
+    if (!cand.empty() && fail(st->project_dist((int) cand.size(), cam_pts.data(), proj.data()))) return;
+    size_t ci = 0;
+    for (const auto &e: cur->kps) {
+        const KeyPt &k = e.second;
+        if (cfg.klt_use_prior && k.is3d) {
+            const float *p = &proj[2 * ci++];
+            if (cur->in_image(p)) {
+                kps3d.insert(kps3d.end(), k.px, k.px + 2);
+                priors3d.insert(priors3d.end(), p, p + 2);
+                ids3d.push_back(k.id);
+                continue;
+            }
+        }
+        ids.push_back(k.id);
+        kps.insert(kps.end(), k.px, k.px + 2);
+        priors.insert(priors.end(), k.px, k.px + 2);
+    }
+    // results are applied after both passes with ONE compute_keypoints call; the frame is not read in between
+    std::vector<int> upd_ids;
+    std::vector<float> upd_px;
+    std::vector<int> removed;
+    if (cfg.klt_use_prior && !priors3d.empty()) {
+        const int n = (int) ids3d.size();
+        std::vector<uint8_t> ok((size_t) n);
+        if (fail(st->fbklt(1, n, kps3d.data(), priors3d.data(), ok.data()))) return;
+        size_t good = 0;
+        for (int i = 0; i < n; i++) {
+            if (ok[(size_t) i]) {
+                upd_ids.push_back(ids3d[(size_t) i]);
+                upd_px.insert(upd_px.end(), &priors3d[2 * (size_t) i], &priors3d[2 * (size_t) i] + 2);
+                good++;
+            } else {  // retry on the full pyramid
+                ids.push_back(ids3d[(size_t) i]);
+                kps.insert(kps.end(), &kps3d[2 * (size_t) i], &kps3d[2 * (size_t) i] + 2);
+                priors.insert(priors.end(), &priors3d[2 * (size_t) i], &priors3d[2 * (size_t) i] + 2);
+            }
+        }
+        if (good < 0.33 * n) {
+            p3p_req = true;
+            priors = kps;
+        }
+    }
+    if (!kps.empty()) {
+        const int n = (int) ids.size();
+        std::vector<uint8_t> ok((size_t) n);
+        if (fail(st->fbklt(cfg.klt_levels, n, kps.data(), priors.data(), ok.data()))) return;
+        for (int i = 0; i < n; i++) {
+            if (ok[(size_t) i]) {
+                upd_ids.push_back(ids[(size_t) i]);
+                upd_px.insert(upd_px.end(), &priors[2 * (size_t) i], &priors[2 * (size_t) i] + 2);
+            } else {
+                removed.push_back(ids[(size_t) i]);
+            }
+        }
+    }
+    const int nu = (int) upd_ids.size();
+    if (nu) {
+        std::vector<float> unpx((size_t) nu * 2);
+        std::vector<double> bv((size_t) nu * 3);
+        if (fail(st->compute_keypoints(nu, upd_px.data(), unpx.data(), bv.data()))) return;
+        for (int i = 0; i < nu; i++) cur->update(upd_ids[(size_t) i], &upd_px[2 * (size_t) i], &unpx[2 * (size_t) i], &bv[3 * (size_t) i]);
+    }
+    for (int id: removed) remove_obs_from_cur(id);
+}
+
+bool Slam::compute_pose() {  // visual_frontend.cpp:245-417
+    if (cur->n_3d < 4) return false;
+    const bool do_p3p = p3p_req || cfg.p3p_enabled;
+    std::vector<double> bvs, wpts, uvs;
+    std::vector<int> ids;
+    for (const auto &e: cur->kps) {
+        const KeyPt &k = e.second;
+        if (!k.is3d) continue;
+        const std::shared_ptr<MapPt> &mp = map_points.at(k.id);
+        if (!mp) continue;
+        if (do_p3p) bvs.insert(bvs.end(), k.bv, k.bv + 3);
+        uvs.push_back((double) k.unpx[0]);
+        uvs.push_back((double) k.unpx[1]);
+        wpts.insert(wpts.end(), mp->X, mp->X + 3);
+        ids.push_back(k.id);
+    }
+    double pose7[7];
+    se3_to_pose7(cur->Twc, pose7);
+    int n = (int) ids.size();
+    std::vector<int> outliers((size_t) n + 1);
+    int n_out = 0, ok = 0;
+    if (do_p3p) {
+        if (fail(st->p3p(n, bvs.data(), wpts.data(), cfg.random_sampling ? 1 : 0, pose7, outliers.data(), &n_out, &ok))) return false;
+        const size_t inliers = (size_t) n - (size_t) (ok ? n_out : 0);
+        bool bad_t = false;
+        for (int i = 0; i < 3; i++) bad_t = bad_t || std::isinf(pose7[i]) || std::isnan(pose7[i]);
+        if (!ok || inliers < 5 || bad_t) {
+            reset_frame();
+            return false;
+        }
+        cur->set_Twc(se3_from_pose7(pose7));
+        // drop the P3P outliers before the refinement (:344-352); indices are ascending
+        std::vector<uint8_t> drop((size_t) n, 0);
+        for (int i = 0; i < n_out; i++) {
+            drop[(size_t) outliers[(size_t) i]] = 1;
+            remove_obs_from_cur(ids[(size_t) outliers[(size_t) i]]);
+        }
+        int w = 0;
+        for (int i = 0; i < n; i++)
+            if (!drop[(size_t) i]) {
+                ids[(size_t) w] = ids[(size_t) i];
+                uvs[2 * (size_t) w] = uvs[2 * (size_t) i]; uvs[2 * (size_t) w + 1] = uvs[2 * (size_t) i + 1];
+                for (int c = 0; c < 3; c++) wpts[3 * (size_t) w + c] = wpts[3 * (size_t) i + c];
+                w++;
+            }
+        n = w;
+        n_out = 0;
+    }
+    ok = 0;
+    if (fail(st->pnp(n, uvs.data(), wpts.data(), pose7, outliers.data(), &n_out, &ok))) return false;
+    const size_t inliers = (size_t) n - (size_t) n_out;
+    bool bad_t = false;
+    for (int i = 0; i < 3; i++) bad_t = bad_t || std::isinf(pose7[i]) || std::isnan(pose7[i]);
+    if (!ok || inliers < 5 || n_out > 0.5 * n || bad_t) {
+        if (!do_p3p) p3p_req = true;
+        reset_frame();
+        return false;
+    }
+    cur->set_Twc(se3_from_pose7(pose7));
+    p3p_req = false;
+    for (int i = 0; i < n_out; i++) remove_obs_from_cur(ids[(size_t) outliers[(size_t) i]]);
+    return true;
+}
+
+void Slam::reset_frame() {  // visual_frontend.cpp:700-714
+    const std::unordered_map<int, KeyPt> copy = cur->kps;
+    for (const auto &e: copy) remove_obs_from_cur(e.first);
+    cur->kps.clear();
+    cur->grid.clear();
+    cur->grid.resize(cur->grid_cells);
+    cur->n_kps = cur->n_2d = cur->n_3d = 0;
+    cur->n_occupied = 0;
+}
+
+float Slam::compute_parallax(int kfid, bool unrotate, bool median) {  // visual_frontend.cpp:596-670
+    auto kit = keyframes.find(kfid);
+    if (kit == keyframes.end()) return 0.f;
+    const FrameRec &kf = *kit->second;
+    double Rkc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (unrotate) {
+        double Rkw[9], Rwc[9];
+        quat_to_rot(kf.Tcw.q, Rkw);
+        quat_to_rot(cur->Twc.q, Rwc);
+        mat3_mul(Rkw, Rwc, Rkc);
+    }
+    float avg = 0.f;
+    int cnt = 0;
+    std::set<float> all;
+    for (const auto &e: cur->kps) {
+        const KeyPt &k = e.second;
+        const KeyPt *kk = kf.find(k.id);
+        if (!kk) continue;
+        float un[2] = {k.unpx[0], k.unpx[1]};
+        if (unrotate) {
+            double r[3];
+            mat3_vec(Rkc, k.bv, r);
+            kf.project_cam_to_image(r, un);
+        }
+        const float dx = un[0] - kk->unpx[0], dy = un[1] - kk->unpx[1];
+        const float par = (float) std::sqrt((double) dx * dx + (double) dy * dy);  // cv::norm(Point2f) -> double, stored in a float
+        avg += par;
+        cnt++;
+        if (median) all.insert(par);
+    }
+    if (!cnt) return 0.f;
+    avg /= (float) cnt;
+    if (median) {
+        auto it = all.begin();
+        std::advance(it, (long) (all.size() / 2));
+        avg = *it;
+    }
+    return avg;
+}
+
+bool Slam::check_ready_for_init() {  // visual_frontend.cpp:419-551
+    const double med = compute_parallax(cur->kfid, false, true);
+    if (med <= cfg.min_avg_rot_parallax) return false;
+    std::shared_ptr<FrameRec> kf = keyframes.at(cur->kfid);
+    if (!kf) return false;
+    if (cur->n_kps < 8) return false;
+    std::vector<int> ids;
+    std::vector<double> bv_kf, bv_cur;
+    double Rck[9], Rkw[9], Rwc[9];
+    quat_to_rot(kf->Tcw.q, Rkw);
+    quat_to_rot(cur->Twc.q, Rwc);
+    mat3_mul(Rkw, Rwc, Rck);
+    int cnt = 0;
+    float avg = 0.f;
+    for (const auto &e: cur->kps) {
+        const KeyPt &k = e.second;
+        const KeyPt *kk = kf->find(k.id);
+        if (!kk) continue;
+        bv_kf.insert(bv_kf.end(), kk->bv, kk->bv + 3);
+        bv_cur.insert(bv_cur.end(), k.bv, k.bv + 3);
+        ids.push_back(k.id);
+        double r[3], u[3];
+        mat3_vec(Rck, k.bv, r);
+        const double K[9] = {cam.fx, 0, cam.cx, 0, cam.fy, cam.cy, 0, 0, 1};
+        mat3_vec(K, r, u);
+        const float rx = (float) (u[0] / u[2]), ry = (float) (u[1] / u[2]);
+        const float dx = rx - kk->unpx[0], dy = ry - kk->unpx[1];
+        avg = (float) ((double) avg + std::sqrt((double) dx * dx + (double) dy * dy));  // float += double (visual_frontend.cpp:487)
+        cnt++;
+    }
+    if (cnt < 8) return false;
+    avg /= (float) cnt;
+    if (avg < cfg.min_avg_rot_parallax) return false;
+    const int n = (int) ids.size();
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    std::vector<int> outliers((size_t) n + 1);
+    int n_out = 0, ok = 0;
+    if (fail(st->five_point(n, bv_kf.data(), bv_cur.data(), cfg.random_sampling ? 1 : 0, R, t, outliers.data(), &n_out, &ok))) return false;
+    if (!ok) return false;
+    for (int i = 0; i < n_out; i++) remove_obs_from_cur(ids[(size_t) outliers[(size_t) i]]);
+    const double tn = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    SE3 T;
+    rot_to_quat(R, T.q);
+    for (int i = 0; i < 3; i++) T.t[i] = t[i] / tn;
+    init_computed = T;
+    // test hook: continue from a given two-view pose instead (the five-point refinement sits at a noise floor)
+    if (init_override.armed) T = se3_from_pose7(init_override.pose7);
+    cur->set_Twc(T);
+    return true;
+}
+
+bool Slam::check_new_keyframe_required() {  // visual_frontend.cpp:554-594
+    auto kit = keyframes.find(cur->kfid);
+    if (kit == keyframes.end()) return false;
+    const FrameRec &kf = *kit->second;
+    const double med = compute_parallax(kf.kfid, true, true);
+    const int id_diff = cur->id - kf.id;
+    if (id_diff >= 5 && cur->n_occupied < 0.33 * cfg.max_keypoints) return true;
+    if (id_diff >= 2 && cur->n_3d < 20) return true;
+    if (id_diff < 2 && cur->n_3d > 0.5 * cfg.max_keypoints) return false;
+    const bool cx = med >= cfg.min_avg_rot_parallax / 2.;
+    const bool c0 = med >= cfg.min_avg_rot_parallax;
+    const bool c1 = cur->n_3d < 0.75 * kf.n_3d;
+    const bool c2 = cur->n_occupied < 0.5 * cfg.max_keypoints && cur->n_3d < 0.85 * kf.n_3d;
+    return (c0 || c1 || c2) && cx;
+}
+
+}  // namespace alva_slam

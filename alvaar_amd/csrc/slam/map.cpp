@@ -1,0 +1,529 @@
+// Frame / map-point / map bookkeeping of the host-side map layer (see slam.hpp).  Mirrors the observable behaviour of
+// src/slam/src/frame.cpp, map_point.cpp and map_manager.cpp of the reference -- including the order in which the hash
+// containers are mutated, which is what fixes their iteration order.
+#include "slam.hpp"
+#include <cmath>
+#include <limits>
+
+namespace alva_slam {
+
+static inline int popcount256(const Desc &a, const Desc &b) {  // cv::norm(a, b, NORM_HAMMING) on 32 bytes (map_point.cpp:106,158,212)
+    int s = 0;
+    for (int i = 0; i < 32; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, a.b + i, 8);
+        __builtin_memcpy(&y, b.b + i, 8);
+        s += __builtin_popcountll(x ^ y);
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------- FrameRec (frame.cpp)
+void FrameRec::init(const Camera *c, size_t cell_size) {  // frame.cpp:9-21
+    cam = c;
+    cell = cell_size;
+    cells_w = (size_t) std::ceil((float) c->width / (float) cell);
+    cells_h = (size_t) std::ceil((float) c->height / (float) cell);
+    grid_cells = cells_w * cells_h;
+    n_occupied = 0;
+    grid.assign(grid_cells, {});
+}
+
+std::vector<KeyPt> FrameRec::keypoints() const {  // frame.cpp:30-39
+    std::vector<KeyPt> v;
+    v.reserve(n_kps);
+    for (const auto &e: kps) v.push_back(e.second);
+    return v;
+}
+std::vector<KeyPt> FrameRec::keypoints2d() const {  // :41-53
+    std::vector<KeyPt> v;
+    v.reserve(n_2d);
+    for (const auto &e: kps)
+        if (!e.second.is3d) v.push_back(e.second);
+    return v;
+}
+std::vector<KeyPt> FrameRec::keypoints3d() const {  // :55-67
+    std::vector<KeyPt> v;
+    v.reserve(n_3d);
+    for (const auto &e: kps)
+        if (e.second.is3d) v.push_back(e.second);
+    return v;
+}
+const KeyPt *FrameRec::find(int id_) const {
+    auto it = kps.find(id_);
+    return it == kps.end() ? nullptr : &it->second;
+}
+
+void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
+    if (kps.count(k.id)) return;
+    kps.emplace(k.id, k);
+    grid_add(k);
+    n_kps++;
+    if (k.is3d) n_3d++;
+    else n_2d++;
+}
+
+void FrameRec::update(int id_, const float *px, const float *unpx, const double *bv) {  // frame.cpp:160-174
+    auto it = kps.find(id_);
+    if (it == kps.end()) return;
+    KeyPt k = it->second;
+    k.px[0] = px[0]; k.px[1] = px[1];
+    k.unpx[0] = unpx[0]; k.unpx[1] = unpx[1];
+    k.bv[0] = bv[0]; k.bv[1] = bv[1]; k.bv[2] = bv[2];
+    const int a = cell_index(it->second.px), b = cell_index(k.px);  // updateKeypointInGrid (:296-311)
+    if (a != b) {
+        grid_remove(it->second);
+        grid_add(k);
+    }
+    it->second = k;
+}
+
+void FrameRec::set_desc(int id_, const Desc &d) {  // :176-185
+    auto it = kps.find(id_);
+    if (it == kps.end()) return;
+    it->second.desc = d;
+    it->second.has_desc = true;
+}
+
+bool FrameRec::change_id(int prev_id, int new_id, bool is3d) {  // :187-207
+    if (kps.count(new_id)) return false;
+    auto it = kps.find(prev_id);
+    if (it == kps.end()) return false;
+    KeyPt k = it->second;
+    k.id = new_id;
+    k.is3d = is3d;
+    remove(prev_id);
+    add(k);
+    return true;
+}
+
+void FrameRec::remove(int id_) {  // :209-232
+    auto it = kps.find(id_);
+    if (it == kps.end()) return;
+    grid_remove(it->second);
+    if (it->second.is3d) n_3d--;
+    else n_2d--;
+    n_kps--;
+    kps.erase(id_);
+}
+
+void FrameRec::turn3d(int id_) {  // :234-248
+    auto it = kps.find(id_);
+    if (it == kps.end()) return;
+    if (!it->second.is3d) {
+        it->second.is3d = true;
+        n_3d++;
+        n_2d--;
+    }
+}
+
+int FrameRec::cell_index(const float *px) const {  // :313-318 (float / size_t -> float division, floor)
+    const int r = (int) std::floor(px[1] / (float) cell);
+    const int c = (int) std::floor(px[0] / (float) cell);
+    return (int) ((size_t) r * cells_w + (size_t) c);
+}
+
+void FrameRec::grid_add(const KeyPt &k) {  // :255-265
+    const int idx = cell_index(k.px);
+    std::vector<int> &c = grid.at((size_t) idx);
+    if (c.empty()) n_occupied++;
+    c.push_back(k.id);
+}
+
+void FrameRec::grid_remove(const KeyPt &k) {  // :267-294
+    const int idx = cell_index(k.px);
+    if (idx < 0 || idx >= (int) grid.size()) return;
+    std::vector<int> &c = grid[(size_t) idx];
+    for (size_t i = 0; i < c.size(); i++)
+        if (c[i] == k.id) {
+            c.erase(c.begin() + (long) i);
+            if (c.empty()) n_occupied--;
+            break;
+        }
+}
+
+void FrameRec::add_covisible(int kf) {  // :348-364
+    if (kf == kfid) return;
+    auto it = covisible.find(kf);
+    if (it != covisible.end()) it->second += 1;
+    else covisible.emplace(kf, 1);
+}
+void FrameRec::remove_covisible(int kf) {  // :366-374
+    if (kf == kfid) return;
+    covisible.erase(kf);
+}
+void FrameRec::decrease_covisible(int kf) {  // :376-396
+    if (kf == kfid) return;
+    auto it = covisible.find(kf);
+    if (it != covisible.end() && it->second != 0) {
+        it->second -= 1;
+        if (it->second == 0) covisible.erase(it);
+    }
+}
+
+void FrameRec::project_cam_to_image(const double *p, float *out) const {  // camera_calibration.cpp:25-32
+    const double iz = 1. / p[2], x = p[0] * iz, y = p[1] * iz;
+    out[0] = (float) (cam->fx * x + cam->cx);
+    out[1] = (float) (cam->fy * y + cam->cy);
+}
+
+void FrameRec::reset() {  // :467-489
+    id = -1;
+    kfid = 0;
+    timestamp = 0.;
+    kps.clear();
+    grid.clear();
+    grid.resize(grid_cells);
+    n_kps = n_2d = n_3d = 0;
+    n_occupied = 0;
+    Twc = SE3();
+    Tcw = SE3();
+    covisible.clear();
+    local_map.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------- MapPt (map_point.cpp)
+void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
+    if (!obs_kfs.count(kf)) return;
+    obs_kfs.erase(kf);
+    if (obs_kfs.empty()) {
+        has_desc = false;
+        kf_desc.clear();
+        kf_desc_dist.clear();
+        return;
+    }
+    if (kf == anchor_kf) anchor_kf = *obs_kfs.begin();
+    float min_dist = (has_desc ? 32 : 0) * 8.f;  // desc_.cols * 8.
+    int min_id = -1;
+    auto itd = kf_desc.find(kf);
+    if (itd != kf_desc.end()) {
+        for (const auto &e: kf_desc) {
+            if (e.first != kf) {
+                const float dist = (float) popcount256(itd->second, e.second);
+                float &dd = kf_desc_dist.find(e.first)->second;
+                dd -= dist;
+                if (dd < min_dist) {
+                    min_dist = dd;
+                    min_id = e.first;
+                }
+            }
+        }
+        kf_desc.erase(kf);
+        kf_desc_dist.erase(kf);
+        if (min_id > 0) {  // sic: keyframe 0 is never chosen (:123)
+            desc = kf_desc.at(min_id);
+            has_desc = true;
+        }
+    }
+}
+
+void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid)
+    if (kf_desc.find(kf) != kf_desc.end()) return;
+    kf_desc.emplace(kf, d);
+    kf_desc_dist.emplace(kf, 0.f);
+    float &nd = kf_desc_dist.find(kf)->second;
+    if (kf_desc.size() == 1) {
+        desc = d;
+        has_desc = true;
+        return;
+    }
+    float min_dist = (has_desc ? 32 : 0) * 8.f;
+    int min_id = -1;
+    for (const auto &e: kf_desc) {
+        const float dist = (float) popcount256(d, e.second);
+        kf_desc_dist.at(e.first) += dist;
+        if (dist < min_dist) {
+            min_dist = dist;
+            min_id = e.first;
+        }
+        nd += dist;
+    }
+    if (nd < min_dist) min_id = kf;
+    desc = kf_desc.at(min_id);  // throws like the reference if no candidate (cannot happen with a non-empty desc_)
+    has_desc = true;
+}
+
+bool MapPt::is_bad() {  // map_point.cpp:183-202
+    if (obs_kfs.size() < 2) {
+        if (!observed && is3d) {
+            is3d = false;
+            return true;
+        }
+    }
+    if (obs_kfs.size() == 0 && !observed) {
+        is3d = false;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------- map (map_manager.cpp)
+std::shared_ptr<FrameRec> Slam::keyframe(int id) const {
+    auto it = keyframes.find(id);
+    return it == keyframes.end() ? nullptr : it->second;
+}
+std::shared_ptr<MapPt> Slam::map_point(int id) const {
+    auto it = map_points.find(id);
+    return it == map_points.end() ? nullptr : it->second;
+}
+
+void Slam::create_keyframe() {  // map_manager.cpp:12-22
+    prepare_frame();
+    extract_keypoints();
+    add_keyframe();
+}
+
+void Slam::prepare_frame() {  // map_manager.cpp:24-81
+    cur->kfid = next_kf_id;
+    if ((int) cur->n_kps > cfg.max_keypoints) {
+        for (size_t ci = 0; ci < cur->grid.size(); ci++) {
+            // the reference iterates the cell's id vector while removals edit it (range-for over a reference, :32-68); a copy of the
+            // ids taken up front visits the same elements because at most one removal happens per cell and it ends the scan
+            const std::vector<int> ids = cur->grid[ci];
+            if (ids.size() > 2) {
+                int to_remove = -1;
+                size_t min_obs = std::numeric_limits<size_t>::max();
+                bool broke = false;
+                for (int lmid: ids) {
+                    auto it = map_points.find(lmid);
+                    if (it != map_points.end()) {
+                        const size_t nobs = it->second->obs_kfs.size();
+                        if (nobs < min_obs) {
+                            to_remove = lmid;
+                            min_obs = nobs;
+                        }
+                    } else {
+                        remove_obs_from_cur(lmid);
+                        broke = true;
+                        break;
+                    }
+                }
+                (void) broke;
+                if (to_remove >= 0) remove_obs_from_cur(to_remove);
+            }
+        }
+    }
+    for (const KeyPt &kp: cur->keypoints()) {
+        auto it = map_points.find(kp.id);
+        if (it == map_points.end()) {
+            remove_obs_from_cur(kp.id);
+            continue;
+        }
+        it->second->obs_kfs.insert(next_kf_id);
+    }
+}
+
+void Slam::extract_keypoints() {  // map_manager.cpp:193-241
+    const std::vector<KeyPt> kps = cur->keypoints();
+    const int n = (int) kps.size();
+    std::vector<float> pts((size_t) n * 2);
+    for (int i = 0; i < n; i++) {
+        pts[2 * (size_t) i] = kps[(size_t) i].px[0];
+        pts[2 * (size_t) i + 1] = kps[(size_t) i].px[1];
+    }
+    // describeKeypoints (:224-241): refresh the descriptors of the tracked keypoints in the raw image
+    if (n) {
+        std::vector<uint8_t> desc((size_t) n * 32), valid((size_t) n);
+        if (fail(st->describe(n, pts.data(), desc.data(), valid.data()))) return;
+        for (int i = 0; i < n; i++)
+            if (valid[(size_t) i]) {
+                Desc d;
+                __builtin_memcpy(d.b, &desc[(size_t) i * 32], 32);
+                cur->set_desc(kps[(size_t) i].id, d);
+                map_points.at(kps[(size_t) i].id)->add_desc(cur->kfid, d);
+            }
+    }
+    const int to_detect = cfg.max_keypoints - (int) cur->n_occupied;
+    if (to_detect > 0) {
+        const int cap = (int) cur->grid_cells + 8;
+        std::vector<float> np((size_t) cap * 2);
+        int count = 0;
+        if (fail(st->detect(cfg.cell_size, n, pts.data(), cap, np.data(), &count))) return;
+        if (count > 0) {
+            std::vector<uint8_t> desc((size_t) count * 32), valid((size_t) count);
+            std::vector<float> unpx((size_t) count * 2);
+            std::vector<double> bv((size_t) count * 3);
+            if (fail(st->describe(count, np.data(), desc.data(), valid.data()))) return;
+            if (fail(st->compute_keypoints(count, np.data(), unpx.data(), bv.data()))) return;
+            for (int i = 0; i < count; i++) {  // addKeypointsToFrame (:166-191)
+                KeyPt k;
+                k.id = next_mp_id;
+                k.px[0] = np[2 * (size_t) i]; k.px[1] = np[2 * (size_t) i + 1];
+                k.unpx[0] = unpx[2 * (size_t) i]; k.unpx[1] = unpx[2 * (size_t) i + 1];
+                for (int c = 0; c < 3; c++) k.bv[c] = bv[3 * (size_t) i + c];
+                if (valid[(size_t) i]) {
+                    __builtin_memcpy(k.desc.b, &desc[(size_t) i * 32], 32);
+                    k.has_desc = true;
+                    cur->add(k);
+                    add_map_point(&k.desc);
+                } else {
+                    cur->add(k);
+                    add_map_point(nullptr);
+                }
+            }
+        }
+    }
+}
+
+void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of the current frame
+    std::shared_ptr<FrameRec> kf = std::make_shared<FrameRec>(*cur);
+    keyframes.emplace(next_kf_id, kf);
+    n_keyframes++;
+    next_kf_id++;
+}
+
+void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
+    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(next_mp_id, next_kf_id);
+    map_points.emplace(next_mp_id, mp);
+    next_mp_id++;
+    n_map_points++;
+}
+
+void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) {  // map_manager.cpp:366-426
+    auto it = map_points.find(id);
+    if (it == map_points.end() || !it->second) return;
+    MapPt &mp = *it->second;
+    if (!mp.is3d) {
+        const std::set<int> obs = mp.obs_kfs;  // getObservedKeyframeIds returns a copy; removals below edit the member
+        for (int kf: obs) {
+            auto k = keyframes.find(kf);
+            if (k != keyframes.end()) k->second->turn3d(id);
+            else mp.remove_obs(kf);
+        }
+        if (mp.observed) cur->turn3d(id);
+    }
+    mp.X[0] = wpt[0]; mp.X[1] = wpt[1]; mp.X[2] = wpt[2];
+    mp.is3d = true;
+    if (anchor_inv_depth >= 0.) mp.inv_depth = anchor_inv_depth;
+}
+
+void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-513
+    auto pit = map_points.find(prev_id), nit = map_points.find(new_id);
+    if (pit == map_points.end() || nit == map_points.end() || !nit->second->is3d) return;
+    std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
+    const std::set<int> next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
+    const std::unordered_map<int, Desc> prev_desc = prev->kf_desc;
+    for (int pk: prev_kfs) {
+        auto kf = keyframes.find(pk);
+        if (kf == keyframes.end()) continue;
+        if (kf->second->change_id(prev_id, new_id, nw->is3d)) {
+            nw->obs_kfs.insert(pk);
+            for (int nk: next_kfs) {
+                auto co = keyframes.find(nk);
+                if (co != keyframes.end()) {
+                    kf->second->add_covisible(nk);
+                    co->second->add_covisible(pk);
+                }
+            }
+        }
+    }
+    for (const auto &e: prev_desc) nw->add_desc(e.first, e.second);
+    if (cur->observes(prev_id)) {
+        if (cur->change_id(prev_id, new_id, nw->is3d)) set_map_point_obs(new_id);
+    }
+    if (prev->is3d) n_map_points--;
+    map_points.erase(pit);
+    n_merges++;
+}
+
+void Slam::remove_keyframe(int kfid) {  // map_manager.cpp:515-557
+    auto it = keyframes.find(kfid);
+    if (it == keyframes.end()) return;
+    for (const KeyPt &kp: it->second->keypoints()) {
+        auto m = map_points.find(kp.id);
+        if (m == map_points.end()) continue;
+        m->second->remove_obs(kfid);
+    }
+    for (const auto &c: it->second->covisible) {
+        auto co = keyframes.find(c.first);
+        if (co != keyframes.end()) co->second->remove_covisible(kfid);
+    }
+    keyframes.erase(it);
+    n_keyframes--;
+}
+
+void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
+    auto it = map_points.find(id);
+    if (it == map_points.end()) return;
+    std::shared_ptr<MapPt> mp = it->second;
+    const std::set<int> obs = mp->obs_kfs;
+    for (int kf: obs) {
+        auto k = keyframes.find(kf);
+        if (k == keyframes.end()) continue;
+        k->second->remove(id);
+        for (int co: obs)
+            if (co != kf) k->second->decrease_covisible(co);
+    }
+    if (mp->observed) cur->remove(id);
+    if (mp->is3d) n_map_points--;
+    map_points.erase(it);
+}
+
+void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-647
+    auto kf = keyframes.find(kfid);
+    if (kf != keyframes.end()) kf->second->remove(mp_id);
+    auto m = map_points.find(mp_id);
+    if (m == map_points.end()) return;
+    m->second->remove_obs(kfid);
+    if (kf != keyframes.end()) {
+        const std::set<int> obs = m->second->obs_kfs;
+        for (int co: obs) {
+            auto c = keyframes.find(co);
+            if (c != keyframes.end()) {
+                kf->second->decrease_covisible(co);
+                c->second->decrease_covisible(kfid);
+            }
+        }
+    }
+}
+
+void Slam::remove_obs_from_cur(int mp_id) {  // map_manager.cpp:649-679
+    cur->remove(mp_id);
+    auto m = map_points.find(mp_id);
+    if (m == map_points.end()) return;
+    m->second->observed = false;
+}
+
+bool Slam::set_map_point_obs(int mp_id) {  // map_manager.cpp:681-708
+    auto m = map_points.find(mp_id);
+    if (m == map_points.end()) return false;
+    m->second->observed = true;
+    return true;
+}
+
+void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-164
+    std::map<int, int> cov;
+    std::unordered_set<int> local_ids;
+    for (const KeyPt &kp: frame.keypoints()) {
+        auto m = map_points.find(kp.id);
+        if (m == map_points.end()) {
+            remove_map_point_obs(kp.id, frame.kfid);
+            remove_obs_from_cur(kp.id);
+            continue;
+        }
+        for (int kf: m->second->obs_kfs) {
+            if (kf != frame.kfid) {
+                auto c = cov.find(kf);
+                if (c != cov.end()) c->second += 1;
+                else cov.emplace(kf, 1);
+            }
+        }
+    }
+    std::set<int> bad;
+    for (const auto &c: cov) {
+        auto kf = keyframes.find(c.first);
+        if (kf != keyframes.end()) {
+            kf->second->covisible[frame.kfid] = c.second;
+            for (const KeyPt &kp: kf->second->keypoints3d())
+                if (!frame.observes(kp.id)) local_ids.insert(kp.id);
+        } else {
+            bad.insert(c.first);
+        }
+    }
+    for (int kf: bad) cov.erase(kf);
+    frame.covisible.swap(cov);
+    if (local_ids.size() > 0.5 * frame.local_map.size()) frame.local_map.swap(local_ids);
+    else frame.local_map.insert(local_ids.begin(), local_ids.end());
+}
+
+}  // namespace alva_slam

@@ -1,0 +1,517 @@
+// Keyframe processing of the host-side map layer: the behaviour of Mapper (src/slam/src/mapper.cpp) and Optimizer::localBA
+// (src/slam/src/optimizer.cpp) of the reference.  The graph work stays here (which keyframes / map points / observations take
+// part, what is written back, what is culled); triangulation, the guided Hamming matching and the bundle-adjustment solve are
+// stage calls on flattened arrays.
+#include "slam.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace alva_slam {
+
+void Slam::process_new_keyframe(int kfid) {  // mapper.cpp:9-64
+    std::shared_ptr<FrameRec> kf = keyframe(kfid);
+    if (!kf) return;
+    if (kfid > 30) remove_keyframe(kfid - 30);  // "just keep the last 30 keyframes"
+    if (kf->kfid > 0 && kf->n_2d > 0) triangulate_temporal(*kf);
+    if (err_) return;
+    if (ready_for_init) {
+        if (kfid == 1 && kf->n_3d < 30) {
+            reset_requested = true;
+            return;
+        }
+        if (kfid < 10 && kf->n_3d < 3) {
+            reset_requested = true;
+            return;
+        }
+    }
+    update_frame_covisibility(*kf);
+    cur->covisible = kf->covisible;
+    if (kfid > 0) matching_to_local_map(*kf);
+    if (err_) return;
+    optimize(kf);
+}
+
+void Slam::triangulate_temporal(FrameRec &frame) {  // mapper.cpp:144-291
+    const std::vector<KeyPt> kps = frame.keypoints2d();
+    if (kps.empty()) return;
+    // pass 1 (host): the gates that decide which keypoints reach the arithmetic, in the reference's order.  The arithmetic of
+    // one keypoint does not depend on the outcome of another (removeMapPointObs / updateMapPoint touch only that keypoint's
+    // map point), so the candidates are triangulated in one batch and the outcomes applied in order afterwards.
+    struct Cand {
+        int id, group;
+        KeyPt kfkp;
+        std::shared_ptr<FrameRec> kf;
+    };
+    std::vector<Cand> cands;
+    std::vector<int> group_kf;
+    std::vector<size_t> cand_of_kp(kps.size(), (size_t) -1);
+    for (size_t i = 0; i < kps.size(); i++) {
+        std::shared_ptr<MapPt> mp = map_point(kps[i].id);
+        if (!mp) {
+            remove_map_point_obs(kps[i].id, frame.kfid);
+            continue;
+        }
+        if (mp->is3d) continue;
+        if (mp->obs_kfs.size() < 2) continue;
+        const int kfid = *mp->obs_kfs.begin();
+        if (frame.kfid == kfid) continue;
+        std::shared_ptr<FrameRec> kf = keyframe(kfid);
+        if (!kf) continue;
+        const KeyPt *kk = kf->find(kps[i].id);
+        if (!kk) continue;
+        int g = -1;
+        for (size_t q = 0; q < group_kf.size(); q++)
+            if (group_kf[q] == kfid) g = (int) q;
+        if (g < 0) {
+            g = (int) group_kf.size();
+            group_kf.push_back(kfid);
+        }
+        cand_of_kp[i] = cands.size();
+        cands.push_back(Cand{kps[i].id, g, *kk, kf});
+    }
+    const int n = (int) cands.size(), G = (int) group_kf.size();
+    if (!n) return;
+    std::vector<double> T((size_t) G * 36), bvl((size_t) n * 3), bvr((size_t) n * 3), wpt((size_t) n * 3), invd((size_t) n), par((size_t) n);
+    std::vector<float> ul((size_t) n * 2), ur((size_t) n * 2);
+    std::vector<int> grp((size_t) n);
+    std::vector<uint8_t> status((size_t) n);
+    for (int g = 0; g < G; g++) {
+        const FrameRec &kf = *keyframe(group_kf[(size_t) g]);
+        const SE3 Tlr = se3_mul(kf.Tcw, frame.Twc);  // Tcicj = Tciw * Twcj (:226-228)
+        const SE3 Trl = se3_inverse(Tlr);
+        double *o = &T[(size_t) g * 36];
+        quat_to_rot(Tlr.q, o); std::memcpy(o + 9, Tlr.t, 24);
+        quat_to_rot(Trl.q, o + 12); std::memcpy(o + 21, Trl.t, 24);
+        quat_to_rot(kf.Twc.q, o + 24); std::memcpy(o + 33, kf.Twc.t, 24);
+    }
+    {
+        size_t c = 0;
+        for (size_t i = 0; i < kps.size(); i++) {
+            if (cand_of_kp[i] == (size_t) -1) continue;
+            const Cand &cd = cands[c];
+            std::memcpy(&bvl[3 * c], cd.kfkp.bv, 24);
+            std::memcpy(&bvr[3 * c], kps[i].bv, 24);
+            ul[2 * c] = cd.kfkp.unpx[0]; ul[2 * c + 1] = cd.kfkp.unpx[1];
+            ur[2 * c] = kps[i].unpx[0]; ur[2 * c + 1] = kps[i].unpx[1];
+            grp[c] = cd.group;
+            c++;
+        }
+    }
+    if (fail(st->triangulate(n, G, T.data(), grp.data(), bvl.data(), bvr.data(), ul.data(), ur.data(), wpt.data(), invd.data(), status.data(),
+                             par.data())))
+        return;
+    for (int c = 0; c < n; c++) {
+        if (status[(size_t) c] == 0) {
+            update_map_point(cands[(size_t) c].id, &wpt[3 * (size_t) c], invd[(size_t) c]);  // :283-286
+        } else if (par[(size_t) c] > 20.) {
+            remove_map_point_obs(cands[(size_t) c].id, frame.kfid);  // :258-262, :274-278
+        }
+    }
+}
+
+bool Slam::matching_to_local_map(FrameRec &frame) {  // mapper.cpp:293-352
+    const size_t max_local = (size_t) cfg.max_keypoints * 10;
+    if (!frame.covisible.empty() && frame.local_map.size() < max_local) {
+        int kfid = frame.covisible.begin()->first;
+        std::shared_ptr<FrameRec> kf = keyframe(kfid);
+        while (!kf && kfid > 0) {
+            kfid--;
+            kf = keyframe(kfid);
+        }
+        if (kf) frame.local_map.insert(kf->local_map.begin(), kf->local_map.end());
+        // "go for another round" (:316-330): the reference dereferences `keyframe` here unconditionally and looks the SAME keyframe up
+        // again; with a null pointer it would crash, so the guard is the only liberty taken
+        if (kf && kf->kfid > 0 && frame.local_map.size() < 0.5 * max_local) {
+            kf = keyframe(kf->kfid);
+            while (!kf && kfid > 0) {
+                kfid--;
+                kf = keyframe(kfid);
+            }
+            if (kf) frame.local_map.insert(kf->local_map.begin(), kf->local_map.end());
+        }
+    }
+    const std::map<int, int> matches = match_to_map(frame, cfg.map_max_proj_px, cfg.map_max_desc_dist, frame.local_map);
+    if (err_ || matches.empty()) return false;
+    for (const auto &m: matches) merge_map_points(m.first, m.second);
+    return true;
+}
+
+// Mapper::matchToMap (mapper.cpp:354-588): flatten the part of the map the call can reach, run the stage, translate indices back
+std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, std::unordered_set<int> &local) {
+    std::map<int, int> result;
+    if (local.empty()) return result;
+    // keyframe table
+    std::vector<int> kf_ids;
+    for (const auto &e: keyframes) kf_ids.push_back(e.first);
+    std::sort(kf_ids.begin(), kf_ids.end());
+    std::unordered_map<int, int> kf_index;
+    std::vector<double> kf_q, kf_t;
+    for (size_t i = 0; i < kf_ids.size(); i++) {
+        kf_index[kf_ids[i]] = (int) i;
+        const FrameRec &k = *keyframes.at(kf_ids[i]);
+        kf_q.insert(kf_q.end(), k.Tcw.q, k.Tcw.q + 4);
+        kf_t.insert(kf_t.end(), k.Tcw.t, k.Tcw.t + 3);
+    }
+    auto fit = kf_index.find(frame.kfid);
+    if (fit == kf_index.end()) return result;
+    // map point table: the frame's keypoints first (grid order), then the local map in ITS iteration order
+    std::vector<int> mp_ids;
+    std::unordered_map<int, int> mp_index;
+    auto intern = [&](int id) {
+        auto it = mp_index.find(id);
+        if (it != mp_index.end()) return it->second;
+        const int idx = (int) mp_ids.size();
+        mp_index.emplace(id, idx);
+        mp_ids.push_back(id);
+        return idx;
+    };
+    std::vector<int> cell_ptr(frame.grid.size() + 1, 0), cell_mp;
+    for (size_t c = 0; c < frame.grid.size(); c++) {
+        cell_ptr[c] = (int) cell_mp.size();
+        for (int id: frame.grid[c]) {
+            // getSurroundingKeypoints keeps ids found in mapKeypoints_ (frame.cpp:333-337); a keypoint whose map point is gone is
+            // repaired by the reference on contact (:459-463) -- repaired here up front
+            if (!frame.find(id)) continue;
+            if (!map_point(id)) continue;
+            cell_mp.push_back(intern(id));
+        }
+    }
+    cell_ptr[frame.grid.size()] = (int) cell_mp.size();
+    std::vector<int> local_idx;
+    for (int id: local) {
+        if (frame.observes(id)) continue;                       // :397-400
+        std::shared_ptr<MapPt> mp = map_point(id);
+        if (!mp || !mp->is3d || !mp->has_desc) continue;         // :404-411
+        local_idx.push_back(intern(id));
+    }
+    if (local_idx.empty()) return result;
+    const int n_mp = (int) mp_ids.size();
+    std::vector<double> mp_wpt((size_t) n_mp * 3);
+    std::vector<uint8_t> mp_is3d((size_t) n_mp), mp_has_desc((size_t) n_mp), obs_desc, obs_has_desc;
+    std::vector<int> obs_ptr((size_t) n_mp + 1, 0), obs_kf;
+    std::vector<float> obs_px;
+    for (int m = 0; m < n_mp; m++) {
+        const MapPt &mp = *map_points.at(mp_ids[(size_t) m]);
+        std::memcpy(&mp_wpt[3 * (size_t) m], mp.X, 24);
+        mp_is3d[(size_t) m] = mp.is3d;
+        mp_has_desc[(size_t) m] = mp.has_desc;
+        obs_ptr[(size_t) m] = (int) obs_kf.size();
+        for (int kf: mp.obs_kfs) {
+            auto ki = kf_index.find(kf);
+            if (ki == kf_index.end()) continue;
+            const KeyPt *kk = keyframes.at(kf)->find(mp.id);
+            if (!kk) continue;
+            obs_kf.push_back(ki->second);
+            obs_px.push_back(kk->px[0]);
+            obs_px.push_back(kk->px[1]);
+            // one 32-byte slot per observation; keyframes in which the keypoint could not be described (within 31 px of the border,
+            // feature_extractor.cpp:191-209) have no entry in mapKeyframeDescriptors_: slot zeroed and flagged
+            auto d = mp.kf_desc.find(kf);
+            if (d != mp.kf_desc.end()) {
+                obs_desc.insert(obs_desc.end(), d->second.b, d->second.b + 32);
+                obs_has_desc.push_back(1);
+            } else {
+                obs_desc.insert(obs_desc.end(), 32, (uint8_t) 0);
+                obs_has_desc.push_back(0);
+            }
+        }
+    }
+    obs_ptr[(size_t) n_mp] = (int) obs_kf.size();
+    std::vector<int> match_of_mp((size_t) n_mp, -1);
+    const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) frame.grid.size(), cell_ptr.data(), cell_mp.data(),
+                                    (int) kf_ids.size(), kf_q.data(), kf_t.data(), n_mp, mp_wpt.data(), mp_is3d.data(), mp_has_desc.data(),
+                                    obs_ptr.data(), obs_kf.data(), obs_px.data(), obs_desc.data(), obs_has_desc.data(), fit->second,
+                                    (int) frame.n_3d, (int) local_idx.size(), local_idx.data(), max_proj_err, dist_ratio, match_of_mp.data());
+    if (fail(rc)) return result;
+    for (int m = 0; m < n_mp; m++)
+        if (match_of_mp[(size_t) m] >= 0) result.emplace(mp_ids[(size_t) m], mp_ids[(size_t) match_of_mp[(size_t) m]]);
+    return result;
+}
+
+void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
+    if (kf->kfid >= 2 && kf->n_3d != 0) local_ba(*kf);
+    if (err_) return;
+    if (cfg.keyframe_filtering_ratio < 1.0 && kf->kfid >= 20) {
+        const std::map<int, int> cov = kf->covisible;
+        for (auto it = cov.rbegin(); it != cov.rend(); ++it) {
+            const int kfid = it->first;
+            if (kfid == 0) break;
+            if (kfid >= kf->kfid) continue;
+            std::shared_ptr<FrameRec> co = keyframe(kfid);
+            if (!co) continue;  // the reference dereferences the null pointer here (:88-92); nothing to remove from
+            if ((int) co->n_3d < cfg.ba_min_common_obs / 2) {
+                remove_keyframe(kfid);
+                n_kf_culled++;
+                continue;
+            }
+            size_t good = 0, total = 0;
+            for (const KeyPt &kp: co->keypoints3d()) {
+                std::shared_ptr<MapPt> mp = map_point(kp.id);
+                if (!mp) {
+                    remove_map_point_obs(kp.id, kfid);
+                    continue;
+                } else if (mp->is_bad()) {
+                    continue;
+                } else if (mp->obs_kfs.size() > 4) {
+                    good++;
+                }
+                total++;
+            }
+            const float ratio = (float) good / (float) total;
+            if (ratio > cfg.keyframe_filtering_ratio) {
+                remove_keyframe(kfid);
+                n_kf_culled++;
+            }
+        }
+    }
+}
+
+// Optimizer::localBA (optimizer.cpp:4-531) with anchored inverse depth (state.hpp:74)
+void Slam::local_ba(FrameRec &new_frame) {
+    const int min_cov = cfg.ba_min_common_obs;
+    if ((int) new_frame.n_3d < min_cov) return;
+    // ---- 1. problem (optimizer.cpp:20-247)
+    std::unordered_map<int, std::shared_ptr<MapPt>> local_mps;      // map_local_plms
+    std::unordered_map<int, std::shared_ptr<FrameRec>> local_kfs;   // map_local_pkfs
+    std::unordered_map<int, int> pose_slot;                          // keyframe id -> row of the flat pose table
+    std::vector<double> poses;
+    std::vector<uint8_t> kf_const;
+    std::unordered_set<int> bad_mps, mps_to_opt, kfs_to_opt, const_kfs;
+    auto add_pose = [&](int kfid, const FrameRec &kf, bool constant) {
+        pose_slot.emplace(kfid, (int) kf_const.size());
+        double p[7];
+        se3_to_pose7(kf.Twc, p);
+        poses.insert(poses.end(), p, p + 7);
+        kf_const.push_back(constant ? 1 : 0);
+    };
+    std::map<int, int> cov = new_frame.covisible;
+    cov.emplace(new_frame.kfid, (int) new_frame.n_3d);
+    bool all_cst = false;
+    const int max_kfid = cov.rbegin()->first;
+    for (auto it = cov.rbegin(); it != cov.rend(); ++it) {
+        const int kfid = it->first;
+        int score = it->second;
+        if (kfid > new_frame.kfid) score = (int) new_frame.n_kps;
+        std::shared_ptr<FrameRec> kf = keyframe(kfid);
+        if (!kf) {
+            new_frame.remove_covisible(kfid);
+            continue;
+        }
+        if (score >= min_cov && !all_cst && kfid > 0) {
+            add_pose(kfid, *kf, false);
+            kfs_to_opt.insert(kfid);
+            for (const KeyPt &kp: kf->keypoints3d()) mps_to_opt.insert(kp.id);
+        } else {
+            add_pose(kfid, *kf, true);
+            const_kfs.insert(kfid);
+            all_cst = true;
+        }
+        local_kfs.emplace(kfid, kf);
+    }
+    struct ObsRec {
+        int kfid, mpid;
+    };
+    std::vector<int> pt_ids, pt_anchor_slot, obs_kf, obs_pt;
+    std::vector<double> pt_anchor_uv, pt_inv, obs_uv;
+    std::vector<ObsRec> obs_rec;
+    std::unordered_map<int, int> pt_slot;  // map_id_invptspar_
+    for (int lmid: mps_to_opt) {
+        std::shared_ptr<MapPt> mp = map_point(lmid);
+        if (!mp) continue;
+        if (mp->is_bad()) {
+            bad_mps.insert(lmid);
+            continue;
+        }
+        local_mps.emplace(lmid, mp);
+        int anchor = -1;
+        const std::set<int> obs = mp->obs_kfs;
+        for (int kfid: obs) {
+            if (kfid > max_kfid) continue;
+            std::shared_ptr<FrameRec> kf;
+            auto lk = local_kfs.find(kfid);
+            if (lk == local_kfs.end()) {
+                kf = keyframe(kfid);
+                if (!kf) {
+                    remove_map_point_obs(kfid, mp->id);  // sic: arguments swapped in the reference (optimizer.cpp:162)
+                    continue;
+                }
+                local_kfs.emplace(kfid, kf);
+                add_pose(kfid, *kf, true);
+                const_kfs.insert(kfid);
+            } else {
+                kf = lk->second;
+            }
+            const KeyPt *kp = kf->find(lmid);
+            if (!kp) {
+                remove_map_point_obs(lmid, kfid);
+                continue;
+            }
+            if (anchor < 0) {  // the first observing keyframe anchors the inverse depth; it gets no residual (:186-201)
+                anchor = kfid;
+                double pc[3];
+                se3_apply(kf->Tcw, mp->X, pc);
+                pt_slot.emplace(lmid, (int) pt_ids.size());
+                pt_ids.push_back(lmid);
+                pt_anchor_slot.push_back(pose_slot.at(kfid));
+                pt_anchor_uv.push_back((double) kp->unpx[0]);
+                pt_anchor_uv.push_back((double) kp->unpx[1]);
+                pt_inv.push_back(1. / pc[2]);  // InvDepthParametersBlock(id, anchor, zanch) stores 1 / zanch
+                continue;
+            }
+            obs_kf.push_back(pose_slot.at(kfid));
+            obs_pt.push_back(pt_slot.at(lmid));
+            obs_uv.push_back((double) kp->unpx[0]);
+            obs_uv.push_back((double) kp->unpx[1]);
+            obs_rec.push_back(ObsRec{kfid, lmid});
+        }
+    }
+    // gauge: at least two constant keyframes (:234-247), taken in the container's order
+    size_t n_const = const_kfs.size();
+    if (n_const < 2) {
+        for (auto it = local_kfs.begin(); n_const < 2 && it != local_kfs.end(); ++it) {
+            kf_const[(size_t) pose_slot.at(it->first)] = 1;
+            const_kfs.insert(it->first);
+            n_const++;  // sic: counted even when the keyframe was constant already
+        }
+    }
+    // ---- 2. solve (:251-262) and 3./4. outlier sweep + second solve without the flagged residuals (:266-359; the loss is never
+    //         reset to L2 there because vright_reprojerr_kfid_lmid stays empty, :315-318)
+    const int n_kf = (int) kf_const.size(), n_pt = (int) pt_ids.size();
+    std::vector<std::pair<int, int>> bad_obs;  // (keyframe, map point)
+    std::vector<uint8_t> alive(obs_rec.size(), 1);
+    bool any_bad = false;
+    for (int round = 0; round < 2; round++) {
+        std::vector<int> sel;
+        for (size_t o = 0; o < obs_rec.size(); o++)
+            if (alive[o]) sel.push_back((int) o);
+        const int n_obs = (int) sel.size();
+        // Ceres drops parameter blocks that no residual block uses (program.cc: RemoveFixedBlocks); the stage gets the same reduced
+        // problem: only points with a live residual, and a free keyframe without residuals is passed as constant
+        std::vector<int> pt_of((size_t) n_pt, -1), pts_used;
+        std::vector<uint8_t> kf_used((size_t) n_kf, 0), kc = kf_const;
+        std::vector<int> okf((size_t) n_obs), opt((size_t) n_obs);
+        std::vector<double> ouv((size_t) n_obs * 2), chi2((size_t) n_obs);
+        std::vector<uint8_t> dpos((size_t) n_obs);
+        for (int i = 0; i < n_obs; i++) {
+            const int o = sel[(size_t) i], p = obs_pt[(size_t) o];
+            if (pt_of[(size_t) p] < 0) {
+                pt_of[(size_t) p] = (int) pts_used.size();
+                pts_used.push_back(p);
+            }
+            okf[(size_t) i] = obs_kf[(size_t) o];
+            opt[(size_t) i] = pt_of[(size_t) p];
+            ouv[2 * (size_t) i] = obs_uv[2 * (size_t) o];
+            ouv[2 * (size_t) i + 1] = obs_uv[2 * (size_t) o + 1];
+            kf_used[(size_t) obs_kf[(size_t) o]] = 1;
+            kf_used[(size_t) pt_anchor_slot[(size_t) p]] = 1;
+        }
+        for (int k = 0; k < n_kf; k++)
+            if (!kf_used[(size_t) k]) kc[(size_t) k] = 1;
+        const int n_used = (int) pts_used.size();
+        std::vector<int> pa((size_t) n_used);
+        std::vector<double> pauv((size_t) n_used * 2), pinv((size_t) n_used);
+        for (int j = 0; j < n_used; j++) {
+            const int p = pts_used[(size_t) j];
+            pa[(size_t) j] = pt_anchor_slot[(size_t) p];
+            pauv[2 * (size_t) j] = pt_anchor_uv[2 * (size_t) p];
+            pauv[2 * (size_t) j + 1] = pt_anchor_uv[2 * (size_t) p + 1];
+            pinv[(size_t) j] = pt_inv[(size_t) p];
+        }
+        if (n_obs > 0) {
+            if (fail(st->local_ba(n_kf, poses.data(), kc.data(), n_used, pa.data(), pauv.data(), pinv.data(), n_obs, okf.data(), opt.data(),
+                                  ouv.data(), 5, chi2.data(), dpos.data())))
+                return;
+            for (int j = 0; j < n_used; j++) pt_inv[(size_t) pts_used[(size_t) j]] = pinv[(size_t) j];
+        }
+        n_ba_runs++;
+        size_t n_bad = 0;
+        for (int i = 0; i < n_obs; i++) {
+            if (chi2[(size_t) i] > (double) cfg.robust_threshold || !dpos[(size_t) i]) {
+                const ObsRec &r = obs_rec[(size_t) sel[(size_t) i]];
+                alive[(size_t) sel[(size_t) i]] = 0;
+                bad_obs.emplace_back(r.kfid, r.mpid);
+                bad_mps.insert(r.mpid);
+                n_bad++;
+            }
+        }
+        if (round == 0) any_bad = n_bad > 0;
+        if (!(cfg.refine_with_l2 && any_bad)) break;
+    }
+    // ---- 5. write-back (:363-530)
+    for (const auto &b: bad_obs) {
+        if (local_kfs.find(b.first) != local_kfs.end()) remove_map_point_obs(b.second, b.first);
+        if (b.first == cur->kfid) remove_obs_from_cur(b.second);
+        bad_mps.insert(b.second);
+    }
+    for (const auto &e: local_kfs) {
+        if (const_kfs.count(e.first)) continue;
+        if (!e.second) continue;
+        auto ps = pose_slot.find(e.first);
+        if (ps != pose_slot.end()) e.second->set_Twc(se3_from_pose7(&poses[7 * (size_t) ps->second]));
+    }
+    for (const auto &e: local_mps) {
+        const int lmid = e.first;
+        const std::shared_ptr<MapPt> &mp = e.second;
+        if (!mp) {
+            bad_mps.erase(lmid);
+            continue;
+        }
+        if (mp->is_bad()) {
+            remove_map_point(lmid);
+            bad_mps.erase(lmid);
+            continue;
+        }
+        if (mp->obs_kfs.size() < 3) {
+            if (mp->anchor_kf < new_frame.kfid - 3 && !mp->observed) {
+                remove_map_point(lmid);
+                bad_mps.erase(lmid);
+                continue;
+            }
+        }
+        auto ps = pt_slot.find(lmid);
+        if (ps == pt_slot.end()) {
+            bad_mps.insert(lmid);
+            continue;
+        }
+        const double inv = pt_inv[(size_t) ps->second], zanch = 1. / inv;
+        if (zanch <= 0.) {
+            remove_map_point(lmid);
+            bad_mps.erase(lmid);
+            continue;
+        }
+        auto ak = local_kfs.find(mp->anchor_kf);
+        if (ak == local_kfs.end()) {
+            bad_mps.insert(lmid);
+            continue;
+        }
+        if (ak->second) {
+            const FrameRec &akf = *ak->second;
+            const KeyPt *kp = akf.find(lmid);
+            const float ux = kp ? kp->unpx[0] : 0.f, uy = kp ? kp->unpx[1] : 0.f;  // a default Keypoint has unpx_ = (0, 0)
+            const double uv[3] = {(double) ux, (double) uy, 1.};
+            double ray[3], pc[3], wpt[3];
+            double sK[9];
+            for (int i = 0; i < 9; i++) sK[i] = zanch * invK[i];  // (zanch * inverseK_) * uvpt, left to right (:468-470)
+            mat3_vec(sK, uv, ray);
+            (void) pc;
+            se3_apply(akf.Twc, ray, wpt);
+            update_map_point(lmid, wpt, inv);
+        } else {
+            bad_mps.insert(lmid);
+        }
+    }
+    for (int lmid: bad_mps) {  // :492-530
+        std::shared_ptr<MapPt> mp;
+        auto lm = local_mps.find(lmid);
+        mp = lm == local_mps.end() ? map_point(lmid) : lm->second;
+        if (!mp) continue;
+        if (mp->is_bad()) {
+            remove_map_point(lmid);
+        } else if (mp->obs_kfs.size() < 3) {
+            if (mp->anchor_kf < new_frame.kfid - 3 && !mp->observed) remove_map_point(lmid);
+        }
+    }
+}
+
+}  // namespace alva_slam

@@ -1,0 +1,195 @@
+// Host-side map layer behind alva_system_* (include/alvaar_system.h): the bookkeeping the reference keeps in
+// Frame / MapPoint / MapManager / Mapper / Optimizer / VisualFrontend (src/slam/src/*.cpp, SURVEY.md §1 layer L2) --
+// keyframes, map points, covisibility, the per-frame state machine -- with every numeric stage behind `Stages`.
+//
+// Container choice is part of the contract, not a style matter: the reference iterates std::unordered_map<int, ...> /
+// std::unordered_set<int> and that order reaches the solvers (the P3P sample stream indexes the keypoints in container order,
+// visual_frontend.cpp:275-298; matchToMap breaks ties by the local map's order, mapper.cpp:395, :571-577; the gauge of the
+// local BA is fixed on the first keyframes of an unordered_map, optimizer.cpp:234-247).  The same libstdc++ containers
+// receiving the same sequence of insert / erase / clear / copy operations iterate in the same order, so the state below uses
+// exactly those containers and every mutation follows the reference's sequence.
+#pragma once
+#include <map>
+#include <memory>
+#include <set>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include "se3.hpp"
+#include "stages.hpp"
+
+namespace alva_slam {
+
+struct Desc {
+    uint8_t b[32];
+};
+
+// struct Keypoint, frame.hpp:17-38
+struct KeyPt {
+    int id = -1;
+    float px[2] = {0, 0};
+    float unpx[2] = {0, 0};
+    double bv[3] = {0, 0, 0};
+    Desc desc{};
+    bool has_desc = false;
+    bool is3d = false;
+};
+
+// tunables, state.hpp:29-78 with the overrides of System::configure (system.cpp:15-19)
+struct Settings {
+    int cell_size = 40;
+    bool clahe = false;
+    float keyframe_filtering_ratio = 0.95f;
+    bool p3p_enabled = true;
+    bool random_sampling = true;       // multiViewRandomEnabled_
+    float min_avg_rot_parallax = 40.f;
+    bool klt_use_prior = true;
+    int klt_levels = 3;
+    float map_max_desc_dist = 0.2f, map_max_proj_px = 2.0f, map_max_reproj_err = 3.0f;
+    int ba_min_common_obs = 25;
+    bool refine_with_l2 = true;
+    float robust_threshold = 5.9915f;
+    int max_keypoints = 0;             // frameMaxNumKeypoints_ (state.cpp:8-11)
+};
+
+// class Frame, frame.hpp:40-178
+struct FrameRec {
+    int id = -1, kfid = 0;
+    double timestamp = 0;
+    std::unordered_map<int, KeyPt> kps;        // mapKeypoints_
+    std::vector<std::vector<int>> grid;        // gridKeypointsIds_
+    size_t grid_cells = 0, n_occupied = 0, cell = 0, cells_w = 0, cells_h = 0, n_kps = 0, n_2d = 0, n_3d = 0;
+    SE3 Twc, Tcw;
+    std::map<int, int> covisible;              // covisibleKeyframeIds_
+    std::unordered_set<int> local_map;         // localMapPointIds_
+    const Camera *cam = nullptr;
+
+    void init(const Camera *c, size_t cell_size);
+    std::vector<KeyPt> keypoints() const;      // container order
+    std::vector<KeyPt> keypoints2d() const;
+    std::vector<KeyPt> keypoints3d() const;
+    const KeyPt *find(int id) const;
+    void add(const KeyPt &k);
+    void update(int id, const float *px, const float *unpx, const double *bv);
+    void set_desc(int id, const Desc &d);
+    bool change_id(int prev_id, int new_id, bool is3d);
+    void remove(int id);
+    void turn3d(int id);
+    bool observes(int id) const { return kps.count(id) != 0; }
+    int cell_index(const float *px) const;
+    void grid_add(const KeyPt &k);
+    void grid_remove(const KeyPt &k);
+    void set_Twc(const SE3 &T) { Twc = T; Tcw = se3_inverse(T); }
+    void add_covisible(int kf);
+    void remove_covisible(int kf);
+    void decrease_covisible(int kf);
+    bool in_image(const float *p) const { return p[0] >= 0 && p[1] >= 0 && p[0] < cam->width && p[1] < cam->height; }
+    void project_cam_to_image(const double *p, float *out) const;  // projCamToImage (no distortion)
+    void reset();
+};
+
+// class MapPoint, map_point.hpp:27-86
+struct MapPt {
+    int id = -1;
+    bool observed = true, is3d = false;
+    std::set<int> obs_kfs;                       // observedKeyframeIds_
+    double X[3] = {0, 0, 0};
+    int anchor_kf = -1;                          // keyframeId_
+    double inv_depth = -1.;
+    Desc desc{};
+    bool has_desc = false;                       // !desc_.empty()
+    std::unordered_map<int, Desc> kf_desc;       // mapKeyframeDescriptors_
+    std::unordered_map<int, float> kf_desc_dist; // mapDescriptorsDist_
+
+    MapPt(int id_, int kf) : id(id_), anchor_kf(kf) { obs_kfs.insert(kf); }
+    MapPt(int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf) {
+        obs_kfs.insert(kf);
+        kf_desc.emplace(kf, d);
+        kf_desc_dist.emplace(kf, 0.f);
+        desc = d;
+        has_desc = true;
+    }
+    void remove_obs(int kf);
+    void add_desc(int kf, const Desc &d);
+    bool is_bad();
+};
+
+struct InitOverride {  // test hook, see alva_system_debug_set_init_pose
+    bool armed = false;
+    double pose7[7];
+};
+
+class Slam {
+public:
+    Slam(Stages *stages, const Camera &cam, const Settings &settings);
+
+    // System::processCameraPose (system.cpp:156-175): returns 1 / 2 / 3
+    int process_frame(const uint8_t *rgba, double timestamp);
+    void reset();  // System::reset (system.cpp:42-55)
+    int last_error() const { return err_; }
+
+    // state (public: the C ABI and the tests read it)
+    Stages *st;
+    Camera cam;
+    Settings cfg;
+    double invK[9];
+    std::shared_ptr<FrameRec> cur;                                   // currFrame_
+    std::unordered_map<int, std::shared_ptr<FrameRec>> keyframes;    // MapManager::mapKeyframes_
+    std::unordered_map<int, std::shared_ptr<MapPt>> map_points;      // MapManager::mapMapPoints_
+    int next_mp_id = 0, next_kf_id = 0, n_map_points = 0, n_keyframes = 0;
+    bool ready_for_init = false, reset_requested = false;           // State::slamReadyForInit_ / slamResetRequested_
+    bool p3p_req = false;
+    int pose_failed = 0;
+    // MotionModel (visual_frontend.hpp:11-68)
+    double mm_prev_time = -1.;
+    SE3 mm_prev_Twc;
+    double mm_log_rel[6] = {0, 0, 0, 0, 0, 0};
+    InitOverride init_override;
+    SE3 init_computed;  // what checkReadyForInit computed itself on the initialisation frame (before any override)
+    // counters for tests / bench
+    long n_ba_runs = 0, n_merges = 0, n_kf_culled = 0;
+
+private:
+    int err_ = 0;
+    bool fail(int rc) { if (rc && !err_) err_ = rc; return rc != 0; }
+
+    // VisualFrontend
+    bool track(const uint8_t *rgba, double timestamp);
+    bool process(double timestamp);
+    void klt_from_motion_prior();
+    bool compute_pose();
+    float compute_parallax(int kfid, bool unrotate, bool median);
+    bool check_ready_for_init();
+    bool check_new_keyframe_required();
+    void reset_frame();
+    void apply_motion_model(SE3 &Twc, double time);
+    void update_motion_model(const SE3 &Twc, double time);
+
+    // MapManager
+    void create_keyframe();
+    void prepare_frame();
+    void extract_keypoints();
+    void add_keyframe();
+    void add_map_point(const Desc *d);
+    void update_map_point(int id, const double *wpt, double anchor_inv_depth);
+    void merge_map_points(int prev_id, int new_id);
+    void remove_keyframe(int kfid);
+    void remove_map_point(int id);
+    void remove_map_point_obs(int mp_id, int kfid);
+    void remove_obs_from_cur(int mp_id);
+    bool set_map_point_obs(int mp_id);
+    void update_frame_covisibility(FrameRec &frame);
+    std::shared_ptr<FrameRec> keyframe(int id) const;
+    std::shared_ptr<MapPt> map_point(int id) const;
+
+    // Mapper
+    void process_new_keyframe(int kfid);
+    void triangulate_temporal(FrameRec &frame);
+    bool matching_to_local_map(FrameRec &frame);
+    std::map<int, int> match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, std::unordered_set<int> &local);
+    void optimize(const std::shared_ptr<FrameRec> &kf);
+    // Optimizer
+    void local_ba(FrameRec &new_frame);
+};
+
+}  // namespace alva_slam

@@ -296,6 +296,16 @@ int alva_match_to_map(alva_ctx *ctx, const double *h_calib10, int cell_size, int
                       const int *d_obs_kf, const float *d_obs_px, const uint8_t *d_obs_desc, int frame_kf,
                       int num_keypoints_3d, int n_local, const int *d_local, float max_proj_err, float dist_ratio,
                       int *d_match_of_mp);
+/* The same for a LIVE map, in which a keyframe may hold a keypoint it could not describe (within 31 px of the border,
+ * src/slam/src/feature_extractor.cpp:191-209): d_mp_has_desc[m] = !MapPoint::desc_.empty() (the gates at mapper.cpp:404, :465),
+ * d_obs_has_desc[o] = MapPoint::mapKeyframeDescriptors_ has an entry for that observation's keyframe (its 32-byte slot is ignored
+ * otherwise).  NULL flags = every observation carries a descriptor (alva_match_to_map). */
+int alva_match_to_map_flags(alva_ctx *ctx, const double *h_calib10, int cell_size, int num_cells_w, int grid_cells,
+                            const int *d_cell_ptr, const int *d_cell_mp, int n_kf, const double *d_kf_q, const double *d_kf_t, int n_mp,
+                            const double *d_mp_wpt, const uint8_t *d_mp_is3d, const uint8_t *d_mp_has_desc, const int *d_obs_ptr,
+                            const int *d_obs_kf, const float *d_obs_px, const uint8_t *d_obs_desc, const uint8_t *d_obs_has_desc,
+                            int frame_kf, int num_keypoints_3d, int n_local, const int *d_local, float max_proj_err, float dist_ratio,
+                            int *d_match_of_mp);
 
 /* ---- f4b: lens distortion paths of CameraCalibration --------------------------------------
  * alva_undistort_points replaces CameraCalibration::undistortImagePoint (src/slam/src/camera_calibration.cpp:56-72) =

@@ -2301,6 +2301,18 @@ int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridC
                      const double *kfQ, const double *kfT, int nMp, const double *mpWpt, const uint8_t *mpIs3d, const int *obsPtr,
                      const int *obsKf, const float *obsPx, const uint8_t *obsDesc, int frameKf, int numKeypoints3d, int nLocal,
                      const int *local, float maxProjErr, float distRatio, int *matchOfMp) {
+    return orc_match_to_map_flags(calib, cellSize, numCellsW, gridCells, cellPtr, cellMp, nKf, kfQ, kfT, nMp, mpWpt, mpIs3d, NULL, obsPtr, obsKf,
+                                  obsPx, obsDesc, NULL, frameKf, numKeypoints3d, nLocal, local, maxProjErr, distRatio, matchOfMp);
+}
+
+/* The same for a LIVE map, where a keyframe may hold a keypoint it could not describe (within 31 px of the border,
+ * feature_extractor.cpp:191-209): mpHasDesc[m] = !MapPoint::desc_.empty(), obsHasDesc[o] = mapKeyframeDescriptors_ has an entry for
+ * that observation's keyframe.  NULL flags = every observation carries a descriptor. */
+int orc_match_to_map_flags(const double *calib, int cellSize, int numCellsW, int gridCells, const int *cellPtr, const int *cellMp, int nKf,
+                           const double *kfQ, const double *kfT, int nMp, const double *mpWpt, const uint8_t *mpIs3d,
+                           const uint8_t *mpHasDesc, const int *obsPtr, const int *obsKf, const float *obsPx, const uint8_t *obsDesc,
+                           const uint8_t *obsHasDesc, int frameKf, int numKeypoints3d, int nLocal, const int *local, float maxProjErr,
+                           float distRatio, int *matchOfMp) {
     (void) nKf;
     const double fx = calib[0], fy = calib[1], cx = calib[2], cy = calib[3], imgW = calib[8], imgH = calib[9];
     const float fovV = 0.5 * imgH / fy, fovH = 0.5 * imgW / fx;
@@ -2321,7 +2333,7 @@ int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridC
     for (int li = 0; li < nLocal; li++) {
         const int M = local[li];
         if (frameObs[M] >= 0) continue;                                /* frame.isObservingKeypoint (:393) */
-        if (!mpIs3d[M] || obsPtr[M] == obsPtr[M + 1]) continue;       /* !is3d_ || desc_.empty() (:404) */
+        if (!mpIs3d[M] || !(mpHasDesc ? mpHasDesc[M] : obsPtr[M] != obsPtr[M + 1])) continue;       /* !is3d_ || desc_.empty() (:404) */
         const double *wpt = mpWpt + 3 * (size_t) M;
         double campt[3];
         mtm_transform(kfQ + 4 * (size_t) frameKf, kfT + 3 * (size_t) frameKf, wpt, campt);
@@ -2344,6 +2356,7 @@ int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridC
                     const float pxDist = (float) sqrt((double) (proj[0] - obsPx[2 * ko]) * (double) (proj[0] - obsPx[2 * ko]) +
                                                       (double) (proj[1] - obsPx[2 * ko + 1]) * (double) (proj[1] - obsPx[2 * ko + 1]));
                     if (pxDist > maxPxDist) continue;
+                    if (mpHasDesc && !mpHasDesc[K]) continue; /* kpMapPoint->desc_.empty() (:465-468) */
                     int cand = 1; /* never both observed in one keyframe (:474-485); both lists ascend */
                     for (int a = obsPtr[K]; a < obsPtr[K + 1] && cand; a++)
                         for (int b = obsPtr[M]; b < obsPtr[M + 1]; b++)
@@ -2367,6 +2380,7 @@ int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridC
                     float dist = 1000.0;
                     for (int a = obsPtr[M]; a < obsPtr[M + 1]; a++)
                         for (int b = obsPtr[K]; b < obsPtr[K + 1]; b++) {
+                            if (obsHasDesc && !(obsHasDesc[a] && obsHasDesc[b])) continue;
                             const float d = (float) orc_hamming256(obsDesc + 32 * (size_t) a, obsDesc + 32 * (size_t) b);
                             if (d < dist) dist = d;
                         }

@@ -76,10 +76,6 @@ int orc_compute_5pt(const double *bv1, const double *bv2, int n, int maxIteratio
 /* f3: the INTENDED algorithm of System::processPlane (system.cpp:177-342) -- PARITY UNPINNED, see alva_oracle_plane.c. */
 int orc_find_plane(const double *pts, int n, const double *pose7_twc, const int *samples3, int numIterations, float *out16);
 
-#ifdef __cplusplus
-}
-#endif
-#endif
 
 /* f2a: the numeric part of Mapper::triangulateTemporal per keypoint (mapper.cpp:246-287): OpenGV triangulate2
  * (opengv/src/triangulation/methods.cpp:67-90), cheirality and reprojection gates.
@@ -111,3 +107,14 @@ int orc_match_to_map(const double *calib, int cellSize, int numCellsW, int gridC
                      const double *kfQ, const double *kfT, int nMp, const double *mpWpt, const uint8_t *mpIs3d, const int *obsPtr,
                      const int *obsKf, const float *obsPx, const uint8_t *obsDesc, int frameKf, int numKeypoints3d, int nLocal,
                      const int *local, float maxProjErr, float distRatio, int *matchOfMp);
+/* live-map variant: mpHasDesc[m] = !desc_.empty(), obsHasDesc[o] = the observation's keyframe has a descriptor (NULL = all do) */
+int orc_match_to_map_flags(const double *calib, int cellSize, int numCellsW, int gridCells, const int *cellPtr, const int *cellMp, int nKf,
+                           const double *kfQ, const double *kfT, int nMp, const double *mpWpt, const uint8_t *mpIs3d,
+                           const uint8_t *mpHasDesc, const int *obsPtr, const int *obsKf, const float *obsPx, const uint8_t *obsDesc,
+                           const uint8_t *obsHasDesc, int frameKf, int numKeypoints3d, int nLocal, const int *local, float maxProjErr,
+                           float distRatio, int *matchOfMp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -3,7 +3,8 @@
 # (portable to the GPU box's host CPU, one Eigen alignment ABI everywhere):
 #   * OpenGV 1.0 sources    (/root/reference/src/libs/opengv/src/**/*.cpp)
 #   * AlvaAR slam sources   (/root/reference/src/slam/src/*.cpp minus embind.cpp)
-#   * oracle/ref_shim.cpp, oracle/ref_shim_map.cpp, oracle/ref_shim_relpose.cpp   (our extern "C" marshalling layers)
+#   * oracle/ref_shim.cpp, ref_shim_map.cpp, ref_shim_relpose.cpp, ref_shim_system.cpp   (our extern "C" marshalling layers)
+# Linked with --wrap=gettimeofday so that ref_freeze_clock(1) disables Ceres' wall-clock caps (ref_shim_system.cpp).
 # from where they lie, and links them with the static OpenCV/Ceres built by
 # build_ref_libs.sh into oracle/_ref/libalva_ref.so.  Objects are cached under
 # oracle/_ref/build/obj and only rebuilt when the source is newer.
@@ -19,6 +20,7 @@ if [ ! -d "$REF/src/slam/src" ]; then
   exit 0
 fi
 "$HERE/build_ref_libs.sh"
+make -s -C "$HERE" >/dev/null
 mkdir -p "$OBJ/opengv" "$OBJ/slam"
 L="$REF/src/libs"
 INC="-I$REF/src/slam/src -I$P/include/opencv4 -I$L/opencv/modules/highgui/include -I$L/opencv/modules/imgcodecs/include \
@@ -46,12 +48,25 @@ compile() { # src obj std
   compile "$HERE/ref_shim.cpp" "$OBJ/ref_shim.o" c++17
   compile "$HERE/ref_shim_map.cpp" "$OBJ/ref_shim_map.o" c++17
   compile "$HERE/ref_shim_relpose.cpp" "$OBJ/ref_shim_relpose.o" c++17
+  compile "$HERE/ref_shim_system.cpp" "$OBJ/ref_shim_system.o" c++17
+  # the product's host-side map layer over the reference's L1 stages (sys_cpu.cpp): host-logic tests without a GPU
+  SLAM="$HERE/../alvaar_amd/csrc/slam"
+  mkdir -p "$OBJ/syscpu"
+  for f in "$SLAM"/*.cpp; do
+    o="$OBJ/syscpu/$(basename "$f" .cpp).o"
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find "$SLAM" -name '*.hpp' -newer "$o")" ]; then
+      echo "g++ -std=c++17 -O2 -fPIC -Wall -DNDEBUG -ffp-contract=off -c '$f' -o '$o'"
+    fi
+  done
+  if [ ! -f "$OBJ/sys_cpu.o" ] || [ "$HERE/sys_cpu.cpp" -nt "$OBJ/sys_cpu.o" ] || [ -n "$(find "$SLAM" "$HERE/alva_oracle.h" -name '*.h*' -newer "$OBJ/sys_cpu.o")" ]; then
+    echo "g++ -std=c++17 $CXXFLAGS $INC -I$HERE -I$HERE/../alvaar_amd/csrc -c '$HERE/sys_cpu.cpp' -o '$OBJ/sys_cpu.o'"
+  fi
 } > "$OBJ/cmds.txt"
 if [ -s "$OBJ/cmds.txt" ]; then
   xargs -P "$J" -I{} bash -c '{}' < "$OBJ/cmds.txt"
 fi
-g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ/ref_shim_relpose.o" "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
+g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ/ref_shim_relpose.o" "$OBJ/ref_shim_system.o" "$OBJ/sys_cpu.o" "$OBJ"/syscpu/*.o "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
   -Wl,--start-group "$P/lib/libopencv_video.a" "$P/lib/libopencv_calib3d.a" "$P/lib/libopencv_features2d.a" \
   "$P/lib/libopencv_flann.a" "$P/lib/libopencv_imgproc.a" "$P/lib/libopencv_core.a" -Wl,--end-group \
-  "$P/lib/libceres.a" "$P"/lib/opencv4/3rdparty/libzlib.a -lpthread -ldl -Wl,--exclude-libs,ALL
+  "$P/lib/libceres.a" "$P"/lib/opencv4/3rdparty/libzlib.a -lpthread -ldl -Wl,--exclude-libs,ALL -Wl,--wrap=gettimeofday -L"$HERE" -lalva_oracle -Wl,-rpath,'$ORIGIN/..'
 echo "built $OUT/libalva_ref.so"

@@ -1,0 +1,265 @@
+// TEST INFRASTRUCTURE ONLY (part of oracle/_ref/libalva_ref.so) -- never linked into, shipped with or loaded by alvaar_amd/.
+//
+// syscpu_*: the product's host-side map layer (alvaar_amd/csrc/slam/*.cpp -- the very sources libalvaar_hip.so compiles) with
+// its numeric stages provided by the REFERENCE's own L1 functions (FeatureTracker, FeatureExtractor, MultiViewGeometry,
+// CameraCalibration and the vendored OpenCV / OpenGV / Ceres under them) instead of the HIP kernels.  Purpose: on a machine
+// without a GPU, check the host logic -- keyframe policy, map bookkeeping, container orders, BA graph construction, write-back,
+// culling -- against the reference's System (ref_system_*, ref_shim_system.cpp) frame by frame.  With identical stage
+// arithmetic underneath, any difference is a bookkeeping difference.  The GPU tests then run the same map layer over the HIP
+// stages (alva_system_*) against the same reference.
+// Two stages have no stand-alone reference entry point and use the plain-C restatements that tests/test_oracle_vs_ref.py pins
+// to the reference: orc_match_to_map_flags (== Mapper::matchToMap on flattened maps) and orc_find_plane.
+#include <sys/time.h>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <sophus/se3.hpp>
+#include <opencv2/core.hpp>
+#include <opencv2/imgproc.hpp>
+#include <opencv2/video/tracking.hpp>
+#include "frame.hpp"
+#include "feature_tracker.hpp"
+#include "feature_extractor.hpp"
+#include "multi_view_geometry.hpp"
+#include "camera_calibration.hpp"
+#include "alva_oracle.h"
+#include "slam/slam.hpp"
+#include "slam/inspect.hpp"
+
+extern "C" int ref_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *calib, int invDepth, int nPt, const int *ptAnchorKf,
+                            const double *ptAnchorUv, double *ptParam, int nObs, const int *obsKf, const int *obsPt, const double *obsUv,
+                            int maxIterations, double functionTolerance, double huberChi2, double *chi2, uint8_t *depthPos, double *info);
+
+namespace {
+using namespace alva_slam;
+typedef std::vector<Eigen::Vector3d, Eigen::aligned_allocator<Eigen::Vector3d>> V3;
+typedef std::vector<Eigen::Vector2d, Eigen::aligned_allocator<Eigen::Vector2d>> V2;
+
+Sophus::SE3d se3_of(const double *p) { return Sophus::SE3d(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), Eigen::Vector3d(p[0], p[1], p[2])); }
+void pose7_of(const Sophus::SE3d &T, double *p) {
+    const Eigen::Quaterniond q = T.unit_quaternion();
+    for (int i = 0; i < 3; i++) p[i] = T.translation()(i);
+    p[3] = q.x(); p[4] = q.y(); p[5] = q.z(); p[6] = q.w();
+}
+
+struct RefStages : Stages {
+    Camera cam;
+    bool clahe = false;
+    std::shared_ptr<CameraCalibration> cal;
+    FeatureExtractor extractor;
+    FeatureTracker tracker;
+    cv::Ptr<cv::CLAHE> clahe_op;
+    cv::Mat raw, cur, prev;
+    std::vector<cv::Mat> cur_pyr, prev_pyr;
+
+    RefStages(const Camera &c, bool clahe_on) : cam(c), clahe(clahe_on), extractor(0.001), tracker(30, 0.01f) {  // state.hpp:55-57
+        cal = std::make_shared<CameraCalibration>(c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.width, c.height, c.border);
+        clahe_op = cv::createCLAHE(3, cv::Size(c.width / 50, c.height / 50));  // visual_frontend.cpp:16-18, state.hpp:45-46
+    }
+    int new_frame(const uint8_t *rgba) override {
+        cv::Mat image(cam.height, cam.width, CV_8UC4, const_cast<uint8_t *>(rgba));
+        cv::cvtColor(image, raw, cv::COLOR_RGBA2GRAY);
+        cv::swap(cur, prev);
+        if (clahe) clahe_op->apply(raw, cur);
+        else cur = raw;
+        if (!cur_pyr.empty()) prev_pyr.swap(cur_pyr);
+        cv::buildOpticalFlowPyramid(cur, cur_pyr, cv::Size(9, 9), 3);
+        return 0;
+    }
+    void reset_images() override {
+        cur.release();
+        prev.release();
+        cur_pyr.clear();
+        prev_pyr.clear();
+    }
+    int fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) override {
+        std::vector<cv::Point2f> vp((size_t) n), vq((size_t) n);
+        for (int i = 0; i < n; i++) {
+            vp[(size_t) i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+            vq[(size_t) i] = cv::Point2f(prior[2 * i], prior[2 * i + 1]);
+        }
+        std::vector<bool> st;
+        tracker.fbKltTracking(prev_pyr, cur_pyr, 9, levels, 30, 0.5f, vp, vq, st);  // state.hpp:50-54
+        for (int i = 0; i < n; i++) {
+            prior[2 * i] = vq[(size_t) i].x;
+            prior[2 * i + 1] = vq[(size_t) i].y;
+            status[i] = st[(size_t) i] ? 1 : 0;
+        }
+        return 0;
+    }
+    int compute_keypoints(int n, const float *px, float *unpx, double *bv) override {
+        for (int i = 0; i < n; i++) {
+            const cv::Point2f u = cal->undistortImagePoint(cv::Point2f(px[2 * i], px[2 * i + 1]));
+            Eigen::Vector3d h(u.x, u.y, 1.);  // Frame::computeKeypoint (frame.cpp:105-113)
+            Eigen::Vector3d b = cal->inverseK_ * h;
+            b.normalize();
+            unpx[2 * i] = u.x; unpx[2 * i + 1] = u.y;
+            bv[3 * i] = b(0); bv[3 * i + 1] = b(1); bv[3 * i + 2] = b(2);
+        }
+        return 0;
+    }
+    int project_dist(int n, const double *P, float *px) override {
+        for (int i = 0; i < n; i++) {
+            const cv::Point2f r = cal->projectCamToImageDist(Eigen::Vector3d(P[3 * i], P[3 * i + 1], P[3 * i + 2]));
+            px[2 * i] = r.x; px[2 * i + 1] = r.y;
+        }
+        return 0;
+    }
+    int p3p(int n, const double *bv, const double *wpt, int do_random, double *pose7, int *outliers, int *n_out, int *ok) override {
+        V3 vb((size_t) n), vw((size_t) n);
+        for (int i = 0; i < n; i++) {
+            vb[(size_t) i] = Eigen::Vector3d(bv[3 * i], bv[3 * i + 1], bv[3 * i + 2]);
+            vw[(size_t) i] = Eigen::Vector3d(wpt[3 * i], wpt[3 * i + 1], wpt[3 * i + 2]);
+        }
+        Sophus::SE3d Twc = se3_of(pose7);
+        std::vector<int> out;
+        *ok = MultiViewGeometry::p3pRansac(vb, vw, 100, 3.0f, false, do_random != 0, cam.fx, cam.fy, Twc, out) ? 1 : 0;  // state.hpp:68-69
+        if (*ok) pose7_of(Twc, pose7);
+        *n_out = (int) out.size();
+        for (size_t i = 0; i < out.size(); i++) outliers[i] = out[i];
+        return 0;
+    }
+    int pnp(int n, const double *uv, const double *wpt, double *pose7, int *outliers, int *n_out, int *ok) override {
+        V2 vk((size_t) n);
+        V3 vw((size_t) n);
+        for (int i = 0; i < n; i++) {
+            vk[(size_t) i] = Eigen::Vector2d(uv[2 * i], uv[2 * i + 1]);
+            vw[(size_t) i] = Eigen::Vector3d(wpt[3 * i], wpt[3 * i + 1], wpt[3 * i + 2]);
+        }
+        Sophus::SE3d Twc = se3_of(pose7);
+        std::vector<int> out;
+        *ok = MultiViewGeometry::ceresPnP(vk, vw, Twc, 5, 5.9915f, true, true, cam.fx, cam.fy, cam.cx, cam.cy, out) ? 1 : 0;
+        pose7_of(Twc, pose7);
+        *n_out = (int) out.size();
+        for (size_t i = 0; i < out.size(); i++) outliers[i] = out[i];
+        return 0;
+    }
+    int five_point(int n, const double *b1, const double *b2, int do_random, double *R, double *t, int *outliers, int *n_out, int *ok) override {
+        V3 v1((size_t) n), v2((size_t) n);
+        for (int i = 0; i < n; i++) {
+            v1[(size_t) i] = Eigen::Vector3d(b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]);
+            v2[(size_t) i] = Eigen::Vector3d(b2[3 * i], b2[3 * i + 1], b2[3 * i + 2]);
+        }
+        Eigen::Matrix3d Rwc = Eigen::Matrix3d::Identity();
+        Eigen::Vector3d twc = Eigen::Vector3d::Zero();
+        std::vector<int> out;
+        *ok = MultiViewGeometry::compute5ptEssentialMatrix(v1, v2, 100, 3.0f, true, do_random != 0, cam.fx, cam.fy, Rwc, twc, out) ? 1 : 0;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) R[3 * r + c] = Rwc(r, c);
+            t[r] = twc(r);
+        }
+        *n_out = (int) out.size();
+        for (size_t i = 0; i < out.size(); i++) outliers[i] = out[i];
+        return 0;
+    }
+    int detect(int cell, int n_occ, const float *occ, int cap, float *pts, int *count) override {
+        std::vector<cv::Point2f> o((size_t) n_occ);
+        for (int i = 0; i < n_occ; i++) o[(size_t) i] = cv::Point2f(occ[2 * i], occ[2 * i + 1]);
+        const std::vector<cv::Point2f> r = extractor.detectFeaturePoints(cur, cell, o, cal->roi_rect_);
+        *count = (int) std::min<size_t>(r.size(), (size_t) cap);
+        for (int i = 0; i < *count; i++) {
+            pts[2 * i] = r[(size_t) i].x;
+            pts[2 * i + 1] = r[(size_t) i].y;
+        }
+        return 0;
+    }
+    int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) override {
+        std::vector<cv::Point2f> v((size_t) n);
+        for (int i = 0; i < n; i++) v[(size_t) i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+        const std::vector<cv::Mat> d = extractor.describeFeaturePoints(raw, v);
+        for (int i = 0; i < n; i++) {
+            const bool ok = i < (int) d.size() && !d[(size_t) i].empty();
+            valid[i] = ok;
+            if (ok) std::memcpy(desc + 32 * (size_t) i, d[(size_t) i].ptr<uint8_t>(0), 32);
+            else std::memset(desc + 32 * (size_t) i, 0, 32);
+        }
+        return 0;
+    }
+    int triangulate(int n, int, const double *T, const int *group, const double *bvl, const double *bvr, const float *ul, const float *ur,
+                    double *wpt, double *inv_depth, uint8_t *status, double *parallax) override {
+        std::vector<double> lpt((size_t) n * 3);
+        // the restatement pinned to MultiViewGeometry::triangulate + the gates of mapper.cpp:246-280 (tests/test_triangulate.py)
+        orc_triangulate(n, T, group, bvl, bvr, ul, ur, cam.fx, cam.fy, cam.cx, cam.cy, 3.0f, lpt.data(), wpt, inv_depth, status, parallax);
+        return 0;
+    }
+    int match_to_map(int cell_size, int ncw, int grid_cells, const int *cell_ptr, const int *cell_mp, int n_kf, const double *kf_q,
+                     const double *kf_t, int n_mp, const double *mp_wpt, const uint8_t *mp_is3d, const uint8_t *mp_has_desc, const int *obs_ptr,
+                     const int *obs_kf, const float *obs_px, const uint8_t *obs_desc, const uint8_t *obs_has_desc, int frame_kf, int n3d,
+                     int n_local, const int *local, float max_proj_err, float dist_ratio, int *match_of_mp) override {
+        const double calib[10] = {cam.fx, cam.fy, cam.cx, cam.cy, cam.k1, cam.k2, cam.p1, cam.p2, (double) cam.width, (double) cam.height};
+        orc_match_to_map_flags(calib, cell_size, ncw, grid_cells, cell_ptr, cell_mp, n_kf, kf_q, kf_t, n_mp, mp_wpt, mp_is3d, mp_has_desc, obs_ptr,
+                               obs_kf, obs_px, obs_desc, obs_has_desc, frame_kf, n3d, n_local, local, max_proj_err, dist_ratio, match_of_mp);
+        return 0;
+    }
+    int local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_anchor_kf, const double *pt_anchor_uv,
+                 double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters, double *chi2,
+                 uint8_t *depth_pos) override {
+        const double calib[4] = {cam.fx, cam.fy, cam.cx, cam.cy};
+        ref_local_ba(n_kf, poses7, kf_const, calib, 1, n_pt, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_pt, obs_uv, max_iters,
+                     0.001, 5.9915f, chi2, depth_pos, nullptr);  // optimizer.cpp:251-262
+        return 0;
+    }
+    int find_plane(int, const double *, const double *, int, float *, int *found) override {
+        *found = 0;
+        return 0;
+    }
+};
+
+struct CpuSys {
+    std::unique_ptr<RefStages> stages;
+    std::unique_ptr<Slam> slam;
+};
+}  // namespace
+
+extern "C" {
+
+void *syscpu_create(int w, int h, double fx, double fy, double cx, double cy, double k1, double k2, double p1, double p2, int cellSize,
+                    int claheEnabled, int doRandom) {
+    auto *s = new CpuSys();
+    Camera cam;
+    cam.width = w; cam.height = h; cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy; cam.k1 = k1; cam.k2 = k2; cam.p1 = p1; cam.p2 = p2;
+    Settings cfg;
+    cfg.cell_size = cellSize > 0 ? cellSize : 40;
+    cfg.clahe = claheEnabled != 0;
+    cfg.random_sampling = doRandom != 0;
+    s->stages.reset(new RefStages(cam, cfg.clahe));
+    s->slam.reset(new Slam(s->stages.get(), cam, cfg));
+    return s;
+}
+void syscpu_destroy(void *p) { delete static_cast<CpuSys *>(p); }
+void syscpu_reset(void *p) { static_cast<CpuSys *>(p)->slam->reset(); }
+int syscpu_find_camera_pose(void *p, const uint8_t *rgba, double timestamp, float *pose16, double *pose7) {
+    Slam &s = *static_cast<CpuSys *>(p)->slam;
+    const int status = s.process_frame(rgba, timestamp);
+    if (pose16) pose_to_array(s.cur->Twc, pose16);
+    if (pose7) se3_to_pose7(s.cur->Twc, pose7);
+    return status;
+}
+void syscpu_set_init_pose(void *p, const double *pose7) {
+    Slam &s = *static_cast<CpuSys *>(p)->slam;
+    s.init_override.armed = pose7 != nullptr;
+    if (pose7) std::memcpy(s.init_override.pose7, pose7, 56);
+}
+void syscpu_state(void *p, int *out) { inspect_state(*static_cast<CpuSys *>(p)->slam, out); }
+int syscpu_frame_keypoints(void *p, int cap, int *ids, float *px, float *unpx, uint8_t *is3d, uint8_t *hasDesc) {
+    return inspect_frame(*static_cast<CpuSys *>(p)->slam->cur, cap, ids, px, unpx, is3d, hasDesc);
+}
+int syscpu_keyframe_ids(void *p, int cap, int *ids) { return inspect_keyframe_ids(*static_cast<CpuSys *>(p)->slam, cap, ids); }
+int syscpu_keyframe(void *p, int kfid, double *pose7, int *info, int cap, int *ids, float *px, uint8_t *is3d) {
+    return inspect_keyframe(*static_cast<CpuSys *>(p)->slam, kfid, pose7, info, cap, ids, px, is3d);
+}
+int syscpu_covisibility(void *p, int kfid, int cap, int *pairs) { return inspect_covisibility(*static_cast<CpuSys *>(p)->slam, kfid, cap, pairs); }
+int syscpu_map_points(void *p, int cap, int *ids, double *xyz, int *flags, double *invDepth, uint8_t *desc) {
+    return inspect_map_points(*static_cast<CpuSys *>(p)->slam, cap, ids, xyz, flags, invDepth, desc);
+}
+void syscpu_counters(void *p, long *out) {
+    Slam &s = *static_cast<CpuSys *>(p)->slam;
+    out[0] = s.n_ba_runs; out[1] = s.n_merges; out[2] = s.n_kf_culled;
+}
+
+}  // extern "C"
