@@ -32,15 +32,19 @@ def _newer(src: Path, dst: Path, deps: list[Path]) -> bool:
 
 
 def build(verbose: bool = False) -> Path:
-    srcs = sorted(CSRC.glob("*.hip"))
-    hdrs = sorted(CSRC.glob("*.hpp")) + sorted((ROOT / "include").glob("*.h"))
+    # *.hip: kernels + C ABI; slam/*.cpp: the host-side map layer (plain C++, no HIP) behind alva_system_*
+    srcs = sorted(CSRC.glob("*.hip")) + sorted((CSRC / "slam").glob("*.cpp"))
+    hdrs = sorted(CSRC.glob("*.hpp")) + sorted((CSRC / "slam").glob("*.hpp")) + sorted((ROOT / "include").glob("*.h"))
     objs = []
     jobs = []
     for s in srcs:
         o = s.with_suffix(".o")
         objs.append(o)
         if _newer(s, o, hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", str(s), "-o", str(o)])
+            if s.suffix == ".cpp":
+                jobs.append([HIPCC, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-c", str(s), "-o", str(o)])
+            else:
+                jobs.append([HIPCC, *FLAGS, "-c", str(s), "-o", str(o)])
 
     def run(cmd):
         if verbose:

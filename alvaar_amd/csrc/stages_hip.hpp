@@ -1,0 +1,41 @@
+// HIP implementation of the map layer's stage interface (see slam/stages.hpp and stages_hip.hip).
+#pragma once
+#include "slam/se3.hpp"
+#include "slam/stages.hpp"
+
+namespace alva_slam {
+
+class HipStages : public Stages {
+public:
+    HipStages();
+    ~HipStages() override;
+    int init(int device, const Camera &cam, bool clahe, const double *invK);
+
+    int new_frame(const uint8_t *rgba) override;
+    void reset_images() override;
+    int fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) override;
+    int compute_keypoints(int n, const float *px, float *unpx, double *bv) override;
+    int project_dist(int n, const double *cam_pts, float *px) override;
+    int p3p(int n, const double *bv, const double *wpt, int do_random, double *pose7, int *outliers, int *n_outliers, int *ok) override;
+    int pnp(int n, const double *unpx_d, const double *wpt, double *pose7, int *outliers, int *n_outliers, int *ok) override;
+    int five_point(int n, const double *bv_kf, const double *bv_cur, int do_random, double *R, double *t, int *outliers, int *n_outliers,
+                   int *ok) override;
+    int detect(int cell, int n_occ, const float *occupied, int cap, float *pts, int *count) override;
+    int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) override;
+    int triangulate(int n, int n_groups, const double *T36, const int *group, const double *bv_l, const double *bv_r, const float *unpx_l,
+                    const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status, double *parallax) override;
+    int match_to_map(int cell_size, int num_cells_w, int grid_cells, const int *cell_ptr, const int *cell_mp, int n_kf, const double *kf_q,
+                     const double *kf_t, int n_mp, const double *mp_wpt, const uint8_t *mp_is3d, const uint8_t *mp_has_desc, const int *obs_ptr,
+                     const int *obs_kf, const float *obs_px, const uint8_t *obs_desc, const uint8_t *obs_has_desc, int frame_kf,
+                     int num_keypoints_3d, int n_local, const int *local, float max_proj_err, float dist_ratio, int *match_of_mp) override;
+    int local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_anchor_kf, const double *pt_anchor_uv,
+                 double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters, double *chi2,
+                 uint8_t *depth_pos) override;
+    int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) override;
+
+private:
+    struct Impl;
+    Impl *m;
+};
+
+}  // namespace alva_slam

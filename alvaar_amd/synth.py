@@ -368,3 +368,45 @@ def make_relpose_problem(n: int, seed: int, outlier_frac: float = 0.2, px_noise:
         return b / np.linalg.norm(b, axis=1, keepdims=True)
     return dict(bv1=np.ascontiguousarray(bearings(X1, False)), bv2=np.ascontiguousarray(bearings(X2, True)), R12=R12, t12=t12, bad=bad,
                 K=(fx, fy, cx, cy))
+
+
+# ----------------------------------------------------------------------------------------------
+# A camera moving in front of a textured plane (rotation + translation): frames for System-level tests
+def plane_camera_pose(k: int):
+    """Twc of frame k: smooth translation (~2 px / frame at the start, so that the 40-px initialisation parallax is reached within ~20
+    frames) with a slow rotation about all three axes.  Returns (R_wc 3x3, t_wc 3)."""
+    t = np.array([0.9 * np.sin(0.016 * k), 0.45 * np.sin(0.011 * k), 0.3 * (1.0 - np.cos(0.01 * k))])
+    w = np.array([0.03 * np.sin(0.02 * k), 0.05 * np.sin(0.013 * k), 0.04 * np.sin(0.009 * k)])
+    return so3_exp(w), t
+
+
+def render_plane(canvas: np.ndarray, width: int, height: int, f: float, R_wc: np.ndarray, t_wc: np.ndarray, plane_z: float = 4.0) -> np.ndarray:
+    """The plane z = plane_z (world frame) textured with `canvas` (1 canvas pixel = plane_z / f metres, canvas centre on the optical
+    axis of the identity pose), seen by a pinhole camera (f, principal point at the image centre) at pose Twc: inverse mapping of
+    every output pixel, bilinear sampling, u8."""
+    ch, cw = canvas.shape
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    d = np.stack([(xs - width * 0.5) / f, (ys - height * 0.5) / f, np.ones_like(xs)], -1) @ R_wc.T
+    lam = (plane_z - t_wc[2]) / d[..., 2]
+    X = t_wc[0] + lam * d[..., 0]
+    Y = t_wc[1] + lam * d[..., 1]
+    s = f / plane_z
+    u = cw * 0.5 + s * X
+    v = ch * 0.5 + s * Y
+    u0 = np.clip(np.floor(u).astype(np.int64), 0, cw - 2)
+    v0 = np.clip(np.floor(v).astype(np.int64), 0, ch - 2)
+    a = np.clip(u - u0, 0.0, 1.0)
+    b = np.clip(v - v0, 0.0, 1.0)
+    c = canvas.astype(np.float64)
+    out = (c[v0, u0] * (1 - a) * (1 - b) + c[v0, u0 + 1] * a * (1 - b) + c[v0 + 1, u0] * (1 - a) * b + c[v0 + 1, u0 + 1] * a * b)
+    out[(lam <= 0) | (u < 0) | (v < 0) | (u > cw - 1) | (v > ch - 1)] = 0
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def plane_stream_frame(canvas: np.ndarray, k: int, width: int, height: int, f: float, noise_seed: int | None = None) -> np.ndarray:
+    R, t = plane_camera_pose(k)
+    g = render_plane(canvas, width, height, f, R, t)
+    if noise_seed is not None:
+        rng = np.random.RandomState(noise_seed + k)
+        g = np.clip(g.astype(np.int16) + rng.randint(-4, 5, g.shape), 0, 255).astype(np.uint8)
+    return gray_to_rgba(g)

@@ -22,8 +22,17 @@ lib.alva_system_find_camera_pose_with_imu.argtypes = [_vp, _vp, _vp, _vp]
 lib.alva_system_find_plane.argtypes = [_vp, _vp, _i]
 lib.alva_system_get_frame_points.argtypes = [_vp, _vp]
 lib.alva_system_get_keypoints.argtypes = [_vp, _vp, _vp, _vp, _i]
-lib.alva_system_set_map_points.argtypes = [_vp, _vp, _vp, _i]
-lib.alva_system_set_pose.argtypes = [_vp, _vp]
+lib.alva_system_configure_ex.argtypes = [_vp, _i, _i] + [_d] * 8 + [_i] * 3
+lib.alva_system_find_camera_pose_ts.argtypes = [_vp, _vp, _d, _vp]
+lib.alva_system_debug_state.argtypes = [_vp, _vp]
+lib.alva_system_debug_pose7.argtypes = [_vp, _vp, _vp]
+lib.alva_system_debug_frame_keypoints.argtypes = [_vp, _i] + [_vp] * 5
+lib.alva_system_debug_keyframe_ids.argtypes = [_vp, _i, _vp]
+lib.alva_system_debug_keyframe.argtypes = [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]
+lib.alva_system_debug_covisibility.argtypes = [_vp, _i, _i, _vp]
+lib.alva_system_debug_map_points.argtypes = [_vp, _i] + [_vp] * 5
+lib.alva_system_debug_counters.argtypes = [_vp, _vp]
+lib.alva_system_debug_set_init_pose.argtypes = [_vp, _vp]
 lib.alva_system_last_error.restype = C.c_char_p
 
 
@@ -39,17 +48,28 @@ def camera_intrinsics(width: int, height: int, fov: float = 45.0):
 
 
 class AlvaAR:
-    def __init__(self, width: int, height: int, fov: float = 45.0, device: int = 0):
+    def __init__(self, width: int, height: int, fov: float = 45.0, device: int = 0, cell_size: int | None = None, clahe: bool = False,
+                 random_sampling: bool = True, distortion=(0.0, 0.0, 0.0, 0.0)):
+        """cell_size / clahe / random_sampling: the settings System::configure hard-codes (system.cpp:15-19, state.hpp:67);
+        None = the shipped configuration through alva_system_configure."""
         self.intrinsics = camera_intrinsics(width, height, fov)
+        self.intrinsics.update(dict(zip(("k1", "k2", "p1", "p2"), map(float, distortion))))
         h = _vp()
         rc = lib.alva_system_create(device, C.byref(h))
         if rc:
             raise AlvaError(lib.alva_system_last_error().decode())
         self.h = h
         k = self.intrinsics
-        rc = lib.alva_system_configure(h, width, height, k["fx"], k["fy"], k["cx"], k["cy"], k["k1"], k["k2"], k["p1"], k["p2"])
+        if cell_size is None and not clahe and random_sampling:
+            rc = lib.alva_system_configure(h, width, height, k["fx"], k["fy"], k["cx"], k["cy"], k["k1"], k["k2"], k["p1"], k["p2"])
+        else:
+            rc = lib.alva_system_configure_ex(h, width, height, k["fx"], k["fy"], k["cx"], k["cy"], k["k1"], k["k2"], k["p1"], k["p2"],
+                                              cell_size or 40, int(clahe), int(random_sampling))
         if rc:
-            raise AlvaError(lib.alva_system_last_error().decode())
+            msg = lib.alva_system_last_error().decode()
+            lib.alva_system_destroy(h)
+            self.h = None
+            raise AlvaError(msg)
         self._pose = np.zeros(16, np.float32)
 
     @staticmethod
@@ -63,10 +83,14 @@ class AlvaAR:
 
     __del__ = close
 
-    def findCameraPose(self, frame_rgba: np.ndarray):  # noqa: N802
-        """returns (pose[16] or None, status) -- the JS wrapper returns the pose only on status 1"""
+    def findCameraPose(self, frame_rgba: np.ndarray, timestamp_ms: float | None = None):  # noqa: N802
+        """returns (pose[16] or None, status) -- the JS wrapper returns the pose only on status 1.  timestamp_ms = None reads the
+        system clock like the reference (system.cpp:114)."""
         frame = np.ascontiguousarray(frame_rgba, np.uint8)
-        status = lib.alva_system_find_camera_pose(self.h, frame.ctypes.data, self._pose.ctypes.data)
+        if timestamp_ms is None:
+            status = lib.alva_system_find_camera_pose(self.h, frame.ctypes.data, self._pose.ctypes.data)
+        else:
+            status = lib.alva_system_find_camera_pose_ts(self.h, frame.ctypes.data, float(timestamp_ms), self._pose.ctypes.data)
         if status < 0:
             raise AlvaError(lib.alva_system_last_error().decode())
         return (self._pose.copy() if status == 1 else None), status
@@ -94,15 +118,60 @@ class AlvaAR:
     def reset(self):
         lib.alva_system_reset(self.h)
 
-    # bootstrap helpers (until the mapper rows of SURVEY.md §8f are built)
-    def keypoints(self, cap: int = 8192):
+    def keypoints(self, cap: int = 16384):
         ids = np.zeros(cap, np.int32)
         px = np.zeros((cap, 2), np.float32)
         is3d = np.zeros(cap, np.uint8)
         n = min(lib.alva_system_get_keypoints(self.h, ids.ctypes.data, px.ctypes.data, is3d.ctypes.data, cap), cap)
         return ids[:n], px[:n], is3d[:n].astype(bool)
 
-    def set_map_points(self, ids, xyz):
-        ids = np.ascontiguousarray(ids, np.int32)
-        xyz = np.ascontiguousarray(xyz, np.float64)
-        return lib.alva_system_set_map_points(self.h, ids.ctypes.data, xyz.ctypes.data, len(ids))
+    # ---- inspection (alva_system_debug_*), same layouts as the reference-side shim of the tests
+    def pose7(self):
+        p, q = np.zeros(7), np.zeros(7)
+        lib.alva_system_debug_pose7(self.h, p.ctypes.data, q.ctypes.data)
+        return p, q
+
+    def state(self):
+        out = np.zeros(16, np.int32)
+        lib.alva_system_debug_state(self.h, out.ctypes.data)
+        return out
+
+    def frame_keypoints(self, cap: int = 16384):
+        ids, px, un = np.zeros(cap, np.int32), np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        i3, hd = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = lib.alva_system_debug_frame_keypoints(self.h, cap, ids.ctypes.data, px.ctypes.data, un.ctypes.data, i3.ctypes.data, hd.ctypes.data)
+        return ids[:n], px[:n], un[:n], i3[:n], hd[:n]
+
+    def keyframe_ids(self, cap: int = 256):
+        ids = np.zeros(cap, np.int32)
+        n = lib.alva_system_debug_keyframe_ids(self.h, cap, ids.ctypes.data)
+        return ids[:n]
+
+    def keyframe(self, kfid: int, cap: int = 16384):
+        pose, info = np.zeros(7), np.zeros(6, np.int32)
+        ids, px, i3 = np.zeros(cap, np.int32), np.zeros((cap, 2), np.float32), np.zeros(cap, np.uint8)
+        n = lib.alva_system_debug_keyframe(self.h, kfid, pose.ctypes.data, info.ctypes.data, cap, ids.ctypes.data, px.ctypes.data, i3.ctypes.data)
+        return pose, info, ids[:n], px[:n], i3[:n]
+
+    def covisibility(self, kfid: int = -1, cap: int = 256):
+        pairs = np.zeros((cap, 2), np.int32)
+        n = lib.alva_system_debug_covisibility(self.h, kfid, cap, pairs.ctypes.data)
+        return pairs[:max(n, 0)]
+
+    def map_points(self, cap: int = 65536):
+        ids, xyz, fl = np.zeros(cap, np.int32), np.zeros((cap, 3)), np.zeros((cap, 5), np.int32)
+        inv, desc = np.zeros(cap), np.zeros((cap, 32), np.uint8)
+        n = lib.alva_system_debug_map_points(self.h, cap, ids.ctypes.data, xyz.ctypes.data, fl.ctypes.data, inv.ctypes.data, desc.ctypes.data)
+        return ids[:n], xyz[:n], fl[:n], inv[:n], desc[:n]
+
+    def counters(self):
+        out = (C.c_long * 3)()
+        lib.alva_system_debug_counters(self.h, out)
+        return dict(ba_solves=out[0], merges=out[1], culled_keyframes=out[2])
+
+    def set_init_pose(self, pose7):
+        if pose7 is None:
+            lib.alva_system_debug_set_init_pose(self.h, None)
+        else:
+            p = np.ascontiguousarray(pose7, np.float64)
+            lib.alva_system_debug_set_init_pose(self.h, p.ctypes.data)

@@ -9,15 +9,16 @@
  * Pose layout (src/slam/src/utils.cpp:3-27): p[0..2] = R row 0, p[4..6] = R row 1, p[8..10] = R row 2,
  * p[12..14] = t, p[3] = p[7] = p[11] = 0, p[15] = 1 (Twc).
  *
- * Scope (DESIGN.md "System surface"): the per-frame loop of SURVEY.md §3.2 runs on the GPU (gray -> pyramid -> fb-KLT ->
- * P3P-LMedS -> PnP), and so does the cold start: keyframe 0 on the first frame, the parallax gate and the five-point
- * initialisation of VisualFrontend::checkReadyForInit (unit baseline), triangulation of every new keyframe's 2-D keypoints
- * against the keyframe that first saw them (Mapper::triangulateTemporal), new keyframes by checkNewKeyframeRequired with grid
- * detection + ORB description in the free cells.  The reference's map layer above that (matching to the local map, local-BA
- * scheduling, keyframe / map-point culling) is not mirrored: alva_local_ba / alva_match_to_map exist in
- * alvaar_hip.h for a host that keeps that graph.  alva_system_set_map_points lets a host attach its own 3-D points instead of
- * the two-view initialisation.  find_plane runs the plane fit the reference intends (alva_find_plane; the reference function itself
- * computes on reinterpreted memory, so its parity is unpinned) on the current frame's 3-D keypoints.
+ * Scope (DESIGN.md "System surface"): the WHOLE per-frame path of System::processCameraPose (system.cpp:156-175) --
+ * VisualFrontend::track/process (motion-model priors, two-pass forward-backward KLT, P3P-LMedS + robust PnP, pose-failure
+ * handling, five-point initialisation, keyframe policy), MapManager::createKeyframe (grid detection + ORB description, descriptor
+ * medoids), Mapper::processNewKeyframe (triangulation, covisibility, guided matching to the local map + map-point merging,
+ * local bundle adjustment with outlier sweep and write-back, map-point and keyframe culling).  The bookkeeping is host code
+ * (alvaar_amd/csrc/slam/), every numeric stage runs on the GPU through include/alvaar_hip.h.  Lens distortion (k1 k2 p1 p2) and CLAHE
+ * are wired (camera_calibration.cpp:34-72, visual_frontend.cpp:678-681).  find_plane runs the plane fit the reference intends
+ * (alva_find_plane; the reference function itself computes on reinterpreted memory, so its parity is unpinned).
+ * Known deviations: a timestamp older than the previous one resets the tracker (status 2) instead of exit(-1)
+ * (visual_frontend.hpp:46-50); P3P-LMedS is solved on the first 7168 3-D keypoints of a frame when there are more.
  */
 #ifndef ALVAAR_SYSTEM_H
 #define ALVAAR_SYSTEM_H
@@ -33,12 +34,21 @@ typedef struct alva_system alva_system;
 
 int alva_system_create(int device, alva_system **out);
 void alva_system_destroy(alva_system *sys);
-/* System::configure (system.cpp:13-40).  Non-zero distortion coefficients are rejected for now. */
+/* System::configure (system.cpp:13-40): cell size 40, CLAHE off, clock-seeded sampling.  A failed call leaves the object
+ * unconfigured (every later call returns ALVA_ERR_ARG) and alva_system_last_error() says why. */
 int alva_system_configure(alva_system *sys, int width, int height, double fx, double fy, double cx, double cy, double k1,
                           double k2, double p1, double p2);
+/* The same with the three settings System::configure hard-codes (system.cpp:15-19; state.hpp:67): the keypoint cell size
+ * (12 at 640x480 = the 2000-keypoint workload of BASELINE configs[1]), CLAHE, and random_sampling = 0 for the fixed sample
+ * streams of OpenGV (seed 12345) that the differential tests use. */
+int alva_system_configure_ex(alva_system *sys, int width, int height, double fx, double fy, double cx, double cy, double k1,
+                             double k2, double p1, double p2, int cell_size, int clahe_enabled, int random_sampling);
 void alva_system_reset(alva_system *sys);
 /* System::findCameraPose (system.cpp:106-121).  h_rgba: width*height*4 bytes, caller-owned; h_pose: float[16]. */
 int alva_system_find_camera_pose(alva_system *sys, const uint8_t *h_rgba, float *h_pose);
+/* The same with the frame's timestamp (milliseconds) as an argument instead of the system clock (system.cpp:114): the
+ * constant-velocity motion model (visual_frontend.hpp:11-68) is the only consumer. */
+int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, double timestamp_ms, float *h_pose);
 /* System::findCameraPoseWithIMU (system.cpp:57-104).  h_imu: [qw,qx,qy,qz,n, n x {ts,gx,gy,gz,ax,ay,az}]. Always returns 1. */
 int alva_system_find_camera_pose_with_imu(alva_system *sys, const uint8_t *h_rgba, const double *h_imu, float *h_pose);
 /* System::findPlane (system.cpp:123-137): 1 on success, 0 otherwise (needs >= 32 observed 3-D points). */
@@ -47,11 +57,24 @@ int alva_system_find_plane(alva_system *sys, float *h_pose, int num_iterations);
  * keypoints, at most 2048 points (the caller's buffer is uint32[4096], src/system.js:64); returns their count. */
 int alva_system_get_frame_points(alva_system *sys, int *h_points);
 
-/* Bootstrap until the mapper rows are built: attach world points to current keypoints by keypoint id.
- * alva_system_get_keypoints returns ids + pixel positions of the current frame's keypoints (capacity cap). */
+/* ids + pixel positions + 3-D flag of the current frame's keypoints, in the frame container's order; returns their number */
 int alva_system_get_keypoints(alva_system *sys, int *h_ids, float *h_px, uint8_t *h_is3d, int cap);
-int alva_system_set_map_points(alva_system *sys, const int *h_ids, const double *h_xyz, int n);
-int alva_system_set_pose(alva_system *sys, const double *h_pose7);
+
+/* ---- inspection (tests, tools): flat views of the map layer's state, same layouts as oracle/ref_shim_system.cpp produces for
+ * the reference's System.  out16: frame id, keyframe id, #keypoints, #2-D, #3-D, occupied cells, #keyframes, #map points, map
+ * initialised, p3pReq_, poseFailedCounter_, next keyframe id, next map point id, |local map|, |covisible|, frameMaxNumKeypoints_. */
+int alva_system_debug_state(alva_system *sys, int *out16);
+int alva_system_debug_pose7(alva_system *sys, double *pose7_twc, double *init_pose7);
+int alva_system_debug_frame_keypoints(alva_system *sys, int cap, int *ids, float *px, float *unpx, uint8_t *is3d, uint8_t *has_desc);
+int alva_system_debug_keyframe_ids(alva_system *sys, int cap, int *ids);
+int alva_system_debug_keyframe(alva_system *sys, int kfid, double *pose7, int *info6, int cap, int *ids, float *px, uint8_t *is3d);
+int alva_system_debug_covisibility(alva_system *sys, int kfid, int cap, int *pairs);
+int alva_system_debug_map_points(alva_system *sys, int cap, int *ids, double *xyz, int *flags5, double *inv_depth, uint8_t *desc);
+int alva_system_debug_counters(alva_system *sys, long *out3 /* local-BA solves, map-point merges, culled keyframes */);
+/* Test hook: the two-view initialisation adopts this pose (Twc of the initialisation frame, unit baseline) instead of its own
+ * five-point result -- OpenGV's refinement sits at a rounding-noise floor of 1e-6..1e-4, so a differential
+ * test against the reference either compares up to that gauge or starts both maps from the same two-view pose.  NULL disarms. */
+int alva_system_debug_set_init_pose(alva_system *sys, const double *pose7);
 const char *alva_system_last_error(void);
 
 #ifdef __cplusplus
@@ -61,14 +84,16 @@ namespace alva {
 /* Drop-in for the reference's `class System` (same method names and argument order). */
 class System {
 public:
-    System() { alva_system_create(0, &s_); }
+    System() { status_ = alva_system_create(0, &s_); }
     ~System() { alva_system_destroy(s_); }
     System(const System &) = delete;
     System &operator=(const System &) = delete;
     void configure(int imageWidth, int imageHeight, double fx, double fy, double cx, double cy, double k1, double k2, double p1,
                    double p2) {
-        alva_system_configure(s_, imageWidth, imageHeight, fx, fy, cx, cy, k1, k2, p1, p2);
+        status_ = s_ ? alva_system_configure(s_, imageWidth, imageHeight, fx, fy, cx, cy, k1, k2, p1, p2) : status_;
     }
+    /* 0 when construction and the last configure succeeded (the reference's methods are void; errors surface here) */
+    int status() const { return status_; }
     void reset() { alva_system_reset(s_); }
     /* native, pointer-typed */
     int findCameraPose(const uint8_t *imageRGBA, float *pose) { return alva_system_find_camera_pose(s_, imageRGBA, pose); }
@@ -95,6 +120,7 @@ public:
 
 private:
     alva_system *s_ = nullptr;
+    int status_ = 0;
 };
 }  // namespace alva
 #endif

@@ -1,106 +1,181 @@
-"""GPU: the reference's System surface (a1) driven like the JS wrapper drives it.
-Scene: the synthetic texture is a fronto-parallel plane at depth Z; the canvas crop moves (2, 1) px per frame, which is
-exactly a camera translation of (2 Z / f, Z / f, 0) per frame with no rotation.  Map points are attached once (the
-mapper rows that would triangulate them are SURVEY.md §8f "next"); from then on every pose comes from the GPU hot loop
-gray -> pyramid -> fb-KLT -> P3P-LMedS -> PnP behind findCameraPose."""
+"""GPU: the drop-in surface (a1 / a10 / a13 / f1) against the REFERENCE ITSELF.
+
+alva_system_* (host-side map layer over the HIP stages) and the reference's own System (oracle/_ref: System -> VisualFrontend ->
+MapManager -> Mapper -> Optimizer over the vendored OpenCV / OpenGV / Ceres; determinism switches of SURVEY.md §8c: explicit
+timestamps, fixed-seed sampling, Ceres' wall-clock caps frozen) are fed the same frames.  Asserted per frame: identical status,
+identical counters (keypoints 2-D / 3-D, occupied cells, keyframes, map points, ids handed out, p3pReq_, poseFailedCounter_), identical
+keypoint ids IN CONTAINER ORDER with identical 3-D / descriptor flags, identical keyframe ids, identical map point tables
+(3-D flag, observed flag, observer count, anchor, descriptor count) and identical descriptor medoids; per keyframe the keypoint set,
+covisibility and local-map size.  Floats: keypoint pixels <= 1e-2 px (the tracker itself is bitwise for equal priors; priors come from
+poses that agree to ~1e-10), poses: RMSE <= 1e-5 (BASELINE.json north_star), map points <= 1e-5.
+
+The two-view initialisation is OpenGV's forward-difference refinement working at its rounding-noise floor (one ulp
+on one input bearing moves the reference's own result by up to 1e-4), so the pose it returns cannot be reproduced to 1e-5 by ANY other
+build of the same algorithm.  The tests therefore (a) compare the initialisation pose at 5e-3 and (b) start both maps from the
+reference's two-view pose (alva_system_debug_set_init_pose) for the 1e-5 comparison of everything that follows; a run WITHOUT the
+hook is compared as well (same discrete trajectory, poses to 2e-2)."""
 import numpy as np
 import pytest
 
 from alvaar_amd import synth
+import sysdiff
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.ref]
 
 
-def test_find_camera_pose_tracks_a_translating_camera():
-    from alvaar_amd.system import AlvaAR
-    w, h, Z = 640, 480, 4.0
-    ar = AlvaAR.Initialize(w, h)                      # src/system.js:47-56
-    K = ar.intrinsics
+def _reference_run(frames, w, h, cell, **kw):
+    ref = sysdiff.RefSystem(w, h, cell, **kw)
+    out, init_pose = [], None
+    for k, rgba in enumerate(frames):
+        st, p7, p16 = ref.step(rgba, 33.0 * k)
+        if init_pose is None and st == 1:
+            init_pose = p7.copy()
+        out.append(dict(status=st, pose7=p7.copy(), pose16=p16.copy(), state=ref.state().copy(), kps=ref.frame_keypoints(), kfs=ref.keyframe_ids().copy(),
+                        mps=ref.map_points()))
+    return ref, out, init_pose
+
+
+def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, **kw):
+    frames = list(frames)
+    ref, rec, init_pose = _reference_run(frames, w, h, cell, **kw)
+    gpu = sysdiff.GpuSystem(w, h, cell, **kw)
+    try:
+        if inject:
+            gpu.set_init_pose(init_pose)
+        sq, cnt, worst_px, worst_x, worst_pose = 0.0, 0, 0.0, 0.0, 0.0
+        for k, rgba in enumerate(frames):
+            st, p7, p16 = gpu.step(rgba, 33.0 * k)
+            r = rec[k]
+            assert st == r["status"], f"frame {k}: status {st} != reference {r['status']}"
+            assert list(gpu.state()) == list(r["state"]), f"frame {k}: state {list(gpu.state())} != reference {list(r['state'])}"
+            ids, px, un, i3, hd = gpu.frame_keypoints()
+            rids, rpx, run, ri3, rhd = r["kps"]
+            assert np.array_equal(ids, rids), f"frame {k}: keypoint ids / container order differ"
+            assert np.array_equal(i3, ri3) and np.array_equal(hd, rhd), f"frame {k}: keypoint flags differ"
+            if len(ids):
+                worst_px = max(worst_px, float(np.abs(px - rpx).max()), float(np.abs(un - run).max()))
+            assert np.array_equal(gpu.keyframe_ids(), r["kfs"]), f"frame {k}: keyframe ids differ"
+            mi, mx, mf, minv, md = gpu.map_points()
+            ri, rx, rf, rinv, rd = r["mps"]
+            assert np.array_equal(mi, ri) and np.array_equal(mf, rf), f"frame {k}: map point table differs"
+            assert np.array_equal(md, rd), f"frame {k}: descriptor medoids differ"
+            if len(mi):
+                worst_x = max(worst_x, float(np.abs(mx - rx).max()))
+            if st == 1:
+                d = sysdiff.pose_diff(r["pose7"], p7)
+                worst_pose = max(worst_pose, d)
+                q = p7[3:] if np.dot(p7[3:], r["pose7"][3:]) >= 0 else -p7[3:]
+                sq += float(np.sum((p7[:3] - r["pose7"][:3]) ** 2) + np.sum((q - r["pose7"][3:]) ** 2))
+                cnt += 7
+                assert np.abs(p16 - r["pose16"]).max() <= max(10 * pose_tol, 1e-5), f"frame {k}: pose array differs"
+        rmse = (sq / max(cnt, 1)) ** 0.5
+        kf_worst = sysdiff.compare_keyframes(ref, gpu, 10 * pose_tol, what="end of stream")
+        c = gpu.counters()
+        assert len(ref.keyframe_ids()) >= min_kf and c["ba_solves"] >= min_ba, (len(ref.keyframe_ids()), c)
+        assert worst_px <= 1e-2, worst_px
+        assert rmse <= pose_tol, f"pose RMSE {rmse} (worst {worst_pose})"
+        assert worst_x <= max(10 * pose_tol, 1e-5), worst_x
+        init_gpu = gpu.pose7()[1]
+        print(f"\n  frames {len(frames)}  keyframes {len(ref.keyframe_ids())}  BA solves {c['ba_solves']}  merges {c['merges']}  "
+              f"pose RMSE {rmse:.2e} (worst {worst_pose:.2e})  keyframe poses {kf_worst:.2e}  map points {worst_x:.2e}  pixels {worst_px:.2e}  "
+              f"own two-view pose vs reference {sysdiff.pose_diff(init_pose, init_gpu):.2e}")
+        return rmse, sysdiff.pose_diff(init_pose, init_gpu)
+    finally:
+        ref.close()
+        gpu.close()
+
+
+def test_system_equals_reference_150_frames():
+    """shipped configuration (cell 40): cold start, two-view initialisation, 8 keyframes, local BA, merges, culling; pose RMSE <= 1e-5"""
+    w, h = 640, 480
     canvas = synth.texture_canvas(w, h, 7)
-    frame = lambda k: synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h))
-    pose, status = ar.findCameraPose(frame(0))
-    assert status == 3 and pose is None               # initialising: keypoints extracted, no map yet
-    pts2d = ar.getFramePoints()
-    assert 50 < len(pts2d) <= 2048 and all(20 <= p["x"] < w - 20 + 3 for p in pts2d)
-    ids, px, is3d = ar.keypoints()
-    assert len(ids) == len(pts2d) and not is3d.any()
-    X = np.stack([(px[:, 0] - K["cx"]) / K["fx"] * Z, (px[:, 1] - K["cy"]) / K["fy"] * Z, np.full(len(px), Z)], 1)
-    assert ar.set_map_points(ids, X) == len(ids)
-    assert len(ar.getFramePoints()) == 0              # getFramePoints reports 2-D (untriangulated) keypoints only
-    errs = []
-    for k in range(1, 13):
-        pose, status = ar.findCameraPose(frame(k))
-        assert status == 1 and pose is not None, k
-        R = pose.reshape(4, 4)[:3, :3]
-        t = pose[12:15]
-        assert pose[15] == 1.0 and pose[3] == pose[7] == pose[11] == 0.0
-        assert np.abs(R - np.eye(3)).max() < 2e-3
-        expect = np.array([2 * k * Z / K["fx"], k * Z / K["fy"], 0.0])
-        errs.append(np.abs(t - expect).max())
-    assert max(errs) < 0.02, errs                     # KLT is sub-pixel; 1 px = Z / f = 0.0069 m here
-    ar.reset()
-    pose, status = ar.findCameraPose(frame(0))
-    assert status == 3
-    ar.close()
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(150)]
+    rmse, dinit = _differential(frames, w, h, 40, True, 1e-5, 8, 6)
+    assert dinit <= 5e-3
 
 
-def test_imu_variant_and_plane_conventions():
-    from alvaar_amd.system import AlvaAR
-    ar = AlvaAR.Initialize(640, 480)
-    rgba = synth.gray_to_rgba(synth.frame_gray(synth.texture_canvas(640, 480, 7), 0, 640, 480))
-    pose = ar.findCameraPoseWithIMU(rgba, (1.0, 0.0, 0.0, 0.0))     # always status 1 (system.cpp:103)
-    assert pose is not None and np.allclose(pose.reshape(4, 4)[:3, :3], np.eye(3)) and pose[15] == 1.0
-    assert ar.findPlane() is None                                     # < 32 observed 3-D points -> 0 (system.cpp:181)
-    ar.close()
+def test_system_equals_reference_without_the_hook():
+    """the same stream with the map started from OUR OWN five-point result: same discrete trajectory, poses at the initialisation's noise floor"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(100)]
+    _differential(frames, w, h, 40, False, 2e-2, 5, 3)
 
 
-def test_find_plane_after_cold_start():
-    """findPlane on the map the cold start built: the scene IS a fronto-parallel plane, so the plane normal must come out along the
-    world z axis and the origin inside the triangulated points (the plane fit is the intended processPlane, parity unpinned)."""
+def test_system_equals_reference_2000_keypoints():
+    """BASELINE configs[1] geometry (cell 12 => 2120 keypoints)"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(60)]
+    _differential(frames, w, h, 12, True, 1e-5, 3, 2)
+
+
+def test_system_equals_reference_rotating_camera_with_noise():
+    w, h = 640, 480
+    f = sysdiff.intrinsics(w, h)[0]
+    canvas = synth.texture_canvas(w, h, 5)
+    frames = [synth.plane_stream_frame(canvas, k, w, h, f, noise_seed=100) for k in range(130)]
+    _differential(frames, w, h, 40, True, 1e-5, 4, 2)
+
+
+def test_system_equals_reference_tracking_loss_and_reset():
+    """scene cut -> KLT / pose failures -> resetFrame, poseFailedCounter_, status 2, re-initialisation (visual_frontend.cpp:73-92,
+    :318-330, :383-399): the status sequence and every counter follow the reference"""
+    w, h = 640, 480
+    canvas, other = synth.texture_canvas(w, h, 7), synth.texture_canvas(w, h, 99)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(40)]
+    frames += [synth.gray_to_rgba(synth.frame_gray(other, 3 * (k % 2) * 20 + k, w, h)) for k in range(40)]
+    frames += [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(40)]
+    # the second initialisation is not covered by the hook (it holds ONE pose): compare poses at the initialisation's noise floor
+    _differential(frames, w, h, 40, True, 2e-2, 0, 0)
+
+
+def test_system_equals_reference_distortion_and_clahe():
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(60)]
+    _differential(frames, w, h, 40, True, 1e-5, 2, 1, clahe=True, dist=(-0.12, 0.03, 0.0006, -0.0004))
+
+
+def test_js_wrapper_conventions():
+    """AlvaAR (src/system.js) call pattern: status 3 while initialising, pose only on status 1, getFramePoints = 2-D keypoints,
+    findCameraPoseWithIMU always returns a pose, findPlane needs 32 observed 3-D points"""
     from alvaar_amd.system import AlvaAR
     w, h = 640, 480
     ar = AlvaAR.Initialize(w, h)
     canvas = synth.texture_canvas(w, h, 7)
-    for k in range(0, 30):
-        pose, status = ar.findCameraPose(synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)))
-    assert status == 1
+    frame = lambda k: synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h))
+    pose, status = ar.findCameraPose(frame(0))
+    assert status == 3 and pose is None
+    pts2d = ar.getFramePoints()
+    assert 50 < len(pts2d) <= 2048 and all(20 <= p["x"] < w - 20 + 3 for p in pts2d)
+    assert ar.findPlane() is None
+    statuses = []
+    for k in range(1, 40):
+        pose, status = ar.findCameraPose(frame(k), 33.0 * k)
+        statuses.append(status)
+    k0 = statuses.index(1)
+    assert statuses[:k0] == [3] * k0 and set(statuses[k0:]) == {1}
+    assert pose[15] == 1.0 and pose[3] == pose[7] == pose[11] == 0.0
+    assert abs(np.linalg.norm(ar.pose7()[1][:3]) - 1.0) < 1e-9     # twc.normalize() at initialisation (visual_frontend.cpp:547)
+    ids, px, is3d = ar.keypoints()
+    assert is3d.sum() >= 30
     plane = ar.findPlane()
     assert plane is not None and plane[15] == 1.0
     R = plane.reshape(4, 4)[:3, :3].T
     Rx = np.array([[1, 0, 0], [0, np.cos(1.0), -np.sin(1.0)], [0, np.sin(1.0), np.cos(1.0)]])
     n = (R @ Rx.T)[:, 0]
-    assert abs(abs(n[2]) - 1.0) < 0.05, n                              # clock-seeded sampling, as in the reference (system.cpp:203)
-    assert plane[14] > 0.5                                             # in front of the first camera (unit-baseline scale)
+    assert abs(abs(n[2]) - 1.0) < 0.05, n                              # the scene IS a fronto-parallel plane
+    ar.reset()
+    pose, status = ar.findCameraPose(frame(0))
+    assert status == 3
+    imu_pose = ar.findCameraPoseWithIMU(frame(1), (1.0, 0.0, 0.0, 0.0))
+    assert imu_pose is not None and np.allclose(imu_pose.reshape(4, 4)[:3, :3], np.eye(3)) and imu_pose[15] == 1.0
     ar.close()
 
 
-def test_cold_start_initialises_its_own_map():
-    """No host-fed map: keyframe 0, parallax gate, 5-point initialisation (unit baseline), triangulation of keyframe 1, then
-    P3P + PnP tracking and new keyframes by the reference's policy -- the path checkReadyForInit -> createKeyframe ->
-    triangulateTemporal -> computePose of the reference, on the same fronto-parallel scene as above."""
+def test_configure_failure_leaves_the_object_unconfigured():
     from alvaar_amd.system import AlvaAR
-    w, h = 640, 480
-    ar = AlvaAR.Initialize(w, h)
-    canvas = synth.texture_canvas(w, h, 7)
-    frame = lambda k: synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h))
-    statuses, poses = [], {}
-    for k in range(0, 60):
-        pose, status = ar.findCameraPose(frame(k))
-        statuses.append(status)
-        if status == 1:
-            poses[k] = pose
-        assert status in (1, 3), (k, status)
-    k0 = statuses.index(1)
-    assert statuses[:k0] == [3] * k0 and all(s == 1 for s in statuses[k0:])
-    assert 17 <= k0 <= 22                                   # (2, 1) px per frame => > 40 px of parallax after 18 frames
-    d = np.array([2.0, 1.0, 0.0]) / np.sqrt(5.0)
-    t0 = poses[k0][12:15]
-    assert abs(np.linalg.norm(t0) - 1.0) < 1e-6             # twc.normalize() (visual_frontend.cpp:547)
-    assert np.abs(t0 - d).max() < 0.03                      # direction of the true translation
-    ids, px, is3d = ar.keypoints()
-    assert is3d.sum() >= 30                                 # the initial map (mapper.cpp:29: fewer than 30 would reset)
-    for k, pose in poses.items():
-        R, t = pose.reshape(4, 4)[:3, :3], pose[12:15]
-        assert np.abs(R - np.eye(3)).max() < 0.02, k
-        assert np.abs(t - d * k / k0).max() < 0.06 * k / k0, (k, t)     # the map's scale is the first baseline
-    ar.close()
+    from alvaar_amd.capi import AlvaError
+    with pytest.raises(AlvaError):
+        AlvaAR(30, 20)

@@ -1,0 +1,93 @@
+"""Host logic of the System surface (a1, a10, a13, f1 of SURVEY.md §8) WITHOUT a GPU: the product's map layer
+(alvaar_amd/csrc/slam/ -- keyframe policy, map bookkeeping, container orders, BA graph construction + write-back, culling, descriptor
+medoids) compiled over the reference's own L1 stages (oracle/sys_cpu.cpp) against the reference's System (oracle/ref_shim_system.cpp)
+on the same frames.  The stage arithmetic is the same code on both sides, so every difference would be a bookkeeping difference:
+status sequence, state counters, keypoints in container order (bitwise pixels), keyframes, covisibility, map point tables and
+descriptor medoids must be IDENTICAL; poses / points agree to rounding (the pose algebra is ours: <= 1e-9)."""
+import numpy as np
+import pytest
+
+from alvaar_amd import synth
+import sysdiff
+
+pytestmark = pytest.mark.ref
+
+
+def _run(frames, w, h, cell, n_min_kf, clahe=False, dist=(0.0, 0.0, 0.0, 0.0), ts=lambda k: 33.0 * k):
+    ref, cpu = sysdiff.RefSystem(w, h, cell, clahe, dist), sysdiff.CpuSystem(w, h, cell, clahe, dist)
+    try:
+        statuses, worst_pose, worst_x = [], 0.0, 0.0
+        for k, rgba in enumerate(frames):
+            s1, p1, a1 = ref.step(rgba, ts(k))
+            s2, p2, a2 = cpu.step(rgba, ts(k))
+            assert s1 == s2, f"frame {k}: status {s1} != {s2}"
+            statuses.append(s1)
+            worst_x = max(worst_x, sysdiff.compare(ref, cpu, 1e-9, px_exact=True, xyz_tol=1e-9, what=f"frame {k}"))
+            d = sysdiff.pose_diff(p1, p2)
+            assert d <= 1e-9, f"frame {k}: pose differs by {d}"
+            assert np.abs(a1 - a2).max() <= 1e-6
+            worst_pose = max(worst_pose, d)
+            if k % 10 == 0:
+                sysdiff.compare_keyframes(ref, cpu, 1e-9, what=f"frame {k}")
+        sysdiff.compare_keyframes(ref, cpu, 1e-9, what="last frame")
+        assert len(ref.keyframe_ids()) >= n_min_kf or ref.state()[11] >= n_min_kf
+        return statuses, cpu.counters(), worst_pose, worst_x
+    finally:
+        ref.close()
+        cpu.close()
+
+
+def test_shipped_configuration_translating_camera():
+    """cell 40 (192 keypoints): cold start, five-point initialisation, 8 keyframes, local BA from keyframe 2, merges, culling"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = (synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(150))
+    statuses, cnt, _, _ = _run(frames, w, h, 40, 8)
+    k0 = statuses.index(1)
+    assert statuses[:k0] == [3] * k0 and set(statuses[k0:]) == {1} and 15 <= k0 <= 25
+    assert cnt["ba_solves"] >= 6 and cnt["merges"] > 0
+
+
+def test_2000_keypoint_workload():
+    """BASELINE configs[1] geometry: cell 12 => 2120 cells"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = (synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(45))
+    statuses, cnt, _, _ = _run(frames, w, h, 12, 3)
+    assert statuses[-1] == 1 and cnt["ba_solves"] >= 1
+
+
+def test_rotating_camera_with_noise():
+    """camera rotating and translating in front of a plane, +-4 gray noise: KLT failures, P3P / PnP outliers, keyframes by parallax"""
+    w, h = 640, 480
+    f = sysdiff.intrinsics(w, h)[0]
+    canvas = synth.texture_canvas(w, h, 5)
+    frames = (synth.plane_stream_frame(canvas, k, w, h, f, noise_seed=100) for k in range(130))
+    statuses, cnt, _, _ = _run(frames, w, h, 40, 4)
+    assert 1 in statuses and cnt["ba_solves"] >= 2
+
+
+def test_tracking_loss_and_reset():
+    """a scene cut (unrelated texture) makes KLT / pose estimation fail: keypoints are dropped, poseFailedCounter_ accumulates, the
+    tracker resets (status 2) and re-initialises -- the failure paths of visual_frontend.cpp:73-92, :318-330, :383-399"""
+    w, h = 640, 480
+    canvas, other = synth.texture_canvas(w, h, 7), synth.texture_canvas(w, h, 99)
+
+    def frames():
+        for k in range(40):
+            yield synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h))
+        for k in range(40):
+            yield synth.gray_to_rgba(synth.frame_gray(other, 3 * (k % 2) * 20 + k, w, h))
+        for k in range(40):
+            yield synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h))
+    statuses, _, _, _ = _run(frames(), w, h, 40, 0)
+    assert 2 in statuses or 3 in statuses[41:], statuses
+
+
+def test_distortion_and_clahe_wired():
+    """non-zero radial / tangential coefficients and CLAHE through the whole path (camera_calibration.cpp:34-72, visual_frontend.cpp:678-681)"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = (synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(60))
+    statuses, _, _, _ = _run(frames, w, h, 40, 2, clahe=True, dist=(-0.12, 0.03, 0.0006, -0.0004))
+    assert 1 in statuses

@@ -1,25 +1,36 @@
-"""Per-frame wall time of the System surface (host-fed RGBA frames, the reference's shipped configuration)."""
-import sys, time
+"""Per-frame wall time of the System surface (host-fed RGBA frames in, pose out) from a cold start: tracking frames and keyframe
+frames separately.  CELL=40 is the reference's shipped configuration (192 keypoints), CELL=12 the 2000-keypoint workload."""
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from alvaar_amd import synth
 from alvaar_amd.system import AlvaAR
 
-w, h, Z = 640, 480, 4.0
-ar = AlvaAR.Initialize(w, h)
-K = ar.intrinsics
+w, h = 640, 480
+cell = int(os.environ.get("CELL", "40"))
+n = int(os.environ.get("FRAMES", "150"))
+ar = AlvaAR(w, h, cell_size=cell, random_sampling=False)
 canvas = synth.texture_canvas(w, h, 7)
-frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(40)]
-ar.findCameraPose(frames[0])
-ids, px, is3d = ar.keypoints()
-X = np.stack([(px[:, 0] - K["cx"]) / K["fx"] * Z, (px[:, 1] - K["cy"]) / K["fy"] * Z, np.full(len(px), Z)], 1)
-ar.set_map_points(ids, X)
-for k in range(1, 8):
-    ar.findCameraPose(frames[k])
-t0 = time.perf_counter()
-ok = 0
-for k in range(8, 40):
-    pose, st = ar.findCameraPose(frames[k])
-    ok += st == 1
-dt = (time.perf_counter() - t0) / 32
-print(f"System::findCameraPose: {dt * 1e3:.3f} ms/frame ({1 / dt:.0f} frames/s), {ok}/32 poses, {len(ids)} keypoints (cell 40), host-fed 1.2 MB RGBA per frame")
+frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(n)]
+track, kf, init = [], [], []
+prev_kf = -1
+for k in range(n):
+    t0 = time.perf_counter()
+    pose, st = ar.findCameraPose(frames[k], 33.0 * k)
+    dt = time.perf_counter() - t0
+    s = ar.state()
+    if st != 1:
+        init.append(dt)
+    elif s[11] != prev_kf:
+        kf.append(dt)
+    else:
+        track.append(dt)
+    prev_kf = s[11]
+s = ar.state()
+ms = lambda v: (1e3 * float(np.median(v)), 1e3 * float(np.mean(v))) if v else (0.0, 0.0)
+print(f"cell {cell}: {s[2]} keypoints ({s[4]} 3-D), {s[6]} keyframes, {ar.counters()}")
+print(f"  tracking frames  {len(track):4d}: median {ms(track)[0]:.3f} ms  mean {ms(track)[1]:.3f} ms  -> {1e3 / ms(track)[1]:.0f} frames/s")
+print(f"  keyframe frames  {len(kf):4d}: median {ms(kf)[0]:.3f} ms  mean {ms(kf)[1]:.3f} ms")
+print(f"  initialising     {len(init):4d}: median {ms(init)[0]:.3f} ms")
+tot = sum(track) + sum(kf)
+print(f"  whole stream after initialisation: {(len(track) + len(kf)) / tot:.0f} frames/s (host-fed 1.2 MB RGBA per frame)")
