@@ -6,6 +6,7 @@
 #include "stages_hip.hpp"
 #include "slam/slam.hpp"
 #include "slam/inspect.hpp"
+#include "slam/stage_trace.hpp"
 #include "../../include/alvaar_system.h"
 #include <chrono>
 #include <cmath>
@@ -23,6 +24,7 @@ static int sys_fail(int rc, const char *what) {
 struct alva_system {
     int device = 0;
     std::unique_ptr<HipStages> stages;
+    std::unique_ptr<TraceStages> trace;  // ALVA_STAGE_TRACE=<file>: log every stage call (debugging aid, see slam/stage_trace.hpp)
     std::unique_ptr<Slam> slam;
     // findCameraPoseWithIMU (system.cpp:57-104)
     double imu_translation[3] = {0, 0, 0}, prev_translation[3] = {0, 0, 0};
@@ -45,6 +47,7 @@ extern "C" int alva_system_create(int device, alva_system **out) {
 extern "C" void alva_system_destroy(alva_system *s) {
     if (!s) return;
     s->slam.reset();
+    s->trace.reset();
     s->stages.reset();
     delete s;
 }
@@ -58,6 +61,7 @@ extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, d
     }
     // a failed (re-)configuration leaves the object unconfigured, never half-built
     s->slam.reset();
+    s->trace.reset();
     s->stages.reset();
     Camera cam;
     cam.width = width; cam.height = height; cam.border = 20;  // system.cpp:29
@@ -74,6 +78,10 @@ extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, d
     if (rc) return sys_fail(rc, "alva_system_configure");
     s->stages = std::move(st);
     s->slam = std::move(slam);
+    if (const char *path = getenv("ALVA_STAGE_TRACE")) {
+        s->trace.reset(new TraceStages(s->stages.get(), path));
+        s->slam->st = s->trace.get();
+    }
     for (int i = 0; i < 3; i++) s->imu_translation[i] = s->prev_translation[i] = 0;
     return ALVA_OK;
 }

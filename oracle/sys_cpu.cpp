@@ -30,6 +30,7 @@
 #include "alva_oracle.h"
 #include "slam/slam.hpp"
 #include "slam/inspect.hpp"
+#include "slam/stage_trace.hpp"
 
 extern "C" int ref_local_ba(int nKf, double *poses, const uint8_t *kfConst, const double *calib, int invDepth, int nPt, const int *ptAnchorKf,
                             const double *ptAnchorUv, double *ptParam, int nObs, const int *obsKf, const int *obsPt, const double *obsUv,
@@ -56,6 +57,8 @@ struct RefStages : Stages {
     cv::Ptr<cv::CLAHE> clahe_op;
     cv::Mat raw, cur, prev;
     std::vector<cv::Mat> cur_pyr, prev_pyr;
+    double perturb = 0.;  // syscpu_set_perturbation
+    unsigned long long lcg = 88172645463325252ULL;
 
     RefStages(const Camera &c, bool clahe_on) : cam(c), clahe(clahe_on), extractor(0.001), tracker(30, 0.01f) {  // state.hpp:55-57
         cal = std::make_shared<CameraCalibration>(c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.width, c.height, c.border);
@@ -100,6 +103,12 @@ struct RefStages : Stages {
             b.normalize();
             unpx[2 * i] = u.x; unpx[2 * i + 1] = u.y;
             bv[3 * i] = b(0); bv[3 * i + 1] = b(1); bv[3 * i + 2] = b(2);
+            if (perturb > 0) {  // sensitivity probe (tests): move every bearing by ~perturb, deterministically
+                for (int c = 0; c < 3; c++) {
+                    lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+                    bv[3 * i + c] *= 1.0 + perturb * ((double) (lcg >> 40) / 8388608.0 - 1.0);
+                }
+            }
         }
         return 0;
     }
@@ -212,6 +221,7 @@ struct RefStages : Stages {
 
 struct CpuSys {
     std::unique_ptr<RefStages> stages;
+    std::unique_ptr<TraceStages> trace;
     std::unique_ptr<Slam> slam;
 };
 }  // namespace
@@ -229,6 +239,10 @@ void *syscpu_create(int w, int h, double fx, double fy, double cx, double cy, do
     cfg.random_sampling = doRandom != 0;
     s->stages.reset(new RefStages(cam, cfg.clahe));
     s->slam.reset(new Slam(s->stages.get(), cam, cfg));
+    if (const char *path = getenv("ALVA_STAGE_TRACE_CPU")) {
+        s->trace.reset(new TraceStages(s->stages.get(), path));
+        s->slam->st = s->trace.get();
+    }
     return s;
 }
 void syscpu_destroy(void *p) { delete static_cast<CpuSys *>(p); }
@@ -245,6 +259,8 @@ void syscpu_set_init_pose(void *p, const double *pose7) {
     s.init_override.armed = pose7 != nullptr;
     if (pose7) std::memcpy(s.init_override.pose7, pose7, 56);
 }
+// sensitivity probe: relative perturbation applied to every bearing the map layer receives (0 = off)
+void syscpu_set_perturbation(void *p, double rel) { static_cast<CpuSys *>(p)->stages->perturb = rel; }
 void syscpu_state(void *p, int *out) { inspect_state(*static_cast<CpuSys *>(p)->slam, out); }
 int syscpu_frame_keypoints(void *p, int cap, int *ids, float *px, float *unpx, uint8_t *is3d, uint8_t *hasDesc) {
     return inspect_frame(*static_cast<CpuSys *>(p)->slam->cur, cap, ids, px, unpx, is3d, hasDesc);

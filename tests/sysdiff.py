@@ -18,8 +18,10 @@ CAP_KP, CAP_MP = 16384, 65536
 
 
 def intrinsics(w, h, fov=45.0):
-    f = 0.5 * h / math.tan(0.5 * math.radians(fov)) if w > h else 0.5 * w / math.tan(0.5 * math.radians(fov))
-    return f, f, w * 0.5, h * 0.5
+    """AlvaAR.getCameraIntrinsics (src/system.js:84-141) -- the same rule alvaar_amd.system.AlvaAR applies"""
+    from alvaar_amd.system import camera_intrinsics
+    k = camera_intrinsics(w, h, fov)
+    return k["fx"], k["fy"], k["cx"], k["cy"]
 
 
 class _ShimSystem:

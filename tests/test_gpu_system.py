@@ -13,7 +13,7 @@ The two-view initialisation is OpenGV's forward-difference refinement working at
 on one input bearing moves the reference's own result by up to 1e-4), so the pose it returns cannot be reproduced to 1e-5 by ANY other
 build of the same algorithm.  The tests therefore (a) compare the initialisation pose at 5e-3 and (b) start both maps from the
 reference's two-view pose (alva_system_debug_set_init_pose) for the 1e-5 comparison of everything that follows; a run WITHOUT the
-hook is compared as well (same discrete trajectory, poses to 2e-2)."""
+hook is compared as well (same discrete trajectory over 100 frames, poses to 2e-2, pixels to 0.2)."""
 import numpy as np
 import pytest
 
@@ -35,17 +35,17 @@ def _reference_run(frames, w, h, cell, **kw):
     return ref, out, init_pose
 
 
-def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, **kw):
+def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, **kw):
     frames = list(frames)
     ref, rec, init_pose = _reference_run(frames, w, h, cell, **kw)
     gpu = sysdiff.GpuSystem(w, h, cell, **kw)
     try:
-        if inject:
-            gpu.set_init_pose(init_pose)
         sq, cnt, worst_px, worst_x, worst_pose = 0.0, 0, 0.0, 0.0, 0.0
         for k, rgba in enumerate(frames):
-            st, p7, p16 = gpu.step(rgba, 33.0 * k)
             r = rec[k]
+            if inject and r["status"] == 1 and (k == 0 or rec[k - 1]["status"] != 1):
+                gpu.set_init_pose(r["pose7"])   # the frame on which the reference (re-)initialises its map: start ours from the same two-view pose
+            st, p7, p16 = gpu.step(rgba, 33.0 * k)
             assert st == r["status"], f"frame {k}: status {st} != reference {r['status']}"
             assert list(gpu.state()) == list(r["state"]), f"frame {k}: state {list(gpu.state())} != reference {list(r['state'])}"
             ids, px, un, i3, hd = gpu.frame_keypoints()
@@ -72,7 +72,7 @@ def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, **kw):
         kf_worst = sysdiff.compare_keyframes(ref, gpu, 10 * pose_tol, what="end of stream")
         c = gpu.counters()
         assert len(ref.keyframe_ids()) >= min_kf and c["ba_solves"] >= min_ba, (len(ref.keyframe_ids()), c)
-        assert worst_px <= 1e-2, worst_px
+        assert worst_px <= px_tol, worst_px
         assert rmse <= pose_tol, f"pose RMSE {rmse} (worst {worst_pose})"
         assert worst_x <= max(10 * pose_tol, 1e-5), worst_x
         init_gpu = gpu.pose7()[1]
@@ -99,7 +99,7 @@ def test_system_equals_reference_without_the_hook():
     w, h = 640, 480
     canvas = synth.texture_canvas(w, h, 7)
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(100)]
-    _differential(frames, w, h, 40, False, 2e-2, 5, 3)
+    _differential(frames, w, h, 40, False, 2e-2, 5, 3, px_tol=0.2)
 
 
 def test_system_equals_reference_2000_keypoints():
@@ -126,8 +126,7 @@ def test_system_equals_reference_tracking_loss_and_reset():
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(40)]
     frames += [synth.gray_to_rgba(synth.frame_gray(other, 3 * (k % 2) * 20 + k, w, h)) for k in range(40)]
     frames += [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(40)]
-    # the second initialisation is not covered by the hook (it holds ONE pose): compare poses at the initialisation's noise floor
-    _differential(frames, w, h, 40, True, 2e-2, 0, 0)
+    _differential(frames, w, h, 40, True, 1e-5, 0, 0)
 
 
 def test_system_equals_reference_distortion_and_clahe():
