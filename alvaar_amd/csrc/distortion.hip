@@ -9,52 +9,28 @@
 //                           to FLOAT (cv::Point3f), zero rvec / tvec (calib3d/src/calibration.cpp:522-)
 // One thread per point, IEEE double in the reference's operation order (compile with -ffp-contract=off), float results.
 #include "common.hpp"
+#include "camera_device.hpp"
 
 namespace {
 
-struct Cam {
-    double fx, fy, cx, cy, k1, k2, p1, p2;
-};
+typedef AlvaCam Cam;
 
 __global__ void __launch_bounds__(256) k_undistort(Cam C, const float *__restrict__ px, int n, float *__restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double ifx = 1. / C.fx, ify = 1. / C.fy;
-    const double u = px[2 * (size_t) i], v = px[2 * (size_t) i + 1];
-    double x = (u - C.cx) * ifx, y = (v - C.cy) * ify;
-    const double x0 = x, y0 = y;
-    for (int j = 0; j < 5; j++) {
-        const double r2 = x * x + y * y;
-        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((0 * r2 + C.k2) * r2 + C.k1) * r2);
-        if (icdist < 0) {
-            x = (u - C.cx) * ifx;
-            y = (v - C.cy) * ify;
-            break;
-        }
-        const double deltaX = 2 * C.p1 * x * y + C.p2 * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
-        const double deltaY = C.p1 * (r2 + 2 * y * y) + 2 * C.p2 * x * y + 0 * r2 + 0 * r2 * r2;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
-    }
-    const double xx = C.fx * x + 0 * y + C.cx, yy = 0 * x + C.fy * y + C.cy, ww = 1. / (0 * x + 0 * y + 1);
-    out[2 * (size_t) i] = (float) (xx * ww);
-    out[2 * (size_t) i + 1] = (float) (yy * ww);
+    float u, v;
+    alva_undistort_dev(C, px[2 * (size_t) i], px[2 * (size_t) i + 1], u, v);
+    out[2 * (size_t) i] = u;
+    out[2 * (size_t) i + 1] = v;
 }
 
 __global__ void __launch_bounds__(256) k_project_dist(Cam C, const double *__restrict__ P, int n, float *__restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double iz = 1. / P[3 * (size_t) i + 2];
-    const float Xf = (float) (P[3 * (size_t) i] * iz), Yf = (float) (P[3 * (size_t) i + 1] * iz);
-    const double x = (double) Xf, y = (double) Yf;
-    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-    const double cdist = 1 + C.k1 * r2 + C.k2 * r4 + 0 * r6;
-    const double icdist2 = 1. / (1 + 0 * r2 + 0 * r4 + 0 * r6);
-    const double xd0 = x * cdist * icdist2 + C.p1 * a1 + C.p2 * a2 + 0 * r2 + 0 * r4;
-    const double yd0 = y * cdist * icdist2 + C.p1 * a3 + C.p2 * a1 + 0 * r2 + 0 * r4;
-    out[2 * (size_t) i] = (float) (xd0 * C.fx + C.cx);
-    out[2 * (size_t) i + 1] = (float) (yd0 * C.fy + C.cy);
+    float u, v;
+    alva_project_dist_dev(C, P[3 * (size_t) i], P[3 * (size_t) i + 1], P[3 * (size_t) i + 2], u, v);
+    out[2 * (size_t) i] = u;
+    out[2 * (size_t) i + 1] = v;
 }
 
 }  // namespace

@@ -307,6 +307,17 @@ __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxL
     klt_point(sh, P, C, mode, maxLevel, maxCount, epsilon, errThresh, fbDist, pts, init, nextio, status_out, err_out, kp);
 }
 
+// the same with the keypoint count in DEVICE memory (written by the kernel that built the list; the grid covers an upper bound)
+__global__ void __launch_bounds__(64) k_klt_dn(LkPyr P, LkPyr C, int mode, int maxLevel, int maxCount, double epsilon, float errThresh,
+                                               float fbDist, const float *__restrict__ pts, const float *init, float *nextio,
+                                               uint8_t *__restrict__ status_out, const int *__restrict__ d_n) {
+    __shared__ LkShared sh;
+    const int per = gridDim.x >> 3;
+    const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (kp >= *d_n) return;
+    klt_point(sh, P, C, mode, maxLevel, maxCount, epsilon, errThresh, fbDist, pts, init, nextio, status_out, nullptr, kp);
+}
+
 // B cameras in one launch (fbKltTracking only): blockIdx.y = camera, each with its own pyramids, keypoint list and count.  The
 // per-camera block sits in device memory; it is wave-uniform, so the compiler reads it with scalar loads.  A camera's keypoints
 // keep the XCD-contiguous order of k_klt, so its pyramid still lives in the L2s of the XCDs that track into it.
@@ -861,6 +872,31 @@ extern "C" int alva_fbklt_track(alva_ctx *ctx, const alva_pyramid *prev, const a
 int alva_fbklt_track_to(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
                         int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, int n) {
     return launch(ctx, prev, curr, 1, num_levels, max_iters, eps, err_thresh, fb_dist, d_pts, d_prior_in, d_out, d_status, nullptr, n);
+}
+
+// fbKltTracking of a keypoint list whose length lives in device memory (internal: the fused tracking step of stages_hip.hip);
+// n_max bounds the grid.  Enqueue only.
+int alva_fbklt_track_dn(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
+                        int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, const int *d_n,
+                        int n_max) {
+    ALVA_ARG(ctx && prev && curr && n_max >= 0 && num_levels >= 0);
+    if (n_max == 0) return ALVA_OK;
+    ALVA_ARG(d_pts && d_prior_in && d_out && d_status && d_n);
+    ALVA_ARG(prev->win == WIN && curr->win == WIN);
+    ALVA_ARG(prev->nlevels == curr->nlevels && prev->lv[0].w == curr->lv[0].w && prev->lv[0].h == curr->lv[0].h);
+    LkPyr P, C;
+    fill_pyr(prev, P);
+    fill_pyr(curr, C);
+    int maxLevel = num_levels;
+    if (prev->nlevels - 1 < maxLevel) maxLevel = prev->nlevels - 1;
+    const int maxCount = max_iters < 0 ? 0 : (max_iters > 100 ? 100 : max_iters);
+    double epsilon = (double) eps;
+    epsilon = epsilon < 0 ? 0 : (epsilon > 10 ? 10 : epsilon);
+    epsilon *= epsilon;
+    hipLaunchKernelGGL(k_klt_dn, dim3(8 * alva_divup(n_max, 8)), dim3(64), 0, ctx->stream, P, C, 1, maxLevel, maxCount, epsilon, err_thresh, fb_dist,
+                       d_pts, d_prior_in, d_out, d_status, d_n);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
 }
 
 // ---- batch of cameras (internal: track_batch.hip) -------------------------------------------------------------------------

@@ -25,6 +25,8 @@ Slam::Slam(Stages *stages, const Camera &c, const Settings &s) : st(stages), cam
     invK[8] = (K[0] * K[4] - K[1] * K[3]) * id;
     cur = std::make_shared<FrameRec>();
     cur->init(&cam, (size_t) cfg.cell_size);
+    st->image_width_ = cam.width;
+    st->image_height_ = cam.height;
 }
 
 void Slam::reset() {  // System::reset (system.cpp:42-55)
@@ -131,149 +133,77 @@ void Slam::update_motion_model(const SE3 &Twc, double time) {  // visual_fronten
     }
 }
 
-void Slam::klt_from_motion_prior() {  // visual_frontend.cpp:103-243
-    std::vector<int> ids3d, ids;
-    std::vector<float> kps3d, priors3d, kps, priors;
-    // projections of the 3-D keypoints' map points with the predicted pose, in container order
-    std::vector<int> cand;
-    std::vector<double> cam_pts;
-    if (cfg.klt_use_prior) {
-        for (const auto &e: cur->kps) {
-            if (!e.second.is3d) continue;
-            const MapPt &mp = *map_points.at(e.second.id);
-            double pc[3];
-            se3_apply(cur->Tcw, mp.X, pc);
-            cand.push_back(e.second.id);
-            cam_pts.insert(cam_pts.end(), pc, pc + 3);
-        }
-    }
-    std::vector<float> proj(cand.size() * 2);
-    if (!cand.empty() && fail(st->project_dist((int) cand.size(), cam_pts.data(), proj.data()))) return;
-    size_t ci = 0;
+// VisualFrontend::kltTrackingFromMotionPrior (visual_frontend.cpp:103-243): the frame's keypoints go to the tracking step as slots in
+// the container's iteration order; its results are applied in the reference's order (updates of the one-level pass first, then the
+// full-pyramid list: the keypoints that never had a prior, then the ones that failed with theirs)
+void Slam::klt_from_motion_prior() {
+    const int n = (int) cur->kps.size();
+    job_ids_.resize((size_t) n);
+    job_px_.resize((size_t) n * 2);
+    job_is3d_.resize((size_t) n);
+    job_wpt_.assign((size_t) n * 3, 0.);
+    int i = 0;
     for (const auto &e: cur->kps) {
         const KeyPt &k = e.second;
-        if (cfg.klt_use_prior && k.is3d) {
-            const float *p = &proj[2 * ci++];
-            if (cur->in_image(p)) {
-                kps3d.insert(kps3d.end(), k.px, k.px + 2);
-                priors3d.insert(priors3d.end(), p, p + 2);
-                ids3d.push_back(k.id);
-                continue;
-            }
-        }
-        ids.push_back(k.id);
-        kps.insert(kps.end(), k.px, k.px + 2);
-        priors.insert(priors.end(), k.px, k.px + 2);
+        job_ids_[(size_t) i] = k.id;
+        job_px_[2 * (size_t) i] = k.px[0];
+        job_px_[2 * (size_t) i + 1] = k.px[1];
+        job_is3d_[(size_t) i] = k.is3d;
+        if (k.is3d) std::memcpy(&job_wpt_[3 * (size_t) i], map_points.at(k.id)->X, 24);
+        i++;
     }
-    // results are applied after both passes with ONE compute_keypoints call; the frame is not read in between
-    std::vector<int> upd_ids;
-    std::vector<float> upd_px;
-    std::vector<int> removed;
-    if (cfg.klt_use_prior && !priors3d.empty()) {
-        const int n = (int) ids3d.size();
-        std::vector<uint8_t> ok((size_t) n);
-        if (fail(st->fbklt(1, n, kps3d.data(), priors3d.data(), ok.data()))) return;
-        size_t good = 0;
-        for (int i = 0; i < n; i++) {
-            if (ok[(size_t) i]) {
-                upd_ids.push_back(ids3d[(size_t) i]);
-                upd_px.insert(upd_px.end(), &priors3d[2 * (size_t) i], &priors3d[2 * (size_t) i] + 2);
-                good++;
-            } else {  // retry on the full pyramid
-                ids.push_back(ids3d[(size_t) i]);
-                kps.insert(kps.end(), &kps3d[2 * (size_t) i], &kps3d[2 * (size_t) i] + 2);
-                priors.insert(priors.end(), &priors3d[2 * (size_t) i], &priors3d[2 * (size_t) i] + 2);
-            }
-        }
-        if (good < 0.33 * n) {
-            p3p_req = true;
-            priors = kps;
-        }
+    TrackJob job;
+    job.n = n;
+    job.px = job_px_.data();
+    job.is3d = job_is3d_.data();
+    job.wpt = job_wpt_.data();
+    std::memcpy(job.Tcw_q, cur->Tcw.q, 32);
+    std::memcpy(job.Tcw_t, cur->Tcw.t, 24);
+    se3_to_pose7(cur->Twc, job.pose7_pred);
+    job.use_prior = cfg.klt_use_prior;
+    job.klt_levels = cfg.klt_levels;
+    job.want_pose = ready_for_init;
+    job.do_p3p = p3p_req || cfg.p3p_enabled;
+    job.do_random = cfg.random_sampling;
+    TrackKlt &r = klt_out_;
+    if (fail(st->track_begin(job, r))) return;
+    for (int pass = 1; pass <= 3; pass++)
+        for (int s = 0; s < n; s++)
+            if (r.code[(size_t) s] == pass) cur->update(job_ids_[(size_t) s], &r.px[2 * (size_t) s], &r.unpx[2 * (size_t) s], &r.bv[3 * (size_t) s]);
+    pose_ids_.clear();
+    for (int s = 0; s < n; s++) {
+        if (!r.code[(size_t) s]) remove_obs_from_cur(job_ids_[(size_t) s]);
+        else if (job_is3d_[(size_t) s]) pose_ids_.push_back(job_ids_[(size_t) s]);
     }
-    if (!kps.empty()) {
-        const int n = (int) ids.size();
-        std::vector<uint8_t> ok((size_t) n);
-        if (fail(st->fbklt(cfg.klt_levels, n, kps.data(), priors.data(), ok.data()))) return;
-        for (int i = 0; i < n; i++) {
-            if (ok[(size_t) i]) {
-                upd_ids.push_back(ids[(size_t) i]);
-                upd_px.insert(upd_px.end(), &priors[2 * (size_t) i], &priors[2 * (size_t) i] + 2);
-            } else {
-                removed.push_back(ids[(size_t) i]);
-            }
-        }
-    }
-    const int nu = (int) upd_ids.size();
-    if (nu) {
-        std::vector<float> unpx((size_t) nu * 2);
-        std::vector<double> bv((size_t) nu * 3);
-        if (fail(st->compute_keypoints(nu, upd_px.data(), unpx.data(), bv.data()))) return;
-        for (int i = 0; i < nu; i++) cur->update(upd_ids[(size_t) i], &upd_px[2 * (size_t) i], &unpx[2 * (size_t) i], &bv[3 * (size_t) i]);
-    }
-    for (int id: removed) remove_obs_from_cur(id);
+    if (r.p3p_req) p3p_req = true;
+    pose_do_p3p_ = job.do_p3p != 0 || r.p3p_req != 0;  // p3pReq_ set by this very pass counts (visual_frontend.cpp:272)
 }
 
-bool Slam::compute_pose() {  // visual_frontend.cpp:245-417
+// VisualFrontend::computePose (visual_frontend.cpp:245-417) on the correspondences the tracking step put together
+bool Slam::compute_pose() {
+    TrackPose &r = pose_out_;
+    if (fail(st->track_pose_collect(r))) return false;
     if (cur->n_3d < 4) return false;
-    const bool do_p3p = p3p_req || cfg.p3p_enabled;
-    std::vector<double> bvs, wpts, uvs;
-    std::vector<int> ids;
-    for (const auto &e: cur->kps) {
-        const KeyPt &k = e.second;
-        if (!k.is3d) continue;
-        const std::shared_ptr<MapPt> &mp = map_points.at(k.id);
-        if (!mp) continue;
-        if (do_p3p) bvs.insert(bvs.end(), k.bv, k.bv + 3);
-        uvs.push_back((double) k.unpx[0]);
-        uvs.push_back((double) k.unpx[1]);
-        wpts.insert(wpts.end(), mp->X, mp->X + 3);
-        ids.push_back(k.id);
-    }
-    double pose7[7];
-    se3_to_pose7(cur->Twc, pose7);
-    int n = (int) ids.size();
-    std::vector<int> outliers((size_t) n + 1);
-    int n_out = 0, ok = 0;
-    if (do_p3p) {
-        if (fail(st->p3p(n, bvs.data(), wpts.data(), cfg.random_sampling ? 1 : 0, pose7, outliers.data(), &n_out, &ok))) return false;
-        const size_t inliers = (size_t) n - (size_t) (ok ? n_out : 0);
-        bool bad_t = false;
-        for (int i = 0; i < 3; i++) bad_t = bad_t || std::isinf(pose7[i]) || std::isnan(pose7[i]);
-        if (!ok || inliers < 5 || bad_t) {
-            reset_frame();
-            return false;
-        }
-        cur->set_Twc(se3_from_pose7(pose7));
-        // drop the P3P outliers before the refinement (:344-352); indices are ascending
-        std::vector<uint8_t> drop((size_t) n, 0);
-        for (int i = 0; i < n_out; i++) {
-            drop[(size_t) outliers[(size_t) i]] = 1;
-            remove_obs_from_cur(ids[(size_t) outliers[(size_t) i]]);
-        }
-        int w = 0;
-        for (int i = 0; i < n; i++)
-            if (!drop[(size_t) i]) {
-                ids[(size_t) w] = ids[(size_t) i];
-                uvs[2 * (size_t) w] = uvs[2 * (size_t) i]; uvs[2 * (size_t) w + 1] = uvs[2 * (size_t) i + 1];
-                for (int c = 0; c < 3; c++) wpts[3 * (size_t) w + c] = wpts[3 * (size_t) i + c];
-                w++;
-            }
-        n = w;
-        n_out = 0;
-    }
-    ok = 0;
-    if (fail(st->pnp(n, uvs.data(), wpts.data(), pose7, outliers.data(), &n_out, &ok))) return false;
-    const size_t inliers = (size_t) n - (size_t) n_out;
-    bool bad_t = false;
-    for (int i = 0; i < 3; i++) bad_t = bad_t || std::isinf(pose7[i]) || std::isnan(pose7[i]);
-    if (!ok || inliers < 5 || n_out > 0.5 * n || bad_t) {
-        if (!do_p3p) p3p_req = true;
+    if (r.status < 0) return false;
+    if (r.status == 0) {  // P3P rejected (:318-330)
         reset_frame();
         return false;
     }
-    cur->set_Twc(se3_from_pose7(pose7));
+    const size_t n = pose_ids_.size();
+    if (pose_do_p3p_) {
+        cur->set_Twc(se3_from_pose7(r.pose7_p3p));
+        for (size_t k = 0; k < n; k++)
+            if (r.p3p_outlier[k]) remove_obs_from_cur(pose_ids_[k]);
+    }
+    if (r.status == 1) {  // refinement rejected (:383-399)
+        if (!pose_do_p3p_) p3p_req = true;
+        reset_frame();
+        return false;
+    }
+    cur->set_Twc(se3_from_pose7(r.pose7));
     p3p_req = false;
-    for (int i = 0; i < n_out; i++) remove_obs_from_cur(ids[(size_t) outliers[(size_t) i]]);
+    for (size_t k = 0; k < n; k++)
+        if (r.pnp_outlier[k]) remove_obs_from_cur(pose_ids_[k]);
     return true;
 }
 

@@ -151,6 +151,14 @@ public:
 
 private:
     int err_ = 0;
+    // the tracking step's slot tables (reused from frame to frame)
+    std::vector<int> job_ids_, pose_ids_;
+    std::vector<float> job_px_;
+    std::vector<uint8_t> job_is3d_;
+    std::vector<double> job_wpt_;
+    TrackKlt klt_out_;
+    TrackPose pose_out_;
+    bool pose_do_p3p_ = true;
     bool fail(int rc) { if (rc && !err_) err_ = rc; return rc != 0; }
 
     // VisualFrontend

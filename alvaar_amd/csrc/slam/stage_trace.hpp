@@ -13,6 +13,8 @@ namespace alva_slam {
 
 class TraceStages : public Stages {
 public:
+    // Tracing composes the tracking step from the fine-grained stages (the default track_begin / track_pose_collect of this object),
+    // so that every stage call is visible -- a fused override of the inner implementation is bypassed while tracing.
     TraceStages(Stages *inner, const char *path) : in_(inner) { f_ = std::fopen(path, "wb"); }
     ~TraceStages() override {
         if (f_) std::fclose(f_);

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace alva_slam {
 
@@ -17,8 +18,47 @@ struct Camera {
     double fx = 0, fy = 0, cx = 0, cy = 0, k1 = 0, k2 = 0, p1 = 0, p2 = 0;
 };
 
+// One tracking step (VisualFrontend::kltTrackingFromMotionPrior + computePose, visual_frontend.cpp:103-417) as data: the frame's
+// keypoints as SLOTS in the frame container's iteration order.
+struct TrackJob {
+    int n = 0;
+    const float *px = nullptr;        // [n][2] keypoint positions in the previous image
+    const uint8_t *is3d = nullptr;    // [n]
+    const double *wpt = nullptr;      // [n][3] world point of the slot's map point (3-D slots; ignored otherwise)
+    double Tcw_q[4] = {0, 0, 0, 1}, Tcw_t[3] = {0, 0, 0};  // predicted pose, world -> camera (motion model applied)
+    double pose7_pred[7] = {0, 0, 0, 0, 0, 0, 1};           // the same as Twc (start of the refinement when P3P is off)
+    int use_prior = 1;                // kltUsePrior_
+    int klt_levels = 3;               // kltPyramidLevels_
+    int want_pose = 0;                // map initialised: solve the pose behind the tracker
+    int do_p3p = 1;                   // p3pReq_ || p3pEnabled_
+    int do_random = 1;                // multiViewRandomEnabled_
+};
+// after the tracker: per slot  code 0 = lost, 1 = tracked from its projected prior on one level, 2 = tracked on the full pyramid,
+// 3 = tracked on the full pyramid after failing with the prior; px / unpx / bv valid where code != 0
+struct TrackKlt {
+    std::vector<uint8_t> code;
+    std::vector<float> px, unpx;
+    std::vector<double> bv;
+    int p3p_req = 0;   // fewer than 33 % of the priors held (visual_frontend.cpp:197-202)
+    int n_pose = 0;    // surviving 3-D slots = correspondences of the pose solve, in slot order
+};
+// after the pose solve: status -1 = not attempted (fewer than 4 correspondences), 0 = P3P rejected, 1 = P3P pose accepted but the
+// refinement rejected, 2 = refined pose accepted; masks indexed by correspondence (k-th surviving 3-D slot)
+struct TrackPose {
+    int status = -1;
+    double pose7_p3p[7] = {0, 0, 0, 0, 0, 0, 1}, pose7[7] = {0, 0, 0, 0, 0, 0, 1};
+    std::vector<uint8_t> p3p_outlier, pnp_outlier;
+};
+
 struct Stages {
     virtual ~Stages() {}
+
+    // The tracking step.  The default implementation composes it from the fine-grained stages below in the reference's order
+    // (track_default.cpp); the HIP implementation overrides it with one device-side chain (one host wait after the tracker, one after
+    // the pose).  track_begin returns with the tracker's results; the pose solve (when job.want_pose) may still be running and is
+    // collected by track_pose_collect -- the map layer does its tracker bookkeeping in between.
+    virtual int track_begin(const TrackJob &job, TrackKlt &out);
+    virtual int track_pose_collect(TrackPose &out);
 
     // System::findCameraPose's cvtColor(RGBA2GRAY) (system.cpp:111-112) + VisualFrontend::preprocessImage
     // (visual_frontend.cpp:672-698): the current image / pyramid become the previous ones, the new frame's gray image
@@ -73,6 +113,18 @@ struct Stages {
 
     // System::processPlane's fit (system.cpp:177-342, intended algorithm, parity unpinned)
     virtual int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) = 0;
+
+    // image size for Frame::isInImage in the default tracking step (set by the map layer)
+    int image_width_ = 0, image_height_ = 0;
+
+protected:
+    // hand-over from the default track_begin to the default track_pose_collect
+    struct PendingPose {
+        bool active = false;
+        int n = 0, do_p3p = 1, do_random = 1;
+        std::vector<double> bv, uv, wpt;
+        double pose7[7];
+    } pending_;
 };
 
 }  // namespace alva_slam
