@@ -48,6 +48,7 @@ struct PnpOut {
     int ok, n_bad;
     int p3p_ok, n_active;  // chained mode: P3P verdict and the number of points handed to the refinement
     int p3p_n_valid_used, pad;
+    double pose_p3p[7];  // chained mode: the accepted P3P pose as the refinement starts from it (normalised quaternion)
 };
 
 struct PnpShared {
@@ -295,7 +296,9 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
                     const double v = R[3 * r] * R[3 * c] + R[3 * r + 1] * R[3 * c + 1] + R[3 * r + 2] * R[3 * c + 2] - (r == c ? 1.0 : 0.0);
                     e += v * v;
                 }
-            s_p3p_ok = p3p->have_model && p3p->n_inliers >= 5 && sqrt(e) < 1e-10;
+            // + the translation test of visual_frontend.cpp:323 (isInf / isNaN)
+            s_p3p_ok = p3p->have_model && p3p->n_inliers >= 5 && sqrt(e) < 1e-10 && isfinite(p3p->model[9]) && isfinite(p3p->model[10]) &&
+                       isfinite(p3p->model[11]);
             if (s_p3p_ok) {
                 // rotation matrix -> unit quaternion (Sophus::SE3d::setRotationMatrix -> Eigen::Quaternion(R))
                 double q[4];
@@ -359,6 +362,7 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
             for (int i = 0; i < 4; i++) sh.x[3 + i] = T.q[i];
         }
         __syncthreads();
+        if (p3p && threadIdx.x < 7) out->pose_p3p[threadIdx.x] = sh.x[threadIdx.x];
     }
     int ok = solve(sh, A, A.use_robust, active, chi2, depth, s_info);
     const int nact = s_nact;
@@ -540,6 +544,12 @@ extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings
 }
 
 extern "C" int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier, int *h_status) {
+    return alva_compute_pose_collect_p3p(ctx, h_pose7, nullptr, h_p3p_outlier, h_pnp_outlier, h_status);
+}
+
+// the same, also returning the accepted P3P pose (status >= 1): the frame keeps it when the refinement is rejected (visual_frontend.cpp:335)
+int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose7_p3p, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
+                                  int *h_status) {
     ALVA_ARG(ctx && h_pose7 && h_status);
     alva_pose_pending *pp = (alva_pose_pending *) ctx->pose_pending;
     if (!pp || !pp->active) {
@@ -567,6 +577,7 @@ extern "C" int alva_compute_pose_collect(alva_ctx *ctx, double *h_pose7, uint8_t
     }
     if (!res.p3p_ok) return ALVA_OK;                                   // :318-330 -> resetFrame, false
     *h_status = 1;                                                      // P3P pose accepted
+    if (h_pose7_p3p) memcpy(h_pose7_p3p, res.pose_p3p, sizeof(res.pose_p3p));
     if (res.n_bad == res.n_active) return ALVA_OK;                      // ceresPnP returns false before writing the pose
     memcpy(h_pose7, res.pose, sizeof(res.pose));
     const int inliers = res.n_active - res.n_bad;

@@ -15,3 +15,11 @@ struct P3pSelectOut {
 int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
                      int do_random, uint32_t seed, float fx, float fy, int n_draws, int *pin_samples, P3pSelectOut *out,
                      uint8_t *inlier);
+
+// alva_compute_pose_collect that also returns the accepted P3P pose (pnp.hip)
+int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose7_p3p, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
+                                  int *h_status);
+// fbKltTracking with the keypoint count in device memory (klt.hip)
+int alva_fbklt_track_dn(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, int num_levels, float err_thresh, float fb_dist,
+                        int max_iters, float eps, const float *d_pts, const float *d_prior_in, float *d_out, uint8_t *d_status, const int *d_n,
+                        int n_max);

@@ -1,10 +1,20 @@
 // Per-frame state machine of the host-side map layer: the behaviour of System::processCameraPose (src/slam/src/system.cpp:156-175)
 // and VisualFrontend (src/slam/src/visual_frontend.cpp) of the reference, with every numeric stage behind `Stages`.
 #include "slam.hpp"
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
 namespace alva_slam {
+
+namespace {
+struct Section {  // adds the scope's wall time to one slot of Slam::t_section
+    double &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Section(double &a) : acc(a) {}
+    ~Section() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 Slam::Slam(Stages *stages, const Camera &c, const Settings &s) : st(stages), cam(c), cfg(s) {
     // State::State (state.cpp:3-12)
@@ -43,11 +53,12 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     reset_requested = false;
 }
 
-int Slam::process_frame(const uint8_t *rgba, double timestamp) {  // system.cpp:156-175
+int Slam::process_frame(const uint8_t *rgba, double timestamp, bool frame_on_device) {  // system.cpp:156-175
     err_ = 0;
     cur->id++;
     cur->timestamp = timestamp;
-    track(rgba, timestamp);
+    track(rgba, timestamp, frame_on_device);
+    fail(st->frame_done());
     if (err_) return err_;
     if (reset_requested) {
         reset();
@@ -57,14 +68,24 @@ int Slam::process_frame(const uint8_t *rgba, double timestamp) {  // system.cpp:
     return 1;
 }
 
-bool Slam::track(const uint8_t *rgba, double timestamp) {  // visual_frontend.cpp:21-35
-    if (fail(st->new_frame(rgba))) return false;  // cvtColor (system.cpp:112) + preprocessImage (:672-698)
+bool Slam::track(const uint8_t *rgba, double timestamp, bool frame_on_device) {  // visual_frontend.cpp:21-35
+    {
+        Section sec(t_section[0]);
+        // cvtColor (system.cpp:112) + preprocessImage (:672-698)
+        if (fail(frame_on_device ? st->new_frame_device(rgba) : st->new_frame(rgba))) return false;
+    }
     const bool kf_required = process(timestamp);
     if (err_) return false;
     if (kf_required) {
-        create_keyframe();
+        {
+            Section sec(t_section[6]);
+            create_keyframe();
+        }
         if (err_) return false;
-        if (!reset_requested && ready_for_init) process_new_keyframe(cur->kfid);
+        if (!reset_requested && ready_for_init) {
+            Section sec(t_section[7]);
+            process_new_keyframe(cur->kfid);
+        }
     }
     return true;
 }
@@ -89,6 +110,7 @@ bool Slam::process(double timestamp) {  // visual_frontend.cpp:37-101
     }
     const bool ok = compute_pose();
     if (err_) return false;
+    Section sec(t_section[5]);
     if (!ok) {
         pose_failed++;
         if (pose_failed > 3) {
@@ -137,6 +159,12 @@ void Slam::update_motion_model(const SE3 &Twc, double time) {  // visual_fronten
 // the container's iteration order; its results are applied in the reference's order (updates of the one-level pass first, then the
 // full-pyramid list: the keypoints that never had a prior, then the ones that failed with theirs)
 void Slam::klt_from_motion_prior() {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    auto lap = [&](int slot) {
+        const auto t1 = std::chrono::steady_clock::now();
+        t_section[slot] += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    };
     const int n = (int) cur->kps.size();
     job_ids_.resize((size_t) n);
     job_px_.resize((size_t) n * 2);
@@ -166,7 +194,9 @@ void Slam::klt_from_motion_prior() {
     job.do_p3p = p3p_req || cfg.p3p_enabled;
     job.do_random = cfg.random_sampling;
     TrackKlt &r = klt_out_;
+    lap(1);
     if (fail(st->track_begin(job, r))) return;
+    lap(2);
     for (int pass = 1; pass <= 3; pass++)
         for (int s = 0; s < n; s++)
             if (r.code[(size_t) s] == pass) cur->update(job_ids_[(size_t) s], &r.px[2 * (size_t) s], &r.unpx[2 * (size_t) s], &r.bv[3 * (size_t) s]);
@@ -175,6 +205,7 @@ void Slam::klt_from_motion_prior() {
         if (!r.code[(size_t) s]) remove_obs_from_cur(job_ids_[(size_t) s]);
         else if (job_is3d_[(size_t) s]) pose_ids_.push_back(job_ids_[(size_t) s]);
     }
+    lap(3);
     if (r.p3p_req) p3p_req = true;
     pose_do_p3p_ = job.do_p3p != 0 || r.p3p_req != 0;  // p3pReq_ set by this very pass counts (visual_frontend.cpp:272)
 }
@@ -182,7 +213,11 @@ void Slam::klt_from_motion_prior() {
 // VisualFrontend::computePose (visual_frontend.cpp:245-417) on the correspondences the tracking step put together
 bool Slam::compute_pose() {
     TrackPose &r = pose_out_;
-    if (fail(st->track_pose_collect(r))) return false;
+    {
+        Section sec(t_section[4]);
+        if (fail(st->track_pose_collect(r))) return false;
+    }
+    Section sec(t_section[5]);
     if (cur->n_3d < 4) return false;
     if (r.status < 0) return false;
     if (r.status == 0) {  // P3P rejected (:318-330)
@@ -230,7 +265,8 @@ float Slam::compute_parallax(int kfid, bool unrotate, bool median) {  // visual_
     }
     float avg = 0.f;
     int cnt = 0;
-    std::set<float> all;
+    std::vector<uint32_t> &all = parallax_bits_;  // the reference's std::set<float>: distinct values, ascending
+    all.clear();
     for (const auto &e: cur->kps) {
         const KeyPt &k = e.second;
         const KeyPt *kk = kf.find(k.id);
@@ -245,14 +281,32 @@ float Slam::compute_parallax(int kfid, bool unrotate, bool median) {  // visual_
         const float par = (float) std::sqrt((double) dx * dx + (double) dy * dy);  // cv::norm(Point2f) -> double, stored in a float
         avg += par;
         cnt++;
-        if (median) all.insert(par);
+        if (median) {
+            uint32_t b;
+            std::memcpy(&b, &par, 4);
+            all.push_back(b);  // non-negative floats order like their bit patterns
+        }
     }
     if (!cnt) return 0.f;
     avg /= (float) cnt;
     if (median) {
-        auto it = all.begin();
-        std::advance(it, (long) (all.size() / 2));
-        avg = *it;
+        // element size/2 of the SET of values (visual_frontend.cpp:661-666): radix sort, drop duplicates, index
+        std::vector<uint32_t> &tmp = parallax_tmp_;
+        tmp.resize(all.size());
+        uint32_t *src = all.data(), *dst = tmp.data();
+        const size_t m = all.size();
+        for (int shift = 0; shift < 32; shift += 11) {
+            size_t hist[2049] = {0};
+            for (size_t i = 0; i < m; i++) hist[((src[i] >> shift) & 2047u) + 1]++;
+            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
+            for (size_t i = 0; i < m; i++) dst[hist[(src[i] >> shift) & 2047u]++] = src[i];
+            std::swap(src, dst);
+        }
+        size_t u = 0;
+        for (size_t i = 0; i < m; i++)
+            if (i == 0 || src[i] != src[u - 1]) src[u++] = src[i];
+        const uint32_t b = src[u / 2];
+        std::memcpy(&avg, &b, 4);
     }
     return avg;
 }

@@ -2,10 +2,22 @@
 // src/slam/src/frame.cpp, map_point.cpp and map_manager.cpp of the reference -- including the order in which the hash
 // containers are mutated, which is what fixes their iteration order.
 #include "slam.hpp"
+#include <chrono>
 #include <cmath>
 #include <limits>
 
 namespace alva_slam {
+
+namespace {
+struct Lap {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(double &acc) {
+        const auto t1 = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    }
+};
+}  // namespace
 
 static inline int popcount256(const Desc &a, const Desc &b) {  // cv::norm(a, b, NORM_HAMMING) on 32 bytes (map_point.cpp:106,158,212)
     int s = 0;
@@ -268,9 +280,12 @@ std::shared_ptr<MapPt> Slam::map_point(int id) const {
 }
 
 void Slam::create_keyframe() {  // map_manager.cpp:12-22
+    Lap lap;
     prepare_frame();
+    lap(t_kf[0]);
     extract_keypoints();
     add_keyframe();
+    lap(t_kf[4]);
 }
 
 void Slam::prepare_frame() {  // map_manager.cpp:24-81
@@ -324,7 +339,9 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     // describeKeypoints (:224-241): refresh the descriptors of the tracked keypoints in the raw image
     if (n) {
         std::vector<uint8_t> desc((size_t) n * 32), valid((size_t) n);
+        Lap lap;
         if (fail(st->describe(n, pts.data(), desc.data(), valid.data()))) return;
+        lap(t_kf[1]);
         for (int i = 0; i < n; i++)
             if (valid[(size_t) i]) {
                 Desc d;
@@ -338,13 +355,16 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
         const int cap = (int) cur->grid_cells + 8;
         std::vector<float> np((size_t) cap * 2);
         int count = 0;
+        Lap lap;
         if (fail(st->detect(cfg.cell_size, n, pts.data(), cap, np.data(), &count))) return;
+        lap(t_kf[2]);
         if (count > 0) {
             std::vector<uint8_t> desc((size_t) count * 32), valid((size_t) count);
             std::vector<float> unpx((size_t) count * 2);
             std::vector<double> bv((size_t) count * 3);
             if (fail(st->describe(count, np.data(), desc.data(), valid.data()))) return;
             if (fail(st->compute_keypoints(count, np.data(), unpx.data(), bv.data()))) return;
+            lap(t_kf[3]);
             for (int i = 0; i < count; i++) {  // addKeypointsToFrame (:166-191)
                 KeyPt k;
                 k.id = next_mp_id;

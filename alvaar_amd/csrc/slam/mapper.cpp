@@ -4,17 +4,31 @@
 // stage calls on flattened arrays.
 #include "slam.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
 namespace alva_slam {
 
+namespace {
+struct Lap {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(double &acc) {
+        const auto t1 = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    }
+};
+}  // namespace
+
 void Slam::process_new_keyframe(int kfid) {  // mapper.cpp:9-64
     std::shared_ptr<FrameRec> kf = keyframe(kfid);
     if (!kf) return;
+    Lap lap;
     if (kfid > 30) remove_keyframe(kfid - 30);  // "just keep the last 30 keyframes"
     if (kf->kfid > 0 && kf->n_2d > 0) triangulate_temporal(*kf);
     if (err_) return;
+    lap(t_kf[5]);
     if (ready_for_init) {
         if (kfid == 1 && kf->n_3d < 30) {
             reset_requested = true;
@@ -27,9 +41,12 @@ void Slam::process_new_keyframe(int kfid) {  // mapper.cpp:9-64
     }
     update_frame_covisibility(*kf);
     cur->covisible = kf->covisible;
+    lap(t_kf[6]);
     if (kfid > 0) matching_to_local_map(*kf);
     if (err_) return;
+    lap(t_kf[7]);
     optimize(kf);
+    lap(t_kf[8]);
 }
 
 void Slam::triangulate_temporal(FrameRec &frame) {  // mapper.cpp:144-291
@@ -219,10 +236,12 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     }
     obs_ptr[(size_t) n_mp] = (int) obs_kf.size();
     std::vector<int> match_of_mp((size_t) n_mp, -1);
+    Lap lap;
     const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) frame.grid.size(), cell_ptr.data(), cell_mp.data(),
                                     (int) kf_ids.size(), kf_q.data(), kf_t.data(), n_mp, mp_wpt.data(), mp_is3d.data(), mp_has_desc.data(),
                                     obs_ptr.data(), obs_kf.data(), obs_px.data(), obs_desc.data(), obs_has_desc.data(), fit->second,
                                     (int) frame.n_3d, (int) local_idx.size(), local_idx.data(), max_proj_err, dist_ratio, match_of_mp.data());
+    lap(t_kf[9]);
     if (fail(rc)) return result;
     for (int m = 0; m < n_mp; m++)
         if (match_of_mp[(size_t) m] >= 0) result.emplace(mp_ids[(size_t) m], mp_ids[(size_t) match_of_mp[(size_t) m]]);
@@ -419,9 +438,11 @@ void Slam::local_ba(FrameRec &new_frame) {
             pinv[(size_t) j] = pt_inv[(size_t) p];
         }
         if (n_obs > 0) {
+            Lap lap;
             if (fail(st->local_ba(n_kf, poses.data(), kc.data(), n_used, pa.data(), pauv.data(), pinv.data(), n_obs, okf.data(), opt.data(),
                                   ouv.data(), 5, chi2.data(), dpos.data())))
                 return;
+            lap(t_kf[10]);
             for (int j = 0; j < n_used; j++) pt_inv[(size_t) pts_used[(size_t) j]] = pinv[(size_t) j];
         }
         n_ba_runs++;

@@ -124,7 +124,7 @@ public:
     Slam(Stages *stages, const Camera &cam, const Settings &settings);
 
     // System::processCameraPose (system.cpp:156-175): returns 1 / 2 / 3
-    int process_frame(const uint8_t *rgba, double timestamp);
+    int process_frame(const uint8_t *rgba, double timestamp, bool frame_on_device = false);
     void reset();  // System::reset (system.cpp:42-55)
     int last_error() const { return err_; }
 
@@ -148,6 +148,13 @@ public:
     SE3 init_computed;  // what checkReadyForInit computed itself on the initialisation frame (before any override)
     // counters for tests / bench
     long n_ba_runs = 0, n_merges = 0, n_kf_culled = 0;
+    // wall-clock seconds spent per section since the last reset of the array (tools/system_probe.py): image upload + pyramid enqueue,
+    // slot gathering, tracking step until its results are back, tracker bookkeeping, waiting for the pose, pose bookkeeping + keyframe
+    // decision, keyframe creation (describe / detect), mapping (triangulation, matching to the local map, local BA)
+    double t_section[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // finer split of the two keyframe sections: prepare, describe tracked, detect, describe + add new | triangulate, covisibility,
+    // local-map matching (flatten, stage, merges), BA build, BA solves, BA write-back, keyframe culling
+    double t_kf[16] = {0};
 
 private:
     int err_ = 0;
@@ -159,10 +166,11 @@ private:
     TrackKlt klt_out_;
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
+    std::vector<uint32_t> parallax_bits_, parallax_tmp_;
     bool fail(int rc) { if (rc && !err_) err_ = rc; return rc != 0; }
 
     // VisualFrontend
-    bool track(const uint8_t *rgba, double timestamp);
+    bool track(const uint8_t *rgba, double timestamp, bool frame_on_device);
     bool process(double timestamp);
     void klt_from_motion_prior();
     bool compute_pose();

@@ -64,6 +64,11 @@ struct Stages {
     // (visual_frontend.cpp:672-698): the current image / pyramid become the previous ones, the new frame's gray image
     // (CLAHE-equalised copy when enabled) and LK pyramid become current.
     virtual int new_frame(const uint8_t *rgba) = 0;
+    // the same with the frame already in the implementation's device memory (frames resident in HBM: a capture pipeline that delivers
+    // into device memory, bench.py's timed loop); unsupported (-4) where there is no device
+    virtual int new_frame_device(const uint8_t *d_rgba) { (void) d_rgba; return -4; }
+    // end of System::processCameraPose: the caller may reuse its frame buffer once this returns
+    virtual int frame_done() { return 0; }
     // VisualFrontend::reset (visual_frontend.cpp:716-727): forget both images / pyramids
     virtual void reset_images() = 0;
 

@@ -5,27 +5,211 @@
 // Host arrays cross into device memory through two bump arenas that are reset per call: a pinned host arena (staging both
 // ways, so every copy is asynchronous on the stream) and a device arena.  One stream synchronisation per method.
 #include "common.hpp"
+#include "camera_device.hpp"
+#include "pose_internal.hpp"
 #include "stages_hip.hpp"
 #include <cmath>
+#include <cstdlib>
 
 namespace alva_slam {
 
 namespace {
 
-// Frame::computeKeypoint's second half (frame.cpp:109-112): bv = normalised K^-1 (unpx, 1), Eigen's operation order
+// Frame::computeKeypoint's second half (frame.cpp:109-112)
 __global__ void __launch_bounds__(256) k_bearing(const float *unpx, int n, const double *invK, double *bv) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double u = (double) unpx[2 * i], v = (double) unpx[2 * i + 1];
-    const double b0 = (invK[0] * u + invK[1] * v) + invK[2] * 1.;
-    const double b1 = (invK[3] * u + invK[4] * v) + invK[5] * 1.;
-    const double b2 = (invK[6] * u + invK[7] * v) + invK[8] * 1.;
-    const double z = (b0 * b0 + b1 * b1) + b2 * b2;
-    if (z > 0.) {
-        const double s = sqrt(z);
-        bv[3 * i] = b0 / s; bv[3 * i + 1] = b1 / s; bv[3 * i + 2] = b2 / s;
-    } else {
-        bv[3 * i] = b0; bv[3 * i + 1] = b1; bv[3 * i + 2] = b2;
+    alva_bearing_dev(invK, unpx[2 * i], unpx[2 * i + 1], bv + 3 * (size_t) i);
+}
+
+// ---- the fused tracking step (VisualFrontend::kltTrackingFromMotionPrior + the set-up of computePose) -------------------------
+// Three single-workgroup glue kernels around the two tracker launches.  Lists are built with STABLE block-wide compaction
+// (ballot + popcount prefix), so every list keeps the slot order = the frame container's iteration order the reference works in.
+struct TrackDev {
+    int n, use_prior, width, height;
+    const float *in_px;        // pinned host, [n][2]
+    const uint8_t *in_is3d;    // pinned host, [n]
+    const double *in_wpt;      // pinned host, [n][3]
+    double q[4], t[3];         // T_cw (predicted)
+    AlvaCam cam;
+    const double *invK;
+    int *cnt;                  // device: nA, nB0, nB, good1, p3p_req, n_pose
+    int *slotA, *slotB;
+    float *ptsA, *priorA, *outA, *ptsB, *priorB, *outB;
+    uint8_t *stA, *stB;
+    uint8_t *d_is3d, *d_code;
+    double *d_wpt;
+    float *d_px;
+    uint8_t *o_code;           // pinned host outputs
+    float *o_px, *o_unpx;
+    double *o_bv;
+    int *o_hdr;
+    double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
+};
+
+#define TRK_NT 1024
+// exclusive prefix of `flag` over the block in thread order; *total = number of set flags.  s_w: 17 ints of LDS.
+__device__ __forceinline__ int block_prefix(bool flag, int *s_w, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long b = __ballot(flag);
+    const int within = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();  // s_w reuse
+    if (lane == 0) s_w[wave] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < TRK_NT / 64; w++) {
+            const int c = s_w[w];
+            s_w[w] = acc;
+            acc += c;
+        }
+        s_w[16] = acc;
+    }
+    __syncthreads();
+    *total = s_w[16];
+    return s_w[wave] + within;
+}
+
+// priors of the 3-D slots from the predicted pose (visual_frontend.cpp:125-152) and the two lists: A = 3-D slots whose projection
+// falls into the image (tracked from it on one level), B = everything else (tracked from its own position on the full pyramid)
+__global__ void __launch_bounds__(TRK_NT) k_track_prepare(TrackDev D) {
+    __shared__ int s_w[17];
+    int baseA = 0, baseB = 0;
+    for (int c0 = 0; c0 < D.n; c0 += TRK_NT) {
+        const int i = c0 + threadIdx.x;
+        bool inA = false, valid = i < D.n;
+        float px = 0.f, py = 0.f, qu = 0.f, qv = 0.f;
+        if (valid) {
+            px = D.in_px[2 * i];
+            py = D.in_px[2 * i + 1];
+            const uint8_t is3 = D.in_is3d[i];
+            D.d_is3d[i] = is3;
+            double X[3] = {0, 0, 0};
+            if (is3) {
+                X[0] = D.in_wpt[3 * (size_t) i]; X[1] = D.in_wpt[3 * (size_t) i + 1]; X[2] = D.in_wpt[3 * (size_t) i + 2];
+            }
+            D.d_wpt[3 * (size_t) i] = X[0]; D.d_wpt[3 * (size_t) i + 1] = X[1]; D.d_wpt[3 * (size_t) i + 2] = X[2];
+            if (D.use_prior && is3) {
+                double pc[3];
+                alva_se3_apply_dev(D.q, D.t, X, pc);
+                alva_project_dist_dev(D.cam, pc[0], pc[1], pc[2], qu, qv);
+                inA = qu >= 0 && qv >= 0 && (double) qu < (double) D.width && (double) qv < (double) D.height;  // Frame::isInImage
+            }
+        }
+        int totA, totB;
+        const int pa = block_prefix(inA, s_w, &totA);
+        const int pb = block_prefix(valid && !inA, s_w, &totB);
+        if (inA) {
+            const int k = baseA + pa;
+            D.slotA[k] = i;
+            D.ptsA[2 * k] = px; D.ptsA[2 * k + 1] = py;
+            D.priorA[2 * k] = qu; D.priorA[2 * k + 1] = qv;
+        } else if (valid) {
+            const int k = baseB + pb;
+            D.slotB[k] = i;
+            D.ptsB[2 * k] = px; D.ptsB[2 * k + 1] = py;
+            D.priorB[2 * k] = px; D.priorB[2 * k + 1] = py;
+        }
+        baseA += totA;
+        baseB += totB;
+    }
+    if (threadIdx.x == 0) {
+        D.cnt[0] = baseA;
+        D.cnt[1] = baseB;
+        D.cnt[2] = baseB;
+        D.cnt[3] = 0;
+        D.cnt[4] = 0;
+        D.cnt[5] = 0;
+    }
+}
+
+// after the one-level pass (:173-203): failures join list B behind its original entries, keeping their order; fewer than 33 % successes
+// => p3pReq_ and every prior of list B falls back to the keypoint's own position
+__global__ void __launch_bounds__(TRK_NT) k_track_pass2(TrackDev D) {
+    __shared__ int s_w[17];
+    const int nA = D.cnt[0], nB0 = D.cnt[1];
+    int failed = 0;
+    for (int c0 = 0; c0 < nA; c0 += TRK_NT) {
+        const int j = c0 + threadIdx.x;
+        const bool bad = j < nA && !D.stA[j];
+        int tot;
+        const int p = block_prefix(bad, s_w, &tot);
+        if (bad) {
+            const int k = nB0 + failed + p;
+            D.slotB[k] = D.slotA[j];
+            D.ptsB[2 * k] = D.ptsA[2 * j]; D.ptsB[2 * k + 1] = D.ptsA[2 * j + 1];
+            D.priorB[2 * k] = D.outA[2 * j]; D.priorB[2 * k + 1] = D.outA[2 * j + 1];  // the forward tracker's result (in/out prior)
+        }
+        failed += tot;
+    }
+    const int good = nA - failed, nB = nB0 + failed;
+    const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
+    __syncthreads();
+    if (req)
+        for (int k = threadIdx.x; k < nB; k += TRK_NT) {
+            D.priorB[2 * k] = D.ptsB[2 * k];
+            D.priorB[2 * k + 1] = D.ptsB[2 * k + 1];
+        }
+    if (threadIdx.x == 0) {
+        D.cnt[2] = nB;
+        D.cnt[3] = good;
+        D.cnt[4] = req ? 1 : 0;
+    }
+}
+
+// after the full-pyramid pass: per-slot verdicts and positions, Frame::computeKeypoint for every tracked slot, and the
+// correspondences of the pose solve (3-D survivors in slot order: visual_frontend.cpp:275-298)
+__global__ void __launch_bounds__(TRK_NT) k_track_finish(TrackDev D) {
+    __shared__ int s_w[17];
+    const int nA = D.cnt[0], nB0 = D.cnt[1], nB = D.cnt[2];
+    for (int i = threadIdx.x; i < D.n; i += TRK_NT) D.d_code[i] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < nA; j += TRK_NT)
+        if (D.stA[j]) {
+            const int s = D.slotA[j];
+            D.d_code[s] = 1;
+            D.d_px[2 * s] = D.outA[2 * j]; D.d_px[2 * s + 1] = D.outA[2 * j + 1];
+        }
+    for (int k = threadIdx.x; k < nB; k += TRK_NT)
+        if (D.stB[k]) {
+            const int s = D.slotB[k];
+            D.d_code[s] = k < nB0 ? 2 : 3;
+            D.d_px[2 * s] = D.outB[2 * k]; D.d_px[2 * s + 1] = D.outB[2 * k + 1];
+        }
+    __syncthreads();
+    int base = 0;
+    for (int c0 = 0; c0 < D.n; c0 += TRK_NT) {
+        const int i = c0 + threadIdx.x;
+        uint8_t code = 0;
+        float px = 0.f, py = 0.f, ux = 0.f, uy = 0.f;
+        double bv[3] = {0, 0, 0};
+        bool pose = false;
+        if (i < D.n) {
+            code = D.d_code[i];
+            if (code) {
+                px = D.d_px[2 * i]; py = D.d_px[2 * i + 1];
+                alva_undistort_dev(D.cam, px, py, ux, uy);
+                alva_bearing_dev(D.invK, ux, uy, bv);
+                pose = D.d_is3d[i] != 0;
+            }
+            D.o_code[i] = code;
+            D.o_px[2 * i] = px; D.o_px[2 * i + 1] = py;
+            D.o_unpx[2 * i] = ux; D.o_unpx[2 * i + 1] = uy;
+            D.o_bv[3 * (size_t) i] = bv[0]; D.o_bv[3 * (size_t) i + 1] = bv[1]; D.o_bv[3 * (size_t) i + 2] = bv[2];
+        }
+        int tot;
+        const int p = block_prefix(pose, s_w, &tot);
+        if (pose) {
+            const size_t k = (size_t) (base + p);
+            D.Pbv[3 * k] = bv[0]; D.Pbv[3 * k + 1] = bv[1]; D.Pbv[3 * k + 2] = bv[2];
+            D.Puv[2 * k] = (double) ux; D.Puv[2 * k + 1] = (double) uy;
+            D.Pwpt[3 * k] = D.d_wpt[3 * (size_t) i]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * (size_t) i + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * (size_t) i + 2];
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) {
+        D.cnt[5] = base;
+        D.o_hdr[0] = nA; D.o_hdr[1] = nB0; D.o_hdr[2] = nB; D.o_hdr[3] = D.cnt[3]; D.o_hdr[4] = D.cnt[4]; D.o_hdr[5] = base;
     }
 }
 
@@ -70,8 +254,17 @@ struct HipStages::Impl {
     int cur = 0;
     uint8_t *d_rgba = nullptr, *d_gray = nullptr, *d_eq = nullptr, *h_rgba = nullptr;
     double *d_invK = nullptr;
+    const uint8_t *registered = nullptr, *last_host_ptr = nullptr;  // page-locked caller buffer (see new_frame)
+    bool allow_register = true, upload_in_flight = false;
+    hipEvent_t upload_done = nullptr;
     double max_quality = 0.001;  // state.hpp:57; lives as long as the reference's FeatureExtractor object (system.cpp:31)
     Arena dev, pin;
+    // the fused tracking step: persistent device / pinned blocks (grown when the keypoint count outgrows them)
+    Arena trk_dev, trk_pin;
+    int trk_cap = 0;
+    bool fused = true;       // ALVA_TRACK_UNFUSED=1: compose the tracking step from the fine-grained stages instead (A/B testing)
+    bool pose_pending = false;
+    int pose_n = 0;
     // a call plans its buffers first (sizes), then the arenas are grown once and carved
     struct Plan {
         std::vector<size_t> sizes;
@@ -122,8 +315,12 @@ HipStages::~HipStages() {
     for (void *b: bufs)
         if (b) (void) hipFree(b);
     if (m->h_rgba) (void) hipHostFree(m->h_rgba);
+    if (m->registered) (void) hipHostUnregister((void *) m->registered);
+    if (m->upload_done) (void) hipEventDestroy(m->upload_done);
     m->dev.release();
     m->pin.release();
+    m->trk_dev.release();
+    m->trk_pin.release();
     alva_ctx_destroy(m->ctx);
     delete m;
 }
@@ -133,6 +330,8 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->cam = cam;
     m->clahe = clahe;
     m->pin.pinned = true;
+    m->trk_pin.pinned = true;
+    m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
     int rc = alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -143,6 +342,8 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     ALVA_HIP(hipMalloc((void **) &m->d_invK, 9 * sizeof(double)));
     ALVA_HIP(hipMemcpy(m->d_invK, invK, 9 * sizeof(double), hipMemcpyHostToDevice));
     ALVA_HIP(hipHostMalloc((void **) &m->h_rgba, P * 4, hipHostMallocDefault));
+    ALVA_HIP(hipEventCreateWithFlags(&m->upload_done, hipEventDisableTiming));
+    m->allow_register = getenv("ALVA_NO_HOST_REGISTER") == nullptr;
     for (auto &p: m->pyr) {
         rc = alva_pyramid_create(m->ctx, cam.width, cam.height, 9, 3, &p);  // state.hpp:51-53: 9 x 9 window, 3 levels
         if (rc) return rc;
@@ -150,14 +351,10 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     return ALVA_OK;
 }
 
-int HipStages::new_frame(const uint8_t *rgba) {
-    ALVA_HIP(hipSetDevice(m->device));
-    const size_t P = (size_t) m->cam.width * m->cam.height;
-    memcpy(m->h_rgba, rgba, P * 4);  // the caller's buffer is pageable (wasm-heap style) memory
-    ALVA_HIP(hipMemcpyAsync(m->d_rgba, m->h_rgba, P * 4, hipMemcpyHostToDevice, m->st));
+int HipStages::build_from(const uint8_t *d_src) {
     m->cur ^= 1;
-    if (!m->clahe) return alva_pyramid_build_from_rgba(m->ctx, m->pyr[m->cur], m->d_rgba, (size_t) m->cam.width * 4, m->d_gray, (size_t) m->cam.width);
-    int rc = alva_rgba2gray(m->ctx, m->d_rgba, (size_t) m->cam.width * 4, m->cam.width, m->cam.height, m->d_gray, (size_t) m->cam.width);
+    if (!m->clahe) return alva_pyramid_build_from_rgba(m->ctx, m->pyr[m->cur], d_src, (size_t) m->cam.width * 4, m->d_gray, (size_t) m->cam.width);
+    int rc = alva_rgba2gray(m->ctx, d_src, (size_t) m->cam.width * 4, m->cam.width, m->cam.height, m->d_gray, (size_t) m->cam.width);
     if (rc) return rc;
     // visual_frontend.cpp:16-18: clip limit 3, grid = image size / 50 (state.hpp:45-46)
     rc = alva_clahe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, 3.0, m->cam.width / 50, m->cam.height / 50, m->d_eq,
@@ -166,7 +363,170 @@ int HipStages::new_frame(const uint8_t *rgba) {
     return alva_pyramid_build_from_gray(m->ctx, m->pyr[m->cur], m->d_eq, (size_t) m->cam.width);
 }
 
+// The caller's frame buffer is pageable memory (the reference's wasm heap).  A caller that hands over the SAME buffer frame after frame
+// -- src/system.js allocates memImg once and copies every frame into it (:63-67, :175) -- gets it page-locked on its second use, and the
+// DMA engine then reads it in place; any other buffer goes through a pinned staging copy.  ALVA_NO_HOST_REGISTER=1 disables the former.
+int HipStages::new_frame(const uint8_t *rgba) {
+    ALVA_HIP(hipSetDevice(m->device));
+    const size_t bytes = (size_t) m->cam.width * m->cam.height * 4;
+    const uint8_t *src = m->h_rgba;
+    if (m->registered == rgba) {
+        src = rgba;
+        m->upload_in_flight = true;
+    } else {
+        if (m->allow_register && m->last_host_ptr == rgba && hipHostRegister((void *) rgba, bytes, hipHostRegisterDefault) == hipSuccess) {
+            if (m->registered) (void) hipHostUnregister((void *) m->registered);
+            m->registered = rgba;
+            src = rgba;
+            m->upload_in_flight = true;
+        } else {
+            (void) hipGetLastError();
+            memcpy(m->h_rgba, rgba, bytes);
+        }
+    }
+    m->last_host_ptr = rgba;
+    ALVA_HIP(hipMemcpyAsync(m->d_rgba, src, bytes, hipMemcpyHostToDevice, m->st));
+    if (m->upload_in_flight) ALVA_HIP(hipEventRecord(m->upload_done, m->st));
+    return build_from(m->d_rgba);
+}
+
+int HipStages::new_frame_device(const uint8_t *d_rgba) {
+    ALVA_HIP(hipSetDevice(m->device));
+    return build_from(d_rgba);
+}
+
+int HipStages::frame_done() {
+    if (m->upload_in_flight) {
+        m->upload_in_flight = false;
+        ALVA_HIP(hipEventSynchronize(m->upload_done));
+    }
+    return ALVA_OK;
+}
+
 void HipStages::reset_images() {}  // the pyramids are rebuilt before they are read again (frame 0 tracks nothing)
+
+// One tracking step as ONE device-side chain: glue -> tracker (one level, from the projected priors) -> glue -> tracker (full pyramid)
+// -> glue, one host wait; then the pose solve (P3P-LMedS -> PnP, alva_compute_pose) is enqueued and collected by track_pose_collect
+// after the map layer has done its tracker bookkeeping.  Inputs are read from and per-slot results written to pinned host memory
+// by the kernels themselves: no copy commands.
+int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
+    if (!m->fused || (job.want_pose && !job.do_p3p)) return Stages::track_begin(job, out);
+    m->pose_pending = false;
+    pending_.active = false;
+    const int n = job.n;
+    out.code.assign((size_t) n, 0);
+    out.px.assign((size_t) n * 2, 0.f);
+    out.unpx.assign((size_t) n * 2, 0.f);
+    out.bv.assign((size_t) n * 3, 0.);
+    out.p3p_req = 0;
+    out.n_pose = 0;
+    if (n == 0) return ALVA_OK;
+    ALVA_HIP(hipSetDevice(m->device));
+    if (n > m->trk_cap) {
+        const int cap = ((n + 1023) / 1024 + 1) * 1024;
+        const size_t c = (size_t) cap;
+        // device: cnt | slotA slotB | ptsA priorA outA ptsB priorB outB | stA stB is3d code | wpt | px | Pbv Puv Pwpt
+        const size_t dev_bytes = 256 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64;
+        const size_t pin_bytes = c * 8 + c + 64 + c * 24 + 256 + c + 64 + c * 16 + c * 24 + 256;
+        int rc = m->trk_dev.grow(dev_bytes, m->st);
+        if (rc) return rc;
+        rc = m->trk_pin.grow(pin_bytes, m->st);
+        if (rc) return rc;
+        m->trk_cap = cap;
+    }
+    const size_t c = (size_t) m->trk_cap;
+    TrackDev D{};
+    {
+        uint8_t *b = m->trk_dev.base;
+        D.cnt = (int *) b; b += 256;
+        D.slotA = (int *) b; b += c * 4;
+        D.slotB = (int *) b; b += c * 4;
+        D.ptsA = (float *) b; b += c * 8;
+        D.priorA = (float *) b; b += c * 8;
+        D.outA = (float *) b; b += c * 8;
+        D.ptsB = (float *) b; b += c * 8;
+        D.priorB = (float *) b; b += c * 8;
+        D.outB = (float *) b; b += c * 8;
+        D.stA = b; b += c;
+        D.stB = b; b += c;
+        D.d_is3d = b; b += c;
+        D.d_code = b; b += c;
+        b += 256 - ((uintptr_t) b & 255);
+        D.d_wpt = (double *) b; b += c * 24;
+        D.d_px = (float *) b; b += c * 8;
+        D.Pbv = (double *) b; b += c * 24;
+        D.Puv = (double *) b; b += c * 16;
+        D.Pwpt = (double *) b; b += c * 24;
+        uint8_t *h = m->trk_pin.base;
+        D.in_px = (const float *) h; h += c * 8;
+        D.in_is3d = h; h += c + 64 - (c & 63);
+        D.in_wpt = (const double *) h; h += c * 24;
+        D.o_hdr = (int *) h; h += 256;
+        D.o_code = h; h += c + 64 - (c & 63);
+        D.o_px = (float *) h; h += c * 8;
+        D.o_unpx = (float *) h; h += c * 8;
+        D.o_bv = (double *) h; h += c * 24;
+    }
+    memcpy((void *) D.in_px, job.px, (size_t) n * 8);
+    memcpy((void *) D.in_is3d, job.is3d, (size_t) n);
+    memcpy((void *) D.in_wpt, job.wpt, (size_t) n * 24);
+    int n3d = 0;
+    for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
+    D.n = n;
+    D.use_prior = job.use_prior;
+    D.width = m->cam.width;
+    D.height = m->cam.height;
+    memcpy(D.q, job.Tcw_q, 32);
+    memcpy(D.t, job.Tcw_t, 24);
+    const Camera &k = m->cam;
+    D.cam = AlvaCam{k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2};
+    D.invK = m->d_invK;
+    const alva_pyramid *prev = m->pyr[m->cur ^ 1], *cur = m->pyr[m->cur];
+    hipLaunchKernelGGL(k_track_prepare, dim3(1), dim3(TRK_NT), 0, m->st, D);
+    int rc = ALVA_OK;
+    if (job.use_prior && n3d > 0)  // state.hpp:50-56 constants; one pyramid level (visual_frontend.cpp:166)
+        rc = alva_fbklt_track_dn(m->ctx, prev, cur, 1, 30.f, 0.5f, 30, 0.01f, D.ptsA, D.priorA, D.outA, D.stA, D.cnt + 0, n3d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_track_pass2, dim3(1), dim3(TRK_NT), 0, m->st, D);
+    rc = alva_fbklt_track_dn(m->ctx, prev, cur, job.klt_levels, 30.f, 0.5f, 30, 0.01f, D.ptsB, D.priorB, D.outB, D.stB, D.cnt + 2, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(TRK_NT), 0, m->st, D);
+    ALVA_LAUNCH_CHECK();
+    ALVA_HIP(hipStreamSynchronize(m->st));
+    memcpy(out.code.data(), D.o_code, (size_t) n);
+    memcpy(out.px.data(), D.o_px, (size_t) n * 8);
+    memcpy(out.unpx.data(), D.o_unpx, (size_t) n * 8);
+    memcpy(out.bv.data(), D.o_bv, (size_t) n * 24);
+    out.p3p_req = D.o_hdr[4];
+    out.n_pose = D.o_hdr[5];
+    if (job.want_pose && out.n_pose >= 4) {
+        // P3P-LMedS keeps its median in LDS: at most 7168 correspondences (the first ones, in slot order, when a frame has more)
+        m->pose_n = out.n_pose > 7168 ? 7168 : out.n_pose;
+        rc = alva_compute_pose_enqueue(m->ctx, D.Pbv, D.Puv, D.Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
+                                       (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
+        if (rc) return rc;
+        m->pose_pending = true;
+    }
+    m->pose_n = out.n_pose >= 4 ? m->pose_n : 0;
+    pose_total_ = out.n_pose;
+    fused_active_ = true;
+    return ALVA_OK;
+}
+
+int HipStages::track_pose_collect(TrackPose &out) {
+    if (!fused_active_) return Stages::track_pose_collect(out);
+    fused_active_ = false;
+    out.status = -1;
+    out.p3p_outlier.assign((size_t) pose_total_, 0);
+    out.pnp_outlier.assign((size_t) pose_total_, 0);
+    if (!m->pose_pending) return ALVA_OK;
+    m->pose_pending = false;
+    int status = 0;
+    int rc = alva_compute_pose_collect_p3p(m->ctx, out.pose7, out.pose7_p3p, out.p3p_outlier.data(), out.pnp_outlier.data(), &status);
+    if (rc) return rc;
+    out.status = status;
+    return ALVA_OK;
+}
 
 int HipStages::fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) {
     if (n <= 0) return ALVA_OK;

@@ -11,7 +11,11 @@ public:
     ~HipStages() override;
     int init(int device, const Camera &cam, bool clahe, const double *invK);
 
+    int track_begin(const TrackJob &job, TrackKlt &out) override;
+    int track_pose_collect(TrackPose &out) override;
     int new_frame(const uint8_t *rgba) override;
+    int new_frame_device(const uint8_t *d_rgba) override;
+    int frame_done() override;
     void reset_images() override;
     int fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) override;
     int compute_keypoints(int n, const float *px, float *unpx, double *bv) override;
@@ -34,8 +38,11 @@ public:
     int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) override;
 
 private:
+    int build_from(const uint8_t *d_src);
     struct Impl;
     Impl *m;
+    bool fused_active_ = false;
+    int pose_total_ = 0;
 };
 
 }  // namespace alva_slam

@@ -80,6 +80,8 @@ extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, d
     s->slam = std::move(slam);
     if (const char *path = getenv("ALVA_STAGE_TRACE")) {
         s->trace.reset(new TraceStages(s->stages.get(), path));
+        s->trace->image_width_ = width;
+        s->trace->image_height_ = height;
         s->slam->st = s->trace.get();
     }
     for (int i = 0; i < 3; i++) s->imu_translation[i] = s->prev_translation[i] = 0;
@@ -106,6 +108,18 @@ extern "C" int alva_system_find_camera_pose_ts(alva_system *s, const uint8_t *h_
     const int status = s->slam->process_frame(h_rgba, timestamp);  // system.cpp:156-175
     if (status < 0) return sys_fail(status, "alva_system_find_camera_pose");
     pose_to_array(s->slam->cur->Twc, h_pose);  // written whatever the status (system.cpp:118)
+    return status;
+}
+
+extern "C" int alva_system_find_camera_pose_device(alva_system *s, const uint8_t *d_rgba, double timestamp, float *h_pose) {
+    g_sys_err[0] = 0;
+    if (!s || !s->slam || !d_rgba || !h_pose) {
+        snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_find_camera_pose_device: not configured or NULL argument");
+        return ALVA_ERR_ARG;
+    }
+    const int status = s->slam->process_frame(d_rgba, timestamp, true);
+    if (status < 0) return sys_fail(status, "alva_system_find_camera_pose_device");
+    pose_to_array(s->slam->cur->Twc, h_pose);
     return status;
 }
 
@@ -212,6 +226,18 @@ extern "C" int alva_system_debug_map_points(alva_system *s, int cap, int *ids, d
 extern "C" int alva_system_debug_counters(alva_system *s, long *out3) {
     if (!s || !s->slam || !out3) return ALVA_ERR_ARG;
     out3[0] = s->slam->n_ba_runs; out3[1] = s->slam->n_merges; out3[2] = s->slam->n_kf_culled;
+    return ALVA_OK;
+}
+extern "C" int alva_system_debug_timing(alva_system *s, double *out8, int reset) {
+    if (!s || !s->slam) return ALVA_ERR_ARG;
+    if (out8) memcpy(out8, s->slam->t_section, sizeof(s->slam->t_section));
+    if (reset) memset(s->slam->t_section, 0, sizeof(s->slam->t_section));
+    return ALVA_OK;
+}
+extern "C" int alva_system_debug_timing_keyframe(alva_system *s, double *out16, int reset) {
+    if (!s || !s->slam) return ALVA_ERR_ARG;
+    if (out16) memcpy(out16, s->slam->t_kf, sizeof(s->slam->t_kf));
+    if (reset) memset(s->slam->t_kf, 0, sizeof(s->slam->t_kf));
     return ALVA_OK;
 }
 extern "C" int alva_system_debug_set_init_pose(alva_system *s, const double *pose7) {

@@ -24,6 +24,7 @@ lib.alva_system_get_frame_points.argtypes = [_vp, _vp]
 lib.alva_system_get_keypoints.argtypes = [_vp, _vp, _vp, _vp, _i]
 lib.alva_system_configure_ex.argtypes = [_vp, _i, _i] + [_d] * 8 + [_i] * 3
 lib.alva_system_find_camera_pose_ts.argtypes = [_vp, _vp, _d, _vp]
+lib.alva_system_find_camera_pose_device.argtypes = [_vp, _vp, _d, _vp]
 lib.alva_system_debug_state.argtypes = [_vp, _vp]
 lib.alva_system_debug_pose7.argtypes = [_vp, _vp, _vp]
 lib.alva_system_debug_frame_keypoints.argtypes = [_vp, _i] + [_vp] * 5
@@ -33,6 +34,8 @@ lib.alva_system_debug_covisibility.argtypes = [_vp, _i, _i, _vp]
 lib.alva_system_debug_map_points.argtypes = [_vp, _i] + [_vp] * 5
 lib.alva_system_debug_counters.argtypes = [_vp, _vp]
 lib.alva_system_debug_set_init_pose.argtypes = [_vp, _vp]
+lib.alva_system_debug_timing.argtypes = [_vp, _vp, _i]
+lib.alva_system_debug_timing_keyframe.argtypes = [_vp, _vp, _i]
 lib.alva_system_last_error.restype = C.c_char_p
 
 
@@ -94,6 +97,13 @@ class AlvaAR:
         if status < 0:
             raise AlvaError(lib.alva_system_last_error().decode())
         return (self._pose.copy() if status == 1 else None), status
+
+    def find_camera_pose_device(self, d_rgba_ptr: int, timestamp_ms: float):
+        """frame already in device memory (torch tensor .data_ptr()); returns the status, the pose is in self._pose"""
+        status = lib.alva_system_find_camera_pose_device(self.h, d_rgba_ptr, float(timestamp_ms), self._pose.ctypes.data)
+        if status < 0:
+            raise AlvaError(lib.alva_system_last_error().decode())
+        return status
 
     def findCameraPoseWithIMU(self, frame_rgba, orientation_wxyz, motion=()):  # noqa: N802
         frame = np.ascontiguousarray(frame_rgba, np.uint8)
@@ -168,6 +178,20 @@ class AlvaAR:
         out = (C.c_long * 3)()
         lib.alva_system_debug_counters(self.h, out)
         return dict(ba_solves=out[0], merges=out[1], culled_keyframes=out[2])
+
+    def timing(self, reset: bool = True):
+        """seconds per section of the frame loop since the last reset (see alva_system_debug_timing)"""
+        out = np.zeros(8)
+        lib.alva_system_debug_timing(self.h, out.ctypes.data, int(reset))
+        names = ("upload+pyramid", "gather", "track_step", "track_apply", "pose_wait", "pose_apply+kf_check", "keyframe_create", "mapping")
+        return dict(zip(names, out))
+
+    def timing_keyframe(self, reset: bool = True):
+        out = np.zeros(16)
+        lib.alva_system_debug_timing_keyframe(self.h, out.ctypes.data, int(reset))
+        names = ("prepare", "describe_tracked", "detect", "describe_new", "insert+copy", "triangulate", "covisibility", "local_map_matching",
+                 "optimize", "(match stage)", "(BA stage)")
+        return dict(zip(names, out[:11]))
 
     def set_init_pose(self, pose7):
         if pose7 is None:

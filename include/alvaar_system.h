@@ -44,11 +44,16 @@ int alva_system_configure(alva_system *sys, int width, int height, double fx, do
 int alva_system_configure_ex(alva_system *sys, int width, int height, double fx, double fy, double cx, double cy, double k1,
                              double k2, double p1, double p2, int cell_size, int clahe_enabled, int random_sampling);
 void alva_system_reset(alva_system *sys);
-/* System::findCameraPose (system.cpp:106-121).  h_rgba: width*height*4 bytes, caller-owned; h_pose: float[16]. */
+/* System::findCameraPose (system.cpp:106-121).  h_rgba: width*height*4 bytes, caller-owned; h_pose: float[16].  A caller that passes
+ * the SAME buffer on consecutive frames (as src/system.js does with its memImg, :63-67, :175) gets it page-locked (hipHostRegister) from its
+ * second use on, so that the GPU's DMA engine reads it in place; it is released with the system (ALVA_NO_HOST_REGISTER=1 disables this). */
 int alva_system_find_camera_pose(alva_system *sys, const uint8_t *h_rgba, float *h_pose);
 /* The same with the frame's timestamp (milliseconds) as an argument instead of the system clock (system.cpp:114): the
  * constant-velocity motion model (visual_frontend.hpp:11-68) is the only consumer. */
 int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, double timestamp_ms, float *h_pose);
+/* The same for a frame that already lives in DEVICE memory of the system's GPU (width*height*4 bytes, 16-byte aligned): no PCIe
+ * upload.  For capture pipelines that deliver into HBM, and for bench.py's timed loop (frames resident in HBM). */
+int alva_system_find_camera_pose_device(alva_system *sys, const uint8_t *d_rgba, double timestamp_ms, float *h_pose);
 /* System::findCameraPoseWithIMU (system.cpp:57-104).  h_imu: [qw,qx,qy,qz,n, n x {ts,gx,gy,gz,ax,ay,az}]. Always returns 1. */
 int alva_system_find_camera_pose_with_imu(alva_system *sys, const uint8_t *h_rgba, const double *h_imu, float *h_pose);
 /* System::findPlane (system.cpp:123-137): 1 on success, 0 otherwise (needs >= 32 observed 3-D points). */
@@ -71,6 +76,13 @@ int alva_system_debug_keyframe(alva_system *sys, int kfid, double *pose7, int *i
 int alva_system_debug_covisibility(alva_system *sys, int kfid, int cap, int *pairs);
 int alva_system_debug_map_points(alva_system *sys, int cap, int *ids, double *xyz, int *flags5, double *inv_depth, uint8_t *desc);
 int alva_system_debug_counters(alva_system *sys, long *out3 /* local-BA solves, map-point merges, culled keyframes */);
+/* wall-clock seconds per section of the frame loop since the last reset: upload + pyramid enqueue, slot gathering, tracking step,
+ * tracker bookkeeping, wait for the pose, pose bookkeeping + keyframe decision, keyframe creation, mapping (incl. local BA) */
+int alva_system_debug_timing(alva_system *sys, double *out8, int reset);
+/* finer split of the keyframe sections: [0] prepareFrame [1] describe tracked keypoints [2] grid detection [3] describe + undistort new
+ * keypoints [4] map insertion + keyframe copy | [5] triangulation [6] covisibility [7] local-map matching incl. flattening and merges
+ * [8] optimize (local BA + culling) ; inside them: [9] the matchToMap stage call [10] the local-BA stage calls */
+int alva_system_debug_timing_keyframe(alva_system *sys, double *out16, int reset);
 /* Test hook: the two-view initialisation adopts this pose (Twc of the initialisation frame, unit baseline) instead of its own
  * five-point result -- OpenGV's refinement sits at a rounding-noise floor of 1e-6..1e-4, so a differential
  * test against the reference either compares up to that gauge or starts both maps from the same two-view pose.  NULL disarms. */

@@ -241,6 +241,8 @@ void *syscpu_create(int w, int h, double fx, double fy, double cx, double cy, do
     s->slam.reset(new Slam(s->stages.get(), cam, cfg));
     if (const char *path = getenv("ALVA_STAGE_TRACE_CPU")) {
         s->trace.reset(new TraceStages(s->stages.get(), path));
+        s->trace->image_width_ = w;
+        s->trace->image_height_ = h;
         s->slam->st = s->trace.get();
     }
     return s;
