@@ -48,6 +48,8 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     next_mp_id = next_kf_id = n_map_points = n_keyframes = 0;
     keyframes.clear();
     map_points.clear();
+    kf_flat_.clear();
+    mp_flat_.clear();
     // State::reset (state.cpp:14-18)
     ready_for_init = false;
     reset_requested = false;
@@ -177,7 +179,7 @@ void Slam::klt_from_motion_prior() {
         job_px_[2 * (size_t) i] = k.px[0];
         job_px_[2 * (size_t) i + 1] = k.px[1];
         job_is3d_[(size_t) i] = k.is3d;
-        if (k.is3d) std::memcpy(&job_wpt_[3 * (size_t) i], map_points.at(k.id)->X, 24);
+        if (k.is3d) std::memcpy(&job_wpt_[3 * (size_t) i], map_points.at(k.id)->X, 24);  // .at: throws like the reference (:131) if the map lost it
         i++;
     }
     TrackJob job;

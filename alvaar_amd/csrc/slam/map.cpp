@@ -318,23 +318,32 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
             }
         }
     }
-    for (const KeyPt &kp: cur->keypoints()) {
-        auto it = map_points.find(kp.id);
-        if (it == map_points.end()) {
-            remove_obs_from_cur(kp.id);
+    // the reference walks a COPY of the keypoints (getKeypoints, :70) because the body may drop keypoints: a snapshot of the ids does
+    ids_scratch_.clear();
+    for (const auto &e: cur->kps) ids_scratch_.push_back(e.first);
+    for (int id: ids_scratch_) {
+        MapPt *mp = mp_raw(id);
+        if (!mp) {
+            remove_obs_from_cur(id);
             continue;
         }
-        it->second->obs_kfs.insert(next_kf_id);
+        mp->obs_kfs.insert(next_kf_id);
     }
 }
 
 void Slam::extract_keypoints() {  // map_manager.cpp:193-241
-    const std::vector<KeyPt> kps = cur->keypoints();
-    const int n = (int) kps.size();
+    const int n = (int) cur->kps.size();
+    std::vector<int> &kp_ids = ids_scratch_;
+    kp_ids.clear();
     std::vector<float> pts((size_t) n * 2);
-    for (int i = 0; i < n; i++) {
-        pts[2 * (size_t) i] = kps[(size_t) i].px[0];
-        pts[2 * (size_t) i + 1] = kps[(size_t) i].px[1];
+    {
+        size_t i = 0;
+        for (const auto &e: cur->kps) {  // getKeypoints(): container order
+            kp_ids.push_back(e.first);
+            pts[2 * i] = e.second.px[0];
+            pts[2 * i + 1] = e.second.px[1];
+            i++;
+        }
     }
     // describeKeypoints (:224-241): refresh the descriptors of the tracked keypoints in the raw image
     if (n) {
@@ -346,8 +355,8 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
             if (valid[(size_t) i]) {
                 Desc d;
                 __builtin_memcpy(d.b, &desc[(size_t) i * 32], 32);
-                cur->set_desc(kps[(size_t) i].id, d);
-                map_points.at(kps[(size_t) i].id)->add_desc(cur->kfid, d);
+                cur->set_desc(kp_ids[(size_t) i], d);
+                map_points.at(kp_ids[(size_t) i])->add_desc(cur->kfid, d);
             }
     }
     const int to_detect = cfg.max_keypoints - (int) cur->n_occupied;
@@ -388,6 +397,8 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
 void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of the current frame
     std::shared_ptr<FrameRec> kf = std::make_shared<FrameRec>(*cur);
     keyframes.emplace(next_kf_id, kf);
+    if (kf_flat_.size() <= (size_t) next_kf_id) kf_flat_.resize((size_t) next_kf_id + 32, nullptr);
+    kf_flat_[(size_t) next_kf_id] = kf.get();
     n_keyframes++;
     next_kf_id++;
 }
@@ -395,6 +406,8 @@ void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of 
 void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
     std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(next_mp_id, next_kf_id);
     map_points.emplace(next_mp_id, mp);
+    if (mp_flat_.size() <= (size_t) next_mp_id) mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
+    mp_flat_[(size_t) next_mp_id] = mp.get();
     next_mp_id++;
     n_map_points++;
 }
@@ -442,6 +455,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
         if (cur->change_id(prev_id, new_id, nw->is3d)) set_map_point_obs(new_id);
     }
     if (prev->is3d) n_map_points--;
+    mp_flat_[(size_t) prev_id] = nullptr;
     map_points.erase(pit);
     n_merges++;
 }
@@ -449,15 +463,15 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
 void Slam::remove_keyframe(int kfid) {  // map_manager.cpp:515-557
     auto it = keyframes.find(kfid);
     if (it == keyframes.end()) return;
-    for (const KeyPt &kp: it->second->keypoints()) {
-        auto m = map_points.find(kp.id);
-        if (m == map_points.end()) continue;
-        m->second->remove_obs(kfid);
+    for (const auto &e: it->second->kps) {  // the body edits map points only
+        MapPt *m = mp_raw(e.first);
+        if (m) m->remove_obs(kfid);
     }
     for (const auto &c: it->second->covisible) {
         auto co = keyframes.find(c.first);
         if (co != keyframes.end()) co->second->remove_covisible(kfid);
     }
+    kf_flat_[(size_t) kfid] = nullptr;
     keyframes.erase(it);
     n_keyframes--;
 }
@@ -476,6 +490,7 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     }
     if (mp->observed) cur->remove(id);
     if (mp->is3d) n_map_points--;
+    mp_flat_[(size_t) id] = nullptr;
     map_points.erase(it);
 }
 
@@ -499,9 +514,9 @@ void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-6
 
 void Slam::remove_obs_from_cur(int mp_id) {  // map_manager.cpp:649-679
     cur->remove(mp_id);
-    auto m = map_points.find(mp_id);
-    if (m == map_points.end()) return;
-    m->second->observed = false;
+    MapPt *m = mp_raw(mp_id);
+    if (!m) return;
+    m->observed = false;
 }
 
 bool Slam::set_map_point_obs(int mp_id) {  // map_manager.cpp:681-708
@@ -514,14 +529,16 @@ bool Slam::set_map_point_obs(int mp_id) {  // map_manager.cpp:681-708
 void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-164
     std::map<int, int> cov;
     std::unordered_set<int> local_ids;
-    for (const KeyPt &kp: frame.keypoints()) {
-        auto m = map_points.find(kp.id);
-        if (m == map_points.end()) {
-            remove_map_point_obs(kp.id, frame.kfid);
-            remove_obs_from_cur(kp.id);
+    ids_scratch_.clear();  // snapshot: the repair branch below edits frame.kps
+    for (const auto &e: frame.kps) ids_scratch_.push_back(e.first);
+    for (int id: ids_scratch_) {
+        MapPt *m = mp_raw(id);
+        if (!m) {
+            remove_map_point_obs(id, frame.kfid);
+            remove_obs_from_cur(id);
             continue;
         }
-        for (int kf: m->second->obs_kfs) {
+        for (int kf: m->obs_kfs) {
             if (kf != frame.kfid) {
                 auto c = cov.find(kf);
                 if (c != cov.end()) c->second += 1;
@@ -530,16 +547,33 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
         }
     }
     std::set<int> bad;
+    // marks: a = observed by `frame`, b = already in local_ids (see slam.hpp)
+    mark_a_.resize((size_t) next_mp_id + 1, 0);
+    mark_b_.resize((size_t) next_mp_id + 1, 0);
+    touched_a_.clear();
+    touched_b_.clear();
+    for (const auto &e: frame.kps) {
+        mark_a_[(size_t) e.first] = 1;
+        touched_a_.push_back(e.first);
+    }
     for (const auto &c: cov) {
-        auto kf = keyframes.find(c.first);
-        if (kf != keyframes.end()) {
-            kf->second->covisible[frame.kfid] = c.second;
-            for (const KeyPt &kp: kf->second->keypoints3d())
-                if (!frame.observes(kp.id)) local_ids.insert(kp.id);
+        FrameRec *kf = kf_raw(c.first);
+        if (kf) {
+            kf->covisible[frame.kfid] = c.second;
+            for (const auto &e: kf->kps) {  // getKeypoints3d(): container order, 3-D only
+                const size_t id = (size_t) e.first;
+                if (e.second.is3d && !mark_a_[id] && !mark_b_[id]) {
+                    mark_b_[id] = 1;
+                    touched_b_.push_back(e.first);
+                    local_ids.insert(e.first);
+                }
+            }
         } else {
             bad.insert(c.first);
         }
     }
+    for (int id: touched_a_) mark_a_[(size_t) id] = 0;
+    for (int id: touched_b_) mark_b_[(size_t) id] = 0;
     for (int kf: bad) cov.erase(kf);
     frame.covisible.swap(cov);
     if (local_ids.size() > 0.5 * frame.local_map.size()) frame.local_map.swap(local_ids);

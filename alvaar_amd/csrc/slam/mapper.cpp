@@ -64,7 +64,7 @@ void Slam::triangulate_temporal(FrameRec &frame) {  // mapper.cpp:144-291
     std::vector<int> group_kf;
     std::vector<size_t> cand_of_kp(kps.size(), (size_t) -1);
     for (size_t i = 0; i < kps.size(); i++) {
-        std::shared_ptr<MapPt> mp = map_point(kps[i].id);
+        MapPt *mp = mp_raw(kps[i].id);
         if (!mp) {
             remove_map_point_obs(kps[i].id, frame.kfid);
             continue;
@@ -162,16 +162,18 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     std::vector<int> kf_ids;
     for (const auto &e: keyframes) kf_ids.push_back(e.first);
     std::sort(kf_ids.begin(), kf_ids.end());
-    std::unordered_map<int, int> kf_index;
+    std::vector<int> kf_index((size_t) next_kf_id + 1, -1);
+    std::vector<const FrameRec *> kf_obj((size_t) next_kf_id + 1, nullptr);
     std::vector<double> kf_q, kf_t;
     for (size_t i = 0; i < kf_ids.size(); i++) {
-        kf_index[kf_ids[i]] = (int) i;
+        kf_index[(size_t) kf_ids[i]] = (int) i;
         const FrameRec &k = *keyframes.at(kf_ids[i]);
+        kf_obj[(size_t) kf_ids[i]] = &k;
         kf_q.insert(kf_q.end(), k.Tcw.q, k.Tcw.q + 4);
         kf_t.insert(kf_t.end(), k.Tcw.t, k.Tcw.t + 3);
     }
-    auto fit = kf_index.find(frame.kfid);
-    if (fit == kf_index.end()) return result;
+    if (frame.kfid < 0 || frame.kfid > next_kf_id || kf_index[(size_t) frame.kfid] < 0) return result;
+    const int frame_kf_index = kf_index[(size_t) frame.kfid];
     // map point table: the frame's keypoints first (grid order), then the local map in ITS iteration order
     std::vector<int> mp_ids;
     std::unordered_map<int, int> mp_index;
@@ -190,18 +192,25 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             // getSurroundingKeypoints keeps ids found in mapKeypoints_ (frame.cpp:333-337); a keypoint whose map point is gone is
             // repaired by the reference on contact (:459-463) -- repaired here up front
             if (!frame.find(id)) continue;
-            if (!map_point(id)) continue;
+            if (!mp_raw(id)) continue;
             cell_mp.push_back(intern(id));
         }
     }
     cell_ptr[frame.grid.size()] = (int) cell_mp.size();
     std::vector<int> local_idx;
+    mark_a_.resize((size_t) next_mp_id + 1, 0);
+    touched_a_.clear();
+    for (const auto &e: frame.kps) {
+        mark_a_[(size_t) e.first] = 1;
+        touched_a_.push_back(e.first);
+    }
     for (int id: local) {
-        if (frame.observes(id)) continue;                       // :397-400
-        std::shared_ptr<MapPt> mp = map_point(id);
+        if (id >= 0 && id <= next_mp_id ? mark_a_[(size_t) id] != 0 : frame.observes(id)) continue;   // frame.isObservingKeypoint (:397-400)
+        const MapPt *mp = mp_raw(id);
         if (!mp || !mp->is3d || !mp->has_desc) continue;         // :404-411
         local_idx.push_back(intern(id));
     }
+    for (int id: touched_a_) mark_a_[(size_t) id] = 0;
     if (local_idx.empty()) return result;
     const int n_mp = (int) mp_ids.size();
     std::vector<double> mp_wpt((size_t) n_mp * 3);
@@ -209,17 +218,16 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     std::vector<int> obs_ptr((size_t) n_mp + 1, 0), obs_kf;
     std::vector<float> obs_px;
     for (int m = 0; m < n_mp; m++) {
-        const MapPt &mp = *map_points.at(mp_ids[(size_t) m]);
+        const MapPt &mp = *mp_raw(mp_ids[(size_t) m]);
         std::memcpy(&mp_wpt[3 * (size_t) m], mp.X, 24);
         mp_is3d[(size_t) m] = mp.is3d;
         mp_has_desc[(size_t) m] = mp.has_desc;
         obs_ptr[(size_t) m] = (int) obs_kf.size();
         for (int kf: mp.obs_kfs) {
-            auto ki = kf_index.find(kf);
-            if (ki == kf_index.end()) continue;
-            const KeyPt *kk = keyframes.at(kf)->find(mp.id);
+            if (kf < 0 || kf > next_kf_id || kf_index[(size_t) kf] < 0) continue;
+            const KeyPt *kk = kf_obj[(size_t) kf]->find(mp.id);
             if (!kk) continue;
-            obs_kf.push_back(ki->second);
+            obs_kf.push_back(kf_index[(size_t) kf]);
             obs_px.push_back(kk->px[0]);
             obs_px.push_back(kk->px[1]);
             // one 32-byte slot per observation; keyframes in which the keypoint could not be described (within 31 px of the border,
@@ -239,7 +247,7 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     Lap lap;
     const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) frame.grid.size(), cell_ptr.data(), cell_mp.data(),
                                     (int) kf_ids.size(), kf_q.data(), kf_t.data(), n_mp, mp_wpt.data(), mp_is3d.data(), mp_has_desc.data(),
-                                    obs_ptr.data(), obs_kf.data(), obs_px.data(), obs_desc.data(), obs_has_desc.data(), fit->second,
+                                    obs_ptr.data(), obs_kf.data(), obs_px.data(), obs_desc.data(), obs_has_desc.data(), frame_kf_index,
                                     (int) frame.n_3d, (int) local_idx.size(), local_idx.data(), max_proj_err, dist_ratio, match_of_mp.data());
     lap(t_kf[9]);
     if (fail(rc)) return result;
@@ -257,7 +265,7 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
             const int kfid = it->first;
             if (kfid == 0) break;
             if (kfid >= kf->kfid) continue;
-            std::shared_ptr<FrameRec> co = keyframe(kfid);
+            FrameRec *co = kf_raw(kfid);
             if (!co) continue;  // the reference dereferences the null pointer here (:88-92); nothing to remove from
             if ((int) co->n_3d < cfg.ba_min_common_obs / 2) {
                 remove_keyframe(kfid);
@@ -265,10 +273,13 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                 continue;
             }
             size_t good = 0, total = 0;
-            for (const KeyPt &kp: co->keypoints3d()) {
-                std::shared_ptr<MapPt> mp = map_point(kp.id);
+            ids_scratch_.clear();  // keypoints whose map point is gone: the reference repairs them while walking a COPY (:101-111); the
+                                   // repair only drops that keypoint from this keyframe, so doing it after the walk is the same thing
+            for (const auto &e: co->kps) {
+                if (!e.second.is3d) continue;
+                MapPt *mp = mp_raw(e.first);
                 if (!mp) {
-                    remove_map_point_obs(kp.id, kfid);
+                    ids_scratch_.push_back(e.first);
                     continue;
                 } else if (mp->is_bad()) {
                     continue;
@@ -277,6 +288,7 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                 }
                 total++;
             }
+            for (int id: ids_scratch_) remove_map_point_obs(id, kfid);
             const float ratio = (float) good / (float) total;
             if (ratio > cfg.keyframe_filtering_ratio) {
                 remove_keyframe(kfid);
@@ -290,15 +302,19 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
 void Slam::local_ba(FrameRec &new_frame) {
     const int min_cov = cfg.ba_min_common_obs;
     if ((int) new_frame.n_3d < min_cov) return;
+    Lap lap_ba;
     // ---- 1. problem (optimizer.cpp:20-247)
     std::unordered_map<int, std::shared_ptr<MapPt>> local_mps;      // map_local_plms
     std::unordered_map<int, std::shared_ptr<FrameRec>> local_kfs;   // map_local_pkfs
-    std::unordered_map<int, int> pose_slot;                          // keyframe id -> row of the flat pose table
+    // keyframe id -> row of the flat pose table / keyframe object: ids are small consecutive integers, so plain arrays beside the
+    // reference's hash maps (which stay, because their iteration ORDER is behaviour, :234-247)
+    std::vector<int> pose_slot((size_t) next_kf_id + 1, -1);
+    std::vector<FrameRec *> kf_flat((size_t) next_kf_id + 1, nullptr);
     std::vector<double> poses;
     std::vector<uint8_t> kf_const;
     std::unordered_set<int> bad_mps, mps_to_opt, kfs_to_opt, const_kfs;
     auto add_pose = [&](int kfid, const FrameRec &kf, bool constant) {
-        pose_slot.emplace(kfid, (int) kf_const.size());
+        pose_slot[(size_t) kfid] = (int) kf_const.size();
         double p[7];
         se3_to_pose7(kf.Twc, p);
         poses.insert(poses.end(), p, p + 7);
@@ -306,6 +322,8 @@ void Slam::local_ba(FrameRec &new_frame) {
     };
     std::map<int, int> cov = new_frame.covisible;
     cov.emplace(new_frame.kfid, (int) new_frame.n_3d);
+    mark_a_.resize((size_t) next_mp_id + 1, 0);
+    touched_a_.clear();
     bool all_cst = false;
     const int max_kfid = cov.rbegin()->first;
     for (auto it = cov.rbegin(); it != cov.rend(); ++it) {
@@ -320,14 +338,21 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (score >= min_cov && !all_cst && kfid > 0) {
             add_pose(kfid, *kf, false);
             kfs_to_opt.insert(kfid);
-            for (const KeyPt &kp: kf->keypoints3d()) mps_to_opt.insert(kp.id);
+            for (const auto &e: kf->kps)
+                if (e.second.is3d && !mark_a_[(size_t) e.first]) {  // a repeated insert would not change the set
+                    mark_a_[(size_t) e.first] = 1;
+                    touched_a_.push_back(e.first);
+                    mps_to_opt.insert(e.first);
+                }
         } else {
             add_pose(kfid, *kf, true);
             const_kfs.insert(kfid);
             all_cst = true;
         }
         local_kfs.emplace(kfid, kf);
+        kf_flat[(size_t) kfid] = kf.get();
     }
+    for (int id: touched_a_) mark_a_[(size_t) id] = 0;
     struct ObsRec {
         int kfid, mpid;
     };
@@ -343,23 +368,22 @@ void Slam::local_ba(FrameRec &new_frame) {
             continue;
         }
         local_mps.emplace(lmid, mp);
-        int anchor = -1;
-        const std::set<int> obs = mp->obs_kfs;
+        int anchor = -1, cur_slot = -1;
+        std::vector<int> &obs = obs_scratch_;  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
+        obs.assign(mp->obs_kfs.begin(), mp->obs_kfs.end());
         for (int kfid: obs) {
             if (kfid > max_kfid) continue;
-            std::shared_ptr<FrameRec> kf;
-            auto lk = local_kfs.find(kfid);
-            if (lk == local_kfs.end()) {
-                kf = keyframe(kfid);
-                if (!kf) {
+            FrameRec *kf = kf_flat[(size_t) kfid];
+            if (!kf) {  // an observing keyframe outside the covisibility set joins as a constant one (:153-172)
+                std::shared_ptr<FrameRec> sp = keyframe(kfid);
+                if (!sp) {
                     remove_map_point_obs(kfid, mp->id);  // sic: arguments swapped in the reference (optimizer.cpp:162)
                     continue;
                 }
-                local_kfs.emplace(kfid, kf);
+                local_kfs.emplace(kfid, sp);
+                kf = kf_flat[(size_t) kfid] = sp.get();
                 add_pose(kfid, *kf, true);
                 const_kfs.insert(kfid);
-            } else {
-                kf = lk->second;
             }
             const KeyPt *kp = kf->find(lmid);
             if (!kp) {
@@ -370,16 +394,17 @@ void Slam::local_ba(FrameRec &new_frame) {
                 anchor = kfid;
                 double pc[3];
                 se3_apply(kf->Tcw, mp->X, pc);
-                pt_slot.emplace(lmid, (int) pt_ids.size());
+                cur_slot = (int) pt_ids.size();
+                pt_slot.emplace(lmid, cur_slot);
                 pt_ids.push_back(lmid);
-                pt_anchor_slot.push_back(pose_slot.at(kfid));
+                pt_anchor_slot.push_back(pose_slot[(size_t) kfid]);
                 pt_anchor_uv.push_back((double) kp->unpx[0]);
                 pt_anchor_uv.push_back((double) kp->unpx[1]);
                 pt_inv.push_back(1. / pc[2]);  // InvDepthParametersBlock(id, anchor, zanch) stores 1 / zanch
                 continue;
             }
-            obs_kf.push_back(pose_slot.at(kfid));
-            obs_pt.push_back(pt_slot.at(lmid));
+            obs_kf.push_back(pose_slot[(size_t) kfid]);
+            obs_pt.push_back(cur_slot);
             obs_uv.push_back((double) kp->unpx[0]);
             obs_uv.push_back((double) kp->unpx[1]);
             obs_rec.push_back(ObsRec{kfid, lmid});
@@ -389,11 +414,12 @@ void Slam::local_ba(FrameRec &new_frame) {
     size_t n_const = const_kfs.size();
     if (n_const < 2) {
         for (auto it = local_kfs.begin(); n_const < 2 && it != local_kfs.end(); ++it) {
-            kf_const[(size_t) pose_slot.at(it->first)] = 1;
+            kf_const[(size_t) pose_slot[(size_t) it->first]] = 1;
             const_kfs.insert(it->first);
             n_const++;  // sic: counted even when the keyframe was constant already
         }
     }
+    lap_ba(t_kf[11]);
     // ---- 2. solve (:251-262) and 3./4. outlier sweep + second solve without the flagged residuals (:266-359; the loss is never
     //         reset to L2 there because vright_reprojerr_kfid_lmid stays empty, :315-318)
     const int n_kf = (int) kf_const.size(), n_pt = (int) pt_ids.size();
@@ -459,6 +485,7 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (round == 0) any_bad = n_bad > 0;
         if (!(cfg.refine_with_l2 && any_bad)) break;
     }
+    lap_ba(t_kf[12]);
     // ---- 5. write-back (:363-530)
     for (const auto &b: bad_obs) {
         if (local_kfs.find(b.first) != local_kfs.end()) remove_map_point_obs(b.second, b.first);
@@ -468,8 +495,8 @@ void Slam::local_ba(FrameRec &new_frame) {
     for (const auto &e: local_kfs) {
         if (const_kfs.count(e.first)) continue;
         if (!e.second) continue;
-        auto ps = pose_slot.find(e.first);
-        if (ps != pose_slot.end()) e.second->set_Twc(se3_from_pose7(&poses[7 * (size_t) ps->second]));
+        const int ps = pose_slot[(size_t) e.first];
+        if (ps >= 0) e.second->set_Twc(se3_from_pose7(&poses[7 * (size_t) ps]));
     }
     for (const auto &e: local_mps) {
         const int lmid = e.first;
@@ -501,13 +528,13 @@ void Slam::local_ba(FrameRec &new_frame) {
             bad_mps.erase(lmid);
             continue;
         }
-        auto ak = local_kfs.find(mp->anchor_kf);
-        if (ak == local_kfs.end()) {
+        const FrameRec *akp = mp->anchor_kf >= 0 && (size_t) mp->anchor_kf < kf_flat.size() ? kf_flat[(size_t) mp->anchor_kf] : nullptr;
+        if (!akp) {  // the anchor keyframe is not part of the problem (:459-463)
             bad_mps.insert(lmid);
             continue;
         }
-        if (ak->second) {
-            const FrameRec &akf = *ak->second;
+        {
+            const FrameRec &akf = *akp;
             const KeyPt *kp = akf.find(lmid);
             const float ux = kp ? kp->unpx[0] : 0.f, uy = kp ? kp->unpx[1] : 0.f;  // a default Keypoint has unpx_ = (0, 0)
             const double uv[3] = {(double) ux, (double) uy, 1.};
@@ -518,10 +545,9 @@ void Slam::local_ba(FrameRec &new_frame) {
             (void) pc;
             se3_apply(akf.Twc, ray, wpt);
             update_map_point(lmid, wpt, inv);
-        } else {
-            bad_mps.insert(lmid);
         }
     }
+    lap_ba(t_kf[13]);
     for (int lmid: bad_mps) {  // :492-530
         std::shared_ptr<MapPt> mp;
         auto lm = local_mps.find(lmid);
@@ -533,6 +559,7 @@ void Slam::local_ba(FrameRec &new_frame) {
             if (mp->anchor_kf < new_frame.kfid - 3 && !mp->observed) remove_map_point(lmid);
         }
     }
+    lap_ba(t_kf[14]);
 }
 
 }  // namespace alva_slam

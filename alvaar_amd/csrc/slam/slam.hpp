@@ -167,6 +167,11 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
+    std::vector<int> ids_scratch_, obs_scratch_;
+    // flat "seen" marks over map point ids (ids are dense, handed out consecutively): inserting a key that is already in a hash set does
+    // not change the set, so duplicate inserts are filtered with a byte look-up instead of a hash look-up
+    std::vector<uint8_t> mark_a_, mark_b_;
+    std::vector<int> touched_a_, touched_b_;   // snapshots of id lists for loops whose bodies may edit the container they walk
     bool fail(int rc) { if (rc && !err_) err_ = rc; return rc != 0; }
 
     // VisualFrontend
@@ -197,6 +202,12 @@ private:
     void update_frame_covisibility(FrameRec &frame);
     std::shared_ptr<FrameRec> keyframe(int id) const;
     std::shared_ptr<MapPt> map_point(int id) const;
+    // The same look-ups through flat mirrors of the two hash maps: ids are handed out consecutively, so id -> object is an array
+    // access.  The hash maps stay authoritative (their iteration order is behaviour); every insert / erase / clear updates the mirror.
+    FrameRec *kf_raw(int id) const { return id >= 0 && (size_t) id < kf_flat_.size() ? kf_flat_[(size_t) id] : nullptr; }
+    MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
+    std::vector<FrameRec *> kf_flat_;
+    std::vector<MapPt *> mp_flat_;
 
     // Mapper
     void process_new_keyframe(int kfid);

@@ -1,32 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- hot-path throughput on MI355X, one JSON line (see the driver contract).
 
-A "step" is one pass of the per-frame hot path of BASELINE.json configs[1] ("640x480 stream, 2000 kp/frame, FAST+ORB+
-Hamming match+PnP full track") over one synthetic frame whose RGBA bytes are ALREADY resident in HBM:
-    RGBA -> gray -> LK pyramid (+Scharr)                                            (a2, a3; one fused chain of launches)
-    forward-backward KLT of the previous frame's keypoints, 3 pyramid levels        (a4)
-    FAST-pyramid + ORB detectAndCompute, nfeatures 2000, 8 levels (the north_star-named detector)   (a5', a6)
-    brute-force Hamming match of the new descriptors against the previous frame's  (a7)
-    P3P + LMedS (100 hypotheses) -> drop its outliers -> robust PnP refinement (5 LM iterations) on ~2000 3-D/2-D pairs,
-    chained as VisualFrontend::computePose chains them                                                    (a8, a9)
-The frame is issued by the native driver alva_frontend_track (C++ host loop in trackMono order): tracker + pose on one
-HIP stream, detector + matcher on a second one.  `value` = frames/s over all ranks (streams are independent: one per
-GPU, no collective on the data path).  The same frame issued call by call from Python ("python_host_two_streams") and
-on a single HIP stream ("one_hip_stream") is reported next to it.
-The same loop with the REFERENCE-ACTUAL detector (grid Shi-Tomasi, cell 12 => 2120 keypoints, + cornerSubPix + ORB
-description of those points; a5 + a6) is timed as well and reported as "ref_detector_variant".
-The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3000 pts, 5 LM iterations), is
-measured in the same run and reported under "local_ba".
+HEADLINE (`value`): frames/s of the reference's OWN dataflow through the drop-in surface -- System::findCameraPose
+(src/slam/src/system.cpp:106-175) = alva_system_find_camera_pose_device -- on a synthetic 640x480 stream with ~2000 keypoints per frame
+(cell size 12 => 2120 cells; BASELINE.json configs[1]), every frame ALREADY resident in HBM.  A "step" is ONE frame through the whole
+per-frame state machine, every stage consuming what the previous one produced:
+    RGBA -> gray -> LK pyramid (+Scharr)                                                        (a2, a3)
+    motion-model priors -> forward-backward KLT, two passes (1 level from the priors, 3 levels for the rest)      (a4; visual_frontend.cpp:103-243)
+    status compaction -> undistortion / bearings -> 3-D gather on the device                  (:275-298)
+    P3P-LMedS (100 hypotheses) -> drop its outliers -> robust PnP (5 LM iterations) on the tracker's OWN survivors (a8, a9; :245-417)
+    host bookkeeping of the frame (keypoint updates / removals, motion model, keyframe decision)
+and on the frames the reference's keyframe policy selects (about every 18th here): grid Shi-Tomasi detection + ORB description (a5, a6),
+triangulation, covisibility, guided Hamming matching to the local map + map-point merges (a7 / f1), local bundle adjustment with outlier
+sweep, write-back and culling (a10-a13).  The stream is the (2, 1) px / frame crop of a textured canvas, 200 frames, played forwards
+and backwards; warm-up covers the two-view initialisation.  `value` = frames/s over all ranks (one independent stream per GPU, no
+collective on the data path).  "system_surface" = the same loop fed from HOST memory (1.2 MB RGBA per frame over PCIe, through the
+caller-owned buffer exactly as src/system.js does).  "sustained" repeats the timed loop for at least 0.5 s.
 
-Secondary lines for a RIG of lock-step cameras on the one GPU (alva_track_batch_*: one launch per stage for all cameras, every camera
-bit-identical to its own single-camera call): "track_mono_batch" (pyramid -> KLT -> pose per camera) and "frame_step_batch" (the
-stage list above per camera, i.e. B times the headline's work) at 16 and 64 cameras, with the PMC-measured HBM traffic of the
-64-camera step; "batched_preprocess" (gray + pyramid of 64 cameras in five launches).  `value` stays the ONE-stream rate: configs[1]
-is one stream per GPU.  --multi-stream adds the older measurement with 4 / 16 host threads driving independent streams.
+"stage_list_driver" is round 1's headline, kept as a secondary line: the stage list of configs[1] (gray, pyramid, fb-KLT, cv::ORB
+detectAndCompute 2000, brute-force Hamming, P3P -> PnP) issued by alva_frontend_track_ahead on THREE HIP streams with FIXED pose
+correspondences -- every stage runs, but the tracker's output feeds nothing, so it is an upper bound of stage throughput, not the
+reference's dataflow.
+The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3000 pts, 5 LM iterations), is measured in the same
+run ("local_ba"), with its own roofline block ("roofline_ba").
 
-Also reported: "roofline" for the dominant kernel (HIP-event timed on the launch stream) and "cpu_baseline"
-(the compiled reference, oracle/_ref, timed on the host on a bounded sample of the same workload; falls back to
-the C restatement, kind "port", when the reference library is absent).
+Secondary lines for a RIG of lock-step cameras on the one GPU (alva_track_batch_*): "track_mono_batch", "frame_step_batch",
+"batched_preprocess"; "config_1280x720" = configs[2].  --multi-stream adds the older 4 / 16 host-thread measurement.
+
+Also reported: "roofline" for the dominant kernel of the headline loop (HIP-event timed on the launch stream) and "cpu_baseline": the
+compiled reference's System (oracle/_ref) on the same frames and configuration on one host core, and 8 independent reference Systems
+on 8 host threads (falls back to the stage-wise C restatement, kind "port", when the reference library is absent).
 """
 from __future__ import annotations
 
@@ -179,6 +182,50 @@ class FrameJob:
             torch.cuda.synchronize(self.dev)
             out[name] = e0.elapsed_time(e1) / reps * 1e3  # us
         return out
+
+
+
+STREAM_FRAMES = 200                  # frames of the synthetic stream resident in HBM (245 MB)
+SYSTEM_CELL = 12                     # 53 x 40 = 2120 cells => ~2000 keypoints per frame
+
+
+def stream_index(k: int) -> int:
+    """frame k of the endless stream: the 200-frame crop sequence forwards, then backwards, ..."""
+    period = 2 * (STREAM_FRAMES - 1)
+    r = k % period
+    return r if r < STREAM_FRAMES else period - r
+
+
+class SystemJob:
+    """The drop-in surface on one GPU: alva::System at cell 12 over a synthetic stream resident in HBM (and the same stream in host
+    memory for the PCIe-fed variant)."""
+
+    def __init__(self, device: int, seed: int, host_copy: bool = True):
+        from alvaar_amd import synth
+        from alvaar_amd.system import AlvaAR
+        self.dev = torch.device("cuda", device)
+        canvas = synth.texture_canvas(W, H, seed)
+        host = np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(STREAM_FRAMES)])
+        self.frames = torch.from_numpy(host).to(self.dev)
+        self.host_frames = host if host_copy else None
+        self.fixed = np.empty_like(host[0])          # the caller-owned frame buffer of the host-fed variant (src/system.js memImg)
+        self.ar = AlvaAR(W, H, device=device, cell_size=SYSTEM_CELL, random_sampling=False)
+        self.k = -1
+        self.status_hist = [0, 0, 0, 0]
+        self.ptrs = [int(self.frames[i].data_ptr()) for i in range(STREAM_FRAMES)]
+
+    def step(self):
+        self.k += 1
+        st = self.ar.find_camera_pose_device(self.ptrs[stream_index(self.k)], 33.0 * self.k)
+        self.status_hist[st] += 1
+        return st == 1
+
+    def step_host(self):
+        self.k += 1
+        np.copyto(self.fixed, self.host_frames[stream_index(self.k)])     # src/system.js:175 memImg.write(frame.data)
+        pose, st = self.ar.findCameraPose(self.fixed, 33.0 * self.k)
+        self.status_hist[st] += 1
+        return st == 1
 
 
 def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5):
@@ -379,49 +426,77 @@ def bench_two_view_init(ctx, reps: int = 10):
                      "on-device Levenberg-Marquardt refinement, one stream synchronisation")
 
 
-def cpu_baseline(seed: int, budget_s: float = 12.0):
-    """Reference CPU path (1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(seed: int, frames_1: int = 150, frames_8: int = 60):
+    """The reference itself on the host cores of this box, same stream, same configuration (cell 12), explicit timestamps, fixed-seed
+    sampling, Ceres' wall-clock caps frozen (they would silently skip work): System::findCameraPose frames/s on ONE core (the reference
+    is single-threaded: wasm, NO_THREADS Ceres) and with 8 independent reference Systems on 8 host threads (streams are independent, so
+    that is how the reference would use 8 cores).  Bounded sample: the first 150 frames of the stream (incl. initialisation and 7 keyframes)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracles
+    from alvaar_amd import synth
+    if not oracles.ref_available():
+        return cpu_baseline_port(seed)
+    import sysdiff
+    import threading
+    canvas = synth.texture_canvas(W, H, seed)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(max(frames_1, frames_8))]
+
+    def run(n, out, slot):
+        ref = sysdiff.RefSystem(W, H, SYSTEM_CELL)
+        t0 = time.perf_counter()
+        st = [ref.step(frames[k], 33.0 * k)[0] for k in range(n)]
+        out[slot] = (time.perf_counter() - t0, st, int(ref.state()[2]), len(ref.keyframe_ids()))
+        ref.close()
+    one = [None]
+    run(frames_1, one, 0)
+    dt1, st1, nkp, nkf = one[0]
+    res = [None] * 8
+    th = [threading.Thread(target=run, args=(frames_8, res, i)) for i in range(8)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt8 = time.perf_counter() - t0
+    pbba = synth.make_ba_problem(20, 3000, 42)
+    t1 = time.perf_counter()
+    r = oracles.Ref.local_ba(pbba, 5, 0.0)
+    dtb = time.perf_counter() - t1
+    return {"value": frames_1 / dt1, "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": f"the reference's System::findCameraPose (oracle/_ref) on the first {frames_1} frames of the same stream, cell {SYSTEM_CELL}: "
+                      f"{st1.count(3)} initialising, {st1.count(1)} tracked, {nkf} keyframes with local BA, {nkp} keypoints at the end; + 1 local-BA solve (20 KF x 3000 pts)",
+            "eight_threads": {"value": 8 * frames_8 / dt8, "unit": "frames/s", "cores": 8,
+                              "sample": f"8 independent reference Systems on 8 host threads, {frames_8} frames each (the reference is single-threaded; independent streams are its only parallelism)"},
+            "local_ba_residual_block_iters_per_s": len(pbba["obs_kf"]) * (int(r["info"][0]) - 1) / dtb,
+            "local_ba_ms": dtb * 1e3}
+
+
+def cpu_baseline_port(seed: int, budget_s: float = 12.0):
+    """Fallback when the compiled reference is absent: the stage-wise C restatement on a bounded sample of the stage list."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracles
     from scipy.spatial.transform import Rotation
     from alvaar_amd import synth
-    use_ref = oracles.ref_available()
-    O = oracles.Ref if use_ref else oracles.Orc
+    O = oracles.Orc
     frames = synth.stream_rgba(W, H, 4, seed=seed, noise=True)
     pts = make_keypoints(NKP, seed)
     pb = synth.make_pnp_problem(NKP, seed, outlier_frac=0.1, pose_noise=0.01)
     prev = O.rgba2gray(frames[0])
-    _, prev_desc = O.orb(prev, 2000)
     n, t0 = 0, time.perf_counter()
     while True:
         k = 1 + n % 3
         g = O.rgba2gray(frames[k])
-        tracked, st = O.fbklt(prev, g, pts, pts, 3)        # builds both pyramids internally (the reference reuses prev's)
-        kp, desc = O.orb(g, 2000)
-        O.bf_match(desc, prev_desc)
+        O.fbklt(prev, g, pts, pts, 3)
         ok, R, t, outl = O.p3p_lmeds(pb["bv"], pb["wpt"], fx=pb["K"][0], fy=pb["K"][1])
-        keep = np.setdiff1d(np.arange(NKP), outl)            # computePose: refine the P3P inliers only
+        keep = np.setdiff1d(np.arange(NKP), outl)
         q = Rotation.from_matrix(R).as_quat()
         O.pnp_refine(pb["uv"][keep], pb["wpt"][keep], np.concatenate([t, q]), pb["K"])
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 40:
             break
     dt = time.perf_counter() - t0
-    pbba = synth.make_ba_problem(20, 3000, 42)
-    t1 = time.perf_counter()
-    r = O.local_ba(pbba, 5, 0.0)
-    dtb = time.perf_counter() - t1
-    prp = synth.make_relpose_problem(2000, 8, 0.25)
-    t2 = time.perf_counter()
-    for _ in range(3):
-        oracles.compute_5pt(prp["bv1"], prp["bv2"], which="ref" if use_ref else "orc")
-    dt5 = (time.perf_counter() - t2) / 3
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "two_view_init_ms": dt5 * 1e3,
-            "sample": f"{n} frames of the same 640x480 / {NKP}-keypoint step (gray, 2 LK pyramids, fb-KLT 3 lvl, cv::ORB detectAndCompute 2000, "
-                      f"BF Hamming, P3P-LMedS 100 it, Ceres PnP) + 1 local-BA solve",
-            "local_ba_residual_block_iters_per_s": len(pbba["obs_kf"]) * (int(r["info"][0]) - 1) / dtb,
-            "local_ba_ms": dtb * 1e3}
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} tracking frames (gray, 2 LK pyramids, fb-KLT 3 levels, P3P-LMedS, PnP) through the C restatement; no keyframes"}
 
 
 def main():
@@ -447,6 +522,7 @@ def main():
     torch.cuda.set_device(local)
     dist = multi.init_process_group(shard, "nccl")   # "nccl" IS RCCL on ROCm; only used for the barrier + timing reduction
 
+    sysjob = SystemJob(local, seed=shard.stream_seed)
     job = FrameJob(local, seed=shard.stream_seed)
 
     def timed(fn, warmup, steps):
@@ -468,39 +544,60 @@ def main():
         torch.cuda.synchronize()
         return el
 
-    headline = job.step if args.serial else (job.step_overlapped if args.python_host else job.step_native)
-    dt = timed(headline, args.warmup, args.steps)
+    # ---- headline: the System surface, frames resident in HBM.  Warm-up must cover the two-view initialisation (frame 18 of this
+    # stream) so that the timed region is tracking + keyframes in their natural proportion; a shorter --warmup is topped up untimed.
+    extra = 0
+    while sysjob.status_hist[1] == 0 and extra < 60:
+        sysjob.step()
+        extra += 1
+    dt = timed(sysjob.step, args.warmup, args.steps)
+    hist_timed = list(sysjob.status_hist)
+    # the same loop for at least 0.5 s (a K-step region can be a few tens of milliseconds long)
+    long_steps = max(args.steps, int(0.6 * args.steps / max(dt, 1e-9)) + 1)
+    dt_long = timed(sysjob.step, 0, long_steps)
+    ar = sysjob.ar
+    ar.timing()
+    ar.timing_keyframe()
+    kf0 = int(ar.state()[11])
+    n_sec = 200
+    for _ in range(n_sec):
+        sysjob.step()
+    sections, kf_detail, n_kf_sec = ar.timing(), ar.timing_keyframe(), int(ar.state()[11]) - kf0
+    sys_state = ar.state()
+    sys_counters = ar.counters()
+    # PCIe-fed variant: host RGBA in, through the caller-owned buffer
+    dt_host = timed(sysjob.step_host, 5, args.steps)
+    # ---- round 1's headline as a secondary line (fixed correspondences, three HIP streams)
+    headline = job.step_native
+    dt_drv = timed(headline, min(args.warmup, 10), args.steps)
     dt_nola = timed(lambda: job.step_native(lookahead=False), 3, args.steps)
-    dt_py = timed(job.step_overlapped, 3, args.steps)
-    # secondary: every stage back-to-back on ONE HIP stream, and the same with the reference-actual detector
     dt_serial = timed(job.step, 3, args.steps)
-    dt_grid = timed(lambda: job.step(grid_detector=True), 3, args.steps)
     if rank == 0:
         fps = world * args.steps / dt
         stage_us = job.stage_times()
         ba, _ = bench_ba(job.ctx)
         P = W * H
-        # ---- roofline: per-KERNEL durations from HIP events recorded on each launch stream, over a second pass of the
-        # same timed loop (the events cost a few us per launch, so they stay out of the pass that gives `value`)
+        # ---- roofline: per-KERNEL durations from HIP events recorded on each launch stream, over a further pass of the headline loop
+        # (the events cost a few us per launch, so they stay out of the pass that gives `value`)
         from alvaar_amd import capi
-        PROF_STEPS = min(args.steps, 100)
-        kt = capi.kernel_times(headline, PROF_STEPS)
-        # ALGORITHMIC bytes per launch (SURVEY.md §8d per-unit figures x the units one launch processes; DESIGN.md §5)
-        L8 = 3.27 * P          # pixels of the 8-level ORB pyramid
+        PROF_STEPS = min(max(args.steps, 40), 100)
+        kt = capi.kernel_times(sysjob.step, PROF_STEPS)
+        nkp = int(sys_state[2])
+        n3d = int(sys_state[4])
+        # ALGORITHMIC bytes per launch (SURVEY.md §8d per-unit figures x the units one launch processes; DESIGN.md §3)
         alg = {
             "k_level0<true>": 4 * P + 2 * P,                        # RGBA in; gray copy + padded level 0 out
             "k_pyr_stage": (P + 4 * P + P / 4) * (1 + 1 / 4 + 1 / 16 + 1 / 64) / 4,   # per launch (4 launches): level in, Scharr out, next level out
-            "k_klt": 2 * 6.64 * P + 24 * NKP,                       # both LK pyramids (gray + int16 Ix,Iy) once + points
-            "k_copy_level0": 2 * P,
-            "k_resize": (L8 - P) * (1 + 1.44) / 7,                  # per launch (7 launches): level l-1 in, level l out
-            "k_fast_nms": L8 + 12 * 6000,                           # every level once; candidate records out
-            "k_blur7_batch": 2 * L8,
-            "k_bf_partial": 32 * 2 * 2000 + 8 * 2000 * 32,
+            # fb-KLT: per launch the levels it walks of BOTH pyramids once (gray u8 + Ix,Iy i16 = 5 B/px per level) + 24 B per point;
+            # two launches per frame: the 3-D keypoints on level 0 only, the rest on levels 0-3 -- the larger one is quoted
+            "k_klt_dn": 2 * 5 * P + 24 * n3d,
+            "k_track_prepare": 33 * nkp + 16 * nkp,                 # slot table in (px, flag, world point), lists out
+            "k_track_finish": 9 * nkp + 41 * nkp + 64 * n3d,        # tracker results in; per-slot results + correspondences out
         }
         per_frame = {k: v[0] / PROF_STEPS * v[1] for k, v in kt.items()}
-        kernels = {k: {"launches_per_frame": round(v[0] / PROF_STEPS, 2), "avg_us": round(v[1], 2),
+        kernels = {k: {"launches_per_frame": round(v[0] / PROF_STEPS, 3), "avg_us": round(v[1], 2),
                        **({"alg_bytes": int(alg[k]), "GBps": round(alg[k] / (v[1] * 1e-6) / 1e9, 1)} if k in alg else {})}
-                   for k, v in sorted(kt.items(), key=lambda kv: -per_frame[kv[0]])}
+                   for k, v in sorted(kt.items(), key=lambda kv: -per_frame[kv[0]])[:24]}
         dom = max(per_frame, key=per_frame.get)
         hbm_dom = max((k for k in per_frame if k in alg), key=per_frame.get)
         achieved = alg[hbm_dom] / (kt[hbm_dom][1] * 1e-6) / 1e9
@@ -510,27 +607,34 @@ def main():
             tj = json.loads(tfile.read_text()).get("kernels", {})
             if hbm_dom in tj:
                 traffic = tj[hbm_dom].get("hbm_bytes_per_launch")
+        us = lambda d, n: {a: round(1e6 * b / max(n, 1), 1) for a, b in d.items()}
         out = {
             "metric": "frames/sec @640x480 2000kp; local-BA residuals/sec (20KFx3k pts)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 image stages, f32 KLT, f64 pose+BA", "data": "synthetic",
-            "config": {"workload": "configs[1]: 640x480 RGBA stream, ORB 2000 kp/frame, FAST+ORB+Hamming match+KLT+PnP full track",
-                       "stages": ["rgba2gray", "lk_pyramid+scharr", "fbklt(3 levels, 2120 pts)", "orb_detect_and_compute(2000, 1.2, 8)",
-                                  "bf_hamming ~2000x2000", "compute_pose = p3p_lmeds(100 it, 2120 pts) -> pnp_refine(5 it, inliers)"],
-                       "host": "alva_frontend_track_ahead (C++; the next resident frame's gray + pyramid are built on a third HIP stream)" if not (args.serial or args.python_host) else "python ctypes",
-                       "not_in_timed_region": [],
+            "config": {"workload": "configs[1]: 640x480 RGBA stream, ~2000 keypoints per frame (cell 12), the reference's System::findCameraPose dataflow "
+                                   "(two-pass fb-KLT from motion-model priors -> P3P-LMedS -> PnP on the tracker's survivors; keyframes: grid detector + ORB "
+                                   "description, triangulation, guided Hamming matching to the local map, local BA) through alva_system_find_camera_pose_device",
+                       "frames_resident_in_hbm": True, "stream": f"{STREAM_FRAMES} frames, (2, 1) px per frame, forwards / backwards",
+                       "keypoints_per_frame": nkp, "keypoints_3d": n3d, "keyframes_in_map": int(sys_state[6]), "map_points": int(sys_state[7]),
+                       "status_histogram_reset_init_tracked": {"1_tracked": hist_timed[1], "2_reset": hist_timed[2], "3_initialising": hist_timed[3]},
+                       "untimed_frames_before_warmup": extra,
                        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
-                       "parallelism": f"{world} independent camera streams, one per GPU, no collective; within a frame the detector "
-                                      "(ORB + match) and the tracker (fb-KLT + pose) run on two HIP streams" + (" [disabled: --serial]" if args.serial else "")},
-            "no_lookahead": {"frames_per_s": world * args.steps / dt_nola, "ms_per_step": dt_nola / args.steps * 1e3,
-                             "stages": "alva_frontend_track: same work, the frame's own gray + pyramid built at the head of its tracker chain"},
-            "python_host_two_streams": {"frames_per_s": world * args.steps / dt_py, "ms_per_step": dt_py / args.steps * 1e3,
-                                        "stages": "same work and overlap, stage calls issued from Python (ctypes) instead of alva_frontend_track"},
-            "one_hip_stream": {"frames_per_s": world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3,
-                               "stages": "same work, every stage back-to-back on one HIP stream"},
-            "ref_detector_variant": {"frames_per_s": world * args.steps / dt_grid, "ms_per_step": dt_grid / args.steps * 1e3,
-                                     "stages": "same loop with detect_grid(cell 12 => 2120 kp)+cornerSubPix+describe instead of ORB"},
+                       "parallelism": f"{world} independent camera streams, one per GPU, no collective"},
+            "sustained": {"frames_per_s": world * long_steps / dt_long, "steps": long_steps, "seconds": dt_long,
+                          "note": "the same timed loop continued for at least 0.5 s"},
+            "system_surface": {"frames_per_s": world * args.steps / dt_host, "ms_per_step": dt_host / args.steps * 1e3,
+                               "note": "the same loop fed from HOST memory: frame copied into the caller-owned buffer (src/system.js:175), 1.2 MB over PCIe per "
+                                       "frame from that buffer (page-locked by the library on its second use), pose out"},
+            "frame_sections_us": {"per_frame": us(sections, n_sec), "frames": n_sec, "keyframes": n_kf_sec,
+                                  "per_keyframe_detail": us(kf_detail, n_kf_sec), "local_ba_solves_total": sys_counters["ba_solves"],
+                                  "note": "host wall-clock per section of the frame loop (alva_system_debug_timing); keyframe sections averaged over ALL frames in per_frame"},
+            "stage_list_driver": {"frames_per_s": world * args.steps / dt_drv, "ms_per_step": dt_drv / args.steps * 1e3,
+                                  "no_lookahead_frames_per_s": world * args.steps / dt_nola, "one_hip_stream_frames_per_s": world * args.steps / dt_serial,
+                                  "note": "round 1's headline: the configs[1] stage list (gray, pyramid, fb-KLT 3 levels, cv::ORB detectAndCompute 2000, BF Hamming, "
+                                          "P3P -> PnP) through alva_frontend_track_ahead on three HIP streams with FIXED pose correspondences; an upper bound of "
+                                          "stage throughput, not the reference's dataflow"},
             "local_ba": ba,
             "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
             "batched_preprocess": bench_batched_preprocess(local) if world == 1 else None,
@@ -542,9 +646,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_us": kt[hbm_dom][1], "alg_bytes_per_launch": int(alg[hbm_dom]),
                          "largest_kernel_by_time": dom,
-                         "note": "avg_us = HIP events around every launch of that kernel, on its launch stream, over a second pass of "
-                                 "the timed loop; every kernel here is latency-bound at ONE 640x480 frame (1.2 MB): the frame moves "
-                                 "through HBM in well under a microsecond, see DESIGN.md §5; rocprofv3 summary in profiles/"},
+                         "note": "avg_us = HIP events around every launch of that kernel, on its launch stream, over a further pass of the "
+                                 "headline loop; every kernel here is latency-bound at ONE 640x480 frame (1.2 MB): the frame moves through HBM "
+                                 "in well under a microsecond, see DESIGN.md §3; rocprofv3 summary in profiles/"},
             "kernels": kernels,
         }
         if args.streams_per_gpu > 1:
@@ -553,7 +657,7 @@ def main():
             # secondary: several independent cameras on the one GPU (native host threads); shows the head-room a single stream leaves
             out["multi_stream"] = [bench_multi_stream(local, s_, 60) for s_ in (4, 16)]
         if not args.no_cpu_baseline and world == 1:   # the contract: reference CPU path timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(7)
+            out["cpu_baseline"] = cpu_baseline(shard.stream_seed)
         print(json.dumps(out))
     if dist:
         td.barrier()

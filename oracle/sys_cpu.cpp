@@ -275,6 +275,15 @@ int syscpu_covisibility(void *p, int kfid, int cap, int *pairs) { return inspect
 int syscpu_map_points(void *p, int cap, int *ids, double *xyz, int *flags, double *invDepth, uint8_t *desc) {
     return inspect_map_points(*static_cast<CpuSys *>(p)->slam, cap, ids, xyz, flags, invDepth, desc);
 }
+void syscpu_timing(void *p, double *sections8, double *keyframe16, int reset) {
+    Slam &s = *static_cast<CpuSys *>(p)->slam;
+    if (sections8) std::memcpy(sections8, s.t_section, sizeof(s.t_section));
+    if (keyframe16) std::memcpy(keyframe16, s.t_kf, sizeof(s.t_kf));
+    if (reset) {
+        std::memset(s.t_section, 0, sizeof(s.t_section));
+        std::memset(s.t_kf, 0, sizeof(s.t_kf));
+    }
+}
 void syscpu_counters(void *p, long *out) {
     Slam &s = *static_cast<CpuSys *>(p)->slam;
     out[0] = s.n_ba_runs; out[1] = s.n_merges; out[2] = s.n_kf_culled;
