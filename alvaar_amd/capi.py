@@ -95,6 +95,7 @@ _sig("alva_track_batch_detections", [_vp, _i] + [C.POINTER(_vp)] * 4)
 _sig("alva_orb_detect_and_compute_batch", [_vp, _vp, _i, _vp, _sz, _vp, _vp, _i])
 _sig("alva_orb_collect_batch", [_vp, _vp, _i, _vp])
 _sig("alva_orb_device_count", [_vp], _vp)
+_sig("alva_orb_ambiguous_rotations", [_vp, _i])
 _sig("alva_bf_match_hamming_batch", [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i])
 _sig("alva_track_batch_set_klt_lanes", [_vp, _i])
 _sig("alva_compute_pose_enqueue", [_vp, _vp, _vp, _vp, _i, _i, _f, _i, C.c_uint32, _i, _f, _f, _f, _f, _f])

@@ -18,6 +18,7 @@
 // per stage (blockIdx.y = level) so that a 640x480 frame (3.3 k tiles) fills the 256 CUs; candidates are appended per tile
 // with one atomic, every cull is a threshold (order-free), and the survivors are put in row-major order at the very end.
 #include "common.hpp"
+#include "exact_sincos.hpp"
 #include <cmath>
 
 int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h,
@@ -736,6 +737,9 @@ __global__ void __launch_bounds__(256) k_angle_emit_b(const OrbItem *__restrict_
     for (int bx = blockIdx.x; bx == 0 || bx * 4 < n3; bx += gridDim.x) angle_emit_body(it.D, it.kp, it.cap, it.total, bx);
 }
 
+// keypoints whose rotation could not be PROVEN to round like the host library's (see exact_sincos.hpp); expected to stay 0
+__device__ int g_orb_ambiguous = 0;
+
 __constant__ int8_t c_pattern_orb[1024] = {
 #include "orb_pattern.inc"
 };
@@ -753,7 +757,11 @@ __device__ __forceinline__ void brief_orb_body(const OrbDev &D, const float *__r
     const int cx = __float2int_rn(rec[0] * inv), cy = __float2int_rn(rec[1] * inv);
     float angle = rec[3];
     angle *= (float) (3.1415926535897932384626433832795 / 180.f);
-    const float a = (float) cos((double) angle), b = (float) sin((double) angle);
+    // (float) cos((double) angle), (float) sin((double) angle) of the host's C library, decided from a double-double evaluation (exact_sincos.hpp)
+    float a, b;
+    int amb = 0;
+    alva_dd::sincos_float(angle, &a, &b, &amb);
+    if (amb && byte == 0) atomicAdd(&g_orb_ambiguous, 1);
     const uint8_t *center = D.pool + L.blur + (size_t) cy * L.pitch + cx;
     const int8_t *pat = c_pattern_orb + byte * 32;
     unsigned val = 0;
@@ -982,6 +990,16 @@ extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
 
 // device-resident total of the last detect_and_compute (internal: lets the driver chain the matcher without a host round trip)
 extern "C" const int *alva_orb_device_count(const alva_orb *orb) { return orb ? orb->d_total : nullptr; }
+
+extern "C" int alva_orb_ambiguous_rotations(int *h_count, int reset) {
+    ALVA_ARG(h_count);
+    ALVA_HIP(hipMemcpyFromSymbol(h_count, HIP_SYMBOL(g_orb_ambiguous), sizeof(int)));
+    if (reset) {
+        const int zero = 0;
+        ALVA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_orb_ambiguous), &zero, sizeof(int)));
+    }
+    return ALVA_OK;
+}
 
 extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const uint8_t *d_gray, size_t gray_pitch, float *d_kp,
                                            uint8_t *d_desc, int cap, int *h_count) {

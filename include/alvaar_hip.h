@@ -157,6 +157,10 @@ int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
 int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, const uint8_t *const *d_gray,
                                       size_t gray_pitch, float *const *d_kp, uint8_t *const *d_desc, int cap);
 int alva_orb_collect_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, int *h_counts);
+/* Number of keypoints (since the last reset) whose rBRIEF rotation (float) cos / sin could not be PROVEN to round like the host C
+ * library's (features2d/src/orb.cpp:230-232): the kernel decides the two floats from a ~100-bit evaluation and only a true value
+ * within 2^-50 of a float rounding boundary is left unproven (probability ~3e-8 per keypoint).  Synchronous. */
+int alva_orb_ambiguous_rotations(int *h_count, int reset);
 /* device-resident keypoint count of the detector's last run (what alva_orb_collect copies to the host) */
 const int *alva_orb_device_count(const alva_orb *orb);
 

@@ -63,7 +63,7 @@ def test_pyramid_from_rgba_fused(ctx):
         assert np.array_equal(hg, og[l]) and np.array_equal(hd, od[l])
 
 
-@pytest.mark.parametrize("nq,nt,seed", [(1, 1, 0), (17, 33, 1), (300, 257, 2), (2120, 2120, 3), (64, 0, 4)])
+@pytest.mark.parametrize("nq,nt,seed", [(1, 1, 0), (17, 33, 1), (300, 257, 2), (2120, 2120, 3), (64, 0, 4), (4000, 4000, 5), (4080, 4100, 6)])   # 4000 x 4000 = BASELINE configs[2]
 def test_bf_match_bit_exact(ctx, nq, nt, seed):
     import torch
     rng = np.random.RandomState(seed)

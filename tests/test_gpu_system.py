@@ -178,3 +178,31 @@ def test_configure_failure_leaves_the_object_unconfigured():
     from alvaar_amd.capi import AlvaError
     with pytest.raises(AlvaError):
         AlvaAR(30, 20)
+
+
+def test_cpp_program_through_the_int_offset_methods(tmp_path):
+    """A C++ program that LINKS libalvaar_hip.so and calls alva::System through the reference's own signatures -- every buffer a 32-bit
+    heap offset passed as int (system.hpp:30-36), buffers from mmap(MAP_32BIT): same statuses and poses as the Python caller."""
+    import subprocess
+    from pathlib import Path
+    from alvaar_amd.system import AlvaAR
+    root = Path(__file__).resolve().parent.parent
+    w, h, n = 640, 480, 40
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(n)])
+    (tmp_path / "frames.bin").write_bytes(frames.tobytes())
+    exe = tmp_path / "system_int_offsets"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", f"-I{root / 'include'}", "-o", str(exe), str(root / "tests" / "cpp" / "system_int_offsets.cpp"),
+                           f"-L{root / 'alvaar_amd'}", "-lalvaar_hip", f"-Wl,-rpath,{root / 'alvaar_amd'}"])
+    out = subprocess.check_output([str(exe), str(w), str(h), str(tmp_path / "frames.bin"), str(n)], text=True).strip().splitlines()
+    assert len(out) == n + 1 and out[-1].startswith("plane ")
+    statuses = [int(l.split()[1]) for l in out[:n]]
+    k0 = statuses.index(1)
+    assert statuses[:k0] == [3] * k0 and set(statuses[k0:]) == {1} and 15 <= k0 <= 25
+    # the clock-seeded default configuration is not bit-reproducible between runs; the discrete behaviour and the geometry are
+    poses = np.array([[float(v) for v in l.split()[3:]] for l in out[:n]])
+    assert np.all(poses[:, 15] == 1.0) and np.all(poses[:, [3, 7, 11]] == 0.0)
+    assert abs(np.linalg.norm(poses[k0, 12:15]) - 1.0) < 1e-6          # unit baseline at initialisation
+    d = np.array([2.0, 1.0, 0.0]) / np.sqrt(5.0)
+    assert np.abs(poses[k0, 12:15] - d).max() < 0.03
+    assert int(out[-1].split()[1]) in (0, 1) and int(out[-1].split()[3]) == 1
