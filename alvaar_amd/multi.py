@@ -70,59 +70,74 @@ def aggregate_rate(units_per_rank: int, seconds_local: float, device: torch.devi
     return world * units_per_rank / max_over_ranks(seconds_local, device)
 
 
-def pack_records(stream_id: int, ids: np.ndarray, xyz: np.ndarray, desc: np.ndarray, capacity: int) -> torch.Tensor:
-    """fixed-capacity byte tensor [capacity, RECORD_BYTES]; unused rows have point id -1"""
+_REC = np.dtype([("stream", "<i4"), ("id", "<i4"), ("xyz", "<f8", 3), ("desc", "u1", 32)])
+
+
+def exchange_device() -> torch.device:
+    """where the map records live for the exchange: the rank's GPU whenever there is one (RCCL moves device memory; a host tensor
+    is an error on the "nccl" backend), the CPU only in GPU-less (gloo) tests"""
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def pack_records(stream_id: int, ids: np.ndarray, xyz: np.ndarray, desc: np.ndarray, capacity: int, device: torch.device | None = None) -> torch.Tensor:
+    """fixed-capacity byte tensor [capacity, RECORD_BYTES] on `device` (default: exchange_device()); unused rows have point id -1"""
     n = len(ids)
     assert n <= capacity and xyz.shape == (n, 3) and desc.shape == (n, 32)
     buf = np.zeros((capacity, RECORD_BYTES), np.uint8)
-    rec = buf.view(np.dtype([("stream", "<i4"), ("id", "<i4"), ("xyz", "<f8", 3), ("desc", "u1", 32)]))[:, 0]
+    rec = buf.view(_REC)[:, 0]
     rec["id"] = -1
     rec["stream"][:n] = stream_id
     rec["id"][:n] = ids
     rec["xyz"][:n] = xyz
     rec["desc"][:n] = desc
-    return torch.from_numpy(buf)
+    return torch.from_numpy(buf).to(device if device is not None else exchange_device())
 
 
 def unpack_records(buf: torch.Tensor):
     a = buf.cpu().numpy().reshape(-1, RECORD_BYTES)
-    rec = a.view(np.dtype([("stream", "<i4"), ("id", "<i4"), ("xyz", "<f8", 3), ("desc", "u1", 32)]))[:, 0]
+    rec = a.view(_REC)[:, 0]
     rec = rec[rec["id"] >= 0]
     return rec["stream"].copy(), rec["id"].copy(), rec["xyz"].copy(), rec["desc"].copy()
 
 
 def all_gather_map(records: torch.Tensor) -> torch.Tensor:
-    """one all_gather of every rank's fixed-size record block -> [world * capacity, RECORD_BYTES] on every rank"""
+    """ONE collective: every rank's fixed-size record block -> [world * capacity, RECORD_BYTES] on every rank, in rank order.  On the
+    "nccl" backend (RCCL over xGMI) the block must be device memory: a host tensor is moved to the rank's GPU first."""
     if not (dist.is_available() and dist.is_initialized()):
         return records
-    out = [torch.empty_like(records) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, records)
-    return torch.cat(out, 0)
+    if dist.get_backend() == "nccl" and not records.is_cuda:
+        records = records.to(exchange_device())
+    records = records.contiguous()
+    out = torch.empty((dist.get_world_size() * records.shape[0], records.shape[1]), dtype=records.dtype, device=records.device)
+    dist.all_gather_into_tensor(out, records)
+    return out
 
 
-def _popcount_rows(x: np.ndarray) -> np.ndarray:
-    return np.unpackbits(x, axis=-1).sum(-1)
-
-
-def fuse_duplicates(stream, ids, xyz, desc, max_dist_m: float = 0.05, max_hamming: int = 51):
-    """Deterministic fuse: a point is absorbed by an EARLIER record (lower (stream, id)) of another stream when it lies
-    within max_dist_m and its descriptor is within max_hamming bits (0.2 * 256, state.hpp:60 mapMaxDescriptorDistance_).
-    Returns (keep mask, absorbed_by index or -1)."""
-    order = np.lexsort((ids, stream))
-    keep = np.ones(len(ids), bool)
-    absorbed = -np.ones(len(ids), np.int64)
-    for pos, i in enumerate(order):
-        prev = order[:pos]
-        prev = prev[keep[prev] & (stream[prev] != stream[i])]
-        if len(prev) == 0:
-            continue
-        d = np.linalg.norm(xyz[prev] - xyz[i], axis=1)
-        cand = prev[d <= max_dist_m]
-        if len(cand) == 0:
-            continue
-        ham = _popcount_rows(desc[cand] ^ desc[i])
-        j = int(np.argmin(ham))  # first minimum = earliest record
-        if ham[j] <= max_hamming:
-            keep[i] = False
-            absorbed[i] = cand[j]
-    return keep, absorbed
+def fuse_duplicates(records: torch.Tensor, ctx, max_dist_m: float = 0.05, max_hamming: int = 51):
+    """Fuse the gathered records ON THE GPU (alva_fuse_map_points): a point is absorbed by the earliest surviving record of another stream
+    within max_dist_m whose descriptor is within max_hamming bits (0.2 * 256, state.hpp:60 mapMaxDescriptorDistance_).
+    records: [N, RECORD_BYTES] uint8 CUDA tensor (all_gather_map's output).  Returns (stream, id, keep mask, absorbed_by) as CUDA tensors
+    over the valid records in (stream, id) order -- absorbed_by indexes that order."""
+    import ctypes as C
+    from .capi import lib, check
+    if not records.is_cuda:
+        raise RuntimeError("fuse_duplicates runs on the GPU: pass the device tensor all_gather_map returns (there is no CPU path)")
+    rec = records.reshape(-1, RECORD_BYTES)
+    ids_all = rec[:, 4:8].contiguous().view(torch.int32).reshape(-1)
+    rec = rec[ids_all >= 0]
+    stream = rec[:, 0:4].contiguous().view(torch.int32).reshape(-1)
+    ids = rec[:, 4:8].contiguous().view(torch.int32).reshape(-1)
+    order = torch.argsort(stream.to(torch.int64) * (1 << 32) + ids.to(torch.int64), stable=True)
+    rec = rec[order]
+    stream, ids = stream[order].contiguous(), ids[order].contiguous()
+    xyz = rec[:, 8:32].contiguous().view(torch.float64).reshape(-1, 3).contiguous()
+    desc = rec[:, 32:64].contiguous()
+    n = int(stream.shape[0])
+    keep = torch.empty(n, dtype=torch.uint8, device=rec.device)
+    absorbed = torch.empty(n, dtype=torch.int32, device=rec.device)
+    rounds = C.c_int(0)
+    lib.alva_fuse_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    torch.cuda.current_stream(rec.device).synchronize()
+    check(lib.alva_fuse_map_points(ctx.h, n, stream.data_ptr(), xyz.data_ptr(), desc.data_ptr(), float(max_dist_m), int(max_hamming),
+                                   keep.data_ptr(), absorbed.data_ptr(), C.byref(rounds)))
+    return stream, ids, keep.bool(), absorbed

@@ -198,18 +198,20 @@ def stream_index(k: int) -> int:
 
 class SystemJob:
     """The drop-in surface on one GPU: alva::System at cell 12 over a synthetic stream resident in HBM (and the same stream in host
-    memory for the PCIe-fed variant)."""
+    memory for the PCIe-fed variant).  width / height / cell default to configs[1]; --config 720p-streams runs configs[4]'s geometry
+    (1280x720, cell 15 => 4080 cells) instead."""
 
-    def __init__(self, device: int, seed: int, host_copy: bool = True):
+    def __init__(self, device: int, seed: int, host_copy: bool = True, width: int = W, height: int = H, cell: int | None = None):
         from alvaar_amd import synth
         from alvaar_amd.system import AlvaAR
         self.dev = torch.device("cuda", device)
-        canvas = synth.texture_canvas(W, H, seed)
-        host = np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(STREAM_FRAMES)])
+        cell = SYSTEM_CELL if cell is None else cell
+        canvas = synth.texture_canvas(width, height, seed)
+        host = np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, width, height, noise_seed=11)) for k in range(STREAM_FRAMES)])
         self.frames = torch.from_numpy(host).to(self.dev)
         self.host_frames = host if host_copy else None
         self.fixed = np.empty_like(host[0])          # the caller-owned frame buffer of the host-fed variant (src/system.js memImg)
-        self.ar = AlvaAR(W, H, device=device, cell_size=SYSTEM_CELL, random_sampling=False)
+        self.ar = AlvaAR(width, height, device=device, cell_size=cell, random_sampling=False)
         self.k = -1
         self.status_hist = [0, 0, 0, 0]
         self.ptrs = [int(self.frames[i].data_ptr()) for i in range(STREAM_FRAMES)]
@@ -505,6 +507,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["640x480", "720p-streams"], default="640x480",
+                    help="640x480 = BASELINE configs[1] (the metric's configuration, default); 720p-streams = configs[4]: one independent "
+                         "1280x720 stream (cell 15 => 4080 cells) per GPU, what an 8-GPU run of that config executes on every rank")
     ap.add_argument("--multi-stream", action="store_true",
                     help="also run the superseded 4- and 16-host-thread measurement (independent alva_frontend objects); off by default: its "
                          "concurrent launches of the same kernels would inflate their averages in a rocprofv3 profile of this command")
@@ -522,7 +527,10 @@ def main():
     torch.cuda.set_device(local)
     dist = multi.init_process_group(shard, "nccl")   # "nccl" IS RCCL on ROCm; only used for the barrier + timing reduction
 
-    sysjob = SystemJob(local, seed=shard.stream_seed)
+    if args.config == "720p-streams":
+        sysjob = SystemJob(local, seed=shard.stream_seed, width=1280, height=720, cell=15)
+    else:
+        sysjob = SystemJob(local, seed=shard.stream_seed)
     job = FrameJob(local, seed=shard.stream_seed)
 
     def timed(fn, warmup, steps):
@@ -613,7 +621,8 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 image stages, f32 KLT, f64 pose+BA", "data": "synthetic",
-            "config": {"workload": "configs[1]: 640x480 RGBA stream, ~2000 keypoints per frame (cell 12), the reference's System::findCameraPose dataflow "
+            "config": {"workload": ("configs[4]: 1280x720 RGBA stream per GPU, ~4000 keypoints per frame (cell 15), " if args.config == "720p-streams" else
+                                    "configs[1]: 640x480 RGBA stream, ~2000 keypoints per frame (cell 12), ") + "the reference's System::findCameraPose dataflow "
                                    "(two-pass fb-KLT from motion-model priors -> P3P-LMedS -> PnP on the tracker's survivors; keyframes: grid detector + ORB "
                                    "description, triangulation, guided Hamming matching to the local map, local BA) through alva_system_find_camera_pose_device",
                        "frames_resident_in_hbm": True, "stream": f"{STREAM_FRAMES} frames, (2, 1) px per frame, forwards / backwards",

@@ -443,6 +443,14 @@ int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_
                   const double *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2,
                   double *h_chi2, uint8_t *h_depth_pos, double *h_info, int *h_ok);
 
+/* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
+ * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist
+ * (metres) whose descriptor is within max_hamming bits (smallest distance wins, earliest record on ties) -- the intent of
+ * MapManager::mergeMapPoints (src/slam/src/map_manager.cpp:428-513) with mapMaxDescriptorDistance_ (state.hpp:60).  d_keep[i] = 1 for
+ * survivors, d_absorbed_by[i] = index of the absorbing record or -1.  *h_rounds = fixed-point rounds taken.  Synchronous. */
+int alva_fuse_map_points(alva_ctx *ctx, int n, const int *d_stream, const double *d_xyz, const uint8_t *d_desc, double max_dist,
+                         int max_hamming, uint8_t *d_keep, int *d_absorbed_by, int *h_rounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,8 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from alvaar_amd import multi
     sh = multi.shard_from_env()
     assert multi.init_process_group(sh, "gloo")
@@ -31,10 +33,13 @@ def _worker(rank, world, port, q):
     r2 = np.random.RandomState(10 + rank)
     xyz = np.concatenate([shared_xyz + 0.001 * rank, r2.uniform(-5, 5, (n - 1, 3))])
     desc = np.concatenate([shared_desc, r2.randint(0, 256, (n - 1, 32)).astype(np.uint8)])
-    rec = multi.pack_records(sh.rank, np.arange(n, dtype=np.int32), xyz, desc, capacity=8)
+    rec = multi.pack_records(sh.rank, np.arange(n, dtype=np.int32), xyz, desc, capacity=8, device=torch.device("cpu"))   # gloo: host tensors
+    assert multi.exchange_device().type == ("cuda" if torch.cuda.is_available() else "cpu")
     allrec = multi.all_gather_map(rec)
+    assert allrec.shape == (world * 8, multi.RECORD_BYTES) and allrec.device == rec.device      # one collective, rank order
     st, ids, X, D = multi.unpack_records(allrec)
-    keep, absorbed = multi.fuse_duplicates(st, ids, X, D)
+    from map_merge_ref import fuse_duplicates_sequential      # the rule's sequential statement (the product evaluates it on the GPU)
+    keep, absorbed = fuse_duplicates_sequential(st, ids, X, D)
     q.put((rank, sh.stream_seed, rate, len(ids), int(keep.sum()), st.tolist()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -64,6 +69,11 @@ def test_single_process_paths_need_no_process_group():
     assert multi.aggregate_rate(10, 2.0) == 5.0
     rec = multi.pack_records(0, np.arange(2, dtype=np.int32), np.zeros((2, 3)), np.zeros((2, 32), np.uint8), 4)
     assert multi.all_gather_map(rec) is rec
+    assert rec.device.type == multi.exchange_device().type     # records are packed where the exchange will read them: the GPU if there is one
+    if not rec.is_cuda:
+        import pytest
+        with pytest.raises(RuntimeError):                       # the fuse has no CPU path
+            multi.fuse_duplicates(rec, None)
 
 
 def test_rig_cameras_partition():
