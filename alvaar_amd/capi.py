@@ -271,6 +271,38 @@ class Context:
                                 C.byref(ok)))
         return dict(ok=bool(ok.value), poses=poses, pts=pts, chi2=chi2[:nobs], depth=depth[:nobs], info=info)
 
+    def local_ba_batch(self, pbs, max_iters=5, ftol=0.0, huber_chi2=5.9915):
+        """alva_local_ba_batch on a list of flat problem dicts (anchored inverse depth); returns one result dict per problem"""
+        import numpy as np
+        n = len(pbs)
+        keep = []
+
+        def arr(x, dt, copy=False):
+            a = np.ascontiguousarray(x, dt)
+            a = a.copy() if copy else a
+            keep.append(a)
+            return a
+        poses = [arr(pb["poses"], np.float64, True) for pb in pbs]
+        kfc = [arr(pb["kf_const"], np.uint8) for pb in pbs]
+        akf = [arr(pb["anchor_kf"], np.int32) for pb in pbs]
+        auv = [arr(pb["anchor_uv"], np.float64) for pb in pbs]
+        pts = [arr(pb["inv_depth"], np.float64, True) for pb in pbs]
+        okf = [arr(pb["obs_kf"], np.int32) for pb in pbs]
+        opt = [arr(pb["obs_pt"], np.int32) for pb in pbs]
+        ouv = [arr(pb["obs_uv"], np.float64) for pb in pbs]
+        chi2 = [np.zeros(len(o)) for o in okf]
+        depth = [np.zeros(len(o), np.uint8) for o in okf]
+        calib = arr(pbs[0]["calib"], np.float64)
+        info = np.zeros((n, 4))
+        ok = np.zeros(n, np.int32)
+        ptrs = lambda lst: (C.c_void_p * n)(*[a.ctypes.data for a in lst])
+        ints = lambda vals: (C.c_int * n)(*vals)
+        lib.alva_local_ba_batch.argtypes = [_vp, _i] + [_vp] * 3 + [_vp] + [_vp] * 4 + [_vp] * 4 + [_i, _d, _d] + [_vp] * 4
+        check(lib.alva_local_ba_batch(self.h, n, ints([len(p) for p in poses]), ptrs(poses), ptrs(kfc), calib.ctypes.data, ints([len(a) for a in akf]),
+                                      ptrs(akf), ptrs(auv), ptrs(pts), ints([len(o) for o in okf]), ptrs(okf), ptrs(opt), ptrs(ouv), max_iters, ftol,
+                                      huber_chi2, ptrs(chi2), ptrs(depth), info.ctypes.data, ok.ctypes.data))
+        return [dict(ok=bool(ok[b]), poses=poses[b], pts=pts[b], chi2=chi2[b], depth=depth[b], info=info[b]) for b in range(n)]
+
     # a5
     def detect_grid(self, gray, cell, occupied=None, roi=None, max_quality=0.001, cap=None):
         """FeatureExtractor::detectFeaturePoints: returns (pts [n,2] float32 cuda tensor, new max_quality)."""

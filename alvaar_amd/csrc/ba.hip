@@ -91,9 +91,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ------------------------------------------------------------------------------------------------------
 template<bool INV, bool WANT_J>
-__global__ void __launch_bounds__(256) k_point(BaDev B, const double *__restrict__ poses, const double *__restrict__ pts) {
+__device__ __forceinline__ void point_body(const BaDev &B, const double *__restrict__ poses, const double *__restrict__ pts, const int BX_, const int BY_) {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = BX_ * 4 + (threadIdx.x >> 6);
     if (p >= B.nPt) return;
     constexpr int DP = INV ? 1 : 3;
     const int o0 = B.ptPtr[p], o1 = B.ptPtr[p + 1];
@@ -201,14 +201,18 @@ __global__ void __launch_bounds__(256) k_point(BaDev B, const double *__restrict
         }
     }
 }
+template<bool INV, bool WANT_J>
+__global__ void __launch_bounds__(256) k_point(BaDev B, const double *__restrict__ poses, const double *__restrict__ pts) {
+    point_body<INV, WANT_J>(B, poses, pts, blockIdx.x, blockIdx.y);
+}
 
 // One wave per (observing kf, anchor kf) pair: sums of J_obs'J_obs (21) and J_obs' r (6).
-__global__ void __launch_bounds__(256) k_pairs(BaDev B) {
+__device__ __forceinline__ void pairs_body(const BaDev &B, const int BX_, const int BY_) {
     // one WORKGROUP per (observing kf, anchor kf) pair: the big pairs (thousands of observations) set the kernel time, so
     // their observations are spread over 256 lanes; lane partials -> butterfly reduce-scatter per wave -> 4 waves in LDS
     // (fixed order: bit-reproducible)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int key = blockIdx.x;
+    const int key = BX_;
     __shared__ double s_part[4][28];
     double v[32];
 #pragma unroll
@@ -232,6 +236,9 @@ __global__ void __launch_bounds__(256) k_pairs(BaDev B) {
     __syncthreads();
     if (threadIdx.x < 27) B.M[(size_t) key * 27 + threadIdx.x] = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
 }
+__global__ void __launch_bounds__(256) k_pairs(BaDev B) {
+    pairs_body(B, blockIdx.x, blockIdx.y);
+}
 
 __device__ __forceinline__ int tri6(int x, int y) {
     if (x > y) {
@@ -251,8 +258,8 @@ __device__ __forceinline__ int tri6(int x, int y) {
 //   k_rowcol   per keyframe: row and column sums of the pair sums
 //   k_hcc      every element of H_cc, g_c, and (first evaluation) the Jacobi scaling of the cameras
 //   k_gmax     (first evaluation) the Jacobi scaling of the points; max |gradient| -> scal[3]
-__global__ void __launch_bounds__(64) k_rowcol(BaDev B) {
-    const int k = blockIdx.x, t = threadIdx.x, nKf = B.nKf;
+__device__ __forceinline__ void rowcol_body(const BaDev &B, const int BX_, const int BY_) {
+    const int k = BX_, t = threadIdx.x, nKf = B.nKf;
     if (t >= 27) return;
     double rs = 0, cs = 0;
     for (int j = 0; j < nKf; j++) {
@@ -262,11 +269,14 @@ __global__ void __launch_bounds__(64) k_rowcol(BaDev B) {
     B.rowcol[(size_t) k * 27 + t] = rs;
     B.rowcol[(size_t) (nKf + k) * 27 + t] = cs;
 }
+__global__ void __launch_bounds__(64) k_rowcol(BaDev B) {
+    rowcol_body(B, blockIdx.x, blockIdx.y);
+}
 
-__global__ void __launch_bounds__(256) k_hcc(BaDev B, int first) {
+__device__ __forceinline__ void hcc_body(const BaDev &B, int first, const int BX_, const int BY_) {
     const int n6 = B.n6, nKf = B.nKf;
     const double *rowsum = B.rowcol, *colsum = B.rowcol + (size_t) nKf * 27;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = BX_ * 256 + threadIdx.x;
     if (e < n6 * n6) {
         const int r = e / n6, c = e - r * n6, cr = r / 6, cc = c / 6, x = r - 6 * cr, y = c - 6 * cc;
         const int kr = B.kfOf[cr], kc = B.kfOf[cc];
@@ -285,9 +295,12 @@ __global__ void __launch_bounds__(256) k_hcc(BaDev B, int first) {
         B.gc[r] = B.inv ? rowsum[kr * 27 + 21 + x] - colsum[kr * 27 + 21 + x] : B.M[(size_t) (kr * nKf + kr) * 27 + 21 + x];
     }
 }
+__global__ void __launch_bounds__(256) k_hcc(BaDev B, int first) {
+    hcc_body(B, first, blockIdx.x, blockIdx.y);
+}
 
 // max |gradient| (scal[3]) and, same single workgroup, the total cost (scal[0] = sum of the per-point costs of k_point)
-__global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
+__device__ __forceinline__ void gmax_body(const BaDev &B, int first, const int BX_, const int BY_) {
     __shared__ double s_red[256], s_cost[256];
     if (first)
         for (int i = threadIdx.x; i < B.npd; i += 256) {
@@ -313,22 +326,28 @@ __global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
         B.scal[0] = s_cost[0];
     }
 }
+__global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
+    gmax_body(B, first, blockIdx.x, blockIdx.y);
+}
 
 // LM diagonal (levenberg_marquardt_strategy.cc:79-90), refreshed only after an accepted step.
-__global__ void __launch_bounds__(256) k_diag(BaDev B) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void diag_body(const BaDev &B, const int BX_, const int BY_) {
+    const int i = BX_ * 256 + threadIdx.x;
     if (i < B.n6) B.dc[i] = fmin(fmax(B.Hcc[(size_t) i * B.n6 + i] * B.sc[i] * B.sc[i], 1e-6), 1e32);
     if (i < B.npd) {
         const int p = i / B.dp, x = i % B.dp;
         B.dpd[i] = fmin(fmax(B.Hpp[(size_t) p * B.dp * B.dp + x * B.dp + x] * B.sp[i] * B.sp[i], 1e-6), 1e32);
     }
 }
+__global__ void __launch_bounds__(256) k_diag(BaDev B) {
+    diag_body(B, blockIdx.x, blockIdx.y);
+}
 
 // per point: hinv = (S_p E'E S_p + D_p^2/radius)^-1 , L = chol(hinv), Zt rows = S_c W S_p L, last column v = L' (S_p E'r)
 template<int DP>
-__global__ void __launch_bounds__(256) k_prep(BaDev B, double radius) {
+__device__ __forceinline__ void prep_body(const BaDev &B, double radius, const int BX_, const int BY_) {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = BX_ * 4 + (threadIdx.x >> 6);
     if (p >= B.nPt) return;
     double Mx[DP * DP], Hi[DP * DP], L[DP * DP], gs[DP];
 #pragma unroll
@@ -382,12 +401,16 @@ __global__ void __launch_bounds__(256) k_prep(BaDev B, double radius) {
         }
     }
 }
+template<int DP>
+__global__ void __launch_bounds__(256) k_prep(BaDev B, double radius) {
+    prep_body<DP>(B, radius, blockIdx.x, blockIdx.y);
+}
 
 // G_part[ks] (16x16 tile) = Zt[kchunk]' Zt[kchunk] on the FP64 matrix core.
 // v_mfma_f64_16x16x4_f64: A[l&15][k=l>>4], B[k=l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
-__global__ void __launch_bounds__(64) k_gemm(BaDev B) {
+__device__ __forceinline__ void gemm_body(const BaDev &B, const int BX_, const int BY_) {
     const int tiles = B.NP / 16;
-    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles, ks = blockIdx.y;
+    const int ti = BX_ / tiles, tj = BX_ % tiles, ks = BY_;
     const int lane = threadIdx.x;
     const int chunk = B.kpad / KSPLIT;
     const int k0 = ks * chunk;
@@ -415,6 +438,9 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 #pragma unroll
     for (int r = 0; r < 4; r++) G[(size_t) ((lane >> 4) + 4 * r) * B.NP + (lane & 15)] = acc[r];
 }
+__global__ void __launch_bounds__(64) k_gemm(BaDev B) {
+    gemm_body(B, blockIdx.x, blockIdx.y);
+}
 
 // S = S_c F'F S_c + D_c^2/radius - G ; rhs = S_c F'r - G[:, n6] ; dense Cholesky; y_c.  One workgroup.
 //
@@ -427,9 +453,9 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 constexpr int SOLVE_NT = 256, NB = 16;
 
 // reduced camera system of this LM step, padded: S [np][np + 1] and the right-hand side [np] right behind it (all CUs)
-__global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius) {
+__device__ __forceinline__ void reduced_system_body(const BaDev &B, double radius, const int BX_, const int BY_) {
     const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = BX_ * 256 + threadIdx.x;
     if (e < np * np) {
         const int r = e / np, c = e - r * np;
         double v = r == c ? 1.0 : 0.0;  // identity padding
@@ -453,9 +479,12 @@ __global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius) 
         B.S[(size_t) np * ld + r] = v;
     }
 }
+__global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius) {
+    reduced_system_body(B, radius, blockIdx.x, blockIdx.y);
+}
 
 template<bool IN_LDS>
-__global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
+__device__ __forceinline__ void solve_body(const BaDev &B, double radius, const int BX_, const int BY_) {
     extern __shared__ double s_S[];
     const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1, nb = np / NB;
     __shared__ double s_inv[NB], s_z[NB];
@@ -631,13 +660,17 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
     }
     if (threadIdx.x == 0) B.scal[5] = s_ok ? 1.0 : 0.0;
 }
+template<bool IN_LDS>
+__global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
+    solve_body<IN_LDS>(B, radius, blockIdx.x, blockIdx.y);
+}
 
 // per point: y_p = hinv (g_s - (S_c W S_p)' y_c); candidate point; partials for the model cost change
 // (1/2 y'(g_s + D y), exact for the exact solution of (H_s + D) y = g_s) and the step norm.
 template<int DP>
-__global__ void __launch_bounds__(256) k_backsub(BaDev B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t) {
+__device__ __forceinline__ void backsub_body(const BaDev &B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t, const int BX_, const int BY_) {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = BX_ * 4 + (threadIdx.x >> 6);
     if (p >= B.nPt) return;
     double t[DP];
 #pragma unroll
@@ -665,12 +698,15 @@ __global__ void __launch_bounds__(256) k_backsub(BaDev B, double radius, const d
         B.partial[3 * (size_t) p + 1] = sn;
     }
 }
+template<int DP>
+__global__ void __launch_bounds__(256) k_backsub(BaDev B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t) {
+    backsub_body<DP>(B, radius, x_t, c_t, blockIdx.x, blockIdx.y);
+}
 
 // candidate poses (SE3 Plus), camera part of mcc / step norm, and the final deterministic reductions.
 // candidate poses, model cost change (scal[1]), squared step norm (scal[2]) and the squared norm of the CANDIDATE (scal[4]: free
 // poses + point parameters c_t written by k_backsub), which becomes x_norm when the step is accepted
-__global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p,
-                                                const double *__restrict__ c_t) {
+__device__ __forceinline__ void update_body(const BaDev &B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p, const double *__restrict__ c_t, const int BX_, const int BY_) {
     __shared__ double s_a[256], s_b[256], s_c[256];
     double mcc = 0, sn = 0, xn = 0;
     for (int k = threadIdx.x; k < B.nKf; k += 256) {
@@ -715,6 +751,10 @@ __global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const do
         B.scal[4] = s_c[0];
     }
 }
+__global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p,
+                                                const double *__restrict__ c_t) {
+    update_body(B, radius, x_p, c_p, c_t, blockIdx.x, blockIdx.y);
+}
 
 // |x|^2 over the variable blocks (free poses in their 7-vector form + all point parameters) -> scal[4]
 
@@ -725,54 +765,155 @@ T *carve(uint8_t *&cur, size_t count) {
     return p;
 }
 
-}  // namespace
+// ---- a batch of problems: every kernel with the problem in blockIdx.z (blockIdx.y for the ones that use one grid dimension), the
+// per-problem description (BaDev) and this iteration's run parameters (BaRun) in device memory.  The bodies are the single-problem
+// kernels' bodies, so a problem's result is bit-identical to its own alva_local_ba.
+struct BaRun {
+    double radius;
+    const double *xp, *xt;  // the accepted point
+    double *cp, *ct;        // the candidate
+    // evaluation modes: 0 = first evaluation at x (every problem) | 1 = restore evaluation at x (the previous step was rejected) |
+    // 2 = evaluation at the candidate (problems that take part in this LM iteration).  Where to evaluate and whether, per mode, as
+    // plain tables: a three-way branch that selected among xp / cp here was miscompiled by hipcc 7.2 (the mode-2 arm left both
+    // pointers undefined), an indexed load cannot be.
+    const double *ev_p[3], *ev_t[3];
+    int ev_on[3];
+    int step;               // take part in this LM iteration
+    int diag;               // refresh the LM diagonal first
+    int pad;
+};
+static_assert(sizeof(BaRun) % 16 == 0, "BaRun array stride");
+#define RUN_SEL(R, mode, p, t)            \
+    if (!(R).ev_on[mode]) return;         \
+    const double *p = (R).ev_p[mode], *t = (R).ev_t[mode];
+__global__ void __launch_bounds__(256) k_point_b(const BaDev *Bs, const BaRun *Rs, int mode) {
+    RUN_SEL(Rs[blockIdx.y], mode, p, t)
+    point_body<true, true>(Bs[blockIdx.y], p, t, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(256) k_pairs_b(const BaDev *Bs, const BaRun *Rs, int mode) {
+    if (!Rs[blockIdx.y].ev_on[mode]) return;
+    const BaDev &B = Bs[blockIdx.y];
+    if ((int) blockIdx.x >= B.nKf * B.nKf) return;
+    pairs_body(B, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(64) k_rowcol_b(const BaDev *Bs, const BaRun *Rs, int mode) {
+    if (!Rs[blockIdx.y].ev_on[mode]) return;
+    const BaDev &B = Bs[blockIdx.y];
+    if ((int) blockIdx.x >= B.nKf) return;
+    rowcol_body(B, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(256) k_hcc_b(const BaDev *Bs, const BaRun *Rs, int mode) {
+    if (!Rs[blockIdx.y].ev_on[mode]) return;
+    hcc_body(Bs[blockIdx.y], mode == 0 ? 1 : 0, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(256) k_gmax_b(const BaDev *Bs, const BaRun *Rs, int mode) {
+    if (!Rs[blockIdx.y].ev_on[mode]) return;
+    gmax_body(Bs[blockIdx.y], mode == 0 ? 1 : 0, 0, 0);
+}
+__global__ void __launch_bounds__(256) k_diag_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.y];
+    if (!R.step || !R.diag) return;
+    diag_body(Bs[blockIdx.y], blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(256) k_prep_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.y];
+    if (!R.step) return;
+    prep_body<1>(Bs[blockIdx.y], R.radius, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(64) k_gemm_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.z];
+    if (!R.step) return;
+    const BaDev &B = Bs[blockIdx.z];
+    const int tiles = B.NP / 16;
+    if ((int) blockIdx.x >= tiles * tiles) return;
+    gemm_body(B, blockIdx.x, blockIdx.y);
+}
+__global__ void __launch_bounds__(256) k_reduced_system_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.y];
+    if (!R.step) return;
+    reduced_system_body(Bs[blockIdx.y], R.radius, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(SOLVE_NT) k_solve_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.x];
+    if (!R.step) return;
+    solve_body<true>(Bs[blockIdx.x], R.radius, 0, 0);
+}
+__global__ void __launch_bounds__(256) k_backsub_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.y];
+    if (!R.step) return;
+    backsub_body<1>(Bs[blockIdx.y], R.radius, R.xt, R.ct, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(256) k_update_b(const BaDev *Bs, const BaRun *Rs) {
+    const BaRun &R = Rs[blockIdx.x];
+    if (!R.step) return;
+    update_body(Bs[blockIdx.x], R.radius, R.xp, R.cp, R.ct, 0, 0);
+}
 
-extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib, int inv_depth,
-                             int n_pt, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv, double *h_pt_param, int n_obs,
-                             const int *h_obs_kf, const int *h_obs_pt, const double *h_obs_uv, int max_iters,
-                             double function_tolerance, double huber_chi2, double *h_chi2, uint8_t *h_depth_pos, double *h_info,
-                             int *h_ok) {
-    ALVA_ARG(ctx && h_poses && h_kf_const && h_calib && h_pt_param && h_ok && n_kf > 0 && n_pt >= 0 && n_obs >= 0 && max_iters >= 0);
-    ALVA_ARG(n_obs == 0 || (h_obs_kf && h_obs_pt && h_obs_uv));
-    ALVA_ARG(!inv_depth || n_pt == 0 || (h_pt_anchor_kf && h_pt_anchor_uv));
-    *h_ok = 1;
-    if (h_info) memset(h_info, 0, 4 * sizeof(double));
-    const int dp = inv_depth ? 1 : 3;
-    // ---- sizes -----------------------------------------------------------------------------------------------
-    const auto t_begin = std::chrono::steady_clock::now();
-    std::vector<int> cidx((size_t) n_kf);
-    int nc = 0;
-    for (int k = 0; k < n_kf; k++) cidx[(size_t) k] = h_kf_const[k] ? -1 : nc++;
-    for (int o = 0; o < n_obs; o++) ALVA_ARG(h_obs_kf[o] >= 0 && h_obs_kf[o] < n_kf && h_obs_pt[o] >= 0 && h_obs_pt[o] < n_pt);
+// ---- one problem on the host: sizes, the carved device block with its pinned mirror, the structure build -------------------------
+struct BaIn {
+    int n_kf;
+    double *h_poses;
+    const uint8_t *h_kf_const;
+    const double *h_calib;
+    int inv_depth, n_pt;
+    const int *h_pt_anchor_kf;
+    const double *h_pt_anchor_uv;
+    double *h_pt_param;
+    int n_obs;
+    const int *h_obs_kf, *h_obs_pt;
+    const double *h_obs_uv;
+    double huber_chi2;
+};
+
+struct BaHost {
     BaDev B{};
-    B.nKf = n_kf; B.nPt = n_pt; B.nObs = n_obs; B.inv = inv_depth; B.dp = dp; B.nc = nc; B.n6 = 6 * nc;
-    B.NP = (B.n6 + 1 + 15) / 16 * 16;
-    B.npd = n_pt * dp;
-    const int kq = 4 * KSPLIT;
-    B.kpad = std::max(kq, (B.npd + kq - 1) / kq * kq);
-    for (int i = 0; i < 4; i++) B.K[i] = h_calib[i];
-    B.huber_a = (double) sqrtf((float) huber_chi2);  // optimizer.cpp:22: std::sqrt of a float
+    std::vector<int> cidx, order;
+    int *d_obsKf = nullptr, *d_ptPtr = nullptr, *d_ancKf = nullptr, *d_cidx = nullptr, *d_pairPerm = nullptr, *d_pairPtr = nullptr, *d_kfOf = nullptr;
+    double *d_obsUv = nullptr, *d_ancUv = nullptr, *d_xp = nullptr, *d_cp = nullptr, *d_xt = nullptr, *d_ct = nullptr;
+    size_t in_bytes = 0, bytes = 0;
+    size_t np16 = 0, solve_lds = 0;
+    // LM state (Ceres TrustRegionMinimizer, trust_region_minimizer.cc:67-136)
+    LmState lm;
+    double x_cost = 0, gmax = 0, x_norm = -1, initial = 0;
+    int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1, ok = 1;
+    bool need_restore = false, done = false;
+    double *xp = nullptr, *xt = nullptr, *cp = nullptr, *ct = nullptr;
 
-    // ---- one scratch block, carved; the INPUT arrays come first and contiguous so that one copy uploads them ----------
-    const size_t nObs = (size_t) n_obs, nPt = (size_t) n_pt, npd = (size_t) B.npd, n6 = (size_t) B.n6, NP = (size_t) B.NP;
-    int *d_obsKf, *d_ptPtr, *d_ancKf, *d_cidx, *d_pairPerm, *d_pairPtr, *d_kfOf;
-    double *d_obsUv, *d_ancUv, *d_xp, *d_cp, *d_xt, *d_ct;
-    size_t in_bytes = 0, off_res = 0;
-    auto layout = [&](uint8_t *base) -> size_t {
+    int sizes(const BaIn &in) {
+        const int n_kf = in.n_kf, n_pt = in.n_pt, n_obs = in.n_obs, dp = in.inv_depth ? 1 : 3;
+        cidx.assign((size_t) n_kf, -1);
+        int nc = 0;
+        for (int k = 0; k < n_kf; k++) cidx[(size_t) k] = in.h_kf_const[k] ? -1 : nc++;
+        for (int o = 0; o < n_obs; o++) ALVA_ARG(in.h_obs_kf[o] >= 0 && in.h_obs_kf[o] < n_kf && in.h_obs_pt[o] >= 0 && in.h_obs_pt[o] < n_pt);
+        B.nKf = n_kf; B.nPt = n_pt; B.nObs = n_obs; B.inv = in.inv_depth; B.dp = dp; B.nc = nc; B.n6 = 6 * nc;
+        B.NP = (B.n6 + 1 + 15) / 16 * 16;
+        B.npd = n_pt * dp;
+        const int kq = 4 * KSPLIT;
+        B.kpad = std::max(kq, (B.npd + kq - 1) / kq * kq);
+        for (int i = 0; i < 4; i++) B.K[i] = in.h_calib[i];
+        B.huber_a = (double) sqrtf((float) in.huber_chi2);  // optimizer.cpp:22: std::sqrt of a float
+        np16 = ((size_t) B.n6 + 15) / 16 * 16;
+        solve_lds = (np16 * (np16 + 1) + np16) * sizeof(double);
+        bytes = layout(nullptr);
+        return ALVA_OK;
+    }
+    // one block, carved; the INPUT arrays come first and contiguous so that one copy uploads them
+    size_t layout(uint8_t *base) {
+        const size_t nObs = (size_t) B.nObs, nPt = (size_t) B.nPt, npd = (size_t) B.npd, n6 = (size_t) B.n6, NP = (size_t) B.NP, dp = (size_t) B.dp;
+        const size_t n_kf = (size_t) B.nKf;
         uint8_t *cur = base;
         d_obsKf = carve<int>(cur, nObs);
         d_obsUv = carve<double>(cur, nObs * 2);
         d_ptPtr = carve<int>(cur, nPt + 1);
         d_ancKf = carve<int>(cur, nPt);
         d_ancUv = carve<double>(cur, nPt * 2);
-        d_cidx = carve<int>(cur, (size_t) n_kf);
-        d_kfOf = carve<int>(cur, (size_t) n_kf);
+        d_cidx = carve<int>(cur, n_kf);
+        d_kfOf = carve<int>(cur, n_kf);
         d_pairPerm = carve<int>(cur, nObs);
-        d_pairPtr = carve<int>(cur, (size_t) n_kf * n_kf + 1);
-        d_xp = carve<double>(cur, (size_t) n_kf * 7);
+        d_pairPtr = carve<int>(cur, n_kf * n_kf + 1);
+        d_xp = carve<double>(cur, n_kf * 7);
         d_xt = carve<double>(cur, npd);
         in_bytes = (size_t) (cur - base);
-        off_res = in_bytes;
         B.chi2 = carve<double>(cur, nObs);   // results the host reads back: chi2 | depth flags, contiguous
         B.depth = carve<uint8_t>(cur, nObs);
         B.Jobs = carve<double>(cur, nObs * 12);
@@ -781,8 +922,8 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         B.Hpp = carve<double>(cur, npd * dp);
         B.gp = carve<double>(cur, npd);
         B.Wt = carve<double>(cur, npd * NP);
-        B.M = carve<double>(cur, (size_t) n_kf * n_kf * 27);
-        B.rowcol = carve<double>(cur, (size_t) n_kf * 27 * 2);
+        B.M = carve<double>(cur, n_kf * n_kf * 27);
+        B.rowcol = carve<double>(cur, n_kf * 27 * 2);
         B.Hcc = carve<double>(cur, n6 * n6);
         B.gc = carve<double>(cur, n6);
         B.sc = carve<double>(cur, n6);
@@ -797,86 +938,171 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         B.yp = carve<double>(cur, npd);
         B.scal = carve<double>(cur, 64);
         B.partial = carve<double>(cur, nPt * 3);
-        d_cp = carve<double>(cur, (size_t) n_kf * 7);
+        d_cp = carve<double>(cur, n_kf * 7);
         d_ct = carve<double>(cur, npd);
         return (size_t) (cur - base);
-    };
-    const size_t bytes = layout(nullptr);
+    }
+    // the analogue of Ceres' program / block-structure build, written into the pinned mirror `stage` of the input arrays; then the
+    // device pointers are bound to `base`
+    int build(const BaIn &in, uint8_t *base, uint8_t *stage) {
+        const int n_kf = in.n_kf, n_pt = in.n_pt, n_obs = in.n_obs;
+        const size_t nPt = (size_t) n_pt, npd = (size_t) B.npd;
+        layout(stage);
+        int *h_obsKf = d_obsKf, *h_ptPtr = d_ptPtr, *h_ancKf = d_ancKf, *h_cidx = d_cidx, *h_kfOf = d_kfOf, *h_pairPerm = d_pairPerm, *h_pairPtr = d_pairPtr;
+        double *h_obsUv = d_obsUv, *h_ancUv = d_ancUv, *h_xp = d_xp, *h_xt = d_xt;
+        layout(base);
+        B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
+        B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
+        // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
+        order.assign((size_t) n_obs, 0);
+        std::vector<int> pairKey((size_t) n_obs);
+        for (size_t p2 = 0; p2 <= nPt; p2++) h_ptPtr[p2] = 0;
+        {
+            std::vector<int> cursor((size_t) n_pt + 1, 0);
+            for (int o = 0; o < n_obs; o++) cursor[(size_t) in.h_obs_pt[o] + 1]++;
+            for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];
+            for (int o = 0; o < n_obs; o++) order[(size_t) cursor[(size_t) in.h_obs_pt[o]]++] = o;
+        }
+        for (int q = 0; q < n_obs; q++) {
+            const int o = order[(size_t) q];
+            h_obsKf[q] = in.h_obs_kf[o];
+            h_obsUv[2 * (size_t) q] = in.h_obs_uv[2 * o];
+            h_obsUv[2 * (size_t) q + 1] = in.h_obs_uv[2 * o + 1];
+            h_ptPtr[(size_t) in.h_obs_pt[o] + 1]++;
+            const int anc = in.inv_depth ? in.h_pt_anchor_kf[in.h_obs_pt[o]] : in.h_obs_kf[o];
+            ALVA_ARG(anc >= 0 && anc < n_kf);
+            pairKey[(size_t) q] = in.h_obs_kf[o] * n_kf + anc;
+        }
+        for (int p2 = 0; p2 < n_pt; p2++) h_ptPtr[(size_t) p2 + 1] += h_ptPtr[(size_t) p2];
+        // the same observations grouped by (observing kf, anchor kf) pair, stable: counting sort again
+        const size_t nPairs = (size_t) n_kf * n_kf;
+        for (size_t i = 0; i <= nPairs; i++) h_pairPtr[i] = 0;
+        for (int q = 0; q < n_obs; q++) h_pairPtr[(size_t) pairKey[(size_t) q] + 1]++;
+        for (size_t i = 0; i < nPairs; i++) h_pairPtr[i + 1] += h_pairPtr[i];
+        {
+            std::vector<int> cursor(h_pairPtr, h_pairPtr + nPairs);
+            for (int q = 0; q < n_obs; q++) h_pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
+        }
+        if (in.inv_depth && n_pt > 0) {
+            memcpy(h_ancKf, in.h_pt_anchor_kf, nPt * 4);
+            memcpy(h_ancUv, in.h_pt_anchor_uv, nPt * 16);
+        }
+        for (int k = 0; k < n_kf; k++) {
+            h_cidx[k] = cidx[(size_t) k];
+            h_kfOf[k] = 0;
+        }
+        for (int k = 0; k < n_kf; k++)
+            if (cidx[(size_t) k] >= 0) h_kfOf[cidx[(size_t) k]] = k;
+        // poses are stored the way PoseParametersBlock(id, SE3d) stores them: unit quaternion
+        for (int k = 0; k < n_kf; k++) {
+            Se3 T;
+            se3_from_pose7(in.h_poses + 7 * k, T);
+            for (int i = 0; i < 3; i++) h_xp[7 * (size_t) k + i] = T.t[i];
+            for (int i = 0; i < 4; i++) h_xp[7 * (size_t) k + 3 + i] = T.q[i];
+        }
+        if (npd) memcpy(h_xt, in.h_pt_param, npd * 8);
+        xp = d_xp; xt = d_xt; cp = d_cp; ct = d_ct;
+        return ALVA_OK;
+    }
+    // Ceres' accept / reject logic on the scalars of the candidate's evaluation (trust_region_minimizer.cc:461-490, :781-829);
+    // returns true when the minimiser stops
+    bool advance(const double *scal, double function_tolerance) {
+        const double cand_cost = scal[0], mcc = scal[1], step_norm = std::sqrt(scal[2]);
+        const bool okstep = scal[5] != 0.0 && std::isfinite(mcc);
+        if (!okstep || !(mcc > 0)) {  // HandleInvalidStep (:461-490)
+            if (++invalid >= 5) {
+                ok = 0;
+                return true;
+            }
+            lm.rejected();
+            nsummaries++;
+            need_restore = true;
+            return false;
+        }
+        invalid = 0;
+        if (step_norm <= 1e-8 * (x_norm + 1e-8)) return true;                                // ParameterToleranceReached
+        if (std::fabs(x_cost - cand_cost) <= function_tolerance * x_cost) return true;      // FunctionToleranceReached
+        const double rel = (x_cost - cand_cost) / mcc;
+        if (rel > 1e-3) {
+            std::swap(xp, cp);
+            std::swap(xt, ct);
+            x_cost = cand_cost;
+            gmax = scal[3];
+            x_norm = std::sqrt(scal[4]);
+            lm.accepted(rel);
+            nsucc++;
+        } else {
+            lm.rejected();
+            need_restore = true;
+        }
+        nsummaries++;
+        return false;
+    }
+    bool loop_ends(int max_iters) const { return iteration >= max_iters || gmax <= 1e-10 || lm.radius <= 1e-32; }
+    // results back in the caller's arrays; r_* point at the downloaded chi2 | depth block, poses and point parameters
+    void finish(const BaIn &in, const uint8_t *r_chi, const double *r_poses, const double *r_pts, double *h_chi2, uint8_t *h_depth_pos, double *h_info) {
+        const size_t npd = (size_t) B.npd;
+        if (npd) memcpy(in.h_pt_param, r_pts, npd * 8);
+        const double *chi2s = reinterpret_cast<const double *>(r_chi);
+        const uint8_t *deps = r_chi + ((uint8_t *) B.depth - (uint8_t *) B.chi2);
+        for (int k = 0; k < in.n_kf; k++)
+            if (cidx[(size_t) k] >= 0) memcpy(in.h_poses + 7 * k, r_poses + 7 * (size_t) k, 56);
+        for (int q = 0; q < in.n_obs; q++) {  // back to the caller's observation order
+            if (h_chi2) h_chi2[order[(size_t) q]] = chi2s[(size_t) q];
+            if (h_depth_pos) h_depth_pos[order[(size_t) q]] = deps[(size_t) q];
+        }
+        if (h_info) {
+            h_info[0] = nsummaries;
+            h_info[1] = initial;
+            h_info[2] = x_cost;
+            h_info[3] = nsucc;
+        }
+    }
+    size_t chi_bytes() const { return (size_t) ((uint8_t *) B.depth - (uint8_t *) B.chi2) + (size_t) B.nObs; }   // chi2 | pad | depth, as carved
+};
+
+}  // namespace
+
+extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib, int inv_depth,
+                             int n_pt, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv, double *h_pt_param, int n_obs,
+                             const int *h_obs_kf, const int *h_obs_pt, const double *h_obs_uv, int max_iters,
+                             double function_tolerance, double huber_chi2, double *h_chi2, uint8_t *h_depth_pos, double *h_info,
+                             int *h_ok) {
+    ALVA_ARG(ctx && h_poses && h_kf_const && h_calib && h_pt_param && h_ok && n_kf > 0 && n_pt >= 0 && n_obs >= 0 && max_iters >= 0);
+    ALVA_ARG(n_obs == 0 || (h_obs_kf && h_obs_pt && h_obs_uv));
+    ALVA_ARG(!inv_depth || n_pt == 0 || (h_pt_anchor_kf && h_pt_anchor_uv));
+    *h_ok = 1;
+    if (h_info) memset(h_info, 0, 4 * sizeof(double));
+    const auto t_begin = std::chrono::steady_clock::now();
+    const BaIn in{n_kf, h_poses, h_kf_const, h_calib, inv_depth, n_pt, h_pt_anchor_kf, h_pt_anchor_uv, h_pt_param, n_obs, h_obs_kf, h_obs_pt, h_obs_uv,
+                  huber_chi2};
+    BaHost H;
+    int rc = H.sizes(in);
+    if (rc) return rc;
+    BaDev &B = H.B;
+    const int dp = B.dp;
+    const size_t nObs = (size_t) n_obs, npd = (size_t) B.npd, NP = (size_t) B.NP;
     uint8_t *base = nullptr;
-    int rc = alva_ctx_scratch(ctx, 4, bytes, (void **) &base);
+    rc = alva_ctx_scratch(ctx, 4, H.bytes, (void **) &base);
     if (rc) return rc;
     // pinned staging: [0, 256) the per-iteration scalars | the input block (mirror of the device layout) | results
     const size_t res_bytes = (nObs * 9 + 511) / 256 * 256 + (size_t) n_kf * 56 + 256 + npd * 8 + 256;
     uint8_t *pin = nullptr;
-    rc = alva_ctx_pinned(ctx, 256 + std::max(in_bytes, res_bytes), (void **) &pin);
+    rc = alva_ctx_pinned(ctx, 256 + std::max(H.in_bytes, res_bytes), (void **) &pin);
     if (rc) return rc;
     uint8_t *stage = pin + 256;
-    layout(stage);  // host mirrors of the input arrays, written in place
-    int *h_obsKf = d_obsKf, *h_ptPtr = d_ptPtr, *h_ancKf = d_ancKf, *h_cidx = d_cidx, *h_kfOf = d_kfOf, *h_pairPerm = d_pairPerm,
-        *h_pairPtr = d_pairPtr;
-    double *h_obsUv = d_obsUv, *h_ancUv = d_ancUv, *h_xp = d_xp, *h_xt = d_xt;
-    layout(base);
-    B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
-    B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
     hipStream_t st = ctx->stream;
     ALVA_HIP(hipStreamSynchronize(st));  // nothing enqueued earlier may still be reading the staging area
-
-    // ---- host-side structure (the analogue of Ceres' program / block-structure build), built in the staging area ---------
-    // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
-    std::vector<int> order((size_t) n_obs), pairKey((size_t) n_obs);
-    for (size_t p2 = 0; p2 <= nPt; p2++) h_ptPtr[p2] = 0;
-    {
-        std::vector<int> cursor((size_t) n_pt + 1, 0);
-        for (int o = 0; o < n_obs; o++) cursor[(size_t) h_obs_pt[o] + 1]++;
-        for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];
-        for (int o = 0; o < n_obs; o++) order[(size_t) cursor[(size_t) h_obs_pt[o]]++] = o;
-    }
-    for (int q = 0; q < n_obs; q++) {
-        const int o = order[(size_t) q];
-        h_obsKf[q] = h_obs_kf[o];
-        h_obsUv[2 * (size_t) q] = h_obs_uv[2 * o];
-        h_obsUv[2 * (size_t) q + 1] = h_obs_uv[2 * o + 1];
-        h_ptPtr[(size_t) h_obs_pt[o] + 1]++;
-        const int anc = inv_depth ? h_pt_anchor_kf[h_obs_pt[o]] : h_obs_kf[o];
-        ALVA_ARG(anc >= 0 && anc < n_kf);
-        pairKey[(size_t) q] = h_obs_kf[o] * n_kf + anc;
-    }
-    for (int p2 = 0; p2 < n_pt; p2++) h_ptPtr[(size_t) p2 + 1] += h_ptPtr[(size_t) p2];
-    // the same observations grouped by (observing kf, anchor kf) pair, stable: counting sort again
-    const size_t nPairs = (size_t) n_kf * n_kf;
-    for (size_t i = 0; i <= nPairs; i++) h_pairPtr[i] = 0;
-    for (int q = 0; q < n_obs; q++) h_pairPtr[(size_t) pairKey[(size_t) q] + 1]++;
-    for (size_t i = 0; i < nPairs; i++) h_pairPtr[i + 1] += h_pairPtr[i];
-    {
-        std::vector<int> cursor(h_pairPtr, h_pairPtr + nPairs);
-        for (int q = 0; q < n_obs; q++) h_pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
-    }
-    if (inv_depth && n_pt > 0) {
-        memcpy(h_ancKf, h_pt_anchor_kf, nPt * 4);
-        memcpy(h_ancUv, h_pt_anchor_uv, nPt * 16);
-    }
-    for (int k = 0; k < n_kf; k++) {
-        h_cidx[k] = cidx[(size_t) k];
-        h_kfOf[k] = 0;
-    }
-    for (int k = 0; k < n_kf; k++)
-        if (cidx[(size_t) k] >= 0) h_kfOf[cidx[(size_t) k]] = k;
-    // poses are stored the way PoseParametersBlock(id, SE3d) stores them: unit quaternion
-    for (int k = 0; k < n_kf; k++) {
-        Se3 T;
-        se3_from_pose7(h_poses + 7 * k, T);
-        for (int i = 0; i < 3; i++) h_xp[7 * (size_t) k + i] = T.t[i];
-        for (int i = 0; i < 4; i++) h_xp[7 * (size_t) k + 3 + i] = T.q[i];
-    }
-    if (npd) memcpy(h_xt, h_pt_param, npd * 8);
+    rc = H.build(in, base, stage);
+    if (rc) return rc;
     const auto t_built = std::chrono::steady_clock::now();
-    ALVA_HIP(hipMemcpyAsync(base, stage, in_bytes, hipMemcpyHostToDevice, st));   // ONE upload from pinned memory
+    ALVA_HIP(hipMemcpyAsync(base, stage, H.in_bytes, hipMemcpyHostToDevice, st));   // ONE upload from pinned memory
     ALVA_HIP(hipMemsetAsync(B.Wt, 0, npd * NP * 8, st));                     // sparsity pattern is fixed: zero once
     ALVA_HIP(hipMemsetAsync(B.Zt, 0, (size_t) B.kpad * NP * 8, st));         // K padding rows stay zero
     const auto t_up = std::chrono::steady_clock::now();
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
-    const size_t np16 = (n6 + 15) / 16 * 16, solve_lds = (np16 * (np16 + 1) + np16) * sizeof(double);
+    const size_t np16 = H.np16, solve_lds = H.solve_lds;
     const bool solve_in_lds = solve_lds <= 152 * 1024;   // + ~5 KB of static LDS in k_solve stays under the CU's 160 KB
     if (solve_in_lds && solve_lds > 48 * 1024)
         ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -903,23 +1129,22 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     };
 
     // ---- Ceres TrustRegionMinimizer::Minimize, restated (trust_region_minimizer.cc:67-136) -------------------
-    rc = eval(d_xp, d_xt, true);
+    rc = eval(H.d_xp, H.d_xt, true);
     if (rc) return rc;
     rc = read_scal();
     if (rc) return rc;
-    double x_cost = scal[0], gmax = scal[3], x_norm = -1, initial = x_cost;
-    LmState lm;
-    int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1;
-    double *xp = d_xp, *xt = d_xt, *cp = d_cp, *ct = d_ct;
-    bool need_restore = false;  // the Jacobian-derived state belongs to a rejected candidate (restored lazily: when the loop ends right
-                                // after a rejection, the last evaluation stays the candidate's, as in the reference)
+    H.x_cost = H.initial = scal[0];
+    H.gmax = scal[3];
+    LmState &lm = H.lm;
+    // need_restore: the Jacobian-derived state belongs to a rejected candidate (restored lazily: when the loop ends right after a
+    // rejection, the last evaluation stays the candidate's, as in the reference)
     while (true) {
-        if (iteration >= max_iters || gmax <= 1e-10 || lm.radius <= 1e-32) break;
-        iteration++;
-        if (need_restore) {
-            rc = eval(xp, xt, false);
+        if (H.loop_ends(max_iters)) break;
+        H.iteration++;
+        if (H.need_restore) {
+            rc = eval(H.xp, H.xt, false);
             if (rc) return rc;
-            need_restore = false;
+            H.need_restore = false;
         }
         const int ndiag = std::max(B.n6, B.npd);
         if (!lm.reuse_diagonal && ndiag > 0) hipLaunchKernelGGL(k_diag, dim3((unsigned) alva_divup(ndiag, 256)), blk, 0, st, B);
@@ -937,81 +1162,231 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_NT), solve_lds, st, B, lm.radius);
         else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_NT), 0, st, B, lm.radius);
         if (n_pt > 0) {
-            if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
-            else hipLaunchKernelGGL(k_backsub<3>, gPt, blk, 0, st, B, lm.radius, (const double *) xt, ct);
+            if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) H.xt, H.ct);
+            else hipLaunchKernelGGL(k_backsub<3>, gPt, blk, 0, st, B, lm.radius, (const double *) H.xt, H.ct);
         }
-        hipLaunchKernelGGL(k_update, dim3(1), blk, 0, st, B, lm.radius, (const double *) xp, cp, (const double *) ct);
+        hipLaunchKernelGGL(k_update, dim3(1), blk, 0, st, B, lm.radius, (const double *) H.xp, H.cp, (const double *) H.ct);
         ALVA_LAUNCH_CHECK();
         // The candidate is evaluated WITH its Jacobian and its norm straight away: when the step is accepted (the normal case) Ceres
         // re-evaluates at the same point (HandleSuccessfulStep, trust_region_minimizer.cc:809-829) and would produce exactly these
         // numbers again, so one host round trip per iteration disappears.  A rejected step costs one re-evaluation at x instead.
-        rc = eval(cp, ct, false);
+        rc = eval(H.cp, H.ct, false);
         if (rc) return rc;
         rc = read_scal();
         if (rc) return rc;
-        const double cand_cost = scal[0], mcc = scal[1], step_norm = std::sqrt(scal[2]);
-        const bool okstep = scal[5] != 0.0 && std::isfinite(mcc);
-        if (!okstep || !(mcc > 0)) {  // HandleInvalidStep (:461-490)
-            if (++invalid >= 5) {
-                *h_ok = 0;
-                break;
-            }
-            lm.rejected();
-            nsummaries++;
-            need_restore = true;
-            continue;
-        }
-        invalid = 0;
-        if (step_norm <= 1e-8 * (x_norm + 1e-8)) break;                                // ParameterToleranceReached
-        if (std::fabs(x_cost - cand_cost) <= function_tolerance * x_cost) break;      // FunctionToleranceReached
-        const double rel = (x_cost - cand_cost) / mcc;
-        if (rel > 1e-3) {
-            std::swap(xp, cp);
-            std::swap(xt, ct);
-            x_cost = cand_cost;
-            gmax = scal[3];
-            x_norm = std::sqrt(scal[4]);
-            lm.accepted(rel);
-            nsucc++;
-        } else {
-            lm.rejected();
-            need_restore = true;
-        }
-        nsummaries++;
+        if (H.advance(scal, function_tolerance)) break;
     }
+    *h_ok = H.ok;
     const auto t_lm = std::chrono::steady_clock::now();
     // results: poses / points at the last accepted x; chi2 / depth flags of the LAST evaluation (what the
     // reference's outlier sweep reads from its cost-function objects, optimizer.cpp:266-309)
     // the input staging area is free again (its upload finished long ago): results land there, three DMA copies
     uint8_t *r_chi = stage;
-    const size_t chi_bytes = (size_t) ((uint8_t *) B.depth - (uint8_t *) B.chi2) + nObs;   // chi2 | pad | depth, as carved
+    const size_t chi_bytes = H.chi_bytes();
     double *r_poses = reinterpret_cast<double *>(stage + (chi_bytes + 255) / 256 * 256);
     double *r_pts = r_poses + (size_t) n_kf * 7 + 32;
     if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, B.chi2, chi_bytes, hipMemcpyDeviceToHost, st));
-    ALVA_HIP(hipMemcpyAsync(r_poses, xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
-    if (npd) ALVA_HIP(hipMemcpyAsync(r_pts, xt, npd * 8, hipMemcpyDeviceToHost, st));
+    ALVA_HIP(hipMemcpyAsync(r_poses, H.xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
+    if (npd) ALVA_HIP(hipMemcpyAsync(r_pts, H.xt, npd * 8, hipMemcpyDeviceToHost, st));
     ALVA_HIP(hipStreamSynchronize(st));
-    if (npd) memcpy(h_pt_param, r_pts, npd * 8);
-    const double *chi2s = reinterpret_cast<const double *>(r_chi);
-    const uint8_t *deps = r_chi + ((uint8_t *) B.depth - (uint8_t *) B.chi2);
-    for (int k = 0; k < n_kf; k++)
-        if (cidx[(size_t) k] >= 0) memcpy(h_poses + 7 * k, r_poses + 7 * (size_t) k, 56);
-    for (int q = 0; q < n_obs; q++) {  // back to the caller's observation order
-        if (h_chi2) h_chi2[order[(size_t) q]] = chi2s[(size_t) q];
-        if (h_depth_pos) h_depth_pos[order[(size_t) q]] = deps[(size_t) q];
-    }
-    if (h_info) {
-        h_info[0] = nsummaries;
-        h_info[1] = initial;
-        h_info[2] = x_cost;
-        h_info[3] = nsucc;
-    }
+    H.finish(in, r_chi, r_poses, r_pts, h_chi2, h_depth_pos, h_info);
     if (getenv("ALVA_BA_TIMING")) {
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return (double) std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3;
         };
         fprintf(stderr, "[alva_local_ba] host structure %.0f us | scratch + upload %.0f us | LM loop (%d summaries) %.0f us | download %.0f us\n",
-                us(t_begin, t_built), us(t_built, t_up), nsummaries, us(t_up, t_lm), us(t_lm, std::chrono::steady_clock::now()));
+                us(t_begin, t_built), us(t_built, t_up), H.nsummaries, us(t_up, t_lm), us(t_lm, std::chrono::steady_clock::now()));
+    }
+    return ALVA_OK;
+}
+
+// `count` independent local-BA problems (anchored inverse depth) in ONE set of launches per LM iteration: a rig's cameras, or the
+// sessions of a server, each with its own keyframes / points / observations (ragged).  Every kernel carries the problem in a grid
+// dimension -- the reduced camera systems factor on `count` compute units at once, the Schur-complement GEMMs form one grouped MFMA
+// launch -- and the host reads ONE block of scalars per iteration for all problems and steps each problem's trust region separately
+// (problems stop at different iterations; a stopped problem's workgroups return at once).  Results are bit-identical to `count`
+// calls of alva_local_ba.  Arrays of `count` pointers / sizes; h_info [count][4]; h_ok [count].
+extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, double *const *h_poses, const uint8_t *const *h_kf_const,
+                                   const double *h_calib, const int *n_pt, const int *const *h_pt_anchor_kf,
+                                   const double *const *h_pt_anchor_uv, double *const *h_pt_param, const int *n_obs, const int *const *h_obs_kf,
+                                   const int *const *h_obs_pt, const double *const *h_obs_uv, int max_iters, double function_tolerance,
+                                   double huber_chi2, double *const *h_chi2, uint8_t *const *h_depth_pos, double *h_info, int *h_ok) {
+    ALVA_ARG(ctx && count > 0 && count <= 4096 && n_kf && h_poses && h_kf_const && h_calib && n_pt && h_pt_anchor_kf && h_pt_anchor_uv &&
+             h_pt_param && n_obs && h_obs_kf && h_obs_pt && h_obs_uv && h_ok && max_iters >= 0);
+    std::vector<BaIn> ins((size_t) count);
+    std::vector<BaHost> Hs((size_t) count);
+    size_t dev_bytes = 0, in_total = 0, res_total = 0;
+    int max_pt = 1, max_kf = 1, max_n6 = 0, max_ndiag = 1, max_tiles = 1;
+    size_t max_np16 = 0, max_lds = 0;
+    for (int b = 0; b < count; b++) {
+        ALVA_ARG(n_kf[b] > 0 && n_pt[b] > 0 && n_obs[b] > 0 && h_poses[b] && h_kf_const[b] && h_pt_anchor_kf[b] && h_pt_anchor_uv[b] && h_pt_param[b] &&
+                 h_obs_kf[b] && h_obs_pt[b] && h_obs_uv[b]);
+        ins[(size_t) b] = BaIn{n_kf[b], h_poses[b], h_kf_const[b], h_calib, 1, n_pt[b], h_pt_anchor_kf[b], h_pt_anchor_uv[b], h_pt_param[b], n_obs[b],
+                               h_obs_kf[b], h_obs_pt[b], h_obs_uv[b], huber_chi2};
+        BaHost &H = Hs[(size_t) b];
+        int rc = H.sizes(ins[(size_t) b]);
+        if (rc) return rc;
+        ALVA_ARG(H.solve_lds <= 152 * 1024);   // the batched factorisation keeps every reduced system in LDS (<= 23 free keyframes)
+        dev_bytes += H.bytes;
+        in_total += H.in_bytes;
+        res_total += (H.chi_bytes() + 255) / 256 * 256 + ((size_t) n_kf[b] * 56 + 255) / 256 * 256 + ((size_t) H.B.npd * 8 + 255) / 256 * 256;
+        max_pt = std::max(max_pt, n_pt[b]);
+        max_kf = std::max(max_kf, n_kf[b]);
+        max_n6 = std::max(max_n6, H.B.n6);
+        max_ndiag = std::max(max_ndiag, std::max(H.B.n6, H.B.npd));
+        max_tiles = std::max(max_tiles, H.B.NP / 16);
+        max_np16 = std::max(max_np16, H.np16);
+        max_lds = std::max(max_lds, H.solve_lds);
+        h_ok[b] = 1;
+    }
+    const size_t cnt = (size_t) count;
+    const size_t off_desc = dev_bytes, off_run = off_desc + (cnt * sizeof(BaDev) + 255) / 256 * 256, off_scal = off_run + (cnt * sizeof(BaRun) + 255) / 256 * 256;
+    uint8_t *base = nullptr;
+    int rc = alva_ctx_scratch(ctx, 4, off_scal + cnt * 64, (void **) &base);
+    if (rc) return rc;
+    // pinned: scalars of all problems | run blocks | descriptors | input mirrors (later: results)
+    const size_t p_run = (cnt * 64 + 255) / 256 * 256, p_desc = p_run + (cnt * sizeof(BaRun) + 255) / 256 * 256,
+                 p_stage = p_desc + (cnt * sizeof(BaDev) + 255) / 256 * 256;
+    uint8_t *pin = nullptr;
+    rc = alva_ctx_pinned(ctx, p_stage + std::max(in_total, res_total) + 256, (void **) &pin);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    ALVA_HIP(hipStreamSynchronize(st));
+    BaDev *d_desc = (BaDev *) (base + off_desc), *h_desc = (BaDev *) (pin + p_desc);
+    BaRun *d_run = (BaRun *) (base + off_run), *h_run = (BaRun *) (pin + p_run);
+    double *d_scal = (double *) (base + off_scal), *h_scal = (double *) pin;
+    {
+        size_t doff = 0, soff = 0;
+        for (int b = 0; b < count; b++) {
+            BaHost &H = Hs[(size_t) b];
+            rc = H.build(ins[(size_t) b], base + doff, pin + p_stage + soff);
+            if (rc) return rc;
+            H.B.scal = d_scal + 8 * (size_t) b;   // every problem's scalars in one block: one read-back per iteration
+            h_desc[b] = H.B;
+            ALVA_HIP(hipMemcpyAsync(base + doff, pin + p_stage + soff, H.in_bytes, hipMemcpyHostToDevice, st));
+            ALVA_HIP(hipMemsetAsync(H.B.Wt, 0, (size_t) H.B.npd * H.B.NP * 8, st));
+            ALVA_HIP(hipMemsetAsync(H.B.Zt, 0, (size_t) H.B.kpad * H.B.NP * 8, st));
+            doff += H.bytes;
+            soff += H.in_bytes;
+        }
+    }
+    ALVA_HIP(hipMemcpyAsync(d_desc, h_desc, cnt * sizeof(BaDev), hipMemcpyHostToDevice, st));
+    if (max_lds > 48 * 1024)
+        ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_b), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    const dim3 blk(256);
+    const unsigned ub = (unsigned) count;
+    auto push_run = [&]() -> int {
+        for (int b = 0; b < count; b++) {
+            BaHost &H = Hs[(size_t) b];
+            BaRun &R = h_run[b];
+            R.radius = H.lm.radius;
+            R.xp = H.xp; R.xt = H.xt; R.cp = H.cp; R.ct = H.ct;
+            R.ev_p[0] = R.ev_p[1] = H.xp; R.ev_t[0] = R.ev_t[1] = H.xt;
+            R.ev_p[2] = H.cp; R.ev_t[2] = H.ct;
+        }
+        ALVA_HIP(hipMemcpyAsync(d_run, h_run, cnt * sizeof(BaRun), hipMemcpyHostToDevice, st));
+        return ALVA_OK;
+    };
+    auto eval = [&](int mode) -> int {
+        hipLaunchKernelGGL(k_point_b, dim3((unsigned) alva_divup(max_pt, 4), ub), blk, 0, st, d_desc, d_run, mode);
+        hipLaunchKernelGGL(k_pairs_b, dim3((unsigned) (max_kf * max_kf), ub), blk, 0, st, d_desc, d_run, mode);
+        hipLaunchKernelGGL(k_rowcol_b, dim3((unsigned) max_kf, ub), dim3(64), 0, st, d_desc, d_run, mode);
+        if (max_n6 > 0) hipLaunchKernelGGL(k_hcc_b, dim3((unsigned) alva_divup(max_n6 * max_n6 + max_n6, 256), ub), blk, 0, st, d_desc, d_run, mode);
+        hipLaunchKernelGGL(k_gmax_b, dim3(1, ub), blk, 0, st, d_desc, d_run, mode);
+        ALVA_LAUNCH_CHECK();
+        return ALVA_OK;
+    };
+    auto read_scal = [&]() -> int {
+        ALVA_HIP(hipMemcpyAsync(h_scal, d_scal, cnt * 64, hipMemcpyDeviceToHost, st));
+        ALVA_HIP(hipStreamSynchronize(st));
+        return ALVA_OK;
+    };
+    for (int b = 0; b < count; b++) {
+        h_run[b] = BaRun{};
+        h_run[b].ev_on[0] = 1;
+    }
+    rc = push_run();
+    if (rc) return rc;
+    rc = eval(0);
+    if (rc) return rc;
+    rc = read_scal();
+    if (rc) return rc;
+    for (int b = 0; b < count; b++) {
+        BaHost &H = Hs[(size_t) b];
+        H.x_cost = H.initial = h_scal[8 * (size_t) b];
+        H.gmax = h_scal[8 * (size_t) b + 3];
+    }
+    for (;;) {
+        int active = 0, restores = 0, diags = 0;
+        for (int b = 0; b < count; b++) {
+            BaHost &H = Hs[(size_t) b];
+            BaRun &R = h_run[b];
+            if (!H.done && H.loop_ends(max_iters)) H.done = true;
+            R.step = R.diag = 0;
+            R.ev_on[0] = R.ev_on[1] = R.ev_on[2] = 0;
+            if (H.done) continue;
+            H.iteration++;
+            R.step = R.ev_on[2] = 1;
+            R.ev_on[1] = H.need_restore ? 1 : 0;
+            H.need_restore = false;
+            R.diag = H.lm.reuse_diagonal ? 0 : 1;
+            H.lm.reuse_diagonal = 1;
+            active++;
+            restores += R.ev_on[1];
+            diags += R.diag;
+        }
+        if (!active) break;
+        rc = push_run();
+        if (rc) return rc;
+        if (restores) {
+            rc = eval(1);
+            if (rc) return rc;
+        }
+        if (diags) hipLaunchKernelGGL(k_diag_b, dim3((unsigned) alva_divup(max_ndiag, 256), ub), blk, 0, st, d_desc, d_run);
+        hipLaunchKernelGGL(k_prep_b, dim3((unsigned) alva_divup(max_pt, 4), ub), blk, 0, st, d_desc, d_run);
+        hipLaunchKernelGGL(k_gemm_b, dim3((unsigned) (max_tiles * max_tiles), KSPLIT, ub), dim3(64), 0, st, d_desc, d_run);
+        if (max_np16 > 0) {
+            const int n16 = (int) max_np16;
+            hipLaunchKernelGGL(k_reduced_system_b, dim3((unsigned) alva_divup(n16 * n16 + n16, 256), ub), blk, 0, st, d_desc, d_run);
+        }
+        hipLaunchKernelGGL(k_solve_b, dim3(ub), dim3(SOLVE_NT), max_lds, st, d_desc, d_run);
+        hipLaunchKernelGGL(k_backsub_b, dim3((unsigned) alva_divup(max_pt, 4), ub), blk, 0, st, d_desc, d_run);
+        hipLaunchKernelGGL(k_update_b, dim3(ub), blk, 0, st, d_desc, d_run);
+        ALVA_LAUNCH_CHECK();
+        rc = eval(2);
+        if (rc) return rc;
+        rc = read_scal();
+        if (rc) return rc;
+        for (int b = 0; b < count; b++) {
+            BaHost &H = Hs[(size_t) b];
+            if (!h_run[b].step) continue;
+            if (H.advance(h_scal + 8 * (size_t) b, function_tolerance)) H.done = true;
+        }
+    }
+    // results: per problem chi2 | depth, poses, point parameters -> the (free again) input staging area
+    {
+        size_t roff = 0;
+        std::vector<size_t> o_chi((size_t) count), o_pose((size_t) count), o_pts((size_t) count);
+        for (int b = 0; b < count; b++) {
+            BaHost &H = Hs[(size_t) b];
+            o_chi[(size_t) b] = roff;
+            ALVA_HIP(hipMemcpyAsync(pin + p_stage + roff, H.B.chi2, H.chi_bytes(), hipMemcpyDeviceToHost, st));
+            roff += (H.chi_bytes() + 255) / 256 * 256;
+            o_pose[(size_t) b] = roff;
+            ALVA_HIP(hipMemcpyAsync(pin + p_stage + roff, H.xp, (size_t) n_kf[b] * 56, hipMemcpyDeviceToHost, st));
+            roff += ((size_t) n_kf[b] * 56 + 255) / 256 * 256;
+            o_pts[(size_t) b] = roff;
+            ALVA_HIP(hipMemcpyAsync(pin + p_stage + roff, H.xt, (size_t) H.B.npd * 8, hipMemcpyDeviceToHost, st));
+            roff += ((size_t) H.B.npd * 8 + 255) / 256 * 256;
+        }
+        ALVA_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < count; b++) {
+            BaHost &H = Hs[(size_t) b];
+            H.finish(ins[(size_t) b], pin + p_stage + o_chi[(size_t) b], (const double *) (pin + p_stage + o_pose[(size_t) b]),
+                     (const double *) (pin + p_stage + o_pts[(size_t) b]), h_chi2 ? h_chi2[b] : nullptr, h_depth_pos ? h_depth_pos[b] : nullptr,
+                     h_info ? h_info + 4 * (size_t) b : nullptr);
+            h_ok[b] = H.ok;
+        }
     }
     return ALVA_OK;
 }

@@ -256,7 +256,7 @@ def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5)
             "poses_accepted": accepted, "frames": n_streams * steps}
 
 
-def bench_720p(device: int, reps: int = 50):
+def bench_720p(device: int, reps: int = 50, valu_peak_tops: float | None = None):
     """BASELINE configs[2]: 1280x720, ORB extract 4000 kp/frame + brute-force Hamming match (secondary line)."""
     import alvaar_amd
     from alvaar_amd import synth, capi
@@ -290,8 +290,15 @@ def bench_720p(device: int, reps: int = 50):
     kt = capi.kernel_times(step, 20)
     P2 = w * h
     algb = {"k_fast_nms": 3.27 * P2, "k_blur7_batch": 2 * 3.27 * P2, "k_bf_partial": 32 * 2 * step.n + 8 * step.n * ((step.n + 63) // 64)}
+    ham = None
+    if "k_bf_partial" in kt and valu_peak_tops:
+        ops = 24.0 * step.n * step.n           # per pair 8 xor + 8 popcount + 8 add on 32-bit words
+        us = kt["k_bf_partial"][1]
+        ham = {"kernel": "k_bf_partial", "ops": ops, "avg_us": round(us, 2), "achieved_Tops": round(ops / (us * 1e-6) / 1e12, 2),
+               "peak_Tops_measured": round(valu_peak_tops, 1), "valu_frac": ops / (us * 1e-6) / 1e12 / valu_peak_tops,
+               "note": "integer VALU bound, not HBM (288 KB of descriptors); queries live in registers, 64 train rows per LDS tile, no cross-lane reduction"}
     return {"workload": "configs[2]: 1280x720, cv::ORB detectAndCompute(4000, 1.2, 8) + BFMatcher(HAMMING) vs the previous frame",
-            "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "keypoints": int(step.n),
+            "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "keypoints": int(step.n), "hamming_valu": ham,
             "kernels": {k: {"avg_us": round(v[1], 2), "launches_per_frame": round(v[0] / 20, 2),
                             **({"GBps": round(algb[k] / (v[1] * 1e-6) / 1e9, 1)} if k in algb else {})}
                         for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8]}}
@@ -309,7 +316,99 @@ def bench_ba(ctx, reps: int = 3):
     iters = int(r["info"][0]) - 1
     return dict(residual_blocks=nobs, lm_iterations=iters, ms_per_solve=dt * 1e3,
                 residual_block_iters_per_s=nobs * iters / dt, final_cost=float(r["info"][2]),
-                note="whole alva_local_ba call incl. host structure build, H2D of the problem and D2H of results"), pb
+                note="whole alva_local_ba call incl. host structure build, H2D of the problem and D2H of results; the synthetic problem of "
+                     "SURVEY.md 8(d) converges by function tolerance 0 after 4 accepted steps (5 iterations allowed)"), pb
+
+
+def bench_ba_batch(ctx, pb, peaks, problems: int = 64, reps: int = 3):
+    """SURVEY.md 8(d) "BA Schur reduce ... report a batched variant (>= 64 problems)": `problems` independent 20 KF x 3000 pts local-BA
+    problems through alva_local_ba_batch (one set of launches per LM iteration for all of them; every problem bit-identical to its own
+    alva_local_ba).  The problems are the SURVEY instance with independently perturbed inverse depths and observations."""
+    from alvaar_amd import capi
+    rng = np.random.RandomState(5)
+    pbs = []
+    for b in range(problems):
+        q = dict(pb)
+        q["inv_depth"] = pb["inv_depth"] * (1.0 + 1e-3 * rng.randn(len(pb["inv_depth"])))
+        q["obs_uv"] = pb["obs_uv"] + 0.05 * rng.randn(*np.asarray(pb["obs_uv"]).shape)
+        pbs.append(q)
+    ctx.local_ba_batch(pbs, 5, 0.0)   # warm (scratch allocation)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = ctx.local_ba_batch(pbs, 5, 0.0)
+    dt = (time.perf_counter() - t0) / reps
+    kt = capi.kernel_times(lambda: ctx.local_ba_batch(pbs, 5, 0.0), 1)
+    nobs = len(pb["obs_kf"])
+    iters = [int(r["info"][0]) - 1 for r in res]
+    work = nobs * sum(iters)
+    nfree = int((np.asarray(pb["kf_const"]) == 0).sum())
+    m = ((6 * nfree + 1 + 15) // 16) * 16
+    out = dict(problems=problems, residual_blocks_per_problem=nobs, lm_iterations=iters[:4] + ["..."], ms_per_batch=dt * 1e3,
+               residual_block_iters_per_s=work / dt, kernel_us_per_batch=round(sum(c * u for c, u in kt.values()), 1), kernels={})
+    for name, (calls, us) in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8]:
+        e = {"launches": calls, "avg_us": round(us, 1)}
+        if name.startswith("k_gemm"):
+            fl = 2.0 * m * m * len(pb["anchor_kf"]) * problems
+            e.update(bound="mfma_f64", flops_per_launch=int(fl), achieved_TFLOPs=round(fl / (us * 1e-6) / 1e12, 2), peak_TFLOPs_measured=round(peaks[0], 1),
+                     frac_of_measured=fl / (us * 1e-6) / 1e12 / peaks[0])
+        if name.startswith("k_point"):
+            by = (60 + 112) * nobs * problems
+            e.update(bound="hbm", alg_bytes_per_launch=int(by), achieved_GBps=round(by / (us * 1e-6) / 1e9, 1), frac=by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        out["kernels"][name] = e
+    out["note"] = ("whole alva_local_ba_batch calls (host structure build of every problem, one upload, the LM loop with one scalar read-back per iteration, "
+                   "results back); launches above are per batch and cover all problems")
+    return out
+
+
+def measured_peaks(ctx):
+    """FP64 MFMA TFLOP/s and integer VALU Tops/s of this GPU (alva_microbench_peaks): the guide lists neither"""
+    import ctypes as C
+    from alvaar_amd.capi import lib, check
+    lib.alva_microbench_peaks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    a, b = C.c_double(0), C.c_double(0)
+    best = [0.0, 0.0]
+    for _ in range(3):
+        check(lib.alva_microbench_peaks(ctx.h, C.byref(a), C.byref(b)))
+        best = [max(best[0], a.value), max(best[1], b.value)]
+    return best
+
+
+def roofline_ba(ctx, pb, peaks):
+    """Roofline of the local-BA kernels on the 20 KF x 3000 pts problem: the per-point Jacobian kernel and the pair reduction against
+    HBM, the Schur-complement GEMM against the MEASURED FP64-MFMA ceiling (event-timed kernels over whole alva_local_ba calls)."""
+    from alvaar_amd import capi
+    reps = 3
+    kt = capi.kernel_times(lambda: ctx.local_ba(pb, 5, 0.0), reps)
+    nobs, npt = len(pb["obs_kf"]), len(pb["anchor_kf"])
+    nfree = int((np.asarray(pb["kf_const"]) == 0).sum())
+    m = ((6 * nfree + 1 + 15) // 16) * 16                      # reduced camera system + rhs column, padded to 16 x 16 MFMA tiles
+    out = {"problem": {"residual_blocks": nobs, "points": npt, "free_keyframes": nfree}, "kernels": {}}
+    alg = {
+        # per residual block and Jacobian evaluation (DESIGN.md section 4): 60 B in (2 observations + indices), 112 B stored (J_obs 2x6 + residual)
+        "k_point<true, true>": ("hbm", (60 + 112) * nobs),
+        "k_pairs": ("hbm", 112 * nobs + 27 * 8 * 400),
+        "k_gemm": ("mfma", 2.0 * m * m * npt),                    # G = Z'Z: [m x points] x [points x m], FP64
+    }
+    for k, (bound, work) in alg.items():
+        hit = [n for n in kt if n.startswith(k.split("<")[0])]
+        if not hit:
+            continue
+        calls, us = kt[hit[0]]
+        if bound == "hbm":
+            a = work / (us * 1e-6) / 1e9
+            out["kernels"][hit[0]] = {"bound": "hbm", "avg_us": round(us, 2), "launches_per_solve": calls / reps, "alg_bytes": int(work),
+                                      "achieved_GBps": round(a, 1), "peak_GBps": HBM_PEAK_GBS, "frac": a / HBM_PEAK_GBS}
+        else:
+            a = work / (us * 1e-6) / 1e12
+            out["kernels"][hit[0]] = {"bound": "mfma_f64", "avg_us": round(us, 2), "launches_per_solve": calls / reps, "flops": int(work),
+                                      "achieved_TFLOPs": round(a, 2), "peak_TFLOPs_measured": round(peaks[0], 1),
+                                      "peak_TFLOPs_spec": 78.6, "frac_of_measured": a / peaks[0]}
+    tot = sum(c / reps * u for c, u in kt.values())
+    out["kernel_us_per_solve"] = round(tot, 1)
+    out["largest"] = {n: round(c / reps * u, 1) for n, (c, u) in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:6]}
+    out["note"] = ("one 20 KF x 3000 pts problem cannot fill the chip: the reduced camera system is 109 x 109 and k_solve is a single-workgroup "
+                   "dependent chain; MFMA utilisation is reported against the measured v_mfma_f64_16x16x4_f64 ceiling (alva_microbench_peaks)")
+    return out
 
 
 def bench_batched_preprocess(device: int, cameras: int = 64, reps: int = 20):
@@ -583,7 +682,8 @@ def main():
     if rank == 0:
         fps = world * args.steps / dt
         stage_us = job.stage_times()
-        ba, _ = bench_ba(job.ctx)
+        ba, ba_pb = bench_ba(job.ctx)
+        peaks = measured_peaks(job.ctx)
         P = W * H
         # ---- roofline: per-KERNEL durations from HIP events recorded on each launch stream, over a further pass of the headline loop
         # (the events cost a few us per launch, so they stay out of the pass that gives `value`)
@@ -645,11 +745,15 @@ def main():
                                           "P3P -> PnP) through alva_frontend_track_ahead on three HIP streams with FIXED pose correspondences; an upper bound of "
                                           "stage throughput, not the reference's dataflow"},
             "local_ba": ba,
+            "roofline_ba": roofline_ba(job.ctx, ba_pb, peaks),
+            "local_ba_batch": bench_ba_batch(job.ctx, ba_pb, peaks) if world == 1 else None,
+            "measured_peaks": {"mfma_f64_TFLOPs": peaks[0], "valu_int32_Tops": peaks[1],
+                               "note": "alva_microbench_peaks: independent v_mfma_f64_16x16x4_f64 chains / xor-popcount-add chains on every SIMD"},
             "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
             "batched_preprocess": bench_batched_preprocess(local) if world == 1 else None,
             "track_mono_batch": [bench_track_mono_batch(local, c_) for c_ in (16, 64)] if world == 1 else None,
             "frame_step_batch": [bench_track_mono_batch(local, c_, detector=True) for c_ in (16, 64)] if world == 1 else None,
-            "config_1280x720": bench_720p(local) if world == 1 else None,
+            "config_1280x720": bench_720p(local, valu_peak_tops=peaks[1]) if world == 1 else None,
             "stage_us": stage_us,
             "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

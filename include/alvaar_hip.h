@@ -443,6 +443,23 @@ int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_
                   const double *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2,
                   double *h_chi2, uint8_t *h_depth_pos, double *h_info, int *h_ok);
 
+/* `count` independent local-BA problems (anchored inverse depth) with ONE set of launches per LM iteration: a rig's cameras or a
+ * server's sessions, each with its own keyframes / points / observations (ragged sizes).  Every kernel carries the problem in a grid
+ * dimension -- the reduced camera systems are factored on `count` compute units at once, the Schur-complement GEMMs form one grouped
+ * FP64-MFMA launch -- and the host reads ONE block of scalars per iteration and steps each problem's trust region separately (problems
+ * stop at different iterations).  Every problem's result is BIT-IDENTICAL to its own alva_local_ba call.  Arguments: arrays of
+ * `count` sizes / host pointers with alva_local_ba's meaning; h_calib[4] shared; h_info [count][4]; h_ok [count].  At most 23 free
+ * keyframes per problem (the reduced system is factored in LDS). */
+int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, double *const *h_poses, const uint8_t *const *h_kf_const,
+                        const double *h_calib, const int *n_pt, const int *const *h_pt_anchor_kf, const double *const *h_pt_anchor_uv,
+                        double *const *h_pt_param, const int *n_obs, const int *const *h_obs_kf, const int *const *h_obs_pt,
+                        const double *const *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2, double *const *h_chi2,
+                        uint8_t *const *h_depth_pos, double *h_info, int *h_ok);
+
+/* ---- measured ceilings for the roofline lines of bench.py (MI355X_MICROARCH.md lists neither): the FP64 matrix rate of
+ * v_mfma_f64_16x16x4_f64 in TFLOP/s and the plain integer VALU rate (xor / popcount-accumulate / add) in 1e12 lane-operations/s. */
+int alva_microbench_peaks(alva_ctx *ctx, double *h_tflops_mfma_f64, double *h_tops_valu_int);
+
 /* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
  * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist
  * (metres) whose descriptor is within max_hamming bits (smallest distance wins, earliest record on ties) -- the intent of

@@ -57,3 +57,26 @@ def test_local_ba_more_cameras_than_fit_in_lds(ctx, nkf, npt, seed):
     assert 6 * int((pb["kf_const"] == 0).sum()) > 136
     g = ctx.local_ba(pb, 5, 0.0)
     ba_compare(g, Orc.local_ba(pb, 5, 0.0))
+
+
+@pytest.mark.parametrize("sizes", [[(20, 3000, 42)], [(20, 3000, 42), (8, 400, 1), (12, 1500, 2), (5, 120, 3)], [(6 + (b % 9), 200 + 37 * b, 10 + b) for b in range(64)]])
+def test_local_ba_batch_bitwise_equal_to_single_solves(ctx, sizes):
+    """alva_local_ba_batch: B ragged problems with one set of launches per LM iteration; every problem's poses, points, chi2 / depth flags
+    and LM bookkeeping (summaries, accepted steps, costs) are BIT-IDENTICAL to its own alva_local_ba call.  Problems stop at different
+    iterations (function tolerance 1e-3, as Optimizer::localBA sets it)."""
+    from alvaar_amd import synth
+    # alternating noise levels: problems converge after different numbers of iterations
+    pbs = [synth.make_ba_problem(k, n, s, pose_noise=(0.0002 if i % 3 == 0 else 0.02), invdepth_noise=(0.001 if i % 3 == 0 else 0.05)) for i, (k, n, s) in enumerate(sizes)]
+    for ftol, iters in ((1e-3, 5), (0.0, 5)):
+        single = [ctx.local_ba(pb, iters, ftol) for pb in pbs]
+        batch = ctx.local_ba_batch(pbs, iters, ftol)
+        stops = set()
+        for a, b in zip(single, batch):
+            assert a["ok"] == b["ok"]
+            assert np.array_equal(a["info"][:4], b["info"])
+            assert np.array_equal(a["poses"].view(np.uint64), b["poses"].view(np.uint64))
+            assert np.array_equal(a["pts"].view(np.uint64), b["pts"].view(np.uint64))
+            assert np.array_equal(a["chi2"].view(np.uint64), b["chi2"].view(np.uint64)) and np.array_equal(a["depth"], b["depth"])
+            stops.add(int(a["info"][0]))
+        if len(sizes) > 8 and ftol > 0:
+            assert len(stops) > 1     # the batch really is ragged in iterations too
