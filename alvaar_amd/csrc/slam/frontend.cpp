@@ -3,6 +3,7 @@
 #include "slam.hpp"
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace alva_slam {
@@ -37,6 +38,8 @@ Slam::Slam(Stages *stages, const Camera &c, const Settings &s) : st(stages), cam
     cur->init(&cam, (size_t) cfg.cell_size);
     st->image_width_ = cam.width;
     st->image_height_ = cam.height;
+    const char *chk = std::getenv("ALVA_CHECK_OBS_MIRROR");
+    check_obs_mirror_ = chk && chk[0] == '1';
 }
 
 void Slam::reset() {  // System::reset (system.cpp:42-55)

@@ -4,6 +4,9 @@
 #include "slam.hpp"
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <limits>
 
 namespace alva_slam {
@@ -201,7 +204,7 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
     if (obs_kfs.empty()) {
         has_desc = false;
         kf_desc.clear();
-        kf_desc_dist.clear();
+        drop_all_desc();
         return;
     }
     if (kf == anchor_kf) anchor_kf = *obs_kfs.begin();
@@ -209,10 +212,10 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
     int min_id = -1;
     auto itd = kf_desc.find(kf);
     if (itd != kf_desc.end()) {
-        for (const auto &e: kf_desc) {
+        for (auto &e: kf_desc) {
             if (e.first != kf) {
-                const float dist = (float) popcount256(itd->second, e.second);
-                float &dd = kf_desc_dist.find(e.first)->second;
+                const float dist = (float) popcount256(itd->second.d, e.second.d);
+                float &dd = e.second.dist;
                 dd -= dist;
                 if (dd < min_dist) {
                     min_dist = dd;
@@ -220,10 +223,10 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
                 }
             }
         }
-        kf_desc.erase(kf);
-        kf_desc_dist.erase(kf);
+        kf_desc.erase(itd);
+        drop_desc(kf);
         if (min_id > 0) {  // sic: keyframe 0 is never chosen (:123)
-            desc = kf_desc.at(min_id);
+            desc = kf_desc.at(min_id).d;
             has_desc = true;
         }
     }
@@ -231,9 +234,8 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
 
 void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid)
     if (kf_desc.find(kf) != kf_desc.end()) return;
-    kf_desc.emplace(kf, d);
-    kf_desc_dist.emplace(kf, 0.f);
-    float &nd = kf_desc_dist.find(kf)->second;
+    DescEntry &mine = kf_desc.emplace(kf, DescEntry{d, 0.f}).first->second;
+    note_desc(kf, d);
     if (kf_desc.size() == 1) {
         desc = d;
         has_desc = true;
@@ -241,9 +243,10 @@ void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the des
     }
     float min_dist = (has_desc ? 32 : 0) * 8.f;
     int min_id = -1;
-    for (const auto &e: kf_desc) {
-        const float dist = (float) popcount256(d, e.second);
-        kf_desc_dist.at(e.first) += dist;
+    float &nd = mine.dist;
+    for (auto &e: kf_desc) {
+        const float dist = (float) popcount256(d, e.second.d);
+        e.second.dist += dist;   // includes the new entry itself (distance 0 to itself, :157-166)
         if (dist < min_dist) {
             min_dist = dist;
             min_id = e.first;
@@ -251,7 +254,7 @@ void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the des
         nd += dist;
     }
     if (nd < min_dist) min_id = kf;
-    desc = kf_desc.at(min_id);  // throws like the reference if no candidate (cannot happen with a non-empty desc_)
+    desc = kf_desc.at(min_id).d;  // throws like the reference if no candidate (cannot happen with a non-empty desc_)
     has_desc = true;
 }
 
@@ -394,8 +397,26 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     }
 }
 
+const ObsPx *Slam::obs_of(const MapPt &mp, int kfid) const {
+    const ObsPx *o = mp.seen_in(kfid);
+    if (o && !o->in_kf) o = nullptr;
+    if (check_obs_mirror_) {
+        const FrameRec *kf = kf_raw(kfid);
+        const KeyPt *kp = kf ? kf->find(mp.id) : nullptr;
+        if ((kp != nullptr) != (o != nullptr) || (kp && (std::memcmp(kp->px, o->px, 8) || std::memcmp(kp->unpx, o->unpx, 8)))) {
+            std::fprintf(stderr, "alva_slam: observation mirror out of sync (map point %d, keyframe %d)\n", mp.id, kfid);
+            std::abort();
+        }
+    }
+    return o;
+}
+
 void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of the current frame
     std::shared_ptr<FrameRec> kf = std::make_shared<FrameRec>(*cur);
+    for (const auto &e: kf->kps) {
+        MapPt *m = mp_raw(e.first);
+        if (m) m->note_px(next_kf_id, e.second);
+    }
     keyframes.emplace(next_kf_id, kf);
     if (kf_flat_.size() <= (size_t) next_kf_id) kf_flat_.resize((size_t) next_kf_id + 32, nullptr);
     kf_flat_[(size_t) next_kf_id] = kf.get();
@@ -417,7 +438,7 @@ void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) 
     if (it == map_points.end() || !it->second) return;
     MapPt &mp = *it->second;
     if (!mp.is3d) {
-        const std::set<int> obs = mp.obs_kfs;  // getObservedKeyframeIds returns a copy; removals below edit the member
+        const SortedIds obs = mp.obs_kfs;  // getObservedKeyframeIds returns a copy; removals below edit the member
         for (int kf: obs) {
             auto k = keyframes.find(kf);
             if (k != keyframes.end()) k->second->turn3d(id);
@@ -434,12 +455,14 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     auto pit = map_points.find(prev_id), nit = map_points.find(new_id);
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
-    const std::set<int> next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
-    const std::unordered_map<int, Desc> prev_desc = prev->kf_desc;
+    const SortedIds next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
+    const std::unordered_map<int, DescEntry> prev_desc = prev->kf_desc;
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;
         if (kf->second->change_id(prev_id, new_id, nw->is3d)) {
+            prev->drop_px(pk);
+            nw->note_px(pk, *kf->second->find(new_id));
             nw->obs_kfs.insert(pk);
             for (int nk: next_kfs) {
                 auto co = keyframes.find(nk);
@@ -450,7 +473,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
             }
         }
     }
-    for (const auto &e: prev_desc) nw->add_desc(e.first, e.second);
+    for (const auto &e: prev_desc) nw->add_desc(e.first, e.second.d);
     if (cur->observes(prev_id)) {
         if (cur->change_id(prev_id, new_id, nw->is3d)) set_map_point_obs(new_id);
     }
@@ -465,7 +488,10 @@ void Slam::remove_keyframe(int kfid) {  // map_manager.cpp:515-557
     if (it == keyframes.end()) return;
     for (const auto &e: it->second->kps) {  // the body edits map points only
         MapPt *m = mp_raw(e.first);
-        if (m) m->remove_obs(kfid);
+        if (m) {
+            m->remove_obs(kfid);
+            m->drop_px(kfid);
+        }
     }
     for (const auto &c: it->second->covisible) {
         auto co = keyframes.find(c.first);
@@ -480,7 +506,7 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     auto it = map_points.find(id);
     if (it == map_points.end()) return;
     std::shared_ptr<MapPt> mp = it->second;
-    const std::set<int> obs = mp->obs_kfs;
+    const SortedIds obs = mp->obs_kfs;
     for (int kf: obs) {
         auto k = keyframes.find(kf);
         if (k == keyframes.end()) continue;
@@ -491,6 +517,7 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     if (mp->observed) cur->remove(id);
     if (mp->is3d) n_map_points--;
     mp_flat_[(size_t) id] = nullptr;
+    if (defer_mp_free_) mp_graveyard_.push_back(mp);
     map_points.erase(it);
 }
 
@@ -499,9 +526,10 @@ void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-6
     if (kf != keyframes.end()) kf->second->remove(mp_id);
     auto m = map_points.find(mp_id);
     if (m == map_points.end()) return;
+    m->second->drop_px(kfid);
     m->second->remove_obs(kfid);
     if (kf != keyframes.end()) {
-        const std::set<int> obs = m->second->obs_kfs;
+        const SortedIds obs = m->second->obs_kfs;
         for (int co: obs) {
             auto c = keyframes.find(co);
             if (c != keyframes.end()) {
@@ -531,6 +559,10 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
     std::unordered_set<int> local_ids;
     ids_scratch_.clear();  // snapshot: the repair branch below edits frame.kps
     for (const auto &e: frame.kps) ids_scratch_.push_back(e.first);
+    // the counts of the reference's std::map<int, int> (:92-103) accumulated in a flat table (keyframe ids are small consecutive
+    // integers) and poured into the ordered map afterwards: a std::map's content and order do not depend on how it was filled
+    std::vector<int> &count = index_scratch_;
+    count.assign((size_t) next_kf_id + 2, 0);
     for (int id: ids_scratch_) {
         MapPt *m = mp_raw(id);
         if (!m) {
@@ -538,14 +570,14 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
             remove_obs_from_cur(id);
             continue;
         }
-        for (int kf: m->obs_kfs) {
+        for (int kf: m->obs_kfs)
             if (kf != frame.kfid) {
-                auto c = cov.find(kf);
-                if (c != cov.end()) c->second += 1;
-                else cov.emplace(kf, 1);
+                if (kf >= 0 && kf <= next_kf_id) count[(size_t) kf]++;
+                else cov[kf] += 1;
             }
-        }
     }
+    for (int kf = 0; kf <= next_kf_id; kf++)
+        if (count[(size_t) kf]) cov[kf] += count[(size_t) kf];
     std::set<int> bad;
     // marks: a = observed by `frame`, b = already in local_ids (see slam.hpp)
     mark_a_.resize((size_t) next_mp_id + 1, 0);

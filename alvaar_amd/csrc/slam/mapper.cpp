@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory_resource>
 
 namespace alva_slam {
 
@@ -163,12 +166,10 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     for (const auto &e: keyframes) kf_ids.push_back(e.first);
     std::sort(kf_ids.begin(), kf_ids.end());
     std::vector<int> kf_index((size_t) next_kf_id + 1, -1);
-    std::vector<const FrameRec *> kf_obj((size_t) next_kf_id + 1, nullptr);
     std::vector<double> kf_q, kf_t;
     for (size_t i = 0; i < kf_ids.size(); i++) {
         kf_index[(size_t) kf_ids[i]] = (int) i;
         const FrameRec &k = *keyframes.at(kf_ids[i]);
-        kf_obj[(size_t) kf_ids[i]] = &k;
         kf_q.insert(kf_q.end(), k.Tcw.q, k.Tcw.q + 4);
         kf_t.insert(kf_t.end(), k.Tcw.t, k.Tcw.t + 3);
     }
@@ -176,14 +177,15 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     const int frame_kf_index = kf_index[(size_t) frame.kfid];
     // map point table: the frame's keypoints first (grid order), then the local map in ITS iteration order
     std::vector<int> mp_ids;
-    std::unordered_map<int, int> mp_index;
+    std::vector<int> &mp_index = index_scratch_;  // id -> row of the table (ids are dense)
+    mp_index.assign((size_t) next_mp_id + 1, -1);
     auto intern = [&](int id) {
-        auto it = mp_index.find(id);
-        if (it != mp_index.end()) return it->second;
-        const int idx = (int) mp_ids.size();
-        mp_index.emplace(id, idx);
-        mp_ids.push_back(id);
-        return idx;
+        int &slot = mp_index[(size_t) id];
+        if (slot < 0) {
+            slot = (int) mp_ids.size();
+            mp_ids.push_back(id);
+        }
+        return slot;
     };
     std::vector<int> cell_ptr(frame.grid.size() + 1, 0), cell_mp;
     for (size_t c = 0; c < frame.grid.size(); c++) {
@@ -191,8 +193,9 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
         for (int id: frame.grid[c]) {
             // getSurroundingKeypoints keeps ids found in mapKeypoints_ (frame.cpp:333-337); a keypoint whose map point is gone is
             // repaired by the reference on contact (:459-463) -- repaired here up front
-            if (!frame.find(id)) continue;
-            if (!mp_raw(id)) continue;
+            const MapPt *gm = mp_raw(id);
+            if (!gm) continue;
+            if (!obs_of(*gm, frame.kfid)) continue;
             cell_mp.push_back(intern(id));
         }
     }
@@ -225,16 +228,22 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
         obs_ptr[(size_t) m] = (int) obs_kf.size();
         for (int kf: mp.obs_kfs) {
             if (kf < 0 || kf > next_kf_id || kf_index[(size_t) kf] < 0) continue;
-            const KeyPt *kk = kf_obj[(size_t) kf]->find(mp.id);
+            const ObsPx *kk = obs_of(mp, kf);
             if (!kk) continue;
             obs_kf.push_back(kf_index[(size_t) kf]);
             obs_px.push_back(kk->px[0]);
             obs_px.push_back(kk->px[1]);
             // one 32-byte slot per observation; keyframes in which the keypoint could not be described (within 31 px of the border,
             // feature_extractor.cpp:191-209) have no entry in mapKeyframeDescriptors_: slot zeroed and flagged
-            auto d = mp.kf_desc.find(kf);
-            if (d != mp.kf_desc.end()) {
-                obs_desc.insert(obs_desc.end(), d->second.b, d->second.b + 32);
+            if (check_obs_mirror_) {
+                auto d = mp.kf_desc.find(kf);
+                if ((d != mp.kf_desc.end()) != (kk->has_desc != 0) || (kk->has_desc && std::memcmp(d->second.d.b, kk->desc.b, 32))) {
+                    std::fprintf(stderr, "alva_slam: descriptor mirror out of sync (map point %d, keyframe %d)\n", mp.id, kf);
+                    std::abort();
+                }
+            }
+            if (kk->has_desc) {
+                obs_desc.insert(obs_desc.end(), kk->desc.b, kk->desc.b + 32);
                 obs_has_desc.push_back(1);
             } else {
                 obs_desc.insert(obs_desc.end(), 32, (uint8_t) 0);
@@ -304,15 +313,28 @@ void Slam::local_ba(FrameRec &new_frame) {
     if ((int) new_frame.n_3d < min_cov) return;
     Lap lap_ba;
     // ---- 1. problem (optimizer.cpp:20-247)
-    std::unordered_map<int, std::shared_ptr<MapPt>> local_mps;      // map_local_plms
-    std::unordered_map<int, std::shared_ptr<FrameRec>> local_kfs;   // map_local_pkfs
+    // The function-local hash containers of the reference live in a bump arena: same container code, same hash, same growth policy
+    // => same iteration order; only where the nodes come from differs.  Map points removed during the write-back stay allocated
+    // until the end of the call (the reference's local shared_ptr copies do the same), so the table can hold plain pointers.
+    if (ba_arena_.size() < ((size_t) 4 << 20)) ba_arena_.resize((size_t) 4 << 20);
+    std::pmr::monotonic_buffer_resource arena(ba_arena_.data(), ba_arena_.size());
+    struct Undefer {
+        Slam *s;
+        ~Undefer() {
+            s->defer_mp_free_ = false;
+            s->mp_graveyard_.clear();
+        }
+    } undefer{this};
+    defer_mp_free_ = true;
+    std::pmr::unordered_map<int, MapPt *> local_mps(&arena);                      // map_local_plms
+    std::pmr::unordered_map<int, std::shared_ptr<FrameRec>> local_kfs(&arena);    // map_local_pkfs
     // keyframe id -> row of the flat pose table / keyframe object: ids are small consecutive integers, so plain arrays beside the
     // reference's hash maps (which stay, because their iteration ORDER is behaviour, :234-247)
     std::vector<int> pose_slot((size_t) next_kf_id + 1, -1);
     std::vector<FrameRec *> kf_flat((size_t) next_kf_id + 1, nullptr);
     std::vector<double> poses;
     std::vector<uint8_t> kf_const;
-    std::unordered_set<int> bad_mps, mps_to_opt, kfs_to_opt, const_kfs;
+    std::pmr::unordered_set<int> bad_mps(&arena), mps_to_opt(&arena), kfs_to_opt(&arena), const_kfs(&arena);
     auto add_pose = [&](int kfid, const FrameRec &kf, bool constant) {
         pose_slot[(size_t) kfid] = (int) kf_const.size();
         double p[7];
@@ -359,9 +381,9 @@ void Slam::local_ba(FrameRec &new_frame) {
     std::vector<int> pt_ids, pt_anchor_slot, obs_kf, obs_pt;
     std::vector<double> pt_anchor_uv, pt_inv, obs_uv;
     std::vector<ObsRec> obs_rec;
-    std::unordered_map<int, int> pt_slot;  // map_id_invptspar_
+    std::pmr::unordered_map<int, int> pt_slot(&arena);  // map_id_invptspar_
     for (int lmid: mps_to_opt) {
-        std::shared_ptr<MapPt> mp = map_point(lmid);
+        MapPt *mp = mp_raw(lmid);
         if (!mp) continue;
         if (mp->is_bad()) {
             bad_mps.insert(lmid);
@@ -385,7 +407,7 @@ void Slam::local_ba(FrameRec &new_frame) {
                 add_pose(kfid, *kf, true);
                 const_kfs.insert(kfid);
             }
-            const KeyPt *kp = kf->find(lmid);
+            const ObsPx *kp = obs_of(*mp, kfid);
             if (!kp) {
                 remove_map_point_obs(lmid, kfid);
                 continue;
@@ -500,7 +522,7 @@ void Slam::local_ba(FrameRec &new_frame) {
     }
     for (const auto &e: local_mps) {
         const int lmid = e.first;
-        const std::shared_ptr<MapPt> &mp = e.second;
+        MapPt *mp = e.second;
         if (!mp) {
             bad_mps.erase(lmid);
             continue;
@@ -535,7 +557,7 @@ void Slam::local_ba(FrameRec &new_frame) {
         }
         {
             const FrameRec &akf = *akp;
-            const KeyPt *kp = akf.find(lmid);
+            const ObsPx *kp = obs_of(*mp, akf.kfid);
             const float ux = kp ? kp->unpx[0] : 0.f, uy = kp ? kp->unpx[1] : 0.f;  // a default Keypoint has unpx_ = (0, 0)
             const double uv[3] = {(double) ux, (double) uy, 1.};
             double ray[3], pc[3], wpt[3];
@@ -549,9 +571,8 @@ void Slam::local_ba(FrameRec &new_frame) {
     }
     lap_ba(t_kf[13]);
     for (int lmid: bad_mps) {  // :492-530
-        std::shared_ptr<MapPt> mp;
         auto lm = local_mps.find(lmid);
-        mp = lm == local_mps.end() ? map_point(lmid) : lm->second;
+        MapPt *mp = lm == local_mps.end() ? mp_raw(lmid) : lm->second;
         if (!mp) continue;
         if (mp->is_bad()) {
             remove_map_point(lmid);

@@ -88,30 +88,128 @@ struct FrameRec {
     void reset();
 };
 
+// std::set<int> as the map layer uses it (insert / erase / count / ordered walk / copy), on a sorted vector.  A std::set<int> walks its
+// keys in ascending order whatever the insertion history, so this is the same container behaviour without a tree node per key.
+struct SortedIds {
+    std::vector<int> v;
+    typedef std::vector<int>::const_iterator const_iterator;
+    const_iterator begin() const { return v.begin(); }
+    const_iterator end() const { return v.end(); }
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+    size_t count(int k) const {
+        for (int x: v)
+            if (x == k) return 1;
+        return 0;
+    }
+    void insert(int k) {
+        size_t i = v.size();
+        while (i > 0 && v[i - 1] > k) i--;
+        if (i > 0 && v[i - 1] == k) return;
+        v.insert(v.begin() + (long) i, k);
+    }
+    void erase(int k) {
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i] == k) {
+                v.erase(v.begin() + (long) i);
+                return;
+            }
+    }
+};
+
+// What one keyframe holds about a map point, gathered in one place: the keypoint with the point's id as the KEYFRAME stores it
+// (in_kf; pixels of a keyframe's keypoints never change after the copy of map_manager.cpp:243-252) and the descriptor the point
+// keeps for that keyframe (has_desc; mapKeyframeDescriptors_).  MapPt::seen mirrors both so that the flattening loops of
+// matchToMap / localBA read an observation from one contiguous record instead of a hash look-up into the keyframe and one into
+// the descriptor map.  Not behaviour: the keyframes and kf_desc stay authoritative, every edit of a KEYFRAME's mapKeypoints_
+// (the copy, removeKeypointById, the id change of mergeMapPoints, removeKeyframe) and of kf_desc updates the mirror, and
+// ALVA_CHECK_OBS_MIRROR=1 compares every read with the authoritative containers.
+struct ObsPx {
+    int kf = -1;
+    uint8_t in_kf = 0, has_desc = 0;
+    float px[2] = {0, 0}, unpx[2] = {0, 0};
+    Desc desc{};
+};
+
+struct DescEntry {
+    Desc d;
+    float dist;
+};
+
 // class MapPoint, map_point.hpp:27-86
 struct MapPt {
     int id = -1;
     bool observed = true, is3d = false;
-    std::set<int> obs_kfs;                       // observedKeyframeIds_
+    SortedIds obs_kfs;                           // observedKeyframeIds_ (std::set<int>)
     double X[3] = {0, 0, 0};
     int anchor_kf = -1;                          // keyframeId_
     double inv_depth = -1.;
     Desc desc{};
     bool has_desc = false;                       // !desc_.empty()
-    std::unordered_map<int, Desc> kf_desc;       // mapKeyframeDescriptors_
-    std::unordered_map<int, float> kf_desc_dist; // mapDescriptorsDist_
+    // mapKeyframeDescriptors_ and mapDescriptorsDist_ in one table: the reference edits the two unordered_maps together (same keys,
+    // same sequence => same iteration order), reads the distances by key only, and walks the descriptors -- this walk's order
+    std::unordered_map<int, DescEntry> kf_desc;
+    std::vector<ObsPx> seen;                     // see ObsPx
 
     MapPt(int id_, int kf) : id(id_), anchor_kf(kf) { obs_kfs.insert(kf); }
     MapPt(int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf) {
         obs_kfs.insert(kf);
-        kf_desc.emplace(kf, d);
-        kf_desc_dist.emplace(kf, 0.f);
+        kf_desc.emplace(kf, DescEntry{d, 0.f});
+        note_desc(kf, d);
         desc = d;
         has_desc = true;
     }
     void remove_obs(int kf);
     void add_desc(int kf, const Desc &d);
     bool is_bad();
+
+    ObsPx *seen_in(int kf) {
+        for (ObsPx &o: seen)
+            if (o.kf == kf) return &o;
+        return nullptr;
+    }
+    const ObsPx *seen_in(int kf) const { return const_cast<MapPt *>(this)->seen_in(kf); }
+    ObsPx &seen_slot(int kf) {
+        ObsPx *o = seen_in(kf);
+        if (o) return *o;
+        seen.emplace_back();
+        seen.back().kf = kf;
+        return seen.back();
+    }
+    void seen_prune(ObsPx *o) {
+        if (o->in_kf || o->has_desc) return;
+        *o = seen.back();
+        seen.pop_back();
+    }
+    void note_px(int kf, const KeyPt &k) {
+        ObsPx &o = seen_slot(kf);
+        o.in_kf = 1;
+        o.px[0] = k.px[0]; o.px[1] = k.px[1];
+        o.unpx[0] = k.unpx[0]; o.unpx[1] = k.unpx[1];
+    }
+    void drop_px(int kf) {
+        ObsPx *o = seen_in(kf);
+        if (!o) return;
+        o->in_kf = 0;
+        seen_prune(o);
+    }
+    void note_desc(int kf, const Desc &d) {
+        ObsPx &o = seen_slot(kf);
+        o.has_desc = 1;
+        o.desc = d;
+    }
+    void drop_desc(int kf) {
+        ObsPx *o = seen_in(kf);
+        if (!o) return;
+        o->has_desc = 0;
+        seen_prune(o);
+    }
+    void drop_all_desc() {
+        for (size_t i = seen.size(); i-- > 0;) {
+            seen[i].has_desc = 0;
+            seen_prune(&seen[i]);
+        }
+    }
 };
 
 struct InitOverride {  // test hook, see alva_system_debug_set_init_pose
@@ -167,7 +265,7 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
-    std::vector<int> ids_scratch_, obs_scratch_;
+    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_;
     // flat "seen" marks over map point ids (ids are dense, handed out consecutively): inserting a key that is already in a hash set does
     // not change the set, so duplicate inserts are filtered with a byte look-up instead of a hash look-up
     std::vector<uint8_t> mark_a_, mark_b_;
@@ -208,6 +306,11 @@ private:
     MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
     std::vector<FrameRec *> kf_flat_;
     std::vector<MapPt *> mp_flat_;
+    bool check_obs_mirror_ = false;
+    std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
+    bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
+    std::vector<std::shared_ptr<MapPt>> mp_graveyard_;
+    const ObsPx *obs_of(const MapPt &mp, int kfid) const;   // the keypoint of `mp` in keyframe `kfid` (null: that keyframe holds none)
 
     // Mapper
     void process_new_keyframe(int kfid);
