@@ -20,6 +20,7 @@
 // This translation unit must be compiled with -ffp-contract=off.
 #include "common.hpp"
 #include "wave_utils.hpp"
+#include "track_slots.hpp"
 #include <cstdlib>
 
 namespace {
@@ -248,6 +249,39 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     __syncthreads();  // LDS reuse by the next level
 }
 
+// The verdict of FeatureTracker::fbKltTracking on one keypoint after its forward pass (feature_tracker.cpp:48-103): status,
+// err (min eigenvalue) <= errThresh, inBorder(level-0 size), then the backward pass on level 0 and the forward-backward distance.
+__device__ __forceinline__ int fbklt_gate(LkShared &sh, const LkPyr &P, const LkPyr &C, int maxCount, double epsilon, float errThresh,
+                                          float fbDist, float ptx, float pty, float nx, float ny, int status, float err) {
+    int ok = status && !(err > errThresh);
+    const float fw = (float) C.lv[0].w, fh = (float) C.lv[0].h;
+    ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
+    if (ok) {
+        // backward LK on level 0 only, initial flow = the original point (:84-87)
+        float bx = ptx, by = pty;
+        int st2 = 1;
+        float err2 = 0.f;
+        lk_level(sh, C.lv[0], P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, nx, ny, bx, by, st2, err2);
+        if (!st2) ok = 0;
+        else {
+            const float ddx = ptx - bx, ddy = pty - by;
+            const double nrm = sqrt((double) ddx * (double) ddx + (double) ddy * (double) ddy);  // cv::norm(Point2f), :103
+            if (nrm > (double) fbDist) ok = 0;
+        }
+    }
+    return ok;
+}
+
+// fbKltTracking of one keypoint given by value: (nx, ny) is the prior on entry and the tracked position on return
+__device__ __forceinline__ int fbklt_value(LkShared &sh, const LkPyr &P, const LkPyr &C, int maxLevel, int maxCount, double epsilon,
+                                           float errThresh, float fbDist, float ptx, float pty, float &nx, float &ny) {
+    int status = 1;
+    float err = 0.f;
+    for (int level = maxLevel; level >= 0; level--)
+        lk_level(sh, P.lv[level], C.lv[level], level, maxLevel, maxCount, epsilon, 1e-4f, ptx, pty, nx, ny, status, err);
+    return fbklt_gate(sh, P, C, maxCount, epsilon, errThresh, fbDist, ptx, pty, nx, ny, status, err);
+}
+
 // One keypoint through the whole pyramid (all arguments wave-uniform).
 // mode 0: plain calcOpticalFlowPyrLK (next in/out, status, err).
 // mode 1: FeatureTracker::fbKltTracking (prior in/out, status).
@@ -269,23 +303,7 @@ __device__ __forceinline__ void klt_point(LkShared &sh, const LkPyr &P, const Lk
         }
         return;
     }
-    // feature_tracker.cpp:48-73: gate on status, err (min eigenvalue) <= errThresh, inBorder(level-0 size)
-    int ok = status && !(err > errThresh);
-    const float fw = (float) C.lv[0].w, fh = (float) C.lv[0].h;
-    ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
-    if (ok) {
-        // backward LK on level 0 only, initial flow = the original point (:84-87)
-        float bx = ptx, by = pty;
-        int st2 = 1;
-        float err2 = 0.f;
-        lk_level(sh, C.lv[0], P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, nx, ny, bx, by, st2, err2);
-        if (!st2) ok = 0;
-        else {
-            const float ddx = ptx - bx, ddy = pty - by;
-            const double nrm = sqrt((double) ddx * (double) ddx + (double) ddy * (double) ddy);  // cv::norm(Point2f), :103
-            if (nrm > (double) fbDist) ok = 0;
-        }
-    }
+    const int ok = fbklt_gate(sh, P, C, maxCount, epsilon, errThresh, fbDist, ptx, pty, nx, ny, status, err);
     if (threadIdx.x == 0) {
         nextio[2 * kp] = nx;
         nextio[2 * kp + 1] = ny;
@@ -316,6 +334,100 @@ __global__ void __launch_bounds__(64) k_klt_dn(LkPyr P, LkPyr C, int mode, int m
     const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (kp >= *d_n) return;
     klt_point(sh, P, C, mode, maxLevel, maxCount, epsilon, errThresh, fbDist, pts, init, nextio, status_out, nullptr, kp);
+}
+
+// ---- the tracking step of one frame, one workgroup per slot of the frame container (track_slots.hpp) ----------------------------
+// per-slot results of a finished slot: Frame::computeKeypoint (frame.cpp:105-113) for a tracked one, zeros for a lost one
+__device__ __forceinline__ void track_slot_store(const TrackSlots &D, int i, int code, float nx, float ny) {
+    float ux = 0.f, uy = 0.f;
+    double bv[3] = {0., 0., 0.};
+    if (code) {
+        alva_undistort_dev(D.cam, nx, ny, ux, uy);
+        alva_bearing_dev(D.invK, ux, uy, bv);
+    } else {
+        nx = 0.f;
+        ny = 0.f;
+    }
+    if (threadIdx.x == 0) {
+        D.d_code[i] = (uint8_t) code;
+        D.d_unpx[2 * i] = ux; D.d_unpx[2 * i + 1] = uy;
+        D.d_bv[3 * (size_t) i] = bv[0]; D.d_bv[3 * (size_t) i + 1] = bv[1]; D.d_bv[3 * (size_t) i + 2] = bv[2];
+        D.o_code[i] = (uint8_t) code;
+        D.o_px[2 * i] = nx; D.o_px[2 * i + 1] = ny;
+        D.o_unpx[2 * i] = ux; D.o_unpx[2 * i + 1] = uy;
+        D.o_bv[3 * (size_t) i] = bv[0]; D.o_bv[3 * (size_t) i + 1] = bv[1]; D.o_bv[3 * (size_t) i + 2] = bv[2];
+    }
+}
+
+// the frame's slot table (positions, 3-D flags, world points) from pinned host memory into device memory, 16 bytes per lane
+__global__ void __launch_bounds__(256) k_track_stage_in(TrackSlots D) {
+    const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t) D.n, q_px = (n * 8 + 15) / 16, q_3d = (n + 15) / 16, q_w = (n * 24 + 15) / 16;
+    const uint4 *src;
+    uint4 *dst;
+    size_t k;
+    if (t < q_px) {
+        src = (const uint4 *) D.in_px; dst = (uint4 *) D.d_pts; k = t;
+    } else if (t < q_px + q_3d) {
+        src = (const uint4 *) D.in_is3d; dst = (uint4 *) D.d_is3d; k = t - q_px;
+    } else if (t < q_px + q_3d + q_w) {
+        src = (const uint4 *) D.in_wpt; dst = (uint4 *) D.d_wpt; k = t - q_px - q_3d;
+    } else return;
+    dst[k] = src[k];
+}
+
+__global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D, int maxLevelPrior, int maxLevelFull, int maxCount,
+                                                  double epsilon, float errThresh, float fbDist) {
+    __shared__ LkShared sh;
+    const int per = gridDim.x >> 3;
+    const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (i >= D.n) return;
+    const float px = D.d_pts[2 * i], py = D.d_pts[2 * i + 1];
+    const int is3 = D.d_is3d[i];
+    double X[3] = {0., 0., 0.};
+    if (is3) {
+        X[0] = D.d_wpt[3 * (size_t) i]; X[1] = D.d_wpt[3 * (size_t) i + 1]; X[2] = D.d_wpt[3 * (size_t) i + 2];
+    }
+    bool from_prior = false;
+    float nx = px, ny = py;
+    if (D.use_prior && is3) {  // visual_frontend.cpp:125-152: project under the predicted pose, keep it if it is inside the image
+        double pc[3];
+        float qu, qv;
+        alva_se3_apply_dev(D.q, D.t, X, pc);
+        alva_project_dist_dev(D.cam, pc[0], pc[1], pc[2], qu, qv);
+        from_prior = qu >= 0 && qv >= 0 && (double) qu < (double) D.width && (double) qv < (double) D.height;  // Frame::isInImage
+        if (from_prior) {
+            nx = qu;
+            ny = qv;
+        }
+    }
+    const int ok = fbklt_value(sh, P, C, from_prior ? maxLevelPrior : maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
+    if (threadIdx.x == 0 && from_prior) {
+        atomicAdd(D.cnt + 0, 1);
+        if (ok) atomicAdd(D.cnt + 1, 1);
+    }
+    int code = ok ? (from_prior ? 1 : 2) : 0;
+    if (from_prior && !ok) {  // full-pyramid retry from where the forward tracker left the keypoint (:185-190)
+        const int ok2 = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
+        code = ok2 ? 3 : 0;
+    }
+    if (threadIdx.x == 0) D.d_retried[i] = (uint8_t) (from_prior && !ok);
+    track_slot_store(D, i, code, nx, ny);
+}
+
+__global__ void __launch_bounds__(64) k_track_klt_retry(LkPyr P, LkPyr C, TrackSlots D, int maxLevelFull, int maxCount, double epsilon,
+                                                        float errThresh, float fbDist) {
+    __shared__ LkShared sh;
+    const int per = gridDim.x >> 3;
+    const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (i >= D.n) return;
+    if (!D.d_retried[i]) return;
+    const int nA = D.cnt[0], good = D.cnt[1];
+    if (!(nA > 0 && (double) good < 0.33 * (double) nA)) return;  // no p3pReq_: the retry of the first launch stands
+    const float px = D.d_pts[2 * i], py = D.d_pts[2 * i + 1];
+    float nx = px, ny = py;                                          // :193-203: every prior falls back to the keypoint's own position
+    const int ok = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
+    track_slot_store(D, i, ok ? 3 : 0, nx, ny);
 }
 
 // B cameras in one launch (fbKltTracking only): blockIdx.y = camera, each with its own pyramids, keypoint list and count.  The
@@ -895,6 +1007,32 @@ int alva_fbklt_track_dn(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyra
     epsilon *= epsilon;
     hipLaunchKernelGGL(k_klt_dn, dim3(8 * alva_divup(n_max, 8)), dim3(64), 0, ctx->stream, P, C, 1, maxLevel, maxCount, epsilon, err_thresh, fb_dist,
                        d_pts, d_prior_in, d_out, d_status, d_n);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+int alva_track_slots_klt(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, const TrackSlots &D, int levels_prior, int levels_full,
+                         float err_thresh, float fb_dist, int max_iters, float eps, int retry) {
+    ALVA_ARG(ctx && prev && curr && D.n >= 0 && levels_prior >= 0 && levels_full >= 0);
+    if (D.n == 0) return ALVA_OK;
+    ALVA_ARG(prev->win == WIN && curr->win == WIN);
+    ALVA_ARG(prev->nlevels == curr->nlevels && prev->lv[0].w == curr->lv[0].w && prev->lv[0].h == curr->lv[0].h);
+    LkPyr P, C;
+    fill_pyr(prev, P);
+    fill_pyr(curr, C);
+    const int top = prev->nlevels - 1;
+    const int lp = levels_prior < top ? levels_prior : top, lf = levels_full < top ? levels_full : top;
+    const int maxCount = max_iters < 0 ? 0 : (max_iters > 100 ? 100 : max_iters);
+    double epsilon = (double) eps;
+    epsilon = epsilon < 0 ? 0 : (epsilon > 10 ? 10 : epsilon);
+    epsilon *= epsilon;
+    const dim3 grid(8 * alva_divup(D.n, 8));
+    if (!retry) {
+        const size_t n = (size_t) D.n, quads = (n * 8 + 15) / 16 + (n + 15) / 16 + (n * 24 + 15) / 16;
+        hipLaunchKernelGGL(k_track_stage_in, dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, ctx->stream, D);
+    }
+    if (!retry) hipLaunchKernelGGL(k_track_klt, grid, dim3(64), 0, ctx->stream, P, C, D, lp, lf, maxCount, epsilon, err_thresh, fb_dist);
+    else hipLaunchKernelGGL(k_track_klt_retry, grid, dim3(64), 0, ctx->stream, P, C, D, lf, maxCount, epsilon, err_thresh, fb_dist);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include "camera_device.hpp"
 #include "pose_internal.hpp"
+#include "track_slots.hpp"
 #include "stages_hip.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -213,6 +214,34 @@ __global__ void __launch_bounds__(TRK_NT) k_track_finish(TrackDev D) {
     }
 }
 
+// The slot-wise step (track_slots.hpp): after the tracker launches every slot holds its verdict, position, undistorted position and
+// bearing; what is left is the list of the pose solve -- the tracked 3-D slots in slot order (visual_frontend.cpp:275-298) -- the
+// header, and the counters' reset for the next frame.
+__global__ void __launch_bounds__(TRK_NT) k_track_compact(TrackSlots D) {
+    __shared__ int s_w[17];
+    int base = 0;
+    for (int c0 = 0; c0 < D.n; c0 += TRK_NT) {
+        const int i = c0 + threadIdx.x;
+        const bool pose = i < D.n && D.d_code[i] != 0 && D.d_is3d[i] != 0;
+        int tot;
+        const int p = block_prefix(pose, s_w, &tot);
+        if (pose) {
+            const size_t k = (size_t) (base + p), j = (size_t) i;
+            D.Pbv[3 * k] = D.d_bv[3 * j]; D.Pbv[3 * k + 1] = D.d_bv[3 * j + 1]; D.Pbv[3 * k + 2] = D.d_bv[3 * j + 2];
+            D.Puv[2 * k] = (double) D.d_unpx[2 * j]; D.Puv[2 * k + 1] = (double) D.d_unpx[2 * j + 1];
+            D.Pwpt[3 * k] = D.d_wpt[3 * j]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * j + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * j + 2];
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) {
+        const int nA = D.cnt[0], good = D.cnt[1];
+        const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
+        D.o_hdr[0] = nA; D.o_hdr[1] = D.n - nA; D.o_hdr[2] = D.n - good; D.o_hdr[3] = good; D.o_hdr[4] = req ? 1 : 0; D.o_hdr[5] = base;
+        D.cnt[0] = 0;
+        D.cnt[1] = 0;
+    }
+}
+
 struct Arena {
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
@@ -263,6 +292,7 @@ struct HipStages::Impl {
     Arena trk_dev, trk_pin;
     int trk_cap = 0;
     bool fused = true;       // ALVA_TRACK_UNFUSED=1: compose the tracking step from the fine-grained stages instead (A/B testing)
+    bool lists = false;      // ALVA_TRACK_LISTS=1: the fused step with explicit keypoint lists (five launches) instead of slot-wise (three)
     bool pose_pending = false;
     int pose_n = 0;
     // a call plans its buffers first (sizes), then the arenas are grown once and carved
@@ -332,6 +362,7 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->pin.pinned = true;
     m->trk_pin.pinned = true;
     m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
+    m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
     int rc = alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -433,8 +464,65 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         rc = m->trk_pin.grow(pin_bytes, m->st);
         if (rc) return rc;
         m->trk_cap = cap;
+        ALVA_HIP(hipMemsetAsync(m->trk_dev.base, 0, 256, m->st));  // the slot-wise step's counters start at zero
     }
     const size_t c = (size_t) m->trk_cap;
+    const alva_pyramid *prev = m->pyr[m->cur ^ 1], *cur = m->pyr[m->cur];
+    const Camera &k = m->cam;
+    int n3d = 0;
+    for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
+    const uint8_t *o_code = nullptr;
+    const float *o_px = nullptr, *o_unpx = nullptr;
+    const double *o_bv = nullptr, *Pbv = nullptr, *Puv = nullptr, *Pwpt = nullptr;
+    const int *o_hdr = nullptr;
+    int rc = ALVA_OK;
+    if (!m->lists) {
+        TrackSlots D{};
+        uint8_t *b = m->trk_dev.base;
+        D.cnt = (int *) b; b += 256;
+        D.d_code = b; b += c;
+        D.d_is3d = b; b += c;    // c is a multiple of 1024: every block below starts 16-byte aligned (k_track_stage_in copies in 16-byte units)
+        b += 256 - ((uintptr_t) b & 255);
+        D.d_pts = (float *) b; b += c * 8;
+        D.d_retried = b; b += c;
+        D.d_unpx = (float *) b; b += c * 8;
+        D.d_bv = (double *) b; b += c * 24;
+        D.d_wpt = (double *) b; b += c * 24;
+        D.Pbv = (double *) b; b += c * 24;
+        D.Puv = (double *) b; b += c * 16;
+        D.Pwpt = (double *) b; b += c * 24;
+        uint8_t *h = m->trk_pin.base;
+        D.in_px = (const float *) h; h += c * 8;
+        D.in_is3d = h; h += c + 64 - (c & 63);
+        D.in_wpt = (const double *) h; h += c * 24;
+        D.o_hdr = (int *) h; h += 256;
+        D.o_code = h; h += c + 64 - (c & 63);
+        D.o_px = (float *) h; h += c * 8;
+        D.o_unpx = (float *) h; h += c * 8;
+        D.o_bv = (double *) h; h += c * 24;
+        memcpy((void *) D.in_px, job.px, (size_t) n * 8);
+        memcpy((void *) D.in_is3d, job.is3d, (size_t) n);
+        memcpy((void *) D.in_wpt, job.wpt, (size_t) n * 24);
+        D.n = n;
+        D.use_prior = job.use_prior;
+        D.width = m->cam.width;
+        D.height = m->cam.height;
+        memcpy(D.q, job.Tcw_q, 32);
+        memcpy(D.t, job.Tcw_t, 24);
+        D.cam = AlvaCam{k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2};
+        D.invK = m->d_invK;
+        // state.hpp:50-56 constants; the prior pass works on one pyramid level (visual_frontend.cpp:166)
+        rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
+        if (rc) return rc;
+        if (job.use_prior && n3d > 0) {
+            rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 1);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_track_compact, dim3(1), dim3(TRK_NT), 0, m->st, D);
+        ALVA_LAUNCH_CHECK();
+        o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
+        Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
+    } else {
     TrackDev D{};
     {
         uint8_t *b = m->trk_dev.base;
@@ -470,20 +558,15 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     memcpy((void *) D.in_px, job.px, (size_t) n * 8);
     memcpy((void *) D.in_is3d, job.is3d, (size_t) n);
     memcpy((void *) D.in_wpt, job.wpt, (size_t) n * 24);
-    int n3d = 0;
-    for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
     D.n = n;
     D.use_prior = job.use_prior;
     D.width = m->cam.width;
     D.height = m->cam.height;
     memcpy(D.q, job.Tcw_q, 32);
     memcpy(D.t, job.Tcw_t, 24);
-    const Camera &k = m->cam;
     D.cam = AlvaCam{k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2};
     D.invK = m->d_invK;
-    const alva_pyramid *prev = m->pyr[m->cur ^ 1], *cur = m->pyr[m->cur];
     hipLaunchKernelGGL(k_track_prepare, dim3(1), dim3(TRK_NT), 0, m->st, D);
-    int rc = ALVA_OK;
     if (job.use_prior && n3d > 0)  // state.hpp:50-56 constants; one pyramid level (visual_frontend.cpp:166)
         rc = alva_fbklt_track_dn(m->ctx, prev, cur, 1, 30.f, 0.5f, 30, 0.01f, D.ptsA, D.priorA, D.outA, D.stA, D.cnt + 0, n3d);
     if (rc) return rc;
@@ -492,17 +575,20 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(TRK_NT), 0, m->st, D);
     ALVA_LAUNCH_CHECK();
+    o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
+    Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
+    }
     ALVA_HIP(hipStreamSynchronize(m->st));
-    memcpy(out.code.data(), D.o_code, (size_t) n);
-    memcpy(out.px.data(), D.o_px, (size_t) n * 8);
-    memcpy(out.unpx.data(), D.o_unpx, (size_t) n * 8);
-    memcpy(out.bv.data(), D.o_bv, (size_t) n * 24);
-    out.p3p_req = D.o_hdr[4];
-    out.n_pose = D.o_hdr[5];
+    memcpy(out.code.data(), o_code, (size_t) n);
+    memcpy(out.px.data(), o_px, (size_t) n * 8);
+    memcpy(out.unpx.data(), o_unpx, (size_t) n * 8);
+    memcpy(out.bv.data(), o_bv, (size_t) n * 24);
+    out.p3p_req = o_hdr[4];
+    out.n_pose = o_hdr[5];
     if (job.want_pose && out.n_pose >= 4) {
         // P3P-LMedS keeps its median in LDS: at most 7168 correspondences (the first ones, in slot order, when a frame has more)
         m->pose_n = out.n_pose > 7168 ? 7168 : out.n_pose;
-        rc = alva_compute_pose_enqueue(m->ctx, D.Pbv, D.Puv, D.Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
+        rc = alva_compute_pose_enqueue(m->ctx, Pbv, Puv, Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
                                        (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
         if (rc) return rc;
         m->pose_pending = true;

@@ -1,0 +1,43 @@
+// The tracking step of one frame, slot-wise (shared by klt.hip, which tracks, and stages_hip.hip, which drives it).
+//
+// VisualFrontend::kltTrackingFromMotionPrior (src/slam/src/visual_frontend.cpp:152-243) builds two keypoint lists -- 3-D keypoints
+// whose projection under the predicted pose falls into the image (one pyramid level, from that projection) and everything else
+// (full pyramid, from the keypoint's own position), the failures of the first list joining the second.  What fbKltTracking
+// computes for a keypoint does not depend on the keypoint's position in a list, so no list is built here: one workgroup per SLOT
+// of the frame container decides by itself which of the two it is, and re-tracks its keypoint on the full pyramid at once when the
+// one-level pass fails -- from where that pass left it, which is what the reference does unless fewer than 33 % of the one-level
+// passes succeeded (p3pReq_, :193-203: then the retry starts from the keypoint's own position).  That count is known only after the
+// launch; a second launch redoes the retried slots in that (rare) case and is otherwise a row of workgroups that exit at once.  Per-slot results go straight to pinned host memory; a small third kernel compacts the correspondences
+// of the pose solve in slot order (:275-298).
+#pragma once
+#include "camera_device.hpp"
+#include <cstdint>
+
+struct TrackSlots {
+    int n, use_prior, width, height;
+    const float *in_px;        // pinned host, [n][2]
+    const uint8_t *in_is3d;    // pinned host, [n]
+    const double *in_wpt;      // pinned host, [n][3]
+    double q[4], t[3];         // T_cw (predicted)
+    AlvaCam cam;
+    const double *invK;        // device, 9
+    int *cnt;                  // device: [0] slots tracked from their projection, [1] of those, successes (zeroed by the compaction kernel)
+    float *d_pts;              // [n][2] device copies of the three inputs (one coalesced pass over the bus; a workgroup per slot reading
+                               // its 33 bytes from host memory by itself is bound by the number of outstanding PCIe reads)
+    uint8_t *d_code;           // per slot: 0 lost | 1 tracked from the projection | 2 tracked on the full pyramid | 3 re-tracked
+    uint8_t *d_retried;        // per slot: 1 = the one-level pass failed and the slot was re-tracked from where that pass left it
+    uint8_t *d_is3d;           // copy of in_is3d
+    float *d_unpx;             // [n][2]
+    double *d_bv, *d_wpt;      // [n][3]; d_wpt = copy of in_wpt
+    uint8_t *o_code;           // pinned host outputs
+    float *o_px, *o_unpx;
+    double *o_bv;
+    int *o_hdr;
+    double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
+};
+
+struct alva_ctx;
+struct alva_pyramid;
+// enqueue only (klt.hip): the first launch over all slots, the retry launch
+int alva_track_slots_klt(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, const TrackSlots &D, int levels_prior, int levels_full,
+                         float err_thresh, float fb_dist, int max_iters, float eps, int retry);

@@ -696,11 +696,11 @@ def main():
         alg = {
             "k_level0<true>": 4 * P + 2 * P,                        # RGBA in; gray copy + padded level 0 out
             "k_pyr_stage": (P + 4 * P + P / 4) * (1 + 1 / 4 + 1 / 16 + 1 / 64) / 4,   # per launch (4 launches): level in, Scharr out, next level out
-            # fb-KLT: per launch the levels it walks of BOTH pyramids once (gray u8 + Ix,Iy i16 = 5 B/px per level) + 24 B per point;
-            # two launches per frame: the 3-D keypoints on level 0 only, the rest on levels 0-3 -- the larger one is quoted
-            "k_klt_dn": 2 * 5 * P + 24 * n3d,
-            "k_track_prepare": 33 * nkp + 16 * nkp,                 # slot table in (px, flag, world point), lists out
-            "k_track_finish": 9 * nkp + 41 * nkp + 64 * n3d,        # tracker results in; per-slot results + correspondences out
+            # fb-KLT, one launch per frame over every slot: the four levels of BOTH pyramids once (gray u8 + Ix,Iy i16 = 5 B/px per level)
+            # + the slot table in (33 B per slot) + per-slot results out (1 + 8 + 8 + 24 B twice: device copy and pinned host)
+            "k_track_klt": 2 * 5 * P * (1 + 1 / 4 + 1 / 16 + 1 / 64) + 33 * nkp + 82 * nkp,
+            "k_track_stage_in": 2 * 33 * nkp,                       # slot table: pinned host -> device
+            "k_track_compact": 42 * nkp + 64 * n3d,                 # per-slot results in; correspondences of the pose solve out
         }
         per_frame = {k: v[0] / PROF_STEPS * v[1] for k, v in kt.items()}
         kernels = {k: {"launches_per_frame": round(v[0] / PROF_STEPS, 3), "avg_us": round(v[1], 2),
@@ -710,11 +710,11 @@ def main():
         hbm_dom = max((k for k in per_frame if k in alg), key=per_frame.get)
         achieved = alg[hbm_dom] / (kt[hbm_dom][1] * 1e-6) / 1e9
         traffic = None
-        tfile = ROOT / "profiles" / "pmc_traffic.json"
-        if tfile.exists():
-            tj = json.loads(tfile.read_text()).get("kernels", {})
-            if hbm_dom in tj:
-                traffic = tj[hbm_dom].get("hbm_bytes_per_launch")
+        for tfile in (ROOT / "profiles" / "r2_pmc_traffic_system.json", ROOT / "profiles" / "pmc_traffic.json"):
+            if traffic is None and tfile.exists():
+                tj = json.loads(tfile.read_text()).get("kernels", {})
+                if hbm_dom in tj:
+                    traffic = tj[hbm_dom].get("hbm_bytes_per_launch")
         us = lambda d, n: {a: round(1e6 * b / max(n, 1), 1) for a, b in d.items()}
         out = {
             "metric": "frames/sec @640x480 2000kp; local-BA residuals/sec (20KFx3k pts)",
