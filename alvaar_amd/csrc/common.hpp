@@ -68,6 +68,24 @@ int alva_ctx_pinned(alva_ctx *ctx, size_t bytes, void **out);
 
 static inline int alva_divup(int a, int b) { return (a + b - 1) / b; }
 
+// Batched launches (B cameras, `per_cam` workgroups each).  Workgroups are dealt to the 8 XCDs round-robin by linear workgroup id and
+// every XCD has its own L2: with the camera in blockIdx.z a camera's consecutive tiles land on eight different L2s, each of which
+// fetches the shared halo rows / overlapping patches again (profiles/r02c_pmc_traffic_frame_step64.json: 2.7x the algorithmic bytes).
+// A 1-D grid of 8 * ceil(B / 8) * per_cam workgroups in which workgroup L serves camera 8 * (L / 8 / per_cam) + L % 8 keeps a camera
+// on ONE XCD, its work items consecutive in time.  With fewer than 8 cameras that would leave XCDs idle: the plain order is used.
+struct AlvaXcdItem {
+    int cam, item;
+};
+static inline unsigned alva_xcd_grid(int count, int per_cam) { return count >= 8 ? 8u * (unsigned) ((count + 7) / 8) * (unsigned) per_cam : (unsigned) count * (unsigned) per_cam; }
+#if defined(__HIPCC__)
+__device__ __forceinline__ AlvaXcdItem alva_xcd_item(int count, int per_cam) {
+    const int L = (int) blockIdx.x;
+    if (count < 8) return AlvaXcdItem{L / per_cam, L % per_cam};
+    const int j = L >> 3;
+    return AlvaXcdItem{(j / per_cam) * 8 + (L & 7), j % per_cam};
+}
+#endif
+
 struct alva_level {
     int w = 0, h = 0;
     uint8_t *gray_base = nullptr;   // allocation base

@@ -127,7 +127,7 @@ int alva_blur7_launch(alva_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
     return ALVA_OK;
 }
 
-// ---- the same for several cameras: blockIdx.z = camera, one BlurBatch per camera in device memory ------------------------------
+// ---- the same for several cameras: camera from alva_xcd_item, one BlurBatch per camera in device memory ------------------------------
 // Throughput form of blur7_tile for the batched launch: the same 64 x 16 tile and the same float operations per pixel in the same
 // order, but four pixels per thread -- dword loads into the byte tile (per-byte reflection only in dwords that cross the image
 // border), v_cvt_f32_ubyteN unpacking, float4 LDS traffic, dword stores.  blur7_tile spends its time on byte-granular addressing
@@ -208,9 +208,11 @@ __device__ __forceinline__ void blur7_tile4(const uint8_t *__restrict__ src, siz
     }
 }
 
-__global__ void __launch_bounds__(256) k_blur7_multi(const BlurBatch *__restrict__ Bs, int n_levels) {
-    const BlurBatch &B = Bs[blockIdx.z];
-    int t = blockIdx.x, l = 0, tilesX = 1;  // blockIdx.x runs over the tiles of all levels
+__global__ void __launch_bounds__(256) k_blur7_multi(const BlurBatch *__restrict__ Bs, int n_levels, int count, int per_cam) {
+    const AlvaXcdItem w = alva_xcd_item(count, per_cam);   // a camera's tiles on one XCD: the 3-row / 4-column halos hit its L2
+    if (w.cam >= count) return;
+    const BlurBatch &B = Bs[w.cam];
+    int t = w.item, l = 0, tilesX = 1;  // the item index runs over the tiles of all levels
     for (; l < n_levels; l++) {
         tilesX = (B.w[l] + BT_W - 1) / BT_W;
         const int nt = tilesX * ((B.h[l] + BT_H - 1) / BT_H);
@@ -240,7 +242,8 @@ int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *
 }
 
 int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles) {
-    hipLaunchKernelGGL(k_blur7_multi, dim3(total_tiles, 1, count), dim3(256), 0, ctx->stream, (const BlurBatch *) d_batches, n_levels);
+    hipLaunchKernelGGL(k_blur7_multi, dim3(alva_xcd_grid(count, total_tiles)), dim3(256), 0, ctx->stream, (const BlurBatch *) d_batches, n_levels, count,
+                       total_tiles);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

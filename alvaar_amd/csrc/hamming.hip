@@ -92,10 +92,13 @@ struct BfItem {
     int nq_cap, nt, nq_pad, chunks;
 };
 
-__global__ void __launch_bounds__(QT) k_bf_partial_b(const BfItem *__restrict__ items) {
+__global__ void __launch_bounds__(QT) k_bf_partial_b(const BfItem *__restrict__ items, int count, int gx, int gy) {
     __shared__ uint4 s_t[TC * 2];
-    const BfItem it = items[blockIdx.z];
-    const int nt = it.nt, t0 = blockIdx.y * TC;
+    const AlvaXcdItem w = alva_xcd_item(count, gx * gy);   // a camera's descriptor sets go through one XCD's L2
+    if (w.cam >= count) return;
+    const BfItem it = items[w.cam];
+    const int bx = w.item % gx, by = w.item / gx;
+    const int nt = it.nt, t0 = by * TC;
     if (t0 >= nt) return;  // also: a match without a train set (its count pointer may be null)
     const int nq = min(it.nq_cap, *it.dnq);
     const int lane = threadIdx.x;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(QT) k_bf_partial_b(const BfItem *__restrict__ 
         s_t[2 * lane + 1] = it.t[2 * (size_t) (t0 + lane) + 1];
     }
     __syncthreads();
-    for (int qb = blockIdx.x; qb * QT < nq; qb += gridDim.x) {
+    for (int qb = bx; qb * QT < nq; qb += gx) {
         const int qi = qb * QT + lane;
         uint4 qa = make_uint4(0, 0, 0, 0), qb4 = qa;
         if (qi < nq) {
@@ -126,15 +129,17 @@ __global__ void __launch_bounds__(QT) k_bf_partial_b(const BfItem *__restrict__ 
             const uint32_t key = (d << 20) | (uint32_t) (t0 + j);
             best = min(best, key);
         }
-        if (qi < nq) it.partial[(size_t) blockIdx.y * it.nq_pad + qi] = best;
+        if (qi < nq) it.partial[(size_t) by * it.nq_pad + qi] = best;
     }
 }
 
-__global__ void __launch_bounds__(256) k_bf_final_b(const BfItem *__restrict__ items) {
-    const BfItem it = items[blockIdx.z];
+__global__ void __launch_bounds__(256) k_bf_final_b(const BfItem *__restrict__ items, int count, int gx) {
+    const AlvaXcdItem w = alva_xcd_item(count, gx);
+    if (w.cam >= count) return;
+    const BfItem it = items[w.cam];
     if (it.nt == 0) return;
     const int nq = min(it.nq_cap, *it.dnq);
-    for (int qi = blockIdx.x * 256 + threadIdx.x; qi < nq; qi += gridDim.x * 256) {
+    for (int qi = w.item * 256 + threadIdx.x; qi < nq; qi += gx * 256) {
         uint32_t best = 0xffffffffu;
         for (int c = 0; c < it.chunks; c++) best = min(best, it.partial[(size_t) c * it.nq_pad + qi]);
         if (best == 0xffffffffu) {
@@ -190,8 +195,10 @@ extern "C" int alva_bf_match_hamming_batch(alva_ctx *ctx, int count, const uint8
     }
     ALVA_HIP(hipMemcpyAsync(dev, items.data(), items.size() * sizeof(BfItem), hipMemcpyHostToDevice, ctx->stream));
     const int qblocks = std::max(1, std::min(alva_divup(cap_query, QT), alva_divup(std::max(expected_queries, 1), QT)));
-    hipLaunchKernelGGL(k_bf_partial_b, dim3(qblocks, max_chunks, count), dim3(QT), 0, ctx->stream, (const BfItem *) dev);
-    hipLaunchKernelGGL(k_bf_final_b, dim3(std::max(1, alva_divup(qblocks * QT, 256)), 1, count), dim3(256), 0, ctx->stream, (const BfItem *) dev);
+    hipLaunchKernelGGL(k_bf_partial_b, dim3(alva_xcd_grid(count, qblocks * max_chunks)), dim3(QT), 0, ctx->stream, (const BfItem *) dev, count, qblocks,
+                       max_chunks);
+    const int fblocks = std::max(1, alva_divup(qblocks * QT, 256));
+    hipLaunchKernelGGL(k_bf_final_b, dim3(alva_xcd_grid(count, fblocks)), dim3(256), 0, ctx->stream, (const BfItem *) dev, count, fblocks);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

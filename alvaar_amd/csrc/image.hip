@@ -41,9 +41,9 @@ __device__ __forceinline__ void store_mirrors(uint8_t *g, size_t pitch, int w, i
 template<bool SRC_RGBA>
 __device__ __forceinline__ void level0_body(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, int win,
                                             uint8_t *__restrict__ dst, size_t dst_pitch, uint8_t *__restrict__ gray_out,
-                                            size_t gray_out_pitch) {
-    int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    int y = blockIdx.y * 4 + threadIdx.y;
+                                            size_t gray_out_pitch, const int bx, const int by) {
+    int x4 = (bx * 64 + threadIdx.x) * 4;
+    int y = by * 4 + threadIdx.y;
     if (x4 >= w || y >= h) return;
     uint32_t packed;
     if (SRC_RGBA) {
@@ -65,18 +65,20 @@ template<bool SRC_RGBA>
 __global__ void __launch_bounds__(256) k_level0(const uint8_t *__restrict__ src, size_t src_pitch, int w, int h, int win,
                                                 uint8_t *__restrict__ dst, size_t dst_pitch,
                                                 uint8_t *__restrict__ gray_out, size_t gray_out_pitch) {
-    level0_body<SRC_RGBA>(src, src_pitch, w, h, win, dst, dst_pitch, gray_out, gray_out_pitch);
+    level0_body<SRC_RGBA>(src, src_pitch, w, h, win, dst, dst_pitch, gray_out, gray_out_pitch, blockIdx.x, blockIdx.y);
 }
-// The same for B cameras in one launch (blockIdx.z = camera): one frame is 1.2 MB and every launch of this file is bound by
+// The same for B cameras in one launch (camera -> XCD affinity, alva_xcd_item): one frame is 1.2 MB and every launch of this file is bound by
 // launch latency, not by HBM; B frames per launch is what lets the same code run at memory speed.
 struct Level0Item {
     const uint8_t *src;
     uint8_t *dst, *gray_out;
 };
 __global__ void __launch_bounds__(256) k_level0_batch(const Level0Item *__restrict__ items, size_t src_pitch, int w, int h, int win,
-                                                      size_t dst_pitch, size_t gray_out_pitch) {
-    const Level0Item it = items[blockIdx.z];
-    level0_body<true>(it.src, src_pitch, w, h, win, it.dst, dst_pitch, it.gray_out, gray_out_pitch);
+                                                      size_t dst_pitch, size_t gray_out_pitch, int count, int gx, int gy) {
+    const AlvaXcdItem wi = alva_xcd_item(count, gx * gy);
+    if (wi.cam >= count) return;
+    const Level0Item it = items[wi.cam];
+    level0_body<true>(it.src, src_pitch, w, h, win, it.dst, dst_pitch, it.gray_out, gray_out_pitch, wi.item % gx, wi.item / gx);
 }
 
 struct StageArgs {
@@ -191,9 +193,11 @@ __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
     if (bid < a.scharr_blocks) scharr_tile(a, bid);
     else pyrdown_tile(a, bid - a.scharr_blocks);
 }
-__global__ void __launch_bounds__(256) k_pyr_stage_batch(const StageArgs *__restrict__ args) {
-    const StageArgs a = args[blockIdx.z];
-    int bid = blockIdx.x;
+__global__ void __launch_bounds__(256) k_pyr_stage_batch(const StageArgs *__restrict__ args, int count, int per_cam) {
+    const AlvaXcdItem wi = alva_xcd_item(count, per_cam);
+    if (wi.cam >= count) return;
+    const StageArgs a = args[wi.cam];
+    int bid = wi.item;
     if (bid < a.scharr_blocks) scharr_tile(a, bid);
     else pyrdown_tile(a, bid - a.scharr_blocks);
 }
@@ -397,10 +401,12 @@ extern "C" int alva_pyramid_build_from_rgba_batch(alva_ctx *ctx, alva_pyramid *c
     ALVA_HIP(hipMemcpyAsync(dev, pin, arg_bytes, hipMemcpyHostToDevice, ctx->stream));
     const Level0Item *d_items = (const Level0Item *) dev;
     const StageArgs *d_st = (const StageArgs *) (dev + off_stage);
-    hipLaunchKernelGGL(k_level0_batch, dim3(alva_divup(L0.w, 256), alva_divup(L0.h, 4), count), dim3(64, 4), 0, ctx->stream, d_items, rgba_pitch, L0.w,
-                       L0.h, p0->win, L0.gray_pitch, gray_out_pitch);
+    const int gx0 = alva_divup(L0.w, 256), gy0 = alva_divup(L0.h, 4);
+    hipLaunchKernelGGL(k_level0_batch, dim3(alva_xcd_grid(count, gx0 * gy0)), dim3(64, 4), 0, ctx->stream, d_items, rgba_pitch, L0.w, L0.h, p0->win,
+                       L0.gray_pitch, gray_out_pitch, count, gx0, gy0);
     for (int l = 0; l < p0->nlevels; l++)
-        hipLaunchKernelGGL(k_pyr_stage_batch, dim3(blocks[l], 1, count), dim3(64, 4), 0, ctx->stream, d_st + (size_t) l * count);
+        hipLaunchKernelGGL(k_pyr_stage_batch, dim3(alva_xcd_grid(count, blocks[l])), dim3(64, 4), 0, ctx->stream, d_st + (size_t) l * count, count,
+                           blocks[l]);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

@@ -889,12 +889,23 @@ __device__ void lk_level_q(LkSharedQ<GL> &sh, const LkLevel &I, const LkLevel &J
 
 template <int GL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_klt_batch_q(const KltBatchItem *__restrict__ items, int maxLevelArg, int maxCount, double epsilon,
-                                                    float errThresh, float fbDist) {
+                                                    float errThresh, float fbDist, int count, int per_cam) {
     __shared__ LkSharedQ<GL> sh;
     constexpr int NG = 64 / GL;
-    const KltBatchItem &it = items[blockIdx.y];
-    const int per = gridDim.x >> 3;
-    const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-contiguous, as k_klt
+    // 8 cameras or more: a camera's keypoints on ONE XCD (both pyramids go through one L2; alva_xcd_item); fewer: the camera's keypoint
+    // list in eight XCD-contiguous pieces, as k_klt
+    int cam, w;
+    if (count >= 8) {
+        const AlvaXcdItem wi = alva_xcd_item(count, per_cam);
+        cam = wi.cam;
+        w = wi.item;
+        if (cam >= count) return;
+    } else {
+        const int per = gridDim.x >> 3;
+        cam = blockIdx.y;
+        w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    const KltBatchItem &it = items[cam];
     if (w * NG >= it.n) return;
     const int grp = (int) threadIdx.x / GL;
     const int kp = w * NG + grp;
@@ -1071,12 +1082,14 @@ int alva_fbklt_track_batch_enqueue(alva_ctx *ctx, const void *d_items, int count
     if (lanes == 64)
         hipLaunchKernelGGL(k_klt_batch, dim3(8 * alva_divup(n_max, 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount, epsilon, err_thresh,
                            fb_dist);
-    else if (lanes == 5)
-        hipLaunchKernelGGL(k_klt_batch_q<5>, dim3(8 * alva_divup(alva_divup(n_max, 12), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
-                           epsilon, err_thresh, fb_dist);
-    else if (lanes == 8)
-        hipLaunchKernelGGL(k_klt_batch_q<8>, dim3(8 * alva_divup(alva_divup(n_max, 8), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
-                           epsilon, err_thresh, fb_dist);
+    else if (lanes == 5 || lanes == 8) {
+        const int per_cam = 8 * alva_divup(alva_divup(n_max, lanes == 5 ? 12 : 8), 8);
+        const dim3 grid = count >= 8 ? dim3(alva_xcd_grid(count, per_cam)) : dim3(per_cam, count);
+        if (lanes == 5)
+            hipLaunchKernelGGL(k_klt_batch_q<5>, grid, dim3(64), 0, ctx->stream, items, num_levels, maxCount, epsilon, err_thresh, fb_dist, count, per_cam);
+        else
+            hipLaunchKernelGGL(k_klt_batch_q<8>, grid, dim3(64), 0, ctx->stream, items, num_levels, maxCount, epsilon, err_thresh, fb_dist, count, per_cam);
+    }
     else if (lanes == 32)
         hipLaunchKernelGGL(k_klt_batch_g<32>, dim3(8 * alva_divup(alva_divup(n_max, 2), 8), count), dim3(64), 0, ctx->stream, items, num_levels, maxCount,
                            epsilon, err_thresh, fb_dist);

@@ -61,7 +61,7 @@ struct OrbDev {
     int umax[17];
 };
 
-// One camera of a batched launch (k_*_b: blockIdx.z = camera): the detector's own state plus the call's arguments.
+// One camera of a batched launch (k_*_b: camera = alva_xcd_item().cam): the detector's own state plus the call's arguments.
 struct OrbItem {
     OrbDev D;
     const uint8_t *gray;
@@ -144,9 +144,9 @@ __device__ __forceinline__ int fast_score_at(const uint8_t *p, int stride, int t
 }
 
 // resize level l from level l-1 (INTER_LINEAR_EXACT)
-__device__ __forceinline__ void resize_body(const OrbDev &D, int l) {
+__device__ __forceinline__ void resize_body(const OrbDev &D, int l, const int bx, const int by) {
     const Level &S = D.lv[l - 1], &T = D.lv[l];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
     if (x >= T.w || y >= T.h) return;
     const int *xo = D.tapOfs + T.tabOff, *xc = D.tapCoef + T.tabOff, *yo = xo + T.w, *yc = xc + T.w;
     const uint8_t *src = D.pool + S.img;
@@ -172,9 +172,9 @@ __device__ __forceinline__ void resize_body(const OrbDev &D, int l) {
 // Four horizontally adjacent outputs per thread (the batched launch): their source bytes lie within 8 consecutive bytes of a row
 // (scale 1.2: 4 outputs span < 5 source pixels), fetched as one unaligned 8-byte load per row instead of 8 byte loads, and stored as
 // one dword.  Same integer arithmetic per pixel as resize_body; quads touching a clamped tap or the right edge take that path.
-__device__ __forceinline__ void resize4_body(const OrbDev &D, int l) {
+__device__ __forceinline__ void resize4_body(const OrbDev &D, int l, const int bx, const int by) {
     const Level &S = D.lv[l - 1], &T = D.lv[l];
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = (bx * 64 + (threadIdx.x & 63)) * 4, y = by * 4 + (threadIdx.x >> 6);
     if (x >= T.w || y >= T.h) return;
     const int *xo = D.tapOfs + T.tabOff, *xc = D.tapCoef + T.tabOff, *yo = xo + T.w, *yc = xc + T.w;
     const uint8_t *src = D.pool + S.img;
@@ -227,8 +227,11 @@ __device__ __forceinline__ void resize4_body(const OrbDev &D, int l) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_resize(OrbDev D, int l) { resize_body(D, l); }
-__global__ void __launch_bounds__(256) k_resize_b(const OrbItem *__restrict__ items, int l) { resize4_body(items[blockIdx.z].D, l); }
+__global__ void __launch_bounds__(256) k_resize(OrbDev D, int l) { resize_body(D, l, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) k_resize_b(const OrbItem *__restrict__ items, int l, int count, int gx, int gy) {
+    const AlvaXcdItem w = alva_xcd_item(count, gx * gy);
+    if (w.cam < count) resize4_body(items[w.cam].D, l, w.item % gx, w.item / gx);
+}
 
 // FAST score map of every level: 64x16 tile + 3 px halo staged in LDS
 constexpr int FT_W = 64, FT_H = 16;
@@ -393,9 +396,11 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
 
 __global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) { fast_nms_body(D, blockIdx.y, blockIdx.x); }
 // batched: blockIdx.x runs over the tiles of ALL levels (a grid sized for level 0 on every level would be 60 % empty workgroups)
-__global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items) {
-    const OrbDev &D = items[blockIdx.z].D;
-    int t = blockIdx.x, l = 0;
+__global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items, int count, int per_cam) {
+    const AlvaXcdItem w = alva_xcd_item(count, per_cam);
+    if (w.cam >= count) return;
+    const OrbDev &D = items[w.cam].D;
+    int t = w.item, l = 0;
     for (; l < D.nlevels; l++) {
         const int nt = ((D.lv[l].w + FT_W - 1) / FT_W) * ((D.lv[l].h + FT_H - 1) / FT_H);
         if (t < nt) break;
@@ -520,15 +525,15 @@ __device__ int compact_ordered(int n, Pred pred, Emit emit) {
 }
 
 // cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept), preserving order
-__device__ __forceinline__ void cull_fast_body(const OrbDev &D) {
-    const Level &L = D.lv[blockIdx.x];
-    const int n = min(D.n1[blockIdx.x], L.candCap), keepN = 2 * L.nKeep;
+__device__ __forceinline__ void cull_fast_body(const OrbDev &D, const int l) {
+    const Level &L = D.lv[l];
+    const int n = min(D.n1[l], L.candCap), keepN = 2 * L.nKeep;
     __shared__ unsigned s_bin, s_rem;
     int thr = 0;
     if (keepN == 0) thr = 1 << 30;
     else if (n > keepN) {
         // largest score v with #{score >= v} >= keepN: prefix sums over the bins in DESCENDING score order
-        const int *hist = D.hist + blockIdx.x * 256;
+        const int *hist = D.hist + l * 256;
         if (threadIdx.x < 64) wave_find_bin([&](int b) { return (unsigned) hist[255 - b]; }, (unsigned) (keepN - 1), &s_bin, &s_rem);
         __syncthreads();
         thr = 255 - (int) s_bin;
@@ -540,19 +545,22 @@ __device__ __forceinline__ void cull_fast_body(const OrbDev &D) {
             D.c2x[o + pos] = D.c1x[o + i];
             D.c2y[o + pos] = D.c1y[o + i];
         });
-    if (threadIdx.x == 0) D.n2[blockIdx.x] = m;
+    if (threadIdx.x == 0) D.n2[l] = m;
 }
 
-__global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) { cull_fast_body(D); }
-__global__ void __launch_bounds__(1024) k_cull_fast_b(const OrbItem *__restrict__ items) { cull_fast_body(items[blockIdx.z].D); }
+__global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) { cull_fast_body(D, blockIdx.x); }
+__global__ void __launch_bounds__(1024) k_cull_fast_b(const OrbItem *__restrict__ items, int count, int nlevels) {
+    const AlvaXcdItem w = alva_xcd_item(count, nlevels);
+    if (w.cam < count) cull_fast_body(items[w.cam].D, w.item);
+}
 
 // Harris response of every surviving candidate (orb.cpp:130-177): one wave each, the 49 block positions spread over the
 // lanes.  a, b, c are INTEGER sums in the reference, so the cross-lane reduction order cannot change them.
-__device__ __forceinline__ void harris_body(const OrbDev &D) {
-    const Level &L = D.lv[blockIdx.y];
-    const int lane = threadIdx.x & 63, n2 = D.n2[blockIdx.y], W = L.pitch;
+__device__ __forceinline__ void harris_body(const OrbDev &D, const int l, const int bx, const int gx) {
+    const Level &L = D.lv[l];
+    const int lane = threadIdx.x & 63, n2 = D.n2[l], W = L.pitch;
     const uint8_t *img = D.pool + L.img;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n2; i += gridDim.x * 4) {
+    for (int i = bx * 4 + (threadIdx.x >> 6); i < n2; i += gx * 4) {
     const int x = D.c2x[L.candOff + i], y = D.c2y[L.candOff + i];
     int a = 0, b = 0, c = 0;
     if (lane < 49) {
@@ -578,8 +586,11 @@ __device__ __forceinline__ void harris_body(const OrbDev &D) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_harris(OrbDev D) { harris_body(D); }
-__global__ void __launch_bounds__(256) k_harris_b(const OrbItem *__restrict__ items) { harris_body(items[blockIdx.z].D); }
+__global__ void __launch_bounds__(256) k_harris(OrbDev D) { harris_body(D, blockIdx.y, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) k_harris_b(const OrbItem *__restrict__ items, int count, int gx, int nlevels) {
+    const AlvaXcdItem w = alva_xcd_item(count, gx * nlevels);
+    if (w.cam < count) harris_body(items[w.cam].D, w.item / gx, w.item % gx, gx);
+}
 
 __device__ __forceinline__ unsigned f2key(float f) {  // order-preserving map float -> uint
     const unsigned u = __float_as_uint(f);
@@ -587,9 +598,9 @@ __device__ __forceinline__ unsigned f2key(float f) {  // order-preserving map fl
 }
 
 // cull by Harris: keep response >= the n_l-th largest, preserving order (radix select on the float keys)
-__device__ __forceinline__ void cull_harris_body(const OrbDev &D) {
-    const Level &L = D.lv[blockIdx.x];
-    const int n = D.n2[blockIdx.x], keepN = L.nKeep, o = L.candOff;
+__device__ __forceinline__ void cull_harris_body(const OrbDev &D, const int l) {
+    const Level &L = D.lv[l];
+    const int n = D.n2[l], keepN = L.nKeep, o = L.candOff;
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_prefix, s_k;
     unsigned thrKey = 0;
@@ -622,7 +633,7 @@ __device__ __forceinline__ void cull_harris_body(const OrbDev &D) {
             D.c3y[o + pos] = D.c2y[o + i];
             D.c3r[o + pos] = D.c2r[o + i];
         });
-    if (threadIdx.x == 0) D.n3[blockIdx.x] = m;
+    if (threadIdx.x == 0) D.n3[l] = m;
     // Deterministic output order: row-major by position inside the level (positions are unique).  Rank sort: every element
     // counts the keys below its own from an LDS copy (broadcast reads, no barriers in the loop); m is ~n_l (a few hundred).
     constexpr int SORT_CAP = 4096;
@@ -656,8 +667,11 @@ __device__ __forceinline__ void cull_harris_body(const OrbDev &D) {
     }
 }
 
-__global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) { cull_harris_body(D); }
-__global__ void __launch_bounds__(1024) k_cull_harris_b(const OrbItem *__restrict__ items) { cull_harris_body(items[blockIdx.z].D); }
+__global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) { cull_harris_body(D, blockIdx.x); }
+__global__ void __launch_bounds__(1024) k_cull_harris_b(const OrbItem *__restrict__ items, int count, int nlevels) {
+    const AlvaXcdItem w = alva_xcd_item(count, nlevels);
+    if (w.cam < count) cull_harris_body(items[w.cam].D, w.item);
+}
 
 __device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_core.simd.hpp:34-71
     const float s = (float) (180 / 3.1415926535897932384626433832795);
@@ -678,8 +692,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {  // mathfuncs_c
 }
 
 // IC angle + output record, one wave per kept keypoint (orb.cpp:181-215, :952-958)
-__device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restrict__ kp, int cap, int *__restrict__ total, const int bx) {
-    const int l = blockIdx.y;
+__device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restrict__ kp, int cap, int *__restrict__ total, const int bx, const int l) {
     const Level &L = D.lv[l];
     const int i = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     int base = 0;
@@ -728,13 +741,15 @@ __device__ __forceinline__ void angle_emit_body(const OrbDev &D, float *__restri
     }
 }
 
-__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) { angle_emit_body(D, kp, cap, total, blockIdx.x); }
-__global__ void __launch_bounds__(256) k_angle_emit_b(const OrbItem *__restrict__ items) {
+__global__ void __launch_bounds__(256) k_angle_emit(OrbDev D, float *__restrict__ kp, int cap, int *__restrict__ total) { angle_emit_body(D, kp, cap, total, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) k_angle_emit_b(const OrbItem *__restrict__ items, int count, int gx, int nlevels) {
     // a level keeps a few hundred keypoints while the launch bound is >= 1024: a short grid that loops instead of ~130 k workgroups
     // (for 64 cameras) of which three quarters find nothing to do
-    const OrbItem &it = items[blockIdx.z];
-    const int n3 = it.D.n3[blockIdx.y];
-    for (int bx = blockIdx.x; bx == 0 || bx * 4 < n3; bx += gridDim.x) angle_emit_body(it.D, it.kp, it.cap, it.total, bx);
+    const AlvaXcdItem w = alva_xcd_item(count, gx * nlevels);
+    if (w.cam >= count) return;
+    const OrbItem &it = items[w.cam];
+    const int l = w.item / gx, n3 = it.D.n3[l];
+    for (int bx = w.item % gx; bx == 0 || bx * 4 < n3; bx += gx) angle_emit_body(it.D, it.kp, it.cap, it.total, bx, l);
 }
 
 // keypoints whose rotation could not be PROVEN to round like the host library's (see exact_sincos.hpp); expected to stay 0
@@ -746,9 +761,9 @@ __constant__ int8_t c_pattern_orb[1024] = {
 
 // steered BRIEF of the ORB keypoints on their (blurred) pyramid level; 32 lanes per keypoint (orb.cpp:219-284)
 __device__ __forceinline__ void brief_orb_body(const OrbDev &D, const float *__restrict__ kp, const int *__restrict__ total, int cap,
-                                               uint8_t *__restrict__ desc) {
+                                               uint8_t *__restrict__ desc, const int bx) {
     const int n = min(*total, cap);
-    const int k = blockIdx.x * 8 + threadIdx.x / 32, byte = threadIdx.x % 32;
+    const int k = bx * 8 + threadIdx.x / 32, byte = threadIdx.x % 32;
     if (k >= n) return;
     const float *rec = kp + 6 * (size_t) k;
     const int l = (int) rec[5];
@@ -778,28 +793,32 @@ __device__ __forceinline__ void brief_orb_body(const OrbDev &D, const float *__r
 
 __global__ void __launch_bounds__(256) k_brief_orb(OrbDev D, const float *__restrict__ kp, const int *__restrict__ total, int cap,
                                                    uint8_t *__restrict__ desc) {
-    brief_orb_body(D, kp, total, cap, desc);
+    brief_orb_body(D, kp, total, cap, desc, blockIdx.x);
 }
-__global__ void __launch_bounds__(256) k_brief_orb_b(const OrbItem *__restrict__ items) {
-    const OrbItem &it = items[blockIdx.z];
-    brief_orb_body(it.D, it.kp, it.total, it.cap, it.desc);
+__global__ void __launch_bounds__(256) k_brief_orb_b(const OrbItem *__restrict__ items, int count, int per_cam) {
+    const AlvaXcdItem w = alva_xcd_item(count, per_cam);
+    if (w.cam >= count) return;
+    const OrbItem &it = items[w.cam];
+    brief_orb_body(it.D, it.kp, it.total, it.cap, it.desc, w.item);
 }
 
-__device__ __forceinline__ void copy_level0_body(const OrbDev &D, const uint8_t *__restrict__ src, size_t pitch) {
+__device__ __forceinline__ void copy_level0_body(const OrbDev &D, const uint8_t *__restrict__ src, size_t pitch, const int bx, const int by) {
     const Level &L = D.lv[0];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
     if (x < L.w && y < L.h) D.pool[L.img + (size_t) y * L.pitch + x] = src[(size_t) y * pitch + x];
     // first launch of the chain: clear the FAST-score histograms here instead of a separate fill command
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (bx == 0 && by == 0) {
         for (int k = threadIdx.x; k < MAXLV * 256; k += 256) D.hist[k] = 0;
         if (threadIdx.x < MAXLV) D.n1[threadIdx.x] = 0;   // k_fast_nms appends with atomics
     }
 }
 
-__global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) { copy_level0_body(D, src, pitch); }
-__global__ void k_copy_level0_b(const OrbItem *__restrict__ items) {
-    const OrbItem &it = items[blockIdx.z];
-    copy_level0_body(it.D, it.gray, it.gray_pitch);
+__global__ void k_copy_level0(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) { copy_level0_body(D, src, pitch, blockIdx.x, blockIdx.y); }
+__global__ void k_copy_level0_b(const OrbItem *__restrict__ items, int count, int gx, int gy) {
+    const AlvaXcdItem w = alva_xcd_item(count, gx * gy);
+    if (w.cam >= count) return;
+    const OrbItem &it = items[w.cam];
+    copy_level0_body(it.D, it.gray, it.gray_pitch, w.item % gx, w.item / gx);
 }
 
 int cv_round_f(float v) { return (int) lrintf(v); }
@@ -1059,7 +1078,7 @@ extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count) {
     return ALVA_OK;
 }
 
-// ---- cv::ORB::detectAndCompute of `count` cameras, one set of launches (blockIdx.z = camera) -----------------------------------
+// ---- cv::ORB::detectAndCompute of `count` cameras, one set of launches (camera from alva_xcd_item) -----------------------------------
 // Every camera has its own detector object (image pool, candidate lists, counters); the objects must share one geometry.  The
 // kernels are the single-camera kernels' bodies, so every camera's keypoints and descriptors are those of its own
 // alva_orb_detect_and_compute.  Enqueue-only; alva_orb_collect_batch() waits and returns the counts.
@@ -1110,27 +1129,36 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
     ALVA_HIP(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, st));
     const OrbItem *items = (const OrbItem *) dev;
     const Level &L0 = D0.lv[0];
-    hipLaunchKernelGGL(k_copy_level0_b, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4), count), dim3(256), 0, st, items);
-    for (int l = 1; l < D0.nlevels; l++)
-        hipLaunchKernelGGL(k_resize_b, dim3(alva_divup(D0.lv[l].w, 256), alva_divup(D0.lv[l].h, 4), count), dim3(256), 0, st, items, l);
+    // every launch below: 1-D grid, camera -> XCD affinity (alva_xcd_item, common.hpp)
+    {
+        const int gx = alva_divup(L0.w, 64), gy = alva_divup(L0.h, 4);
+        hipLaunchKernelGGL(k_copy_level0_b, dim3(alva_xcd_grid(count, gx * gy)), dim3(256), 0, st, items, count, gx, gy);
+    }
+    for (int l = 1; l < D0.nlevels; l++) {
+        const int gx = alva_divup(D0.lv[l].w, 256), gy = alva_divup(D0.lv[l].h, 4);
+        hipLaunchKernelGGL(k_resize_b, dim3(alva_xcd_grid(count, gx * gy)), dim3(256), 0, st, items, l, count, gx, gy);
+    }
     int fastTiles = 0;
     for (int l = 0; l < D0.nlevels; l++) fastTiles += alva_divup(D0.lv[l].w, FT_W) * alva_divup(D0.lv[l].h, FT_H);
-    hipLaunchKernelGGL(k_fast_nms_b, dim3(fastTiles, 1, count), dim3(256), 0, st, items);
-    hipLaunchKernelGGL(k_cull_fast_b, dim3(D0.nlevels, 1, count), dim3(1024), 0, st, items);
-    hipLaunchKernelGGL(k_harris_b, dim3(64, D0.nlevels, count), dim3(256), 0, st, items);   // wave-strided loop, as k_harris
-    hipLaunchKernelGGL(k_cull_harris_b, dim3(D0.nlevels, 1, count), dim3(1024), 0, st, items);
+    hipLaunchKernelGGL(k_fast_nms_b, dim3(alva_xcd_grid(count, fastTiles)), dim3(256), 0, st, items, count, fastTiles);
+    hipLaunchKernelGGL(k_cull_fast_b, dim3(alva_xcd_grid(count, D0.nlevels)), dim3(1024), 0, st, items, count, D0.nlevels);
+    hipLaunchKernelGGL(k_harris_b, dim3(alva_xcd_grid(count, 64 * D0.nlevels)), dim3(256), 0, st, items, count, 64, D0.nlevels);   // wave-strided loop, as k_harris
+    hipLaunchKernelGGL(k_cull_harris_b, dim3(alva_xcd_grid(count, D0.nlevels)), dim3(1024), 0, st, items, count, D0.nlevels);
     int maxKeep = 0, nmax = 0;
     for (int l = 0; l < D0.nlevels; l++) {
         const int bound = std::min(D0.lv[l].candCap, std::max(4 * D0.lv[l].nKeep + 64, 1024));
         maxKeep = std::max(maxKeep, bound);
         nmax += bound;
     }
-    hipLaunchKernelGGL(k_angle_emit_b, dim3(std::min(64, alva_divup(maxKeep, 4)), D0.nlevels, count), dim3(256), 0, st, items);
+    {
+        const int gx = std::min(64, alva_divup(maxKeep, 4));
+        hipLaunchKernelGGL(k_angle_emit_b, dim3(alva_xcd_grid(count, gx * D0.nlevels)), dim3(256), 0, st, items, count, gx, D0.nlevels);
+    }
     ALVA_LAUNCH_CHECK();
     rc = alva_blur7_multi_launch(ctx, dev + off_blur, count, D0.nlevels, blurTiles);
     if (rc) return rc;
     nmax = std::min(nmax, cap);
-    if (nmax > 0) hipLaunchKernelGGL(k_brief_orb_b, dim3(alva_divup(nmax, 8), 1, count), dim3(256), 0, st, items);
+    if (nmax > 0) hipLaunchKernelGGL(k_brief_orb_b, dim3(alva_xcd_grid(count, alva_divup(nmax, 8))), dim3(256), 0, st, items, count, alva_divup(nmax, 8));
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;
 }

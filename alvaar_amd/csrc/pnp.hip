@@ -72,9 +72,9 @@ __device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robu
                      uint8_t *depth_out) {
     Se3 T;
     se3_from_pose7(p7, T);
-    double acc[NACC];
+    double acc[32];  // NACC sums + padding: reduced in place by wave_reduce_scatter32 (a second 32-entry copy does not fit the register file)
 #pragma unroll
-    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+    for (int k = 0; k < 32; k++) acc[k] = 0.0;
     for (int i = threadIdx.x; i < A.n; i += NT) {
         if (!active[i]) continue;
         const double X[3] = {A.wpt[3 * i], A.wpt[3 * i + 1], A.wpt[3 * i + 2]};
@@ -110,11 +110,8 @@ __device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robu
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (WANT_J) {
-        double v[32];
-#pragma unroll
-        for (int k = 0; k < 32; k++) v[k] = k < NACC ? acc[k] : 0.0;
-        wave_reduce_scatter32(v);  // lane l ends with the wave total of value l >> 1
-        if (!(lane & 1) && (lane >> 1) < NACC) sh.part[wave][lane >> 1] = v[0];
+        wave_reduce_scatter32(acc);  // lane l ends with the wave total of value l >> 1
+        if (!(lane & 1) && (lane >> 1) < NACC) sh.part[wave][lane >> 1] = acc[0];
     } else {
         double v = acc[27];
 #pragma unroll
@@ -131,7 +128,7 @@ __device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robu
 }
 
 // One ceres::Solve on the pose in sh.x.  Returns (block-uniformly) 1 = usable, 0 = failure.
-__device__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *active, double *chi2, uint8_t *depth, double *info) {
+__device__ __forceinline__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *active, double *chi2, uint8_t *depth, double *info) {
     double *H = sh.H, *g = sh.g, *scale = sh.scale, *diag = sh.diag;
     double x_cost = 0, gmax = 0, x_norm = -1, initial = 0, mcc = 0;
     LmState lm;

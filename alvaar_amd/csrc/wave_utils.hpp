@@ -22,8 +22,12 @@ __device__ __forceinline__ void wave_reduce_scatter32(double (&v)[32]) {
         const bool hi = (lane & (2 * half)) != 0;
 #pragma unroll
         for (int k = 0; k < half; k++) {
-            const double send = hi ? v[k] : v[k + half];
-            const double keep = hi ? v[k + half] : v[k];
+            // the two candidates pinned to registers first: otherwise the compiler rewrites "hi ? v[k] : v[k + half]" as
+            // v[hi ? k : k + half], i.e. a lane-dependent index, and the whole array moves to scratch memory
+            double lo_v = v[k], hi_v = v[k + half];
+            asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+            const double send = hi ? lo_v : hi_v;
+            const double keep = hi ? hi_v : lo_v;
             v[k] = keep + __shfl_xor(send, 2 * half);
         }
     }

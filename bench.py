@@ -494,7 +494,7 @@ def bench_track_mono_batch(device: int, cameras: int = 64, reps: int = 10, seed:
     steps_done, fallbacks = tb.stats()
     tb.close()
     traffic = None   # HBM bytes per step from the PMC counters of the 64-camera step with the detector lane (two --pmc passes, tools/frame_step_pmc.py)
-    tfile = ROOT / "profiles" / "r02c_pmc_traffic_frame_step64.json"
+    tfile = ROOT / "profiles" / "r2_pmc_traffic_frame_step64.json"
     if detector and cameras == 64 and tfile.exists():
         per_step = {"k_pyr_stage_batch": 4, "k_resize_b": 7}
         traffic = int(sum(v["hbm_bytes_per_launch"] * per_step.get(k, 1) for k, v in json.loads(tfile.read_text())["kernels"].items()
