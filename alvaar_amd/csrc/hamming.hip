@@ -92,20 +92,23 @@ struct BfItem {
     int nq_cap, nt, nq_pad, chunks;
 };
 
+constexpr int BTPB = 4;
 __global__ void __launch_bounds__(QT) k_bf_partial_b(const BfItem *__restrict__ items, int count, int gx, int gy) {
-    __shared__ uint4 s_t[TC * 2];
+    __shared__ uint4 s_t[TC * BTPB * 2];
     const AlvaXcdItem w = alva_xcd_item(count, gx * gy);   // a camera's descriptor sets go through one XCD's L2
     if (w.cam >= count) return;
     const BfItem it = items[w.cam];
     const int bx = w.item % gx, by = w.item / gx;
-    const int nt = it.nt, t0 = by * TC;
+    const int nt = it.nt, t0 = by * (TC * BTPB);
     if (t0 >= nt) return;  // also: a match without a train set (its count pointer may be null)
     const int nq = min(it.nq_cap, *it.dnq);
     const int lane = threadIdx.x;
-    const int tcount = min(TC, nt - t0);
-    if (lane < tcount) {
-        s_t[2 * lane] = it.t[2 * (size_t) (t0 + lane)];
-        s_t[2 * lane + 1] = it.t[2 * (size_t) (t0 + lane) + 1];
+    // BTPB train tiles per workgroup: the partial minima written for (and read back by) k_bf_final_b shrink by that factor; the
+    // keys carry the train index, so the minimum over a larger set is the same minimum
+    const int tcount = min(TC * BTPB, nt - t0);
+    for (int j = lane; j < tcount; j += QT) {
+        s_t[2 * j] = it.t[2 * (size_t) (t0 + j)];
+        s_t[2 * j + 1] = it.t[2 * (size_t) (t0 + j) + 1];
     }
     __syncthreads();
     for (int qb = bx; qb * QT < nq; qb += gx) {
@@ -168,7 +171,7 @@ extern "C" int alva_bf_match_hamming_batch(alva_ctx *ctx, int count, const uint8
     std::vector<BfItem> items((size_t) count);
     for (int c = 0; c < count; c++) {
         ALVA_ARG(n_train[c] >= 0 && n_train[c] < (1 << 20));
-        const int chunks = alva_divup(n_train[c], TC);
+        const int chunks = alva_divup(n_train[c], TC * BTPB);
         max_chunks = chunks > max_chunks ? chunks : max_chunks;
         partial_words += (size_t) chunks * nq_pad;
     }
@@ -181,7 +184,7 @@ extern "C" int alva_bf_match_hamming_batch(alva_ctx *ctx, int count, const uint8
     for (int c = 0; c < count; c++) {
         BfItem &it = items[(size_t) c];
         it.nt = n_train[c];
-        it.chunks = alva_divup(n_train[c], TC);
+        it.chunks = alva_divup(n_train[c], TC * BTPB);
         if (it.nt > 0) ALVA_ARG(d_query[c] && d_train[c] && d_n_query[c] && d_idx[c] && d_dist[c] && ((uintptr_t) d_query[c] % 16) == 0 && ((uintptr_t) d_train[c] % 16) == 0);
         it.q = (const uint4 *) d_query[c];
         it.t = (const uint4 *) d_train[c];
