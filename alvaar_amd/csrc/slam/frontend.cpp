@@ -53,6 +53,7 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     map_points.clear();
     kf_flat_.clear();
     mp_flat_.clear();
+    mp_nobs_.clear();
     // State::reset (state.cpp:14-18)
     ready_for_init = false;
     reset_requested = false;
@@ -172,24 +173,36 @@ void Slam::klt_from_motion_prior() {
     };
     const int n = (int) cur->kps.size();
     job_ids_.resize((size_t) n);
-    job_px_.resize((size_t) n * 2);
     job_is3d_.resize((size_t) n);
-    job_wpt_.assign((size_t) n * 3, 0.);
+    float *jpx = nullptr;
+    uint8_t *j3d = nullptr;
+    double *jw = nullptr;
+    if (!st->track_slot_buffers(n, &jpx, &j3d, &jw)) {
+        job_px_.resize((size_t) n * 2);
+        job_stage3d_.resize((size_t) n);
+        job_wpt_.resize((size_t) n * 3);
+        jpx = job_px_.data();
+        j3d = job_stage3d_.data();
+        jw = job_wpt_.data();
+    }
     int i = 0;
     for (const auto &e: cur->kps) {
         const KeyPt &k = e.second;
         job_ids_[(size_t) i] = k.id;
-        job_px_[2 * (size_t) i] = k.px[0];
-        job_px_[2 * (size_t) i + 1] = k.px[1];
+        jpx[2 * (size_t) i] = k.px[0];
+        jpx[2 * (size_t) i + 1] = k.px[1];
+        j3d[(size_t) i] = k.is3d;
         job_is3d_[(size_t) i] = k.is3d;
-        if (k.is3d) std::memcpy(&job_wpt_[3 * (size_t) i], map_points.at(k.id)->X, 24);  // .at: throws like the reference (:131) if the map lost it
+        double *w = jw + 3 * (size_t) i;
+        if (k.is3d) std::memcpy(w, map_points.at(k.id)->X, 24);  // .at: throws like the reference (:131) if the map lost it
+        else w[0] = w[1] = w[2] = 0.;
         i++;
     }
     TrackJob job;
     job.n = n;
-    job.px = job_px_.data();
-    job.is3d = job_is3d_.data();
-    job.wpt = job_wpt_.data();
+    job.px = jpx;
+    job.is3d = j3d;
+    job.wpt = jw;
     std::memcpy(job.Tcw_q, cur->Tcw.q, 32);
     std::memcpy(job.Tcw_t, cur->Tcw.t, 24);
     se3_to_pose7(cur->Twc, job.pose7_pred);
@@ -204,10 +217,10 @@ void Slam::klt_from_motion_prior() {
     lap(2);
     for (int pass = 1; pass <= 3; pass++)
         for (int s = 0; s < n; s++)
-            if (r.code[(size_t) s] == pass) cur->update(job_ids_[(size_t) s], &r.px[2 * (size_t) s], &r.unpx[2 * (size_t) s], &r.bv[3 * (size_t) s]);
+            if (r.code_v[(size_t) s] == pass) cur->update(job_ids_[(size_t) s], &r.px_v[2 * (size_t) s], &r.unpx_v[2 * (size_t) s], &r.bv_v[3 * (size_t) s]);
     pose_ids_.clear();
     for (int s = 0; s < n; s++) {
-        if (!r.code[(size_t) s]) remove_obs_from_cur(job_ids_[(size_t) s]);
+        if (!r.code_v[(size_t) s]) remove_obs_from_cur(job_ids_[(size_t) s]);
         else if (job_is3d_[(size_t) s]) pose_ids_.push_back(job_ids_[(size_t) s]);
     }
     lap(3);

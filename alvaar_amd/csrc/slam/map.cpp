@@ -331,6 +331,7 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
             continue;
         }
         mp->obs_kfs.insert(next_kf_id);
+        sync_nobs(*mp);
     }
 }
 
@@ -427,8 +428,12 @@ void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of 
 void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
     std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(next_mp_id, next_kf_id);
     map_points.emplace(next_mp_id, mp);
-    if (mp_flat_.size() <= (size_t) next_mp_id) mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
+    if (mp_flat_.size() <= (size_t) next_mp_id) {
+        mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
+        mp_nobs_.resize(mp_flat_.size(), 0);
+    }
     mp_flat_[(size_t) next_mp_id] = mp.get();
+    sync_nobs(*mp);
     next_mp_id++;
     n_map_points++;
 }
@@ -444,6 +449,7 @@ void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) 
             if (k != keyframes.end()) k->second->turn3d(id);
             else mp.remove_obs(kf);
         }
+        sync_nobs(mp);
         if (mp.observed) cur->turn3d(id);
     }
     mp.X[0] = wpt[0]; mp.X[1] = wpt[1]; mp.X[2] = wpt[2];
@@ -464,6 +470,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
             prev->drop_px(pk);
             nw->note_px(pk, *kf->second->find(new_id));
             nw->obs_kfs.insert(pk);
+            sync_nobs(*nw);
             for (int nk: next_kfs) {
                 auto co = keyframes.find(nk);
                 if (co != keyframes.end()) {
@@ -479,6 +486,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     }
     if (prev->is3d) n_map_points--;
     mp_flat_[(size_t) prev_id] = nullptr;
+    mp_nobs_[(size_t) prev_id] = 0;
     map_points.erase(pit);
     n_merges++;
 }
@@ -491,6 +499,7 @@ void Slam::remove_keyframe(int kfid) {  // map_manager.cpp:515-557
         if (m) {
             m->remove_obs(kfid);
             m->drop_px(kfid);
+            sync_nobs(*m);
         }
     }
     for (const auto &c: it->second->covisible) {
@@ -517,6 +526,7 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     if (mp->observed) cur->remove(id);
     if (mp->is3d) n_map_points--;
     mp_flat_[(size_t) id] = nullptr;
+    mp_nobs_[(size_t) id] = 0;
     if (defer_mp_free_) mp_graveyard_.push_back(mp);
     map_points.erase(it);
 }
@@ -528,6 +538,7 @@ void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-6
     if (m == map_points.end()) return;
     m->second->drop_px(kfid);
     m->second->remove_obs(kfid);
+    sync_nobs(*m->second);
     if (kf != keyframes.end()) {
         const SortedIds obs = m->second->obs_kfs;
         for (int co: obs) {

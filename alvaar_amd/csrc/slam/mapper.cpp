@@ -286,7 +286,17 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                                    // repair only drops that keypoint from this keyframe, so doing it after the walk is the same thing
             for (const auto &e: co->kps) {
                 if (!e.second.is3d) continue;
+                const unsigned nobs = mp_nobs_[(size_t) e.first];
+                if (nobs >= 2 && !check_obs_mirror_) {  // two observers or more: isBad() is false and has no side effect (map_point.cpp:183-202)
+                    if (nobs > 4) good++;
+                    total++;
+                    continue;
+                }
                 MapPt *mp = mp_raw(e.first);
+                if (mp && check_obs_mirror_ && (mp->obs_kfs.size() > 255 ? 255u : (unsigned) mp->obs_kfs.size()) != nobs) {
+                    std::fprintf(stderr, "alva_slam: observer count mirror out of sync (map point %d)\n", mp->id);
+                    std::abort();
+                }
                 if (!mp) {
                     ids_scratch_.push_back(e.first);
                     continue;

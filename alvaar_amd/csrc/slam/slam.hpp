@@ -259,7 +259,7 @@ private:
     // the tracking step's slot tables (reused from frame to frame)
     std::vector<int> job_ids_, pose_ids_;
     std::vector<float> job_px_;
-    std::vector<uint8_t> job_is3d_;
+    std::vector<uint8_t> job_is3d_, job_stage3d_;
     std::vector<double> job_wpt_;
     TrackKlt klt_out_;
     TrackPose pose_out_;
@@ -306,6 +306,10 @@ private:
     MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
     std::vector<FrameRec *> kf_flat_;
     std::vector<MapPt *> mp_flat_;
+    // observer count per map point id (0 = no such point), saturated at 255: the keyframe filter of Mapper::optimize asks "more than
+    // four observers?" of every 3-D keypoint of every covisible keyframe; a byte table answers without touching the map point
+    std::vector<uint8_t> mp_nobs_;
+    void sync_nobs(const MapPt &mp) { mp_nobs_[(size_t) mp.id] = (uint8_t) (mp.obs_kfs.size() > 255 ? 255 : mp.obs_kfs.size()); }
     bool check_obs_mirror_ = false;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns

@@ -36,6 +36,11 @@ struct TrackJob {
 // after the tracker: per slot  code 0 = lost, 1 = tracked from its projected prior on one level, 2 = tracked on the full pyramid,
 // 3 = tracked on the full pyramid after failing with the prior; px / unpx / bv valid where code != 0
 struct TrackKlt {
+    // read through the views; they point at the vectors below (default implementation) or at the implementation's own staging
+    // (the HIP stages: pinned host memory the kernels wrote, valid until the next track_begin)
+    const uint8_t *code_v = nullptr;
+    const float *px_v = nullptr, *unpx_v = nullptr;
+    const double *bv_v = nullptr;
     std::vector<uint8_t> code;
     std::vector<float> px, unpx;
     std::vector<double> bv;
@@ -59,6 +64,9 @@ struct Stages {
     // collected by track_pose_collect -- the map layer does its tracker bookkeeping in between.
     virtual int track_begin(const TrackJob &job, TrackKlt &out);
     virtual int track_pose_collect(TrackPose &out);
+    // Where the map layer may assemble the slot table of the next track_begin (positions, 3-D flags, world points; capacity n):
+    // an implementation that stages its inputs anyway hands out that staging, so the table is written once.  false = none.
+    virtual bool track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) { (void) n; (void) px; (void) is3d; (void) wpt; return false; }
 
     // System::findCameraPose's cvtColor(RGBA2GRAY) (system.cpp:111-112) + VisualFrontend::preprocessImage
     // (visual_frontend.cpp:672-698): the current image / pyramid become the previous ones, the new frame's gray image

@@ -126,6 +126,10 @@ int Stages::track_begin(const TrackJob &job, TrackKlt &out) {
     P.do_p3p = job.do_p3p || out.p3p_req;
     P.do_random = job.do_random;
     std::memcpy(P.pose7, job.pose7_pred, sizeof(P.pose7));
+    out.code_v = out.code.data();
+    out.px_v = out.px.data();
+    out.unpx_v = out.unpx.data();
+    out.bv_v = out.bv.data();
     return 0;
 }
 

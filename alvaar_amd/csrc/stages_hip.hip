@@ -293,6 +293,46 @@ struct HipStages::Impl {
     int trk_cap = 0;
     bool fused = true;       // ALVA_TRACK_UNFUSED=1: compose the tracking step from the fine-grained stages instead (A/B testing)
     bool lists = false;      // ALVA_TRACK_LISTS=1: the fused step with explicit keypoint lists (five launches) instead of slot-wise (three)
+    // pinned staging of the tracking step: slot table in (the map layer writes it there directly, track_slot_buffers), results out
+    struct TrackPin {
+        float *in_px;
+        uint8_t *in_is3d;
+        double *in_wpt;
+        int *o_hdr;
+        uint8_t *o_code;
+        float *o_px, *o_unpx;
+        double *o_bv;
+    };
+    TrackPin track_pin() const {
+        const size_t c = (size_t) trk_cap;
+        TrackPin P;
+        uint8_t *h = trk_pin.base;
+        P.in_px = (float *) h; h += c * 8;
+        P.in_is3d = h; h += c + 64 - (c & 63);
+        P.in_wpt = (double *) h; h += c * 24;
+        P.o_hdr = (int *) h; h += 256;
+        P.o_code = h; h += c + 64 - (c & 63);
+        P.o_px = (float *) h; h += c * 8;
+        P.o_unpx = (float *) h; h += c * 8;
+        P.o_bv = (double *) h; h += c * 24;
+        return P;
+    }
+    int track_reserve(int n) {
+        if (n <= trk_cap) return ALVA_OK;
+        const int cap = ((n + 1023) / 1024 + 1) * 1024;
+        const size_t c = (size_t) cap;
+        // device: cnt | slotA slotB | ptsA priorA outA ptsB priorB outB | stA stB is3d code | wpt | px | Pbv Puv Pwpt  (the list form; the
+        // slot-wise form needs less)
+        const size_t dev_bytes = 256 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64;
+        const size_t pin_bytes = c * 8 + c + 64 + c * 24 + 256 + c + 64 + c * 16 + c * 24 + 256;
+        int rc = trk_dev.grow(dev_bytes, st);
+        if (rc) return rc;
+        rc = trk_pin.grow(pin_bytes, st);
+        if (rc) return rc;
+        trk_cap = cap;
+        ALVA_HIP(hipMemsetAsync(trk_dev.base, 0, 256, st));  // the slot-wise step's counters start at zero
+        return ALVA_OK;
+    }
     bool pose_pending = false;
     int pose_n = 0;
     // a call plans its buffers first (sizes), then the arenas are grown once and carved
@@ -445,27 +485,15 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     m->pose_pending = false;
     pending_.active = false;
     const int n = job.n;
-    out.code.assign((size_t) n, 0);
-    out.px.assign((size_t) n * 2, 0.f);
-    out.unpx.assign((size_t) n * 2, 0.f);
-    out.bv.assign((size_t) n * 3, 0.);
+    out.code_v = nullptr;
+    out.px_v = out.unpx_v = nullptr;
+    out.bv_v = nullptr;
     out.p3p_req = 0;
     out.n_pose = 0;
     if (n == 0) return ALVA_OK;
     ALVA_HIP(hipSetDevice(m->device));
-    if (n > m->trk_cap) {
-        const int cap = ((n + 1023) / 1024 + 1) * 1024;
-        const size_t c = (size_t) cap;
-        // device: cnt | slotA slotB | ptsA priorA outA ptsB priorB outB | stA stB is3d code | wpt | px | Pbv Puv Pwpt
-        const size_t dev_bytes = 256 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64;
-        const size_t pin_bytes = c * 8 + c + 64 + c * 24 + 256 + c + 64 + c * 16 + c * 24 + 256;
-        int rc = m->trk_dev.grow(dev_bytes, m->st);
-        if (rc) return rc;
-        rc = m->trk_pin.grow(pin_bytes, m->st);
-        if (rc) return rc;
-        m->trk_cap = cap;
-        ALVA_HIP(hipMemsetAsync(m->trk_dev.base, 0, 256, m->st));  // the slot-wise step's counters start at zero
-    }
+    int rc = m->track_reserve(n);
+    if (rc) return rc;
     const size_t c = (size_t) m->trk_cap;
     const alva_pyramid *prev = m->pyr[m->cur ^ 1], *cur = m->pyr[m->cur];
     const Camera &k = m->cam;
@@ -475,7 +503,13 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     const float *o_px = nullptr, *o_unpx = nullptr;
     const double *o_bv = nullptr, *Pbv = nullptr, *Puv = nullptr, *Pwpt = nullptr;
     const int *o_hdr = nullptr;
-    int rc = ALVA_OK;
+    const Impl::TrackPin pin = m->track_pin();
+    const bool staged = job.px == pin.in_px && job.is3d == pin.in_is3d && job.wpt == pin.in_wpt;   // track_slot_buffers was used
+    if (!staged) {
+        memcpy(pin.in_px, job.px, (size_t) n * 8);
+        memcpy(pin.in_is3d, job.is3d, (size_t) n);
+        memcpy(pin.in_wpt, job.wpt, (size_t) n * 24);
+    }
     if (!m->lists) {
         TrackSlots D{};
         uint8_t *b = m->trk_dev.base;
@@ -491,18 +525,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.Pbv = (double *) b; b += c * 24;
         D.Puv = (double *) b; b += c * 16;
         D.Pwpt = (double *) b; b += c * 24;
-        uint8_t *h = m->trk_pin.base;
-        D.in_px = (const float *) h; h += c * 8;
-        D.in_is3d = h; h += c + 64 - (c & 63);
-        D.in_wpt = (const double *) h; h += c * 24;
-        D.o_hdr = (int *) h; h += 256;
-        D.o_code = h; h += c + 64 - (c & 63);
-        D.o_px = (float *) h; h += c * 8;
-        D.o_unpx = (float *) h; h += c * 8;
-        D.o_bv = (double *) h; h += c * 24;
-        memcpy((void *) D.in_px, job.px, (size_t) n * 8);
-        memcpy((void *) D.in_is3d, job.is3d, (size_t) n);
-        memcpy((void *) D.in_wpt, job.wpt, (size_t) n * 24);
+        D.in_px = pin.in_px; D.in_is3d = pin.in_is3d; D.in_wpt = pin.in_wpt;
+        D.o_hdr = pin.o_hdr; D.o_code = pin.o_code; D.o_px = pin.o_px; D.o_unpx = pin.o_unpx; D.o_bv = pin.o_bv;
         D.n = n;
         D.use_prior = job.use_prior;
         D.width = m->cam.width;
@@ -545,19 +569,9 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.Pbv = (double *) b; b += c * 24;
         D.Puv = (double *) b; b += c * 16;
         D.Pwpt = (double *) b; b += c * 24;
-        uint8_t *h = m->trk_pin.base;
-        D.in_px = (const float *) h; h += c * 8;
-        D.in_is3d = h; h += c + 64 - (c & 63);
-        D.in_wpt = (const double *) h; h += c * 24;
-        D.o_hdr = (int *) h; h += 256;
-        D.o_code = h; h += c + 64 - (c & 63);
-        D.o_px = (float *) h; h += c * 8;
-        D.o_unpx = (float *) h; h += c * 8;
-        D.o_bv = (double *) h; h += c * 24;
+        D.in_px = pin.in_px; D.in_is3d = pin.in_is3d; D.in_wpt = pin.in_wpt;
+        D.o_hdr = pin.o_hdr; D.o_code = pin.o_code; D.o_px = pin.o_px; D.o_unpx = pin.o_unpx; D.o_bv = pin.o_bv;
     }
-    memcpy((void *) D.in_px, job.px, (size_t) n * 8);
-    memcpy((void *) D.in_is3d, job.is3d, (size_t) n);
-    memcpy((void *) D.in_wpt, job.wpt, (size_t) n * 24);
     D.n = n;
     D.use_prior = job.use_prior;
     D.width = m->cam.width;
@@ -579,10 +593,10 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
     }
     ALVA_HIP(hipStreamSynchronize(m->st));
-    memcpy(out.code.data(), o_code, (size_t) n);
-    memcpy(out.px.data(), o_px, (size_t) n * 8);
-    memcpy(out.unpx.data(), o_unpx, (size_t) n * 8);
-    memcpy(out.bv.data(), o_bv, (size_t) n * 24);
+    out.code_v = o_code;   // read in place (pinned host memory, written by the kernels; stays until the next track_begin)
+    out.px_v = o_px;
+    out.unpx_v = o_unpx;
+    out.bv_v = o_bv;
     out.p3p_req = o_hdr[4];
     out.n_pose = o_hdr[5];
     if (job.want_pose && out.n_pose >= 4) {
@@ -597,6 +611,16 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     pose_total_ = out.n_pose;
     fused_active_ = true;
     return ALVA_OK;
+}
+
+bool HipStages::track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) {
+    if (!m->fused || n <= 0) return false;
+    if (hipSetDevice(m->device) != hipSuccess || m->track_reserve(n) != ALVA_OK) return false;
+    const Impl::TrackPin pin = m->track_pin();
+    *px = pin.in_px;
+    *is3d = pin.in_is3d;
+    *wpt = pin.in_wpt;
+    return true;
 }
 
 int HipStages::track_pose_collect(TrackPose &out) {

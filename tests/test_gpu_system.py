@@ -110,6 +110,17 @@ def test_system_equals_reference_2000_keypoints():
     _differential(frames, w, h, 12, True, 1e-5, 3, 2)
 
 
+def test_system_equals_reference_long_stream():
+    """660 frames (200-frame crop sequence with noise, forwards / backwards): more than 30 keyframes -- the 30-keyframe window, the keyframe
+    filter of Mapper::optimize (from keyframe 20 on), the second local-map round; >= 120 tracked frames after initialisation"""
+    w, h, n = 640, 480, 200
+    canvas = synth.texture_canvas(w, h, 7)
+    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
+    period = 2 * (n - 1)
+    frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(660)]
+    _differential(frames, w, h, 40, True, 1e-5, 8, 30)
+
+
 def test_system_equals_reference_rotating_camera_with_noise():
     w, h = 640, 480
     f = sysdiff.intrinsics(w, h)[0]

@@ -91,3 +91,26 @@ def test_distortion_and_clahe_wired():
     frames = (synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(60))
     statuses, _, _, _ = _run(frames, w, h, 40, 2, clahe=True, dist=(-0.12, 0.03, 0.0006, -0.0004))
     assert 1 in statuses
+
+
+def test_long_stream_keyframe_window_and_filter():
+    """660 frames (the 200-frame crop sequence forwards / backwards, cell 40): more than 30 keyframes, so the 30-keyframe window
+    (mapper.cpp:24-28), the keyframe filter of Mapper::optimize from keyframe 20 on (:74-141) and the second local-map round
+    (:316-330) all run; every mirror the map layer keeps beside the reference's containers is checked on every read
+    (ALVA_CHECK_OBS_MIRROR=1)"""
+    import os
+    w, h, n = 640, 480, 200
+    canvas = synth.texture_canvas(w, h, 7)
+    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
+    period = 2 * (n - 1)
+
+    def frames():
+        for k in range(660):
+            r = k % period
+            yield base[r if r < n else period - r]
+    os.environ["ALVA_CHECK_OBS_MIRROR"] = "1"
+    try:
+        statuses, cnt, _, _ = _run(frames(), w, h, 40, 31)
+    finally:
+        del os.environ["ALVA_CHECK_OBS_MIRROR"]
+    assert statuses[-1] == 1 and cnt["culled_keyframes"] >= 1 and cnt["ba_solves"] >= 30, cnt
