@@ -230,6 +230,47 @@ class SystemJob:
         return st == 1
 
 
+def bench_system_streams(device: int, n_streams: int, steps: int = 300):
+    """S independent camera sessions on ONE GPU: S alva::System objects (each its own HIP stream, pyramids, map), one host thread each,
+    all fed the same resident frames.  A single session leaves the GPU idle most of the time (every kernel of its chain is latency-
+    bound) and its host-side map layer runs on one core; sessions are independent, so they overlap.  Aggregate frames/s."""
+    import threading
+    jobs = [SystemJob(device, 7, host_copy=False) if i == 0 else None for i in range(n_streams)]
+    for i in range(1, n_streams):   # share the resident frames (read-only); every session has its own System
+        j = SystemJob.__new__(SystemJob)
+        j.__dict__.update(jobs[0].__dict__)
+        from alvaar_amd.system import AlvaAR
+        j.ar = AlvaAR(W, H, device=device, cell_size=SYSTEM_CELL, random_sampling=False)
+        j.k = -1
+        j.status_hist = [0, 0, 0, 0]
+        jobs[i] = j
+    for j in jobs:   # past the initialisation, into steady tracking
+        for _ in range(60):
+            j.step()
+    start = threading.Barrier(n_streams + 1)
+    done = []
+
+    def run(j):
+        start.wait()
+        for _ in range(steps):
+            j.step()
+        done.append(time.perf_counter())
+    th = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = max(done) - t0
+    tracked = sum(j.status_hist[1] for j in jobs)
+    for j in jobs:
+        j.ar.close()
+    return {"sessions": n_streams, "frames_per_s": n_streams * steps / dt, "frames_per_s_per_session": steps / dt, "steps_per_session": steps,
+            "tracked_frac": tracked / (n_streams * (steps + 60)),
+            "note": "S independent alva::System sessions on one GPU, one host thread each (Python threads; the C call releases the GIL), frames resident in HBM"}
+
+
 def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5):
     """S independent camera streams on ONE GPU, each with its own alva_frontend (two HIP streams) and its own host thread
     inside the library (alva_frontend_run_many).  Every stage of a single stream is latency-bound at these sizes, so
@@ -615,6 +656,9 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="accepted for compatibility (the default now)")
     ap.add_argument("--python-host", action="store_true", help="headline number with the stage calls issued from Python")
     ap.add_argument("--serial", action="store_true", help="headline number on one HIP stream (no detector/tracker overlap)")
+    ap.add_argument("--system-streams", type=str, default="",
+                    help="comma-separated session counts: also time S independent alva::System sessions on rank 0's GPU (reported under "
+                         "system_streams; not part of value; off by default for the same reason as --multi-stream)")
     ap.add_argument("--streams-per-gpu", type=int, default=0,
                     help="also time S concurrent independent streams on rank 0's GPU (reported under multi_stream; not part of value)")
     args = ap.parse_args()
@@ -769,6 +813,8 @@ def main():
         elif world == 1 and args.multi_stream:
             # secondary: several independent cameras on the one GPU (native host threads); shows the head-room a single stream leaves
             out["multi_stream"] = [bench_multi_stream(local, s_, 60) for s_ in (4, 16)]
+        if args.system_streams and world == 1:
+            out["system_streams"] = [bench_system_streams(local, int(v)) for v in args.system_streams.split(",")]
         if not args.no_cpu_baseline and world == 1:   # the contract: reference CPU path timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(shard.stream_seed)
         print(json.dumps(out))
