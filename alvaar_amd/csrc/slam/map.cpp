@@ -69,9 +69,48 @@ const KeyPt *FrameRec::find(int id_) const {
     return it == kps.end() ? nullptr : &it->second;
 }
 
+void FrameRec::slim_build() {
+    slim.clear();
+    slim.active = true;
+    slim.buckets = kps.bucket_count();
+    const size_t n = kps.size();
+    slim.id.reserve(n); slim.next.reserve(n); slim.prev.reserve(n); slim.is3d.reserve(n);
+    int last = -1;
+    for (auto &e: kps) {
+        const int s = slim.alloc();
+        slim.id[(size_t) s] = e.first;
+        slim.is3d[(size_t) s] = e.second.is3d;
+        slim.prev[(size_t) s] = last;
+        slim.next[(size_t) s] = -1;
+        if (last >= 0) slim.next[(size_t) last] = s;
+        else slim.head = s;
+        last = s;
+        e.second.slim = s;
+    }
+}
+
+bool FrameRec::slim_matches() const {
+    int s = slim.head;
+    for (const auto &e: kps) {
+        if (s < 0 || slim.id[(size_t) s] != e.first || (slim.is3d[(size_t) s] != 0) != e.second.is3d || e.second.slim != s) return false;
+        s = slim.next[(size_t) s];
+    }
+    return s < 0;
+}
+
 void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
     if (kps.count(k.id)) return;
-    kps.emplace(k.id, k);
+    if (slim.active) {
+        // where libstdc++ will link the new node: in front of its bucket's first node, or at the list's front when the bucket is empty
+        const size_t b = kps.bucket(k.id);
+        auto first = kps.begin(b);
+        const int before = first != kps.end(b) ? first->second.slim : -1;
+        auto it = kps.emplace(k.id, k).first;
+        if (kps.bucket_count() != slim.buckets) slim_build();   // grew: rehashed, the whole order changed
+        else it->second.slim = slim.insert(k.id, k.is3d, before);
+    } else {
+        kps.emplace(k.id, k);
+    }
     grid_add(k);
     n_kps++;
     if (k.is3d) n_3d++;
@@ -119,6 +158,7 @@ void FrameRec::remove(int id_) {  // :209-232
     if (it->second.is3d) n_3d--;
     else n_2d--;
     n_kps--;
+    if (slim.active) slim.erase(it->second.slim);
     kps.erase(id_);
 }
 
@@ -127,6 +167,7 @@ void FrameRec::turn3d(int id_) {  // :234-248
     if (it == kps.end()) return;
     if (!it->second.is3d) {
         it->second.is3d = true;
+        if (slim.active) slim.is3d[(size_t) it->second.slim] = 1;
         n_3d++;
         n_2d--;
     }
@@ -187,6 +228,7 @@ void FrameRec::reset() {  // :467-489
     kfid = 0;
     timestamp = 0.;
     kps.clear();
+    slim.clear();
     grid.clear();
     grid.resize(grid_cells);
     n_kps = n_2d = n_3d = 0;
@@ -398,6 +440,13 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     }
 }
 
+void Slam::check_slim(const FrameRec &kf) const {
+    if (check_obs_mirror_ && kf.slim.active && !kf.slim_matches()) {
+        std::fprintf(stderr, "alva_slam: keypoint order mirror of keyframe %d out of sync\n", kf.kfid);
+        std::abort();
+    }
+}
+
 const ObsPx *Slam::obs_of(const MapPt &mp, int kfid) const {
     const ObsPx *o = mp.seen_in(kfid);
     if (o && !o->in_kf) o = nullptr;
@@ -414,6 +463,7 @@ const ObsPx *Slam::obs_of(const MapPt &mp, int kfid) const {
 
 void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of the current frame
     std::shared_ptr<FrameRec> kf = std::make_shared<FrameRec>(*cur);
+    kf->slim_build();
     for (const auto &e: kf->kps) {
         MapPt *m = mp_raw(e.first);
         if (m) m->note_px(next_kf_id, e.second);
@@ -574,7 +624,9 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
     // integers) and poured into the ordered map afterwards: a std::map's content and order do not depend on how it was filled
     std::vector<int> &count = index_scratch_;
     count.assign((size_t) next_kf_id + 2, 0);
-    for (int id: ids_scratch_) {
+    for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
+        const int id = ids_scratch_[oi];
+        prefetch_mp(ids_scratch_.data(), oi, ids_scratch_.size());
         MapPt *m = mp_raw(id);
         if (!m) {
             remove_map_point_obs(id, frame.kfid);
@@ -603,14 +655,15 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
         FrameRec *kf = kf_raw(c.first);
         if (kf) {
             kf->covisible[frame.kfid] = c.second;
-            for (const auto &e: kf->kps) {  // getKeypoints3d(): container order, 3-D only
-                const size_t id = (size_t) e.first;
-                if (e.second.is3d && !mark_a_[id] && !mark_b_[id]) {
+            check_slim(*kf);
+            kf->for_each_id([&](int kid, bool is3d) {  // getKeypoints3d(): container order, 3-D only
+                const size_t id = (size_t) kid;
+                if (is3d && !mark_a_[id] && !mark_b_[id]) {
                     mark_b_[id] = 1;
-                    touched_b_.push_back(e.first);
-                    local_ids.insert(e.first);
+                    touched_b_.push_back(kid);
+                    local_ids.insert(kid);
                 }
-            }
+            });
         } else {
             bad.insert(c.first);
         }

@@ -221,6 +221,7 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     std::vector<int> obs_ptr((size_t) n_mp + 1, 0), obs_kf;
     std::vector<float> obs_px;
     for (int m = 0; m < n_mp; m++) {
+        prefetch_mp(mp_ids.data(), (size_t) m, (size_t) n_mp);
         const MapPt &mp = *mp_raw(mp_ids[(size_t) m]);
         std::memcpy(&mp_wpt[3 * (size_t) m], mp.X, 24);
         mp_is3d[(size_t) m] = mp.is3d;
@@ -284,29 +285,30 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
             size_t good = 0, total = 0;
             ids_scratch_.clear();  // keypoints whose map point is gone: the reference repairs them while walking a COPY (:101-111); the
                                    // repair only drops that keypoint from this keyframe, so doing it after the walk is the same thing
-            for (const auto &e: co->kps) {
-                if (!e.second.is3d) continue;
-                const unsigned nobs = mp_nobs_[(size_t) e.first];
+            check_slim(*co);
+            co->for_each_id([&](int kid, bool is3d) {
+                if (!is3d) return;
+                const unsigned nobs = mp_nobs_[(size_t) kid];
                 if (nobs >= 2 && !check_obs_mirror_) {  // two observers or more: isBad() is false and has no side effect (map_point.cpp:183-202)
                     if (nobs > 4) good++;
                     total++;
-                    continue;
+                    return;
                 }
-                MapPt *mp = mp_raw(e.first);
+                MapPt *mp = mp_raw(kid);
                 if (mp && check_obs_mirror_ && (mp->obs_kfs.size() > 255 ? 255u : (unsigned) mp->obs_kfs.size()) != nobs) {
                     std::fprintf(stderr, "alva_slam: observer count mirror out of sync (map point %d)\n", mp->id);
                     std::abort();
                 }
                 if (!mp) {
-                    ids_scratch_.push_back(e.first);
-                    continue;
+                    ids_scratch_.push_back(kid);
+                    return;
                 } else if (mp->is_bad()) {
-                    continue;
+                    return;
                 } else if (mp->obs_kfs.size() > 4) {
                     good++;
                 }
                 total++;
-            }
+            });
             for (int id: ids_scratch_) remove_map_point_obs(id, kfid);
             const float ratio = (float) good / (float) total;
             if (ratio > cfg.keyframe_filtering_ratio) {
@@ -370,12 +372,14 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (score >= min_cov && !all_cst && kfid > 0) {
             add_pose(kfid, *kf, false);
             kfs_to_opt.insert(kfid);
-            for (const auto &e: kf->kps)
-                if (e.second.is3d && !mark_a_[(size_t) e.first]) {  // a repeated insert would not change the set
-                    mark_a_[(size_t) e.first] = 1;
-                    touched_a_.push_back(e.first);
-                    mps_to_opt.insert(e.first);
+            check_slim(*kf);
+            kf->for_each_id([&](int kid, bool is3d) {
+                if (is3d && !mark_a_[(size_t) kid]) {  // a repeated insert would not change the set
+                    mark_a_[(size_t) kid] = 1;
+                    touched_a_.push_back(kid);
+                    mps_to_opt.insert(kid);
                 }
+            });
         } else {
             add_pose(kfid, *kf, true);
             const_kfs.insert(kfid);
@@ -392,7 +396,10 @@ void Slam::local_ba(FrameRec &new_frame) {
     std::vector<double> pt_anchor_uv, pt_inv, obs_uv;
     std::vector<ObsRec> obs_rec;
     std::pmr::unordered_map<int, int> pt_slot(&arena);  // map_id_invptspar_
-    for (int lmid: mps_to_opt) {
+    ids_scratch_.assign(mps_to_opt.begin(), mps_to_opt.end());   // the set's order, as an array (for the prefetcher; the loop below does not edit the set)
+    for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
+        const int lmid = ids_scratch_[oi];
+        prefetch_mp(ids_scratch_.data(), oi, ids_scratch_.size());
         MapPt *mp = mp_raw(lmid);
         if (!mp) continue;
         if (mp->is_bad()) {

@@ -33,6 +33,66 @@ struct KeyPt {
     Desc desc{};
     bool has_desc = false;
     bool is3d = false;
+    int slim = -1;   // slot in the owning frame's SlimOrder (keyframes only; see there)
+};
+
+// (id, is3d) of a KEYFRAME's keypoints in the iteration order of its mapKeypoints_, as flat arrays.  Three loops of every keyframe step
+// walk all keypoints of every covisible keyframe only to look at these two fields (updateFrameCovisibility map_manager.cpp:116-140, the
+// free-keyframe sweep of localBA optimizer.cpp:60-100, the keyframe filter mapper.cpp:94-128); walking 29 x 2600 hash nodes of 128
+// bytes each is most of their cost.  The order of a libstdc++ unordered_map with unique keys is its singly linked node list: an insert
+// puts the node at the FRONT of its bucket's run (immediately before the run's current first node) or, when the bucket is empty, at the
+// front of the whole list; an erase unlinks; a rehash (growth only) rebuilds.  A keyframe's table is a copy that never grows (the only
+// inserts are the id changes of mergeMapPoints: erase + insert), so the mirror is maintained with exactly that rule and rebuilt by a walk
+// if the bucket count ever changes.  ALVA_CHECK_OBS_MIRROR=1 compares it with the container at every use.
+struct SlimOrder {
+    std::vector<int> id, next, prev;
+    std::vector<uint8_t> is3d;
+    int head = -1, free_head = -1;
+    bool active = false;
+    size_t buckets = 0;
+    void clear() {
+        id.clear(); next.clear(); prev.clear(); is3d.clear();
+        head = free_head = -1;
+        active = false;
+        buckets = 0;
+    }
+    int alloc() {
+        if (free_head >= 0) {
+            const int s = free_head;
+            free_head = next[(size_t) s];
+            return s;
+        }
+        id.push_back(-1); next.push_back(-1); prev.push_back(-1); is3d.push_back(0);
+        return (int) id.size() - 1;
+    }
+    // before < 0: at the front of the list; otherwise immediately before slot `before`
+    int insert(int key, bool three_d, int before) {
+        const int s = alloc();
+        id[(size_t) s] = key;
+        is3d[(size_t) s] = three_d;
+        if (before < 0 || before == head) {
+            next[(size_t) s] = head;
+            prev[(size_t) s] = -1;
+            if (head >= 0) prev[(size_t) head] = s;
+            head = s;
+        } else {
+            const int p = prev[(size_t) before];
+            next[(size_t) s] = before;
+            prev[(size_t) s] = p;
+            next[(size_t) p] = s;
+            prev[(size_t) before] = s;
+        }
+        return s;
+    }
+    void erase(int s) {
+        const int p = prev[(size_t) s], n = next[(size_t) s];
+        if (p >= 0) next[(size_t) p] = n;
+        else head = n;
+        if (n >= 0) prev[(size_t) n] = p;
+        id[(size_t) s] = -1;
+        next[(size_t) s] = free_head;
+        free_head = s;
+    }
 };
 
 // tunables, state.hpp:29-78 with the overrides of System::configure (system.cpp:15-19)
@@ -57,6 +117,7 @@ struct FrameRec {
     int id = -1, kfid = 0;
     double timestamp = 0;
     std::unordered_map<int, KeyPt> kps;        // mapKeypoints_
+    SlimOrder slim;                            // mirror of (id, is3d) in kps' order; active for keyframes only
     std::vector<std::vector<int>> grid;        // gridKeypointsIds_
     size_t grid_cells = 0, n_occupied = 0, cell = 0, cells_w = 0, cells_h = 0, n_kps = 0, n_2d = 0, n_3d = 0;
     SE3 Twc, Tcw;
@@ -75,6 +136,17 @@ struct FrameRec {
     bool change_id(int prev_id, int new_id, bool is3d);
     void remove(int id);
     void turn3d(int id);
+    void slim_build();                         // (re)build the mirror by one walk over kps
+    bool slim_matches() const;                 // the mirror equals the container, element by element (check mode)
+    // f(id, is3d) for every keypoint in mapKeypoints_ order -- through the mirror when there is one
+    template <class F>
+    void for_each_id(F &&f) const {
+        if (slim.active) {
+            for (int sl = slim.head; sl >= 0; sl = slim.next[(size_t) sl]) f(slim.id[(size_t) sl], slim.is3d[(size_t) sl] != 0);
+        } else {
+            for (const auto &e: kps) f(e.first, e.second.is3d);
+        }
+    }
     bool observes(int id) const { return kps.count(id) != 0; }
     int cell_index(const float *px) const;
     void grid_add(const KeyPt &k);
@@ -302,6 +374,24 @@ private:
     std::shared_ptr<MapPt> map_point(int id) const;
     // The same look-ups through flat mirrors of the two hash maps: ids are handed out consecutively, so id -> object is an array
     // access.  The hash maps stay authoritative (their iteration order is behaviour); every insert / erase / clear updates the mirror.
+    // software prefetch for loops that visit map points in an order the hardware cannot predict: the object `far` items ahead, its two
+    // small vectors' storage `near` items ahead (their addresses are only known once the object is in cache)
+    void prefetch_mp(const int *ids, size_t i, size_t n, size_t near_d = 6, size_t far_d = 14) const {
+        if (i + far_d < n) {
+            const MapPt *f = mp_raw(ids[i + far_d]);
+            if (f) __builtin_prefetch(f);
+        }
+        if (i + near_d < n) {
+            const MapPt *m = mp_raw(ids[i + near_d]);
+            if (m) {
+                __builtin_prefetch(m->obs_kfs.v.data());
+                const char *rec = (const char *) m->seen.data();
+                __builtin_prefetch(rec);
+                __builtin_prefetch(rec + 64);
+                __builtin_prefetch(rec + 128);
+            }
+        }
+    }
     FrameRec *kf_raw(int id) const { return id >= 0 && (size_t) id < kf_flat_.size() ? kf_flat_[(size_t) id] : nullptr; }
     MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
     std::vector<FrameRec *> kf_flat_;
@@ -311,6 +401,7 @@ private:
     std::vector<uint8_t> mp_nobs_;
     void sync_nobs(const MapPt &mp) { mp_nobs_[(size_t) mp.id] = (uint8_t) (mp.obs_kfs.size() > 255 ? 255 : mp.obs_kfs.size()); }
     bool check_obs_mirror_ = false;
+    void check_slim(const FrameRec &kf) const;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
     std::vector<std::shared_ptr<MapPt>> mp_graveyard_;
