@@ -286,6 +286,34 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
             ids_scratch_.clear();  // keypoints whose map point is gone: the reference repairs them while walking a COPY (:101-111); the
                                    // repair only drops that keypoint from this keyframe, so doing it after the walk is the same thing
             check_slim(*co);
+            bool counted = false;
+            if (co->slim.active && !check_obs_mirror_) {
+                // Nothing in this loop depends on the ORDER of the walk: good / total are counts, isBad() acts on one map point, and the
+                // repairs drop different keypoints of this keyframe (erasing from a hash table or a cell list commutes).  So the mirror's
+                // slots are taken in memory order, with the observer-count byte table in front of the map point.
+                const SlimOrder &so = co->slim;
+                const size_t ns = so.id.size();
+                for (size_t sl = 0; sl < ns; sl++) {
+                    const int kid = so.id[sl];
+                    if (kid < 0 || !so.is3d[sl]) continue;
+                    const unsigned nobs = mp_nobs_[(size_t) kid];
+                    if (nobs >= 2) {  // two observers or more: isBad() is false and has no side effect (map_point.cpp:183-202)
+                        good += nobs > 4;
+                        total++;
+                        continue;
+                    }
+                    MapPt *mp = mp_raw(kid);
+                    if (!mp) {
+                        ids_scratch_.push_back(kid);
+                        continue;
+                    }
+                    if (mp->is_bad()) continue;
+                    if (mp->obs_kfs.size() > 4) good++;
+                    total++;
+                }
+                counted = true;
+            }
+            if (!counted)
             co->for_each_id([&](int kid, bool is3d) {
                 if (!is3d) return;
                 const unsigned nobs = mp_nobs_[(size_t) kid];
