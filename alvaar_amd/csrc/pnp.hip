@@ -24,6 +24,7 @@
 #include "pose_internal.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -40,6 +41,7 @@ struct PnpArgs {
     int use_robust, apply_l2, max_iters;
     double ftol;
     double pose0[7];  // initial pose (ignored in chained mode)
+    int seq;          // k_pnp publishes it in PnpOut::seq after every result (system-scope release): a host may poll that word
 };
 
 struct PnpOut {
@@ -47,7 +49,7 @@ struct PnpOut {
     double info[8];
     int ok, n_bad;
     int p3p_ok, n_active;  // chained mode: P3P verdict and the number of points handed to the refinement
-    int p3p_n_valid_used, pad;
+    int p3p_n_valid_used, seq;
     double pose_p3p[7];  // chained mode: the accepted P3P pose as the refinement starts from it (normalised quaternion)
 };
 
@@ -394,6 +396,9 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ act
                                             const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
                                             uint8_t *__restrict__ p3p_outlier) {
     pnp_block(A, active, chi2, depth, bad, out, p3p, inlier0, p3p_outlier);
+    __threadfence_system();   // this thread's writes to `out` / `bad` / `p3p_outlier` (possibly pinned host memory) ...
+    __syncthreads();          // ... of every thread ...
+    if (threadIdx.x == 0) __hip_atomic_store(&out->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the word a host may poll
 }
 
 // B chained P3P -> PnP problems in one launch, one workgroup each (blockIdx.x = camera).
@@ -474,6 +479,7 @@ struct alva_pose_pending {
     size_t poff_out, poff_bad, poff_po;
     uint8_t *pin;
     bool active;
+    int seq = 0;
 };
 
 static void pose_pending_free(void *p) { delete (alva_pose_pending *) p; }
@@ -496,6 +502,8 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
     rc = alva_p3p_enqueue(ctx, P.bearings, P.wpts, n, P.p3p_iters, P.p3p_err, P.do_random, P.seed, P.fx, P.fy, P.H, (int *) P.pin, d_sel,
                           d_inl);
     if (rc) return rc;
+    P.A.seq = ++P.seq;
+    ((PnpOut *) (P.pin + P.poff_out))->seq = 0;   // the staging may be fresh memory; every earlier user of it has completed (polled or synchronised)
     hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad,
                        (PnpOut *) (P.pin + P.poff_out), (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po);
     ALVA_LAUNCH_CHECK();
@@ -559,8 +567,24 @@ int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose
     const int n = P.n;
     if (n < 4) return ALVA_OK;
     PnpOut res{};
+    static const bool poll = getenv("ALVA_NO_POLL") == nullptr;
     for (;;) {
-        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        if (poll) {
+            // k_pnp publishes its sequence number after all results; spinning on that word in pinned memory returns a few microseconds
+            // before hipStreamSynchronize would (the stream itself is waited for by whoever synchronises next)
+            const volatile int *flag = &((const PnpOut *) (P.pin + P.poff_out))->seq;
+            unsigned spins = 0;
+            while (*flag != P.seq) {
+                if (++spins > (1u << 26)) {
+                    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        } else {
+            ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        }
         memcpy(&res, P.pin + P.poff_out, sizeof(res));
         if (res.p3p_n_valid_used >= P.p3p_iters || P.H >= P.max_draws) break;
         P.H = std::min(P.max_draws, P.H * 2);   // rare: too many degenerate samples, redo with a longer prefix of the stream

@@ -239,6 +239,8 @@ __global__ void __launch_bounds__(TRK_NT) k_track_compact(TrackSlots D) {
         D.o_hdr[0] = nA; D.o_hdr[1] = D.n - nA; D.o_hdr[2] = D.n - good; D.o_hdr[3] = good; D.o_hdr[4] = req ? 1 : 0; D.o_hdr[5] = base;
         D.cnt[0] = 0;
         D.cnt[1] = 0;
+        __threadfence_system();
+        __hip_atomic_store(D.o_hdr + 8, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -292,6 +294,8 @@ struct HipStages::Impl {
     Arena trk_dev, trk_pin;
     int trk_cap = 0;
     bool fused = true;       // ALVA_TRACK_UNFUSED=1: compose the tracking step from the fine-grained stages instead (A/B testing)
+    bool poll = true;        // wait for the tracking step by polling its completion word in pinned memory (ALVA_NO_POLL=1: stream synchronisation)
+    int trk_seq = 0;
     bool lists = false;      // ALVA_TRACK_LISTS=1: the fused step with explicit keypoint lists (five launches) instead of slot-wise (three)
     // pinned staging of the tracking step: slot table in (the map layer writes it there directly, track_slot_buffers), results out
     struct TrackPin {
@@ -403,6 +407,7 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->trk_pin.pinned = true;
     m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
     m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
+    m->poll = getenv("ALVA_NO_POLL") == nullptr;
     int rc = alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -503,6 +508,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     const float *o_px = nullptr, *o_unpx = nullptr;
     const double *o_bv = nullptr, *Pbv = nullptr, *Puv = nullptr, *Pwpt = nullptr;
     const int *o_hdr = nullptr;
+    int poll_seq = 0;
     const Impl::TrackPin pin = m->track_pin();
     const bool staged = job.px == pin.in_px && job.is3d == pin.in_is3d && job.wpt == pin.in_wpt;   // track_slot_buffers was used
     if (!staged) {
@@ -542,8 +548,10 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
             rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 1);
             if (rc) return rc;
         }
+        D.seq = ++m->trk_seq;
         hipLaunchKernelGGL(k_track_compact, dim3(1), dim3(TRK_NT), 0, m->st, D);
         ALVA_LAUNCH_CHECK();
+        poll_seq = m->poll ? D.seq : 0;
         o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
         Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
     } else {
@@ -592,7 +600,22 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
     Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
     }
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    if (poll_seq) {
+        // the compaction kernel publishes its sequence number after all results (system-scope release); spinning on that word in pinned
+        // memory returns a few microseconds before hipStreamSynchronize would
+        const volatile int *flag = o_hdr + 8;
+        unsigned spins = 0;
+        while (*flag != poll_seq) {
+            if (++spins > (1u << 26)) {   // ~ seconds: something is wrong with the stream; let the runtime report it
+                ALVA_HIP(hipStreamSynchronize(m->st));
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+        ALVA_HIP(hipStreamSynchronize(m->st));
+    }
     out.code_v = o_code;   // read in place (pinned host memory, written by the kernels; stays until the next track_begin)
     out.px_v = o_px;
     out.unpx_v = o_unpx;

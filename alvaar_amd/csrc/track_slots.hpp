@@ -33,6 +33,7 @@ struct TrackSlots {
     float *o_px, *o_unpx;
     double *o_bv;
     int *o_hdr;
+    int seq;                   // written to o_hdr[8] (system scope) after everything else: the host may poll it instead of waiting on the stream
     double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
 };
 
