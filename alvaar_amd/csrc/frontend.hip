@@ -145,6 +145,9 @@ extern "C" int alva_frontend_track_ahead(alva_frontend *fe, const uint8_t *d_rgb
             ALVA_HIP(hipStreamWaitEvent(fe->B->stream, fe->prebuilt_done, 0));
         }
     } else {
+        // a look-ahead build for ANOTHER frame may still be writing this pyramid / gray image on lane C: order lane A behind it
+        if (fe->prebuilt && fe->prebuilt_done && hipEventQuery(fe->prebuilt_done) != hipSuccess)
+            ALVA_HIP(hipStreamWaitEvent(fe->A->stream, fe->prebuilt_done, 0));
         // lane A: preprocessImage
         rc = alva_pyramid_build_from_rgba(fe->A, fe->pyr[cur], d_rgba, rgba_pitch, fe->d_gray[g], (size_t) fe->width);
         if (rc) return rc;

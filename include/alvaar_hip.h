@@ -223,7 +223,9 @@ int alva_compute_pose(alva_ctx *ctx, const double *d_bearings, const double *d_u
                       float fx, float fy, float cx, float cy, double *h_pose7, uint8_t *h_p3p_outlier,
                       uint8_t *h_pnp_outlier, int *h_status);
 /* The same in two halves: _enqueue launches the chain without waiting, _collect waits and returns the results.  No other
- * call may be made on `ctx` in between (other contexts / streams are free to run: that is the point). */
+ * call may be made on `ctx` in between (other contexts / streams are free to run: that is the point).  _collect waits on a completion
+ * word the last kernel publishes in pinned host memory after all results (ALVA_NO_POLL=1: on the stream instead); later calls on `ctx`
+ * are stream-ordered behind the chain either way. */
 int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
                               int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th,
                               float fx, float fy, float cx, float cy);
@@ -356,8 +358,10 @@ int alva_frontend_track(alva_frontend *fe, const uint8_t *d_rgba, size_t rgba_pi
                         float fy, float cx, float cy, double *h_pose7, int *h_pose_status, int *h_n_keypoints);
 /* The same with one frame of look-ahead: d_rgba_next (may be NULL) is the frame the NEXT call will pass as d_rgba; its gray
  * image and pyramid are built on a third HIP stream while this frame is tracked, so preprocessImage leaves the dependent chain
- * pyramid -> KLT -> P3P -> PnP.  The buffer must not change until that call; a next call with any other d_rgba simply rebuilds.
- * Results are identical to alva_frontend_track. */
+ * pyramid -> KLT -> P3P -> PnP.  Contract: d_rgba_next is read asynchronously from now until the NEXT alva_frontend_track* call on this
+ * object has returned, so its contents must not change in between, and "the same pointer" on that next call means "the same, unchanged
+ * contents" (the look-ahead result is used as is).  A next call with any other d_rgba waits for the pending look-ahead build and
+ * rebuilds.  Results are identical to alva_frontend_track. */
 int alva_frontend_track_ahead(alva_frontend *fe, const uint8_t *d_rgba, size_t rgba_pitch, const uint8_t *d_rgba_next,
                               const float *d_pts, int n_pts, const double *d_bearings, const double *d_uv, const double *d_wpts,
                               int n_corr, float fx, float fy, float cx, float cy, double *h_pose7, int *h_pose_status,
