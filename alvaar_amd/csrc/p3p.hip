@@ -513,7 +513,16 @@ extern "C" int alva_p3p_draw_samples(int n_points, int count, int do_random, uin
 
 int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold,
                      int do_random, uint32_t seed, float fx, float fy, int H, int *pin_samples, P3pSelectOut *out, uint8_t *inlier) {
-    ALVA_ARG(n >= 4 && n <= 7168);  // LDS-resident median select (n * 8 B + histogram < 64 KB)
+    // LDS-resident median select: n * 8 B of keys beside ~8 KB of static LDS.  Up to 7168 keys fit the default 64 KB per workgroup; gfx950
+    // has 160 KB per CU and a workgroup may take it all once the kernel's limit is raised (a 4K frame has ~10 k 3-D keypoints)
+    ALVA_ARG(n >= 4 && n <= 19000);
+    if (n > 7168) {
+        static bool raised = false;
+        if (!raised) {
+            ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_p3p), hipFuncAttributeMaxDynamicSharedMemorySize, 19000 * 8));
+            raised = true;
+        }
+    }
     float focal = fx + fy;          // multi_view_geometry.cpp:72-76
     focal /= 2.f;
     const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));

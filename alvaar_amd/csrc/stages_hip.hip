@@ -623,8 +623,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     out.p3p_req = o_hdr[4];
     out.n_pose = o_hdr[5];
     if (job.want_pose && out.n_pose >= 4) {
-        // P3P-LMedS keeps its median in LDS: at most 7168 correspondences (the first ones, in slot order, when a frame has more)
-        m->pose_n = out.n_pose > 7168 ? 7168 : out.n_pose;
+        // P3P-LMedS keeps its median in LDS: at most 19000 correspondences (the first ones, in slot order, when a frame has more)
+        m->pose_n = out.n_pose > 19000 ? 19000 : out.n_pose;
         rc = alva_compute_pose_enqueue(m->ctx, Pbv, Puv, Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
                                        (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
         if (rc) return rc;
@@ -723,9 +723,9 @@ int HipStages::p3p(int n, const double *bv, const double *wpt, int do_random, do
     *ok = 0;
     *n_outliers = 0;
     if (n < 4) return ALVA_OK;  // multi_view_geometry.cpp:40-43
-    // the LMedS median lives in LDS: at most 7168 correspondences per call; a larger frame is solved on its first 7168 keypoints
+    // the LMedS median lives in LDS: at most 19000 correspondences per call; a larger frame is solved on its first 19000 keypoints
     // (container order) and the rest is left to the PnP's chi2 sweep
-    const int nn = n > 7168 ? 7168 : n;
+    const int nn = n > 19000 ? 19000 : n;
     Impl::Plan p;
     const size_t a = p.add((size_t) nn * 24), b = p.add((size_t) nn * 24);
     std::vector<uint8_t *> d, h;

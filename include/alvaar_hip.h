@@ -196,7 +196,7 @@ int alva_bf_match_hamming_batch(alva_ctx *ctx, int count, const uint8_t *const *
  * seeds with `seed` (the reference's fixed seed is 12345u), do_random != 0 seeds from the clock like
  * the reference's default.  alva_p3p_draw_samples exposes that index stream (count x 4 int32).
  * Outputs (host): R row-major 3x3 + t (Twc), outlier index list (capacity n); *h_ok = 1 on success
- * (>= 5 inliers and an orthogonal R, multi_view_geometry.cpp:82-91).  n <= 7168. */
+ * (>= 5 inliers and an orthogonal R, multi_view_geometry.cpp:82-91).  n <= 19000 (the LMedS median is LDS-resident). */
 int alva_p3p_draw_samples(int n_points, int count, int do_random, uint32_t seed, int *h_samples);
 int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters,
                    float err_threshold, int do_random, uint32_t seed, float fx, float fy, double *h_R,

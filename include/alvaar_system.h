@@ -18,7 +18,7 @@
  * are wired (camera_calibration.cpp:34-72, visual_frontend.cpp:678-681).  find_plane runs the plane fit the reference intends
  * (alva_find_plane; the reference function itself computes on reinterpreted memory, so its parity is unpinned).
  * Known deviations: a timestamp older than the previous one resets the tracker (status 2) instead of exit(-1)
- * (visual_frontend.hpp:46-50); P3P-LMedS is solved on the first 7168 3-D keypoints of a frame when there are more.
+ * (visual_frontend.hpp:46-50); P3P-LMedS is solved on the first 19000 3-D keypoints of a frame when there are more (a 3840x2160 frame has ~10 k).
  */
 #ifndef ALVAAR_SYSTEM_H
 #define ALVAAR_SYSTEM_H

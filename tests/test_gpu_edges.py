@@ -115,10 +115,10 @@ def test_argument_errors_are_reported(ctx):
         alvaar_amd.Pyramid(ctx, 130, 96, 9, 3)            # width must be a multiple of 4
     with pytest.raises(alvaar_amd.AlvaError):
         alvaar_amd.Pyramid(ctx, 128, 96, 2, 3)            # window too small
-    big = torch.zeros((7200, 3), dtype=torch.float64, device="cuda")
+    big = torch.zeros((19001, 3), dtype=torch.float64, device="cuda")
     with pytest.raises(alvaar_amd.AlvaError):
-        ctx.p3p_lmeds(big, big)                           # LDS-resident median: n <= 7168
-    assert "7168" in alvaar_amd.lib.alva_last_error().decode() or "n <=" in alvaar_amd.lib.alva_last_error().decode()
+        ctx.p3p_lmeds(big, big)                           # LDS-resident median: n <= 19000
+    assert "19000" in alvaar_amd.lib.alva_last_error().decode() or "n <=" in alvaar_amd.lib.alva_last_error().decode()
 
 
 def test_ba_without_points_or_with_all_cameras_fixed(ctx):

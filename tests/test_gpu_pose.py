@@ -32,7 +32,7 @@ def test_sampler_matches_reference_stream():
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,seed,outl", [(2000, 3, 0.1), (192, 4, 0.3), (12, 5, 0.0), (501, 6, 0.45), (4080, 7, 0.2)])
+@pytest.mark.parametrize("n,seed,outl", [(2000, 3, 0.1), (192, 4, 0.3), (12, 5, 0.0), (501, 6, 0.45), (4080, 7, 0.2), (10432, 8, 0.2), (19000, 9, 0.1)])
 def test_p3p_lmeds(ctx, n, seed, outl):
     import torch
     pb = synth.make_pnp_problem(n, seed, outlier_frac=outl)
