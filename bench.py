@@ -6,8 +6,9 @@ HEADLINE (`value`): frames/s of the reference's OWN dataflow through the drop-in
 (cell size 12 => 2120 cells; BASELINE.json configs[1]), every frame ALREADY resident in HBM.  A "step" is ONE frame through the whole
 per-frame state machine, every stage consuming what the previous one produced:
     RGBA -> gray -> LK pyramid (+Scharr)                                                        (a2, a3)
-    motion-model priors -> forward-backward KLT, two passes (1 level from the priors, 3 levels for the rest)      (a4; visual_frontend.cpp:103-243)
-    status compaction -> undistortion / bearings -> 3-D gather on the device                  (:275-298)
+    motion-model priors -> forward-backward KLT (1 level from the priors, the full pyramid for the rest and for the retries), one
+        workgroup per slot of the frame container, with undistortion / bearings                (a4; visual_frontend.cpp:103-243)
+    compaction of the 3-D survivors on the device                                              (:275-298)
     P3P-LMedS (100 hypotheses) -> drop its outliers -> robust PnP (5 LM iterations) on the tracker's OWN survivors (a8, a9; :245-417)
     host bookkeeping of the frame (keypoint updates / removals, motion model, keyframe decision)
 and on the frames the reference's keyframe policy selects (about every 18th here): grid Shi-Tomasi detection + ORB description (a5, a6),
@@ -25,7 +26,8 @@ The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3
 run ("local_ba"), with its own roofline block ("roofline_ba").
 
 Secondary lines for a RIG of lock-step cameras on the one GPU (alva_track_batch_*): "track_mono_batch", "frame_step_batch",
-"batched_preprocess"; "config_1280x720" = configs[2].  --multi-stream adds the older 4 / 16 host-thread measurement.
+"batched_preprocess"; "config_1280x720" = configs[2].  --multi-stream adds the older 4 / 16 host-thread measurement of the stage-list
+driver; --system-streams 2,4,8 adds "system_streams": S independent alva::System sessions on the one GPU, one host thread each.
 
 Also reported: "roofline" for the dominant kernel of the headline loop (HIP-event timed on the launch stream) and "cpu_baseline": the
 compiled reference's System (oracle/_ref) on the same frames and configuration on one host core, and 8 independent reference Systems
