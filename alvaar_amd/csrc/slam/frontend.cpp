@@ -38,6 +38,7 @@ Slam::Slam(Stages *stages, const Camera &c, const Settings &s) : st(stages), cam
     cur->init(&cam, (size_t) cfg.cell_size);
     st->image_width_ = cam.width;
     st->image_height_ = cam.height;
+    ba_arena_.assign((size_t) 4 << 20, 0);   // local_ba's arena, touched now rather than inside the first keyframe that optimises
     const char *chk = std::getenv("ALVA_CHECK_OBS_MIRROR");
     check_obs_mirror_ = chk && chk[0] == '1';
 }

@@ -427,6 +427,174 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     return ALVA_OK;
 }
 
+int HipStages::warm_up(int cell) {
+    const Camera &k = m->cam;
+    const int W = k.width, H = k.height;
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() {
+        lcg = lcg * 1664525u + 1013904223u;
+        return (float) (lcg >> 8) * (1.f / 16777216.f);
+    };
+    int rc;
+    // two frames: gray + pyramid (+ CLAHE)
+    {
+        std::vector<uint8_t> img((size_t) W * H * 4);
+        for (size_t i = 0; i < img.size(); i += 4) {  // a smooth pattern with some texture: trackable, detectable
+            const size_t p = i / 4, x = p % (size_t) W, y = p / (size_t) W;
+            const uint8_t v = (uint8_t) (128 + 60 * std::sin(0.13 * (double) x) * std::cos(0.11 * (double) y) + 30 * ((x / 7 + y / 5) & 1));
+            img[i] = img[i + 1] = img[i + 2] = v;
+            img[i + 3] = 255;
+        }
+        std::vector<uint8_t> img2(img);   // two different buffers: the same pointer twice would get page-locked (new_frame)
+        for (int f = 0; f < 2; f++) {
+            rc = new_frame(f ? img2.data() : img.data());
+            if (rc) return rc;
+            rc = frame_done();
+            if (rc) return rc;
+        }
+        ALVA_HIP(hipStreamSynchronize(m->st));
+        m->last_host_ptr = nullptr;
+    }
+    const int cw = (W + cell - 1) / cell, chh = (H + cell - 1) / cell, n = cw * chh;
+    // the tracking step (stage-in, tracker, retry, compaction) and the pose solve behind it
+    {
+        float *px;
+        uint8_t *is3d;
+        double *wpt;
+        std::vector<float> vpx;
+        std::vector<uint8_t> v3;
+        std::vector<double> vw;
+        if (!track_slot_buffers(n + n / 4, &px, &is3d, &wpt)) {
+            vpx.resize((size_t) (n + n / 4) * 2); v3.resize((size_t) (n + n / 4)); vw.resize((size_t) (n + n / 4) * 3);
+            px = vpx.data(); is3d = v3.data(); wpt = vw.data();
+        }
+        for (int i = 0; i < n; i++) {
+            const float x = 12.f + rnd() * (float) (W - 24), y = 12.f + rnd() * (float) (H - 24);
+            px[2 * i] = x; px[2 * i + 1] = y;
+            is3d[i] = (i % 8) != 0;
+            const double z = 3.0 + 2.0 * rnd();
+            wpt[3 * i] = ((double) x - k.cx) / k.fx * z; wpt[3 * i + 1] = ((double) y - k.cy) / k.fy * z; wpt[3 * i + 2] = z;
+        }
+        TrackJob job;
+        job.n = n;
+        job.px = px; job.is3d = is3d; job.wpt = wpt;
+        job.want_pose = 1;
+        job.do_random = 0;
+        TrackKlt kl;
+        TrackPose po;
+        rc = track_begin(job, kl);
+        if (!rc) rc = track_pose_collect(po);
+        if (rc) return rc;
+    }
+    // keyframe stages
+    {
+        std::vector<float> pts((size_t) n * 2), un((size_t) n * 2), np((size_t) (n + 8) * 2);
+        std::vector<double> bv((size_t) n * 3);
+        std::vector<uint8_t> desc((size_t) n * 32), valid((size_t) n);
+        for (int i = 0; i < n; i++) {
+            pts[2 * (size_t) i] = 40.f + rnd() * (float) (W - 80);
+            pts[2 * (size_t) i + 1] = 40.f + rnd() * (float) (H - 80);
+        }
+        rc = describe(n, pts.data(), desc.data(), valid.data());
+        if (!rc) rc = compute_keypoints(n, pts.data(), un.data(), bv.data());
+        if (rc) return rc;
+        const double q = m->max_quality;
+        int count = 0;
+        rc = detect(cell, n / 2, pts.data(), n + 8, np.data(), &count);
+        m->max_quality = q;
+        if (rc) return rc;
+    }
+    {   // triangulation
+        const int nt = n / 4 + 8;
+        std::vector<double> T(36, 0.), bl((size_t) nt * 3), br((size_t) nt * 3), w((size_t) nt * 3), inv((size_t) nt), par((size_t) nt);
+        std::vector<float> ul((size_t) nt * 2), ur((size_t) nt * 2);
+        std::vector<int> grp((size_t) nt, 0);
+        std::vector<uint8_t> st((size_t) nt);
+        for (int b = 0; b < 3; b++) {   // R = I, t = (0.3, 0, 0) / its inverse / the keyframe's pose
+            T[12 * b] = T[12 * b + 4] = T[12 * b + 8] = 1.;
+        }
+        T[9] = 0.3; T[21] = -0.3;
+        for (int i = 0; i < nt; i++) {
+            const double x = -0.3 + 0.6 * rnd(), y = -0.2 + 0.4 * rnd(), z = 4.;
+            const double l[3] = {x, y, z}, r[3] = {x - 0.3, y, z};
+            const double nl = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]), nr = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            for (int c = 0; c < 3; c++) {
+                bl[3 * (size_t) i + c] = l[c] / nl;
+                br[3 * (size_t) i + c] = r[c] / nr;
+            }
+            ul[2 * (size_t) i] = (float) (k.fx * l[0] / z + k.cx); ul[2 * (size_t) i + 1] = (float) (k.fy * l[1] / z + k.cy);
+            ur[2 * (size_t) i] = (float) (k.fx * r[0] / z + k.cx); ur[2 * (size_t) i + 1] = (float) (k.fy * r[1] / z + k.cy);
+        }
+        rc = triangulate(nt, 1, T.data(), grp.data(), bl.data(), br.data(), ul.data(), ur.data(), w.data(), inv.data(), st.data(), par.data());
+        if (rc) return rc;
+    }
+    const int n_kf = 14;
+    {   // matchToMap: the frame's keypoints (one per cell) + a local map of 3 n points with 6 observations each
+        const int n_local = 3 * n, n_mp = n + n_local, per = 6;
+        std::vector<int> cell_ptr((size_t) n + 1), cell_mp((size_t) n), obs_ptr((size_t) n_mp + 1), obs_kf, local((size_t) n_local), match((size_t) n_mp);
+        std::vector<double> kq((size_t) n_kf * 4, 0.), kt((size_t) n_kf * 3, 0.), X((size_t) n_mp * 3);
+        std::vector<uint8_t> m3((size_t) n_mp, 1), mhd((size_t) n_mp, 1), od, ohd;
+        std::vector<float> opx;
+        for (int f = 0; f < n_kf; f++) {
+            kq[4 * (size_t) f + 3] = 1.;
+            kt[3 * (size_t) f] = -0.05 * f;
+        }
+        for (int i = 0; i <= n; i++) cell_ptr[(size_t) i] = i;
+        for (int i = 0; i < n; i++) cell_mp[(size_t) i] = i;
+        for (int i = 0; i < n_local; i++) local[(size_t) i] = n + i;
+        for (int p = 0; p < n_mp; p++) {
+            const int c = p % n;
+            const double x = ((c % cw) + 0.5 + 0.3 * (p / n)) * cell, y = ((c / cw) + 0.5) * cell, z = 4.;
+            X[3 * (size_t) p] = (x - k.cx) / k.fx * z; X[3 * (size_t) p + 1] = (y - k.cy) / k.fy * z; X[3 * (size_t) p + 2] = z;
+            obs_ptr[(size_t) p] = (int) obs_kf.size();
+            for (int o = 0; o < per; o++) {
+                obs_kf.push_back((p + o) % n_kf);
+                opx.push_back((float) x);
+                opx.push_back((float) y);
+                for (int b = 0; b < 32; b++) od.push_back((uint8_t) (rnd() * 255.f));
+                ohd.push_back(1);
+            }
+        }
+        obs_ptr[(size_t) n_mp] = (int) obs_kf.size();
+        rc = match_to_map(cell, cw, n, cell_ptr.data(), cell_mp.data(), n_kf, kq.data(), kt.data(), n_mp, X.data(), m3.data(), mhd.data(), obs_ptr.data(),
+                          obs_kf.data(), opx.data(), od.data(), ohd.data(), n_kf - 1, n, n_local, local.data(), 2.0f, 0.2f, match.data());
+        if (rc) return rc;
+    }
+    {   // local BA: 14 keyframes, 3 n points anchored round-robin, 6 further observations each
+        const int n_pt = 3 * n, per = 6, n_obs = n_pt * per;
+        std::vector<double> poses((size_t) n_kf * 7, 0.), auv((size_t) n_pt * 2), inv((size_t) n_pt, 0.25), ouv((size_t) n_obs * 2), chi2((size_t) n_obs);
+        std::vector<uint8_t> kc((size_t) n_kf, 0), dp((size_t) n_obs);
+        std::vector<int> pa((size_t) n_pt), okf((size_t) n_obs), opt((size_t) n_obs);
+        kc[0] = kc[1] = 1;
+        for (int f = 0; f < n_kf; f++) {
+            poses[7 * (size_t) f] = 0.05 * f;   // Twc: camera f sits at x = 0.05 f
+            poses[7 * (size_t) f + 6] = 1.;
+        }
+        for (int p = 0; p < n_pt; p++) {
+            const int a = p % n_kf;
+            const double u = 40. + rnd() * (W - 80), v = 40. + rnd() * (H - 80), z = 4.;
+            pa[(size_t) p] = a;
+            auv[2 * (size_t) p] = u; auv[2 * (size_t) p + 1] = v;
+            const double xw = (u - k.cx) / k.fx * z + 0.05 * a, yw = (v - k.cy) / k.fy * z;
+            for (int o = 0; o < per; o++) {
+                const int f = (a + 1 + o) % n_kf;
+                const size_t e = (size_t) p * per + (size_t) o;
+                okf[e] = f;
+                opt[e] = p;
+                ouv[2 * e] = k.fx * (xw - 0.05 * f) / z + k.cx + 0.4 * (rnd() - 0.5);
+                ouv[2 * e + 1] = k.fy * yw / z + k.cy + 0.4 * (rnd() - 0.5);
+            }
+        }
+        rc = local_ba(n_kf, poses.data(), kc.data(), n_pt, pa.data(), auv.data(), inv.data(), n_obs, okf.data(), opt.data(), ouv.data(), 5, chi2.data(),
+                      dp.data());
+        if (rc) return rc;
+    }
+    pending_.active = false;
+    fused_active_ = false;
+    m->pose_pending = false;
+    return ALVA_OK;
+}
+
 int HipStages::build_from(const uint8_t *d_src) {
     m->cur ^= 1;
     if (!m->clahe) return alva_pyramid_build_from_rgba(m->ctx, m->pyr[m->cur], d_src, (size_t) m->cam.width * 4, m->d_gray, (size_t) m->cam.width);

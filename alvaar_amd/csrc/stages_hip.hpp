@@ -10,6 +10,10 @@ public:
     HipStages();
     ~HipStages() override;
     int init(int device, const Camera &cam, bool clahe, const double *invK);
+    // One pass of synthetic data through every stage at the sizes a `cell`-pixel grid produces: loads the kernels' code objects, grows
+    // the staging arenas and the context scratch to their working sizes and raises the launch attributes, so that none of this lands in
+    // the first frames / the first keyframes.  No state survives it (the detector's adaptive threshold is restored).
+    int warm_up(int cell);
 
     int track_begin(const TrackJob &job, TrackKlt &out) override;
     int track_pose_collect(TrackPose &out) override;

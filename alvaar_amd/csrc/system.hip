@@ -76,6 +76,11 @@ extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, d
     std::unique_ptr<Slam> slam(new Slam(st.get(), cam, cfg));
     const int rc = st->init(s->device, cam, cfg.clahe, slam->invK);
     if (rc) return sys_fail(rc, "alva_system_configure");
+    if (!getenv("ALVA_NO_WARMUP")) {
+        // code-object loads, arena growth and launch attributes belong to configure, not to the first frames and keyframes
+        const int wrc = st->warm_up(cell_size);
+        if (wrc) return sys_fail(wrc, "alva_system_configure (warm-up)");
+    }
     s->stages = std::move(st);
     s->slam = std::move(slam);
     if (const char *path = getenv("ALVA_STAGE_TRACE")) {
