@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 
 namespace alva_slam {
 
@@ -195,8 +196,13 @@ void Slam::klt_from_motion_prior() {
         j3d[(size_t) i] = k.is3d;
         job_is3d_[(size_t) i] = k.is3d;
         double *w = jw + 3 * (size_t) i;
-        if (k.is3d) std::memcpy(w, map_points.at(k.id)->X, 24);  // .at: throws like the reference (:131) if the map lost it
-        else w[0] = w[1] = w[2] = 0.;
+        if (k.is3d) {
+            const MapPt *mp = mp_raw(k.id);
+            if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() throws in the reference (:131) if the map lost it
+            std::memcpy(w, mp->X, 24);
+        } else {
+            w[0] = w[1] = w[2] = 0.;
+        }
         i++;
     }
     TrackJob job;

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <stdexcept>
 
 namespace alva_slam {
 
@@ -382,10 +383,12 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     std::vector<int> &kp_ids = ids_scratch_;
     kp_ids.clear();
     std::vector<float> pts((size_t) n * 2);
+    std::vector<KeyPt *> nodes((size_t) n);   // the keypoints themselves (node addresses are stable; nothing is inserted or erased before they are used)
     {
         size_t i = 0;
-        for (const auto &e: cur->kps) {  // getKeypoints(): container order
+        for (auto &e: cur->kps) {  // getKeypoints(): container order
             kp_ids.push_back(e.first);
+            nodes[i] = &e.second;
             pts[2 * i] = e.second.px[0];
             pts[2 * i + 1] = e.second.px[1];
             i++;
@@ -401,8 +404,11 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
             if (valid[(size_t) i]) {
                 Desc d;
                 __builtin_memcpy(d.b, &desc[(size_t) i * 32], 32);
-                cur->set_desc(kp_ids[(size_t) i], d);
-                map_points.at(kp_ids[(size_t) i])->add_desc(cur->kfid, d);
+                nodes[(size_t) i]->desc = d;        // Frame::updateKeypointDesc (frame.cpp:176-185)
+                nodes[(size_t) i]->has_desc = true;
+                MapPt *mp = mp_raw(kp_ids[(size_t) i]);
+                if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() in the reference (:233)
+                mp->add_desc(cur->kfid, d);
             }
     }
     const int to_detect = cfg.max_keypoints - (int) cur->n_occupied;
