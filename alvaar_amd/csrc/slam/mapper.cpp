@@ -177,8 +177,17 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     const int frame_kf_index = kf_index[(size_t) frame.kfid];
     // map point table: the frame's keypoints first (grid order), then the local map in ITS iteration order
     std::vector<int> mp_ids;
-    std::vector<int> &mp_index = index_scratch_;  // id -> row of the table (ids are dense)
-    mp_index.assign((size_t) next_mp_id + 1, -1);
+    // id -> row of the table (ids are dense).  The table persists (all -1 between calls) and only the rows used here are reset at the
+    // end: ids are never reused and a long run hands out millions, so clearing it per keyframe would cost O(ids ever handed out)
+    std::vector<int> &mp_index = mp_index_;
+    if (mp_index.size() < (size_t) next_mp_id + 1) mp_index.resize((size_t) next_mp_id + 1 + (size_t) next_mp_id / 2, -1);
+    struct ResetIndex {
+        std::vector<int> &index;
+        const std::vector<int> &ids;
+        ~ResetIndex() {
+            for (int id: ids) index[(size_t) id] = -1;
+        }
+    } reset_index{mp_index, mp_ids};
     auto intern = [&](int id) {
         int &slot = mp_index[(size_t) id];
         if (slot < 0) {

@@ -337,7 +337,7 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
-    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_;
+    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_;
     // flat "seen" marks over map point ids (ids are dense, handed out consecutively): inserting a key that is already in a hash set does
     // not change the set, so duplicate inserts are filtered with a byte look-up instead of a hash look-up
     std::vector<uint8_t> mark_a_, mark_b_;
