@@ -33,7 +33,8 @@ def fold(path, counter):
 
 def main():
     fetch, write = fold(sys.argv[1], "FETCH_SIZE"), fold(sys.argv[2], "WRITE_SIZE")
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes) over bench.py's frame loop, MI355X",
+    import os
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes) over: " + os.environ.get("PMC_COMMAND", "bench.py's frame loop") + "; MI355X",
            "corrections": __doc__.split("\n\n", 2)[2].strip(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, (0, 0.0))

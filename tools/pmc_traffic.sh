@@ -12,4 +12,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 f=$(find /tmp/pmc_${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 w=$(find /tmp/pmc_${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-if [ -n "$f" ] && [ -n "$w" ]; then python3 "$repo/tools/pmc_summary.py" "$f" "$w" "$repo/gpurun_out/${name}_pmc_traffic.json" | head -${LINES_OUT:-16}; else echo "counter pass failed"; tail -5 "$repo"/gpurun_out/${name}_pmc_*.log; fi
+if [ -n "$f" ] && [ -n "$w" ]; then PMC_COMMAND="$*" python3 "$repo/tools/pmc_summary.py" "$f" "$w" "$repo/gpurun_out/${name}_pmc_traffic.json" | head -${LINES_OUT:-16}; else echo "counter pass failed"; tail -5 "$repo"/gpurun_out/${name}_pmc_*.log; fi
