@@ -101,12 +101,14 @@ def test_bf_match_full_size_properties(ctx):
     assert np.array_equal(perm[idx2.cpu().numpy()], np.arange(4080)) and int(dist2.abs().sum()) == 0
 
 
-def test_batched_pyramids_equal_single_builds(ctx):
-    """alva_pyramid_build_from_rgba_batch (one grid layer per camera) == one alva_pyramid_build_from_rgba per camera, bit for bit."""
+@pytest.mark.parametrize("B", [5, 9])
+def test_batched_pyramids_equal_single_builds(ctx, B):
+    """alva_pyramid_build_from_rgba_batch == one alva_pyramid_build_from_rgba per camera, bit for bit (9 cameras: the camera -> XCD
+    order of the batched launches, alva_xcd_item; 5: the plain order)."""
     import torch
     import alvaar_amd
     from alvaar_amd import capi
-    w, h, B = 320, 240, 5
+    w, h = 320, 240
     frames = [torch.from_numpy(synth.gray_to_rgba(synth.frame_gray(synth.texture_canvas(w, h, 20 + c), c, w, h, noise_seed=c), seed=c)).cuda()
               for c in range(B)]
     single = [alvaar_amd.Pyramid(ctx, w, h, 9, 3) for _ in range(B)]

@@ -20,14 +20,17 @@ def _camera(seed, n_pts, n_corr, frames=3, outlier_frac=0.15, w=W, h=H):
     return dict(frames=fr, pts=pts, bv=bv, uv=uv, wp=wp)
 
 
-@pytest.mark.parametrize("lanes", [5, 8, 16, 32, 64])
-def test_batch_equals_single_cameras(ctx, lanes):
+@pytest.mark.parametrize("lanes,many", [(5, False), (8, False), (16, False), (32, False), (64, False), (5, True), (8, True)])
+def test_batch_equals_single_cameras(ctx, lanes, many):
     """ragged rig: different frames, keypoint counts and correspondence counts per camera, one camera without keypoints and one
-    with too few correspondences for a pose"""
+    with too few correspondences for a pose.  many = 11 cameras: from 8 cameras on the batched launches use the camera -> XCD order
+    (alva_xcd_item), below that the plain one"""
     import torch
     import alvaar_amd
     K = synth.make_pnp_problem(8, 1)["K"]
     spec = [(600, 600), (250, 333), (0, 90), (431, 3), (1000, 1200), (61, 4), (1, 50)]
+    if many:
+        spec += [(777, 40), (12, 900), (340, 340), (999, 5)]
     cams = [_camera(11 + i, a, b) for i, (a, b) in enumerate(spec)]
     B = len(cams)
     tb = alvaar_amd.TrackBatch(0, W, H, B, 1000, 1200)
@@ -121,13 +124,16 @@ def test_batch_rejects_bad_arguments():
     tb.close()
 
 
-def test_batch_with_detector_equals_single_cameras(ctx):
+@pytest.mark.parametrize("many", [False, True])
+def test_batch_with_detector_equals_single_cameras(ctx, many):
     """the detector lane (cv::ORB + Hamming match per camera, batched over the cameras) gives every camera the keypoints, descriptors
     and matches of its own alva_frontend_track"""
     import torch
     import alvaar_amd
     K = synth.make_pnp_problem(8, 1)["K"]
     spec = [(300, 300), (120, 90), (0, 40), (500, 700), (64, 8)]
+    if many:
+        spec += [(222, 100), (499, 31), (17, 650), (400, 400)]
     cams = [_camera(41 + i, a, b, frames=4) for i, (a, b) in enumerate(spec)]
     B = len(cams)
     tb = alvaar_amd.TrackBatch(0, W, H, B, 500, 700)
