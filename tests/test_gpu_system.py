@@ -223,13 +223,14 @@ def test_tracking_step_variants_agree_bitwise(monkeypatch):
     """the tracking step three ways -- slot-wise (default: tracker launch, retry launch, compaction), with explicit keypoint lists
     (ALVA_TRACK_LISTS=1: the reference's two lists built on the device) and composed from the fine-grained stages
     (ALVA_TRACK_UNFUSED=1: host round trips between them, the reference's own statement order): same statuses, states, keypoints and
-    poses -- the two fused forms to the last bit, the composed one to 1e-9 -- through initialisation, keyframes, merges and local BA"""
+    poses -- the two fused forms to the last bit, the composed one to 1e-9 -- through initialisation, keyframes, merges and local BA; and
+    the default form once more with stream waits instead of completion words and without the warm start (ALVA_NO_POLL, ALVA_NO_WARMUP)"""
     w, h = 640, 480
     canvas = synth.texture_canvas(w, h, 7)
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(70)]
     runs = []
-    for env in ({}, {"ALVA_TRACK_LISTS": "1"}, {"ALVA_TRACK_UNFUSED": "1"}):
-        for key in ("ALVA_TRACK_LISTS", "ALVA_TRACK_UNFUSED"):
+    for env in ({}, {"ALVA_TRACK_LISTS": "1"}, {"ALVA_TRACK_UNFUSED": "1"}, {"ALVA_NO_POLL": "1", "ALVA_NO_WARMUP": "1"}):
+        for key in ("ALVA_TRACK_LISTS", "ALVA_TRACK_UNFUSED", "ALVA_NO_POLL", "ALVA_NO_WARMUP"):
             monkeypatch.delenv(key, raising=False)
         for key, v in env.items():
             monkeypatch.setenv(key, v)
@@ -243,7 +244,7 @@ def test_tracking_step_variants_agree_bitwise(monkeypatch):
         gpu.close()
         runs.append(rec)
     worst = 0.0
-    for other, name in ((runs[1], "lists"), (runs[2], "unfused")):
+    for other, name in ((runs[1], "lists"), (runs[2], "unfused"), (runs[3], "lists")):   # the last: stream waits, cold start -- bitwise too
         for k, (a, b) in enumerate(zip(runs[0], other)):
             assert a[0] == b[0] and a[1] == b[1], f"{name} frame {k}: status / state"
             assert np.array_equal(a[2], b[2]) and np.array_equal(a[5], b[5]), f"{name} frame {k}: keypoint ids / flags"
