@@ -121,6 +121,17 @@ def test_system_equals_reference_long_stream():
     _differential(frames, w, h, 40, True, 1e-5, 8, 30)
 
 
+def test_system_equals_reference_long_stream_2000_keypoints():
+    """the same stream at BASELINE configs[1]'s geometry (cell 12 => ~2500 keypoints), 560 frames: > 30 keyframes, ~15 culled by the keyframe
+    filter, ~3000 map-point merges"""
+    w, h, n = 640, 480, 200
+    canvas = synth.texture_canvas(w, h, 7)
+    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
+    period = 2 * (n - 1)
+    frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(560)]
+    _differential(frames, w, h, 12, True, 1e-5, 8, 25)
+
+
 def test_system_equals_reference_rotating_camera_with_noise():
     w, h = 640, 480
     f = sysdiff.intrinsics(w, h)[0]
