@@ -421,9 +421,7 @@ __global__ void __launch_bounds__(64) k_track_klt_retry(LkPyr P, LkPyr C, TrackS
     const int per = gridDim.x >> 3;
     const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (i >= D.n) return;
-    if (!D.d_retried[i]) return;
-    const int nA = D.cnt[0], good = D.cnt[1];
-    if (!(nA > 0 && (double) good < 0.33 * (double) nA)) return;  // no p3pReq_: the retry of the first launch stands
+    if (!D.d_retried[i]) return;   // launched only when the first launch's counts said p3pReq_ (the host read them from the header)
     const float px = D.d_pts[2 * i], py = D.d_pts[2 * i + 1];
     float nx = px, ny = py;                                          // :193-203: every prior falls back to the keypoint's own position
     const int ok = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);

@@ -677,6 +677,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     const double *o_bv = nullptr, *Pbv = nullptr, *Puv = nullptr, *Pwpt = nullptr;
     const int *o_hdr = nullptr;
     int poll_seq = 0;
+    TrackSlots slots_D{};
+    bool slots_path = false;
     const Impl::TrackPin pin = m->track_pin();
     const bool staged = job.px == pin.in_px && job.is3d == pin.in_is3d && job.wpt == pin.in_wpt;   // track_slot_buffers was used
     if (!staged) {
@@ -712,14 +714,12 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         // state.hpp:50-56 constants; the prior pass works on one pyramid level (visual_frontend.cpp:166)
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
         if (rc) return rc;
-        if (job.use_prior && n3d > 0) {
-            rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 1);
-            if (rc) return rc;
-        }
         D.seq = ++m->trk_seq;
         hipLaunchKernelGGL(k_track_compact, dim3(1), dim3(TRK_NT), 0, m->st, D);
         ALVA_LAUNCH_CHECK();
         poll_seq = m->poll ? D.seq : 0;
+        slots_D = D;
+        slots_path = true;
         o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
         Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
     } else {
@@ -768,27 +768,44 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
     Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
     }
-    if (poll_seq) {
-        // the compaction kernel publishes its sequence number after all results (system-scope release); spinning on that word in pinned
-        // memory returns a few microseconds before hipStreamSynchronize would
-        const volatile int *flag = o_hdr + 8;
-        unsigned spins = 0;
-        while (*flag != poll_seq) {
-            if (++spins > (1u << 26)) {   // ~ seconds: something is wrong with the stream; let the runtime report it
-                ALVA_HIP(hipStreamSynchronize(m->st));
-                break;
+    auto wait_step = [&](int seq) -> int {
+        if (seq) {
+            // the compaction kernel publishes its sequence number after all results (system-scope release); spinning on that word in
+            // pinned memory returns a few microseconds before hipStreamSynchronize would
+            const volatile int *flag = o_hdr + 8;
+            unsigned spins = 0;
+            while (*flag != seq) {
+                if (++spins > (1u << 26)) {   // ~ seconds: something is wrong with the stream; let the runtime report it
+                    ALVA_HIP(hipStreamSynchronize(m->st));
+                    break;
+                }
+                __builtin_ia32_pause();
             }
-            __builtin_ia32_pause();
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        } else {
+            ALVA_HIP(hipStreamSynchronize(m->st));
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    } else {
-        ALVA_HIP(hipStreamSynchronize(m->st));
+        return ALVA_OK;
+    };
+    rc = wait_step(poll_seq);
+    if (rc) return rc;
+    int p3p_req = o_hdr[4];
+    if (slots_path && p3p_req) {
+        // fewer than 33 % of the one-level passes held (visual_frontend.cpp:193-203): the retries must start from the keypoints' own
+        // positions instead -- redo them and compact again (rare: tracking is about to be lost)
+        rc = alva_track_slots_klt(m->ctx, prev, cur, slots_D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 1);
+        if (rc) return rc;
+        slots_D.seq = ++m->trk_seq;
+        hipLaunchKernelGGL(k_track_compact, dim3(1), dim3(TRK_NT), 0, m->st, slots_D);
+        ALVA_LAUNCH_CHECK();
+        rc = wait_step(m->poll ? slots_D.seq : 0);
+        if (rc) return rc;
     }
     out.code_v = o_code;   // read in place (pinned host memory, written by the kernels; stays until the next track_begin)
     out.px_v = o_px;
     out.unpx_v = o_unpx;
     out.bv_v = o_bv;
-    out.p3p_req = o_hdr[4];
+    out.p3p_req = p3p_req;
     out.n_pose = o_hdr[5];
     if (job.want_pose && out.n_pose >= 4) {
         // P3P-LMedS keeps its median in LDS: at most 19000 correspondences (the first ones, in slot order, when a frame has more)

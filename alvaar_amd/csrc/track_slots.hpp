@@ -7,7 +7,8 @@
 // of the frame container decides by itself which of the two it is, and re-tracks its keypoint on the full pyramid at once when the
 // one-level pass fails -- from where that pass left it, which is what the reference does unless fewer than 33 % of the one-level
 // passes succeeded (p3pReq_, :193-203: then the retry starts from the keypoint's own position).  That count is known only after the
-// launch; a second launch redoes the retried slots in that (rare) case and is otherwise a row of workgroups that exit at once.  Per-slot results go straight to pinned host memory; a small third kernel compacts the correspondences
+// launch: the compaction kernel puts it into the header, and in that (rare) case the host launches the retry kernel, which redoes the
+// retried slots from their own positions, and the compaction once more.  Per-slot results go straight to pinned host memory; a small third kernel compacts the correspondences
 // of the pose solve in slot order (:275-298).
 #pragma once
 #include "camera_device.hpp"
