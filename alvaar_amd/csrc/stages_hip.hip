@@ -218,20 +218,47 @@ __global__ void __launch_bounds__(TRK_NT) k_track_finish(TrackDev D) {
 // bearing; what is left is the list of the pose solve -- the tracked 3-D slots in slot order (visual_frontend.cpp:275-298) -- the
 // header, and the counters' reset for the next frame.
 __global__ void __launch_bounds__(TRK_NT) k_track_compact(TrackSlots D) {
-    __shared__ int s_w[17];
+    // up to CH * 1024 slots in ONE round: every thread takes its CH slots' flags first (the loads of all chunks in flight together), the
+    // per-wave counts of all chunks are scanned once, then the gathers run; more slots (a 4K frame) take further rounds of the same
+    constexpr int CH = 4;
+    __shared__ int s_cnt[CH * (TRK_NT / 64) + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
-    for (int c0 = 0; c0 < D.n; c0 += TRK_NT) {
-        const int i = c0 + threadIdx.x;
-        const bool pose = i < D.n && D.d_code[i] != 0 && D.d_is3d[i] != 0;
-        int tot;
-        const int p = block_prefix(pose, s_w, &tot);
-        if (pose) {
-            const size_t k = (size_t) (base + p), j = (size_t) i;
-            D.Pbv[3 * k] = D.d_bv[3 * j]; D.Pbv[3 * k + 1] = D.d_bv[3 * j + 1]; D.Pbv[3 * k + 2] = D.d_bv[3 * j + 2];
-            D.Puv[2 * k] = (double) D.d_unpx[2 * j]; D.Puv[2 * k + 1] = (double) D.d_unpx[2 * j + 1];
-            D.Pwpt[3 * k] = D.d_wpt[3 * j]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * j + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * j + 2];
+    for (int r0 = 0; r0 < D.n; r0 += CH * TRK_NT) {
+        bool pose[CH];
+        int within[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int i = r0 + c * TRK_NT + (int) threadIdx.x;
+            pose[c] = i < D.n && D.d_code[i] != 0 && D.d_is3d[i] != 0;
         }
-        base += tot;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const unsigned long long b = __ballot(pose[c]);
+            within[c] = __popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[c * (TRK_NT / 64) + wave] = __popcll(b);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = base;
+            for (int q = 0; q < CH * (TRK_NT / 64); q++) {
+                const int v = s_cnt[q];
+                s_cnt[q] = acc;
+                acc += v;
+            }
+            s_cnt[CH * (TRK_NT / 64)] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+            if (pose[c]) {
+                const size_t k = (size_t) (s_cnt[c * (TRK_NT / 64) + wave] + within[c]), j = (size_t) (r0 + c * TRK_NT + (int) threadIdx.x);
+                D.Pbv[3 * k] = D.d_bv[3 * j]; D.Pbv[3 * k + 1] = D.d_bv[3 * j + 1]; D.Pbv[3 * k + 2] = D.d_bv[3 * j + 2];
+                D.Puv[2 * k] = (double) D.d_unpx[2 * j]; D.Puv[2 * k + 1] = (double) D.d_unpx[2 * j + 1];
+                D.Pwpt[3 * k] = D.d_wpt[3 * j]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * j + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * j + 2];
+            }
+        base = s_cnt[CH * (TRK_NT / 64)];
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         const int nA = D.cnt[0], good = D.cnt[1];
