@@ -348,14 +348,11 @@ __device__ __forceinline__ void track_slot_store(const TrackSlots &D, int i, int
         nx = 0.f;
         ny = 0.f;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // device memory only: the compaction kernel publishes them to the host (track_slots.hpp)
         D.d_code[i] = (uint8_t) code;
+        D.d_px[2 * i] = nx; D.d_px[2 * i + 1] = ny;
         D.d_unpx[2 * i] = ux; D.d_unpx[2 * i + 1] = uy;
         D.d_bv[3 * (size_t) i] = bv[0]; D.d_bv[3 * (size_t) i + 1] = bv[1]; D.d_bv[3 * (size_t) i + 2] = bv[2];
-        D.o_code[i] = (uint8_t) code;
-        D.o_px[2 * i] = nx; D.o_px[2 * i + 1] = ny;
-        D.o_unpx[2 * i] = ux; D.o_unpx[2 * i + 1] = uy;
-        D.o_bv[3 * (size_t) i] = bv[0]; D.o_bv[3 * (size_t) i + 1] = bv[1]; D.o_bv[3 * (size_t) i + 2] = bv[2];
     }
 }
 

