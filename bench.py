@@ -743,10 +743,10 @@ def main():
             "k_level0<true>": 4 * P + 2 * P,                        # RGBA in; gray copy + padded level 0 out
             "k_pyr_stage": (P + 4 * P + P / 4) * (1 + 1 / 4 + 1 / 16 + 1 / 64) / 4,   # per launch (4 launches): level in, Scharr out, next level out
             # fb-KLT, one launch per frame over every slot: the four levels of BOTH pyramids once (gray u8 + Ix,Iy i16 = 5 B/px per level)
-            # + the slot table in (33 B per slot) + per-slot results out (1 + 8 + 8 + 24 B twice: device copy and pinned host)
-            "k_track_klt": 2 * 5 * P * (1 + 1 / 4 + 1 / 16 + 1 / 64) + 33 * nkp + 82 * nkp,
+            # + the slot table in (33 B per slot) + per-slot results out (1 + 8 + 8 + 24 B, device memory)
+            "k_track_klt": 2 * 5 * P * (1 + 1 / 4 + 1 / 16 + 1 / 64) + 33 * nkp + 41 * nkp,
             "k_track_stage_in": 2 * 33 * nkp,                       # slot table: pinned host -> device
-            "k_track_compact": 42 * nkp + 64 * n3d,                 # per-slot results in; correspondences of the pose solve out
+            "k_track_compact": 42 * nkp + 41 * nkp + 64 * n3d,      # per-slot results in; the same to pinned host + correspondences of the pose solve out
         }
         per_frame = {k: v[0] / PROF_STEPS * v[1] for k, v in kt.items()}
         kernels = {k: {"launches_per_frame": round(v[0] / PROF_STEPS, 3), "avg_us": round(v[1], 2),
