@@ -135,9 +135,14 @@ extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgb
 }
 
 extern "C" int alva_system_find_camera_pose_with_imu(alva_system *s, const uint8_t *h_rgba, const double *h_imu, float *h_pose) {
+    const double ts = (double) std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    return alva_system_find_camera_pose_with_imu_ts(s, h_rgba, h_imu, ts, h_pose);   // system.cpp:87: milliseconds of the system clock
+}
+
+extern "C" int alva_system_find_camera_pose_with_imu_ts(alva_system *s, const uint8_t *h_rgba, const double *h_imu, double timestamp, float *h_pose) {
     if (!s || !s->slam || !h_imu || !h_pose) return ALVA_ERR_ARG;
     float tmp[16];
-    const int status = alva_system_find_camera_pose(s, h_rgba, tmp);
+    const int status = alva_system_find_camera_pose_ts(s, h_rgba, timestamp, tmp);
     if (status < 0) return status;
     // system.cpp:66-103: orientation = inverse of the IMU quaternion (w, -x, y, z); the translation integrates the visual one
     double q[4] = {-h_imu[1], h_imu[2], h_imu[3], h_imu[0]};

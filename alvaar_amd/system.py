@@ -19,6 +19,7 @@ lib.alva_system_reset.argtypes = [_vp]
 lib.alva_system_reset.restype = None
 lib.alva_system_find_camera_pose.argtypes = [_vp, _vp, _vp]
 lib.alva_system_find_camera_pose_with_imu.argtypes = [_vp, _vp, _vp, _vp]
+lib.alva_system_find_camera_pose_with_imu_ts.argtypes = [_vp, _vp, _vp, C.c_double, _vp]
 lib.alva_system_find_plane.argtypes = [_vp, _vp, _i]
 lib.alva_system_get_frame_points.argtypes = [_vp, _vp]
 lib.alva_system_get_keypoints.argtypes = [_vp, _vp, _vp, _vp, _i]
@@ -105,14 +106,17 @@ class AlvaAR:
             raise AlvaError(lib.alva_system_last_error().decode())
         return status
 
-    def findCameraPoseWithIMU(self, frame_rgba, orientation_wxyz, motion=()):  # noqa: N802
+    def findCameraPoseWithIMU(self, frame_rgba, orientation_wxyz, motion=(), timestamp_ms: float | None = None):  # noqa: N802
         frame = np.ascontiguousarray(frame_rgba, np.uint8)
         imu = np.zeros(256, np.float64)
         imu[:4] = orientation_wxyz
         imu[4] = len(motion)
         for k, smp in enumerate(motion):
             imu[5 + 7 * k:12 + 7 * k] = smp
-        status = lib.alva_system_find_camera_pose_with_imu(self.h, frame.ctypes.data, imu.ctypes.data, self._pose.ctypes.data)
+        if timestamp_ms is None:
+            status = lib.alva_system_find_camera_pose_with_imu(self.h, frame.ctypes.data, imu.ctypes.data, self._pose.ctypes.data)
+        else:
+            status = lib.alva_system_find_camera_pose_with_imu_ts(self.h, frame.ctypes.data, imu.ctypes.data, float(timestamp_ms), self._pose.ctypes.data)
         return self._pose.copy() if status == 1 else None
 
     def findPlane(self, num_iterations: int = 250):  # noqa: N802

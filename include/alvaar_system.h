@@ -56,6 +56,8 @@ int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, dou
 int alva_system_find_camera_pose_device(alva_system *sys, const uint8_t *d_rgba, double timestamp_ms, float *h_pose);
 /* System::findCameraPoseWithIMU (system.cpp:57-104).  h_imu: [qw,qx,qy,qz,n, n x {ts,gx,gy,gz,ax,ay,az}]. Always returns 1. */
 int alva_system_find_camera_pose_with_imu(alva_system *sys, const uint8_t *h_rgba, const double *h_imu, float *h_pose);
+/* the same with the caller's timestamp in milliseconds instead of the wall clock (system.cpp:87), as alva_system_find_camera_pose_ts */
+int alva_system_find_camera_pose_with_imu_ts(alva_system *sys, const uint8_t *h_rgba, const double *h_imu, double timestamp_ms, float *h_pose);
 /* System::findPlane (system.cpp:123-137): 1 on success, 0 otherwise (needs >= 32 observed 3-D points). */
 int alva_system_find_plane(alva_system *sys, float *h_pose, int num_iterations);
 /* System::getFramePoints (system.cpp:139-154): writes x,y int pairs of the current 2-D (not yet triangulated)

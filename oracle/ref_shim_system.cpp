@@ -120,6 +120,18 @@ int ref_system_find_camera_pose(void *p, const uint8_t *rgba, double timestamp, 
     return status;
 }
 
+// The pose array System::findCameraPoseWithIMU hands back (system.cpp:66-103) for an IMU quaternion (w, x, y, z) and a translation, with the
+// reference's own classes: Eigen quaternion (w, -x, y, z) -> rotation matrix -> inverse, Sophus::SE3d, Utils::toPoseArray.  (The call
+// itself reads the wall clock for its timestamp, system.cpp:87, so the tests drive processCameraPose with explicit timestamps and build the
+// expected array from this.)
+void ref_imu_pose(const double *imu_wxyz, const double *translation3, float *pose16) {
+    Eigen::Quaterniond orientation(imu_wxyz[0], -imu_wxyz[1], imu_wxyz[2], imu_wxyz[3]);
+    Eigen::Matrix3d qwc = orientation.toRotationMatrix().inverse();
+    Sophus::SE3d Twc(qwc, Eigen::Vector3d(0.0, 0.0, 0.0));
+    Twc.translation() = Eigen::Vector3d(translation3[0], translation3[1], translation3[2]);
+    Utils::toPoseArray(Twc, pose16);
+}
+
 int ref_system_find_plane(void *p, float *pose16, int numIterations) {
     auto *r = static_cast<RefSys *>(p);
     cv::Mat m = r->sys.processPlane(r->sys.mapManager_->getCurrentFrameMapPoints(), r->sys.currFrame_->getTwc(), numIterations);

@@ -286,3 +286,46 @@ def test_tracking_step_variants_agree_bitwise(monkeypatch):
                 worst = max(worst, float(np.abs(a[6] - b[6]).max()))
     assert worst <= 1e-9, worst
     print(f"\n  composed vs fused step: worst pose difference {worst:.2e}")
+
+
+def test_imu_surface_equals_reference_composition():
+    """System::findCameraPoseWithIMU (system.cpp:57-104): orientation from the IMU quaternion (w, -x, y, z), inverted; translation = the
+    visual translation integrated over the tracked frames (reset of the increment on every frame that is not tracked).  Expected arrays come
+    from the reference's own classes (oracle/ref_shim_system.cpp: ref_imu_pose = Eigen quaternion -> matrix -> inverse, Sophus::SE3d,
+    Utils::toPoseArray) fed with the reference System's status and translation per frame."""
+    import ctypes as C
+    import oracles
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(70)]
+    ref, rec, _ = _reference_run(frames, w, h, 40)
+    ref.close()
+    L = oracles.ref_lib()
+    L.ref_imu_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.RandomState(4)
+    gpu = sysdiff.GpuSystem(w, h, 40)
+    cur, prev = np.zeros(3), np.zeros(3)
+    worst, tracked = 0.0, 0
+    for k, f in enumerate(frames):
+        r = rec[k]
+        if r["status"] == 1 and (k == 0 or rec[k - 1]["status"] != 1):
+            gpu.set_init_pose(r["pose7"])
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        got = gpu.ar.findCameraPoseWithIMU(f, q, motion=[(33.0 * k, 0.01, 0.02, 0.03, 0.0, 9.8, 0.1)], timestamp_ms=33.0 * k)
+        assert got is not None                       # the call always reports 1 (system.cpp:103)
+        if r["status"] == 1:                         # :89-99
+            t = r["pose7"][:3]
+            cur = cur + t - prev
+            prev = t.copy()
+            tracked += 1
+        else:
+            prev = np.zeros(3)
+        want = np.zeros(16, np.float32)
+        qq, cc = np.ascontiguousarray(q), np.ascontiguousarray(cur)
+        L.ref_imu_pose(qq.ctypes.data, cc.ctypes.data, want.ctypes.data)
+        worst = max(worst, float(np.abs(got - want).max()))
+        assert np.abs(got - want).max() <= 2e-6, (k, got, want)
+    gpu.close()
+    assert tracked >= 30 and np.linalg.norm(cur) > 0.1
+    print(f"\n  IMU surface: worst difference to the reference composition {worst:.1e} over {len(frames)} frames ({tracked} tracked)")
