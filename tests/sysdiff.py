@@ -51,6 +51,11 @@ class _ShimSystem:
             getattr(self.L, self.prefix + "_destroy")(self.h)
             self.h = None
 
+    def reset(self):
+        """System::reset (system.cpp:42-55)"""
+        getattr(self.L, self.prefix + "_reset").argtypes = [_vp]
+        getattr(self.L, self.prefix + "_reset")(self.h)
+
     def step(self, rgba, ts):
         pose16, pose7 = np.zeros(16, np.float32), np.zeros(7)
         rgba = np.ascontiguousarray(rgba)
@@ -122,6 +127,9 @@ class GpuSystem:
 
     def close(self):
         self.ar.close()
+
+    def reset(self):
+        self.ar.reset()
 
     def step(self, rgba, ts):
         pose, st = self.ar.findCameraPose(rgba, ts)

@@ -23,10 +23,12 @@ import sysdiff
 pytestmark = [pytest.mark.gpu, pytest.mark.ref]
 
 
-def _reference_run(frames, w, h, cell, **kw):
+def _reference_run(frames, w, h, cell, reset_at=(), **kw):
     ref = sysdiff.RefSystem(w, h, cell, **kw)
     out, init_pose = [], None
     for k, rgba in enumerate(frames):
+        if k in reset_at:
+            ref.reset()
         st, p7, p16 = ref.step(rgba, 33.0 * k)
         if init_pose is None and st == 1:
             init_pose = p7.copy()
@@ -35,14 +37,16 @@ def _reference_run(frames, w, h, cell, **kw):
     return ref, out, init_pose
 
 
-def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, **kw):
+def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, reset_at=(), **kw):
     frames = list(frames)
-    ref, rec, init_pose = _reference_run(frames, w, h, cell, **kw)
+    ref, rec, init_pose = _reference_run(frames, w, h, cell, reset_at=reset_at, **kw)
     gpu = sysdiff.GpuSystem(w, h, cell, **kw)
     try:
         sq, cnt, worst_px, worst_x, worst_pose = 0.0, 0, 0.0, 0.0, 0.0
         for k, rgba in enumerate(frames):
             r = rec[k]
+            if k in reset_at:   # the caller's System::reset between two frames (system.cpp:42-55)
+                gpu.reset()
             if inject and r["status"] == 1 and (k == 0 or rec[k - 1]["status"] != 1):
                 gpu.set_init_pose(r["pose7"])   # the frame on which the reference (re-)initialises its map: start ours from the same two-view pose
             st, p7, p16 = gpu.step(rgba, 33.0 * k)
@@ -329,3 +333,12 @@ def test_imu_surface_equals_reference_composition():
     gpu.close()
     assert tracked >= 30 and np.linalg.norm(cur) > 0.1
     print(f"\n  IMU surface: worst difference to the reference composition {worst:.1e} over {len(frames)} frames ({tracked} tracked)")
+
+
+def test_system_equals_reference_explicit_reset():
+    """System::reset called by the host in the middle of a tracked stream: frame, map and counters cleared, motion model / p3pReq_ / the
+    detector's adaptive threshold kept; re-initialisation and 60 more frames compared like the ones before"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(110)]
+    _differential(frames, w, h, 40, True, 1e-5, 2, 1, reset_at=(48,))

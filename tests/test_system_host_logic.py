@@ -13,11 +13,14 @@ import sysdiff
 pytestmark = pytest.mark.ref
 
 
-def _run(frames, w, h, cell, n_min_kf, clahe=False, dist=(0.0, 0.0, 0.0, 0.0), ts=lambda k: 33.0 * k):
+def _run(frames, w, h, cell, n_min_kf, clahe=False, dist=(0.0, 0.0, 0.0, 0.0), ts=lambda k: 33.0 * k, reset_at=()):
     ref, cpu = sysdiff.RefSystem(w, h, cell, clahe, dist), sysdiff.CpuSystem(w, h, cell, clahe, dist)
     try:
         statuses, worst_pose, worst_x = [], 0.0, 0.0
         for k, rgba in enumerate(frames):
+            if k in reset_at:   # the caller's System::reset (system.cpp:42-55) between two frames
+                ref.reset()
+                cpu.reset()
             s1, p1, a1 = ref.step(rgba, ts(k))
             s2, p2, a2 = cpu.step(rgba, ts(k))
             assert s1 == s2, f"frame {k}: status {s1} != {s2}"
@@ -129,3 +132,14 @@ def test_long_stream_keyframe_window_and_filter(cell, frames_total):
     finally:
         del os.environ["ALVA_CHECK_OBS_MIRROR"]
     assert statuses[-1] == 1 and cnt["culled_keyframes"] >= 1 and cnt["ba_solves"] >= 25, cnt
+
+
+def test_explicit_reset_between_frames():
+    """System::reset called by the host in the middle of a tracked stream (system.cpp:42-55: frame, map, counters cleared; the motion
+    model, p3pReq_ and the detector's adaptive threshold survive): the stream re-initialises, and everything after the reset is compared
+    like everything before it"""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = (synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(110))
+    statuses, cnt, _, _ = _run(frames, w, h, 40, 0, reset_at=(48,))
+    assert statuses[47] == 1 and statuses[48] == 3 and statuses[-1] == 1, (statuses[44:52], statuses[-5:])
