@@ -342,3 +342,11 @@ def test_system_equals_reference_explicit_reset():
     canvas = synth.texture_canvas(w, h, 7)
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(110)]
     _differential(frames, w, h, 40, True, 1e-5, 2, 1, reset_at=(48,))
+
+
+def test_system_equals_reference_1280x720():
+    """BASELINE configs[4]'s geometry through the surface: 1280x720, cell 15 (4080 cells)"""
+    w, h = 1280, 720
+    canvas = synth.texture_canvas(w, h, 9)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=3)) for k in range(60)]
+    _differential(frames, w, h, 15, True, 1e-5, 3, 2)
