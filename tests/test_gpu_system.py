@@ -350,3 +350,44 @@ def test_system_equals_reference_1280x720():
     canvas = synth.texture_canvas(w, h, 9)
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=3)) for k in range(60)]
     _differential(frames, w, h, 15, True, 1e-5, 3, 2)
+
+
+def test_concurrent_sessions_equal_their_solo_runs():
+    """four alva::System sessions driven from four host threads at once (different grids, different streams): every session's statuses,
+    poses and keypoints are those of the same session run alone -- nothing in the library is shared between sessions but the device"""
+    import threading
+    w, h = 640, 480
+    specs = [(40, 7, False), (12, 5, True), (24, 9, False), (12, 7, False)]   # cell size, canvas seed, noise
+
+    def frames_of(seed, noise):
+        canvas = synth.texture_canvas(w, h, seed)
+        return [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11 if noise else None)) for k in range(70)]
+
+    def run(cell, frames, out):
+        gpu = sysdiff.GpuSystem(w, h, cell)
+        for k, f in enumerate(frames):
+            st, p7, p16 = gpu.step(f, 33.0 * k)
+            ids, px, un, i3, hd = gpu.frame_keypoints()
+            out.append((st, p7.copy(), ids.copy(), px.copy()))
+        out.append(gpu.counters())
+        gpu.close()
+
+    streams = [frames_of(seed, noise) for _, seed, noise in specs]
+    solo = []
+    for (cell, _, _), fr in zip(specs, streams):
+        rec = []
+        run(cell, fr, rec)
+        solo.append(rec)
+    together = [[] for _ in specs]
+    threads = [threading.Thread(target=run, args=(cell, fr, rec)) for (cell, _, _), fr, rec in zip(specs, streams, together)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s, (a, b) in enumerate(zip(solo, together)):
+        assert len(a) == len(b) == 71, s
+        assert a[-1] == b[-1] and a[-1]["ba_solves"] >= 1, (s, a[-1], b[-1])
+        for k in range(70):
+            assert a[k][0] == b[k][0], (s, k)
+            assert np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), (s, k)
+            assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), (s, k)
