@@ -78,6 +78,9 @@ struct BaDev {
     double *yc;     // [NP]
     double *yp;     // [npd]
     double *scal;   // scalars: 0 cost, 1 mcc, 2 step_norm^2, 3 gmax, 4 x_norm^2, 5 chol_ok
+    double *h_scal; // single problem: pinned host mirror of scal[0..7] + the evaluation's sequence number at [8] (k_gmax publishes it last,
+                    // system-scope release; the host polls it instead of a copy command + stream wait per LM iteration); null in a batch
+    long long seq;
     double *partial;  // [nPt][3] per-point partials for mcc / step norm / x norm
 };
 
@@ -324,6 +327,12 @@ __device__ __forceinline__ void gmax_body(const BaDev &B, int first, const int B
     if (threadIdx.x == 0) {
         B.scal[3] = s_red[0];
         B.scal[0] = s_cost[0];
+        if (B.h_scal) {   // the other scalars were written by earlier kernels of this stream (device memory): re-read here, published by THIS kernel
+            B.h_scal[0] = s_cost[0]; B.h_scal[1] = B.scal[1]; B.h_scal[2] = B.scal[2]; B.h_scal[3] = s_red[0];
+            B.h_scal[4] = B.scal[4]; B.h_scal[5] = B.scal[5]; B.h_scal[6] = B.scal[6]; B.h_scal[7] = B.scal[7];
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<long long *>(B.h_scal + 8), B.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
@@ -1102,6 +1111,12 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     const auto t_up = std::chrono::steady_clock::now();
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
+    // per-iteration scalars: published by k_gmax into the first 128 bytes of the pinned staging and polled (ALVA_NO_POLL=1: copy + wait)
+    static const bool poll = getenv("ALVA_NO_POLL") == nullptr;
+    double *pin_scal = reinterpret_cast<double *>(pin);
+    long long eval_seq = 0;
+    reinterpret_cast<volatile long long *>(pin_scal + 8)[0] = 0;
+    B.h_scal = poll ? pin_scal : nullptr;
     const size_t np16 = H.np16, solve_lds = H.solve_lds;
     const bool solve_in_lds = solve_lds <= 152 * 1024;   // + ~5 KB of static LDS in k_solve stays under the CU's 160 KB
     if (solve_in_lds && solve_lds > 48 * 1024)
@@ -1115,13 +1130,27 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         hipLaunchKernelGGL(k_pairs, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, B);
         hipLaunchKernelGGL(k_rowcol, dim3((unsigned) n_kf), dim3(64), 0, st, B);
         if (B.n6 > 0) hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
-        hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);  // also sums the cost
+        B.seq = ++eval_seq;
+        hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);  // also sums the cost; publishes the scalars
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     };
     double scal[8];
-    double *pin_scal = reinterpret_cast<double *>(pin);
     auto read_scal = [&]() -> int {
+        if (poll) {
+            const volatile long long *flag = reinterpret_cast<const volatile long long *>(pin_scal + 8);
+            unsigned spins = 0;
+            while (*flag != eval_seq) {
+                if (++spins > (1u << 26)) {
+                    ALVA_HIP(hipStreamSynchronize(st));
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            memcpy(scal, pin_scal, sizeof(scal));
+            return ALVA_OK;
+        }
         ALVA_HIP(hipMemcpyAsync(pin_scal, B.scal, sizeof(scal), hipMemcpyDeviceToHost, st));  // pinned: a plain DMA, no staging
         ALVA_HIP(hipStreamSynchronize(st));
         memcpy(scal, pin_scal, sizeof(scal));
