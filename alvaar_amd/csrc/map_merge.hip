@@ -115,7 +115,11 @@ extern "C" int alva_fuse_map_points(alva_ctx *ctx, int n, const int *d_stream, c
         }
         if (!pin[0] || rounds > n) break;
     }
-    if (a != d_keep) ALVA_HIP(hipMemcpyAsync(d_keep, a, (size_t) n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (a != d_keep) {
+        // "synchronous" in the header: the caller may read d_keep on ANY stream when this returns
+        ALVA_HIP(hipMemcpyAsync(d_keep, a, (size_t) n, hipMemcpyDeviceToDevice, ctx->stream));
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    }
     if (h_rounds) *h_rounds = rounds;
     return ALVA_OK;
 }

@@ -2,6 +2,7 @@
 // (v_mfma_f64_16x16x4_f64 -- the instruction the Schur-complement GEMM and the reduced-camera Cholesky of ba.hip run on) and the plain
 // integer VALU rate (v_xor / v_bcnt / v_add -- the Hamming matchers).  Independent accumulator chains, every SIMD of the chip busy.
 #include "common.hpp"
+#include <chrono>
 
 namespace {
 
@@ -38,7 +39,39 @@ __global__ void __launch_bounds__(256) k_valu_int_peak(int iters, unsigned *sink
     if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345u) sink[0] = a0;
 }
 
+__global__ void k_null(int *sink) {
+    if (sink && threadIdx.x == 12345) sink[0] = 1;
+}
+
 }  // namespace
+
+// Launch-latency figures for the end-to-end bound of SURVEY.md 8(d) ("~10-15 kernel launches ~ 50-100 us"): the time per kernel of a
+// chain of `chain` DEPENDENT empty launches on one stream (each waits for its predecessor: what a stage chain pays per link), and
+// the round trip of one empty launch + stream synchronisation (what a host decision between two stages pays).  Microseconds.
+extern "C" int alva_microbench_launch(alva_ctx *ctx, int chain, double *h_us_per_dependent_launch, double *h_us_launch_sync_roundtrip) {
+    ALVA_ARG(ctx && chain > 0);
+    void *sink = nullptr;
+    int rc = alva_ctx_scratch(ctx, 9, 256, &sink);
+    if (rc) return rc;
+    for (int i = 0; i < 8; i++) hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, ctx->stream, (int *) sink);
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_us_per_dependent_launch) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < chain; i++) hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, ctx->stream, (int *) sink);
+        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        *h_us_per_dependent_launch = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / chain;
+    }
+    if (h_us_launch_sync_roundtrip) {
+        const int reps = 50;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; i++) {
+            hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, ctx->stream, (int *) sink);
+            ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        *h_us_launch_sync_roundtrip = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
+    return ALVA_OK;
+}
 
 // *h_tflops = FP64 MFMA rate (2 * 16 * 16 * 4 flop per instruction per wave); *h_tops = integer VALU lane-operations per second / 1e12
 // (3 counted instructions per inner triple: xor, bcnt-accumulate, add).  Synchronous; ~10 ms.

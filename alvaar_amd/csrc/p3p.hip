@@ -16,6 +16,7 @@
 // FP64 VALU work (100 x N x ~40 flop); bytes are negligible (48 N read once per hypothesis,
 // L2-resident).  No MFMA: nothing here is GEMM-shaped.
 #include "common.hpp"
+#include <atomic>
 #include "pose_internal.hpp"
 #include <cmath>
 #include <ctime>
@@ -517,10 +518,12 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     // has 160 KB per CU and a workgroup may take it all once the kernel's limit is raised (a 4K frame has ~10 k 3-D keypoints)
     ALVA_ARG(n >= 4 && n <= 19000);
     if (n > 7168) {
-        static bool raised = false;
-        if (!raised) {
+        // the attribute is per DEVICE (one code object per device); sessions on several host threads reach this concurrently
+        static std::atomic<bool> raised[64];
+        const bool tracked = ctx->device >= 0 && ctx->device < 64;
+        if (!tracked || !raised[ctx->device].load(std::memory_order_acquire)) {
             ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_p3p), hipFuncAttributeMaxDynamicSharedMemorySize, 19000 * 8));
-            raised = true;
+            if (tracked) raised[ctx->device].store(true, std::memory_order_release);
         }
     }
     float focal = fx + fy;          // multi_view_geometry.cpp:72-76

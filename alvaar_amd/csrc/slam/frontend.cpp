@@ -226,6 +226,17 @@ void Slam::klt_from_motion_prior() {
     for (int pass = 1; pass <= 3; pass++)
         for (int s = 0; s < n; s++)
             if (r.code_v[(size_t) s] == pass) cur->update(job_ids_[(size_t) s], &r.px_v[2 * (size_t) s], &r.unpx_v[2 * (size_t) s], &r.bv_v[3 * (size_t) s]);
+    {
+        const long full = cfg.klt_levels + 1;
+        long work = 0;
+        for (int s = 0; s < n; s++) {
+            const int c = r.code_v[(size_t) s];
+            const bool prior = job_is3d_[(size_t) s] && cfg.klt_use_prior;
+            work += c == 1 ? 2 : c == 2 ? full + 1 : c == 3 ? 1 + full + 1 : (prior ? 1 : full);
+        }
+        n_klt_kp_levels += work;
+        n_klt_slots += n;
+    }
     pose_ids_.clear();
     for (int s = 0; s < n; s++) {
         if (!r.code_v[(size_t) s]) remove_obs_from_cur(job_ids_[(size_t) s]);

@@ -354,6 +354,9 @@ public:
     SE3 init_computed;  // what checkReadyForInit computed itself on the initialisation frame (before any override)
     // counters for tests / bench
     long n_ba_runs = 0, n_merges = 0, n_kf_culled = 0;
+    // fb-KLT work done by the tracking steps (bench.py: keypoint-levels per second): LK passes over one pyramid level,
+    // forwards + the one-level backward pass, counted from the per-slot result codes (a lost slot counts its first pass only)
+    long n_klt_kp_levels = 0, n_klt_slots = 0;
     // wall-clock seconds spent per section since the last reset of the array (tools/system_probe.py): image upload + pyramid enqueue,
     // slot gathering, tracking step until its results are back, tracker bookkeeping, waiting for the pose, pose bookkeeping + keyframe
     // decision, keyframe creation (describe / detect), mapping (triangulation, matching to the local map, local BA)

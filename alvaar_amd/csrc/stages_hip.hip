@@ -295,6 +295,7 @@ struct Arena {
             base = nullptr;
         }
         size_t c = cap ? cap : (size_t) 1 << 20;
+        cap = 0;   // nothing is held while the allocation below can still fail (a failed grow must not leave cap > 0 with base == nullptr)
         while (c < need) c *= 2;
         if (pinned) ALVA_HIP(hipHostMalloc((void **) &base, c, hipHostMallocDefault));
         else ALVA_HIP(hipMalloc((void **) &base, c));
@@ -323,8 +324,9 @@ struct HipStages::Impl {
     int cur = 0;
     uint8_t *d_rgba = nullptr, *d_gray = nullptr, *d_eq = nullptr, *h_rgba = nullptr;
     double *d_invK = nullptr;
-    const uint8_t *registered = nullptr, *last_host_ptr = nullptr;  // page-locked caller buffer (see new_frame)
-    bool allow_register = true, upload_in_flight = false;
+    const uint8_t *registered = nullptr, *registered_dev = nullptr;  // caller buffer locked + mapped by register_frame_buffer
+    size_t registered_bytes = 0;
+    bool upload_in_flight = false;
     hipEvent_t upload_done = nullptr;
     double max_quality = 0.001;  // state.hpp:57; lives as long as the reference's FeatureExtractor object (system.cpp:31)
     Arena dev, pin;
@@ -373,6 +375,10 @@ struct HipStages::Impl {
         if (rc) return rc;
         trk_cap = cap;
         ALVA_HIP(hipMemsetAsync(trk_dev.base, 0, 256, st));  // the slot-wise step's counters start at zero
+        // fresh (or recycled) pinned memory: the completion word must not equal a sequence number the host is about to wait for.  The
+        // stream is idle here (both grows synchronised it), so a plain host store cannot race a kernel's publication.
+        ALVA_HIP(hipStreamSynchronize(st));
+        track_pin().o_hdr[8] = 0;
         return ALVA_OK;
     }
     bool pose_pending = false;
@@ -457,7 +463,6 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     ALVA_HIP(hipMemcpy(m->d_invK, invK, 9 * sizeof(double), hipMemcpyHostToDevice));
     ALVA_HIP(hipHostMalloc((void **) &m->h_rgba, P * 4, hipHostMallocDefault));
     ALVA_HIP(hipEventCreateWithFlags(&m->upload_done, hipEventDisableTiming));
-    m->allow_register = getenv("ALVA_NO_HOST_REGISTER") == nullptr;
     for (auto &p: m->pyr) {
         rc = alva_pyramid_create(m->ctx, cam.width, cam.height, 9, 3, &p);  // state.hpp:51-53: 9 x 9 window, 3 levels
         if (rc) return rc;
@@ -483,15 +488,13 @@ int HipStages::warm_up(int cell) {
             img[i] = img[i + 1] = img[i + 2] = v;
             img[i + 3] = 255;
         }
-        std::vector<uint8_t> img2(img);   // two different buffers: the same pointer twice would get page-locked (new_frame)
         for (int f = 0; f < 2; f++) {
-            rc = new_frame(f ? img2.data() : img.data());
+            rc = new_frame(img.data());
             if (rc) return rc;
             rc = frame_done();
             if (rc) return rc;
         }
         ALVA_HIP(hipStreamSynchronize(m->st));
-        m->last_host_ptr = nullptr;
     }
     const int cw = (W + cell - 1) / cell, chh = (H + cell - 1) / cell, n = cw * chh;
     // the tracking step (stage-in, tracker, retry, compaction) and the pose solve behind it
@@ -645,30 +648,57 @@ int HipStages::build_from(const uint8_t *d_src) {
     return alva_pyramid_build_from_gray(m->ctx, m->pyr[m->cur], m->d_eq, (size_t) m->cam.width);
 }
 
-// The caller's frame buffer is pageable memory (the reference's wasm heap).  A caller that hands over the SAME buffer frame after frame
-// -- src/system.js allocates memImg once and copies every frame into it (:63-67, :175) -- gets it page-locked on its second use, and the
-// DMA engine then reads it in place; any other buffer goes through a pinned staging copy.  ALVA_NO_HOST_REGISTER=1 disables the former.
+// The caller's frame buffer is pageable memory (the reference's wasm heap): by default a frame goes through a pinned staging copy
+// (one memcpy + one DMA).  A caller that reuses ONE buffer -- src/system.js allocates memImg once and writes every frame into it
+// (:63-67, :175) -- registers it explicitly (register_frame_buffer = alva_system_register_frame_buffer): the pages are locked and
+// mapped, and k_level0 (gray + pyramid level 0) then reads the frame straight out of host memory over PCIe -- no staging copy, no
+// copy command, no separate device RGBA buffer.  Registration is the caller's statement about the buffer's lifetime; nothing is
+// inferred from pointer values (an address seen twice says nothing about the pages behind it).
+int HipStages::register_frame_buffer(const uint8_t *buf, size_t bytes) {
+    ALVA_HIP(hipSetDevice(m->device));
+    const int urc = unregister_frame_buffer();
+    if (urc) return urc;
+    if (!buf) return ALVA_OK;
+    ALVA_ARG(bytes >= (size_t) m->cam.width * m->cam.height * 4 && ((uintptr_t) buf & 15) == 0);
+    ALVA_HIP(hipHostRegister((void *) buf, bytes, hipHostRegisterMapped));
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, (void *) buf, 0) != hipSuccess || !dp) {
+        (void) hipGetLastError();
+        (void) hipHostUnregister((void *) buf);
+        alva_set_error("alva_system_register_frame_buffer: the registered buffer has no device mapping");
+        return ALVA_ERR_HIP;
+    }
+    m->registered = buf;
+    m->registered_dev = (const uint8_t *) dp;
+    m->registered_bytes = bytes;
+    return ALVA_OK;
+}
+
+int HipStages::unregister_frame_buffer() {
+    if (!m->registered) return ALVA_OK;
+    ALVA_HIP(hipSetDevice(m->device));
+    ALVA_HIP(hipStreamSynchronize(m->st));   // no kernel may still be reading the pages
+    m->upload_in_flight = false;
+    const uint8_t *b = m->registered;
+    m->registered = m->registered_dev = nullptr;
+    m->registered_bytes = 0;
+    ALVA_HIP(hipHostUnregister((void *) b));
+    return ALVA_OK;
+}
+
 int HipStages::new_frame(const uint8_t *rgba) {
     ALVA_HIP(hipSetDevice(m->device));
     const size_t bytes = (size_t) m->cam.width * m->cam.height * 4;
-    const uint8_t *src = m->h_rgba;
-    if (m->registered == rgba) {
-        src = rgba;
+    if (m->registered && rgba >= m->registered && rgba + bytes <= m->registered + m->registered_bytes && (((uintptr_t) rgba) & 15) == 0) {
+        // zero-copy: the image kernels read the caller's pages; frame_done() waits for them before the call returns the buffer
+        const int rc = build_from(m->registered_dev + (rgba - m->registered));
+        if (rc) return rc;
         m->upload_in_flight = true;
-    } else {
-        if (m->allow_register && m->last_host_ptr == rgba && hipHostRegister((void *) rgba, bytes, hipHostRegisterDefault) == hipSuccess) {
-            if (m->registered) (void) hipHostUnregister((void *) m->registered);
-            m->registered = rgba;
-            src = rgba;
-            m->upload_in_flight = true;
-        } else {
-            (void) hipGetLastError();
-            memcpy(m->h_rgba, rgba, bytes);
-        }
+        ALVA_HIP(hipEventRecord(m->upload_done, m->st));
+        return ALVA_OK;
     }
-    m->last_host_ptr = rgba;
-    ALVA_HIP(hipMemcpyAsync(m->d_rgba, src, bytes, hipMemcpyHostToDevice, m->st));
-    if (m->upload_in_flight) ALVA_HIP(hipEventRecord(m->upload_done, m->st));
+    memcpy(m->h_rgba, rgba, bytes);
+    ALVA_HIP(hipMemcpyAsync(m->d_rgba, m->h_rgba, bytes, hipMemcpyHostToDevice, m->st));
     return build_from(m->d_rgba);
 }
 

@@ -21,6 +21,9 @@ public:
     int new_frame(const uint8_t *rgba) override;
     int new_frame_device(const uint8_t *d_rgba) override;
     int frame_done() override;
+    // explicit page-lock + device mapping of the caller's frame buffer (see new_frame); buf == nullptr releases it
+    int register_frame_buffer(const uint8_t *buf, size_t bytes);
+    int unregister_frame_buffer();
     void reset_images() override;
     int fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) override;
     int compute_keypoints(int n, const float *px, float *unpx, double *bv) override;

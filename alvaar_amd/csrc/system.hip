@@ -21,6 +21,13 @@ static int sys_fail(int rc, const char *what) {
     return rc;
 }
 
+// No C++ exception may cross the C ABI (the reference's contract: "no exceptions"): the map layer keeps the reference's
+// .at() look-ups (std::out_of_range on an inconsistent map) and its containers can throw std::bad_alloc.  Every entry point that runs
+// the map layer goes through guarded(): the error text is kept, the tracker is asked to reset (what the reference's own failure paths
+// do, visual_frontend.cpp:73-92) and ALVA_ERR_STATE is returned.
+template <class F>
+static int guarded(alva_system *s, const char *what, F &&body);
+
 struct alva_system {
     int device = 0;
     std::unique_ptr<HipStages> stages;
@@ -29,6 +36,20 @@ struct alva_system {
     // findCameraPoseWithIMU (system.cpp:57-104)
     double imu_translation[3] = {0, 0, 0}, prev_translation[3] = {0, 0, 0};
 };
+
+template <class F>
+static int guarded(alva_system *s, const char *what, F &&body) {
+    try {
+        return body();
+    } catch (const std::exception &e) {
+        snprintf(g_sys_err, sizeof(g_sys_err), "%s: %s", what, e.what());
+    } catch (...) {
+        snprintf(g_sys_err, sizeof(g_sys_err), "%s: unknown C++ exception", what);
+    }
+    if (s && s->stages) (void) s->stages->frame_done();   // no kernel keeps reading a caller-owned frame buffer behind an error return
+    if (s && s->slam) s->slam->reset_requested = true;
+    return ALVA_ERR_STATE;
+}
 
 extern "C" int alva_system_create(int device, alva_system **out) {
     g_sys_err[0] = 0;
@@ -52,8 +73,8 @@ extern "C" void alva_system_destroy(alva_system *s) {
     delete s;
 }
 
-extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, double fx, double fy, double cx, double cy, double k1, double k2,
-                                        double p1, double p2, int cell_size, int clahe_enabled, int random_sampling) {
+static int configure_impl(alva_system *s, int width, int height, double fx, double fy, double cx, double cy, double k1, double k2,
+                          double p1, double p2, int cell_size, int clahe_enabled, int random_sampling) {
     g_sys_err[0] = 0;
     if (!s || width < 64 || height < 64 || width % 4 || cell_size < 8 || !(fx > 0) || !(fy > 0)) {
         snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_configure: bad argument");
@@ -93,6 +114,13 @@ extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, d
     return ALVA_OK;
 }
 
+extern "C" int alva_system_configure_ex(alva_system *s, int width, int height, double fx, double fy, double cx, double cy, double k1, double k2,
+                                        double p1, double p2, int cell_size, int clahe_enabled, int random_sampling) {
+    return guarded(s, "alva_system_configure", [&]() -> int {
+        return configure_impl(s, width, height, fx, fy, cx, cy, k1, k2, p1, p2, cell_size, clahe_enabled, random_sampling);
+    });
+}
+
 extern "C" int alva_system_configure(alva_system *s, int width, int height, double fx, double fy, double cx, double cy, double k1, double k2,
                                      double p1, double p2) {
     return alva_system_configure_ex(s, width, height, fx, fy, cx, cy, k1, k2, p1, p2, 40 /* system.cpp:15 */, 0 /* :17 */, 1 /* state.hpp:67 */);
@@ -100,8 +128,25 @@ extern "C" int alva_system_configure(alva_system *s, int width, int height, doub
 
 extern "C" void alva_system_reset(alva_system *s) {  // system.cpp:42-55
     if (!s || !s->slam) return;
-    s->slam->reset();
+    guarded(s, "alva_system_reset", [&]() -> int { s->slam->reset(); return ALVA_OK; });
     for (double &v: s->prev_translation) v = 0;
+}
+
+extern "C" int alva_system_register_frame_buffer(alva_system *s, const uint8_t *h_rgba, size_t bytes) {
+    g_sys_err[0] = 0;
+    if (!s || !s->stages || !h_rgba) {
+        snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_register_frame_buffer: not configured or NULL argument");
+        return ALVA_ERR_ARG;
+    }
+    const int rc = s->stages->register_frame_buffer(h_rgba, bytes);
+    return rc ? sys_fail(rc, "alva_system_register_frame_buffer") : ALVA_OK;
+}
+
+extern "C" int alva_system_unregister_frame_buffer(alva_system *s) {
+    g_sys_err[0] = 0;
+    if (!s || !s->stages) return ALVA_OK;
+    const int rc = s->stages->unregister_frame_buffer();
+    return rc ? sys_fail(rc, "alva_system_unregister_frame_buffer") : ALVA_OK;
 }
 
 extern "C" int alva_system_find_camera_pose_ts(alva_system *s, const uint8_t *h_rgba, double timestamp, float *h_pose) {
@@ -110,10 +155,12 @@ extern "C" int alva_system_find_camera_pose_ts(alva_system *s, const uint8_t *h_
         snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_find_camera_pose: not configured or NULL argument");
         return ALVA_ERR_ARG;
     }
-    const int status = s->slam->process_frame(h_rgba, timestamp);  // system.cpp:156-175
-    if (status < 0) return sys_fail(status, "alva_system_find_camera_pose");
-    pose_to_array(s->slam->cur->Twc, h_pose);  // written whatever the status (system.cpp:118)
-    return status;
+    return guarded(s, "alva_system_find_camera_pose", [&]() -> int {
+        const int status = s->slam->process_frame(h_rgba, timestamp);  // system.cpp:156-175
+        if (status < 0) return sys_fail(status, "alva_system_find_camera_pose");
+        pose_to_array(s->slam->cur->Twc, h_pose);  // written whatever the status (system.cpp:118)
+        return status;
+    });
 }
 
 extern "C" int alva_system_find_camera_pose_device(alva_system *s, const uint8_t *d_rgba, double timestamp, float *h_pose) {
@@ -122,10 +169,12 @@ extern "C" int alva_system_find_camera_pose_device(alva_system *s, const uint8_t
         snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_find_camera_pose_device: not configured or NULL argument");
         return ALVA_ERR_ARG;
     }
-    const int status = s->slam->process_frame(d_rgba, timestamp, true);
-    if (status < 0) return sys_fail(status, "alva_system_find_camera_pose_device");
-    pose_to_array(s->slam->cur->Twc, h_pose);
-    return status;
+    return guarded(s, "alva_system_find_camera_pose_device", [&]() -> int {
+        const int status = s->slam->process_frame(d_rgba, timestamp, true);
+        if (status < 0) return sys_fail(status, "alva_system_find_camera_pose_device");
+        pose_to_array(s->slam->cur->Twc, h_pose);
+        return status;
+    });
 }
 
 extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgba, float *h_pose) {
@@ -169,15 +218,18 @@ extern "C" int alva_system_find_camera_pose_with_imu_ts(alva_system *s, const ui
 
 extern "C" int alva_system_find_plane(alva_system *s, float *h_pose, int num_iterations) {
     if (!s || !s->slam || !h_pose || num_iterations <= 0) return 0;
-    // MapManager::getCurrentFrameMapPoints (map_manager.cpp:340-357): observed 3-D map points, in the map's container order
-    std::vector<double> pts;
-    for (const auto &e: s->slam->map_points)
-        if (e.second->observed && e.second->is3d) pts.insert(pts.end(), e.second->X, e.second->X + 3);
-    double pose7[7];
-    se3_to_pose7(s->slam->cur->Twc, pose7);
-    int found = 0;
-    if (s->stages->find_plane((int) (pts.size() / 3), pts.data(), pose7, num_iterations, h_pose, &found) != ALVA_OK) return 0;
-    return found ? 1 : 0;
+    const int rc = guarded(s, "alva_system_find_plane", [&]() -> int {
+        // MapManager::getCurrentFrameMapPoints (map_manager.cpp:340-357): observed 3-D map points, in the map's container order
+        std::vector<double> pts;
+        for (const auto &e: s->slam->map_points)
+            if (e.second->observed && e.second->is3d) pts.insert(pts.end(), e.second->X, e.second->X + 3);
+        double pose7[7];
+        se3_to_pose7(s->slam->cur->Twc, pose7);
+        int found = 0;
+        if (s->stages->find_plane((int) (pts.size() / 3), pts.data(), pose7, num_iterations, h_pose, &found) != ALVA_OK) return 0;
+        return found ? 1 : 0;
+    });
+    return rc == 1 ? 1 : 0;
 }
 
 extern "C" int alva_system_get_frame_points(alva_system *s, int *h_points) {
@@ -236,6 +288,12 @@ extern "C" int alva_system_debug_map_points(alva_system *s, int cap, int *ids, d
 extern "C" int alva_system_debug_counters(alva_system *s, long *out3) {
     if (!s || !s->slam || !out3) return ALVA_ERR_ARG;
     out3[0] = s->slam->n_ba_runs; out3[1] = s->slam->n_merges; out3[2] = s->slam->n_kf_culled;
+    return ALVA_OK;
+}
+extern "C" int alva_system_debug_klt_work(alva_system *s, long *out2, int reset) {
+    if (!s || !s->slam || !out2) return ALVA_ERR_ARG;
+    out2[0] = s->slam->n_klt_kp_levels; out2[1] = s->slam->n_klt_slots;
+    if (reset) s->slam->n_klt_kp_levels = s->slam->n_klt_slots = 0;
     return ALVA_OK;
 }
 extern "C" int alva_system_debug_timing(alva_system *s, double *out8, int reset) {

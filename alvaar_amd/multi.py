@@ -42,9 +42,13 @@ def shard_from_env() -> Shard:
     return Shard(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_process_group(shard: Shard, backend: str | None = None) -> bool:
-    if shard.world <= 1:
+def init_process_group(shard: Shard, backend: str | None = None, force: bool = False) -> bool:
+    """force=True initialises the group for a single rank too (world_size 1): the shared-map exchange then runs through the real
+    backend -- RCCL on a GPU box -- instead of the no-group short cut; MASTER_PORT must be set or free."""
+    if shard.world <= 1 and not force:
         return False
+    if shard.world <= 1:
+        os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -141,3 +145,34 @@ def fuse_duplicates(records: torch.Tensor, ctx, max_dist_m: float = 0.05, max_ha
     check(lib.alva_fuse_map_points(ctx.h, n, stream.data_ptr(), xyz.data_ptr(), desc.data_ptr(), float(max_dist_m), int(max_hamming),
                                    keep.data_ptr(), absorbed.data_ptr(), C.byref(rounds)))
     return stream, ids, keep.bool(), absorbed
+
+
+def system_map_records(ar, stream_id: int, capacity: int, device: torch.device | None = None):
+    """The 3-D map points of one alva::System session (alva_system_debug_map_points: id, world position, descriptor medoid) as the
+    fixed-capacity record block of the exchange; points without a descriptor are skipped, the newest are dropped beyond `capacity`
+    (ids are handed out consecutively, so "older absorbs newer" keeps the established part of the map).  Returns (block, n_records)."""
+    ids, xyz, flags, inv, desc = ar.map_points(cap=262144)
+    m = (flags[:, 0] != 0) & (flags[:, 4] > 0)   # is3d, at least one keyframe descriptor => a medoid (inspect_map_points)
+    ids, xyz, desc = ids[m], xyz[m], desc[m]
+    o = np.argsort(ids, kind="stable")[:capacity]
+    return pack_records(stream_id, ids[o].astype(np.int32), xyz[o], desc[o], capacity, device), int(len(o))
+
+
+def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384):
+    """One shared-map merge (north_star: "RCCL over xGMI only for the optional shared-map merge"): pack this rank's map, ONE
+    all_gather_into_tensor over the process group (RCCL when the backend is nccl), fuse the duplicates on the GPU.  Returns a dict
+    of sizes and wall times; the fused set is identical on every rank (same input, deterministic rule)."""
+    import time
+    t0 = time.perf_counter()
+    block, n = system_map_records(ar, shard.rank, capacity)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    allrec = all_gather_map(block)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    stream, ids, keep, absorbed = fuse_duplicates(allrec, ctx)
+    kept = int(keep.sum().item())
+    t3 = time.perf_counter()
+    return {"records_this_rank": n, "records_gathered": int(stream.shape[0]), "kept": kept, "fused": int(stream.shape[0]) - kept,
+            "bytes_gathered": int(allrec.numel()), "backend": dist.get_backend() if dist.is_available() and dist.is_initialized() else None,
+            "pack_us": (t1 - t0) * 1e6, "all_gather_us": (t2 - t1) * 1e6, "fuse_us": (t3 - t2) * 1e6}

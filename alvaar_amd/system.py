@@ -25,6 +25,8 @@ lib.alva_system_get_frame_points.argtypes = [_vp, _vp]
 lib.alva_system_get_keypoints.argtypes = [_vp, _vp, _vp, _vp, _i]
 lib.alva_system_configure_ex.argtypes = [_vp, _i, _i] + [_d] * 8 + [_i] * 3
 lib.alva_system_find_camera_pose_ts.argtypes = [_vp, _vp, _d, _vp]
+lib.alva_system_register_frame_buffer.argtypes = [_vp, _vp, C.c_size_t]
+lib.alva_system_unregister_frame_buffer.argtypes = [_vp]
 lib.alva_system_find_camera_pose_device.argtypes = [_vp, _vp, _d, _vp]
 lib.alva_system_debug_state.argtypes = [_vp, _vp]
 lib.alva_system_debug_pose7.argtypes = [_vp, _vp, _vp]
@@ -34,6 +36,7 @@ lib.alva_system_debug_keyframe.argtypes = [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]
 lib.alva_system_debug_covisibility.argtypes = [_vp, _i, _i, _vp]
 lib.alva_system_debug_map_points.argtypes = [_vp, _i] + [_vp] * 5
 lib.alva_system_debug_counters.argtypes = [_vp, _vp]
+lib.alva_system_debug_klt_work.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_set_init_pose.argtypes = [_vp, _vp]
 lib.alva_system_debug_timing.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_timing_keyframe.argtypes = [_vp, _vp, _i]
@@ -75,6 +78,13 @@ class AlvaAR:
             self.h = None
             raise AlvaError(msg)
         self._pose = np.zeros(16, np.float32)
+        # src/system.js:63-67: ONE frame buffer (memImg) allocated at construction and reused for every frame; here it is page-locked and
+        # mapped once (alva_system_register_frame_buffer) so that the gray / pyramid kernel reads it in place.  4096-byte aligned.
+        nbytes = width * height * 4
+        self._mem_raw = np.empty(nbytes + 4096, np.uint8)
+        off = (-self._mem_raw.ctypes.data) % 4096
+        self.mem_img = self._mem_raw[off:off + nbytes].reshape(height, width, 4)
+        self._registered = lib.alva_system_register_frame_buffer(h, self.mem_img.ctypes.data, nbytes) == 0
 
     @staticmethod
     def Initialize(width: int, height: int, fov: float = 45.0) -> "AlvaAR":  # noqa: N802 (reference name)
@@ -82,7 +92,7 @@ class AlvaAR:
 
     def close(self):
         if getattr(self, "h", None):
-            lib.alva_system_destroy(self.h)
+            lib.alva_system_destroy(self.h)   # releases the frame-buffer registration before mem_img goes away
             self.h = None
 
     __del__ = close
@@ -90,7 +100,7 @@ class AlvaAR:
     def findCameraPose(self, frame_rgba: np.ndarray, timestamp_ms: float | None = None):  # noqa: N802
         """returns (pose[16] or None, status) -- the JS wrapper returns the pose only on status 1.  timestamp_ms = None reads the
         system clock like the reference (system.cpp:114)."""
-        frame = np.ascontiguousarray(frame_rgba, np.uint8)
+        frame = self._stage(frame_rgba)
         if timestamp_ms is None:
             status = lib.alva_system_find_camera_pose(self.h, frame.ctypes.data, self._pose.ctypes.data)
         else:
@@ -98,6 +108,14 @@ class AlvaAR:
         if status < 0:
             raise AlvaError(lib.alva_system_last_error().decode())
         return (self._pose.copy() if status == 1 else None), status
+
+    def _stage(self, frame_rgba) -> np.ndarray:
+        """memImg.write(frame.data) (src/system.js:175): the frame goes into the wrapper's own registered buffer -- unless the caller
+        already wrote it there (passes self.mem_img itself)."""
+        if frame_rgba is self.mem_img:
+            return self.mem_img
+        np.copyto(self.mem_img, np.asarray(frame_rgba, np.uint8).reshape(self.mem_img.shape))
+        return self.mem_img
 
     def find_camera_pose_device(self, d_rgba_ptr: int, timestamp_ms: float):
         """frame already in device memory (torch tensor .data_ptr()); returns the status, the pose is in self._pose"""
@@ -107,7 +125,7 @@ class AlvaAR:
         return status
 
     def findCameraPoseWithIMU(self, frame_rgba, orientation_wxyz, motion=(), timestamp_ms: float | None = None):  # noqa: N802
-        frame = np.ascontiguousarray(frame_rgba, np.uint8)
+        frame = self._stage(frame_rgba)
         imu = np.zeros(256, np.float64)
         imu[:4] = orientation_wxyz
         imu[4] = len(motion)
@@ -182,6 +200,12 @@ class AlvaAR:
         out = (C.c_long * 3)()
         lib.alva_system_debug_counters(self.h, out)
         return dict(ba_solves=out[0], merges=out[1], culled_keyframes=out[2])
+
+    def klt_work(self, reset: bool = True):
+        """(keypoint-levels, slots) of the tracking steps since the last reset"""
+        out = (C.c_long * 2)()
+        lib.alva_system_debug_klt_work(self.h, out, int(reset))
+        return int(out[0]), int(out[1])
 
     def timing(self, reset: bool = True):
         """seconds per section of the frame loop since the last reset (see alva_system_debug_timing)"""

@@ -212,7 +212,6 @@ class SystemJob:
         host = np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, width, height, noise_seed=11)) for k in range(STREAM_FRAMES)])
         self.frames = torch.from_numpy(host).to(self.dev)
         self.host_frames = host if host_copy else None
-        self.fixed = np.empty_like(host[0])          # the caller-owned frame buffer of the host-fed variant (src/system.js memImg)
         self.ar = AlvaAR(width, height, device=device, cell_size=cell, random_sampling=False)
         self.k = -1
         self.status_hist = [0, 0, 0, 0]
@@ -226,10 +225,37 @@ class SystemJob:
 
     def step_host(self):
         self.k += 1
-        np.copyto(self.fixed, self.host_frames[stream_index(self.k)])     # src/system.js:175 memImg.write(frame.data)
-        pose, st = self.ar.findCameraPose(self.fixed, 33.0 * self.k)
+        # src/system.js:175 memImg.write(frame.data): AlvaAR.findCameraPose copies the caller's frame into its ONE registered frame buffer
+        pose, st = self.ar.findCameraPose(self.host_frames[stream_index(self.k)], 33.0 * self.k)
         self.status_hist[st] += 1
         return st == 1
+
+    def warm_to_steady_state(self, max_frames: int = 2500, then_untimed: int = 0):
+        """Untimed: run until the map is in the regime a long session lives in -- the 30-keyframe window full (mapper.cpp:24-28 removes
+        keyframe k - 30 from keyframe 31 on) -- then on to the middle of a keyframe period, so that a K-step window holds round(K / period)
+        keyframes: the nearest whole number to their natural share.  Returns (frames run, keyframe period in frames)."""
+        n0 = self.k
+        kf_frames = []
+        last = int(self.ar.state()[11])
+        while self.k - n0 < max_frames:
+            self.step()
+            nk = int(self.ar.state()[11])
+            if nk != last:
+                kf_frames.append(self.k)
+                last = nk
+            if nk >= 34 and len(kf_frames) >= 8:
+                break
+        period = float(np.median(np.diff(kf_frames[-8:]))) if len(kf_frames) >= 3 else 0.0
+        if period > 2:
+            # the caller runs `then_untimed` more untimed steps (--warmup) before its window: aim so that the WINDOW starts mid-period
+            target = int(period // 2 - then_untimed) % int(period)
+            while (self.k - kf_frames[-1]) != target and self.k - n0 < max_frames + 64:
+                self.step()
+                nk = int(self.ar.state()[11])
+                if nk != last:
+                    kf_frames.append(self.k)
+                    last = nk
+        return self.k - n0, period
 
 
 def bench_system_streams(device: int, n_streams: int, steps: int = 300):
@@ -570,11 +596,77 @@ def bench_two_view_init(ctx, reps: int = 10):
                      "on-device Levenberg-Marquardt refinement, one stream synchronisation")
 
 
+def cpu_stage_table(width: int, height: int, cell: int, orb_features: int, seed: int, budget_s: float = 4.0):
+    """SURVEY.md 8(d) "CPU baseline timing (2)": per-stage milliseconds of the reference's own L1 functions / vendored OpenCV, OpenGV and
+    Ceres calls (oracle/_ref: FeatureExtractor::detectFeaturePoints feature_extractor.cpp:11-158, describeFeaturePoints :160-214,
+    FeatureTracker::fbKltTracking feature_tracker.cpp:5-111, MultiViewGeometry::p3pRansac / ceresPnP multi_view_geometry.cpp:24-223,
+    cv::cvtColor, cv::buildOpticalFlowPyramid, cv::BFMatcher, cv::ORB::detectAndCompute) on this box's host cores, same synthetic
+    frames as the GPU path.  "ms_1_thread" = median over the repetitions on one core.  The reference build has NO intra-call
+    threading (wasm, single-threaded; OpenCV without a parallel backend, Ceres NO_THREADS -- as shipped), so "8 threads" means 8
+    independent callers: "ms_8_callers" is the wall time per call when 8 host threads each run the stage on their own data."""
+    import threading
+    import oracles
+    from alvaar_amd import synth
+    R = oracles.Ref
+    canvas = synth.texture_canvas(width, height, seed)
+    rgba = [synth.gray_to_rgba(synth.frame_gray(canvas, k, width, height, noise_seed=11)) for k in (0, 1, 5)]
+    gray = [R.rgba2gray(f) for f in rgba]
+    pts, _ = R.detect_grid(gray[0], cell)
+    n = len(pts)
+    d0, _ = R.describe(gray[0], pts)
+    d5, _ = R.describe(gray[2], pts)
+    pb = synth.make_pnp_problem(n, seed, outlier_frac=0.1, pose_noise=0.01)
+    stages = {
+        "cvtColor(RGBA2GRAY)": lambda: R.rgba2gray(rgba[1]),
+        "buildOpticalFlowPyramid(9x9, 3)": lambda: R.build_pyramid(gray[1]),
+        "detectFeaturePoints": lambda: R.detect_grid(gray[1], cell),
+        "describeFeaturePoints": lambda: R.describe(gray[1], pts),
+        "fbKltTracking(3 levels)": lambda: R.fbklt(gray[0], gray[1], pts, pts, 3),
+        "BFMatcher(HAMMING) NxN": lambda: R.bf_match(d0, d5),
+        "p3pRansac(100 it)": lambda: R.p3p_lmeds(pb["bv"], pb["wpt"], fx=pb["K"][0], fy=pb["K"][1]),
+        "ceresPnP": lambda: R.pnp_refine(pb["uv"], pb["wpt"], pb["pose_init"], pb["K"]),
+        f"cv::ORB::detectAndCompute({orb_features})": lambda: R.orb(gray[1], orb_features),
+    }
+    out = {}
+    per = budget_s / len(stages)
+    for name, fn in stages.items():
+        t0 = time.perf_counter()
+        fn()
+        first = time.perf_counter() - t0
+        reps = int(min(20, max(3, 0.5 * per / max(first, 1e-6))))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ms1 = float(np.median(ts)) * 1e3
+        reps8 = max(2, reps // 3)
+        go = threading.Barrier(9)
+
+        def run():
+            go.wait()
+            for _ in range(reps8):
+                fn()
+        th = [threading.Thread(target=run) for _ in range(8)]
+        for t in th:
+            t.start()
+        go.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        ms8 = (time.perf_counter() - t0) / (8 * reps8) * 1e3
+        out[name] = {"ms_1_thread": round(ms1, 3), "ms_8_callers": round(ms8, 3), "reps": reps}
+    return {"geometry": f"{width}x{height}, cell {cell}", "keypoints": n, "stages": out}
+
+
 def cpu_baseline(seed: int, frames_1: int = 150, frames_8: int = 60):
-    """The reference itself on the host cores of this box, same stream, same configuration (cell 12), explicit timestamps, fixed-seed
-    sampling, Ceres' wall-clock caps frozen (they would silently skip work): System::findCameraPose frames/s on ONE core (the reference
-    is single-threaded: wasm, NO_THREADS Ceres) and with 8 independent reference Systems on 8 host threads (streams are independent, so
-    that is how the reference would use 8 cores).  Bounded sample: the first 150 frames of the stream (incl. initialisation and 7 keyframes)."""
+    """The reference itself on the host cores of this box (SURVEY.md 8(d) "CPU baseline timing" (1)-(3)), same stream, explicit
+    timestamps, fixed-seed sampling, Ceres' wall-clock caps frozen (they would silently skip work):
+      (1) System::findCameraPose frames/s on ONE core (the reference is single-threaded: wasm, NO_THREADS Ceres) at cell 12 (the metric's
+          ~2000 keypoints; this is `value`), at the SHIPPED cell 40 (system.cpp:15), at 1280x720 / cell 15 (configs[4]); and 8 independent
+          reference Systems on 8 host threads (streams are independent: that is how the reference would use 8 cores);
+      (2) per-stage milliseconds, cpu_stage_table();  (3) one local-BA solve through Ceres with the reference's cost functions.
+    Bounded sample: the first frames of the stream (incl. initialisation and the first keyframes); ~15 s of CPU work in total."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracles
     from alvaar_amd import synth
@@ -583,12 +675,12 @@ def cpu_baseline(seed: int, frames_1: int = 150, frames_8: int = 60):
     import sysdiff
     import threading
     canvas = synth.texture_canvas(W, H, seed)
-    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(max(frames_1, frames_8))]
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(max(frames_1, frames_8, 200))]
 
-    def run(n, out, slot):
-        ref = sysdiff.RefSystem(W, H, SYSTEM_CELL)
+    def run(n, out, slot, w=W, h=H, cell=SYSTEM_CELL, fr=frames):
+        ref = sysdiff.RefSystem(w, h, cell)
         t0 = time.perf_counter()
-        st = [ref.step(frames[k], 33.0 * k)[0] for k in range(n)]
+        st = [ref.step(fr[k], 33.0 * k)[0] for k in range(n)]
         out[slot] = (time.perf_counter() - t0, st, int(ref.state()[2]), len(ref.keyframe_ids()))
         ref.close()
     one = [None]
@@ -602,15 +694,26 @@ def cpu_baseline(seed: int, frames_1: int = 150, frames_8: int = 60):
     for t in th:
         t.join()
     dt8 = time.perf_counter() - t0
+    c40 = [None]
+    run(200, c40, 0, cell=40)
+    canvas720 = synth.texture_canvas(1280, 720, seed)
+    frames720 = [synth.gray_to_rgba(synth.frame_gray(canvas720, k, 1280, 720, noise_seed=11)) for k in range(40)]
+    c720 = [None]
+    run(40, c720, 0, w=1280, h=720, cell=15, fr=frames720)
     pbba = synth.make_ba_problem(20, 3000, 42)
     t1 = time.perf_counter()
     r = oracles.Ref.local_ba(pbba, 5, 0.0)
     dtb = time.perf_counter() - t1
+    desc = lambda tup, n: f"{tup[1].count(3)} initialising, {tup[1].count(1)} tracked, {tup[3]} keyframes, {tup[2]} keypoints at the end, {n} frames"
     return {"value": frames_1 / dt1, "unit": "frames/s", "cores": 1, "kind": "reference",
             "sample": f"the reference's System::findCameraPose (oracle/_ref) on the first {frames_1} frames of the same stream, cell {SYSTEM_CELL}: "
                       f"{st1.count(3)} initialising, {st1.count(1)} tracked, {nkf} keyframes with local BA, {nkp} keypoints at the end; + 1 local-BA solve (20 KF x 3000 pts)",
             "eight_threads": {"value": 8 * frames_8 / dt8, "unit": "frames/s", "cores": 8,
                               "sample": f"8 independent reference Systems on 8 host threads, {frames_8} frames each (the reference is single-threaded; independent streams are its only parallelism)"},
+            "system_cell40_shipped": {"value": 200 / c40[0][0], "unit": "frames/s", "cores": 1, "sample": "640x480, cell 40 (system.cpp:15): " + desc(c40[0], 200)},
+            "system_1280x720_cell15": {"value": 40 / c720[0][0], "unit": "frames/s", "cores": 1, "sample": "configs[4] geometry: " + desc(c720[0], 40)},
+            "stages_640x480": cpu_stage_table(W, H, SYSTEM_CELL, 2000, seed, budget_s=3.0),
+            "stages_1280x720": cpu_stage_table(1280, 720, 15, 4000, seed, budget_s=5.0),
             "local_ba_residual_block_iters_per_s": len(pbba["obs_kf"]) * (int(r["info"][0]) - 1) / dtb,
             "local_ba_ms": dtb * 1e3}
 
@@ -643,6 +746,71 @@ def cpu_baseline_port(seed: int, budget_s: float = 12.0):
             "sample": f"{n} tracking frames (gray, 2 LK pyramids, fb-KLT 3 levels, P3P-LMedS, PnP) through the C restatement; no keyframes"}
 
 
+def launch_latency(ctx):
+    import ctypes as C
+    from alvaar_amd.capi import lib, check
+    lib.alva_microbench_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    a, b = C.c_double(0), C.c_double(0)
+    best = [1e9, 1e9]
+    for _ in range(3):
+        check(lib.alva_microbench_launch(ctx.h, 200, C.byref(a), C.byref(b)))
+        best = [min(best[0], a.value), min(best[1], b.value)]
+    return best
+
+
+def pmc_reference(kernel: str, sources: list[str]):
+    """HBM traffic and L2 hit rate of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside this
+    process).  The file is stamped with the commit and the sha256 of the kernel's source files at capture time: if the sources have
+    changed since, the numbers are reported as stale (null) instead of silently carried over."""
+    import hashlib
+    f = ROOT / "profiles" / "r3_pmc_track_klt.json"
+    if not f.exists():
+        return None, None, {"file": None, "note": "no PMC capture committed for this kernel"}
+    j = json.loads(f.read_text())
+    now = {src: hashlib.sha256((ROOT / src).read_bytes()).hexdigest()[:16] for src in sources}
+    stale = any(j.get("source_sha16", {}).get(src) != h for src, h in now.items())
+    k = j.get("kernels", {}).get(kernel, {})
+    stamp = {"file": str(f.relative_to(ROOT)), "captured_at_commit": j.get("commit"), "source_sha16_at_capture": j.get("source_sha16"), "stale": stale}
+    if stale:
+        return None, None, stamp
+    return k.get("hbm_bytes_per_launch"), k.get("l2_hit_rate"), stamp
+
+
+def run_system_line(local: int, seed: int, width: int, height: int, cell: int, steps: int):
+    """A secondary System line (default-on for configs[4]'s geometry): steady-state warm-up, then >= 0.5 s of the resident-frame loop."""
+    job = SystemJob(local, seed, host_copy=False, width=width, height=height, cell=cell)
+    extra, period = job.warm_to_steady_state()
+    torch.cuda.synchronize()
+    kf0 = int(job.ar.state()[11])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(steps):
+            job.step()
+        n += steps
+        if time.perf_counter() - t0 > 0.5:
+            break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = job.ar.state()
+    job.ar.timing(); job.ar.timing_keyframe()
+    for _ in range(200):
+        job.step()
+    kfd = int(job.ar.state()[11])
+    sec, kfsec = job.ar.timing(), job.ar.timing_keyframe()
+    nk = max(kfd - int(st[11]), 1)
+    out = {"workload": f"{width}x{height} RGBA stream, cell {cell}, alva_system_find_camera_pose_device, frames resident in HBM",
+           "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3, "steps": n, "keyframes_in_region": int(st[11]) - kf0,
+           "untimed_frames_to_steady_state": extra, "keyframe_period_frames": period,
+           "keypoints_per_frame": int(st[2]), "keypoints_3d": int(st[4]), "keyframes_in_map": int(st[6]), "map_points": int(st[7]),
+           "ms_per_keyframe": round(1e3 * (sec["keyframe_create"] + sec["mapping"]) / nk, 3),
+           "tracking_frame_us": round(1e6 * sum(v for k_, v in sec.items() if k_ not in ("keyframe_create", "mapping")) / 200, 1)}
+    job.ar.close()
+    del job
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -656,13 +824,13 @@ def main():
                     help="also run the superseded 4- and 16-host-thread measurement (independent alva_frontend objects); off by default: its "
                          "concurrent launches of the same kernels would inflate their averages in a rocprofv3 profile of this command")
     ap.add_argument("--no-multi-stream", action="store_true", help="accepted for compatibility (the default now)")
-    ap.add_argument("--python-host", action="store_true", help="headline number with the stage calls issued from Python")
-    ap.add_argument("--serial", action="store_true", help="headline number on one HIP stream (no detector/tracker overlap)")
+    ap.add_argument("--quick", action="store_true", help="headline, roofline and CPU baseline only (skips the secondary rig / batch lines)")
     ap.add_argument("--system-streams", type=str, default="",
                     help="comma-separated session counts: also time S independent alva::System sessions on rank 0's GPU (reported under "
                          "system_streams; not part of value; off by default for the same reason as --multi-stream)")
     ap.add_argument("--streams-per-gpu", type=int, default=0,
                     help="also time S concurrent independent streams on rank 0's GPU (reported under multi_stream; not part of value)")
+    ap.add_argument("--merge-every", type=int, default=4, help="shared-map merge (RCCL all_gather + fuse) every this many keyframes in the merge line")
     args = ap.parse_args()
 
     from alvaar_amd import multi
@@ -670,13 +838,20 @@ def main():
     shard = multi.shard_from_env()
     rank, world, local = shard.rank, shard.world, shard.local_rank
     torch.cuda.set_device(local)
-    dist = multi.init_process_group(shard, "nccl")   # "nccl" IS RCCL on ROCm; only used for the barrier + timing reduction
+    # "nccl" IS RCCL on ROCm.  The data path has no collective (independent streams); the group carries the barrier + timing reduction
+    # and the optional shared-map merge -- initialised for ONE rank too, so that the merge line below runs on RCCL in every run.
+    try:
+        dist = multi.init_process_group(shard, "nccl", force=True)
+        dist_err = None
+    except Exception as e:   # a single-GPU box without a usable RCCL still measures the data path
+        if world > 1:
+            raise
+        dist, dist_err = False, repr(e)
 
-    if args.config == "720p-streams":
-        sysjob = SystemJob(local, seed=shard.stream_seed, width=1280, height=720, cell=15)
-    else:
-        sysjob = SystemJob(local, seed=shard.stream_seed)
-    job = FrameJob(local, seed=shard.stream_seed)
+    is720 = args.config == "720p-streams"
+    Wc, Hc, cellc = (1280, 720, 15) if is720 else (W, H, SYSTEM_CELL)
+    sysjob = SystemJob(local, seed=shard.stream_seed, width=Wc, height=Hc, cell=cellc)
+    job = None if is720 else FrameJob(local, seed=shard.stream_seed)
 
     def timed(fn, warmup, steps):
         """W untimed + exactly K timed steps, barrier + device sync on both sides, MAX over ranks"""
@@ -697,45 +872,86 @@ def main():
         torch.cuda.synchronize()
         return el
 
-    # ---- headline: the System surface, frames resident in HBM.  Warm-up must cover the two-view initialisation (frame 18 of this
-    # stream) so that the timed region is tracking + keyframes in their natural proportion; a shorter --warmup is topped up untimed.
-    extra = 0
-    while sysjob.status_hist[1] == 0 and extra < 60:
-        sysjob.step()
-        extra += 1
+    # ---- headline: the System surface, frames resident in HBM, STEADY STATE.  The untimed top-up runs the session until the 30-keyframe
+    # window is full (keyframe 34; ~600 frames) and on to the middle of a keyframe period, so the K timed steps hold round(K / period)
+    # keyframes -- a keyframe costs several tracking frames, and a window right after initialisation (2-3 keyframes in the map, cheap
+    # keyframes) overstated the rate a session sustains by 1.5x (round 2's verdict).  --warmup W steps run on top, as the contract says.
+    extra, period = sysjob.warm_to_steady_state(then_untimed=args.warmup)
+    kf_before = int(sysjob.ar.state()[11])
     dt = timed(sysjob.step, args.warmup, args.steps)
+    kf_in_window = int(sysjob.ar.state()[11]) - kf_before
     hist_timed = list(sysjob.status_hist)
-    # the same loop for at least 0.5 s (a K-step region can be a few tens of milliseconds long)
+    # the same loop for at least 0.5 s
     long_steps = max(args.steps, int(0.6 * args.steps / max(dt, 1e-9)) + 1)
+    kf_before = int(sysjob.ar.state()[11])
     dt_long = timed(sysjob.step, 0, long_steps)
+    kf_long = int(sysjob.ar.state()[11]) - kf_before
     ar = sysjob.ar
     ar.timing()
     ar.timing_keyframe()
+    ar.klt_work()
     kf0 = int(ar.state()[11])
-    n_sec = 200
+    n_sec = 400
     for _ in range(n_sec):
         sysjob.step()
     sections, kf_detail, n_kf_sec = ar.timing(), ar.timing_keyframe(), int(ar.state()[11]) - kf0
     sys_state = ar.state()
     sys_counters = ar.counters()
-    # PCIe-fed variant: host RGBA in, through the caller-owned buffer
-    dt_host = timed(sysjob.step_host, 5, args.steps)
-    # ---- round 1's headline as a secondary line (fixed correspondences, three HIP streams)
-    headline = job.step_native
-    dt_drv = timed(headline, min(args.warmup, 10), args.steps)
-    dt_nola = timed(lambda: job.step_native(lookahead=False), 3, args.steps)
-    dt_serial = timed(job.step, 3, args.steps)
+    # PCIe-fed variant: host RGBA in through AlvaAR.findCameraPose (memImg.write + the registered buffer read in place), same length
+    dt_host = timed(sysjob.step_host, 5, long_steps)
+    ar.timing()
+    for _ in range(100):
+        sysjob.step_host()
+    sections_host = ar.timing()
+    t0 = time.perf_counter()
+    for i in range(50):
+        np.copyto(ar.mem_img, sysjob.host_frames[i])
+    copy_us = (time.perf_counter() - t0) / 50 * 1e6
+    # ---- the optional shared-map merge on the process group's backend (RCCL): pack -> ONE all_gather_into_tensor -> fuse on the GPU
+    merge = None
+    try:
+        import alvaar_amd
+        mctx = alvaar_amd.Context(local)
+        rounds = []
+        for _ in range(3):
+            for _ in range(int(max(period, 8) * args.merge_every)):
+                sysjob.step()
+            if dist:
+                td.barrier()
+            rounds.append(multi.map_merge_round(ar, mctx, shard))
+        last = rounds[-1]
+        merge = {"every_keyframes": args.merge_every, "backend": last["backend"], "world": world, "records_this_rank": last["records_this_rank"],
+                 "records_gathered": last["records_gathered"], "fused": last["fused"], "bytes_gathered_per_rank": last["bytes_gathered"],
+                 "pack_us": round(min(r["pack_us"] for r in rounds), 1), "all_gather_us": round(min(r["all_gather_us"] for r in rounds), 1),
+                 "fuse_us": round(min(r["fuse_us"] for r in rounds), 1),
+                 "note": "north_star's optional shared-map merge: this rank's 3-D map points (id, xyz, descriptor medoid; 64 B records) -> one "
+                         "all_gather_into_tensor on the process group (RCCL over xGMI when N > 1; one rank fuses nothing: the rule only fuses "
+                         "across streams) -> alva_fuse_map_points; NOT part of `value` (the data path has no collective); pack_us is host-side "
+                         "(debug export of the map + numpy packing)"}
+    except Exception as e:
+        merge = {"error": repr(e), "process_group_error": dist_err}
+    dt_drv = dt_nola = dt_serial = None
+    if job is not None:
+        # ---- round 1's headline as a secondary line (fixed correspondences, three HIP streams)
+        dt_drv = timed(job.step_native, min(args.warmup, 10), args.steps)
+        dt_nola = timed(lambda: job.step_native(lookahead=False), 3, args.steps)
+        dt_serial = timed(job.step, 3, args.steps)
     if rank == 0:
+        import alvaar_amd
+        from alvaar_amd import capi
         fps = world * args.steps / dt
-        stage_us = job.stage_times()
-        ba, ba_pb = bench_ba(job.ctx)
-        peaks = measured_peaks(job.ctx)
-        P = W * H
+        bctx = job.ctx if job is not None else alvaar_amd.Context(local)
+        stage_us = job.stage_times() if job is not None else None
+        ba, ba_pb = bench_ba(bctx)
+        peaks = measured_peaks(bctx)
+        lat_dep, lat_rt = launch_latency(bctx)
+        P = Wc * Hc
         # ---- roofline: per-KERNEL durations from HIP events recorded on each launch stream, over a further pass of the headline loop
         # (the events cost a few us per launch, so they stay out of the pass that gives `value`)
-        from alvaar_amd import capi
-        PROF_STEPS = min(max(args.steps, 40), 100)
+        PROF_STEPS = 200
+        ar.klt_work()
         kt = capi.kernel_times(sysjob.step, PROF_STEPS)
+        klt_levels, klt_slots = ar.klt_work()
         nkp = int(sys_state[2])
         n3d = int(sys_state[4])
         # ALGORITHMIC bytes per launch (SURVEY.md §8d per-unit figures x the units one launch processes)
@@ -751,65 +967,106 @@ def main():
         per_frame = {k: v[0] / PROF_STEPS * v[1] for k, v in kt.items()}
         kernels = {k: {"launches_per_frame": round(v[0] / PROF_STEPS, 3), "avg_us": round(v[1], 2),
                        **({"alg_bytes": int(alg[k]), "GBps": round(alg[k] / (v[1] * 1e-6) / 1e9, 1)} if k in alg else {})}
-                   for k, v in sorted(kt.items(), key=lambda kv: -per_frame[kv[0]])[:24]}
+                   for k, v in sorted(kt.items(), key=lambda kv: -per_frame[kv[0]])[:28]}
         dom = max(per_frame, key=per_frame.get)
         hbm_dom = max((k for k in per_frame if k in alg), key=per_frame.get)
         achieved = alg[hbm_dom] / (kt[hbm_dom][1] * 1e-6) / 1e9
-        traffic = None
-        for tfile in (ROOT / "profiles" / "r2_pmc_traffic_system.json", ROOT / "profiles" / "pmc_traffic.json"):
-            if traffic is None and tfile.exists():
-                tj = json.loads(tfile.read_text()).get("kernels", {})
-                if hbm_dom in tj:
-                    traffic = tj[hbm_dom].get("hbm_bytes_per_launch")
+        traffic, l2_hit, pmc_stamp = pmc_reference(hbm_dom, ["alvaar_amd/csrc/klt.hip", "alvaar_amd/csrc/stages_hip.hip", "alvaar_amd/csrc/track_slots.hpp"])
+        klt_us_total = kt["k_track_klt"][0] * kt["k_track_klt"][1] if "k_track_klt" in kt else None
+        # ---- SURVEY.md 8(d), last table row: the three end-to-end bounds of one frame next to the achieved number
+        chain = ["k_level0<true>", "k_pyr_stage", "k_track_stage_in", "k_track_klt", "k_track_compact", "k_p3p", "k_pnp"]
+        chain_launches = sum(round(kt[k][0] / PROF_STEPS) for k in chain if k in kt)
+        chain_kernel_us = sum(per_frame.get(k, 0.0) for k in chain)
+        launches_per_frame = sum(v[0] for v in kt.values()) / PROF_STEPS
+        bounds = {
+            "hbm_frames_per_s": HBM_PEAK_GBS * 1e9 / (18.3 * P),
+            "pcie_gen5_host_fed_frames_per_s": 63e9 / (4 * P),
+            "launch_latency_frames_per_s": 1e6 / (chain_launches * lat_dep + 2 * lat_rt),
+            "dependent_kernel_chain_frames_per_s": 1e6 / max(chain_kernel_us, 1e-9),
+            "achieved_frames_per_s": fps / world, "achieved_sustained_frames_per_s": long_steps / dt_long,
+            "inputs": {"irreducible_hbm_bytes_per_frame": int(18.3 * P), "rgba_bytes_per_frame": 4 * P, "pcie_GBps": 63.0,
+                       "us_per_dependent_empty_launch": round(lat_dep, 2), "us_launch_plus_sync_round_trip": round(lat_rt, 2),
+                       "launches_on_the_tracking_chain": chain_launches, "host_waits_per_tracking_frame": 2,
+                       "launches_per_frame_all": round(launches_per_frame, 2), "tracking_chain_kernel_us": round(chain_kernel_us, 1)},
+            "note": "SURVEY.md 8(d): HBM roof = 8 TB/s over the irreducible 18.3 P bytes of a frame; PCIe Gen5 x16 upload of the RGBA frame for a "
+                    "host-fed stream; launch latency = the tracking frame's dependent launches (gray, 4 pyramid stages, stage-in, fb-KLT, "
+                    "compaction, P3P, PnP) at the measured empty-launch rate + its two host waits at the measured launch+sync round trip "
+                    "(alva_microbench_launch); dependent_kernel_chain = the same chain's measured kernel durations with zero gaps -- the bound "
+                    "this single stream actually runs against"}
         us = lambda d, n: {a: round(1e6 * b / max(n, 1), 1) for a, b in d.items()}
+        full = not args.quick and world == 1
         out = {
             "metric": "frames/sec @640x480 2000kp; local-BA residuals/sec (20KFx3k pts)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 image stages, f32 KLT, f64 pose+BA", "data": "synthetic",
-            "config": {"workload": ("configs[4]: 1280x720 RGBA stream per GPU, ~4000 keypoints per frame (cell 15), " if args.config == "720p-streams" else
+            "config": {"workload": ("configs[4]: 1280x720 RGBA stream per GPU, ~4000 keypoints per frame (cell 15), " if is720 else
                                     "configs[1]: 640x480 RGBA stream, ~2000 keypoints per frame (cell 12), ") + "the reference's System::findCameraPose dataflow "
                                    "(two-pass fb-KLT from motion-model priors -> P3P-LMedS -> PnP on the tracker's survivors; keyframes: grid detector + ORB "
-                                   "description, triangulation, guided Hamming matching to the local map, local BA) through alva_system_find_camera_pose_device",
+                                   "description, triangulation, guided Hamming matching to the local map, local BA) through alva_system_find_camera_pose_device, "
+                                   "STEADY STATE (30-keyframe window full)",
                        "frames_resident_in_hbm": True, "stream": f"{STREAM_FRAMES} frames, (2, 1) px per frame, forwards / backwards",
                        "keypoints_per_frame": nkp, "keypoints_3d": n3d, "keyframes_in_map": int(sys_state[6]), "map_points": int(sys_state[7]),
+                       "keyframes_created_so_far": int(sys_state[11]),
                        "status_histogram_reset_init_tracked": {"1_tracked": hist_timed[1], "2_reset": hist_timed[2], "3_initialising": hist_timed[3]},
-                       "untimed_frames_before_warmup": extra,
+                       "untimed_frames_to_steady_state": extra, "keyframe_period_frames": period,
+                       "keyframes_in_timed_window": kf_in_window, "natural_keyframes_per_window": (args.steps / period) if period else None,
                        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
-                       "parallelism": f"{world} independent camera streams, one per GPU, no collective"},
-            "sustained": {"frames_per_s": world * long_steps / dt_long, "steps": long_steps, "seconds": dt_long,
+                       "parallelism": f"{world} independent camera streams, one per GPU, no collective on the data path"},
+            "value_window": {"frames_per_s": fps, "steps": args.steps, "seconds": dt, "keyframes": kf_in_window},
+            "sustained": {"frames_per_s": world * long_steps / dt_long, "steps": long_steps, "seconds": dt_long, "keyframes": kf_long,
+                          "value_over_sustained": fps / (world * long_steps / dt_long),
                           "note": "the same timed loop continued for at least 0.5 s"},
-            "system_surface": {"frames_per_s": world * args.steps / dt_host, "ms_per_step": dt_host / args.steps * 1e3,
-                               "note": "the same loop fed from HOST memory: frame copied into the caller-owned buffer (src/system.js:175), 1.2 MB over PCIe per "
-                                       "frame from that buffer (page-locked by the library on its second use), pose out"},
+            "system_surface": {"frames_per_s": world * long_steps / dt_host, "ms_per_step": dt_host / long_steps * 1e3, "steps": long_steps,
+                               "caller_copy_us": round(copy_us, 1),
+                               "per_frame_us_host_fed": us(sections_host, 100),
+                               "note": "the same loop fed from HOST memory exactly as src/system.js does: memImg.write(frame) = one 1.2 MB copy into the wrapper's "
+                                       "ONE frame buffer (caller_copy_us, numpy), which is registered (alva_system_register_frame_buffer) and read in place over "
+                                       "PCIe by the gray / pyramid kernel -- no staging copy, no copy command; 'upload+pyramid' in per_frame_us_host_fed is the "
+                                       "enqueue, the PCIe read itself overlaps the slot gathering"},
+            "bounds": bounds,
             "frame_sections_us": {"per_frame": us(sections, n_sec), "frames": n_sec, "keyframes": n_kf_sec,
-                                  "per_keyframe_detail": us(kf_detail, n_kf_sec), "local_ba_solves_total": sys_counters["ba_solves"],
+                                  "per_keyframe_detail": us(kf_detail, n_kf_sec),
+                                  "ms_per_keyframe": round(1e3 * (sections["keyframe_create"] + sections["mapping"]) / max(n_kf_sec, 1), 3),
+                                  "local_ba_solves_total": sys_counters["ba_solves"],
                                   "note": "host wall-clock per section of the frame loop (alva_system_debug_timing); keyframe sections averaged over ALL frames in per_frame"},
-            "stage_list_driver": {"frames_per_s": world * args.steps / dt_drv, "ms_per_step": dt_drv / args.steps * 1e3,
-                                  "no_lookahead_frames_per_s": world * args.steps / dt_nola, "one_hip_stream_frames_per_s": world * args.steps / dt_serial,
-                                  "note": "round 1's headline: the configs[1] stage list (gray, pyramid, fb-KLT 3 levels, cv::ORB detectAndCompute 2000, BF Hamming, "
-                                          "P3P -> PnP) through alva_frontend_track_ahead on three HIP streams with FIXED pose correspondences; an upper bound of "
-                                          "stage throughput, not the reference's dataflow"},
+            "klt": {"keypoint_levels_per_s": (klt_levels / (klt_us_total * 1e-6)) if klt_us_total else None,
+                    "keypoint_levels_per_frame": klt_levels / PROF_STEPS, "slots_per_frame": klt_slots / PROF_STEPS,
+                    "kernel_us": kt.get("k_track_klt", (0, None))[1], "l2_hit_rate": l2_hit, "pmc": pmc_stamp,
+                    "note": "SURVEY.md 8(d) fb-KLT row: the tracker is an L2-gather / dependent-iteration-latency kernel, so its figures are "
+                            "keypoint-levels per second of kernel time (LK passes over one pyramid level: forward levels + the backward pass, "
+                            "counted from the per-slot result codes) and the L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS), PMC pass under profiles/)"},
+            "map_merge": merge,
             "local_ba": ba,
-            "roofline_ba": roofline_ba(job.ctx, ba_pb, peaks),
-            "local_ba_batch": bench_ba_batch(job.ctx, ba_pb, peaks) if world == 1 else None,
+            "roofline_ba": roofline_ba(bctx, ba_pb, peaks),
             "measured_peaks": {"mfma_f64_TFLOPs": peaks[0], "valu_int32_Tops": peaks[1],
                                "note": "alva_microbench_peaks: independent v_mfma_f64_16x16x4_f64 chains / xor-popcount-add chains on every SIMD"},
-            "two_view_init": bench_two_view_init(job.ctx) if world == 1 else None,
-            "batched_preprocess": bench_batched_preprocess(local) if world == 1 else None,
-            "track_mono_batch": [bench_track_mono_batch(local, c_) for c_ in (16, 64)] if world == 1 else None,
-            "frame_step_batch": [bench_track_mono_batch(local, c_, detector=True) for c_ in (16, 64)] if world == 1 else None,
-            "config_1280x720": bench_720p(local, valu_peak_tops=peaks[1]) if world == 1 else None,
-            "stage_us": stage_us,
-            "roofline": {"bound": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "latency", "roofline_axis": "hbm", "kernel": hbm_dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stamp": pmc_stamp,
                          "avg_us": kt[hbm_dom][1], "alg_bytes_per_launch": int(alg[hbm_dom]),
                          "largest_kernel_by_time": dom,
-                         "note": "avg_us = HIP events around every launch of that kernel, on its launch stream, over a further pass of the "
-                                 "headline loop; every kernel here is latency-bound at ONE 640x480 frame (1.2 MB): the frame moves through HBM "
-                                 "in well under a microsecond, see DESIGN.md §3; rocprofv3 summary in profiles/"},
+                         "note": "the contract's roofline object for the dominant kernel: algorithmic bytes / HIP-event kernel time against the 8 TB/s HBM peak. "
+                                 "It is NOT what limits this kernel: traffic == algorithmic bytes (nothing re-read) and the frame is 1.2 MB; the "
+                                 "kernel runs as long as its slowest keypoint's dependent LK iterations (bound: latency) -- its own figures are under 'klt', "
+                                 "the frame's bounds under 'bounds'; rocprofv3 summary in profiles/"},
             "kernels": kernels,
         }
+        if job is not None:
+            out["stage_list_driver"] = {"frames_per_s": world * args.steps / dt_drv, "ms_per_step": dt_drv / args.steps * 1e3,
+                                        "no_lookahead_frames_per_s": world * args.steps / dt_nola, "one_hip_stream_frames_per_s": world * args.steps / dt_serial,
+                                        "note": "round 1's headline: the configs[1] stage list (gray, pyramid, fb-KLT 3 levels, cv::ORB detectAndCompute 2000, BF Hamming, "
+                                                "P3P -> PnP) through alva_frontend_track_ahead on three HIP streams with FIXED pose correspondences; an upper bound of "
+                                                "stage throughput, not the reference's dataflow"}
+            out["stage_us"] = stage_us
+        if full:
+            if not is720:
+                out["system_720p"] = run_system_line(local, shard.stream_seed, 1280, 720, 15, args.steps)   # configs[4]'s geometry, default-on
+            out["local_ba_batch"] = bench_ba_batch(bctx, ba_pb, peaks)
+            out["two_view_init"] = bench_two_view_init(bctx)
+            out["batched_preprocess"] = bench_batched_preprocess(local)
+            out["track_mono_batch"] = [bench_track_mono_batch(local, c_) for c_ in (16, 64)]
+            out["frame_step_batch"] = [bench_track_mono_batch(local, c_, detector=True) for c_ in (16, 64)]
+            out["config_1280x720"] = bench_720p(local, valu_peak_tops=peaks[1])
         if args.streams_per_gpu > 1:
             out["multi_stream"] = [bench_multi_stream(local, args.streams_per_gpu, max(20, args.steps // 2))]
         elif world == 1 and args.multi_stream:

@@ -463,6 +463,9 @@ int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, double *const
 /* ---- measured ceilings for the roofline lines of bench.py (MI355X_MICROARCH.md lists neither): the FP64 matrix rate of
  * v_mfma_f64_16x16x4_f64 in TFLOP/s and the plain integer VALU rate (xor / popcount-accumulate / add) in 1e12 lane-operations/s. */
 int alva_microbench_peaks(alva_ctx *ctx, double *h_tflops_mfma_f64, double *h_tops_valu_int);
+/* Launch latency for the end-to-end bound of a frame (bench.py "bounds"): microseconds per kernel of `chain` dependent empty
+ * launches on the context's stream, and the round trip of one empty launch + stream synchronisation.  Synchronous. */
+int alva_microbench_launch(alva_ctx *ctx, int chain, double *h_us_per_dependent_launch, double *h_us_launch_sync_roundtrip);
 
 /* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
  * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist

@@ -44,10 +44,17 @@ int alva_system_configure(alva_system *sys, int width, int height, double fx, do
 int alva_system_configure_ex(alva_system *sys, int width, int height, double fx, double fy, double cx, double cy, double k1,
                              double k2, double p1, double p2, int cell_size, int clahe_enabled, int random_sampling);
 void alva_system_reset(alva_system *sys);
-/* System::findCameraPose (system.cpp:106-121).  h_rgba: width*height*4 bytes, caller-owned; h_pose: float[16].  A caller that passes
- * the SAME buffer on consecutive frames (as src/system.js does with its memImg, :63-67, :175) gets it page-locked (hipHostRegister) from its
- * second use on, so that the GPU's DMA engine reads it in place; it is released with the system (ALVA_NO_HOST_REGISTER=1 disables this). */
+/* System::findCameraPose (system.cpp:106-121).  h_rgba: width*height*4 bytes, caller-owned, read-only to the callee and not retained
+ * beyond the call; h_pose: float[16].  By default the frame is copied through a pinned staging buffer. */
 int alva_system_find_camera_pose(alva_system *sys, const uint8_t *h_rgba, float *h_pose);
+/* Optional, for a caller that reuses ONE frame buffer the way src/system.js reuses its memImg (:63-67, :175): page-lock and map
+ * `bytes` (>= width*height*4, 16-byte aligned) at h_rgba.  Frames passed from inside the registered range are then read in place
+ * over PCIe by the gray / pyramid kernel (no staging copy, no copy command); every find_camera_pose* call still returns only after the
+ * GPU has finished reading the buffer.  The registration is the caller's promise that the memory stays allocated until
+ * alva_system_unregister_frame_buffer / alva_system_configure / alva_system_destroy; one buffer per system (a second call replaces
+ * the first).  Must be called after alva_system_configure. */
+int alva_system_register_frame_buffer(alva_system *sys, const uint8_t *h_rgba, size_t bytes);
+int alva_system_unregister_frame_buffer(alva_system *sys);
 /* The same with the frame's timestamp (milliseconds) as an argument instead of the system clock (system.cpp:114): the
  * constant-velocity motion model (visual_frontend.hpp:11-68) is the only consumer. */
 int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, double timestamp_ms, float *h_pose);
@@ -78,6 +85,9 @@ int alva_system_debug_keyframe(alva_system *sys, int kfid, double *pose7, int *i
 int alva_system_debug_covisibility(alva_system *sys, int kfid, int cap, int *pairs);
 int alva_system_debug_map_points(alva_system *sys, int cap, int *ids, double *xyz, int *flags5, double *inv_depth, uint8_t *desc);
 int alva_system_debug_counters(alva_system *sys, long *out3 /* local-BA solves, map-point merges, culled keyframes */);
+/* fb-KLT work since the last reset: out2[0] = keypoint-levels (LK passes over one pyramid level, forwards + the backward pass, from
+ * the per-slot result codes), out2[1] = slots handed to the tracking steps */
+int alva_system_debug_klt_work(alva_system *sys, long *out2, int reset);
 /* wall-clock seconds per section of the frame loop since the last reset: upload + pyramid enqueue, slot gathering, tracking step,
  * tracker bookkeeping, wait for the pose, pose bookkeeping + keyframe decision, keyframe creation, mapping (incl. local BA) */
 int alva_system_debug_timing(alva_system *sys, double *out8, int reset);

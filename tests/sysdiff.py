@@ -181,3 +181,36 @@ def compare_keyframes(a, b, pose_tol, what=""):
 def pose_diff(pa, pb):
     q = pb[3:] if np.dot(pa[3:], pb[3:]) >= 0 else -pb[3:]
     return max(np.abs(pa[:3] - pb[:3]).max(), np.abs(pa[3:] - q).max())
+
+
+def _quat_to_rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def sim3_aligned_diff(ref_poses7, got_poses7):
+    """Two trajectories of the same camera in two maps whose gauges (scale, world frame) may differ: align `got` to `ref` with the
+    similarity transform that best maps its camera centres (Umeyama 1991, closed form), then report
+      (scale, worst |centre difference| / trajectory extent, worst rotation difference in radians)
+    of the aligned trajectory.  pose7 = (t, q_xyzw) of Twc."""
+    A = np.array([p[:3] for p in got_poses7], np.float64)
+    B = np.array([p[:3] for p in ref_poses7], np.float64)
+    ma, mb = A.mean(0), B.mean(0)
+    Ac, Bc = A - ma, B - mb
+    U, S, Vt = np.linalg.svd(Bc.T @ Ac / len(A))
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt
+    var = (Ac ** 2).sum() / len(A)
+    c = float(np.trace(np.diag(S) @ D) / var) if var > 0 else 1.0
+    t = mb - c * R @ ma
+    extent = float(np.linalg.norm(Bc, axis=1).max()) or 1.0
+    dpos = float(np.linalg.norm((c * (R @ A.T).T + t) - B, axis=1).max()) / extent
+    drot = 0.0
+    for pr, pg in zip(ref_poses7, got_poses7):
+        Rr, Rg = _quat_to_rot(pr[3:]), R @ _quat_to_rot(pg[3:])
+        drot = max(drot, float(np.arccos(np.clip((np.trace(Rr.T @ Rg) - 1) / 2, -1, 1))))
+    return c, dpos, drot

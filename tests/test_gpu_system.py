@@ -21,6 +21,9 @@ from alvaar_amd import synth
 import sysdiff
 
 pytestmark = [pytest.mark.gpu, pytest.mark.ref]
+# the unhooked run after Sim(3) alignment (measured on MI355X): what is left is NOT gauge -- the two-view pose's
+# rotation / translation-direction trade-off on a near-planar scene is a real (if tiny) difference of the reconstruction
+ALIGNED_TOL = 5e-3
 
 
 def _reference_run(frames, w, h, cell, reset_at=(), **kw):
@@ -32,13 +35,14 @@ def _reference_run(frames, w, h, cell, reset_at=(), **kw):
         st, p7, p16 = ref.step(rgba, 33.0 * k)
         if init_pose is None and st == 1:
             init_pose = p7.copy()
-        out.append(dict(status=st, pose7=p7.copy(), pose16=p16.copy(), state=ref.state().copy(), kps=ref.frame_keypoints(), kfs=ref.keyframe_ids().copy(),
-                        mps=ref.map_points()))
+        out.append(dict(status=st, pose7=p7.copy(), pose16=p16.copy(), state=ref.state().copy(), kps=tuple(a.copy() for a in ref.frame_keypoints()),
+                        kfs=ref.keyframe_ids().copy(), mps=tuple(a.copy() for a in ref.map_points())))   # copies: the slices would pin the capacity-sized arrays
     return ref, out, init_pose
 
 
-def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, reset_at=(), **kw):
+def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, reset_at=(), aligned_tol=None, min_kf_created=0, **kw):
     frames = list(frames)
+    traj_ref, traj_gpu = [], []
     ref, rec, init_pose = _reference_run(frames, w, h, cell, reset_at=reset_at, **kw)
     gpu = sysdiff.GpuSystem(w, h, cell, **kw)
     try:
@@ -66,6 +70,8 @@ def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1
             if len(mi):
                 worst_x = max(worst_x, float(np.abs(mx - rx).max()))
             if st == 1:
+                traj_ref.append(r["pose7"].copy())
+                traj_gpu.append(p7.copy())
                 d = sysdiff.pose_diff(r["pose7"], p7)
                 worst_pose = max(worst_pose, d)
                 q = p7[3:] if np.dot(p7[3:], r["pose7"][3:]) >= 0 else -p7[3:]
@@ -76,10 +82,15 @@ def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1
         kf_worst = sysdiff.compare_keyframes(ref, gpu, 10 * pose_tol, what="end of stream")
         c = gpu.counters()
         assert len(ref.keyframe_ids()) >= min_kf and c["ba_solves"] >= min_ba, (len(ref.keyframe_ids()), c)
+        assert int(gpu.state()[11]) >= min_kf_created, f"only {int(gpu.state()[11])} keyframes were created"
         assert worst_px <= px_tol, worst_px
         assert rmse <= pose_tol, f"pose RMSE {rmse} (worst {worst_pose})"
         assert worst_x <= max(10 * pose_tol, 1e-5), worst_x
         init_gpu = gpu.pose7()[1]
+        if aligned_tol is not None:
+            scale, dpos, drot = sysdiff.sim3_aligned_diff(traj_ref, traj_gpu)
+            print(f"\n  after Sim(3) alignment of the trajectory: scale {scale:.8f}, centres {dpos:.2e} of the extent, rotations {drot:.2e} rad")
+            assert dpos <= aligned_tol and drot <= aligned_tol, (scale, dpos, drot)
         print(f"\n  frames {len(frames)}  keyframes {len(ref.keyframe_ids())}  BA solves {c['ba_solves']}  merges {c['merges']}  "
               f"pose RMSE {rmse:.2e} (worst {worst_pose:.2e})  keyframe poses {kf_worst:.2e}  map points {worst_x:.2e}  pixels {worst_px:.2e}  "
               f"own two-view pose vs reference {sysdiff.pose_diff(init_pose, init_gpu):.2e}")
@@ -99,11 +110,15 @@ def test_system_equals_reference_150_frames():
 
 
 def test_system_equals_reference_without_the_hook():
-    """the same stream with the map started from OUR OWN five-point result: same discrete trajectory, poses at the initialisation's noise floor"""
+    """the same stream with the map started from OUR OWN five-point result (no alva_system_debug_set_init_pose): identical DISCRETE
+    state on every one of 160 frames (statuses, counters, keypoint ids in container order, keyframes, map tables, medoids).  The two maps
+    start from two-view poses that differ at OpenGV's refinement noise floor, so the raw poses are compared at that
+    floor (2e-2) and, because part of that difference is the map's gauge (scale / world frame), again after a Sim(3) alignment of the
+    trajectories."""
     w, h = 640, 480
     canvas = synth.texture_canvas(w, h, 7)
-    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(100)]
-    _differential(frames, w, h, 40, False, 2e-2, 5, 3, px_tol=0.2)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(160)]
+    _differential(frames, w, h, 40, False, 2e-2, 8, 6, px_tol=0.2, aligned_tol=ALIGNED_TOL)
 
 
 def test_system_equals_reference_2000_keypoints():
@@ -114,21 +129,28 @@ def test_system_equals_reference_2000_keypoints():
     _differential(frames, w, h, 12, True, 1e-5, 3, 2)
 
 
-def _differential_long(*args, attempts=4, **kw):
+LONG_ATTEMPTS = []   # (test, attempts needed) of this session's long-stream differentials, printed by each of them
+
+
+def _differential_long(*args, attempts=2, name="", **kw):
     """A long stream against the reference, allowing for the REFERENCE's own run-to-run differences.  Two runs of the reference's System on
     the same frames in one process differ from each other from the first local BA on (pose 4e-14 ... 9e-14 at frame 37 of this stream:
     tools/ref_determinism_probe.py; Ceres keeps its parameter blocks ordered by ADDRESS, so reduction orders follow the heap layout), and
     the pipeline amplifies 1e-12 to a changed discrete decision within a few hundred frames.  Our path is
-    deterministic; a stream passes when it agrees frame by frame with SOME run of the reference.  Observed: about one reference run in five
-    of the 560-frame, 2500-keypoint stream takes another discrete path somewhere; none of the shorter streams ever did."""
+    deterministic; a stream passes when it agrees frame by frame with one of at most TWO runs of the reference (observed: about one
+    reference run in five of the 560-frame, 2500-keypoint stream takes another discrete path somewhere; none of the shorter streams ever
+    did) -- the attempts needed are recorded and printed, and the first decision that differed is printed with its frame."""
     last = None
-    for _ in range(attempts):
+    for a in range(1, attempts + 1):
         try:
-            return _differential(*args, **kw)
+            out = _differential(*args, **kw)
+            LONG_ATTEMPTS.append((name, a))
+            print(f"\n  long-stream differential '{name}': agreed with reference run {a} of at most {attempts}; this session so far: {LONG_ATTEMPTS}")
+            return out
         except AssertionError as e:
             last = e
-            print(f"\n  differs from this run of the reference ({str(e).splitlines()[0][:120]}); running the reference again")
-    raise last
+            print(f"\n  '{name}': differs from run {a} of the reference -- first difference: {str(e).splitlines()[0][:200]}")
+    raise AssertionError(f"'{name}' disagreed with {attempts} consecutive runs of the reference; last: {last}")
 
 
 def test_system_equals_reference_long_stream():
@@ -139,7 +161,7 @@ def test_system_equals_reference_long_stream():
     base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
     period = 2 * (n - 1)
     frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(660)]
-    _differential_long(frames, w, h, 40, True, 1e-5, 8, 30)
+    _differential_long(frames, w, h, 40, True, 1e-5, 8, 30, name="660 frames, cell 40")
 
 
 def test_system_equals_reference_long_stream_2000_keypoints():
@@ -150,7 +172,7 @@ def test_system_equals_reference_long_stream_2000_keypoints():
     base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
     period = 2 * (n - 1)
     frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(560)]
-    _differential_long(frames, w, h, 12, True, 1e-5, 8, 25)
+    _differential_long(frames, w, h, 12, True, 1e-5, 8, 25, name="560 frames, cell 12")
 
 
 def test_system_equals_reference_rotating_camera_with_noise():
@@ -350,6 +372,18 @@ def test_system_equals_reference_1280x720():
     canvas = synth.texture_canvas(w, h, 9)
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=3)) for k in range(60)]
     _differential(frames, w, h, 15, True, 1e-5, 3, 2)
+
+
+def test_system_equals_reference_1280x720_long_stream():
+    """configs[4]'s geometry over a LONG stream: 1280x720, cell 15 (~5500 keypoints), 440 frames forwards / backwards => more than 20
+    keyframes: the keyframe filter of Mapper::optimize (from keyframe 20 on, mapper.cpp:66-142), map-point culling and local BA over a
+    full covisibility window at the size configs[4] names (reference: visual_frontend.cpp:517-552, mapper.cpp:9-64)"""
+    w, h, n = 1280, 720, 150
+    canvas = synth.texture_canvas(w, h, 9)
+    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=3)) for k in range(n)]
+    period = 2 * (n - 1)
+    frames = (base[(k % period) if (k % period) < n else period - (k % period)] for k in range(440))
+    _differential_long(list(frames), w, h, 15, True, 1e-5, 8, 20, min_kf_created=21, name="440 frames, 1280x720, cell 15")
 
 
 def test_concurrent_sessions_equal_their_solo_runs():
