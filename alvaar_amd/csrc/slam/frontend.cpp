@@ -280,7 +280,7 @@ bool Slam::compute_pose() {
 }
 
 void Slam::reset_frame() {  // visual_frontend.cpp:700-714
-    const std::unordered_map<int, KeyPt> copy = cur->kps;
+    const KpTable copy = cur->kps;
     for (const auto &e: copy) remove_obs_from_cur(e.first);
     cur->kps.clear();
     cur->grid.clear();

@@ -65,53 +65,10 @@ std::vector<KeyPt> FrameRec::keypoints3d() const {  // :55-67
         if (e.second.is3d) v.push_back(e.second);
     return v;
 }
-const KeyPt *FrameRec::find(int id_) const {
-    auto it = kps.find(id_);
-    return it == kps.end() ? nullptr : &it->second;
-}
-
-void FrameRec::slim_build() {
-    slim.clear();
-    slim.active = true;
-    slim.buckets = kps.bucket_count();
-    const size_t n = kps.size();
-    slim.id.reserve(n); slim.next.reserve(n); slim.prev.reserve(n); slim.is3d.reserve(n);
-    int last = -1;
-    for (auto &e: kps) {
-        const int s = slim.alloc();
-        slim.id[(size_t) s] = e.first;
-        slim.is3d[(size_t) s] = e.second.is3d;
-        slim.prev[(size_t) s] = last;
-        slim.next[(size_t) s] = -1;
-        if (last >= 0) slim.next[(size_t) last] = s;
-        else slim.head = s;
-        last = s;
-        e.second.slim = s;
-    }
-}
-
-bool FrameRec::slim_matches() const {
-    int s = slim.head;
-    for (const auto &e: kps) {
-        if (s < 0 || slim.id[(size_t) s] != e.first || (slim.is3d[(size_t) s] != 0) != e.second.is3d || e.second.slim != s) return false;
-        s = slim.next[(size_t) s];
-    }
-    return s < 0;
-}
+const KeyPt *FrameRec::find(int id_) const { return kps.find_ptr(id_); }
 
 void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
-    if (kps.count(k.id)) return;
-    if (slim.active) {
-        // where libstdc++ will link the new node: in front of its bucket's first node, or at the list's front when the bucket is empty
-        const size_t b = kps.bucket(k.id);
-        auto first = kps.begin(b);
-        const int before = first != kps.end(b) ? first->second.slim : -1;
-        auto it = kps.emplace(k.id, k).first;
-        if (kps.bucket_count() != slim.buckets) slim_build();   // grew: rehashed, the whole order changed
-        else it->second.slim = slim.insert(k.id, k.is3d, before);
-    } else {
-        kps.emplace(k.id, k);
-    }
+    if (!kps.emplace(k)) return;
     grid_add(k);
     n_kps++;
     if (k.is3d) n_3d++;
@@ -119,32 +76,28 @@ void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
 }
 
 void FrameRec::update(int id_, const float *px, const float *unpx, const double *bv) {  // frame.cpp:160-174
-    auto it = kps.find(id_);
-    if (it == kps.end()) return;
-    KeyPt k = it->second;
-    k.px[0] = px[0]; k.px[1] = px[1];
-    k.unpx[0] = unpx[0]; k.unpx[1] = unpx[1];
-    k.bv[0] = bv[0]; k.bv[1] = bv[1]; k.bv[2] = bv[2];
-    const int a = cell_index(it->second.px), b = cell_index(k.px);  // updateKeypointInGrid (:296-311)
-    if (a != b) {
-        grid_remove(it->second);
-        grid_add(k);
-    }
-    it->second = k;
+    KeyPt *cur_kp = kps.find_ptr(id_);
+    if (!cur_kp) return;
+    const int a = cell_index(cur_kp->px), b = cell_index(px);  // updateKeypointInGrid (:296-311)
+    if (a != b) grid_remove(*cur_kp);
+    cur_kp->px[0] = px[0]; cur_kp->px[1] = px[1];
+    cur_kp->unpx[0] = unpx[0]; cur_kp->unpx[1] = unpx[1];
+    cur_kp->bv[0] = bv[0]; cur_kp->bv[1] = bv[1]; cur_kp->bv[2] = bv[2];
+    if (a != b) grid_add(*cur_kp);
 }
 
 void FrameRec::set_desc(int id_, const Desc &d) {  // :176-185
-    auto it = kps.find(id_);
-    if (it == kps.end()) return;
-    it->second.desc = d;
-    it->second.has_desc = true;
+    KeyPt *k = kps.find_ptr(id_);
+    if (!k) return;
+    k->desc = d;
+    k->has_desc = true;
 }
 
 bool FrameRec::change_id(int prev_id, int new_id, bool is3d) {  // :187-207
     if (kps.count(new_id)) return false;
-    auto it = kps.find(prev_id);
-    if (it == kps.end()) return false;
-    KeyPt k = it->second;
+    const KeyPt *old = kps.find_ptr(prev_id);
+    if (!old) return false;
+    KeyPt k = *old;
     k.id = new_id;
     k.is3d = is3d;
     remove(prev_id);
@@ -153,22 +106,20 @@ bool FrameRec::change_id(int prev_id, int new_id, bool is3d) {  // :187-207
 }
 
 void FrameRec::remove(int id_) {  // :209-232
-    auto it = kps.find(id_);
-    if (it == kps.end()) return;
-    grid_remove(it->second);
-    if (it->second.is3d) n_3d--;
+    const KeyPt *k = kps.find_ptr(id_);
+    if (!k) return;
+    grid_remove(*k);
+    if (k->is3d) n_3d--;
     else n_2d--;
     n_kps--;
-    if (slim.active) slim.erase(it->second.slim);
     kps.erase(id_);
 }
 
 void FrameRec::turn3d(int id_) {  // :234-248
-    auto it = kps.find(id_);
-    if (it == kps.end()) return;
-    if (!it->second.is3d) {
-        it->second.is3d = true;
-        if (slim.active) slim.is3d[(size_t) it->second.slim] = 1;
+    const KeyPt *k = kps.find_ptr(id_);
+    if (!k) return;
+    if (!k->is3d) {
+        kps.set_3d(id_);
         n_3d++;
         n_2d--;
     }
@@ -229,7 +180,6 @@ void FrameRec::reset() {  // :467-489
     kfid = 0;
     timestamp = 0.;
     kps.clear();
-    slim.clear();
     grid.clear();
     grid.resize(grid_cells);
     n_kps = n_2d = n_3d = 0;
@@ -253,20 +203,22 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
     if (kf == anchor_kf) anchor_kf = *obs_kfs.begin();
     float min_dist = (has_desc ? 32 : 0) * 8.f;  // desc_.cols * 8.
     int min_id = -1;
-    auto itd = kf_desc.find(kf);
-    if (itd != kf_desc.end()) {
-        for (auto &e: kf_desc) {
-            if (e.first != kf) {
-                const float dist = (float) popcount256(itd->second.d, e.second.d);
-                float &dd = e.second.dist;
+    const int sd = kf_desc.find_slot(kf);
+    if (sd != FlatHash<DescEntry>::END) {
+        const Desc mine = kf_desc.val(sd).d;
+        for (int se = kf_desc.first(); se != FlatHash<DescEntry>::END; se = kf_desc.next(se)) {
+            if (se != sd) {
+                DescEntry &e = kf_desc.val(se);
+                const float dist = (float) popcount256(mine, e.d);
+                float &dd = e.dist;
                 dd -= dist;
                 if (dd < min_dist) {
                     min_dist = dd;
-                    min_id = e.first;
+                    min_id = kf_desc.key(se);
                 }
             }
         }
-        kf_desc.erase(itd);
+        kf_desc.erase_slot(sd);
         drop_desc(kf);
         if (min_id > 0) {  // sic: keyframe 0 is never chosen (:123)
             desc = kf_desc.at(min_id).d;
@@ -276,8 +228,8 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
 }
 
 void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid)
-    if (kf_desc.find(kf) != kf_desc.end()) return;
-    DescEntry &mine = kf_desc.emplace(kf, DescEntry{d, 0.f}).first->second;
+    const std::pair<int, bool> ins = kf_desc.insert_slot(kf, DescEntry{d, 0.f});
+    if (!ins.second) return;
     note_desc(kf, d);
     if (kf_desc.size() == 1) {
         desc = d;
@@ -286,13 +238,14 @@ void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the des
     }
     float min_dist = (has_desc ? 32 : 0) * 8.f;
     int min_id = -1;
-    float &nd = mine.dist;
-    for (auto &e: kf_desc) {
-        const float dist = (float) popcount256(d, e.second.d);
-        e.second.dist += dist;   // includes the new entry itself (distance 0 to itself, :157-166)
+    float &nd = kf_desc.val(ins.first).dist;   // no insert below: the reference stays valid
+    for (int se = kf_desc.first(); se != FlatHash<DescEntry>::END; se = kf_desc.next(se)) {
+        DescEntry &e = kf_desc.val(se);
+        const float dist = (float) popcount256(d, e.d);
+        e.dist += dist;   // includes the new entry itself (distance 0 to itself, :157-166)
         if (dist < min_dist) {
             min_dist = dist;
-            min_id = e.first;
+            min_id = kf_desc.key(se);
         }
         nd += dist;
     }
@@ -384,10 +337,10 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     std::vector<int> &kp_ids = ids_scratch_;
     kp_ids.clear();
     std::vector<float> pts((size_t) n * 2);
-    std::vector<KeyPt *> nodes((size_t) n);   // the keypoints themselves (node addresses are stable; nothing is inserted or erased before they are used)
+    std::vector<KeyPt *> nodes((size_t) n);   // the keypoints themselves (nothing is inserted or erased before they are used)
     {
         size_t i = 0;
-        for (auto &e: cur->kps) {  // getKeypoints(): container order
+        for (auto e: cur->kps) {  // getKeypoints(): container order
             kp_ids.push_back(e.first);
             nodes[i] = &e.second;
             pts[2 * i] = e.second.px[0];
@@ -428,6 +381,8 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
             if (fail(st->describe(count, np.data(), desc.data(), valid.data()))) return;
             if (fail(st->compute_keypoints(count, np.data(), unpx.data(), bv.data()))) return;
             lap(t_kf[3]);
+            Lap fine;
+            t_fine[26] += (double) count;
             for (int i = 0; i < count; i++) {  // addKeypointsToFrame (:166-191)
                 KeyPt k;
                 k.id = next_mp_id;
@@ -444,14 +399,8 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
                     add_map_point(nullptr);
                 }
             }
+            fine(t_fine[13]);   // new keypoints + map points
         }
-    }
-}
-
-void Slam::check_slim(const FrameRec &kf) const {
-    if (check_obs_mirror_ && kf.slim.active && !kf.slim_matches()) {
-        std::fprintf(stderr, "alva_slam: keypoint order mirror of keyframe %d out of sync\n", kf.kfid);
-        std::abort();
     }
 }
 
@@ -470,12 +419,14 @@ const ObsPx *Slam::obs_of(const MapPt &mp, int kfid) const {
 }
 
 void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of the current frame
+    Lap fine;
     std::shared_ptr<FrameRec> kf = std::make_shared<FrameRec>(*cur);
-    kf->slim_build();
+    fine(t_fine[10]);   // frame copy
     for (const auto &e: kf->kps) {
         MapPt *m = mp_raw(e.first);
         if (m) m->note_px(next_kf_id, e.second);
     }
+    fine(t_fine[12]);   // observation mirror
     keyframes.emplace(next_kf_id, kf);
     if (kf_flat_.size() <= (size_t) next_kf_id) kf_flat_.resize((size_t) next_kf_id + 32, nullptr);
     kf_flat_[(size_t) next_kf_id] = kf.get();
@@ -484,7 +435,7 @@ void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of 
 }
 
 void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
-    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d, &desc_pool_) : std::make_shared<MapPt>(next_mp_id, next_kf_id, &desc_pool_);
+    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(next_mp_id, next_kf_id);
     map_points.emplace(next_mp_id, mp);
     if (mp_flat_.size() <= (size_t) next_mp_id) {
         mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
@@ -520,7 +471,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
     const SortedIds next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
-    const std::pmr::unordered_map<int, DescEntry> prev_desc = prev->kf_desc;   // a copy (default resource), in the original's order
+    const FlatHash<DescEntry> prev_desc = prev->kf_desc;   // a copy, in the original's order
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;
@@ -624,8 +575,9 @@ bool Slam::set_map_point_obs(int mp_id) {  // map_manager.cpp:681-708
 }
 
 void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-164
+    Lap fine;
     std::map<int, int> cov;
-    std::unordered_set<int> local_ids;
+    FlatSet local_ids;
     ids_scratch_.clear();  // snapshot: the repair branch below edits frame.kps
     for (const auto &e: frame.kps) ids_scratch_.push_back(e.first);
     // the counts of the reference's std::map<int, int> (:92-103) accumulated in a flat table (keyframe ids are small consecutive
@@ -649,6 +601,7 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
     }
     for (int kf = 0; kf <= next_kf_id; kf++)
         if (count[(size_t) kf]) cov[kf] += count[(size_t) kf];
+    fine(t_fine[14]);   // covisibility counts
     std::set<int> bad;
     // marks: a = observed by `frame`, b = already in local_ids (see slam.hpp)
     mark_a_.resize((size_t) next_mp_id + 1, 0);
@@ -663,7 +616,6 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
         FrameRec *kf = kf_raw(c.first);
         if (kf) {
             kf->covisible[frame.kfid] = c.second;
-            check_slim(*kf);
             kf->for_each_id([&](int kid, bool is3d) {  // getKeypoints3d(): container order, 3-D only
                 const size_t id = (size_t) kid;
                 if (is3d && !mark_a_[id] && !mark_b_[id]) {
@@ -680,8 +632,11 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
     for (int id: touched_b_) mark_b_[(size_t) id] = 0;
     for (int kf: bad) cov.erase(kf);
     frame.covisible.swap(cov);
+    fine(t_fine[15]);   // local ids of the covisible keyframes
+    t_fine[27] += (double) local_ids.size(); t_fine[28] += (double) frame.covisible.size();
     if (local_ids.size() > 0.5 * frame.local_map.size()) frame.local_map.swap(local_ids);
     else frame.local_map.insert(local_ids.begin(), local_ids.end());
+    fine(t_fine[16]);   // swap / union into the frame's local map
 }
 
 }  // namespace alva_slam

@@ -29,6 +29,7 @@ void Slam::process_new_keyframe(int kfid) {  // mapper.cpp:9-64
     if (!kf) return;
     Lap lap;
     if (kfid > 30) remove_keyframe(kfid - 30);  // "just keep the last 30 keyframes"
+    lap(t_fine[9]);
     if (kf->kfid > 0 && kf->n_2d > 0) triangulate_temporal(*kf);
     if (err_) return;
     lap(t_kf[5]);
@@ -131,6 +132,7 @@ void Slam::triangulate_temporal(FrameRec &frame) {  // mapper.cpp:144-291
 }
 
 bool Slam::matching_to_local_map(FrameRec &frame) {  // mapper.cpp:293-352
+    Lap fine;
     const size_t max_local = (size_t) cfg.max_keypoints * 10;
     if (!frame.covisible.empty() && frame.local_map.size() < max_local) {
         int kfid = frame.covisible.begin()->first;
@@ -151,16 +153,20 @@ bool Slam::matching_to_local_map(FrameRec &frame) {  // mapper.cpp:293-352
             if (kf) frame.local_map.insert(kf->local_map.begin(), kf->local_map.end());
         }
     }
+    fine(t_fine[0]);   // local-map union
     const std::map<int, int> matches = match_to_map(frame, cfg.map_max_proj_px, cfg.map_max_desc_dist, frame.local_map);
+    fine(t_fine[1]);   // match_to_map (flatten + stage)
     if (err_ || matches.empty()) return false;
     for (const auto &m: matches) merge_map_points(m.first, m.second);
+    fine(t_fine[2]);   // merges
     return true;
 }
 
 // Mapper::matchToMap (mapper.cpp:354-588): flatten the part of the map the call can reach, run the stage, translate indices back
-std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, std::unordered_set<int> &local) {
+std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, FlatSet &local) {
     std::map<int, int> result;
     if (local.empty()) return result;
+    Lap fine;
     // keyframe table
     std::vector<int> kf_ids;
     for (const auto &e: keyframes) kf_ids.push_back(e.first);
@@ -211,6 +217,7 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
         }
     }
     cell_ptr[frame.grid.size()] = (int) cell_mp.size();
+    fine(t_fine[3]);   // keyframe table + grid cells
     std::vector<int> local_idx;
     mark_a_.resize((size_t) next_mp_id + 1, 0);
     touched_a_.clear();
@@ -225,6 +232,7 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
         local_idx.push_back(intern(id));
     }
     for (int id: touched_a_) mark_a_[(size_t) id] = 0;
+    fine(t_fine[4]);   // local list
     if (local_idx.empty()) return result;
     const int n_mp = (int) mp_ids.size();
     std::vector<double> mp_wpt((size_t) n_mp * 3);
@@ -264,6 +272,8 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
         }
     }
     obs_ptr[(size_t) n_mp] = (int) obs_kf.size();
+    fine(t_fine[5]);   // per-map-point flatten
+    t_fine[20] += (double) n_mp; t_fine[21] += (double) obs_kf.size(); t_fine[22] += (double) local_idx.size();
     std::vector<int> match_of_mp((size_t) n_mp, -1);
     Lap lap;
     const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) frame.grid.size(), cell_ptr.data(), cell_mp.data(),
@@ -289,24 +299,25 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
             FrameRec *co = kf_raw(kfid);
             if (!co) continue;  // the reference dereferences the null pointer here (:88-92); nothing to remove from
             if ((int) co->n_3d < cfg.ba_min_common_obs / 2) {
+                Lap rm;
                 remove_keyframe(kfid);
+                rm(t_fine[8]);
                 n_kf_culled++;
                 continue;
             }
             size_t good = 0, total = 0;
             ids_scratch_.clear();  // keypoints whose map point is gone: the reference repairs them while walking a COPY (:101-111); the
                                    // repair only drops that keypoint from this keyframe, so doing it after the walk is the same thing
-            check_slim(*co);
             bool counted = false;
-            if (co->slim.active && !check_obs_mirror_) {
+            if (!check_obs_mirror_) {
                 // Nothing in this loop depends on the ORDER of the walk: good / total are counts, isBad() acts on one map point, and the
-                // repairs drop different keypoints of this keyframe (erasing from a hash table or a cell list commutes).  So the mirror's
+                // repairs drop different keypoints of this keyframe (erasing from a hash table or a cell list commutes).  So the table's
                 // slots are taken in memory order, with the observer-count byte table in front of the map point.
-                const SlimOrder &so = co->slim;
-                const size_t ns = so.id.size();
+                const FlatHash<FlatNoValue> &so = co->kps.ids;
+                const size_t ns = so.slots();
                 for (size_t sl = 0; sl < ns; sl++) {
-                    const int kid = so.id[sl];
-                    if (kid < 0 || !so.is3d[sl]) continue;
+                    if (!so.slot_live(sl) || !so.tag((int) sl)) continue;
+                    const int kid = so.key((int) sl);
                     const unsigned nobs = mp_nobs_[(size_t) kid];
                     if (nobs >= 2) {  // two observers or more: isBad() is false and has no side effect (map_point.cpp:183-202)
                         good += nobs > 4;
@@ -351,7 +362,9 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
             for (int id: ids_scratch_) remove_map_point_obs(id, kfid);
             const float ratio = (float) good / (float) total;
             if (ratio > cfg.keyframe_filtering_ratio) {
+                Lap rm;
                 remove_keyframe(kfid);
+                rm(t_fine[8]);   // keyframe filter: removals
                 n_kf_culled++;
             }
         }
@@ -411,7 +424,6 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (score >= min_cov && !all_cst && kfid > 0) {
             add_pose(kfid, *kf, false);
             kfs_to_opt.insert(kfid);
-            check_slim(*kf);
             kf->for_each_id([&](int kid, bool is3d) {
                 if (is3d && !mark_a_[(size_t) kid]) {  // a repeated insert would not change the set
                     mark_a_[(size_t) kid] = 1;
@@ -428,6 +440,8 @@ void Slam::local_ba(FrameRec &new_frame) {
         kf_flat[(size_t) kfid] = kf.get();
     }
     for (int id: touched_a_) mark_a_[(size_t) id] = 0;
+    Lap fine;
+    t_fine[6] += std::chrono::duration<double>(fine.t0 - lap_ba.t0).count();   // BA build phase 1: keyframes + points to optimise
     struct ObsRec {
         int kfid, mpid;
     };
@@ -488,6 +502,8 @@ void Slam::local_ba(FrameRec &new_frame) {
             obs_rec.push_back(ObsRec{kfid, lmid});
         }
     }
+    fine(t_fine[7]);   // BA build phase 2: observations
+    t_fine[23] += (double) pt_ids.size(); t_fine[24] += (double) obs_rec.size(); t_fine[25] += (double) kf_const.size();
     // gauge: at least two constant keyframes (:234-247), taken in the container's order
     size_t n_const = const_kfs.size();
     if (n_const < 2) {

@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+#include "flat_hash.hpp"
 #include "se3.hpp"
 #include "stages.hpp"
 
@@ -34,66 +35,67 @@ struct KeyPt {
     Desc desc{};
     bool has_desc = false;
     bool is3d = false;
-    int slim = -1;   // slot in the owning frame's SlimOrder (keyframes only; see there)
 };
 
-// (id, is3d) of a KEYFRAME's keypoints in the iteration order of its mapKeypoints_, as flat arrays.  Three loops of every keyframe step
-// walk all keypoints of every covisible keyframe only to look at these two fields (updateFrameCovisibility map_manager.cpp:116-140, the
-// free-keyframe sweep of localBA optimizer.cpp:60-100, the keyframe filter mapper.cpp:94-128); walking 29 x 2600 hash nodes of 128
-// bytes each is most of their cost.  The order of a libstdc++ unordered_map with unique keys is its singly linked node list: an insert
-// puts the node at the FRONT of its bucket's run (immediately before the run's current first node) or, when the bucket is empty, at the
-// front of the whole list; an erase unlinks; a rehash (growth only) rebuilds.  A keyframe's table is a copy that never grows (the only
-// inserts are the id changes of mergeMapPoints: erase + insert), so the mirror is maintained with exactly that rule and rebuilt by a walk
-// if the bucket count ever changes.  ALVA_CHECK_OBS_MIRROR=1 compares it with the container at every use.
-struct SlimOrder {
-    std::vector<int> id, next, prev;
-    std::vector<uint8_t> is3d;
-    int head = -1, free_head = -1;
-    bool active = false;
-    size_t buckets = 0;
+// mapKeypoints_ (std::unordered_map<int, Keypoint>, frame.hpp:170): the ids in a FlatHash -- libstdc++'s iteration order on flat arrays,
+// flat_hash.hpp -- whose per-element tag is the keypoint's 3-D flag, and the keypoints themselves in a parallel array indexed by slot.
+// Three loops of every keyframe step walk ALL keypoints of every covisible keyframe only to look at (id, is3d)
+// (updateFrameCovisibility map_manager.cpp:116-140, the free-keyframe sweep of localBA optimizer.cpp:60-100, the keyframe filter
+// mapper.cpp:94-128): they read 12-byte slots; a keyframe (a COPY of the frame, map_manager.cpp:243-252) is three vector copies.
+// References to keypoints are invalidated by an insert (the reference's nodes are stable): no caller keeps one across an insert.
+class KpTable {
+public:
+    FlatHash<FlatNoValue> ids;   // key = keypoint id, tag = is3d
+    std::vector<KeyPt> kp;       // by slot
+
+    size_t size() const { return ids.size(); }
+    bool empty() const { return ids.empty(); }
+    size_t count(int id) const { return ids.count(id); }
+    size_t bucket_count() const { return ids.bucket_count(); }
     void clear() {
-        id.clear(); next.clear(); prev.clear(); is3d.clear();
-        head = free_head = -1;
-        active = false;
-        buckets = 0;
+        ids.clear();
+        kp.clear();
     }
-    int alloc() {
-        if (free_head >= 0) {
-            const int s = free_head;
-            free_head = next[(size_t) s];
-            return s;
+    KeyPt *find_ptr(int id) {
+        const int s = ids.find_slot(id);
+        return s == FlatHash<FlatNoValue>::END ? nullptr : &kp[(size_t) s];
+    }
+    const KeyPt *find_ptr(int id) const { return const_cast<KpTable *>(this)->find_ptr(id); }
+    bool emplace(const KeyPt &k) {
+        const std::pair<int, bool> r = ids.insert_slot(k.id, FlatNoValue(), k.is3d ? 1 : 0);
+        if (!r.second) return false;
+        if ((size_t) r.first >= kp.size()) kp.resize((size_t) r.first + 1);
+        kp[(size_t) r.first] = k;
+        return true;
+    }
+    void erase(int id) { ids.erase(id); }
+    void set_3d(int id) {
+        const int s = ids.find_slot(id);
+        if (s != FlatHash<FlatNoValue>::END) {
+            ids.set_tag(s, 1);
+            kp[(size_t) s].is3d = true;
         }
-        id.push_back(-1); next.push_back(-1); prev.push_back(-1); is3d.push_back(0);
-        return (int) id.size() - 1;
     }
-    // before < 0: at the front of the list; otherwise immediately before slot `before`
-    int insert(int key, bool three_d, int before) {
-        const int s = alloc();
-        id[(size_t) s] = key;
-        is3d[(size_t) s] = three_d;
-        if (before < 0 || before == head) {
-            next[(size_t) s] = head;
-            prev[(size_t) s] = -1;
-            if (head >= 0) prev[(size_t) head] = s;
-            head = s;
-        } else {
-            const int p = prev[(size_t) before];
-            next[(size_t) s] = before;
-            prev[(size_t) s] = p;
-            next[(size_t) p] = s;
-            prev[(size_t) before] = s;
+    // for (auto &e: table) e.first / e.second, in mapKeypoints_ order
+    template <class T, class K>
+    struct Iter {
+        T *t;
+        int s;
+        struct Ref {
+            int first;
+            K &second;
+        };
+        Ref operator*() const { return Ref{t->ids.key(s), t->kp[(size_t) s]}; }
+        Iter &operator++() {
+            s = t->ids.next(s);
+            return *this;
         }
-        return s;
-    }
-    void erase(int s) {
-        const int p = prev[(size_t) s], n = next[(size_t) s];
-        if (p >= 0) next[(size_t) p] = n;
-        else head = n;
-        if (n >= 0) prev[(size_t) n] = p;
-        id[(size_t) s] = -1;
-        next[(size_t) s] = free_head;
-        free_head = s;
-    }
+        bool operator!=(const Iter &o) const { return s != o.s; }
+    };
+    Iter<KpTable, KeyPt> begin() { return {this, ids.first()}; }
+    Iter<KpTable, KeyPt> end() { return {this, FlatHash<FlatNoValue>::END}; }
+    Iter<const KpTable, const KeyPt> begin() const { return {this, ids.first()}; }
+    Iter<const KpTable, const KeyPt> end() const { return {this, FlatHash<FlatNoValue>::END}; }
 };
 
 // tunables, state.hpp:29-78 with the overrides of System::configure (system.cpp:15-19)
@@ -148,13 +150,12 @@ struct CellIds {
 struct FrameRec {
     int id = -1, kfid = 0;
     double timestamp = 0;
-    std::unordered_map<int, KeyPt> kps;        // mapKeypoints_
-    SlimOrder slim;                            // mirror of (id, is3d) in kps' order; active for keyframes only
+    KpTable kps;                               // mapKeypoints_
     std::vector<CellIds> grid;                 // gridKeypointsIds_
     size_t grid_cells = 0, n_occupied = 0, cell = 0, cells_w = 0, cells_h = 0, n_kps = 0, n_2d = 0, n_3d = 0;
     SE3 Twc, Tcw;
     std::map<int, int> covisible;              // covisibleKeyframeIds_
-    std::unordered_set<int> local_map;         // localMapPointIds_
+    FlatSet local_map;                         // localMapPointIds_ (std::unordered_set<int>)
     const Camera *cam = nullptr;
 
     void init(const Camera *c, size_t cell_size);
@@ -168,16 +169,11 @@ struct FrameRec {
     bool change_id(int prev_id, int new_id, bool is3d);
     void remove(int id);
     void turn3d(int id);
-    void slim_build();                         // (re)build the mirror by one walk over kps
-    bool slim_matches() const;                 // the mirror equals the container, element by element (check mode)
-    // f(id, is3d) for every keypoint in mapKeypoints_ order -- through the mirror when there is one
+    // f(id, is3d) for every keypoint in mapKeypoints_ order (reads the 12-byte order slots only)
     template <class F>
     void for_each_id(F &&f) const {
-        if (slim.active) {
-            for (int sl = slim.head; sl >= 0; sl = slim.next[(size_t) sl]) f(slim.id[(size_t) sl], slim.is3d[(size_t) sl] != 0);
-        } else {
-            for (const auto &e: kps) f(e.first, e.second.is3d);
-        }
+        const FlatHash<FlatNoValue> &h = kps.ids;
+        for (int sl = h.first(); sl != FlatHash<FlatNoValue>::END; sl = h.next(sl)) f(h.key(sl), h.tag(sl) != 0);
     }
     bool observes(int id) const { return kps.count(id) != 0; }
     int cell_index(const float *px) const;
@@ -251,14 +247,13 @@ struct MapPt {
     Desc desc{};
     bool has_desc = false;                       // !desc_.empty()
     // mapKeyframeDescriptors_ and mapDescriptorsDist_ in one table: the reference edits the two unordered_maps together (same keys,
-    // same sequence => same iteration order), reads the distances by key only, and walks the descriptors -- this walk's order
-    // its nodes and bucket arrays come from a pool owned by the map (same container code, same order; one table per map point and one
-    // insert per tracked keypoint per keyframe make the allocator matter)
-    std::pmr::unordered_map<int, DescEntry> kf_desc;
+    // same sequence => same iteration order), reads the distances by key only, and walks the descriptors -- in libstdc++'s order, on
+    // flat arrays (flat_hash.hpp): the medoid loops of addDesc / removeObservedKeyframeId read contiguous 48-byte slots
+    FlatHash<DescEntry> kf_desc;
     std::vector<ObsPx> seen;                     // see ObsPx
 
-    MapPt(int id_, int kf, std::pmr::memory_resource *mr) : id(id_), anchor_kf(kf), kf_desc(mr) { obs_kfs.insert(kf); }
-    MapPt(int id_, int kf, const Desc &d, std::pmr::memory_resource *mr) : id(id_), anchor_kf(kf), kf_desc(mr) {
+    MapPt(int id_, int kf) : id(id_), anchor_kf(kf) { obs_kfs.insert(kf); }
+    MapPt(int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf) {
         obs_kfs.insert(kf);
         kf_desc.emplace(kf, DescEntry{d, 0.f});
         note_desc(kf, d);
@@ -337,8 +332,6 @@ public:
     Camera cam;
     Settings cfg;
     double invK[9];
-    // pool behind every map point's descriptor table; declared before the containers that hold map points: destroyed after them
-    std::pmr::unsynchronized_pool_resource desc_pool_;
     std::shared_ptr<FrameRec> cur;                                   // currFrame_
     std::unordered_map<int, std::shared_ptr<FrameRec>> keyframes;    // MapManager::mapKeyframes_
     std::unordered_map<int, std::shared_ptr<MapPt>> map_points;      // MapManager::mapMapPoints_
@@ -364,6 +357,8 @@ public:
     // finer split of the two keyframe sections: prepare, describe tracked, detect, describe + add new | triangulate, covisibility,
     // local-map matching (flatten, stage, merges), BA build, BA solves, BA write-back, keyframe culling
     double t_kf[16] = {0};
+    // finer laps for profiling (tools/system_sustained.py FINE=1): see the FINE_* indices in mapper.cpp / map.cpp
+    double t_fine[32] = {0};
 
 private:
     int err_ = 0;
@@ -440,7 +435,6 @@ private:
     std::vector<uint8_t> mp_nobs_;
     void sync_nobs(const MapPt &mp) { mp_nobs_[(size_t) mp.id] = (uint8_t) (mp.obs_kfs.size() > 255 ? 255 : mp.obs_kfs.size()); }
     bool check_obs_mirror_ = false;
-    void check_slim(const FrameRec &kf) const;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
     std::vector<std::shared_ptr<MapPt>> mp_graveyard_;
@@ -450,7 +444,7 @@ private:
     void process_new_keyframe(int kfid);
     void triangulate_temporal(FrameRec &frame);
     bool matching_to_local_map(FrameRec &frame);
-    std::map<int, int> match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, std::unordered_set<int> &local);
+    std::map<int, int> match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, FlatSet &local);
     void optimize(const std::shared_ptr<FrameRec> &kf);
     // Optimizer
     void local_ba(FrameRec &new_frame);

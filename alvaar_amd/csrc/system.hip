@@ -308,6 +308,12 @@ extern "C" int alva_system_debug_timing_keyframe(alva_system *s, double *out16, 
     if (reset) memset(s->slam->t_kf, 0, sizeof(s->slam->t_kf));
     return ALVA_OK;
 }
+extern "C" int alva_system_debug_timing_fine(alva_system *s, double *out32, int reset) {
+    if (!s || !s->slam) return ALVA_ERR_ARG;
+    if (out32) memcpy(out32, s->slam->t_fine, sizeof(s->slam->t_fine));
+    if (reset) memset(s->slam->t_fine, 0, sizeof(s->slam->t_fine));
+    return ALVA_OK;
+}
 extern "C" int alva_system_debug_set_init_pose(alva_system *s, const double *pose7) {
     if (!s || !s->slam) return ALVA_ERR_ARG;
     s->slam->init_override.armed = pose7 != nullptr;

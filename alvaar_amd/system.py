@@ -40,6 +40,7 @@ lib.alva_system_debug_klt_work.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_set_init_pose.argtypes = [_vp, _vp]
 lib.alva_system_debug_timing.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_timing_keyframe.argtypes = [_vp, _vp, _i]
+lib.alva_system_debug_timing_fine.argtypes = [_vp, _vp, _i]
 lib.alva_system_last_error.restype = C.c_char_p
 
 
@@ -220,6 +221,18 @@ class AlvaAR:
         names = ("prepare", "describe_tracked", "detect", "describe_new", "insert+copy", "triangulate", "covisibility", "local_map_matching",
                  "optimize", "(match stage)", "(BA stage)", "(BA build)", "(BA solves+sweep)", "(BA write-back)", "(BA culling)", "(descriptor medoids)")
         return dict(zip(names, out[:16]))
+
+    FINE_NAMES = ("match: local-map union", "match: flatten+stage", "match: merges", "flatten: kf table + cells", "flatten: local list",
+                  "flatten: per map point", "BA build: keyframes + point set", "BA build: observations", "filter: keyframe removals",
+                  "window: remove kf-30", "copy: frame", "copy: order mirror", "copy: observation mirror", "new keypoints + map points",
+                  "covis: counts", "covis: local ids", "covis: into local map", "", "", "",
+                  "#flattened map points", "#flattened observations", "#local candidates", "#BA points", "#BA residual blocks", "#BA keyframes",
+                  "#new keypoints", "#local ids", "#covisible keyframes", "", "", "")
+
+    def timing_fine(self, reset: bool = True):
+        out = np.zeros(32)
+        lib.alva_system_debug_timing_fine(self.h, out.ctypes.data, int(reset))
+        return {n: v for n, v in zip(self.FINE_NAMES, out) if n}
 
     def set_init_pose(self, pose7):
         if pose7 is None:

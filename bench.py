@@ -746,6 +746,14 @@ def cpu_baseline_port(seed: int, budget_s: float = 12.0):
             "sample": f"{n} tracking frames (gray, 2 LK pyramids, fb-KLT 3 levels, P3P-LMedS, PnP) through the C restatement; no keyframes"}
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg: str):
+    """progress on stderr (stdout carries the one JSON line)"""
+    print(f"[bench {time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def launch_latency(ctx):
     import ctypes as C
     from alvaar_amd.capi import lib, check
@@ -876,11 +884,14 @@ def main():
     # window is full (keyframe 34; ~600 frames) and on to the middle of a keyframe period, so the K timed steps hold round(K / period)
     # keyframes -- a keyframe costs several tracking frames, and a window right after initialisation (2-3 keyframes in the map, cheap
     # keyframes) overstated the rate a session sustains by 1.5x (round 2's verdict).  --warmup W steps run on top, as the contract says.
+    log("warming the session into steady state")
     extra, period = sysjob.warm_to_steady_state(then_untimed=args.warmup)
+    log(f"steady state after {extra} frames, keyframe period {period}")
     kf_before = int(sysjob.ar.state()[11])
     dt = timed(sysjob.step, args.warmup, args.steps)
     kf_in_window = int(sysjob.ar.state()[11]) - kf_before
     hist_timed = list(sysjob.status_hist)
+    log(f"headline window: {args.steps / dt:.0f} frames/s per rank")
     # the same loop for at least 0.5 s
     long_steps = max(args.steps, int(0.6 * args.steps / max(dt, 1e-9)) + 1)
     kf_before = int(sysjob.ar.state()[11])
@@ -897,6 +908,7 @@ def main():
     sections, kf_detail, n_kf_sec = ar.timing(), ar.timing_keyframe(), int(ar.state()[11]) - kf0
     sys_state = ar.state()
     sys_counters = ar.counters()
+    log(f"sustained: {long_steps / dt_long:.0f} frames/s per rank")
     # PCIe-fed variant: host RGBA in through AlvaAR.findCameraPose (memImg.write + the registered buffer read in place), same length
     dt_host = timed(sysjob.step_host, 5, long_steps)
     ar.timing()
@@ -907,6 +919,7 @@ def main():
     for i in range(50):
         np.copyto(ar.mem_img, sysjob.host_frames[i])
     copy_us = (time.perf_counter() - t0) / 50 * 1e6
+    log(f"host-fed: {long_steps / dt_host:.0f} frames/s per rank")
     # ---- the optional shared-map merge on the process group's backend (RCCL): pack -> ONE all_gather_into_tensor -> fuse on the GPU
     merge = None
     try:
@@ -930,6 +943,7 @@ def main():
                          "(debug export of the map + numpy packing)"}
     except Exception as e:
         merge = {"error": repr(e), "process_group_error": dist_err}
+    log(f"map merge: {merge}")
     dt_drv = dt_nola = dt_serial = None
     if job is not None:
         # ---- round 1's headline as a secondary line (fixed correspondences, three HIP streams)
@@ -942,6 +956,7 @@ def main():
         fps = world * args.steps / dt
         bctx = job.ctx if job is not None else alvaar_amd.Context(local)
         stage_us = job.stage_times() if job is not None else None
+        log("stage list driver done; local BA")
         ba, ba_pb = bench_ba(bctx)
         peaks = measured_peaks(bctx)
         lat_dep, lat_rt = launch_latency(bctx)
@@ -949,6 +964,7 @@ def main():
         # ---- roofline: per-KERNEL durations from HIP events recorded on each launch stream, over a further pass of the headline loop
         # (the events cost a few us per launch, so they stay out of the pass that gives `value`)
         PROF_STEPS = 200
+        log("kernel times of the headline loop")
         ar.klt_work()
         kt = capi.kernel_times(sysjob.step, PROF_STEPS)
         klt_levels, klt_slots = ar.klt_work()
@@ -995,6 +1011,7 @@ def main():
                     "this single stream actually runs against"}
         us = lambda d, n: {a: round(1e6 * b / max(n, 1), 1) for a, b in d.items()}
         full = not args.quick and world == 1
+        log("assembling the line")
         out = {
             "metric": "frames/sec @640x480 2000kp; local-BA residuals/sec (20KFx3k pts)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1059,6 +1076,7 @@ def main():
                                                 "stage throughput, not the reference's dataflow"}
             out["stage_us"] = stage_us
         if full:
+            log("secondary lines")
             if not is720:
                 out["system_720p"] = run_system_line(local, shard.stream_seed, 1280, 720, 15, args.steps)   # configs[4]'s geometry, default-on
             out["local_ba_batch"] = bench_ba_batch(bctx, ba_pb, peaks)
@@ -1075,7 +1093,9 @@ def main():
         if args.system_streams and world == 1:
             out["system_streams"] = [bench_system_streams(local, int(v)) for v in args.system_streams.split(",")]
         if not args.no_cpu_baseline and world == 1:   # the contract: reference CPU path timed on rank 0 at N = 1 only
+            log("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(shard.stream_seed)
+            log("done")
         print(json.dumps(out))
     if dist:
         td.barrier()

@@ -91,6 +91,8 @@ int alva_system_debug_klt_work(alva_system *sys, long *out2, int reset);
 /* wall-clock seconds per section of the frame loop since the last reset: upload + pyramid enqueue, slot gathering, tracking step,
  * tracker bookkeeping, wait for the pose, pose bookkeeping + keyframe decision, keyframe creation, mapping (incl. local BA) */
 int alva_system_debug_timing(alva_system *sys, double *out8, int reset);
+/* finer laps of the keyframe path + element counts (profiling aid; indices documented in alvaar_amd/system.py: timing_fine) */
+int alva_system_debug_timing_fine(alva_system *sys, double *out32, int reset);
 /* finer split of the keyframe sections: [0] prepareFrame [1] describe tracked keypoints [2] grid detection [3] describe + undistort new
  * keypoints [4] map insertion + keyframe copy | [5] triangulation [6] covisibility [7] local-map matching incl. flattening and merges
  * [8] optimize (local BA + culling) ; inside them: [9] the matchToMap stage call [10] the local-BA stage calls */

@@ -192,20 +192,23 @@ def _quat_to_rot(q):
 
 def sim3_aligned_diff(ref_poses7, got_poses7):
     """Two trajectories of the same camera in two maps whose gauges (scale, world frame) may differ: align `got` to `ref` with the
-    similarity transform that best maps its camera centres (Umeyama 1991, closed form), then report
+    similarity transform of the gauge (rotation = chordal mean of the relative orientations, scale and translation by least squares on
+    the camera centres), then report
       (scale, worst |centre difference| / trajectory extent, worst rotation difference in radians)
     of the aligned trajectory.  pose7 = (t, q_xyzw) of Twc."""
     A = np.array([p[:3] for p in got_poses7], np.float64)
     B = np.array([p[:3] for p in ref_poses7], np.float64)
     ma, mb = A.mean(0), B.mean(0)
     Ac, Bc = A - ma, B - mb
-    U, S, Vt = np.linalg.svd(Bc.T @ Ac / len(A))
-    D = np.eye(3)
-    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
-        D[2, 2] = -1
+    # rotation of the gauge from the ORIENTATIONS (chordal mean of Rr_i Rg_i^T): the centres alone do not fix it when the camera moves
+    # along a line (the synthetic streams do: a rotation about that line leaves every centre where it is)
+    M = sum(_quat_to_rot(pr[3:]) @ _quat_to_rot(pg[3:]).T for pr, pg in zip(ref_poses7, got_poses7))
+    U, S, Vt = np.linalg.svd(M)
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
     R = U @ D @ Vt
-    var = (Ac ** 2).sum() / len(A)
-    c = float(np.trace(np.diag(S) @ D) / var) if var > 0 else 1.0
+    RA = (R @ Ac.T).T
+    den = float((RA ** 2).sum())
+    c = float((Bc * RA).sum() / den) if den > 0 else 1.0
     t = mb - c * R @ ma
     extent = float(np.linalg.norm(Bc, axis=1).max()) or 1.0
     dpos = float(np.linalg.norm((c * (R @ A.T).T + t) - B, axis=1).max()) / extent
