@@ -928,14 +928,15 @@ void circle_halfwidths(int radius, int *hw) {  // drawing.cpp:1477-1617 (Circle,
 
 }  // namespace
 
-extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int cell_size,
-                                const float *d_occupied, int n_occ, int roi_x, int roi_y, int roi_w, int roi_h, double *h_max_quality,
-                                float *d_out_pts, int cap, int *h_count) {
-    ALVA_ARG(ctx && d_gray && h_max_quality && d_out_pts && h_count && width > 8 && height > 8 && cap >= 0 && n_occ >= 0);
+extern "C" int alva_detect_grid_enqueue(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int cell_size,
+                                        const float *d_occupied, int n_occ, int roi_x, int roi_y, int roi_w, int roi_h, double max_quality,
+                                        float *d_out_pts, int cap, alva_detect_pending *pending) {
+    ALVA_ARG(ctx && d_gray && pending && d_out_pts && width > 8 && height > 8 && cap >= 0 && n_occ >= 0);
+    pending->h_cnt = nullptr;
+    pending->n_cells = 0;
     ALVA_ARG(cell_size >= 4 && cell_size <= MAX_CELL);
     ALVA_ARG(n_occ == 0 || d_occupied);
     ALVA_ARG(width < 65536 && height < 32768);
-    *h_count = 0;
     GridArgs A{};
     A.gray = d_gray;
     A.pitch = gray_pitch;
@@ -946,7 +947,7 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     A.nCH = height / cell_size;
     A.radius = cell_size / 4;
     A.roiX = roi_x; A.roiY = roi_y; A.roiW = roi_w; A.roiH = roi_h;
-    A.maxQuality = *h_max_quality;
+    A.maxQuality = max_quality;
     A.occupied = d_occupied;
     A.nOcc = n_occ;
     circle_halfwidths(A.radius, A.hw);
@@ -1009,12 +1010,32 @@ extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gra
     const int maxPts = std::min(cap, 2 * nCells);
     if (maxPts > 0) hipLaunchKernelGGL(k_subpix, dim3(maxPts), dim3(64), 0, st, d_gray, gray_pitch, width, height, d_out_pts, d_cnt, cap);
     ALVA_LAUNCH_CHECK();
-    ALVA_HIP(hipStreamSynchronize(st));
-    const CompactOut res = *h_cnt;
+    pending->h_cnt = h_cnt;
+    pending->n_cells = nCells;
+    return ALVA_OK;
+}
+
+// waits for the enqueued detection and applies the adaptive threshold rule (feature_extractor.cpp:138-145)
+extern "C" int alva_detect_grid_collect(alva_ctx *ctx, const alva_detect_pending *pending, double *h_max_quality, int *h_count) {
+    ALVA_ARG(ctx && pending && h_max_quality && h_count);
+    *h_count = 0;
+    if (!pending->h_cnt) return ALVA_OK;   // no cells: nothing was enqueued
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    const CompactOut res = *static_cast<const CompactOut *>(pending->h_cnt);
     *h_count = res.n_total;
-    // adaptive threshold (:138-145)
-    const double freeCells = (double) ((size_t) nCells - (size_t) res.n_occupied);
+    const double freeCells = (double) ((size_t) pending->n_cells - (size_t) res.n_occupied);
     if ((double) res.n_total < 0.33 * freeCells) *h_max_quality *= 0.5;
     else if ((double) res.n_total > 0.9 * freeCells) *h_max_quality *= 1.5;
     return ALVA_OK;
+}
+
+extern "C" int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int cell_size,
+                                const float *d_occupied, int n_occ, int roi_x, int roi_y, int roi_w, int roi_h, double *h_max_quality,
+                                float *d_out_pts, int cap, int *h_count) {
+    ALVA_ARG(h_max_quality && h_count);
+    alva_detect_pending pending;
+    const int rc = alva_detect_grid_enqueue(ctx, d_gray, gray_pitch, width, height, cell_size, d_occupied, n_occ, roi_x, roi_y, roi_w, roi_h,
+                                            *h_max_quality, d_out_pts, cap, &pending);
+    if (rc) return rc;
+    return alva_detect_grid_collect(ctx, &pending, h_max_quality, h_count);
 }

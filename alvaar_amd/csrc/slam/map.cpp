@@ -348,12 +348,22 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
             i++;
         }
     }
-    // describeKeypoints (:224-241): refresh the descriptors of the tracked keypoints in the raw image
+    // describeKeypoints (:224-241): refresh the descriptors of the tracked keypoints in the raw image.  The detector of :213 needs only
+    // the image and the tracked positions, so it is STARTED before the descriptor medoids are updated on the host (nothing it reads
+    // or writes is touched by them) and collected afterwards: the two overlap.
+    const int to_detect = cfg.max_keypoints - (int) cur->n_occupied;
+    const int cap = (int) cur->grid_cells + 8;
+    std::vector<uint8_t> desc((size_t) n * 32), valid((size_t) n);
     if (n) {
-        std::vector<uint8_t> desc((size_t) n * 32), valid((size_t) n);
         Lap lap;
         if (fail(st->describe(n, pts.data(), desc.data(), valid.data()))) return;
         lap(t_kf[1]);
+    }
+    Lap lap_det;
+    if (to_detect > 0 && fail(st->detect_begin(cfg.cell_size, n, pts.data(), cap))) return;
+    lap_det(t_kf[2]);
+    if (n) {
+        Lap lap;
         for (int i = 0; i < n; i++)
             if (valid[(size_t) i]) {
                 Desc d;
@@ -366,13 +376,11 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
             }
         lap(t_kf[15]);
     }
-    const int to_detect = cfg.max_keypoints - (int) cur->n_occupied;
     if (to_detect > 0) {
-        const int cap = (int) cur->grid_cells + 8;
         std::vector<float> np((size_t) cap * 2);
         int count = 0;
         Lap lap;
-        if (fail(st->detect(cfg.cell_size, n, pts.data(), cap, np.data(), &count))) return;
+        if (fail(st->detect_end(np.data(), &count))) return;
         lap(t_kf[2]);
         if (count > 0) {
             std::vector<uint8_t> desc((size_t) count * 32), valid((size_t) count);

@@ -162,27 +162,25 @@ bool Slam::matching_to_local_map(FrameRec &frame) {  // mapper.cpp:293-352
     return true;
 }
 
-// Mapper::matchToMap (mapper.cpp:354-588): flatten the part of the map the call can reach, run the stage, translate indices back
+// Mapper::matchToMap (mapper.cpp:354-588): flatten the part of the map the call can reach, run the stage, translate indices back.
+// The arrays are assembled in the stage's scratch (pinned memory behind the HIP stages: one upload of one contiguous block).
 std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float dist_ratio, FlatSet &local) {
     std::map<int, int> result;
     if (local.empty()) return result;
     Lap fine;
     // keyframe table
-    std::vector<int> kf_ids;
+    std::vector<int> &kf_ids = kf_ids_scratch_;
+    kf_ids.clear();
     for (const auto &e: keyframes) kf_ids.push_back(e.first);
     std::sort(kf_ids.begin(), kf_ids.end());
-    std::vector<int> kf_index((size_t) next_kf_id + 1, -1);
-    std::vector<double> kf_q, kf_t;
-    for (size_t i = 0; i < kf_ids.size(); i++) {
-        kf_index[(size_t) kf_ids[i]] = (int) i;
-        const FrameRec &k = *keyframes.at(kf_ids[i]);
-        kf_q.insert(kf_q.end(), k.Tcw.q, k.Tcw.q + 4);
-        kf_t.insert(kf_t.end(), k.Tcw.t, k.Tcw.t + 3);
-    }
+    std::vector<int> &kf_index = index_scratch_;
+    kf_index.assign((size_t) next_kf_id + 1, -1);
+    for (size_t i = 0; i < kf_ids.size(); i++) kf_index[(size_t) kf_ids[i]] = (int) i;
     if (frame.kfid < 0 || frame.kfid > next_kf_id || kf_index[(size_t) frame.kfid] < 0) return result;
     const int frame_kf_index = kf_index[(size_t) frame.kfid];
     // map point table: the frame's keypoints first (grid order), then the local map in ITS iteration order
-    std::vector<int> mp_ids;
+    std::vector<int> &mp_ids = touched_b_;
+    mp_ids.clear();
     // id -> row of the table (ids are dense).  The table persists (all -1 between calls) and only the rows used here are reset at the
     // end: ids are never reused and a long run hands out millions, so clearing it per keyframe would cost O(ids ever handed out)
     std::vector<int> &mp_index = mp_index_;
@@ -194,17 +192,23 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             for (int id: ids) index[(size_t) id] = -1;
         }
     } reset_index{mp_index, mp_ids};
-    auto intern = [&](int id) {
+    size_t obs_bound = 0;   // upper bound of the observations to flatten (every observer of every table row)
+    auto intern = [&](int id, const MapPt &mp) {
         int &slot = mp_index[(size_t) id];
         if (slot < 0) {
             slot = (int) mp_ids.size();
             mp_ids.push_back(id);
+            obs_bound += mp.obs_kfs.size();
         }
         return slot;
     };
-    std::vector<int> cell_ptr(frame.grid.size() + 1, 0), cell_mp;
-    for (size_t c = 0; c < frame.grid.size(); c++) {
-        cell_ptr[c] = (int) cell_mp.size();
+    const size_t n_grid = frame.grid.size();
+    std::vector<int> &cell_mp_v = ids_scratch_;   // cell lists and local list are small: built in vectors, copied into the block below
+    std::vector<int> &cell_ptr_v = obs_scratch_;
+    cell_mp_v.clear();
+    cell_ptr_v.assign(n_grid + 1, 0);
+    for (size_t c = 0; c < n_grid; c++) {
+        cell_ptr_v[c] = (int) cell_mp_v.size();
         const CellIds &cell_ids = frame.grid[c];
         for (size_t ci = 0; ci < cell_ids.size(); ci++) {
             const int id = cell_ids[ci];
@@ -213,46 +217,80 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             const MapPt *gm = mp_raw(id);
             if (!gm) continue;
             if (!obs_of(*gm, frame.kfid)) continue;
-            cell_mp.push_back(intern(id));
+            cell_mp_v.push_back(intern(id, *gm));
         }
     }
-    cell_ptr[frame.grid.size()] = (int) cell_mp.size();
+    cell_ptr_v[n_grid] = (int) cell_mp_v.size();
     fine(t_fine[3]);   // keyframe table + grid cells
-    std::vector<int> local_idx;
+    std::vector<int> &local_idx = local_scratch_;
+    local_idx.clear();
     mark_a_.resize((size_t) next_mp_id + 1, 0);
     touched_a_.clear();
-    for (const auto &e: frame.kps) {
-        mark_a_[(size_t) e.first] = 1;
-        touched_a_.push_back(e.first);
-    }
+    frame.for_each_id([&](int kid, bool) {
+        mark_a_[(size_t) kid] = 1;
+        touched_a_.push_back(kid);
+    });
     for (int id: local) {
         if (id >= 0 && id <= next_mp_id ? mark_a_[(size_t) id] != 0 : frame.observes(id)) continue;   // frame.isObservingKeypoint (:397-400)
         const MapPt *mp = mp_raw(id);
         if (!mp || !mp->is3d || !mp->has_desc) continue;         // :404-411
-        local_idx.push_back(intern(id));
+        local_idx.push_back(intern(id, *mp));
     }
     for (int id: touched_a_) mark_a_[(size_t) id] = 0;
     fine(t_fine[4]);   // local list
     if (local_idx.empty()) return result;
-    const int n_mp = (int) mp_ids.size();
-    std::vector<double> mp_wpt((size_t) n_mp * 3);
-    std::vector<uint8_t> mp_is3d((size_t) n_mp), mp_has_desc((size_t) n_mp), obs_desc, obs_has_desc;
-    std::vector<int> obs_ptr((size_t) n_mp + 1, 0), obs_kf;
-    std::vector<float> obs_px;
+    const int n_mp = (int) mp_ids.size(), n_kf = (int) kf_ids.size(), n_cell = (int) cell_mp_v.size(), n_local = (int) local_idx.size();
+    // ---- one block: fixed-size arrays first, the per-observation arrays (sized by the bound) last
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_cp = take((n_grid + 1) * 4), o_cm = take((size_t) n_cell * 4 + 4), o_q = take((size_t) n_kf * 32), o_t = take((size_t) n_kf * 24),
+                 o_w = take((size_t) n_mp * 24), o_3 = take((size_t) n_mp), o_hd = take((size_t) n_mp), o_op = take((size_t) (n_mp + 1) * 4),
+                 o_l = take((size_t) n_local * 4), o_m = take((size_t) n_mp * 4), o_ok = take(obs_bound * 4 + 4), o_oh = take(obs_bound + 4),
+                 o_ox = take(obs_bound * 8 + 8), o_od = take(obs_bound * 32 + 32);
+    uint8_t *blk = st->stage_scratch(off);
+    if (!blk) {
+        fail(-3);
+        return result;
+    }
+    int *cell_ptr = (int *) (blk + o_cp), *cell_mp = (int *) (blk + o_cm), *obs_ptr = (int *) (blk + o_op), *local_p = (int *) (blk + o_l),
+        *match_of_mp = (int *) (blk + o_m), *obs_kf = (int *) (blk + o_ok);
+    double *kf_q = (double *) (blk + o_q), *kf_t = (double *) (blk + o_t), *mp_wpt = (double *) (blk + o_w);
+    uint8_t *mp_is3d = blk + o_3, *mp_has_desc = blk + o_hd, *obs_has_desc = blk + o_oh, *obs_desc = blk + o_od;
+    float *obs_px = (float *) (blk + o_ox);
+    std::memcpy(cell_ptr, cell_ptr_v.data(), (n_grid + 1) * 4);
+    std::memcpy(cell_mp, cell_mp_v.data(), (size_t) n_cell * 4);
+    std::memcpy(local_p, local_idx.data(), (size_t) n_local * 4);
+    for (int i = 0; i < n_kf; i++) {
+        const FrameRec &k = *kf_raw(kf_ids[(size_t) i]);
+        std::memcpy(kf_q + 4 * (size_t) i, k.Tcw.q, 32);
+        std::memcpy(kf_t + 3 * (size_t) i, k.Tcw.t, 24);
+    }
+    size_t no = 0;
     for (int m = 0; m < n_mp; m++) {
         prefetch_mp(mp_ids.data(), (size_t) m, (size_t) n_mp);
         const MapPt &mp = *mp_raw(mp_ids[(size_t) m]);
         std::memcpy(&mp_wpt[3 * (size_t) m], mp.X, 24);
         mp_is3d[(size_t) m] = mp.is3d;
         mp_has_desc[(size_t) m] = mp.has_desc;
-        obs_ptr[(size_t) m] = (int) obs_kf.size();
+        obs_ptr[(size_t) m] = (int) no;
+        // observers (obs_kfs, ascending) against the per-keyframe records (seen, ascending): one pass over both
+        const ObsPx *sp = mp.seen.data(), *se = sp + mp.seen.size();
         for (int kf: mp.obs_kfs) {
+            while (sp != se && sp->kf < kf) sp++;
             if (kf < 0 || kf > next_kf_id || kf_index[(size_t) kf] < 0) continue;
-            const ObsPx *kk = obs_of(mp, kf);
+            const ObsPx *kk = sp != se && sp->kf == kf && sp->in_kf ? sp : nullptr;
+            if (check_obs_mirror_ && kk != obs_of(mp, kf)) {
+                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync (map point %d, keyframe %d)\n", mp.id, kf);
+                std::abort();
+            }
             if (!kk) continue;
-            obs_kf.push_back(kf_index[(size_t) kf]);
-            obs_px.push_back(kk->px[0]);
-            obs_px.push_back(kk->px[1]);
+            obs_kf[no] = kf_index[(size_t) kf];
+            obs_px[2 * no] = kk->px[0];
+            obs_px[2 * no + 1] = kk->px[1];
             // one 32-byte slot per observation; keyframes in which the keypoint could not be described (within 31 px of the border,
             // feature_extractor.cpp:191-209) have no entry in mapKeyframeDescriptors_: slot zeroed and flagged
             if (check_obs_mirror_) {
@@ -262,24 +300,20 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
                     std::abort();
                 }
             }
-            if (kk->has_desc) {
-                obs_desc.insert(obs_desc.end(), kk->desc.b, kk->desc.b + 32);
-                obs_has_desc.push_back(1);
-            } else {
-                obs_desc.insert(obs_desc.end(), 32, (uint8_t) 0);
-                obs_has_desc.push_back(0);
-            }
+            if (kk->has_desc) std::memcpy(obs_desc + 32 * no, kk->desc.b, 32);
+            else std::memset(obs_desc + 32 * no, 0, 32);
+            obs_has_desc[no] = kk->has_desc;
+            no++;
         }
     }
-    obs_ptr[(size_t) n_mp] = (int) obs_kf.size();
+    obs_ptr[(size_t) n_mp] = (int) no;
+    for (int m = 0; m < n_mp; m++) match_of_mp[(size_t) m] = -1;
     fine(t_fine[5]);   // per-map-point flatten
-    t_fine[20] += (double) n_mp; t_fine[21] += (double) obs_kf.size(); t_fine[22] += (double) local_idx.size();
-    std::vector<int> match_of_mp((size_t) n_mp, -1);
+    t_fine[20] += (double) n_mp; t_fine[21] += (double) no; t_fine[22] += (double) n_local;
     Lap lap;
-    const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) frame.grid.size(), cell_ptr.data(), cell_mp.data(),
-                                    (int) kf_ids.size(), kf_q.data(), kf_t.data(), n_mp, mp_wpt.data(), mp_is3d.data(), mp_has_desc.data(),
-                                    obs_ptr.data(), obs_kf.data(), obs_px.data(), obs_desc.data(), obs_has_desc.data(), frame_kf_index,
-                                    (int) frame.n_3d, (int) local_idx.size(), local_idx.data(), max_proj_err, dist_ratio, match_of_mp.data());
+    const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) n_grid, cell_ptr, cell_mp, n_kf, kf_q, kf_t, n_mp, mp_wpt, mp_is3d,
+                                    mp_has_desc, obs_ptr, obs_kf, obs_px, obs_desc, obs_has_desc, frame_kf_index, (int) frame.n_3d, n_local, local_p,
+                                    max_proj_err, dist_ratio, match_of_mp);
     lap(t_kf[9]);
     if (fail(rc)) return result;
     for (int m = 0; m < n_mp; m++)
@@ -442,12 +476,13 @@ void Slam::local_ba(FrameRec &new_frame) {
     for (int id: touched_a_) mark_a_[(size_t) id] = 0;
     Lap fine;
     t_fine[6] += std::chrono::duration<double>(fine.t0 - lap_ba.t0).count();   // BA build phase 1: keyframes + points to optimise
-    struct ObsRec {
-        int kfid, mpid;
-    };
-    std::vector<int> pt_ids, pt_anchor_slot, obs_kf, obs_pt;
-    std::vector<double> pt_anchor_uv, pt_inv, obs_uv;
-    std::vector<ObsRec> obs_rec;
+    // the problem's arrays live in a member (capacity persists from keyframe to keyframe: no allocator traffic, no first-touch faults)
+    typedef BaScratch::ObsRec ObsRec;
+    BaScratch &bs = ba_scratch_;
+    std::vector<int> &pt_ids = bs.pt_ids, &pt_anchor_slot = bs.pt_anchor_slot, &obs_kf = bs.obs_kf, &obs_pt = bs.obs_pt;
+    std::vector<double> &pt_anchor_uv = bs.pt_anchor_uv, &pt_inv = bs.pt_inv, &obs_uv = bs.obs_uv;
+    std::vector<ObsRec> &obs_rec = bs.obs_rec;
+    pt_ids.clear(); pt_anchor_slot.clear(); obs_kf.clear(); obs_pt.clear(); pt_anchor_uv.clear(); pt_inv.clear(); obs_uv.clear(); obs_rec.clear();
     std::pmr::unordered_map<int, int> pt_slot(&arena);  // map_id_invptspar_
     ids_scratch_.assign(mps_to_opt.begin(), mps_to_opt.end());   // the set's order, as an array (for the prefetcher; the loop below does not edit the set)
     for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
@@ -463,6 +498,7 @@ void Slam::local_ba(FrameRec &new_frame) {
         int anchor = -1, cur_slot = -1;
         std::vector<int> &obs = obs_scratch_;  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
         obs.assign(mp->obs_kfs.begin(), mp->obs_kfs.end());
+        size_t si = 0;   // walks mp->seen (sorted by keyframe like obs) beside the observers; a repair below edits it: start over
         for (int kfid: obs) {
             if (kfid > max_kfid) continue;
             FrameRec *kf = kf_flat[(size_t) kfid];
@@ -470,6 +506,7 @@ void Slam::local_ba(FrameRec &new_frame) {
                 std::shared_ptr<FrameRec> sp = keyframe(kfid);
                 if (!sp) {
                     remove_map_point_obs(kfid, mp->id);  // sic: arguments swapped in the reference (optimizer.cpp:162)
+                    si = 0;
                     continue;
                 }
                 local_kfs.emplace(kfid, sp);
@@ -477,9 +514,15 @@ void Slam::local_ba(FrameRec &new_frame) {
                 add_pose(kfid, *kf, true);
                 const_kfs.insert(kfid);
             }
-            const ObsPx *kp = obs_of(*mp, kfid);
+            while (si < mp->seen.size() && mp->seen[si].kf < kfid) si++;
+            const ObsPx *kp = si < mp->seen.size() && mp->seen[si].kf == kfid && mp->seen[si].in_kf ? &mp->seen[si] : nullptr;
+            if (check_obs_mirror_ && kp != obs_of(*mp, kfid)) {
+                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync in localBA (map point %d, keyframe %d)\n", mp->id, kfid);
+                std::abort();
+            }
             if (!kp) {
                 remove_map_point_obs(lmid, kfid);
+                si = 0;
                 continue;
             }
             if (anchor < 0) {  // the first observing keyframe anchors the inverse depth; it gets no residual (:186-201)
@@ -518,20 +561,25 @@ void Slam::local_ba(FrameRec &new_frame) {
     //         reset to L2 there because vright_reprojerr_kfid_lmid stays empty, :315-318)
     const int n_kf = (int) kf_const.size(), n_pt = (int) pt_ids.size();
     std::vector<std::pair<int, int>> bad_obs;  // (keyframe, map point)
-    std::vector<uint8_t> alive(obs_rec.size(), 1);
+    std::vector<uint8_t> &alive = bs.alive;
+    alive.assign(obs_rec.size(), 1);
     bool any_bad = false;
     for (int round = 0; round < 2; round++) {
-        std::vector<int> sel;
+        std::vector<int> &sel = bs.sel;
+        sel.clear();
         for (size_t o = 0; o < obs_rec.size(); o++)
             if (alive[o]) sel.push_back((int) o);
         const int n_obs = (int) sel.size();
         // Ceres drops parameter blocks that no residual block uses (program.cc: RemoveFixedBlocks); the stage gets the same reduced
         // problem: only points with a live residual, and a free keyframe without residuals is passed as constant
-        std::vector<int> pt_of((size_t) n_pt, -1), pts_used;
-        std::vector<uint8_t> kf_used((size_t) n_kf, 0), kc = kf_const;
-        std::vector<int> okf((size_t) n_obs), opt((size_t) n_obs);
-        std::vector<double> ouv((size_t) n_obs * 2), chi2((size_t) n_obs);
-        std::vector<uint8_t> dpos((size_t) n_obs);
+        std::vector<int> &pt_of = bs.pt_of, &pts_used = bs.pts_used, &okf = bs.okf, &opt = bs.opt;
+        std::vector<uint8_t> &kf_used = bs.kf_used, &kc = bs.kc, &dpos = bs.dpos;
+        std::vector<double> &ouv = bs.ouv, &chi2 = bs.chi2;
+        pt_of.assign((size_t) n_pt, -1);
+        pts_used.clear();
+        kf_used.assign((size_t) n_kf, 0);
+        kc = kf_const;
+        okf.resize((size_t) n_obs); opt.resize((size_t) n_obs); ouv.resize((size_t) n_obs * 2); chi2.resize((size_t) n_obs); dpos.resize((size_t) n_obs);
         for (int i = 0; i < n_obs; i++) {
             const int o = sel[(size_t) i], p = obs_pt[(size_t) o];
             if (pt_of[(size_t) p] < 0) {
@@ -548,8 +596,9 @@ void Slam::local_ba(FrameRec &new_frame) {
         for (int k = 0; k < n_kf; k++)
             if (!kf_used[(size_t) k]) kc[(size_t) k] = 1;
         const int n_used = (int) pts_used.size();
-        std::vector<int> pa((size_t) n_used);
-        std::vector<double> pauv((size_t) n_used * 2), pinv((size_t) n_used);
+        std::vector<int> &pa = bs.pa;
+        std::vector<double> &pauv = bs.pauv, &pinv = bs.pinv;
+        pa.resize((size_t) n_used); pauv.resize((size_t) n_used * 2); pinv.resize((size_t) n_used);
         for (int j = 0; j < n_used; j++) {
             const int p = pts_used[(size_t) j];
             pa[(size_t) j] = pt_anchor_slot[(size_t) p];

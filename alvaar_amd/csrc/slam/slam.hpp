@@ -264,23 +264,26 @@ struct MapPt {
     void add_desc(int kf, const Desc &d);
     bool is_bad();
 
+    // `seen` is kept sorted by keyframe id (like obs_kfs), so the flattening loops walk the two lists side by side
     ObsPx *seen_in(int kf) {
-        for (ObsPx &o: seen)
+        for (ObsPx &o: seen) {
             if (o.kf == kf) return &o;
+            if (o.kf > kf) break;
+        }
         return nullptr;
     }
     const ObsPx *seen_in(int kf) const { return const_cast<MapPt *>(this)->seen_in(kf); }
     ObsPx &seen_slot(int kf) {
-        ObsPx *o = seen_in(kf);
-        if (o) return *o;
-        seen.emplace_back();
-        seen.back().kf = kf;
-        return seen.back();
+        size_t i = seen.size();
+        while (i > 0 && seen[i - 1].kf > kf) i--;
+        if (i > 0 && seen[i - 1].kf == kf) return seen[i - 1];
+        ObsPx o;
+        o.kf = kf;
+        return *seen.insert(seen.begin() + (long) i, o);
     }
     void seen_prune(ObsPx *o) {
         if (o->in_kf || o->has_desc) return;
-        *o = seen.back();
-        seen.pop_back();
+        seen.erase(seen.begin() + (o - seen.data()));
     }
     void note_px(int kf, const KeyPt &k) {
         ObsPx &o = seen_slot(kf);
@@ -371,7 +374,7 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
-    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_;
+    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_, kf_ids_scratch_, local_scratch_;
     // flat "seen" marks over map point ids (ids are dense, handed out consecutively): inserting a key that is already in a hash set does
     // not change the set, so duplicate inserts are filtered with a byte look-up instead of a hash look-up
     std::vector<uint8_t> mark_a_, mark_b_;
@@ -436,6 +439,15 @@ private:
     void sync_nobs(const MapPt &mp) { mp_nobs_[(size_t) mp.id] = (uint8_t) (mp.obs_kfs.size() > 255 ? 255 : mp.obs_kfs.size()); }
     bool check_obs_mirror_ = false;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
+    struct BaScratch {   // local_ba's problem arrays (see there)
+        struct ObsRec {
+            int kfid, mpid;
+        };
+        std::vector<int> pt_ids, pt_anchor_slot, obs_kf, obs_pt, sel, pt_of, pts_used, okf, opt, pa;
+        std::vector<double> pt_anchor_uv, pt_inv, obs_uv, ouv, chi2, pauv, pinv;
+        std::vector<ObsRec> obs_rec;
+        std::vector<uint8_t> alive, kf_used, kc, dpos;
+    } ba_scratch_;
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
     std::vector<std::shared_ptr<MapPt>> mp_graveyard_;
     const ObsPx *obs_of(const MapPt &mp, int kfid) const;   // the keypoint of `mp` in keyframe `kfid` (null: that keyframe holds none)

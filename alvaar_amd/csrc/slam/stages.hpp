@@ -103,6 +103,14 @@ struct Stages {
     // the detector's adaptive quality threshold is state of the implementation and survives System::reset like the
     // reference's FeatureExtractor object does (system.cpp:31, :42-55).
     virtual int detect(int cell, int n_occ, const float *occupied, int cap, float *pts, int *count) = 0;
+    // The same call split so that the caller can work while the detector runs: detect_begin starts it, detect_end delivers what
+    // detect() would have.  Default: nothing happens until detect_end, which calls detect().  No other stage call in between.
+    virtual int detect_begin(int cell, int n_occ, const float *occupied, int cap) {
+        det_cell_ = cell; det_n_occ_ = n_occ; det_cap_ = cap;
+        det_occ_.assign(occupied, occupied + 2 * (size_t) (n_occ > 0 ? n_occ : 0));
+        return 0;
+    }
+    virtual int detect_end(float *pts, int *count) { return detect(det_cell_, det_n_occ_, det_occ_.data(), det_cap_, pts, count); }
     // FeatureExtractor::describeFeaturePoints(imageRaw, pts) (map_manager.cpp:204, :218) on the current RAW gray image
     virtual int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) = 0;
 
@@ -111,6 +119,13 @@ struct Stages {
                             const float *unpx_l, const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status,
                             double *parallax) = 0;
 
+    // Host scratch of at least `bytes` in which the map layer may assemble the arrays of the NEXT match_to_map / local_ba call (valid
+    // until that call returns).  An implementation that stages its inputs anyway hands out that staging (the HIP stages: pinned memory,
+    // uploaded with one copy when the arrays of the call lie inside it); the default is a plain vector.  nullptr = allocation failed.
+    virtual uint8_t *stage_scratch(size_t bytes) {
+        if (scratch_.size() < bytes) scratch_.resize(bytes + bytes / 2);
+        return scratch_.data();
+    }
     // Mapper::matchToMap on a flattened map (mapper.cpp:354-588); see alva_match_to_map_flags for the layout
     virtual int match_to_map(int cell_size, int num_cells_w, int grid_cells, const int *cell_ptr, const int *cell_mp, int n_kf,
                              const double *kf_q, const double *kf_t, int n_mp, const double *mp_wpt, const uint8_t *mp_is3d,
@@ -131,6 +146,9 @@ struct Stages {
     int image_width_ = 0, image_height_ = 0;
 
 protected:
+    std::vector<uint8_t> scratch_;
+    int det_cell_ = 0, det_n_occ_ = 0, det_cap_ = 0;
+    std::vector<float> det_occ_;
     // hand-over from the default track_begin to the default track_pose_collect
     struct PendingPose {
         bool active = false;

@@ -5,6 +5,7 @@
 // Host arrays cross into device memory through two bump arenas that are reset per call: a pinned host arena (staging both
 // ways, so every copy is asynchronous on the stream) and a device arena.  One stream synchronisation per method.
 #include "common.hpp"
+#include <algorithm>
 #include "camera_device.hpp"
 #include "pose_internal.hpp"
 #include "track_slots.hpp"
@@ -383,6 +384,9 @@ struct HipStages::Impl {
     }
     bool pose_pending = false;
     int pose_n = 0;
+    alva_detect_pending det_pending{};   // detect_begin -> detect_end
+    const uint8_t *det_h = nullptr;
+    int det_cap = 0;
     // a call plans its buffers first (sizes), then the arenas are grown once and carved
     struct Plan {
         std::vector<size_t> sizes;
@@ -1043,6 +1047,13 @@ int HipStages::five_point(int n, const double *bv_kf, const double *bv_cur, int 
 }
 
 int HipStages::detect(int cell, int n_occ, const float *occupied, int cap, float *pts, int *count) {
+    const int rc = detect_begin(cell, n_occ, occupied, cap);
+    return rc ? rc : detect_end(pts, count);
+}
+
+// the detector enqueued on the stream (all its launches + the copy of the whole output buffer back: the count is not known yet); the
+// map layer updates its descriptor medoids meanwhile
+int HipStages::detect_begin(int cell, int n_occ, const float *occupied, int cap) {
     Impl::Plan p;
     const size_t a = p.add((size_t) (n_occ > 0 ? n_occ : 1) * 8), b = p.add((size_t) cap * 8);
     std::vector<uint8_t *> d, h;
@@ -1052,15 +1063,20 @@ int HipStages::detect(int cell, int n_occ, const float *occupied, int cap, float
     const Camera &k = m->cam;
     const uint8_t *img = m->clahe ? m->d_eq : m->d_gray;  // detection runs on currImage_ (map_manager.cpp:213)
     // roi = CameraCalibration::roi_rect_ (camera_calibration.cpp:20): the image minus a border of 20 px
-    rc = alva_detect_grid(m->ctx, img, (size_t) k.width, k.width, k.height, cell, (const float *) d[a], n_occ, k.border, k.border,
-                          k.width - 2 * k.border, k.height - 2 * k.border, &m->max_quality, (float *) d[b], cap, count);
+    rc = alva_detect_grid_enqueue(m->ctx, img, (size_t) k.width, k.width, k.height, cell, (const float *) d[a], n_occ, k.border, k.border,
+                                  k.width - 2 * k.border, k.height - 2 * k.border, m->max_quality, (float *) d[b], cap, &m->det_pending);
     if (rc) return rc;
-    if (*count > cap) *count = cap;
-    if (*count > 0) {
-        DOWN(b, (size_t) *count * 8);
-        ALVA_HIP(hipStreamSynchronize(m->st));
-        memcpy(pts, h[b], (size_t) *count * 8);
-    }
+    m->det_h = h[b];
+    m->det_cap = cap;
+    if (cap > 0) DOWN(b, (size_t) cap * 8);
+    return ALVA_OK;
+}
+
+int HipStages::detect_end(float *pts, int *count) {
+    const int rc = alva_detect_grid_collect(m->ctx, &m->det_pending, &m->max_quality, count);   // waits for the stream: the copy above is done too
+    if (rc) return rc;
+    if (*count > m->det_cap) *count = m->det_cap;
+    if (*count > 0) memcpy(pts, m->det_h, (size_t) *count * 8);
     return ALVA_OK;
 }
 
@@ -1115,6 +1131,12 @@ int HipStages::triangulate(int n, int n_groups, const double *T36, const int *gr
     return ALVA_OK;
 }
 
+uint8_t *HipStages::stage_scratch(size_t bytes) {
+    // the call that follows carves [0, bytes) of both arenas: its arrays are already in place in the pinned one
+    if (m->dev.grow(bytes, m->st) != ALVA_OK || m->pin.grow(bytes, m->st) != ALVA_OK) return nullptr;
+    return m->pin.base;
+}
+
 int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, const int *cell_ptr, const int *cell_mp, int n_kf, const double *kf_q,
                             const double *kf_t, int n_mp, const double *mp_wpt, const uint8_t *mp_is3d, const uint8_t *mp_has_desc,
                             const int *obs_ptr, const int *obs_kf, const float *obs_px, const uint8_t *obs_desc, const uint8_t *obs_has_desc,
@@ -1122,6 +1144,42 @@ int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, cons
                             int *match_of_mp) {
     if (n_mp <= 0) return ALVA_OK;
     const int n_obs = obs_ptr[n_mp], n_cell = cell_ptr[grid_cells];
+    const Camera &k = m->cam;
+    const double calib[10] = {k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (double) k.width, (double) k.height};
+    // The map layer assembled the arrays in stage_scratch() (= the pinned arena): they go up with ONE copy of the span they cover and the
+    // kernels read the same offsets of the device arena; the matches come back into the caller's array, which lies in the span too.
+    const uint8_t *pb = m->pin.base, *pe = pb ? pb + m->pin.cap : nullptr;
+    const uint8_t *ptrs[] = {(const uint8_t *) cell_ptr, (const uint8_t *) cell_mp, (const uint8_t *) kf_q, (const uint8_t *) kf_t, (const uint8_t *) mp_wpt,
+                             mp_is3d, mp_has_desc, (const uint8_t *) obs_ptr, (const uint8_t *) obs_kf, (const uint8_t *) obs_px, obs_desc, obs_has_desc,
+                             (const uint8_t *) local, (const uint8_t *) match_of_mp};
+    const size_t lens[] = {(size_t) (grid_cells + 1) * 4, (size_t) n_cell * 4, (size_t) n_kf * 32, (size_t) n_kf * 24, (size_t) n_mp * 24, (size_t) n_mp,
+                           (size_t) n_mp, (size_t) (n_mp + 1) * 4, (size_t) n_obs * 4, (size_t) n_obs * 8, (size_t) n_obs * 32, (size_t) n_obs,
+                           (size_t) n_local * 4, (size_t) n_mp * 4};
+    bool in_place = pb != nullptr;
+    size_t lo = (size_t) -1, hi = 0;
+    for (int i = 0; i < 14 && in_place; i++) {
+        if (lens[i] == 0) continue;
+        if (ptrs[i] < pb || ptrs[i] + lens[i] > pe) in_place = false;
+        else {
+            if (i < 13) {   // inputs: the span to upload
+                lo = std::min(lo, (size_t) (ptrs[i] - pb));
+                hi = std::max(hi, (size_t) (ptrs[i] - pb) + lens[i]);
+            }
+        }
+    }
+    if (in_place && m->dev.cap >= m->pin.cap) {
+        auto dv = [&](const void *hp) { return m->dev.base + ((const uint8_t *) hp - pb); };
+        ALVA_HIP(hipMemcpyAsync(m->dev.base + lo, pb + lo, hi - lo, hipMemcpyHostToDevice, m->st));
+        int rc = alva_match_to_map_flags(m->ctx, calib, cell_size, num_cells_w, grid_cells, (const int *) dv(cell_ptr), (const int *) dv(cell_mp), n_kf,
+                                         (const double *) dv(kf_q), (const double *) dv(kf_t), n_mp, (const double *) dv(mp_wpt), dv(mp_is3d),
+                                         dv(mp_has_desc), (const int *) dv(obs_ptr), (const int *) dv(obs_kf), (const float *) dv(obs_px), dv(obs_desc),
+                                         dv(obs_has_desc), frame_kf, num_keypoints_3d, n_local, (const int *) dv(local), max_proj_err, dist_ratio,
+                                         (int *) dv(match_of_mp));
+        if (rc) return rc;
+        ALVA_HIP(hipMemcpyAsync(match_of_mp, dv(match_of_mp), (size_t) n_mp * 4, hipMemcpyDeviceToHost, m->st));
+        ALVA_HIP(hipStreamSynchronize(m->st));
+        return ALVA_OK;
+    }
     Impl::Plan p;
     const size_t icp = p.add((size_t) (grid_cells + 1) * 4), icm = p.add((size_t) (n_cell > 0 ? n_cell : 1) * 4), iq = p.add((size_t) n_kf * 32),
                  it = p.add((size_t) n_kf * 24), iw = p.add((size_t) n_mp * 24), i3 = p.add((size_t) n_mp), ihd = p.add((size_t) n_mp),
@@ -1144,8 +1202,6 @@ int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, cons
     UP(iod, obs_desc, (size_t) n_obs * 32);
     UP(ioh, obs_has_desc, (size_t) n_obs);
     UP(il, local, (size_t) n_local * 4);
-    const Camera &k = m->cam;
-    const double calib[10] = {k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (double) k.width, (double) k.height};
     rc = alva_match_to_map_flags(m->ctx, calib, cell_size, num_cells_w, grid_cells, (const int *) d[icp], (const int *) d[icm], n_kf,
                                  (const double *) d[iq], (const double *) d[it], n_mp, (const double *) d[iw], d[i3], d[ihd], (const int *) d[iop],
                                  (const int *) d[iok], (const float *) d[iox], d[iod], d[ioh], frame_kf, num_keypoints_3d, n_local,

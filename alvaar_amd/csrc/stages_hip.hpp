@@ -33,6 +33,8 @@ public:
     int five_point(int n, const double *bv_kf, const double *bv_cur, int do_random, double *R, double *t, int *outliers, int *n_outliers,
                    int *ok) override;
     int detect(int cell, int n_occ, const float *occupied, int cap, float *pts, int *count) override;
+    int detect_begin(int cell, int n_occ, const float *occupied, int cap) override;
+    int detect_end(float *pts, int *count) override;
     int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) override;
     int triangulate(int n, int n_groups, const double *T36, const int *group, const double *bv_l, const double *bv_r, const float *unpx_l,
                     const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status, double *parallax) override;
@@ -44,6 +46,7 @@ public:
                  double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters, double *chi2,
                  uint8_t *depth_pos) override;
     int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) override;
+    uint8_t *stage_scratch(size_t bytes) override;
 
 private:
     int build_from(const uint8_t *d_src);

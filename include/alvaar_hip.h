@@ -172,6 +172,19 @@ const int *alva_orb_device_count(const alva_orb *orb);
 int alva_detect_grid(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height,
                      int cell_size, const float *d_occupied, int n_occ, int roi_x, int roi_y, int roi_w,
                      int roi_h, double *h_max_quality, float *d_out_pts, int cap, int *h_count);
+/* The same call split at its only host wait: _enqueue launches the detection on the context's stream with the threshold `max_quality`
+ * and returns at once; _collect waits, reports the count and applies the adaptive-threshold rule (:138-145) to *h_max_quality.  The
+ * caller does host work in between (the map layer updates its descriptor medoids while the detector runs).  No other call on the
+ * context between the two. */
+typedef struct alva_detect_pending {
+    void *h_cnt;
+    int n_cells;
+    int reserved;
+} alva_detect_pending;
+int alva_detect_grid_enqueue(alva_ctx *ctx, const uint8_t *d_gray, size_t gray_pitch, int width, int height, int cell_size,
+                             const float *d_occupied, int n_occ, int roi_x, int roi_y, int roi_w, int roi_h, double max_quality,
+                             float *d_out_pts, int cap, alva_detect_pending *pending);
+int alva_detect_grid_collect(alva_ctx *ctx, const alva_detect_pending *pending, double *h_max_quality, int *h_count);
 
 /* ---- a7: Hamming brute-force matcher ----------------------------------------------------------
  * Replaces cv::BFMatcher(NORM_HAMMING).match(query, train) (core/src/batch_distance.cpp:199-251,
