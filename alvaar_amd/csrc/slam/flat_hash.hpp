@@ -50,6 +50,7 @@ public:
     void set_tag(int slot, uint8_t t) { slot_[(size_t) slot].tag = t; }
     // walks in MEMORY order, for loops whose result does not depend on the order: slot indices 0 .. slots() - 1, erased ones are not live
     size_t slots() const { return slot_.size(); }
+    const void *slot_storage() const { return slot_.data(); }   // for software prefetch
     bool slot_live(size_t slot) const { return slot_[slot].live != 0; }
 
     int find_slot(int k) const {  // slot or END
@@ -104,6 +105,17 @@ public:
         head_ = END;
         free_ = END;
         count_ = 0;
+    }
+
+    // a freshly constructed container (one bucket, policy reset) that keeps the arrays' capacity: for function-local containers of the
+    // reference that are rebuilt on every call
+    void reset() {
+        slot_.clear();
+        bkt_.assign(1, EMPTY);
+        head_ = END;
+        free_ = END;
+        count_ = 0;
+        pol_ = std::__detail::_Prime_rehash_policy();
     }
 
     // ---- the std::unordered_map spelling of the same operations, for code that reads like the reference's

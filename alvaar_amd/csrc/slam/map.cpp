@@ -364,7 +364,8 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     lap_det(t_kf[2]);
     if (n) {
         Lap lap;
-        for (int i = 0; i < n; i++)
+        for (int i = 0; i < n; i++) {
+            prefetch_mp_desc(kp_ids.data(), (size_t) i, (size_t) n);
             if (valid[(size_t) i]) {
                 Desc d;
                 __builtin_memcpy(d.b, &desc[(size_t) i * 32], 32);
@@ -374,6 +375,7 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
                 if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() in the reference (:233)
                 mp->add_desc(cur->kfid, d);
             }
+        }
         lap(t_kf[15]);
     }
     if (to_detect > 0) {
@@ -511,8 +513,12 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
 void Slam::remove_keyframe(int kfid) {  // map_manager.cpp:515-557
     auto it = keyframes.find(kfid);
     if (it == keyframes.end()) return;
-    for (const auto &e: it->second->kps) {  // the body edits map points only
-        MapPt *m = mp_raw(e.first);
+    std::vector<int> &ids = rm_ids_;   // the keyframe's ids in container order (the body edits map points only)
+    ids.clear();
+    it->second->for_each_id([&](int kid, bool) { ids.push_back(kid); });
+    for (size_t i = 0; i < ids.size(); i++) {
+        prefetch_mp_desc(ids.data(), i, ids.size());
+        MapPt *m = mp_raw(ids[i]);
         if (m) {
             m->remove_obs(kfid);
             m->drop_px(kfid);

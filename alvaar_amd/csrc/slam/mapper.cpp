@@ -424,7 +424,9 @@ void Slam::local_ba(FrameRec &new_frame) {
         }
     } undefer{this};
     defer_mp_free_ = true;
-    std::pmr::unordered_map<int, MapPt *> local_mps(&arena);                      // map_local_plms
+    // (the two big ones -- thousands of map points -- on flat arrays with libstdc++'s order, flat_hash.hpp; capacity kept between calls)
+    FlatHash<MapPt *> &local_mps = ba_scratch_.local_mps;                         // map_local_plms
+    local_mps.reset();
     std::pmr::unordered_map<int, std::shared_ptr<FrameRec>> local_kfs(&arena);    // map_local_pkfs
     // keyframe id -> row of the flat pose table / keyframe object: ids are small consecutive integers, so plain arrays beside the
     // reference's hash maps (which stay, because their iteration ORDER is behaviour, :234-247)
@@ -432,7 +434,9 @@ void Slam::local_ba(FrameRec &new_frame) {
     std::vector<FrameRec *> kf_flat((size_t) next_kf_id + 1, nullptr);
     std::vector<double> poses;
     std::vector<uint8_t> kf_const;
-    std::pmr::unordered_set<int> bad_mps(&arena), mps_to_opt(&arena), kfs_to_opt(&arena), const_kfs(&arena);
+    std::pmr::unordered_set<int> bad_mps(&arena), kfs_to_opt(&arena), const_kfs(&arena);
+    FlatSet &mps_to_opt = ba_scratch_.mps_to_opt;
+    mps_to_opt.reset();
     auto add_pose = [&](int kfid, const FrameRec &kf, bool constant) {
         pose_slot[(size_t) kfid] = (int) kf_const.size();
         double p[7];
@@ -483,8 +487,18 @@ void Slam::local_ba(FrameRec &new_frame) {
     std::vector<double> &pt_anchor_uv = bs.pt_anchor_uv, &pt_inv = bs.pt_inv, &obs_uv = bs.obs_uv;
     std::vector<ObsRec> &obs_rec = bs.obs_rec;
     pt_ids.clear(); pt_anchor_slot.clear(); obs_kf.clear(); obs_pt.clear(); pt_anchor_uv.clear(); pt_inv.clear(); obs_uv.clear(); obs_rec.clear();
-    std::pmr::unordered_map<int, int> pt_slot(&arena);  // map_id_invptspar_
-    ids_scratch_.assign(mps_to_opt.begin(), mps_to_opt.end());   // the set's order, as an array (for the prefetcher; the loop below does not edit the set)
+    // map_id_invptspar_ is only looked up by id: a persistent id -> slot table (mp_index_, all -1 between calls, see match_to_map)
+    std::vector<int> &pt_slot = mp_index_;
+    if (pt_slot.size() < (size_t) next_mp_id + 1) pt_slot.resize((size_t) next_mp_id + 1 + (size_t) next_mp_id / 2, -1);
+    struct ResetSlots {
+        std::vector<int> &index;
+        const std::vector<int> &ids;
+        ~ResetSlots() {
+            for (int id: ids) index[(size_t) id] = -1;
+        }
+    } reset_slots{pt_slot, pt_ids};
+    ids_scratch_.clear();
+    for (int id: mps_to_opt) ids_scratch_.push_back(id);   // the set's order, as an array (for the prefetcher; the loop below does not edit the set)
     for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
         const int lmid = ids_scratch_[oi];
         prefetch_mp(ids_scratch_.data(), oi, ids_scratch_.size());
@@ -494,7 +508,7 @@ void Slam::local_ba(FrameRec &new_frame) {
             bad_mps.insert(lmid);
             continue;
         }
-        local_mps.emplace(lmid, mp);
+        local_mps.insert_slot(lmid, mp);
         int anchor = -1, cur_slot = -1;
         std::vector<int> &obs = obs_scratch_;  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
         obs.assign(mp->obs_kfs.begin(), mp->obs_kfs.end());
@@ -530,7 +544,7 @@ void Slam::local_ba(FrameRec &new_frame) {
                 double pc[3];
                 se3_apply(kf->Tcw, mp->X, pc);
                 cur_slot = (int) pt_ids.size();
-                pt_slot.emplace(lmid, cur_slot);
+                pt_slot[(size_t) lmid] = cur_slot;
                 pt_ids.push_back(lmid);
                 pt_anchor_slot.push_back(pose_slot[(size_t) kfid]);
                 pt_anchor_uv.push_back((double) kp->unpx[0]);
@@ -641,9 +655,9 @@ void Slam::local_ba(FrameRec &new_frame) {
         const int ps = pose_slot[(size_t) e.first];
         if (ps >= 0) e.second->set_Twc(se3_from_pose7(&poses[7 * (size_t) ps]));
     }
-    for (const auto &e: local_mps) {
-        const int lmid = e.first;
-        MapPt *mp = e.second;
+    for (int ls = local_mps.first(); ls != FlatHash<MapPt *>::END; ls = local_mps.next(ls)) {
+        const int lmid = local_mps.key(ls);
+        MapPt *mp = local_mps.val(ls);
         if (!mp) {
             bad_mps.erase(lmid);
             continue;
@@ -660,12 +674,12 @@ void Slam::local_ba(FrameRec &new_frame) {
                 continue;
             }
         }
-        auto ps = pt_slot.find(lmid);
-        if (ps == pt_slot.end()) {
+        const int ps = pt_slot[(size_t) lmid];
+        if (ps < 0) {
             bad_mps.insert(lmid);
             continue;
         }
-        const double inv = pt_inv[(size_t) ps->second], zanch = 1. / inv;
+        const double inv = pt_inv[(size_t) ps], zanch = 1. / inv;
         if (zanch <= 0.) {
             remove_map_point(lmid);
             bad_mps.erase(lmid);
@@ -692,8 +706,8 @@ void Slam::local_ba(FrameRec &new_frame) {
     }
     lap_ba(t_kf[13]);
     for (int lmid: bad_mps) {  // :492-530
-        auto lm = local_mps.find(lmid);
-        MapPt *mp = lm == local_mps.end() ? mp_raw(lmid) : lm->second;
+        const int lm = local_mps.find_slot(lmid);
+        MapPt *mp = lm == FlatHash<MapPt *>::END ? mp_raw(lmid) : local_mps.val(lm);
         if (!mp) continue;
         if (mp->is_bad()) {
             remove_map_point(lmid);

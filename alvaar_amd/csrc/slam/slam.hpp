@@ -374,7 +374,7 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
-    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_, kf_ids_scratch_, local_scratch_;
+    std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_, kf_ids_scratch_, local_scratch_, rm_ids_;
     // flat "seen" marks over map point ids (ids are dense, handed out consecutively): inserting a key that is already in a hash set does
     // not change the set, so duplicate inserts are filtered with a byte look-up instead of a hash look-up
     std::vector<uint8_t> mark_a_, mark_b_;
@@ -429,6 +429,28 @@ private:
             }
         }
     }
+    // the same for loops that run the descriptor-medoid update of every visited map point (addDesc / removeObservedKeyframeId read the
+    // whole descriptor table: ~48 bytes per observing keyframe)
+    void prefetch_mp_desc(const int *ids, size_t i, size_t n, size_t near_d = 4, size_t far_d = 10) const {
+        if (i + far_d < n) {
+            const MapPt *f = mp_raw(ids[i + far_d]);
+            if (f) {
+                __builtin_prefetch(f);
+                __builtin_prefetch((const char *) f + 64);
+                __builtin_prefetch((const char *) f + 128);
+            }
+        }
+        if (i + near_d < n) {
+            const MapPt *m = mp_raw(ids[i + near_d]);
+            if (m) {
+                const char *t = (const char *) m->kf_desc.slot_storage();
+                const size_t bytes = m->kf_desc.slots() * 48;
+                for (size_t o = 0; o < bytes && o < 1024; o += 64) __builtin_prefetch(t + o);
+                __builtin_prefetch(m->seen.data());
+                __builtin_prefetch(m->obs_kfs.v.data());
+            }
+        }
+    }
     FrameRec *kf_raw(int id) const { return id >= 0 && (size_t) id < kf_flat_.size() ? kf_flat_[(size_t) id] : nullptr; }
     MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
     std::vector<FrameRec *> kf_flat_;
@@ -447,6 +469,8 @@ private:
         std::vector<double> pt_anchor_uv, pt_inv, obs_uv, ouv, chi2, pauv, pinv;
         std::vector<ObsRec> obs_rec;
         std::vector<uint8_t> alive, kf_used, kc, dpos;
+        FlatHash<MapPt *> local_mps;
+        FlatSet mps_to_opt;
     } ba_scratch_;
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
     std::vector<std::shared_ptr<MapPt>> mp_graveyard_;

@@ -218,69 +218,97 @@ __global__ void __launch_bounds__(TRK_NT) k_track_finish(TrackDev D) {
 // The slot-wise step (track_slots.hpp): after the tracker launches every slot holds its verdict, position, undistorted position and
 // bearing; what is left is the list of the pose solve -- the tracked 3-D slots in slot order (visual_frontend.cpp:275-298) -- the
 // header, and the counters' reset for the next frame.
-__global__ void __launch_bounds__(TRK_NT) k_track_compact(TrackSlots D) {
-    // up to CH * 1024 slots in ONE round: every thread takes its CH slots' flags first (the loads of all chunks in flight together), the
-    // per-wave counts of all chunks are scanned once, then the gathers run; more slots (a 4K frame) take further rounds of the same
-    constexpr int CH = 4;
-    __shared__ int s_cnt[CH * (TRK_NT / 64) + 1];
+constexpr int CMP_NT = 256, CMP_MAX_WG = 32;
+__global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) {
+    // SEVERAL workgroups (one used to do all of it: 107 KB to the host + 145 KB of gathers through one compute unit took 23 us).
+    // Every workgroup owns a contiguous slice of the slots.  It counts the pose flags of the slots in front of its slice by itself
+    // (2 bytes per slot: cheaper than a cross-workgroup scan), copies its slice's results to pinned host memory and gathers its slice's
+    // correspondences.  Ordering against the completion word: every workgroup ends with a system-scope fence and an arrival on a device
+    // counter; the workgroup that arrives LAST writes the header and then the word (system-scope release) -- the host reads the word
+    // with acquire semantics, so it sees every slice.
+    __shared__ int s_cnt[CMP_NT / 64 + 1];
+    const int G = (int) gridDim.x, g = (int) blockIdx.x;
+    const int per = ((D.n + G - 1) / G + 63) / 64 * 64;   // slice length, a multiple of the wave size
+    const int lo = g * per, hi = min(D.n, lo + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pose flags in front of the slice (and, for the header, behind it): ballot counts
+    int before = 0, total = 0;
+    for (int i0 = 0; i0 < D.n; i0 += CMP_NT) {
+        const int i = i0 + (int) threadIdx.x;
+        const bool f = i < D.n && D.d_code[i] != 0 && D.d_is3d[i] != 0;
+        const unsigned long long bal = __ballot(f);
+        const int wbase = i0 + wave * 64;
+        if (lane == 0) {
+            const int c = __popcll(bal);
+            total += c;
+            if (wbase + 64 <= lo) before += c;
+            else if (wbase < lo) before += __popcll(bal & ((1ull << (lo - wbase)) - 1ull));   // (lo is a multiple of 64: never taken)
+        }
+    }
+    if (lane == 0) s_cnt[wave] = before;
+    __syncthreads();
     int base = 0;
-    for (int r0 = 0; r0 < D.n; r0 += CH * TRK_NT) {
-        bool pose[CH];
-        int within[CH];
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int i = r0 + c * TRK_NT + (int) threadIdx.x;
-            uint8_t code = 0;
-            if (i < D.n) {   // the slot's results to the host, from THIS kernel (see track_slots.hpp)
-                code = D.d_code[i];
-                const size_t j = (size_t) i;
-                D.o_code[i] = code;
-                D.o_px[2 * j] = D.d_px[2 * j]; D.o_px[2 * j + 1] = D.d_px[2 * j + 1];
-                D.o_unpx[2 * j] = D.d_unpx[2 * j]; D.o_unpx[2 * j + 1] = D.d_unpx[2 * j + 1];
-                D.o_bv[3 * j] = D.d_bv[3 * j]; D.o_bv[3 * j + 1] = D.d_bv[3 * j + 1]; D.o_bv[3 * j + 2] = D.d_bv[3 * j + 2];
-            }
-            pose[c] = i < D.n && code != 0 && D.d_is3d[i] != 0;
+    for (int w = 0; w < CMP_NT / 64; w++) base += s_cnt[w];
+    __syncthreads();
+    if (lane == 0) s_cnt[wave] = total;
+    __syncthreads();
+    int n_pose = 0;
+    for (int w = 0; w < CMP_NT / 64; w++) n_pose += s_cnt[w];
+    __syncthreads();
+    for (int i0 = lo; i0 < hi; i0 += CMP_NT) {
+        const int i = i0 + (int) threadIdx.x;
+        uint8_t code = 0;
+        bool pose = false;
+        float px[2] = {0, 0}, ux[2] = {0, 0};
+        double bv[3] = {0, 0, 0};
+        if (i < hi) {   // the slot's results to the host, from THIS kernel (see track_slots.hpp)
+            const size_t j = (size_t) i;
+            code = D.d_code[i];
+            px[0] = D.d_px[2 * j]; px[1] = D.d_px[2 * j + 1];
+            ux[0] = D.d_unpx[2 * j]; ux[1] = D.d_unpx[2 * j + 1];
+            bv[0] = D.d_bv[3 * j]; bv[1] = D.d_bv[3 * j + 1]; bv[2] = D.d_bv[3 * j + 2];
+            D.o_code[i] = code;
+            D.o_px[2 * j] = px[0]; D.o_px[2 * j + 1] = px[1];
+            D.o_unpx[2 * j] = ux[0]; D.o_unpx[2 * j + 1] = ux[1];
+            D.o_bv[3 * j] = bv[0]; D.o_bv[3 * j + 1] = bv[1]; D.o_bv[3 * j + 2] = bv[2];
+            pose = code != 0 && D.d_is3d[i] != 0;
         }
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const unsigned long long b = __ballot(pose[c]);
-            within[c] = __popcll(b & ((1ull << lane) - 1ull));
-            if (lane == 0) s_cnt[c * (TRK_NT / 64) + wave] = __popcll(b);
-        }
+        const unsigned long long bal = __ballot(pose);
+        if (lane == 0) s_cnt[wave] = __popcll(bal);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int acc = base;
-            for (int q = 0; q < CH * (TRK_NT / 64); q++) {
-                const int v = s_cnt[q];
-                s_cnt[q] = acc;
-                acc += v;
-            }
-            s_cnt[CH * (TRK_NT / 64)] = acc;
+        int wofs = 0, all = 0;
+        for (int w = 0; w < CMP_NT / 64; w++) {
+            if (w < wave) wofs += s_cnt[w];
+            all += s_cnt[w];
         }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CH; c++)
-            if (pose[c]) {
-                const size_t k = (size_t) (s_cnt[c * (TRK_NT / 64) + wave] + within[c]), j = (size_t) (r0 + c * TRK_NT + (int) threadIdx.x);
-                D.Pbv[3 * k] = D.d_bv[3 * j]; D.Pbv[3 * k + 1] = D.d_bv[3 * j + 1]; D.Pbv[3 * k + 2] = D.d_bv[3 * j + 2];
-                D.Puv[2 * k] = (double) D.d_unpx[2 * j]; D.Puv[2 * k + 1] = (double) D.d_unpx[2 * j + 1];
-                D.Pwpt[3 * k] = D.d_wpt[3 * j]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * j + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * j + 2];
-            }
-        base = s_cnt[CH * (TRK_NT / 64)];
+        if (pose) {
+            const size_t k = (size_t) (base + wofs + __popcll(bal & ((1ull << lane) - 1ull))), j = (size_t) i;
+            D.Pbv[3 * k] = bv[0]; D.Pbv[3 * k + 1] = bv[1]; D.Pbv[3 * k + 2] = bv[2];
+            D.Puv[2 * k] = (double) ux[0]; D.Puv[2 * k + 1] = (double) ux[1];
+            D.Pwpt[3 * k] = D.d_wpt[3 * j]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * j + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * j + 2];
+        }
+        base += all;
         __syncthreads();
     }
-    __threadfence_system();   // this thread's writes to the host ...
-    __syncthreads();          // ... of every thread, before the header and the completion word
+    __threadfence_system();   // this thread's writes to the host (and the device) ...
+    __syncthreads();          // ... of every thread of the workgroup, before its arrival
     if (threadIdx.x == 0) {
-        const int nA = D.cnt[0], good = D.cnt[1];
-        const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
-        D.o_hdr[0] = nA; D.o_hdr[1] = D.n - nA; D.o_hdr[2] = D.n - good; D.o_hdr[3] = good; D.o_hdr[4] = req ? 1 : 0; D.o_hdr[5] = base;
-        D.cnt[0] = 0;
-        D.cnt[1] = 0;
-        __threadfence_system();
-        __hip_atomic_store(D.o_hdr + 8, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const int arrived = __hip_atomic_fetch_add(D.cnt + 8, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == G - 1) {   // last: every slice is out
+            const int nA = D.cnt[0], good = D.cnt[1];
+            const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
+            D.o_hdr[0] = nA; D.o_hdr[1] = D.n - nA; D.o_hdr[2] = D.n - good; D.o_hdr[3] = good; D.o_hdr[4] = req ? 1 : 0; D.o_hdr[5] = n_pose;
+            D.cnt[0] = 0;
+            D.cnt[1] = 0;
+            D.cnt[8] = 0;
+            __threadfence_system();
+            __hip_atomic_store(D.o_hdr + 8, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+}
+static inline int compact_grid(int n) {   // ~256 slots per workgroup
+    const int g = (n + 255) / 256;
+    return g < 1 ? 1 : g > CMP_MAX_WG ? CMP_MAX_WG : g;
 }
 
 struct Arena {
@@ -788,7 +816,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
         if (rc) return rc;
         D.seq = ++m->trk_seq;
-        hipLaunchKernelGGL(k_track_compact, dim3(1), dim3(TRK_NT), 0, m->st, D);
+        hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
         ALVA_LAUNCH_CHECK();
         poll_seq = m->poll ? D.seq : 0;
         slots_D = D;
@@ -869,7 +897,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         rc = alva_track_slots_klt(m->ctx, prev, cur, slots_D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 1);
         if (rc) return rc;
         slots_D.seq = ++m->trk_seq;
-        hipLaunchKernelGGL(k_track_compact, dim3(1), dim3(TRK_NT), 0, m->st, slots_D);
+        hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(slots_D.n)), dim3(CMP_NT), 0, m->st, slots_D);
         ALVA_LAUNCH_CHECK();
         rc = wait_step(m->poll ? slots_D.seq : 0);
         if (rc) return rc;
