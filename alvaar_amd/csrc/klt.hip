@@ -399,10 +399,6 @@ __global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D
         }
     }
     const int ok = fbklt_value(sh, P, C, from_prior ? maxLevelPrior : maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
-    if (threadIdx.x == 0 && from_prior) {
-        atomicAdd(D.cnt + 0, 1);
-        if (ok) atomicAdd(D.cnt + 1, 1);
-    }
     int code = ok ? (from_prior ? 1 : 2) : 0;
     if (from_prior && !ok) {  // full-pyramid retry from where the forward tracker left the keypoint (:185-190)
         const int ok2 = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
@@ -410,6 +406,22 @@ __global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D
     }
     if (threadIdx.x == 0) D.d_retried[i] = (uint8_t) (from_prior && !ok);
     track_slot_store(D, i, code, nx, ny);
+    if (threadIdx.x == 0) {
+        // ONE atomic per slot on the packed counter (track_slots.hpp).  Its return value tells the last slot of the launch that it is
+        // the last, and hands it every count: it publishes them to the host right away -- nothing but the atomic's own result is read,
+        // so no fence is needed in front of the arrival.
+        const unsigned long long add = (1ull << 48) | ((unsigned long long) (code != 0 && is3 != 0) << 32) |
+                                       ((unsigned long long) (from_prior ? 1 : 0) << 16) | (unsigned long long) (from_prior && ok ? 1 : 0);
+        const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long *>(D.cnt) + 2, add);
+        const unsigned long long now = before + add;
+        if ((int) (now >> 48) == D.n) {
+            const int n_pose = (int) ((now >> 32) & 0xffff), nA = (int) ((now >> 16) & 0xffff), good = (int) (now & 0xffff);
+            D.o_hdr[10] = n_pose; D.o_hdr[11] = nA; D.o_hdr[12] = good;
+            D.o_hdr[13] = nA > 0 && (double) good < 0.33 * (double) nA ? 1 : 0;
+            __threadfence_system();
+            __hip_atomic_store(D.o_hdr + 9, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(64) k_track_klt_retry(LkPyr P, LkPyr C, TrackSlots D, int maxLevelFull, int maxCount, double epsilon,

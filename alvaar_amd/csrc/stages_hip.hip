@@ -295,11 +295,11 @@ __global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) {
     if (threadIdx.x == 0) {
         const int arrived = __hip_atomic_fetch_add(D.cnt + 8, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == G - 1) {   // last: every slice is out
-            const int nA = D.cnt[0], good = D.cnt[1];
+            const unsigned long long packed = reinterpret_cast<unsigned long long *>(D.cnt)[2];   // the tracker launch's counts (track_slots.hpp)
+            const int nA = (int) ((packed >> 16) & 0xffff), good = (int) (packed & 0xffff);
             const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
             D.o_hdr[0] = nA; D.o_hdr[1] = D.n - nA; D.o_hdr[2] = D.n - good; D.o_hdr[3] = good; D.o_hdr[4] = req ? 1 : 0; D.o_hdr[5] = n_pose;
-            D.cnt[0] = 0;
-            D.cnt[1] = 0;
+            reinterpret_cast<unsigned long long *>(D.cnt)[2] = 0ull;
             D.cnt[8] = 0;
             __threadfence_system();
             __hip_atomic_store(D.o_hdr + 8, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -408,6 +408,7 @@ struct HipStages::Impl {
         // stream is idle here (both grows synchronised it), so a plain host store cannot race a kernel's publication.
         ALVA_HIP(hipStreamSynchronize(st));
         track_pin().o_hdr[8] = 0;
+        track_pin().o_hdr[9] = 0;
         return ALVA_OK;
     }
     bool pose_pending = false;
@@ -813,9 +814,9 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.cam = AlvaCam{k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2};
         D.invK = m->d_invK;
         // state.hpp:50-56 constants; the prior pass works on one pyramid level (visual_frontend.cpp:166)
+        D.seq = ++m->trk_seq;   // the tracker launch publishes its counts under this number too (o_hdr[9])
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
         if (rc) return rc;
-        D.seq = ++m->trk_seq;
         hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
         ALVA_LAUNCH_CHECK();
         poll_seq = m->poll ? D.seq : 0;
@@ -888,6 +889,24 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         }
         return ALVA_OK;
     };
+    // The tracker launch's last workgroup has published the step's counts one kernel EARLIER (o_hdr[9..13], track_slots.hpp): in the
+    // normal case (no p3pReq_) the pose solve is enqueued NOW -- host-side sample draw + two launches, queued behind the compaction
+    // kernel in stream order -- instead of after the compaction's completion word: the GPU goes from the compaction straight into P3P.
+    bool pose_early = false;
+    const int n_pose_cap = 19000;   // P3P-LMedS keeps its median in LDS: at most 19000 correspondences (the first ones, in slot order)
+    if (slots_path && poll_seq && job.want_pose) {
+        const volatile int *early = o_hdr + 9;
+        unsigned spins = 0;
+        while (*early != poll_seq && ++spins < (1u << 26)) __builtin_ia32_pause();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (*early == poll_seq && !o_hdr[13] && o_hdr[10] >= 4) {
+            m->pose_n = o_hdr[10] > n_pose_cap ? n_pose_cap : o_hdr[10];
+            rc = alva_compute_pose_enqueue(m->ctx, Pbv, Puv, Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
+                                           (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
+            if (rc) return rc;
+            pose_early = true;
+        }
+    }
     rc = wait_step(poll_seq);
     if (rc) return rc;
     int p3p_req = o_hdr[4];
@@ -908,9 +927,14 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     out.bv_v = o_bv;
     out.p3p_req = p3p_req;
     out.n_pose = o_hdr[5];
-    if (job.want_pose && out.n_pose >= 4) {
-        // P3P-LMedS keeps its median in LDS: at most 19000 correspondences (the first ones, in slot order, when a frame has more)
-        m->pose_n = out.n_pose > 19000 ? 19000 : out.n_pose;
+    if (pose_early) {
+        if (p3p_req || out.n_pose != o_hdr[10]) {   // cannot happen: both kernels count the same flags
+            alva_set_error("tracking step: the tracker's early counts (%d) disagree with the compaction (%d)", o_hdr[10], out.n_pose);
+            return ALVA_ERR_STATE;
+        }
+        m->pose_pending = true;
+    } else if (job.want_pose && out.n_pose >= 4) {
+        m->pose_n = out.n_pose > n_pose_cap ? n_pose_cap : out.n_pose;
         rc = alva_compute_pose_enqueue(m->ctx, Pbv, Puv, Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
                                        (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
         if (rc) return rc;

@@ -25,7 +25,10 @@ struct TrackSlots {
     double q[4], t[3];         // T_cw (predicted)
     AlvaCam cam;
     const double *invK;        // device, 9
-    int *cnt;                  // device: [0] slots tracked from their projection, [1] of those, successes (zeroed by the compaction kernel)
+    int *cnt;                  // device, 256 bytes, zeroed by the compaction kernel.  (unsigned long long *) cnt + 2 = the tracker launch's ONE
+                               // packed counter: arrivals << 48 | tracked 3-D slots << 32 | slots tracked from their projection << 16 |
+                               // successes of those (one atomic per workgroup; counts fit 16 bits: a frame holds < 65536 slots);
+                               // cnt[8] = the compaction kernel's arrival counter
     float *d_pts;              // [n][2] device copies of the three inputs (one coalesced pass over the bus; a workgroup per slot reading
                                // its 33 bytes from host memory by itself is bound by the number of outstanding PCIe reads)
     uint8_t *d_code;           // per slot: 0 lost | 1 tracked from the projection | 2 tracked on the full pyramid | 3 re-tracked
@@ -38,6 +41,9 @@ struct TrackSlots {
     double *o_bv;
     int *o_hdr;
     int seq;                   // written to o_hdr[8] (system scope) after everything else: the host may poll it instead of waiting on the stream
+                               // o_hdr[10..13] + word o_hdr[9]: the tracker's counts, published by the LAST workgroup of the tracker launch
+                               // itself -- the host learns the size of the pose problem one kernel earlier and enqueues the pose solve
+                               // (sample draw + two launches) while the compaction kernel runs
     double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
 };
 
