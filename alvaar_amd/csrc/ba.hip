@@ -991,10 +991,14 @@ struct BaHost {
         B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
         B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
         // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
-        order.assign((size_t) n_obs, 0);
+        order.resize((size_t) n_obs);
         std::vector<int> pairKey((size_t) n_obs);
         for (size_t p2 = 0; p2 <= nPt; p2++) h_ptPtr[p2] = 0;
-        {
+        bool grouped = true;   // the map layer hands the observations over point by point already: then the sort is the identity
+        for (int o = 1; o < n_obs && grouped; o++) grouped = in.h_obs_pt[o] >= in.h_obs_pt[o - 1];
+        if (grouped) {
+            for (int o = 0; o < n_obs; o++) order[(size_t) o] = o;
+        } else {
             std::vector<int> cursor((size_t) n_pt + 1, 0);
             for (int o = 0; o < n_obs; o++) cursor[(size_t) in.h_obs_pt[o] + 1]++;
             for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];

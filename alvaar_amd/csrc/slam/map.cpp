@@ -388,8 +388,7 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
             std::vector<uint8_t> desc((size_t) count * 32), valid((size_t) count);
             std::vector<float> unpx((size_t) count * 2);
             std::vector<double> bv((size_t) count * 3);
-            if (fail(st->describe(count, np.data(), desc.data(), valid.data()))) return;
-            if (fail(st->compute_keypoints(count, np.data(), unpx.data(), bv.data()))) return;
+            if (fail(st->describe_and_compute(count, np.data(), desc.data(), valid.data(), unpx.data(), bv.data()))) return;
             lap(t_kf[3]);
             Lap fine;
             t_fine[26] += (double) count;

@@ -114,6 +114,13 @@ struct Stages {
     // FeatureExtractor::describeFeaturePoints(imageRaw, pts) (map_manager.cpp:204, :218) on the current RAW gray image
     virtual int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) = 0;
 
+    // describe() + compute_keypoints() of the SAME points in one call (MapManager::addKeypointsToFrame needs both for the detector's new
+    // points, map_manager.cpp:166-191 / :218): the default composes the two; an implementation with a device round trip per call saves one
+    virtual int describe_and_compute(int n, const float *pts, uint8_t *desc, uint8_t *valid, float *unpx, double *bv) {
+        const int rc = describe(n, pts, desc, valid);
+        return rc ? rc : compute_keypoints(n, pts, unpx, bv);
+    }
+
     // per-keypoint arithmetic of Mapper::triangulateTemporal (mapper.cpp:222-287); see alva_triangulate
     virtual int triangulate(int n, int n_groups, const double *T36, const int *group, const double *bv_l, const double *bv_r,
                             const float *unpx_l, const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status,

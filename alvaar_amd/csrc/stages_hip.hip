@@ -441,6 +441,16 @@ struct HipStages::Impl {
         }
         return ALVA_OK;
     }
+    // planned buffers i0 .. i1 (consecutive in both arenas, same offsets) with ONE copy command instead of one per buffer: a copy
+    // command costs ~5 us of host time and ~5-10 us of queue latency, and the small keyframe stages issued 4 - 10 of them each
+    int up_span(const Plan &p, const std::vector<uint8_t *> &d, const std::vector<uint8_t *> &h, size_t i0, size_t i1) {
+        ALVA_HIP(hipMemcpyAsync(d[i0], h[i0], (size_t) (h[i1] - h[i0]) + p.sizes[i1], hipMemcpyHostToDevice, st));
+        return ALVA_OK;
+    }
+    int down_span(const Plan &p, const std::vector<uint8_t *> &d, const std::vector<uint8_t *> &h, size_t i0, size_t i1) {
+        ALVA_HIP(hipMemcpyAsync(h[i0], d[i0], (size_t) (h[i1] - h[i0]) + p.sizes[i1], hipMemcpyDeviceToHost, st));
+        return ALVA_OK;
+    }
 };
 
 #define UP(i, src, bytes)                                                                         \
@@ -1004,8 +1014,8 @@ int HipStages::compute_keypoints(int n, const float *px, float *unpx, double *bv
     if (rc) return rc;
     hipLaunchKernelGGL(k_bearing, dim3(alva_divup(n, 256)), dim3(256), 0, m->st, (const float *) d[b], n, m->d_invK, (double *) d[c]);
     ALVA_LAUNCH_CHECK();
-    DOWN(b, (size_t) n * 8);
-    DOWN(c, (size_t) n * 24);
+    rc = m->down_span(p, d, h, b, c);
+    if (rc) return rc;
     ALVA_HIP(hipStreamSynchronize(m->st));
     memcpy(unpx, h[b], (size_t) n * 8);
     memcpy(bv, h[c], (size_t) n * 24);
@@ -1142,11 +1152,36 @@ int HipStages::describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) 
     UP(a, pts, (size_t) n * 8);
     rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) d[a], n, d[b], d[c]);
     if (rc) return rc;
-    DOWN(b, (size_t) n * 32);
-    DOWN(c, (size_t) n);
+    rc = m->down_span(p, d, h, b, c);
+    if (rc) return rc;
     ALVA_HIP(hipStreamSynchronize(m->st));
     memcpy(desc, h[b], (size_t) n * 32);
     memcpy(valid, h[c], (size_t) n);
+    return ALVA_OK;
+}
+
+int HipStages::describe_and_compute(int n, const float *pts, uint8_t *desc, uint8_t *valid, float *unpx, double *bv) {
+    if (n <= 0) return ALVA_OK;
+    Impl::Plan p;
+    const size_t a = p.add((size_t) n * 8), b = p.add((size_t) n * 32), c = p.add((size_t) n), u = p.add((size_t) n * 8), v = p.add((size_t) n * 24);
+    std::vector<uint8_t *> d, h;
+    int rc = m->carve(p, d, h);
+    if (rc) return rc;
+    UP(a, pts, (size_t) n * 8);
+    rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) d[a], n, d[b], d[c]);
+    if (rc) return rc;
+    const Camera &k = m->cam;
+    rc = alva_undistort_points(m->ctx, (const float *) d[a], n, k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (float *) d[u]);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bearing, dim3(alva_divup(n, 256)), dim3(256), 0, m->st, (const float *) d[u], n, m->d_invK, (double *) d[v]);
+    ALVA_LAUNCH_CHECK();
+    rc = m->down_span(p, d, h, b, v);   // descriptors | validity | undistorted positions | bearings: one copy back, one wait
+    if (rc) return rc;
+    ALVA_HIP(hipStreamSynchronize(m->st));
+    memcpy(desc, h[b], (size_t) n * 32);
+    memcpy(valid, h[c], (size_t) n);
+    memcpy(unpx, h[u], (size_t) n * 8);
+    memcpy(bv, h[v], (size_t) n * 24);
     return ALVA_OK;
 }
 
@@ -1160,21 +1195,21 @@ int HipStages::triangulate(int n, int n_groups, const double *T36, const int *gr
     std::vector<uint8_t *> d, h;
     int rc = m->carve(p, d, h);
     if (rc) return rc;
-    UP(iT, T36, (size_t) n_groups * 288);
-    UP(ig, group, (size_t) n * 4);
-    UP(il, bv_l, (size_t) n * 24);
-    UP(ir, bv_r, (size_t) n * 24);
-    UP(iul, unpx_l, (size_t) n * 8);
-    UP(iur, unpx_r, (size_t) n * 8);
+    memcpy(h[iT], T36, (size_t) n_groups * 288);
+    memcpy(h[ig], group, (size_t) n * 4);
+    memcpy(h[il], bv_l, (size_t) n * 24);
+    memcpy(h[ir], bv_r, (size_t) n * 24);
+    memcpy(h[iul], unpx_l, (size_t) n * 8);
+    memcpy(h[iur], unpx_r, (size_t) n * 8);
+    rc = m->up_span(p, d, h, iT, iur);
+    if (rc) return rc;
     const Camera &k = m->cam;
     rc = alva_triangulate(m->ctx, n, (const double *) d[iT], n_groups, (const int *) d[ig], (const double *) d[il], (const double *) d[ir],
                           (const float *) d[iul], (const float *) d[iur], k.fx, k.fy, k.cx, k.cy, 3.0f /* mapMaxReprojectionError_ */,
                           (double *) d[ilp], (double *) d[iw], (double *) d[iid], d[ist], (double *) d[ipar]);
     if (rc) return rc;
-    DOWN(iw, (size_t) n * 24);
-    DOWN(iid, (size_t) n * 8);
-    DOWN(ist, (size_t) n);
-    DOWN(ipar, (size_t) n * 8);
+    rc = m->down_span(p, d, h, iw, ipar);
+    if (rc) return rc;
     ALVA_HIP(hipStreamSynchronize(m->st));
     memcpy(wpt, h[iw], (size_t) n * 24);
     memcpy(inv_depth, h[iid], (size_t) n * 8);

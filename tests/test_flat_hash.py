@@ -1,0 +1,16 @@
+"""CPU: FlatHash (alvaar_amd/csrc/slam/flat_hash.hpp) -- the map layer's keypoint tables, local maps and descriptor tables -- iterates in
+exactly libstdc++'s std::unordered_map / std::unordered_set order.  The reference's numerics depend on that order (P3P sample indices,
+matchToMap ties, the local BA's gauge, the descriptor medoid: SURVEY.md 8c "canonicalise ... because unordered_map order leaks"), so the
+emulation is driven side by side with the REAL containers through random operation sequences -- inserts across many rehashes, erases by
+key and by iterator, clears (bucket count kept), copies, swaps, range inserts -- and compared after every step (tests/cpp/flat_hash_vs_std.cpp)."""
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_flat_hash_iterates_like_libstdcxx(tmp_path):
+    exe = tmp_path / "flat_hash_vs_std"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", str(exe), str(ROOT / "tests" / "cpp" / "flat_hash_vs_std.cpp")])
+    out = subprocess.check_output([str(exe), "10"], text=True)
+    assert out.startswith("ok ") and int(out.split()[1]) > 300000, out

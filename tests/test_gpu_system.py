@@ -13,7 +13,7 @@ The two-view initialisation is OpenGV's forward-difference refinement working at
 on one input bearing moves the reference's own result by up to 1e-4), so the pose it returns cannot be reproduced to 1e-5 by ANY other
 build of the same algorithm.  The tests therefore (a) compare the initialisation pose at 5e-3 and (b) start both maps from the
 reference's two-view pose (alva_system_debug_set_init_pose) for the 1e-5 comparison of everything that follows; a run WITHOUT the
-hook is compared as well (same discrete trajectory over 100 frames, poses to 2e-2, pixels to 0.2)."""
+hook is compared as well (same discrete trajectory over 160 frames, raw poses to 1e-3, after a Sim(3) alignment to 1e-4, pixels to 0.1)."""
 import numpy as np
 import pytest
 
@@ -21,9 +21,10 @@ from alvaar_amd import synth
 import sysdiff
 
 pytestmark = [pytest.mark.gpu, pytest.mark.ref]
-# the unhooked run after Sim(3) alignment (measured on MI355X): what is left is NOT gauge -- the two-view pose's
-# rotation / translation-direction trade-off on a near-planar scene is a real (if tiny) difference of the reconstruction
-ALIGNED_TOL = 5e-3
+# the unhooked run after Sim(3) alignment of the trajectories (gauge rotation from the orientations, scale + translation from the camera
+# centres): measured on MI355X 3.6e-5 of the trajectory's extent (centres) and 1.1e-5 rad (rotations), scale 1.0000064 -- most of the raw
+# difference (RMSE 3.7e-5, worst 1.6e-4) IS gauge; what is left is the two-view pose's noise floor
+ALIGNED_TOL = 1e-4
 
 
 def _reference_run(frames, w, h, cell, reset_at=(), **kw):
@@ -112,13 +113,13 @@ def test_system_equals_reference_150_frames():
 def test_system_equals_reference_without_the_hook():
     """the same stream with the map started from OUR OWN five-point result (no alva_system_debug_set_init_pose): identical DISCRETE
     state on every one of 160 frames (statuses, counters, keypoint ids in container order, keyframes, map tables, medoids).  The two maps
-    start from two-view poses that differ at OpenGV's refinement noise floor, so the raw poses are compared at that
-    floor (2e-2) and, because part of that difference is the map's gauge (scale / world frame), again after a Sim(3) alignment of the
-    trajectories."""
+    start from two-view poses that differ at OpenGV's refinement noise floor, so the raw poses are compared at 1e-3
+    (round 2: 2e-2) and, because most of that difference is the map's gauge (scale / world frame), again after a Sim(3) alignment of the
+    trajectories at 1e-4."""
     w, h = 640, 480
     canvas = synth.texture_canvas(w, h, 7)
     frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(160)]
-    _differential(frames, w, h, 40, False, 2e-2, 8, 6, px_tol=0.2, aligned_tol=ALIGNED_TOL)
+    _differential(frames, w, h, 40, False, 1e-3, 8, 6, px_tol=0.1, aligned_tol=ALIGNED_TOL)
 
 
 def test_system_equals_reference_2000_keypoints():
