@@ -16,7 +16,7 @@
 //   k_pairs   one workgroup per (observing kf, anchor kf) pair: sum of J_obs' J_obs and J_obs' r over the pair's
 //             observations (a permutation built once on the host) -- from these 27 numbers per pair every
 //             block of F'F and F'r follows by signs.
-//   k_rowcol, k_hcc, k_gmax   F'F, F'r, Jacobi column scaling (iteration 0), gradient max-norm, total cost.
+//   k_assemble   F'F, F'r, Jacobi column scaling (iteration 0), gradient max-norm, total cost, the step's scalars (one workgroup).
 // Per LM step:
 //   k_prep    per point: (E'E + D^2)^-1, its Cholesky factor L, Z_p = S_c W_p S_p L  and v_p = L'(E'r)
 //   k_gemm    G = Z' Z with v appended as one more column: ONE dense [6*cams+1 x points*d]^2 FP64 GEMM on
@@ -25,7 +25,7 @@
 //   k_reduced_system   S and the right-hand side, padded to a multiple of 16
 //   k_solve   blocked dense Cholesky of the reduced camera system in one workgroup + blocked triangular solves
 //   k_backsub per point: y_p, candidate point; model-cost-change and step-norm partials
-//   k_update  candidate poses, model cost change, step norm, candidate norm
+//             (+ one workgroup for the candidate poses and the camera part of model cost change / step norm / candidate norm)
 //   then the candidate is evaluated WITH its Jacobian (the first five kernels above): an accepted step -- the normal case --
 //   needs exactly that evaluation next (trust_region_minimizer.cc:809-829), so the host reads its scalars ONCE per LM
 //   iteration and applies Ceres' accept / reject logic; a rejected step re-evaluates at the previous point.
@@ -78,7 +78,7 @@ struct BaDev {
     double *yc;     // [NP]
     double *yp;     // [npd]
     double *scal;   // scalars: 0 cost, 1 mcc, 2 step_norm^2, 3 gmax, 4 x_norm^2, 5 chol_ok
-    double *h_scal; // single problem: pinned host mirror of scal[0..7] + the evaluation's sequence number at [8] (k_gmax publishes it last,
+    double *h_scal; // single problem: pinned host mirror of scal[0..7] + the evaluation's sequence number at [8] (k_assemble publishes it last,
                     // system-scope release; the host polls it instead of a copy command + stream wait per LM iteration); null in a batch
     long long seq;
     double *partial;  // [nPt][3] per-point partials for mcc / step norm / x norm
@@ -256,116 +256,159 @@ __device__ __forceinline__ int tri6(int x, int y) {
 // With M[c][a] = sum over observations (cam c, anchor a) of [J'J (21) | J'r (6)]:
 //   F'F(c,c) = sum_a M[c][a] + sum_c' M[c'][c]      F'F(c,a) = -(M[c][a] + M[a][c])  (c != a)
 //   F'r(c)   = sum_a m[c][a] - sum_c' m[c'][c]       (J_anchor = -J_obs).  XYZ mode: only M[c][c].
-// Assembly of the camera block H_cc / g_c from the per-pair sums, in three small launches instead of one single-workgroup
-// kernel (which spent 34 us walking 11.6 k dependent index computations + loads with 256 threads):
-//   k_rowcol   per keyframe: row and column sums of the pair sums
-//   k_hcc      every element of H_cc, g_c, and (first evaluation) the Jacobi scaling of the cameras
-//   k_gmax     (first evaluation) the Jacobi scaling of the points; max |gradient| -> scal[3]
-__device__ __forceinline__ void rowcol_body(const BaDev &B, const int BX_, const int BY_) {
-    const int k = BX_, t = threadIdx.x, nKf = B.nKf;
-    if (t >= 27) return;
-    double rs = 0, cs = 0;
-    for (int j = 0; j < nKf; j++) {
-        rs += B.M[(size_t) (k * nKf + j) * 27 + t];
-        cs += B.M[(size_t) (j * nKf + k) * 27 + t];
-    }
-    B.rowcol[(size_t) k * 27 + t] = rs;
-    B.rowcol[(size_t) (nKf + k) * 27 + t] = cs;
-}
-__global__ void __launch_bounds__(64) k_rowcol(BaDev B) {
-    rowcol_body(B, blockIdx.x, blockIdx.y);
-}
-
-__device__ __forceinline__ void hcc_body(const BaDev &B, int first, const int BX_, const int BY_) {
-    const int n6 = B.n6, nKf = B.nKf;
-    const double *rowsum = B.rowcol, *colsum = B.rowcol + (size_t) nKf * 27;
-    const int e = BX_ * 256 + threadIdx.x;
-    if (e < n6 * n6) {
-        const int r = e / n6, c = e - r * n6, cr = r / 6, cc = c / 6, x = r - 6 * cr, y = c - 6 * cc;
-        const int kr = B.kfOf[cr], kc = B.kfOf[cc];
-        const int t = tri6(x, y);
-        double v = 0;
-        if (B.inv) {
-            if (kr == kc) v = rowsum[kr * 27 + t] + colsum[kr * 27 + t];
-            else v = -(B.M[(size_t) (kr * nKf + kc) * 27 + t] + B.M[(size_t) (kc * nKf + kr) * 27 + t]);
-        } else {
-            if (kr == kc) v = B.M[(size_t) (kr * nKf + kr) * 27 + t];
+// Assembly of the camera block H_cc / g_c from the per-pair sums:
+// ONE workgroup (1024 threads) per problem does all three steps -- they used to be three launches (k_rowcol, k_hcc, k_gmax: 8 + 6.5 + 12 us
+// of kernels and two launch gaps per evaluation for ~20 k loads and 12 k stores):
+//   1. per keyframe the row and column sums of the pair sums, into LDS (fixed order over the keyframes)
+//   2. every element of H_cc and g_c (+ the Jacobi scaling of the cameras at the first evaluation); g_c also into LDS
+//   3. the evaluation's scalars: total cost, max |gradient| (+ the points' Jacobi scaling at the first evaluation), and the step's model
+//      cost change / squared step norm / squared candidate norm from the per-point partials of k_backsub and the camera part its pose
+//      workgroup left behind the partials -- then the scalars are published to the host (single problem)
+constexpr int ASM_NT = 1024;
+static inline size_t assemble_lds(int n_kf) { return (size_t) 2 * n_kf * 27 * sizeof(double); }   // row | column sums (dynamic LDS)
+__device__ __forceinline__ void assemble_body(const BaDev &B, int first) {
+    extern __shared__ double s_rc[];
+    __shared__ double s_red[5][ASM_NT / 64];
+    __shared__ int s_kfof[64];   // free camera -> keyframe (a dependent global load in front of every pair-sum load otherwise)
+    const int nKf = B.nKf, n6 = B.n6, tid = threadIdx.x;
+    if (tid < B.nc && tid < 64) s_kfof[tid] = B.kfOf[tid];   // (visible after the barrier behind the row / column sums)
+    double *rowsum = s_rc, *colsum = s_rc + (size_t) nKf * 27;
+    for (int e = tid; e < 2 * nKf * 27; e += ASM_NT) {
+        const bool col = e >= nKf * 27;
+        const int q = col ? e - nKf * 27 : e, k = q / 27, t = q - 27 * k;
+        // sum over the keyframes IN ORDER, eight loads in flight at a time (one dependent load per add ran at one L2 round trip per term)
+        const size_t stride = col ? (size_t) nKf * 27 : 27, first_e = col ? (size_t) k * 27 + t : (size_t) k * nKf * 27 + t;
+        double acc = 0;
+        for (int j0 = 0; j0 < nKf; j0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = j0 + u < nKf ? B.M[first_e + (size_t) (j0 + u) * stride] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j0 + u < nKf) acc += v[u];
         }
-        B.Hcc[e] = v;
-        if (first && r == c) B.sc[r] = 1.0 / (1.0 + sqrt(v));
-    } else if (e < n6 * n6 + n6) {
-        const int r = e - n6 * n6, kr = B.kfOf[r / 6], x = r % 6;
-        B.gc[r] = B.inv ? rowsum[kr * 27 + 21 + x] - colsum[kr * 27 + 21 + x] : B.M[(size_t) (kr * nKf + kr) * 27 + 21 + x];
+        s_rc[e] = acc;
     }
-}
-__global__ void __launch_bounds__(256) k_hcc(BaDev B, int first) {
-    hcc_body(B, first, blockIdx.x, blockIdx.y);
-}
-
-// max |gradient| (scal[3]) and, same single workgroup, the total cost (scal[0] = sum of the per-point costs of k_point)
-__device__ __forceinline__ void gmax_body(const BaDev &B, int first, const int BX_, const int BY_) {
-    __shared__ double s_red[256], s_cost[256];
+    __syncthreads();
+    double gm = 0;
+    {
+        // H_cc row by row: wave w takes rows w, w + 16, ..., lane l the columns l, l + 64, ... -- no division by the runtime size (a
+        // flat element index cost ~150 instructions of index arithmetic per element, and 16 waves share the compute unit's four SIMDs:
+        // the kernel was bound by that).  Two rows x two column chunks per trip: their (up to eight) pair-sum loads are issued
+        // together, then the stores (which may alias the loads as far as the compiler knows).
+        const double *__restrict__ M = B.M;
+        const int lane = tid & 63, wave = tid >> 6, NW = ASM_NT / 64;
+        const bool lds_map = B.nc <= 64;
+        for (int r0 = wave; r0 < n6; r0 += 2 * NW) {
+            for (int c0 = lane; c0 < n6; c0 += 128) {
+                double v[4];
+                int er[4], ec[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = r0 + (u >> 1) * NW, c = c0 + (u & 1) * 64;
+                    er[u] = r; ec[u] = c;
+                    v[u] = 0;
+                    if (r < n6 && c < n6) {
+                        const int cr = r / 6, cc = c / 6, x = r - 6 * cr, y = c - 6 * cc;
+                        const int kr = lds_map ? s_kfof[cr] : B.kfOf[cr], kc = lds_map ? s_kfof[cc] : B.kfOf[cc];
+                        const int t = tri6(x, y);
+                        if (B.inv) {
+                            if (kr == kc) v[u] = rowsum[kr * 27 + t] + colsum[kr * 27 + t];
+                            else v[u] = -(M[(size_t) (kr * nKf + kc) * 27 + t] + M[(size_t) (kc * nKf + kr) * 27 + t]);
+                        } else {
+                            if (kr == kc) v[u] = M[(size_t) (kr * nKf + kr) * 27 + t];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (er[u] < n6 && ec[u] < n6) {
+                        B.Hcc[(size_t) er[u] * n6 + ec[u]] = v[u];
+                        if (first && er[u] == ec[u]) B.sc[er[u]] = 1.0 / (1.0 + sqrt(v[u]));
+                    }
+            }
+        }
+        for (int r = tid; r < n6; r += ASM_NT) {
+            const int cr = r / 6, x = r - 6 * cr, kr = lds_map ? s_kfof[cr] : B.kfOf[cr];
+            const double g = B.inv ? rowsum[kr * 27 + 21 + x] - colsum[kr * 27 + 21 + x] : M[(size_t) (kr * nKf + kr) * 27 + 21 + x];
+            B.gc[r] = g;
+            gm = fmax(gm, fabs(g));
+        }
+    }
     if (first)
-        for (int i = threadIdx.x; i < B.npd; i += 256) {
+        for (int i = tid; i < B.npd; i += ASM_NT) {
             const int p = i / B.dp, x = i % B.dp;
             B.sp[i] = 1.0 / (1.0 + sqrt(B.Hpp[(size_t) p * B.dp * B.dp + x * B.dp + x]));
         }
-    double gm = 0, v = 0;
-    for (int r = threadIdx.x; r < B.n6; r += 256) gm = fmax(gm, fabs(B.gc[r]));
-    for (int i = threadIdx.x; i < B.npd; i += 256) gm = fmax(gm, fabs(B.gp[i]));
-    for (int p = threadIdx.x; p < B.nPt; p += 256) v += B.ptCost[p];
-    s_red[threadIdx.x] = gm;
-    s_cost[threadIdx.x] = v;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) {
-            s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + s2]);
-            s_cost[threadIdx.x] += s_cost[threadIdx.x + s2];
-        }
-        __syncthreads();
+    double cost = 0, mcc = 0, sn = 0, xn = 0;
+    for (int i = tid; i < B.npd; i += ASM_NT) gm = fmax(gm, fabs(B.gp[i]));
+    for (int p = tid; p < B.nPt; p += ASM_NT) {
+        cost += B.ptCost[p];
+        mcc += B.partial[3 * (size_t) p];
+        sn += B.partial[3 * (size_t) p + 1];
+        xn += B.partial[3 * (size_t) p + 2];
     }
-    if (threadIdx.x == 0) {
-        B.scal[3] = s_red[0];
-        B.scal[0] = s_cost[0];
-        if (B.h_scal) {   // the other scalars were written by earlier kernels of this stream (device memory): re-read here, published by THIS kernel
-            B.h_scal[0] = s_cost[0]; B.h_scal[1] = B.scal[1]; B.h_scal[2] = B.scal[2]; B.h_scal[3] = s_red[0];
-            B.h_scal[4] = B.scal[4]; B.h_scal[5] = B.scal[5]; B.h_scal[6] = B.scal[6]; B.h_scal[7] = B.scal[7];
+    // wave totals (xor butterfly: the same value on every lane), then the 16 wave totals in wave order: a fixed summation tree
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gm = fmax(gm, __shfl_xor(gm, off));
+        cost += __shfl_xor(cost, off);
+        mcc += __shfl_xor(mcc, off);
+        sn += __shfl_xor(sn, off);
+        xn += __shfl_xor(xn, off);
+    }
+    if (lane == 0) {
+        s_red[0][wave] = gm; s_red[1][wave] = cost; s_red[2][wave] = mcc; s_red[3][wave] = sn; s_red[4][wave] = xn;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double g2 = 0, c2 = 0, m2 = 0, s2 = 0, x2 = 0;
+        for (int w = 0; w < ASM_NT / 64; w++) {
+            g2 = fmax(g2, s_red[0][w]);
+            c2 += s_red[1][w]; m2 += s_red[2][w]; s2 += s_red[3][w]; x2 += s_red[4][w];
+        }
+        const double *cam = B.partial + 3 * (size_t) B.nPt;   // camera part of the step's scalars (k_backsub's pose workgroup)
+        B.scal[0] = c2;
+        B.scal[3] = g2;
+        B.scal[1] = m2 + cam[0];
+        B.scal[2] = s2 + cam[1];
+        B.scal[4] = x2 + cam[2];
+        if (B.h_scal) {   // scal[5] (Cholesky ok) was written by k_solve of this stream: re-read here, published by THIS kernel
+            B.h_scal[0] = c2; B.h_scal[1] = m2 + cam[0]; B.h_scal[2] = s2 + cam[1]; B.h_scal[3] = g2;
+            B.h_scal[4] = x2 + cam[2]; B.h_scal[5] = B.scal[5]; B.h_scal[6] = B.scal[6]; B.h_scal[7] = B.scal[7];
             __threadfence_system();
             __hip_atomic_store(reinterpret_cast<long long *>(B.h_scal + 8), B.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-__global__ void __launch_bounds__(256) k_gmax(BaDev B, int first) {
-    gmax_body(B, first, blockIdx.x, blockIdx.y);
-}
+__global__ void __launch_bounds__(ASM_NT) k_assemble(BaDev B, int first) { assemble_body(B, first); }
 
-// LM diagonal (levenberg_marquardt_strategy.cc:79-90), refreshed only after an accepted step.
-__device__ __forceinline__ void diag_body(const BaDev &B, const int BX_, const int BY_) {
-    const int i = BX_ * 256 + threadIdx.x;
-    if (i < B.n6) B.dc[i] = fmin(fmax(B.Hcc[(size_t) i * B.n6 + i] * B.sc[i] * B.sc[i], 1e-6), 1e32);
-    if (i < B.npd) {
-        const int p = i / B.dp, x = i % B.dp;
-        B.dpd[i] = fmin(fmax(B.Hpp[(size_t) p * B.dp * B.dp + x * B.dp + x] * B.sp[i] * B.sp[i], 1e-6), 1e32);
-    }
-}
-__global__ void __launch_bounds__(256) k_diag(BaDev B) {
-    diag_body(B, blockIdx.x, blockIdx.y);
-}
-
+// The LM diagonal (levenberg_marquardt_strategy.cc:79-90) is refreshed only after an accepted step (`refresh`): the points' part by k_prep
+// (each point its own entries), the cameras' part by k_reduced_system (the thread of each diagonal element) -- no launch of its own.
 // per point: hinv = (S_p E'E S_p + D_p^2/radius)^-1 , L = chol(hinv), Zt rows = S_c W S_p L, last column v = L' (S_p E'r)
 template<int DP>
-__device__ __forceinline__ void prep_body(const BaDev &B, double radius, const int BX_, const int BY_) {
+__device__ __forceinline__ void prep_body(const BaDev &B, double radius, int refresh, const int BX_, const int BY_) {
     const int lane = threadIdx.x & 63;
     const int p = BX_ * 4 + (threadIdx.x >> 6);
     if (p >= B.nPt) return;
-    double Mx[DP * DP], Hi[DP * DP], L[DP * DP], gs[DP];
+    double Mx[DP * DP], Hi[DP * DP], L[DP * DP], gs[DP], dpd[DP];
+#pragma unroll
+    for (int x = 0; x < DP; x++) {
+        const int i = p * DP + x;
+        if (refresh) {
+            dpd[x] = fmin(fmax(B.Hpp[(size_t) p * DP * DP + x * DP + x] * B.sp[i] * B.sp[i], 1e-6), 1e32);
+            if (lane == 0) B.dpd[i] = dpd[x];
+        } else {
+            dpd[x] = B.dpd[i];
+        }
+    }
 #pragma unroll
     for (int x = 0; x < DP; x++) {
         gs[x] = B.gp[(size_t) p * DP + x] * B.sp[p * DP + x];
 #pragma unroll
         for (int y = 0; y < DP; y++)
-            Mx[x * DP + y] = B.Hpp[(size_t) p * DP * DP + x * DP + y] * B.sp[p * DP + x] * B.sp[p * DP + y] +
-                             (x == y ? B.dpd[p * DP + x] / radius : 0.0);
+            Mx[x * DP + y] = B.Hpp[(size_t) p * DP * DP + x * DP + y] * B.sp[p * DP + x] * B.sp[p * DP + y] + (x == y ? dpd[x] / radius : 0.0);
     }
     if (DP == 1) {
         Hi[0] = 1.0 / Mx[0];
@@ -411,8 +454,8 @@ __device__ __forceinline__ void prep_body(const BaDev &B, double radius, const i
     }
 }
 template<int DP>
-__global__ void __launch_bounds__(256) k_prep(BaDev B, double radius) {
-    prep_body<DP>(B, radius, blockIdx.x, blockIdx.y);
+__global__ void __launch_bounds__(256) k_prep(BaDev B, double radius, int refresh) {
+    prep_body<DP>(B, radius, refresh, blockIdx.x, blockIdx.y);
 }
 
 // G_part[ks] (16x16 tile) = Zt[kchunk]' Zt[kchunk] on the FP64 matrix core.
@@ -459,10 +502,13 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 //   trailing update  A22 -= L21 L21' as 16 x 16 tiles on v_mfma_f64_16x16x4_f64, one wavefront per tile
 // = 3 barriers per 16 columns instead of 3 per column; the triangular solves are blocked the same way.  Row stride is
 // odd (padded size + 1) so that threads reading different rows hit different LDS banks.
-constexpr int SOLVE_NT = 256, NB = 16;
+constexpr int SOLVE_NT = 256, NB = 16;   // measured and dropped: 1024 threads (16 waves for the trailing update's tiles): 80 vs 67 us, the
+                                        // barriers cost more than the tiles save; triangular solves through explicit inverses of the diagonal
+                                        // blocks' factors (computed by a spare wave beside the panel): 91 us, the inverse is a longer chain
+                                        // than the panel it hides behind
 
 // reduced camera system of this LM step, padded: S [np][np + 1] and the right-hand side [np] right behind it (all CUs)
-__device__ __forceinline__ void reduced_system_body(const BaDev &B, double radius, const int BX_, const int BY_) {
+__device__ __forceinline__ void reduced_system_body(const BaDev &B, double radius, int refresh, const int BX_, const int BY_) {
     const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1;
     const int e = BX_ * 256 + threadIdx.x;
     if (e < np * np) {
@@ -472,8 +518,16 @@ __device__ __forceinline__ void reduced_system_body(const BaDev &B, double radiu
             double g = 0;
 #pragma unroll
             for (int ks = 0; ks < KSPLIT; ks++) g += B.Gpart[((size_t) ks * B.NP + r) * B.NP + c];
-            v = B.Hcc[(size_t) r * n + c] * B.sc[r] * B.sc[c] - g;
-            if (r == c) v += B.dc[r] / radius;
+            const double h = B.Hcc[(size_t) r * n + c] * B.sc[r] * B.sc[c];
+            v = h - g;
+            if (r == c) {
+                double dcr = B.dc[r];
+                if (refresh) {
+                    dcr = fmin(fmax(h, 1e-6), 1e32);
+                    B.dc[r] = dcr;
+                }
+                v += dcr / radius;
+            }
         }
         B.S[(size_t) r * ld + c] = v;
     } else if (e < np * np + np) {
@@ -488,8 +542,8 @@ __device__ __forceinline__ void reduced_system_body(const BaDev &B, double radiu
         B.S[(size_t) np * ld + r] = v;
     }
 }
-__global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius) {
-    reduced_system_body(B, radius, blockIdx.x, blockIdx.y);
+__global__ void __launch_bounds__(256) k_reduced_system(BaDev B, double radius, int refresh) {
+    reduced_system_body(B, radius, refresh, blockIdx.x, blockIdx.y);
 }
 
 template<bool IN_LDS>
@@ -676,9 +730,15 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
 
 // per point: y_p = hinv (g_s - (S_c W S_p)' y_c); candidate point; partials for the model cost change
 // (1/2 y'(g_s + D y), exact for the exact solution of (H_s + D) y = g_s) and the step norm.
+__device__ __forceinline__ void pose_update_body(const BaDev &B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p);
 template<int DP>
-__device__ __forceinline__ void backsub_body(const BaDev &B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t, const int BX_, const int BY_) {
+__device__ __forceinline__ void backsub_body(const BaDev &B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t,
+                                             const double *__restrict__ x_p, double *__restrict__ c_p, const int BX_, const int BY_) {
     const int lane = threadIdx.x & 63;
+    if (BX_ == (B.nPt + 3) / 4) {   // one workgroup behind the points': the candidate poses and the camera part of the step's scalars
+        pose_update_body(B, radius, x_p, c_p);
+        return;
+    }
     const int p = BX_ * 4 + (threadIdx.x >> 6);
     if (p >= B.nPt) return;
     double t[DP];
@@ -690,7 +750,7 @@ __device__ __forceinline__ void backsub_body(const BaDev &B, double radius, cons
         t[x] = B.gp[(size_t) p * DP + x] * B.sp[p * DP + x] - v * B.sp[p * DP + x];
     }
     if (lane == 0) {
-        double mcc = 0, sn = 0;
+        double mcc = 0, sn = 0, xn = 0;
 #pragma unroll
         for (int x = 0; x < DP; x++) {
             double y = 0;
@@ -700,22 +760,26 @@ __device__ __forceinline__ void backsub_body(const BaDev &B, double radius, cons
             const double gs = B.gp[(size_t) p * DP + x] * B.sp[p * DP + x];
             mcc += 0.5 * y * (gs + B.dpd[p * DP + x] / radius * y);
             const double d = -y * B.sp[p * DP + x];
-            c_t[p * DP + x] = x_t[p * DP + x] + d;
+            const double cv = x_t[p * DP + x] + d;
+            c_t[p * DP + x] = cv;
             sn += d * d;
+            xn += cv * cv;
         }
         B.partial[3 * (size_t) p] = mcc;
         B.partial[3 * (size_t) p + 1] = sn;
+        B.partial[3 * (size_t) p + 2] = xn;
     }
 }
 template<int DP>
-__global__ void __launch_bounds__(256) k_backsub(BaDev B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t) {
-    backsub_body<DP>(B, radius, x_t, c_t, blockIdx.x, blockIdx.y);
+__global__ void __launch_bounds__(256) k_backsub(BaDev B, double radius, const double *__restrict__ x_t, double *__restrict__ c_t,
+                                                 const double *__restrict__ x_p, double *__restrict__ c_p) {
+    backsub_body<DP>(B, radius, x_t, c_t, x_p, c_p, blockIdx.x, blockIdx.y);
 }
 
-// candidate poses (SE3 Plus), camera part of mcc / step norm, and the final deterministic reductions.
-// candidate poses, model cost change (scal[1]), squared step norm (scal[2]) and the squared norm of the CANDIDATE (scal[4]: free
-// poses + point parameters c_t written by k_backsub), which becomes x_norm when the step is accepted
-__device__ __forceinline__ void update_body(const BaDev &B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p, const double *__restrict__ c_t, const int BX_, const int BY_) {
+// candidate poses (SE3 Plus) and the CAMERA part of the step's scalars -- model cost change, squared step norm, squared norm of the
+// candidate -- left behind the per-point partials (B.partial[3 nPt ..]); k_assemble of the candidate's evaluation adds the points' part
+// and publishes them.  One workgroup (the extra one of k_backsub); a problem has a few tens of keyframes.
+__device__ __forceinline__ void pose_update_body(const BaDev &B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p) {
     __shared__ double s_a[256], s_b[256], s_c[256];
     double mcc = 0, sn = 0, xn = 0;
     for (int k = threadIdx.x; k < B.nKf; k += 256) {
@@ -737,11 +801,6 @@ __device__ __forceinline__ void update_body(const BaDev &B, double radius, const
             xn += cv * cv;
         }
     }
-    for (int p = threadIdx.x; p < B.nPt; p += 256) {
-        mcc += B.partial[3 * (size_t) p];
-        sn += B.partial[3 * (size_t) p + 1];
-    }
-    for (int i = threadIdx.x; i < B.npd; i += 256) xn += c_t[i] * c_t[i];
     s_a[threadIdx.x] = mcc;
     s_b[threadIdx.x] = sn;
     s_c[threadIdx.x] = xn;
@@ -755,14 +814,11 @@ __device__ __forceinline__ void update_body(const BaDev &B, double radius, const
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        B.scal[1] = s_a[0];
-        B.scal[2] = s_b[0];
-        B.scal[4] = s_c[0];
+        double *cam = B.partial + 3 * (size_t) B.nPt;
+        cam[0] = s_a[0];
+        cam[1] = s_b[0];
+        cam[2] = s_c[0];
     }
-}
-__global__ void __launch_bounds__(256) k_update(BaDev B, double radius, const double *__restrict__ x_p, double *__restrict__ c_p,
-                                                const double *__restrict__ c_t) {
-    update_body(B, radius, x_p, c_p, c_t, blockIdx.x, blockIdx.y);
 }
 
 // |x|^2 over the variable blocks (free poses in their 7-vector form + all point parameters) -> scal[4]
@@ -833,29 +889,14 @@ __global__ void __launch_bounds__(256) k_pairs_b(const BaDev *Bs, const BaRun *R
     if ((int) blockIdx.x >= B.nKf * B.nKf) return;
     pairs_body(B, blockIdx.x, 0);
 }
-__global__ void __launch_bounds__(64) k_rowcol_b(const BaDev *Bs, const BaRun *Rs, int mode) {
-    if (!Rs[blockIdx.y].ev_on[mode]) return;
-    const BaDev &B = Bs[blockIdx.y];
-    if ((int) blockIdx.x >= B.nKf) return;
-    rowcol_body(B, blockIdx.x, 0);
-}
-__global__ void __launch_bounds__(256) k_hcc_b(const BaDev *Bs, const BaRun *Rs, int mode) {
-    if (!Rs[blockIdx.y].ev_on[mode]) return;
-    hcc_body(Bs[blockIdx.y], mode == 0 ? 1 : 0, blockIdx.x, 0);
-}
-__global__ void __launch_bounds__(256) k_gmax_b(const BaDev *Bs, const BaRun *Rs, int mode) {
-    if (!Rs[blockIdx.y].ev_on[mode]) return;
-    gmax_body(Bs[blockIdx.y], mode == 0 ? 1 : 0, 0, 0);
-}
-__global__ void __launch_bounds__(256) k_diag_b(const BaDev *Bs, const BaRun *Rs) {
-    const BaRun &R = Rs[blockIdx.y];
-    if (!R.step || !R.diag) return;
-    diag_body(Bs[blockIdx.y], blockIdx.x, 0);
+__global__ void __launch_bounds__(ASM_NT) k_assemble_b(const BaDev *Bs, const BaRun *Rs, int mode) {
+    if (!Rs[blockIdx.x].ev_on[mode]) return;
+    assemble_body(Bs[blockIdx.x], mode == 0 ? 1 : 0);
 }
 __global__ void __launch_bounds__(256) k_prep_b(const BaDev *Bs, const BaRun *Rs) {
     const BaRun &R = Rs[blockIdx.y];
     if (!R.step) return;
-    prep_body<1>(Bs[blockIdx.y], R.radius, blockIdx.x, 0);
+    prep_body<1>(Bs[blockIdx.y], R.radius, R.diag, blockIdx.x, 0);
 }
 __global__ void __launch_bounds__(64) k_gemm_b(const BaDev *Bs, const BaRun *Rs) {
     const BaRun &R = Rs[blockIdx.z];
@@ -868,7 +909,7 @@ __global__ void __launch_bounds__(64) k_gemm_b(const BaDev *Bs, const BaRun *Rs)
 __global__ void __launch_bounds__(256) k_reduced_system_b(const BaDev *Bs, const BaRun *Rs) {
     const BaRun &R = Rs[blockIdx.y];
     if (!R.step) return;
-    reduced_system_body(Bs[blockIdx.y], R.radius, blockIdx.x, 0);
+    reduced_system_body(Bs[blockIdx.y], R.radius, R.diag, blockIdx.x, 0);
 }
 __global__ void __launch_bounds__(SOLVE_NT) k_solve_b(const BaDev *Bs, const BaRun *Rs) {
     const BaRun &R = Rs[blockIdx.x];
@@ -878,12 +919,9 @@ __global__ void __launch_bounds__(SOLVE_NT) k_solve_b(const BaDev *Bs, const BaR
 __global__ void __launch_bounds__(256) k_backsub_b(const BaDev *Bs, const BaRun *Rs) {
     const BaRun &R = Rs[blockIdx.y];
     if (!R.step) return;
-    backsub_body<1>(Bs[blockIdx.y], R.radius, R.xt, R.ct, blockIdx.x, 0);
-}
-__global__ void __launch_bounds__(256) k_update_b(const BaDev *Bs, const BaRun *Rs) {
-    const BaRun &R = Rs[blockIdx.x];
-    if (!R.step) return;
-    update_body(Bs[blockIdx.x], R.radius, R.xp, R.cp, R.ct, 0, 0);
+    const BaDev &B = Bs[blockIdx.y];
+    if ((int) blockIdx.x > (B.nPt + 3) / 4) return;   // the grid covers the largest problem (+ its pose workgroup)
+    backsub_body<1>(B, R.radius, R.xt, R.ct, R.xp, R.cp, blockIdx.x, 0);
 }
 
 // ---- one problem on the host: sizes, the carved device block with its pinned mirror, the structure build -------------------------
@@ -974,7 +1012,7 @@ struct BaHost {
         B.yc = carve<double>(cur, NP);
         B.yp = carve<double>(cur, npd);
         B.scal = carve<double>(cur, 64);
-        B.partial = carve<double>(cur, nPt * 3);
+        B.partial = carve<double>(cur, nPt * 3 + 8);   // per point: mcc, step^2, candidate^2 partials; then the camera part (3)
         d_cp = carve<double>(cur, n_kf * 7);
         d_ct = carve<double>(cur, npd);
         return (size_t) (cur - base);
@@ -1143,7 +1181,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     const auto t_up = std::chrono::steady_clock::now();
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
-    // per-iteration scalars: published by k_gmax into the first 128 bytes of the pinned staging and polled (ALVA_NO_POLL=1: copy + wait)
+    // per-iteration scalars: published by k_assemble into the first 128 bytes of the pinned staging and polled (ALVA_NO_POLL=1: copy + wait)
     static const bool poll = getenv("ALVA_NO_POLL") == nullptr;
     double *pin_scal = reinterpret_cast<double *>(pin);
     long long eval_seq = 0;
@@ -1160,10 +1198,8 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
             else hipLaunchKernelGGL((k_point<false, true>), gPt, blk, 0, st, B, xp, xt);
         }
         hipLaunchKernelGGL(k_pairs, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, B);
-        hipLaunchKernelGGL(k_rowcol, dim3((unsigned) n_kf), dim3(64), 0, st, B);
-        if (B.n6 > 0) hipLaunchKernelGGL(k_hcc, dim3((unsigned) alva_divup(B.n6 * B.n6 + B.n6, 256)), blk, 0, st, B, first ? 1 : 0);
         B.seq = ++eval_seq;
-        hipLaunchKernelGGL(k_gmax, dim3(1), blk, 0, st, B, first ? 1 : 0);  // also sums the cost; publishes the scalars
+        hipLaunchKernelGGL(k_assemble, dim3(1), dim3(ASM_NT), assemble_lds(n_kf), st, B, first ? 1 : 0);  // H_cc, g_c, the scalars; publishes them
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     };
@@ -1207,26 +1243,25 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
             if (rc) return rc;
             H.need_restore = false;
         }
-        const int ndiag = std::max(B.n6, B.npd);
-        if (!lm.reuse_diagonal && ndiag > 0) hipLaunchKernelGGL(k_diag, dim3((unsigned) alva_divup(ndiag, 256)), blk, 0, st, B);
+        const int refresh = lm.reuse_diagonal ? 0 : 1;   // the LM diagonal is refreshed inside k_prep / k_reduced_system
         lm.reuse_diagonal = 1;
         if (n_pt > 0) {
-            if (dp == 1) hipLaunchKernelGGL(k_prep<1>, gPt, blk, 0, st, B, lm.radius);
-            else hipLaunchKernelGGL(k_prep<3>, gPt, blk, 0, st, B, lm.radius);
+            if (dp == 1) hipLaunchKernelGGL(k_prep<1>, gPt, blk, 0, st, B, lm.radius, refresh);
+            else hipLaunchKernelGGL(k_prep<3>, gPt, blk, 0, st, B, lm.radius, refresh);
         }
         const int tiles = B.NP / 16;
         hipLaunchKernelGGL(k_gemm, dim3((unsigned) (tiles * tiles), KSPLIT), dim3(64), 0, st, B);
         if (np16 > 0) {
             const int np16i = (int) np16;
-            hipLaunchKernelGGL(k_reduced_system, dim3((unsigned) alva_divup(np16i * np16i + np16i, 256)), blk, 0, st, B, lm.radius);
+            hipLaunchKernelGGL(k_reduced_system, dim3((unsigned) alva_divup(np16i * np16i + np16i, 256)), blk, 0, st, B, lm.radius, refresh);
         }
         if (solve_in_lds) hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(SOLVE_NT), solve_lds, st, B, lm.radius);
         else hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(SOLVE_NT), 0, st, B, lm.radius);
-        if (n_pt > 0) {
-            if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, gPt, blk, 0, st, B, lm.radius, (const double *) H.xt, H.ct);
-            else hipLaunchKernelGGL(k_backsub<3>, gPt, blk, 0, st, B, lm.radius, (const double *) H.xt, H.ct);
+        {   // the points' back-substitution + ONE more workgroup for the candidate poses
+            const dim3 gBs(gPt.x + 1);
+            if (dp == 1) hipLaunchKernelGGL(k_backsub<1>, n_pt > 0 ? gBs : dim3(1), blk, 0, st, B, lm.radius, (const double *) H.xt, H.ct, (const double *) H.xp, H.cp);
+            else hipLaunchKernelGGL(k_backsub<3>, n_pt > 0 ? gBs : dim3(1), blk, 0, st, B, lm.radius, (const double *) H.xt, H.ct, (const double *) H.xp, H.cp);
         }
-        hipLaunchKernelGGL(k_update, dim3(1), blk, 0, st, B, lm.radius, (const double *) H.xp, H.cp, (const double *) H.ct);
         ALVA_LAUNCH_CHECK();
         // The candidate is evaluated WITH its Jacobian and its norm straight away: when the step is accepted (the normal case) Ceres
         // re-evaluates at the same point (HandleSuccessfulStep, trust_region_minimizer.cc:809-829) and would produce exactly these
@@ -1380,9 +1415,7 @@ extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, do
     auto eval = [&](int mode) -> int {
         hipLaunchKernelGGL(k_point_b, dim3((unsigned) alva_divup(max_pt, 4), ub), blk, 0, st, d_desc, d_run, mode);
         hipLaunchKernelGGL(k_pairs_b, dim3((unsigned) (max_kf * max_kf), ub), blk, 0, st, d_desc, d_run, mode);
-        hipLaunchKernelGGL(k_rowcol_b, dim3((unsigned) max_kf, ub), dim3(64), 0, st, d_desc, d_run, mode);
-        if (max_n6 > 0) hipLaunchKernelGGL(k_hcc_b, dim3((unsigned) alva_divup(max_n6 * max_n6 + max_n6, 256), ub), blk, 0, st, d_desc, d_run, mode);
-        hipLaunchKernelGGL(k_gmax_b, dim3(1, ub), blk, 0, st, d_desc, d_run, mode);
+        hipLaunchKernelGGL(k_assemble_b, dim3(ub), dim3(ASM_NT), assemble_lds(max_kf), st, d_desc, d_run, mode);
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     };
@@ -1432,7 +1465,7 @@ extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, do
             rc = eval(1);
             if (rc) return rc;
         }
-        if (diags) hipLaunchKernelGGL(k_diag_b, dim3((unsigned) alva_divup(max_ndiag, 256), ub), blk, 0, st, d_desc, d_run);
+        (void) diags;   // the diagonal refresh rides in k_prep_b / k_reduced_system_b (BaRun::diag)
         hipLaunchKernelGGL(k_prep_b, dim3((unsigned) alva_divup(max_pt, 4), ub), blk, 0, st, d_desc, d_run);
         hipLaunchKernelGGL(k_gemm_b, dim3((unsigned) (max_tiles * max_tiles), KSPLIT, ub), dim3(64), 0, st, d_desc, d_run);
         if (max_np16 > 0) {
@@ -1440,8 +1473,7 @@ extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, do
             hipLaunchKernelGGL(k_reduced_system_b, dim3((unsigned) alva_divup(n16 * n16 + n16, 256), ub), blk, 0, st, d_desc, d_run);
         }
         hipLaunchKernelGGL(k_solve_b, dim3(ub), dim3(SOLVE_NT), max_lds, st, d_desc, d_run);
-        hipLaunchKernelGGL(k_backsub_b, dim3((unsigned) alva_divup(max_pt, 4), ub), blk, 0, st, d_desc, d_run);
-        hipLaunchKernelGGL(k_update_b, dim3(ub), blk, 0, st, d_desc, d_run);
+        hipLaunchKernelGGL(k_backsub_b, dim3((unsigned) alva_divup(max_pt, 4) + 1, ub), blk, 0, st, d_desc, d_run);
         ALVA_LAUNCH_CHECK();
         rc = eval(2);
         if (rc) return rc;
