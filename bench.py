@@ -3,35 +3,36 @@
 
 HEADLINE (`value`): frames/s of the reference's OWN dataflow through the drop-in surface -- System::findCameraPose
 (src/slam/src/system.cpp:106-175) = alva_system_find_camera_pose_device -- on a synthetic 640x480 stream with ~2000 keypoints per frame
-(cell size 12 => 2120 cells; BASELINE.json configs[1]), every frame ALREADY resident in HBM.  A "step" is ONE frame through the whole
-per-frame state machine, every stage consuming what the previous one produced:
+(cell size 12 => 2120 cells; BASELINE.json configs[1]), every frame ALREADY resident in HBM, in the STEADY STATE of a long session.  A
+"step" is ONE frame through the whole per-frame state machine, every stage consuming what the previous one produced:
     RGBA -> gray -> LK pyramid (+Scharr)                                                        (a2, a3)
     motion-model priors -> forward-backward KLT (1 level from the priors, the full pyramid for the rest and for the retries), one
         workgroup per slot of the frame container, with undistortion / bearings                (a4; visual_frontend.cpp:103-243)
     compaction of the 3-D survivors on the device                                              (:275-298)
     P3P-LMedS (100 hypotheses) -> drop its outliers -> robust PnP (5 LM iterations) on the tracker's OWN survivors (a8, a9; :245-417)
     host bookkeeping of the frame (keypoint updates / removals, motion model, keyframe decision)
-and on the frames the reference's keyframe policy selects (about every 18th here): grid Shi-Tomasi detection + ORB description (a5, a6),
+and on the frames the reference's keyframe policy selects (every 18th here): grid Shi-Tomasi detection + ORB description (a5, a6),
 triangulation, covisibility, guided Hamming matching to the local map + map-point merges (a7 / f1), local bundle adjustment with outlier
 sweep, write-back and culling (a10-a13).  The stream is the (2, 1) px / frame crop of a textured canvas, 200 frames, played forwards
-and backwards; warm-up covers the two-view initialisation.  `value` = frames/s over all ranks (one independent stream per GPU, no
-collective on the data path).  "system_surface" = the same loop fed from HOST memory (1.2 MB RGBA per frame over PCIe, through the
-caller-owned buffer exactly as src/system.js does).  "sustained" repeats the timed loop for at least 0.5 s.
+and backwards.  UNTIMED top-up before the window: the session runs until the 30-keyframe window of the reference's mapper is full
+(keyframe 34, ~600 frames) and on to the middle of a keyframe period, so that the K timed steps hold round(K / period) keyframes --
+round 2's window sat right after initialisation (2-3 cheap keyframes in the map) and overstated the sustained rate 1.5x.
+`value` = frames/s over all ranks (one independent stream per GPU, no collective on the data path); "value_window", "sustained" (the
+same loop for >= 0.5 s), the keyframes inside each, and "system_surface" (the same loop fed from HOST memory exactly as src/system.js
+does: one copy into the wrapper's registered frame buffer, read in place over PCIe) are reported side by side.
 
-"stage_list_driver" is round 1's headline, kept as a secondary line: the stage list of configs[1] (gray, pyramid, fb-KLT, cv::ORB
-detectAndCompute 2000, brute-force Hamming, P3P -> PnP) issued by alva_frontend_track_ahead on THREE HIP streams with FIXED pose
-correspondences -- every stage runs, but the tracker's output feeds nothing, so it is an upper bound of stage throughput, not the
-reference's dataflow.
-The second half of BASELINE.json's metric, local-BA residual blocks/s (20 KF x 3000 pts, 5 LM iterations), is measured in the same
-run ("local_ba"), with its own roofline block ("roofline_ba").
+Beside it: "bounds" = the three end-to-end bounds of a frame (HBM, PCIe, launch latency) + the measured dependent kernel
+chain; "klt" = the tracker's own figures (keypoint-levels/s, L2 hit rate); "roofline" = the contract's object for the dominant kernel
+(bound: latency -- see its note); "local_ba" / "roofline_ba" = the second half of BASELINE.json's metric (20 KF x 3000 pts, 5 LM
+iterations); "system_720p" = configs[4]'s geometry through the same surface; "map_merge" = the optional shared-map merge on the
+process group's backend (RCCL: one all_gather_into_tensor + fuse; initialised for ONE rank too); "system_streams" = 4 / 8 independent
+sessions on the one GPU; "cpu_baseline" = the compiled reference (oracle/_ref) on this box's host cores: System frames/s at cell 12 /
+cell 40 (shipped) / 1280x720, 1 core and 8 threads, per-stage milliseconds of its L1 functions, one Ceres local-BA solve.
 
-Secondary lines for a RIG of lock-step cameras on the one GPU (alva_track_batch_*): "track_mono_batch", "frame_step_batch",
-"batched_preprocess"; "config_1280x720" = configs[2].  --multi-stream adds the older 4 / 16 host-thread measurement of the stage-list
-driver; --system-streams 2,4,8 adds "system_streams": S independent alva::System sessions on the one GPU, one host thread each.
-
-Also reported: "roofline" for the dominant kernel of the headline loop (HIP-event timed on the launch stream) and "cpu_baseline": the
-compiled reference's System (oracle/_ref) on the same frames and configuration on one host core, and 8 independent reference Systems
-on 8 host threads (falls back to the stage-wise C restatement, kind "port", when the reference library is absent).
+Secondary lines for a RIG of lock-step cameras (alva_track_batch_*): "track_mono_batch", "frame_step_batch", "batched_preprocess";
+"config_1280x720" = configs[2]; "stage_list_driver" = round 1's headline (fixed correspondences: an upper bound of stage throughput,
+not the reference's dataflow).  --quick skips the secondary lines, --no-cpu-baseline the reference.  stdout carries exactly ONE line
+(the JSON); everything else -- progress, the reference's and RCCL's own prints -- goes to stderr.
 """
 from __future__ import annotations
 
@@ -272,9 +273,8 @@ def bench_system_streams(device: int, n_streams: int, steps: int = 300):
         j.k = -1
         j.status_hist = [0, 0, 0, 0]
         jobs[i] = j
-    for j in jobs:   # past the initialisation, into steady tracking
-        for _ in range(60):
-            j.step()
+    for j in jobs:   # past the initialisation, into the steady state (30-keyframe window full), like the headline
+        j.warm_to_steady_state()
     start = threading.Barrier(n_streams + 1)
     done = []
 
@@ -295,7 +295,7 @@ def bench_system_streams(device: int, n_streams: int, steps: int = 300):
     for j in jobs:
         j.ar.close()
     return {"sessions": n_streams, "frames_per_s": n_streams * steps / dt, "frames_per_s_per_session": steps / dt, "steps_per_session": steps,
-            "tracked_frac": tracked / (n_streams * (steps + 60)),
+            "tracked_frac": tracked / max(sum(sum(j.status_hist) for j in jobs), 1),
             "note": "S independent alva::System sessions on one GPU, one host thread each (Python threads; the C call releases the GIL), frames resident in HBM"}
 
 
@@ -834,12 +834,17 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="accepted for compatibility (the default now)")
     ap.add_argument("--quick", action="store_true", help="headline, roofline and CPU baseline only (skips the secondary rig / batch lines)")
     ap.add_argument("--system-streams", type=str, default="",
-                    help="comma-separated session counts: also time S independent alva::System sessions on rank 0's GPU (reported under "
-                         "system_streams; not part of value; off by default for the same reason as --multi-stream)")
+                    help="comma-separated session counts: time S independent alva::System sessions on rank 0's GPU (reported under "
+                         "system_streams; not part of value); default 4,8 in a full run")
     ap.add_argument("--streams-per-gpu", type=int, default=0,
                     help="also time S concurrent independent streams on rank 0's GPU (reported under multi_stream; not part of value)")
     ap.add_argument("--merge-every", type=int, default=4, help="shared-map merge (RCCL all_gather + fuse) every this many keyframes in the merge line")
     args = ap.parse_args()
+    # stdout carries exactly one line, the JSON: the compiled reference (cpu_baseline) and RCCL print to the C-level stdout, so fd 1 is
+    # pointed at stderr for the duration of the run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     from alvaar_amd import multi
     import torch.distributed as td
@@ -1090,13 +1095,16 @@ def main():
         elif world == 1 and args.multi_stream:
             # secondary: several independent cameras on the one GPU (native host threads); shows the head-room a single stream leaves
             out["multi_stream"] = [bench_multi_stream(local, s_, 60) for s_ in (4, 16)]
-        if args.system_streams and world == 1:
-            out["system_streams"] = [bench_system_streams(local, int(v)) for v in args.system_streams.split(",")]
+        if world == 1 and (args.system_streams or full):
+            # S independent alva::System sessions on the ONE GPU, a host thread each: what a single latency-bound stream leaves idle
+            counts = [int(v) for v in args.system_streams.split(",")] if args.system_streams else [4, 8]
+            out["system_streams"] = [bench_system_streams(local, c_) for c_ in counts]
         if not args.no_cpu_baseline and world == 1:   # the contract: reference CPU path timed on rank 0 at N = 1 only
             log("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(shard.stream_seed)
             log("done")
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         td.barrier()
         td.destroy_process_group()
