@@ -48,8 +48,15 @@ struct LkPyr {
 struct LkShared {
     short2 dxy[NPX + 3];  // (Ix, Iy) of the template window
     int2 pxy[NPX + 3];    // (diff * Ix, diff * Iy) of the current iteration
+    int2 zer[NPX + 3];    // zeros (written once per kernel): the second operand of the b chains' scalar-pixel lanes -- a read of 0 instead
+                          // of a select per row (the chains' row offsets are instruction immediates, so the zeros span the rows too)
     uint8_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level)
 };
+// once per kernel, before the first lk_level
+__device__ __forceinline__ void lk_shared_init(LkShared &sh) {
+    for (int i = threadIdx.x; i < NPX + 3; i += 64) sh.zer[i] = make_int2(0, 0);
+    __syncthreads();
+}
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
@@ -175,6 +182,8 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     nexty -= halfWin;
     float pdx = 0.f, pdy = 0.f;
     int tx0 = 0x40000000, ty0 = 0x40000000;  // tile origin in image coordinates (invalid: staged on first use)
+    int pinx = 0x40000000, piny = 0x40000000;   // integer window origin of the previous iteration
+    int s00[2] = {0, 0}, s01[2] = {0, 0}, s10[2] = {0, 0}, s11[2] = {0, 0};   // this lane's 2 x 4 tile bytes at that origin
     for (int j = 0; j < maxCount; j++) {
         const int inx = (int) floorf(nextx), iny = (int) floorf(nexty);
         if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
@@ -196,13 +205,29 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         }
         __syncthreads();  // tile staged; previous iteration's chain reads are done before px/py are overwritten
         const int tbase = (iny - ty0) * TW + (inx - tx0);
+        {
+            // The eight tile bytes of BOTH rounds first (one LDS latency instead of two: in program order the second round's reads sat
+            // behind the first round's store), then the arithmetic, then the two stores.  And only when the window's INTEGER origin
+            // moved: once the iteration is down to sub-pixel steps -- most iterations -- the bytes are last iteration's, only the
+            // weights change, and the LDS round trip drops out of the dependent chain altogether.
+            if (inx != pinx || iny != piny) {   // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int p = min(lane + 64 * r, NPX - 1);
-            const uint8_t *src = sh.jt + toff[r] + tbase;
-            const int jval = descale(bl_u8(src[0], src[1], src[TW], src[TW + 1], wt), 9);
-            const int diff = (int) (short) (jval - rI[r]);
-            sh.pxy[p] = make_int2(diff * rIx[r], diff * rIy[r]);
+                for (int r = 0; r < 2; r++) {
+                    const uint8_t *src = sh.jt + toff[r] + tbase;
+                    s00[r] = src[0]; s01[r] = src[1]; s10[r] = src[TW]; s11[r] = src[TW + 1];
+                }
+                pinx = inx;
+                piny = iny;
+            }
+            int2 out[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int jval = descale(bl_u8(s00[r], s01[r], s10[r], s11[r], wt), 9);
+                const int diff = (int) (short) (jval - rI[r]);
+                out[r] = make_int2(diff * rIx[r], diff * rIy[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) sh.pxy[min(lane + 64 * r, NPX - 1)] = out[r];
         }
         __syncthreads();
         // b chains (lkpyramid.cpp:553-562, 628-646): lanes 0..7 = (vector lane q: pixels q and q+4, component),
@@ -211,24 +236,29 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         {
             const int l10 = min(lane, 9), comp = l10 & 1, q = l10 >> 1;
             const bool two = q < 4;
-            const int qa = two ? q : 8, qb = two ? q + 4 : 8;
+            const int qa = two ? q : 8;
             const int *src = reinterpret_cast<const int *>(sh.pxy) + comp;
+            // second pixel of the chain: column q + 4, or -- scalar-pixel lanes -- the zeros (va + 0 == va: same value as the select)
+            const int *srcb = two ? src + 2 * (q + 4) : reinterpret_cast<const int *>(sh.zer);
 #pragma unroll
             for (int y = 0; y < WIN; y++) {
                 const int va = src[2 * (y * WIN + qa)];
-                int vb = src[2 * (y * WIN + qb)];
-                vb = two ? vb : 0;
+                const int vb = srcb[2 * (y * WIN)];
                 bacc += (float) (va + vb);
             }
         }
+        // The reduce of intrin_sse's v_reduce_sum + the scalar pixel, sres = b[8 + c] + ((b[0 + c] + b[4 + c]) + 0) + ((b[2 + c] + b[6 + c]) + 0),
+        // with the chains on lanes 2 q + c: three DPP row shifts bring the operands together (IEEE addition is commutative, so
+        // "upper lane + lower lane" is the reference's "lower + upper" to the last bit) and two broadcasts deliver the result -- instead
+        // of ten v_readlane and the scalar-register hazards behind them
         float ib[2];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const float s0 = lane_bcast(bacc, 0 + c) + lane_bcast(bacc, 4 + c);  // qb0[0|1] + qb1[0|1]
-            const float s2 = lane_bcast(bacc, 2 + c) + lane_bcast(bacc, 6 + c);  // qb0[2|3] + qb1[2|3]
-            float sres = lane_bcast(bacc, 8 + c);
-            sres += (s0 + 0.f) + (s2 + 0.f);
-            ib[c] = sres;
+        {
+            float t = bacc + dpp_row_shr<4>(bacc);   // lanes 4 + c: b[4 + c] + b[0 + c];  lanes 6 + c: b[6 + c] + b[2 + c]
+            t = t + 0.f;
+            const float u = t + dpp_row_shr<2>(t);   // lanes 6 + c: (s2 + 0) + (s0 + 0)
+            const float w = bacc + dpp_row_shr<2>(u);   // lanes 8 + c: b[8 + c] + ((s0 + 0) + (s2 + 0))
+            ib[0] = lane_bcast(w, 8);
+            ib[1] = lane_bcast(w, 9);
         }
         const float b1 = ib[0] * (1.f / (1 << 20)), b2 = ib[1] * (1.f / (1 << 20));
         const float dx = (A12 * b2 - A22 * b1) * D;
@@ -237,8 +267,20 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         nexty += dy;
         nx = nextx + halfWin;
         ny = nexty + halfWin;
-        if ((double) dx * (double) dx + (double) dy * (double) dy <= epsilon) break;
-        if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
+        // The two stopping rules of lkpyramid.cpp:671-679 are written in double there.  (1) |delta|^2 <= epsilon: the squares are exact
+        // in double, their sum is rounded once; the same sum in float is within 3 float ulps of it, so the double arithmetic (half-rate
+        // instructions on the critical path of every iteration) is only needed inside a band of +-1e-5 (relative) around epsilon.
+        // (2) fabs((double) (dx + pdx)) < 0.01: the argument IS a float; no float lies between 0.01f (= 0.00999999977...) and 0.01, so
+        // "< 0.01 in double" is "<= 0.01f in float", exactly.
+        {
+            const float d2 = dx * dx + dy * dy, ef = (float) epsilon;
+            bool stop;
+            if (d2 > ef * 1.00001f) stop = false;
+            else if (d2 < ef * 0.99999f) stop = true;
+            else stop = (double) dx * (double) dx + (double) dy * (double) dy <= epsilon;
+            if (stop) break;
+        }
+        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
             nx -= dx * 0.5f;
             ny -= dy * 0.5f;
             break;
@@ -316,6 +358,7 @@ __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxL
                                             float *nextio, uint8_t *__restrict__ status_out, float *__restrict__ err_out,
                                             int n) {
     __shared__ LkShared sh;
+    lk_shared_init(sh);
     // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Giving every XCD one CONTIGUOUS
     // eighth of the keypoint list (callers keep keypoints in spatial / grid order) keeps an image region in one L2
     // instead of pulling the whole pyramid through all eight.
@@ -330,6 +373,7 @@ __global__ void __launch_bounds__(64) k_klt_dn(LkPyr P, LkPyr C, int mode, int m
                                                float fbDist, const float *__restrict__ pts, const float *init, float *nextio,
                                                uint8_t *__restrict__ status_out, const int *__restrict__ d_n) {
     __shared__ LkShared sh;
+    lk_shared_init(sh);
     const int per = gridDim.x >> 3;
     const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (kp >= *d_n) return;
@@ -376,6 +420,7 @@ __global__ void __launch_bounds__(256) k_track_stage_in(TrackSlots D) {
 __global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D, int maxLevelPrior, int maxLevelFull, int maxCount,
                                                   double epsilon, float errThresh, float fbDist) {
     __shared__ LkShared sh;
+    lk_shared_init(sh);
     const int per = gridDim.x >> 3;
     const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (i >= D.n) return;
@@ -427,6 +472,7 @@ __global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D
 __global__ void __launch_bounds__(64) k_track_klt_retry(LkPyr P, LkPyr C, TrackSlots D, int maxLevelFull, int maxCount, double epsilon,
                                                         float errThresh, float fbDist) {
     __shared__ LkShared sh;
+    lk_shared_init(sh);
     const int per = gridDim.x >> 3;
     const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (i >= D.n) return;
@@ -451,6 +497,7 @@ struct KltBatchItem {
 __global__ void __launch_bounds__(64) k_klt_batch(const KltBatchItem *__restrict__ items, int maxLevel, int maxCount, double epsilon,
                                                   float errThresh, float fbDist) {
     __shared__ LkShared sh;
+    lk_shared_init(sh);
     const KltBatchItem &it = items[blockIdx.y];
     const int per = gridDim.x >> 3;
     const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);

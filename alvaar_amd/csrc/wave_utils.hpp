@@ -12,6 +12,13 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// v of the lane `n` positions below within the 16-lane DPP row (row_shr:n; lanes without a source read 0): a cross-lane move that costs
+// no LDS round trip and no scalar register
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, true));
+}
+
 // Sum of 32 per-lane values over the 64 lanes of a wave: at distance d each lane keeps half of its values and adds the
 // partner's copy of that half (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges instead of 32 x 6).  On return v[0] of lane l holds the
 // wave total of value (l >> 1).  The summation order is fixed (bit-reproducible).
