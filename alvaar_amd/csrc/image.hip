@@ -188,6 +188,133 @@ __device__ __forceinline__ void pyrdown_tile(const StageArgs &a, int bid) {
     for (int k = 0; k < 4 && x + k < a.dw; k++) store_mirrors(a.ng, a.ng_pitch, a.dw, a.dh, a.win, x + k, y, out[k]);
 }
 
+// ---- everything behind level 0 in ONE launch ---------------------------------------------------------------------------------------
+// The stage kernels above are a chain of four dependent launches (level l+1 is read by stage l+1 only after stage l wrote it): at one
+// 640x480 frame each is ~5 us of kernel for ~0.5 MB, i.e. four launch latencies in front of the tracker.  Here every workgroup that needs
+// a level computes it ITSELF from level 0, in LDS: the pyramid is a 5x5 filter per level, so a 16 x 16 tile of level L (+ 1 px for Scharr)
+// has a (2^L 17 + ...) ~ 39 / 81 / 165 pixel footprint in level 0 -- 28 KB of LDS at most, a few thousand taps per workgroup.  Roles by
+// workgroup index: Scharr of level 0 (scharr_tile, as before) | for L = 1 .. 3: tile of level L from level 0 through the levels between
+// (none of them read from memory), its interior + REFLECT_101 border written once, Scharr of level L from the same LDS tile.
+// Integer arithmetic and border rule are the stage kernels' (pyrDown: borderInterpolate REFLECT_101 on the INPUT level's size,
+// pyramids.cpp:760-775; Scharr: the REFLECT_101 padding, lkpyramid.cpp:83-121): an out-of-image tile entry holds the value of its
+// mirror image, which is what the padding of the stored level holds.  Results are bit-identical (tests/test_gpu_image.py).
+// Output tile side per target level: 16 x 16 for levels 1 and 2, 8 x 8 for level 3 -- its footprint in level 0 would be 165 x 165
+// (28 KB of LDS, 650 LDS reads per thread for the level-1 tile alone: the launch's critical path, and the LDS bill of every workgroup
+// of the launch); with 8 x 8 it is 101 x 101.  Buffer sides: footprints (t + 2) -> 2 (n - 1) + 5 per level down.
+__host__ __device__ constexpr int rest_tile(int L) { return L == 3 ? 8 : 16; }
+constexpr int R3 = 18;                   // target tile + halo: 18 (levels 1, 2) or 10 (level 3)
+constexpr int R2 = 23;                   // level 2 inside a level-3 workgroup: 2 * 9 + 5
+constexpr int R1 = 49;                   // level 1: 2 * 22 + 5 (level-3 workgroup) > 39 = 2 * 17 + 5 (level-2 workgroup)
+constexpr int R0 = 101;                  // level 0: 2 * 48 + 5 (level-3 workgroup) > 81 (level 2) > 39 (level 1)
+constexpr int R0P = (R0 + 3 + 3) / 4 * 4;   // level-0 LDS pitch (dword staging: up to 3 bytes of alignment slack)
+struct RestLevel {
+    uint8_t *g;
+    size_t g_pitch;
+    int16_t *d;
+    size_t d_pitch;
+    int w, h;
+};
+struct RestArgs {
+    StageArgs s0;          // Scharr of level 0
+    RestLevel lv[4];
+    int nlevels, win;
+    int first[4], bx[4];   // deep tiles of level L: first workgroup index, tiles per row
+};
+struct Span {
+    int lo, hi;            // inclusive, unmirrored coordinates
+};
+__device__ __forceinline__ int mirror101(int c, int n) { return c < 0 ? -c : (c >= n ? 2 * (n - 1) - c : c); }
+// the range of the level below that the entries of `s` (mirrored into [0, n)) read: 2 m - 2 .. 2 m + 2
+__device__ __forceinline__ Span below(Span s, int n) { return Span{2 * max(s.lo, 0) - 2, 2 * min(s.hi, n - 1) + 2}; }
+
+// dst tile (span dx, dy at a level of size n_x x n_y) from the src tile (span sx, sy) of the level below: pyrDown at the mirrored coordinate
+__device__ __forceinline__ void down_tile(const uint8_t *src, int spitch, Span sx, Span sy, uint8_t *dst, int dpitch, Span dx, Span dy, int nx,
+                                          int ny, int tid) {
+    const int dw = dx.hi - dx.lo + 1, dh = dy.hi - dy.lo + 1;
+    for (int e = tid; e < dw * dh; e += 256) {
+        const int j = e / dw, i = e - j * dw;
+        const int mx = mirror101(dx.lo + i, nx), my = mirror101(dy.lo + j, ny);
+        const uint8_t *p = src + (2 * my - 2 - sy.lo) * spitch + (2 * mx - 2 - sx.lo);
+        int acc = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const uint8_t *q = p + r * spitch;
+            const int srow = q[0] + q[4] + 4 * (q[1] + q[3]) + 6 * q[2];
+            acc += ((r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4)) * srow;
+        }
+        dst[j * dpitch + i] = (uint8_t) ((acc + 128) >> 8);
+    }
+}
+
+__device__ __forceinline__ void deep_tile(const RestArgs &A, int L, int bid) {
+    __shared__ __attribute__((aligned(16))) uint8_t b0[R0 * R0P];
+    __shared__ uint8_t b1[R1 * R1], b2[R2 * R2], b3[R3 * R3];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const RestLevel &T = A.lv[L];
+    const int ts = rest_tile(L);
+    const int ox = (bid % A.bx[L]) * ts, oy = (bid / A.bx[L]) * ts;
+    // spans per level, from the target down to level 0
+    Span sx[4], sy[4];
+    sx[L] = Span{ox - 1, min(ox + ts, T.w)};   // one pixel of halo for Scharr; beyond the level's last column + 1 nothing is needed
+    sy[L] = Span{oy - 1, min(oy + ts, T.h)};
+    for (int l = L; l >= 1; l--) {
+        sx[l - 1] = below(sx[l], A.lv[l].w);
+        sy[l - 1] = below(sy[l], A.lv[l].h);
+    }
+    // ---- level 0 footprint from memory, aligned dwords (columns >= -4: inside the REFLECT_101 padding of `win` >= 3 ... 9 pixels)
+    const RestLevel &Z = A.lv[0];
+    const int xa = (sx[0].lo & ~3);   // floor to a multiple of 4 (also for negative lo: two's complement)
+    const int ndw = (sx[0].hi - xa) / 4 + 1, nrow = sy[0].hi - sy[0].lo + 1;
+    for (int e = tid; e < ndw * nrow; e += 256) {
+        const int r = e / ndw, c = e - r * ndw;
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(Z.g + (ptrdiff_t) (sy[0].lo + r) * (ptrdiff_t) Z.g_pitch + xa + 4 * c);
+        *reinterpret_cast<uint32_t *>(b0 + r * R0P + 4 * c) = v;
+    }
+    __syncthreads();
+    const Span s0x{xa, sx[0].hi};   // the staged columns start at xa
+    // levels 1 .. L in LDS: intermediate levels in their own buffers, the TARGET level always in the small buffer b3
+    Span px = s0x, py = sy[0];
+    for (int l = 1; l <= L; l++) {
+        const uint8_t *src = l == 1 ? b0 : (l == 2 ? b1 : b2);
+        const int sp = l == 1 ? R0P : (l == 2 ? R1 : R2);
+        uint8_t *dst = l == L ? b3 : (l == 1 ? b1 : b2);
+        const int dp = l == L ? R3 : (l == 1 ? R1 : R2);
+        down_tile(src, sp, px, py, dst, dp, sx[l], sy[l], A.lv[l].w, A.lv[l].h, tid);
+        __syncthreads();
+        px = sx[l];
+        py = sy[l];
+    }
+    // ---- this workgroup's 16 x 16 pixels of level L: the stored level (+ border mirrors) and its Scharr derivatives
+    const int tx = tid % ts, ty = tid / ts;
+    const int x = ox + tx, y = oy + ty;
+    if (ty >= ts || x >= T.w || y >= T.h) return;
+    const uint8_t *c = b3 + (ty + 1) * R3 + (tx + 1);   // entry of (x, y): spans start at ox - 1, oy - 1
+    const uint8_t v = c[0];
+    T.g[(size_t) y * T.g_pitch + x] = v;
+    store_mirrors(T.g, T.g_pitch, T.w, T.h, A.win, x, y, v);
+    int t0[3], t1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int p0 = c[-R3 + k - 1], p1 = c[k - 1], p2 = c[R3 + k - 1];
+        t0[k] = (p0 + p2) * 3 + p1 * 10;
+        t1[k] = p2 - p0;
+    }
+    const short ix = (short) (t0[2] - t0[0]), iy = (short) ((t1[2] + t1[0]) * 3 + t1[1] * 10);
+    int16_t *drow = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(T.d) + (size_t) y * T.d_pitch) + 2 * x;
+    *reinterpret_cast<uint32_t *>(drow) = (uint32_t) (uint16_t) ix | ((uint32_t) (uint16_t) iy << 16);
+}
+
+__global__ void __launch_bounds__(256) k_pyr_rest(RestArgs A) {
+    const int bid = blockIdx.x;
+    if (bid < A.s0.scharr_blocks) {
+        scharr_tile(A.s0, bid);
+        return;
+    }
+    int L = 1;
+    while (L + 1 < A.nlevels && bid >= A.first[L + 1]) L++;
+    deep_tile(A, L, bid - A.first[L]);
+}
+
 __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
     int bid = blockIdx.x;
     if (bid < a.scharr_blocks) scharr_tile(a, bid);
@@ -330,6 +457,27 @@ static int stage_args(const alva_pyramid *p, int l, StageArgs &a) {  // returns 
 }
 
 static int build_rest(alva_ctx *ctx, alva_pyramid *p) {
+    static const bool staged = getenv("ALVA_PYRAMID_STAGES") != nullptr;   // A/B: the chain of stage launches instead of the fused one
+    if (!staged && p->nlevels >= 2 && p->nlevels <= 4 && p->win >= 3) {
+        RestArgs A{};
+        (void) stage_args(p, 0, A.s0);
+        A.s0.dw = 0;
+        A.nlevels = p->nlevels;
+        A.win = p->win;
+        int blocks = A.s0.scharr_blocks;
+        for (int l = 0; l < p->nlevels; l++) {
+            const alva_level &L = p->lv[l];
+            A.lv[l] = RestLevel{L.gray, L.gray_pitch, L.deriv, L.deriv_pitch, L.w, L.h};
+            if (l >= 1) {
+                A.first[l] = blocks;
+                A.bx[l] = alva_divup(L.w, rest_tile(l));
+                blocks += A.bx[l] * alva_divup(L.h, rest_tile(l));
+            }
+        }
+        hipLaunchKernelGGL(k_pyr_rest, dim3(blocks), dim3(64, 4), 0, ctx->stream, A);
+        ALVA_LAUNCH_CHECK();
+        return ALVA_OK;
+    }
     for (int l = 0; l < p->nlevels; l++) {
         StageArgs a;
         const int blocks = stage_args(p, l, a);

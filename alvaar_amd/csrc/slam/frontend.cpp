@@ -283,6 +283,7 @@ void Slam::reset_frame() {  // visual_frontend.cpp:700-714
     const KpTable copy = cur->kps;
     for (const auto &e: copy) remove_obs_from_cur(e.first);
     cur->kps.clear();
+    cur->ids3d_valid_ = false;
     cur->grid.clear();
     cur->grid.resize(cur->grid_cells);
     cur->n_kps = cur->n_2d = cur->n_3d = 0;
@@ -304,9 +305,13 @@ float Slam::compute_parallax(int kfid, bool unrotate, bool median) {  // visual_
     int cnt = 0;
     std::vector<uint32_t> &all = parallax_bits_;  // the reference's std::set<float>: distinct values, ascending
     all.clear();
-    for (const auto &e: cur->kps) {
-        const KeyPt &k = e.second;
-        const KeyPt *kk = kf.find(k.id);
+    const FlatHash<FlatNoValue> &cids = cur->kps.ids, &kids = kf.kps.ids;
+    for (int sl = cids.first(); sl != FlatHash<FlatNoValue>::END; sl = cids.next(sl)) {
+        const KeyPt &k = cur->kps.kp[(size_t) sl];
+        // the keyframe's keypoint with the same id.  The frame IS a copy of that keyframe's table that has only lost elements since
+        // (and gained none: new keypoints come with a new keyframe), so the id usually sits in the SAME slot of the keyframe's table:
+        // checked first, the hash look-up only when an edit of the keyframe (a merge) moved it
+        const KeyPt *kk = (size_t) sl < kids.slots() && kids.slot_live((size_t) sl) && kids.key(sl) == k.id ? &kf.kps.kp[(size_t) sl] : kf.find(k.id);
         if (!kk) continue;
         float un[2] = {k.unpx[0], k.unpx[1]};
         if (unrotate) {
@@ -332,11 +337,21 @@ float Slam::compute_parallax(int kfid, bool unrotate, bool median) {  // visual_
         tmp.resize(all.size());
         uint32_t *src = all.data(), *dst = tmp.data();
         const size_t m = all.size();
-        for (int shift = 0; shift < 32; shift += 11) {
-            size_t hist[2049] = {0};
-            for (size_t i = 0; i < m; i++) hist[((src[i] >> shift) & 2047u) + 1]++;
-            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
-            for (size_t i = 0; i < m; i++) dst[hist[(src[i] >> shift) & 2047u]++] = src[i];
+        // three 11-bit digits; the three histograms in ONE counting pass
+        static thread_local uint32_t hist[3][2049];
+        std::memset(hist, 0, sizeof(hist));
+        for (size_t i = 0; i < m; i++) {
+            const uint32_t v = src[i];
+            hist[0][(v & 2047u) + 1]++;
+            hist[1][((v >> 11) & 2047u) + 1]++;
+            hist[2][(v >> 22) + 1]++;
+        }
+        for (int d = 0; d < 3; d++) {
+            uint32_t *h = hist[d];
+            if (h[((src[0] >> (11 * d)) & 2047u) + 1] == m) continue;   // every key has the same digit here: the pass would not move anything
+            for (int b = 0; b < 2048; b++) h[b + 1] += h[b];
+            const int shift = 11 * d;
+            for (size_t i = 0; i < m; i++) dst[h[(src[i] >> shift) & 2047u]++] = src[i];
             std::swap(src, dst);
         }
         size_t u = 0;

@@ -69,6 +69,7 @@ const KeyPt *FrameRec::find(int id_) const { return kps.find_ptr(id_); }
 
 void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
     if (!kps.emplace(k)) return;
+    ids3d_valid_ = false;
     grid_add(k);
     n_kps++;
     if (k.is3d) n_3d++;
@@ -113,6 +114,7 @@ void FrameRec::remove(int id_) {  // :209-232
     else n_2d--;
     n_kps--;
     kps.erase(id_);
+    ids3d_valid_ = false;
 }
 
 void FrameRec::turn3d(int id_) {  // :234-248
@@ -120,6 +122,7 @@ void FrameRec::turn3d(int id_) {  // :234-248
     if (!k) return;
     if (!k->is3d) {
         kps.set_3d(id_);
+        ids3d_valid_ = false;
         n_3d++;
         n_2d--;
     }
@@ -180,6 +183,7 @@ void FrameRec::reset() {  // :467-489
     kfid = 0;
     timestamp = 0.;
     kps.clear();
+    ids3d_valid_ = false;
     grid.clear();
     grid.resize(grid_cells);
     n_kps = n_2d = n_3d = 0;
@@ -457,14 +461,14 @@ void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
 }
 
 void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) {  // map_manager.cpp:366-426
-    auto it = map_points.find(id);
-    if (it == map_points.end() || !it->second) return;
-    MapPt &mp = *it->second;
+    MapPt *mpp = mp_raw(id);   // the flat mirror of mapMapPoints_ (same membership)
+    if (!mpp) return;
+    MapPt &mp = *mpp;
     if (!mp.is3d) {
         const SortedIds obs = mp.obs_kfs;  // getObservedKeyframeIds returns a copy; removals below edit the member
         for (int kf: obs) {
-            auto k = keyframes.find(kf);
-            if (k != keyframes.end()) k->second->turn3d(id);
+            FrameRec *k = kf_raw(kf);
+            if (k) k->turn3d(id);
             else mp.remove_obs(kf);
         }
         sync_nobs(mp);
@@ -629,14 +633,14 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
         FrameRec *kf = kf_raw(c.first);
         if (kf) {
             kf->covisible[frame.kfid] = c.second;
-            kf->for_each_id([&](int kid, bool is3d) {  // getKeypoints3d(): container order, 3-D only
+            for (int kid: kf->ids3d()) {  // getKeypoints3d(): container order, 3-D only
                 const size_t id = (size_t) kid;
-                if (is3d && !mark_a_[id] && !mark_b_[id]) {
+                if (!mark_a_[id] && !mark_b_[id]) {
                     mark_b_[id] = 1;
                     touched_b_.push_back(kid);
                     local_ids.insert(kid);
                 }
-            });
+            }
         } else {
             bad.insert(c.first);
         }

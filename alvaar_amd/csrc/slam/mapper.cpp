@@ -347,11 +347,7 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                 // Nothing in this loop depends on the ORDER of the walk: good / total are counts, isBad() acts on one map point, and the
                 // repairs drop different keypoints of this keyframe (erasing from a hash table or a cell list commutes).  So the table's
                 // slots are taken in memory order, with the observer-count byte table in front of the map point.
-                const FlatHash<FlatNoValue> &so = co->kps.ids;
-                const size_t ns = so.slots();
-                for (size_t sl = 0; sl < ns; sl++) {
-                    if (!so.slot_live(sl) || !so.tag((int) sl)) continue;
-                    const int kid = so.key((int) sl);
+                for (int kid: co->ids3d()) {
                     const unsigned nobs = mp_nobs_[(size_t) kid];
                     if (nobs >= 2) {  // two observers or more: isBad() is false and has no side effect (map_point.cpp:183-202)
                         good += nobs > 4;
@@ -462,13 +458,12 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (score >= min_cov && !all_cst && kfid > 0) {
             add_pose(kfid, *kf, false);
             kfs_to_opt.insert(kfid);
-            kf->for_each_id([&](int kid, bool is3d) {
-                if (is3d && !mark_a_[(size_t) kid]) {  // a repeated insert would not change the set
+            for (int kid: kf->ids3d())
+                if (!mark_a_[(size_t) kid]) {  // a repeated insert would not change the set
                     mark_a_[(size_t) kid] = 1;
                     touched_a_.push_back(kid);
                     mps_to_opt.insert(kid);
                 }
-            });
         } else {
             add_pose(kfid, *kf, true);
             const_kfs.insert(kfid);

@@ -175,6 +175,21 @@ struct FrameRec {
         const FlatHash<FlatNoValue> &h = kps.ids;
         for (int sl = h.first(); sl != FlatHash<FlatNoValue>::END; sl = h.next(sl)) f(h.key(sl), h.tag(sl) != 0);
     }
+    // the ids of the 3-D keypoints in mapKeypoints_ order (getKeypoints3d, frame.cpp:55-67) as ONE contiguous array, cached: three loops
+    // of every keyframe step walk this list for every covisible keyframe (covisibility's local ids, the local BA's point set, the
+    // keyframe filter) and a keyframe is edited rarely (merges, culled observations); every edit of kps invalidates the cache
+    const std::vector<int> &ids3d() const {
+        if (!ids3d_valid_) {
+            ids3d_.clear();
+            for_each_id([&](int kid, bool three_d) {
+                if (three_d) ids3d_.push_back(kid);
+            });
+            ids3d_valid_ = true;
+        }
+        return ids3d_;
+    }
+    mutable std::vector<int> ids3d_;
+    mutable bool ids3d_valid_ = false;
     bool observes(int id) const { return kps.count(id) != 0; }
     int cell_index(const float *px) const;
     void grid_add(const KeyPt &k);
