@@ -1213,7 +1213,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
                     ALVA_HIP(hipStreamSynchronize(st));
                     break;
                 }
-                __builtin_ia32_pause();
+                alva_poll_relax(spins);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             memcpy(scal, pin_scal, sizeof(scal));
@@ -1305,7 +1305,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
                 ALVA_HIP(hipStreamSynchronize(st));
                 break;
             }
-            __builtin_ia32_pause();
+            alva_poll_relax(spins);
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {

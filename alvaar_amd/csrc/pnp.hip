@@ -579,7 +579,7 @@ int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose
                     ALVA_HIP(hipStreamSynchronize(ctx->stream));
                     break;
                 }
-                __builtin_ia32_pause();
+                alva_poll_relax(spins);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         } else {

@@ -891,7 +891,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
                     ALVA_HIP(hipStreamSynchronize(m->st));
                     break;
                 }
-                __builtin_ia32_pause();
+                alva_poll_relax(spins);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         } else {
@@ -907,7 +907,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     if (slots_path && poll_seq && job.want_pose) {
         const volatile int *early = o_hdr + 9;
         unsigned spins = 0;
-        while (*early != poll_seq && ++spins < (1u << 26)) __builtin_ia32_pause();
+        while (*early != poll_seq && ++spins < (1u << 26)) alva_poll_relax(spins);
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (*early == poll_seq && !o_hdr[13] && o_hdr[10] >= 4) {
             m->pose_n = o_hdr[10] > n_pose_cap ? n_pose_cap : o_hdr[10];
