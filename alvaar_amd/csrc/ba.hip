@@ -1171,7 +1171,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     if (rc) return rc;
     uint8_t *stage = pin + 256;
     hipStream_t st = ctx->stream;
-    ALVA_HIP(hipStreamSynchronize(st));  // nothing enqueued earlier may still be reading the staging area
+    ALVA_HIP(alva_stream_sync(st));  // nothing enqueued earlier may still be reading the staging area
     rc = H.build(in, base, stage);
     if (rc) return rc;
     const auto t_built = std::chrono::steady_clock::now();
@@ -1210,7 +1210,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
             unsigned spins = 0;
             while (*flag != eval_seq) {
                 if (++spins > (1u << 26)) {
-                    ALVA_HIP(hipStreamSynchronize(st));
+                    ALVA_HIP(alva_stream_sync(st));
                     break;
                 }
                 alva_poll_relax(spins);
@@ -1220,7 +1220,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
             return ALVA_OK;
         }
         ALVA_HIP(hipMemcpyAsync(pin_scal, B.scal, sizeof(scal), hipMemcpyDeviceToHost, st));  // pinned: a plain DMA, no staging
-        ALVA_HIP(hipStreamSynchronize(st));
+        ALVA_HIP(alva_stream_sync(st));
         memcpy(scal, pin_scal, sizeof(scal));
         return ALVA_OK;
     };
@@ -1302,7 +1302,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         unsigned spins = 0;
         while (*flag != eval_seq) {
             if (++spins > (1u << 26)) {
-                ALVA_HIP(hipStreamSynchronize(st));
+                ALVA_HIP(alva_stream_sync(st));
                 break;
             }
             alva_poll_relax(spins);
@@ -1312,7 +1312,7 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, B.chi2, chi_bytes, hipMemcpyDeviceToHost, st));
         ALVA_HIP(hipMemcpyAsync(r_poses, H.xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
         if (npd) ALVA_HIP(hipMemcpyAsync(r_pts, H.xt, npd * 8, hipMemcpyDeviceToHost, st));
-        ALVA_HIP(hipStreamSynchronize(st));
+        ALVA_HIP(alva_stream_sync(st));
     }
     H.finish(in, r_chi, r_poses, r_pts, h_chi2, h_depth_pos, h_info);
     if (getenv("ALVA_BA_TIMING")) {
@@ -1376,7 +1376,7 @@ extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, do
     rc = alva_ctx_pinned(ctx, p_stage + std::max(in_total, res_total) + 256, (void **) &pin);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    ALVA_HIP(hipStreamSynchronize(st));
+    ALVA_HIP(alva_stream_sync(st));
     BaDev *d_desc = (BaDev *) (base + off_desc), *h_desc = (BaDev *) (pin + p_desc);
     BaRun *d_run = (BaRun *) (base + off_run), *h_run = (BaRun *) (pin + p_run);
     double *d_scal = (double *) (base + off_scal), *h_scal = (double *) pin;
@@ -1421,7 +1421,7 @@ extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, do
     };
     auto read_scal = [&]() -> int {
         ALVA_HIP(hipMemcpyAsync(h_scal, d_scal, cnt * 64, hipMemcpyDeviceToHost, st));
-        ALVA_HIP(hipStreamSynchronize(st));
+        ALVA_HIP(alva_stream_sync(st));
         return ALVA_OK;
     };
     for (int b = 0; b < count; b++) {
@@ -1501,7 +1501,7 @@ extern "C" int alva_local_ba_batch(alva_ctx *ctx, int count, const int *n_kf, do
             ALVA_HIP(hipMemcpyAsync(pin + p_stage + roff, H.xt, (size_t) H.B.npd * 8, hipMemcpyDeviceToHost, st));
             roff += ((size_t) H.B.npd * 8 + 255) / 256 * 256;
         }
-        ALVA_HIP(hipStreamSynchronize(st));
+        ALVA_HIP(alva_stream_sync(st));
         for (int b = 0; b < count; b++) {
             BaHost &H = Hs[(size_t) b];
             H.finish(ins[(size_t) b], pin + p_stage + o_chi[(size_t) b], (const double *) (pin + p_stage + o_pose[(size_t) b]),

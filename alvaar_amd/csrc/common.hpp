@@ -74,13 +74,37 @@ static inline int alva_divup(int a, int b) { return (a + b - 1) / b; }
 // cores a yielded thread comes back late (4 sessions: 8.3 k frames/s spinning, 6.0 k yielding).
 #include <sched.h>
 #include <cstdlib>
+// Several sessions on ONE host thread (alva_system_group, system.hip): every session runs in a fiber, and a wait hands the thread to the
+// next session instead of spinning -- the hook below is that switch (null outside a group's worker thread).
+extern thread_local void (*alva_fiber_yield)(void);
 static inline void alva_poll_relax(unsigned spins) {
+    if (alva_fiber_yield) {
+        alva_fiber_yield();
+        return;
+    }
     static const unsigned yield_after = [] {
         const char *e = getenv("ALVA_POLL_YIELD_AFTER");
         return e ? (unsigned) strtoul(e, nullptr, 10) : 0xffffffffu;
     }();
     if (spins < yield_after) __builtin_ia32_pause();
     else sched_yield();
+}
+// hipStreamSynchronize for the session paths: inside a group's fiber the wait is a query loop that lets the thread's other sessions run
+static inline hipError_t alva_stream_sync(hipStream_t st) {
+    if (!alva_fiber_yield) return hipStreamSynchronize(st);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        alva_fiber_yield();
+    }
+}
+static inline hipError_t alva_event_sync(hipEvent_t ev) {
+    if (!alva_fiber_yield) return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        alva_fiber_yield();
+    }
 }
 
 // Batched launches (B cameras, `per_cam` workgroups each).  Workgroups are dealt to the 8 XCDs round-robin by linear workgroup id and

@@ -1,6 +1,8 @@
 // Context, error reporting, scratch management.
 #include "common.hpp"
 
+thread_local void (*alva_fiber_yield)(void) = nullptr;
+
 static thread_local char g_err[512] = "";
 
 void alva_set_error(const char *fmt, ...) {
@@ -44,7 +46,7 @@ void prof_drain() {
     for (ProfRec &r: g_prof_recs) {
         if (!r.e0 || !r.e1) continue;
         float ms = 0.f;
-        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+        if (alva_event_sync(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             std::string key(r.name);
             if (!key.empty() && key.front() == '(' && key.back() == ')') key = key.substr(1, key.size() - 2);  // (k<a, b>) -> k<a, b>
             auto &a = g_prof_acc[key];
@@ -161,7 +163,7 @@ extern "C" int alva_ctx_create_with_priority(int device, int priority_class, alv
 extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
-    (void) hipStreamSynchronize(ctx->stream);
+    (void) alva_stream_sync(ctx->stream);
     for (auto &s: ctx->scratch)
         if (s.ptr) (void) hipFree(s.ptr);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
@@ -174,7 +176,7 @@ extern "C" void alva_ctx_destroy(alva_ctx *ctx) {
 
 extern "C" int alva_ctx_sync(alva_ctx *ctx) {
     ALVA_ARG(ctx != nullptr);
-    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    ALVA_HIP(alva_stream_sync(ctx->stream));
     return ALVA_OK;
 }
 
@@ -193,7 +195,7 @@ extern "C" void *alva_ctx_stream(alva_ctx *ctx) { return ctx ? (void *) ctx->str
 
 int alva_ctx_pinned(alva_ctx *ctx, size_t bytes, void **out) {
     if (ctx->pinned_bytes < bytes) {
-        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        ALVA_HIP(alva_stream_sync(ctx->stream));
         if (ctx->pinned) ALVA_HIP(hipHostFree(ctx->pinned));
         ctx->pinned = nullptr;
         ctx->pinned_bytes = 0;
@@ -214,7 +216,7 @@ int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out) {
     alva_scratch &s = ctx->scratch[slot];
     if (s.bytes < bytes) {
         // growing frees the old block: wait for work that may still read it
-        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        ALVA_HIP(alva_stream_sync(ctx->stream));
         if (s.ptr) ALVA_HIP(hipFree(s.ptr));
         s.ptr = nullptr;
         s.bytes = 0;

@@ -1020,7 +1020,7 @@ extern "C" int alva_detect_grid_collect(alva_ctx *ctx, const alva_detect_pending
     ALVA_ARG(ctx && pending && h_max_quality && h_count);
     *h_count = 0;
     if (!pending->h_cnt) return ALVA_OK;   // no cells: nothing was enqueued
-    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    ALVA_HIP(alva_stream_sync(ctx->stream));
     const CompactOut res = *static_cast<const CompactOut *>(pending->h_cnt);
     *h_count = res.n_total;
     const double freeCells = (double) ((size_t) pending->n_cells - (size_t) res.n_occupied);

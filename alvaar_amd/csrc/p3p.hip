@@ -582,7 +582,7 @@ extern "C" int alva_p3p_lmeds(alva_ctx *ctx, const double *d_bearings, const dou
         rc = alva_p3p_enqueue(ctx, d_bearings, d_wpts, n, max_iters, err_threshold, do_random, seed, fx, fy, H, (int *) pin,
                               (SelectOut *) (pin + off_out), pin + off_inl);
         if (rc) return rc;
-        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        ALVA_HIP(alva_stream_sync(ctx->stream));
         memcpy(&res, pin + off_out, sizeof(res));
         inl = pin + off_inl;
         if (res.n_valid_used >= max_iters || H >= max_draws) break;

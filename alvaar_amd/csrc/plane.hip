@@ -278,7 +278,7 @@ extern "C" int alva_find_plane(alva_ctx *ctx, const double *d_points, int n, con
     hipLaunchKernelGGL(k_plane_hyp, dim3(num_iterations), dim3(PL_NT), (size_t) n * sizeof(float), ctx->stream, A);
     hipLaunchKernelGGL(k_plane_finish, dim3(1), dim3(PL_NT), 0, ctx->stream, A, (PlaneFinish *) (pin + off_fin));
     ALVA_LAUNCH_CHECK();
-    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    ALVA_HIP(alva_stream_sync(ctx->stream));
     PlaneFinish fin;
     memcpy(&fin, pin + off_fin, sizeof(fin));
     if (fin.n_inliers < 32) return ALVA_OK;  // :261-269

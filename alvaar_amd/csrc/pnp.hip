@@ -452,7 +452,7 @@ extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *
     hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, A, base + off_act, (double *) base, base + off_dep, pin + 256,
                        (PnpOut *) pin, (const P3pSelectOut *) nullptr, (const uint8_t *) nullptr, (uint8_t *) nullptr);
     ALVA_LAUNCH_CHECK();
-    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    ALVA_HIP(alva_stream_sync(ctx->stream));
     PnpOut res;
     memcpy(&res, pin, sizeof(res));
     const uint8_t *bad = pin + 256;
@@ -576,14 +576,14 @@ int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose
             unsigned spins = 0;
             while (*flag != P.seq) {
                 if (++spins > (1u << 26)) {
-                    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+                    ALVA_HIP(alva_stream_sync(ctx->stream));
                     break;
                 }
                 alva_poll_relax(spins);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         } else {
-            ALVA_HIP(hipStreamSynchronize(ctx->stream));
+            ALVA_HIP(alva_stream_sync(ctx->stream));
         }
         memcpy(&res, P.pin + P.poff_out, sizeof(res));
         if (res.p3p_n_valid_used >= P.p3p_iters || P.H >= P.max_draws) break;

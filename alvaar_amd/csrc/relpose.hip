@@ -1625,7 +1625,7 @@ extern "C" int alva_relpose_hypotheses(alva_ctx *ctx, const double *d_bv1, const
                   (int *) (pin + off_c)};
     hipLaunchKernelGGL(k_relpose_hyp, dim3(n_samples), dim3(64), 0, ctx->stream, A);
     ALVA_LAUNCH_CHECK();
-    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    ALVA_HIP(alva_stream_sync(ctx->stream));
     memcpy(h_models12, pin + off_m, (size_t) n_samples * 96);
     memcpy(h_counts, pin + off_c, (size_t) n_samples * 4);
     return ALVA_OK;
@@ -1685,7 +1685,7 @@ extern "C" int alva_compute_5pt_essential(alva_ctx *ctx, const double *d_bv1, co
                 hipLaunchKernelGGL(k_relpose_lm<false>, dim3(1), dim3(RP_LM_NT), 0, ctx->stream, C);
             ALVA_LAUNCH_CHECK();
         }
-        ALVA_HIP(hipStreamSynchronize(ctx->stream));
+        ALVA_HIP(alva_stream_sync(ctx->stream));
         memcpy(&sel, pin + off_sel, sizeof(sel));
         memcpy(&lm, pin + off_lm, sizeof(lm));
         mask = pin + off_mask;

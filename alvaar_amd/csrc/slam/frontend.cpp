@@ -189,8 +189,11 @@ void Slam::klt_from_motion_prior() {
         jw = job_wpt_.data();
     }
     int i = 0;
-    for (const auto &e: cur->kps) {
-        const KeyPt &k = e.second;
+    job_slots_.resize((size_t) n);
+    const FlatHash<FlatNoValue> &order = cur->kps.ids;
+    for (int sl = order.first(); sl != FlatHash<FlatNoValue>::END; sl = order.next(sl)) {
+        const KeyPt &k = cur->kps.kp[(size_t) sl];
+        job_slots_[(size_t) i] = sl;   // the table slot of tracking slot i: the results are written back without a look-up by id
         job_ids_[(size_t) i] = k.id;
         jpx[2 * (size_t) i] = k.px[0];
         jpx[2 * (size_t) i + 1] = k.px[1];
@@ -223,9 +226,10 @@ void Slam::klt_from_motion_prior() {
     lap(1);
     if (fail(st->track_begin(job, r))) return;
     lap(2);
+    // (nothing is inserted or erased between the gather above and here: the slots are still the keypoints')
     for (int pass = 1; pass <= 3; pass++)
         for (int s = 0; s < n; s++)
-            if (r.code_v[(size_t) s] == pass) cur->update(job_ids_[(size_t) s], &r.px_v[2 * (size_t) s], &r.unpx_v[2 * (size_t) s], &r.bv_v[3 * (size_t) s]);
+            if (r.code_v[(size_t) s] == pass) cur->update_slot(job_slots_[(size_t) s], &r.px_v[2 * (size_t) s], &r.unpx_v[2 * (size_t) s], &r.bv_v[3 * (size_t) s]);
     {
         const long full = cfg.klt_levels + 1;
         long work = 0;

@@ -79,6 +79,13 @@ void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
 void FrameRec::update(int id_, const float *px, const float *unpx, const double *bv) {  // frame.cpp:160-174
     KeyPt *cur_kp = kps.find_ptr(id_);
     if (!cur_kp) return;
+    update_kp(*cur_kp, px, unpx, bv);
+}
+
+void FrameRec::update_slot(int slot, const float *px, const float *unpx, const double *bv) { update_kp(kps.kp[(size_t) slot], px, unpx, bv); }
+
+void FrameRec::update_kp(KeyPt &kp, const float *px, const float *unpx, const double *bv) {
+    KeyPt *cur_kp = &kp;
     const int a = cell_index(cur_kp->px), b = cell_index(px);  // updateKeypointInGrid (:296-311)
     if (a != b) grid_remove(*cur_kp);
     cur_kp->px[0] = px[0]; cur_kp->px[1] = px[1];

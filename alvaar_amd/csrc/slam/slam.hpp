@@ -165,6 +165,8 @@ struct FrameRec {
     const KeyPt *find(int id) const;
     void add(const KeyPt &k);
     void update(int id, const float *px, const float *unpx, const double *bv);
+    void update_slot(int slot, const float *px, const float *unpx, const double *bv);   // the same for a keypoint given by its table slot
+    void update_kp(KeyPt &kp, const float *px, const float *unpx, const double *bv);
     void set_desc(int id, const Desc &d);
     bool change_id(int prev_id, int new_id, bool is3d);
     void remove(int id);
@@ -381,7 +383,7 @@ public:
 private:
     int err_ = 0;
     // the tracking step's slot tables (reused from frame to frame)
-    std::vector<int> job_ids_, pose_ids_;
+    std::vector<int> job_ids_, pose_ids_, job_slots_;
     std::vector<float> job_px_;
     std::vector<uint8_t> job_is3d_, job_stage3d_;
     std::vector<double> job_wpt_;

@@ -318,7 +318,7 @@ struct Arena {
     int grow(size_t need, hipStream_t st) {
         if (need <= cap) return ALVA_OK;
         if (base) {
-            ALVA_HIP(hipStreamSynchronize(st));
+            ALVA_HIP(alva_stream_sync(st));
             if (pinned) ALVA_HIP(hipHostFree(base));
             else ALVA_HIP(hipFree(base));
             base = nullptr;
@@ -406,7 +406,7 @@ struct HipStages::Impl {
         ALVA_HIP(hipMemsetAsync(trk_dev.base, 0, 256, st));  // the slot-wise step's counters start at zero
         // fresh (or recycled) pinned memory: the completion word must not equal a sequence number the host is about to wait for.  The
         // stream is idle here (both grows synchronised it), so a plain host store cannot race a kernel's publication.
-        ALVA_HIP(hipStreamSynchronize(st));
+        ALVA_HIP(alva_stream_sync(st));
         track_pin().o_hdr[8] = 0;
         track_pin().o_hdr[9] = 0;
         return ALVA_OK;
@@ -486,7 +486,7 @@ HipStages::~HipStages() {
     delete m;
 }
 
-int HipStages::init(int device, const Camera &cam, bool clahe, const double *invK) {
+int HipStages::init(int device, const Camera &cam, bool clahe, const double *invK, void *hip_stream) {
     m->device = device;
     m->cam = cam;
     m->clahe = clahe;
@@ -495,7 +495,7 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
     m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
     m->poll = getenv("ALVA_NO_POLL") == nullptr;
-    int rc = alva_ctx_create(device, nullptr, 1, &m->ctx);
+    int rc = hip_stream ? alva_ctx_create(device, hip_stream, 0, &m->ctx) : alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
     const size_t P = (size_t) cam.width * cam.height;
@@ -537,7 +537,7 @@ int HipStages::warm_up(int cell) {
             rc = frame_done();
             if (rc) return rc;
         }
-        ALVA_HIP(hipStreamSynchronize(m->st));
+        ALVA_HIP(alva_stream_sync(m->st));
     }
     const int cw = (W + cell - 1) / cell, chh = (H + cell - 1) / cell, n = cw * chh;
     // the tracking step (stage-in, tracker, retry, compaction) and the pose solve behind it
@@ -720,7 +720,7 @@ int HipStages::register_frame_buffer(const uint8_t *buf, size_t bytes) {
 int HipStages::unregister_frame_buffer() {
     if (!m->registered) return ALVA_OK;
     ALVA_HIP(hipSetDevice(m->device));
-    ALVA_HIP(hipStreamSynchronize(m->st));   // no kernel may still be reading the pages
+    ALVA_HIP(alva_stream_sync(m->st));   // no kernel may still be reading the pages
     m->upload_in_flight = false;
     const uint8_t *b = m->registered;
     m->registered = m->registered_dev = nullptr;
@@ -753,7 +753,7 @@ int HipStages::new_frame_device(const uint8_t *d_rgba) {
 int HipStages::frame_done() {
     if (m->upload_in_flight) {
         m->upload_in_flight = false;
-        ALVA_HIP(hipEventSynchronize(m->upload_done));
+        ALVA_HIP(alva_event_sync(m->upload_done));
     }
     return ALVA_OK;
 }
@@ -888,14 +888,14 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
             unsigned spins = 0;
             while (*flag != seq) {
                 if (++spins > (1u << 26)) {   // ~ seconds: something is wrong with the stream; let the runtime report it
-                    ALVA_HIP(hipStreamSynchronize(m->st));
+                    ALVA_HIP(alva_stream_sync(m->st));
                     break;
                 }
                 alva_poll_relax(spins);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         } else {
-            ALVA_HIP(hipStreamSynchronize(m->st));
+            ALVA_HIP(alva_stream_sync(m->st));
         }
         return ALVA_OK;
     };
@@ -995,7 +995,7 @@ int HipStages::fbklt(int levels, int n, const float *pts, float *prior, uint8_t 
     if (rc) return rc;
     DOWN(b, (size_t) n * 8);
     DOWN(c, (size_t) n);
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(prior, h[b], (size_t) n * 8);
     memcpy(status, h[c], (size_t) n);
     return ALVA_OK;
@@ -1016,7 +1016,7 @@ int HipStages::compute_keypoints(int n, const float *px, float *unpx, double *bv
     ALVA_LAUNCH_CHECK();
     rc = m->down_span(p, d, h, b, c);
     if (rc) return rc;
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(unpx, h[b], (size_t) n * 8);
     memcpy(bv, h[c], (size_t) n * 24);
     return ALVA_OK;
@@ -1034,7 +1034,7 @@ int HipStages::project_dist(int n, const double *cam_pts, float *px) {
     rc = alva_project_dist(m->ctx, (const double *) d[a], n, k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (float *) d[b]);
     if (rc) return rc;
     DOWN(b, (size_t) n * 8);
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(px, h[b], (size_t) n * 8);
     return ALVA_OK;
 }
@@ -1154,7 +1154,7 @@ int HipStages::describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) 
     if (rc) return rc;
     rc = m->down_span(p, d, h, b, c);
     if (rc) return rc;
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(desc, h[b], (size_t) n * 32);
     memcpy(valid, h[c], (size_t) n);
     return ALVA_OK;
@@ -1177,7 +1177,7 @@ int HipStages::describe_and_compute(int n, const float *pts, uint8_t *desc, uint
     ALVA_LAUNCH_CHECK();
     rc = m->down_span(p, d, h, b, v);   // descriptors | validity | undistorted positions | bearings: one copy back, one wait
     if (rc) return rc;
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(desc, h[b], (size_t) n * 32);
     memcpy(valid, h[c], (size_t) n);
     memcpy(unpx, h[u], (size_t) n * 8);
@@ -1210,7 +1210,7 @@ int HipStages::triangulate(int n, int n_groups, const double *T36, const int *gr
     if (rc) return rc;
     rc = m->down_span(p, d, h, iw, ipar);
     if (rc) return rc;
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(wpt, h[iw], (size_t) n * 24);
     memcpy(inv_depth, h[iid], (size_t) n * 8);
     memcpy(status, h[ist], (size_t) n);
@@ -1264,7 +1264,7 @@ int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, cons
                                          (int *) dv(match_of_mp));
         if (rc) return rc;
         ALVA_HIP(hipMemcpyAsync(match_of_mp, dv(match_of_mp), (size_t) n_mp * 4, hipMemcpyDeviceToHost, m->st));
-        ALVA_HIP(hipStreamSynchronize(m->st));
+        ALVA_HIP(alva_stream_sync(m->st));
         return ALVA_OK;
     }
     Impl::Plan p;
@@ -1295,7 +1295,7 @@ int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, cons
                                  (const int *) d[il], max_proj_err, dist_ratio, (int *) d[im]);
     if (rc) return rc;
     DOWN(im, (size_t) n_mp * 4);
-    ALVA_HIP(hipStreamSynchronize(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));
     memcpy(match_of_mp, h[im], (size_t) n_mp * 4);
     return ALVA_OK;
 }

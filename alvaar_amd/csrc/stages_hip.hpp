@@ -9,7 +9,8 @@ class HipStages : public Stages {
 public:
     HipStages();
     ~HipStages() override;
-    int init(int device, const Camera &cam, bool clahe, const double *invK);
+    // hip_stream != nullptr: run on that (caller-owned) stream instead of a stream of its own -- sessions of a group may share streams
+    int init(int device, const Camera &cam, bool clahe, const double *invK, void *hip_stream = nullptr);
     // One pass of synthetic data through every stage at the sizes a `cell`-pixel grid produces: loads the kernels' code objects, grows
     // the staging arenas and the context scratch to their working sizes and raises the launch attributes, so that none of this lands in
     // the first frames / the first keyframes.  No state survives it (the detector's adaptive threshold is restored).

@@ -10,7 +10,12 @@
 #include "../../include/alvaar_system.h"
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
+#include <ucontext.h>
+#include <vector>
 
 using namespace alva_slam;
 
@@ -33,6 +38,7 @@ struct alva_system {
     std::unique_ptr<HipStages> stages;
     std::unique_ptr<TraceStages> trace;  // ALVA_STAGE_TRACE=<file>: log every stage call (debugging aid, see slam/stage_trace.hpp)
     std::unique_ptr<Slam> slam;
+    void *hip_stream = nullptr;   // alva_system_set_stream: the stream the next configure builds the stages on (null: a stream of its own)
     // findCameraPoseWithIMU (system.cpp:57-104)
     double imu_translation[3] = {0, 0, 0}, prev_translation[3] = {0, 0, 0};
 };
@@ -95,7 +101,7 @@ static int configure_impl(alva_system *s, int width, int height, double fx, doub
     cfg.random_sampling = random_sampling != 0;
     std::unique_ptr<HipStages> st(new HipStages());
     std::unique_ptr<Slam> slam(new Slam(st.get(), cam, cfg));
-    const int rc = st->init(s->device, cam, cfg.clahe, slam->invK);
+    const int rc = st->init(s->device, cam, cfg.clahe, slam->invK, s->hip_stream);
     if (rc) return sys_fail(rc, "alva_system_configure");
     if (!getenv("ALVA_NO_WARMUP")) {
         // code-object loads, arena growth and launch attributes belong to configure, not to the first frames and keyframes
@@ -318,5 +324,172 @@ extern "C" int alva_system_debug_set_init_pose(alva_system *s, const double *pos
     if (!s || !s->slam) return ALVA_ERR_ARG;
     s->slam->init_override.armed = pose7 != nullptr;
     if (pose7) memcpy(s->slam->init_override.pose7, pose7, 7 * sizeof(double));
+    return ALVA_OK;
+}
+
+
+// ---- a GROUP of sessions on a few host threads ------------------------------------------------------------------------------------
+// One session is a chain of latency-bound kernels with the host waiting in between: a thread per session burns a core on waits (8
+// sessions on 8 cores: 9.3 k frames/s, every core spinning).  A group runs its sessions as FIBERS: W worker threads, each with a share
+// of the sessions; a session executes the unmodified synchronous path (alva_system_find_camera_pose_device) on its own stack, and
+// every wait of that path -- the completion-word polls and the stream waits, all through alva_poll_relax / alva_stream_sync
+// (common.hpp) -- switches to the thread's next session instead of spinning.  The GPU sees the sessions' streams side by side; the host
+// threads only ever execute map-layer work.  Sessions stay independent: every session's results are those of its solo run, bit for bit.
+namespace {
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    alva_system *sys = nullptr;
+    const uint8_t *d_rgba = nullptr;
+    double ts = 0;
+    float *pose = nullptr;
+    int *status = nullptr;
+    bool done = true;
+};
+struct Worker;
+thread_local Worker *g_worker = nullptr;
+struct Worker {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    int current = -1;
+    static void yield_hook() {
+        Worker *w = g_worker;
+        swapcontext(&w->fibers[(size_t) w->current].ctx, &w->sched);
+    }
+    static void entry() {
+        Worker *w = g_worker;
+        Fiber &f = w->fibers[(size_t) w->current];
+        *f.status = alva_system_find_camera_pose_device(f.sys, f.d_rgba, f.ts, f.pose);
+        f.done = true;
+        swapcontext(&f.ctx, &w->sched);
+    }
+    // run the first n fibers to completion, round robin over the unfinished ones
+    void run(int n) {
+        g_worker = this;
+        alva_fiber_yield = &Worker::yield_hook;
+        for (int i = 0; i < n; i++) {
+            Fiber &f = fibers[(size_t) i];
+            if (f.stack.empty()) f.stack.resize((size_t) 1 << 20);
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack.data();
+            f.ctx.uc_stack.ss_size = f.stack.size();
+            f.ctx.uc_link = &sched;
+            makecontext(&f.ctx, (void (*)()) & Worker::entry, 0);
+            f.done = false;
+        }
+        int left = n;
+        while (left > 0)
+            for (int i = 0; i < n; i++) {
+                if (fibers[(size_t) i].done) continue;
+                current = i;
+                swapcontext(&sched, &fibers[(size_t) i].ctx);
+                if (fibers[(size_t) i].done) left--;
+            }
+        alva_fiber_yield = nullptr;
+        g_worker = nullptr;
+        current = -1;
+    }
+};
+}  // namespace
+
+struct alva_system_group {
+    std::vector<std::thread> threads;
+    std::vector<Worker> workers;
+    std::vector<int> share;          // sessions of worker w in this call
+    std::vector<hipStream_t> streams;   // alva_system_group_stream: streams that several sessions share (destroyed with the group)
+    int stream_device = 0;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    long generation = 0;
+    int pending = 0;
+    bool quit = false;
+    void loop(int w) {
+        long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+            }
+            if (share[(size_t) w] > 0) workers[(size_t) w].run(share[(size_t) w]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+};
+
+extern "C" int alva_system_set_stream(alva_system *s, void *hip_stream) {
+    if (!s) return ALVA_ERR_ARG;
+    s->hip_stream = hip_stream;
+    return ALVA_OK;
+}
+
+extern "C" int alva_system_group_stream(alva_system_group *g, int device, int index, void **out_stream) {
+    if (!g || !out_stream || index < 0) return ALVA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if ((int) g->streams.size() <= index) g->streams.resize((size_t) index + 1, nullptr);
+    if (!g->streams[(size_t) index]) {
+        if (hipSetDevice(device) != hipSuccess) return ALVA_ERR_HIP;
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ALVA_ERR_HIP;
+        g->streams[(size_t) index] = st;
+        g->stream_device = device;
+    }
+    *out_stream = g->streams[(size_t) index];
+    return ALVA_OK;
+}
+
+extern "C" int alva_system_group_create(int n_threads, alva_system_group **out) {
+    if (!out || n_threads < 1 || n_threads > 256) return ALVA_ERR_ARG;
+    alva_system_group *g = new alva_system_group();
+    g->workers.resize((size_t) n_threads);
+    g->share.assign((size_t) n_threads, 0);
+    for (int w = 0; w < n_threads; w++) g->threads.emplace_back([g, w] { g->loop(w); });
+    *out = g;
+    return ALVA_OK;
+}
+
+extern "C" void alva_system_group_destroy(alva_system_group *g) {
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->quit = true;
+    }
+    g->cv_go.notify_all();
+    for (std::thread &t: g->threads) t.join();
+    if (!g->streams.empty()) (void) hipSetDevice(g->stream_device);
+    for (hipStream_t st: g->streams)
+        if (st) (void) hipStreamDestroy(st);
+    delete g;
+}
+
+extern "C" int alva_system_group_find_camera_pose_device(alva_system_group *g, int count, alva_system *const *systems, const uint8_t *const *d_rgba,
+                                                         double timestamp_ms, float *h_poses, int *h_status) {
+    if (!g || count < 0 || (count > 0 && (!systems || !d_rgba || !h_poses || !h_status))) return ALVA_ERR_ARG;
+    if (count == 0) return ALVA_OK;
+    const int W = (int) g->workers.size();
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        for (int w = 0; w < W; w++) g->share[(size_t) w] = 0;
+        for (int i = 0; i < count; i++) {   // session i -> worker i % W, always the same worker for the same i (its stacks stay warm)
+            Worker &wk = g->workers[(size_t) (i % W)];
+            const int k = g->share[(size_t) (i % W)]++;
+            if ((int) wk.fibers.size() <= k) wk.fibers.resize((size_t) k + 1);
+            Fiber &f = wk.fibers[(size_t) k];
+            f.sys = systems[i];
+            f.d_rgba = d_rgba[i];
+            f.ts = timestamp_ms;
+            f.pose = h_poses + 16 * (size_t) i;
+            f.status = h_status + i;
+        }
+        g->pending = W;
+        g->generation++;
+    }
+    g->cv_go.notify_all();
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv_done.wait(lk, [&] { return g->pending == 0; });
     return ALVA_OK;
 }

@@ -42,6 +42,12 @@ lib.alva_system_debug_timing.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_timing_keyframe.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_timing_fine.argtypes = [_vp, _vp, _i]
 lib.alva_system_last_error.restype = C.c_char_p
+lib.alva_system_group_create.argtypes = [_i, C.POINTER(_vp)]
+lib.alva_system_group_destroy.argtypes = [_vp]
+lib.alva_system_group_destroy.restype = None
+lib.alva_system_group_find_camera_pose_device.argtypes = [_vp, _i, _vp, _vp, _d, _vp, _vp]
+lib.alva_system_group_stream.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
+lib.alva_system_set_stream.argtypes = [_vp, _vp]
 
 
 def camera_intrinsics(width: int, height: int, fov: float = 45.0):
@@ -57,7 +63,7 @@ def camera_intrinsics(width: int, height: int, fov: float = 45.0):
 
 class AlvaAR:
     def __init__(self, width: int, height: int, fov: float = 45.0, device: int = 0, cell_size: int | None = None, clahe: bool = False,
-                 random_sampling: bool = True, distortion=(0.0, 0.0, 0.0, 0.0)):
+                 random_sampling: bool = True, distortion=(0.0, 0.0, 0.0, 0.0), hip_stream=None):
         """cell_size / clahe / random_sampling: the settings System::configure hard-codes (system.cpp:15-19, state.hpp:67);
         None = the shipped configuration through alva_system_configure."""
         self.intrinsics = camera_intrinsics(width, height, fov)
@@ -67,6 +73,8 @@ class AlvaAR:
         if rc:
             raise AlvaError(lib.alva_system_last_error().decode())
         self.h = h
+        if hip_stream is not None:   # a stream shared with other sessions (SystemGroup.stream)
+            lib.alva_system_set_stream(h, hip_stream)
         k = self.intrinsics
         if cell_size is None and not clahe and random_sampling:
             rc = lib.alva_system_configure(h, width, height, k["fx"], k["fy"], k["cx"], k["cy"], k["k1"], k["k2"], k["p1"], k["p2"])
@@ -240,3 +248,50 @@ class AlvaAR:
         else:
             p = np.ascontiguousarray(pose7, np.float64)
             lib.alva_system_debug_set_init_pose(self.h, p.ctypes.data)
+
+
+class SystemGroup:
+    """alva_system_group: S AlvaAR sessions advanced one frame per call on `n_threads` host threads (sessions are fibers: a session's
+    waits for the GPU run the thread's other sessions).  No reference counterpart (the reference is one System per worker)."""
+
+    def __init__(self, sessions, n_threads: int):
+        h = _vp()
+        rc = lib.alva_system_group_create(int(n_threads), C.byref(h))
+        if rc:
+            raise AlvaError("alva_system_group_create failed")
+        self.h = h
+        self.set_sessions(sessions)
+
+    def stream(self, index: int, device: int = 0):
+        """the group's shared HIP stream number `index` (created on first use): pass it to AlvaAR(..., hip_stream=...)"""
+        st = _vp()
+        if lib.alva_system_group_stream(self.h, device, index, C.byref(st)):
+            raise AlvaError("alva_system_group_stream failed")
+        return st
+
+    def set_sessions(self, sessions):
+        self.sessions = list(sessions)
+        n = len(self.sessions)
+        self._sys = (_vp * n)(*[s.h for s in self.sessions])
+        self._ptr = (_vp * n)()
+        self.poses = np.zeros((n, 16), np.float32)
+        self.status = np.zeros(n, np.int32)
+
+    def step_device(self, d_rgba_ptrs, timestamp_ms: float):
+        """one frame per session (device pointers, one per session); returns the status array (view)"""
+        for i, p in enumerate(d_rgba_ptrs):
+            self._ptr[i] = p
+        rc = lib.alva_system_group_find_camera_pose_device(self.h, len(self.sessions), self._sys, self._ptr, float(timestamp_ms),
+                                                           self.poses.ctypes.data, self.status.ctypes.data)
+        if rc:
+            raise AlvaError("alva_system_group_find_camera_pose_device failed")
+        if (self.status < 0).any():
+            raise AlvaError(lib.alva_system_last_error().decode() or "a session of the group failed")
+        return self.status
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.alva_system_group_destroy(self.h)
+            self.h = None
+
+    __del__ = close

@@ -299,6 +299,45 @@ def bench_system_streams(device: int, n_streams: int, steps: int = 300):
             "note": "S independent alva::System sessions on one GPU, one host thread each (Python threads; the C call releases the GIL), frames resident in HBM"}
 
 
+def bench_system_group(device: int, n_sessions: int, n_threads: int, steps: int = 200, n_streams: int = 0):
+    """S independent alva::System sessions on ONE GPU through alva_system_group: W host threads, the sessions as fibers -- a session's
+    waits for the GPU run the thread's other sessions, so the threads execute map-layer work only.  All sessions replay the same resident
+    stream in lock-step (keyframes coincide: the worst case for the host).  Aggregate frames/s in the steady state."""
+    from alvaar_amd.system import AlvaAR, SystemGroup
+    base = SystemJob(device, 7, host_copy=False)
+    group = SystemGroup([], n_threads)
+    if n_streams > 0:   # sessions share n_streams HIP streams (session i -> worker i % n_threads -> stream (i % n_threads) % n_streams)
+        base.ar.close()
+        sessions = [AlvaAR(W, H, device=device, cell_size=SYSTEM_CELL, random_sampling=False, hip_stream=group.stream((i % n_threads) % n_streams, device))
+                    for i in range(n_sessions)]
+        base.ar = sessions[0]
+    else:
+        sessions = [base.ar] + [AlvaAR(W, H, device=device, cell_size=SYSTEM_CELL, random_sampling=False) for _ in range(n_sessions - 1)]
+    group.set_sessions(sessions)
+    k = 0
+
+    def step():
+        nonlocal k
+        ptr = base.ptrs[stream_index(k)]
+        st = group.step_device([ptr] * n_sessions, 33.0 * k)
+        k += 1
+        return st
+    while int(base.ar.state()[11]) < 34 and k < 2500:   # steady state: the 30-keyframe window full
+        step()
+    t0 = time.perf_counter()
+    tracked = 0
+    for _ in range(steps):
+        tracked += int((step() == 1).sum())
+    dt = time.perf_counter() - t0
+    group.close()
+    for s in sessions:
+        s.close()
+    return {"sessions": n_sessions, "host_threads": n_threads, "hip_streams": n_streams or n_sessions, "frames_per_s": n_sessions * steps / dt, "ms_per_group_step": dt / steps * 1e3,
+            "tracked_frac": tracked / (n_sessions * steps),
+            "note": "alva_system_group: sessions are fibers on the worker threads (a wait for the GPU switches to the thread's next session); "
+                    "frames resident in HBM, every session its own map / streams / kernels"}
+
+
 def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5):
     """S independent camera streams on ONE GPU, each with its own alva_frontend (two HIP streams) and its own host thread
     inside the library (alva_frontend_run_many).  Every stage of a single stream is latency-bound at these sizes, so
@@ -1099,6 +1138,7 @@ def main():
             # S independent alva::System sessions on the ONE GPU, a host thread each: what a single latency-bound stream leaves idle
             counts = [int(v) for v in args.system_streams.split(",")] if args.system_streams else [4, 8]
             out["system_streams"] = [bench_system_streams(local, c_) for c_ in counts]
+            out["system_group"] = [bench_system_group(local, s_, 8) for s_ in (8, 16, 32)]
         if not args.no_cpu_baseline and world == 1:   # the contract: reference CPU path timed on rank 0 at N = 1 only
             log("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(shard.stream_seed)

@@ -53,6 +53,23 @@ int alva_system_find_camera_pose(alva_system *sys, const uint8_t *h_rgba, float 
  * GPU has finished reading the buffer.  The registration is the caller's promise that the memory stays allocated until
  * alva_system_unregister_frame_buffer / alva_system_configure / alva_system_destroy; one buffer per system (a second call replaces
  * the first).  Must be called after alva_system_configure. */
+/* ---- many sessions on a few host threads (no reference counterpart: the reference is one System per process / worker).  A group
+ * owns n_threads worker threads; alva_system_group_find_camera_pose_device runs ONE frame of each of `count` configured systems
+ * (session i: frame d_rgba[i] in device memory, pose -> h_poses[16 i ..], status / error code -> h_status[i]) and returns when all are
+ * done.  Sessions are fibers on the workers: a session's waits for the GPU hand the thread to the worker's next session, so the
+ * threads only execute map-layer work and the GPU sees the sessions' streams side by side.  Every session's results equal its solo run
+ * bit for bit.  Systems must not be used from other threads during the call. */
+typedef struct alva_system_group alva_system_group;
+int alva_system_group_create(int n_threads, alva_system_group **out);
+void alva_system_group_destroy(alva_system_group *group);
+/* Streams for sessions to SHARE: the GPU's command processor slows down sharply beyond a handful of concurrently active hardware queues
+ * (measured: empty launches 2.5 us each on 1 - 4 streams, 26 us each on 8), so a group's sessions run on a few streams rather than one
+ * each.  alva_system_group_stream returns (creating it on first use) the group's stream number `index`; alva_system_set_stream makes a
+ * system build its stages on that stream at its next alva_system_configure*.  The systems must be destroyed before the group. */
+int alva_system_group_stream(alva_system_group *group, int device, int index, void **out_stream);
+int alva_system_set_stream(alva_system *sys, void *hip_stream);
+int alva_system_group_find_camera_pose_device(alva_system_group *group, int count, alva_system *const *systems, const uint8_t *const *d_rgba,
+                                              double timestamp_ms, float *h_poses, int *h_status);
 int alva_system_register_frame_buffer(alva_system *sys, const uint8_t *h_rgba, size_t bytes);
 int alva_system_unregister_frame_buffer(alva_system *sys);
 /* The same with the frame's timestamp (milliseconds) as an argument instead of the system clock (system.cpp:114): the

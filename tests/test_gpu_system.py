@@ -426,3 +426,53 @@ def test_concurrent_sessions_equal_their_solo_runs():
             assert a[k][0] == b[k][0], (s, k)
             assert np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), (s, k)
             assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), (s, k)
+
+
+def test_group_sessions_equal_their_solo_runs():
+    """alva_system_group: six sessions (different grids / streams, one 1280x720) advanced frame by frame on TWO host threads -- three
+    fibers per thread, every GPU wait of a session running the thread's other sessions: statuses, poses (bitwise), keypoint ids and
+    pixels (bitwise) and the counters are those of each session's solo run"""
+    import torch
+    from alvaar_amd.system import AlvaAR, SystemGroup
+    specs = [(640, 480, 40, 7, False), (640, 480, 12, 5, True), (640, 480, 24, 9, False), (640, 480, 12, 7, False), (1280, 720, 15, 9, True),
+             (640, 480, 40, 3, True)]
+    n = 60
+
+    def frames_of(w, h, seed, noise):
+        canvas = synth.texture_canvas(w, h, seed)
+        return np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11 if noise else None)) for k in range(n)])
+
+    dev = [torch.from_numpy(frames_of(w, h, seed, noise)).cuda() for w, h, cell, seed, noise in specs]
+
+    def record(ar):
+        ids, px, i3 = ar.keypoints()
+        return ar.pose7()[0].copy(), ids.copy(), px.copy(), list(ar.state())
+
+    solo = []
+    for (w, h, cell, seed, noise), fr in zip(specs, dev):
+        ar = AlvaAR(w, h, cell_size=cell, random_sampling=False)
+        rec = []
+        for k in range(n):
+            st = ar.find_camera_pose_device(int(fr[k].data_ptr()), 33.0 * k)
+            rec.append((st,) + record(ar))
+        rec.append(ar.counters())
+        ar.close()
+        solo.append(rec)
+    sessions = [AlvaAR(w, h, cell_size=cell, random_sampling=False) for w, h, cell, seed, noise in specs]
+    group = SystemGroup(sessions, 2)
+    together = [[] for _ in specs]
+    for k in range(n):
+        st = group.step_device([int(fr[k].data_ptr()) for fr in dev], 33.0 * k)
+        for i, ar in enumerate(sessions):
+            together[i].append((int(st[i]),) + record(ar))
+    for i, ar in enumerate(sessions):
+        together[i].append(ar.counters())
+    group.close()
+    for ar in sessions:
+        ar.close()
+    for i, (a, b) in enumerate(zip(solo, together)):
+        assert a[-1] == b[-1] and a[-1]["ba_solves"] >= 1, (i, a[-1], b[-1])
+        for k in range(n):
+            assert a[k][0] == b[k][0] and a[k][4] == b[k][4], (i, k)
+            assert np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), (i, k)
+            assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), (i, k)
