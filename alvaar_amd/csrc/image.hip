@@ -218,7 +218,7 @@ struct RestArgs {
     StageArgs s0;          // Scharr of level 0
     RestLevel lv[4];
     int nlevels, win;
-    int first[4], bx[4];   // deep tiles of level L: first workgroup index, tiles per row
+    int first[4], bx[4], ntiles[4];   // deep tiles of level L: first workgroup index, tiles per row, number of tiles
 };
 struct Span {
     int lo, hi;            // inclusive, unmirrored coordinates
@@ -312,7 +312,14 @@ __global__ void __launch_bounds__(256) k_pyr_rest(RestArgs A) {
     }
     int L = 1;
     while (L + 1 < A.nlevels && bid >= A.first[L + 1]) L++;
-    deep_tile(A, L, bid - A.first[L]);
+    // XCD-aware order inside a level (workgroup b runs on XCD b % 8, each with its own L2): every XCD gets one CONTIGUOUS eighth of the
+    // level's tiles (row-major), so neighbouring tiles -- whose level-0 footprints share cache lines -- meet in one L2 instead of pulling
+    // the same lines through eight (PMC: 9.3 MB fetched per launch with the plain order against ~2.1 MB algorithmic)
+    const int n = A.ntiles[L];
+    const int lb = bid - A.first[L], per = (n + 7) / 8;
+    const int tile = (lb & 7) * per + (lb >> 3);
+    if (tile >= n) return;   // (whole workgroup: no barrier is skipped by a part of it)
+    deep_tile(A, L, tile);
 }
 
 __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
@@ -471,7 +478,9 @@ static int build_rest(alva_ctx *ctx, alva_pyramid *p) {
             if (l >= 1) {
                 A.first[l] = blocks;
                 A.bx[l] = alva_divup(L.w, rest_tile(l));
-                blocks += A.bx[l] * alva_divup(L.h, rest_tile(l));
+                const int tiles = A.bx[l] * alva_divup(L.h, rest_tile(l));
+                A.ntiles[l] = tiles;
+                blocks += 8 * alva_divup(tiles, 8);   // eight XCD shares of equal length (the kernel drops the padding workgroups)
             }
         }
         hipLaunchKernelGGL(k_pyr_rest, dim3(blocks), dim3(64, 4), 0, ctx->stream, A);
