@@ -107,3 +107,27 @@ extern "C" int alva_microbench_peaks(alva_ctx *ctx, double *h_tflops_mfma_f64, d
     (void) hipEventDestroy(e1);
     return ALVA_OK;
 }
+
+unsigned long long *alva_kstamp_buffer() {
+    static unsigned long long *buf = [] {
+        unsigned long long *b = nullptr;
+        if (getenv("ALVA_KSTAMPS") && hipMalloc((void **) &b, 4096 * 8) == hipSuccess) (void) hipMemset(b, 0, 4096 * 8);
+        return b;
+    }();
+    return buf;
+}
+
+// copies the stamp buffer (4096 x u64; see common.hpp) to the host and clears it; ALVA_ERR_STATE without ALVA_KSTAMPS=1
+extern "C" int alva_debug_kstamps(unsigned long long *h_out) {
+    ALVA_ARG(h_out);
+    unsigned long long *b = alva_kstamp_buffer();
+    if (!b) {
+        alva_set_error("alva_debug_kstamps: the process was not started with ALVA_KSTAMPS=1");
+        return ALVA_ERR_STATE;
+    }
+    ALVA_HIP(hipDeviceSynchronize());
+    ALVA_HIP(hipMemcpy(h_out, b, 4096 * 8, hipMemcpyDeviceToHost));
+    ALVA_HIP(hipMemset(b, 0, 4096 * 8));
+    return ALVA_OK;
+}
+

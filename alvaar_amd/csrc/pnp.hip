@@ -42,7 +42,10 @@ struct PnpArgs {
     double ftol;
     double pose0[7];  // initial pose (ignored in chained mode)
     int seq;          // k_pnp publishes it in PnpOut::seq after every result (system-scope release): a host may poll that word
+    unsigned long long *dbg;   // phase stamps (alva_kstamp_buffer) or null
 };
+// sequential stamps from entry 2048 (entry 2047 = how many)
+#define PNP_STAMP() do { if (A.dbg && threadIdx.x == 0 && sh.nstamp < 2000) A.dbg[2048 + sh.nstamp++] = wall_clock64(); } while (0)
 
 struct PnpOut {
     double pose[7];
@@ -53,223 +56,462 @@ struct PnpOut {
     double pose_p3p[7];  // chained mode: the accepted P3P pose as the refinement starts from it (normalised quaternion)
 };
 
+// LmState of lm_device.hpp without member initialisers (it lives in LDS)
+struct LmPod {
+    double radius, decrease_factor;
+    int reuse_diagonal;
+    __device__ __forceinline__ void reset() {
+        radius = 1e4;
+        decrease_factor = 2.0;
+        reuse_diagonal = 0;
+    }
+    __device__ __forceinline__ void accepted(double q) {
+        LmState t;
+        t.radius = radius; t.decrease_factor = decrease_factor; t.reuse_diagonal = reuse_diagonal;
+        t.accepted(q);
+        radius = t.radius; decrease_factor = t.decrease_factor; reuse_diagonal = t.reuse_diagonal;
+    }
+    __device__ __forceinline__ void rejected() {
+        LmState t;
+        t.radius = radius; t.decrease_factor = decrease_factor; t.reuse_diagonal = reuse_diagonal;
+        t.rejected();
+        radius = t.radius; decrease_factor = t.decrease_factor; reuse_diagonal = t.reuse_diagonal;
+    }
+};
+
 struct PnpShared {
     double part[NW][NACC];
     double acc[NACC];
     double x[7], cand[7];
-    int flag;
+    double T[12];   // R_wc row-major | t_wc of the pose the NEXT evaluation uses (written by lane 0 beside the step)
+    int flag, nstamp;
     // minimiser state (touched by lane 0 only; kept in LDS so that dynamic indexing never goes to scratch memory)
-    double H[36], g[6], scale[6], diag[6], Hs[36], gs[6], M[36], y[6], step[6], delta[6];
+    double H[36], g[6], scale[6], diag[6];
+    // ... and its scalars: loop-carried in every thread's registers they cost ~20 VGPRs of the 256 and pushed the evaluation's
+    // accumulators into scratch around the point loop
+    double x_cost, gmax, x_norm, initial, mcc;
+    LmPod lm;
+    int iteration, nsucc, invalid, nsummaries;
 };
 
-enum { F_DONE = 0, F_EVAL_CAND = 1, F_RETRY = 2, F_ACCEPT = 3, F_FAIL = 4 };
+enum { F_DONE = 0, F_EVAL_CAND = 1, F_FAIL = 4 };
 
 __device__ __forceinline__ int tri(int a, int b) {  // index of (a,b), a <= b, in the packed upper triangle of a 6x6
     return a * 6 - a * (a - 1) / 2 + (b - a);
 }
 
-// Block-wide evaluation at pose p7: cost (+ packed J^T J and J^T r when WANT_J) into sh.acc.
+// ---- lane 0's arithmetic between two evaluations ---------------------------------------------------------------------------------
+// One lane runs the trust-region step while 511 wait, so its LATENCY is kernel time (stamps: 5.4 us per step with IEEE divides and
+// square roots -- 39 of them in a 6x6 Cholesky solve, ~100 ns each as a dependent chain).  Reciprocals and reciprocal square roots are
+// therefore the hardware estimates refined by two Newton steps (<= 1-2 ulp; the results of this kernel are compared under a
+// tolerance, the iteration itself is Ceres', not bit-for-bit Eigen), each used once per pivot and multiplied in.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+// g ~ sqrt(x), returns 1 / sqrt(x) (x > 0, normal)
+__device__ __forceinline__ double fast_rsqrt(double x, double &g) {
+    const double r = __builtin_amdgcn_rsq(x);
+    g = x * r;
+    double h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    return 2.0 * h;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double g;
+    (void) fast_rsqrt(x, g);
+    return x > 0 ? g : 0.0;
+}
+
+// Cholesky solve of the damped 6x6 system, all loops unrolled on registers; one reciprocal square root per pivot
+__device__ __forceinline__ bool chol6_solve(double (&A)[36], double (&b)[6]) {
+    double inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = A[7 * j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[6 * j + k] * A[6 * j + k];
+        if (!(d > 0)) return false;
+        double root;
+        inv[j] = fast_rsqrt(d, root);
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[6 * i + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= A[6 * i + k] * A[6 * j + k];
+            A[6 * i + j] = v * inv[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= A[6 * i + k] * b[k];
+        b[i] = v * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v -= A[6 * k + i] * b[k];
+        b[i] = v * inv[i];
+    }
+    return true;
+}
+
+// R_wc | t_wc of pose7 (quaternion normalised as Sophus does on construction)
+__device__ __forceinline__ void pose_to_T(const double *p, double *T12) {
+    double root;
+    const double inv = fast_rsqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6], root);
+    const double q[4] = {p[3] * inv, p[4] * inv, p[5] * inv, p[6] * inv};
+    quat_to_R(q, T12);
+    T12[9] = p[0]; T12[10] = p[1]; T12[11] = p[2];
+}
+
+// out7 = Exp(d6) * x7 (se3_plus of lm_device.hpp with the fast reciprocals; sin / cos by one sincos per angle)
+__device__ __forceinline__ void se3_plus_fast(const double *x7, const double *d6, double *out7) {
+    double root;
+    const double invn = fast_rsqrt(x7[3] * x7[3] + x7[4] * x7[4] + x7[5] * x7[5] + x7[6] * x7[6], root);
+    const double b4[4] = {x7[3] * invn, x7[4] * invn, x7[5] * invn, x7[6] * invn};
+    const double *u = d6, *w = d6 + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double imag, real, Rd[9], V[9];
+    const bool small = th2 < 1e-10 * 1e-10;
+    double theta = 0, inv_theta = 0;
+    if (small) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+    } else {
+        inv_theta = fast_rsqrt(th2, theta);
+        double sh_, ch_;
+        sincos(0.5 * theta, &sh_, &ch_);
+        imag = sh_ * inv_theta;
+        real = ch_;
+    }
+    const double qd[4] = {imag * w[0], imag * w[1], imag * w[2], real};
+    quat_to_R(qd, Rd);
+    if (small) {   // theta < 1e-10
+#pragma unroll
+        for (int i = 0; i < 9; i++) V[i] = Rd[i];
+    } else {
+        const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        double st, ct;
+        sincos(theta, &st, &ct);
+        const double inv_th2 = inv_theta * inv_theta;
+        const double a = (1 - ct) * inv_th2, b = (theta - st) * (inv_th2 * inv_theta);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double o2 = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
+                V[3 * r + c] = (r == c ? 1.0 : 0.0) + a * O[3 * r + c] + b * o2;
+            }
+    }
+    const double *a4 = qd;
+    const double qn[4] = {a4[3] * b4[0] + a4[0] * b4[3] + a4[1] * b4[2] - a4[2] * b4[1],
+                          a4[3] * b4[1] + a4[1] * b4[3] + a4[2] * b4[0] - a4[0] * b4[2],
+                          a4[3] * b4[2] + a4[2] * b4[3] + a4[0] * b4[1] - a4[1] * b4[0],
+                          a4[3] * b4[3] - a4[0] * b4[0] - a4[1] * b4[1] - a4[2] * b4[2]};
+    const double inv2 = fast_rsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], root);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        out7[i] = (V[3 * i] * u[0] + V[3 * i + 1] * u[1] + V[3 * i + 2] * u[2]) + (Rd[3 * i] * x7[0] + Rd[3 * i + 1] * x7[1] + Rd[3 * i + 2] * x7[2]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out7[3 + i] = qn[i] * inv2;
+}
+
+// Block-wide evaluation at the pose in sh.T: cost (+ packed J^T J and J^T r when WANT_J) into sh.acc.  Inlined at its call sites: the
+// problem's scalars stay in SGPRs and the pointers keep their address space (as an out-of-line function every field of the argument
+// struct was re-read through flat loads inside the point loop: four dependent memory round trips per point).  The next point's five
+// doubles are requested before the current one is processed.
+// The loop is FP64-issue bound on the one CU (a wave64 FP64 instruction takes 4 cycles; 2300 points x ~230 instructions / 4 SIMDs), and a
+// third of those instructions were three IEEE divides / square roots per point: 1 / z, and Huber's sqrt(s), a / sqrt(s), sqrt(rho').
+// They are the refined hardware estimates here (<= 2 ulp).
+// Returns this thread's verdicts of multi_view_geometry.cpp:194-207 as a mask: bit k = point threadIdx.x + k * NT is active and has
+// chi2 > chi2_th or a non-positive depth AT THIS evaluation (the reference reads the cost functors' members after the solve, i.e. the
+// values of the minimiser's last evaluation) -- the outlier sweep needs no chi2 / depth arrays in memory.
 template<bool WANT_J>
-__device__ void eval(PnpShared &sh, const PnpArgs &A, const double *p7, int robust, const uint8_t *active, double *chi2_out,
-                     uint8_t *depth_out) {
-    Se3 T;
-    se3_from_pose7(p7, T);
+__device__ __forceinline__ unsigned long long eval(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *__restrict__ active) {
+    PNP_STAMP();
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = sh.T[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = sh.T[9 + k];
+    const double *__restrict__ wpt = A.wpt, *__restrict__ uvp = A.uv;
+    const int n = A.n;
+    const double K0 = A.K[0], K1 = A.K[1], K2 = A.K[2], K3 = A.K[3], ha = A.huber_a, hb = ha * ha, chi2_th = A.chi2_th;
     double acc[32];  // NACC sums + padding: reduced in place by wave_reduce_scatter32 (a second 32-entry copy does not fit the register file)
 #pragma unroll
     for (int k = 0; k < 32; k++) acc[k] = 0.0;
-    for (int i = threadIdx.x; i < A.n; i += NT) {
-        if (!active[i]) continue;
-        const double X[3] = {A.wpt[3 * i], A.wpt[3 * i + 1], A.wpt[3 * i + 2]};
-        double r[2], JR[6], chi2;
-        int dp;
-        reproj<WANT_J>(T, A.K, X, A.uv[2 * i], A.uv[2 * i + 1], r, JR, chi2, dp);
-        chi2_out[i] = chi2;
-        depth_out[i] = (uint8_t) dp;
-        double rho0, rho1;
-        huber_rho(chi2, A.huber_a, robust, rho0, rho1);
-        acc[27] += 0.5 * rho0;
-        if (WANT_J) {
-            double JH[6];
-            times_hat(JR, X, JH);
-            const double s = sqrt(rho1);
-            double J[12];
+    unsigned long long badmask = 0, bit = 1;
+    int i = threadIdx.x;
+    uint8_t a = 0;
+    double X[3] = {0, 0, 1}, u = 0, v = 0;
+    if (i < n) {
+        a = active[i];
+        X[0] = wpt[3 * i]; X[1] = wpt[3 * i + 1]; X[2] = wpt[3 * i + 2];
+        u = uvp[2 * i]; v = uvp[2 * i + 1];
+    }
+    while (i < n) {
+        const int in = i + NT;
+        uint8_t an = 0;
+        double Xn[3] = {0, 0, 1}, un = 0, vn = 0;
+        if (in < n) {
+            an = active[in];
+            Xn[0] = wpt[3 * in]; Xn[1] = wpt[3 * in + 1]; Xn[2] = wpt[3 * in + 2];
+            un = uvp[2 * in]; vn = uvp[2 * in + 1];
+        }
+        if (a) {
+            // reproj of lm_device.hpp (ceres_parametrization.cpp:96-155)
+            const double d0 = X[0] - t[0], d1 = X[1] - t[1], d2 = X[2] - t[2];
+            const double c0 = R[0] * d0 + R[3] * d1 + R[6] * d2;
+            const double c1 = R[1] * d0 + R[4] * d1 + R[7] * d2;
+            const double c2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+            const double iz = fast_rcp(c2);
+            const double r0 = K0 * c0 * iz + K2 - u, r1 = K1 * c1 * iz + K3 - v;
+            const double chi2 = r0 * r0 + r1 * r1;
+            if (chi2 > chi2_th || !(c2 > 0)) badmask |= bit;
+            double rho0 = chi2, s = 1.0;
+            if (robust && chi2 > hb) {   // Huber (loss_function.cc:48-62) and the corrector's sqrt(rho') (corrector.cc:41-110)
+                double root;
+                const double ir = fast_rsqrt(chi2, root);
+                rho0 = 2.0 * ha * root - hb;
+                double rho1 = ha * ir;
+                rho1 = rho1 > 2.2250738585072014e-308 ? rho1 : 2.2250738585072014e-308;
+                s = fast_sqrt(rho1);
+            }
+            acc[27] += 0.5 * rho0;
+            if (WANT_J) {
+                const double iz2 = iz * iz;
+                const double Jp[6] = {iz * K0, 0, -c0 * iz2 * K0, 0, iz * K1, -c1 * iz2 * K1};
+                double JR[6], JH[6];
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++)
+                for (int rr = 0; rr < 2; rr++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    J[6 * rr + c] = -JR[3 * rr + c] * s;
-                    J[6 * rr + 3 + c] = JH[3 * rr + c] * s;
+                    for (int cc = 0; cc < 3; cc++)  // R_cw[k][cc] = R_wc[cc][k]
+                        JR[3 * rr + cc] = Jp[3 * rr] * R[3 * cc] + Jp[3 * rr + 1] * R[3 * cc + 1] + Jp[3 * rr + 2] * R[3 * cc + 2];
+                times_hat(JR, X, JH);
+                double J[12];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        J[6 * rr + c] = -JR[3 * rr + c] * s;
+                        J[6 * rr + 3 + c] = JH[3 * rr + c] * s;
+                    }
+                const double rs0 = r0 * s, rs1 = r1 * s;
+                int tt = 0;
+#pragma unroll
+                for (int aa = 0; aa < 6; aa++) {
+                    acc[21 + aa] += J[aa] * rs0 + J[6 + aa] * rs1;
+#pragma unroll
+                    for (int bb = aa; bb < 6; bb++) acc[tt++] += J[aa] * J[bb] + J[6 + aa] * J[6 + bb];
                 }
-            const double r0 = r[0] * s, r1 = r[1] * s;
-            int t = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
-#pragma unroll
-                for (int b = a; b < 6; b++) acc[t++] += J[a] * J[b] + J[6 + a] * J[6 + b];
             }
         }
+        bit <<= 1;
+        i = in;
+        a = an;
+        X[0] = Xn[0]; X[1] = Xn[1]; X[2] = Xn[2];
+        u = un; v = vn;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (WANT_J) {
         wave_reduce_scatter32(acc);  // lane l ends with the wave total of value l >> 1
         if (!(lane & 1) && (lane >> 1) < NACC) sh.part[wave][lane >> 1] = acc[0];
     } else {
-        double v = acc[27];
+        double vv = acc[27];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sh.part[wave][27] = v;
+        for (int off = 32; off > 0; off >>= 1) vv += __shfl_down(vv, off);
+        if (lane == 0) sh.part[wave][27] = vv;
     }
     __syncthreads();
     if (threadIdx.x < NACC && (WANT_J || threadIdx.x == 27)) {
-        double v = 0;
-        for (int w = 0; w < NW; w++) v += sh.part[w][threadIdx.x];
-        sh.acc[threadIdx.x] = v;
+        double vv = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) vv += sh.part[w][threadIdx.x];
+        sh.acc[threadIdx.x] = vv;
     }
     __syncthreads();
+    PNP_STAMP();
+    return badmask;
 }
 
-// One ceres::Solve on the pose in sh.x.  Returns (block-uniformly) 1 = usable, 0 = failure.
-__device__ __forceinline__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *active, double *chi2, uint8_t *depth, double *info) {
-    double *H = sh.H, *g = sh.g, *scale = sh.scale, *diag = sh.diag;
-    double x_cost = 0, gmax = 0, x_norm = -1, initial = 0, mcc = 0;
-    LmState lm;
-    int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1;
+// ---- lane 0 between two evaluations: out-of-line on purpose ---------------------------------------------------------------------------
+// These run on ONE lane; inlined into the kernel their ~200 live registers (two 6x6 matrices, the sincos expansions) are allocated on top
+// of the evaluation loop's and the excess goes to scratch in both.  As functions they get their own allocation, the kernel keeps only
+// pointers across the call, and all minimiser state lives in LDS (`sh` arrives as a generic pointer into it).
 
-    eval<true>(sh, A, sh.x, robust, active, chi2, depth);
-    if (threadIdx.x == 0) {
-        for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
-        for (int a = 0; a < 6; a++) g[a] = sh.acc[21 + a];
-        x_cost = initial = sh.acc[27];
+// steps until one is valid (trust_region_minimizer.cc:377-451): F_EVAL_CAND (candidate in sh.cand, its R | t in sh.T), F_DONE or F_FAIL
+__device__ __forceinline__ int lm_next_step(PnpShared &sh, int max_iters) {
+    double *H = sh.H, *g = sh.g, *scale = sh.scale, *diag = sh.diag;
+    for (;;) {
+        if (sh.iteration >= max_iters || sh.gmax <= 1e-10 || sh.lm.radius <= 1e-32) return F_DONE;
+        sh.iteration++;
+        // everything below is straight-line code on registers (all loops unrolled, constant indices)
+        double Hr[36], gr[6], sc[6], Mr[36], yr[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) sc[a] = scale[a];
+#pragma unroll
         for (int a = 0; a < 6; a++) {
-            scale[a] = 1.0 / (1.0 + sqrt(H[7 * a]));  // trust_region_minimizer.cc:266-275, iteration 0 only
+            gr[a] = g[a] * sc[a];
+#pragma unroll
+            for (int b = 0; b < 6; b++) Hr[6 * a + b] = H[6 * a + b] * sc[a] * sc[b];
+        }
+        if (!sh.lm.reuse_diagonal) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) diag[a] = fmin(fmax(Hr[7 * a], 1e-6), 1e32);
+        }
+#pragma unroll
+        for (int k = 0; k < 36; k++) Mr[k] = Hr[k];
+        const double inv_radius = fast_rcp(sh.lm.radius);
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            Mr[7 * a] += diag[a] * inv_radius;
+            yr[a] = gr[a];
+        }
+        const bool okstep = chol6_solve(Mr, yr);
+        sh.lm.reuse_diagonal = 1;
+        double mcc = 0;
+        if (okstep) {
+            double sg = 0, sHs = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) sg += -yr[a] * gr[a];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) sHs += yr[a] * Hr[6 * a + b] * yr[b];
+            mcc = -sg - 0.5 * sHs;  // = -(J s)'(f + J s / 2), trust_region_minimizer.cc:419-431
+        }
+        sh.mcc = mcc;
+        if (!okstep || !(mcc > 0)) {
+            if (++sh.invalid >= 5) return F_FAIL;
+            sh.lm.rejected();
+            sh.nsummaries++;
+            continue;
+        }
+        sh.invalid = 0;
+        double delta[6], x7[7], cand[7];
+#pragma unroll
+        for (int a = 0; a < 6; a++) delta[a] = -yr[a] * sc[a];
+#pragma unroll
+        for (int a = 0; a < 7; a++) x7[a] = sh.x[a];
+        se3_plus_fast(x7, delta, cand);
+#pragma unroll
+        for (int a = 0; a < 7; a++) sh.cand[a] = cand[a];
+        double T12[12];
+        pose_to_T(cand, T12);
+#pragma unroll
+        for (int a = 0; a < 12; a++) sh.T[a] = T12[a];
+        return F_EVAL_CAND;
+    }
+}
+
+// after the first evaluation of a solve: gradient / Hessian / cost in, Jacobi scaling (trust_region_minimizer.cc:266-275), first step
+__device__ __noinline__ int lm_first_step(PnpShared *shp, int max_iters) {
+    PnpShared &sh = *shp;
+    double *H = sh.H, *g = sh.g;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
+    double gmax = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        g[a] = sh.acc[21 + a];
+        gmax = fmax(gmax, fabs(g[a]));
+        sh.scale[a] = fast_rcp(1.0 + fast_sqrt(H[7 * a]));
+    }
+    sh.gmax = gmax;
+    sh.x_cost = sh.initial = sh.acc[27];
+    return lm_next_step(sh, max_iters);
+}
+
+// after a candidate's evaluation: the verdict (trust_region_minimizer.cc:744-829), then the next step
+__device__ __noinline__ int lm_after_candidate(PnpShared *shp, int max_iters, double ftol) {
+    PnpShared &sh = *shp;
+    double *H = sh.H, *g = sh.g;
+    const double cand_cost = sh.acc[27], x_cost = sh.x_cost;
+    double sn = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) sn += (sh.x[i] - sh.cand[i]) * (sh.x[i] - sh.cand[i]);
+    if (sqrt(sn) <= 1e-8 * (sh.x_norm + 1e-8)) return F_DONE;            // ParameterToleranceReached
+    if (fabs(x_cost - cand_cost) <= ftol * x_cost) return F_DONE;        // FunctionToleranceReached
+    const double rel = (x_cost - cand_cost) / sh.mcc;
+    if (rel > 1e-3) {
+        double nn = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const double c = sh.cand[i];
+            sh.x[i] = c;
+            nn += c * c;
+        }
+        sh.x_norm = sqrt(nn);
+        sh.lm.accepted(rel);
+        sh.nsucc++;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
+        double gmax = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            g[a] = sh.acc[21 + a];
             gmax = fmax(gmax, fabs(g[a]));
         }
+        sh.gmax = gmax;
+        sh.x_cost = cand_cost;
+    } else {
+        sh.lm.rejected();
     }
-    int result = 1;
-    for (;;) {
-        if (threadIdx.x == 0) {
-            int flag;
-            if (iteration >= A.max_iters || gmax <= 1e-10 || lm.radius <= 1e-32) {
-                flag = F_DONE;
-            } else {
-                iteration++;
-                // everything below is straight-line code on registers (all loops unrolled, constant indices)
-                double Hr[36], gr[6], sc[6], Mr[36], yr[6];
+    sh.nsummaries++;
+    return lm_next_step(sh, max_iters);
+}
+
+// lane 0, before a solve (a barrier must follow): minimiser state, and R | t of the start pose for the first evaluation
+__device__ __forceinline__ void solve_begin(PnpShared &sh) {
+    sh.x_cost = 0; sh.gmax = 0; sh.x_norm = -1; sh.initial = 0; sh.mcc = 0;
+    sh.lm.reset();
+    sh.iteration = 0; sh.nsucc = 1; sh.invalid = 0; sh.nsummaries = 1;
+    double T12[12];
+    pose_to_T(sh.x, T12);
 #pragma unroll
-                for (int a = 0; a < 6; a++) sc[a] = scale[a];
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    gr[a] = g[a] * sc[a];
-#pragma unroll
-                    for (int b = 0; b < 6; b++) Hr[6 * a + b] = H[6 * a + b] * sc[a] * sc[b];
-                }
-                if (!lm.reuse_diagonal) {
-#pragma unroll
-                    for (int a = 0; a < 6; a++) diag[a] = fmin(fmax(Hr[7 * a], 1e-6), 1e32);
-                }
-#pragma unroll
-                for (int k = 0; k < 36; k++) Mr[k] = Hr[k];
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    Mr[7 * a] += diag[a] / lm.radius;
-                    yr[a] = gr[a];
-                }
-                const bool okstep = chol_solve_fixed<6>(Mr, yr);
-                lm.reuse_diagonal = 1;
-                double *step = sh.step;
-                mcc = 0;
-                if (okstep) {
-                    double sg = 0, sHs = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) {
-                        step[a] = -yr[a];
-                        sg += -yr[a] * gr[a];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int b = 0; b < 6; b++) sHs += yr[a] * Hr[6 * a + b] * yr[b];
-                    mcc = -sg - 0.5 * sHs;  // = -(J s)'(f + J s / 2), trust_region_minimizer.cc:419-431
-                }
-                if (!okstep || !(mcc > 0)) {
-                    if (++invalid >= 5) flag = F_FAIL;
-                    else {
-                        lm.rejected();
-                        nsummaries++;
-                        flag = F_RETRY;
-                    }
-                } else {
-                    invalid = 0;
-                    double *delta = sh.delta;
-                    for (int a = 0; a < 6; a++) delta[a] = step[a] * scale[a];
-                    se3_plus(sh.x, delta, sh.cand);
-                    flag = F_EVAL_CAND;
-                }
-            }
-            sh.flag = flag;
-        }
-        __syncthreads();
-        int flag = sh.flag;
-        __syncthreads();  // everyone has read the flag before thread 0 may overwrite it
-        if (flag == F_DONE) break;
-        if (flag == F_FAIL) {
-            result = 0;
-            break;
-        }
-        if (flag == F_RETRY) continue;
+    for (int a = 0; a < 12; a++) sh.T[a] = T12[a];
+}
+
+// One ceres::Solve on the pose in sh.x (after solve_begin).  Returns (block-uniformly) 1 = usable, 0 = failure.
+// Between two evaluations lane 0 runs ONE block -- the verdict on the candidate just evaluated, then steps until one is valid -- so
+// there is one flag exchange per evaluation.
+// `bad` = the verdict mask of the LAST evaluation (see eval).
+__device__ __forceinline__ int solve(PnpShared &sh, const PnpArgs &A, int robust, const uint8_t *active, double *info, unsigned long long &bad) {
+    bad = eval<true>(sh, A, robust, active);
+    if (threadIdx.x == 0) sh.flag = lm_first_step(&sh, A.max_iters);
+    __syncthreads();
+    int flag = sh.flag;   // (lane 0 writes it again only behind the two barriers of the next evaluation)
+    while (flag == F_EVAL_CAND) {
         // The candidate is evaluated WITH its Jacobian: when the step is accepted Ceres re-evaluates at the same point
         // (HandleSuccessfulStep, trust_region_minimizer.cc:809-829), which would produce exactly these sums again.
-        eval<true>(sh, A, sh.cand, robust, active, chi2, depth);
-        if (threadIdx.x == 0) {
-            const double cand_cost = sh.acc[27];
-            double sn = 0;
-            for (int i = 0; i < 7; i++) sn += (sh.x[i] - sh.cand[i]) * (sh.x[i] - sh.cand[i]);
-            if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) flag = F_DONE;                       // ParameterToleranceReached
-            else if (fabs(x_cost - cand_cost) <= A.ftol * x_cost) flag = F_DONE;        // FunctionToleranceReached
-            else {
-                const double rel = (x_cost - cand_cost) / mcc;
-                if (rel > 1e-3) {
-                    double nn = 0;
-                    for (int i = 0; i < 7; i++) {
-                        sh.x[i] = sh.cand[i];
-                        nn += sh.x[i] * sh.x[i];
-                    }
-                    x_norm = sqrt(nn);
-                    lm.accepted(rel);
-                    nsucc++;
-                    flag = F_ACCEPT;
-                    for (int a = 0; a < 6; a++)
-                        for (int b = a; b < 6; b++) H[6 * a + b] = H[6 * b + a] = sh.acc[tri(a, b)];
-                    gmax = 0;
-                    for (int a = 0; a < 6; a++) {
-                        g[a] = sh.acc[21 + a];
-                        gmax = fmax(gmax, fabs(g[a]));
-                    }
-                    x_cost = cand_cost;
-                    nsummaries++;
-                } else {
-                    lm.rejected();
-                    nsummaries++;
-                    flag = F_RETRY;
-                }
-            }
-            sh.flag = flag;
-        }
+        bad = eval<true>(sh, A, robust, active);
+        if (threadIdx.x == 0) sh.flag = lm_after_candidate(&sh, A.max_iters, A.ftol);
         __syncthreads();
         flag = sh.flag;
-        __syncthreads();
-        if (flag == F_DONE) break;
     }
     if (threadIdx.x == 0 && info) {
-        info[0] = nsummaries;
-        info[1] = initial;
-        info[2] = x_cost;
-        info[3] = nsucc;
+        info[0] = sh.nsummaries;
+        info[1] = sh.initial;
+        info[2] = sh.x_cost;
+        info[3] = sh.nsucc;
     }
     __syncthreads();
-    return result;
+    return flag == F_DONE;
 }
 
 // p3p / inlier0 non-null = chained mode (VisualFrontend::computePose, visual_frontend.cpp:300-375): the initial pose is the
@@ -282,13 +524,45 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
     __shared__ PnpShared sh;
     __shared__ int s_nbad, s_p3p_ok, s_nact;
     __shared__ double s_info[8];
-    if (threadIdx.x < 8) s_info[threadIdx.x] = 0;
+    __shared__ double s_model[12];
+    __shared__ int s_sel[4];
     if (threadIdx.x == 0) {
+        sh.nstamp = 0;
         s_nbad = 0;
         s_nact = 0;
+    }
+    if (threadIdx.x < 8) s_info[threadIdx.x] = 0;
+    __syncthreads();
+    PNP_STAMP();
+    // One memory phase: the selection record (lanes 12.. of wave 0; lane 0 alone would walk it in dependent round trips) and the pass over
+    // the P3P inlier mask.  Chained mode: the robust solve reads that mask as its activity mask directly, and its complement goes out to
+    // the host's (pinned) buffer NOW, under the solve, instead of in the kernel's tail behind the final system-scope fence (should the P3P
+    // model be refused below, the rare path overwrites it with zeros).
+    if (p3p) {
+        if (threadIdx.x < 12) s_model[threadIdx.x] = p3p->model[threadIdx.x];
+        if (threadIdx.x == 12) s_sel[0] = p3p->have_model;
+        if (threadIdx.x == 13) s_sel[1] = p3p->n_inliers;
+        if (threadIdx.x == 14) s_sel[2] = p3p->n_valid_used;
+    }
+    const uint8_t *act1 = inlier0 ? inlier0 : active;
+    {
+        int na = 0;
+        for (int i = threadIdx.x; i < A.n; i += NT) {
+            uint8_t a = 1;
+            if (inlier0) a = inlier0[i];
+            else active[i] = 1;
+            if (p3p_outlier) p3p_outlier[i] = !a;
+            na += a;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) na += __shfl_down(na, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_nact, na);
+    }
+    __syncthreads();   // (also publishes `active` in the unchained mode: every thread wrote only the entries it reads)
+    if (threadIdx.x == 0) {
         s_p3p_ok = 1;
         if (p3p) {
-            const double *R = p3p->model;
+            const double *R = s_model;
             double e = 0;
             for (int r = 0; r < 3; r++)
                 for (int c = 0; c < 3; c++) {
@@ -296,8 +570,7 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
                     e += v * v;
                 }
             // + the translation test of visual_frontend.cpp:323 (isInf / isNaN)
-            s_p3p_ok = p3p->have_model && p3p->n_inliers >= 5 && sqrt(e) < 1e-10 && isfinite(p3p->model[9]) && isfinite(p3p->model[10]) &&
-                       isfinite(p3p->model[11]);
+            s_p3p_ok = s_sel[0] && s_sel[1] >= 5 && sqrt(e) < 1e-10 && isfinite(R[9]) && isfinite(R[10]) && isfinite(R[11]);
             if (s_p3p_ok) {
                 // rotation matrix -> unit quaternion (Sophus::SE3d::setRotationMatrix -> Eigen::Quaternion(R))
                 double q[4];
@@ -318,12 +591,17 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
                     q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
                     q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
                 }
-                for (int c = 0; c < 3; c++) sh.x[c] = p3p->model[9 + c];
-                for (int c = 0; c < 4; c++) sh.x[3 + c] = q[c];
+                // ... normalised like PoseParametersBlock(0, Sophus::SE3d(q, t)) does before the solve
+                const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                for (int c = 0; c < 3; c++) sh.x[c] = R[9 + c];
+                for (int c = 0; c < 4; c++) sh.x[3 + c] = q[c] / nq;
             }
         } else {
-            for (int c = 0; c < 7; c++) sh.x[c] = A.pose0[c];
+            const double nq = sqrt(A.pose0[3] * A.pose0[3] + A.pose0[4] * A.pose0[4] + A.pose0[5] * A.pose0[5] + A.pose0[6] * A.pose0[6]);
+            for (int c = 0; c < 3; c++) sh.x[c] = A.pose0[c];
+            for (int c = 0; c < 4; c++) sh.x[3 + c] = A.pose0[3 + c] / nq;
         }
+        if (s_p3p_ok) solve_begin(sh);
     }
     __syncthreads();
     if (!s_p3p_ok) {
@@ -332,7 +610,7 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
             out->p3p_ok = 0;
             out->n_bad = 0;
             out->n_active = 0;
-            out->p3p_n_valid_used = p3p->n_valid_used;
+            out->p3p_n_valid_used = s_sel[2];
         }
         if (threadIdx.x < 8) out->info[threadIdx.x] = 0;
         for (int i = threadIdx.x; i < A.n; i += NT) {
@@ -341,53 +619,41 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
         }
         return;
     }
-    {
-        int na = 0;
-        for (int i = threadIdx.x; i < A.n; i += NT) {
-            const uint8_t a = inlier0 ? inlier0[i] : (uint8_t) 1;
-            active[i] = a;
-            chi2[i] = 0.0;
-            depth[i] = 1;
-            na += a;
-        }
-        atomicAdd(&s_nact, na);
-    }
-    __syncthreads();
-    {
-        // normalise like PoseParametersBlock(0, Sophus::SE3d(q, t)) does before the solve
-        if (threadIdx.x == 0) {
-            Se3 T;
-            se3_from_pose7(sh.x, T);
-            for (int i = 0; i < 4; i++) sh.x[3 + i] = T.q[i];
-        }
-        __syncthreads();
-        if (p3p && threadIdx.x < 7) out->pose_p3p[threadIdx.x] = sh.x[threadIdx.x];
-    }
-    int ok = solve(sh, A, A.use_robust, active, chi2, depth, s_info);
+    if (p3p && threadIdx.x < 7) out->pose_p3p[threadIdx.x] = sh.x[threadIdx.x];
+    unsigned long long badmask;
+    int ok = solve(sh, A, A.use_robust, act1, s_info, badmask);
     const int nact = s_nact;
-    int nb = 0;
-    for (int i = threadIdx.x; i < A.n; i += NT) {
-        const bool b = active[i] && (chi2[i] > A.chi2_th || !depth[i]);  // multi_view_geometry.cpp:194-207
-        bad[i] = b;
-        if (p3p_outlier) p3p_outlier[i] = !inlier0[i];
-        if (b) {
-            nb++;
-            if (A.apply_l2) active[i] = 0;
+    {
+        // multi_view_geometry.cpp:194-207 from the verdicts of the last evaluation, which this thread still holds for its own points
+        int nb = 0, k = 0;
+        for (int i = threadIdx.x; i < A.n; i += NT, k++) {
+            const bool b = (badmask >> k) & 1ull;
+            bad[i] = b;
+            if (A.apply_l2) active[i] = act1[i] && !b;
+            nb += b;
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nb += __shfl_down(nb, off);
+        if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&s_nbad, nb);
     }
-    atomicAdd(&s_nbad, nb);
     __syncthreads();
     const int nbad = s_nbad;
     if (nbad == nact) ok = 0;
-    else if (A.apply_l2 && nbad > 0) ok = solve(sh, A, 0, active, chi2, depth, s_info + 4);  // :214-218
+    else if (A.apply_l2 && nbad > 0) {   // :214-218
+        if (threadIdx.x == 0) solve_begin(sh);
+        __syncthreads();
+        ok = solve(sh, A, 0, active, s_info + 4, badmask);
+    }
     if (threadIdx.x < 7) out->pose[threadIdx.x] = sh.x[threadIdx.x];
     if (threadIdx.x < 8) out->info[threadIdx.x] = s_info[threadIdx.x];
+    PNP_STAMP();
+    if (A.dbg && threadIdx.x == 0) A.dbg[2047] = (unsigned long long) sh.nstamp;
     if (threadIdx.x == 0) {
         out->ok = ok;
         out->n_bad = nbad;
         out->p3p_ok = 1;
         out->n_active = nact;
-        out->p3p_n_valid_used = p3p ? p3p->n_valid_used : 0;
+        out->p3p_n_valid_used = p3p ? s_sel[2] : 0;
     }
 }
 
@@ -423,7 +689,7 @@ __global__ void __launch_bounds__(NT) k_pnp_batch(const PnpBatchItem *__restrict
 extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *d_wpts, int n, double *h_pose7, int max_iters,
                                float chi2_th, int use_robust, int apply_l2_after_robust, float fx, float fy, float cx, float cy,
                                int *h_outliers, int *h_n_outliers, double *h_info, int *h_ok) {
-    ALVA_ARG(ctx && h_pose7 && h_outliers && h_n_outliers && h_ok && n >= 0 && max_iters >= 0);
+    ALVA_ARG(ctx && h_pose7 && h_outliers && h_n_outliers && h_ok && n >= 0 && n <= 64 * NT && max_iters >= 0);   // (64 verdict bits per thread)
     *h_ok = 0;
     *h_n_outliers = 0;
     if (h_info) memset(h_info, 0, 8 * sizeof(double));
@@ -441,6 +707,7 @@ extern "C" int alva_pnp_refine(alva_ctx *ctx, const double *d_uv, const double *
     A.max_iters = max_iters;
     A.ftol = 1.e-3;  // :186
     memcpy(A.pose0, h_pose7, sizeof(A.pose0));
+    A.dbg = alva_kstamp_buffer();
     // device scratch: chi2(n) | active(n) | depth(n);  pinned (written by the kernel, read after the sync): out | bad(n)
     const size_t off_act = (size_t) n * 8, off_dep = off_act + (size_t) n;
     uint8_t *base = nullptr, *pin = nullptr;
@@ -513,7 +780,7 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
 extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
                                          int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx,
                                          float fy, float cx, float cy) {
-    ALVA_ARG(ctx && n >= 0 && p3p_iters > 0 && pnp_iters >= 0);
+    ALVA_ARG(ctx && n >= 0 && n <= 64 * NT && p3p_iters > 0 && pnp_iters >= 0);
     if (!ctx->pose_pending) {
         ctx->pose_pending = new alva_pose_pending();
         ctx->pose_pending_free = pose_pending_free;
@@ -545,6 +812,7 @@ extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings
     A.apply_l2 = 1;     // state.hpp:76 robustCostRefineWithL2_
     A.max_iters = pnp_iters;
     A.ftol = 1.e-3;
+    A.dbg = alva_kstamp_buffer();
     return pose_launch(ctx, P);
 }
 

@@ -479,6 +479,9 @@ int alva_microbench_peaks(alva_ctx *ctx, double *h_tflops_mfma_f64, double *h_to
 /* Launch latency for the end-to-end bound of a frame (bench.py "bounds"): microseconds per kernel of `chain` dependent empty
  * launches on the context's stream, and the round trip of one empty launch + stream synchronisation.  Synchronous. */
 int alva_microbench_launch(alva_ctx *ctx, int chain, double *h_us_per_dependent_launch, double *h_us_launch_sync_roundtrip);
+/* Debug (no reference counterpart): phase stamps of the pose kernels (100 MHz wall clock), recorded only when the process runs with
+ * ALVA_KSTAMPS=1: 4096 x u64 -- k_p3p 8 per workgroup from entry 0, k_pnp sequentially from entry 2048; cleared by the call. */
+int alva_debug_kstamps(unsigned long long *h_out);
 
 /* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
  * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist

@@ -284,6 +284,11 @@ void syscpu_timing(void *p, double *sections8, double *keyframe16, int reset) {
         std::memset(s.t_kf, 0, sizeof(s.t_kf));
     }
 }
+void syscpu_timing_fine(void *p, double *out32, int reset) {
+    Slam &s = *static_cast<CpuSys *>(p)->slam;
+    if (out32) std::memcpy(out32, s.t_fine, sizeof(s.t_fine));
+    if (reset) std::memset(s.t_fine, 0, sizeof(s.t_fine));
+}
 void syscpu_counters(void *p, long *out) {
     Slam &s = *static_cast<CpuSys *>(p)->slam;
     out[0] = s.n_ba_runs; out[1] = s.n_merges; out[2] = s.n_kf_culled;

@@ -19,7 +19,8 @@ idx = lambda k: (k % period) if (k % period) < NF else period - (k % period)
 s = sysdiff.CpuSystem(w, h, cell)
 L = s.L
 L.syscpu_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-sec, kf = np.zeros(8), np.zeros(16)
+L.syscpu_timing_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+sec, kf, fine = np.zeros(8), np.zeros(16), np.zeros(32)
 names8 = ("upload+pyramid", "gather", "track_step", "track_apply", "pose_wait", "pose_apply+kf_check", "keyframe_create", "mapping")
 names16 = ("prepare", "describe_tracked", "detect", "describe_new", "insert+copy", "triangulate", "covisibility", "local_map_matching",
            "optimize", "(match stage)", "(BA stage)", "(BA build)", "(BA solves+sweep)", "(BA write-back)", "(BA culling)", "(descriptor medoids)")
@@ -27,6 +28,7 @@ t0 = time.time()
 for k in range(n):
     if k == n - win:
         L.syscpu_timing(s.h, sec.ctypes.data, kf.ctypes.data, 1)
+        L.syscpu_timing_fine(s.h, fine.ctypes.data, 1)
         kf0 = int(s.state()[11])
     s.step(frames[idx(k)], 33.0 * k)
 L.syscpu_timing(s.h, sec.ctypes.data, kf.ctypes.data, 1)
@@ -42,3 +44,6 @@ host = {"prepare": d["prepare"], "medoids": d["(descriptor medoids)"],
         "BA sweep (net of stage)": d["(BA solves+sweep)"] - d["(BA stage)"], "BA write-back": d["(BA write-back)"],
         "keyframe filter": d["optimize"] - d["(BA build)"] - d["(BA solves+sweep)"] - d["(BA write-back)"] - d["(BA culling)"]}
 print("  HOST-ONLY us per keyframe:", {a: round(b, 1) for a, b in host.items()}, "sum", round(sum(host.values()), 1))
+L.syscpu_timing_fine(s.h, fine.ctypes.data, 1)
+from alvaar_amd.system import AlvaAR
+print("  fine, per keyframe (us | counts):", {a: round((1e6 if not a.startswith("#") else 1) * b / max(nkf, 1), 1) for a, b in zip(AlvaAR.FINE_NAMES, fine) if a})
