@@ -82,7 +82,9 @@ struct BaDev {
                     // system-scope release; the host polls it instead of a copy command + stream wait per LM iteration); null in a batch
     long long seq;
     double *partial;  // [nPt][3] per-point partials for mcc / step norm / x norm
+    unsigned long long *dbg;   // phase stamps of k_solve (alva_kstamp_buffer, entries 3072..) or null
 };
+#define SOLVE_STAMP(k) do { if (B.dbg && threadIdx.x == 0) B.dbg[3072 + (k)] = wall_clock64(); } while (0)
 
 constexpr int KSPLIT = 8;
 
@@ -552,6 +554,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
     const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1, nb = np / NB;
     __shared__ double s_inv[NB], s_z[NB];
     __shared__ int s_ok;
+    SOLVE_STAMP(0);
     double *S = IN_LDS ? s_S : B.S;            // [np][ld]
     double *y = IN_LDS ? s_S + (size_t) np * ld : B.S + (size_t) np * ld;  // [np] right-hand side / solution
     if (IN_LDS) {  // matrix + right-hand side from k_reduced_system: coalesced, eight loads in flight per thread (one load -> one
@@ -582,9 +585,11 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
     }
     if (threadIdx.x == 0) s_ok = 1;
     __syncthreads();
+    SOLVE_STAMP(1);
     const int lane = threadIdx.x & 63;
     for (int kb = 0; kb < nb; kb++) {
         const int base = kb * NB;
+        SOLVE_STAMP(8 + 4 * kb);
 
         // ---- diagonal block: lane i (< 16) owns row i --------------------------------------------------------------
         if (threadIdx.x < 64) {
@@ -597,8 +602,12 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
             for (int j = 0; j < NB; j++) {
                 const double d = lane_bcast(a[j], j);
                 if (!(d > 0)) ok = 0;
-                const double inv = rsqrt(d), piv = d * inv;
-                a[j] = (lane & 15) == j ? piv : a[j] * inv;  // rows above j hold garbage in column j: never read
+                // the pivot's reciprocal square root is the head of every column's dependent chain (and 1 / L_jj of both triangular
+                // solves): refined hardware estimate instead of the IEEE-rounded rsqrt / divide (~10 dependent instructions instead of
+                // ~30 each, x ~330 pivots per call).  The DIAGONAL of the factor stores 1 / L_jj: the solves multiply.
+                double piv;
+                const double inv = alva_fast_rsqrt(d > 0 ? d : 1.0, piv);
+                a[j] = (lane & 15) == j ? inv : a[j] * inv;  // rows above j hold garbage in column j: never read
                 if (lane == j) s_inv[j] = inv;
 #pragma unroll
                 for (int k = j + 1; k < NB; k++) {
@@ -614,6 +623,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
             if (lane == 0 && !ok) s_ok = 0;
         }
         __syncthreads();
+        SOLVE_STAMP(9 + 4 * kb);
         if (!s_ok) break;
         // ---- panel: x L11' = a for every row below --------------------------------------------------------------------
         const int m = np - base - NB;  // rows below the block
@@ -632,6 +642,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
             for (int j = 0; j < NB; j++) rowp[j] = x[j];
         }
         __syncthreads();
+        SOLVE_STAMP(10 + 4 * kb);
         // ---- trailing update A22 -= L21 L21': a rank-16 update, i.e. one 16 x 16 x 16 product per 16 x 16 tile of the lower triangle
         //      = four v_mfma_f64_16x16x4_f64 per tile, one wavefront per tile (operand a: L[rowa + (lane & 15)][4c + (lane >> 4)],
         //      operand b the same for rowb; result row (lane >> 4) + 4r, column lane & 15).  Diagonal tiles are updated in full: the
@@ -659,6 +670,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
         }
         __syncthreads();
     }
+    SOLVE_STAMP(2);
     if (s_ok) {
         // ---- L z = rhs, blocked -----------------------------------------------------------------------------------------
         for (int kb = 0; kb < nb; kb++) {
@@ -671,7 +683,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
                 double yi = y[base + i];
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
-                    const double zj = lane_bcast(yi, j) / lane_bcast(l[j], j);
+                    const double zj = lane_bcast(yi, j) * lane_bcast(l[j], j);   // (the diagonal holds 1 / L_jj)
                     if (i == j) yi = zj;
                     else if (i > j) yi -= l[j] * zj;
                 }
@@ -690,6 +702,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
             }
             __syncthreads();
         }
+        SOLVE_STAMP(3);
         // ---- L' y = z, blocked, last block first ------------------------------------------------------------------------------
         for (int kb = nb - 1; kb >= 0; kb--) {
             const int base = kb * NB;
@@ -701,7 +714,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
                 double zi = y[base + i];
 #pragma unroll
                 for (int j = NB - 1; j >= 0; j--) {
-                    const double yj = lane_bcast(zi, j) / lane_bcast(lc[j], j);
+                    const double yj = lane_bcast(zi, j) * lane_bcast(lc[j], j);
                     if (i == j) zi = yj;
                     else if (i < j) zi -= lc[j] * yj;
                 }
@@ -719,9 +732,11 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
             }
             __syncthreads();
         }
+        SOLVE_STAMP(4);
         for (int r = threadIdx.x; r < n; r += SOLVE_NT) B.yc[r] = y[r];
     }
     if (threadIdx.x == 0) B.scal[5] = s_ok ? 1.0 : 0.0;
+    SOLVE_STAMP(5);
 }
 template<bool IN_LDS>
 __global__ void __launch_bounds__(SOLVE_NT) k_solve(BaDev B, double radius) {
@@ -1012,6 +1027,7 @@ struct BaHost {
         B.yc = carve<double>(cur, NP);
         B.yp = carve<double>(cur, npd);
         B.scal = carve<double>(cur, 64);
+        B.dbg = alva_kstamp_buffer();
         B.partial = carve<double>(cur, nPt * 3 + 8);   // per point: mcc, step^2, candidate^2 partials; then the camera part (3)
         d_cp = carve<double>(cur, n_kf * 7);
         d_ct = carve<double>(cur, npd);

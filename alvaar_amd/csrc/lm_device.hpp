@@ -204,3 +204,27 @@ struct LmState {
         reuse_diagonal = 1;
     }
 };
+
+#ifdef __HIPCC__
+// Reciprocal / reciprocal square root for places where ONE lane's (or one wave's) dependent chain is kernel time -- the pivots of the
+// small Cholesky factorisations, a minimiser step on lane 0: the hardware estimates refined by two Newton steps (<= 1-2 ulp) cost ~10
+// dependent instructions where the IEEE-rounded divide / square root expand to 25-30.  x > 0 and normal.
+__device__ __forceinline__ double alva_fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+// returns 1 / sqrt(x); root ~ sqrt(x)
+__device__ __forceinline__ double alva_fast_rsqrt(double x, double &root) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    root = fma(g, e, g);
+    h = fma(h, e, h);
+    return 2.0 * h;
+}
+#endif
+

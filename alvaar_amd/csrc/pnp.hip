@@ -105,24 +105,8 @@ __device__ __forceinline__ int tri(int a, int b) {  // index of (a,b), a <= b, i
 // square roots -- 39 of them in a 6x6 Cholesky solve, ~100 ns each as a dependent chain).  Reciprocals and reciprocal square roots are
 // therefore the hardware estimates refined by two Newton steps (<= 1-2 ulp; the results of this kernel are compared under a
 // tolerance, the iteration itself is Ceres', not bit-for-bit Eigen), each used once per pivot and multiplied in.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-// g ~ sqrt(x), returns 1 / sqrt(x) (x > 0, normal)
-__device__ __forceinline__ double fast_rsqrt(double x, double &g) {
-    const double r = __builtin_amdgcn_rsq(x);
-    g = x * r;
-    double h = 0.5 * r;
-    double e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    return 2.0 * h;
-}
+__device__ __forceinline__ double fast_rcp(double x) { return alva_fast_rcp(x); }
+__device__ __forceinline__ double fast_rsqrt(double x, double &g) { return alva_fast_rsqrt(x, g); }   // g ~ sqrt(x), returns 1 / sqrt(x)
 __device__ __forceinline__ double fast_sqrt(double x) {
     double g;
     (void) fast_rsqrt(x, g);
@@ -662,6 +646,10 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ act
                                             const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
                                             uint8_t *__restrict__ p3p_outlier) {
     pnp_block(A, active, chi2, depth, bad, out, p3p, inlier0, p3p_outlier);
+    // (Measured alternatives to this fence, 2.5 us of kernel tail: plain stores + s_waitcnt vmcnt(0) -> the host reads stale masks (host
+    // memory is cached in L2); every host-visible word as a system-scope write-through store + vmcnt(0) -> correct, the fence's time
+    // reappears in front of every later vmcnt wait of the storing waves (the counter is in-order and a write-through store is acknowledged
+    // by the bus), +4 us over the kernel.)
     __threadfence_system();   // this thread's writes to `out` / `bad` / `p3p_outlier` (possibly pinned host memory) ...
     __syncthreads();          // ... of every thread ...
     if (threadIdx.x == 0) __hip_atomic_store(&out->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the word a host may poll

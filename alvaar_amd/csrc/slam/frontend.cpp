@@ -82,6 +82,10 @@ bool Slam::track(const uint8_t *rgba, double timestamp, bool frame_on_device) { 
         Section sec(t_section[0]);
         // cvtColor (system.cpp:112) + preprocessImage (:672-698)
         if (fail(frame_on_device ? st->new_frame_device(rgba) : st->new_frame(rgba))) return false;
+        if (next_frame_hint) {   // alva_system_hint_next_frame_device: the stages may build that frame's images beside this frame's pose solve
+            if (frame_on_device) st->hint_next_frame_device(next_frame_hint);
+            next_frame_hint = nullptr;
+        }
     }
     const bool kf_required = process(timestamp);
     if (err_) return false;

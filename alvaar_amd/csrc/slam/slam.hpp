@@ -379,6 +379,7 @@ public:
     double t_kf[16] = {0};
     // finer laps for profiling (tools/system_sustained.py FINE=1): see the FINE_* indices in mapper.cpp / map.cpp
     double t_fine[32] = {0};
+    const uint8_t *next_frame_hint = nullptr;   // device pointer of the frame after the next processed one (optional, see Stages)
 
 private:
     int err_ = 0;

@@ -349,9 +349,16 @@ struct HipStages::Impl {
     hipStream_t st = nullptr;
     Camera cam;
     bool clahe = false;
-    alva_pyramid *pyr[2] = {nullptr, nullptr};
-    int cur = 0;
-    uint8_t *d_rgba = nullptr, *d_gray = nullptr, *d_eq = nullptr, *h_rgba = nullptr;
+    // Three pyramids / two gray images in rotation: the current frame's, the previous frame's (the tracker reads both) and the one a
+    // look-ahead build may be filling for the next frame (hint_next_frame_device).  d_gray always names the CURRENT frame's image.
+    alva_pyramid *pyr[3] = {nullptr, nullptr, nullptr};
+    int cur = 0, prev = 1, nxt = 2;
+    uint8_t *d_rgba = nullptr, *d_gray = nullptr, *d_gray_next = nullptr, *d_eq = nullptr, *h_rgba = nullptr;
+    // look-ahead: the hinted source, whether its build has been enqueued (on ahead_st, behind ev_chain) / is complete up to ev_ahead
+    const uint8_t *ahead_src = nullptr;
+    bool ahead_enqueued = false, ahead_dirty = false;
+    hipStream_t ahead_st = nullptr;
+    hipEvent_t ev_chain = nullptr, ev_ahead = nullptr;
     double *d_invK = nullptr;
     const uint8_t *registered = nullptr, *registered_dev = nullptr;  // caller buffer locked + mapped by register_frame_buffer
     size_t registered_bytes = 0;
@@ -472,7 +479,13 @@ HipStages::~HipStages() {
     (void) hipSetDevice(m->device);
     if (m->ctx) (void) alva_ctx_sync(m->ctx);
     for (auto &p: m->pyr) alva_pyramid_destroy(p);
-    void *bufs[] = {m->d_rgba, m->d_gray, m->d_eq, m->d_invK};
+    if (m->ahead_st) {
+        (void) hipStreamSynchronize(m->ahead_st);
+        (void) hipStreamDestroy(m->ahead_st);
+    }
+    if (m->ev_chain) (void) hipEventDestroy(m->ev_chain);
+    if (m->ev_ahead) (void) hipEventDestroy(m->ev_ahead);
+    void *bufs[] = {m->d_rgba, m->d_gray, m->d_gray_next, m->d_eq, m->d_invK};
     for (void *b: bufs)
         if (b) (void) hipFree(b);
     if (m->h_rgba) (void) hipHostFree(m->h_rgba);
@@ -501,6 +514,10 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     const size_t P = (size_t) cam.width * cam.height;
     ALVA_HIP(hipMalloc((void **) &m->d_rgba, P * 4));
     ALVA_HIP(hipMalloc((void **) &m->d_gray, P));
+    ALVA_HIP(hipMalloc((void **) &m->d_gray_next, P));
+    ALVA_HIP(hipStreamCreateWithFlags(&m->ahead_st, hipStreamNonBlocking));
+    ALVA_HIP(hipEventCreateWithFlags(&m->ev_chain, hipEventDisableTiming));
+    ALVA_HIP(hipEventCreateWithFlags(&m->ev_ahead, hipEventDisableTiming));
     if (clahe) ALVA_HIP(hipMalloc((void **) &m->d_eq, P));
     ALVA_HIP(hipMalloc((void **) &m->d_invK, 9 * sizeof(double)));
     ALVA_HIP(hipMemcpy(m->d_invK, invK, 9 * sizeof(double), hipMemcpyHostToDevice));
@@ -680,7 +697,23 @@ int HipStages::warm_up(int cell) {
 }
 
 int HipStages::build_from(const uint8_t *d_src) {
-    m->cur ^= 1;
+    Impl &M = *m;
+    const bool hit = M.ahead_enqueued && M.ahead_src == d_src;
+    if (M.ahead_dirty) {
+        // a look-ahead build wrote (or is writing) pyr[nxt] / d_gray_next on its own stream: whatever this frame does with those
+        // buffers -- read them (hit) or rebuild them (miss) -- comes behind it
+        ALVA_HIP(hipStreamWaitEvent(M.st, M.ev_ahead, 0));
+        M.ahead_dirty = false;
+    }
+    M.ahead_enqueued = false;
+    M.ahead_src = nullptr;
+    // rotate: previous <- current <- next; the old previous becomes the free slot
+    const int freed = M.prev;
+    M.prev = M.cur;
+    M.cur = M.nxt;
+    M.nxt = freed;
+    std::swap(M.d_gray, M.d_gray_next);
+    if (hit) return ALVA_OK;
     if (!m->clahe) return alva_pyramid_build_from_rgba(m->ctx, m->pyr[m->cur], d_src, (size_t) m->cam.width * 4, m->d_gray, (size_t) m->cam.width);
     int rc = alva_rgba2gray(m->ctx, d_src, (size_t) m->cam.width * 4, m->cam.width, m->cam.height, m->d_gray, (size_t) m->cam.width);
     if (rc) return rc;
@@ -689,6 +722,32 @@ int HipStages::build_from(const uint8_t *d_src) {
                     (size_t) m->cam.width);
     if (rc) return rc;
     return alva_pyramid_build_from_gray(m->ctx, m->pyr[m->cur], m->d_eq, (size_t) m->cam.width);
+}
+
+// Look-ahead (no reference counterpart; the reference receives one frame per call): the caller names the frame of its NEXT call, and its
+// gray image + LK pyramid are built on a second stream beside the current frame's pose solve, into the rotation's free slot.  The build
+// is enqueued behind the tracker (ev_chain: the tracker fills the chip, the pose kernels leave most of it idle) or, in a frame that
+// tracks nothing, at the end of the call.  The next new_frame_device takes the slot over when its pointer is the hinted one, and rebuilds
+// as usual when it is not: results never depend on hints.
+void HipStages::hint_next_frame_device(const uint8_t *d_rgba) {
+    if (m->clahe) return;   // (the CLAHE chain shares d_eq / context scratch with the current frame: no look-ahead there)
+    m->ahead_src = d_rgba;
+    m->ahead_enqueued = false;
+}
+
+int HipStages::build_ahead() {
+    Impl &M = *m;
+    if (!M.ahead_src || M.ahead_enqueued) return ALVA_OK;
+    ALVA_HIP(hipEventRecord(M.ev_chain, M.st));
+    ALVA_HIP(hipStreamWaitEvent(M.ahead_st, M.ev_chain, 0));
+    M.ctx->stream = M.ahead_st;   // (the image kernels launch on the context stream)
+    const int rc = alva_pyramid_build_from_rgba(M.ctx, M.pyr[M.nxt], M.ahead_src, (size_t) M.cam.width * 4, M.d_gray_next, (size_t) M.cam.width);
+    M.ctx->stream = M.st;
+    if (rc) return rc;
+    ALVA_HIP(hipEventRecord(M.ev_ahead, M.ahead_st));
+    M.ahead_enqueued = true;
+    M.ahead_dirty = true;
+    return ALVA_OK;
 }
 
 // The caller's frame buffer is pageable memory (the reference's wasm heap): by default a frame goes through a pinned staging copy
@@ -751,6 +810,10 @@ int HipStages::new_frame_device(const uint8_t *d_rgba) {
 }
 
 int HipStages::frame_done() {
+    if (m->ahead_src && !m->ahead_enqueued) {   // a frame that tracked nothing: the look-ahead goes out now
+        const int rc = build_ahead();
+        if (rc) return rc;
+    }
     if (m->upload_in_flight) {
         m->upload_in_flight = false;
         ALVA_HIP(alva_event_sync(m->upload_done));
@@ -779,7 +842,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     int rc = m->track_reserve(n);
     if (rc) return rc;
     const size_t c = (size_t) m->trk_cap;
-    const alva_pyramid *prev = m->pyr[m->cur ^ 1], *cur = m->pyr[m->cur];
+    const alva_pyramid *prev = m->pyr[m->prev], *cur = m->pyr[m->cur];
     const Camera &k = m->cam;
     int n3d = 0;
     for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
@@ -829,6 +892,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         if (rc) return rc;
         hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
         ALVA_LAUNCH_CHECK();
+        rc = build_ahead();   // a hinted next frame: its images go out behind the tracker, beside the pose solve
+        if (rc) return rc;
         poll_seq = m->poll ? D.seq : 0;
         slots_D = D;
         slots_path = true;
@@ -991,7 +1056,7 @@ int HipStages::fbklt(int levels, int n, const float *pts, float *prior, uint8_t 
     UP(a, pts, (size_t) n * 8);
     UP(b, prior, (size_t) n * 8);
     // state.hpp:50-56: kltError_ 30, kltMaxFbDistance_ 0.5, 30 iterations, 0.01 px
-    rc = alva_fbklt_track(m->ctx, m->pyr[m->cur ^ 1], m->pyr[m->cur], levels, 30.f, 0.5f, 30, 0.01f, (const float *) d[a], (float *) d[b], d[c], n);
+    rc = alva_fbklt_track(m->ctx, m->pyr[m->prev], m->pyr[m->cur], levels, 30.f, 0.5f, 30, 0.01f, (const float *) d[a], (float *) d[b], d[c], n);
     if (rc) return rc;
     DOWN(b, (size_t) n * 8);
     DOWN(c, (size_t) n);

@@ -21,6 +21,7 @@ public:
     bool track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) override;
     int new_frame(const uint8_t *rgba) override;
     int new_frame_device(const uint8_t *d_rgba) override;
+    void hint_next_frame_device(const uint8_t *d_rgba) override;
     int frame_done() override;
     // explicit page-lock + device mapping of the caller's frame buffer (see new_frame); buf == nullptr releases it
     int register_frame_buffer(const uint8_t *buf, size_t bytes);
@@ -52,6 +53,7 @@ public:
 
 private:
     int build_from(const uint8_t *d_src);
+    int build_ahead();
     struct Impl;
     Impl *m;
     bool fused_active_ = false;

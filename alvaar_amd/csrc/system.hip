@@ -183,6 +183,16 @@ extern "C" int alva_system_find_camera_pose_device(alva_system *s, const uint8_t
     });
 }
 
+extern "C" int alva_system_hint_next_frame_device(alva_system *s, const uint8_t *d_rgba_next) {
+    g_sys_err[0] = 0;
+    if (!s || !s->slam) {
+        snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_hint_next_frame_device: not configured");
+        return ALVA_ERR_ARG;
+    }
+    s->slam->next_frame_hint = d_rgba_next;
+    return ALVA_OK;
+}
+
 extern "C" int alva_system_find_camera_pose(alva_system *s, const uint8_t *h_rgba, float *h_pose) {
     // system.cpp:114: milliseconds of the system clock
     const double ts = (double) std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();

@@ -28,6 +28,7 @@ lib.alva_system_find_camera_pose_ts.argtypes = [_vp, _vp, _d, _vp]
 lib.alva_system_register_frame_buffer.argtypes = [_vp, _vp, C.c_size_t]
 lib.alva_system_unregister_frame_buffer.argtypes = [_vp]
 lib.alva_system_find_camera_pose_device.argtypes = [_vp, _vp, _d, _vp]
+lib.alva_system_hint_next_frame_device.argtypes = [_vp, _vp]
 lib.alva_system_debug_state.argtypes = [_vp, _vp]
 lib.alva_system_debug_pose7.argtypes = [_vp, _vp, _vp]
 lib.alva_system_debug_frame_keypoints.argtypes = [_vp, _i] + [_vp] * 5
@@ -126,8 +127,11 @@ class AlvaAR:
         np.copyto(self.mem_img, np.asarray(frame_rgba, np.uint8).reshape(self.mem_img.shape))
         return self.mem_img
 
-    def find_camera_pose_device(self, d_rgba_ptr: int, timestamp_ms: float):
-        """frame already in device memory (torch tensor .data_ptr()); returns the status, the pose is in self._pose"""
+    def find_camera_pose_device(self, d_rgba_ptr: int, timestamp_ms: float, next_d_rgba_ptr: int | None = None):
+        """frame already in device memory (torch tensor .data_ptr()); returns the status, the pose is in self._pose.
+        next_d_rgba_ptr: the frame the NEXT call will pass (alva_system_hint_next_frame_device: its pyramid is built ahead)"""
+        if next_d_rgba_ptr:
+            lib.alva_system_hint_next_frame_device(self.h, next_d_rgba_ptr)
         status = lib.alva_system_find_camera_pose_device(self.h, d_rgba_ptr, float(timestamp_ms), self._pose.ctypes.data)
         if status < 0:
             raise AlvaError(lib.alva_system_last_error().decode())

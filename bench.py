@@ -224,6 +224,14 @@ class SystemJob:
         self.status_hist[st] += 1
         return st == 1
 
+    def step_ahead(self):
+        """the same step with the NEXT frame named (alva_system_hint_next_frame_device): its gray image / pyramid are built beside this
+        frame's pose solve"""
+        self.k += 1
+        st = self.ar.find_camera_pose_device(self.ptrs[stream_index(self.k)], 33.0 * self.k, self.ptrs[stream_index(self.k + 1)])
+        self.status_hist[st] += 1
+        return st == 1
+
     def step_host(self):
         self.k += 1
         # src/system.js:175 memImg.write(frame.data): AlvaAR.findCameraPose copies the caller's frame into its ONE registered frame buffer
@@ -953,6 +961,11 @@ def main():
     sys_state = ar.state()
     sys_counters = ar.counters()
     log(f"sustained: {long_steps / dt_long:.0f} frames/s per rank")
+    # the same loop with look-ahead hints (the caller names the next frame: its images are built beside this frame's pose solve)
+    kf_before = int(ar.state()[11])
+    dt_ahead = timed(sysjob.step_ahead, 5, long_steps)
+    kf_ahead = int(ar.state()[11]) - kf_before
+    log(f"with next-frame hints: {long_steps / dt_ahead:.0f} frames/s per rank")
     # PCIe-fed variant: host RGBA in through AlvaAR.findCameraPose (memImg.write + the registered buffer read in place), same length
     dt_host = timed(sysjob.step_host, 5, long_steps)
     ar.timing()
@@ -1078,6 +1091,12 @@ def main():
             "sustained": {"frames_per_s": world * long_steps / dt_long, "steps": long_steps, "seconds": dt_long, "keyframes": kf_long,
                           "value_over_sustained": fps / (world * long_steps / dt_long),
                           "note": "the same timed loop continued for at least 0.5 s"},
+            "system_lookahead": {"frames_per_s": world * long_steps / dt_ahead, "ms_per_step": dt_ahead / long_steps * 1e3, "steps": long_steps,
+                                 "keyframes": kf_ahead,
+                                 "note": "the sustained loop with alva_system_hint_next_frame_device before every call (the caller names the frame "
+                                         "of its next call; gray + LK pyramid of that frame are built on a second stream beside this frame's "
+                                         "pose solve; results identical, tests/test_gpu_system.py).  NOT `value`: the reference's "
+                                         "findCameraPose is handed one frame per call"},
             "system_surface": {"frames_per_s": world * long_steps / dt_host, "ms_per_step": dt_host / long_steps * 1e3, "steps": long_steps,
                                "caller_copy_us": round(copy_us, 1),
                                "per_frame_us_host_fed": us(sections_host, 100),

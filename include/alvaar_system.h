@@ -78,6 +78,12 @@ int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, dou
 /* The same for a frame that already lives in DEVICE memory of the system's GPU (width*height*4 bytes, 16-byte aligned): no PCIe
  * upload.  For capture pipelines that deliver into HBM, and for bench.py's timed loop (frames resident in HBM). */
 int alva_system_find_camera_pose_device(alva_system *sys, const uint8_t *d_rgba, double timestamp_ms, float *h_pose);
+/* Look-ahead for frames in device memory (no reference counterpart: the reference is handed one frame per call).  Called BEFORE
+ * alva_system_find_camera_pose_device(frame k), it names frame k+1 (device memory that stays valid and unchanged until that call): the
+ * gray image and LK pyramid of frame k+1 are then built on a second stream beside frame k's pose solve, and call k+1 finds them
+ * ready when it passes the same pointer (any other pointer: the look-ahead is dropped and the frame is built as usual).  Results are
+ * identical with and without hints.  One hint per call; NULL cancels. */
+int alva_system_hint_next_frame_device(alva_system *sys, const uint8_t *d_rgba_next);
 /* System::findCameraPoseWithIMU (system.cpp:57-104).  h_imu: [qw,qx,qy,qz,n, n x {ts,gx,gy,gz,ax,ay,az}]. Always returns 1. */
 int alva_system_find_camera_pose_with_imu(alva_system *sys, const uint8_t *h_rgba, const double *h_imu, float *h_pose);
 /* the same with the caller's timestamp in milliseconds instead of the wall clock (system.cpp:87), as alva_system_find_camera_pose_ts */

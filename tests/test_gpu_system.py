@@ -476,3 +476,38 @@ def test_group_sessions_equal_their_solo_runs():
             assert a[k][0] == b[k][0] and a[k][4] == b[k][4], (i, k)
             assert np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), (i, k)
             assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), (i, k)
+
+
+def test_next_frame_hints_do_not_change_results():
+    """alva_system_hint_next_frame_device: the next frame's gray image + pyramid built ahead on a second stream.  A 70-frame stream
+    (initialisation, keyframes with local BA, a forwards / backwards sweep) with a correct hint on most frames, a WRONG hint on every
+    seventh (dropped, the frame is rebuilt), none on every fifth, and one frame passed twice: statuses, poses (bitwise), keypoint ids and
+    pixels (bitwise) and the counters equal the run without hints"""
+    import torch
+    from alvaar_amd.system import AlvaAR
+    w, h, n = 640, 480, 70
+    canvas = synth.texture_canvas(w, h, 7)
+    dev = torch.from_numpy(np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(40)])).cuda()
+    order = [k if k < 40 else 79 - k for k in range(n)]
+    order[50] = order[49]   # the same frame twice in a row (hinted correctly: the hint names the buffer it is reading from)
+
+    def run(hints: bool):
+        ar = AlvaAR(w, h, cell_size=12, random_sampling=False)
+        rec = []
+        for k in range(n):
+            nxt = None
+            if hints and k + 1 < n and k % 5 != 4:
+                nxt = int(dev[order[k + 1] if k % 7 != 6 else (order[k + 1] + 3) % 40].data_ptr())
+            st = ar.find_camera_pose_device(int(dev[order[k]].data_ptr()), 33.0 * k, nxt)
+            ids, px, i3 = ar.keypoints()
+            rec.append((st, ar.pose7()[0].copy(), ids.copy(), px.copy(), list(ar.state())))
+        rec.append(ar.counters())
+        ar.close()
+        return rec
+
+    a, b = run(False), run(True)
+    assert a[-1] == b[-1] and a[-1]["ba_solves"] >= 1, (a[-1], b[-1])
+    for k in range(n):
+        assert a[k][0] == b[k][0] and a[k][4] == b[k][4], k
+        assert np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), k
+        assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), k
