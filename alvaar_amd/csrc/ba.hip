@@ -504,6 +504,9 @@ __global__ void __launch_bounds__(64) k_gemm(BaDev B) {
 //   trailing update  A22 -= L21 L21' as 16 x 16 tiles on v_mfma_f64_16x16x4_f64, one wavefront per tile
 // = 3 barriers per 16 columns instead of 3 per column; the triangular solves are blocked the same way.  Row stride is
 // odd (padded size + 1) so that threads reading different rows hit different LDS banks.
+#ifndef ALVA_SOLVE_LOOKAHEAD
+#define ALVA_SOLVE_LOOKAHEAD 1
+#endif
 constexpr int SOLVE_NT = 256, NB = 16;   // measured and dropped: 1024 threads (16 waves for the trailing update's tiles): 80 vs 67 us, the
                                         // barriers cost more than the tiles save; triangular solves through explicit inverses of the diagonal
                                         // blocks' factors (computed by a spare wave beside the panel): 91 us, the inverse is a longer chain
@@ -552,156 +555,191 @@ template<bool IN_LDS>
 __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const int BX_, const int BY_) {
     extern __shared__ double s_S[];
     const int n = B.n6, np = (n + NB - 1) / NB * NB, ld = np + 1, nb = np / NB;
-    __shared__ double s_inv[NB], s_z[NB];
+    __shared__ double s_z[NB];
     __shared__ int s_ok;
     SOLVE_STAMP(0);
     double *S = IN_LDS ? s_S : B.S;            // [np][ld]
     double *y = IN_LDS ? s_S + (size_t) np * ld : B.S + (size_t) np * ld;  // [np] right-hand side / solution
-    if (IN_LDS) {  // matrix + right-hand side from k_reduced_system: coalesced, eight loads in flight per thread (one load -> one
-                   // LDS store per trip took 14 us for the 100 KB of a 108-unknown system)
+    // micro-tile enumeration of a lower triangle, row by row: t -> (ta, tb), the same for every trailing size
+    constexpr int TILE_LUT = 1024;   // 16 x 16 tiles: covers np <= 736; larger systems decode arithmetically
+    __shared__ unsigned short s_tile[TILE_LUT];
+    auto fill_lut = [&]() {
+        for (int t = threadIdx.x; t < TILE_LUT; t += SOLVE_NT) {
+            int ta = (int) ((sqrtf(8.f * (float) t + 1.f) - 1.f) * 0.5f);
+            while (ta * (ta + 1) / 2 > t) ta--;
+            while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+            s_tile[t] = (unsigned short) ((ta << 8) | (t - ta * (ta + 1) / 2));
+        }
+    };
+    if (IN_LDS) {
+        // matrix + right-hand side from k_reduced_system into LDS: a chain of round trips to memory another kernel has just written, so
+        // as many loads in flight as the register file allows (32 per thread: two trips for the 100 KB of a 108-unknown system; eight in
+        // flight took six trips, 6.1 us, a tenth of the kernel) and the tile table computed while the first trip flies.  Tried and
+        // dropped: fetching only the lower triangle (the one half the factorisation reads) -- its row / column arithmetic per word
+        // costs what the halved traffic saves, with a packed source as well (6.8 - 7.5 us).
         const int total = np * ld + np;
-        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * SOLVE_NT) {
-            double v[8];
+        bool lut_done = false;
+        for (int e0 = threadIdx.x; e0 < total || !lut_done; e0 += 32 * SOLVE_NT) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 32; u++) {
                 const int e = e0 + u * SOLVE_NT;
                 v[u] = e < total ? B.S[e] : 0.0;
             }
+            if (!lut_done) {
+                fill_lut();
+                lut_done = true;
+            }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 32; u++) {
                 const int e = e0 + u * SOLVE_NT;
                 if (e < total) s_S[e] = v[u];
             }
         }
-    }
-    // micro-tile enumeration of a lower triangle, row by row: t -> (ta, tb), the same for every trailing size
-    constexpr int TILE_LUT = 1024;   // 16 x 16 tiles: covers np <= 736; larger systems decode arithmetically
-    __shared__ unsigned short s_tile[TILE_LUT];
-    for (int t = threadIdx.x; t < TILE_LUT; t += SOLVE_NT) {
-        int ta = (int) ((sqrtf(8.f * (float) t + 1.f) - 1.f) * 0.5f);
-        while (ta * (ta + 1) / 2 > t) ta--;
-        while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
-        s_tile[t] = (unsigned short) ((ta << 8) | (t - ta * (ta + 1) / 2));
+    } else {
+        fill_lut();
     }
     if (threadIdx.x == 0) s_ok = 1;
     __syncthreads();
     SOLVE_STAMP(1);
     const int lane = threadIdx.x & 63;
+    // ---- diagonal block at `base`, by ONE wave: lane i (< 16) owns row i ---------------------------------------------------------
+    auto diag_factor = [&](const int base) {
+        double a[NB];
+        const int row = base + (lane & 15);
+#pragma unroll
+        for (int k = 0; k < NB; k++) a[k] = S[(size_t) row * ld + base + k];
+        int ok = 1;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double d = lane_bcast(a[j], j);
+            if (!(d > 0)) ok = 0;
+            // the pivot's reciprocal square root is the head of every column's dependent chain (and 1 / L_jj of both triangular
+            // solves): refined hardware estimate instead of the IEEE-rounded rsqrt / divide (~10 dependent instructions instead of
+            // ~30 each, x ~330 pivots per call).  The DIAGONAL of the factor stores 1 / L_jj: the solves multiply.
+            double piv;
+            const double inv = alva_fast_rsqrt(d > 0 ? d : 1.0, piv);
+            a[j] = (lane & 15) == j ? inv : a[j] * inv;  // rows above j hold garbage in column j: never read
+#pragma unroll
+            for (int k = j + 1; k < NB; k++) {
+                const double lkj = lane_bcast(a[j], k);
+                a[k] -= a[j] * lkj;  // used for rows >= k only
+            }
+        }
+        if (lane < NB) {
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+                if (k <= lane) S[(size_t) row * ld + base + k] = a[k];
+        }
+        if (lane == 0 && !ok) s_ok = 0;
+    };
+    // one 16 x 16 tile of the trailing update A22 -= L21 L21' (a rank-16 update = four v_mfma_f64_16x16x4_f64 per tile, one wavefront per
+    // tile: operand a: L[rowa + (lane & 15)][4c + (lane >> 4)], operand b the same for rowb; result row (lane >> 4) + 4r, column
+    // lane & 15).  Diagonal tiles are updated in full: the strict upper triangle is never read.
+    auto trailing_tile = [&](const int base, const int t) {
+        int ta, tb;
+        if (t < TILE_LUT) {
+            ta = s_tile[t] >> 8;
+            tb = s_tile[t] & 255;
+        } else {
+            ta = (int) ((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while (ta * (ta + 1) / 2 > t) ta--;
+            while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+            tb = t - ta * (ta + 1) / 2;
+        }
+        const double *La = S + (size_t) (base + NB + NB * ta + (lane & 15)) * ld + base + (lane >> 4);
+        const double *Lb = S + (size_t) (base + NB + NB * tb + (lane & 15)) * ld + base + (lane >> 4);
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NB / 4; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * c], Lb[4 * c], acc, 0, 0, 0);
+        double *C = S + (size_t) (base + NB + NB * ta + (lane >> 4)) * ld + base + NB + NB * tb + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) C[(size_t) (4 * r) * ld] -= acc[r];
+    };
+    // The factorisation carries the right-hand side along as ROW np of the matrix (it is stored there): the panel solve of block kb turns
+    // its 16 entries into z = L11^-1 y and the trailing update subtracts L21 z from the rest -- the forward substitution L z = rhs costs no
+    // pass (and no barriers) of its own.  Look-ahead: while three waves run the trailing update of block kb, the first wave updates the ONE
+    // tile the next diagonal block lives in and factors it (stamps before: 2.2 us per diagonal block with three waves waiting).
+    const int wave = threadIdx.x >> 6;
+    constexpr bool LOOKAHEAD = ALVA_SOLVE_LOOKAHEAD;
+    if (LOOKAHEAD) {
+        if (wave == 0) diag_factor(0);
+        __syncthreads();
+    }
     for (int kb = 0; kb < nb; kb++) {
         const int base = kb * NB;
         SOLVE_STAMP(8 + 4 * kb);
-
-        // ---- diagonal block: lane i (< 16) owns row i --------------------------------------------------------------
-        if (threadIdx.x < 64) {
-            double a[NB];
-            const int row = base + (lane & 15);
+        if (!LOOKAHEAD) {
+            if (wave == 0) diag_factor(base);
+            __syncthreads();
+        }
+        if (!s_ok) break;
+        // ---- panel: x L11' = a for every row below (and the right-hand side's row) ------------------------------------------------
+        // Every row needs all 120 off-diagonal entries and the 16 pivots of L11: the same values for every thread.  Lane j of each wave
+        // holds row j of the block in registers and the entries are BROADCAST from there (v_readlane, a scalar operand of the FMA) instead
+        // of 136 uniform-address LDS reads per thread (stamps: 2.2 us per panel, LDS-latency bound).
+        const int m = np - base - NB;  // rows below the block
+        {
+            double l[NB];
+            const double *lrow = S + (size_t) (base + (lane & 15)) * ld + base;
 #pragma unroll
-            for (int k = 0; k < NB; k++) a[k] = S[(size_t) row * ld + base + k];
-            int ok = 1;
+            for (int k = 0; k < NB; k++) {
+                l[k] = lrow[k];   // (k > lane & 15: strict upper triangle, garbage, never broadcast)
+                // pinned HERE, in every lane: the loop below runs with few lanes (one, for the right-hand side's row of the last
+                // blocks) and reads lanes 0..15 whatever their state; a load sunk into the loop would never execute for them
+                asm volatile("" : "+v"(l[k]));
+            }
+            for (int r = threadIdx.x; r <= m; r += SOLVE_NT) {   // r == m: the right-hand side (y = S + np * ld)
+                double *rowp = S + (size_t) (base + NB + r) * ld + base;
+                double x[NB];
 #pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const double d = lane_bcast(a[j], j);
-                if (!(d > 0)) ok = 0;
-                // the pivot's reciprocal square root is the head of every column's dependent chain (and 1 / L_jj of both triangular
-                // solves): refined hardware estimate instead of the IEEE-rounded rsqrt / divide (~10 dependent instructions instead of
-                // ~30 each, x ~330 pivots per call).  The DIAGONAL of the factor stores 1 / L_jj: the solves multiply.
-                double piv;
-                const double inv = alva_fast_rsqrt(d > 0 ? d : 1.0, piv);
-                a[j] = (lane & 15) == j ? inv : a[j] * inv;  // rows above j hold garbage in column j: never read
-                if (lane == j) s_inv[j] = inv;
+                for (int j = 0; j < NB; j++) x[j] = rowp[j];
 #pragma unroll
-                for (int k = j + 1; k < NB; k++) {
-                    const double lkj = lane_bcast(a[j], k);
-                    a[k] -= a[j] * lkj;  // used for rows >= k only
+                for (int j = 0; j < NB; j++) {
+                    double v = x[j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) v -= x[k] * lane_bcast(l[k], j);   // L11[j][k]
+                    x[j] = v * lane_bcast(l[j], j);                                 // the diagonal holds 1 / L_jj
                 }
-            }
-            if (lane < NB) {
 #pragma unroll
-                for (int k = 0; k < NB; k++)
-                    if (k <= lane) S[(size_t) row * ld + base + k] = a[k];
+                for (int j = 0; j < NB; j++) rowp[j] = x[j];
             }
-            if (lane == 0 && !ok) s_ok = 0;
         }
         __syncthreads();
         SOLVE_STAMP(9 + 4 * kb);
-        if (!s_ok) break;
-        // ---- panel: x L11' = a for every row below --------------------------------------------------------------------
-        const int m = np - base - NB;  // rows below the block
-        for (int r = threadIdx.x; r < m; r += SOLVE_NT) {
-            double *rowp = S + (size_t) (base + NB + r) * ld + base;
-            double x[NB];
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                double v = rowp[j];
-                const double *lj = S + (size_t) (base + j) * ld + base;
-#pragma unroll
-                for (int k = 0; k < j; k++) v -= x[k] * lj[k];
-                x[j] = v * s_inv[j];
-            }
-#pragma unroll
-            for (int j = 0; j < NB; j++) rowp[j] = x[j];
-        }
-        __syncthreads();
-        SOLVE_STAMP(10 + 4 * kb);
-        // ---- trailing update A22 -= L21 L21': a rank-16 update, i.e. one 16 x 16 x 16 product per 16 x 16 tile of the lower triangle
-        //      = four v_mfma_f64_16x16x4_f64 per tile, one wavefront per tile (operand a: L[rowa + (lane & 15)][4c + (lane >> 4)],
-        //      operand b the same for rowb; result row (lane >> 4) + 4r, column lane & 15).  Diagonal tiles are updated in full: the
-        //      strict upper triangle is never read.
+        // ---- trailing update + the next diagonal block -------------------------------------------------------------------------------
         const int mt = m / NB, ntile = mt * (mt + 1) / 2;
-        for (int t = threadIdx.x >> 6; t < ntile; t += SOLVE_NT / 64) {
-            int ta, tb;
-            if (t < TILE_LUT) {
-                ta = s_tile[t] >> 8;
-                tb = s_tile[t] & 255;
-            } else {
-                ta = (int) ((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-                while (ta * (ta + 1) / 2 > t) ta--;
-                while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
-                tb = t - ta * (ta + 1) / 2;
+        if (!LOOKAHEAD) {
+            for (int t = wave; t < ntile; t += SOLVE_NT / 64) trailing_tile(base, t);
+            for (int c = threadIdx.x; c < m; c += SOLVE_NT) {
+                const double *lr = S + (size_t) (base + NB + c) * ld + base;
+                double v = y[base + NB + c];
+#pragma unroll
+                for (int k = 0; k < NB; k++) v -= lr[k] * y[base + k];
+                y[base + NB + c] = v;
             }
-            const double *La = S + (size_t) (base + NB + NB * ta + (lane & 15)) * ld + base + (lane >> 4);
-            const double *Lb = S + (size_t) (base + NB + NB * tb + (lane & 15)) * ld + base + (lane >> 4);
-            double4_t acc = {0, 0, 0, 0};
+        } else if (wave == 0) {
+            if (ntile > 0) {
+                trailing_tile(base, 0);            // tile (0, 0): the next diagonal block
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // other lanes' stores of the tile, before this wave reads it back
+                __builtin_amdgcn_wave_barrier();
+                diag_factor(base + NB);
+            }
+        } else {
+            for (int t = wave; t < ntile; t += SOLVE_NT / 64 - 1) trailing_tile(base, t);
+            // the right-hand side's part of the update: y[c] -= L21[c][:] . z
+            for (int c = threadIdx.x - 64; c < m; c += SOLVE_NT - 64) {
+                const double *lr = S + (size_t) (base + NB + c) * ld + base;
+                double v = y[base + NB + c];
 #pragma unroll
-            for (int c = 0; c < NB / 4; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * c], Lb[4 * c], acc, 0, 0, 0);
-            double *C = S + (size_t) (base + NB + NB * ta + (lane >> 4)) * ld + base + NB + NB * tb + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; r++) C[(size_t) (4 * r) * ld] -= acc[r];
+                for (int k = 0; k < NB; k++) v -= lr[k] * y[base + k];
+                y[base + NB + c] = v;
+            }
         }
         __syncthreads();
     }
     SOLVE_STAMP(2);
     if (s_ok) {
-        // ---- L z = rhs, blocked -----------------------------------------------------------------------------------------
-        for (int kb = 0; kb < nb; kb++) {
-            const int base = kb * NB;
-            if (threadIdx.x < 64) {
-                const int i = lane & 15;
-                double l[NB];
-#pragma unroll
-                for (int k = 0; k < NB; k++) l[k] = S[(size_t) (base + i) * ld + base + k];
-                double yi = y[base + i];
-#pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    const double zj = lane_bcast(yi, j) * lane_bcast(l[j], j);   // (the diagonal holds 1 / L_jj)
-                    if (i == j) yi = zj;
-                    else if (i > j) yi -= l[j] * zj;
-                }
-                if (lane < NB) {
-                    y[base + i] = yi;
-                    s_z[i] = yi;
-                }
-            }
-            __syncthreads();
-            for (int r = base + NB + threadIdx.x; r < np; r += SOLVE_NT) {
-                const double *lr = S + (size_t) r * ld + base;
-                double v = y[r];
-#pragma unroll
-                for (int k = 0; k < NB; k++) v -= lr[k] * s_z[k];
-                y[r] = v;
-            }
-            __syncthreads();
-        }
         SOLVE_STAMP(3);
         // ---- L' y = z, blocked, last block first ------------------------------------------------------------------------------
         for (int kb = nb - 1; kb >= 0; kb--) {
