@@ -8,7 +8,9 @@ from pathlib import Path
 # torch would bind it to /opt/rocm's copy and leave two HIP runtimes in one process.
 import torch  # noqa: F401  (plumbing: device memory + streams)
 
-_LIB_PATH = Path(__file__).resolve().parent / "libalvaar_hip.so"
+import os
+# ALVA_LIB: another build of the same library (A/B measurements on one GPU box); the default is the in-tree build
+_LIB_PATH = Path(os.environ["ALVA_LIB"]) if os.environ.get("ALVA_LIB") else Path(__file__).resolve().parent / "libalvaar_hip.so"
 
 
 class AlvaError(RuntimeError):

@@ -392,6 +392,18 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
+    // compute_parallax's pairing for the keyframe check, put together WHILE the GPU solves the pose (prepare_parallax): slot in the
+    // frame's table, the frame keypoint's bearing and the reference keyframe's undistorted pixel of the same id, contiguous
+    struct ParPair {
+        int slot, id;
+        float kf_unpx[2];
+        double bv[3];
+    };
+    std::vector<ParPair> par_pairs_;
+    int par_frame_ = -1, par_kfid_ = -1;   // the frame / keyframe the pairs were collected for
+    void prepare_parallax();
+    float parallax_of_pairs(const FrameRec &kf);
+    float median_of_distinct(std::vector<uint32_t> &all);
     std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_, kf_ids_scratch_, local_scratch_, rm_ids_;
     // flat "seen" marks over map point ids (ids are dense, handed out consecutively): inserting a key that is already in a hash set does
     // not change the set, so duplicate inserts are filtered with a byte look-up instead of a hash look-up

@@ -237,7 +237,7 @@ class AlvaAR:
     FINE_NAMES = ("match: local-map union", "match: flatten+stage", "match: merges", "flatten: kf table + cells", "flatten: local list",
                   "flatten: per map point", "BA build: keyframes + point set", "BA build: observations", "filter: keyframe removals",
                   "window: remove kf-30", "copy: frame", "copy: order mirror", "copy: observation mirror", "new keypoints + map points",
-                  "covis: counts", "covis: local ids", "covis: into local map", "", "", "",
+                  "covis: counts", "covis: local ids", "covis: into local map", "parallax pairs (all frames)", "parallax (all frames)", "parallax sort (all frames)",
                   "#flattened map points", "#flattened observations", "#local candidates", "#BA points", "#BA residual blocks", "#BA keyframes",
                   "#new keypoints", "#local ids", "#covisible keyframes", "", "", "")
 
