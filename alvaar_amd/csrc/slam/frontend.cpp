@@ -123,9 +123,7 @@ bool Slam::process(double timestamp) {  // visual_frontend.cpp:37-101
     }
     {
         const auto t_pp0 = std::chrono::steady_clock::now();
-        static const bool prep = getenv("ALVA_NO_PARPAIRS") == nullptr;
-        if (prep) prepare_parallax();
-        else par_frame_ = -1;   // host work that only needs the tracker's results, placed under the pose solve the GPU is running
+        prepare_parallax();   // host work that only needs the tracker's results, placed under the pose solve the GPU is running
         t_fine[17] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pp0).count();
     }
     const bool ok = compute_pose();
