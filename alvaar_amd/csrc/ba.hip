@@ -662,7 +662,7 @@ __device__ __forceinline__ void solve_body(const BaDev &B, double radius, const 
     // tile the next diagonal block lives in and factors it (stamps before: 2.2 us per diagonal block with three waves waiting).
     const int wave = threadIdx.x >> 6;
     constexpr bool LOOKAHEAD = ALVA_SOLVE_LOOKAHEAD;
-    if (LOOKAHEAD) {
+    if (LOOKAHEAD && nb > 0) {   // (nb == 0: every camera constant, nothing to factor)
         if (wave == 0) diag_factor(0);
         __syncthreads();
     }

@@ -461,10 +461,12 @@ __global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D
         const unsigned long long now = before + add;
         if ((int) (now >> 48) == D.n) {
             const int n_pose = (int) ((now >> 32) & 0xffff), nA = (int) ((now >> 16) & 0xffff), good = (int) (now & 0xffff);
-            D.o_hdr[10] = n_pose; D.o_hdr[11] = nA; D.o_hdr[12] = good;
-            D.o_hdr[13] = nA > 0 && (double) good < 0.33 * (double) nA ? 1 : 0;
-            __threadfence_system();
-            __hip_atomic_store(D.o_hdr + 9, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // everything the host needs now -- the launch's sequence number, the size of the pose problem, p3pReq_ -- in ONE 8-byte
+            // system-scope store: a single word is consistent by itself, so no system-scope fence (an L2 write-back, ~2.5 us at the very
+            // end of the longest kernel of the frame) stands in front of it.  [seq : 32 | p3pReq_ : 1 | n_pose : 31] at o_hdr[10..11]
+            const int req = nA > 0 && (double) good < 0.33 * (double) nA ? 1 : 0;
+            const unsigned long long word = ((unsigned long long) (unsigned) D.seq << 32) | ((unsigned long long) req << 31) | (unsigned) n_pose;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(D.o_hdr + 10), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -198,6 +198,9 @@ __device__ int p3p_kneip(const V3 f[3], const V3 p[3], int which, double sol[12]
 //      only ever reads distances[mid-1] and distances[mid]): 8 passes of a 256-bin LDS histogram
 //   3. the workgroup that finishes LAST (device-scope counter) picks the best of the first max_iters valid hypotheses
 //      and classifies the inliers of the winner (Lmeds.hpp:150-190)
+// (Tried and dropped: starting the first digit at the highest bit in which the keys differ -- min / max reduced across the workgroup first;
+// the squared distances of a model share sign and upper exponent bits, so from bit 63 the first pass decides little.  The two extra
+// barriers cost more (score phase +1.2 us) than the shorter select saved (-0.3 us): the select is barrier-bound, not atomic-bound.)
 // k-th smallest of n 64-bit keys in LDS, NT threads (256 bins).  Most-significant-digit radix select, 8 bits per pass, with two histogram
 // buffers (the next pass's buffer is cleared while this pass counts: two barriers per pass instead of four) and an early exit: as
 // soon as the selected bin holds ONE key, that key is the answer and one scan fetches it (squared distances of a model differ
@@ -273,6 +276,7 @@ struct P3pArgs {
     SelectOut *out;
     uint8_t *inlier;
     unsigned long long *dbg;   // phase stamps (alva_kstamp_buffer) or null
+    unsigned long long *masks; // one launch (MODE 0): H x ceil(n / 64) words, hypothesis h's inlier mask (bit i = score(i) <= threshold)
 };
 // The single-problem launch carries its samples IN the kernel arguments when they fit (the hypothesis then starts with one scalar load from
 // the argument segment instead of a pointer chase into pinned host memory over the bus)
@@ -288,6 +292,12 @@ struct P3pInlineSamples {
 // an explicit s_waitcnt vmcnt(0) (the compiler may not drop inline asm).
 __device__ __forceinline__ void agent_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long agent_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double agent_load(const double *p) {
     return __longlong_as_double((long long) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -361,6 +371,26 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h, const i
     // ---- 2. LMedS penalty ----------------------------------------------------------------------------------------
     double pen = INFINITY;
     if (MODE != 2 && s_valid) {
+        if (MODE == 0) {
+            // ... and, while the score is at hand, this hypothesis' inlier mask (Lmeds.hpp:180-183: raw, unsquared distance <= threshold),
+            // one ballot per 64 points: should this hypothesis win, the selecting workgroup copies the mask instead of scoring all
+            // points once more (stamps: 2.9 us of the kernel's serial tail)
+            const int words = (n + 63) >> 6;
+            for (int base = wave * 64; base < n; base += NT) {   // wave-uniform bounds: the mask is a ballot
+                const int i = base + lane;
+                bool in = false;
+                if (i < n) {
+                    double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
+                    in = d <= A.threshold;
+                    if (d < 0) d = 0;
+                    double v = d * d;
+                    if (v != v) v = INFINITY;  // NaN scores order last (std::sort's behaviour with NaN is unspecified)
+                    s_keys[i] = (unsigned long long) __double_as_longlong(v);
+                }
+                const unsigned long long mk = __ballot(in);
+                if (lane == 0) agent_store(A.masks + (size_t) h * words + (base >> 6), mk);
+            }
+        } else
         for (int i = threadIdx.x; i < n; i += NT) {
             double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
             if (d < 0) d = 0;
@@ -415,6 +445,8 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h, const i
         return;
     }
     if (MODE == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's mask words have landed ...
+        __syncthreads();                                    // ... before thread 0 arrives
         if (threadIdx.x == 0) {
             agent_store(A.penalty + h, s_valid ? pen : -1.0);   // one word: penalties are >= 0 (or +inf), a failed model publishes -1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's model stores (lanes 0..3) and the word above have landed
@@ -501,6 +533,16 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h, const i
     }
     __syncthreads();
     int cnt = 0;
+    if (MODE == 0) {   // the winner's mask, as its own workgroup classified the points
+        const int words = (n + 63) >> 6;
+        for (int w = threadIdx.x; w < words; w += NT) {
+            const unsigned long long mk = agent_load(A.masks + (size_t) bestI * words + w);
+            s_keys[w] = mk;
+            cnt += __popcll(mk);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += NT) A.inlier[i] = (uint8_t) ((s_keys[i >> 6] >> (i & 63)) & 1ull);
+    } else
     for (int i = threadIdx.x; i < n; i += NT) {
         const double d = p3p_score(s_m, ld3(wpt + 3 * (size_t) i), ld3(bv + 3 * (size_t) i));
         const bool in = d <= A.threshold;  // Lmeds.hpp:180-183 (raw, unsquared distance)
@@ -596,7 +638,8 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     // scratch layout: models | valid | penalty
     size_t off_valid = (size_t) H * 12 * sizeof(double);
     size_t off_pen = (off_valid + (size_t) H * sizeof(int) + 63) / 64 * 64;
-    size_t total = off_pen + (size_t) H * sizeof(double);
+    const size_t off_masks = (off_pen + (size_t) H * sizeof(double) + 63) / 64 * 64;
+    size_t total = off_masks + (size_t) H * (((size_t) n + 63) / 64) * 8;
     uint8_t *base = nullptr;
     int rc = alva_ctx_scratch(ctx, 2, total, (void **) &base);
     if (rc) return rc;
@@ -611,6 +654,7 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     A.models = (double *) base;
     A.valid = (int *) (base + off_valid);
     A.penalty = (double *) (base + off_pen);
+    A.masks = (unsigned long long *) (base + off_masks);
     A.counter = ctx->d_counters;  // slot 0: zero between launches (the last workgroup resets it)
     A.out = out;
     A.inlier = inlier;

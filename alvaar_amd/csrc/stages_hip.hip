@@ -416,6 +416,8 @@ struct HipStages::Impl {
         ALVA_HIP(alva_stream_sync(st));
         track_pin().o_hdr[8] = 0;
         track_pin().o_hdr[9] = 0;
+        track_pin().o_hdr[10] = 0;
+        track_pin().o_hdr[11] = 0;
         return ALVA_OK;
     }
     bool pose_pending = false;
@@ -887,7 +889,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.cam = AlvaCam{k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2};
         D.invK = m->d_invK;
         // state.hpp:50-56 constants; the prior pass works on one pyramid level (visual_frontend.cpp:166)
-        D.seq = ++m->trk_seq;   // the tracker launch publishes its counts under this number too (o_hdr[9])
+        D.seq = ++m->trk_seq;   // the tracker launch publishes its counts under this number too (the word at o_hdr[10])
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
         if (rc) return rc;
         hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
@@ -964,18 +966,23 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         }
         return ALVA_OK;
     };
-    // The tracker launch's last workgroup has published the step's counts one kernel EARLIER (o_hdr[9..13], track_slots.hpp): in the
+    // The tracker launch's last workgroup has published the step's counts one kernel EARLIER (the 64-bit word at o_hdr[10], track_slots.hpp): in the
     // normal case (no p3pReq_) the pose solve is enqueued NOW -- host-side sample draw + two launches, queued behind the compaction
     // kernel in stream order -- instead of after the compaction's completion word: the GPU goes from the compaction straight into P3P.
     bool pose_early = false;
+    int early_n_pose = -1;
     const int n_pose_cap = 19000;   // P3P-LMedS keeps its median in LDS: at most 19000 correspondences (the first ones, in slot order)
     if (slots_path && poll_seq && job.want_pose) {
-        const volatile int *early = o_hdr + 9;
+        const volatile unsigned long long *early = reinterpret_cast<const volatile unsigned long long *>(o_hdr + 10);
         unsigned spins = 0;
-        while (*early != poll_seq && ++spins < (1u << 26)) alva_poll_relax(spins);
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        if (*early == poll_seq && !o_hdr[13] && o_hdr[10] >= 4) {
-            m->pose_n = o_hdr[10] > n_pose_cap ? n_pose_cap : o_hdr[10];
+        unsigned long long word = *early;
+        while ((int) (word >> 32) != poll_seq && ++spins < (1u << 26)) {
+            alva_poll_relax(spins);
+            word = *early;
+        }
+        early_n_pose = (int) (word & 0x7fffffffu);
+        if ((int) (word >> 32) == poll_seq && !((word >> 31) & 1) && early_n_pose >= 4) {
+            m->pose_n = early_n_pose > n_pose_cap ? n_pose_cap : early_n_pose;
             rc = alva_compute_pose_enqueue(m->ctx, Pbv, Puv, Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
                                            (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
             if (rc) return rc;
@@ -1003,8 +1010,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     out.p3p_req = p3p_req;
     out.n_pose = o_hdr[5];
     if (pose_early) {
-        if (p3p_req || out.n_pose != o_hdr[10]) {   // cannot happen: both kernels count the same flags
-            alva_set_error("tracking step: the tracker's early counts (%d) disagree with the compaction (%d)", o_hdr[10], out.n_pose);
+        if (p3p_req || out.n_pose != early_n_pose) {   // cannot happen: both kernels count the same flags
+            alva_set_error("tracking step: the tracker's early counts (%d) disagree with the compaction (%d)", early_n_pose, out.n_pose);
             return ALVA_ERR_STATE;
         }
         m->pose_pending = true;

@@ -41,9 +41,9 @@ struct TrackSlots {
     double *o_bv;
     int *o_hdr;
     int seq;                   // written to o_hdr[8] (system scope) after everything else: the host may poll it instead of waiting on the stream
-                               // o_hdr[10..13] + word o_hdr[9]: the tracker's counts, published by the LAST workgroup of the tracker launch
-                               // itself -- the host learns the size of the pose problem one kernel earlier and enqueues the pose solve
-                               // (sample draw + two launches) while the compaction kernel runs
+                               // o_hdr[10..11] as ONE 64-bit word [seq : 32 | p3pReq_ : 1 | n_pose : 31]: the tracker's counts, published by
+                               // the LAST workgroup of the tracker launch itself -- the host learns the size of the pose problem one kernel
+                               // earlier and enqueues the pose solve (sample draw + two launches) while the compaction kernel runs
     double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
 };
 
