@@ -208,15 +208,23 @@ void Slam::klt_from_motion_prior() {
         jpx[2 * (size_t) i + 1] = k.px[1];
         j3d[(size_t) i] = k.is3d;
         job_is3d_[(size_t) i] = k.is3d;
-        double *w = jw + 3 * (size_t) i;
-        if (k.is3d) {
-            const MapPt *mp = mp_raw(k.id);
+        i++;
+    }
+    // the 3-D keypoints' world points: one map point per keypoint, each behind a pointer table -- a second pass so that the objects of
+    // the next iterations can be requested ahead (this loop runs with the GPU idle, at the head of the frame's critical path)
+    for (int s = 0; s < n; s++) {
+        if (s + 16 < n && job_is3d_[(size_t) s + 16]) {
+            const MapPt *f = mp_raw(job_ids_[(size_t) s + 16]);
+            if (f) __builtin_prefetch(f->X);
+        }
+        double *w = jw + 3 * (size_t) s;
+        if (job_is3d_[(size_t) s]) {
+            const MapPt *mp = mp_raw(job_ids_[(size_t) s]);
             if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() throws in the reference (:131) if the map lost it
             std::memcpy(w, mp->X, 24);
         } else {
             w[0] = w[1] = w[2] = 0.;
         }
-        i++;
     }
     TrackJob job;
     job.n = n;

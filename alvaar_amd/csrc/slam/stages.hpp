@@ -76,7 +76,7 @@ struct Stages {
     // into device memory, bench.py's timed loop); unsupported (-4) where there is no device
     virtual int new_frame_device(const uint8_t *d_rgba) { (void) d_rgba; return -4; }
     // Optional: the frame the NEXT new_frame_device call will pass (device memory, valid until then).  An implementation may build that
-    // frame's gray image / pyramid ahead, beside the current frame's pose solve; results never depend on the hint (a wrong one is dropped).
+    // frame's gray image / pyramid ahead, behind the current frame's pose solve; results never depend on the hint (a wrong one is dropped).
     virtual void hint_next_frame_device(const uint8_t *d_rgba) { (void) d_rgba; }
     // end of System::processCameraPose: the caller may reuse its frame buffer once this returns
     virtual int frame_done() { return 0; }

@@ -354,11 +354,9 @@ struct HipStages::Impl {
     alva_pyramid *pyr[3] = {nullptr, nullptr, nullptr};
     int cur = 0, prev = 1, nxt = 2;
     uint8_t *d_rgba = nullptr, *d_gray = nullptr, *d_gray_next = nullptr, *d_eq = nullptr, *h_rgba = nullptr;
-    // look-ahead: the hinted source, whether its build has been enqueued (on ahead_st, behind ev_chain) / is complete up to ev_ahead
+    // look-ahead: the hinted source, whether its build has been enqueued (same stream, behind the pose kernels)
     const uint8_t *ahead_src = nullptr;
-    bool ahead_enqueued = false, ahead_dirty = false;
-    hipStream_t ahead_st = nullptr;
-    hipEvent_t ev_chain = nullptr, ev_ahead = nullptr;
+    bool ahead_enqueued = false;
     double *d_invK = nullptr;
     const uint8_t *registered = nullptr, *registered_dev = nullptr;  // caller buffer locked + mapped by register_frame_buffer
     size_t registered_bytes = 0;
@@ -481,12 +479,6 @@ HipStages::~HipStages() {
     (void) hipSetDevice(m->device);
     if (m->ctx) (void) alva_ctx_sync(m->ctx);
     for (auto &p: m->pyr) alva_pyramid_destroy(p);
-    if (m->ahead_st) {
-        (void) hipStreamSynchronize(m->ahead_st);
-        (void) hipStreamDestroy(m->ahead_st);
-    }
-    if (m->ev_chain) (void) hipEventDestroy(m->ev_chain);
-    if (m->ev_ahead) (void) hipEventDestroy(m->ev_ahead);
     void *bufs[] = {m->d_rgba, m->d_gray, m->d_gray_next, m->d_eq, m->d_invK};
     for (void *b: bufs)
         if (b) (void) hipFree(b);
@@ -517,9 +509,6 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     ALVA_HIP(hipMalloc((void **) &m->d_rgba, P * 4));
     ALVA_HIP(hipMalloc((void **) &m->d_gray, P));
     ALVA_HIP(hipMalloc((void **) &m->d_gray_next, P));
-    ALVA_HIP(hipStreamCreateWithFlags(&m->ahead_st, hipStreamNonBlocking));
-    ALVA_HIP(hipEventCreateWithFlags(&m->ev_chain, hipEventDisableTiming));
-    ALVA_HIP(hipEventCreateWithFlags(&m->ev_ahead, hipEventDisableTiming));
     if (clahe) ALVA_HIP(hipMalloc((void **) &m->d_eq, P));
     ALVA_HIP(hipMalloc((void **) &m->d_invK, 9 * sizeof(double)));
     ALVA_HIP(hipMemcpy(m->d_invK, invK, 9 * sizeof(double), hipMemcpyHostToDevice));
@@ -701,12 +690,6 @@ int HipStages::warm_up(int cell) {
 int HipStages::build_from(const uint8_t *d_src) {
     Impl &M = *m;
     const bool hit = M.ahead_enqueued && M.ahead_src == d_src;
-    if (M.ahead_dirty) {
-        // a look-ahead build wrote (or is writing) pyr[nxt] / d_gray_next on its own stream: whatever this frame does with those
-        // buffers -- read them (hit) or rebuild them (miss) -- comes behind it
-        ALVA_HIP(hipStreamWaitEvent(M.st, M.ev_ahead, 0));
-        M.ahead_dirty = false;
-    }
     M.ahead_enqueued = false;
     M.ahead_src = nullptr;
     // rotate: previous <- current <- next; the old previous becomes the free slot
@@ -727,10 +710,12 @@ int HipStages::build_from(const uint8_t *d_src) {
 }
 
 // Look-ahead (no reference counterpart; the reference receives one frame per call): the caller names the frame of its NEXT call, and its
-// gray image + LK pyramid are built on a second stream beside the current frame's pose solve, into the rotation's free slot.  The build
-// is enqueued behind the tracker (ev_chain: the tracker fills the chip, the pose kernels leave most of it idle) or, in a frame that
-// tracks nothing, at the end of the call.  The next new_frame_device takes the slot over when its pointer is the hinted one, and rebuilds
-// as usual when it is not: results never depend on hints.
+// gray image + LK pyramid are enqueued on the SAME stream right behind this frame's pose kernels, into the rotation's free slot: they run
+// while the host does its pose bookkeeping, the keyframe decision and the next frame's slot table -- a window in which the GPU is otherwise
+// idle -- instead of at the start of the next call.  (First version: a second stream beside the pose solve, ordered by two events.  The
+// cross-queue waits cost what the overlap gained: 2 721 vs 2 742 frames/s sustained, `profiles/r3j_bench_n1.json`.)  The next
+// new_frame_device takes the slot over when its pointer is the hinted one, and rebuilds as usual when it is not: results never depend
+// on hints.  A frame that enqueues no pose solve builds ahead at the end of the call.
 void HipStages::hint_next_frame_device(const uint8_t *d_rgba) {
     if (m->clahe) return;   // (the CLAHE chain shares d_eq / context scratch with the current frame: no look-ahead there)
     m->ahead_src = d_rgba;
@@ -740,15 +725,9 @@ void HipStages::hint_next_frame_device(const uint8_t *d_rgba) {
 int HipStages::build_ahead() {
     Impl &M = *m;
     if (!M.ahead_src || M.ahead_enqueued) return ALVA_OK;
-    ALVA_HIP(hipEventRecord(M.ev_chain, M.st));
-    ALVA_HIP(hipStreamWaitEvent(M.ahead_st, M.ev_chain, 0));
-    M.ctx->stream = M.ahead_st;   // (the image kernels launch on the context stream)
     const int rc = alva_pyramid_build_from_rgba(M.ctx, M.pyr[M.nxt], M.ahead_src, (size_t) M.cam.width * 4, M.d_gray_next, (size_t) M.cam.width);
-    M.ctx->stream = M.st;
     if (rc) return rc;
-    ALVA_HIP(hipEventRecord(M.ev_ahead, M.ahead_st));
     M.ahead_enqueued = true;
-    M.ahead_dirty = true;
     return ALVA_OK;
 }
 
@@ -894,8 +873,6 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         if (rc) return rc;
         hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
         ALVA_LAUNCH_CHECK();
-        rc = build_ahead();   // a hinted next frame: its images go out behind the tracker, beside the pose solve
-        if (rc) return rc;
         poll_seq = m->poll ? D.seq : 0;
         slots_D = D;
         slots_path = true;
@@ -987,6 +964,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
                                            (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
             if (rc) return rc;
             pose_early = true;
+            rc = build_ahead();   // a hinted next frame: its images are queued behind the pose kernels
+            if (rc) return rc;
         }
     }
     rc = wait_step(poll_seq);

@@ -961,7 +961,7 @@ def main():
     sys_state = ar.state()
     sys_counters = ar.counters()
     log(f"sustained: {long_steps / dt_long:.0f} frames/s per rank")
-    # the same loop with look-ahead hints (the caller names the next frame: its images are built beside this frame's pose solve)
+    # the same loop with look-ahead hints (the caller names the next frame: its images are built behind this frame's pose solve)
     kf_before = int(ar.state()[11])
     dt_ahead = timed(sysjob.step_ahead, 5, long_steps)
     kf_ahead = int(ar.state()[11]) - kf_before
@@ -1094,8 +1094,8 @@ def main():
             "system_lookahead": {"frames_per_s": world * long_steps / dt_ahead, "ms_per_step": dt_ahead / long_steps * 1e3, "steps": long_steps,
                                  "keyframes": kf_ahead,
                                  "note": "the sustained loop with alva_system_hint_next_frame_device before every call (the caller names the frame "
-                                         "of its next call; gray + LK pyramid of that frame are built on a second stream beside this frame's "
-                                         "pose solve; results identical, tests/test_gpu_system.py).  NOT `value`: the reference's "
+                                         "of its next call; gray + LK pyramid of that frame are enqueued behind this frame's pose kernels and run "
+                                         "while the host does its bookkeeping; results identical, tests/test_gpu_system.py).  NOT `value`: the reference's "
                                          "findCameraPose is handed one frame per call"},
             "system_surface": {"frames_per_s": world * long_steps / dt_host, "ms_per_step": dt_host / long_steps * 1e3, "steps": long_steps,
                                "caller_copy_us": round(copy_us, 1),

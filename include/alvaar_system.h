@@ -80,7 +80,8 @@ int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, dou
 int alva_system_find_camera_pose_device(alva_system *sys, const uint8_t *d_rgba, double timestamp_ms, float *h_pose);
 /* Look-ahead for frames in device memory (no reference counterpart: the reference is handed one frame per call).  Called BEFORE
  * alva_system_find_camera_pose_device(frame k), it names frame k+1 (device memory that stays valid and unchanged until that call): the
- * gray image and LK pyramid of frame k+1 are then built on a second stream beside frame k's pose solve, and call k+1 finds them
+ * gray image and LK pyramid of frame k+1 are then enqueued right behind frame k's pose kernels (they run while the host does call k's
+ * bookkeeping and builds call k+1's slot table, a window in which the GPU is otherwise idle), and call k+1 finds them
  * ready when it passes the same pointer (any other pointer: the look-ahead is dropped and the frame is built as usual).  Results are
  * identical with and without hints.  One hint per call; NULL cancels. */
 int alva_system_hint_next_frame_device(alva_system *sys, const uint8_t *d_rgba_next);
