@@ -1,3 +1,4 @@
+"""Concurrency on one GPU: the empty-launch rate and the tracking step of S sessions on S host threads at once (what caps system_streams / system_group)"""
 import sys, time, threading
 sys.path.insert(0, ".")
 import bench

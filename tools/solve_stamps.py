@@ -1,4 +1,4 @@
-"""local-BA bench line + per-kernel times on the 20 KF x 3000 pts problem"""
+"""local-BA bench line, per-kernel times and (ALVA_KSTAMPS=1) the in-kernel phase stamps of k_solve on the 20 KF x 3000 pts problem"""
 import sys, json
 sys.path.insert(0, ".")
 import bench
