@@ -298,11 +298,13 @@ __global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) {
             const unsigned long long packed = reinterpret_cast<unsigned long long *>(D.cnt)[2];   // the tracker launch's counts (track_slots.hpp)
             const int nA = (int) ((packed >> 16) & 0xffff), good = (int) (packed & 0xffff);
             const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
-            D.o_hdr[0] = nA; D.o_hdr[1] = D.n - nA; D.o_hdr[2] = D.n - good; D.o_hdr[3] = good; D.o_hdr[4] = req ? 1 : 0; D.o_hdr[5] = n_pose;
             reinterpret_cast<unsigned long long *>(D.cnt)[2] = 0ull;
             D.cnt[8] = 0;
-            __threadfence_system();
-            __hip_atomic_store(D.o_hdr + 8, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the step's completion word carries what the host reads of the header -- [seq : 32 | p3pReq_ : 1 | n_pose : 31] at
+            // o_hdr[12..13], ONE 8-byte system-scope store: every slice's results are already behind its workgroup's fence + arrival,
+            // so no second system-scope fence (an L2 write-back, ~2.5 us of the tracking step) stands in front of it
+            const unsigned long long word = ((unsigned long long) (unsigned) D.seq << 32) | ((unsigned long long) (req ? 1 : 0) << 31) | (unsigned) n_pose;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(D.o_hdr + 12), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -416,6 +418,8 @@ struct HipStages::Impl {
         track_pin().o_hdr[9] = 0;
         track_pin().o_hdr[10] = 0;
         track_pin().o_hdr[11] = 0;
+        track_pin().o_hdr[12] = 0;
+        track_pin().o_hdr[13] = 0;
         return ALVA_OK;
     }
     bool pose_pending = false;
@@ -924,8 +928,27 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     o_code = D.o_code; o_px = D.o_px; o_unpx = D.o_unpx; o_bv = D.o_bv; o_hdr = D.o_hdr;
     Pbv = D.Pbv; Puv = D.Puv; Pwpt = D.Pwpt;
     }
+    int step_req = 0, step_n_pose = 0;   // the slot-wise step's header, out of its completion word
     auto wait_step = [&](int seq) -> int {
-        if (seq) {
+        if (seq && slots_path) {
+            // the compaction kernel publishes [seq | p3pReq_ | n_pose] as one word after all results; spinning on it in pinned memory
+            // returns a few microseconds before hipStreamSynchronize would
+            const volatile unsigned long long *flag = reinterpret_cast<const volatile unsigned long long *>(o_hdr + 12);
+            unsigned spins = 0;
+            unsigned long long word = *flag;
+            while ((int) (word >> 32) != seq) {
+                if (++spins > (1u << 26)) {   // ~ seconds: something is wrong with the stream; let the runtime report it
+                    ALVA_HIP(alva_stream_sync(m->st));
+                    word = *flag;
+                    break;
+                }
+                alva_poll_relax(spins);
+                word = *flag;
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            step_req = (int) ((word >> 31) & 1);
+            step_n_pose = (int) (word & 0x7fffffffu);
+        } else if (seq) {
             // the compaction kernel publishes its sequence number after all results (system-scope release); spinning on that word in
             // pinned memory returns a few microseconds before hipStreamSynchronize would
             const volatile int *flag = o_hdr + 8;
@@ -940,6 +963,11 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         } else {
             ALVA_HIP(alva_stream_sync(m->st));
+            if (slots_path) {
+                const unsigned long long word = *reinterpret_cast<const volatile unsigned long long *>(o_hdr + 12);
+                step_req = (int) ((word >> 31) & 1);
+                step_n_pose = (int) (word & 0x7fffffffu);
+            }
         }
         return ALVA_OK;
     };
@@ -970,7 +998,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     }
     rc = wait_step(poll_seq);
     if (rc) return rc;
-    int p3p_req = o_hdr[4];
+    int p3p_req = slots_path ? step_req : o_hdr[4];
     if (slots_path && p3p_req) {
         // fewer than 33 % of the one-level passes held (visual_frontend.cpp:193-203): the retries must start from the keypoints' own
         // positions instead -- redo them and compact again (rare: tracking is about to be lost)
@@ -987,7 +1015,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     out.unpx_v = o_unpx;
     out.bv_v = o_bv;
     out.p3p_req = p3p_req;
-    out.n_pose = o_hdr[5];
+    out.n_pose = slots_path ? step_n_pose : o_hdr[5];
     if (pose_early) {
         if (p3p_req || out.n_pose != early_n_pose) {   // cannot happen: both kernels count the same flags
             alva_set_error("tracking step: the tracker's early counts (%d) disagree with the compaction (%d)", early_n_pose, out.n_pose);

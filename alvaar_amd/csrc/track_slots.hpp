@@ -40,7 +40,8 @@ struct TrackSlots {
     float *o_px, *o_unpx;
     double *o_bv;
     int *o_hdr;
-    int seq;                   // written to o_hdr[8] (system scope) after everything else: the host may poll it instead of waiting on the stream
+    int seq;                   // the compaction's completion word [seq : 32 | p3pReq_ : 1 | n_pose : 31] at o_hdr[12..13] (system scope) after
+                               // everything else: the host may poll it instead of waiting on the stream
                                // o_hdr[10..11] as ONE 64-bit word [seq : 32 | p3pReq_ : 1 | n_pose : 31]: the tracker's counts, published by
                                // the LAST workgroup of the tracker launch itself -- the host learns the size of the pose problem one kernel
                                // earlier and enqueues the pose solve (sample draw + two launches) while the compaction kernel runs
