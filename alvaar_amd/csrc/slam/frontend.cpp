@@ -206,8 +206,9 @@ void Slam::klt_from_motion_prior() {
         job_ids_[(size_t) i] = k.id;
         jpx[2 * (size_t) i] = k.px[0];
         jpx[2 * (size_t) i + 1] = k.px[1];
-        j3d[(size_t) i] = k.is3d;
-        job_is3d_[(size_t) i] = k.is3d;
+        const uint8_t is3d = order.tag(sl) != 0;   // the table's tag IS the 3-D flag (KpTable): the flag inside the 80-byte record sits on its second cache line
+        j3d[(size_t) i] = is3d;
+        job_is3d_[(size_t) i] = is3d;
         i++;
     }
     // the 3-D keypoints' world points: one map point per keypoint, each behind a pointer table -- a second pass so that the objects of
