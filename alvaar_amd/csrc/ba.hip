@@ -996,6 +996,7 @@ struct BaIn {
 struct BaHost {
     BaDev B{};
     std::vector<int> cidx, order;
+    bool grouped_ = false;   // the caller's observations arrived grouped by point: `order` is the identity
     int *d_obsKf = nullptr, *d_ptPtr = nullptr, *d_ancKf = nullptr, *d_cidx = nullptr, *d_pairPerm = nullptr, *d_pairPtr = nullptr, *d_kfOf = nullptr;
     double *d_obsUv = nullptr, *d_ancUv = nullptr, *d_xp = nullptr, *d_cp = nullptr, *d_xt = nullptr, *d_ct = nullptr;
     size_t in_bytes = 0, bytes = 0;
@@ -1082,40 +1083,44 @@ struct BaHost {
         layout(base);
         B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
         B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
-        // observations grouped by point, original order kept inside a point: a stable counting sort (O(n))
+        // observations grouped by point, original order kept inside a point: a stable counting sort (O(n)).  The map layer hands them
+        // over point by point already (then the sort is the identity): ONE pass then copies them, counts per point and per (observing
+        // keyframe, anchor keyframe) pair -- the host structure of an in-system solve is a fixed cost of every keyframe (it was ~80 us
+        // of six passes and three vector allocations for 14 k observations)
         order.resize((size_t) n_obs);
-        std::vector<int> pairKey((size_t) n_obs);
+        static thread_local std::vector<int> pairKey, cursor;
+        pairKey.resize((size_t) n_obs);
         for (size_t p2 = 0; p2 <= nPt; p2++) h_ptPtr[p2] = 0;
-        bool grouped = true;   // the map layer hands the observations over point by point already: then the sort is the identity
+        const size_t nPairs = (size_t) n_kf * n_kf;
+        for (size_t i = 0; i <= nPairs; i++) h_pairPtr[i] = 0;
+        bool grouped = true;
         for (int o = 1; o < n_obs && grouped; o++) grouped = in.h_obs_pt[o] >= in.h_obs_pt[o - 1];
+        grouped_ = grouped;
         if (grouped) {
             for (int o = 0; o < n_obs; o++) order[(size_t) o] = o;
         } else {
-            std::vector<int> cursor((size_t) n_pt + 1, 0);
+            cursor.assign((size_t) n_pt + 1, 0);
             for (int o = 0; o < n_obs; o++) cursor[(size_t) in.h_obs_pt[o] + 1]++;
             for (int p2 = 0; p2 < n_pt; p2++) cursor[(size_t) p2 + 1] += cursor[(size_t) p2];
             for (int o = 0; o < n_obs; o++) order[(size_t) cursor[(size_t) in.h_obs_pt[o]]++] = o;
         }
         for (int q = 0; q < n_obs; q++) {
-            const int o = order[(size_t) q];
-            h_obsKf[q] = in.h_obs_kf[o];
+            const int o = order[(size_t) q], pt = in.h_obs_pt[o], kf = in.h_obs_kf[o];
+            h_obsKf[q] = kf;
             h_obsUv[2 * (size_t) q] = in.h_obs_uv[2 * o];
             h_obsUv[2 * (size_t) q + 1] = in.h_obs_uv[2 * o + 1];
-            h_ptPtr[(size_t) in.h_obs_pt[o] + 1]++;
-            const int anc = in.inv_depth ? in.h_pt_anchor_kf[in.h_obs_pt[o]] : in.h_obs_kf[o];
+            h_ptPtr[(size_t) pt + 1]++;
+            const int anc = in.inv_depth ? in.h_pt_anchor_kf[pt] : kf;
             ALVA_ARG(anc >= 0 && anc < n_kf);
-            pairKey[(size_t) q] = in.h_obs_kf[o] * n_kf + anc;
+            const int key = kf * n_kf + anc;
+            pairKey[(size_t) q] = key;
+            h_pairPtr[(size_t) key + 1]++;
         }
         for (int p2 = 0; p2 < n_pt; p2++) h_ptPtr[(size_t) p2 + 1] += h_ptPtr[(size_t) p2];
         // the same observations grouped by (observing kf, anchor kf) pair, stable: counting sort again
-        const size_t nPairs = (size_t) n_kf * n_kf;
-        for (size_t i = 0; i <= nPairs; i++) h_pairPtr[i] = 0;
-        for (int q = 0; q < n_obs; q++) h_pairPtr[(size_t) pairKey[(size_t) q] + 1]++;
         for (size_t i = 0; i < nPairs; i++) h_pairPtr[i + 1] += h_pairPtr[i];
-        {
-            std::vector<int> cursor(h_pairPtr, h_pairPtr + nPairs);
-            for (int q = 0; q < n_obs; q++) h_pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
-        }
+        cursor.assign(h_pairPtr, h_pairPtr + nPairs);
+        for (int q = 0; q < n_obs; q++) h_pairPerm[(size_t) cursor[(size_t) pairKey[(size_t) q]]++] = q;
         if (in.inv_depth && n_pt > 0) {
             memcpy(h_ancKf, in.h_pt_anchor_kf, nPt * 4);
             memcpy(h_ancUv, in.h_pt_anchor_uv, nPt * 16);
@@ -1180,9 +1185,14 @@ struct BaHost {
         const uint8_t *deps = r_chi + ((uint8_t *) B.depth - (uint8_t *) B.chi2);
         for (int k = 0; k < in.n_kf; k++)
             if (cidx[(size_t) k] >= 0) memcpy(in.h_poses + 7 * k, r_poses + 7 * (size_t) k, 56);
-        for (int q = 0; q < in.n_obs; q++) {  // back to the caller's observation order
-            if (h_chi2) h_chi2[order[(size_t) q]] = chi2s[(size_t) q];
-            if (h_depth_pos) h_depth_pos[order[(size_t) q]] = deps[(size_t) q];
+        if (grouped_) {   // the caller's order IS the device order
+            if (h_chi2) memcpy(h_chi2, chi2s, (size_t) in.n_obs * 8);
+            if (h_depth_pos) memcpy(h_depth_pos, deps, (size_t) in.n_obs);
+        } else {
+            for (int q = 0; q < in.n_obs; q++) {  // back to the caller's observation order
+                if (h_chi2) h_chi2[order[(size_t) q]] = chi2s[(size_t) q];
+                if (h_depth_pos) h_depth_pos[order[(size_t) q]] = deps[(size_t) q];
+            }
         }
         if (h_info) {
             h_info[0] = nsummaries;
@@ -1225,7 +1235,9 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     if (rc) return rc;
     uint8_t *stage = pin + 256;
     hipStream_t st = ctx->stream;
+    const auto t_sized = std::chrono::steady_clock::now();
     ALVA_HIP(alva_stream_sync(st));  // nothing enqueued earlier may still be reading the staging area
+    const auto t_synced = std::chrono::steady_clock::now();
     rc = H.build(in, base, stage);
     if (rc) return rc;
     const auto t_built = std::chrono::steady_clock::now();
@@ -1373,8 +1385,9 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return (double) std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3;
         };
-        fprintf(stderr, "[alva_local_ba] host structure %.0f us | scratch + upload %.0f us | LM loop (%d summaries) %.0f us | download %.0f us\n",
-                us(t_begin, t_built), us(t_built, t_up), H.nsummaries, us(t_up, t_lm), us(t_lm, std::chrono::steady_clock::now()));
+        fprintf(stderr, "[alva_local_ba] host structure %.0f us (sizes + arenas %.0f, stream sync %.0f, build %.0f) | scratch + upload %.0f us | LM loop (%d summaries) %.0f us | download %.0f us\n",
+                us(t_begin, t_built), us(t_begin, t_sized), us(t_sized, t_synced), us(t_synced, t_built), us(t_built, t_up), H.nsummaries, us(t_up, t_lm),
+                us(t_lm, std::chrono::steady_clock::now()));
     }
     return ALVA_OK;
 }

@@ -501,6 +501,8 @@ __device__ __forceinline__ int solve(PnpShared &sh, const PnpArgs &A, int robust
 // p3p / inlier0 non-null = chained mode (VisualFrontend::computePose, visual_frontend.cpp:300-375): the initial pose is the
 // P3P-LMedS model and only its inliers are refined; the P3P acceptance tests of multi_view_geometry.cpp:82-91 run here.
 // `out`, `bad` and `p3p_outlier` may live in pinned host memory (written once, at the end).
+// (`chi2` / `depth`: per-point scratch of earlier versions; the verdicts now stay in registers -- see eval -- and the two arrays are unused,
+// kept in the signatures so that the callers' scratch layouts did not have to move)
 __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict__ active, double *__restrict__ chi2,
                                           uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
                                           const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
