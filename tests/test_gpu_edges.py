@@ -199,3 +199,27 @@ def test_run_many_helper(ctx):
         assert wall > 0 and accepted == 12 * streams
         for f in fes:
             f.close()
+
+
+def test_kernel_stamps_are_opt_in():
+    """alva_debug_kstamps: ALVA_ERR_STATE (with a message) in a process started without ALVA_KSTAMPS=1; with it (a child process: the
+    switch is read once) the pose kernels record their phases in order -- tools/pose_stamps.py prints the per-phase medians"""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    from alvaar_amd import capi
+    lib = capi.lib
+    lib.alva_debug_kstamps.argtypes = [C.c_void_p]
+    buf = np.zeros(4096, np.uint64)
+    if not os.environ.get("ALVA_KSTAMPS"):
+        assert lib.alva_debug_kstamps(buf.ctypes.data) != 0
+        assert b"ALVA_KSTAMPS" in lib.alva_last_error()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FRAMES="80", SAMPLE="10")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pose_stamps.py")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    span = [ln for ln in out.stdout.splitlines() if "kernel span" in ln]
+    assert span and 5.0 < float(span[0].split()[-1]) < 200.0, out.stdout[-2000:]
+    evals = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("evals ")]
+    assert evals and float(evals[0].split()[-1]) >= 2.0, out.stdout[-2000:]
