@@ -1200,16 +1200,18 @@ int HipStages::detect_begin(int cell, int n_occ, const float *occupied, int cap)
     std::vector<uint8_t *> d, h;
     int rc = m->carve(p, d, h);
     if (rc) return rc;
-    UP(a, occupied, (size_t) n_occ * 8);
+    // Small keyframe stages read their inputs from and write their results to the PINNED mirror of the plan directly (h[], device-
+    // accessible, uncached by the GPU): a copy command is a blit kernel of its own (~9 us on the GPU + a launch + two queue gaps), and these
+    // stages move 3 - 80 KB.  The wait that ends each stage is a stream synchronisation, which makes the kernels' writes visible.
+    if (n_occ > 0) memcpy(h[a], occupied, (size_t) n_occ * 8);
     const Camera &k = m->cam;
     const uint8_t *img = m->clahe ? m->d_eq : m->d_gray;  // detection runs on currImage_ (map_manager.cpp:213)
     // roi = CameraCalibration::roi_rect_ (camera_calibration.cpp:20): the image minus a border of 20 px
-    rc = alva_detect_grid_enqueue(m->ctx, img, (size_t) k.width, k.width, k.height, cell, (const float *) d[a], n_occ, k.border, k.border,
-                                  k.width - 2 * k.border, k.height - 2 * k.border, m->max_quality, (float *) d[b], cap, &m->det_pending);
+    rc = alva_detect_grid_enqueue(m->ctx, img, (size_t) k.width, k.width, k.height, cell, (const float *) h[a], n_occ, k.border, k.border,
+                                  k.width - 2 * k.border, k.height - 2 * k.border, m->max_quality, (float *) h[b], cap, &m->det_pending);
     if (rc) return rc;
     m->det_h = h[b];
     m->det_cap = cap;
-    if (cap > 0) DOWN(b, (size_t) cap * 8);
     return ALVA_OK;
 }
 
@@ -1228,10 +1230,8 @@ int HipStages::describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) 
     std::vector<uint8_t *> d, h;
     int rc = m->carve(p, d, h);
     if (rc) return rc;
-    UP(a, pts, (size_t) n * 8);
-    rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) d[a], n, d[b], d[c]);
-    if (rc) return rc;
-    rc = m->down_span(p, d, h, b, c);
+    memcpy(h[a], pts, (size_t) n * 8);
+    rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) h[a], n, h[b], h[c]);
     if (rc) return rc;
     ALVA_HIP(alva_stream_sync(m->st));
     memcpy(desc, h[b], (size_t) n * 32);
@@ -1246,17 +1246,15 @@ int HipStages::describe_and_compute(int n, const float *pts, uint8_t *desc, uint
     std::vector<uint8_t *> d, h;
     int rc = m->carve(p, d, h);
     if (rc) return rc;
-    UP(a, pts, (size_t) n * 8);
-    rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) d[a], n, d[b], d[c]);
+    memcpy(h[a], pts, (size_t) n * 8);
+    rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) h[a], n, h[b], h[c]);
     if (rc) return rc;
     const Camera &k = m->cam;
-    rc = alva_undistort_points(m->ctx, (const float *) d[a], n, k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (float *) d[u]);
+    rc = alva_undistort_points(m->ctx, (const float *) h[a], n, k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (float *) h[u]);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bearing, dim3(alva_divup(n, 256)), dim3(256), 0, m->st, (const float *) d[u], n, m->d_invK, (double *) d[v]);
+    hipLaunchKernelGGL(k_bearing, dim3(alva_divup(n, 256)), dim3(256), 0, m->st, (const float *) h[u], n, m->d_invK, (double *) h[v]);
     ALVA_LAUNCH_CHECK();
-    rc = m->down_span(p, d, h, b, v);   // descriptors | validity | undistorted positions | bearings: one copy back, one wait
-    if (rc) return rc;
-    ALVA_HIP(alva_stream_sync(m->st));
+    ALVA_HIP(alva_stream_sync(m->st));   // descriptors | validity | undistorted positions | bearings: one wait
     memcpy(desc, h[b], (size_t) n * 32);
     memcpy(valid, h[c], (size_t) n);
     memcpy(unpx, h[u], (size_t) n * 8);
@@ -1280,14 +1278,10 @@ int HipStages::triangulate(int n, int n_groups, const double *T36, const int *gr
     memcpy(h[ir], bv_r, (size_t) n * 24);
     memcpy(h[iul], unpx_l, (size_t) n * 8);
     memcpy(h[iur], unpx_r, (size_t) n * 8);
-    rc = m->up_span(p, d, h, iT, iur);
-    if (rc) return rc;
     const Camera &k = m->cam;
-    rc = alva_triangulate(m->ctx, n, (const double *) d[iT], n_groups, (const int *) d[ig], (const double *) d[il], (const double *) d[ir],
-                          (const float *) d[iul], (const float *) d[iur], k.fx, k.fy, k.cx, k.cy, 3.0f /* mapMaxReprojectionError_ */,
-                          (double *) d[ilp], (double *) d[iw], (double *) d[iid], d[ist], (double *) d[ipar]);
-    if (rc) return rc;
-    rc = m->down_span(p, d, h, iw, ipar);
+    rc = alva_triangulate(m->ctx, n, (const double *) h[iT], n_groups, (const int *) h[ig], (const double *) h[il], (const double *) h[ir],
+                          (const float *) h[iul], (const float *) h[iur], k.fx, k.fy, k.cx, k.cy, 3.0f /* mapMaxReprojectionError_ */,
+                          (double *) d[ilp], (double *) h[iw], (double *) h[iid], h[ist], (double *) h[ipar]);
     if (rc) return rc;
     ALVA_HIP(alva_stream_sync(m->st));
     memcpy(wpt, h[iw], (size_t) n * 24);
@@ -1340,9 +1334,8 @@ int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, cons
                                          (const double *) dv(kf_q), (const double *) dv(kf_t), n_mp, (const double *) dv(mp_wpt), dv(mp_is3d),
                                          dv(mp_has_desc), (const int *) dv(obs_ptr), (const int *) dv(obs_kf), (const float *) dv(obs_px), dv(obs_desc),
                                          dv(obs_has_desc), frame_kf, num_keypoints_3d, n_local, (const int *) dv(local), max_proj_err, dist_ratio,
-                                         (int *) dv(match_of_mp));
+                                         match_of_mp);   // (pinned, written once per entry by the last kernel: no copy back)
         if (rc) return rc;
-        ALVA_HIP(hipMemcpyAsync(match_of_mp, dv(match_of_mp), (size_t) n_mp * 4, hipMemcpyDeviceToHost, m->st));
         ALVA_HIP(alva_stream_sync(m->st));
         return ALVA_OK;
     }
