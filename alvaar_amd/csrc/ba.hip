@@ -1051,6 +1051,7 @@ struct BaHost {
         B.Hpp = carve<double>(cur, npd * dp);
         B.gp = carve<double>(cur, npd);
         B.Wt = carve<double>(cur, npd * NP);
+        B.Zt = carve<double>(cur, (size_t) B.kpad * NP);   // right behind Wt: the two are zeroed by ONE fill
         B.M = carve<double>(cur, n_kf * n_kf * 27);
         B.rowcol = carve<double>(cur, n_kf * 27 * 2);
         B.Hcc = carve<double>(cur, n6 * n6);
@@ -1060,7 +1061,6 @@ struct BaHost {
         B.dc = carve<double>(cur, n6);
         B.dpd = carve<double>(cur, npd);
         B.hinv = carve<double>(cur, npd * dp);
-        B.Zt = carve<double>(cur, (size_t) B.kpad * NP);
         B.Gpart = carve<double>(cur, (size_t) KSPLIT * NP * NP);
         B.S = carve<double>(cur, (n6 + 16) * (n6 + 17) + n6 + 16);  // padded to a multiple of 16, odd row stride, + rhs
         B.yc = carve<double>(cur, NP);
@@ -1242,8 +1242,8 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     if (rc) return rc;
     const auto t_built = std::chrono::steady_clock::now();
     ALVA_HIP(hipMemcpyAsync(base, stage, H.in_bytes, hipMemcpyHostToDevice, st));   // ONE upload from pinned memory
-    ALVA_HIP(hipMemsetAsync(B.Wt, 0, npd * NP * 8, st));                     // sparsity pattern is fixed: zero once
-    ALVA_HIP(hipMemsetAsync(B.Zt, 0, (size_t) B.kpad * NP * 8, st));         // K padding rows stay zero
+    // Wt: the sparsity pattern is fixed, zero once; Zt: the K padding rows stay zero -- neighbours in the layout, one fill
+    ALVA_HIP(hipMemsetAsync(B.Wt, 0, (size_t) ((uint8_t *) B.Zt - (uint8_t *) B.Wt) + (size_t) B.kpad * NP * 8, st));
     const auto t_up = std::chrono::steady_clock::now();
 
     const dim3 gPt((unsigned) alva_divup(std::max(n_pt, 1), 4)), blk(256);
