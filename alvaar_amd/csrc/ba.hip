@@ -898,8 +898,8 @@ __global__ void __launch_bounds__(256) k_results(BaResultsArgs R) {
         const int arrived = __hip_atomic_fetch_add(R.counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == (int) gridDim.x - 1) {
             *R.counter = 0;
-            __threadfence_system();
-            __hip_atomic_store(R.word, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // every workgroup's words are behind its own system-scope fence + arrival: the completion word is one store, no second fence
+            __hip_atomic_store(R.word, R.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
