@@ -1,0 +1,80 @@
+"""Records ONE run of the reference's own System (oracle/_ref) on the 560-frame, cell-12 stream of
+tests/test_gpu_system.py::test_system_equals_reference_long_stream_2000_keypoints as per-frame digests:
+tests/golden/system_long_560_cell12.npz.
+
+Why: the reference is not run-to-run reproducible on this stream (Ceres orders parameter blocks by address: DESIGN.md section 5) -- about
+one run in five takes another discrete path -- while the HIP path is (tools/gpu_determinism_probe.py).  The GPU test compares against at
+most two LIVE runs of the reference; when both happen to be minority runs it falls back to this recording of a MAJORITY run (the path at
+least two of the runs made here agree on, frame by frame).
+
+Per frame: status, the state counters, 64-bit digests (blake2b) of the keypoint ids in container order + their flags, of the keypoint
+pixels (raw + undistorted, the float bytes), of the keyframe ids, of the map-point table (ids + flags) and of the descriptor medoids; the
+pose (7 doubles).  Run from the repository root, CPU only, ~2 minutes per reference run:  python tests/golden/make_system_long_golden.py"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from alvaar_amd import synth  # noqa: E402
+import sysdiff  # noqa: E402
+
+W, H, N, FRAMES, CELL = 640, 480, 200, 560, 12
+
+
+def stream():
+    canvas = synth.texture_canvas(W, H, 7)
+    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(N)]
+    period = 2 * (N - 1)
+    return [base[(k % period) if (k % period) < N else period - (k % period)] for k in range(FRAMES)]
+
+
+def dig(*arrays) -> np.uint64:
+    hsh = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        hsh.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(hsh.digest(), np.uint64)[0]
+
+
+def frame_record(sysobj, st, p7):
+    """(status, state, digests[5], pose7) of the frame just processed; shared with the test"""
+    ids, px, un, i3, hd = sysobj.frame_keypoints()
+    mi, mx, mf, minv, md = sysobj.map_points()
+    d = np.array([dig(ids, i3, hd), dig(px, un), dig(sysobj.keyframe_ids()), dig(mi, mf), dig(md)], np.uint64)
+    return int(st), np.array(list(sysobj.state()), np.int64), d, np.array(p7, np.float64)
+
+
+def one_run(frames):
+    ref = sysdiff.RefSystem(W, H, CELL)
+    out = []
+    for k, f in enumerate(frames):
+        st, p7, _ = ref.step(f, 33.0 * k)
+        out.append(frame_record(ref, st, p7))
+    ref.close()
+    return out
+
+
+def same_path(a, b):
+    return all(x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) for x, y in zip(a, b))
+
+
+if __name__ == "__main__":
+    frames = stream()
+    runs = []
+    for r in range(7):
+        runs.append(one_run(frames))
+        print(f"reference run {r}: keyframes created {int(runs[-1][-1][1][11])}", flush=True)
+        mates = [i for i in range(r) if same_path(runs[i], runs[r])]
+        if mates:
+            print(f"  same discrete path as run {mates[0]}: recording it ({r + 1} runs made)")
+            rec = runs[r]
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", "system_long_560_cell12.npz"),
+                                status=np.array([x[0] for x in rec], np.int32), state=np.stack([x[1] for x in rec]),
+                                digests=np.stack([x[2] for x in rec]), pose7=np.stack([x[3] for x in rec]),
+                                runs_made=np.int32(r + 1))
+            break
+    else:
+        raise SystemExit("no two of seven reference runs agreed")
