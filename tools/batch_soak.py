@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import alvaar_amd  # noqa: E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 from alvaar_amd import synth  # noqa: E402
 
 steps, B = int(sys.argv[1]) if len(sys.argv) > 1 else 5000, 16

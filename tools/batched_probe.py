@@ -3,6 +3,6 @@
 import sys
 sys.path.insert(0, ".")
 import torch
-import bench
+import bench_detail as bench
 r = bench.bench_batched_preprocess(0, 64, reps=5)
 print({k: r[k] for k in ("cameras", "ms_per_batch", "achieved_GBps", "alg_bytes_per_batch")})

@@ -1,7 +1,7 @@
 """Concurrency on one GPU: the empty-launch rate and the tracking step of S sessions on S host threads at once (what caps system_streams / system_group)"""
 import sys, time, threading
 sys.path.insert(0, ".")
-import bench
+import bench_detail as bench
 import numpy as np
 def run(S):
     jobs = [bench.SystemJob(0, 7, host_copy=False)]

@@ -6,7 +6,7 @@ os.environ["ALVA_FE_TIMING"] = "1"
 sys.path.insert(0, ".")
 import time  # noqa: E402
 import torch  # noqa: E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 la = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 job = bench.FrameJob(0, 7)

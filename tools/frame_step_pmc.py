@@ -6,6 +6,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ["ALVA_TRACK_BATCH_ONE_LANE"] = "1"
 sys.path.insert(0, ".")
 import torch  # noqa: F401,E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 r = bench.bench_track_mono_batch(0, 64, reps=1, detector=True)
 print(r["ms_per_step"], r["alg_bytes_per_step"])

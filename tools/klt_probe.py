@@ -2,7 +2,7 @@
 import sys, time
 sys.path.insert(0, ".")
 import torch
-import bench
+import bench_detail as bench
 
 job = bench.FrameJob(0, seed=7)
 ctx = job.ctx

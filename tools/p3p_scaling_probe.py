@@ -5,7 +5,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ["ALVA_TRACK_BATCH_ONE_LANE"] = "1"
 sys.path.insert(0, ".")
 import torch  # noqa: F401,E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 for n in (265, 530, 1060, 2120, 4240):
     bench.NKP = n
     r = bench.bench_track_mono_batch(0, 64, reps=3)

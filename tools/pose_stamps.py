@@ -4,7 +4,7 @@ os.environ["ALVA_KSTAMPS"] = "1"
 sys.path.insert(0, ".")
 import ctypes as C
 import numpy as np
-import bench
+import bench_detail as bench  # noqa: E402
 from alvaar_amd import system as S
 
 lib = S.lib

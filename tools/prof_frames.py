@@ -5,7 +5,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 mode = sys.argv[2] if len(sys.argv) > 2 else "native"

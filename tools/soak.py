@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 import numpy as np  # noqa: E402
 import psutil  # noqa: E402
 import torch  # noqa: E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 from alvaar_amd import synth  # noqa: E402
 from alvaar_amd.system import AlvaAR  # noqa: E402
 

@@ -1,7 +1,7 @@
 """local-BA bench line, per-kernel times and (ALVA_KSTAMPS=1) the in-kernel phase stamps of k_solve on the 20 KF x 3000 pts problem"""
 import sys, json
 sys.path.insert(0, ".")
-import bench
+import bench_detail as bench  # noqa: E402
 from alvaar_amd import capi
 ctx = capi.Context(0)
 r, pb = bench.bench_ba(ctx, reps=10)

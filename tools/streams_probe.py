@@ -1,6 +1,6 @@
 import sys, json
 sys.path.insert(0, ".")
-import bench
+import bench_detail as bench  # noqa: E402
 for n in (4, 8):
     r = bench.bench_system_streams(0, n, steps=300)
     print(n, "sessions:", round(r["frames_per_s"]), "frames/s")

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import torch
-import bench
+import bench_detail as bench  # noqa: E402
 
 n, win = int(os.environ.get("FRAMES", "1000")), int(os.environ.get("WINDOW", "400"))
 bench.SYSTEM_CELL = int(os.environ.get("CELL", "12"))

@@ -3,7 +3,7 @@ import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, ".")
 import torch  # noqa: F401
-import bench
+import bench_detail as bench  # noqa: E402
 job = bench.SystemJob(0, 7, host_copy=False)
 ar = job.ar
 extra = 0

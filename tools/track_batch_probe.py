@@ -5,7 +5,7 @@ import sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, ".")
 import torch  # noqa: F401,E402
-import bench  # noqa: E402
+import bench_detail as bench  # noqa: E402
 
 det = os.environ.get("DETECTOR") == "1"
 feat = 2000
