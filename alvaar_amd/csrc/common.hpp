@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "../../include/alvaar_hip.h"
+#include "lane.hpp"
 
 void alva_set_error(const char *fmt, ...);
 
@@ -17,10 +18,20 @@ void alva_prof_mark(hipStream_t stream, const char *kernel, int end);
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)            \
     do {                                                                                             \
+        alva_lane_flush(); /* deposits of this thread's lane go out before any direct launch (lane.hpp) */ \
         if (g_alva_prof_on) alva_prof_mark((streamId), #kernelName, 0);                              \
         (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);         \
         if (g_alva_prof_on) alva_prof_mark((streamId), #kernelName, 1);                              \
     } while (0)
+
+// every other stream operation of this library: the thread's lane (lane.hpp) issues its deposits first, so that stream order == program
+// order for a session whether or not it runs inside a group (a function-like macro is not re-expanded inside its own replacement)
+#define hipMemcpyAsync(...) (alva_lane_flush(), hipMemcpyAsync(__VA_ARGS__))
+#define hipMemsetAsync(...) (alva_lane_flush(), hipMemsetAsync(__VA_ARGS__))
+#define hipEventRecord(...) (alva_lane_flush(), hipEventRecord(__VA_ARGS__))
+#define hipStreamWaitEvent(...) (alva_lane_flush(), hipStreamWaitEvent(__VA_ARGS__))
+#define hipStreamSynchronize(...) (alva_lane_flush(), hipStreamSynchronize(__VA_ARGS__))
+#define hipDeviceSynchronize() (alva_lane_flush(), hipDeviceSynchronize())
 
 #define ALVA_HIP(expr)                                                                         \
     do {                                                                                       \
@@ -91,6 +102,7 @@ static inline void alva_poll_relax(unsigned spins) {
 }
 // hipStreamSynchronize for the session paths: inside a group's fiber the wait is a query loop that lets the thread's other sessions run
 static inline hipError_t alva_stream_sync(hipStream_t st) {
+    alva_lane_flush();   // a deposit not yet issued would make an idle stream look finished
     if (!alva_fiber_yield) return hipStreamSynchronize(st);
     for (;;) {
         const hipError_t e = hipStreamQuery(st);
@@ -99,6 +111,7 @@ static inline hipError_t alva_stream_sync(hipStream_t st) {
     }
 }
 static inline hipError_t alva_event_sync(hipEvent_t ev) {
+    alva_lane_flush();
     if (!alva_fiber_yield) return hipEventSynchronize(ev);
     for (;;) {
         const hipError_t e = hipEventQuery(ev);

@@ -12,6 +12,7 @@
 // complete after ONE launch.  Launch plan for an L-level pyramid: 1 + L launches
 //   [gray L0 (+border)] , [scharr(l) | pyrDown(l -> l+1) (+border)] for l = 0..L-2 , [scharr(L-1)]
 #include "common.hpp"
+#include "multi_kernel.hpp"
 
 namespace {
 
@@ -67,6 +68,18 @@ __global__ void __launch_bounds__(256) k_level0(const uint8_t *__restrict__ src,
                                                 uint8_t *__restrict__ gray_out, size_t gray_out_pitch) {
     level0_body<SRC_RGBA>(src, src_pitch, w, h, win, dst, dst_pitch, gray_out, gray_out_pitch, blockIdx.x, blockIdx.y);
 }
+// several sessions' frames in one launch (lane.hpp): the 2-D grid of the single launch, row-major in bx
+struct Level0Args {
+    const uint8_t *src;
+    size_t src_pitch;
+    int w, h, win, gx0;
+    uint8_t *dst;
+    size_t dst_pitch;
+    uint8_t *gray_out;
+    size_t gray_out_pitch;
+};
+ALVA_MULTI_KERNEL(MK_LEVEL0, k_level0_multi, Level0Args, dim3(64, 4), 256,
+                  level0_body<true>(A.src, A.src_pitch, A.w, A.h, A.win, A.dst, A.dst_pitch, A.gray_out, A.gray_out_pitch, bx % A.gx0, bx / A.gx0));
 // The same for B cameras in one launch (camera -> XCD affinity, alva_xcd_item): one frame is 1.2 MB and every launch of this file is bound by
 // launch latency, not by HBM; B frames per launch is what lets the same code run at memory speed.
 struct Level0Item {
@@ -309,8 +322,7 @@ __device__ __forceinline__ void deep_tile(const RestArgs &A, int L, int bid) {
     *reinterpret_cast<uint32_t *>(drow) = (uint32_t) (uint16_t) ix | ((uint32_t) (uint16_t) iy << 16);
 }
 
-__global__ void __launch_bounds__(256) k_pyr_rest(RestArgs A) {
-    const int bid = blockIdx.x;
+__device__ __forceinline__ void pyr_rest_body(const RestArgs &A, const int bid) {
     if (bid < A.s0.scharr_blocks) {
         scharr_tile(A.s0, bid);
         return;
@@ -326,6 +338,8 @@ __global__ void __launch_bounds__(256) k_pyr_rest(RestArgs A) {
     if (tile >= n) return;   // (whole workgroup: no barrier is skipped by a part of it)
     deep_tile(A, L, tile);
 }
+__global__ void __launch_bounds__(256) k_pyr_rest(RestArgs A) { pyr_rest_body(A, (int) blockIdx.x); }
+ALVA_MULTI_KERNEL(MK_PYR_REST, k_pyr_rest_multi, RestArgs, dim3(64, 4), 256, pyr_rest_body(A, bx));
 
 __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
     int bid = blockIdx.x;
@@ -468,7 +482,8 @@ static int stage_args(const alva_pyramid *p, int l, StageArgs &a) {  // returns 
     return a.scharr_blocks + down_blocks;
 }
 
-static int build_rest(alva_ctx *ctx, alva_pyramid *p) {
+// lane_ok: level 0 was deposited on the lane too (a level 0 launched directly runs on the context's own stream: the rest must follow it there)
+static int build_rest(alva_ctx *ctx, alva_pyramid *p, bool lane_ok = false) {
     static const bool staged = getenv("ALVA_PYRAMID_STAGES") != nullptr;   // A/B: the chain of stage launches instead of the fused one
     if (!staged && p->nlevels >= 2 && p->nlevels <= 4 && p->win >= 3) {
         RestArgs A{};
@@ -488,6 +503,7 @@ static int build_rest(alva_ctx *ctx, alva_pyramid *p) {
                 blocks += 8 * alva_divup(tiles, 8);   // eight XCD shares of equal length (the kernel drops the padding workgroups)
             }
         }
+        if (lane_ok && alva_lane_defer(MK_PYR_REST, ctx, (unsigned) blocks, 0, &A, sizeof(A))) return ALVA_OK;
         hipLaunchKernelGGL(k_pyr_rest, dim3(blocks), dim3(64, 4), 0, ctx->stream, A);
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
@@ -519,6 +535,8 @@ extern "C" int alva_pyramid_build_from_rgba(alva_ctx *ctx, alva_pyramid *pyr, co
     ALVA_ARG(rgba_pitch >= (size_t) L.w * 4);
     if (d_gray_out) ALVA_ARG(gray_out_pitch % 4 == 0 && gray_out_pitch >= (size_t) L.w && ((uintptr_t) d_gray_out % 4) == 0);
     dim3 block(64, 4), grid(alva_divup(L.w, 256), alva_divup(L.h, 4));
+    const Level0Args LA{d_rgba, rgba_pitch, L.w, L.h, pyr->win, (int) grid.x, L.gray, L.gray_pitch, d_gray_out, gray_out_pitch};
+    if (alva_lane_defer(MK_LEVEL0, ctx, grid.x * grid.y, 0, &LA, sizeof(LA))) return build_rest(ctx, pyr, true);
     hipLaunchKernelGGL(k_level0<true>, grid, block, 0, ctx->stream, d_rgba, rgba_pitch, L.w, L.h, pyr->win, L.gray, L.gray_pitch,
                        d_gray_out, gray_out_pitch);
     ALVA_LAUNCH_CHECK();

@@ -19,6 +19,7 @@
 //
 // This translation unit must be compiled with -ffp-contract=off.
 #include "common.hpp"
+#include "multi_kernel.hpp"
 #include "wave_utils.hpp"
 #include "track_slots.hpp"
 #include <cstdlib>
@@ -401,8 +402,8 @@ __device__ __forceinline__ void track_slot_store(const TrackSlots &D, int i, int
 }
 
 // the frame's slot table (positions, 3-D flags, world points) from pinned host memory into device memory, 16 bytes per lane
-__global__ void __launch_bounds__(256) k_track_stage_in(TrackSlots D) {
-    const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void track_stage_in_body(const TrackSlots &D, const int bx) {
+    const size_t t = (size_t) bx * 256 + threadIdx.x;
     const size_t n = (size_t) D.n, q_px = (n * 8 + 15) / 16, q_3d = (n + 15) / 16, q_w = (n * 24 + 15) / 16;
     const uint4 *src;
     uint4 *dst;
@@ -416,13 +417,17 @@ __global__ void __launch_bounds__(256) k_track_stage_in(TrackSlots D) {
     } else return;
     dst[k] = src[k];
 }
+__global__ void __launch_bounds__(256) k_track_stage_in(TrackSlots D) { track_stage_in_body(D, (int) blockIdx.x); }
+ALVA_MULTI_KERNEL(MK_STAGE_IN, k_track_stage_in_multi, TrackSlots, dim3(256), 256, track_stage_in_body(A, bx));
 
-__global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D, int maxLevelPrior, int maxLevelFull, int maxCount,
-                                                  double epsilon, float errThresh, float fbDist) {
+// gx = the launch's workgroups (a multiple of 8), bx = this one: slot i = the XCD-contiguous order of k_klt
+__device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, const TrackSlots &D, const int maxLevelPrior, const int maxLevelFull,
+                                               const int maxCount, const double epsilon, const float errThresh, const float fbDist, const int bx,
+                                               const int gx) {
     __shared__ LkShared sh;
     lk_shared_init(sh);
-    const int per = gridDim.x >> 3;
-    const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int per = gx >> 3;
+    const int i = (bx & 7) * per + (bx >> 3);
     if (i >= D.n) return;
     const float px = D.d_pts[2 * i], py = D.d_pts[2 * i + 1];
     const int is3 = D.d_is3d[i];
@@ -470,6 +475,17 @@ __global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D
         }
     }
 }
+__global__ void __launch_bounds__(64) k_track_klt(LkPyr P, LkPyr C, TrackSlots D, int maxLevelPrior, int maxLevelFull, int maxCount,
+                                                  double epsilon, float errThresh, float fbDist) {
+    track_klt_body(P, C, D, maxLevelPrior, maxLevelFull, maxCount, epsilon, errThresh, fbDist, (int) blockIdx.x, (int) gridDim.x);
+}
+struct TrackKltArgs {
+    LkPyr P, C;
+    TrackSlots D;
+    int maxLevelPrior, maxLevelFull, maxCount;
+    float errThresh, fbDist;
+    double epsilon;
+};
 
 __global__ void __launch_bounds__(64) k_track_klt_retry(LkPyr P, LkPyr C, TrackSlots D, int maxLevelFull, int maxCount, double epsilon,
                                                         float errThresh, float fbDist) {
@@ -996,6 +1012,119 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
 }
 
+// ---- the tracking step of one frame in the throughput layout: GL lanes per slot, 64 / GL slots per wave (lk_level_q) -------------------
+// What k_track_klt computes for a slot, for the sessions of a group (lane.hpp): S sessions' trackers in one launch fill the chip several
+// times over, so the layout that finishes a SLOT soonest (a wave per slot: 2 300 short-lived waves, issue rate 0.18) loses to the one
+// that does the most slots per wave-cycle (measured with 8 concurrent sessions: k_track_klt 74 -> 106 us each and every small kernel
+// beside it 3 - 5x slower, the chip's wave slots held by trackers; k_klt_batch_q tracks a 2 120-keypoint camera in 11 us of a 64-camera
+// launch).  Slots of a wave run the pyramid levels together; a slot tracked from its projection joins at level maxLevelPrior.  Bitwise
+// equal to k_track_klt: the same arithmetic per slot (lk_level_q is lk_level's summation order, see above), the same gates.
+template <int GL>
+__device__ __forceinline__ int fbklt_value_q(LkSharedQ<GL> &sh, const LkPyr &P, const LkPyr &C, const int myMax, const int top, const int maxCount,
+                                             const double epsilon, const float errThresh, const float fbDist, const bool has, const float ptx,
+                                             const float pty, float &nx, float &ny) {
+    int status = 1;
+    float err = 0.f;
+    for (int level = top; level >= 0; level--)   // top = the wave's highest starting level (wave-uniform)
+        lk_level_q<GL>(sh, P.lv[level], C.lv[level], level, myMax, maxCount, epsilon, 1e-4f, has && level <= myMax, ptx, pty, nx, ny, status, err);
+    int ok = status && !(err > errThresh);
+    const float fw = (float) C.lv[0].w, fh = (float) C.lv[0].h;
+    ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
+    float bx = ptx, by = pty;
+    int st2 = 1;
+    float err2 = 0.f;
+    lk_level_q<GL>(sh, C.lv[0], P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, has && ok, nx, ny, bx, by, st2, err2);
+    if (ok) {
+        if (!st2) ok = 0;
+        else {
+            const float ddx = ptx - bx, ddy = pty - by;
+            const double nrm = sqrt((double) ddx * (double) ddx + (double) ddy * (double) ddy);
+            if (nrm > (double) fbDist) ok = 0;
+        }
+    }
+    return has ? ok : 0;
+}
+
+template <int GL>
+__device__ __forceinline__ void track_klt_q_body(const LkPyr &P, const LkPyr &C, const TrackSlots &D, const int maxLevelPrior, const int maxLevelFull,
+                                                 const int maxCount, const double epsilon, const float errThresh, const float fbDist, const int bx,
+                                                 const int gx) {
+    __shared__ LkSharedQ<GL> sh;
+    constexpr int NG = 64 / GL;
+    const int per = gx >> 3;
+    const int w = (bx & 7) * per + (bx >> 3);   // the XCD-contiguous order of k_klt, in units of NG slots
+    if (w * NG >= D.n) return;
+    const int grp = (int) threadIdx.x / GL;
+    const int i = w * NG + grp;
+    const bool has = grp < NG && i < D.n;
+    const bool leader = has && (int) threadIdx.x == grp * GL;
+    const int ic = has ? i : D.n - 1;
+    const float px = D.d_pts[2 * ic], py = D.d_pts[2 * ic + 1];
+    const int is3 = D.d_is3d[ic];
+    bool from_prior = false;
+    float nx = px, ny = py;
+    if (D.use_prior && is3) {  // visual_frontend.cpp:125-152: project under the predicted pose, keep it if it is inside the image
+        const double X[3] = {D.d_wpt[3 * (size_t) ic], D.d_wpt[3 * (size_t) ic + 1], D.d_wpt[3 * (size_t) ic + 2]};
+        double pc[3];
+        float qu, qv;
+        alva_se3_apply_dev(D.q, D.t, X, pc);
+        alva_project_dist_dev(D.cam, pc[0], pc[1], pc[2], qu, qv);
+        from_prior = qu >= 0 && qv >= 0 && (double) qu < (double) D.width && (double) qv < (double) D.height;  // Frame::isInImage
+        if (from_prior) {
+            nx = qu;
+            ny = qv;
+        }
+    }
+    const int myMax = from_prior ? maxLevelPrior : maxLevelFull;
+    const int top = __any(has && !from_prior) ? maxLevelFull : maxLevelPrior;
+    const int ok = fbklt_value_q<GL>(sh, P, C, myMax, top, maxCount, epsilon, errThresh, fbDist, has, px, py, nx, ny);
+    int code = ok ? (from_prior ? 1 : 2) : 0;
+    const bool retry = has && from_prior && !ok;
+    if (__any(retry)) {  // full-pyramid retry from where the forward tracker left the keypoint (:185-190)
+        float rx = nx, ry = ny;
+        const int ok2 = fbklt_value_q<GL>(sh, P, C, maxLevelFull, maxLevelFull, maxCount, epsilon, errThresh, fbDist, retry, px, py, rx, ry);
+        if (retry) {
+            nx = rx;
+            ny = ry;
+            code = ok2 ? 3 : 0;
+        }
+    }
+    // per-slot results: Frame::computeKeypoint for a tracked slot, zeros for a lost one (track_slot_store, by the slot's first lane)
+    float ux = 0.f, uy = 0.f;
+    double bv[3] = {0., 0., 0.};
+    if (code) {
+        alva_undistort_dev(D.cam, nx, ny, ux, uy);
+        alva_bearing_dev(D.invK, ux, uy, bv);
+    } else {
+        nx = 0.f;
+        ny = 0.f;
+    }
+    if (leader) {
+        D.d_retried[i] = (uint8_t) retry;
+        D.d_code[i] = (uint8_t) code;
+        D.d_px[2 * i] = nx; D.d_px[2 * i + 1] = ny;
+        D.d_unpx[2 * i] = ux; D.d_unpx[2 * i + 1] = uy;
+        D.d_bv[3 * (size_t) i] = bv[0]; D.d_bv[3 * (size_t) i + 1] = bv[1]; D.d_bv[3 * (size_t) i + 2] = bv[2];
+    }
+    // ONE atomic per wave on the packed counter (track_slots.hpp): the wave's slots, tracked 3-D slots, slots from the projection, successes of those
+    const unsigned long long b_has = __ballot(leader), b_pose = __ballot(leader && code != 0 && is3 != 0), b_prior = __ballot(leader && from_prior),
+                             b_good = __ballot(leader && from_prior && ok);
+    if (threadIdx.x == 0) {
+        const unsigned long long add = ((unsigned long long) __popcll(b_has) << 48) | ((unsigned long long) __popcll(b_pose) << 32) |
+                                       ((unsigned long long) __popcll(b_prior) << 16) | (unsigned long long) __popcll(b_good);
+        const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long *>(D.cnt) + 2, add);
+        const unsigned long long now = before + add;
+        if ((int) (now >> 48) == D.n) {   // the launch's last wave of this session publishes the counts (see k_track_klt)
+            const int n_pose = (int) ((now >> 32) & 0xffff), nA = (int) ((now >> 16) & 0xffff), good = (int) (now & 0xffff);
+            const int req = nA > 0 && (double) good < 0.33 * (double) nA ? 1 : 0;
+            const unsigned long long word = ((unsigned long long) (unsigned) D.seq << 32) | ((unsigned long long) req << 31) | (unsigned) n_pose;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(D.o_hdr + 10), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+ALVA_MULTI_KERNEL_ATTR(MK_TRACK_KLT, k_track_klt_q_multi, TrackKltArgs, dim3(64), __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))),
+                       track_klt_q_body<5>(A.P, A.C, A.D, A.maxLevelPrior, A.maxLevelFull, A.maxCount, A.epsilon, A.errThresh, A.fbDist, bx, (int) gx));
+
 int fill_pyr(const alva_pyramid *p, LkPyr &out) {
     out.nlevels = p->nlevels;
     for (int l = 0; l < p->nlevels && l < MAXL; l++) {
@@ -1096,7 +1225,11 @@ int alva_track_slots_klt(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyr
     const dim3 grid(8 * alva_divup(D.n, 8));
     if (!retry) {
         const size_t n = (size_t) D.n, quads = (n * 8 + 15) / 16 + (n + 15) / 16 + (n * 24 + 15) / 16;
-        hipLaunchKernelGGL(k_track_stage_in, dim3((unsigned) ((quads + 255) / 256)), dim3(256), 0, ctx->stream, D);
+        const unsigned g_in = (unsigned) ((quads + 255) / 256);
+        const bool in_lane = alva_lane_defer(MK_STAGE_IN, ctx, g_in, 0, &D, sizeof(D));
+        if (!in_lane) hipLaunchKernelGGL(k_track_stage_in, dim3(g_in), dim3(256), 0, ctx->stream, D);
+        const TrackKltArgs KA{P, C, D, lp, lf, maxCount, err_thresh, fb_dist, epsilon};
+        if (alva_lane_defer(MK_TRACK_KLT, ctx, (unsigned) (8 * alva_divup(alva_divup(D.n, 12), 8)), 0, &KA, sizeof(KA))) return ALVA_OK;   // 12 slots per wave
     }
     if (!retry) hipLaunchKernelGGL(k_track_klt, grid, dim3(64), 0, ctx->stream, P, C, D, lp, lf, maxCount, epsilon, err_thresh, fb_dist);
     else hipLaunchKernelGGL(k_track_klt_retry, grid, dim3(64), 0, ctx->stream, P, C, D, lf, maxCount, epsilon, err_thresh, fb_dist);

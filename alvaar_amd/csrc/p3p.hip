@@ -16,6 +16,7 @@
 // FP64 VALU work (100 x N x ~40 flop); bytes are negligible (48 N read once per hypothesis,
 // L2-resident).  No MFMA: nothing here is GEMM-shaped.
 #include "common.hpp"
+#include "multi_kernel.hpp"
 #include <atomic>
 #include "pose_internal.hpp"
 #include <cmath>
@@ -562,6 +563,8 @@ __device__ __forceinline__ void p3p_block(const P3pArgs &A, const int h, const i
 // score 3.6 us, select 5.3 us, inliers 5.1 us per workgroup before).
 constexpr int P3P_NT = 512;
 __global__ void __launch_bounds__(P3P_NT) k_p3p(P3pArgs A) { p3p_block<0, P3P_NT>(A, blockIdx.x); }
+// several sessions' problems in one launch (lane.hpp): the samples come through A.samples (pinned host memory), as in k_p3p
+ALVA_MULTI_KERNEL(MK_P3P, k_p3p_multi, P3pArgs, dim3(P3P_NT), P3P_NT, p3p_block<0, P3P_NT>(A, bx));
 __global__ void __launch_bounds__(P3P_NT) k_p3p_s(P3pArgs A, P3pInlineSamples S) { p3p_block<0, P3P_NT>(A, blockIdx.x, S.v + 4 * blockIdx.x); }
 
 // B independent problems in one launch: blockIdx.y = problem (camera), each with its own correspondences, sample list, scratch
@@ -659,6 +662,8 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     A.out = out;
     A.inlier = inlier;
     A.dbg = alva_kstamp_buffer();
+    // (n <= 7168: the multi kernel keeps the default dynamic-LDS limit)
+    if (n <= 7168 && alva_lane_defer(MK_P3P, ctx, (unsigned) H, (unsigned) ((size_t) n * sizeof(double)), &A, sizeof(A))) return ALVA_OK;
     static const bool inline_ok = getenv("ALVA_P3P_NO_INLINE_SAMPLES") == nullptr;
     if (H <= P3P_INLINE_H && inline_ok) {
         P3pInlineSamples S;

@@ -18,6 +18,7 @@
 // allows fused multiply-add contraction: the normal-equation accumulation is half the instructions as FMAs.  Results
 // are compared with the reference under a tolerance (FP64 sums in a different order anyway), not bitwise.
 #include "common.hpp"
+#include "multi_kernel.hpp"
 #pragma clang fp contract(fast)
 #include "lm_device.hpp"
 #include "wave_utils.hpp"
@@ -643,10 +644,10 @@ __device__ __forceinline__ void pnp_block(const PnpArgs &A, uint8_t *__restrict_
     }
 }
 
-__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ active, double *__restrict__ chi2,
-                                            uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
-                                            const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
-                                            uint8_t *__restrict__ p3p_outlier) {
+__device__ __forceinline__ void pnp_body(const PnpArgs &A, uint8_t *__restrict__ active, double *__restrict__ chi2,
+                                         uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
+                                         const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
+                                         uint8_t *__restrict__ p3p_outlier) {
     pnp_block(A, active, chi2, depth, bad, out, p3p, inlier0, p3p_outlier);
     // (Measured alternatives to this fence, 2.5 us of kernel tail: plain stores + s_waitcnt vmcnt(0) -> the host reads stale masks (host
     // memory is cached in L2); every host-visible word as a system-scope write-through store + vmcnt(0) -> correct, the fence's time
@@ -655,6 +656,12 @@ __global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ act
     __threadfence_system();   // this thread's writes to `out` / `bad` / `p3p_outlier` (possibly pinned host memory) ...
     __syncthreads();          // ... of every thread ...
     if (threadIdx.x == 0) __hip_atomic_store(&out->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the word a host may poll
+}
+__global__ void __launch_bounds__(NT) k_pnp(PnpArgs A, uint8_t *__restrict__ active, double *__restrict__ chi2,
+                                            uint8_t *__restrict__ depth, uint8_t *__restrict__ bad, PnpOut *__restrict__ out,
+                                            const P3pSelectOut *__restrict__ p3p, const uint8_t *__restrict__ inlier0,
+                                            uint8_t *__restrict__ p3p_outlier) {
+    pnp_body(A, active, chi2, depth, bad, out, p3p, inlier0, p3p_outlier);
 }
 
 // B chained P3P -> PnP problems in one launch, one workgroup each (blockIdx.x = camera).
@@ -668,6 +675,8 @@ struct PnpBatchItem {
     const uint8_t *inlier0;
     uint8_t *p3p_outlier;
 };
+// several sessions' refinements in one launch (lane.hpp): one workgroup each, with k_pnp's completion word
+ALVA_MULTI_KERNEL(MK_PNP, k_pnp_multi, PnpBatchItem, dim3(NT), NT, pnp_body(A.A, A.active, A.chi2, A.depth, A.bad, A.out, A.p3p, A.inlier0, A.p3p_outlier));
 
 __global__ void __launch_bounds__(NT) k_pnp_batch(const PnpBatchItem *__restrict__ items) {
     const PnpBatchItem &it = items[blockIdx.x];
@@ -761,6 +770,9 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
     if (rc) return rc;
     P.A.seq = ++P.seq;
     ((PnpOut *) (P.pin + P.poff_out))->seq = 0;   // the staging may be fresh memory; every earlier user of it has completed (polled or synchronised)
+    const PnpBatchItem item{P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad, (PnpOut *) (P.pin + P.poff_out),
+                            (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po};
+    if (alva_lane_defer(MK_PNP, ctx, 1, 0, &item, sizeof(item))) return ALVA_OK;
     hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad,
                        (PnpOut *) (P.pin + P.poff_out), (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po);
     ALVA_LAUNCH_CHECK();

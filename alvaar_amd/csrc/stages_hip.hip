@@ -5,6 +5,7 @@
 // Host arrays cross into device memory through two bump arenas that are reset per call: a pinned host arena (staging both
 // ways, so every copy is asynchronous on the stream) and a device arena.  One stream synchronisation per method.
 #include "common.hpp"
+#include "multi_kernel.hpp"
 #include <algorithm>
 #include "camera_device.hpp"
 #include "pose_internal.hpp"
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(TRK_NT) k_track_finish(TrackDev D) {
 // bearing; what is left is the list of the pose solve -- the tracked 3-D slots in slot order (visual_frontend.cpp:275-298) -- the
 // header, and the counters' reset for the next frame.
 constexpr int CMP_NT = 256, CMP_MAX_WG = 32;
-__global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) {
+__device__ __forceinline__ void track_compact_body(const TrackSlots &D, const int g, const int G) {
     // SEVERAL workgroups (one used to do all of it: 107 KB to the host + 145 KB of gathers through one compute unit took 23 us).
     // Every workgroup owns a contiguous slice of the slots.  It counts the pose flags of the slots in front of its slice by itself
     // (2 bytes per slot: cheaper than a cross-workgroup scan), copies its slice's results to pinned host memory and gathers its slice's
@@ -227,7 +228,6 @@ __global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) {
     // counter; the workgroup that arrives LAST writes the header and then the word (system-scope release) -- the host reads the word
     // with acquire semantics, so it sees every slice.
     __shared__ int s_cnt[CMP_NT / 64 + 1];
-    const int G = (int) gridDim.x, g = (int) blockIdx.x;
     const int per = ((D.n + G - 1) / G + 63) / 64 * 64;   // slice length, a multiple of the wave size
     const int lo = g * per, hi = min(D.n, lo + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -308,6 +308,8 @@ __global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) {
         }
     }
 }
+__global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) { track_compact_body(D, (int) blockIdx.x, (int) gridDim.x); }
+ALVA_MULTI_KERNEL(MK_TRACK_COMPACT, k_track_compact_multi, TrackSlots, dim3(CMP_NT), CMP_NT, track_compact_body(A, bx, (int) gx));
 static inline int compact_grid(int n) {   // ~256 slots per workgroup
     const int g = (n + 255) / 256;
     return g < 1 ? 1 : g > CMP_MAX_WG ? CMP_MAX_WG : g;
@@ -710,7 +712,10 @@ int HipStages::build_from(const uint8_t *d_src) {
     rc = alva_clahe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, 3.0, m->cam.width / 50, m->cam.height / 50, m->d_eq,
                     (size_t) m->cam.width);
     if (rc) return rc;
-    return alva_pyramid_build_from_gray(m->ctx, m->pyr[m->cur], m->d_eq, (size_t) m->cam.width);
+    rc = alva_pyramid_build_from_gray(m->ctx, m->pyr[m->cur], m->d_eq, (size_t) m->cam.width);
+    if (rc) return rc;
+    if (g_alva_lane) ALVA_HIP(alva_stream_sync(m->st));   // in a group the tracker runs on the lane's stream: these images are on the session's own
+    return ALVA_OK;
 }
 
 // Look-ahead (no reference counterpart; the reference receives one frame per call): the caller names the frame of its NEXT call, and its
@@ -775,6 +780,14 @@ int HipStages::unregister_frame_buffer() {
 
 int HipStages::new_frame(const uint8_t *rgba) {
     ALVA_HIP(hipSetDevice(m->device));
+    // a HOST frame inside a group (no group entry point takes one): the upload, its completion event and the kernels that read it belong on
+    // the session's own stream -- the images are built there and waited for, so that the lane's tracker may read them
+    struct NoLane {
+        alva_lane *saved = g_alva_lane;
+        NoLane() { g_alva_lane = nullptr; }
+        ~NoLane() { g_alva_lane = saved; }
+    } no_lane;
+    const bool in_group = no_lane.saved != nullptr;
     const size_t bytes = (size_t) m->cam.width * m->cam.height * 4;
     if (m->registered && rgba >= m->registered && rgba + bytes <= m->registered + m->registered_bytes && (((uintptr_t) rgba) & 15) == 0) {
         // zero-copy: the image kernels read the caller's pages; frame_done() waits for them before the call returns the buffer
@@ -782,11 +795,15 @@ int HipStages::new_frame(const uint8_t *rgba) {
         if (rc) return rc;
         m->upload_in_flight = true;
         ALVA_HIP(hipEventRecord(m->upload_done, m->st));
+        if (in_group) ALVA_HIP(alva_stream_sync(m->st));
         return ALVA_OK;
     }
     memcpy(m->h_rgba, rgba, bytes);
     ALVA_HIP(hipMemcpyAsync(m->d_rgba, m->h_rgba, bytes, hipMemcpyHostToDevice, m->st));
-    return build_from(m->d_rgba);
+    const int rc = build_from(m->d_rgba);
+    if (rc) return rc;
+    if (in_group) ALVA_HIP(alva_stream_sync(m->st));
+    return ALVA_OK;
 }
 
 int HipStages::new_frame_device(const uint8_t *d_rgba) {
@@ -875,8 +892,10 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.seq = ++m->trk_seq;   // the tracker launch publishes its counts under this number too (the word at o_hdr[10])
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
-        ALVA_LAUNCH_CHECK();
+        if (!alva_lane_defer(MK_TRACK_COMPACT, m->ctx, (unsigned) compact_grid(D.n), 0, &D, sizeof(D))) {
+            hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
+            ALVA_LAUNCH_CHECK();
+        }
         poll_seq = m->poll ? D.seq : 0;
         slots_D = D;
         slots_path = true;
@@ -994,6 +1013,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
             pose_early = true;
             rc = build_ahead();   // a hinted next frame: its images are queued behind the pose kernels
             if (rc) return rc;
+            alva_lane_yield();    // in a group: the thread's other sessions deposit their pose solves before this one starts its bookkeeping
         }
     }
     rc = wait_step(poll_seq);
@@ -1032,6 +1052,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     m->pose_n = out.n_pose >= 4 ? m->pose_n : 0;
     pose_total_ = out.n_pose;
     fused_active_ = true;
+    if (!m->pose_pending) alva_lane_clean();   // in a group: the compaction's word was the chain's last (lane.hpp); with a pose solve, its own is
     return ALVA_OK;
 }
 
@@ -1056,6 +1077,7 @@ int HipStages::track_pose_collect(TrackPose &out) {
     int status = 0;
     int rc = alva_compute_pose_collect_p3p(m->ctx, out.pose7, out.pose7_p3p, out.p3p_outlier.data(), out.pnp_outlier.data(), &status);
     if (rc) return rc;
+    alva_lane_clean();   // the refinement's completion word has been seen: nothing of this session is left on the lane
     out.status = status;
     return ALVA_OK;
 }

@@ -14,7 +14,9 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
 #include <ucontext.h>
+#include <unistd.h>
 #include <vector>
 
 using namespace alva_slam;
@@ -346,15 +348,36 @@ extern "C" int alva_system_debug_set_init_pose(alva_system *s, const double *pos
 // (common.hpp) -- switches to the thread's next session instead of spinning.  The GPU sees the sessions' streams side by side; the host
 // threads only ever execute map-layer work.  Sessions stay independent: every session's results are those of its solo run, bit for bit.
 namespace {
+const size_t kFiberStack = [] {   // ALVA_FIBER_STACK_KB (default 4 MiB: map layer + HIP runtime + exception unwinding run on it)
+    const char *e = getenv("ALVA_FIBER_STACK_KB");
+    const size_t kb = e ? (size_t) strtoul(e, nullptr, 10) : 4096;
+    return (kb < 256 ? 256 : kb) << 10;
+}();
 struct Fiber {
     ucontext_t ctx;
-    std::vector<char> stack;
+    char *stack = nullptr;
+    void *stack_map = nullptr;
+    Fiber() = default;
+    Fiber(const Fiber &) = delete;
+    Fiber(Fiber &&o) noexcept { *this = std::move(o); }
+    Fiber &operator=(Fiber &&o) noexcept {
+        memcpy(&ctx, &o.ctx, sizeof(ctx));
+        stack = o.stack; stack_map = o.stack_map; sys = o.sys; d_rgba = o.d_rgba; ts = o.ts; pose = o.pose; status = o.status; done = o.done;
+        lane = o.lane; lane_dirty = o.lane_dirty;
+        o.stack = nullptr; o.stack_map = nullptr;
+        return *this;
+    }
+    ~Fiber() {
+        if (stack_map) munmap(stack_map, kFiberStack + (size_t) sysconf(_SC_PAGESIZE));
+    }
     alva_system *sys = nullptr;
     const uint8_t *d_rgba = nullptr;
     double ts = 0;
     float *pose = nullptr;
     int *status = nullptr;
     bool done = true;
+    alva_lane *lane = nullptr;   // the shared launches this session's tracking chain goes through, if any (lane.hpp)
+    bool lane_dirty = false;     // chain work deposited whose completion the session's host side has not seen yet
 };
 struct Worker;
 thread_local Worker *g_worker = nullptr;
@@ -373,31 +396,71 @@ struct Worker {
         f.done = true;
         swapcontext(&f.ctx, &w->sched);
     }
+    double t_run = 0, t_work = 0;   // seconds inside run() | inside fiber slices that did more than poll
+    long n_slices = 0, n_work_slices = 0;
     // run the first n fibers to completion, round robin over the unfinished ones
     void run(int n) {
+        const auto t_run0 = std::chrono::steady_clock::now();
         g_worker = this;
         alva_fiber_yield = &Worker::yield_hook;
         for (int i = 0; i < n; i++) {
             Fiber &f = fibers[(size_t) i];
-            if (f.stack.empty()) f.stack.resize((size_t) 1 << 20);
+            if (!f.stack) {   // own mapping with a PROT_NONE guard page below it: an overflow faults instead of corrupting the heap
+                const size_t page = (size_t) sysconf(_SC_PAGESIZE);
+                void *p = mmap(nullptr, kFiberStack + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+                if (p == MAP_FAILED) {
+                    *f.status = ALVA_ERR_STATE;
+                    f.done = true;
+                    continue;
+                }
+                (void) mprotect(p, page, PROT_NONE);
+                f.stack = (char *) p + page;
+                f.stack_map = p;
+            }
             getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack.data();
-            f.ctx.uc_stack.ss_size = f.stack.size();
+            f.ctx.uc_stack.ss_sp = f.stack;
+            f.ctx.uc_stack.ss_size = kFiberStack;
             f.ctx.uc_link = &sched;
             makecontext(&f.ctx, (void (*)()) & Worker::entry, 0);
             f.done = false;
         }
-        int left = n;
+        int left = 0;
+        for (int i = 0; i < n; i++) {
+            Fiber &f = fibers[(size_t) i];
+            if (f.done) {   // never started (no stack): it still counts as one of its lane's sessions of this step
+                if (f.lane) alva_lane_session_done(f.lane);
+            } else left++;
+        }
         while (left > 0)
             for (int i = 0; i < n; i++) {
-                if (fibers[(size_t) i].done) continue;
+                Fiber &f = fibers[(size_t) i];
+                if (f.done) continue;
                 current = i;
-                swapcontext(&sched, &fibers[(size_t) i].ctx);
-                if (fibers[(size_t) i].done) left--;
+                // HIP's current device is per THREAD and the fibers share this one: whatever the previous fiber set must not leak into
+                // this one's allocations and launches after a yield
+                (void) hipSetDevice(f.sys->device);
+                if (f.lane) alva_lane_tick(f.lane);
+                g_alva_lane = f.lane;
+                g_alva_lane_dirty = &f.lane_dirty;
+                const auto t_in = std::chrono::steady_clock::now();
+                swapcontext(&sched, &f.ctx);
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+                n_slices++;
+                if (dt > 1.5e-6) {   // (a slice that only looked at a completion word and yielded again is a poll, not work)
+                    t_work += dt;
+                    n_work_slices++;
+                }
+                g_alva_lane = nullptr;
+                g_alva_lane_dirty = nullptr;
+                if (f.done) {
+                    left--;
+                    if (f.lane) alva_lane_session_done(f.lane);
+                }
             }
         alva_fiber_yield = nullptr;
         g_worker = nullptr;
         current = -1;
+        t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
     }
 };
 }  // namespace
@@ -407,6 +470,10 @@ struct alva_system_group {
     std::vector<Worker> workers;
     std::vector<int> share;          // sessions of worker w in this call
     std::vector<hipStream_t> streams;   // alva_system_group_stream: streams that several sessions share (destroyed with the group)
+    std::vector<alva_lane *> lanes;     // shared launches (lane.hpp): lane k = a stream of its own + the sessions i with (i / workers) % lanes == k
+    std::vector<hipStream_t> lane_streams;
+    int n_lanes = 2;                    // ALVA_GROUP_LANES / alva_system_group_set_lanes; 0: every session launches for itself
+    bool lockstep = true;
     int stream_device = 0;
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
@@ -452,10 +519,60 @@ extern "C" int alva_system_group_stream(alva_system_group *g, int device, int in
     return ALVA_OK;
 }
 
+extern "C" int alva_system_group_set_lockstep(alva_system_group *g, int on) {
+    if (!g) return ALVA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->mu);   // (the workers are parked between two group calls)
+    g->lockstep = on != 0;
+    return ALVA_OK;
+}
+
+extern "C" int alva_system_group_time_stats(alva_system_group *g, double *out4, int reset) {
+    if (!g || !out4) return ALVA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->mu);
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (Worker &w: g->workers) {
+        out4[0] += w.t_run;
+        out4[1] += w.t_work;
+        out4[2] += (double) w.n_slices;
+        out4[3] += (double) w.n_work_slices;
+        if (reset) {
+            w.t_run = w.t_work = 0;
+            w.n_slices = w.n_work_slices = 0;
+        }
+    }
+    return ALVA_OK;
+}
+
+extern "C" int alva_system_group_set_lanes(alva_system_group *g, int n_lanes) {
+    if (!g || n_lanes < 0 || n_lanes > 64) return ALVA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->n_lanes = n_lanes;
+    return ALVA_OK;
+}
+
+extern "C" int alva_system_group_launch_stats(alva_system_group *g, long *out2) {
+    if (!g || !out2) return ALVA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->mu);
+    out2[0] = out2[1] = 0;
+    for (alva_lane *l: g->lanes)
+        if (l) {
+            long a = 0, b = 0;
+            alva_lane_stats(l, &a, &b);
+            out2[0] += a;
+            out2[1] += b;
+        }
+    return ALVA_OK;
+}
+
 extern "C" int alva_system_group_create(int n_threads, alva_system_group **out) {
     if (!out || n_threads < 1 || n_threads > 256) return ALVA_ERR_ARG;
     alva_system_group *g = new alva_system_group();
     g->workers.resize((size_t) n_threads);
+    {
+        const char *e = getenv("ALVA_GROUP_LOCKSTEP");   // default on; 0 = every session launches for itself (round 3's behaviour)
+        g->lockstep = !e || atoi(e) != 0;
+        if (const char *l = getenv("ALVA_GROUP_LANES")) g->n_lanes = atoi(l) < 0 ? 0 : (atoi(l) > 64 ? 64 : atoi(l));
+    }
     g->share.assign((size_t) n_threads, 0);
     for (int w = 0; w < n_threads; w++) g->threads.emplace_back([g, w] { g->loop(w); });
     *out = g;
@@ -470,6 +587,10 @@ extern "C" void alva_system_group_destroy(alva_system_group *g) {
     }
     g->cv_go.notify_all();
     for (std::thread &t: g->threads) t.join();
+    for (alva_lane *l: g->lanes)
+        if (l) alva_lane_destroy(l);
+    for (hipStream_t st: g->lane_streams)
+        if (st) (void) hipStreamDestroy(st);
     if (!g->streams.empty()) (void) hipSetDevice(g->stream_device);
     for (hipStream_t st: g->streams)
         if (st) (void) hipStreamDestroy(st);
@@ -490,10 +611,38 @@ extern "C" int alva_system_group_find_camera_pose_device(alva_system_group *g, i
             if ((int) wk.fibers.size() <= k) wk.fibers.resize((size_t) k + 1);
             Fiber &f = wk.fibers[(size_t) k];
             f.sys = systems[i];
+            f.lane = nullptr;
+            f.lane_dirty = false;
+            if (g->lockstep && g->n_lanes > 0 && systems[i]) {
+                // lane (i / W) % lanes: a worker's sessions sit on DIFFERENT lanes, so that it does the host half of one lane's sessions
+                // while another lane's launches run.  A lane's stream is created on the device of its first session; sessions of another
+                // device launch for themselves.
+                const size_t k = (size_t) ((i / W) % g->n_lanes);
+                if (g->lanes.size() <= k) {
+                    g->lanes.resize(k + 1, nullptr);
+                    g->lane_streams.resize(k + 1, nullptr);
+                }
+                if (!g->lanes[k]) {
+                    hipStream_t st = nullptr;
+                    if (hipSetDevice(systems[i]->device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+                        g->lane_streams[k] = st;
+                        g->lanes[k] = alva_lane_create(systems[i]->device, st);
+                    }
+                }
+                if (g->lanes[k] && alva_lane_device(g->lanes[k]) == systems[i]->device) f.lane = g->lanes[k];
+            }
             f.d_rgba = d_rgba[i];
             f.ts = timestamp_ms;
             f.pose = h_poses + 16 * (size_t) i;
             f.status = h_status + i;
+        }
+        // every lane learns how many of this step's sessions run on its stream: a kind that all of them have deposited goes out at once
+        for (size_t k = 0; k < g->lanes.size(); k++) {
+            if (!g->lanes[k]) continue;
+            int on_lane = 0;
+            for (int w = 0; w < W; w++)
+                for (int j = 0; j < g->share[(size_t) w]; j++) on_lane += g->workers[(size_t) w].fibers[(size_t) j].lane == g->lanes[k] ? 1 : 0;
+            alva_lane_begin_step(g->lanes[k], on_lane);
         }
         g->pending = W;
         g->generation++;
@@ -501,5 +650,7 @@ extern "C" int alva_system_group_find_camera_pose_device(alva_system_group *g, i
     g->cv_go.notify_all();
     std::unique_lock<std::mutex> lk(g->mu);
     g->cv_done.wait(lk, [&] { return g->pending == 0; });
+    for (alva_lane *l: g->lanes)
+        if (l) alva_lane_flush_now(l);   // (nothing is left when every session waited for its frame; a frame that tracks nothing may leave its images)
     return ALVA_OK;
 }

@@ -49,6 +49,10 @@ lib.alva_system_group_destroy.restype = None
 lib.alva_system_group_find_camera_pose_device.argtypes = [_vp, _i, _vp, _vp, _d, _vp, _vp]
 lib.alva_system_group_stream.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
 lib.alva_system_set_stream.argtypes = [_vp, _vp]
+lib.alva_system_group_set_lockstep.argtypes = [_vp, _i]
+lib.alva_system_group_launch_stats.argtypes = [_vp, _vp]
+lib.alva_system_group_set_lanes.argtypes = [_vp, _i]
+lib.alva_system_group_time_stats.argtypes = [_vp, _vp, _i]
 
 
 def camera_intrinsics(width: int, height: int, fov: float = 45.0):
@@ -272,6 +276,30 @@ class SystemGroup:
         if lib.alva_system_group_stream(self.h, device, index, C.byref(st)):
             raise AlvaError("alva_system_group_stream failed")
         return st
+
+    def set_lockstep(self, on: bool):
+        """lock-step launches (include/alvaar_system.h): one launch per kernel kind for the sessions of a worker that share a stream"""
+        if lib.alva_system_group_set_lockstep(self.h, 1 if on else 0):
+            raise AlvaError("alva_system_group_set_lockstep failed")
+
+    def set_lanes(self, lanes: int):
+        """number of lanes (group-owned streams that carry the shared tracking-chain launches); session i -> lane (i // n_threads) % lanes"""
+        if lib.alva_system_group_set_lanes(self.h, int(lanes)):
+            raise AlvaError("alva_system_group_set_lanes failed")
+
+    def time_stats(self, reset: bool = True):
+        """workers' seconds inside group steps, seconds of them inside session slices that did work (not polls), slices, working slices"""
+        out = (C.c_double * 4)()
+        if lib.alva_system_group_time_stats(self.h, out, 1 if reset else 0):
+            raise AlvaError("alva_system_group_time_stats failed")
+        return float(out[0]), float(out[1]), int(out[2]), int(out[3])
+
+    def launch_stats(self):
+        """(combined launches issued, session launches they carried) since the group was created"""
+        out = (C.c_long * 2)()
+        if lib.alva_system_group_launch_stats(self.h, out):
+            raise AlvaError("alva_system_group_launch_stats failed")
+        return int(out[0]), int(out[1])
 
     def set_sessions(self, sessions):
         self.sessions = list(sessions)

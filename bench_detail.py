@@ -203,14 +203,29 @@ def bench_system_streams(device: int, n_streams: int, steps: int = 300):
             "note": "S independent alva::System sessions on one GPU, one host thread each (Python threads; the C call releases the GIL), frames resident in HBM"}
 
 
-def bench_system_group(device: int, n_sessions: int, n_threads: int, steps: int = 200, n_streams: int = 0):
+def _cpu_throttled():
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines()) if k in ("nr_throttled", "throttled_usec", "usage_usec")}
+    except Exception:
+        return {}
+
+
+def bench_system_group(device: int, n_sessions: int, n_threads: int, steps: int = 200, n_streams: int = 0, lockstep: bool = True, lanes: int = 2,
+                       stagger: int = 0):
     """S independent alva::System sessions on ONE GPU through alva_system_group: W host threads, the sessions as fibers -- a session's
-    waits for the GPU run the thread's other sessions, so the threads execute map-layer work only.  All sessions replay the same resident
-    stream in lock-step (keyframes coincide: the worst case for the host).  Aggregate frames/s in the steady state."""
+    waits for the GPU run the thread's other sessions, so the threads execute map-layer work only.  Session i runs on worker i % W and
+    belongs to lane (i // W) % lanes: with lock-step launches (include/alvaar_system.h) the seven launches of a lane's tracking frames
+    are issued once per kind for all of its sessions, on the lane's stream, while the workers do the host half of the other lanes'
+    sessions; every session keeps a stream of its own for its keyframe stages (n_streams = 0; k > 0: session i on shared stream
+    (i % W) % k).  stagger = 0: all sessions replay the same resident stream in lock-step (keyframes coincide on one group step: the
+    worst case); stagger = d: session i is d * i frames ahead in the stream, so the sessions' keyframes spread over the keyframe period
+    as those of independent cameras do.  Aggregate frames/s in the steady state."""
     from alvaar_amd.system import AlvaAR, SystemGroup
     base = SystemJob(device, 7, host_copy=False)
     group = SystemGroup([], n_threads)
-    if n_streams > 0:   # sessions share n_streams HIP streams (session i -> worker i % n_threads -> stream (i % n_threads) % n_streams)
+    group.set_lockstep(lockstep)
+    group.set_lanes(lanes)
+    if n_streams > 0:
         base.ar.close()
         sessions = [AlvaAR(W, H, device=device, cell_size=SYSTEM_CELL, random_sampling=False, hip_stream=group.stream((i % n_threads) % n_streams, device))
                     for i in range(n_sessions)]
@@ -222,24 +237,47 @@ def bench_system_group(device: int, n_sessions: int, n_threads: int, steps: int 
 
     def step():
         nonlocal k
-        ptr = base.ptrs[stream_index(k)]
-        st = group.step_device([ptr] * n_sessions, 33.0 * k)
+        st = group.step_device([base.ptrs[stream_index(k + stagger * i)] for i in range(n_sessions)], 33.0 * k)
         k += 1
         return st
     while int(base.ar.state()[11]) < 34 and k < 2500:   # steady state: the 30-keyframe window full
         step()
+    l0, c0 = group.launch_stats()
+    group.time_stats()
+    thr0 = _cpu_throttled()
+    kf0 = int(base.ar.state()[11])
     t0 = time.perf_counter()
     tracked = 0
+    step_ms, kf_seen = [], kf0
     for _ in range(steps):
+        ts = time.perf_counter()
         tracked += int((step() == 1).sum())
+        kf_now = int(base.ar.state()[11])
+        step_ms.append(((time.perf_counter() - ts) * 1e3, kf_now != kf_seen))
+        kf_seen = kf_now
     dt = time.perf_counter() - t0
-    group.close()
+    trk = sorted(m for m, is_kf in step_ms if not is_kf)
+    kfs = [m for m, is_kf in step_ms if is_kf]
+    l1, c1 = group.launch_stats()
+    t_run, t_work, n_slices, n_work = group.time_stats()
+    thr1 = _cpu_throttled()
+    kf = int(base.ar.state()[11]) - kf0
     for s in sessions:
         s.close()
-    return {"sessions": n_sessions, "host_threads": n_threads, "hip_streams": n_streams or n_sessions, "frames_per_s": n_sessions * steps / dt, "ms_per_group_step": dt / steps * 1e3,
-            "tracked_frac": tracked / (n_sessions * steps),
+    group.close()
+    return {"sessions": n_sessions, "host_threads": n_threads, "session_streams": n_streams or n_sessions, "lockstep": lockstep,
+            "lanes": lanes if lockstep else 0,
+            "frames_per_s": n_sessions * steps / dt, "ms_per_group_step": dt / steps * 1e3, "keyframes_per_session": kf,
+            "tracked_frac": tracked / (n_sessions * steps), "stagger_frames": stagger,
+            "ms_tracking_step_median": round(trk[len(trk) // 2], 3) if trk else None, "ms_keyframe_step_mean": round(sum(kfs) / len(kfs), 3) if kfs else None,
+            "keyframe_steps": len(kfs),
+            "worker_busy_frac": round(t_work / max(t_run, 1e-9), 3), "host_work_us_per_frame": round(1e6 * t_work / (n_sessions * steps), 1),
+            "worker_slices_per_frame": round(n_slices / (n_sessions * steps), 1),
+            "cgroup_cpu": {k_: thr1.get(k_, 0) - thr0.get(k_, 0) for k_ in thr1}, "process_cpu_cores_used": round((thr1.get("usage_usec", 0) - thr0.get("usage_usec", 0)) / (dt * 1e6), 2) if thr1 else None,
+            "chain_launches_issued_per_group_step": round((l1 - l0) / steps, 2), "session_launches_carried_per_group_step": round((c1 - c0) / steps, 2),
             "note": "alva_system_group: sessions are fibers on the worker threads (a wait for the GPU switches to the thread's next session); "
-                    "frames resident in HBM, every session its own map / streams / kernels"}
+                    "frames resident in HBM, every session its own map / pyramids / kernels' work; lockstep: one launch per kernel kind for the "
+                    "sessions of a lane (lane.hpp)"}
 
 
 def bench_multi_stream(device: int, n_streams: int, steps: int, warmup: int = 5):
@@ -605,7 +643,8 @@ def run_secondary(local: int, seed: int, steps: int, bctx, ba_pb, peaks, is720: 
         except Exception as e:   # noqa: BLE001 -- a secondary line must not take the record down
             out[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
-    guarded("system_group", lambda: [bench_system_group(local, s_, 8) for s_ in group_sessions])
+    guarded("system_group", lambda: [bench_system_group(local, s_, 8) for s_ in group_sessions] +
+            [bench_system_group(local, 32, 8, lockstep=False)])
     guarded("system_streams", lambda: [bench_system_streams(local, c_) for c_ in (4, 8)])
     if not is720:
         guarded("system_720p", lambda: run_system_line(local, seed, 1280, 720, 15, steps))
@@ -641,6 +680,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma-separated line names (e.g. system_group)")
     ap.add_argument("--sessions", type=str, default="8,16,32,64")
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--stagger", type=int, default=0)
+    ap.add_argument("--no-lockstep", action="store_true")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     bctx = alvaar_amd.Context(0)
@@ -648,7 +692,8 @@ def main():
         res = {}
         for name in args.only.split(","):
             if name == "system_group":
-                res[name] = [bench_system_group(0, int(s_), 8) for s_ in args.sessions.split(",")]
+                res[name] = [bench_system_group(0, int(s_), args.threads, lockstep=not args.no_lockstep, n_streams=args.streams, lanes=args.lanes, stagger=args.stagger)
+                             for s_ in args.sessions.split(",")]
             elif name == "system_streams":
                 res[name] = [bench_system_streams(0, c_) for c_ in (4, 8)]
             elif name == "system_720p":

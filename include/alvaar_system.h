@@ -47,12 +47,6 @@ void alva_system_reset(alva_system *sys);
 /* System::findCameraPose (system.cpp:106-121).  h_rgba: width*height*4 bytes, caller-owned, read-only to the callee and not retained
  * beyond the call; h_pose: float[16].  By default the frame is copied through a pinned staging buffer. */
 int alva_system_find_camera_pose(alva_system *sys, const uint8_t *h_rgba, float *h_pose);
-/* Optional, for a caller that reuses ONE frame buffer the way src/system.js reuses its memImg (:63-67, :175): page-lock and map
- * `bytes` (>= width*height*4, 16-byte aligned) at h_rgba.  Frames passed from inside the registered range are then read in place
- * over PCIe by the gray / pyramid kernel (no staging copy, no copy command); every find_camera_pose* call still returns only after the
- * GPU has finished reading the buffer.  The registration is the caller's promise that the memory stays allocated until
- * alva_system_unregister_frame_buffer / alva_system_configure / alva_system_destroy; one buffer per system (a second call replaces
- * the first).  Must be called after alva_system_configure. */
 /* ---- many sessions on a few host threads (no reference counterpart: the reference is one System per process / worker).  A group
  * owns n_threads worker threads; alva_system_group_find_camera_pose_device runs ONE frame of each of `count` configured systems
  * (session i: frame d_rgba[i] in device memory, pose -> h_poses[16 i ..], status / error code -> h_status[i]) and returns when all are
@@ -70,6 +64,28 @@ int alva_system_group_stream(alva_system_group *group, int device, int index, vo
 int alva_system_set_stream(alva_system *sys, void *hip_stream);
 int alva_system_group_find_camera_pose_device(alva_system_group *group, int count, alva_system *const *systems, const uint8_t *const *d_rgba,
                                               double timestamp_ms, float *h_poses, int *h_status);
+/* LOCK-STEP LAUNCHES (default on; ALVA_GROUP_LOCKSTEP=0 or alva_system_group_set_lockstep(group, 0) turns them off).  The group owns
+ * `lanes` streams of its own (default 2; ALVA_GROUP_LANES / alva_system_group_set_lanes; 0 = none); session i of a call runs on worker
+ * i % n_threads and belongs to lane (i / n_threads) % lanes.  The seven launches of a tracking frame -- gray + pyramid level 0, pyramid,
+ * slot table, fb-KLT, compaction, P3P-LMedS, PnP -- are issued ONCE PER KIND for all sessions of a lane (blockIdx.y = session; the
+ * argument blocks ride in the kernel arguments) on the lane's stream, by the thread whose session completes the set, instead of seven per
+ * session: S side-by-side chains of small kernels saturate the GPU's command path and wave slots long before its arithmetic.  A worker
+ * holds sessions of different lanes and does the host half of one lane's sessions while another lane's launches run.  Everything else a
+ * session launches (keyframe stages, local BA) stays on the session's own stream.  Results are unchanged bit for bit (same arithmetic
+ * per slot / hypothesis / correspondence).  alva_system_group_launch_stats: out2 = {combined launches issued, session launches they
+ * carried}. */
+int alva_system_group_set_lanes(alva_system_group *group, int lanes);
+/* summed over the workers since the last reset: out4 = {seconds inside group steps, seconds inside session slices that did more than
+ * look at a completion word, slices, slices that did work} -- how much of the workers' time is map-layer work and how much is waiting */
+int alva_system_group_time_stats(alva_system_group *group, double *out4, int reset);
+int alva_system_group_set_lockstep(alva_system_group *group, int on);
+int alva_system_group_launch_stats(alva_system_group *group, long *out2);
+/* Optional, for a caller that reuses ONE frame buffer the way src/system.js reuses its memImg (:63-67, :175): page-lock and map
+ * `bytes` (>= width*height*4, 16-byte aligned) at h_rgba.  Frames passed from inside the registered range are then read in place
+ * over PCIe by the gray / pyramid kernel (no staging copy, no copy command); every find_camera_pose* call still returns only after the
+ * GPU has finished reading the buffer.  The registration is the caller's promise that the memory stays allocated until
+ * alva_system_unregister_frame_buffer / alva_system_configure / alva_system_destroy; one buffer per system (a second call replaces
+ * the first).  Must be called after alva_system_configure. */
 int alva_system_register_frame_buffer(alva_system *sys, const uint8_t *h_rgba, size_t bytes);
 int alva_system_unregister_frame_buffer(alva_system *sys);
 /* The same with the frame's timestamp (milliseconds) as an argument instead of the system clock (system.cpp:114): the

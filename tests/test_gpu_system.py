@@ -474,10 +474,14 @@ def test_concurrent_sessions_equal_their_solo_runs():
             assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), (s, k)
 
 
-def test_group_sessions_equal_their_solo_runs():
+@pytest.mark.parametrize("mode", ["one_lane", "three_lanes", "two_lanes_shared_session_streams", "no_lockstep"])
+def test_group_sessions_equal_their_solo_runs(mode):
     """alva_system_group: six sessions (different grids / streams, one 1280x720) advanced frame by frame on TWO host threads -- three
     fibers per thread, every GPU wait of a session running the thread's other sessions: statuses, poses (bitwise), keypoint ids and
-    pixels (bitwise) and the counters are those of each session's solo run"""
+    pixels (bitwise) and the counters are those of each session's solo run.  With lanes (lane.hpp) the launches of the sessions' tracking
+    frames are issued once per kind for all sessions of a lane -- sessions of different image sizes and keypoint counts in one launch,
+    deposits arriving from both worker threads -- and the launch statistics must show that they really were shared.  one_lane: all six
+    sessions; three_lanes: two each (one per worker); two_lanes_shared_session_streams: the sessions' OWN streams are shared too."""
     import torch
     from alvaar_amd.system import AlvaAR, SystemGroup
     specs = [(640, 480, 40, 7, False), (640, 480, 12, 5, True), (640, 480, 24, 9, False), (640, 480, 12, 7, False), (1280, 720, 15, 9, True),
@@ -504,8 +508,13 @@ def test_group_sessions_equal_their_solo_runs():
         rec.append(ar.counters())
         ar.close()
         solo.append(rec)
-    sessions = [AlvaAR(w, h, cell_size=cell, random_sampling=False) for w, h, cell, seed, noise in specs]
-    group = SystemGroup(sessions, 2)
+    group = SystemGroup([], 2)
+    group.set_lockstep(mode != "no_lockstep")
+    group.set_lanes({"one_lane": 1, "three_lanes": 3}.get(mode, 2))
+    shared = mode == "two_lanes_shared_session_streams"
+    sessions = [AlvaAR(w, h, cell_size=cell, random_sampling=False, hip_stream=group.stream(i % 2) if shared else None)
+                for i, (w, h, cell, seed, noise) in enumerate(specs)]
+    group.set_sessions(sessions)
     together = [[] for _ in specs]
     for k in range(n):
         st = group.step_device([int(fr[k].data_ptr()) for fr in dev], 33.0 * k)
@@ -513,9 +522,14 @@ def test_group_sessions_equal_their_solo_runs():
             together[i].append((int(st[i]),) + record(ar))
     for i, ar in enumerate(sessions):
         together[i].append(ar.counters())
-    group.close()
+    launches, carried = group.launch_stats()
     for ar in sessions:
         ar.close()
+    group.close()
+    if mode == "no_lockstep":
+        assert launches == 0                                       # no lane: every session launches for itself
+    else:
+        assert carried > 1.2 * launches > 0, (mode, launches, carried)   # (sessions of different sizes, not all tracking at once)
     for i, (a, b) in enumerate(zip(solo, together)):
         assert a[-1] == b[-1] and a[-1]["ba_solves"] >= 1, (i, a[-1], b[-1])
         for k in range(n):
