@@ -743,3 +743,72 @@ def frontend_run_many(fes, steps, warmup, frames, pts, bearings, uv, wpts, K):
     check(lib.alva_frontend_run_many(a_fe, n, steps, warmup, a_fr, ring, frames[0].stride(1), a_pts, pts[0].shape[0], a_bv, a_uv, a_wp,
                                      bearings[0].shape[0], K[0], K[1], K[2], K[3], C.byref(secs), C.byref(acc)))
     return secs.value, acc.value
+
+
+import numpy as np  # noqa: E402  (MedoidStore builds its operation records with numpy)
+
+
+class MedoidStore:
+    """alva_medoid_store (include/alvaar_hip.h, f1): the map points' descriptor tables on the device, edited by replaying operation logs.
+    ops: list of (mp_slot, op, kf, desc32 | None, rehash_to) in program order (op 0 add, 1 remove, 2 clear, 3 reset)."""
+    OP = np.dtype([("op", "<i4"), ("kf", "<i4"), ("rehash_to", "<i4"), ("next", "<i4"), ("desc", "u1", 32), ("pad", "<i4", 4)])
+    TABLE_SLOT = np.dtype([("key", "<i4"), ("next", "<i4"), ("dist", "<f4"), ("pad", "<i4"), ("desc", "u1", 32)])
+
+    def __init__(self, ctx: "Context"):
+        lib.alva_medoid_store_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.alva_medoid_store_destroy.argtypes = [C.c_void_p]
+        lib.alva_medoid_store_destroy.restype = None
+        lib.alva_medoid_replay.argtypes = [C.c_void_p, _i, C.c_void_p, _i, C.c_void_p, C.c_void_p, _i]
+        lib.alva_medoid_export.argtypes = [C.c_void_p, _i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.alva_medoid_dump.argtypes = [C.c_void_p, _i, C.c_void_p, C.c_size_t]
+        lib.alva_medoid_table_bytes.restype = C.c_size_t
+        lib.alva_medoid_op_bytes.restype = C.c_size_t
+        assert lib.alva_medoid_op_bytes() == self.OP.itemsize
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        check(lib.alva_medoid_store_create(ctx.h, C.byref(self.h)))
+
+    def replay(self, ops, slots: int):
+        rec = np.zeros(len(ops), self.OP)
+        first, last, touched = {}, {}, []
+        for i, (slot, op, kf, desc, rehash_to) in enumerate(ops):
+            rec[i]["op"], rec[i]["kf"], rec[i]["rehash_to"], rec[i]["next"] = op, kf, rehash_to, -1
+            if desc is not None:
+                rec[i]["desc"] = desc
+            if slot in last:
+                rec[last[slot]]["next"] = i
+            else:
+                first[slot] = i
+                touched.append(slot)
+            last[slot] = i
+        mp = np.array(touched, np.int32)
+        fo = np.array([first[s] for s in touched], np.int32)
+        check(lib.alva_medoid_replay(self.h, len(ops), rec.ctypes.data, len(mp), mp.ctypes.data, fo.ctypes.data, int(slots)))
+
+    def export(self, slots):
+        s = np.ascontiguousarray(slots, np.int32)
+        desc, valid, info = np.zeros((len(s), 32), np.uint8), np.zeros(len(s), np.uint8), np.zeros((len(s), 3), np.int32)
+        check(lib.alva_medoid_export(self.h, len(s), s.ctypes.data, desc.ctypes.data, valid.ctypes.data, info.ctypes.data))
+        return desc, valid, info
+
+    def dump(self, slot: int):
+        """the raw table of one map point -> (medoid bytes, has medoid, [(key, dist)] in the container's iteration order, bucket count)"""
+        n = lib.alva_medoid_table_bytes()
+        raw = np.zeros(n, np.uint8)
+        check(lib.alva_medoid_dump(self.h, int(slot), raw.ctypes.data, n))
+        hdr = raw[:32].view(np.int32)   # head, free, count, nbkt, used, medoid_valid, overflow, medoid_kf
+        cap = 48                        # alva_medoid::CAP (csrc/slam/medoid_table.hpp): 64-byte header | CAP slots | 59 bucket heads + pad
+        assert n == 64 + cap * self.TABLE_SLOT.itemsize + 60 * 4, "medoid table layout changed"
+        slots = raw[64:64 + cap * self.TABLE_SLOT.itemsize].view(self.TABLE_SLOT)
+        out, s = [], int(hdr[0])
+        while s != -1 and len(out) <= cap:
+            out.append((int(slots[s]["key"]), float(slots[s]["dist"])))
+            s = int(slots[s]["next"])
+        return raw[32:64].copy(), bool(hdr[5]), out, int(hdr[3]), bool(hdr[6])
+
+    def close(self):
+        if self.h:
+            lib.alva_medoid_store_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close

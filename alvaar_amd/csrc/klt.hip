@@ -1210,6 +1210,7 @@ int alva_fbklt_track_dn(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyra
 int alva_track_slots_klt(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyramid *curr, const TrackSlots &D, int levels_prior, int levels_full,
                          float err_thresh, float fb_dist, int max_iters, float eps, int retry) {
     ALVA_ARG(ctx && prev && curr && D.n >= 0 && levels_prior >= 0 && levels_full >= 0);
+    ALVA_ARG(D.n < 65536);   // the packed counter of the tracker launch gives 16 bits to each count (track_slots.hpp)
     if (D.n == 0) return ALVA_OK;
     ALVA_ARG(prev->win == WIN && curr->win == WIN);
     ALVA_ARG(prev->nlevels == curr->nlevels && prev->lv[0].w == curr->lv[0].w && prev->lv[0].h == curr->lv[0].h);

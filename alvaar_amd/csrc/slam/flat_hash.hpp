@@ -34,6 +34,17 @@ public:
     static constexpr int END = -1;
 
     FlatHash() : bkt_(1, EMPTY) {}
+    FlatHash(const FlatHash &) = default;
+    FlatHash &operator=(const FlatHash &) = default;
+    // moves leave the source a valid EMPTY container (a moved-from vector would leave bucket_of() dividing by a bucket count of zero)
+    FlatHash(FlatHash &&o) : FlatHash() { swap(o); }
+    FlatHash &operator=(FlatHash &&o) {
+        if (this != &o) {
+            reset();
+            swap(o);
+        }
+        return *this;
+    }
 
     size_t size() const { return count_; }
     bool empty() const { return count_ == 0; }

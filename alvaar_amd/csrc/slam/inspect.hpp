@@ -70,11 +70,13 @@ inline int inspect_covisibility(const Slam &s, int kfid, int cap, int *pairs) {
     return n;
 }
 
-// ascending id; flags[5i..] = is3d, observed, #observing keyframes, anchor keyframe, #descriptors
-inline int inspect_map_points(const Slam &s, int cap, int *ids, double *xyz, int *flags, double *inv_depth, uint8_t *desc) {
+// ascending id; flags[5i..] = is3d, observed, #observing keyframes, anchor keyframe, #descriptors; desc = desc_ (the descriptor medoid,
+// fetched from the stages' tables: pending edits are replayed first)
+inline int inspect_map_points(Slam &s, int cap, int *ids, double *xyz, int *flags, double *inv_depth, uint8_t *desc) {
     std::vector<int> v;
     for (const auto &e: s.map_points) v.push_back(e.first);
     std::sort(v.begin(), v.end());
+    std::vector<int> slots;
     for (size_t i = 0; i < v.size() && (int) i < cap; i++) {
         const MapPt &m = *s.map_points.at(v[i]);
         ids[i] = v[i];
@@ -84,9 +86,19 @@ inline int inspect_map_points(const Slam &s, int cap, int *ids, double *xyz, int
             flags[5 * i + 4] = (int) m.kf_desc.size();
         }
         if (inv_depth) inv_depth[i] = m.inv_depth;
-        if (desc) {
-            if (m.has_desc) std::memcpy(desc + 32 * i, m.desc.b, 32);
-            else std::memset(desc + 32 * i, 0, 32);
+        slots.push_back(m.dev_slot);
+    }
+    if (desc && !slots.empty()) {
+        s.flush_medoids();
+        std::vector<uint8_t> valid(slots.size());
+        std::vector<int> info(3 * slots.size());
+        const int rc = s.st->medoid_export((int) slots.size(), slots.data(), desc, valid.data(), info.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < slots.size(); i++) {
+            const MapPt &m = *s.map_points.at(v[i]);
+            // the map layer's own view of the same table must agree with the stages' (key count; desc_ present) and nothing may have overflowed
+            if (info[3 * i + 2] || info[3 * i] != (int) m.kf_desc.size() || (valid[i] != 0) != m.has_desc) return -5;
+            if (!valid[i]) std::memset(desc + 32 * i, 0, 32);
         }
     }
     return (int) v.size();

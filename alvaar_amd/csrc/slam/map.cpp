@@ -209,60 +209,24 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
         has_desc = false;
         kf_desc.clear();
         drop_all_desc();
+        mlog->push(dev_slot, alva_medoid::OP_CLEAR, -1, nullptr, 0);
         return;
     }
     if (kf == anchor_kf) anchor_kf = *obs_kfs.begin();
-    float min_dist = (has_desc ? 32 : 0) * 8.f;  // desc_.cols * 8.
-    int min_id = -1;
-    const int sd = kf_desc.find_slot(kf);
-    if (sd != FlatHash<DescEntry>::END) {
-        const Desc mine = kf_desc.val(sd).d;
-        for (int se = kf_desc.first(); se != FlatHash<DescEntry>::END; se = kf_desc.next(se)) {
-            if (se != sd) {
-                DescEntry &e = kf_desc.val(se);
-                const float dist = (float) popcount256(mine, e.d);
-                float &dd = e.dist;
-                dd -= dist;
-                if (dd < min_dist) {
-                    min_dist = dd;
-                    min_id = kf_desc.key(se);
-                }
-            }
-        }
-        kf_desc.erase_slot(sd);
+    // :93-128: the distances of the remaining descriptors, the new desc_ -- in the stages' table (medoid_table.hpp remove_desc)
+    if (kf_desc.erase(kf)) {
         drop_desc(kf);
-        if (min_id > 0) {  // sic: keyframe 0 is never chosen (:123)
-            desc = kf_desc.at(min_id).d;
-            has_desc = true;
-        }
+        mlog->push(dev_slot, alva_medoid::OP_REMOVE, kf, nullptr, 0);
     }
 }
 
-void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid)
-    const std::pair<int, bool> ins = kf_desc.insert_slot(kf, DescEntry{d, 0.f});
-    if (!ins.second) return;
+void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid: medoid_table.hpp add_desc)
+    const size_t buckets = kf_desc.bucket_count();
+    if (!kf_desc.insert_slot(kf).second) return;
     note_desc(kf, d);
-    if (kf_desc.size() == 1) {
-        desc = d;
-        has_desc = true;
-        return;
-    }
-    float min_dist = (has_desc ? 32 : 0) * 8.f;
-    int min_id = -1;
-    float &nd = kf_desc.val(ins.first).dist;   // no insert below: the reference stays valid
-    for (int se = kf_desc.first(); se != FlatHash<DescEntry>::END; se = kf_desc.next(se)) {
-        DescEntry &e = kf_desc.val(se);
-        const float dist = (float) popcount256(d, e.d);
-        e.dist += dist;   // includes the new entry itself (distance 0 to itself, :157-166)
-        if (dist < min_dist) {
-            min_dist = dist;
-            min_id = kf_desc.key(se);
-        }
-        nd += dist;
-    }
-    if (nd < min_dist) min_id = kf;
-    desc = kf_desc.at(min_id).d;  // throws like the reference if no candidate (cannot happen with a non-empty desc_)
-    has_desc = true;
+    has_desc = true;   // desc_ is never empty again until the last observation goes
+    // the bucket count of the rehash this insert caused, if any: the table in the stages replays the list surgery, not the growth policy
+    mlog->push(dev_slot, alva_medoid::OP_ADD, kf, d.b, kf_desc.bucket_count() != buckets ? (int) kf_desc.bucket_count() : 0);
 }
 
 bool MapPt::is_bad() {  // map_point.cpp:183-202
@@ -287,6 +251,21 @@ std::shared_ptr<FrameRec> Slam::keyframe(int id) const {
 std::shared_ptr<MapPt> Slam::map_point(int id) const {
     auto it = map_points.find(id);
     return it == map_points.end() ? nullptr : it->second;
+}
+
+void Slam::flush_medoids() {
+    MedoidLog &L = med_log;
+    if (L.ops.empty()) return;
+    std::vector<int> &firsts = med_firsts_;
+    firsts.resize(L.touched.size());
+    for (size_t i = 0; i < L.touched.size(); i++) {
+        const size_t s = (size_t) L.touched[i];
+        firsts[i] = L.first_op[s];
+        L.first_op[s] = L.last_op[s] = -1;
+    }
+    fail(st->medoid_replay((int) L.ops.size(), L.ops.data(), (int) L.touched.size(), L.touched.data(), firsts.data(), L.next_slot));
+    L.ops.clear();
+    L.touched.clear();
 }
 
 void Slam::create_keyframe() {  // map_manager.cpp:12-22
@@ -455,7 +434,7 @@ void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of 
 }
 
 void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
-    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(next_mp_id, next_kf_id);
+    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(&med_log, next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(&med_log, next_mp_id, next_kf_id);
     map_points.emplace(next_mp_id, mp);
     if (mp_flat_.size() <= (size_t) next_mp_id) {
         mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
@@ -491,7 +470,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
     const SortedIds next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
-    const FlatHash<DescEntry> prev_desc = prev->kf_desc;   // a copy, in the original's order
+    const FlatHash<FlatNoValue> prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;
@@ -509,7 +488,12 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
             }
         }
     }
-    for (const auto &e: prev_desc) nw->add_desc(e.first, e.second.d);
+    for (int se = prev_desc.first(); se != FlatHash<FlatNoValue>::END; se = prev_desc.next(se)) {
+        // (the descriptor bytes of prev's entry: its mirror holds them, see ObsPx)
+        const ObsPx *o = prev->seen_in(prev_desc.key(se));
+        if (!o || !o->has_desc) throw std::out_of_range("descriptor mirror");
+        nw->add_desc(prev_desc.key(se), o->desc);
+    }
     if (cur->observes(prev_id)) {
         if (cur->change_id(prev_id, new_id, nw->is3d)) set_map_point_obs(new_id);
     }

@@ -51,6 +51,7 @@ void Slam::process_new_keyframe(int kfid) {  // mapper.cpp:9-64
     lap(t_kf[7]);
     optimize(kf);
     lap(t_kf[8]);
+    flush_medoids();   // this keyframe's descriptor-table edits (new descriptors, merges, culled observations) go to the stages in one piece
 }
 
 void Slam::triangulate_temporal(FrameRec &frame) {  // mapper.cpp:144-291
@@ -294,8 +295,7 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             // one 32-byte slot per observation; keyframes in which the keypoint could not be described (within 31 px of the border,
             // feature_extractor.cpp:191-209) have no entry in mapKeyframeDescriptors_: slot zeroed and flagged
             if (check_obs_mirror_) {
-                auto d = mp.kf_desc.find(kf);
-                if ((d != mp.kf_desc.end()) != (kk->has_desc != 0) || (kk->has_desc && std::memcmp(d->second.d.b, kk->desc.b, 32))) {
+                if ((mp.kf_desc.count(kf) != 0) != (kk->has_desc != 0)) {
                     std::fprintf(stderr, "alva_slam: descriptor mirror out of sync (map point %d, keyframe %d)\n", mp.id, kf);
                     std::abort();
                 }

@@ -248,9 +248,42 @@ struct ObsPx {
     Desc desc{};
 };
 
-struct DescEntry {
-    Desc d;
-    float dist;
+// The operation log of the map points' descriptor tables (Stages::medoid_replay, medoid_table.hpp) + the allocator of their slots.
+// The map layer edits the KEY sets (MapPt::kf_desc) at once -- its control flow reads nothing else -- and appends what happened here;
+// Slam::flush_medoids hands the log to the stages once per keyframe.
+struct MedoidLog {
+    std::vector<alva_medoid::MedoidOp> ops;
+    std::vector<int> touched;                 // slots with operations in `ops`, in first-touch order
+    std::vector<int> first_op, last_op;       // per slot: chain head / tail in `ops`, -1 = none
+    std::vector<int> free_slots;
+    int next_slot = 0;
+    int alloc() {
+        int s;
+        if (!free_slots.empty()) {
+            s = free_slots.back();
+            free_slots.pop_back();
+        } else {
+            s = next_slot++;
+            first_op.push_back(-1);
+            last_op.push_back(-1);
+        }
+        push(s, alva_medoid::OP_RESET, -1, nullptr, 0);   // whoever had the slot before: a fresh table
+        return s;
+    }
+    void release(int s) { free_slots.push_back(s); }
+    void push(int slot, int op, int kf, const uint8_t *desc, int rehash_to) {
+        alva_medoid::MedoidOp o{};
+        o.op = op; o.kf = kf; o.rehash_to = rehash_to; o.next = -1;
+        if (desc) std::memcpy(o.desc, desc, 32);
+        const int idx = (int) ops.size();
+        ops.push_back(o);
+        if (last_op[(size_t) slot] >= 0) ops[(size_t) last_op[(size_t) slot]].next = idx;
+        else {
+            first_op[(size_t) slot] = idx;
+            touched.push_back(slot);
+        }
+        last_op[(size_t) slot] = idx;
+    }
 };
 
 // class MapPoint, map_point.hpp:27-86
@@ -261,22 +294,23 @@ struct MapPt {
     double X[3] = {0, 0, 0};
     int anchor_kf = -1;                          // keyframeId_
     double inv_depth = -1.;
-    Desc desc{};
     bool has_desc = false;                       // !desc_.empty()
-    // mapKeyframeDescriptors_ and mapDescriptorsDist_ in one table: the reference edits the two unordered_maps together (same keys,
-    // same sequence => same iteration order), reads the distances by key only, and walks the descriptors -- in libstdc++'s order, on
-    // flat arrays (flat_hash.hpp): the medoid loops of addDesc / removeObservedKeyframeId read contiguous 48-byte slots
-    FlatHash<DescEntry> kf_desc;
+    // the KEYS of mapKeyframeDescriptors_ / mapDescriptorsDist_ (the reference edits the two unordered_maps together: same keys, same
+    // sequence => same iteration order) in libstdc++'s order (flat_hash.hpp).  The descriptors, the distance sums and desc_ itself live
+    // in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`, nothing of them is read back by the map layer
+    FlatHash<FlatNoValue> kf_desc;
+    MedoidLog *mlog = nullptr;
+    int dev_slot = -1;
     std::vector<ObsPx> seen;                     // see ObsPx
 
-    MapPt(int id_, int kf) : id(id_), anchor_kf(kf) { obs_kfs.insert(kf); }
-    MapPt(int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf) {
+    MapPt(MedoidLog *log, int id_, int kf) : id(id_), anchor_kf(kf), mlog(log), dev_slot(log->alloc()) { obs_kfs.insert(kf); }
+    MapPt(MedoidLog *log, int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf), mlog(log), dev_slot(log->alloc()) {
         obs_kfs.insert(kf);
-        kf_desc.emplace(kf, DescEntry{d, 0.f});
-        note_desc(kf, d);
-        desc = d;
-        has_desc = true;
+        add_desc(kf, d);
     }
+    MapPt(const MapPt &) = delete;
+    MapPt &operator=(const MapPt &) = delete;
+    ~MapPt() { mlog->release(dev_slot); }
     void remove_obs(int kf);
     void add_desc(int kf, const Desc &d);
     bool is_bad();
@@ -352,6 +386,9 @@ public:
     Camera cam;
     Settings cfg;
     double invK[9];
+    MedoidLog med_log;                                               // (declared before the map points: they release their slots into it)
+    void flush_medoids();                                            // hand the logged descriptor-table edits to the stages (once per keyframe)
+    std::vector<int> med_firsts_;
     std::shared_ptr<FrameRec> cur;                                   // currFrame_
     std::unordered_map<int, std::shared_ptr<FrameRec>> keyframes;    // MapManager::mapKeyframes_
     std::unordered_map<int, std::shared_ptr<MapPt>> map_points;      // MapManager::mapMapPoints_
@@ -474,7 +511,7 @@ private:
             const MapPt *m = mp_raw(ids[i + near_d]);
             if (m) {
                 const char *t = (const char *) m->kf_desc.slot_storage();
-                const size_t bytes = m->kf_desc.slots() * 48;
+                const size_t bytes = m->kf_desc.slots() * 12;
                 for (size_t o = 0; o < bytes && o < 1024; o += 64) __builtin_prefetch(t + o);
                 __builtin_prefetch(m->seen.data());
                 __builtin_prefetch(m->obs_kfs.v.data());

@@ -9,7 +9,9 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <vector>
+#include "medoid_table.hpp"
 
 namespace alva_slam {
 
@@ -149,6 +151,40 @@ struct Stages {
                          double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters,
                          double *chi2, uint8_t *depth_pos) = 0;
 
+    // MapPoint's descriptor tables and medoids (map_point.cpp:73-181; medoid_table.hpp) as a replayed operation log: the map layer keeps
+    // only the KEY sets of the tables (its control flow needs nothing else) and logs every edit -- addDesc, the descriptor half of
+    // removeObservedKeyframeId, the release when the last observation goes, a new map point -- per map point SLOT (slots are recycled;
+    // `slots` = highest slot in use + 1).  mp_slot[i] names a map point with operations in this log, first_op[i] the head of its chain
+    // (MedoidOp::next).  medoid_replay may only ENQUEUE the work (the HIP stages: one wavefront per touched map point, behind the
+    // keyframe's other kernels); medoid_export waits for everything replayed so far and returns desc_ / !desc_.empty() / {#descriptors,
+    // keyframe desc_ was taken from, overflow} per requested slot; medoid_dump copies one table as it is (tests).
+    // The defaults keep the tables on the host (the GPU-less harness under oracle/); the HIP stages override all three.
+    virtual int medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) {
+        if ((int) med_tables_.size() < slots) {
+            const size_t old = med_tables_.size();
+            med_tables_.resize((size_t) slots + 1024);
+            for (size_t i = old; i < med_tables_.size(); i++) alva_medoid::reset(med_tables_[i]);
+        }
+        for (int i = 0; i < n_mp; i++)
+            for (int o = first_op[i]; o >= 0 && o < n_ops; o = ops[o].next) alva_medoid::apply(med_tables_[(size_t) mp_slot[i]], ops[o]);
+        return 0;
+    }
+    virtual int medoid_export(int n, const int *mp_slot, uint8_t *desc32, uint8_t *valid, int *info3) {
+        for (int i = 0; i < n; i++) {
+            static const alva_medoid::Table fresh = [] { alva_medoid::Table t{}; alva_medoid::reset(t); return t; }();
+            const alva_medoid::Table &t = mp_slot[i] >= 0 && (size_t) mp_slot[i] < med_tables_.size() ? med_tables_[(size_t) mp_slot[i]] : fresh;
+            if (desc32) memcpy(desc32 + 32 * (size_t) i, t.medoid, 32);
+            if (valid) valid[i] = (uint8_t) t.medoid_valid;
+            if (info3) { info3[3 * i] = t.count; info3[3 * i + 1] = t.medoid_kf; info3[3 * i + 2] = t.overflow; }
+        }
+        return 0;
+    }
+    virtual int medoid_dump(int mp_slot, alva_medoid::Table *out) {
+        if (mp_slot < 0 || (size_t) mp_slot >= med_tables_.size()) return -1;
+        *out = med_tables_[(size_t) mp_slot];
+        return 0;
+    }
+
     // System::processPlane's fit (system.cpp:177-342, intended algorithm, parity unpinned)
     virtual int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) = 0;
 
@@ -156,6 +192,7 @@ struct Stages {
     int image_width_ = 0, image_height_ = 0;
 
 protected:
+    std::vector<alva_medoid::Table> med_tables_;   // (default medoid_* only)
     std::vector<uint8_t> scratch_;
     int det_cell_ = 0, det_n_occ_ = 0, det_cap_ = 0;
     std::vector<float> det_occ_;

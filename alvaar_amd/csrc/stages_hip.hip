@@ -349,6 +349,7 @@ struct Arena {
 
 struct HipStages::Impl {
     int device = 0;
+    alva_medoid_store *med = nullptr;   // the map points' descriptor tables (medoid.hip), created with the first replay
     alva_ctx *ctx = nullptr;
     hipStream_t st = nullptr;
     Camera cam;
@@ -495,6 +496,7 @@ HipStages::~HipStages() {
     m->pin.release();
     m->trk_dev.release();
     m->trk_pin.release();
+    alva_medoid_store_destroy(m->med);
     alva_ctx_destroy(m->ctx);
     delete m;
 }
@@ -1404,6 +1406,31 @@ int HipStages::local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n
     // optimizer.cpp:251-262: function tolerance 1e-3, Huber on sqrt(robustCostThreshold_) -- a float in the reference (:8, :22)
     return alva_local_ba(m->ctx, n_kf, poses7, kf_const, calib, 1, n_pt, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_pt, obs_uv,
                          max_iters, 0.001, (double) 5.9915f, chi2, depth_pos, info, &ok);
+}
+
+// f1: the map points' descriptor tables live on the device (medoid.hip); the replay is enqueued behind the keyframe's other work on the
+// session's stream and nothing waits for it -- only an export does
+int HipStages::medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) {
+    ALVA_HIP(hipSetDevice(m->device));
+    if (!m->med) {
+        const int rc = alva_medoid_store_create(m->ctx, &m->med);
+        if (rc) return rc;
+    }
+    return alva_medoid_replay(m->med, n_ops, ops, n_mp, mp_slot, first_op, slots);
+}
+int HipStages::medoid_export(int n, const int *mp_slot, uint8_t *desc32, uint8_t *valid, int *info3) {
+    if (!m->med) {   // nothing was ever replayed: every table is a fresh one
+        if (desc32) memset(desc32, 0, 32 * (size_t) n);
+        if (valid) memset(valid, 0, (size_t) n);
+        if (info3)
+            for (int i = 0; i < n; i++) { info3[3 * i] = 0; info3[3 * i + 1] = -1; info3[3 * i + 2] = 0; }
+        return ALVA_OK;
+    }
+    return alva_medoid_export(m->med, n, mp_slot, desc32, valid, info3);
+}
+int HipStages::medoid_dump(int mp_slot, alva_medoid::Table *out) {
+    if (!m->med) return ALVA_ERR_STATE;
+    return alva_medoid_dump(m->med, mp_slot, out, sizeof(*out));
 }
 
 int HipStages::find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) {

@@ -50,6 +50,9 @@ public:
                  uint8_t *depth_pos) override;
     int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) override;
     uint8_t *stage_scratch(size_t bytes) override;
+    int medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) override;
+    int medoid_export(int n, const int *mp_slot, uint8_t *desc32, uint8_t *valid, int *info3) override;
+    int medoid_dump(int mp_slot, alva_medoid::Table *out) override;
 
 private:
     int build_from(const uint8_t *d_src);

@@ -483,6 +483,24 @@ int alva_microbench_launch(alva_ctx *ctx, int chain, double *h_us_per_dependent_
  * ALVA_KSTAMPS=1: 4096 x u64 -- k_p3p 8 per workgroup from entry 0, k_pnp sequentially from entry 2048; cleared by the call. */
 int alva_debug_kstamps(unsigned long long *h_out);
 
+/* f1: MapPoint's descriptor tables -- mapKeyframeDescriptors_, mapDescriptorsDist_, desc_ -- on the device, edited by
+ * REPLAYING a log of MapPoint::addDesc (map_point.cpp:131-181), the descriptor half of MapPoint::removeObservedKeyframeId (:93-128),
+ * the release when the last observation goes (:80-91) and "new map point" operations.  A store holds one fixed-size table per map point
+ * SLOT (alva_medoid_table_bytes()); operations are 64-byte records (alva_medoid_op_bytes(): int op {0 add, 1 remove, 2 clear, 3 reset},
+ * int keyframe, int rehash_to (bucket count of the rehash this insert triggers in the reference's unordered_map, 0 = none), int next
+ * (index of the same map point's next operation, -1 = last), uint8 descriptor[32], 16 bytes padding).  alva_medoid_replay ENQUEUES
+ * the log on the context's stream (one wavefront per listed map point: mp_slot[i] with its chain head first_op[i]; `slots` = highest
+ * slot in use + 1); alva_medoid_export waits and returns per requested slot desc_ (32 B), !desc_.empty(), {#descriptors, keyframe
+ * desc_ was taken from, overflow flag}; alva_medoid_dump copies one raw table (tests; layout in csrc/slam/medoid_table.hpp). */
+typedef struct alva_medoid_store alva_medoid_store;
+size_t alva_medoid_table_bytes(void);
+size_t alva_medoid_op_bytes(void);
+int alva_medoid_store_create(alva_ctx *ctx, alva_medoid_store **out);
+void alva_medoid_store_destroy(alva_medoid_store *store);
+int alva_medoid_replay(alva_medoid_store *store, int n_ops, const void *ops, int n_mp, const int *mp_slot, const int *first_op, int slots);
+int alva_medoid_export(alva_medoid_store *store, int n, const int *mp_slot, uint8_t *h_desc32, uint8_t *h_valid, int *h_info3);
+int alva_medoid_dump(alva_medoid_store *store, int mp_slot, void *h_table, size_t bytes);
+
 /* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
  * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist
  * (metres) whose descriptor is within max_hamming bits (smallest distance wins, earliest record on ties) -- the intent of

@@ -114,3 +114,40 @@ extern "C" int ref_match_to_map(const double *calib, int cellSize, int nKf, cons
     }
     return n;
 }
+
+// MapPoint's descriptor bookkeeping, driven operation by operation on ONE reference MapPoint (map_point.cpp:73-181):
+//   op 0: addObservedKeyframeId(kf) + addDesc(kf, desc)      op 1: removeObservedKeyframeId(kf)
+// After every operation: desc_ (32 bytes, zeros when empty), !desc_.empty(), the bucket count of mapKeyframeDescriptors_ (the caller
+// derives the rehash points from it), its size, and -- in ITERATION order -- the keys and their mapDescriptorsDist_ sums (cap entries
+// per operation).  Pins medoid.hip / medoid_table.hpp against the reference's own class.
+extern "C" int ref_mappoint_desc_ops(int first_kf, const uint8_t *first_desc, int nOps, const int *op, const int *kf, const uint8_t *desc, int cap,
+                                     uint8_t *outMedoid, uint8_t *outHas, int *outBuckets, int *outCount, int *outKeys, float *outDist) {
+    auto mat_of = [](const uint8_t *d) {
+        cv::Mat m(1, 32, CV_8U);
+        std::memcpy(m.data, d, 32);
+        return m;
+    };
+    MapPoint mp = first_desc ? MapPoint(1, first_kf, mat_of(first_desc)) : MapPoint(1, first_kf);
+    for (int i = 0; i < nOps; i++) {
+        if (op[i] == 0) {
+            mp.addObservedKeyframeId(kf[i]);
+            mp.addDesc(kf[i], mat_of(desc + 32 * (size_t) i));
+        } else {
+            mp.removeObservedKeyframeId(kf[i]);
+        }
+        const bool has = !mp.desc_.empty();
+        outHas[i] = has;
+        if (has) std::memcpy(outMedoid + 32 * (size_t) i, mp.desc_.data, 32);
+        else std::memset(outMedoid + 32 * (size_t) i, 0, 32);
+        outBuckets[i] = (int) mp.mapKeyframeDescriptors_.bucket_count();
+        outCount[i] = (int) mp.mapKeyframeDescriptors_.size();
+        int j = 0;
+        for (const auto &e: mp.mapKeyframeDescriptors_) {
+            if (j >= cap) return -1;
+            outKeys[(size_t) i * cap + j] = e.first;
+            outDist[(size_t) i * cap + j] = mp.mapDescriptorsDist_.at(e.first);
+            j++;
+        }
+    }
+    return 0;
+}

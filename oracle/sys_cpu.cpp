@@ -289,6 +289,16 @@ void syscpu_timing_fine(void *p, double *out32, int reset) {
     if (out32) std::memcpy(out32, s.t_fine, sizeof(s.t_fine));
     if (reset) std::memset(s.t_fine, 0, sizeof(s.t_fine));
 }
+// The product's descriptor-table record (alvaar_amd/csrc/slam/medoid_table.hpp), HOST build, one map point: applies `n` logged operations
+// (64-byte MedoidOp records, chained or not: applied in array order) to `table` (alva_medoid::Table bytes, in/out; reset first when
+// `fresh`).  tests/test_medoid_table.py drives it operation by operation against the reference's MapPoint (ref_mappoint_desc_ops).
+int syscpu_medoid_apply(void *table, int fresh, int n, const void *ops) {
+    alva_medoid::Table &t = *static_cast<alva_medoid::Table *>(table);
+    if (fresh) alva_medoid::reset(t);
+    const alva_medoid::MedoidOp *o = static_cast<const alva_medoid::MedoidOp *>(ops);
+    for (int i = 0; i < n; i++) alva_medoid::apply(t, o[i]);
+    return (int) sizeof(alva_medoid::Table);
+}
 void syscpu_counters(void *p, long *out) {
     Slam &s = *static_cast<CpuSys *>(p)->slam;
     out[0] = s.n_ba_runs; out[1] = s.n_merges; out[2] = s.n_kf_culled;
