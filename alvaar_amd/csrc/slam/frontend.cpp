@@ -57,6 +57,7 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     mp_flat_.clear();
     mp_nobs_.clear();
     mp_index_.clear();
+    shared_ids.clear();
     // State::reset (state.cpp:14-18)
     ready_for_init = false;
     reset_requested = false;

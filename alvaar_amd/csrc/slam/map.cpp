@@ -498,6 +498,13 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
         if (cur->change_id(prev_id, new_id, nw->is3d)) set_map_point_obs(new_id);
     }
     if (prev->is3d) n_map_points--;
+    {   // the survivor keeps the absorbed point's place in the shared map, unless it has one of its own
+        auto sh = shared_ids.find(prev_id);
+        if (sh != shared_ids.end()) {
+            shared_ids.emplace(new_id, sh->second);
+            shared_ids.erase(sh);
+        }
+    }
     mp_flat_[(size_t) prev_id] = nullptr;
     mp_nobs_[(size_t) prev_id] = 0;
     map_points.erase(pit);

@@ -404,6 +404,10 @@ public:
     SE3 init_computed;  // what checkReadyForInit computed itself on the initialisation frame (before any override)
     // counters for tests / bench
     long n_ba_runs = 0, n_merges = 0, n_kf_culled = 0;
+    // The shared-map merge across sessions (north_star's optional extra; no reference counterpart): map point id of THIS session ->
+    // (stream, id) of the point that absorbed it in the shared map.  Set by alva_system_set_shared_ids after a merge round, inherited by
+    // MapManager::mergeMapPoints' survivor, dropped with the map point.
+    std::unordered_map<int, std::pair<int, int>> shared_ids;
     // fb-KLT work done by the tracking steps (bench.py: keypoint-levels per second): LK passes over one pyramid level,
     // forwards + the one-level backward pass, counted from the per-slot result codes (a lost slot counts its first pass only)
     long n_klt_kp_levels = 0, n_klt_slots = 0;
@@ -467,7 +471,9 @@ private:
     void add_keyframe();
     void add_map_point(const Desc *d);
     void update_map_point(int id, const double *wpt, double anchor_inv_depth);
-    void merge_map_points(int prev_id, int new_id);
+public:
+    void merge_map_points(int prev_id, int new_id);   // (public: alva_system_merge_map_points applies a shared-map merge through it)
+private:
     void remove_keyframe(int kfid);
     void remove_map_point(int id);
     void remove_map_point_obs(int mp_id, int kfid);

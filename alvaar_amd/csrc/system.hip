@@ -8,6 +8,7 @@
 #include "slam/inspect.hpp"
 #include "slam/stage_trace.hpp"
 #include "../../include/alvaar_system.h"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -303,6 +304,59 @@ extern "C" int alva_system_debug_map_points(alva_system *s, int cap, int *ids, d
     if (!s || !s->slam) return ALVA_ERR_ARG;
     return inspect_map_points(*s->slam, cap, ids, xyz, flags5, inv_depth, desc);
 }
+// ---- the shared-map merge across sessions, applied (north_star's optional extra; semantics: MapManager::mergeMapPoints, map_manager.cpp:428-513)
+extern "C" int alva_system_merge_map_points(alva_system *s, int prev_id, int new_id) {
+    if (!s || !s->slam) return ALVA_ERR_ARG;
+    return guarded(s, "alva_system_merge_map_points", [&]() -> int {
+        // MapManager::mergeMapPoints is written for the mapper's own merges -- a keypoint of the new keyframe against a local-map point
+        // the frame does NOT see (mapper.cpp:354-588): a frame or keyframe that observes BOTH points cannot change one id into the other
+        // (Frame::updateKeypointId fails) and would be left with a keypoint of a map point that no longer exists.  Two points of a session
+        // that a shared-map round declares the same are merged only where the reference's routine is safe: never co-observed.
+        Slam &S = *s->slam;
+        const auto ia = S.map_points.find(prev_id), ib = S.map_points.find(new_id);
+        if (ia == S.map_points.end() || ib == S.map_points.end() || prev_id == new_id) return 0;
+        const std::shared_ptr<MapPt> a = ia->second, b = ib->second;
+        if (S.cur->observes(prev_id) && S.cur->observes(new_id)) return 0;
+        for (int kf: a->obs_kfs)
+            if (b->obs_kfs.count(kf)) return 0;
+        const long before = s->slam->n_merges;
+        s->slam->merge_map_points(prev_id, new_id);
+        return s->slam->n_merges > before ? 1 : 0;   // 0: the reference's early return (a point is gone, or the survivor is not 3-D)
+    });
+}
+extern "C" int alva_system_set_shared_ids(alva_system *s, int n, const int *local_id, const int *shared_stream, const int *shared_id) {
+    if (!s || !s->slam || n < 0 || (n > 0 && (!local_id || !shared_stream || !shared_id))) return ALVA_ERR_ARG;
+    return guarded(s, "alva_system_set_shared_ids", [&]() -> int {
+        int applied = 0;
+        for (int i = 0; i < n; i++)
+            if (s->slam->map_points.count(local_id[i])) {
+                s->slam->shared_ids[local_id[i]] = {shared_stream[i], shared_id[i]};
+                applied++;
+            }
+        return applied;
+    });
+}
+extern "C" int alva_system_get_shared_ids(alva_system *s, int cap, int *local_id, int *shared_stream, int *shared_id) {
+    if (!s || !s->slam || cap < 0) return ALVA_ERR_ARG;
+    return guarded(s, "alva_system_get_shared_ids", [&]() -> int {
+        std::vector<std::pair<int, std::pair<int, int>>> v;
+        for (auto it = s->slam->shared_ids.begin(); it != s->slam->shared_ids.end();) {
+            if (!s->slam->map_points.count(it->first)) it = s->slam->shared_ids.erase(it);   // the map point has been culled since
+            else {
+                v.push_back(*it);
+                ++it;
+            }
+        }
+        std::sort(v.begin(), v.end());
+        for (size_t i = 0; i < v.size() && (int) i < cap; i++) {
+            if (local_id) local_id[i] = v[i].first;
+            if (shared_stream) shared_stream[i] = v[i].second.first;
+            if (shared_id) shared_id[i] = v[i].second.second;
+        }
+        return (int) v.size();
+    });
+}
+
 extern "C" int alva_system_debug_counters(alva_system *s, long *out3) {
     if (!s || !s->slam || !out3) return ALVA_ERR_ARG;
     out3[0] = s->slam->n_ba_runs; out3[1] = s->slam->n_merges; out3[2] = s->slam->n_kf_culled;

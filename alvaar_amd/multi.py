@@ -158,10 +158,71 @@ def system_map_records(ar, stream_id: int, capacity: int, device: torch.device |
     return pack_records(stream_id, ids[o].astype(np.int32), xyz[o], desc[o], capacity, device), int(len(o))
 
 
-def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384):
+def similarity_fit(src: np.ndarray, dst: np.ndarray):
+    """Umeyama's closed-form similarity dst ~ s R src + t over matched 3-D points [n, 3] -> (s, R, t, rms residual)."""
+    n = len(src)
+    mu_s, mu_d = src.mean(0), dst.mean(0)
+    a, b = src - mu_s, dst - mu_d
+    U, D, Vt = np.linalg.svd(b.T @ a / n)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    var = (a ** 2).sum() / n
+    s = float((D * np.diag(S)).sum() / var) if var > 0 else 1.0
+    t = mu_d - s * R @ mu_s
+    rms = float(np.sqrt((((s * (R @ src.T)).T + t - dst) ** 2).sum(1).mean()))
+    return s, R, t, rms
+
+
+def frames_are_registered(xyz_absorbed: np.ndarray, xyz_kept: np.ndarray, max_scale_dev=0.02, max_rot_deg=1.0, max_trans_m=0.05):
+    """The merge's premise, checked on its own output: the fused pairs must be explained by the IDENTITY -- a similarity fitted to them may
+    differ from it by less than 2 % in scale, 1 degree in rotation and 5 cm in translation.  Independent monocular maps (own gauge: own
+    origin, orientation and scale) fail this -- or fuse nothing -- and are not merged; they have to be registered into one frame first."""
+    if len(xyz_absorbed) < 4:
+        return True, {"pairs": int(len(xyz_absorbed)), "note": "fewer than 4 pairs: nothing to fit"}
+    s, R, t, rms = similarity_fit(xyz_absorbed, xyz_kept)
+    ang = float(np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))))
+    ok = abs(s - 1) <= max_scale_dev and ang <= max_rot_deg and float(np.linalg.norm(t)) <= max_trans_m
+    return ok, {"pairs": int(len(xyz_absorbed)), "scale": s, "rotation_deg": ang, "translation_m": float(np.linalg.norm(t)), "rms_m": rms}
+
+
+def apply_merge(ar, my_stream: int, stream: np.ndarray, ids: np.ndarray, keep: np.ndarray, absorbed_by: np.ndarray, xyz: np.ndarray | None = None):
+    """Make the fused set real for ONE session (`ar`, stream number `my_stream`): every map point of this session that the round absorbed
+    into another stream's point gets that point's (stream, id) as its shared id (alva_system_set_shared_ids); two of this session's OWN
+    points that ended up in the same shared point are one point -- the newer is merged into the older through the session's
+    MapManager::mergeMapPoints path (alva_system_merge_map_points, map_manager.cpp:428-513).  Identical input on every rank => every
+    rank derives the same shared ids.  Refuses (applies nothing) when the fused pairs contradict the one-world-frame premise."""
+    stream, ids, keep, absorbed_by = (np.asarray(v) for v in (stream, ids, keep, absorbed_by))
+    gone = np.flatnonzero(~keep.astype(bool))
+    reg = {"pairs": int(len(gone))}
+    if xyz is not None and len(gone):
+        ok, reg = frames_are_registered(np.asarray(xyz)[gone], np.asarray(xyz)[absorbed_by[gone]])
+        if not ok:
+            return {"applied": 0, "local_merges": 0, "registered": False, "registration": reg}
+    mine = gone[stream[gone] == my_stream]
+    kept_idx = absorbed_by[mine]
+    n_set = ar.set_shared_ids(ids[mine], stream[kept_idx], ids[kept_idx]) if len(mine) else 0
+    # this session's points that share one kept point: merge the newer (higher id) into the oldest of them
+    local_merges = 0
+    groups: dict[int, list[int]] = {}
+    for i, k in zip(mine, kept_idx):
+        groups.setdefault(int(k), []).append(int(ids[i]))
+    for k, members in groups.items():
+        members.sort()
+        if stream[k] == my_stream:          # (cannot happen with the cross-stream rule; kept for a rule that fuses inside a stream)
+            members = [int(ids[k])] + members
+        for newer in members[1:]:
+            local_merges += int(ar.merge_map_points(newer, members[0]))
+    return {"applied": int(n_set), "local_merges": local_merges, "registered": True, "registration": reg}
+
+
+def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384, apply: bool = True):
     """One shared-map merge (north_star: "RCCL over xGMI only for the optional shared-map merge"): pack this rank's map, ONE
-    all_gather_into_tensor over the process group (RCCL when the backend is nccl), fuse the duplicates on the GPU.  Returns a dict
-    of sizes and wall times; the fused set is identical on every rank (same input, deterministic rule)."""
+    all_gather_into_tensor over the process group (RCCL when the backend is nccl), fuse the duplicates on the GPU, and APPLY the result to
+    this rank's session (apply_merge: shared ids for its absorbed points, its own duplicates merged through MapManager::mergeMapPoints'
+    path) -- after checking that the fused pairs agree with the one-world-frame premise (frames_are_registered).  Returns a dict of sizes
+    and wall times; the fused set is identical on every rank (same input, deterministic rule)."""
     import time
     t0 = time.perf_counter()
     block, n = system_map_records(ar, shard.rank, capacity)
@@ -173,6 +234,18 @@ def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384):
     stream, ids, keep, absorbed = fuse_duplicates(allrec, ctx)
     kept = int(keep.sum().item())
     t3 = time.perf_counter()
-    return {"records_this_rank": n, "records_gathered": int(stream.shape[0]), "kept": kept, "fused": int(stream.shape[0]) - kept,
-            "bytes_gathered": int(allrec.numel()), "backend": dist.get_backend() if dist.is_available() and dist.is_initialized() else None,
-            "pack_us": (t1 - t0) * 1e6, "all_gather_us": (t2 - t1) * 1e6, "fuse_us": (t3 - t2) * 1e6}
+    out = {"records_this_rank": n, "records_gathered": int(stream.shape[0]), "kept": kept, "fused": int(stream.shape[0]) - kept,
+           "bytes_gathered": int(allrec.numel()), "backend": dist.get_backend() if dist.is_available() and dist.is_initialized() else None,
+           "pack_us": (t1 - t0) * 1e6, "all_gather_us": (t2 - t1) * 1e6, "fuse_us": (t3 - t2) * 1e6}
+    if apply:
+        # the positions of the valid records in fuse_duplicates' (stream, id) order, for the registration check
+        rec = allrec.reshape(-1, RECORD_BYTES)
+        rec = rec[rec[:, 4:8].contiguous().view(torch.int32).reshape(-1) >= 0]
+        st_all = rec[:, 0:4].contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+        id_all = rec[:, 4:8].contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+        order = torch.argsort(st_all * (1 << 32) + id_all, stable=True)
+        xyz = rec[order][:, 8:32].contiguous().view(torch.float64).reshape(-1, 3).cpu().numpy()
+        res = apply_merge(ar, shard.rank, stream.cpu().numpy(), ids.cpu().numpy(), keep.cpu().numpy(), absorbed.cpu().numpy().astype(np.int64), xyz)
+        out.update(applied=res["applied"], local_merges=res["local_merges"], registered=res["registered"], registration=res["registration"],
+                   apply_us=(time.perf_counter() - t3) * 1e6)
+    return out

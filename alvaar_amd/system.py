@@ -37,6 +37,9 @@ lib.alva_system_debug_keyframe.argtypes = [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]
 lib.alva_system_debug_covisibility.argtypes = [_vp, _i, _i, _vp]
 lib.alva_system_debug_map_points.argtypes = [_vp, _i] + [_vp] * 5
 lib.alva_system_debug_counters.argtypes = [_vp, _vp]
+lib.alva_system_merge_map_points.argtypes = [_vp, _i, _i]
+lib.alva_system_set_shared_ids.argtypes = [_vp, _i, _vp, _vp, _vp]
+lib.alva_system_get_shared_ids.argtypes = [_vp, _i, _vp, _vp, _vp]
 lib.alva_system_debug_klt_work.argtypes = [_vp, _vp, _i]
 lib.alva_system_debug_set_init_pose.argtypes = [_vp, _vp]
 lib.alva_system_debug_timing.argtypes = [_vp, _vp, _i]
@@ -212,6 +215,28 @@ class AlvaAR:
         inv, desc = np.zeros(cap), np.zeros((cap, 32), np.uint8)
         n = lib.alva_system_debug_map_points(self.h, cap, ids.ctypes.data, xyz.ctypes.data, fl.ctypes.data, inv.ctypes.data, desc.ctypes.data)
         return ids[:n], xyz[:n], fl[:n], inv[:n], desc[:n]
+
+    def merge_map_points(self, prev_id: int, new_id: int) -> bool:
+        """MapManager::mergeMapPoints(prev_id, new_id) on this session's map (include/alvaar_system.h); False = the reference's early return"""
+        rc = lib.alva_system_merge_map_points(self.h, int(prev_id), int(new_id))
+        if rc < 0:
+            raise AlvaError(lib.alva_system_last_error().decode())
+        return rc == 1
+
+    def set_shared_ids(self, local_ids, shared_stream, shared_id) -> int:
+        a, b, c = (np.ascontiguousarray(v, np.int32) for v in (local_ids, shared_stream, shared_id))
+        rc = lib.alva_system_set_shared_ids(self.h, len(a), a.ctypes.data, b.ctypes.data, c.ctypes.data)
+        if rc < 0:
+            raise AlvaError(lib.alva_system_last_error().decode())
+        return rc
+
+    def shared_ids(self, cap: int = 65536):
+        a, b, c = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = lib.alva_system_get_shared_ids(self.h, cap, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+        if n < 0:
+            raise AlvaError(lib.alva_system_last_error().decode())
+        n = min(n, cap)
+        return a[:n], b[:n], c[:n]
 
     def counters(self):
         out = (C.c_long * 3)()

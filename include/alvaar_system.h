@@ -125,6 +125,24 @@ int alva_system_debug_keyframe(alva_system *sys, int kfid, double *pose7, int *i
 int alva_system_debug_covisibility(alva_system *sys, int kfid, int cap, int *pairs);
 int alva_system_debug_map_points(alva_system *sys, int cap, int *ids, double *xyz, int *flags5, double *inv_depth, uint8_t *desc);
 int alva_system_debug_counters(alva_system *sys, long *out3 /* local-BA solves, map-point merges, culled keyframes */);
+/* ---- the optional SHARED-MAP MERGE across sessions, applied to a session (north_star's extra; the reference has one map: parity unpinned).
+ * A merge round (alvaar_amd/multi.py: pack -> ONE all_gather over the process group -> alva_fuse_map_points) decides, for map points of
+ * DIFFERENT streams that coincide -- same world position within 5 cm, descriptors within 51 bits; this presumes that the streams' maps live
+ * in ONE world frame (a rig with known extrinsics, a shared initialisation, or maps registered beforehand), which the round verifies with
+ * a similarity fit over the fused pairs before it applies anything -- which point of the shared map each absorbed point IS.  Applying it:
+ *   alva_system_set_shared_ids      map point `local_id[i]` of this session is point (shared_stream[i], shared_id[i]) of the shared map;
+ *                                   returns how many of the ids exist.  The table follows MapManager::mergeMapPoints (the survivor
+ *                                   inherits it) and forgets culled points; alva_system_get_shared_ids reads it (ascending local id).
+ *   alva_system_merge_map_points    MapManager::mergeMapPoints(prev_id, new_id) (map_manager.cpp:428-513) on this session's own map: two
+ *                                   of its points that the round found to be the SAME shared point become one; 1 = merged, 0 = not
+ *                                   merged: the reference's early return (a point is gone or the survivor is not 3-D), or the two
+ *                                   points are observed together by the current frame or by a keyframe -- the reference's routine
+ *                                   only ever meets points that are not (a new keyframe's keypoint against a local-map point the
+ *                                   frame does not see) and would leave that frame with a keypoint of a vanished map point; such a
+ *                                   pair keeps its two ids and the same shared id. */
+int alva_system_merge_map_points(alva_system *sys, int prev_id, int new_id);
+int alva_system_set_shared_ids(alva_system *sys, int n, const int *local_id, const int *shared_stream, const int *shared_id);
+int alva_system_get_shared_ids(alva_system *sys, int cap, int *local_id, int *shared_stream, int *shared_id);
 /* fb-KLT work since the last reset: out2[0] = keypoint-levels (LK passes over one pyramid level, forwards + the backward pass, from
  * the per-slot result codes), out2[1] = slots handed to the tracking steps */
 int alva_system_debug_klt_work(alva_system *sys, long *out2, int reset);
