@@ -158,4 +158,5 @@ struct alva_pyramid {
 // Debug: in-kernel phase stamps (wall_clock64, 100 MHz) of the pose kernels.  Null unless the process runs with ALVA_KSTAMPS=1; then
 // a 4096-entry device buffer that k_p3p (entries 0..2047: 8 per workgroup) and k_pnp (2048..) write and alva_debug_kstamps reads.
 unsigned long long *alva_kstamp_buffer();
+unsigned long long *alva_klt_stamp_buffer();   // null unless ALVA_KLT_STAMPS=1: per-slot wall time + verdict of the tracker launch (microbench.hip)
 

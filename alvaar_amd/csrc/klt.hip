@@ -425,6 +425,7 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
                                                const int maxCount, const double epsilon, const float errThresh, const float fbDist, const int bx,
                                                const int gx) {
     __shared__ LkShared sh;
+    const unsigned long long t_begin = D.dbg ? wall_clock64() : 0ull;
     lk_shared_init(sh);
     const int per = gx >> 3;
     const int i = (bx & 7) * per + (bx >> 3);
@@ -456,6 +457,9 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
     }
     if (threadIdx.x == 0) D.d_retried[i] = (uint8_t) (from_prior && !ok);
     track_slot_store(D, i, code, nx, ny);
+    if (D.dbg && threadIdx.x == 0 && i < 16384)
+        D.dbg[i] = ((wall_clock64() - t_begin) & 0xffffffffull) | ((unsigned long long) code << 32) | ((unsigned long long) (from_prior ? 1 : 0) << 36) |
+                   ((unsigned long long) (from_prior && !ok ? 1 : 0) << 37);
     if (threadIdx.x == 0) {
         // ONE atomic per slot on the packed counter (track_slots.hpp).  Its return value tells the last slot of the launch that it is
         // the last, and hands it every count: it publishes them to the host right away -- nothing but the atomic's own result is read,

@@ -117,6 +117,28 @@ unsigned long long *alva_kstamp_buffer() {
     return buf;
 }
 
+// Debug: per-SLOT stamps of the tracker launch (ALVA_KLT_STAMPS=1): entry i = slot i's wall time in the kernel (100 MHz ticks, low 32 bits)
+// | result code << 32 | tracked-from-projection << 36 | retried << 37, overwritten by every launch; 16384 entries
+unsigned long long *alva_klt_stamp_buffer() {
+    static unsigned long long *buf = [] {
+        unsigned long long *b = nullptr;
+        if (getenv("ALVA_KLT_STAMPS") && hipMalloc((void **) &b, 16384 * 8) == hipSuccess) (void) hipMemset(b, 0, 16384 * 8);
+        return b;
+    }();
+    return buf;
+}
+extern "C" int alva_debug_klt_stamps(unsigned long long *h_out16384) {
+    ALVA_ARG(h_out16384);
+    unsigned long long *b = alva_klt_stamp_buffer();
+    if (!b) {
+        alva_set_error("alva_debug_klt_stamps: the process was not started with ALVA_KLT_STAMPS=1");
+        return ALVA_ERR_STATE;
+    }
+    ALVA_HIP(hipDeviceSynchronize());
+    ALVA_HIP(hipMemcpy(h_out16384, b, 16384 * 8, hipMemcpyDeviceToHost));
+    return ALVA_OK;
+}
+
 // copies the stamp buffer (4096 x u64; see common.hpp) to the host and clears it; ALVA_ERR_STATE without ALVA_KSTAMPS=1
 extern "C" int alva_debug_kstamps(unsigned long long *h_out) {
     ALVA_ARG(h_out);

@@ -890,6 +890,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         memcpy(D.t, job.Tcw_t, 24);
         D.cam = AlvaCam{k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2};
         D.invK = m->d_invK;
+        D.dbg = alva_klt_stamp_buffer();
         // state.hpp:50-56 constants; the prior pass works on one pyramid level (visual_frontend.cpp:166)
         D.seq = ++m->trk_seq;   // the tracker launch publishes its counts under this number too (the word at o_hdr[10])
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);

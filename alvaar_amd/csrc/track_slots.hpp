@@ -46,6 +46,7 @@ struct TrackSlots {
                                // the LAST workgroup of the tracker launch itself -- the host learns the size of the pose problem one kernel
                                // earlier and enqueues the pose solve (sample draw + two launches) while the compaction kernel runs
     double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
+    unsigned long long *dbg;   // null, or the per-slot stamp buffer of ALVA_KLT_STAMPS=1 (microbench.hip)
 };
 
 struct alva_ctx;

@@ -1,6 +1,7 @@
-"""Records ONE run of the reference's own System (oracle/_ref) on the 560-frame, cell-12 stream of
-tests/test_gpu_system.py::test_system_equals_reference_long_stream_2000_keypoints as per-frame digests:
-tests/golden/system_long_560_cell12.npz.
+"""Records ONE run of the reference's own System (oracle/_ref) on each of the three LONG streams of tests/test_gpu_system.py as per-frame
+digests:  system_long_560_cell12.npz   (640x480, cell 12, 560 frames: test_system_equals_reference_long_stream_2000_keypoints)
+          system_long_660_cell40.npz   (640x480, cell 40, 660 frames: test_system_equals_reference_long_stream)
+          system_long_440_720p.npz     (1280x720, cell 15, 440 frames: test_system_equals_reference_1280x720_long_stream)
 
 Why: the reference is not run-to-run reproducible on this stream (Ceres orders parameter blocks by address: DESIGN.md section 5) -- about
 one run in five takes another discrete path -- while the HIP path is (tools/gpu_determinism_probe.py).  The GPU test compares against at
@@ -9,7 +10,8 @@ least two of the runs made here agree on, frame by frame).
 
 Per frame: status, the state counters, 64-bit digests (blake2b) of the keypoint ids in container order + their flags, of the keypoint
 pixels (raw + undistorted, the float bytes), of the keyframe ids, of the map-point table (ids + flags) and of the descriptor medoids; the
-pose (7 doubles).  Run from the repository root, CPU only, ~2 minutes per reference run:  python tests/golden/make_system_long_golden.py"""
+pose (7 doubles).  Run from the repository root, CPU only, up to ~2 minutes per reference run:
+    python tests/golden/make_system_long_golden.py [560_cell12] [660_cell40] [440_720p]        (default: all three)"""
 import hashlib
 import os
 import sys
@@ -22,14 +24,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from alvaar_amd import synth  # noqa: E402
 import sysdiff  # noqa: E402
 
-W, H, N, FRAMES, CELL = 640, 480, 200, 560, 12
+# name -> (width, height, frames of the crop sequence, frames of the stream, cell, canvas seed, noise seed): the tests' own parameters
+STREAMS = {"560_cell12": (640, 480, 200, 560, 12, 7, 11), "660_cell40": (640, 480, 200, 660, 40, 7, 11), "440_720p": (1280, 720, 150, 440, 15, 9, 3)}
+FILES = {"560_cell12": "system_long_560_cell12.npz", "660_cell40": "system_long_660_cell40.npz", "440_720p": "system_long_440_720p.npz"}
 
 
-def stream():
-    canvas = synth.texture_canvas(W, H, 7)
-    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H, noise_seed=11)) for k in range(N)]
-    period = 2 * (N - 1)
-    return [base[(k % period) if (k % period) < N else period - (k % period)] for k in range(FRAMES)]
+def stream(name="560_cell12"):
+    w, h, n, frames, cell, cseed, nseed = STREAMS[name]
+    canvas = synth.texture_canvas(w, h, cseed)
+    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=nseed)) for k in range(n)]
+    period = 2 * (n - 1)
+    return [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(frames)]
 
 
 def dig(*arrays) -> np.uint64:
@@ -47,8 +52,9 @@ def frame_record(sysobj, st, p7):
     return int(st), np.array(list(sysobj.state()), np.int64), d, np.array(p7, np.float64)
 
 
-def one_run(frames):
-    ref = sysdiff.RefSystem(W, H, CELL)
+def one_run(frames, name="560_cell12"):
+    w, h, _, _, cell, _, _ = STREAMS[name]
+    ref = sysdiff.RefSystem(w, h, cell)
     out = []
     for k, f in enumerate(frames):
         st, p7, _ = ref.step(f, 33.0 * k)
@@ -61,20 +67,24 @@ def same_path(a, b):
     return all(x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) for x, y in zip(a, b))
 
 
-if __name__ == "__main__":
-    frames = stream()
+def record(name):
+    frames = stream(name)
     runs = []
     for r in range(7):
-        runs.append(one_run(frames))
-        print(f"reference run {r}: keyframes created {int(runs[-1][-1][1][11])}", flush=True)
+        runs.append(one_run(frames, name))
+        print(f"[{name}] reference run {r}: keyframes created {int(runs[-1][-1][1][11])}", flush=True)
         mates = [i for i in range(r) if same_path(runs[i], runs[r])]
         if mates:
-            print(f"  same discrete path as run {mates[0]}: recording it ({r + 1} runs made)")
+            print(f"[{name}]   same discrete path as run {mates[0]}: recording it ({r + 1} runs made)", flush=True)
             rec = runs[r]
-            np.savez_compressed(os.path.join(ROOT, "tests", "golden", "system_long_560_cell12.npz"),
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", FILES[name]),
                                 status=np.array([x[0] for x in rec], np.int32), state=np.stack([x[1] for x in rec]),
                                 digests=np.stack([x[2] for x in rec]), pose7=np.stack([x[3] for x in rec]),
                                 runs_made=np.int32(r + 1))
-            break
-    else:
-        raise SystemExit("no two of seven reference runs agreed")
+            return
+    raise SystemExit(f"[{name}] no two of seven reference runs agreed")
+
+
+if __name__ == "__main__":
+    for name in (sys.argv[1:] or list(STREAMS)):
+        record(name)

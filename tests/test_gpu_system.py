@@ -208,7 +208,7 @@ def test_system_equals_reference_long_stream():
     base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
     period = 2 * (n - 1)
     frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(660)]
-    _differential_long(frames, w, h, 40, True, 1e-5, 8, 30, name="660 frames, cell 40")
+    _differential_long(frames, w, h, 40, True, 1e-5, 8, 30, name="660 frames, cell 40", recording="system_long_660_cell40.npz")
 
 
 def test_system_equals_reference_long_stream_2000_keypoints():
@@ -430,7 +430,8 @@ def test_system_equals_reference_1280x720_long_stream():
     base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=3)) for k in range(n)]
     period = 2 * (n - 1)
     frames = (base[(k % period) if (k % period) < n else period - (k % period)] for k in range(440))
-    _differential_long(list(frames), w, h, 15, True, 1e-5, 8, 20, min_kf_created=21, name="440 frames, 1280x720, cell 15")
+    _differential_long(list(frames), w, h, 15, True, 1e-5, 8, 20, min_kf_created=21, name="440 frames, 1280x720, cell 15",
+                       recording="system_long_440_720p.npz")
 
 
 def test_concurrent_sessions_equal_their_solo_runs():
@@ -573,15 +574,18 @@ def test_next_frame_hints_do_not_change_results():
         assert np.array_equal(a[k][2], b[k][2]) and np.array_equal(a[k][3].view(np.uint32), b[k][3].view(np.uint32)), k
 
 
-def test_long_stream_equals_the_recorded_reference_run():
-    """The 560-frame, cell-12 stream against the COMMITTED recording of a majority run of the reference (tests/golden/
+@pytest.mark.parametrize("name", ["560_cell12", "660_cell40", "440_720p"])
+def test_long_stream_equals_the_recorded_reference_run(name):
+    """Each of the three long streams against the COMMITTED recording of a majority run of the reference on it (tests/golden/
     make_system_long_golden.py): deterministic on both sides, so this comparison never needs a second attempt -- every frame's status,
     counters, keypoint ids / flags / pixels (digests of the bytes), keyframe ids, map-point table and descriptor medoids equal the
-    recording, pose RMSE <= 1e-5."""
-    w, h, n = 640, 480, 200
-    canvas = synth.texture_canvas(w, h, 7)
-    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
-    period = 2 * (n - 1)
-    frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(560)]
-    rmse = _against_recording(frames, w, h, 12, "system_long_560_cell12.npz", 1e-5)
-    print(f"\n  560 frames against the recording: pose RMSE {rmse:.2e}")
+    recording, pose RMSE <= 1e-5 (from the recording's two-view pose: the init-pose hook, see README "pose parity")."""
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_system_long_golden", os.path.join(gdir, "make_system_long_golden.py"))
+    gold = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gold)
+    w, h, _, n_frames, cell, _, _ = gold.STREAMS[name]
+    rmse = _against_recording(gold.stream(name), w, h, cell, gold.FILES[name], 1e-5)
+    print(f"\n  {n_frames} frames ({name}) against the recording: pose RMSE {rmse:.2e}")
