@@ -394,7 +394,17 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
     }
 }
 
-__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) { fast_nms_body(D, blockIdx.y, blockIdx.x); }
+// One frame: workgroup b of a level runs on XCD b % 8 (each with its own L2), so every XCD gets one CONTIGUOUS eighth of the level's tiles
+// (row-major): the 4-px halo rows and the 128-byte lines that neighbouring tiles share then meet in ONE L2 instead of being fetched through
+// up to three (PMC, plain order: 2.06 MB fetched per launch at 640x480 against ~1.0 MB of pyramid; the same cure as k_pyr_rest's).  The
+// grid's x extent is a multiple of 8 (run_fast_stages); the candidate order was never defined (tile completion order), later stages sort.
+__global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
+    const Level &L = D.lv[blockIdx.y];
+    const int n = ((L.w + FT_W - 1) / FT_W) * ((L.h + FT_H - 1) / FT_H), per = (n + 7) / 8;
+    const int b = (int) blockIdx.x, j = b >> 3;
+    if (j >= per) return;
+    fast_nms_body(D, blockIdx.y, (b & 7) * per + j);
+}
 // batched: blockIdx.x runs over the tiles of ALL levels (a grid sized for level 0 on every level would be 60 % empty workgroups)
 __global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items, int count, int per_cam) {
     const AlvaXcdItem w = alva_xcd_item(count, per_cam);
@@ -993,7 +1003,7 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
         hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
     if (fused) {
         // ORB: candidate order is irrelevant downstream (k_cull_harris re-sorts by position), so FAST + NMS is one launch
-        hipLaunchKernelGGL(k_fast_nms, dim3(o->maxTiles, D.nlevels), dim3(256), 0, st, D);
+        hipLaunchKernelGGL(k_fast_nms, dim3(8 * alva_divup(o->maxTiles, 8), D.nlevels), dim3(256), 0, st, D);
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     }

@@ -1,6 +1,14 @@
 // Wave64 helpers shared by the kernels: broadcasts through v_readlane (no LDS crossbar round trip) and the butterfly
 // reduce-scatter used for the 27/28-value normal-equation sums.
 #pragma once
+// This library's device code is written for gfx950 (MI355X) only: wave64 DPP row shifts, v_mfma_f64_16x16x4_f64, and -- in the tracking
+// step, P3P and the local BA -- completion words that are RELAXED system-scope stores behind an agent-scope arrival counter
+// (stages_hip.hip k_track_compact, klt.hip k_track_klt, ba.hip k_results): correct because on this part a store that has been
+// acknowledged at system scope is visible to the host, posted PCIe writes stay in order, and s_waitcnt vmcnt(0) covers stores.  Another
+// target must re-derive that (or go back to release stores + fences), so it is refused at compile time instead of inheriting it silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "alvaar_amd device code targets gfx950 only (see wave_utils.hpp)"
+#endif
 #include <hip/hip_runtime.h>
 
 // value held by `lane` (a wave-uniform index) delivered to every lane

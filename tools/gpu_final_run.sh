@@ -1,14 +1,20 @@
-# consolidated GPU run: tests, PMC passes (stamped), bench line (reads the fresh stamp), rocprofv3 kernel stats of the same command
-export ALVA_COMMIT=${ALVA_COMMIT:-d34bb1a}
-T=${TAG:-r3i}
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${T}_pytest.log
+# consolidated GPU run: tests, PMC passes (stamped), bench line (reads the fresh stamp), rocprofv3 kernel stats of the same command,
+# ORB (configs[2]) kernel times + HBM traffic.   usage (GPU box, repo root): ALVA_COMMIT=<sha> TAG=r4x tools/gpu_final_run.sh
+export ALVA_COMMIT=${ALVA_COMMIT:-unknown}
+T=${TAG:-r4}
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${T}_pytest.log
 tools/pmc_klt.sh > gpurun_out/${T}_pmc.log 2>&1
-cp gpurun_out/r3_pmc_track_klt.json profiles/r3_pmc_track_klt.json
-python bench.py > gpurun_out/${T}_bench_n1.json 2> gpurun_out/${T}_bench.err
-tail -c 400 gpurun_out/${T}_bench.err
+cp gpurun_out/r4_pmc_track_klt.json profiles/r4_pmc_track_klt.json
+python bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err
+cp bench_detail.json gpurun_out/${T}_bench_detail.json
+tail -c 300 gpurun_out/${T}_bench.err
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline --quick > $R/gpurun_out/${T}_bench_prof.log 2>&1
-cp $(find /tmp/prof_$T -name '*kernel_stats.csv' | head -1) $R/gpurun_out/${T}_bench_kernel_stats.csv
+cp $(find /tmp/prof_$T -name '*kernel_stats.csv' | head -1) $R/gpurun_out/${T}_kernel_stats_bench.csv
 cd $R
+python tools/orb_kernels.py 1280 720 4000 > gpurun_out/${T}_orb_kernels_720p.txt 2>&1
+LINES_OUT=12 tools/pmc_traffic.sh ${T}_orb720 python tools/orb_kernels.py 1280 720 4000 > gpurun_out/${T}_orb720_pmc.txt 2>&1
 cat gpurun_out/${T}_pytest.log
+wc -c gpurun_out/${T}_bench_line.json
