@@ -643,8 +643,9 @@ def run_secondary(local: int, seed: int, steps: int, bctx, ba_pb, peaks, is720: 
         except Exception as e:   # noqa: BLE001 -- a secondary line must not take the record down
             out[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
-    guarded("system_group", lambda: [bench_system_group(local, s_, 8) for s_ in group_sessions] +
-            [bench_system_group(local, 32, 8, lockstep=False)])
+    # 16 worker threads (the GPU boxes give the container 16 CPUs), 4 lanes; and the same 32 sessions without lock-step launches
+    guarded("system_group", lambda: [bench_system_group(local, s_, 16, lanes=4) for s_ in group_sessions] +
+            [bench_system_group(local, 32, 16, lockstep=False), bench_system_group(local, 32, 8, lanes=2)])
     guarded("system_streams", lambda: [bench_system_streams(local, c_) for c_ in (4, 8)])
     if not is720:
         guarded("system_720p", lambda: run_system_line(local, seed, 1280, 720, 15, steps))
@@ -680,9 +681,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma-separated line names (e.g. system_group)")
     ap.add_argument("--sessions", type=str, default="8,16,32,64")
-    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--streams", type=int, default=0)
-    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=4)
     ap.add_argument("--stagger", type=int, default=0)
     ap.add_argument("--no-lockstep", action="store_true")
     args = ap.parse_args()
