@@ -482,6 +482,10 @@ int alva_microbench_launch(alva_ctx *ctx, int chain, double *h_us_per_dependent_
 /* Debug (no reference counterpart): phase stamps of the pose kernels (100 MHz wall clock), recorded only when the process runs with
  * ALVA_KSTAMPS=1: 4096 x u64 -- k_p3p 8 per workgroup from entry 0, k_pnp sequentially from entry 2048; cleared by the call. */
 int alva_debug_kstamps(unsigned long long *h_out);
+/* Debug: with ALVA_KLT_STAMPS=1 in the environment the tracker launch of the System path (k_track_klt) records, per slot of the frame
+ * container, its wall time in the kernel (100 MHz ticks, bits 0-31) | result code << 32 | tracked-from-projection << 36 | retried << 37;
+ * copies the 16384 entries of the last launch to the host.  ALVA_ERR_STATE without the variable. */
+int alva_debug_klt_stamps(unsigned long long *h_out16384);
 
 /* f1: MapPoint's descriptor tables -- mapKeyframeDescriptors_, mapDescriptorsDist_, desc_ -- on the device, edited by
  * REPLAYING a log of MapPoint::addDesc (map_point.cpp:131-181), the descriptor half of MapPoint::removeObservedKeyframeId (:93-128),
