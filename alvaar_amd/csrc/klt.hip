@@ -1023,21 +1023,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // beside it 3 - 5x slower, the chip's wave slots held by trackers; k_klt_batch_q tracks a 2 120-keypoint camera in 11 us of a 64-camera
 // launch).  Slots of a wave run the pyramid levels together; a slot tracked from its projection joins at level maxLevelPrior.  Bitwise
 // equal to k_track_klt: the same arithmetic per slot (lk_level_q is lk_level's summation order, see above), the same gates.
+// the two throughput layouts behind one face: slots per wave, lanes per slot, the LDS block, one pyramid level of every slot of the wave
 template <int GL>
-__device__ __forceinline__ int fbklt_value_q(LkSharedQ<GL> &sh, const LkPyr &P, const LkPyr &C, const int myMax, const int top, const int maxCount,
+struct LayoutQ {   // lk_level_q: GL lanes per slot (5 used)
+    static constexpr int LANES = GL, SLOTS = 64 / GL;
+    typedef LkSharedQ<GL> Shared;
+    static __device__ __forceinline__ void level(Shared &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
+                                                 bool live, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
+        lk_level_q<GL>(sh, I, J, level, maxLevel, maxCount, epsilon, 1e-4f, live, ptx, pty, nx, ny, status, err);
+    }
+};
+template <int L>
+struct LayoutG {   // lk_level_g: L = 32 or 16 lanes per slot, pixel -> lane like lk_level
+    static constexpr int LANES = L, SLOTS = 64 / L;
+    typedef LkSharedG<L> Shared;
+    static __device__ __forceinline__ void level(Shared &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
+                                                 bool live, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
+        lk_level_g<L>(sh, I, J, level, maxLevel, maxCount, epsilon, 1e-4f, live, ptx, pty, nx, ny, status, err);
+    }
+};
+
+template <class LAY>
+__device__ __forceinline__ int fbklt_value_w(typename LAY::Shared &sh, const LkPyr &P, const LkPyr &C, const int myMax, const int top, const int maxCount,
                                              const double epsilon, const float errThresh, const float fbDist, const bool has, const float ptx,
                                              const float pty, float &nx, float &ny) {
     int status = 1;
     float err = 0.f;
     for (int level = top; level >= 0; level--)   // top = the wave's highest starting level (wave-uniform)
-        lk_level_q<GL>(sh, P.lv[level], C.lv[level], level, myMax, maxCount, epsilon, 1e-4f, has && level <= myMax, ptx, pty, nx, ny, status, err);
+        LAY::level(sh, P.lv[level], C.lv[level], level, myMax, maxCount, epsilon, has && level <= myMax, ptx, pty, nx, ny, status, err);
     int ok = status && !(err > errThresh);
     const float fw = (float) C.lv[0].w, fh = (float) C.lv[0].h;
     ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
     float bx = ptx, by = pty;
     int st2 = 1;
     float err2 = 0.f;
-    lk_level_q<GL>(sh, C.lv[0], P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, has && ok, nx, ny, bx, by, st2, err2);
+    LAY::level(sh, C.lv[0], P.lv[0], 0, 0, maxCount, epsilon, has && ok, nx, ny, bx, by, st2, err2);
     if (ok) {
         if (!st2) ok = 0;
         else {
@@ -1049,12 +1069,13 @@ __device__ __forceinline__ int fbklt_value_q(LkSharedQ<GL> &sh, const LkPyr &P, 
     return has ? ok : 0;
 }
 
-template <int GL>
-__device__ __forceinline__ void track_klt_q_body(const LkPyr &P, const LkPyr &C, const TrackSlots &D, const int maxLevelPrior, const int maxLevelFull,
+template <class LAY>
+__device__ __forceinline__ void track_klt_w_body(const LkPyr &P, const LkPyr &C, const TrackSlots &D, const int maxLevelPrior, const int maxLevelFull,
                                                  const int maxCount, const double epsilon, const float errThresh, const float fbDist, const int bx,
                                                  const int gx) {
-    __shared__ LkSharedQ<GL> sh;
-    constexpr int NG = 64 / GL;
+    __shared__ typename LAY::Shared sh;
+    constexpr int NG = LAY::SLOTS, GL = LAY::LANES;
+    const unsigned long long t_begin = D.dbg ? wall_clock64() : 0ull;
     const int per = gx >> 3;
     const int w = (bx & 7) * per + (bx >> 3);   // the XCD-contiguous order of k_klt, in units of NG slots
     if (w * NG >= D.n) return;
@@ -1081,12 +1102,12 @@ __device__ __forceinline__ void track_klt_q_body(const LkPyr &P, const LkPyr &C,
     }
     const int myMax = from_prior ? maxLevelPrior : maxLevelFull;
     const int top = __any(has && !from_prior) ? maxLevelFull : maxLevelPrior;
-    const int ok = fbklt_value_q<GL>(sh, P, C, myMax, top, maxCount, epsilon, errThresh, fbDist, has, px, py, nx, ny);
+    const int ok = fbklt_value_w<LAY>(sh, P, C, myMax, top, maxCount, epsilon, errThresh, fbDist, has, px, py, nx, ny);
     int code = ok ? (from_prior ? 1 : 2) : 0;
     const bool retry = has && from_prior && !ok;
     if (__any(retry)) {  // full-pyramid retry from where the forward tracker left the keypoint (:185-190)
         float rx = nx, ry = ny;
-        const int ok2 = fbklt_value_q<GL>(sh, P, C, maxLevelFull, maxLevelFull, maxCount, epsilon, errThresh, fbDist, retry, px, py, rx, ry);
+        const int ok2 = fbklt_value_w<LAY>(sh, P, C, maxLevelFull, maxLevelFull, maxCount, epsilon, errThresh, fbDist, retry, px, py, rx, ry);
         if (retry) {
             nx = rx;
             ny = ry;
@@ -1109,6 +1130,9 @@ __device__ __forceinline__ void track_klt_q_body(const LkPyr &P, const LkPyr &C,
         D.d_px[2 * i] = nx; D.d_px[2 * i + 1] = ny;
         D.d_unpx[2 * i] = ux; D.d_unpx[2 * i + 1] = uy;
         D.d_bv[3 * (size_t) i] = bv[0]; D.d_bv[3 * (size_t) i + 1] = bv[1]; D.d_bv[3 * (size_t) i + 2] = bv[2];
+        if (D.dbg && i < 16384)
+            D.dbg[i] = ((wall_clock64() - t_begin) & 0xffffffffull) | ((unsigned long long) code << 32) | ((unsigned long long) (from_prior ? 1 : 0) << 36) |
+                       ((unsigned long long) (retry ? 1 : 0) << 37);
     }
     // ONE atomic per wave on the packed counter (track_slots.hpp): the wave's slots, tracked 3-D slots, slots from the projection, successes of those
     const unsigned long long b_has = __ballot(leader), b_pose = __ballot(leader && code != 0 && is3 != 0), b_prior = __ballot(leader && from_prior),
@@ -1126,8 +1150,31 @@ __device__ __forceinline__ void track_klt_q_body(const LkPyr &P, const LkPyr &C,
         }
     }
 }
-ALVA_MULTI_KERNEL_ATTR(MK_TRACK_KLT, k_track_klt_q_multi, TrackKltArgs, dim3(64), __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))),
-                       track_klt_q_body<5>(A.P, A.C, A.D, A.maxLevelPrior, A.maxLevelFull, A.maxCount, A.epsilon, A.errThresh, A.fbDist, bx, (int) gx));
+// the single session's launch in a throughput layout (ALVA_TRACK_KLT_LANES = 32 | 16 | 5: A/B against the wave-per-slot k_track_klt)
+template <class LAY>
+__global__ void __launch_bounds__(64) k_track_klt_w(LkPyr P, LkPyr C, TrackSlots D, int maxLevelPrior, int maxLevelFull, int maxCount, double epsilon,
+                                                    float errThresh, float fbDist) {
+    track_klt_w_body<LAY>(P, C, D, maxLevelPrior, maxLevelFull, maxCount, epsilon, errThresh, fbDist, (int) blockIdx.x, (int) gridDim.x);
+}
+// the lane's tracker (lane.hpp): 12 slots per wave by default; ALVA_LANE_KLT_LANES = 32 | 16 | 64 registers another layout instead (A/B:
+// what finishes a slot soonest -- a wave per slot, 81 us for one session -- against what does the most slots per wave-cycle)
+static int lane_klt_lanes() {
+    static const int v = [] {
+        const char *e = getenv("ALVA_LANE_KLT_LANES");
+        const int l = e ? atoi(e) : 5;
+        return (l == 32 || l == 16 || l == 64) ? l : 5;
+    }();
+    return v;
+}
+static int lane_klt_slots_per_wave() { return lane_klt_lanes() == 64 ? 1 : (lane_klt_lanes() == 32 ? 2 : (lane_klt_lanes() == 16 ? 4 : 12)); }
+ALVA_MULTI_KERNEL_ATTR_IF(lane_klt_lanes() == 5, MK_TRACK_KLT, k_track_klt_q_multi, TrackKltArgs, dim3(64), __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))),
+                          track_klt_w_body<LayoutQ<5>>(A.P, A.C, A.D, A.maxLevelPrior, A.maxLevelFull, A.maxCount, A.epsilon, A.errThresh, A.fbDist, bx, (int) gx));
+ALVA_MULTI_KERNEL_ATTR_IF(lane_klt_lanes() == 32, MK_TRACK_KLT, k_track_klt_g32_multi, TrackKltArgs, dim3(64), __launch_bounds__(64),
+                          track_klt_w_body<LayoutG<32>>(A.P, A.C, A.D, A.maxLevelPrior, A.maxLevelFull, A.maxCount, A.epsilon, A.errThresh, A.fbDist, bx, (int) gx));
+ALVA_MULTI_KERNEL_ATTR_IF(lane_klt_lanes() == 16, MK_TRACK_KLT, k_track_klt_g16_multi, TrackKltArgs, dim3(64), __launch_bounds__(64),
+                          track_klt_w_body<LayoutG<16>>(A.P, A.C, A.D, A.maxLevelPrior, A.maxLevelFull, A.maxCount, A.epsilon, A.errThresh, A.fbDist, bx, (int) gx));
+ALVA_MULTI_KERNEL_ATTR_IF(lane_klt_lanes() == 64, MK_TRACK_KLT, k_track_klt_multi, TrackKltArgs, dim3(64), __launch_bounds__(64),
+                          track_klt_body(A.P, A.C, A.D, A.maxLevelPrior, A.maxLevelFull, A.maxCount, A.epsilon, A.errThresh, A.fbDist, bx, (int) gx));
 
 int fill_pyr(const alva_pyramid *p, LkPyr &out) {
     out.nlevels = p->nlevels;
@@ -1234,7 +1281,17 @@ int alva_track_slots_klt(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyr
         const bool in_lane = alva_lane_defer(MK_STAGE_IN, ctx, g_in, 0, &D, sizeof(D));
         if (!in_lane) hipLaunchKernelGGL(k_track_stage_in, dim3(g_in), dim3(256), 0, ctx->stream, D);
         const TrackKltArgs KA{P, C, D, lp, lf, maxCount, err_thresh, fb_dist, epsilon};
-        if (alva_lane_defer(MK_TRACK_KLT, ctx, (unsigned) (8 * alva_divup(alva_divup(D.n, 12), 8)), 0, &KA, sizeof(KA))) return ALVA_OK;   // 12 slots per wave
+        if (alva_lane_defer(MK_TRACK_KLT, ctx, (unsigned) (8 * alva_divup(alva_divup(D.n, lane_klt_slots_per_wave()), 8)), 0, &KA, sizeof(KA))) return ALVA_OK;
+    }
+    static const int lanes = getenv("ALVA_TRACK_KLT_LANES") ? atoi(getenv("ALVA_TRACK_KLT_LANES")) : 64;
+    if (!retry && lanes != 64) {
+        const int per_wave = lanes == 32 ? 2 : (lanes == 16 ? 4 : 12);
+        const dim3 gw((unsigned) (8 * alva_divup(alva_divup(D.n, per_wave), 8)));
+        if (lanes == 32) hipLaunchKernelGGL((k_track_klt_w<LayoutG<32>>), gw, dim3(64), 0, ctx->stream, P, C, D, lp, lf, maxCount, epsilon, err_thresh, fb_dist);
+        else if (lanes == 16) hipLaunchKernelGGL((k_track_klt_w<LayoutG<16>>), gw, dim3(64), 0, ctx->stream, P, C, D, lp, lf, maxCount, epsilon, err_thresh, fb_dist);
+        else hipLaunchKernelGGL((k_track_klt_w<LayoutQ<5>>), gw, dim3(64), 0, ctx->stream, P, C, D, lp, lf, maxCount, epsilon, err_thresh, fb_dist);
+        ALVA_LAUNCH_CHECK();
+        return ALVA_OK;
     }
     if (!retry) hipLaunchKernelGGL(k_track_klt, grid, dim3(64), 0, ctx->stream, P, C, D, lp, lf, maxCount, epsilon, err_thresh, fb_dist);
     else hipLaunchKernelGGL(k_track_klt_retry, grid, dim3(64), 0, ctx->stream, P, C, D, lf, maxCount, epsilon, err_thresh, fb_dist);

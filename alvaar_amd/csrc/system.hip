@@ -526,7 +526,7 @@ struct alva_system_group {
     std::vector<hipStream_t> streams;   // alva_system_group_stream: streams that several sessions share (destroyed with the group)
     std::vector<alva_lane *> lanes;     // shared launches (lane.hpp): lane k = a stream of its own + the sessions i with (i / workers) % lanes == k
     std::vector<hipStream_t> lane_streams;
-    int n_lanes = 2;                    // ALVA_GROUP_LANES / alva_system_group_set_lanes; 0: every session launches for itself
+    int n_lanes = 4;                    // ALVA_GROUP_LANES / alva_system_group_set_lanes; 0: every session launches for itself
     bool lockstep = true;
     int stream_device = 0;
     std::mutex mu;
@@ -668,10 +668,10 @@ extern "C" int alva_system_group_find_camera_pose_device(alva_system_group *g, i
             f.lane = nullptr;
             f.lane_dirty = false;
             if (g->lockstep && g->n_lanes > 0 && systems[i]) {
-                // lane (i / W) % lanes: a worker's sessions sit on DIFFERENT lanes, so that it does the host half of one lane's sessions
-                // while another lane's launches run.  A lane's stream is created on the device of its first session; sessions of another
+                // lane (i + i / W) % lanes: a worker's consecutive sessions (i, i + W, ...) sit on DIFFERENT lanes, so that it does the
+                // host half of one lane's sessions while another lane's launches run, and every lane draws its sessions from all workers.  A lane's stream is created on the device of its first session; sessions of another
                 // device launch for themselves.
-                const size_t k = (size_t) ((i / W) % g->n_lanes);
+                const size_t k = (size_t) ((i + i / W) % g->n_lanes);
                 if (g->lanes.size() <= k) {
                     g->lanes.resize(k + 1, nullptr);
                     g->lane_streams.resize(k + 1, nullptr);

@@ -308,7 +308,7 @@ class SystemGroup:
             raise AlvaError("alva_system_group_set_lockstep failed")
 
     def set_lanes(self, lanes: int):
-        """number of lanes (group-owned streams that carry the shared tracking-chain launches); session i -> lane (i // n_threads) % lanes"""
+        """number of lanes (group-owned streams that carry the shared tracking-chain launches); session i -> lane (i + i // n_threads) % lanes"""
         if lib.alva_system_group_set_lanes(self.h, int(lanes)):
             raise AlvaError("alva_system_group_set_lanes failed")
 

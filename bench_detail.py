@@ -214,7 +214,7 @@ def bench_system_group(device: int, n_sessions: int, n_threads: int, steps: int 
                        stagger: int = 0):
     """S independent alva::System sessions on ONE GPU through alva_system_group: W host threads, the sessions as fibers -- a session's
     waits for the GPU run the thread's other sessions, so the threads execute map-layer work only.  Session i runs on worker i % W and
-    belongs to lane (i // W) % lanes: with lock-step launches (include/alvaar_system.h) the seven launches of a lane's tracking frames
+    belongs to lane (i + i // W) % lanes: with lock-step launches (include/alvaar_system.h) the seven launches of a lane's tracking frames
     are issued once per kind for all of its sessions, on the lane's stream, while the workers do the host half of the other lanes'
     sessions; every session keeps a stream of its own for its keyframe stages (n_streams = 0; k > 0: session i on shared stream
     (i % W) % k).  stagger = 0: all sessions replay the same resident stream in lock-step (keyframes coincide on one group step: the

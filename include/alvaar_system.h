@@ -65,8 +65,8 @@ int alva_system_set_stream(alva_system *sys, void *hip_stream);
 int alva_system_group_find_camera_pose_device(alva_system_group *group, int count, alva_system *const *systems, const uint8_t *const *d_rgba,
                                               double timestamp_ms, float *h_poses, int *h_status);
 /* LOCK-STEP LAUNCHES (default on; ALVA_GROUP_LOCKSTEP=0 or alva_system_group_set_lockstep(group, 0) turns them off).  The group owns
- * `lanes` streams of its own (default 2; ALVA_GROUP_LANES / alva_system_group_set_lanes; 0 = none); session i of a call runs on worker
- * i % n_threads and belongs to lane (i / n_threads) % lanes.  The seven launches of a tracking frame -- gray + pyramid level 0, pyramid,
+ * `lanes` streams of its own (default 4; ALVA_GROUP_LANES / alva_system_group_set_lanes; 0 = none); session i of a call runs on worker
+ * i % n_threads and belongs to lane (i + i / n_threads) % lanes.  The seven launches of a tracking frame -- gray + pyramid level 0, pyramid,
  * slot table, fb-KLT, compaction, P3P-LMedS, PnP -- are issued ONCE PER KIND for all sessions of a lane (blockIdx.y = session; the
  * argument blocks ride in the kernel arguments) on the lane's stream, by the thread whose session completes the set, instead of seven per
  * session: S side-by-side chains of small kernels saturate the GPU's command path and wave slots long before its arithmetic.  A worker

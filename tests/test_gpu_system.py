@@ -491,7 +491,12 @@ def test_group_sessions_equal_their_solo_runs(mode):
 
     def frames_of(w, h, seed, noise):
         canvas = synth.texture_canvas(w, h, seed)
-        return np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11 if noise else None)) for k in range(n)])
+        fr = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11 if noise else None)) for k in range(n)]
+        if seed == 3:   # the LAST session loses tracking in the middle (a scene cut for 14 frames: KLT / pose failures, status 2, reset,
+            other = synth.texture_canvas(w, h, 99)   # re-initialisation) while its lane mates keep tracking: frames that deposit images
+            for k in range(30, 44):                  # and then track nothing, sessions that leave the lock-step
+                fr[k] = synth.gray_to_rgba(synth.frame_gray(other, 3 * (k % 2) * 20 + k, w, h))
+        return np.stack(fr)
 
     dev = [torch.from_numpy(frames_of(w, h, seed, noise)).cuda() for w, h, cell, seed, noise in specs]
 
@@ -509,6 +514,7 @@ def test_group_sessions_equal_their_solo_runs(mode):
         rec.append(ar.counters())
         ar.close()
         solo.append(rec)
+    assert 2 in [r[0] for r in solo[-1][:n]], "the scene cut was meant to cost the last session its tracking"
     group = SystemGroup([], 2)
     group.set_lockstep(mode != "no_lockstep")
     group.set_lanes({"one_lane": 1, "three_lanes": 3}.get(mode, 2))
@@ -532,7 +538,7 @@ def test_group_sessions_equal_their_solo_runs(mode):
     else:
         assert carried > 1.2 * launches > 0, (mode, launches, carried)   # (sessions of different sizes, not all tracking at once)
     for i, (a, b) in enumerate(zip(solo, together)):
-        assert a[-1] == b[-1] and a[-1]["ba_solves"] >= 1, (i, a[-1], b[-1])
+        assert a[-1] == b[-1] and (a[-1]["ba_solves"] >= 1 or i == len(specs) - 1), (i, a[-1], b[-1])   # (the last session was reset late)
         for k in range(n):
             assert a[k][0] == b[k][0] and a[k][4] == b[k][4], (i, k)
             assert np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), (i, k)

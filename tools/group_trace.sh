@@ -10,4 +10,4 @@ tail -1 "$repo/gpurun_out/gt_${tag}.log"
 f=$(find "$out" -name "*kernel_trace.csv" | head -1)
 # tracker launches in the window: lock-step = W per group step (one per worker), otherwise S
 if [ "$lock" = "1" ]; then n=$((lanes * steps * ((S / lanes + 3) / 4))); else n=$((S * steps)); fi
-python3 "$repo/tools/group_trace_fold.py" "$f" $n ${TL:-} | tee "$repo/gpurun_out/gt_${tag}_fold.txt"
+python3 "$repo/tools/group_trace_fold.py" "$f" $n ${TL:-0} ${BIN:-} | tee "$repo/gpurun_out/gt_${tag}_fold.txt"

@@ -37,10 +37,35 @@ for s, e, n, _ in win:
 print(f"{'kernel':34s} {'calls':>7s} {'mean us':>9s} {'share of kernel time':>8s}")
 for n, (c, d) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"{n:34s} {c:7d} {d / c / 1e3:9.1f} {d / tot:8.3f}")
-if len(sys.argv) > 3:   # timeline of the last <ms> milliseconds of the window
+if len(sys.argv) > 3 and float(sys.argv[3]) > 0:   # timeline of the last <ms> milliseconds of the window
     span = float(sys.argv[3]) * 1e6
     tl = [k for k in win if k[0] >= t1 - span]
     base = tl[0][0]
     print(f"--- timeline of the last {sys.argv[3]} ms ({len(tl)} launches)")
     for s, e, n, q in tl:
         print(f"  q{q:>3} {n:34s} start {(s - base) / 1e3:9.1f}  dur {(e - s) / 1e3:8.1f}")
+if len(sys.argv) > 4:   # coarse histogram of the whole window: per bin (ms) the busy fraction (union), launches, mean concurrency
+    binw = float(sys.argv[4]) * 1e6
+    nb = int((t1 - t0) / binw) + 1
+    busy_b, sum_b, cnt_b = [0.0] * nb, [0.0] * nb, [0] * nb
+    ev = []
+    for s, e, n, q in win:
+        cnt_b[int((s - t0) / binw)] += 1
+        b0, b1 = int((s - t0) / binw), int((e - t0) / binw)
+        for b in range(b0, min(b1, nb - 1) + 1):
+            lo, hi = max(s, t0 + b * binw), min(e, t0 + (b + 1) * binw)
+            sum_b[b] += max(0.0, hi - lo)
+        ev.append((s, 1)); ev.append((e, -1))
+    ev.sort()
+    depth, last = 0, t0
+    for t, d in ev:
+        if depth > 0:
+            a, bb = last, t
+            b0, b1 = int((a - t0) / binw), int((bb - t0) / binw)
+            for b in range(b0, min(b1, nb - 1) + 1):
+                lo, hi = max(a, t0 + b * binw), min(bb, t0 + (b + 1) * binw)
+                busy_b[b] += max(0.0, hi - lo)
+        depth += d
+        last = t
+    print(f"--- per {sys.argv[4]} ms bin: busy fraction | launches | mean kernels in flight")
+    print(" ".join(f"{busy_b[b] / binw:.2f}|{cnt_b[b]}|{sum_b[b] / binw:.1f}" for b in range(nb)))
