@@ -16,5 +16,6 @@ cp $(find /tmp/prof_$T -name '*kernel_stats.csv' | head -1) $R/gpurun_out/${T}_k
 cd $R
 python tools/orb_kernels.py 1280 720 4000 > gpurun_out/${T}_orb_kernels_720p.txt 2>&1
 LINES_OUT=12 tools/pmc_traffic.sh ${T}_orb720 python tools/orb_kernels.py 1280 720 4000 > gpurun_out/${T}_orb720_pmc.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 cat gpurun_out/${T}_pytest.log
 wc -c gpurun_out/${T}_bench_line.json
