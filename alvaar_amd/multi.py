@@ -187,6 +187,87 @@ def frames_are_registered(xyz_absorbed: np.ndarray, xyz_kept: np.ndarray, max_sc
     return ok, {"pairs": int(len(xyz_absorbed)), "scale": s, "rotation_deg": ang, "translation_m": float(np.linalg.norm(t)), "rms_m": rms}
 
 
+def _split_records(records: torch.Tensor):
+    """valid records of a gathered block in fuse_duplicates' (stream, id) order -> (stream, id, xyz [n,3] f64, desc [n,32] u8), CUDA tensors"""
+    rec = records.reshape(-1, RECORD_BYTES)
+    rec = rec[rec[:, 4:8].contiguous().view(torch.int32).reshape(-1) >= 0]
+    stream = rec[:, 0:4].contiguous().view(torch.int32).reshape(-1)
+    ids = rec[:, 4:8].contiguous().view(torch.int32).reshape(-1)
+    order = torch.argsort(stream.to(torch.int64) * (1 << 32) + ids.to(torch.int64), stable=True)
+    rec = rec[order]
+    return (stream[order].contiguous(), ids[order].contiguous(), rec[:, 8:32].contiguous().view(torch.float64).reshape(-1, 3).contiguous(),
+            rec[:, 32:64].contiguous())
+
+
+def register_streams(records: torch.Tensor, ctx, max_hamming: int = 51, iters: int = 300, rel_tol: float = 0.03, min_inliers: int = 20):
+    """Bring the maps of INDEPENDENT monocular sessions into one frame -- each has its own gauge (origin, orientation, SCALE) -- before the
+    fuse rule compares positions: for every stream s > s0 (s0 = the lowest stream id in the block) a similarity x_s0 ~ s R x_s + t from
+    descriptor correspondences alone.  Candidates: mutual nearest neighbours in Hamming distance between the two streams' descriptor
+    medoids (alva_bf_match_hamming, both directions) within max_hamming bits; model: RANSAC over 3-point Umeyama fits (fixed seed: every
+    rank derives the same transform from the same gathered block), inlier = residual below rel_tol x the spread of s0's matched points,
+    refit on the inliers.  Returns {stream: dict(scale, R, t, inliers, candidates, rms)}; a stream with fewer than min_inliers stays out."""
+    stream, ids, xyz, desc = _split_records(records)
+    st_np = stream.cpu().numpy()
+    streams = sorted(set(int(s) for s in st_np))
+    out = {}
+    if len(streams) < 2:
+        return out
+    s0 = streams[0]
+    m0 = torch.from_numpy(st_np == s0).to(desc.device)
+    d0, x0 = desc[m0].contiguous(), xyz[m0].cpu().numpy()
+    for s in streams[1:]:
+        ms = torch.from_numpy(st_np == s).to(desc.device)
+        ds, xs = desc[ms].contiguous(), xyz[ms].cpu().numpy()
+        if len(xs) < 3 or len(x0) < 3:
+            continue
+        i_s0, dist_s0 = ctx.bf_match_hamming(ds, d0)     # for every point of s: its nearest in s0
+        i_0s, _ = ctx.bf_match_hamming(d0, ds)           # and back
+        i_s0, dist_s0, i_0s = i_s0.cpu().numpy(), dist_s0.cpu().numpy(), i_0s.cpu().numpy()
+        k = np.arange(len(xs))
+        mutual = (i_0s[i_s0] == k) & (dist_s0 <= max_hamming)
+        src, dst = xs[mutual], x0[i_s0[mutual]]
+        info = {"candidates": int(mutual.sum()), "inliers": 0}
+        if len(src) >= max(3, min_inliers):
+            tol = rel_tol * float(np.sqrt(((dst - dst.mean(0)) ** 2).sum(1).mean()))
+            rng = np.random.RandomState(12345 + s)
+            best = None
+            for _ in range(iters):
+                pick = rng.choice(len(src), 3, replace=False)
+                sc, R, t, _ = similarity_fit(src[pick], dst[pick])
+                if not np.isfinite(sc) or sc <= 0:
+                    continue
+                res = np.sqrt((((sc * (R @ src.T)).T + t - dst) ** 2).sum(1))
+                inl = res < tol
+                if best is None or inl.sum() > best.sum():
+                    best = inl
+            if best is not None and best.sum() >= min_inliers:
+                for _ in range(2):   # refit on the inliers, re-classify, refit
+                    sc, R, t, rms = similarity_fit(src[best], dst[best])
+                    best = np.sqrt((((sc * (R @ src.T)).T + t - dst) ** 2).sum(1)) < tol
+                if best.sum() >= min_inliers:
+                    sc, R, t, rms = similarity_fit(src[best], dst[best])
+                    info.update(scale=sc, R=R, t=t, inliers=int(best.sum()), rms=rms, tol=tol)
+        out[s] = info
+    return out
+
+
+def apply_registration(records: torch.Tensor, reg: dict) -> torch.Tensor:
+    """the gathered block with every registered stream's positions moved into the reference stream's frame (x <- s R x + t)"""
+    rec = records.reshape(-1, RECORD_BYTES).clone()
+    valid = rec[:, 4:8].contiguous().view(torch.int32).reshape(-1) >= 0
+    stream = rec[:, 0:4].contiguous().view(torch.int32).reshape(-1)
+    xyz = rec[:, 8:32].contiguous().view(torch.float64).reshape(-1, 3)
+    for s, r in reg.items():
+        if "scale" not in r:
+            continue
+        msk = valid & (stream == s)
+        R = torch.from_numpy(np.asarray(r["R"])).to(xyz.device)
+        t = torch.from_numpy(np.asarray(r["t"])).to(xyz.device)
+        xyz[msk] = r["scale"] * (xyz[msk] @ R.T) + t
+    rec[:, 8:32] = xyz.contiguous().view(torch.uint8).reshape(-1, 24)
+    return rec
+
+
 def apply_merge(ar, my_stream: int, stream: np.ndarray, ids: np.ndarray, keep: np.ndarray, absorbed_by: np.ndarray, xyz: np.ndarray | None = None):
     """Make the fused set real for ONE session (`ar`, stream number `my_stream`): every map point of this session that the round absorbed
     into another stream's point gets that point's (stream, id) as its shared id (alva_system_set_shared_ids); two of this session's OWN
@@ -217,12 +298,14 @@ def apply_merge(ar, my_stream: int, stream: np.ndarray, ids: np.ndarray, keep: n
     return {"applied": int(n_set), "local_merges": local_merges, "registered": True, "registration": reg}
 
 
-def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384, apply: bool = True):
+def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384, apply: bool = True, register: bool = False):
     """One shared-map merge (north_star: "RCCL over xGMI only for the optional shared-map merge"): pack this rank's map, ONE
     all_gather_into_tensor over the process group (RCCL when the backend is nccl), fuse the duplicates on the GPU, and APPLY the result to
     this rank's session (apply_merge: shared ids for its absorbed points, its own duplicates merged through MapManager::mergeMapPoints'
-    path) -- after checking that the fused pairs agree with the one-world-frame premise (frames_are_registered).  Returns a dict of sizes
-    and wall times; the fused set is identical on every rank (same input, deterministic rule)."""
+    path) -- after checking that the fused pairs agree with the one-world-frame premise (frames_are_registered).  register=True first
+    moves every stream into the lowest stream's frame by a similarity estimated from descriptor correspondences (register_streams): what
+    maps of independently initialised monocular sessions need.  Returns a dict of sizes and wall times; the fused set (and the
+    similarities) are identical on every rank (same input, deterministic rules)."""
     import time
     t0 = time.perf_counter()
     block, n = system_map_records(ar, shard.rank, capacity)
@@ -231,6 +314,10 @@ def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384, apply: bool = 
     allrec = all_gather_map(block)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    reg = None
+    if register:   # independent monocular maps: one frame first (similarities from descriptor correspondences), then the position rule
+        reg = register_streams(allrec, ctx)
+        allrec = apply_registration(allrec, reg)
     stream, ids, keep, absorbed = fuse_duplicates(allrec, ctx)
     kept = int(keep.sum().item())
     t3 = time.perf_counter()
@@ -248,4 +335,6 @@ def map_merge_round(ar, ctx, shard: Shard, capacity: int = 16384, apply: bool = 
         res = apply_merge(ar, shard.rank, stream.cpu().numpy(), ids.cpu().numpy(), keep.cpu().numpy(), absorbed.cpu().numpy().astype(np.int64), xyz)
         out.update(applied=res["applied"], local_merges=res["local_merges"], registered=res["registered"], registration=res["registration"],
                    apply_us=(time.perf_counter() - t3) * 1e6)
+    if reg is not None:
+        out["stream_frames"] = {int(s): {k_: (np.asarray(v).tolist() if isinstance(v, np.ndarray) else v) for k_, v in r.items()} for s, r in reg.items()}
     return out

@@ -122,3 +122,67 @@ def test_maps_in_different_frames_are_not_merged():
     assert res == {"applied": 0, "local_merges": 0, "registered": False, "registration": reg}
     s, R, t, rms = multi.similarity_fit(p, q)
     assert abs(s - 1.2) < 1e-9 and rms < 1e-12
+
+
+def _round_registered(sessions, ctx):
+    import torch
+    from alvaar_amd import multi
+    blocks = [multi.system_map_records(ar, s, 8192)[0] for s, ar in enumerate(sessions)]
+    allrec = torch.cat(blocks, 0)
+    reg = multi.register_streams(allrec, ctx)
+    moved = multi.apply_registration(allrec, reg)
+    stream, ids, keep, absorbed = multi.fuse_duplicates(moved, ctx)
+    _, _, xyz, _ = multi._split_records(moved)
+    args = (stream.cpu().numpy(), ids.cpu().numpy(), keep.cpu().numpy(), absorbed.cpu().numpy().astype(np.int64), xyz.cpu().numpy())
+    return reg, args, [multi.apply_merge(ar, s, *args) for s, ar in enumerate(sessions)]
+
+
+def _centre(ar):
+    return ar.pose7()[0][:3].copy()
+
+
+@pytest.mark.parametrize("case", ["scaled_gauge", "late_start"])
+def test_independent_monocular_maps_are_registered_then_merged(case):
+    """Two sessions of one scene with DIFFERENT gauges.  scaled_gauge: session b's two-view translation is 1.3x session a's (test hook), so
+    its whole map and trajectory are 1.3x larger.  late_start: b starts 8 frames later and initialises by itself -- its world origin is
+    another camera position.  Without registration the one-world-frame check refuses the round (or nothing fuses); register_streams finds
+    the similarity from descriptor correspondences alone, after which the maps fuse, b's points get a's ids as shared ids, and b's camera
+    centre mapped through the similarity lands on a's."""
+    import torch
+    import alvaar_amd
+    from alvaar_amd.system import AlvaAR
+    canvas = synth.texture_canvas(W, H, 7)
+    frames = torch.from_numpy(np.stack([synth.gray_to_rgba(synth.frame_gray(canvas, k, W, H)) for k in range(100)])).cuda()
+    a, b = (AlvaAR(W, H, cell_size=24, random_sampling=False) for _ in range(2))
+    off = 8 if case == "late_start" else 0
+    prev = 3
+    for k in range(90):
+        sa = a.find_camera_pose_device(int(frames[k].data_ptr()), 33.0 * k)
+        if case == "scaled_gauge" and sa == 1 and prev != 1:
+            p = a.pose7()[0].copy()
+            p[:3] *= 1.3
+            b.set_init_pose(p)          # b's two-view pose: a's, with a 1.3x longer baseline
+        prev = sa
+        if k >= off:
+            sb = b.find_camera_pose_device(int(frames[k].data_ptr()), 33.0 * k)
+    assert sa == 1 and sb == 1
+    ctx = alvaar_amd.Context(0)
+    (_, _, keep0, _, _), res0 = _round([a, b], ctx)
+    assert res0[1]["applied"] == 0 and (not res0[1]["registered"] or int((~keep0.astype(bool)).sum()) < 4), "different gauges must not merge as they are"
+    reg, (stream, ids, keep, absorbed, xyz), res = _round_registered([a, b], ctx)
+    r = reg[1]
+    assert r["inliers"] >= 30 and r["inliers"] > 0.5 * r["candidates"], r
+    if case == "scaled_gauge":
+        assert abs(r["scale"] - 1 / 1.3) < 0.02, r["scale"]
+    else:
+        assert abs(r["scale"] - 1) < 0.1 and np.linalg.norm(r["t"]) > 0.05, r
+    fused = int((~keep.astype(bool)).sum())
+    assert fused >= 30 and res[1]["registered"] and res[1]["applied"] == fused and res[0]["applied"] == 0
+    loc, sst, sid = b.shared_ids()
+    assert len(loc) == fused and (sst == 0).all()
+    # the similarity maps b's camera onto a's: centres agree to a few percent of the distance travelled
+    ca, cb = _centre(a), _centre(b)
+    mapped = r["scale"] * (np.asarray(r["R"]) @ cb) + np.asarray(r["t"])
+    assert np.linalg.norm(mapped - ca) < 0.05 * max(np.linalg.norm(ca), 1e-3), (mapped, ca)
+    a.close()
+    b.close()
