@@ -49,7 +49,7 @@ struct OrbDev {
     uint8_t *pool;          // images | scores | blurred
     int *rowCnt, *rowStart; // per row survivors / exclusive offsets (per level)
     int *n1, *n2, *n3;      // per level counts after NMS, after FAST cull, after Harris cull
-    int *hist;              // [nlevels][256] FAST score histogram
+    int *hist;              // [MAXLV][256] FAST score histogram, then [MAXLV][FAST_REGIONS] append counters of the fused FAST + NMS kernel
     int *c1x, *c1y, *c1s;   // NMS survivors (row-major per level)
     int *c2x, *c2y;         // after the FAST-score cull
     float *c2r;             // Harris responses
@@ -235,6 +235,16 @@ __global__ void __launch_bounds__(256) k_resize_b(const OrbItem *__restrict__ it
 
 // FAST score map of every level: 64x16 tile + 3 px halo staged in LDS
 constexpr int FT_W = 64, FT_H = 16;
+// The fused kernel's tiles append their survivors to the level's candidate list with one atomic per tile.  ONE counter per level meant
+// ~900 atomics with a return value on one address from eight XCDs at level 0 of a 1280x720 frame -- serialised at ~50 ns each they WERE the
+// kernel's 50 us (its tiles' own work is ~7 us of the chip).  FAST_REGIONS counters per level (behind the score histograms in D.hist,
+// zeroed per frame with them), each owning a fixed slice of the list; k_cull_fast walks the slices (the list's order was never defined).
+constexpr int FAST_REGIONS = 32;   // (8: 37 + 26 us for FAST + cull at 1280x720; 32: 31 + 23)
+constexpr int FAST_HIST_INTS = 12 * 256 + 12 * FAST_REGIONS + 12 * FAST_REGIONS * 256;   // D.hist: flat | region counters | per-region (MAXLV = 12)
+__host__ __device__ inline int fast_region_cap(int w, int h) {
+    const int nt = ((w + FT_W - 1) / FT_W) * ((h + FT_H - 1) / FT_H);
+    return (nt + FAST_REGIONS - 1) / FAST_REGIONS * (FT_W * FT_H / 4);
+}
 __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
     const Level &L = D.lv[blockIdx.y];
     const int tilesX = (L.w + FT_W - 1) / FT_W, tilesY = (L.h + FT_H - 1) / FT_H;
@@ -376,34 +386,46 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
             s_row[r] = tot;
             tot += c;
         }
-        s_base = tot ? atomicAdd(&D.n1[lvl], tot) : 0;
+        s_base = tot ? atomicAdd(&D.hist[MAXLV * 256 + lvl * FAST_REGIONS + (int) (tile % FAST_REGIONS)], tot) : 0;   // the tile's REGION of the list
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < FT_H / 4; it++) {
         if ((keepm[it] >> lane) & 1ull) {
             const int r = it * 4 + wave;
-            const int pos = s_base + s_row[r] + __popcll(keepm[it] & ((1ull << lane) - 1ull));
-            if (pos < L.candCap) {
+            const int rcap = fast_region_cap(L.w, L.h);
+            const int inr = s_base + s_row[r] + __popcll(keepm[it] & ((1ull << lane) - 1ull));
+            const int pos = (int) (tile % FAST_REGIONS) * rcap + inr;
+            if (inr < rcap) {
                 D.c1x[L.candOff + pos] = x0 + lane;
                 D.c1y[L.candOff + pos] = y0 + r;
                 D.c1s[L.candOff + pos] = myscore[it];
-                atomicAdd(&D.hist[lvl * 256 + myscore[it]], 1);
+                // the level's score histogram, one per REGION too: with the append counter's contention gone, ~20 k atomics on a few hundred
+                // hot counters from every XCD were the next 12 us (k_cull_fast adds the regions' histograms up: 8 loads per thread)
+                atomicAdd(&D.hist[MAXLV * 256 + MAXLV * FAST_REGIONS + (lvl * FAST_REGIONS + (int) (tile % FAST_REGIONS)) * 256 + myscore[it]], 1);
             }
         }
     }
 }
 
-// One frame: workgroup b of a level runs on XCD b % 8 (each with its own L2), so every XCD gets one CONTIGUOUS eighth of the level's tiles
-// (row-major): the 4-px halo rows and the 128-byte lines that neighbouring tiles share then meet in ONE L2 instead of being fetched through
-// up to three (PMC, plain order: 2.06 MB fetched per launch at 640x480 against ~1.0 MB of pyramid; the same cure as k_pyr_rest's).  The
-// grid's x extent is a multiple of 8 (run_fast_stages); the candidate order was never defined (tile completion order), later stages sort.
+// One frame: a 1-D grid over the tiles of ALL levels (a grid sized for level 0 on every level was 60 % empty workgroups: 7 232 dispatched
+// for 2 950 tiles at 1280x720 -- the launch was bound by workgroup dispatch, SQ counters: 1 100 waves resident on average of 8 192).  Each
+// level's share is padded to a multiple of 8 and, inside it, workgroup b runs on XCD b % 8 (each with its own L2), so every XCD gets one
+// CONTIGUOUS eighth of the level's tiles (row-major): the 4-px halo rows and the 128-byte lines that neighbouring tiles share meet in ONE
+// L2 instead of being fetched through up to three (PMC, plain order: 2.06 MB fetched per launch at 640x480 against ~1.0 MB of pyramid;
+// the same cure as k_pyr_rest's).  The candidate order was never defined (tile completion order), later stages sort.
 __global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
-    const Level &L = D.lv[blockIdx.y];
-    const int n = ((L.w + FT_W - 1) / FT_W) * ((L.h + FT_H - 1) / FT_H), per = (n + 7) / 8;
-    const int b = (int) blockIdx.x, j = b >> 3;
-    if (j >= per) return;
-    fast_nms_body(D, blockIdx.y, (b & 7) * per + j);
+    int b = (int) blockIdx.x, l = 0, n = 0, per = 0;
+    for (; l < D.nlevels; l++) {
+        n = ((D.lv[l].w + FT_W - 1) / FT_W) * ((D.lv[l].h + FT_H - 1) / FT_H);
+        per = (n + 7) / 8;
+        if (b < 8 * per) break;
+        b -= 8 * per;
+    }
+    if (l >= D.nlevels) return;
+    const int tile = (b & 7) * per + (b >> 3);
+    if (tile >= n) return;
+    fast_nms_body(D, l, tile);
 }
 // batched: blockIdx.x runs over the tiles of ALL levels (a grid sized for level 0 on every level would be 60 % empty workgroups)
 __global__ void __launch_bounds__(256) k_fast_nms_b(const OrbItem *__restrict__ items, int count, int per_cam) {
@@ -537,25 +559,62 @@ __device__ int compact_ordered(int n, Pred pred, Emit emit) {
 // cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept), preserving order
 __device__ __forceinline__ void cull_fast_body(const OrbDev &D, const int l) {
     const Level &L = D.lv[l];
-    const int n = min(D.n1[l], L.candCap), keepN = 2 * L.nKeep;
+    // the candidate list arrives in FAST_REGIONS slices (fast_nms_body): logical index i -> slice r with pre[r] <= i < pre[r + 1]
+    __shared__ int s_pre[FAST_REGIONS + 1];
+    const int rcap = fast_region_cap(L.w, L.h);
+    if (threadIdx.x < 64) {   // exclusive prefix sums of the slice counts: one load per lane, a wave scan
+        const int lane = threadIdx.x;
+        const int c = lane < FAST_REGIONS ? min(D.hist[MAXLV * 256 + l * FAST_REGIONS + lane], rcap) : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < FAST_REGIONS; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane < FAST_REGIONS) s_pre[lane] = incl - c;
+        if (lane == FAST_REGIONS - 1) s_pre[FAST_REGIONS] = incl;
+    }
+    __syncthreads();
+    const int n = s_pre[FAST_REGIONS], keepN = 2 * L.nKeep;
+    const int o = L.candOff;
+    // a thread's logical indices only grow (i, i + 1024, ...): its slice cursor moves forward, no search per element
     __shared__ unsigned s_bin, s_rem;
     int thr = 0;
     if (keepN == 0) thr = 1 << 30;
     else if (n > keepN) {
-        // largest score v with #{score >= v} >= keepN: prefix sums over the bins in DESCENDING score order
-        const int *hist = D.hist + l * 256;
-        if (threadIdx.x < 64) wave_find_bin([&](int b) { return (unsigned) hist[255 - b]; }, (unsigned) (keepN - 1), &s_bin, &s_rem);
+        // largest score v with #{score >= v} >= keepN: prefix sums over the bins in DESCENDING score order.  The histogram comes from the
+        // FAST + NMS kernel in FAST_REGIONS parts (building it here from the list was tried: an extra pass over the scores, +5 us at 1280x720)
+        __shared__ unsigned s_hist[256];
+        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        {
+            const int *rh = D.hist + MAXLV * 256 + MAXLV * FAST_REGIONS + l * FAST_REGIONS * 256;
+            unsigned acc = 0;
+            const int bin = threadIdx.x & 255, part = threadIdx.x >> 8;   // 4 partial sums per bin
+            for (int rr = part; rr < FAST_REGIONS; rr += 4) acc += (unsigned) rh[rr * 256 + bin];
+            atomicAdd(&s_hist[bin], acc);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) wave_find_bin([&](int b) { return s_hist[255 - b]; }, (unsigned) (keepN - 1), &s_bin, &s_rem);
         __syncthreads();
         thr = 255 - (int) s_bin;
     }
-    const int o = L.candOff;
+    int r = 0, p_of_i = 0;   // (pred and emit run for the same i in the same loop iteration of compact_ordered: one look-up)
     const int m = compact_ordered(
-        n, [&](int i) { return D.c1s[o + i] >= thr; },
-        [&](int i, int pos) {
-            D.c2x[o + pos] = D.c1x[o + i];
-            D.c2y[o + pos] = D.c1y[o + i];
+        n,
+        [&](int i) {
+            while (s_pre[r + 1] <= i) r++;
+            p_of_i = o + r * rcap + (i - s_pre[r]);
+            return D.c1s[p_of_i] >= thr;
+        },
+        [&](int, int pos) {
+            D.c2x[o + pos] = D.c1x[p_of_i];
+            D.c2y[o + pos] = D.c1y[p_of_i];
         });
-    if (threadIdx.x == 0) D.n2[l] = m;
+    if (threadIdx.x == 0) {
+        D.n2[l] = m;
+        D.n1[l] = n;
+    }
 }
 
 __global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) { cull_fast_body(D, blockIdx.x); }
@@ -816,10 +875,13 @@ __device__ __forceinline__ void copy_level0_body(const OrbDev &D, const uint8_t 
     const Level &L = D.lv[0];
     const int x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
     if (x < L.w && y < L.h) D.pool[L.img + (size_t) y * L.pitch + x] = src[(size_t) y * pitch + x];
-    // first launch of the chain: clear the FAST-score histograms here instead of a separate fill command
-    if (bx == 0 && by == 0) {
-        for (int k = threadIdx.x; k < MAXLV * 256; k += 256) D.hist[k] = 0;
-        if (threadIdx.x < MAXLV) D.n1[threadIdx.x] = 0;   // k_fast_nms appends with atomics
+    // first launch of the chain: clear the FAST-score histograms and append counters here instead of a separate fill command, every
+    // workgroup a slice (flat histograms | region counters | per-region histograms: 100 k ints)
+    {
+        const int gx = (L.w + 63) / 64, gy = (L.h + 3) / 4, nb = gx * gy, lb = by * gx + bx;
+        const int total = MAXLV * 256 + MAXLV * FAST_REGIONS + D.nlevels * FAST_REGIONS * 256;
+        for (int k = lb * 256 + (int) threadIdx.x; k < total; k += nb * 256) D.hist[k] = 0;
+        if (lb == 0 && threadIdx.x < MAXLV) D.n1[threadIdx.x] = 0;   // (the unfused FAST path's counts)
     }
 }
 
@@ -897,7 +959,9 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
         L.rowOff = rows;
         rows += L.h;
         L.candOff = cands;
-        L.candCap = L.w * L.h / 4 + 64;
+        // NMS survivors: at most a quarter of the pixels.  The fused FAST + NMS kernel appends per REGION (FAST_REGIONS counters per level, a
+        // tile's region = tile % FAST_REGIONS): room for every tile of a region to deliver its maximum of FT_W * FT_H / 4
+        L.candCap = std::max(L.w * L.h / 4 + 64, FAST_REGIONS * fast_region_cap(L.w, L.h));
         cands += L.candCap;
         o->maxRows = std::max(o->maxRows, L.h);
         o->maxTiles = std::max(o->maxTiles, ((L.w + FT_W - 1) / FT_W) * ((L.h + FT_H - 1) / FT_H));
@@ -942,7 +1006,7 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
     const size_t o_pool = take(pool), o_rowCnt = take((size_t) rows * 4), o_rowStart = take((size_t) rows * 4), o_n = take(3 * MAXLV * 4),
-                 o_hist = take((size_t) MAXLV * 256 * 4), o_c1 = take((size_t) cands * 12), o_c2 = take((size_t) cands * 12),
+                 o_hist = take((size_t) FAST_HIST_INTS * 4), o_c1 = take((size_t) cands * 12), o_c2 = take((size_t) cands * 12),
                  o_c3 = take((size_t) cands * 12), o_tap = take(tapOfs.size() * 8), o_total = take(64);
     hipError_t e = hipMalloc(&o->d_block, off);
     if (e != hipSuccess) {
@@ -1003,7 +1067,10 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
         hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
     if (fused) {
         // ORB: candidate order is irrelevant downstream (k_cull_harris re-sorts by position), so FAST + NMS is one launch
-        hipLaunchKernelGGL(k_fast_nms, dim3(8 * alva_divup(o->maxTiles, 8), D.nlevels), dim3(256), 0, st, D);
+        int total = 0;
+        for (int l = 0; l < D.nlevels; l++)
+            total += 8 * alva_divup(alva_divup(D.lv[l].w, FT_W) * alva_divup(D.lv[l].h, FT_H), 8);
+        hipLaunchKernelGGL(k_fast_nms, dim3((unsigned) total), dim3(256), 0, st, D);
         ALVA_LAUNCH_CHECK();
         return ALVA_OK;
     }
