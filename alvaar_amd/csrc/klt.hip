@@ -461,21 +461,26 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
         D.dbg[i] = ((wall_clock64() - t_begin) & 0xffffffffull) | ((unsigned long long) code << 32) | ((unsigned long long) (from_prior ? 1 : 0) << 36) |
                    ((unsigned long long) (from_prior && !ok ? 1 : 0) << 37);
     if (threadIdx.x == 0) {
-        // ONE atomic per slot on the packed counter (track_slots.hpp).  Its return value tells the last slot of the launch that it is
-        // the last, and hands it every count: it publishes them to the host right away -- nothing but the atomic's own result is read,
-        // so no fence is needed in front of the arrival.
+        // ONE atomic per slot on a packed counter (track_slots.hpp) -- STRIPED: 2 600 atomics-with-return on one address from eight XCDs
+        // queue at the memory side (k_fast_nms: 900 of them were that kernel's 50 us), so slot i arrives on stripe i % TRK_STRIPES, the
+        // last arrival of a stripe adds the stripe's totals to the top counter, and the last of those learns that the launch is complete
+        // and publishes the counts to the host right away: nothing but the atomics' own results is read, so no fence is needed.
         const unsigned long long add = (1ull << 48) | ((unsigned long long) (code != 0 && is3 != 0) << 32) |
                                        ((unsigned long long) (from_prior ? 1 : 0) << 16) | (unsigned long long) (from_prior && ok ? 1 : 0);
-        const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long *>(D.cnt) + 2, add);
-        const unsigned long long now = before + add;
-        if ((int) (now >> 48) == D.n) {
-            const int n_pose = (int) ((now >> 32) & 0xffff), nA = (int) ((now >> 16) & 0xffff), good = (int) (now & 0xffff);
-            // everything the host needs now -- the launch's sequence number, the size of the pose problem, p3pReq_ -- in ONE 8-byte
-            // system-scope store: a single word is consistent by itself, so no system-scope fence (an L2 write-back, ~2.5 us at the very
-            // end of the longest kernel of the frame) stands in front of it.  [seq : 32 | p3pReq_ : 1 | n_pose : 31] at o_hdr[10..11]
-            const int req = nA > 0 && (double) good < 0.33 * (double) nA ? 1 : 0;
-            const unsigned long long word = ((unsigned long long) (unsigned) D.seq << 32) | ((unsigned long long) req << 31) | (unsigned) n_pose;
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(D.o_hdr + 10), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const int st = i % TRK_STRIPES, in_stripe = (D.n - st + TRK_STRIPES - 1) / TRK_STRIPES;
+        unsigned long long *stripes = reinterpret_cast<unsigned long long *>(D.cnt) + 16;
+        const unsigned long long s_now = atomicAdd(stripes + st, add) + add;
+        if ((int) (s_now >> 48) == in_stripe) {
+            const unsigned long long now = atomicAdd(reinterpret_cast<unsigned long long *>(D.cnt) + 2, s_now) + s_now;
+            if ((int) (now >> 48) == D.n) {
+                const int n_pose = (int) ((now >> 32) & 0xffff), nA = (int) ((now >> 16) & 0xffff), good = (int) (now & 0xffff);
+                // everything the host needs now -- the launch's sequence number, the size of the pose problem, p3pReq_ -- in ONE 8-byte
+                // system-scope store: a single word is consistent by itself, so no system-scope fence (an L2 write-back, ~2.5 us at the very
+                // end of the longest kernel of the frame) stands in front of it.  [seq : 32 | p3pReq_ : 1 | n_pose : 31] at o_hdr[10..11]
+                const int req = nA > 0 && (double) good < 0.33 * (double) nA ? 1 : 0;
+                const unsigned long long word = ((unsigned long long) (unsigned) D.seq << 32) | ((unsigned long long) req << 31) | (unsigned) n_pose;
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(D.o_hdr + 10), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

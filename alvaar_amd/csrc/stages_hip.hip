@@ -299,6 +299,7 @@ __device__ __forceinline__ void track_compact_body(const TrackSlots &D, const in
             const int nA = (int) ((packed >> 16) & 0xffff), good = (int) (packed & 0xffff);
             const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
             reinterpret_cast<unsigned long long *>(D.cnt)[2] = 0ull;
+            for (int s = 0; s < TRK_STRIPES; s++) reinterpret_cast<unsigned long long *>(D.cnt)[16 + s] = 0ull;   // the tracker's arrival stripes
             D.cnt[8] = 0;
             // the step's completion word carries what the host reads of the header -- [seq : 32 | p3pReq_ : 1 | n_pose : 31] at
             // o_hdr[12..13], ONE 8-byte system-scope store: every slice's results are already behind its workgroup's fence + arrival,
@@ -406,14 +407,14 @@ struct HipStages::Impl {
         const size_t c = (size_t) cap;
         // device: cnt | slotA slotB | ptsA priorA outA ptsB priorB outB | stA stB is3d code | wpt | px | Pbv Puv Pwpt  (the list form; the
         // slot-wise form needs less)
-        const size_t dev_bytes = 256 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64;
+        const size_t dev_bytes = 1024 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64;
         const size_t pin_bytes = c * 8 + c + 64 + c * 24 + 256 + c + 64 + c * 16 + c * 24 + 256;
         int rc = trk_dev.grow(dev_bytes, st);
         if (rc) return rc;
         rc = trk_pin.grow(pin_bytes, st);
         if (rc) return rc;
         trk_cap = cap;
-        ALVA_HIP(hipMemsetAsync(trk_dev.base, 0, 256, st));  // the slot-wise step's counters start at zero
+        ALVA_HIP(hipMemsetAsync(trk_dev.base, 0, 1024, st));  // the slot-wise step's counters start at zero
         // fresh (or recycled) pinned memory: the completion word must not equal a sequence number the host is about to wait for.  The
         // stream is idle here (both grows synchronised it), so a plain host store cannot race a kernel's publication.
         ALVA_HIP(alva_stream_sync(st));
@@ -867,7 +868,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     if (!m->lists) {
         TrackSlots D{};
         uint8_t *b = m->trk_dev.base;
-        D.cnt = (int *) b; b += 256;
+        D.cnt = (int *) b; b += 1024;
         D.d_code = b; b += c;
         D.d_is3d = b; b += c;    // c is a multiple of 1024: every block below starts 16-byte aligned (k_track_stage_in copies in 16-byte units)
         b += 256 - ((uintptr_t) b & 255);
@@ -908,7 +909,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     TrackDev D{};
     {
         uint8_t *b = m->trk_dev.base;
-        D.cnt = (int *) b; b += 256;
+        D.cnt = (int *) b; b += 1024;
         D.slotA = (int *) b; b += c * 4;
         D.slotB = (int *) b; b += c * 4;
         D.ptsA = (float *) b; b += c * 8;

@@ -17,6 +17,7 @@
 #include "camera_device.hpp"
 #include <cstdint>
 
+constexpr int TRK_STRIPES = 64;   // arrival stripes of the wave-per-slot tracker launch: (unsigned long long *) cnt + 16 .. + 31 (see cnt below)
 struct TrackSlots {
     int n, use_prior, width, height;
     const float *in_px;        // pinned host, [n][2]
@@ -25,7 +26,7 @@ struct TrackSlots {
     double q[4], t[3];         // T_cw (predicted)
     AlvaCam cam;
     const double *invK;        // device, 9
-    int *cnt;                  // device, 256 bytes, zeroed by the compaction kernel.  (unsigned long long *) cnt + 2 = the tracker launch's ONE
+    int *cnt;                  // device, 1024 bytes, zeroed by the compaction kernel.  (unsigned long long *) cnt + 2 = the tracker launch's ONE
                                // packed counter: arrivals << 48 | tracked 3-D slots << 32 | slots tracked from their projection << 16 |
                                // successes of those (one atomic per workgroup; counts fit 16 bits: a frame holds < 65536 slots);
                                // cnt[8] = the compaction kernel's arrival counter
