@@ -72,6 +72,7 @@ _sig("alva_ctx_wait", [_vp, _vp])
 _sig("alva_prof_enable", [_i])
 _sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
+_sig("alva_orb_debug_level", [_vp, _vp, _i, _i, _vp, _sz, _vp, _vp])
 _sig("alva_match_to_map", [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _vp])
 _sig("alva_undistort_points", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
 _sig("alva_project_dist", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
@@ -519,6 +520,14 @@ class Orb:
         check(lib.alva_orb_collect(ctx.h, self.h, C.byref(cnt)))
         n = min(cnt.value, kp.shape[0])
         return kp[:n], (desc[:n] if desc is not None else None)
+
+    def level(self, l: int, blurred: bool = False):
+        """level l of the pyramid the last run built (blurred: its 7x7 blur) as a cuda uint8 tensor [h, w] (alva_orb_debug_level)"""
+        w, h = C.c_int(0), C.c_int(0)
+        check(lib.alva_orb_debug_level(self.ctx.h, self.h, l, int(blurred), None, 0, C.byref(w), C.byref(h)))
+        out = torch.empty((h.value, w.value), dtype=torch.uint8, device=f"cuda:{self.ctx.device}")
+        check(lib.alva_orb_debug_level(self.ctx.h, self.h, l, int(blurred), _ptr(out), out.stride(0), None, None))
+        return out
 
     def detect_and_compute(self, gray, describe=True, cap=None):
         """returns (kp [n,6] float32 {x,y,size,angle,response,octave}, desc [n,32] u8) cuda tensors"""

@@ -59,6 +59,11 @@ struct OrbDev {
     const int *tapCoef;     // resize tap coefficient (second tap, 0..256), -1 = clamp to first, -2 = clamp to last
     int *h_n3;              // pinned host mirror of n3, written by k_angle_emit (the host reads it after the stream sync)
     int umax[17];
+    // the fused pyramid launch (k_pyramid): levels 1 .. pyrFused in ONE launch, every tile recomputing its ancestors from level 0 in LDS
+    int pyrFused;               // 0 = none (then k_resize per level)
+    int pyrFirst[MAXLV + 2];    // workgroup ranges: segment j < pyrFused = level pyrFused - j (deepest first), segment pyrFused = the level-0 copy
+    int pyrSpanOff[MAXLV];      // level l's span table in pyrSpan
+    const int *pyrSpan;         // per level l: [tile column][k = 0 .. l - 1] (x0, nx) in level k, then [tile row][k] (y0, ny)
 };
 
 // One camera of a batched launch (k_*_b: camera = alva_xcd_item().cam): the detector's own state plus the call's arguments.
@@ -245,6 +250,154 @@ __host__ __device__ inline int fast_region_cap(int w, int h) {
     const int nt = ((w + FT_W - 1) / FT_W) * ((h + FT_H - 1) / FT_H);
     return (nt + FAST_REGIONS - 1) / FAST_REGIONS * (FT_W * FT_H / 4);
 }
+// ---- levels 1 .. F of the pyramid in ONE launch ---------------------------------------------------------------------------------------------
+// cv::ORB resizes level l from level l - 1 (orb.cpp:1086-1099, INTER_LINEAR_EXACT): a chain, seven dependent launches of ~7 us each at
+// 1280x720 although the chip needs < 1 us for any of them.  Every level IS a pure integer function of level 0, so a workgroup that owns
+// a PT_W x PT_H tile of level l recomputes the part of levels 1 .. l - 1 under that tile itself, in LDS, from the footprint of the tile
+// in the caller's image: the same taps at the same global coordinates, the same (acc + 2^15) >> 16 per pixel -> the same bytes as the
+// chain, with no inter-level wait at all.  The footprint of a level-7 tile at scale 1.2 is 138 x 81 source pixels and ~27x its own
+// size in recomputed pixels; all levels together are ~11 M pixel evaluations, a few microseconds of the chip.  The per-axis spans of every
+// tile in every ancestor level are tabulated at create time (orb_build), so a workgroup starts with one table read instead of a chain
+// of l dependent tap look-ups.  Deepest levels take the lowest workgroup numbers (longest chain first); the last segment of the grid
+// copies level 0 and clears the frame's counters (what k_copy_level0 did).
+constexpr int PT_W = 32, PT_H = 16;
+constexpr int PYR_BUF_A = 12288, PYR_BUF_B = 8192;   // even / odd ancestor levels' regions (level 0's footprint is the largest)
+constexpr int PYR_TAPS = 2048;                       // all stages' taps of one tile
+
+__device__ __forceinline__ void pyr_tile_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int l, const int tile) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[PYR_BUF_A];
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[PYR_BUF_B];
+    __shared__ int s_taps[PYR_TAPS];
+    __shared__ int s_x0[MAXLV], s_nx[MAXLV], s_y0[MAXLV], s_ny[MAXLV], s_toff[MAXLV + 1];
+    const Level &T = D.lv[l];
+    const int tid = threadIdx.x;
+    const int gxt = (T.w + PT_W - 1) / PT_W;
+    const int tx = tile % gxt, ty = tile / gxt;
+    if (tid < l) {                      // ancestor k = tid: the tile's span there
+        const int *sx = D.pyrSpan + D.pyrSpanOff[l] + (tx * l + tid) * 2;
+        s_x0[tid] = sx[0];
+        s_nx[tid] = sx[1];
+    } else if (tid >= 64 && tid < 64 + l) {
+        const int k = tid - 64;
+        const int *sy = D.pyrSpan + D.pyrSpanOff[l] + (gxt * l + ty * l + k) * 2;
+        s_y0[k] = sy[0];
+        s_ny[k] = sy[1];
+    } else if (tid == 128) {
+        s_x0[l] = tx * PT_W;
+        s_nx[l] = min(PT_W, T.w - tx * PT_W);
+        s_y0[l] = ty * PT_H;
+        s_ny[l] = min(PT_H, T.h - ty * PT_H);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int k = 1; k <= l; k++) {
+            s_toff[k] = t;
+            t += s_nx[k] + s_ny[k];
+        }
+        s_toff[0] = t;                  // total
+    }
+    // level 0's footprint -> s_a, dwords (unaligned loads; the last dword of a row by bytes when it would pass the image's edge)
+    {
+        const int X0 = s_x0[0], NX = s_nx[0], Y0 = s_y0[0], NY = s_ny[0], W0 = D.lv[0].w;
+        const int stride = (NX + 3) & ~3, dwr = stride >> 2;
+        for (int r = tid >> 5; r < NY; r += 8) {
+            const uint8_t *row = src + (size_t) (Y0 + r) * pitch + X0;
+            for (int c = tid & 31; c < dwr; c += 32) {
+                uint32_t v;
+                if (X0 + 4 * c + 4 <= W0) __builtin_memcpy(&v, row + 4 * c, 4);
+                else {
+                    v = 0;
+                    for (int j = 0; j < 4; j++)
+                        if (X0 + 4 * c + j < W0) v |= (uint32_t) row[4 * c + j] << (8 * j);
+                }
+                *reinterpret_cast<uint32_t *>(s_a + r * stride + 4 * c) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // every stage's taps, relative to the region they read: (first source index) | (weight of the second tap << 16); a clamped tap
+    // (-1 / -2: copies the first / last source element) is weight 0 on that element -- 256 * v + 0 * v, the same ufixedpoint16 value
+    {
+        const int total = s_toff[0];
+        for (int i = tid; i < total; i += 256) {
+            int k = 1;
+            while (k < l && i >= s_toff[k + 1]) k++;
+            const Level &K = D.lv[k], &S = D.lv[k - 1];
+            int j = i - s_toff[k];
+            const bool yax = j >= s_nx[k];
+            if (yax) j -= s_nx[k];
+            const int g = (yax ? s_y0[k] : s_x0[k]) + j;
+            const int tp = K.tabOff + (yax ? K.w : 0) + g;
+            const int c = D.tapCoef[tp], of = D.tapOfs[tp];
+            const int base = yax ? s_y0[k - 1] : s_x0[k - 1], sn = yax ? S.h : S.w;
+            int a, wb;
+            if (c == -1) { a = 0; wb = 0; }
+            else if (c == -2) { a = sn - 1; wb = 0; }
+            else { a = of; wb = c; }
+            s_taps[i] = (a - base) | (wb << 16);
+        }
+    }
+    __syncthreads();
+    const int lx = tid & 31, ly = tid >> 5;
+    for (int k = 1; k <= l; k++) {
+        const uint8_t *in = (k - 1) & 1 ? s_b : s_a;
+        uint8_t *outl = k & 1 ? s_b : s_a;
+        const int sstride = (s_nx[k - 1] + 3) & ~3;
+        const int onx = s_nx[k], ony = s_ny[k], ostride = (onx + 3) & ~3;
+        const int *tapx = s_taps + s_toff[k], *tapy = tapx + onx;
+        const bool last = k == l;
+        uint8_t *gout = D.pool + D.lv[k].img + (size_t) s_y0[k] * D.lv[k].pitch + s_x0[k];
+        const int gpitch = D.lv[k].pitch;
+        for (int xx = lx; xx < onx; xx += 32) {
+            const int t = tapx[xx];
+            const int xa = t & 0xffff, wb = t >> 16, wa = 256 - wb, xb = xa + (wb != 0);
+#pragma unroll 2
+            for (int yy = ly; yy < ony; yy += 8) {
+                const int u = tapy[yy];
+                const int r0 = u & 0xffff, c1 = u >> 16, c0 = 256 - c1, r1 = r0 + (c1 != 0);
+                const uint8_t *p0 = in + r0 * sstride, *p1 = in + r1 * sstride;
+                const unsigned h0 = (unsigned) wa * p0[xa] + (unsigned) wb * p0[xb];
+                const unsigned h1 = (unsigned) wa * p1[xa] + (unsigned) wb * p1[xb];
+                const unsigned acc = (unsigned) c0 * h0 + (unsigned) c1 * h1;
+                const uint8_t v = (uint8_t) min((acc + 32768u) >> 16, 255u);
+                if (last) gout[(size_t) yy * gpitch + xx] = v;
+                else outl[yy * ostride + xx] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the level-0 segment: 512 x 4 pixels per workgroup, 8 bytes per thread, and the frame's counters cleared in slices (see copy_level0_body)
+__device__ __forceinline__ void pyr_copy0_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int b, const int nb) {
+    const Level &L = D.lv[0];
+    const int gxw = (L.w + 511) / 512;
+    const int x = (b % gxw) * 512 + (int) (threadIdx.x & 63) * 8, y = (b / gxw) * 4 + (int) (threadIdx.x >> 6);
+    if (x < L.w && y < L.h) {
+        const uint8_t *p = src + (size_t) y * pitch + x;
+        uint8_t *q = D.pool + L.img + (size_t) y * L.pitch + x;
+        if (x + 8 <= L.w) {
+            unsigned long long v;
+            __builtin_memcpy(&v, p, 8);
+            *reinterpret_cast<unsigned long long *>(q) = v;   // pool rows are 64-byte aligned
+        } else {
+            for (int j = 0; x + j < L.w; j++) q[j] = p[j];
+        }
+    }
+    const int total = MAXLV * 256 + MAXLV * FAST_REGIONS + D.nlevels * FAST_REGIONS * 256;
+    for (int k = b * 256 + (int) threadIdx.x; k < total; k += nb * 256) D.hist[k] = 0;
+    if (b == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;   // n1 | n2 (k_cull_fast appends through n2)
+}
+
+__global__ void __launch_bounds__(256) k_pyramid(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) {
+    const int b = (int) blockIdx.x, F = D.pyrFused;
+    int j = 0;
+    while (j < F && b >= D.pyrFirst[j + 1]) j++;
+    if (j < F) pyr_tile_body(D, src, pitch, F - j, b - D.pyrFirst[j]);
+    else pyr_copy0_body(D, src, pitch, b - D.pyrFirst[F], D.pyrFirst[F + 1] - D.pyrFirst[F]);
+}
+
 __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
     const Level &L = D.lv[blockIdx.y];
     const int tilesX = (L.w + FT_W - 1) / FT_W, tilesY = (L.h + FT_H - 1) / FT_H;
@@ -556,71 +709,83 @@ __device__ int compact_ordered(int n, Pred pred, Emit emit) {
     return carry;
 }
 
-// cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept), preserving order
-__device__ __forceinline__ void cull_fast_body(const OrbDev &D, const int l) {
+// cull by FAST score: keep score >= the (2 n_l)-th largest (all ties kept).  One workgroup per REGION of the level's candidate list
+// (fast_nms_body appends per region): every workgroup finds the level's threshold from the regions' histograms (8 K ints, L2), then
+// filters its own slice and appends the survivors to the level's second list with ONE atomic on n2[l] (zeroed by the frame's first
+// launch).  The list's order was never defined (tile completion order) and nothing downstream depends on it: cull_harris_body ranks by
+// response and emits in position order.  (One 1024-thread workgroup per level walking the whole list in order was 25.7 us at 1280x720,
+// with eight workgroups on the chip.)
+__device__ __forceinline__ void cull_fast_body(const OrbDev &D, const int l, const int r) {
     const Level &L = D.lv[l];
-    // the candidate list arrives in FAST_REGIONS slices (fast_nms_body): logical index i -> slice r with pre[r] <= i < pre[r + 1]
-    __shared__ int s_pre[FAST_REGIONS + 1];
-    const int rcap = fast_region_cap(L.w, L.h);
-    if (threadIdx.x < 64) {   // exclusive prefix sums of the slice counts: one load per lane, a wave scan
-        const int lane = threadIdx.x;
+    __shared__ int s_n, s_mine, s_base, s_wc[4];
+    __shared__ unsigned s_hist[256], s_bin, s_rem;
+    const int rcap = fast_region_cap(L.w, L.h), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
         const int c = lane < FAST_REGIONS ? min(D.hist[MAXLV * 256 + l * FAST_REGIONS + lane], rcap) : 0;
-        int incl = c;
+        int tot = c;
 #pragma unroll
-        for (int d = 1; d < FAST_REGIONS; d <<= 1) {
-            const int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        if (lane < FAST_REGIONS) s_pre[lane] = incl - c;
-        if (lane == FAST_REGIONS - 1) s_pre[FAST_REGIONS] = incl;
+        for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+        if (lane == r) s_mine = c;
+        if (lane == 0) s_n = tot;
     }
     __syncthreads();
-    const int n = s_pre[FAST_REGIONS], keepN = 2 * L.nKeep;
-    const int o = L.candOff;
-    // a thread's logical indices only grow (i, i + 1024, ...): its slice cursor moves forward, no search per element
-    __shared__ unsigned s_bin, s_rem;
+    const int n = s_n, mine = s_mine, keepN = 2 * L.nKeep;
     int thr = 0;
     if (keepN == 0) thr = 1 << 30;
     else if (n > keepN) {
-        // largest score v with #{score >= v} >= keepN: prefix sums over the bins in DESCENDING score order.  The histogram comes from the
-        // FAST + NMS kernel in FAST_REGIONS parts (building it here from the list was tried: an extra pass over the scores, +5 us at 1280x720)
-        __shared__ unsigned s_hist[256];
-        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+        // largest score v with #{score >= v} >= keepN: prefix sums over the bins in DESCENDING score order
+        const int *rh = D.hist + MAXLV * 256 + MAXLV * FAST_REGIONS + l * FAST_REGIONS * 256;
+        unsigned acc = 0;
+#pragma unroll 8
+        for (int rr = 0; rr < FAST_REGIONS; rr++) acc += (unsigned) rh[rr * 256 + tid];
+        s_hist[tid] = acc;
         __syncthreads();
-        {
-            const int *rh = D.hist + MAXLV * 256 + MAXLV * FAST_REGIONS + l * FAST_REGIONS * 256;
-            unsigned acc = 0;
-            const int bin = threadIdx.x & 255, part = threadIdx.x >> 8;   // 4 partial sums per bin
-            for (int rr = part; rr < FAST_REGIONS; rr += 4) acc += (unsigned) rh[rr * 256 + bin];
-            atomicAdd(&s_hist[bin], acc);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) wave_find_bin([&](int b) { return s_hist[255 - b]; }, (unsigned) (keepN - 1), &s_bin, &s_rem);
+        if (tid < 64) wave_find_bin([&](int b) { return s_hist[255 - b]; }, (unsigned) (keepN - 1), &s_bin, &s_rem);
         __syncthreads();
         thr = 255 - (int) s_bin;
     }
-    int r = 0, p_of_i = 0;   // (pred and emit run for the same i in the same loop iteration of compact_ordered: one look-up)
-    const int m = compact_ordered(
-        n,
-        [&](int i) {
-            while (s_pre[r + 1] <= i) r++;
-            p_of_i = o + r * rcap + (i - s_pre[r]);
-            return D.c1s[p_of_i] >= thr;
-        },
-        [&](int, int pos) {
-            D.c2x[o + pos] = D.c1x[p_of_i];
-            D.c2y[o + pos] = D.c1y[p_of_i];
-        });
-    if (threadIdx.x == 0) {
-        D.n2[l] = m;
-        D.n1[l] = n;
+    const int o = L.candOff, src0 = o + r * rcap;
+    // pass 1: how many of the slice survive; pass 2 (after the one atomic) writes them
+    int cnt = 0;
+    for (int i = tid; i < mine; i += 256) cnt += D.c1s[src0 + i] >= thr;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (lane == 0) s_wc[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+        s_base = tot ? atomicAdd(&D.n2[l], tot) : 0;
+        if (r == 0) D.n1[l] = n;
+    }
+    __syncthreads();
+    int carry = s_base;
+    for (int b = 0; b < mine; b += 256) {
+        const int i = b + tid;
+        const bool k = i < mine && D.c1s[src0 + i] >= thr;
+        const unsigned long long m = __ballot(k);
+        __syncthreads();   // (s_wc of the previous round / of pass 1 has been read)
+        if (lane == 0) s_wc[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int c = s_wc[w];
+            before += w < wave ? c : 0;
+            tot += c;
+        }
+        if (k) {
+            const int pos = o + carry + before + __popcll(m & ((1ull << lane) - 1ull));
+            D.c2x[pos] = D.c1x[src0 + i];
+            D.c2y[pos] = D.c1y[src0 + i];
+        }
+        carry += tot;
     }
 }
 
-__global__ void __launch_bounds__(1024) k_cull_fast(OrbDev D) { cull_fast_body(D, blockIdx.x); }
-__global__ void __launch_bounds__(1024) k_cull_fast_b(const OrbItem *__restrict__ items, int count, int nlevels) {
-    const AlvaXcdItem w = alva_xcd_item(count, nlevels);
-    if (w.cam < count) cull_fast_body(items[w.cam].D, w.item);
+__global__ void __launch_bounds__(256) k_cull_fast(OrbDev D) { cull_fast_body(D, blockIdx.y, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_cull_fast_b(const OrbItem *__restrict__ items, int count, int nlevels) {
+    const AlvaXcdItem w = alva_xcd_item(count, nlevels * FAST_REGIONS);
+    if (w.cam < count) cull_fast_body(items[w.cam].D, w.item / FAST_REGIONS, w.item % FAST_REGIONS);
 }
 
 // Harris response of every surviving candidate (orb.cpp:130-177): one wave each, the 49 block positions spread over the
@@ -666,8 +831,9 @@ __device__ __forceinline__ unsigned f2key(float f) {  // order-preserving map fl
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// cull by Harris: keep response >= the n_l-th largest, preserving order (radix select on the float keys)
-__device__ __forceinline__ void cull_harris_body(const OrbDev &D, const int l) {
+// cull by Harris for a level with more than HARRIS_RANK_CAP candidates: keep response >= the n_l-th largest, preserving the list's order
+// (radix select on the float keys, passes over global memory)
+__device__ __forceinline__ void cull_harris_big(const OrbDev &D, const int l) {
     const Level &L = D.lv[l];
     const int n = D.n2[l], keepN = L.nKeep, o = L.candOff;
     __shared__ unsigned s_hist[256];
@@ -734,6 +900,83 @@ __device__ __forceinline__ void cull_harris_body(const OrbDev &D, const int l) {
             D.c3r[o + rank] = er[q];
         }
     }
+}
+
+
+// cull by Harris: keep response >= the n_l-th largest (ties kept), emit in row-major position order.  A candidate is kept iff FEWER than
+// n_l responses are strictly greater than its own (the same set as "key >= the n_l-th largest key"), and its place in the output is the
+// number of kept candidates at smaller positions: two counting passes over an LDS copy of the keys (broadcast 16-byte reads), no
+// selection passes over global memory, no dependence on the order the candidates arrive in.  (Radix select + ordered compaction + rank
+// sort: 25.6 us at 1280x720 for ~1 700 candidates at level 0.)
+constexpr int HARRIS_RANK_CAP = 4096;
+__device__ __forceinline__ void cull_harris_body(const OrbDev &D, const int l) {
+    const Level &L = D.lv[l];
+    const int n = D.n2[l], keepN = L.nKeep, o = L.candOff;
+    if (n > HARRIS_RANK_CAP) {
+        cull_harris_big(D, l);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned s_k[HARRIS_RANK_CAP + 4];
+    __shared__ int s_m;
+    const int tid = threadIdx.x;
+    int ex[4] = {0, 0, 0, 0}, ey[4] = {0, 0, 0, 0};
+    float er[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned rk[4];
+    if (tid == 0) s_m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = tid + q * 1024;
+        rk[q] = 0;
+        if (i < n) {
+            ex[q] = D.c2x[o + i];
+            ey[q] = D.c2y[o + i];
+            er[q] = D.c2r[o + i];
+            rk[q] = f2key(er[q]);
+            s_k[i] = rk[q];
+        }
+    }
+    if (tid < 4) s_k[n + tid] = 0u;   // padding of the last 16-byte group: never greater than a key
+    __syncthreads();
+    const int n4 = (n + 3) >> 2;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int j = 0; j < n4; j++) {
+        const uint4 k = reinterpret_cast<const uint4 *>(s_k)[j];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cnt[q] += (int) (k.x > rk[q]) + (int) (k.y > rk[q]) + (int) (k.z > rk[q]) + (int) (k.w > rk[q]);
+    }
+    __syncthreads();
+    bool keep[4];
+    unsigned pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = tid + q * 1024;
+        keep[q] = i < n && cnt[q] < keepN;
+        pk[q] = keep[q] ? ((unsigned) ey[q] << 16) | (unsigned) ex[q] : 0xffffffffu;
+        if (i < n) s_k[i] = pk[q];
+    }
+    if (tid < 4) s_k[n + tid] = 0xffffffffu;   // never smaller than a position key
+    __syncthreads();
+    int rank[4] = {0, 0, 0, 0};
+    for (int j = 0; j < n4; j++) {
+        const uint4 k = reinterpret_cast<const uint4 *>(s_k)[j];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rank[q] += (int) (k.x < pk[q]) + (int) (k.y < pk[q]) + (int) (k.z < pk[q]) + (int) (k.w < pk[q]);
+    }
+    int kept = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (keep[q]) {
+            D.c3x[o + rank[q]] = ex[q];
+            D.c3y[o + rank[q]] = ey[q];
+            D.c3r[o + rank[q]] = er[q];
+            kept++;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) kept += __shfl_xor(kept, d);
+    if ((tid & 63) == 0 && kept) atomicAdd(&s_m, kept);
+    __syncthreads();
+    if (tid == 0) D.n3[l] = s_m;
 }
 
 __global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) { cull_harris_body(D, blockIdx.x); }
@@ -881,7 +1124,7 @@ __device__ __forceinline__ void copy_level0_body(const OrbDev &D, const uint8_t 
         const int gx = (L.w + 63) / 64, gy = (L.h + 3) / 4, nb = gx * gy, lb = by * gx + bx;
         const int total = MAXLV * 256 + MAXLV * FAST_REGIONS + D.nlevels * FAST_REGIONS * 256;
         for (int k = lb * 256 + (int) threadIdx.x; k < total; k += nb * 256) D.hist[k] = 0;
-        if (lb == 0 && threadIdx.x < MAXLV) D.n1[threadIdx.x] = 0;   // (the unfused FAST path's counts)
+        if (lb == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;   // n1 (the unfused FAST path's counts) | n2 (k_cull_fast appends through it)
     }
 }
 
@@ -904,6 +1147,9 @@ struct alva_orb {
     int maxRows = 0, maxTiles = 0, candTotal = 0;
     int *d_total = nullptr;
     bool fast_only = false;
+    void *d_blur_batch = nullptr;   // the levels' BlurBatch in device memory (the pool's addresses never change)
+    int blurTiles = 0;
+    bool chain_resize = false;      // ALVA_ORB_PYRAMID=chain: one k_resize per level (the fused launch's check)
 };
 
 static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float scale_factor, int nlevels, int fast_threshold, int border,
@@ -994,6 +1240,57 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
             tapCoef.resize(tapCoef.size() + L.w + L.h, 0);
         }
     }
+    // the fused pyramid launch's plan: spans of every tile column / row of level l in its ancestors 0 .. l - 1 (pyr_tile_body), and
+    // which levels fit its LDS buffers (a prefix 1 .. pyrFused; steeper pyramids than 1.2 leave the deep levels to k_resize)
+    std::vector<int> spans;
+    D.pyrFused = 0;
+    for (int l = 1; l < nlevels; l++) {
+        const Level &T = D.lv[l];
+        const int gxt = alva_divup(T.w, PT_W), gyt = alva_divup(T.h, PT_H);
+        std::vector<int> sp((size_t) (gxt + gyt) * l * 2);
+        int maxw[MAXLV] = {0}, maxh[MAXLV] = {0};
+        for (int axis = 0; axis < 2; axis++) {
+            const int nt = axis ? gyt : gxt, ts = axis ? PT_H : PT_W;
+            for (int t = 0; t < nt; t++) {
+                int a0 = t * ts, an = std::min(ts, (axis ? T.h : T.w) - a0);
+                for (int k = l; k >= 1; k--) {
+                    const Level &K = D.lv[k], &S = D.lv[k - 1];
+                    const int *to = tapOfs.data() + K.tabOff + (axis ? K.w : 0);
+                    const int sn = axis ? S.h : S.w;
+                    const int lo = to[a0], hi = std::min(to[a0 + an - 1] + 1, sn - 1);
+                    a0 = lo;
+                    an = hi - lo + 1;
+                    int *e = sp.data() + ((axis ? (size_t) gxt * l : 0) + (size_t) t * l + (size_t) (k - 1)) * 2;
+                    e[0] = a0;
+                    e[1] = an;
+                    int &m = (axis ? maxh : maxw)[k - 1];
+                    m = std::max(m, an);
+                }
+            }
+        }
+        bool fits = true;
+        int taps = PT_W + PT_H;
+        for (int k = 0; k < l; k++) {
+            fits = fits && ((maxw[k] + 3) & ~3) * maxh[k] <= (k & 1 ? PYR_BUF_B : PYR_BUF_A) && maxw[k] < 65536 && maxh[k] < 65536;
+            if (k >= 1) taps += maxw[k] + maxh[k];
+        }
+        if (!fits || taps > PYR_TAPS) break;
+        D.pyrFused = l;
+        D.pyrSpanOff[l] = (int) spans.size();
+        spans.insert(spans.end(), sp.begin(), sp.end());
+    }
+    {
+        int first = 0;
+        for (int j = 0; j < D.pyrFused; j++) {
+            const Level &T = D.lv[D.pyrFused - j];
+            D.pyrFirst[j] = first;
+            first += alva_divup(T.w, PT_W) * alva_divup(T.h, PT_H);
+        }
+        D.pyrFirst[D.pyrFused] = first;
+        first += alva_divup(D.lv[0].w, 512) * alva_divup(D.lv[0].h, 4);
+        D.pyrFirst[D.pyrFused + 1] = first;
+    }
+    if (spans.empty()) spans.push_back(0);
     for (int l = 0; l < nlevels; l++) {
         Level &L = D.lv[l];
         const size_t bytes = (size_t) L.pitch * L.h;
@@ -1007,7 +1304,8 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
     const size_t o_pool = take(pool), o_rowCnt = take((size_t) rows * 4), o_rowStart = take((size_t) rows * 4), o_n = take(3 * MAXLV * 4),
                  o_hist = take((size_t) FAST_HIST_INTS * 4), o_c1 = take((size_t) cands * 12), o_c2 = take((size_t) cands * 12),
-                 o_c3 = take((size_t) cands * 12), o_tap = take(tapOfs.size() * 8), o_total = take(64);
+                 o_c3 = take((size_t) cands * 12), o_tap = take(tapOfs.size() * 8), o_total = take(64), o_span = take(spans.size() * 4),
+                 o_blur = take(alva_blur7_batch_size());
     hipError_t e = hipMalloc(&o->d_block, off);
     if (e != hipSuccess) {
         delete o;
@@ -1029,6 +1327,12 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     D.tapOfs = d_tap;
     D.tapCoef = d_tap + tapOfs.size();
     o->d_total = (int *) (b + o_total);
+    D.pyrSpan = (const int *) (b + o_span);
+    o->d_blur_batch = b + o_blur;
+    {
+        const char *e_ = getenv("ALVA_ORB_PYRAMID");
+        o->chain_resize = e_ && !strcmp(e_, "chain");
+    }
     e = hipHostMalloc((void **) &D.h_n3, MAXLV * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void) hipFree(o->d_block);
@@ -1039,6 +1343,29 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     memset(D.h_n3, 0, MAXLV * sizeof(int));
     ALVA_HIP(hipMemcpyAsync(d_tap, tapOfs.data(), tapOfs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ALVA_HIP(hipMemcpyAsync(d_tap + tapOfs.size(), tapCoef.data(), tapCoef.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ALVA_HIP(hipMemcpyAsync(b + o_span, spans.data(), spans.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint8_t> blurBatch(alva_blur7_batch_size());
+    {
+        const uint8_t *bs[MAXLV];
+        uint8_t *bd[MAXLV];
+        int bw[MAXLV], bh[MAXLV], bp[MAXLV];
+        for (int l = 0; l < nlevels; l++) {
+            const Level &L = D.lv[l];
+            bs[l] = D.pool + L.img;
+            bd[l] = D.pool + L.blur;
+            bw[l] = L.w;
+            bh[l] = L.h;
+            bp[l] = L.pitch;
+        }
+        o->blurTiles = alva_blur7_batch_fill(blurBatch.data(), nlevels, bs, bd, bw, bh, bp);
+        if (o->blurTiles < 0) {
+            (void) hipStreamSynchronize(ctx->stream);
+            alva_orb_destroy(o);
+            alva_set_error("alva_orb_create: image pool rows are not 4-byte aligned");
+            return ALVA_ERR_STATE;
+        }
+        ALVA_HIP(hipMemcpyAsync(o->d_blur_batch, blurBatch.data(), blurBatch.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
     ALVA_HIP(hipStreamSynchronize(ctx->stream));
     *out = o;
     return ALVA_OK;
@@ -1062,8 +1389,14 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
     OrbDev &D = o->D;
     hipStream_t st = ctx->stream;
     const Level &L0 = D.lv[0];
-    hipLaunchKernelGGL(k_copy_level0, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4)), dim3(256), 0, st, D, d_gray, gray_pitch);
-    for (int l = 1; l < D.nlevels; l++)
+    int chained = 1;   // first level that still needs its own k_resize
+    if (o->chain_resize) {
+        hipLaunchKernelGGL(k_copy_level0, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4)), dim3(256), 0, st, D, d_gray, gray_pitch);
+    } else {
+        hipLaunchKernelGGL(k_pyramid, dim3((unsigned) D.pyrFirst[D.pyrFused + 1]), dim3(256), 0, st, D, d_gray, gray_pitch);
+        chained = D.pyrFused + 1;
+    }
+    for (int l = chained; l < D.nlevels; l++)
         hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
     if (fused) {
         // ORB: candidate order is irrelevant downstream (k_cull_harris re-sorts by position), so FAST + NMS is one launch
@@ -1087,6 +1420,20 @@ extern "C" int alva_orb_collect(alva_ctx *ctx, alva_orb *orb, int *h_count);
 // device-resident total of the last detect_and_compute (internal: lets the driver chain the matcher without a host round trip)
 extern "C" const int *alva_orb_device_count(const alva_orb *orb) { return orb ? orb->d_total : nullptr; }
 
+// one level of the detector's pyramid as the last alva_orb_detect_and_compute left it (which = 0) or its 7x7 blur (which = 1): w x h bytes
+extern "C" int alva_orb_debug_level(alva_ctx *ctx, alva_orb *orb, int level, int which, uint8_t *d_out, size_t out_pitch, int *w, int *h) {
+    ALVA_ARG(ctx && orb && level >= 0 && level < orb->D.nlevels && (which == 0 || which == 1));
+    const Level &L = orb->D.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!d_out) return ALVA_OK;
+    ALVA_ARG(out_pitch >= (size_t) L.w);
+    ALVA_HIP(hipMemcpy2DAsync(d_out, out_pitch, orb->D.pool + (which ? L.blur : L.img), (size_t) L.pitch, (size_t) L.w, (size_t) L.h, hipMemcpyDeviceToDevice,
+                              ctx->stream));
+    ALVA_HIP(hipStreamSynchronize(ctx->stream));
+    return ALVA_OK;
+}
+
 extern "C" int alva_orb_ambiguous_rotations(int *h_count, int reset) {
     ALVA_ARG(h_count);
     ALVA_HIP(hipMemcpyFromSymbol(h_count, HIP_SYMBOL(g_orb_ambiguous), sizeof(int)));
@@ -1104,7 +1451,7 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     hipStream_t st = ctx->stream;
     int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cull_fast, dim3(D.nlevels), dim3(1024), 0, st, D);
+    hipLaunchKernelGGL(k_cull_fast, dim3(FAST_REGIONS, D.nlevels), dim3(256), 0, st, D);
     hipLaunchKernelGGL(k_harris, dim3(256, D.nlevels), dim3(256), 0, st, D);   // wave-strided over the level's candidates
     hipLaunchKernelGGL(k_cull_harris, dim3(D.nlevels), dim3(1024), 0, st, D);
     int maxKeep = 0;
@@ -1114,18 +1461,9 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     hipLaunchKernelGGL(k_angle_emit, dim3(alva_divup(maxKeep, 4), D.nlevels), dim3(256), 0, st, D, d_kp, cap, orb->d_total);
     ALVA_LAUNCH_CHECK();
     if (d_desc) {
-        const uint8_t *bs[MAXLV];
-        uint8_t *bd[MAXLV];
-        int bw[MAXLV], bh[MAXLV], bp[MAXLV];
-        for (int l = 0; l < D.nlevels; l++) {
-            const Level &L = D.lv[l];
-            bs[l] = D.pool + L.img;
-            bd[l] = D.pool + L.blur;
-            bw[l] = L.w;
-            bh[l] = L.h;
-            bp[l] = L.pitch;
-        }
-        rc = alva_blur7_batch_launch(ctx, D.nlevels, bs, bd, bw, bh, bp);
+        // the levels' 7x7 blur: a 1-D grid over the real tiles of all levels, four pixels per thread (describe.hip; the (maxTiles, level)
+        // grid of k_blur7_batch was 60 % empty workgroups at 1280x720 and byte-granular: 31 us)
+        rc = alva_blur7_multi_launch(ctx, orb->d_blur_batch, 1, D.nlevels, orb->blurTiles);
         if (rc) return rc;
         int nmax = 0;
         for (int l = 0; l < D.nlevels; l++) nmax += std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024));
@@ -1218,7 +1556,7 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
     int fastTiles = 0;
     for (int l = 0; l < D0.nlevels; l++) fastTiles += alva_divup(D0.lv[l].w, FT_W) * alva_divup(D0.lv[l].h, FT_H);
     hipLaunchKernelGGL(k_fast_nms_b, dim3(alva_xcd_grid(count, fastTiles)), dim3(256), 0, st, items, count, fastTiles);
-    hipLaunchKernelGGL(k_cull_fast_b, dim3(alva_xcd_grid(count, D0.nlevels)), dim3(1024), 0, st, items, count, D0.nlevels);
+    hipLaunchKernelGGL(k_cull_fast_b, dim3(alva_xcd_grid(count, D0.nlevels * FAST_REGIONS)), dim3(256), 0, st, items, count, D0.nlevels);
     hipLaunchKernelGGL(k_harris_b, dim3(alva_xcd_grid(count, 64 * D0.nlevels)), dim3(256), 0, st, items, count, 64, D0.nlevels);   // wave-strided loop, as k_harris
     hipLaunchKernelGGL(k_cull_harris_b, dim3(alva_xcd_grid(count, D0.nlevels)), dim3(1024), 0, st, items, count, D0.nlevels);
     int maxKeep = 0, nmax = 0;

@@ -161,6 +161,10 @@ int alva_orb_collect_batch(alva_ctx *ctx, alva_orb *const *orbs, int count, int 
  * library's (features2d/src/orb.cpp:230-232): the kernel decides the two floats from a ~100-bit evaluation and only a true value
  * within 2^-50 of a float rounding boundary is left unproven (probability ~3e-8 per keypoint).  Synchronous. */
 int alva_orb_ambiguous_rotations(int *h_count, int reset);
+/* One level of the detector's pyramid as the last run left it (which = 0: orb.cpp:1086-1099's resize chain; which = 1: its 7x7 sigma-2
+ * blur, orb.cpp:1188) copied to d_out (w x h bytes, rows out_pitch apart; d_out NULL only returns the size).  For stage-level parity tests.
+ * ALVA_ORB_PYRAMID=chain (read at alva_orb_create) builds the pyramid with one resize launch per level instead of the fused launch. */
+int alva_orb_debug_level(alva_ctx *ctx, alva_orb *orb, int level, int which, uint8_t *d_out, size_t out_pitch, int *w, int *h);
 /* device-resident keypoint count of the detector's last run (what alva_orb_collect copies to the host) */
 const int *alva_orb_device_count(const alva_orb *orb);
 

@@ -1968,6 +1968,27 @@ static int retain_best(orc_cand *c, int n, int keep) {
     return m;
 }
 
+/* The detector's image pyramid alone (orb.cpp:1041-1058 sizes, :1086-1099 the resize chain): level l is written to out + the sum of the
+ * earlier levels' sizes, dims[2 l] = width, dims[2 l + 1] = height.  out == NULL only fills dims.  Returns the total byte count. */
+long orc_orb_pyramid(const uint8_t *gray, int w, int h, float scaleFactorF, int nlevels, uint8_t *out, int *dims) {
+    double scaleFactor = (double) scaleFactorF;
+    long total = 0, prev = 0;
+    for (int l = 0; l < nlevels; l++) {
+        float sc = (float) pow(scaleFactor, (double) l);
+        float inv = 1.0f / sc;
+        int lw = cv_round_f((float) w * inv), lh = cv_round_f((float) h * inv);
+        dims[2 * l] = lw;
+        dims[2 * l + 1] = lh;
+        if (out) {
+            if (l == 0) memcpy(out, gray, (size_t) w * h);
+            else resize_linear_exact(out + prev, dims[2 * l - 2], dims[2 * l - 1], out + total, lw, lh);
+        }
+        prev = total;
+        total += (long) lw * lh;
+    }
+    return total;
+}
+
 int orc_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures, float scaleFactorF, int nlevels, int fastThreshold,
                                int doDescribe, float *kp /* [cap][6] */, uint8_t *desc, int cap) {
     double scaleFactor = (double) scaleFactorF;

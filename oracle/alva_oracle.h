@@ -36,6 +36,8 @@ int orc_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures,
 
 /* a6 */
 void orc_orb_blur(const uint8_t *gray, int w, int h, uint8_t *out /* w*h */);
+/* the detector's image pyramid (cv::ORB's INTER_LINEAR_EXACT resize chain), levels concatenated; returns the byte count */
+long orc_orb_pyramid(const uint8_t *gray, int w, int h, float scaleFactor, int nlevels, uint8_t *out, int *dims /* [nlevels][2] */);
 void orc_describe(const uint8_t *gray, int w, int h, const float *pts, int n, uint8_t *desc /* n*32 */, uint8_t *valid);
 
 /* a7 */

@@ -248,6 +248,27 @@ int ref_orb_detect_and_compute(const uint8_t *gray, int w, int h, int nfeatures,
     return (int) kps.size();
 }
 
+// a5': the detector's image pyramid as cv::ORB builds it (orb.cpp:1041-1058 level sizes, :1086-1099 resize(prev, cur, sz, 0, 0,
+// INTER_LINEAR_EXACT)); levels concatenated, dims[2 l] = width, dims[2 l + 1] = height.  Returns the byte count.
+long ref_orb_pyramid(const uint8_t *gray, int w, int h, float scaleFactor, int nlevels, uint8_t *out, int *dims) {
+    cv::Mat prev = wrapGray(gray, w, h).clone();
+    long total = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const float scale = (float) std::pow((double) scaleFactor, (double) l);
+        const cv::Size sz(cvRound((float) w * (1.0f / scale)), cvRound((float) h * (1.0f / scale)));
+        cv::Mat cur;
+        if (l == 0) cur = prev;
+        else cv::resize(prev, cur, sz, 0, 0, cv::INTER_LINEAR_EXACT);
+        dims[2 * l] = cur.cols;
+        dims[2 * l + 1] = cur.rows;
+        if (out)
+            for (int y = 0; y < cur.rows; y++) std::memcpy(out + total + (size_t) y * cur.cols, cur.ptr<uint8_t>(y), (size_t) cur.cols);
+        total += (long) cur.cols * cur.rows;
+        prev = cur;
+    }
+    return total;
+}
+
 // a7: cv::BFMatcher(NORM_HAMMING).match (batch_distance.cpp:199-251): per query best train idx + distance.
 int ref_bf_match_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist) {
     cv::Mat mq(nq, 32, CV_8UC1, const_cast<uint8_t *>(q)), mt(nt, 32, CV_8UC1, const_cast<uint8_t *>(t));

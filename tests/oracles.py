@@ -101,6 +101,24 @@ class Orc:
         return kp[:n].copy(), desc[:n].copy()
 
     @classmethod
+    def orb_pyramid(cls, gray, scale=1.2, nlevels=8):
+        """cv::ORB's image pyramid (INTER_LINEAR_EXACT resize chain, orb.cpp:1041-1099) as a list of uint8 arrays"""
+        import ctypes as C
+        h, w = gray.shape
+        fn = getattr(cls._lib(), cls._pfx + "orb_pyramid")
+        fn.restype = C.c_long
+        dims = np.zeros((nlevels, 2), np.int32)
+        g = np.ascontiguousarray(gray)
+        total = fn(_p(g), w, h, _f(scale), nlevels, None, _p(dims))
+        out = np.zeros(total, np.uint8)
+        fn(_p(g), w, h, _f(scale), nlevels, _p(out), _p(dims))
+        levels, off = [], 0
+        for lw, lh in dims:
+            levels.append(out[off:off + lw * lh].reshape(lh, lw).copy())
+            off += lw * lh
+        return levels
+
+    @classmethod
     def cell_mineig(cls, gray, x, y, cell):
         h, w = gray.shape
         blur = np.zeros((cell, cell), np.uint8)
@@ -551,6 +569,9 @@ class Ref:
 
 
 # ---- f2b: two-view initialisation (compute5ptEssentialMatrix).  Models are (R 3x3, t 3): X1 = R X2 + t -------------------------------
+Ref.orb_pyramid = classmethod(Orc.orb_pyramid.__func__)   # same marshalling, ref_orb_pyramid (cv::resize INTER_LINEAR_EXACT chain)
+
+
 def _bv(a):
     return np.ascontiguousarray(a, np.float64)
 

@@ -71,6 +71,46 @@ def test_orb_other_pyramid_parameters(ctx, w, h, seed, nf, scale, nlevels, thr):
     orb.close()
 
 
+@pytest.mark.parametrize("w,h,seed,scale,nlevels", [(640, 480, 1, 1.2, 8), (1280, 720, 3, 1.2, 8), (333, 201, 4, 1.2, 8), (640, 480, 7, 1.5, 4),
+                                                   (320, 240, 9, 2.0, 4), (400, 300, 8, 1.1, 12), (96, 64, 5, 1.2, 8)])
+def test_orb_pyramid_and_blur_levels(ctx, w, h, seed, scale, nlevels, monkeypatch):
+    """Every byte of every pyramid level (cv::ORB's INTER_LINEAR_EXACT chain, orb.cpp:1086-1099) and of its 7x7 blur (:1188) against the
+    oracle (pinned to cv::resize / cv::GaussianBlur in test_oracle_vs_ref.py) -- from the fused launch, in which every tile recomputes
+    its ancestors from level 0 (steep pyramids leave their deep levels to the per-level launch), and from ALVA_ORB_PYRAMID=chain."""
+    import torch
+    import alvaar_amd
+    g = _img(w, h, seed, noise=True)
+    want = Orc.orb_pyramid(g, scale, nlevels)
+    for mode in ("fused", "chain"):
+        if mode == "chain":
+            monkeypatch.setenv("ALVA_ORB_PYRAMID", "chain")
+        orb = alvaar_amd.Orb(ctx, w, h, 300, scale=scale, nlevels=nlevels)
+        for rep in range(2):
+            orb.detect_and_compute(torch.from_numpy(g).cuda())
+        for l, lv in enumerate(want):
+            got = orb.level(l).cpu().numpy()
+            assert got.shape == lv.shape and np.array_equal(got, lv), (mode, l, int((got != lv).sum()))
+            assert np.array_equal(orb.level(l, blurred=True).cpu().numpy(), Orc.orb_blur(lv)), (mode, "blur", l)
+        orb.close()
+
+
+def test_orb_many_features_takes_the_radix_cull(ctx):
+    """more than 4096 candidates at a level after the FAST cull: the Harris cull's selection passes instead of its LDS ranking"""
+    import torch
+    import alvaar_amd
+    w, h, nf = 1280, 720, 14000
+    g = _img(w, h, 3, noise=True)   # 14 k FAST corners at level 0: 6 080 + ties enter its Harris cull
+    orb = alvaar_amd.Orb(ctx, w, h, nf)
+    kp, desc = orb.detect_and_compute(torch.from_numpy(g).cuda())
+    kp, desc = kp.cpu().numpy(), desc.cpu().numpy()
+    rkp, rd = Orc.orb(g, nf, cap=4 * nf)
+    assert len(kp) == len(rkp) and (rkp[:, 5] == 0).sum() > 2500
+    ri = orb_key(rkp)
+    assert np.array_equal(kp.view(np.uint32), rkp[ri].view(np.uint32))
+    assert (desc != rd[ri]).any(axis=1).sum() == 0
+    orb.close()
+
+
 @pytest.mark.parametrize("thr", [1, 60, 120])
 def test_fast_threshold_extremes(ctx, thr):
     import torch

@@ -215,6 +215,18 @@ def test_fast_bit_exact(w, h, seed, thr):
     assert np.array_equal(oxy, rxy) and np.array_equal(osc, rsc)
 
 
+@pytest.mark.parametrize("w,h,seed,scale,nlevels", [(640, 480, 1, 1.2, 8), (1280, 720, 3, 1.2, 8), (333, 201, 4, 1.2, 8), (640, 480, 7, 1.5, 4),
+                                                   (320, 240, 9, 2.0, 4), (400, 300, 8, 1.1, 12)])
+def test_orb_pyramid_bit_exact(w, h, seed, scale, nlevels):
+    """cv::ORB's pyramid (sizes orb.cpp:1041-1058, resize(prev, cur, INTER_LINEAR_EXACT) :1086-1099): every byte of every level"""
+    g = _img(w, h, seed, noise=True)
+    ol, rl = Orc.orb_pyramid(g, scale, nlevels), Ref.orb_pyramid(g, scale, nlevels)
+    assert len(ol) == len(rl) == nlevels
+    for a, b in zip(ol, rl):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(ol[0], g)
+
+
 def orb_key(kp):
     """canonical order: (octave, y, x) -- cv::ORB's own order within a level comes from std::nth_element"""
     return np.lexsort((kp[:, 0], kp[:, 1], kp[:, 5]))

@@ -12,6 +12,15 @@ g = torch.from_numpy(synth.frame_gray(synth.texture_canvas(w, h, 7), 1, w, h, no
 orb = alvaar_amd.Orb(ctx, w, h, nf)
 for _ in range(5):
     orb.detect_and_compute(g)
+import time
+kp_buf = torch.zeros((4 * nf + 1024, 6), dtype=torch.float32, device="cuda")
+desc_buf = torch.zeros((4 * nf + 1024, 32), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    orb.enqueue(g, kp_buf, desc_buf)
+    orb.collect()
+print("wall per detectAndCompute (enqueue + collect, caller's buffers): %.1f us" % ((time.perf_counter() - t0) / 200 * 1e6))
 kt = capi.kernel_times(lambda: orb.detect_and_compute(g), 50)
 tot = 0
 for k, (calls, us) in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
