@@ -59,11 +59,9 @@ struct OrbDev {
     const int *tapCoef;     // resize tap coefficient (second tap, 0..256), -1 = clamp to first, -2 = clamp to last
     int *h_n3;              // pinned host mirror of n3, written by k_angle_emit (the host reads it after the stream sync)
     int umax[17];
-    // the fused pyramid launch (k_pyramid): levels 1 .. pyrFused in ONE launch, every tile recomputing its ancestors from level 0 in LDS
-    int pyrFused;               // 0 = none (then k_resize per level)
-    int pyrFirst[MAXLV + 2];    // workgroup ranges: segment j < pyrFused = level pyrFused - j (deepest first), segment pyrFused = the level-0 copy
-    int pyrSpanOff[MAXLV];      // level l's span table in pyrSpan
-    const int *pyrSpan;         // per level l: [tile column][k = 0 .. l - 1] (x0, nx) in level k, then [tile row][k] (y0, ny)
+    // the fused pyramid launch (k_pyramid): levels 0 .. pyrFused in ONE launch, a workgroup per column of the pyramid (pyr_column_body)
+    int pyrFused;               // 0 = none (then k_copy_level0 + k_resize per level)
+    const int *pyrSpan;         // [tile column of level pyrFused][k = 0 .. pyrFused - 1] (x0, nx, owned x0, owned x1) in level k, then the rows' (y0, ny, ...)
 };
 
 // One camera of a batched launch (k_*_b: camera = alva_xcd_item().cam): the detector's own state plus the call's arguments.
@@ -250,60 +248,62 @@ __host__ __device__ inline int fast_region_cap(int w, int h) {
     const int nt = ((w + FT_W - 1) / FT_W) * ((h + FT_H - 1) / FT_H);
     return (nt + FAST_REGIONS - 1) / FAST_REGIONS * (FT_W * FT_H / 4);
 }
-// ---- levels 1 .. F of the pyramid in ONE launch ---------------------------------------------------------------------------------------------
-// cv::ORB resizes level l from level l - 1 (orb.cpp:1086-1099, INTER_LINEAR_EXACT): a chain, seven dependent launches of ~7 us each at
-// 1280x720 although the chip needs < 1 us for any of them.  Every level IS a pure integer function of level 0, so a workgroup that owns
-// a PT_W x PT_H tile of level l recomputes the part of levels 1 .. l - 1 under that tile itself, in LDS, from the footprint of the tile
-// in the caller's image: the same taps at the same global coordinates, the same (acc + 2^15) >> 16 per pixel -> the same bytes as the
-// chain, with no inter-level wait at all.  The footprint of a level-7 tile at scale 1.2 is 138 x 81 source pixels and ~27x its own
-// size in recomputed pixels; all levels together are ~11 M pixel evaluations, a few microseconds of the chip.  The per-axis spans of every
-// tile in every ancestor level are tabulated at create time (orb_build), so a workgroup starts with one table read instead of a chain
-// of l dependent tap look-ups.  Deepest levels take the lowest workgroup numbers (longest chain first); the last segment of the grid
-// copies level 0 and clears the frame's counters (what k_copy_level0 did).
-constexpr int PT_W = 32, PT_H = 16;
-constexpr int PYR_BUF_A = 12288, PYR_BUF_B = 8192;   // even / odd ancestor levels' regions (level 0's footprint is the largest)
-constexpr int PYR_TAPS = 2048;                       // all stages' taps of one tile
+// ---- levels 0 .. F of the pyramid in ONE launch ---------------------------------------------------------------------------------------------
+// cv::ORB resizes level l from level l - 1 (orb.cpp:1086-1099, INTER_LINEAR_EXACT): a chain, seven dependent launches of 7 - 8 us each at
+// 1280x720 (plus the copy of level 0) although the chip needs < 1 us for any of them.  Every level IS a pure integer function of level 0,
+// so a workgroup takes a COLUMN of the pyramid: a PT_W x PT_H tile of the deepest fused level F and everything under it.  It loads the
+// tile's footprint in the caller's image into LDS, computes the region of level 1 that the column needs from it, level 2 from that, ...
+// (the same taps at the same global coordinates, the same (acc + 2^15) >> 16 per pixel -> the same bytes as the chain), and of every
+// level it WRITES the rectangle it owns: the levels are partitioned among the columns by the first source index of each tile (per axis:
+// column t owns [first(t), first(t + 1)) of level k; the regions are widened to contain what they own, which matters where a level's
+// last pixels are not read by the next level).  No inter-level wait, no second pass: ~1.9 x the pyramid's pixels are evaluated (the
+// halos), level 0 is read ~2 x (from L2).  The per-axis tables -- region and owned range of every tile column / row in every level
+// -- are built at create time (orb_build), so a workgroup starts with one table read instead of a chain of F dependent tap look-ups.
+// (A first form gave every level its own tiles, each recomputing ALL its ancestors: 5.8 x the pixels, 37.7 us; the chain: 72 us.)
+constexpr int PT_W = 16, PT_H = 8;
+constexpr int PYR_BUF_A = 12288, PYR_BUF_B = 8192;   // even / odd levels' regions (level 0's footprint is the largest)
+constexpr int PYR_TAPS = 2048;                       // all stages' taps of one column
 
-__device__ __forceinline__ void pyr_tile_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int l, const int tile) {
+__device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int tile) {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[PYR_BUF_A];
     __shared__ __attribute__((aligned(16))) uint8_t s_b[PYR_BUF_B];
     __shared__ int s_taps[PYR_TAPS];
-    __shared__ int s_x0[MAXLV], s_nx[MAXLV], s_y0[MAXLV], s_ny[MAXLV], s_toff[MAXLV + 1];
-    const Level &T = D.lv[l];
-    const int tid = threadIdx.x;
+    // per level: region (x0, nx, y0, ny) and owned range [ox0, ox1) x [oy0, oy1)
+    __shared__ int s_x0[MAXLV], s_nx[MAXLV], s_y0[MAXLV], s_ny[MAXLV], s_ox0[MAXLV], s_ox1[MAXLV], s_oy0[MAXLV], s_oy1[MAXLV], s_toff[MAXLV + 1];
+    const int F = D.pyrFused, tid = threadIdx.x;
+    const Level &T = D.lv[F];
     const int gxt = (T.w + PT_W - 1) / PT_W;
     const int tx = tile % gxt, ty = tile / gxt;
-    if (tid < l) {                      // ancestor k = tid: the tile's span there
-        const int *sx = D.pyrSpan + D.pyrSpanOff[l] + (tx * l + tid) * 2;
-        s_x0[tid] = sx[0];
-        s_nx[tid] = sx[1];
-    } else if (tid >= 64 && tid < 64 + l) {
+    if (tid < F) {
+        const int *e = D.pyrSpan + (tx * F + tid) * 4;
+        s_x0[tid] = e[0]; s_nx[tid] = e[1]; s_ox0[tid] = e[2]; s_ox1[tid] = e[3];
+    } else if (tid >= 64 && tid < 64 + F) {
         const int k = tid - 64;
-        const int *sy = D.pyrSpan + D.pyrSpanOff[l] + (gxt * l + ty * l + k) * 2;
-        s_y0[k] = sy[0];
-        s_ny[k] = sy[1];
+        const int *e = D.pyrSpan + (gxt * F + ty * F + k) * 4;
+        s_y0[k] = e[0]; s_ny[k] = e[1]; s_oy0[k] = e[2]; s_oy1[k] = e[3];
     } else if (tid == 128) {
-        s_x0[l] = tx * PT_W;
-        s_nx[l] = min(PT_W, T.w - tx * PT_W);
-        s_y0[l] = ty * PT_H;
-        s_ny[l] = min(PT_H, T.h - ty * PT_H);
+        s_x0[F] = tx * PT_W;
+        s_nx[F] = min(PT_W, T.w - tx * PT_W);
+        s_y0[F] = ty * PT_H;
+        s_ny[F] = min(PT_H, T.h - ty * PT_H);
     }
     __syncthreads();
     if (tid == 0) {
         int t = 0;
-        for (int k = 1; k <= l; k++) {
+        for (int k = 1; k <= F; k++) {
             s_toff[k] = t;
             t += s_nx[k] + s_ny[k];
         }
         s_toff[0] = t;                  // total
     }
-    // level 0's footprint -> s_a, dwords (unaligned loads; the last dword of a row by bytes when it would pass the image's edge)
+    const int lx = tid & 31, ly = tid >> 5;
+    // level 0: the column's footprint -> s_a (unaligned dword loads; the last dword of a row by bytes when it would pass the image's edge)
     {
         const int X0 = s_x0[0], NX = s_nx[0], Y0 = s_y0[0], NY = s_ny[0], W0 = D.lv[0].w;
         const int stride = (NX + 3) & ~3, dwr = stride >> 2;
-        for (int r = tid >> 5; r < NY; r += 8) {
+        for (int r = ly; r < NY; r += 8) {
             const uint8_t *row = src + (size_t) (Y0 + r) * pitch + X0;
-            for (int c = tid & 31; c < dwr; c += 32) {
+            for (int c = lx; c < dwr; c += 32) {
                 uint32_t v;
                 if (X0 + 4 * c + 4 <= W0) __builtin_memcpy(&v, row + 4 * c, 4);
                 else {
@@ -322,7 +322,7 @@ __device__ __forceinline__ void pyr_tile_body(const OrbDev &D, const uint8_t *__
         const int total = s_toff[0];
         for (int i = tid; i < total; i += 256) {
             int k = 1;
-            while (k < l && i >= s_toff[k + 1]) k++;
+            while (k < F && i >= s_toff[k + 1]) k++;
             const Level &K = D.lv[k], &S = D.lv[k - 1];
             int j = i - s_toff[k];
             const bool yax = j >= s_nx[k];
@@ -338,20 +338,30 @@ __device__ __forceinline__ void pyr_tile_body(const OrbDev &D, const uint8_t *__
             s_taps[i] = (a - base) | (wb << 16);
         }
     }
+    // level 0's owned rectangle: the copy into the pool
+    {
+        const Level &L0 = D.lv[0];
+        const int stride = (s_nx[0] + 3) & ~3, X0 = s_x0[0], Y0 = s_y0[0];
+        const int ox0 = s_ox0[0], onx = s_ox1[0] - ox0, oy0 = s_oy0[0], ony = s_oy1[0] - oy0;
+        for (int r = ly; r < ony; r += 8)
+            for (int c = lx; c < onx; c += 32) D.pool[L0.img + (size_t) (oy0 + r) * L0.pitch + ox0 + c] = s_a[(oy0 - Y0 + r) * stride + (ox0 - X0 + c)];
+    }
     __syncthreads();
-    const int lx = tid & 31, ly = tid >> 5;
-    for (int k = 1; k <= l; k++) {
+    for (int k = 1; k <= F; k++) {
         const uint8_t *in = (k - 1) & 1 ? s_b : s_a;
         uint8_t *outl = k & 1 ? s_b : s_a;
         const int sstride = (s_nx[k - 1] + 3) & ~3;
-        const int onx = s_nx[k], ony = s_ny[k], ostride = (onx + 3) & ~3;
+        const int rx0 = s_x0[k], ry0 = s_y0[k], onx = s_nx[k], ony = s_ny[k], ostride = (onx + 3) & ~3;
         const int *tapx = s_taps + s_toff[k], *tapy = tapx + onx;
-        const bool last = k == l;
-        uint8_t *gout = D.pool + D.lv[k].img + (size_t) s_y0[k] * D.lv[k].pitch + s_x0[k];
+        const bool last = k == F;
+        // owned rectangle, relative to the region (the deepest level owns its whole tile)
+        const int wx0 = last ? 0 : s_ox0[k] - rx0, wx1 = last ? onx : s_ox1[k] - rx0, wy0 = last ? 0 : s_oy0[k] - ry0, wy1 = last ? ony : s_oy1[k] - ry0;
+        uint8_t *gout = D.pool + D.lv[k].img + (size_t) ry0 * D.lv[k].pitch + rx0;
         const int gpitch = D.lv[k].pitch;
         for (int xx = lx; xx < onx; xx += 32) {
             const int t = tapx[xx];
             const int xa = t & 0xffff, wb = t >> 16, wa = 256 - wb, xb = xa + (wb != 0);
+            const bool ownx = xx >= wx0 && xx < wx1;
 #pragma unroll 2
             for (int yy = ly; yy < ony; yy += 8) {
                 const int u = tapy[yy];
@@ -361,41 +371,27 @@ __device__ __forceinline__ void pyr_tile_body(const OrbDev &D, const uint8_t *__
                 const unsigned h1 = (unsigned) wa * p1[xa] + (unsigned) wb * p1[xb];
                 const unsigned acc = (unsigned) c0 * h0 + (unsigned) c1 * h1;
                 const uint8_t v = (uint8_t) min((acc + 32768u) >> 16, 255u);
-                if (last) gout[(size_t) yy * gpitch + xx] = v;
-                else outl[yy * ostride + xx] = v;
+                if (!last) outl[yy * ostride + xx] = v;
+                if (ownx && yy >= wy0 && yy < wy1) gout[(size_t) yy * gpitch + xx] = v;
             }
         }
         __syncthreads();
     }
 }
 
-// the level-0 segment: 512 x 4 pixels per workgroup, 8 bytes per thread, and the frame's counters cleared in slices (see copy_level0_body)
-__device__ __forceinline__ void pyr_copy0_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int b, const int nb) {
-    const Level &L = D.lv[0];
-    const int gxw = (L.w + 511) / 512;
-    const int x = (b % gxw) * 512 + (int) (threadIdx.x & 63) * 8, y = (b / gxw) * 4 + (int) (threadIdx.x >> 6);
-    if (x < L.w && y < L.h) {
-        const uint8_t *p = src + (size_t) y * pitch + x;
-        uint8_t *q = D.pool + L.img + (size_t) y * L.pitch + x;
-        if (x + 8 <= L.w) {
-            unsigned long long v;
-            __builtin_memcpy(&v, p, 8);
-            *reinterpret_cast<unsigned long long *>(q) = v;   // pool rows are 64-byte aligned
-        } else {
-            for (int j = 0; x + j < L.w; j++) q[j] = p[j];
-        }
-    }
-    const int total = MAXLV * 256 + MAXLV * FAST_REGIONS + D.nlevels * FAST_REGIONS * 256;
-    for (int k = b * 256 + (int) threadIdx.x; k < total; k += nb * 256) D.hist[k] = 0;
-    if (b == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;   // n1 | n2 (k_cull_fast appends through n2)
-}
-
+// grid: 8 * ceil(columns / 8) workgroups; workgroup b runs on XCD b % 8 (each with its own L2), so every XCD gets one CONTIGUOUS eighth of
+// the columns (row-major) and neighbouring columns' overlapping footprints meet in one L2.  Every workgroup also clears a slice of the
+// frame's counters (what k_copy_level0 does for the chain: the score histograms, the append counters, n1 | n2).
 __global__ void __launch_bounds__(256) k_pyramid(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) {
-    const int b = (int) blockIdx.x, F = D.pyrFused;
-    int j = 0;
-    while (j < F && b >= D.pyrFirst[j + 1]) j++;
-    if (j < F) pyr_tile_body(D, src, pitch, F - j, b - D.pyrFirst[j]);
-    else pyr_copy0_body(D, src, pitch, b - D.pyrFirst[F], D.pyrFirst[F + 1] - D.pyrFirst[F]);
+    const Level &T = D.lv[D.pyrFused];
+    const int nt = ((T.w + PT_W - 1) / PT_W) * ((T.h + PT_H - 1) / PT_H), per = (nt + 7) / 8;
+    const int b = (int) blockIdx.x, tile = (b & 7) * per + (b >> 3);
+    {
+        const int total = MAXLV * 256 + MAXLV * FAST_REGIONS + D.nlevels * FAST_REGIONS * 256, nb = (int) gridDim.x;
+        for (int k = b * 256 + (int) threadIdx.x; k < total; k += nb * 256) D.hist[k] = 0;
+        if (b == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;   // n1 | n2 (k_cull_fast appends through n2)
+    }
+    if (tile < nt) pyr_column_body(D, src, pitch, tile);
 }
 
 __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
@@ -903,80 +899,109 @@ __device__ __forceinline__ void cull_harris_big(const OrbDev &D, const int l) {
 }
 
 
-// cull by Harris: keep response >= the n_l-th largest (ties kept), emit in row-major position order.  A candidate is kept iff FEWER than
-// n_l responses are strictly greater than its own (the same set as "key >= the n_l-th largest key"), and its place in the output is the
-// number of kept candidates at smaller positions: two counting passes over an LDS copy of the keys (broadcast 16-byte reads), no
-// selection passes over global memory, no dependence on the order the candidates arrive in.  (Radix select + ordered compaction + rank
-// sort: 25.6 us at 1280x720 for ~1 700 candidates at level 0.)
-constexpr int HARRIS_RANK_CAP = 4096;
+// cull by Harris: keep response >= the n_l-th largest (ties kept), emit in row-major position order.  The level's candidates (<= 4096: four
+// per thread) stay in registers: the radix select makes its four passes over them with an LDS histogram (no passes over global memory),
+// and the output position of a survivor is (survivors in earlier rows) + (survivors of its row to its left) -- a per-row count, a scan
+// over the rows, a slot per survivor, and a look at the handful of survivors that share its row: O(n) work for one workgroup, and no
+// dependence on the order the candidates arrive in.  (Radix select over global memory + ordered compaction + an m^2 rank sort: 25.6 us at
+// 1280x720; ranking all pairs in LDS instead: 205 us -- 3 M pairs are too many for ONE compute unit.)
+constexpr int HARRIS_RANK_CAP = 4096, HARRIS_ROW_CAP = 2048;
 __device__ __forceinline__ void cull_harris_body(const OrbDev &D, const int l) {
     const Level &L = D.lv[l];
     const int n = D.n2[l], keepN = L.nKeep, o = L.candOff;
-    if (n > HARRIS_RANK_CAP) {
+    if (n > HARRIS_RANK_CAP || L.h > HARRIS_ROW_CAP) {
         cull_harris_big(D, l);
         return;
     }
-    __shared__ __attribute__((aligned(16))) unsigned s_k[HARRIS_RANK_CAP + 4];
-    __shared__ int s_m;
-    const int tid = threadIdx.x;
+    __shared__ unsigned s_hist[256], s_prefix, s_k;
+    __shared__ int s_row[HARRIS_ROW_CAP], s_start[HARRIS_ROW_CAP], s_list[HARRIS_RANK_CAP], s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ex[4] = {0, 0, 0, 0}, ey[4] = {0, 0, 0, 0};
     float er[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned rk[4];
-    if (tid == 0) s_m = 0;
+    unsigned rk[4] = {0u, 0u, 0u, 0u};
+    bool valid[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int i = tid + q * 1024;
-        rk[q] = 0;
-        if (i < n) {
+        valid[q] = i < n;
+        if (valid[q]) {
             ex[q] = D.c2x[o + i];
             ey[q] = D.c2y[o + i];
             er[q] = D.c2r[o + i];
             rk[q] = f2key(er[q]);
-            s_k[i] = rk[q];
         }
     }
-    if (tid < 4) s_k[n + tid] = 0u;   // padding of the last 16-byte group: never greater than a key
-    __syncthreads();
-    const int n4 = (n + 3) >> 2;
-    int cnt[4] = {0, 0, 0, 0};
-    for (int j = 0; j < n4; j++) {
-        const uint4 k = reinterpret_cast<const uint4 *>(s_k)[j];
+    for (int y = tid; y < L.h; y += 1024) s_row[y] = 0;
+    unsigned thrKey = 0;
+    if (keepN == 0) thrKey = 0xffffffffu;
+    else if (n > keepN) {
+        // the keepN-th largest = element of rank (n - keepN) in ascending order
+        unsigned prefix = 0, mask = 0;
+        unsigned k = (unsigned) (n - keepN);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++) cnt[q] += (int) (k.x > rk[q]) + (int) (k.y > rk[q]) + (int) (k.z > rk[q]) + (int) (k.w > rk[q]);
+            for (int q = 0; q < 4; q++)
+                if (valid[q] && (rk[q] & mask) == prefix) atomicAdd(&s_hist[(rk[q] >> shift) & 255u], 1u);
+            __syncthreads();
+            if (tid < 64) wave_find_bin([&](int b) { return s_hist[b]; }, k, &s_prefix, &s_k);
+            __syncthreads();
+            prefix |= s_prefix << shift;
+            k = s_k;
+            mask |= 0xffu << shift;
+        }
+        thrKey = prefix;
     }
     __syncthreads();
     bool keep[4];
-    unsigned pk[4];
+    int slot[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int i = tid + q * 1024;
-        keep[q] = i < n && cnt[q] < keepN;
-        pk[q] = keep[q] ? ((unsigned) ey[q] << 16) | (unsigned) ex[q] : 0xffffffffu;
-        if (i < n) s_k[i] = pk[q];
+        keep[q] = valid[q] && rk[q] >= thrKey && (keepN != 0);
+        if (keep[q]) slot[q] = atomicAdd(&s_row[ey[q]], 1);
     }
-    if (tid < 4) s_k[n + tid] = 0xffffffffu;   // never smaller than a position key
     __syncthreads();
-    int rank[4] = {0, 0, 0, 0};
-    for (int j = 0; j < n4; j++) {
-        const uint4 k = reinterpret_cast<const uint4 *>(s_k)[j];
+    // exclusive scan of the per-row counts: two rows per thread, a wave scan, the 16 wave totals
+    {
+        const int r0 = 2 * tid, a = r0 < L.h ? s_row[r0] : 0, b = r0 + 1 < L.h ? s_row[r0 + 1] : 0;
+        const int sum = a + b;
+        int incl = sum;
 #pragma unroll
-        for (int q = 0; q < 4; q++) rank[q] += (int) (k.x < pk[q]) + (int) (k.y < pk[q]) + (int) (k.z < pk[q]) + (int) (k.w < pk[q]);
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) before += w < wave ? s_wsum[w] : 0;
+        const int excl = before + incl - sum;
+        if (r0 < L.h) s_start[r0] = excl;
+        if (r0 + 1 < L.h) s_start[r0 + 1] = excl + a;
     }
-    int kept = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (keep[q]) s_list[s_start[ey[q]] + slot[q]] = ex[q];
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (keep[q]) {
-            D.c3x[o + rank[q]] = ex[q];
-            D.c3y[o + rank[q]] = ey[q];
-            D.c3r[o + rank[q]] = er[q];
-            kept++;
+            const int st = s_start[ey[q]], c = s_row[ey[q]];
+            int pos = st;
+            for (int j = 0; j < c; j++) pos += s_list[st + j] < ex[q];
+            D.c3x[o + pos] = ex[q];
+            D.c3y[o + pos] = ey[q];
+            D.c3r[o + pos] = er[q];
         }
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) kept += __shfl_xor(kept, d);
-    if ((tid & 63) == 0 && kept) atomicAdd(&s_m, kept);
-    __syncthreads();
-    if (tid == 0) D.n3[l] = s_m;
+    if (tid == 0) {
+        int m = 0;
+        for (int w = 0; w < 16; w++) m += s_wsum[w];
+        D.n3[l] = m;
+    }
 }
 
 __global__ void __launch_bounds__(1024) k_cull_harris(OrbDev D) { cull_harris_body(D, blockIdx.x); }
@@ -1161,6 +1186,10 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     OrbDev &D = o->D;
     D.nlevels = nlevels;
     D.threshold = std::min(std::max(fast_threshold, 0), 255);
+    {
+        const char *e_ = getenv("ALVA_ORB_PYRAMID");
+        o->chain_resize = e_ && !strcmp(e_, "chain");
+    }
     const double scaleFactor = (double) scale_factor;
     // features per level (orb.cpp:799-813)
     {
@@ -1240,55 +1269,61 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
             tapCoef.resize(tapCoef.size() + L.w + L.h, 0);
         }
     }
-    // the fused pyramid launch's plan: spans of every tile column / row of level l in its ancestors 0 .. l - 1 (pyr_tile_body), and
-    // which levels fit its LDS buffers (a prefix 1 .. pyrFused; steeper pyramids than 1.2 leave the deep levels to k_resize)
+    // the fused pyramid launch's plan (pyr_column_body): the deepest level F whose columns fit the kernel's LDS buffers (steeper pyramids
+    // than 1.2 leave their deep levels to k_resize), and per tile column / row of level F its region and owned range in every level below
     std::vector<int> spans;
     D.pyrFused = 0;
-    for (int l = 1; l < nlevels; l++) {
-        const Level &T = D.lv[l];
+    for (int F = nlevels - 1; F >= 1 && !o->chain_resize; F--) {
+        const Level &T = D.lv[F];
         const int gxt = alva_divup(T.w, PT_W), gyt = alva_divup(T.h, PT_H);
-        std::vector<int> sp((size_t) (gxt + gyt) * l * 2);
+        std::vector<int> sp((size_t) (gxt + gyt) * F * 4);
         int maxw[MAXLV] = {0}, maxh[MAXLV] = {0};
         for (int axis = 0; axis < 2; axis++) {
             const int nt = axis ? gyt : gxt, ts = axis ? PT_H : PT_W;
+            auto dim = [&](int k) { return axis ? D.lv[k].h : D.lv[k].w; };
+            auto taps = [&](int k) { return tapOfs.data() + D.lv[k].tabOff + (axis ? D.lv[k].w : 0); };   // level k's taps into level k - 1
+            // first source index of every tile in every level below (the plain tap chain): the ownership boundaries
+            std::vector<int> first((size_t) (nt + 1) * F);
             for (int t = 0; t < nt; t++) {
-                int a0 = t * ts, an = std::min(ts, (axis ? T.h : T.w) - a0);
-                for (int k = l; k >= 1; k--) {
-                    const Level &K = D.lv[k], &S = D.lv[k - 1];
-                    const int *to = tapOfs.data() + K.tabOff + (axis ? K.w : 0);
-                    const int sn = axis ? S.h : S.w;
-                    const int lo = to[a0], hi = std::min(to[a0 + an - 1] + 1, sn - 1);
+                int a0 = t * ts;
+                for (int k = F; k >= 1; k--) {
+                    a0 = taps(k)[a0];
+                    first[(size_t) t * F + (k - 1)] = t == 0 ? 0 : a0;
+                }
+            }
+            for (int k = 0; k < F; k++) first[(size_t) nt * F + k] = dim(k);
+            for (int t = 0; t < nt; t++) {
+                int a0 = t * ts, an = std::min(ts, dim(F) - a0);
+                for (int k = F; k >= 1; k--) {
+                    const int sn = dim(k - 1);
+                    int lo = taps(k)[a0], hi = std::min(taps(k)[a0 + an - 1] + 1, sn - 1);
+                    const int o0 = first[(size_t) t * F + (k - 1)], o1 = std::max(first[(size_t) (t + 1) * F + (k - 1)], o0);
+                    if (o1 > o0) {   // the region contains what the column owns
+                        lo = std::min(lo, o0);
+                        hi = std::max(hi, o1 - 1);
+                    }
                     a0 = lo;
                     an = hi - lo + 1;
-                    int *e = sp.data() + ((axis ? (size_t) gxt * l : 0) + (size_t) t * l + (size_t) (k - 1)) * 2;
+                    int *e = sp.data() + ((axis ? (size_t) gxt * F : 0) + (size_t) t * F + (size_t) (k - 1)) * 4;
                     e[0] = a0;
                     e[1] = an;
+                    e[2] = o0;
+                    e[3] = o1;
                     int &m = (axis ? maxh : maxw)[k - 1];
                     m = std::max(m, an);
                 }
             }
         }
         bool fits = true;
-        int taps = PT_W + PT_H;
-        for (int k = 0; k < l; k++) {
+        int ntaps = PT_W + PT_H;
+        for (int k = 0; k < F; k++) {
             fits = fits && ((maxw[k] + 3) & ~3) * maxh[k] <= (k & 1 ? PYR_BUF_B : PYR_BUF_A) && maxw[k] < 65536 && maxh[k] < 65536;
-            if (k >= 1) taps += maxw[k] + maxh[k];
+            if (k >= 1) ntaps += maxw[k] + maxh[k];
         }
-        if (!fits || taps > PYR_TAPS) break;
-        D.pyrFused = l;
-        D.pyrSpanOff[l] = (int) spans.size();
-        spans.insert(spans.end(), sp.begin(), sp.end());
-    }
-    {
-        int first = 0;
-        for (int j = 0; j < D.pyrFused; j++) {
-            const Level &T = D.lv[D.pyrFused - j];
-            D.pyrFirst[j] = first;
-            first += alva_divup(T.w, PT_W) * alva_divup(T.h, PT_H);
-        }
-        D.pyrFirst[D.pyrFused] = first;
-        first += alva_divup(D.lv[0].w, 512) * alva_divup(D.lv[0].h, 4);
-        D.pyrFirst[D.pyrFused + 1] = first;
+        if (!fits || ntaps > PYR_TAPS) continue;
+        D.pyrFused = F;
+        spans = sp;
+        break;
     }
     if (spans.empty()) spans.push_back(0);
     for (int l = 0; l < nlevels; l++) {
@@ -1329,10 +1364,6 @@ static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float 
     o->d_total = (int *) (b + o_total);
     D.pyrSpan = (const int *) (b + o_span);
     o->d_blur_batch = b + o_blur;
-    {
-        const char *e_ = getenv("ALVA_ORB_PYRAMID");
-        o->chain_resize = e_ && !strcmp(e_, "chain");
-    }
     e = hipHostMalloc((void **) &D.h_n3, MAXLV * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void) hipFree(o->d_block);
@@ -1390,10 +1421,12 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
     hipStream_t st = ctx->stream;
     const Level &L0 = D.lv[0];
     int chained = 1;   // first level that still needs its own k_resize
-    if (o->chain_resize) {
+    if (D.pyrFused == 0) {
         hipLaunchKernelGGL(k_copy_level0, dim3(alva_divup(L0.w, 64), alva_divup(L0.h, 4)), dim3(256), 0, st, D, d_gray, gray_pitch);
     } else {
-        hipLaunchKernelGGL(k_pyramid, dim3((unsigned) D.pyrFirst[D.pyrFused + 1]), dim3(256), 0, st, D, d_gray, gray_pitch);
+        const Level &T = D.lv[D.pyrFused];
+        const int nt = alva_divup(T.w, PT_W) * alva_divup(T.h, PT_H);
+        hipLaunchKernelGGL(k_pyramid, dim3((unsigned) (8 * alva_divup(nt, 8))), dim3(256), 0, st, D, d_gray, gray_pitch);
         chained = D.pyrFused + 1;
     }
     for (int l = chained; l < D.nlevels; l++)
