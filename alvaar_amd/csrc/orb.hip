@@ -393,6 +393,19 @@ __global__ void __launch_bounds__(256) k_pyramid(OrbDev D, const uint8_t *__rest
     }
     if (tile < nt) pyr_column_body(D, src, pitch, tile);
 }
+// batched: camera = alva_xcd_item().cam (a camera's columns on one XCD), item = column
+__global__ void __launch_bounds__(256) k_pyramid_b(const OrbItem *__restrict__ items, int count, int per_cam) {
+    const AlvaXcdItem w = alva_xcd_item(count, per_cam);
+    if (w.cam >= count) return;
+    const OrbItem &it = items[w.cam];
+    const OrbDev &D = it.D;
+    {
+        const int total = MAXLV * 256 + MAXLV * FAST_REGIONS + D.nlevels * FAST_REGIONS * 256;
+        for (int k = w.item * 256 + (int) threadIdx.x; k < total; k += per_cam * 256) D.hist[k] = 0;
+        if (w.item == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;
+    }
+    pyr_column_body(D, it.gray, it.gray_pitch, w.item);
+}
 
 __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
     const Level &L = D.lv[blockIdx.y];
@@ -1542,7 +1555,7 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
     int blurTiles = 0;
     for (int c = 0; c < count; c++) {
         const alva_orb *o = orbs[c];
-        ALVA_ARG(o && !o->fast_only && d_gray[c] && d_kp[c] && d_desc[c] && o->D.nlevels == D0.nlevels && o->maxTiles == orbs[0]->maxTiles);
+        ALVA_ARG(o && !o->fast_only && d_gray[c] && d_kp[c] && d_desc[c] && o->D.nlevels == D0.nlevels && o->maxTiles == orbs[0]->maxTiles && o->D.pyrFused == D0.pyrFused);
         for (int l = 0; l < D0.nlevels; l++)
             ALVA_ARG(o->D.lv[l].w == D0.lv[l].w && o->D.lv[l].h == D0.lv[l].h && o->D.lv[l].nKeep == D0.lv[l].nKeep && o->D.lv[l].candCap == D0.lv[l].candCap);
         OrbItem it{};
@@ -1578,11 +1591,18 @@ extern "C" int alva_orb_detect_and_compute_batch(alva_ctx *ctx, alva_orb *const 
     const OrbItem *items = (const OrbItem *) dev;
     const Level &L0 = D0.lv[0];
     // every launch below: 1-D grid, camera -> XCD affinity (alva_xcd_item, common.hpp)
-    {
+    int chained = 1;   // first level that still needs its own k_resize_b
+    if (D0.pyrFused == 0) {
         const int gx = alva_divup(L0.w, 64), gy = alva_divup(L0.h, 4);
         hipLaunchKernelGGL(k_copy_level0_b, dim3(alva_xcd_grid(count, gx * gy)), dim3(256), 0, st, items, count, gx, gy);
+    } else {
+        // levels 0 .. pyrFused of every camera in one launch (pyr_column_body; the objects share one geometry, hence one plan shape)
+        const Level &T = D0.lv[D0.pyrFused];
+        const int nt = alva_divup(T.w, PT_W) * alva_divup(T.h, PT_H);
+        hipLaunchKernelGGL(k_pyramid_b, dim3(alva_xcd_grid(count, nt)), dim3(256), 0, st, items, count, nt);
+        chained = D0.pyrFused + 1;
     }
-    for (int l = 1; l < D0.nlevels; l++) {
+    for (int l = chained; l < D0.nlevels; l++) {
         const int gx = alva_divup(D0.lv[l].w, 256), gy = alva_divup(D0.lv[l].h, 4);
         hipLaunchKernelGGL(k_resize_b, dim3(alva_xcd_grid(count, gx * gy)), dim3(256), 0, st, items, l, count, gx, gy);
     }

@@ -339,7 +339,7 @@ def bench_720p(device: int, reps: int = 50, valu_peak_tops: float | None = None)
     dt = (time.perf_counter() - t0) / reps
     kt = capi.kernel_times(step, 20)
     P2 = w * h
-    algb = {"k_fast_nms": 3.27 * P2, "k_blur7_batch": 2 * 3.27 * P2, "k_bf_partial": 32 * 2 * step.n + 8 * step.n * ((step.n + 63) // 64)}
+    algb = {"k_fast_nms": 3.27 * P2, "k_blur7_multi": 2 * 3.27 * P2, "k_pyramid": (1 + 3.27) * P2, "k_bf_partial": 32 * 2 * step.n + 8 * step.n * ((step.n + 63) // 64)}
     ham = None
     if "k_bf_partial" in kt and valu_peak_tops:
         ops = 24.0 * step.n * step.n           # per pair 8 xor + 8 popcount + 8 add on 32-bit words
