@@ -260,7 +260,11 @@ __host__ __device__ inline int fast_region_cap(int w, int h) {
 // halos), level 0 is read ~2 x (from L2).  The per-axis tables -- region and owned range of every tile column / row in every level
 // -- are built at create time (orb_build), so a workgroup starts with one table read instead of a chain of F dependent tap look-ups.
 // (A first form gave every level its own tiles, each recomputing ALL its ancestors: 5.8 x the pixels, 37.7 us; the chain: 72 us.)
-constexpr int PT_W = 16, PT_H = 8;
+#ifndef ALVA_PT_W
+#define ALVA_PT_W 16
+#define ALVA_PT_H 8
+#endif
+constexpr int PT_W = ALVA_PT_W, PT_H = ALVA_PT_H;   // (tools/build_variant.sh builds other sizes for A/B runs)
 constexpr int PYR_BUF_A = 12288, PYR_BUF_B = 8192;   // even / odd levels' regions (level 0's footprint is the largest)
 constexpr int PYR_TAPS = 2048;                       // all stages' taps of one column
 
