@@ -268,7 +268,9 @@ constexpr int PT_W = ALVA_PT_W, PT_H = ALVA_PT_H;   // (tools/build_variant.sh b
 constexpr int PYR_BUF_A = 12288, PYR_BUF_B = 8192;   // even / odd levels' regions (level 0's footprint is the largest)
 constexpr int PYR_TAPS = 2048;                       // all stages' taps of one column
 
-__device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int tile) {
+#define PYR_STAMP(k) do { if (dbg && threadIdx.x == 0 && tile < 256) dbg[16 * tile + (k)] = wall_clock64(); } while (0)
+__device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *__restrict__ src, const size_t pitch, const int tile, unsigned long long *dbg) {
+    PYR_STAMP(0);
     __shared__ __attribute__((aligned(16))) uint8_t s_a[PYR_BUF_A];
     __shared__ __attribute__((aligned(16))) uint8_t s_b[PYR_BUF_B];
     __shared__ int s_taps[PYR_TAPS];
@@ -300,6 +302,7 @@ __device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *
         }
         s_toff[0] = t;                  // total
     }
+    PYR_STAMP(1);
     const int lx = tid & 31, ly = tid >> 5;
     // level 0: the column's footprint -> s_a (unaligned dword loads; the last dword of a row by bytes when it would pass the image's edge)
     {
@@ -320,6 +323,7 @@ __device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *
         }
     }
     __syncthreads();
+    PYR_STAMP(2);
     // every stage's taps, relative to the region they read: (first source index) | (weight of the second tap << 16); a clamped tap
     // (-1 / -2: copies the first / last source element) is weight 0 on that element -- 256 * v + 0 * v, the same ufixedpoint16 value
     {
@@ -351,6 +355,7 @@ __device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *
             for (int c = lx; c < onx; c += 32) D.pool[L0.img + (size_t) (oy0 + r) * L0.pitch + ox0 + c] = s_a[(oy0 - Y0 + r) * stride + (ox0 - X0 + c)];
     }
     __syncthreads();
+    PYR_STAMP(3);
     for (int k = 1; k <= F; k++) {
         const uint8_t *in = (k - 1) & 1 ? s_b : s_a;
         uint8_t *outl = k & 1 ? s_b : s_a;
@@ -380,13 +385,14 @@ __device__ __forceinline__ void pyr_column_body(const OrbDev &D, const uint8_t *
             }
         }
         __syncthreads();
+        PYR_STAMP(3 + k);
     }
 }
 
 // grid: 8 * ceil(columns / 8) workgroups; workgroup b runs on XCD b % 8 (each with its own L2), so every XCD gets one CONTIGUOUS eighth of
 // the columns (row-major) and neighbouring columns' overlapping footprints meet in one L2.  Every workgroup also clears a slice of the
 // frame's counters (what k_copy_level0 does for the chain: the score histograms, the append counters, n1 | n2).
-__global__ void __launch_bounds__(256) k_pyramid(OrbDev D, const uint8_t *__restrict__ src, size_t pitch) {
+__global__ void __launch_bounds__(256) k_pyramid(OrbDev D, const uint8_t *__restrict__ src, size_t pitch, unsigned long long *dbg) {
     const Level &T = D.lv[D.pyrFused];
     const int nt = ((T.w + PT_W - 1) / PT_W) * ((T.h + PT_H - 1) / PT_H), per = (nt + 7) / 8;
     const int b = (int) blockIdx.x, tile = (b & 7) * per + (b >> 3);
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(256) k_pyramid(OrbDev D, const uint8_t *__rest
         for (int k = b * 256 + (int) threadIdx.x; k < total; k += nb * 256) D.hist[k] = 0;
         if (b == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;   // n1 | n2 (k_cull_fast appends through n2)
     }
-    if (tile < nt) pyr_column_body(D, src, pitch, tile);
+    if (tile < nt) pyr_column_body(D, src, pitch, tile, dbg);
 }
 // batched: camera = alva_xcd_item().cam (a camera's columns on one XCD), item = column
 __global__ void __launch_bounds__(256) k_pyramid_b(const OrbItem *__restrict__ items, int count, int per_cam) {
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(256) k_pyramid_b(const OrbItem *__restrict__ i
         for (int k = w.item * 256 + (int) threadIdx.x; k < total; k += per_cam * 256) D.hist[k] = 0;
         if (w.item == 0 && threadIdx.x < 2 * MAXLV) D.n1[threadIdx.x] = 0;
     }
-    pyr_column_body(D, it.gray, it.gray_pitch, w.item);
+    pyr_column_body(D, it.gray, it.gray_pitch, w.item, nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_fast_score(OrbDev D) {
@@ -580,6 +586,8 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
 // CONTIGUOUS eighth of the level's tiles (row-major): the 4-px halo rows and the 128-byte lines that neighbouring tiles share meet in ONE
 // L2 instead of being fetched through up to three (PMC, plain order: 2.06 MB fetched per launch at 640x480 against ~1.0 MB of pyramid;
 // the same cure as k_pyr_rest's).  The candidate order was never defined (tile completion order), later stages sort.
+// (SQ counters at 1280x720, profiles/r4h_sq_orb720.txt: 7.97 M VALU wave-instructions for 3.0 M pixels = 170 lane-instructions per pixel, the SIMDs'
+// VALU 54 % busy over the launch, 8 waves per SIMD resident (the maximum: 60 VGPRs) -- an instruction-count kernel now, not a latency one)
 __global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
     int b = (int) blockIdx.x, l = 0, n = 0, per = 0;
     for (; l < D.nlevels; l++) {
@@ -1443,7 +1451,7 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
     } else {
         const Level &T = D.lv[D.pyrFused];
         const int nt = alva_divup(T.w, PT_W) * alva_divup(T.h, PT_H);
-        hipLaunchKernelGGL(k_pyramid, dim3((unsigned) (8 * alva_divup(nt, 8))), dim3(256), 0, st, D, d_gray, gray_pitch);
+        hipLaunchKernelGGL(k_pyramid, dim3((unsigned) (8 * alva_divup(nt, 8))), dim3(256), 0, st, D, d_gray, gray_pitch, alva_kstamp_buffer());   // (stamps: ALVA_KSTAMPS=1, tools/pyr_stamps.py)
         chained = D.pyrFused + 1;
     }
     for (int l = chained; l < D.nlevels; l++)
