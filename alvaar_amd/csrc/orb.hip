@@ -458,9 +458,10 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
     __shared__ __attribute__((aligned(4))) uint8_t g[GH * GW];
     __shared__ uint8_t sc[SH * SW];
     __shared__ unsigned short list[SH * (FT_W + 2)], list2[SH * (FT_W + 2)];
-    __shared__ int s_n, s_n2, s_row[FT_H], s_base;
+    __shared__ int s_n, s_n2, s_ns, s_base;
+    __shared__ unsigned s_surv[FT_W * FT_H / 4 + 64];   // NMS survivors: score | x << 8 | y << 16 (tile coordinates)
     const uint8_t *img = D.pool + L.img;
-    if (threadIdx.x == 0) s_n = s_n2 = 0;
+    if (threadIdx.x == 0) s_n = s_n2 = s_ns = 0;
     // gray tile, a dword per thread and step (x0 - 4 and the level's rows are 4-byte aligned); bytes are clamped one by one only in
     // dwords that cross the image border
     static_assert(GW % 4 == 0, "dword tile rows");
@@ -534,49 +535,48 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
         sc[ly * SW + lx] = (uint8_t) fast_corner_score(d, D.threshold);
     }
     __syncthreads();
-    // NMS: wave w takes rows w, w + 4, ...; one lane per column
-    const int wave = threadIdx.x >> 6;
-    unsigned long long keepm[FT_H / 4];
-    int myscore[FT_H / 4];
-#pragma unroll
-    for (int it = 0; it < FT_H / 4; it++) {
-        const int r = it * 4 + wave, gx = x0 + lane, gy = y0 + r;
-        const uint8_t *q = sc + (r + 1) * SW + lane + 1;
-        const int v = q[0];
-        bool keep = v > 0 && gx >= lo && gx < hx && gy >= lo && gy < hy;
-        keep = keep && v > q[-1] && v > q[1] && v > q[-SW - 1] && v > q[-SW] && v > q[-SW + 1] && v > q[SW - 1] && v > q[SW] && v > q[SW + 1];
-        if (L.border > 0) keep = keep && L.w > 2 * L.border && L.h > 2 * L.border;   // KeyPointsFilter::runByImageBorder
-        keepm[it] = __ballot(keep);
-        myscore[it] = v;
-        if (lane == 0) s_row[r] = __popcll(keepm[it]);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int r = 0; r < FT_H; r++) {
-            const int c = s_row[r];
-            s_row[r] = tot;
-            tot += c;
-        }
-        s_base = tot ? atomicAdd(&D.hist[MAXLV * 256 + lvl * FAST_REGIONS + (int) (tile % FAST_REGIONS)], tot) : 0;   // the tile's REGION of the list
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < FT_H / 4; it++) {
-        if ((keepm[it] >> lane) & 1ull) {
-            const int r = it * 4 + wave;
-            const int rcap = fast_region_cap(L.w, L.h);
-            const int inr = s_base + s_row[r] + __popcll(keepm[it] & ((1ull << lane) - 1ull));
-            const int pos = (int) (tile % FAST_REGIONS) * rcap + inr;
-            if (inr < rcap) {
-                D.c1x[L.candOff + pos] = x0 + lane;
-                D.c1y[L.candOff + pos] = y0 + r;
-                D.c1s[L.candOff + pos] = myscore[it];
-                // the level's score histogram, one per REGION too: with the append counter's contention gone, ~20 k atomics on a few hundred
-                // hot counters from every XCD were the next 12 us (k_cull_fast adds the regions' histograms up: 8 loads per thread)
-                atomicAdd(&D.hist[MAXLV * 256 + MAXLV * FAST_REGIONS + (lvl * FAST_REGIONS + (int) (tile % FAST_REGIONS)) * 256 + myscore[it]], 1);
+    // NMS over the corner LIST (a few per cent of the tile's pixels; walking all 1024 pixels with nine score reads each was 15 % of the
+    // kernel's instructions): the strict local maxima inside the tile proper are packed into LDS (at most a quarter of the pixels can
+    // be one), the tile takes its place in its region's slice of the candidate list with ONE atomic, then they are written out
+    for (int j0 = 0; j0 < nc; j0 += 256) {
+        const int j = j0 + (int) threadIdx.x;
+        bool keep = false;
+        unsigned packed = 0;
+        if (j < nc) {
+            const int ly = list[j] >> 8, lx = list[j] & 255;   // score-tile coordinates: pixel (x0 + lx - 1, y0 + ly - 1)
+            if (ly >= 1 && ly <= FT_H && lx >= 1 && lx <= FT_W) {
+                const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+                const uint8_t *q = sc + ly * SW + lx;
+                const int v = q[0];
+                keep = v > 0 && gx >= lo && gx < hx && gy >= lo && gy < hy;
+                keep = keep && v > q[-1] && v > q[1] && v > q[-SW - 1] && v > q[-SW] && v > q[-SW + 1] && v > q[SW - 1] && v > q[SW] && v > q[SW + 1];
+                if (L.border > 0) keep = keep && L.w > 2 * L.border && L.h > 2 * L.border;   // KeyPointsFilter::runByImageBorder
+                packed = (unsigned) v | ((unsigned) (lx - 1) << 8) | ((unsigned) (ly - 1) << 16);
             }
         }
+        const unsigned long long m = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_ns, __popcll(m));
+        base = __shfl(base, 0);
+        if (keep) s_surv[base + __popcll(m & ((1ull << lane) - 1ull))] = packed;
+    }
+    __syncthreads();
+    const int ns = s_ns;
+    if (threadIdx.x == 0) s_base = ns ? atomicAdd(&D.hist[MAXLV * 256 + lvl * FAST_REGIONS + (int) (tile % FAST_REGIONS)], ns) : 0;   // the tile's REGION of the list
+    __syncthreads();
+    const int rcap = fast_region_cap(L.w, L.h);
+    for (int j = threadIdx.x; j < ns; j += 256) {
+        const int inr = s_base + j;
+        if (inr >= rcap) continue;
+        const unsigned pk = s_surv[j];
+        const int score = (int) (pk & 255u);
+        const int pos = (int) (tile % FAST_REGIONS) * rcap + inr;
+        D.c1x[L.candOff + pos] = x0 + (int) ((pk >> 8) & 255u);
+        D.c1y[L.candOff + pos] = y0 + (int) (pk >> 16);
+        D.c1s[L.candOff + pos] = score;
+        // the level's score histogram, one per REGION too: with the append counter's contention gone, ~20 k atomics on a few hundred
+        // hot counters from every XCD were the next 12 us (k_cull_fast adds the regions' histograms up)
+        atomicAdd(&D.hist[MAXLV * 256 + MAXLV * FAST_REGIONS + (lvl * FAST_REGIONS + (int) (tile % FAST_REGIONS)) * 256 + score], 1);
     }
 }
 
