@@ -115,6 +115,34 @@ __device__ __forceinline__ bool fast_is_corner(const int d[16], int threshold) {
     return has9(dark) || has9(bright);
 }
 
+// The same test straight from the pixels, for the fused kernel's packed second step: ring pixel q is "darker" iff v - q > t iff q + (t - v) < 0
+// and "brighter" iff v - q < -t iff (v + t) - q < 0, so each of the 32 comparisons is one add and one v_alignbit that shifts the sign bit
+// into the mask (a compare + select + shift-or is three).  The masks come out in reversed ring order; "9 contiguous" does not care.
+__device__ __forceinline__ bool fast_is_corner_at(const uint8_t *p, int stride, int threshold) {
+    const int v = p[0], A = threshold - v, B = v + threshold;
+    unsigned dark = 0, bright = 0;
+#define ALVA_RING(off)                                                                  \
+    {                                                                                   \
+        const int q = p[(off)];                                                         \
+        dark = __builtin_amdgcn_alignbit(dark, (unsigned) (q + A), 31);                 \
+        bright = __builtin_amdgcn_alignbit(bright, (unsigned) (B - q), 31);             \
+    }
+    ALVA_RING(3 * stride) ALVA_RING(3 * stride + 1) ALVA_RING(2 * stride + 2) ALVA_RING(stride + 3)
+    ALVA_RING(3) ALVA_RING(-stride + 3) ALVA_RING(-2 * stride + 2) ALVA_RING(-3 * stride + 1)
+    ALVA_RING(-3 * stride) ALVA_RING(-3 * stride - 1) ALVA_RING(-2 * stride - 2) ALVA_RING(-stride - 3)
+    ALVA_RING(-3) ALVA_RING(stride - 3) ALVA_RING(2 * stride - 2) ALVA_RING(3 * stride - 1)
+#undef ALVA_RING
+    auto has9 = [](unsigned m) -> bool {
+        m |= m << 16;
+        unsigned r = m & (m >> 1);
+        r &= r >> 2;
+        r &= r >> 4;
+        r &= m >> 8;
+        return (r & 0xffffu) != 0;
+    };
+    return has9(dark) || has9(bright);
+}
+
 // cornerScore<16> (fast_score.cpp:120-): max over the 16 arcs of 9 of min(d) and min(-d), floored at threshold, minus 1.
 // The arc minima / maxima come from doubling windows (2, 4, 8, then +1): min and max are exact in any association.
 __device__ __forceinline__ int fast_corner_score(const int d[16], int threshold) {
@@ -516,9 +544,7 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
         if (j < n2) {
             code = list2[j];
             const int ly = code >> 8, lx = code & 255;
-            int d[16];
-            fast_ring(g + (ly + 3) * GW + lx + 3, GW, d);
-            corner = fast_is_corner(d, D.threshold);
+            corner = fast_is_corner_at(g + (ly + 3) * GW + lx + 3, GW, D.threshold);
         }
         const unsigned long long m = __ballot(corner);
         int base = 0;
