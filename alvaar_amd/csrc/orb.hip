@@ -612,7 +612,7 @@ __device__ __forceinline__ void fast_nms_body(const OrbDev &D, const int lvl, co
 // CONTIGUOUS eighth of the level's tiles (row-major): the 4-px halo rows and the 128-byte lines that neighbouring tiles share meet in ONE
 // L2 instead of being fetched through up to three (PMC, plain order: 2.06 MB fetched per launch at 640x480 against ~1.0 MB of pyramid;
 // the same cure as k_pyr_rest's).  The candidate order was never defined (tile completion order), later stages sort.
-// (SQ counters at 1280x720, profiles/r4h_sq_orb720.txt: 7.97 M VALU wave-instructions for 3.0 M pixels = 170 lane-instructions per pixel, the SIMDs'
+// (SQ counters at 1280x720 before the list NMS, profiles/r4h_sq_orb720.txt: 7.97 M VALU wave-instructions for 3.0 M pixels = 170 lane-instructions per pixel, the SIMDs'
 // VALU 54 % busy over the launch, 8 waves per SIMD resident (the maximum: 60 VGPRs) -- an instruction-count kernel now, not a latency one)
 __global__ void __launch_bounds__(256) k_fast_nms(OrbDev D) {
     int b = (int) blockIdx.x, l = 0, n = 0, per = 0;
