@@ -135,12 +135,6 @@ void FrameRec::turn3d(int id_) {  // :234-248
     }
 }
 
-int FrameRec::cell_index(const float *px) const {  // :313-318 (float / size_t -> float division, floor)
-    const int r = (int) std::floor(px[1] / (float) cell);
-    const int c = (int) std::floor(px[0] / (float) cell);
-    return (int) ((size_t) r * cells_w + (size_t) c);
-}
-
 void FrameRec::grid_add(const KeyPt &k) {  // :255-265
     const int idx = cell_index(k.px);
     CellIds &c = grid.at((size_t) idx);

@@ -1,0 +1,80 @@
+"""Where the host-side map layer spends its time, WITHOUT a GPU and without perf: the product's slam/*.cpp over the reference's CPU stages
+(oracle/_ref: syscpu_*, test infrastructure) on the bench stream under a SIGPROF sampler (tools/sampler/sampler.c).  Only samples whose
+stack passes through alva_slam:: are counted; the stage calls (CPU OpenCV / Ceres under syscpu stages) are excluded by name.
+env: FRAMES (700), WINDOW (400), HZ (2000)"""
+import os, sys, time, subprocess, collections
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np
+import ctypes as C
+import sysdiff
+from alvaar_amd import synth
+
+n, win, hz = int(os.environ.get("FRAMES", "700")), int(os.environ.get("WINDOW", "400")), int(os.environ.get("HZ", "5000"))
+w, h, cell = 640, 480, 12
+NF = 200
+canvas = synth.texture_canvas(w, h, 7)
+frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(NF)]
+period = 2 * (NF - 1)
+idx = lambda k: (k % period) if (k % period) < NF else period - (k % period)
+here = os.path.dirname(os.path.abspath(__file__))
+S = C.CDLL(os.path.join(here, "sampler", "libsampler.so"))
+s = sysdiff.CpuSystem(w, h, cell)
+for k in range(n - win):
+    s.step(frames[idx(k)], 33.0 * k)
+S.prof_start(hz)
+cpu0 = time.perf_counter()
+for k in range(n - win, n):
+    s.step(frames[idx(k)], 33.0 * k)
+cpu_s = time.perf_counter() - cpu0
+S.prof_stop()
+cnt, depth = S.prof_count(), S.prof_depth()
+buf = (C.c_void_p * (cnt * depth))()
+S.prof_get(buf)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(cnt, depth)
+S.prof_sym.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_ulong)]
+cache = {}
+def sym(pc):
+    if pc in cache:
+        return cache[pc]
+    nb, mb, off = C.create_string_buffer(512), C.create_string_buffer(512), C.c_ulong(0)
+    r = ("?", "?") if not S.prof_sym(C.c_void_p(int(pc)), nb, 512, mb, 512, C.byref(off)) else (nb.value.decode(), os.path.basename(mb.value.decode()))
+    cache[pc] = r
+    return r
+names = set()
+for row in a:
+    for pc in row:
+        if pc == 0:
+            break
+        names.add(sym(pc)[0])
+dem = {}
+if names:
+    out = subprocess.run(["c++filt"], input="\n".join(sorted(names)), capture_output=True, text=True).stdout.splitlines()
+    dem = dict(zip(sorted(names), out))
+incl, leaf, total_slam = collections.Counter(), collections.Counter(), 0
+per = cpu_s / max(cnt, 1)   # seconds per sample (wall clock: the harness is one busy thread)
+for row in a:
+    st = []
+    for pc in row:
+        if pc == 0:
+            break
+        nm, mod = sym(pc)
+        st.append((dem.get(nm, nm), mod))
+    own = next((i for i, (f, m) in enumerate(st) if "alva_slam::" in f and "alva_slam::Stages::" not in f), None)
+    if own is None:
+        continue
+    # callee side of the innermost map-layer frame: libc / libstdc++ helpers belong to it; anything else inside the reference library
+    # (its CPU stages: OpenCV, Ceres, OpenGV, the harness's stage class, the default Stages) is stage time, not map-layer time
+    if any(m.startswith("libalva_ref") for f, m in st[:own]):
+        continue
+    total_slam += 1
+    leaf[st[own][0][:120]] += 1
+    for f in dict.fromkeys(f for f, m in st[own:] if "alva_slam::" in f):
+        incl[f[:120]] += 1
+print(f"{cnt} samples, {per * 1e3:.2f} ms of CPU each, over {win} frames; {total_slam} in the map layer (host-only) = {total_slam * per * 1e6 / win:.0f} us per frame")
+print("-- innermost map-layer frame (self + libc / libstdc++ callees):")
+for f, c in leaf.most_common(30):
+    print(f"  {100.0 * c / total_slam:5.1f} %  {c * per * 1e6 / win:7.1f} us/frame  {f}")
+print("-- inclusive:")
+for f, c in incl.most_common(24):
+    print(f"  {100.0 * c / total_slam:5.1f} %  {f}")
