@@ -18,7 +18,10 @@ frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) f
 period = 2 * (NF - 1)
 idx = lambda k: (k % period) if (k % period) < NF else period - (k % period)
 here = os.path.dirname(os.path.abspath(__file__))
-S = C.CDLL(os.path.join(here, "sampler", "libsampler.so"))
+so = os.path.join(here, "sampler", "libsampler.so")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(here, "sampler", "sampler.c")):
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(here, "sampler", "sampler.c"), "-ldl"])
+S = C.CDLL(so)
 s = sysdiff.CpuSystem(w, h, cell)
 for k in range(n - win):
     s.step(frames[idx(k)], 33.0 * k)
