@@ -38,6 +38,7 @@ static inline int popcount256(const Desc &a, const Desc &b) {  // cv::norm(a, b,
 void FrameRec::init(const Camera *c, size_t cell_size) {  // frame.cpp:9-21
     cam = c;
     cell = cell_size;
+    cell_f = (float) cell;
     cells_w = (size_t) std::ceil((float) c->width / (float) cell);
     cells_h = (size_t) std::ceil((float) c->height / (float) cell);
     grid_cells = cells_w * cells_h;

@@ -153,6 +153,7 @@ struct FrameRec {
     KpTable kps;                               // mapKeypoints_
     std::vector<CellIds> grid;                 // gridKeypointsIds_
     size_t grid_cells = 0, n_occupied = 0, cell = 0, cells_w = 0, cells_h = 0, n_kps = 0, n_2d = 0, n_3d = 0;
+    float cell_f = 0.f;   // (float) cell
     SE3 Twc, Tcw;
     std::map<int, int> covisible;              // covisibleKeyframeIds_
     FlatSet local_map;                         // localMapPointIds_ (std::unordered_set<int>)
@@ -201,7 +202,7 @@ struct FrameRec {
         return i - (v < (float) i);
     }
     int cell_index(const float *px) const {
-        const int r = floor_to_int(px[1] / (float) cell), c = floor_to_int(px[0] / (float) cell);
+        const int r = floor_to_int(px[1] / cell_f), c = floor_to_int(px[0] / cell_f);   // cell_f = (float) cell (an unsigned 64-bit -> float conversion per call otherwise)
         return (int) ((size_t) r * cells_w + (size_t) c);
     }
     void grid_add(const KeyPt &k);

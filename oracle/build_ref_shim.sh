@@ -55,7 +55,7 @@ compile() { # src obj std
   for f in "$SLAM"/*.cpp; do
     o="$OBJ/syscpu/$(basename "$f" .cpp).o"
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find "$SLAM" -name '*.hpp' -newer "$o")" ]; then
-      echo "g++ -std=c++17 -O2 -fPIC -Wall -DNDEBUG -ffp-contract=off -c '$f' -o '$o'"
+      echo "g++ -std=c++17 -O2 -g -fPIC -Wall -DNDEBUG -ffp-contract=off -c '$f' -o '$o'"   # (-g: line numbers for tools/host_profile_cpu.py; same code)
     fi
   done
   if [ ! -f "$OBJ/sys_cpu.o" ] || [ "$HERE/sys_cpu.cpp" -nt "$OBJ/sys_cpu.o" ] || [ -n "$(find "$SLAM" "$HERE/alva_oracle.h" -name '*.h*' -newer "$OBJ/sys_cpu.o")" ]; then

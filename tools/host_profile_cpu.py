@@ -36,12 +36,16 @@ buf = (C.c_void_p * (cnt * depth))()
 S.prof_get(buf)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(cnt, depth)
 S.prof_sym.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_ulong)]
-cache = {}
+cache, modinfo = {}, {}
 def sym(pc):
     if pc in cache:
         return cache[pc]
     nb, mb, off = C.create_string_buffer(512), C.create_string_buffer(512), C.c_ulong(0)
-    r = ("?", "?") if not S.prof_sym(C.c_void_p(int(pc)), nb, 512, mb, 512, C.byref(off)) else (nb.value.decode(), os.path.basename(mb.value.decode()))
+    if not S.prof_sym(C.c_void_p(int(pc)), nb, 512, mb, 512, C.byref(off)):
+        r = ("?", "?")
+    else:
+        r = (nb.value.decode(), os.path.basename(mb.value.decode()))
+        modinfo[pc] = (mb.value.decode(), off.value)
     cache[pc] = r
     return r
 names = set()
@@ -55,6 +59,7 @@ if names:
     out = subprocess.run(["c++filt"], input="\n".join(sorted(names)), capture_output=True, text=True).stdout.splitlines()
     dem = dict(zip(sorted(names), out))
 incl, leaf, total_slam = collections.Counter(), collections.Counter(), 0
+own_pcs = collections.Counter()
 per = cpu_s / max(cnt, 1)   # seconds per sample (wall clock: the harness is one busy thread)
 for row in a:
     st = []
@@ -72,6 +77,7 @@ for row in a:
         continue
     total_slam += 1
     leaf[st[own][0][:120]] += 1
+    own_pcs[int(row[own])] += 1
     for f in dict.fromkeys(f for f, m in st[own:] if "alva_slam::" in f):
         incl[f[:120]] += 1
 print(f"{cnt} samples, {per * 1e3:.2f} ms of CPU each, over {win} frames; {total_slam} in the map layer (host-only) = {total_slam * per * 1e6 / win:.0f} us per frame")
@@ -81,3 +87,33 @@ for f, c in leaf.most_common(30):
 print("-- inclusive:")
 for f, c in incl.most_common(24):
     print(f"  {100.0 * c / total_slam:5.1f} %  {f}")
+# source lines of the innermost map-layer frames (the harness builds the map layer with -g; a return address points behind the call: - 1)
+bymod = collections.defaultdict(list)
+for pc, c in own_pcs.items():
+    if pc in modinfo:
+        bymod[modinfo[pc][0]].append((pc, modinfo[pc][1]))
+lines, callers = collections.Counter(), collections.Counter()
+for mod, lst in bymod.items():
+    # -i: the whole inline chain of every address; a chain is reported innermost first, one line per level, chains separated by the
+    # next address's echo (-a)
+    out = subprocess.run(["addr2line", "-e", mod, "-C", "-i", "-a"] + [hex(max(o - 1, 0)) for _, o in lst], capture_output=True, text=True).stdout.splitlines()
+    chains, cur_chain = [], None
+    for ln in out:
+        if ln.startswith("0x"):
+            cur_chain = []
+            chains.append(cur_chain)
+        elif cur_chain is not None:
+            cur_chain.append(ln.split("/")[-1].split(" ")[0])
+    for (pc, _), ch in zip(lst, chains):
+        if not ch:
+            continue
+        lines[ch[0]] += own_pcs[pc]
+        # the first level of the chain that is the map layer's own source (not libstdc++ / fortify headers)
+        own_src = next((x for x in ch if x.split(":")[0] in ("slam.hpp", "map.cpp", "mapper.cpp", "frontend.cpp", "flat_hash.hpp", "se3.hpp", "medoid_table.hpp", "inspect.hpp", "track_default.cpp")), ch[-1])
+        callers[own_src + ("  <- " + ch[0] if ch[0] != own_src else "")] += own_pcs[pc]
+print("-- source lines (innermost map-layer frame; inlined callees count at their own lines):")
+for ln, c in lines.most_common(40):
+    print(f"  {100.0 * c / total_slam:5.1f} %  {ln}")
+print("-- the same, attributed to the map layer's own source line (with the library line it was in):")
+for ln, c in callers.most_common(45):
+    print(f"  {100.0 * c / total_slam:5.1f} %  {ln}")

@@ -48,6 +48,6 @@ int prof_sym(void *addr, char *name, int ncap, char *mod, int mcap, unsigned lon
     name[ncap - 1] = 0;
     strncpy(mod, di.dli_fname ? di.dli_fname : "?", mcap - 1);
     mod[mcap - 1] = 0;
-    *off = di.dli_saddr ? (unsigned long) ((char *) addr - (char *) di.dli_saddr) : 0;
+    *off = (unsigned long) ((char *) addr - (char *) di.dli_fbase);   /* offset in the module: what addr2line wants for a shared object */
     return 1;
 }
