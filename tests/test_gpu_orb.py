@@ -53,7 +53,7 @@ def test_orb_detect_and_compute(ctx, w, h, seed, nf):
 
 
 @pytest.mark.parametrize("w,h,seed,nf,scale,nlevels,thr", [(640, 480, 7, 500, 1.5, 4, 20), (400, 300, 8, 1000, 1.2, 3, 7), (320, 240, 9, 200, 2.0, 2, 40),
-                                                           (256, 256, 10, 300, 1.2, 1, 20)])
+                                                           (256, 256, 10, 300, 1.2, 1, 20), (640, 480, 11, 500, 2.0, 5, 20)])
 def test_orb_other_pyramid_parameters(ctx, w, h, seed, nf, scale, nlevels, thr):
     """cv::ORB::create with other scale factors / level counts / FAST thresholds than the reference's defaults"""
     import torch
@@ -72,11 +72,12 @@ def test_orb_other_pyramid_parameters(ctx, w, h, seed, nf, scale, nlevels, thr):
 
 
 @pytest.mark.parametrize("w,h,seed,scale,nlevels", [(640, 480, 1, 1.2, 8), (1280, 720, 3, 1.2, 8), (333, 201, 4, 1.2, 8), (640, 480, 7, 1.5, 4),
-                                                   (320, 240, 9, 2.0, 4), (400, 300, 8, 1.1, 12), (96, 64, 5, 1.2, 8)])
+                                                   (320, 240, 9, 2.0, 4), (400, 300, 8, 1.1, 12), (96, 64, 5, 1.2, 8), (640, 480, 11, 2.0, 5), (800, 600, 12, 1.7, 6)])
 def test_orb_pyramid_and_blur_levels(ctx, w, h, seed, scale, nlevels, monkeypatch):
     """Every byte of every pyramid level (cv::ORB's INTER_LINEAR_EXACT chain, orb.cpp:1086-1099) and of its 7x7 blur (:1188) against the
     oracle (pinned to cv::resize / cv::GaussianBlur in test_oracle_vs_ref.py) -- from the fused launch, in which every tile recomputes
-    its ancestors from level 0 (steep pyramids leave their deep levels to the per-level launch), and from ALVA_ORB_PYRAMID=chain."""
+    its ancestors from level 0 (steep pyramids leave their deep levels to the per-level launch: scale 2.0 x 5 levels and 1.7 x 6 do), and
+    from ALVA_ORB_PYRAMID=chain."""
     import torch
     import alvaar_amd
     g = _img(w, h, seed, noise=True)
