@@ -14,3 +14,12 @@ def test_flat_hash_iterates_like_libstdcxx(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", str(exe), str(ROOT / "tests" / "cpp" / "flat_hash_vs_std.cpp")])
     out = subprocess.check_output([str(exe), "10"], text=True)
     assert out.startswith("ok ") and int(out.split()[1]) > 300000, out
+
+
+def test_cell_index_floor_is_std_floor(tmp_path):
+    """Frame::getKeypointCellIdx (frame.cpp:313-318) floors a float quotient; the map layer does it by truncation + correction
+    (FrameRec::floor_to_int, slam.hpp): equal to (int) std::floor for every cell boundary +- ulps, dense grids and random bit patterns"""
+    exe = tmp_path / "cell_index_floor"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", str(exe), str(ROOT / "tests" / "cpp" / "cell_index_floor.cpp")])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.strip().endswith(" 0 mismatches") and int(out.split()[0]) > 5000000, out
