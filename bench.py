@@ -404,7 +404,9 @@ def main():
         P = Wc * Hc
         # ---- roofline: per-KERNEL durations from HIP events recorded on each launch stream, over a further pass of the headline loop
         # (the events cost a few us per launch, so they stay out of the pass that gives `value`)
-        PROF_STEPS = 200
+        # one whole period of the synthetic stream (forward and back through its frames): the tracker's launch time follows the frame's
+        # content (its slowest slots), and a 200-step window of it was 10 % off the rocprofv3 average over the whole command in one run
+        PROF_STEPS = 2 * (STREAM_FRAMES - 1)
         log("kernel times of the headline loop")
         ar.klt_work()
         kt = capi.kernel_times(sysjob.step, PROF_STEPS)
