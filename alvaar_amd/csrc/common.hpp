@@ -69,6 +69,9 @@ struct alva_ctx {
     hipEvent_t fence = nullptr;  // lazily created; alva_ctx_wait records it on this context's stream
     void *pose_pending = nullptr;  // alva_compute_pose_enqueue -> _collect hand-over (pnp.hip)
     void (*pose_pending_free)(void *) = nullptr;
+    // alva_p3p_enqueue's last launch went to the group's lane (deposited) rather than to this context's stream: the refinement that
+    // consumes its output must travel the same way, or the two would run on unordered streams (pnp.hip pose_launch)
+    bool p3p_deferred = false;
 };
 
 int alva_ctx_scratch(alva_ctx *ctx, int slot, size_t bytes, void **out);

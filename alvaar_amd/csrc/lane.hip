@@ -61,10 +61,16 @@ struct alva_lane {
     int next_slot = 0;
 
     bool slot_ready(Slot &s) {
-        if (!s.host) {
-            if (hipHostMalloc((void **) &s.host, SLOT_BYTES, hipHostMallocDefault) != hipSuccess) return false;
-            if (hipMalloc((void **) &s.dev, SLOT_BYTES) != hipSuccess) return false;
-            if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return false;
+        if (!s.host) {   // all or nothing: a partial allocation is released, so that a later flush starts from scratch
+            uint8_t *h = nullptr, *d = nullptr;
+            hipEvent_t e = nullptr;
+            if (hipHostMalloc((void **) &h, SLOT_BYTES, hipHostMallocDefault) != hipSuccess || hipMalloc((void **) &d, SLOT_BYTES) != hipSuccess ||
+                hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                if (h) (void) hipHostFree(h);
+                if (d) (void) hipFree(d);
+                return false;
+            }
+            s.host = h; s.dev = d; s.done = e;
         }
         if (s.busy) {
             (void) hipEventSynchronize(s.done);   // (eight flushes back: long over)
@@ -113,7 +119,34 @@ struct alva_lane {
             (void) (hipEventRecord)(s.done, stream);
             s.busy = true;
         } else if (total > 0) {
-            alva_set_error("lane: argument tables of %zu bytes could not be staged", total);   // (the sessions' completion polls time out and report)
+            // the staging slots cannot carry this flush (tables larger than a slot, or the slot's allocation failed): a one-off device
+            // table filled by a synchronous copy -- slow, but every deposit is launched and its owner's completion words arrive
+            uint8_t *tmp = nullptr;
+            std::vector<uint8_t> img(total);
+            for (int k = 0; k <= upto; k++) {
+                const Pending &p = kind[k];
+                if (!p.count) continue;
+                memcpy(img.data() + off_gx[k], p.gx.data(), (size_t) p.count * 4);
+                memcpy(img.data() + off[k], p.args.data(), p.args.size());
+            }
+            if (hipMalloc((void **) &tmp, total) == hipSuccess && (hipMemcpy)(tmp, img.data(), total, hipMemcpyHostToDevice) == hipSuccess) {
+                for (int k = 0; k <= upto; k++) {
+                    Pending &p = kind[k];
+                    if (!p.count) continue;
+                    unsigned gmax = 0, smax = 0;
+                    for (int i = 0; i < p.count; i++) {
+                        gmax = p.gx[(size_t) i] > gmax ? p.gx[(size_t) i] : gmax;
+                        smax = p.shmem[(size_t) i] > smax ? p.shmem[(size_t) i] : smax;
+                    }
+                    g_kinds[k].launch(stream, tmp + off[k], (const unsigned *) (tmp + off_gx[k]), p.count, gmax, smax);
+                    launches++;
+                    entries += p.count;
+                }
+                (void) (hipStreamSynchronize)(stream);
+            } else {
+                alva_set_error("lane: argument tables of %zu bytes could not be staged", total);   // (the sessions' completion polls time out and report)
+            }
+            if (tmp) (void) hipFree(tmp);
         }
         for (int k = 0; k <= upto; k++) {
             Pending &p = kind[k];

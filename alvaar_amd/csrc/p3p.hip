@@ -663,7 +663,8 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     A.inlier = inlier;
     A.dbg = alva_kstamp_buffer();
     // (n <= 7168: the multi kernel keeps the default dynamic-LDS limit)
-    if (n <= 7168 && alva_lane_defer(MK_P3P, ctx, (unsigned) H, (unsigned) ((size_t) n * sizeof(double)), &A, sizeof(A))) return ALVA_OK;
+    ctx->p3p_deferred = n <= 7168 && alva_lane_defer(MK_P3P, ctx, (unsigned) H, (unsigned) ((size_t) n * sizeof(double)), &A, sizeof(A));
+    if (ctx->p3p_deferred) return ALVA_OK;
     static const bool inline_ok = getenv("ALVA_P3P_NO_INLINE_SAMPLES") == nullptr;
     if (H <= P3P_INLINE_H && inline_ok) {
         P3pInlineSamples S;

@@ -772,7 +772,9 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
     ((PnpOut *) (P.pin + P.poff_out))->seq = 0;   // the staging may be fresh memory; every earlier user of it has completed (polled or synchronised)
     const PnpBatchItem item{P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad, (PnpOut *) (P.pin + P.poff_out),
                             (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po};
-    if (alva_lane_defer(MK_PNP, ctx, 1, 0, &item, sizeof(item))) return ALVA_OK;
+    // deposited only behind a DEPOSITED P3P (same lane stream, chain order); a P3P that was launched on this context's own stream
+    // (n > 7168) is followed on that stream: the lane's stream and the session's are not ordered against each other
+    if (ctx->p3p_deferred && alva_lane_defer(MK_PNP, ctx, 1, 0, &item, sizeof(item))) return ALVA_OK;
     hipLaunchKernelGGL(k_pnp, dim3(1), dim3(NT), 0, ctx->stream, P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad,
                        (PnpOut *) (P.pin + P.poff_out), (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po);
     ALVA_LAUNCH_CHECK();

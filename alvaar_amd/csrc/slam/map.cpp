@@ -220,6 +220,7 @@ void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the des
     if (!kf_desc.insert_slot(kf).second) return;
     note_desc(kf, d);
     has_desc = true;   // desc_ is never empty again until the last observation goes
+    if (kf_desc.size() > (size_t) alva_medoid::CAP || kf_desc.bucket_count() > (size_t) alva_medoid::NBKT) mlog->overflow = true;
     // the bucket count of the rehash this insert caused, if any: the table in the stages replays the list surgery, not the growth policy
     mlog->push(dev_slot, alva_medoid::OP_ADD, kf, d.b, kf_desc.bucket_count() != buckets ? (int) kf_desc.bucket_count() : 0);
 }
@@ -250,6 +251,11 @@ std::shared_ptr<MapPt> Slam::map_point(int id) const {
 
 void Slam::flush_medoids() {
     MedoidLog &L = med_log;
+    if (L.overflow) {
+        L.overflow = false;
+        std::fprintf(stderr, "alva_slam: a map point holds more descriptors than its table (medoid_table.hpp CAP / NBKT)\n");
+        fail(-4);
+    }
     if (L.ops.empty()) return;
     std::vector<int> &firsts = med_firsts_;
     firsts.resize(L.touched.size());

@@ -268,6 +268,9 @@ struct MedoidLog {
     std::vector<int> first_op, last_op;       // per slot: chain head / tail in `ops`, -1 = none
     std::vector<int> free_slots;
     int next_slot = 0;
+    // a map point's key set outgrew what its table in the stages holds (medoid_table.hpp: CAP descriptors, NBKT buckets): the table would
+    // drop the descriptor and diverge from the key set, so the frame fails instead (Slam::flush_medoids, ALVA_ERR_STATE)
+    bool overflow = false;
     int alloc() {
         int s;
         if (!free_slots.empty()) {

@@ -492,7 +492,7 @@ struct Worker {
                 current = i;
                 // HIP's current device is per THREAD and the fibers share this one: whatever the previous fiber set must not leak into
                 // this one's allocations and launches after a yield
-                (void) hipSetDevice(f.sys->device);
+                if (f.sys) (void) hipSetDevice(f.sys->device);   // (a NULL session entry is answered with ALVA_ERR_ARG by the fiber's body)
                 if (f.lane) alva_lane_tick(f.lane);
                 g_alva_lane = f.lane;
                 g_alva_lane_dirty = &f.lane_dirty;

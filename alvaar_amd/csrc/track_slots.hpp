@@ -17,7 +17,8 @@
 #include "camera_device.hpp"
 #include <cstdint>
 
-constexpr int TRK_STRIPES = 64;   // arrival stripes of the wave-per-slot tracker launch: (unsigned long long *) cnt + 16 .. + 31 (see cnt below)
+constexpr int TRK_STRIPES = 64;   // arrival stripes of the wave-per-slot tracker launch: (unsigned long long *) cnt + 16 .. + 16 + TRK_STRIPES - 1 (see cnt below)
+static_assert((16 + TRK_STRIPES) * 8 <= 1024, "the arrival stripes must fit the 1024-byte counter block");
 struct TrackSlots {
     int n, use_prior, width, height;
     const float *in_px;        // pinned host, [n][2]

@@ -109,12 +109,13 @@ def roofline_ba(ctx, pb, peaks):
     return out
 
 
-def cpu_baseline(seed: int, frames_1: int = 150, frames_8: int = 60):
+def cpu_baseline(seed: int, frames_1: int = 150, frames_8: int = 150):
     """The reference itself on the host cores of this box (SURVEY.md 8(d) "CPU baseline timing" (1)-(3)), same stream, explicit
     timestamps, fixed-seed sampling, Ceres' wall-clock caps frozen (they would silently skip work):
       (1) System::findCameraPose frames/s on ONE core (the reference is single-threaded: wasm, NO_THREADS Ceres) at cell 12 (the metric's
           ~2000 keypoints; this is `value`), at the SHIPPED cell 40 (system.cpp:15), at 1280x720 / cell 15 (configs[4]); and 8 independent
-          reference Systems on 8 host threads (streams are independent: that is how the reference would use 8 cores);
+          reference Systems on 8 host threads, each on the SAME frames_1 frames as the one-core sample (streams are independent: that
+          is how the reference would use 8 cores; same frames => the two figures are comparable);
       (2) per-stage milliseconds, cpu_stage_table();  (3) one local-BA solve through Ceres with the reference's cost functions.
     Bounded sample: the first frames of the stream (incl. initialisation and the first keyframes); ~15 s of CPU work in total."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -512,16 +513,23 @@ def main():
             out["cpu_baseline"] = cpu_baseline(shard.stream_seed)
         out["detail_file"] = "bench_detail.json"
         write_detail(out)
-        # the driver's line: printed NOW, before the secondary lines -- nothing else is ever written to stdout
-        os.write(real_stdout, (compact_line(out) + "\n").encode())
-        log("compact line written")
-        if not args.quick and world == 1:
+        secondary = not args.quick and world == 1
+        if secondary:
+            # the three secondary figures the driver's record should carry (~10 s): 32 sessions on this GPU through
+            # alva_system_group, the 1280x720 System stream (configs[4] geometry), configs[2]'s ORB + Hamming frame -- measured BEFORE
+            # the line is printed, flat keys in the compact line
             import bench_detail
             sysjob.ar.close()
             del sysjob
             torch.cuda.empty_cache()
+            out.update(bench_detail.run_secondary(local, shard.stream_seed, args.steps, bctx, ba_pb, peaks, is720, part="line"))
+            write_detail(out)
+        # the driver's line: printed NOW, before the remaining secondary lines -- nothing else is ever written to stdout
+        os.write(real_stdout, (compact_line(out) + "\n").encode())
+        log("compact line written")
+        if secondary:
             out.update(bench_detail.run_secondary(local, shard.stream_seed, args.steps, bctx, ba_pb, peaks, is720,
-                                                  with_cpu=not args.no_cpu_baseline))
+                                                  with_cpu=not args.no_cpu_baseline, part="rest"))
             write_detail(out)
             log("bench_detail.json written")
     if dist:

@@ -160,12 +160,32 @@ def compact_line(full: dict) -> str:
     fs = g("frame_sections_us", {})
     if "ms_per_keyframe" in fs:
         out["ms_per_keyframe"] = fs["ms_per_keyframe"]
+    # secondary figures measured before the line is printed (bench.py, run_secondary(part="line")): flat keys
+    g32 = g("system_group32") or {}
+    if "frames_per_s" in g32:
+        out["group32_frames_per_s"] = _r(g32["frames_per_s"])
+        if g32.get("ms_keyframe_step_mean") is not None:
+            out["group32_ms_keyframe_step"] = _r(g32["ms_keyframe_step_mean"])
+    s720 = g("system_720p") or {}
+    if "frames_per_s" in s720:
+        out["system_720p_frames_per_s"] = _r(s720["frames_per_s"])
+        if "ms_per_keyframe" in s720:
+            out["system_720p_ms_per_keyframe"] = _r(s720["ms_per_keyframe"])
+    c720 = g("config_1280x720") or {}
+    if "ms_per_frame" in c720:
+        out["orb720_us_per_frame"] = _r(1e3 * c720["ms_per_frame"])
+        fn = (c720.get("kernels") or {}).get("k_fast_nms") or {}
+        if "GBps" in fn:
+            out["orb720_k_fast_nms_GBps"] = _r(fn["GBps"])
+    bd = g("bounds", {}).get("inputs", {})
+    if "tracking_chain_kernel_us" in bd:
+        out["tracking_chain"] = {"launches": bd.get("launches_on_the_tracking_chain"), "kernel_us": _r(bd["tracking_chain_kernel_us"])}
     mm = g("map_merge") or {}
     if mm and "error" not in mm:
         out["map_merge"] = {k: _r(mm[k]) for k in ("backend", "world", "records_gathered", "fused", "applied", "all_gather_us", "fuse_us") if k in mm}
     if "detail_file" in full:
         out["detail_file"] = full["detail_file"]
-    optional = ["map_merge", "ms_per_keyframe", "system_surface", "steps_timed", "seconds_timed", "keyframes_timed", "value_window", "local_ba"]
+    optional = ["map_merge", "tracking_chain", "orb720_k_fast_nms_GBps", "group32_ms_keyframe_step", "system_720p_ms_per_keyframe", "ms_per_keyframe", "system_surface", "steps_timed", "seconds_timed", "keyframes_timed", "value_window", "local_ba"]
     line = json.dumps(out, separators=(",", ":"))
     while len(line) >= COMPACT_LIMIT and optional:
         out.pop(optional.pop(0), None)

@@ -632,8 +632,10 @@ def stage_list_driver(local: int, seed: int, steps: int):
 
 
 def run_secondary(local: int, seed: int, steps: int, bctx, ba_pb, peaks, is720: bool = False, with_cpu: bool = True,
-                  group_sessions=(8, 16, 32, 64)) -> dict:
-    """Every secondary line, each guarded: a failing line is recorded as {"error": ...} and never costs the others."""
+                  group_sessions=(8, 16, 32, 64), part: str = "all") -> dict:
+    """Every secondary line, each guarded: a failing line is recorded as {"error": ...} and never costs the others.
+    part = "line": only the three figures bench.py's compact line carries (32 sessions, the 1280x720 System stream, configs[2]);
+    part = "rest": everything else (the group sweep keeps its 32-session entry: a second sample of the same figure)."""
     out = {}
 
     def guarded(name, fn):
@@ -643,18 +645,25 @@ def run_secondary(local: int, seed: int, steps: int, bctx, ba_pb, peaks, is720: 
         except Exception as e:   # noqa: BLE001 -- a secondary line must not take the record down
             out[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
+    if part == "line":
+        guarded("system_group32", lambda: bench_system_group(local, 32, 16, lanes=4))
+        if not is720:
+            guarded("system_720p", lambda: run_system_line(local, seed, 1280, 720, 15, steps))
+        guarded("config_1280x720", lambda: bench_720p(local, valu_peak_tops=peaks[1]))
+        return out
     # 16 worker threads (the GPU boxes give the container 16 CPUs), 4 lanes; and the same 32 sessions without lock-step launches
     guarded("system_group", lambda: [bench_system_group(local, s_, 16, lanes=4) for s_ in group_sessions] +
             [bench_system_group(local, 32, 16, lockstep=False), bench_system_group(local, 32, 8, lanes=2)])
     guarded("system_streams", lambda: [bench_system_streams(local, c_) for c_ in (4, 8)])
-    if not is720:
+    if not is720 and part == "all":
         guarded("system_720p", lambda: run_system_line(local, seed, 1280, 720, 15, steps))
     guarded("local_ba_batch", lambda: bench_ba_batch(bctx, ba_pb, peaks))
     guarded("two_view_init", lambda: bench_two_view_init(bctx))
     guarded("batched_preprocess", lambda: bench_batched_preprocess(local))
     guarded("track_mono_batch", lambda: [bench_track_mono_batch(local, c_) for c_ in (16, 64)])
     guarded("frame_step_batch", lambda: [bench_track_mono_batch(local, c_, detector=True) for c_ in (16, 64)])
-    guarded("config_1280x720", lambda: bench_720p(local, valu_peak_tops=peaks[1]))
+    if part == "all":
+        guarded("config_1280x720", lambda: bench_720p(local, valu_peak_tops=peaks[1]))
 
     def sld():
         a, b = stage_list_driver(local, seed, steps)

@@ -48,6 +48,23 @@ def test_compact_line_survives_oversized_text_and_keeps_the_contract_keys():
         assert k in got, k
 
 
+def test_compact_line_carries_the_secondary_figures_as_flat_keys():
+    """32 sessions, the 1280x720 System stream and configs[2]'s frame are measured before the line is printed and
+    travel in it as flat keys (bench.py, run_secondary(part="line")); the line of a round-4 record with them stays < 4 KB"""
+    full = json.loads((ROOT / "profiles" / "r4i_bench_detail.json").read_text())
+    full["system_group32"] = next(g_ for g_ in full["system_group"] if g_["sessions"] == 32)
+    line = bench_common.compact_line(full)
+    assert len(line) < 4096
+    got = json.loads(line)
+    assert got["group32_frames_per_s"] == pytest.approx(full["system_group32"]["frames_per_s"], rel=1e-4)
+    assert got["system_720p_frames_per_s"] == pytest.approx(full["system_720p"]["frames_per_s"], rel=1e-4)
+    assert got["orb720_us_per_frame"] == pytest.approx(1e3 * full["config_1280x720"]["ms_per_frame"], rel=1e-4)
+    assert got["orb720_k_fast_nms_GBps"] > 0 and got["tracking_chain"]["launches"] >= 1
+    assert "ms_per_keyframe" in got and "value_window" in got
+    for k in CONTRACT + ("roofline", "cpu_baseline"):
+        assert k in got, k
+
+
 def test_compact_line_of_a_minimal_record():
     line = bench_common.compact_line({"metric": "m", "value": 1.0, "unit": "frames/s", "n_gpus": 1, "steps": 2, "warmup": 0, "ms_per_step": 1000.0,
                                       "config": {"workload": "x"}})
