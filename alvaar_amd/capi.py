@@ -36,6 +36,8 @@ class PyrLevel(C.Structure):
 
 
 def _sig(name, argtypes, restype=_i):
+    if os.environ.get("ALVA_LIB") and not hasattr(lib, name):
+        return None   # an OLDER build loaded for an A/B measurement may lack the newest entry points (the in-tree build never does)
     fn = getattr(lib, name)
     fn.argtypes = argtypes
     fn.restype = restype
@@ -73,6 +75,7 @@ _sig("alva_prof_enable", [_i])
 _sig("alva_prof_report", [C.c_char_p, _sz])
 _sig("alva_orb_collect", [_vp, _vp, _vp])
 _sig("alva_orb_debug_level", [_vp, _vp, _i, _i, _vp, _sz, _vp, _vp])
+_sig("alva_match_to_map_records", [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _vp])
 _sig("alva_match_to_map", [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _vp])
 _sig("alva_undistort_points", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
 _sig("alva_project_dist", [_vp, _vp, _i] + [C.c_double] * 8 + [_vp])
@@ -346,6 +349,37 @@ class Context:
                                     kf_q.shape[0], _ptr(kf_q), _ptr(kf_t), n_mp, _ptr(mp_wpt), _ptr(mp_is3d), _ptr(obs_ptr), _ptr(obs_kf),
                                     _ptr(obs_px), _ptr(obs_desc), int(frame_kf), int(num_kp3d), local.shape[0], _ptr(local),
                                     float(max_proj_err), float(dist_ratio), _ptr(out)))
+        return out
+
+    MP_ENT_CAP = 40   # csrc/slam/mp_rec.hpp
+
+    @staticmethod
+    def mp_record_dtype():
+        """numpy layout of one map-point record (csrc/slam/mp_rec.hpp, 1024 bytes)"""
+        import numpy as np
+        ent = np.dtype([("kf", "<i4"), ("flags", "u1"), ("pad", "u1", 3), ("px", "<f4", 2), ("unpx", "<f4", 2)])
+        rec = np.dtype([("X", "<f8", 3), ("inv_depth", "<f8"), ("id", "<i4"), ("anchor_kf", "<i4"), ("is3d", "u1"), ("has_desc", "u1"),
+                        ("observed", "u1"), ("n_ent", "u1"), ("n_obs", "u1"), ("overflow", "u1"), ("pad8", "u1", 2), ("dev_slot", "<i4"),
+                        ("pad32", "<i4", 3), ("ent", ent, Context.MP_ENT_CAP)])
+        assert ent.itemsize == 24 and rec.itemsize == 1024
+        return rec
+
+    def match_to_map_records(self, calib10, cell_size, num_cells_w, grid_cells, cell_ptr, cell_mp, kf_ids, kf_q, kf_t, frame_kf_index, mp_slot,
+                             chunk_table, medoid_store, num_kp3d, local, max_proj_err=2.0, dist_ratio=0.2):
+        """Mapper::matchToMap on map-point RECORDS (alva_match_to_map_records): mp_slot [n_mp] names each row's record; chunk_table is a cuda
+        int64 tensor of the record chunks' addresses (pinned host memory, 4096 records per chunk); descriptors come from medoid_store's
+        tables.  Returns match_of_mp [n_mp] int32 (cuda)."""
+        import numpy as np
+        lib.alva_medoid_tables.restype = C.c_void_p
+        lib.alva_medoid_tables.argtypes = [C.c_void_p]
+        n_mp = mp_slot.shape[0]
+        out = torch.empty(n_mp, dtype=torch.int32, device=mp_slot.device)
+        cal = np.ascontiguousarray(calib10, np.float64)
+        frame_kf_id = int(kf_ids[int(frame_kf_index)].item())
+        check(lib.alva_match_to_map_records(self.h, cal.ctypes.data, int(cell_size), int(num_cells_w), int(grid_cells), _ptr(cell_ptr), _ptr(cell_mp),
+                                            kf_ids.shape[0], _ptr(kf_ids), _ptr(kf_q), _ptr(kf_t), int(frame_kf_index), frame_kf_id, n_mp, _ptr(mp_slot),
+                                            _ptr(chunk_table), lib.alva_medoid_tables(medoid_store.h), int(num_kp3d), local.shape[0],
+                                            _ptr(local), float(max_proj_err), float(dist_ratio), _ptr(out)))
         return out
 
     # f4b

@@ -306,6 +306,8 @@ extern "C" int alva_medoid_export(alva_medoid_store *s, int n, const int *mp_slo
     return ALVA_OK;
 }
 
+extern "C" const void *alva_medoid_tables(alva_medoid_store *s) { return s ? s->tables : nullptr; }
+
 extern "C" int alva_medoid_dump(alva_medoid_store *s, int mp_slot, void *table_out, size_t bytes) {
     ALVA_ARG(s && table_out && bytes == sizeof(Table) && mp_slot >= 0 && mp_slot < s->cap);
     ALVA_HIP(hipSetDevice(s->ctx->device));

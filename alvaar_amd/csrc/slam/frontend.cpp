@@ -55,6 +55,7 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     map_points.clear();
     kf_flat_.clear();
     mp_flat_.clear();
+    mp_rec_.clear();
     mp_nobs_.clear();
     mp_index_.clear();
     shared_ids.clear();
@@ -216,12 +217,12 @@ void Slam::klt_from_motion_prior() {
     // the next iterations can be requested ahead (this loop runs with the GPU idle, at the head of the frame's critical path)
     for (int s = 0; s < n; s++) {
         if (s + 16 < n && job_is3d_[(size_t) s + 16]) {
-            const MapPt *f = mp_raw(job_ids_[(size_t) s + 16]);
-            if (f) __builtin_prefetch(f->X);
+            const MpRec *f = rec_raw(job_ids_[(size_t) s + 16]);
+            if (f) __builtin_prefetch(f);
         }
         double *w = jw + 3 * (size_t) s;
         if (job_is3d_[(size_t) s]) {
-            const MapPt *mp = mp_raw(job_ids_[(size_t) s]);
+            const MpRec *mp = rec_raw(job_ids_[(size_t) s]);
             if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() throws in the reference (:131) if the map lost it
             std::memcpy(w, mp->X, 24);
         } else {

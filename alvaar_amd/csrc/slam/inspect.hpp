@@ -80,12 +80,12 @@ inline int inspect_map_points(Slam &s, int cap, int *ids, double *xyz, int *flag
     for (size_t i = 0; i < v.size() && (int) i < cap; i++) {
         const MapPt &m = *s.map_points.at(v[i]);
         ids[i] = v[i];
-        if (xyz) std::memcpy(xyz + 3 * i, m.X, 24);
+        if (xyz) std::memcpy(xyz + 3 * i, m.r->X, 24);
         if (flags) {
-            flags[5 * i] = m.is3d; flags[5 * i + 1] = m.observed; flags[5 * i + 2] = (int) m.obs_kfs.size(); flags[5 * i + 3] = m.anchor_kf;
+            flags[5 * i] = m.r->is3d; flags[5 * i + 1] = m.r->observed; flags[5 * i + 2] = (int) m.n_obs(); flags[5 * i + 3] = m.r->anchor_kf;
             flags[5 * i + 4] = (int) m.kf_desc.size();
         }
-        if (inv_depth) inv_depth[i] = m.inv_depth;
+        if (inv_depth) inv_depth[i] = m.r->inv_depth;
         slots.push_back(m.dev_slot);
     }
     if (desc && !slots.empty()) {
@@ -97,7 +97,7 @@ inline int inspect_map_points(Slam &s, int cap, int *ids, double *xyz, int *flag
         for (size_t i = 0; i < slots.size(); i++) {
             const MapPt &m = *s.map_points.at(v[i]);
             // the map layer's own view of the same table must agree with the stages' (key count; desc_ present) and nothing may have overflowed
-            if (info[3 * i + 2] || info[3 * i] != (int) m.kf_desc.size() || (valid[i] != 0) != m.has_desc) return -5;
+            if (info[3 * i + 2] || info[3 * i] != (int) m.kf_desc.size() || (valid[i] != 0) != (m.r->has_desc != 0)) return -5;
             if (!valid[i]) std::memset(desc + 32 * i, 0, 32);
         }
     }

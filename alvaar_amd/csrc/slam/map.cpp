@@ -198,16 +198,16 @@ void FrameRec::reset() {  // :467-489
 
 // ---------------------------------------------------------------------------------------------------- MapPt (map_point.cpp)
 void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
-    if (!obs_kfs.count(kf)) return;
-    obs_kfs.erase(kf);
-    if (obs_kfs.empty()) {
-        has_desc = false;
+    if (!obs_has(kf)) return;
+    obs_erase(kf);
+    if (r->n_obs == 0) {
+        r->has_desc = 0;
         kf_desc.clear();
         drop_all_desc();
         mlog->push(dev_slot, alva_medoid::OP_CLEAR, -1, nullptr, 0);
         return;
     }
-    if (kf == anchor_kf) anchor_kf = *obs_kfs.begin();
+    if (kf == r->anchor_kf) r->anchor_kf = obs_first();
     // :93-128: the distances of the remaining descriptors, the new desc_ -- in the stages' table (medoid_table.hpp remove_desc)
     if (kf_desc.erase(kf)) {
         drop_desc(kf);
@@ -217,23 +217,23 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
 
 void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid: medoid_table.hpp add_desc)
     const size_t buckets = kf_desc.bucket_count();
-    if (!kf_desc.insert_slot(kf).second) return;
-    note_desc(kf, d);
-    has_desc = true;   // desc_ is never empty again until the last observation goes
+    if (!kf_desc.insert_slot(kf, d).second) return;
+    note_desc(kf);
+    r->has_desc = 1;   // desc_ is never empty again until the last observation goes
     if (kf_desc.size() > (size_t) alva_medoid::CAP || kf_desc.bucket_count() > (size_t) alva_medoid::NBKT) mlog->overflow = true;
     // the bucket count of the rehash this insert caused, if any: the table in the stages replays the list surgery, not the growth policy
     mlog->push(dev_slot, alva_medoid::OP_ADD, kf, d.b, kf_desc.bucket_count() != buckets ? (int) kf_desc.bucket_count() : 0);
 }
 
 bool MapPt::is_bad() {  // map_point.cpp:183-202
-    if (obs_kfs.size() < 2) {
-        if (!observed && is3d) {
-            is3d = false;
+    if (r->n_obs < 2) {
+        if (!r->observed && r->is3d) {
+            r->is3d = 0;
             return true;
         }
     }
-    if (obs_kfs.size() == 0 && !observed) {
-        is3d = false;
+    if (r->n_obs == 0 && !r->observed) {
+        r->is3d = 0;
         return true;
     }
     return false;
@@ -293,7 +293,7 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
                 for (int lmid: ids) {
                     auto it = map_points.find(lmid);
                     if (it != map_points.end()) {
-                        const size_t nobs = it->second->obs_kfs.size();
+                        const size_t nobs = it->second->n_obs();
                         if (nobs < min_obs) {
                             to_remove = lmid;
                             min_obs = nobs;
@@ -318,7 +318,7 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
             remove_obs_from_cur(id);
             continue;
         }
-        mp->obs_kfs.insert(next_kf_id);
+        mp->obs_insert(next_kf_id);
         sync_nobs(*mp);
     }
 }
@@ -404,14 +404,23 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     }
 }
 
-const ObsPx *Slam::obs_of(const MapPt &mp, int kfid) const {
-    const ObsPx *o = mp.seen_in(kfid);
-    if (o && !o->in_kf) o = nullptr;
+bool Slam::ensure_rec_chunk(int slot) {
+    const size_t c = (size_t) slot >> MP_CHUNK_SHIFT;
+    while (med_log.chunks.size() <= c) {
+        MpRec *chunk = st->mp_arena_chunk((int) med_log.chunks.size());
+        if (!chunk) return false;
+        med_log.chunks.push_back(chunk);
+    }
+    return true;
+}
+
+const ObsEnt *Slam::obs_of(const MapPt &mp, int kfid) const {
+    const ObsEnt *o = mp.in_kf(kfid);
     if (check_obs_mirror_) {
         const FrameRec *kf = kf_raw(kfid);
-        const KeyPt *kp = kf ? kf->find(mp.id) : nullptr;
+        const KeyPt *kp = kf ? kf->find(mp.id()) : nullptr;
         if ((kp != nullptr) != (o != nullptr) || (kp && (std::memcmp(kp->px, o->px, 8) || std::memcmp(kp->unpx, o->unpx, 8)))) {
-            std::fprintf(stderr, "alva_slam: observation mirror out of sync (map point %d, keyframe %d)\n", mp.id, kfid);
+            std::fprintf(stderr, "alva_slam: observation mirror out of sync (map point %d, keyframe %d)\n", mp.id(), kfid);
             std::abort();
         }
     }
@@ -435,13 +444,21 @@ void Slam::add_keyframe() {  // map_manager.cpp:243-252: an independent copy of 
 }
 
 void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
-    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(&med_log, next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(&med_log, next_mp_id, next_kf_id);
+    const int slot = med_log.alloc();   // descriptor-table slot = record slot
+    if (!ensure_rec_chunk(slot)) {
+        med_log.release(slot);
+        fail(-3);
+        return;
+    }
+    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(&med_log, slot, next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(&med_log, slot, next_mp_id, next_kf_id);
     map_points.emplace(next_mp_id, mp);
     if (mp_flat_.size() <= (size_t) next_mp_id) {
         mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
+        mp_rec_.resize(mp_flat_.size(), nullptr);
         mp_nobs_.resize(mp_flat_.size(), 0);
     }
     mp_flat_[(size_t) next_mp_id] = mp.get();
+    mp_rec_[(size_t) next_mp_id] = mp->r;
     sync_nobs(*mp);
     next_mp_id++;
     n_map_points++;
@@ -451,34 +468,34 @@ void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) 
     MapPt *mpp = mp_raw(id);   // the flat mirror of mapMapPoints_ (same membership)
     if (!mpp) return;
     MapPt &mp = *mpp;
-    if (!mp.is3d) {
-        const SortedIds obs = mp.obs_kfs;  // getObservedKeyframeIds returns a copy; removals below edit the member
+    if (!mp.r->is3d) {
+        const ObsList obs = mp.observers();  // getObservedKeyframeIds returns a copy; removals below edit the member
         for (int kf: obs) {
             FrameRec *k = kf_raw(kf);
             if (k) k->turn3d(id);
             else mp.remove_obs(kf);
         }
         sync_nobs(mp);
-        if (mp.observed) cur->turn3d(id);
+        if (mp.r->observed) cur->turn3d(id);
     }
-    mp.X[0] = wpt[0]; mp.X[1] = wpt[1]; mp.X[2] = wpt[2];
-    mp.is3d = true;
-    if (anchor_inv_depth >= 0.) mp.inv_depth = anchor_inv_depth;
+    mp.r->X[0] = wpt[0]; mp.r->X[1] = wpt[1]; mp.r->X[2] = wpt[2];
+    mp.r->is3d = 1;
+    if (anchor_inv_depth >= 0.) mp.r->inv_depth = anchor_inv_depth;
 }
 
 void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-513
     auto pit = map_points.find(prev_id), nit = map_points.find(new_id);
-    if (pit == map_points.end() || nit == map_points.end() || !nit->second->is3d) return;
+    if (pit == map_points.end() || nit == map_points.end() || !nit->second->r->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
-    const SortedIds next_kfs = nw->obs_kfs, prev_kfs = prev->obs_kfs;
-    const FlatHash<FlatNoValue> prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order
+    const ObsList next_kfs = nw->observers(), prev_kfs = prev->observers();
+    const FlatHash<Desc> prev_desc = prev->kf_desc;   // a copy (keys + bytes), in the original's order
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;
-        if (kf->second->change_id(prev_id, new_id, nw->is3d)) {
+        if (kf->second->change_id(prev_id, new_id, nw->r->is3d != 0)) {
             prev->drop_px(pk);
             nw->note_px(pk, *kf->second->find(new_id));
-            nw->obs_kfs.insert(pk);
+            nw->obs_insert(pk);
             sync_nobs(*nw);
             for (int nk: next_kfs) {
                 auto co = keyframes.find(nk);
@@ -489,16 +506,11 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
             }
         }
     }
-    for (int se = prev_desc.first(); se != FlatHash<FlatNoValue>::END; se = prev_desc.next(se)) {
-        // (the descriptor bytes of prev's entry: its mirror holds them, see ObsPx)
-        const ObsPx *o = prev->seen_in(prev_desc.key(se));
-        if (!o || !o->has_desc) throw std::out_of_range("descriptor mirror");
-        nw->add_desc(prev_desc.key(se), o->desc);
-    }
+    for (int se = prev_desc.first(); se != FlatHash<Desc>::END; se = prev_desc.next(se)) nw->add_desc(prev_desc.key(se), prev_desc.val(se));
     if (cur->observes(prev_id)) {
-        if (cur->change_id(prev_id, new_id, nw->is3d)) set_map_point_obs(new_id);
+        if (cur->change_id(prev_id, new_id, nw->r->is3d != 0)) set_map_point_obs(new_id);
     }
-    if (prev->is3d) n_map_points--;
+    if (prev->r->is3d) n_map_points--;
     {   // the survivor keeps the absorbed point's place in the shared map, unless it has one of its own
         auto sh = shared_ids.find(prev_id);
         if (sh != shared_ids.end()) {
@@ -507,6 +519,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
         }
     }
     mp_flat_[(size_t) prev_id] = nullptr;
+    mp_rec_[(size_t) prev_id] = nullptr;
     mp_nobs_[(size_t) prev_id] = 0;
     map_points.erase(pit);
     n_merges++;
@@ -540,7 +553,7 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     auto it = map_points.find(id);
     if (it == map_points.end()) return;
     std::shared_ptr<MapPt> mp = it->second;
-    const SortedIds obs = mp->obs_kfs;
+    const ObsList obs = mp->observers();
     for (int kf: obs) {
         auto k = keyframes.find(kf);
         if (k == keyframes.end()) continue;
@@ -548,9 +561,10 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
         for (int co: obs)
             if (co != kf) k->second->decrease_covisible(co);
     }
-    if (mp->observed) cur->remove(id);
-    if (mp->is3d) n_map_points--;
+    if (mp->r->observed) cur->remove(id);
+    if (mp->r->is3d) n_map_points--;
     mp_flat_[(size_t) id] = nullptr;
+    mp_rec_[(size_t) id] = nullptr;
     mp_nobs_[(size_t) id] = 0;
     if (defer_mp_free_) mp_graveyard_.push_back(mp);
     map_points.erase(it);
@@ -565,7 +579,7 @@ void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-6
     m->second->remove_obs(kfid);
     sync_nobs(*m->second);
     if (kf != keyframes.end()) {
-        const SortedIds obs = m->second->obs_kfs;
+        const ObsList obs = m->second->observers();
         for (int co: obs) {
             auto c = keyframes.find(co);
             if (c != keyframes.end()) {
@@ -578,15 +592,15 @@ void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-6
 
 void Slam::remove_obs_from_cur(int mp_id) {  // map_manager.cpp:649-679
     cur->remove(mp_id);
-    MapPt *m = mp_raw(mp_id);
+    MpRec *m = rec_raw(mp_id);
     if (!m) return;
-    m->observed = false;
+    m->observed = 0;
 }
 
 bool Slam::set_map_point_obs(int mp_id) {  // map_manager.cpp:681-708
     auto m = map_points.find(mp_id);
     if (m == map_points.end()) return false;
-    m->second->observed = true;
+    m->second->r->observed = 1;
     return true;
 }
 
@@ -603,17 +617,20 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
     for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
         const int id = ids_scratch_[oi];
         prefetch_mp(ids_scratch_.data(), oi, ids_scratch_.size());
-        MapPt *m = mp_raw(id);
+        const MpRec *m = rec_raw(id);
         if (!m) {
             remove_map_point_obs(id, frame.kfid);
             remove_obs_from_cur(id);
             continue;
         }
-        for (int kf: m->obs_kfs)
+        for (int e = 0; e < m->n_ent; e++) {
+            if (!(m->ent[e].flags & MPF_OBS)) continue;
+            const int kf = m->ent[e].kf;
             if (kf != frame.kfid) {
                 if (kf >= 0 && kf <= next_kf_id) count[(size_t) kf]++;
                 else cov[kf] += 1;
             }
+        }
     }
     for (int kf = 0; kf <= next_kf_id; kf++)
         if (count[(size_t) kf]) cov[kf] += count[(size_t) kf];

@@ -74,9 +74,9 @@ void Slam::triangulate_temporal(FrameRec &frame) {  // mapper.cpp:144-291
             remove_map_point_obs(kps[i].id, frame.kfid);
             continue;
         }
-        if (mp->is3d) continue;
-        if (mp->obs_kfs.size() < 2) continue;
-        const int kfid = *mp->obs_kfs.begin();
+        if (mp->r->is3d) continue;
+        if (mp->n_obs() < 2) continue;
+        const int kfid = mp->obs_first();
         if (frame.kfid == kfid) continue;
         std::shared_ptr<FrameRec> kf = keyframe(kfid);
         if (!kf) continue;
@@ -178,7 +178,6 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     kf_index.assign((size_t) next_kf_id + 1, -1);
     for (size_t i = 0; i < kf_ids.size(); i++) kf_index[(size_t) kf_ids[i]] = (int) i;
     if (frame.kfid < 0 || frame.kfid > next_kf_id || kf_index[(size_t) frame.kfid] < 0) return result;
-    const int frame_kf_index = kf_index[(size_t) frame.kfid];
     // map point table: the frame's keypoints first (grid order), then the local map in ITS iteration order
     std::vector<int> &mp_ids = touched_b_;
     mp_ids.clear();
@@ -193,13 +192,11 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             for (int id: ids) index[(size_t) id] = -1;
         }
     } reset_index{mp_index, mp_ids};
-    size_t obs_bound = 0;   // upper bound of the observations to flatten (every observer of every table row)
-    auto intern = [&](int id, const MapPt &mp) {
+    auto intern = [&](int id) {
         int &slot = mp_index[(size_t) id];
         if (slot < 0) {
             slot = (int) mp_ids.size();
             mp_ids.push_back(id);
-            obs_bound += mp.obs_kfs.size();
         }
         return slot;
     };
@@ -218,7 +215,7 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             const MapPt *gm = mp_raw(id);
             if (!gm) continue;
             if (!obs_of(*gm, frame.kfid)) continue;
-            cell_mp_v.push_back(intern(id, *gm));
+            cell_mp_v.push_back(intern(id));
         }
     }
     cell_ptr_v[n_grid] = (int) cell_mp_v.size();
@@ -233,87 +230,79 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     });
     for (int id: local) {
         if (id >= 0 && id <= next_mp_id ? mark_a_[(size_t) id] != 0 : frame.observes(id)) continue;   // frame.isObservingKeypoint (:397-400)
-        const MapPt *mp = mp_raw(id);
+        const MpRec *mp = rec_raw(id);
         if (!mp || !mp->is3d || !mp->has_desc) continue;         // :404-411
-        local_idx.push_back(intern(id, *mp));
+        local_idx.push_back(intern(id));
     }
     for (int id: touched_a_) mark_a_[(size_t) id] = 0;
     fine(t_fine[4]);   // local list
     if (local_idx.empty()) return result;
     const int n_mp = (int) mp_ids.size(), n_kf = (int) kf_ids.size(), n_cell = (int) cell_mp_v.size(), n_local = (int) local_idx.size();
-    // ---- one block: fixed-size arrays first, the per-observation arrays (sized by the bound) last
+    // ---- one block for the call's own arrays: the map itself is NOT flattened -- the stage reads the records (mp_rec.hpp) of the rows'
+    //      slots and the descriptor tables of the same slots, so this keyframe's descriptor edits go to the stages first
+    flush_medoids();
+    if (err_) return result;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
         off += (bytes + 255) / 256 * 256;
         return o;
     };
-    const size_t o_cp = take((n_grid + 1) * 4), o_cm = take((size_t) n_cell * 4 + 4), o_q = take((size_t) n_kf * 32), o_t = take((size_t) n_kf * 24),
-                 o_w = take((size_t) n_mp * 24), o_3 = take((size_t) n_mp), o_hd = take((size_t) n_mp), o_op = take((size_t) (n_mp + 1) * 4),
-                 o_l = take((size_t) n_local * 4), o_m = take((size_t) n_mp * 4), o_ok = take(obs_bound * 4 + 4), o_oh = take(obs_bound + 4),
-                 o_ox = take(obs_bound * 8 + 8), o_od = take(obs_bound * 32 + 32);
+    const size_t o_cp = take((n_grid + 1) * 4), o_cm = take((size_t) n_cell * 4 + 4), o_ki = take((size_t) n_kf * 4), o_q = take((size_t) n_kf * 32),
+                 o_t = take((size_t) n_kf * 24), o_s = take((size_t) n_mp * 4), o_l = take((size_t) n_local * 4), o_m = take((size_t) n_mp * 4);
     uint8_t *blk = st->stage_scratch(off);
     if (!blk) {
         fail(-3);
         return result;
     }
-    int *cell_ptr = (int *) (blk + o_cp), *cell_mp = (int *) (blk + o_cm), *obs_ptr = (int *) (blk + o_op), *local_p = (int *) (blk + o_l),
-        *match_of_mp = (int *) (blk + o_m), *obs_kf = (int *) (blk + o_ok);
-    double *kf_q = (double *) (blk + o_q), *kf_t = (double *) (blk + o_t), *mp_wpt = (double *) (blk + o_w);
-    uint8_t *mp_is3d = blk + o_3, *mp_has_desc = blk + o_hd, *obs_has_desc = blk + o_oh, *obs_desc = blk + o_od;
-    float *obs_px = (float *) (blk + o_ox);
+    int *cell_ptr = (int *) (blk + o_cp), *cell_mp = (int *) (blk + o_cm), *kf_id_p = (int *) (blk + o_ki), *mp_slot = (int *) (blk + o_s),
+        *local_p = (int *) (blk + o_l), *match_of_mp = (int *) (blk + o_m);
+    double *kf_q = (double *) (blk + o_q), *kf_t = (double *) (blk + o_t);
     std::memcpy(cell_ptr, cell_ptr_v.data(), (n_grid + 1) * 4);
     std::memcpy(cell_mp, cell_mp_v.data(), (size_t) n_cell * 4);
     std::memcpy(local_p, local_idx.data(), (size_t) n_local * 4);
     for (int i = 0; i < n_kf; i++) {
         const FrameRec &k = *kf_raw(kf_ids[(size_t) i]);
+        kf_id_p[i] = kf_ids[(size_t) i];
         std::memcpy(kf_q + 4 * (size_t) i, k.Tcw.q, 32);
         std::memcpy(kf_t + 3 * (size_t) i, k.Tcw.t, 24);
     }
     size_t no = 0;
     for (int m = 0; m < n_mp; m++) {
-        prefetch_mp(mp_ids.data(), (size_t) m, (size_t) n_mp);
-        const MapPt &mp = *mp_raw(mp_ids[(size_t) m]);
-        std::memcpy(&mp_wpt[3 * (size_t) m], mp.X, 24);
-        mp_is3d[(size_t) m] = mp.is3d;
-        mp_has_desc[(size_t) m] = mp.has_desc;
-        obs_ptr[(size_t) m] = (int) no;
-        // observers (obs_kfs, ascending) against the per-keyframe records (seen, ascending): one pass over both
-        const ObsPx *sp = mp.seen.data(), *se = sp + mp.seen.size();
-        for (int kf: mp.obs_kfs) {
-            while (sp != se && sp->kf < kf) sp++;
-            if (kf < 0 || kf > next_kf_id || kf_index[(size_t) kf] < 0) continue;
-            const ObsPx *kk = sp != se && sp->kf == kf && sp->in_kf ? sp : nullptr;
-            if (check_obs_mirror_ && kk != obs_of(mp, kf)) {
-                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync (map point %d, keyframe %d)\n", mp.id, kf);
-                std::abort();
-            }
-            if (!kk) continue;
-            obs_kf[no] = kf_index[(size_t) kf];
-            obs_px[2 * no] = kk->px[0];
-            obs_px[2 * no + 1] = kk->px[1];
-            // one 32-byte slot per observation; keyframes in which the keypoint could not be described (within 31 px of the border,
-            // feature_extractor.cpp:191-209) have no entry in mapKeyframeDescriptors_: slot zeroed and flagged
-            if (check_obs_mirror_) {
-                if ((mp.kf_desc.count(kf) != 0) != (kk->has_desc != 0)) {
-                    std::fprintf(stderr, "alva_slam: descriptor mirror out of sync (map point %d, keyframe %d)\n", mp.id, kf);
+        const MpRec &mp = *rec_raw(mp_ids[(size_t) m]);
+        mp_slot[m] = mp.dev_slot;
+        no += mp.n_obs;
+        match_of_mp[m] = -1;
+        if (check_obs_mirror_) {   // the records against the authoritative containers: every observer's keypoint, every descriptor key
+            const MapPt &o = *mp_raw(mp_ids[(size_t) m]);
+            int n_desc = 0;
+            for (int e = 0; e < mp.n_ent; e++) {
+                const ObsEnt &en = mp.ent[e];
+                if (en.flags & MPF_DESC) n_desc++;
+                if (((en.flags & MPF_DESC) != 0) != (o.kf_desc.count(en.kf) != 0)) {
+                    std::fprintf(stderr, "alva_slam: descriptor mirror out of sync (map point %d, keyframe %d)\n", mp.id, en.kf);
                     std::abort();
                 }
+                if ((en.flags & MPF_OBS) && kf_raw(en.kf)) (void) obs_of(o, en.kf);
             }
-            if (kk->has_desc) std::memcpy(obs_desc + 32 * no, kk->desc.b, 32);
-            else std::memset(obs_desc + 32 * no, 0, 32);
-            obs_has_desc[no] = kk->has_desc;
-            no++;
+            if (n_desc != (int) o.kf_desc.size()) {
+                std::fprintf(stderr, "alva_slam: descriptor table of map point %d has keys without a record entry\n", mp.id);
+                std::abort();
+            }
         }
     }
-    obs_ptr[(size_t) n_mp] = (int) no;
-    for (int m = 0; m < n_mp; m++) match_of_mp[(size_t) m] = -1;
-    fine(t_fine[5]);   // per-map-point flatten
+    fine(t_fine[5]);   // per-map-point slots
     t_fine[20] += (double) n_mp; t_fine[21] += (double) no; t_fine[22] += (double) n_local;
     Lap lap;
-    const int rc = st->match_to_map((int) frame.cell, (int) frame.cells_w, (int) n_grid, cell_ptr, cell_mp, n_kf, kf_q, kf_t, n_mp, mp_wpt, mp_is3d,
-                                    mp_has_desc, obs_ptr, obs_kf, obs_px, obs_desc, obs_has_desc, frame_kf_index, (int) frame.n_3d, n_local, local_p,
-                                    max_proj_err, dist_ratio, match_of_mp);
+    MatchJob job;
+    job.cell_size = (int) frame.cell; job.num_cells_w = (int) frame.cells_w; job.grid_cells = (int) n_grid;
+    job.cell_ptr = cell_ptr; job.cell_mp = cell_mp;
+    job.n_kf = n_kf; job.kf_ids = kf_id_p; job.kf_q = kf_q; job.kf_t = kf_t;
+    job.n_mp = n_mp; job.mp_slot = mp_slot;
+    job.frame_kfid = frame.kfid; job.num_keypoints_3d = (int) frame.n_3d;
+    job.n_local = n_local; job.local = local_p;
+    job.max_proj_err = max_proj_err; job.dist_ratio = dist_ratio;
+    const int rc = st->match_to_map_rec(job, match_of_mp);
     lap(t_kf[9]);
     if (fail(rc)) return result;
     for (int m = 0; m < n_mp; m++)
@@ -360,7 +349,7 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                         continue;
                     }
                     if (mp->is_bad()) continue;
-                    if (mp->obs_kfs.size() > 4) good++;
+                    if (mp->n_obs() > 4) good++;
                     total++;
                 }
                 counted = true;
@@ -375,8 +364,8 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                     return;
                 }
                 MapPt *mp = mp_raw(kid);
-                if (mp && check_obs_mirror_ && (mp->obs_kfs.size() > 255 ? 255u : (unsigned) mp->obs_kfs.size()) != nobs) {
-                    std::fprintf(stderr, "alva_slam: observer count mirror out of sync (map point %d)\n", mp->id);
+                if (mp && check_obs_mirror_ && (unsigned) mp->n_obs() != nobs) {
+                    std::fprintf(stderr, "alva_slam: observer count mirror out of sync (map point %d)\n", mp->id());
                     std::abort();
                 }
                 if (!mp) {
@@ -384,7 +373,7 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
                     return;
                 } else if (mp->is_bad()) {
                     return;
-                } else if (mp->obs_kfs.size() > 4) {
+                } else if (mp->n_obs() > 4) {
                     good++;
                 }
                 total++;
@@ -505,16 +494,16 @@ void Slam::local_ba(FrameRec &new_frame) {
         }
         local_mps.insert_slot(lmid, mp);
         int anchor = -1, cur_slot = -1;
-        std::vector<int> &obs = obs_scratch_;  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
-        obs.assign(mp->obs_kfs.begin(), mp->obs_kfs.end());
-        size_t si = 0;   // walks mp->seen (sorted by keyframe like obs) beside the observers; a repair below edits it: start over
+        const ObsList obs = mp->observers();  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
+        const MpRec &rec = *mp->r;
+        int si = 0;   // walks the record's entries (sorted by keyframe like obs) beside the observers; a repair below edits them: start over
         for (int kfid: obs) {
             if (kfid > max_kfid) continue;
             FrameRec *kf = kf_flat[(size_t) kfid];
             if (!kf) {  // an observing keyframe outside the covisibility set joins as a constant one (:153-172)
                 std::shared_ptr<FrameRec> sp = keyframe(kfid);
                 if (!sp) {
-                    remove_map_point_obs(kfid, mp->id);  // sic: arguments swapped in the reference (optimizer.cpp:162)
+                    remove_map_point_obs(kfid, mp->id());  // sic: arguments swapped in the reference (optimizer.cpp:162)
                     si = 0;
                     continue;
                 }
@@ -523,10 +512,10 @@ void Slam::local_ba(FrameRec &new_frame) {
                 add_pose(kfid, *kf, true);
                 const_kfs.insert(kfid);
             }
-            while (si < mp->seen.size() && mp->seen[si].kf < kfid) si++;
-            const ObsPx *kp = si < mp->seen.size() && mp->seen[si].kf == kfid && mp->seen[si].in_kf ? &mp->seen[si] : nullptr;
+            while (si < rec.n_ent && rec.ent[si].kf < kfid) si++;
+            const ObsEnt *kp = si < rec.n_ent && rec.ent[si].kf == kfid && (rec.ent[si].flags & MPF_INKF) ? &rec.ent[si] : nullptr;
             if (check_obs_mirror_ && kp != obs_of(*mp, kfid)) {
-                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync in localBA (map point %d, keyframe %d)\n", mp->id, kfid);
+                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync in localBA (map point %d, keyframe %d)\n", mp->id(), kfid);
                 std::abort();
             }
             if (!kp) {
@@ -537,7 +526,7 @@ void Slam::local_ba(FrameRec &new_frame) {
             if (anchor < 0) {  // the first observing keyframe anchors the inverse depth; it gets no residual (:186-201)
                 anchor = kfid;
                 double pc[3];
-                se3_apply(kf->Tcw, mp->X, pc);
+                se3_apply(kf->Tcw, rec.X, pc);
                 cur_slot = (int) pt_ids.size();
                 pt_slot[(size_t) lmid] = cur_slot;
                 pt_ids.push_back(lmid);
@@ -662,8 +651,8 @@ void Slam::local_ba(FrameRec &new_frame) {
             bad_mps.erase(lmid);
             continue;
         }
-        if (mp->obs_kfs.size() < 3) {
-            if (mp->anchor_kf < new_frame.kfid - 3 && !mp->observed) {
+        if (mp->n_obs() < 3) {
+            if (mp->r->anchor_kf < new_frame.kfid - 3 && !mp->r->observed) {
                 remove_map_point(lmid);
                 bad_mps.erase(lmid);
                 continue;
@@ -680,14 +669,14 @@ void Slam::local_ba(FrameRec &new_frame) {
             bad_mps.erase(lmid);
             continue;
         }
-        const FrameRec *akp = mp->anchor_kf >= 0 && (size_t) mp->anchor_kf < kf_flat.size() ? kf_flat[(size_t) mp->anchor_kf] : nullptr;
+        const FrameRec *akp = mp->r->anchor_kf >= 0 && (size_t) mp->r->anchor_kf < kf_flat.size() ? kf_flat[(size_t) mp->r->anchor_kf] : nullptr;
         if (!akp) {  // the anchor keyframe is not part of the problem (:459-463)
             bad_mps.insert(lmid);
             continue;
         }
         {
             const FrameRec &akf = *akp;
-            const ObsPx *kp = obs_of(*mp, akf.kfid);
+            const ObsEnt *kp = obs_of(*mp, akf.kfid);
             const float ux = kp ? kp->unpx[0] : 0.f, uy = kp ? kp->unpx[1] : 0.f;  // a default Keypoint has unpx_ = (0, 0)
             const double uv[3] = {(double) ux, (double) uy, 1.};
             double ray[3], pc[3], wpt[3];
@@ -706,8 +695,8 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (!mp) continue;
         if (mp->is_bad()) {
             remove_map_point(lmid);
-        } else if (mp->obs_kfs.size() < 3) {
-            if (mp->anchor_kf < new_frame.kfid - 3 && !mp->observed) remove_map_point(lmid);
+        } else if (mp->n_obs() < 3) {
+            if (mp->r->anchor_kf < new_frame.kfid - 3 && !mp->r->observed) remove_map_point(lmid);
         }
     }
     lap_ba(t_kf[14]);

@@ -29,6 +29,7 @@ namespace alva_medoid {
 constexpr int CAP = 48;      // descriptors per map point: one per keyframe that holds it; the mapper's window is 30 keyframes
 constexpr int NBKT = 59;     // libstdc++'s bucket counts on the way: 1, 13, 29, 59 (the 60th element would rehash to 127)
 constexpr int END = -1, EMPTY = -1, BEFORE_BEGIN = -2;
+constexpr int FREE_KEY = (int) 0x80000000;   // key of a slot on the free list (a reader that scans slots 0 .. used - 1 instead of walking the list)
 
 enum Op : int { OP_ADD = 0, OP_REMOVE = 1, OP_CLEAR = 2, OP_RESET = 3 };
 // one logged operation; `next` chains the operations of ONE map point in program order (-1 ends the chain)
@@ -168,6 +169,7 @@ ALVA_MED_HD inline void erase_slot(Table &t, int s) {   // unordered_map::erase(
     if (prev == BEFORE_BEGIN) t.head = nx;
     else t.slot[prev].next = nx;
     t.slot[s].next = t.free_;
+    t.slot[s].key = FREE_KEY;
     t.free_ = s;
     t.count--;
 }

@@ -17,6 +17,7 @@
 #include <unordered_set>
 #include <vector>
 #include "flat_hash.hpp"
+#include "mp_rec.hpp"
 #include "se3.hpp"
 #include "stages.hpp"
 
@@ -216,49 +217,6 @@ struct FrameRec {
     void reset();
 };
 
-// std::set<int> as the map layer uses it (insert / erase / count / ordered walk / copy), on a sorted vector.  A std::set<int> walks its
-// keys in ascending order whatever the insertion history, so this is the same container behaviour without a tree node per key.
-struct SortedIds {
-    std::vector<int> v;
-    typedef std::vector<int>::const_iterator const_iterator;
-    const_iterator begin() const { return v.begin(); }
-    const_iterator end() const { return v.end(); }
-    size_t size() const { return v.size(); }
-    bool empty() const { return v.empty(); }
-    size_t count(int k) const {
-        for (int x: v)
-            if (x == k) return 1;
-        return 0;
-    }
-    void insert(int k) {
-        size_t i = v.size();
-        while (i > 0 && v[i - 1] > k) i--;
-        if (i > 0 && v[i - 1] == k) return;
-        v.insert(v.begin() + (long) i, k);
-    }
-    void erase(int k) {
-        for (size_t i = 0; i < v.size(); i++)
-            if (v[i] == k) {
-                v.erase(v.begin() + (long) i);
-                return;
-            }
-    }
-};
-
-// What one keyframe holds about a map point, gathered in one place: the keypoint with the point's id as the KEYFRAME stores it
-// (in_kf; pixels of a keyframe's keypoints never change after the copy of map_manager.cpp:243-252) and the descriptor the point
-// keeps for that keyframe (has_desc; mapKeyframeDescriptors_).  MapPt::seen mirrors both so that the flattening loops of
-// matchToMap / localBA read an observation from one contiguous record instead of a hash look-up into the keyframe and one into
-// the descriptor map.  Not behaviour: the keyframes and kf_desc stay authoritative, every edit of a KEYFRAME's mapKeypoints_
-// (the copy, removeKeypointById, the id change of mergeMapPoints, removeKeyframe) and of kf_desc updates the mirror, and
-// ALVA_CHECK_OBS_MIRROR=1 compares every read with the authoritative containers.
-struct ObsPx {
-    int kf = -1;
-    uint8_t in_kf = 0, has_desc = 0;
-    float px[2] = {0, 0}, unpx[2] = {0, 0};
-    Desc desc{};
-};
-
 // The operation log of the map points' descriptor tables (Stages::medoid_replay, medoid_table.hpp) + the allocator of their slots.
 // The map layer edits the KEY sets (MapPt::kf_desc) at once -- its control flow reads nothing else -- and appends what happened here;
 // Slam::flush_medoids hands the log to the stages once per keyframe.
@@ -268,6 +226,10 @@ struct MedoidLog {
     std::vector<int> first_op, last_op;       // per slot: chain head / tail in `ops`, -1 = none
     std::vector<int> free_slots;
     int next_slot = 0;
+    // the record arena (mp_rec.hpp): chunks of MP_CHUNK records handed out by the stages (pinned memory behind the HIP stages); record
+    // `s` belongs to the map point that holds descriptor-table slot `s`
+    std::vector<MpRec *> chunks;
+    MpRec *rec(int s) const { return chunks[(size_t) s >> MP_CHUNK_SHIFT] + (s & (MP_CHUNK - 1)); }
     // a map point's key set outgrew what its table in the stages holds (medoid_table.hpp: CAP descriptors, NBKT buckets): the table would
     // drop the descriptor and diverge from the key set, so the frame fails instead (Slam::flush_medoids, ALVA_ERR_STATE)
     bool overflow = false;
@@ -300,84 +262,98 @@ struct MedoidLog {
     }
 };
 
-// class MapPoint, map_point.hpp:27-86
+// class MapPoint, map_point.hpp:27-86.  The scalars, the observing keyframes (observedKeyframeIds_) and what each keyframe holds about
+// the point live in the RECORD `r` (mp_rec.hpp: fixed stride, pinned, read by the kernels); the object keeps the descriptor table's
+// host copy and the record's owner-ship.  Not behaviour: the keyframes' own tables stay authoritative for "which keypoint does keyframe
+// kf hold", every edit of a KEYFRAME's mapKeypoints_ (the copy, removeKeypointById, the id change of mergeMapPoints, removeKeyframe)
+// updates the entry's MPF_INKF half, and ALVA_CHECK_OBS_MIRROR=1 compares every read with the authoritative containers.
 struct MapPt {
-    int id = -1;
-    bool observed = true, is3d = false;
-    SortedIds obs_kfs;                           // observedKeyframeIds_ (std::set<int>)
-    double X[3] = {0, 0, 0};
-    int anchor_kf = -1;                          // keyframeId_
-    double inv_depth = -1.;
-    bool has_desc = false;                       // !desc_.empty()
-    // the KEYS of mapKeyframeDescriptors_ / mapDescriptorsDist_ (the reference edits the two unordered_maps together: same keys, same
-    // sequence => same iteration order) in libstdc++'s order (flat_hash.hpp).  The descriptors, the distance sums and desc_ itself live
-    // in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`, nothing of them is read back by the map layer
-    FlatHash<FlatNoValue> kf_desc;
+    MpRec *r = nullptr;
+    // mapKeyframeDescriptors_ (the reference edits it and mapDescriptorsDist_ together: same keys, same sequence => same iteration
+    // order) in libstdc++'s order (flat_hash.hpp), with the descriptor bytes (merges copy them to the survivor).  The distance sums and
+    // desc_ itself live in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`, nothing is read back
+    FlatHash<Desc> kf_desc;
     MedoidLog *mlog = nullptr;
     int dev_slot = -1;
-    std::vector<ObsPx> seen;                     // see ObsPx
 
-    MapPt(MedoidLog *log, int id_, int kf) : id(id_), anchor_kf(kf), mlog(log), dev_slot(log->alloc()) { obs_kfs.insert(kf); }
-    MapPt(MedoidLog *log, int id_, int kf, const Desc &d) : id(id_), anchor_kf(kf), mlog(log), dev_slot(log->alloc()) {
-        obs_kfs.insert(kf);
-        add_desc(kf, d);
+    MapPt(MedoidLog *log, int slot, int id_, int kf) : r(log->rec(slot)), mlog(log), dev_slot(slot) {
+        rec_init(*r, id_, kf, slot);
+        obs_insert(kf);
     }
+    MapPt(MedoidLog *log, int slot, int id_, int kf, const Desc &d) : MapPt(log, slot, id_, kf) { add_desc(kf, d); }
     MapPt(const MapPt &) = delete;
     MapPt &operator=(const MapPt &) = delete;
-    ~MapPt() { mlog->release(dev_slot); }
+    ~MapPt() {
+        r->id = -1;
+        r->n_ent = r->n_obs = 0;
+        mlog->release(dev_slot);
+    }
+    int id() const { return r->id; }
+    // observedKeyframeIds_ (std::set<int>)
+    size_t n_obs() const { return r->n_obs; }
+    bool obs_has(int kf) const {
+        const int i = rec_find(*r, kf);
+        return i >= 0 && (r->ent[i].flags & MPF_OBS);
+    }
+    int obs_first() const {   // *begin()
+        for (int i = 0; i < r->n_ent; i++)
+            if (r->ent[i].flags & MPF_OBS) return r->ent[i].kf;
+        return -1;
+    }
+    void obs_insert(int kf) {
+        ObsEnt *e = rec_slot(*r, kf);
+        if (!e) {
+            mlog->overflow = true;
+            return;
+        }
+        if (!(e->flags & MPF_OBS)) {
+            e->flags |= MPF_OBS;
+            r->n_obs++;
+        }
+    }
+    void obs_erase(int kf) {
+        const int i = rec_find(*r, kf);
+        if (i >= 0 && (r->ent[i].flags & MPF_OBS)) rec_clear_flag(*r, i, MPF_OBS);
+    }
+    ObsList observers() const { return rec_observers(*r); }   // getObservedKeyframeIds(): a copy
     void remove_obs(int kf);
     void add_desc(int kf, const Desc &d);
     bool is_bad();
 
-    // `seen` is kept sorted by keyframe id (like obs_kfs), so the flattening loops walk the two lists side by side
-    ObsPx *seen_in(int kf) {
-        for (ObsPx &o: seen) {
-            if (o.kf == kf) return &o;
-            if (o.kf > kf) break;
-        }
-        return nullptr;
-    }
-    const ObsPx *seen_in(int kf) const { return const_cast<MapPt *>(this)->seen_in(kf); }
-    ObsPx &seen_slot(int kf) {
-        size_t i = seen.size();
-        while (i > 0 && seen[i - 1].kf > kf) i--;
-        if (i > 0 && seen[i - 1].kf == kf) return seen[i - 1];
-        ObsPx o;
-        o.kf = kf;
-        return *seen.insert(seen.begin() + (long) i, o);
-    }
-    void seen_prune(ObsPx *o) {
-        if (o->in_kf || o->has_desc) return;
-        seen.erase(seen.begin() + (o - seen.data()));
+    // the keypoint this point has in keyframe kf (null: that keyframe holds none)
+    const ObsEnt *in_kf(int kf) const {
+        const int i = rec_find(*r, kf);
+        return i >= 0 && (r->ent[i].flags & MPF_INKF) ? &r->ent[i] : nullptr;
     }
     void note_px(int kf, const KeyPt &k) {
-        ObsPx &o = seen_slot(kf);
-        o.in_kf = 1;
-        o.px[0] = k.px[0]; o.px[1] = k.px[1];
-        o.unpx[0] = k.unpx[0]; o.unpx[1] = k.unpx[1];
+        ObsEnt *e = rec_slot(*r, kf);
+        if (!e) {
+            mlog->overflow = true;
+            return;
+        }
+        e->flags |= MPF_INKF;
+        e->px[0] = k.px[0]; e->px[1] = k.px[1];
+        e->unpx[0] = k.unpx[0]; e->unpx[1] = k.unpx[1];
     }
     void drop_px(int kf) {
-        ObsPx *o = seen_in(kf);
-        if (!o) return;
-        o->in_kf = 0;
-        seen_prune(o);
+        const int i = rec_find(*r, kf);
+        if (i >= 0 && (r->ent[i].flags & MPF_INKF)) rec_clear_flag(*r, i, MPF_INKF);
     }
-    void note_desc(int kf, const Desc &d) {
-        ObsPx &o = seen_slot(kf);
-        o.has_desc = 1;
-        o.desc = d;
+    void note_desc(int kf) {
+        ObsEnt *e = rec_slot(*r, kf);
+        if (!e) {
+            mlog->overflow = true;
+            return;
+        }
+        e->flags |= MPF_DESC;
     }
     void drop_desc(int kf) {
-        ObsPx *o = seen_in(kf);
-        if (!o) return;
-        o->has_desc = 0;
-        seen_prune(o);
+        const int i = rec_find(*r, kf);
+        if (i >= 0 && (r->ent[i].flags & MPF_DESC)) rec_clear_flag(*r, i, MPF_DESC);
     }
     void drop_all_desc() {
-        for (size_t i = seen.size(); i-- > 0;) {
-            seen[i].has_desc = 0;
-            seen_prune(&seen[i]);
-        }
+        for (int i = r->n_ent; i-- > 0;)
+            if (r->ent[i].flags & MPF_DESC) rec_clear_flag(*r, i, MPF_DESC);
     }
 };
 
@@ -500,52 +476,51 @@ private:
     // access.  The hash maps stay authoritative (their iteration order is behaviour); every insert / erase / clear updates the mirror.
     // software prefetch for loops that visit map points in an order the hardware cannot predict: the object `far` items ahead, its two
     // small vectors' storage `near` items ahead (their addresses are only known once the object is in cache)
-    void prefetch_mp(const int *ids, size_t i, size_t n, size_t near_d = 6, size_t far_d = 14) const {
+    void prefetch_mp(const int *ids, size_t i, size_t n, size_t far_d = 10) const {
         if (i + far_d < n) {
-            const MapPt *f = mp_raw(ids[i + far_d]);
-            if (f) __builtin_prefetch(f);
-        }
-        if (i + near_d < n) {
-            const MapPt *m = mp_raw(ids[i + near_d]);
-            if (m) {
-                __builtin_prefetch(m->obs_kfs.v.data());
-                const char *rec = (const char *) m->seen.data();
-                __builtin_prefetch(rec);
-                __builtin_prefetch(rec + 64);
-                __builtin_prefetch(rec + 128);
+            const MpRec *f = rec_raw(ids[i + far_d]);   // the record's address is a table look-up away: header + the first entries
+            if (f) {
+                const char *c = (const char *) f;
+                __builtin_prefetch(c);
+                __builtin_prefetch(c + 64);
+                __builtin_prefetch(c + 128);
+                __builtin_prefetch(c + 192);
             }
         }
     }
-    // the same for loops that run the descriptor-medoid update of every visited map point (addDesc / removeObservedKeyframeId read the
-    // whole descriptor table: ~48 bytes per observing keyframe)
+    // the same for loops that run the descriptor-medoid update of every visited map point (addDesc / removeObservedKeyframeId edit the
+    // key table: 44 bytes per descriptor)
     void prefetch_mp_desc(const int *ids, size_t i, size_t n, size_t near_d = 4, size_t far_d = 10) const {
         if (i + far_d < n) {
             const MapPt *f = mp_raw(ids[i + far_d]);
             if (f) {
                 __builtin_prefetch(f);
                 __builtin_prefetch((const char *) f + 64);
-                __builtin_prefetch((const char *) f + 128);
+                const char *c = (const char *) f->r;
+                __builtin_prefetch(c);
+                __builtin_prefetch(c + 64);
+                __builtin_prefetch(c + 128);
             }
         }
         if (i + near_d < n) {
             const MapPt *m = mp_raw(ids[i + near_d]);
             if (m) {
                 const char *t = (const char *) m->kf_desc.slot_storage();
-                const size_t bytes = m->kf_desc.slots() * 12;
+                const size_t bytes = m->kf_desc.slots() * 44;
                 for (size_t o = 0; o < bytes && o < 1024; o += 64) __builtin_prefetch(t + o);
-                __builtin_prefetch(m->seen.data());
-                __builtin_prefetch(m->obs_kfs.v.data());
             }
         }
     }
     FrameRec *kf_raw(int id) const { return id >= 0 && (size_t) id < kf_flat_.size() ? kf_flat_[(size_t) id] : nullptr; }
     MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
+    MpRec *rec_raw(int id) const { return id >= 0 && (size_t) id < mp_rec_.size() ? mp_rec_[(size_t) id] : nullptr; }   // the record alone (hot loops)
     std::vector<FrameRec *> kf_flat_;
     std::vector<MapPt *> mp_flat_;
+    std::vector<MpRec *> mp_rec_;
     // observer count per map point id (0 = no such point), saturated at 255: the keyframe filter of Mapper::optimize asks "more than
     // four observers?" of every 3-D keypoint of every covisible keyframe; a byte table answers without touching the map point
     std::vector<uint8_t> mp_nobs_;
-    void sync_nobs(const MapPt &mp) { mp_nobs_[(size_t) mp.id] = (uint8_t) (mp.obs_kfs.size() > 255 ? 255 : mp.obs_kfs.size()); }
+    void sync_nobs(const MapPt &mp) { mp_nobs_[(size_t) mp.r->id] = mp.r->n_obs; }
     bool check_obs_mirror_ = false;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
     struct BaScratch {   // local_ba's problem arrays (see there)
@@ -561,7 +536,8 @@ private:
     } ba_scratch_;
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
     std::vector<std::shared_ptr<MapPt>> mp_graveyard_;
-    const ObsPx *obs_of(const MapPt &mp, int kfid) const;   // the keypoint of `mp` in keyframe `kfid` (null: that keyframe holds none)
+    const ObsEnt *obs_of(const MapPt &mp, int kfid) const;   // the keypoint of `mp` in keyframe `kfid` (null: that keyframe holds none)
+    bool ensure_rec_chunk(int slot);                          // the arena chunk of record `slot` exists (asks the stages for it)
 
     // Mapper
     void process_new_keyframe(int kfid);

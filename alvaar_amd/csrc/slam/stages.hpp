@@ -12,6 +12,8 @@
 #include <cstring>
 #include <vector>
 #include "medoid_table.hpp"
+#include "mp_rec.hpp"
+#include <memory>
 
 namespace alva_slam {
 
@@ -55,6 +57,23 @@ struct TrackPose {
     int status = -1;
     double pose7_p3p[7] = {0, 0, 0, 0, 0, 0, 1}, pose7[7] = {0, 0, 0, 0, 0, 0, 1};
     std::vector<uint8_t> p3p_outlier, pnp_outlier;
+};
+
+// Mapper::matchToMap (mapper.cpp:354-588) as a job over the map layer's RECORDS (mp_rec.hpp): the frame's grid cells and the local
+// list name rows of a map-point table, a row names the record / descriptor-table slot of its map point; the observations are read
+// from the records, the descriptors from the tables of the same slots (flush the medoid log first).
+struct MatchJob {
+    int cell_size = 0, num_cells_w = 0, grid_cells = 0;
+    const int *cell_ptr = nullptr, *cell_mp = nullptr;   // [grid_cells + 1], rows of the cells' keypoints
+    int n_kf = 0;
+    const int *kf_ids = nullptr;                         // the keyframes of the map, ascending id
+    const double *kf_q = nullptr, *kf_t = nullptr;       // their poses world -> camera
+    int n_mp = 0;
+    const int *mp_slot = nullptr;                        // row -> record slot
+    int frame_kfid = 0, num_keypoints_3d = 0;
+    int n_local = 0;
+    const int *local = nullptr;                          // rows of the local map points, in the local map's order
+    float max_proj_err = 0.f, dist_ratio = 0.f;
 };
 
 struct Stages {
@@ -131,6 +150,15 @@ struct Stages {
                             const float *unpx_l, const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status,
                             double *parallax) = 0;
 
+    // Chunk `chunk` of the map layer's record arena (mp_rec.hpp): MP_CHUNK zero-filled MpRec records that stay where they are for the
+    // life of the stages object.  The map layer edits them in place; an implementation whose kernels read the records hands out memory
+    // they can reach (the HIP stages: pinned host memory, gathered by zero-copy reads).  nullptr = allocation failed.
+    virtual MpRec *mp_arena_chunk(int chunk) {
+        if ((size_t) chunk >= arena_.size()) arena_.resize((size_t) chunk + 1);
+        if (!arena_[(size_t) chunk]) arena_[(size_t) chunk].reset(new MpRec[MP_CHUNK]());
+        return arena_[(size_t) chunk].get();
+    }
+
     // Host scratch of at least `bytes` in which the map layer may assemble the arrays of the NEXT match_to_map / local_ba call (valid
     // until that call returns).  An implementation that stages its inputs anyway hands out that staging (the HIP stages: pinned memory,
     // uploaded with one copy when the arrays of the call lie inside it); the default is a plain vector.  nullptr = allocation failed.
@@ -145,6 +173,11 @@ struct Stages {
                              const uint8_t *obs_desc, const uint8_t *obs_has_desc, int frame_kf,
                              int num_keypoints_3d, int n_local, const int *local, float max_proj_err, float dist_ratio,
                              int *match_of_mp) = 0;
+
+    // The same call on the records.  Default: flatten the rows' records (observing keyframes that exist and hold the keypoint; the
+    // descriptor an observation's keyframe contributed, from the default medoid tables) and call match_to_map -- the GPU-less harness;
+    // the HIP stages gather the records on the device instead and never build the flat map.
+    virtual int match_to_map_rec(const MatchJob &job, int *match_of_mp);
 
     // the solve inside Optimizer::localBA (optimizer.cpp:251-262, anchored inverse depth); see alva_local_ba
     virtual int local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_anchor_kf, const double *pt_anchor_uv,
@@ -193,6 +226,7 @@ struct Stages {
 
 protected:
     std::vector<alva_medoid::Table> med_tables_;   // (default medoid_* only)
+    std::vector<std::unique_ptr<MpRec[]>> arena_;  // (default mp_arena_chunk only)
     std::vector<uint8_t> scratch_;
     int det_cell_ = 0, det_n_occ_ = 0, det_cap_ = 0;
     std::vector<float> det_occ_;

@@ -190,3 +190,53 @@ int Stages::track_pose_collect(TrackPose &out) {  // visual_frontend.cpp:245-417
 }
 
 }  // namespace alva_slam
+
+namespace alva_slam {
+
+// Mapper::matchToMap on the records, default: the flat map of match_to_map built from the rows' records (the HIP stages do not run this)
+int Stages::match_to_map_rec(const MatchJob &J, int *match_of_mp) {
+    std::vector<int> kf_index;
+    int max_kf = -1;
+    for (int i = 0; i < J.n_kf; i++) max_kf = J.kf_ids[i] > max_kf ? J.kf_ids[i] : max_kf;
+    kf_index.assign((size_t) max_kf + 2, -1);
+    for (int i = 0; i < J.n_kf; i++) kf_index[(size_t) J.kf_ids[i]] = i;
+    if (J.frame_kfid < 0 || J.frame_kfid > max_kf || kf_index[(size_t) J.frame_kfid] < 0) return -1;
+    std::vector<double> wpt((size_t) J.n_mp * 3);
+    std::vector<uint8_t> is3d((size_t) J.n_mp), has_desc((size_t) J.n_mp), obs_hd, obs_desc;
+    std::vector<int> obs_ptr((size_t) J.n_mp + 1), obs_kf;
+    std::vector<float> obs_px;
+    static const alva_medoid::Table fresh = [] { alva_medoid::Table t{}; alva_medoid::reset(t); return t; }();
+    for (int m = 0; m < J.n_mp; m++) {
+        const int slot = J.mp_slot[m];
+        const MpRec &r = arena_[(size_t) slot >> MP_CHUNK_SHIFT][(size_t) (slot & (MP_CHUNK - 1))];
+        const alva_medoid::Table &t = (size_t) slot < med_tables_.size() ? med_tables_[(size_t) slot] : fresh;
+        std::memcpy(&wpt[3 * (size_t) m], r.X, 24);
+        is3d[(size_t) m] = r.is3d;
+        has_desc[(size_t) m] = r.has_desc;
+        obs_ptr[(size_t) m] = (int) obs_kf.size();
+        for (int e = 0; e < r.n_ent; e++) {
+            const ObsEnt &en = r.ent[e];
+            if (!(en.flags & MPF_OBS) || !(en.flags & MPF_INKF)) continue;
+            if (en.kf < 0 || en.kf > max_kf || kf_index[(size_t) en.kf] < 0) continue;
+            obs_kf.push_back(kf_index[(size_t) en.kf]);
+            obs_px.push_back(en.px[0]);
+            obs_px.push_back(en.px[1]);
+            // keyframes in which the keypoint could not be described (within 31 px of the border, feature_extractor.cpp:191-209) have no
+            // entry in mapKeyframeDescriptors_: slot zeroed and flagged
+            const int ds = alva_medoid::find_slot(t, en.kf);
+            const size_t at = obs_desc.size();
+            obs_desc.resize(at + 32, 0);
+            if (ds != alva_medoid::END) std::memcpy(&obs_desc[at], t.slot[ds].desc, 32);
+            obs_hd.push_back(ds != alva_medoid::END ? 1 : 0);
+        }
+    }
+    obs_ptr[(size_t) J.n_mp] = (int) obs_kf.size();
+    if (obs_kf.empty()) {   // (the arrays must not be null)
+        obs_kf.push_back(0); obs_px.resize(2, 0.f); obs_desc.resize(32, 0); obs_hd.push_back(0);
+    }
+    return match_to_map(J.cell_size, J.num_cells_w, J.grid_cells, J.cell_ptr, J.cell_mp, J.n_kf, J.kf_q, J.kf_t, J.n_mp, wpt.data(), is3d.data(),
+                        has_desc.data(), obs_ptr.data(), obs_kf.data(), obs_px.data(), obs_desc.data(), obs_hd.data(), kf_index[(size_t) J.frame_kfid],
+                        J.num_keypoints_3d, J.n_local, J.local, J.max_proj_err, J.dist_ratio, match_of_mp);
+}
+
+}  // namespace alva_slam

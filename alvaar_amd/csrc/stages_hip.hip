@@ -370,6 +370,10 @@ struct HipStages::Impl {
     hipEvent_t upload_done = nullptr;
     double max_quality = 0.001;  // state.hpp:57; lives as long as the reference's FeatureExtractor object (system.cpp:31)
     Arena dev, pin;
+    // the map layer's record arena (slam/mp_rec.hpp): chunks of pinned host memory + the device-resident table of their addresses
+    std::vector<MpRec *> rec_chunks;
+    const MpRec **d_rec_tab = nullptr;
+    static constexpr int REC_TAB_CAP = 4096;   // 16.7 M map points
     // the fused tracking step: persistent device / pinned blocks (grown when the keypoint count outgrows them)
     Arena trk_dev, trk_pin;
     int trk_cap = 0;
@@ -498,6 +502,8 @@ HipStages::~HipStages() {
     m->trk_dev.release();
     m->trk_pin.release();
     alva_medoid_store_destroy(m->med);
+    for (MpRec *c: m->rec_chunks) (void) hipHostFree(c);
+    if (m->d_rec_tab) (void) hipFree(m->d_rec_tab);
     alva_ctx_destroy(m->ctx);
     delete m;
 }
@@ -1395,6 +1401,68 @@ int HipStages::match_to_map(int cell_size, int num_cells_w, int grid_cells, cons
     DOWN(im, (size_t) n_mp * 4);
     ALVA_HIP(alva_stream_sync(m->st));
     memcpy(match_of_mp, h[im], (size_t) n_mp * 4);
+    return ALVA_OK;
+}
+
+// The record arena: pinned, zero-filled, never moved.  The kernels find a record through the device-resident table of chunk addresses.
+MpRec *HipStages::mp_arena_chunk(int chunk) {
+    if (chunk < 0 || chunk >= Impl::REC_TAB_CAP) return nullptr;
+    if (hipSetDevice(m->device) != hipSuccess) return nullptr;
+    if (!m->d_rec_tab) {
+        if (hipMalloc((void **) &m->d_rec_tab, (size_t) Impl::REC_TAB_CAP * sizeof(void *)) != hipSuccess) return nullptr;
+        if (hipMemset(m->d_rec_tab, 0, (size_t) Impl::REC_TAB_CAP * sizeof(void *)) != hipSuccess) return nullptr;
+    }
+    while ((int) m->rec_chunks.size() <= chunk) {
+        MpRec *c = nullptr;
+        if (hipHostMalloc((void **) &c, (size_t) MP_CHUNK * sizeof(MpRec), hipHostMallocDefault) != hipSuccess) return nullptr;
+        memset(c, 0, (size_t) MP_CHUNK * sizeof(MpRec));
+        const MpRec *cc = c;
+        // (rare: once per 4096 map points) a blocking 8-byte copy: the kernels of later calls read the entry
+        if (hipMemcpy(m->d_rec_tab + m->rec_chunks.size(), &cc, sizeof(cc), hipMemcpyHostToDevice) != hipSuccess) {
+            (void) hipHostFree(c);
+            return nullptr;
+        }
+        m->rec_chunks.push_back(c);
+    }
+    return m->rec_chunks[(size_t) chunk];
+}
+
+// Mapper::matchToMap on the records: the job's own arrays (cells, keyframe table, row slots, local list) lie in stage_scratch() and go
+// up with ONE copy; the map itself is gathered by the kernels (alva_match_to_map_records)
+int HipStages::match_to_map_rec(const MatchJob &J, int *match_of_mp) {
+    if (J.n_mp <= 0) return ALVA_OK;
+    if (!m->med || !alva_medoid_tables(m->med) || !m->d_rec_tab) return ALVA_ERR_STATE;   // (map points exist => their tables were replayed)
+    int frame_kf = -1;
+    for (int i = 0; i < J.n_kf; i++)
+        if (J.kf_ids[i] == J.frame_kfid) frame_kf = i;
+    if (frame_kf < 0) return ALVA_ERR_ARG;
+    const int n_cell = J.cell_ptr[J.grid_cells];
+    const Camera &k = m->cam;
+    const double calib[10] = {k.fx, k.fy, k.cx, k.cy, k.k1, k.k2, k.p1, k.p2, (double) k.width, (double) k.height};
+    const uint8_t *pb = m->pin.base, *pe = pb ? pb + m->pin.cap : nullptr;
+    const uint8_t *ptrs[] = {(const uint8_t *) J.cell_ptr, (const uint8_t *) J.cell_mp, (const uint8_t *) J.kf_ids, (const uint8_t *) J.kf_q,
+                             (const uint8_t *) J.kf_t, (const uint8_t *) J.mp_slot, (const uint8_t *) J.local, (const uint8_t *) match_of_mp};
+    const size_t lens[] = {(size_t) (J.grid_cells + 1) * 4, (size_t) n_cell * 4, (size_t) J.n_kf * 4, (size_t) J.n_kf * 32, (size_t) J.n_kf * 24,
+                           (size_t) J.n_mp * 4, (size_t) J.n_local * 4, (size_t) J.n_mp * 4};
+    size_t lo = (size_t) -1, hi = 0;
+    for (int i = 0; i < 8; i++) {
+        if (lens[i] == 0) continue;
+        if (!pb || ptrs[i] < pb || ptrs[i] + lens[i] > pe) return ALVA_ERR_ARG;   // the map layer assembles the job in stage_scratch()
+        if (i < 7) {
+            lo = std::min(lo, (size_t) (ptrs[i] - pb));
+            hi = std::max(hi, (size_t) (ptrs[i] - pb) + lens[i]);
+        }
+    }
+    if (m->dev.cap < m->pin.cap) return ALVA_ERR_STATE;
+    auto dv = [&](const void *hp) { return m->dev.base + ((const uint8_t *) hp - pb); };
+    ALVA_HIP(hipMemcpyAsync(m->dev.base + lo, pb + lo, hi - lo, hipMemcpyHostToDevice, m->st));
+    const int rc = alva_match_to_map_records(m->ctx, calib, J.cell_size, J.num_cells_w, J.grid_cells, (const int *) dv(J.cell_ptr), (const int *) dv(J.cell_mp),
+                                             J.n_kf, (const int *) dv(J.kf_ids), (const double *) dv(J.kf_q), (const double *) dv(J.kf_t), frame_kf,
+                                             J.frame_kfid, J.n_mp, (const int *) dv(J.mp_slot), (const void *const *) m->d_rec_tab,
+                                             alva_medoid_tables(m->med), J.num_keypoints_3d, J.n_local, (const int *) dv(J.local), J.max_proj_err,
+                                             J.dist_ratio, match_of_mp);   // (pinned, written once per entry by the last kernel: no copy back)
+    if (rc) return rc;
+    ALVA_HIP(alva_stream_sync(m->st));
     return ALVA_OK;
 }
 

@@ -45,6 +45,8 @@ public:
                      const double *kf_t, int n_mp, const double *mp_wpt, const uint8_t *mp_is3d, const uint8_t *mp_has_desc, const int *obs_ptr,
                      const int *obs_kf, const float *obs_px, const uint8_t *obs_desc, const uint8_t *obs_has_desc, int frame_kf,
                      int num_keypoints_3d, int n_local, const int *local, float max_proj_err, float dist_ratio, int *match_of_mp) override;
+    int match_to_map_rec(const MatchJob &job, int *match_of_mp) override;
+    MpRec *mp_arena_chunk(int chunk) override;
     int local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_anchor_kf, const double *pt_anchor_uv,
                  double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters, double *chi2,
                  uint8_t *depth_pos) override;

@@ -241,7 +241,7 @@ extern "C" int alva_system_find_plane(alva_system *s, float *h_pose, int num_ite
         // MapManager::getCurrentFrameMapPoints (map_manager.cpp:340-357): observed 3-D map points, in the map's container order
         std::vector<double> pts;
         for (const auto &e: s->slam->map_points)
-            if (e.second->observed && e.second->is3d) pts.insert(pts.end(), e.second->X, e.second->X + 3);
+            if (e.second->r->observed && e.second->r->is3d) pts.insert(pts.end(), e.second->r->X, e.second->r->X + 3);
         double pose7[7];
         se3_to_pose7(s->slam->cur->Twc, pose7);
         int found = 0;
@@ -317,8 +317,8 @@ extern "C" int alva_system_merge_map_points(alva_system *s, int prev_id, int new
         if (ia == S.map_points.end() || ib == S.map_points.end() || prev_id == new_id) return 0;
         const std::shared_ptr<MapPt> a = ia->second, b = ib->second;
         if (S.cur->observes(prev_id) && S.cur->observes(new_id)) return 0;
-        for (int kf: a->obs_kfs)
-            if (b->obs_kfs.count(kf)) return 0;
+        for (int kf: a->observers())
+            if (b->obs_has(kf)) return 0;
         const long before = s->slam->n_merges;
         s->slam->merge_map_points(prev_id, new_id);
         return s->slam->n_merges > before ? 1 : 0;   // 0: the reference's early return (a point is gone, or the survivor is not 3-D)

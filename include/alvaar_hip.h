@@ -330,6 +330,22 @@ int alva_match_to_map_flags(alva_ctx *ctx, const double *h_calib10, int cell_siz
                             int frame_kf, int num_keypoints_3d, int n_local, const int *d_local, float max_proj_err, float dist_ratio,
                             int *d_match_of_mp);
 
+/* The same call on the map layer's RECORDS instead of a flattened map (round 5; csrc/slam/mp_rec.hpp states the layout: one
+ * 1024-byte record per map point -- worldPoint_, is3d_, !desc_.empty(), and per keyframe an entry {keyframe id, flags
+ * observed-by / holds-the-keypoint / has-a-descriptor, the keypoint's px_ and unpx_ in that keyframe}, i.e.
+ * MapPoint::observedKeyframeIds_ + what Frame::getKeypointById returns for it (src/slam/src/mapper.cpp:487-515) -- in chunks of
+ * 4096 records of PINNED host memory that the host edits in place).  The caller names one record slot per table row
+ * (d_mp_slot); a gather kernel reads the rows' records out of host memory (d_record_chunks: device-readable table of the chunks'
+ * addresses), keeps the observations whose keyframe is listed in d_kf_ids (ascending ids; d_kf_q / d_kf_t their T_cw;
+ * frame_kf_index / frame_kf_id name the keyframe being matched) and holds the keypoint, and takes the descriptors from the
+ * device-resident descriptor tables of the same slots (d_desc_tables = alva_medoid_tables(): mapKeyframeDescriptors_, what
+ * MapPoint::computeMinDescDist iterates, map_point.cpp:206-222).  Grid, local list, thresholds and output as above.  Enqueue only. */
+int alva_match_to_map_records(alva_ctx *ctx, const double *h_calib10, int cell_size, int num_cells_w, int grid_cells,
+                              const int *d_cell_ptr, const int *d_cell_mp, int n_kf, const int *d_kf_ids, const double *d_kf_q,
+                              const double *d_kf_t, int frame_kf_index, int frame_kf_id, int n_mp, const int *d_mp_slot,
+                              const void *const *d_record_chunks, const void *d_desc_tables, int num_keypoints_3d, int n_local,
+                              const int *d_local, float max_proj_err, float dist_ratio, int *d_match_of_mp);
+
 /* ---- f4b: lens distortion paths of CameraCalibration --------------------------------------
  * alva_undistort_points replaces CameraCalibration::undistortImagePoint (src/slam/src/camera_calibration.cpp:56-72) =
  * cv::undistortPoints(pts, out, K, D, R = K) with D = (k1, k2, p1, p2), 5 fixed iterations
@@ -508,6 +524,9 @@ void alva_medoid_store_destroy(alva_medoid_store *store);
 int alva_medoid_replay(alva_medoid_store *store, int n_ops, const void *ops, int n_mp, const int *mp_slot, const int *first_op, int slots);
 int alva_medoid_export(alva_medoid_store *store, int n, const int *mp_slot, uint8_t *h_desc32, uint8_t *h_valid, int *h_info3);
 int alva_medoid_dump(alva_medoid_store *store, int mp_slot, void *h_table, size_t bytes);
+/* the device array of tables (valid until the next alva_medoid_replay grows it; NULL before the first replay): kernels that read the
+ * descriptors in place (alva_match_to_map_records) */
+const void *alva_medoid_tables(alva_medoid_store *store);
 
 /* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
  * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist

@@ -84,3 +84,68 @@ def test_hip_equals_oracle_full_size(ctx, n, seed, kw):
                            len(pb["kf_id"]) - 1, pb["num_kp3d"], d(local)).cpu().numpy()
     got = {int(pb["mp_id"][m]): int(pb["mp_id"][out[m]]) for m in range(len(out)) if out[m] >= 0}
     assert got == exp and len(exp) > 500
+
+
+def _records_of(pb, shuffle_seed):
+    """The flat synthetic map as map-point RECORDS (csrc/slam/mp_rec.hpp) in pinned chunks + the operations that fill the descriptor
+    tables: row m -> a record slot chosen by a permutation (slots are recycled in the product: rows and slots do not coincide), an entry
+    per observation {keyframe id, observed | holds-the-keypoint | has-a-descriptor, px}, plus -- like a live map has them -- entries the
+    gather must drop: an observer keyframe that is not in the keyframe table, and an entry without the holds-the-keypoint flag."""
+    import torch
+    from alvaar_amd.capi import Context
+    dt = Context.mp_record_dtype()
+    n_mp = len(pb["mp_id"])
+    rng = np.random.RandomState(shuffle_seed)
+    n_slots = n_mp + 500
+    slot_of = rng.permutation(n_slots)[:n_mp].astype(np.int32)
+    n_chunks = (n_slots + 4095) // 4096
+    chunks = [torch.zeros(4096 * dt.itemsize, dtype=torch.uint8).pin_memory() for _ in range(n_chunks)]
+    views = [c.numpy().view(dt) for c in chunks]
+    ops = []
+    kf_id = pb["kf_id"]
+    for m in range(n_mp):
+        s = int(slot_of[m])
+        r = views[s >> 12][s & 4095]
+        r["X"], r["id"], r["is3d"], r["observed"], r["dev_slot"], r["inv_depth"] = pb["mp_wpt"][m], pb["mp_id"][m], pb["mp_is3d"][m], 1, s, -1.0
+        a, b = int(pb["obs_ptr"][m]), int(pb["obs_ptr"][m + 1])
+        ents = [(int(kf_id[pb["obs_kf"][o]]), 7, pb["obs_px"][o]) for o in range(a, b)]
+        if m % 7 == 0:
+            ents.append((3, 1 | 2 | 4, np.array([5.0, 5.0], np.float32)))          # keyframe 3 is not in the table (ids start at 10)
+        if m % 11 == 0:   # observed-by without a keypoint, in a keyframe of the table that does not observe the point otherwise
+            free = [int(k) for k in kf_id[:-1] if int(k) not in {e[0] for e in ents}]
+            if free:
+                ents.append((free[0], 1, np.array([9.0, 9.0], np.float32)))
+        ents.sort(key=lambda e: e[0])
+        r["n_ent"], r["n_obs"], r["has_desc"] = len(ents), len(ents), 1 if b > a else 0
+        for i, (kf, fl, px) in enumerate(ents):
+            r["ent"][i]["kf"], r["ent"][i]["flags"], r["ent"][i]["px"] = kf, fl, px
+        ops.append((s, 3, -1, None, 0))
+        for o in range(a, b):
+            ops.append((s, 0, int(kf_id[pb["obs_kf"][o]]), pb["obs_desc"][o], 0))
+    table = torch.tensor([c.data_ptr() for c in chunks], dtype=torch.int64).cuda()
+    return chunks, table, slot_of, ops, n_slots
+
+
+@pytest.mark.gpu
+def test_hip_record_form_equals_oracle_and_golden(ctx):
+    """alva_match_to_map_records -- the form the System uses since round 5: records gathered out of pinned host memory, descriptors read
+    from the device-resident tables -- on the golden problems and on a full-size one: the same matches as the oracle / the reference."""
+    import torch
+    from alvaar_amd.capi import MedoidStore
+    problems = [(pb, aux, exp) for pb, aux, exp in _golden()]
+    big = synth.make_match_to_map_problem(4000, 7)
+    aux_big = py_match_to_map_aux(big)
+    problems.append((big, aux_big, orc_match_to_map(big, aux_big)))
+    for k, (pb, aux, exp) in enumerate(problems):
+        cell_mp, local = flatten_match_to_map(pb, aux)
+        chunks, table, slot_of, ops, n_slots = _records_of(pb, 100 + k)
+        store = MedoidStore(ctx)
+        store.replay(ops, n_slots)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        out = ctx.match_to_map_records(pb["calib"], pb["cell_size"], aux["num_cells_w"], aux["grid_cells"], d(np.asarray(aux["cell_ptr"], np.int32)), d(cell_mp),
+                                       d(np.asarray(pb["kf_id"], np.int32)), d(aux["kf_q"]), d(aux["kf_t"]), len(pb["kf_id"]) - 1, d(slot_of), table, store,
+                                       pb["num_kp3d"], d(local)).cpu().numpy()
+        got = {int(pb["mp_id"][m]): int(pb["mp_id"][out[m]]) for m in range(len(out)) if out[m] >= 0}
+        assert got == exp, f"problem {k}"
+        store.close()
+        del chunks
