@@ -277,6 +277,32 @@ class Context:
                                 C.byref(ok)))
         return dict(ok=bool(ok.value), poses=poses, pts=pts, chi2=chi2[:nobs], depth=depth[:nobs], info=info)
 
+    def local_ba_csr(self, pb, max_iters=5, ftol=0.0, huber_chi2=5.9915, chi2_threshold=5.9915):
+        """alva_local_ba_csr: the same solve for observations grouped by point (the problem dict's observations are stably sorted by
+        point here); the sweep's test per residual block comes back as booleans in the SORTED order, `order` maps back."""
+        import numpy as np
+        poses = np.ascontiguousarray(pb["poses"], np.float64).copy()
+        kfc = np.ascontiguousarray(pb["kf_const"], np.uint8)
+        calib = np.ascontiguousarray(pb["calib"], np.float64)
+        akf = np.ascontiguousarray(pb["anchor_kf"], np.int32)
+        auv = np.ascontiguousarray(pb["anchor_uv"], np.float64)
+        pts = np.ascontiguousarray(pb["inv_depth"], np.float64).copy()
+        opt0 = np.asarray(pb["obs_pt"], np.int64)
+        order = np.argsort(opt0, kind="stable")
+        okf = np.ascontiguousarray(np.asarray(pb["obs_kf"], np.int32)[order])
+        ouv = np.ascontiguousarray(np.asarray(pb["obs_uv"], np.float64)[order])
+        nobs, npt = len(okf), len(akf)
+        ptr = np.zeros(npt + 1, np.int32)
+        np.cumsum(np.bincount(opt0, minlength=npt), out=ptr[1:])
+        bits = np.zeros((nobs + 63) // 64 + 1, np.uint64)
+        nbad, ok, info = C.c_int(0), C.c_int(0), np.zeros(9)
+        lib.alva_local_ba_csr.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp, _vp]
+        check(lib.alva_local_ba_csr(self.h, len(poses), poses.ctypes.data, kfc.ctypes.data, calib.ctypes.data, npt, ptr.ctypes.data, akf.ctypes.data,
+                                    auv.ctypes.data, pts.ctypes.data, nobs, okf.ctypes.data, ouv.ctypes.data, max_iters, ftol, huber_chi2,
+                                    chi2_threshold, bits.ctypes.data, C.byref(nbad), info.ctypes.data, C.byref(ok)))
+        bad = np.unpackbits(bits.view(np.uint8), bitorder="little")[:nobs].astype(bool)
+        return dict(ok=bool(ok.value), poses=poses, pts=pts, bad=bad, n_bad=nbad.value, order=order, info=info)
+
     def local_ba_batch(self, pbs, max_iters=5, ftol=0.0, huber_chi2=5.9915):
         """alva_local_ba_batch on a list of flat problem dicts (anchored inverse depth); returns one result dict per problem"""
         import numpy as np

@@ -904,6 +904,86 @@ __global__ void __launch_bounds__(256) k_results(BaResultsArgs R) {
     }
 }
 
+// ---- the (observing keyframe, anchor keyframe) grouping of the observations ON THE DEVICE (alva_local_ba_csr): a stable counting sort
+// over chunks of 256 observations -- per-chunk histograms, one scan, per-chunk scatter with the rank inside the chunk -- so that
+// pairPerm / pairPtr are exactly what BaHost::build's two host passes produce (ascending observation index inside a pair), and the host
+// never walks the observations for it
+constexpr int PAIR_CHUNK = 256;
+struct PairArgs {
+    const int *obsKf, *ptPtr, *ancKf;
+    int nObs, nPt, nKf, nChunks;
+    int *key;        // [nObs]
+    int *hist;       // [nChunks][nKf * nKf] -> exclusive bases
+    int *pairPtr;    // [nKf * nKf + 1]
+    int *pairPerm;   // [nObs]
+};
+__global__ void __launch_bounds__(PAIR_CHUNK) k_pair_hist(PairArgs A) {
+    extern __shared__ int s_hist[];
+    const int nPairs = A.nKf * A.nKf;
+    for (int i = threadIdx.x; i < nPairs; i += PAIR_CHUNK) s_hist[i] = 0;
+    __syncthreads();
+    const int q = blockIdx.x * PAIR_CHUNK + threadIdx.x;
+    if (q < A.nObs) {
+        int lo = 0, hi = A.nPt;   // the point of observation q: the last p with ptPtr[p] <= q
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (A.ptPtr[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        const int key = A.obsKf[q] * A.nKf + A.ancKf[lo];
+        A.key[q] = key;
+        atomicAdd(&s_hist[key], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nPairs; i += PAIR_CHUNK) A.hist[(size_t) blockIdx.x * nPairs + i] = s_hist[i];
+}
+__global__ void __launch_bounds__(1024) k_pair_scan(PairArgs A) {
+    __shared__ int s_tot[1024];
+    const int nPairs = A.nKf * A.nKf, k = threadIdx.x;
+    int tot = 0;
+    if (k < nPairs)
+        for (int c = 0; c < A.nChunks; c++) {
+            int *h = A.hist + (size_t) c * nPairs + k;
+            const int v = *h;
+            *h = tot;
+            tot += v;
+        }
+    s_tot[k] = k < nPairs ? tot : 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the per-key totals
+        const int v = k >= off ? s_tot[k - off] : 0;
+        __syncthreads();
+        s_tot[k] += v;
+        __syncthreads();
+    }
+    if (k < nPairs) {
+        const int base = s_tot[k] - tot;
+        A.pairPtr[k] = base;
+        if (k == nPairs - 1) A.pairPtr[nPairs] = s_tot[k];
+        for (int c = 0; c < A.nChunks; c++) A.hist[(size_t) c * nPairs + k] += base;
+    }
+}
+__global__ void __launch_bounds__(PAIR_CHUNK) k_pair_fill(PairArgs A) {
+    __shared__ int s_key[PAIR_CHUNK];
+    const int q = blockIdx.x * PAIR_CHUNK + threadIdx.x, nPairs = A.nKf * A.nKf;
+    const int key = q < A.nObs ? A.key[q] : -1;
+    s_key[threadIdx.x] = key;
+    __syncthreads();
+    if (q >= A.nObs) return;
+    int rank = 0;
+    for (int t = 0; t < (int) threadIdx.x; t++) rank += s_key[t] == key;
+    A.pairPerm[A.hist[(size_t) blockIdx.x * nPairs + key] + rank] = q;
+}
+// the outlier sweep's per-observation test (optimizer.cpp:266-309: chi2 above the threshold, or the point behind the camera) as a bit
+// per observation, so that the host reads 1 / 72 of the chi2 | depth block
+__global__ void __launch_bounds__(256) k_bad_bits(const double *__restrict__ chi2, const uint8_t *__restrict__ depth, int n, double threshold,
+                                                 unsigned long long *__restrict__ bits) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool bad = q < n && (chi2[q] > threshold || !depth[q]);
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && q < n) bits[q >> 6] = m;
+}
+
 template<typename T>
 T *carve(uint8_t *&cur, size_t count) {
     T *p = reinterpret_cast<T *>(cur);
@@ -993,10 +1073,22 @@ struct BaIn {
     double huber_chi2;
 };
 
+// the same problem with the observations already grouped by point (alva_local_ba_csr): h_pt_ptr[n_pt + 1], observation arrays in that order
+struct BaCsr {
+    const int *h_pt_ptr;
+    double chi2_threshold;
+    unsigned long long *h_bad_bits;
+    int *h_n_bad;
+};
+
 struct BaHost {
     BaDev B{};
     std::vector<int> cidx, order;
     bool grouped_ = false;   // the caller's observations arrived grouped by point: `order` is the identity
+    bool csr_ = false;       // the pair grouping is built on the device (k_pair_*): its arrays lie behind the uploaded block
+    int *d_pairKey = nullptr, *d_pairHist = nullptr;
+    unsigned long long *d_badBits = nullptr;
+    int n_chunks = 0;
     int *d_obsKf = nullptr, *d_ptPtr = nullptr, *d_ancKf = nullptr, *d_cidx = nullptr, *d_pairPerm = nullptr, *d_pairPtr = nullptr, *d_kfOf = nullptr;
     double *d_obsUv = nullptr, *d_ancUv = nullptr, *d_xp = nullptr, *d_cp = nullptr, *d_xt = nullptr, *d_ct = nullptr;
     size_t in_bytes = 0, bytes = 0;
@@ -1008,11 +1100,19 @@ struct BaHost {
     bool need_restore = false, done = false;
     double *xp = nullptr, *xt = nullptr, *cp = nullptr, *ct = nullptr;
 
-    int sizes(const BaIn &in) {
+    int sizes(const BaIn &in, const BaCsr *csr = nullptr) {
         const int n_kf = in.n_kf, n_pt = in.n_pt, n_obs = in.n_obs, dp = in.inv_depth ? 1 : 3;
         cidx.assign((size_t) n_kf, -1);
         int nc = 0;
         for (int k = 0; k < n_kf; k++) cidx[(size_t) k] = in.h_kf_const[k] ? -1 : nc++;
+        csr_ = csr != nullptr;
+        if (csr) {
+            unsigned bad = 0;   // (branch-free passes: the arrays are the map layer's own, the check is the C ABI's)
+            for (int o = 0; o < n_obs; o++) bad |= (unsigned) in.h_obs_kf[o] >= (unsigned) n_kf;
+            for (int p2 = 0; p2 < n_pt; p2++) bad |= (unsigned) in.h_pt_anchor_kf[p2] >= (unsigned) n_kf || csr->h_pt_ptr[p2] > csr->h_pt_ptr[p2 + 1];
+            ALVA_ARG(!bad && csr->h_pt_ptr[0] == 0 && csr->h_pt_ptr[n_pt] == n_obs && n_kf <= 32);
+            n_chunks = (n_obs + PAIR_CHUNK - 1) / PAIR_CHUNK;
+        } else
         for (int o = 0; o < n_obs; o++) ALVA_ARG(in.h_obs_kf[o] >= 0 && in.h_obs_kf[o] < n_kf && in.h_obs_pt[o] >= 0 && in.h_obs_pt[o] < n_pt);
         B.nKf = n_kf; B.nPt = n_pt; B.nObs = n_obs; B.inv = in.inv_depth; B.dp = dp; B.nc = nc; B.n6 = 6 * nc;
         B.NP = (B.n6 + 1 + 15) / 16 * 16;
@@ -1038,11 +1138,20 @@ struct BaHost {
         d_ancUv = carve<double>(cur, nPt * 2);
         d_cidx = carve<int>(cur, n_kf);
         d_kfOf = carve<int>(cur, n_kf);
-        d_pairPerm = carve<int>(cur, nObs);
-        d_pairPtr = carve<int>(cur, n_kf * n_kf + 1);
+        if (!csr_) {
+            d_pairPerm = carve<int>(cur, nObs);
+            d_pairPtr = carve<int>(cur, n_kf * n_kf + 1);
+        }
         d_xp = carve<double>(cur, n_kf * 7);
         d_xt = carve<double>(cur, npd);
         in_bytes = (size_t) (cur - base);
+        if (csr_) {
+            d_pairPerm = carve<int>(cur, nObs);
+            d_pairPtr = carve<int>(cur, n_kf * n_kf + 1);
+            d_pairKey = carve<int>(cur, nObs);
+            d_pairHist = carve<int>(cur, (size_t) n_chunks * n_kf * n_kf);
+            d_badBits = carve<unsigned long long>(cur, nObs / 64 + 2);
+        }
         B.chi2 = carve<double>(cur, nObs);   // results the host reads back: chi2 | depth flags, contiguous
         B.depth = carve<uint8_t>(cur, nObs);
         B.Jobs = carve<double>(cur, nObs * 12);
@@ -1142,6 +1251,53 @@ struct BaHost {
         xp = d_xp; xt = d_xt; cp = d_cp; ct = d_ct;
         return ALVA_OK;
     }
+    // the same for observations that arrive grouped by point with their ptPtr (alva_local_ba_csr): the input arrays are copied as they
+    // are; the pair grouping is left to the device (enqueue_pairs, behind the upload)
+    int build_csr(const BaIn &in, const BaCsr &csr, uint8_t *base, uint8_t *stage) {
+        const int n_kf = in.n_kf, n_pt = in.n_pt, n_obs = in.n_obs;
+        const size_t nPt = (size_t) n_pt, npd = (size_t) B.npd;
+        layout(stage);
+        int *h_obsKf = d_obsKf, *h_ptPtr = d_ptPtr, *h_ancKf = d_ancKf, *h_cidx = d_cidx, *h_kfOf = d_kfOf;
+        double *h_obsUv = d_obsUv, *h_ancUv = d_ancUv, *h_xp = d_xp, *h_xt = d_xt;
+        layout(base);
+        B.obsKf = d_obsKf; B.obsUv = d_obsUv; B.ptPtr = d_ptPtr; B.ancKf = d_ancKf; B.ancUv = d_ancUv; B.cidx = d_cidx; B.kfOf = d_kfOf;
+        B.pairPerm = d_pairPerm; B.pairPtr = d_pairPtr;
+        grouped_ = true;
+        if (n_obs) {
+            memcpy(h_obsKf, in.h_obs_kf, (size_t) n_obs * 4);
+            memcpy(h_obsUv, in.h_obs_uv, (size_t) n_obs * 16);
+        }
+        memcpy(h_ptPtr, csr.h_pt_ptr, (nPt + 1) * 4);
+        if (n_pt > 0) {
+            memcpy(h_ancKf, in.h_pt_anchor_kf, nPt * 4);
+            memcpy(h_ancUv, in.h_pt_anchor_uv, nPt * 16);
+        }
+        for (int k = 0; k < n_kf; k++) {
+            h_cidx[k] = cidx[(size_t) k];
+            h_kfOf[k] = 0;
+        }
+        for (int k = 0; k < n_kf; k++)
+            if (cidx[(size_t) k] >= 0) h_kfOf[cidx[(size_t) k]] = k;
+        for (int k = 0; k < n_kf; k++) {
+            Se3 T;
+            se3_from_pose7(in.h_poses + 7 * k, T);
+            for (int i = 0; i < 3; i++) h_xp[7 * (size_t) k + i] = T.t[i];
+            for (int i = 0; i < 4; i++) h_xp[7 * (size_t) k + 3 + i] = T.q[i];
+        }
+        if (npd) memcpy(h_xt, in.h_pt_param, npd * 8);
+        xp = d_xp; xt = d_xt; cp = d_cp; ct = d_ct;
+        return ALVA_OK;
+    }
+    void enqueue_pairs(hipStream_t st) {
+        if (B.nObs <= 0) {
+            (void) hipMemsetAsync(d_pairPtr, 0, ((size_t) B.nKf * B.nKf + 1) * 4, st);
+            return;
+        }
+        PairArgs A{d_obsKf, d_ptPtr, d_ancKf, B.nObs, B.nPt, B.nKf, n_chunks, d_pairKey, d_pairHist, d_pairPtr, d_pairPerm};
+        hipLaunchKernelGGL(k_pair_hist, dim3((unsigned) n_chunks), dim3(PAIR_CHUNK), (size_t) B.nKf * B.nKf * 4, st, A);
+        hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, A);
+        hipLaunchKernelGGL(k_pair_fill, dim3((unsigned) n_chunks), dim3(PAIR_CHUNK), 0, st, A);
+    }
     // Ceres' accept / reject logic on the scalars of the candidate's evaluation (trust_region_minimizer.cc:461-490, :781-829);
     // returns true when the minimiser stops
     bool advance(const double *scal, double function_tolerance) {
@@ -1206,21 +1362,16 @@ struct BaHost {
 
 }  // namespace
 
-extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib, int inv_depth,
-                             int n_pt, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv, double *h_pt_param, int n_obs,
-                             const int *h_obs_kf, const int *h_obs_pt, const double *h_obs_uv, int max_iters,
-                             double function_tolerance, double huber_chi2, double *h_chi2, uint8_t *h_depth_pos, double *h_info,
-                             int *h_ok) {
-    ALVA_ARG(ctx && h_poses && h_kf_const && h_calib && h_pt_param && h_ok && n_kf > 0 && n_pt >= 0 && n_obs >= 0 && max_iters >= 0);
-    ALVA_ARG(n_obs == 0 || (h_obs_kf && h_obs_pt && h_obs_uv));
-    ALVA_ARG(!inv_depth || n_pt == 0 || (h_pt_anchor_kf && h_pt_anchor_uv));
+// one solve: `csr` null = alva_local_ba (observations in any order, the structure built on the host, chi2 / depth flags returned);
+// non-null = alva_local_ba_csr (observations grouped by point, the pair grouping built on the device, the sweep's flags returned as bits)
+static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_iters, double function_tolerance, double *h_chi2,
+                    uint8_t *h_depth_pos, double *h_info, int *h_ok) {
+    const int n_kf = in.n_kf, n_pt = in.n_pt, n_obs = in.n_obs, inv_depth = in.inv_depth;
     *h_ok = 1;
     if (h_info) memset(h_info, 0, 4 * sizeof(double));
     const auto t_begin = std::chrono::steady_clock::now();
-    const BaIn in{n_kf, h_poses, h_kf_const, h_calib, inv_depth, n_pt, h_pt_anchor_kf, h_pt_anchor_uv, h_pt_param, n_obs, h_obs_kf, h_obs_pt, h_obs_uv,
-                  huber_chi2};
     BaHost H;
-    int rc = H.sizes(in);
+    int rc = H.sizes(in, csr);
     if (rc) return rc;
     BaDev &B = H.B;
     const int dp = B.dp;
@@ -1238,10 +1389,11 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     const auto t_sized = std::chrono::steady_clock::now();
     ALVA_HIP(alva_stream_sync(st));  // nothing enqueued earlier may still be reading the staging area
     const auto t_synced = std::chrono::steady_clock::now();
-    rc = H.build(in, base, stage);
+    rc = csr ? H.build_csr(in, *csr, base, stage) : H.build(in, base, stage);
     if (rc) return rc;
     const auto t_built = std::chrono::steady_clock::now();
     ALVA_HIP(hipMemcpyAsync(base, stage, H.in_bytes, hipMemcpyHostToDevice, st));   // ONE upload from pinned memory
+    if (csr) H.enqueue_pairs(st);
     // Wt: the sparsity pattern is fixed, zero once; Zt: the K padding rows stay zero -- neighbours in the layout, one fill
     ALVA_HIP(hipMemsetAsync(B.Wt, 0, (size_t) ((uint8_t *) B.Zt - (uint8_t *) B.Wt) + (size_t) B.kpad * NP * 8, st));
     const auto t_up = std::chrono::steady_clock::now();
@@ -1344,13 +1496,18 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
     // reference's outlier sweep reads from its cost-function objects, optimizer.cpp:266-309)
     // the input staging area is free again (its upload finished long ago): results land there, three DMA copies
     uint8_t *r_chi = stage;
-    const size_t chi_bytes = H.chi_bytes();
+    const size_t bad_words = csr ? (nObs + 63) / 64 : 0;
+    if (csr && n_obs) {
+        hipLaunchKernelGGL(k_bad_bits, dim3((unsigned) alva_divup(n_obs, 256)), dim3(256), 0, st, (const double *) B.chi2, (const uint8_t *) B.depth, n_obs,
+                           csr->chi2_threshold, H.d_badBits);
+    }
+    const size_t chi_bytes = csr ? bad_words * 8 : H.chi_bytes();
     double *r_poses = reinterpret_cast<double *>(stage + (chi_bytes + 255) / 256 * 256);
     double *r_pts = r_poses + (size_t) n_kf * 7 + 32;
     if (poll) {
         // (chi_bytes, the pose block and the point block are multiples of 8 bytes or are rounded up inside their 256-byte carved slots)
         BaResultsArgs R{};
-        R.src[0] = reinterpret_cast<const unsigned long long *>(B.chi2); R.dst[0] = reinterpret_cast<unsigned long long *>(r_chi);
+        R.src[0] = csr ? H.d_badBits : reinterpret_cast<const unsigned long long *>(B.chi2); R.dst[0] = reinterpret_cast<unsigned long long *>(r_chi);
         R.words[0] = n_obs ? (chi_bytes + 7) / 8 : 0;
         R.src[1] = reinterpret_cast<const unsigned long long *>(H.xp); R.dst[1] = reinterpret_cast<unsigned long long *>(r_poses);
         R.words[1] = (size_t) n_kf * 7;
@@ -1375,11 +1532,32 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {
-        if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, B.chi2, chi_bytes, hipMemcpyDeviceToHost, st));
+        if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, csr ? (const void *) H.d_badBits : (const void *) B.chi2, chi_bytes, hipMemcpyDeviceToHost, st));
         ALVA_HIP(hipMemcpyAsync(r_poses, H.xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
         if (npd) ALVA_HIP(hipMemcpyAsync(r_pts, H.xt, npd * 8, hipMemcpyDeviceToHost, st));
         ALVA_HIP(alva_stream_sync(st));
     }
+    if (csr) {
+        // poses / point parameters as finish() returns them; the sweep's flags as bits
+        if (npd) memcpy(in.h_pt_param, r_pts, npd * 8);
+        for (int k = 0; k < n_kf; k++)
+            if (H.cidx[(size_t) k] >= 0) memcpy(in.h_poses + 7 * k, r_poses + 7 * (size_t) k, 56);
+        int n_bad = 0;
+        const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(r_chi);
+        for (size_t w = 0; w < bad_words; w++) {
+            unsigned long long v = bits[w];
+            if (w == bad_words - 1 && (nObs & 63)) v &= (1ull << (nObs & 63)) - 1ull;
+            csr->h_bad_bits[w] = v;
+            n_bad += __builtin_popcountll(v);
+        }
+        if (csr->h_n_bad) *csr->h_n_bad = n_bad;
+        if (h_info) {
+            h_info[0] = H.nsummaries;
+            h_info[1] = H.initial;
+            h_info[2] = H.x_cost;
+            h_info[3] = H.nsucc;
+        }
+    } else
     H.finish(in, r_chi, r_poses, r_pts, h_chi2, h_depth_pos, h_info);
     if (getenv("ALVA_BA_TIMING")) {
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -1390,6 +1568,32 @@ extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uin
                 us(t_lm, std::chrono::steady_clock::now()));
     }
     return ALVA_OK;
+}
+
+extern "C" int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib, int inv_depth,
+                             int n_pt, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv, double *h_pt_param, int n_obs,
+                             const int *h_obs_kf, const int *h_obs_pt, const double *h_obs_uv, int max_iters,
+                             double function_tolerance, double huber_chi2, double *h_chi2, uint8_t *h_depth_pos, double *h_info,
+                             int *h_ok) {
+    ALVA_ARG(ctx && h_poses && h_kf_const && h_calib && h_pt_param && h_ok && n_kf > 0 && n_pt >= 0 && n_obs >= 0 && max_iters >= 0);
+    ALVA_ARG(n_obs == 0 || (h_obs_kf && h_obs_pt && h_obs_uv));
+    ALVA_ARG(!inv_depth || n_pt == 0 || (h_pt_anchor_kf && h_pt_anchor_uv));
+    const BaIn in{n_kf, h_poses, h_kf_const, h_calib, inv_depth, n_pt, h_pt_anchor_kf, h_pt_anchor_uv, h_pt_param, n_obs, h_obs_kf, h_obs_pt, h_obs_uv,
+                  huber_chi2};
+    return ba_drive(ctx, in, nullptr, max_iters, function_tolerance, h_chi2, h_depth_pos, h_info, h_ok);
+}
+
+extern "C" int alva_local_ba_csr(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib, int n_pt,
+                                 const int *h_pt_ptr, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv, double *h_pt_inv_depth, int n_obs,
+                                 const int *h_obs_kf, const double *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2,
+                                 double chi2_threshold, unsigned long long *h_bad_bits, int *h_n_bad, double *h_info, int *h_ok) {
+    ALVA_ARG(ctx && h_poses && h_kf_const && h_calib && h_pt_inv_depth && h_ok && h_pt_ptr && h_bad_bits && n_kf > 0 && n_pt >= 0 && n_obs >= 0 &&
+             max_iters >= 0);
+    ALVA_ARG(n_obs == 0 || (h_obs_kf && h_obs_uv));
+    ALVA_ARG(n_pt == 0 || (h_pt_anchor_kf && h_pt_anchor_uv));
+    const BaIn in{n_kf, h_poses, h_kf_const, h_calib, 1, n_pt, h_pt_anchor_kf, h_pt_anchor_uv, h_pt_inv_depth, n_obs, h_obs_kf, nullptr, h_obs_uv, huber_chi2};
+    const BaCsr csr{h_pt_ptr, chi2_threshold, h_bad_bits, h_n_bad};
+    return ba_drive(ctx, in, &csr, max_iters, function_tolerance, nullptr, nullptr, h_info, h_ok);
 }
 
 // `count` independent local-BA problems (anchored inverse depth) in ONE set of launches per LM iteration: a rig's cameras, or the

@@ -464,14 +464,23 @@ void Slam::local_ba(FrameRec &new_frame) {
     for (int id: touched_a_) mark_a_[(size_t) id] = 0;
     Lap fine;
     t_fine[6] += std::chrono::duration<double>(fine.t0 - lap_ba.t0).count();   // BA build phase 1: keyframes + points to optimise
-    // the problem's arrays live in a member (capacity persists from keyframe to keyframe: no allocator traffic, no first-touch faults)
-    typedef BaScratch::ObsRec ObsRec;
+    // The problem's arrays live in a member (capacity persists from keyframe to keyframe: no allocator traffic, no first-touch faults) and
+    // are written ONCE, in the form the solve consumes (Stages::local_ba_csr): residual blocks grouped by point behind a pt_ptr table,
+    // only points that have a residual block (Ceres drops parameter blocks that no residual block uses, program.cc RemoveFixedBlocks:
+    // an anchored point that nothing else observes keeps its inverse depth and is remembered in `lone`).  Round 4 pushed every observation
+    // through five vectors here, copied the live ones into a second set per round and the stage sorted / copied them a third time.
     BaScratch &bs = ba_scratch_;
-    std::vector<int> &pt_ids = bs.pt_ids, &pt_anchor_slot = bs.pt_anchor_slot, &obs_kf = bs.obs_kf, &obs_pt = bs.obs_pt;
-    std::vector<double> &pt_anchor_uv = bs.pt_anchor_uv, &pt_inv = bs.pt_inv, &obs_uv = bs.obs_uv;
-    std::vector<ObsRec> &obs_rec = bs.obs_rec;
-    pt_ids.clear(); pt_anchor_slot.clear(); obs_kf.clear(); obs_pt.clear(); pt_anchor_uv.clear(); pt_inv.clear(); obs_uv.clear(); obs_rec.clear();
-    // map_id_invptspar_ is only looked up by id: a persistent id -> slot table (mp_index_, all -1 between calls, see match_to_map)
+    std::vector<int> &pt_ids = bs.pt_ids, &anc_slot = bs.pt_anchor_slot, &obs_kf = bs.obs_kf, &pt_ptr = bs.pt_ptr, &lone_ids = bs.lone_ids,
+                     &slot_ids = bs.slot_ids;
+    std::vector<double> &anc_uv = bs.pt_anchor_uv, &pinv = bs.pt_inv, &obs_uv = bs.obs_uv, &lone_inv = bs.lone_inv;
+    const size_t max_pts = mps_to_opt.size();
+    pt_ids.resize(max_pts); anc_slot.resize(max_pts); anc_uv.resize(2 * max_pts); pinv.resize(max_pts); pt_ptr.resize(max_pts + 1);
+    lone_ids.clear(); lone_inv.clear(); slot_ids.clear();
+    size_t obs_cap = std::max<size_t>(obs_kf.size(), 8 * max_pts + 64);
+    obs_kf.resize(obs_cap); obs_uv.resize(2 * obs_cap);
+    int n_used = 0, n_obs = 0;
+    // map_id_invptspar_ is only looked up by id: a persistent id -> slot table (mp_index_, all -1 between calls, see match_to_map):
+    // j >= 0 = the point's row in the solve, -2 - i = lone point i
     std::vector<int> &pt_slot = mp_index_;
     if (pt_slot.size() < (size_t) next_mp_id + 1) pt_slot.resize((size_t) next_mp_id + 1 + (size_t) next_mp_id / 2, -1);
     struct ResetSlots {
@@ -480,7 +489,9 @@ void Slam::local_ba(FrameRec &new_frame) {
         ~ResetSlots() {
             for (int id: ids) index[(size_t) id] = -1;
         }
-    } reset_slots{pt_slot, pt_ids};
+    } reset_slots{pt_slot, slot_ids};
+    std::vector<uint8_t> &kf_used = bs.kf_used;
+    kf_used.assign(64, 0);
     ids_scratch_.clear();
     for (int id: mps_to_opt) ids_scratch_.push_back(id);   // the set's order, as an array (for the prefetcher; the loop below does not edit the set)
     for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
@@ -493,7 +504,13 @@ void Slam::local_ba(FrameRec &new_frame) {
             continue;
         }
         local_mps.insert_slot(lmid, mp);
-        int anchor = -1, cur_slot = -1;
+        if ((size_t) n_obs + MP_ENT_CAP > obs_cap) {
+            obs_cap *= 2;
+            obs_kf.resize(obs_cap);
+            obs_uv.resize(2 * obs_cap);
+        }
+        int anchor = -1;
+        const int q0 = n_obs;
         const ObsList obs = mp->observers();  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
         const MpRec &rec = *mp->r;
         int si = 0;   // walks the record's entries (sorted by keyframe like obs) beside the observers; a repair below edits them: start over
@@ -523,28 +540,38 @@ void Slam::local_ba(FrameRec &new_frame) {
                 si = 0;
                 continue;
             }
+            const int ps = pose_slot[(size_t) kfid];
             if (anchor < 0) {  // the first observing keyframe anchors the inverse depth; it gets no residual (:186-201)
                 anchor = kfid;
                 double pc[3];
                 se3_apply(kf->Tcw, rec.X, pc);
-                cur_slot = (int) pt_ids.size();
-                pt_slot[(size_t) lmid] = cur_slot;
-                pt_ids.push_back(lmid);
-                pt_anchor_slot.push_back(pose_slot[(size_t) kfid]);
-                pt_anchor_uv.push_back((double) kp->unpx[0]);
-                pt_anchor_uv.push_back((double) kp->unpx[1]);
-                pt_inv.push_back(1. / pc[2]);  // InvDepthParametersBlock(id, anchor, zanch) stores 1 / zanch
+                anc_slot[(size_t) n_used] = ps;
+                anc_uv[2 * (size_t) n_used] = (double) kp->unpx[0];
+                anc_uv[2 * (size_t) n_used + 1] = (double) kp->unpx[1];
+                pinv[(size_t) n_used] = 1. / pc[2];  // InvDepthParametersBlock(id, anchor, zanch) stores 1 / zanch
                 continue;
             }
-            obs_kf.push_back(pose_slot[(size_t) kfid]);
-            obs_pt.push_back(cur_slot);
-            obs_uv.push_back((double) kp->unpx[0]);
-            obs_uv.push_back((double) kp->unpx[1]);
-            obs_rec.push_back(ObsRec{kfid, lmid});
+            obs_kf[(size_t) n_obs] = ps;
+            obs_uv[2 * (size_t) n_obs] = (double) kp->unpx[0];
+            obs_uv[2 * (size_t) n_obs + 1] = (double) kp->unpx[1];
+            n_obs++;
         }
+        if (anchor < 0) continue;
+        slot_ids.push_back(lmid);
+        if (n_obs == q0) {   // anchored, no residual block: not a parameter of the solve
+            pt_slot[(size_t) lmid] = -2 - (int) lone_ids.size();
+            lone_ids.push_back(lmid);
+            lone_inv.push_back(pinv[(size_t) n_used]);
+            continue;
+        }
+        pt_slot[(size_t) lmid] = n_used;
+        pt_ids[(size_t) n_used] = lmid;
+        pt_ptr[(size_t) n_used] = q0;
+        n_used++;
     }
+    pt_ptr[(size_t) n_used] = n_obs;
     fine(t_fine[7]);   // BA build phase 2: observations
-    t_fine[23] += (double) pt_ids.size(); t_fine[24] += (double) obs_rec.size(); t_fine[25] += (double) kf_const.size();
+    t_fine[23] += (double) (n_used + (int) lone_ids.size()); t_fine[24] += (double) n_obs; t_fine[25] += (double) kf_const.size();
     // gauge: at least two constant keyframes (:234-247), taken in the container's order
     size_t n_const = const_kfs.size();
     if (n_const < 2) {
@@ -557,74 +584,83 @@ void Slam::local_ba(FrameRec &new_frame) {
     lap_ba(t_kf[11]);
     // ---- 2. solve (:251-262) and 3./4. outlier sweep + second solve without the flagged residuals (:266-359; the loss is never
     //         reset to L2 there because vright_reprojerr_kfid_lmid stays empty, :315-318)
-    const int n_kf = (int) kf_const.size(), n_pt = (int) pt_ids.size();
+    const int n_kf = (int) kf_const.size();
+    if (n_kf > 64) {
+        fail(-1);
+        return;
+    }
+    std::vector<int> &slot_kfid = bs.slot_kfid;   // pose slot -> keyframe id
+    slot_kfid.assign((size_t) n_kf, -1);
+    for (const auto &e: local_kfs) slot_kfid[(size_t) pose_slot[(size_t) e.first]] = e.first;
     std::vector<std::pair<int, int>> bad_obs;  // (keyframe, map point)
-    std::vector<uint8_t> &alive = bs.alive;
-    alive.assign(obs_rec.size(), 1);
-    bool any_bad = false;
-    for (int round = 0; round < 2; round++) {
-        std::vector<int> &sel = bs.sel;
-        sel.clear();
-        for (size_t o = 0; o < obs_rec.size(); o++)
-            if (alive[o]) sel.push_back((int) o);
-        const int n_obs = (int) sel.size();
-        // Ceres drops parameter blocks that no residual block uses (program.cc: RemoveFixedBlocks); the stage gets the same reduced
-        // problem: only points with a live residual, and a free keyframe without residuals is passed as constant
-        std::vector<int> &pt_of = bs.pt_of, &pts_used = bs.pts_used, &okf = bs.okf, &opt = bs.opt;
-        std::vector<uint8_t> &kf_used = bs.kf_used, &kc = bs.kc, &dpos = bs.dpos;
-        std::vector<double> &ouv = bs.ouv, &chi2 = bs.chi2;
-        pt_of.assign((size_t) n_pt, -1);
-        pts_used.clear();
+    std::vector<uint64_t> &bits = bs.bad_bits;
+    std::vector<uint8_t> &kc = bs.kc;
+    // a free keyframe without residual blocks is passed as constant (Ceres would drop its parameter block)
+    auto run_round = [&](int np, const int *ptr, const int *aslot, const double *auv, double *inv, int no, const int *okf, const double *ouv,
+                         const int *ids) -> int {
         kf_used.assign((size_t) n_kf, 0);
+        for (int q = 0; q < no; q++) kf_used[(size_t) okf[q]] = 1;
+        for (int j = 0; j < np; j++) kf_used[(size_t) aslot[j]] = 1;
         kc = kf_const;
-        okf.resize((size_t) n_obs); opt.resize((size_t) n_obs); ouv.resize((size_t) n_obs * 2); chi2.resize((size_t) n_obs); dpos.resize((size_t) n_obs);
-        for (int i = 0; i < n_obs; i++) {
-            const int o = sel[(size_t) i], p = obs_pt[(size_t) o];
-            if (pt_of[(size_t) p] < 0) {
-                pt_of[(size_t) p] = (int) pts_used.size();
-                pts_used.push_back(p);
-            }
-            okf[(size_t) i] = obs_kf[(size_t) o];
-            opt[(size_t) i] = pt_of[(size_t) p];
-            ouv[2 * (size_t) i] = obs_uv[2 * (size_t) o];
-            ouv[2 * (size_t) i + 1] = obs_uv[2 * (size_t) o + 1];
-            kf_used[(size_t) obs_kf[(size_t) o]] = 1;
-            kf_used[(size_t) pt_anchor_slot[(size_t) p]] = 1;
-        }
         for (int k = 0; k < n_kf; k++)
             if (!kf_used[(size_t) k]) kc[(size_t) k] = 1;
-        const int n_used = (int) pts_used.size();
-        std::vector<int> &pa = bs.pa;
-        std::vector<double> &pauv = bs.pauv, &pinv = bs.pinv;
-        pa.resize((size_t) n_used); pauv.resize((size_t) n_used * 2); pinv.resize((size_t) n_used);
-        for (int j = 0; j < n_used; j++) {
-            const int p = pts_used[(size_t) j];
-            pa[(size_t) j] = pt_anchor_slot[(size_t) p];
-            pauv[2 * (size_t) j] = pt_anchor_uv[2 * (size_t) p];
-            pauv[2 * (size_t) j + 1] = pt_anchor_uv[2 * (size_t) p + 1];
-            pinv[(size_t) j] = pt_inv[(size_t) p];
-        }
-        if (n_obs > 0) {
+        bits.assign((size_t) no / 64 + 2, 0);
+        int n_bad = 0;
+        if (no > 0) {
             Lap lap;
-            if (fail(st->local_ba(n_kf, poses.data(), kc.data(), n_used, pa.data(), pauv.data(), pinv.data(), n_obs, okf.data(), opt.data(),
-                                  ouv.data(), 5, chi2.data(), dpos.data())))
-                return;
+            if (fail(st->local_ba_csr(n_kf, poses.data(), kc.data(), np, ptr, aslot, auv, inv, no, okf, ouv, 5, (double) cfg.robust_threshold, bits.data(),
+                                      &n_bad)))
+                return -1;
             lap(t_kf[10]);
-            for (int j = 0; j < n_used; j++) pt_inv[(size_t) pts_used[(size_t) j]] = pinv[(size_t) j];
         }
         n_ba_runs++;
-        size_t n_bad = 0;
-        for (int i = 0; i < n_obs; i++) {
-            if (chi2[(size_t) i] > (double) cfg.robust_threshold || !dpos[(size_t) i]) {
-                const ObsRec &r = obs_rec[(size_t) sel[(size_t) i]];
-                alive[(size_t) sel[(size_t) i]] = 0;
-                bad_obs.emplace_back(r.kfid, r.mpid);
-                bad_mps.insert(r.mpid);
-                n_bad++;
+        // the flagged residual blocks, in residual order: (keyframe id, map point id)
+        int j = 0;
+        for (size_t w = 0; w * 64 < (size_t) no; w++) {
+            uint64_t v = bits[w];
+            while (v) {
+                const int q = (int) (w * 64) + __builtin_ctzll(v);
+                v &= v - 1;
+                while (ptr[j + 1] <= q) j++;
+                bad_obs.emplace_back(slot_kfid[(size_t) okf[q]], ids[j]);
+                bad_mps.insert(ids[j]);
             }
         }
-        if (round == 0) any_bad = n_bad > 0;
-        if (!(cfg.refine_with_l2 && any_bad)) break;
+        return n_bad;
+    };
+    const int n_bad0 = run_round(n_used, pt_ptr.data(), anc_slot.data(), anc_uv.data(), pinv.data(), n_obs, obs_kf.data(), obs_uv.data(), pt_ids.data());
+    if (n_bad0 < 0) return;
+    if (cfg.refine_with_l2 && n_bad0 > 0) {
+        // the second round's problem: the first one without the flagged residual blocks (and without the points that lose their last one)
+        std::vector<int> &ptr2 = bs.ptr2, &as2 = bs.as2, &okf2 = bs.okf2, &ids2 = bs.ids2, &from2 = bs.from2;
+        std::vector<double> &auv2 = bs.auv2, &inv2 = bs.inv2, &ouv2 = bs.ouv2;
+        ptr2.resize((size_t) n_used + 1); as2.resize((size_t) n_used); ids2.resize((size_t) n_used); from2.resize((size_t) n_used);
+        auv2.resize(2 * (size_t) n_used); inv2.resize((size_t) n_used); okf2.resize((size_t) n_obs); ouv2.resize(2 * (size_t) n_obs);
+        const std::vector<uint64_t> bits0 = bits;
+        int np2 = 0, no2 = 0;
+        for (int j = 0; j < n_used; j++) {
+            const int q0 = no2;
+            for (int q = pt_ptr[(size_t) j]; q < pt_ptr[(size_t) j + 1]; q++) {
+                if ((bits0[(size_t) q >> 6] >> (q & 63)) & 1) continue;
+                okf2[(size_t) no2] = obs_kf[(size_t) q];
+                ouv2[2 * (size_t) no2] = obs_uv[2 * (size_t) q];
+                ouv2[2 * (size_t) no2 + 1] = obs_uv[2 * (size_t) q + 1];
+                no2++;
+            }
+            if (no2 == q0) continue;
+            ptr2[(size_t) np2] = q0;
+            as2[(size_t) np2] = anc_slot[(size_t) j];
+            auv2[2 * (size_t) np2] = anc_uv[2 * (size_t) j];
+            auv2[2 * (size_t) np2 + 1] = anc_uv[2 * (size_t) j + 1];
+            inv2[(size_t) np2] = pinv[(size_t) j];
+            ids2[(size_t) np2] = pt_ids[(size_t) j];
+            from2[(size_t) np2] = j;
+            np2++;
+        }
+        ptr2[(size_t) np2] = no2;
+        if (run_round(np2, ptr2.data(), as2.data(), auv2.data(), inv2.data(), no2, okf2.data(), ouv2.data(), ids2.data()) < 0) return;
+        if (no2 > 0)
+            for (int j2 = 0; j2 < np2; j2++) pinv[(size_t) from2[(size_t) j2]] = inv2[(size_t) j2];
     }
     lap_ba(t_kf[12]);
     // ---- 5. write-back (:363-530)
@@ -659,11 +695,11 @@ void Slam::local_ba(FrameRec &new_frame) {
             }
         }
         const int ps = pt_slot[(size_t) lmid];
-        if (ps < 0) {
+        if (ps == -1) {
             bad_mps.insert(lmid);
             continue;
         }
-        const double inv = pt_inv[(size_t) ps], zanch = 1. / inv;
+        const double inv = ps >= 0 ? pinv[(size_t) ps] : lone_inv[(size_t) (-2 - ps)], zanch = 1. / inv;
         if (zanch <= 0.) {
             remove_map_point(lmid);
             bad_mps.erase(lmid);

@@ -524,13 +524,10 @@ private:
     bool check_obs_mirror_ = false;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
     struct BaScratch {   // local_ba's problem arrays (see there)
-        struct ObsRec {
-            int kfid, mpid;
-        };
-        std::vector<int> pt_ids, pt_anchor_slot, obs_kf, obs_pt, sel, pt_of, pts_used, okf, opt, pa;
-        std::vector<double> pt_anchor_uv, pt_inv, obs_uv, ouv, chi2, pauv, pinv;
-        std::vector<ObsRec> obs_rec;
-        std::vector<uint8_t> alive, kf_used, kc, dpos;
+        std::vector<int> pt_ids, pt_anchor_slot, obs_kf, pt_ptr, lone_ids, slot_ids, slot_kfid, ptr2, as2, okf2, ids2, from2;
+        std::vector<double> pt_anchor_uv, pt_inv, obs_uv, lone_inv, auv2, inv2, ouv2;
+        std::vector<uint64_t> bad_bits;
+        std::vector<uint8_t> kf_used, kc;
         FlatHash<MapPt *> local_mps;
         FlatSet mps_to_opt;
     } ba_scratch_;

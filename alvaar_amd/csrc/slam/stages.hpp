@@ -184,6 +184,32 @@ struct Stages {
                          double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters,
                          double *chi2, uint8_t *depth_pos) = 0;
 
+    // The same solve for residual blocks GROUPED BY POINT (the map layer emits them that way): pt_ptr[n_pt + 1] delimits each point's
+    // blocks in obs_kf / obs_uv; every point has at least one.  The outlier sweep's test (optimizer.cpp:266-309: chi2 > chi2_threshold or
+    // the point behind the camera) comes back as one bit per residual block (bad_bits: n_obs / 64 + 1 words) + their count.  Default:
+    // local_ba() on the expanded arrays (the GPU-less harness); the HIP stages run alva_local_ba_csr.
+    virtual int local_ba_csr(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_ptr, const int *pt_anchor_kf,
+                             const double *pt_anchor_uv, double *pt_inv_depth, int n_obs, const int *obs_kf, const double *obs_uv, int max_iters,
+                             double chi2_threshold, uint64_t *bad_bits, int *n_bad) {
+        std::vector<int> obs_pt((size_t) n_obs);
+        for (int p = 0; p < n_pt; p++)
+            for (int q = pt_ptr[p]; q < pt_ptr[p + 1]; q++) obs_pt[(size_t) q] = p;
+        std::vector<double> chi2((size_t) n_obs);
+        std::vector<uint8_t> dpos((size_t) n_obs);
+        const int rc = local_ba(n_kf, poses7, kf_const, n_pt, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_pt.data(), obs_uv, max_iters,
+                                chi2.data(), dpos.data());
+        if (rc) return rc;
+        int nb = 0;
+        for (int w = 0; w < n_obs / 64 + 1; w++) bad_bits[w] = 0;
+        for (int q = 0; q < n_obs; q++)
+            if (chi2[(size_t) q] > chi2_threshold || !dpos[(size_t) q]) {
+                bad_bits[q >> 6] |= 1ull << (q & 63);
+                nb++;
+            }
+        *n_bad = nb;
+        return 0;
+    }
+
     // MapPoint's descriptor tables and medoids (map_point.cpp:73-181; medoid_table.hpp) as a replayed operation log: the map layer keeps
     // only the KEY sets of the tables (its control flow needs nothing else) and logs every edit -- addDesc, the descriptor half of
     // removeObservedKeyframeId, the release when the last observation goes, a new map point -- per map point SLOT (slots are recycled;

@@ -1478,6 +1478,22 @@ int HipStages::local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n
                          max_iters, 0.001, (double) 5.9915f, chi2, depth_pos, info, &ok);
 }
 
+int HipStages::local_ba_csr(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_ptr, const int *pt_anchor_kf,
+                            const double *pt_anchor_uv, double *pt_inv_depth, int n_obs, const int *obs_kf, const double *obs_uv, int max_iters,
+                            double chi2_threshold, uint64_t *bad_bits, int *n_bad) {
+    const Camera &k = m->cam;
+    const double calib[4] = {k.fx, k.fy, k.cx, k.cy};
+    double info[4];
+    int ok = 0;
+    if (n_kf > 32) {   // (the device-side pair grouping is sized for the mapper's window; larger problems take the host-structured solve)
+        return Stages::local_ba_csr(n_kf, poses7, kf_const, n_pt, pt_ptr, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_uv, max_iters,
+                                    chi2_threshold, bad_bits, n_bad);
+    }
+    // optimizer.cpp:251-262: function tolerance 1e-3, Huber on sqrt(robustCostThreshold_) -- a float in the reference (:8, :22)
+    return alva_local_ba_csr(m->ctx, n_kf, poses7, kf_const, calib, n_pt, pt_ptr, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_uv,
+                             max_iters, 0.001, (double) 5.9915f, chi2_threshold, (unsigned long long *) bad_bits, n_bad, info, &ok);
+}
+
 // f1: the map points' descriptor tables live on the device (medoid.hip); the replay is enqueued behind the keyframe's other work on the
 // session's stream and nothing waits for it -- only an export does
 int HipStages::medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) {

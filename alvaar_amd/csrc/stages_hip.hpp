@@ -50,6 +50,9 @@ public:
     int local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_anchor_kf, const double *pt_anchor_uv,
                  double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters, double *chi2,
                  uint8_t *depth_pos) override;
+    int local_ba_csr(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_ptr, const int *pt_anchor_kf,
+                     const double *pt_anchor_uv, double *pt_inv_depth, int n_obs, const int *obs_kf, const double *obs_uv, int max_iters,
+                     double chi2_threshold, uint64_t *bad_bits, int *n_bad) override;
     int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) override;
     uint8_t *stage_scratch(size_t bytes) override;
     int medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) override;

@@ -480,6 +480,18 @@ int alva_local_ba(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_
                   const double *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2,
                   double *h_chi2, uint8_t *h_depth_pos, double *h_info, int *h_ok);
 
+/* The same solve for a caller that holds its observations GROUPED BY POINT (round 5: the map layer's localBA build emits them that
+ * way): h_pt_ptr[n_pt + 1] delimits each point's residual blocks in h_obs_kf / h_obs_uv (anchored inverse depth only).  The
+ * (observing keyframe, anchor keyframe) grouping that the camera-block assembly needs is built on the DEVICE (a stable counting
+ * sort, identical to the host-built one: results are bit-identical to alva_local_ba on the same problem), and the outlier sweep's
+ * test of Optimizer::localBA (src/slam/src/optimizer.cpp:266-309: chi2 > chi2_threshold, or the point behind the camera) comes back as
+ * one BIT per residual block (h_bad_bits: (n_obs + 63) / 64 words; *h_n_bad their count) instead of the chi2 / depth arrays.
+ * n_kf <= 32.  Synchronous. */
+int alva_local_ba_csr(alva_ctx *ctx, int n_kf, double *h_poses, const uint8_t *h_kf_const, const double *h_calib, int n_pt,
+                      const int *h_pt_ptr, const int *h_pt_anchor_kf, const double *h_pt_anchor_uv, double *h_pt_inv_depth, int n_obs,
+                      const int *h_obs_kf, const double *h_obs_uv, int max_iters, double function_tolerance, double huber_chi2,
+                      double chi2_threshold, unsigned long long *h_bad_bits, int *h_n_bad, double *h_info, int *h_ok);
+
 /* `count` independent local-BA problems (anchored inverse depth) with ONE set of launches per LM iteration: a rig's cameras or a
  * server's sessions, each with its own keyframes / points / observations (ragged sizes).  Every kernel carries the problem in a grid
  * dimension -- the reduced camera systems are factored on `count` compute units at once, the Schur-complement GEMMs form one grouped

@@ -80,3 +80,25 @@ def test_local_ba_batch_bitwise_equal_to_single_solves(ctx, sizes):
             stops.add(int(a["info"][0]))
         if len(sizes) > 8 and ftol > 0:
             assert len(stops) > 1     # the batch really is ragged in iterations too
+
+
+@pytest.mark.parametrize("nkf,npt,seed,iters,ftol", [(6, 200, 1, 5, 0.0), (20, 3000, 42, 5, 0.0), (14, 1500, 9, 5, 1e-3), (3, 10, 4, 5, 0.0), (31, 900, 12, 3, 0.0)])
+def test_local_ba_csr_bitwise_equal_to_the_host_structured_solve(ctx, nkf, npt, seed, iters, ftol):
+    """alva_local_ba_csr -- observations grouped by point, the (observing, anchor) pair grouping built by the device's stable counting
+    sort, the outlier sweep's test returned as one bit per residual block -- against alva_local_ba on the same problem: poses and point
+    parameters BIT-IDENTICAL, iteration counts equal, the bits == (chi2 > threshold or point behind the camera) of the host-structured
+    solve."""
+    pb = dict(synth.make_ba_problem(nkf, npt, seed))
+    rng = np.random.RandomState(seed)
+    # outliers, so that the sweep has something to flag
+    bad_obs = rng.choice(len(pb["obs_kf"]), max(2, len(pb["obs_kf"]) // 200), replace=False)
+    uv = pb["obs_uv"].copy()
+    uv[bad_obs] += rng.uniform(4, 9, (len(bad_obs), 2))
+    pb["obs_uv"] = uv
+    a = ctx.local_ba(pb, iters, ftol)
+    b = ctx.local_ba_csr(pb, iters, ftol, chi2_threshold=5.9915)
+    assert a["ok"] == b["ok"] and list(a["info"][:4]) == list(b["info"][:4])
+    assert np.array_equal(a["poses"].view(np.uint64), b["poses"].view(np.uint64))
+    assert np.array_equal(a["pts"].view(np.uint64), b["pts"].view(np.uint64))
+    want = (a["chi2"] > 5.9915) | (a["depth"] == 0)
+    assert np.array_equal(b["bad"], want[b["order"]]) and b["n_bad"] == int(want.sum()) and b["n_bad"] >= 1
