@@ -44,7 +44,8 @@ def build(verbose: bool = False) -> Path:
             if s.suffix == ".cpp":
                 # -mpopcnt: the descriptor medoids are popcount loops (every x86-64 CPU since 2008 has the instruction; without the flag
                 # __builtin_popcountll is a bit-twiddling sequence)
-                jobs.append([HIPCC, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mpopcnt", "-Wall", "-c", str(s), "-o", str(o)])
+                # -gline-tables-only: line numbers for tools/host_profile_gpu.py's sampled stacks (same code)
+                jobs.append([HIPCC, "-x", "c++", "-O2", "-gline-tables-only", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mpopcnt", "-Wall", "-c", str(s), "-o", str(o)])
             else:
                 jobs.append([HIPCC, *FLAGS, "-c", str(s), "-o", str(o)])
 

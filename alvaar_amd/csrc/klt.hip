@@ -1281,10 +1281,12 @@ int alva_track_slots_klt(alva_ctx *ctx, const alva_pyramid *prev, const alva_pyr
     epsilon *= epsilon;
     const dim3 grid(8 * alva_divup(D.n, 8));
     if (!retry) {
-        const size_t n = (size_t) D.n, quads = (n * 8 + 15) / 16 + (n + 15) / 16 + (n * 24 + 15) / 16;
-        const unsigned g_in = (unsigned) ((quads + 255) / 256);
-        const bool in_lane = alva_lane_defer(MK_STAGE_IN, ctx, g_in, 0, &D, sizeof(D));
-        if (!in_lane) hipLaunchKernelGGL(k_track_stage_in, dim3(g_in), dim3(256), 0, ctx->stream, D);
+        if (D.in_px) {   // a slot table in pinned host memory: one coalesced pass copies it (null: the host wrote it into d_pts / d_is3d / d_wpt)
+            const size_t n = (size_t) D.n, quads = (n * 8 + 15) / 16 + (n + 15) / 16 + (n * 24 + 15) / 16;
+            const unsigned g_in = (unsigned) ((quads + 255) / 256);
+            const bool in_lane = alva_lane_defer(MK_STAGE_IN, ctx, g_in, 0, &D, sizeof(D));
+            if (!in_lane) hipLaunchKernelGGL(k_track_stage_in, dim3(g_in), dim3(256), 0, ctx->stream, D);
+        }
         const TrackKltArgs KA{P, C, D, lp, lf, maxCount, err_thresh, fb_dist, epsilon};
         if (alva_lane_defer(MK_TRACK_KLT, ctx, (unsigned) (8 * alva_divup(alva_divup(D.n, lane_klt_slots_per_wave()), 8)), 0, &KA, sizeof(KA))) return ALVA_OK;
     }

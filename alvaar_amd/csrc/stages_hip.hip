@@ -376,6 +376,22 @@ struct HipStages::Impl {
     static constexpr int REC_TAB_CAP = 4096;   // 16.7 M map points
     // the fused tracking step: persistent device / pinned blocks (grown when the keypoint count outgrows them)
     Arena trk_dev, trk_pin;
+    uint8_t *trk_in = nullptr;   // see track_reserve
+    bool bar_table = true;       // ALVA_NO_BAR_TABLE=1: the pinned slot table + k_track_stage_in (A/B)
+    struct TrackIn {
+        float *px;
+        uint8_t *is3d;
+        double *wpt;
+    };
+    TrackIn track_in() const {
+        const size_t c = (size_t) trk_cap;
+        TrackIn T;
+        uint8_t *b = trk_in;
+        T.px = (float *) b; b += c * 8;
+        T.is3d = b; b += c + 256 - (c & 255);
+        T.wpt = (double *) b;
+        return T;
+    }
     int trk_cap = 0;
     bool fused = true;       // ALVA_TRACK_UNFUSED=1: compose the tracking step from the fine-grained stages instead (A/B testing)
     bool poll = true;        // wait for the tracking step by polling its completion word in pinned memory (ALVA_NO_POLL=1: stream synchronisation)
@@ -417,6 +433,24 @@ struct HipStages::Impl {
         if (rc) return rc;
         rc = trk_pin.grow(pin_bytes, st);
         if (rc) return rc;
+        // the slot table (positions | 3-D flags | world points) in DEVICE memory that the host writes directly: the whole of the device's
+        // memory is visible to the CPU (large BAR; tools/probes/bar_probe.cpp: 128 KB of ordinary stores in 2.6 us, write-combined and
+        // posted), so the map layer assembles the table where the tracker reads it and the copy kernel of rounds 2 - 4 (k_track_stage_in:
+        // 7 us + a launch gap in front of every frame's tracker) is gone.  Uncached on the device side: an L2 must not answer with last
+        // frame's line.  The host never READS this memory (a load over the bus costs ~1 us).
+        if (trk_in) {
+            ALVA_HIP(alva_stream_sync(st));
+            ALVA_HIP(hipFree(trk_in));
+            trk_in = nullptr;
+        }
+        if (bar_table) {
+            const size_t in_bytes = c * 8 + c + 256 + c * 24;
+            if (hipExtMallocWithFlags((void **) &trk_in, in_bytes, hipDeviceMallocUncached) != hipSuccess) {
+                (void) hipGetLastError();
+                trk_in = nullptr;
+                bar_table = false;   // no such memory here: the pinned table + the copy kernel
+            }
+        }
         trk_cap = cap;
         ALVA_HIP(hipMemsetAsync(trk_dev.base, 0, 1024, st));  // the slot-wise step's counters start at zero
         // fresh (or recycled) pinned memory: the completion word must not equal a sequence number the host is about to wait for.  The
@@ -501,6 +535,7 @@ HipStages::~HipStages() {
     m->pin.release();
     m->trk_dev.release();
     m->trk_pin.release();
+    if (m->trk_in) (void) hipFree(m->trk_in);
     alva_medoid_store_destroy(m->med);
     for (MpRec *c: m->rec_chunks) (void) hipHostFree(c);
     if (m->d_rec_tab) (void) hipFree(m->d_rec_tab);
@@ -517,6 +552,7 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
     m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
     m->poll = getenv("ALVA_NO_POLL") == nullptr;
+    m->bar_table = getenv("ALVA_NO_BAR_TABLE") == nullptr;
     int rc = hip_stream ? alva_ctx_create(device, hip_stream, 0, &m->ctx) : alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -839,7 +875,26 @@ void HipStages::reset_images() {}  // the pyramids are rebuilt before they are r
 // after the map layer has done its tracker bookkeeping.  Inputs are read from and per-slot results written to pinned host memory
 // by the kernels themselves: no copy commands.
 int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
-    if (!m->fused || (job.want_pose && !job.do_p3p)) return Stages::track_begin(job, out);
+    if (!m->fused || (job.want_pose && !job.do_p3p)) {
+        if (m->trk_in && job.n > 0 && job.px == m->track_in().px) {
+            // the composed step READS the slot table on the host, and this one was written into device memory (track_slot_buffers): one
+            // copy back instead of a load over the bus per element (p3pEnabled_ off: not the shipped configuration)
+            static thread_local std::vector<uint8_t> back;
+            const size_t n = (size_t) job.n;
+            back.resize(n * 40);
+            ALVA_HIP(hipSetDevice(m->device));
+            __builtin_ia32_sfence();
+            ALVA_HIP(hipMemcpy(back.data(), job.px, n * 8, hipMemcpyDeviceToHost));
+            ALVA_HIP(hipMemcpy(back.data() + n * 8, job.wpt, n * 24, hipMemcpyDeviceToHost));
+            ALVA_HIP(hipMemcpy(back.data() + n * 32, job.is3d, n, hipMemcpyDeviceToHost));
+            TrackJob j2 = job;
+            j2.px = (const float *) back.data();
+            j2.wpt = (const double *) (back.data() + n * 8);
+            j2.is3d = back.data() + n * 32;
+            return Stages::track_begin(j2, out);
+        }
+        return Stages::track_begin(job, out);
+    }
     m->pose_pending = false;
     pending_.active = false;
     const int n = job.n;
@@ -855,8 +910,11 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     const size_t c = (size_t) m->trk_cap;
     const alva_pyramid *prev = m->pyr[m->prev], *cur = m->pyr[m->cur];
     const Camera &k = m->cam;
+    const bool in_device = m->bar_table && m->trk_in && !m->lists && job.px == m->track_in().px && job.is3d == m->track_in().is3d &&
+                           job.wpt == m->track_in().wpt;   // track_slot_buffers handed out the device table: it is written, never read here
     int n3d = 0;
-    for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
+    if (!in_device)
+        for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
     const uint8_t *o_code = nullptr;
     const float *o_px = nullptr, *o_unpx = nullptr;
     const double *o_bv = nullptr, *Pbv = nullptr, *Puv = nullptr, *Pwpt = nullptr;
@@ -866,7 +924,9 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     bool slots_path = false;
     const Impl::TrackPin pin = m->track_pin();
     const bool staged = job.px == pin.in_px && job.is3d == pin.in_is3d && job.wpt == pin.in_wpt;   // track_slot_buffers was used
-    if (!staged) {
+    if (in_device) {
+        __builtin_ia32_sfence();   // the table's write-combined stores leave the core before the launch's doorbell does
+    } else if (!staged) {
         memcpy(pin.in_px, job.px, (size_t) n * 8);
         memcpy(pin.in_is3d, job.is3d, (size_t) n);
         memcpy(pin.in_wpt, job.wpt, (size_t) n * 24);
@@ -888,6 +948,11 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.Puv = (double *) b; b += c * 16;
         D.Pwpt = (double *) b; b += c * 24;
         D.in_px = pin.in_px; D.in_is3d = pin.in_is3d; D.in_wpt = pin.in_wpt;
+        if (in_device) {   // the table is where the tracker reads it: no copy kernel (in_px == nullptr tells alva_track_slots_klt)
+            const Impl::TrackIn T = m->track_in();
+            D.d_pts = T.px; D.d_is3d = T.is3d; D.d_wpt = T.wpt;
+            D.in_px = nullptr; D.in_is3d = nullptr; D.in_wpt = nullptr;
+        }
         D.o_hdr = pin.o_hdr; D.o_code = pin.o_code; D.o_px = pin.o_px; D.o_unpx = pin.o_unpx; D.o_bv = pin.o_bv;
         D.n = n;
         D.use_prior = job.use_prior;
@@ -1069,6 +1134,13 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
 bool HipStages::track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) {
     if (!m->fused || n <= 0) return false;
     if (hipSetDevice(m->device) != hipSuccess || m->track_reserve(n) != ALVA_OK) return false;
+    if (m->bar_table && m->trk_in && !m->lists) {   // device memory, written in place (track_reserve)
+        const Impl::TrackIn T = m->track_in();
+        *px = T.px;
+        *is3d = T.is3d;
+        *wpt = T.wpt;
+        return true;
+    }
     const Impl::TrackPin pin = m->track_pin();
     *px = pin.in_px;
     *is3d = pin.in_is3d;
