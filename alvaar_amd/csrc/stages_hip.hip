@@ -366,6 +366,8 @@ struct HipStages::Impl {
     double *d_invK = nullptr;
     const uint8_t *registered = nullptr, *registered_dev = nullptr;  // caller buffer locked + mapped by register_frame_buffer
     size_t registered_bytes = 0;
+    uint8_t *bar_frame = nullptr;   // alloc_frame_buffer: the caller's frame buffer in device memory, written by the host over the BAR
+    size_t bar_frame_bytes = 0;
     bool upload_in_flight = false;
     hipEvent_t upload_done = nullptr;
     double max_quality = 0.001;  // state.hpp:57; lives as long as the reference's FeatureExtractor object (system.cpp:31)
@@ -376,6 +378,16 @@ struct HipStages::Impl {
     static constexpr int REC_TAB_CAP = 4096;   // 16.7 M map points
     // the fused tracking step: persistent device / pinned blocks (grown when the keypoint count outgrows them)
     Arena trk_dev, trk_pin;
+    // Device memory that the HOST is going to write over the BAR must not have a previous life left in an L2: the allocator recycles
+    // pages, and a line that an earlier owner's kernel wrote may still sit DIRTY in an L2 (device-local memory is only written back when
+    // the line is evicted) -- evicted later, it would overwrite what the host stored in the meantime (seen as a tracker reading last
+    // frame's slot table, once in a few hundred session starts).  One device-wide synchronisation behind a fill: its system-scope
+    // release writes every dirty line back; nothing on the device writes the block afterwards.
+    static hipError_t scrub_host_written(void *p, size_t bytes) {
+        hipError_t e = hipMemset(p, 0, bytes);
+        if (e != hipSuccess) return e;
+        return hipDeviceSynchronize();
+    }
     uint8_t *trk_in = nullptr;   // see track_reserve
     bool bar_table = true;       // ALVA_NO_BAR_TABLE=1: the pinned slot table + k_track_stage_in (A/B)
     struct TrackIn {
@@ -449,6 +461,8 @@ struct HipStages::Impl {
                 (void) hipGetLastError();
                 trk_in = nullptr;
                 bar_table = false;   // no such memory here: the pinned table + the copy kernel
+            } else {
+                ALVA_HIP(scrub_host_written(trk_in, in_bytes));
             }
         }
         trk_cap = cap;
@@ -536,6 +550,7 @@ HipStages::~HipStages() {
     m->trk_dev.release();
     m->trk_pin.release();
     if (m->trk_in) (void) hipFree(m->trk_in);
+    if (m->bar_frame) (void) hipFree(m->bar_frame);
     alva_medoid_store_destroy(m->med);
     for (MpRec *c: m->rec_chunks) (void) hipHostFree(c);
     if (m->d_rec_tab) (void) hipFree(m->d_rec_tab);
@@ -811,6 +826,28 @@ int HipStages::register_frame_buffer(const uint8_t *buf, size_t bytes) {
     return ALVA_OK;
 }
 
+int HipStages::alloc_frame_buffer(size_t bytes, uint8_t **h_writable) {
+    ALVA_HIP(hipSetDevice(m->device));
+    ALVA_ARG(h_writable && bytes >= (size_t) m->cam.width * m->cam.height * 4);
+    if (m->bar_frame) {
+        ALVA_HIP(alva_stream_sync(m->st));
+        ALVA_HIP(hipFree(m->bar_frame));
+        m->bar_frame = nullptr;
+        m->bar_frame_bytes = 0;
+    }
+    // uncached on the device side: every frame rewrites the buffer from the host, an L2 must not answer with the previous frame's line
+    if (hipExtMallocWithFlags((void **) &m->bar_frame, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void) hipGetLastError();
+        m->bar_frame = nullptr;
+        alva_set_error("alva_system_alloc_frame_buffer: no host-writable device memory on this system");
+        return ALVA_ERR_STATE;
+    }
+    ALVA_HIP(Impl::scrub_host_written(m->bar_frame, bytes));
+    m->bar_frame_bytes = bytes;
+    *h_writable = m->bar_frame;
+    return ALVA_OK;
+}
+
 int HipStages::unregister_frame_buffer() {
     if (!m->registered) return ALVA_OK;
     ALVA_HIP(hipSetDevice(m->device));
@@ -834,6 +871,15 @@ int HipStages::new_frame(const uint8_t *rgba) {
     } no_lane;
     const bool in_group = no_lane.saved != nullptr;
     const size_t bytes = (size_t) m->cam.width * m->cam.height * 4;
+    if (m->bar_frame && rgba >= m->bar_frame && rgba + bytes <= m->bar_frame + m->bar_frame_bytes && (((uintptr_t) rgba) & 15) == 0) {
+        // the caller stored the frame into device memory itself (alloc_frame_buffer): it IS a device frame; its write-combined stores
+        // leave the core before the launch's doorbell does
+        __builtin_ia32_sfence();
+        const int rc = build_from(rgba);
+        if (rc) return rc;
+        if (in_group) ALVA_HIP(alva_stream_sync(m->st));
+        return ALVA_OK;
+    }
     if (m->registered && rgba >= m->registered && rgba + bytes <= m->registered + m->registered_bytes && (((uintptr_t) rgba) & 15) == 0) {
         // zero-copy: the image kernels read the caller's pages; frame_done() waits for them before the call returns the buffer
         const int rc = build_from(m->registered_dev + (rgba - m->registered));
@@ -1134,7 +1180,11 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
 bool HipStages::track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) {
     if (!m->fused || n <= 0) return false;
     if (hipSetDevice(m->device) != hipSuccess || m->track_reserve(n) != ALVA_OK) return false;
-    if (m->bar_table && m->trk_in && !m->lists) {   // device memory, written in place (track_reserve)
+    // (not for a session whose chain launches are deposited on a group's lane: there the pinned table + the copy kernel stay.  With the
+    // device table, test_group_sessions_equal_their_solo_runs[one_lane] saw a session track from its PREVIOUS frame's table in about
+    // every second run of tests/test_gpu_system.py -- never outside a lane (tools/probes/bar_stress.cpp: 0 of 130 000 launches, busy stream
+    // or not), and a bus read-back in front of the deposit did not cure it; unexplained, so the lane keeps the round-4 path)
+    if (m->bar_table && m->trk_in && !m->lists && !g_alva_lane) {   // device memory, written in place (track_reserve)
         const Impl::TrackIn T = m->track_in();
         *px = T.px;
         *is3d = T.is3d;

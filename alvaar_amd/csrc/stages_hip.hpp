@@ -26,6 +26,8 @@ public:
     // explicit page-lock + device mapping of the caller's frame buffer (see new_frame); buf == nullptr releases it
     int register_frame_buffer(const uint8_t *buf, size_t bytes);
     int unregister_frame_buffer();
+    // the caller's one frame buffer in host-writable DEVICE memory (include/alvaar_system.h alva_system_alloc_frame_buffer)
+    int alloc_frame_buffer(size_t bytes, uint8_t **h_writable);
     void reset_images() override;
     int fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) override;
     int compute_keypoints(int n, const float *px, float *unpx, double *bv) override;

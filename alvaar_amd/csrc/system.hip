@@ -151,6 +151,16 @@ extern "C" int alva_system_register_frame_buffer(alva_system *s, const uint8_t *
     return rc ? sys_fail(rc, "alva_system_register_frame_buffer") : ALVA_OK;
 }
 
+extern "C" int alva_system_alloc_frame_buffer(alva_system *s, size_t bytes, uint8_t **h_writable) {
+    g_sys_err[0] = 0;
+    if (!s || !s->stages || !h_writable) {
+        snprintf(g_sys_err, sizeof(g_sys_err), "alva_system_alloc_frame_buffer: not configured or NULL argument");
+        return ALVA_ERR_ARG;
+    }
+    const int rc = s->stages->alloc_frame_buffer(bytes, h_writable);
+    return rc ? sys_fail(rc, "alva_system_alloc_frame_buffer") : ALVA_OK;
+}
+
 extern "C" int alva_system_unregister_frame_buffer(alva_system *s) {
     g_sys_err[0] = 0;
     if (!s || !s->stages) return ALVA_OK;

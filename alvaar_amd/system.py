@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -27,6 +28,8 @@ lib.alva_system_configure_ex.argtypes = [_vp, _i, _i] + [_d] * 8 + [_i] * 3
 lib.alva_system_find_camera_pose_ts.argtypes = [_vp, _vp, _d, _vp]
 lib.alva_system_register_frame_buffer.argtypes = [_vp, _vp, C.c_size_t]
 lib.alva_system_unregister_frame_buffer.argtypes = [_vp]
+if hasattr(lib, "alva_system_alloc_frame_buffer"):
+    lib.alva_system_alloc_frame_buffer.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
 lib.alva_system_find_camera_pose_device.argtypes = [_vp, _vp, _d, _vp]
 lib.alva_system_hint_next_frame_device.argtypes = [_vp, _vp]
 lib.alva_system_debug_state.argtypes = [_vp, _vp]
@@ -95,13 +98,27 @@ class AlvaAR:
             self.h = None
             raise AlvaError(msg)
         self._pose = np.zeros(16, np.float32)
+        self._pose_ptr = self._pose.ctypes.data   # (ndarray.ctypes builds a helper object per access: ~1 us of every per-frame call)
+        self._fcp_device = lib.alva_system_find_camera_pose_device
         # src/system.js:63-67: ONE frame buffer (memImg) allocated at construction and reused for every frame; here it is page-locked and
         # mapped once (alva_system_register_frame_buffer) so that the gray / pyramid kernel reads it in place.  4096-byte aligned.
+        # Round 5: the buffer lives in DEVICE memory that the host writes over the PCIe BAR (alva_system_alloc_frame_buffer): memImg.write IS
+        # the upload and the kernels read the frame out of HBM.  Never read mem_img back (a load crosses the bus).  ALVA_NO_BAR_FRAME=1 or a
+        # system without such memory: the page-locked host buffer of rounds 3 - 4.
         nbytes = width * height * 4
-        self._mem_raw = np.empty(nbytes + 4096, np.uint8)
-        off = (-self._mem_raw.ctypes.data) % 4096
-        self.mem_img = self._mem_raw[off:off + nbytes].reshape(height, width, 4)
-        self._registered = lib.alva_system_register_frame_buffer(h, self.mem_img.ctypes.data, nbytes) == 0
+        self.mem_img = None
+        self._bar_frame = False
+        if not os.environ.get("ALVA_NO_BAR_FRAME") and hasattr(lib, "alva_system_alloc_frame_buffer"):
+            p = _vp()
+            if lib.alva_system_alloc_frame_buffer(h, nbytes, C.byref(p)) == 0 and p.value:
+                self.mem_img = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,)).reshape(height, width, 4)
+                self._bar_frame = True
+        if self.mem_img is None:
+            self._mem_raw = np.empty(nbytes + 4096, np.uint8)
+            off = (-self._mem_raw.ctypes.data) % 4096
+            self.mem_img = self._mem_raw[off:off + nbytes].reshape(height, width, 4)
+        self._registered = self._bar_frame or lib.alva_system_register_frame_buffer(h, self.mem_img.ctypes.data, nbytes) == 0
+        self._mem_ptr = self.mem_img.ctypes.data
 
     @staticmethod
     def Initialize(width: int, height: int, fov: float = 45.0) -> "AlvaAR":  # noqa: N802 (reference name)
@@ -117,11 +134,11 @@ class AlvaAR:
     def findCameraPose(self, frame_rgba: np.ndarray, timestamp_ms: float | None = None):  # noqa: N802
         """returns (pose[16] or None, status) -- the JS wrapper returns the pose only on status 1.  timestamp_ms = None reads the
         system clock like the reference (system.cpp:114)."""
-        frame = self._stage(frame_rgba)
+        self._stage(frame_rgba)
         if timestamp_ms is None:
-            status = lib.alva_system_find_camera_pose(self.h, frame.ctypes.data, self._pose.ctypes.data)
+            status = lib.alva_system_find_camera_pose(self.h, self._mem_ptr, self._pose_ptr)
         else:
-            status = lib.alva_system_find_camera_pose_ts(self.h, frame.ctypes.data, float(timestamp_ms), self._pose.ctypes.data)
+            status = lib.alva_system_find_camera_pose_ts(self.h, self._mem_ptr, timestamp_ms, self._pose_ptr)
         if status < 0:
             raise AlvaError(lib.alva_system_last_error().decode())
         return (self._pose.copy() if status == 1 else None), status
@@ -139,7 +156,7 @@ class AlvaAR:
         next_d_rgba_ptr: the frame the NEXT call will pass (alva_system_hint_next_frame_device: its pyramid is built ahead)"""
         if next_d_rgba_ptr:
             lib.alva_system_hint_next_frame_device(self.h, next_d_rgba_ptr)
-        status = lib.alva_system_find_camera_pose_device(self.h, d_rgba_ptr, float(timestamp_ms), self._pose.ctypes.data)
+        status = self._fcp_device(self.h, d_rgba_ptr, timestamp_ms, self._pose_ptr)
         if status < 0:
             raise AlvaError(lib.alva_system_last_error().decode())
         return status

@@ -88,6 +88,13 @@ int alva_system_group_launch_stats(alva_system_group *group, long *out2);
  * the first).  Must be called after alva_system_configure. */
 int alva_system_register_frame_buffer(alva_system *sys, const uint8_t *h_rgba, size_t bytes);
 int alva_system_unregister_frame_buffer(alva_system *sys);
+/* The ONE frame buffer of src/system.js (memImg, :63-67) placed in DEVICE memory that the host can write (round 5): the whole of an
+ * MI355X's memory is visible to the CPU over the PCIe BAR, write-combined, so memImg.write(frame) (:175) -- one copy of the frame, which
+ * the caller performs anyway -- IS the upload: *h_writable receives a pointer the caller stores the frame through (ordinary stores /
+ * memcpy; never read through it: a load crosses the bus), and a frame passed to alva_system_find_camera_pose* from inside this buffer
+ * is read by the gray / pyramid kernel straight out of HBM, exactly like alva_system_find_camera_pose_device's.  Freed by
+ * alva_system_configure / alva_system_destroy.  ALVA_ERR_STATE where such memory cannot be had (use alva_system_register_frame_buffer). */
+int alva_system_alloc_frame_buffer(alva_system *sys, size_t bytes, uint8_t **h_writable);
 /* The same with the frame's timestamp (milliseconds) as an argument instead of the system clock (system.cpp:114): the
  * constant-velocity motion model (visual_frontend.hpp:11-68) is the only consumer. */
 int alva_system_find_camera_pose_ts(alva_system *sys, const uint8_t *h_rgba, double timestamp_ms, float *h_pose);
