@@ -10,6 +10,7 @@
 // the sequential scan does.  Sums of popcounts are exact in float, so the order of the additions does not matter.
 #include "common.hpp"
 #include "slam/medoid_table.hpp"
+#include "slam/mp_rec.hpp"
 #include <algorithm>
 #include <vector>
 
@@ -179,6 +180,39 @@ __global__ void __launch_bounds__(256) k_medoid_export(const Table *__restrict__
     reinterpret_cast<int *>(o + 36)[1] = t.medoid_kf;
 }
 
+// The shared-map exchange's record block (alvaar_amd/multi.py: stream id | point id | xyz 3 x f64 | descriptor medoid 32 B = 64 B) written
+// straight from the resident data: one thread per record SLOT reads the map-point record's header out of pinned host memory (slam/mp_rec.hpp:
+// id, is3d, !desc_.empty(), worldPoint_) and the medoid out of the descriptor table of the same slot; 3-D points with a descriptor claim
+// an output row with one atomic (the consumers order the block by (stream, id) themselves).  Rows beyond `capacity` are counted, not
+// written: the caller falls back to the host-side export, which keeps the OLDEST `capacity` points.
+__global__ void __launch_bounds__(256) k_pack_map_records(const alva_slam::MpRec *const *__restrict__ chunks, int n_slots,
+                                                          const Table *__restrict__ tables, int stream_id, int capacity,
+                                                          uint8_t *__restrict__ out, int *__restrict__ count) {
+    const int s = (int) (blockIdx.x * 256 + threadIdx.x);
+    if (s >= n_slots) return;
+    const alva_slam::MpRec *r = chunks[s >> alva_slam::MP_CHUNK_SHIFT] + (s & (alva_slam::MP_CHUNK - 1));
+    const unsigned long long *h8 = reinterpret_cast<const unsigned long long *>(r);
+    const unsigned long long ida = __builtin_nontemporal_load(h8 + 4), fl = __builtin_nontemporal_load(h8 + 5);
+    const int id = (int) (unsigned) (ida & 0xffffffffull);
+    if (id < 0 || !(fl & 0xffull) || !((fl >> 8) & 0xffull)) return;   // free record | not 3-D | no descriptor
+    const Table &t = tables[s];
+    if (!t.medoid_valid || t.count <= 0) return;   // (at least one keyframe descriptor: what the host-side export requires too)
+    const int row = atomicAdd(count, 1);
+    if (row >= capacity) return;
+    uint8_t *o = out + 64 * (size_t) row;
+    reinterpret_cast<int *>(o)[0] = stream_id;
+    reinterpret_cast<int *>(o)[1] = id;
+    for (int k = 0; k < 3; k++) reinterpret_cast<unsigned long long *>(o + 8)[k] = __builtin_nontemporal_load(h8 + k);
+    for (int k = 0; k < 4; k++) reinterpret_cast<unsigned long long *>(o + 32)[k] = reinterpret_cast<const unsigned long long *>(t.medoid)[k];
+}
+__global__ void __launch_bounds__(256) k_pack_fill_unused(uint8_t *__restrict__ out, const int *__restrict__ count, int capacity) {
+    const int row = (int) (blockIdx.x * 256 + threadIdx.x);
+    if (row >= capacity || row < *count) return;
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(out + 64 * (size_t) row);
+    for (int k = 0; k < 8; k++) o[k] = 0ull;
+    reinterpret_cast<int *>(o)[1] = -1;   // unused row: point id -1
+}
+
 }  // namespace
 
 struct alva_medoid_store {
@@ -307,6 +341,29 @@ extern "C" int alva_medoid_export(alva_medoid_store *s, int n, const int *mp_slo
 }
 
 extern "C" const void *alva_medoid_tables(alva_medoid_store *s) { return s ? s->tables : nullptr; }
+
+extern "C" int alva_pack_map_records(alva_medoid_store *s, const void *const *d_record_chunks, int n_slots, int stream_id, int capacity, uint8_t *d_out,
+                                     int *h_count) {
+    ALVA_ARG(s && d_record_chunks && n_slots >= 0 && capacity >= 0 && d_out && h_count && n_slots <= s->cap);
+    ALVA_HIP(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    int *d_count = nullptr, *pin = nullptr;
+    int rc = alva_ctx_scratch(s->ctx, 11, 256, (void **) &d_count);
+    if (rc) return rc;
+    rc = alva_ctx_pinned(s->ctx, 256, (void **) &pin);
+    if (rc) return rc;
+    ALVA_HIP(alva_stream_sync(st));   // nothing enqueued earlier may still use the context's staging
+    ALVA_HIP(hipMemsetAsync(d_count, 0, 4, st));
+    if (n_slots > 0)
+        hipLaunchKernelGGL(k_pack_map_records, dim3((unsigned) alva_divup(n_slots, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const alva_slam::MpRec *const *>(d_record_chunks), n_slots, (const Table *) s->tables, stream_id, capacity, d_out, d_count);
+    if (capacity > 0) hipLaunchKernelGGL(k_pack_fill_unused, dim3((unsigned) alva_divup(capacity, 256)), dim3(256), 0, st, d_out, (const int *) d_count, capacity);
+    ALVA_LAUNCH_CHECK();
+    ALVA_HIP(hipMemcpyAsync(pin, d_count, 4, hipMemcpyDeviceToHost, st));
+    ALVA_HIP(alva_stream_sync(st));
+    *h_count = *pin;
+    return ALVA_OK;
+}
 
 extern "C" int alva_medoid_dump(alva_medoid_store *s, int mp_slot, void *table_out, size_t bytes) {
     ALVA_ARG(s && table_out && bytes == sizeof(Table) && mp_slot >= 0 && mp_slot < s->cap);

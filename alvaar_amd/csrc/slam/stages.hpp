@@ -244,6 +244,13 @@ struct Stages {
         return 0;
     }
 
+    // the shared-map exchange's record block written on the device from the records + descriptor tables of slots 0 .. n_slots - 1
+    // (alva_pack_map_records); -4 where the map is not device-resident (the default stages)
+    virtual int pack_map_records(int n_slots, int stream_id, int capacity, uint8_t *d_out, int *count) {
+        (void) n_slots; (void) stream_id; (void) capacity; (void) d_out; (void) count;
+        return -4;
+    }
+
     // System::processPlane's fit (system.cpp:177-342, intended algorithm, parity unpinned)
     virtual int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) = 0;
 

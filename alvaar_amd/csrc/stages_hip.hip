@@ -1636,6 +1636,10 @@ int HipStages::medoid_export(int n, const int *mp_slot, uint8_t *desc32, uint8_t
     }
     return alva_medoid_export(m->med, n, mp_slot, desc32, valid, info3);
 }
+int HipStages::pack_map_records(int n_slots, int stream_id, int capacity, uint8_t *d_out, int *count) {
+    if (!m->med || !m->d_rec_tab) return ALVA_ERR_STATE;
+    return alva_pack_map_records(m->med, (const void *const *) m->d_rec_tab, n_slots, stream_id, capacity, d_out, count);
+}
 int HipStages::medoid_dump(int mp_slot, alva_medoid::Table *out) {
     if (!m->med) return ALVA_ERR_STATE;
     return alva_medoid_dump(m->med, mp_slot, out, sizeof(*out));

@@ -60,6 +60,7 @@ public:
     int medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) override;
     int medoid_export(int n, const int *mp_slot, uint8_t *desc32, uint8_t *valid, int *info3) override;
     int medoid_dump(int mp_slot, alva_medoid::Table *out) override;
+    int pack_map_records(int n_slots, int stream_id, int capacity, uint8_t *d_out, int *count) override;
 
 private:
     int build_from(const uint8_t *d_src);

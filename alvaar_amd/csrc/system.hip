@@ -334,6 +334,16 @@ extern "C" int alva_system_merge_map_points(alva_system *s, int prev_id, int new
         return s->slam->n_merges > before ? 1 : 0;   // 0: the reference's early return (a point is gone, or the survivor is not 3-D)
     });
 }
+extern "C" int alva_system_pack_map_records(alva_system *s, int stream_id, int capacity, uint8_t *d_out, int *h_count) {
+    if (!s || !s->slam || !d_out || !h_count || capacity < 0) return ALVA_ERR_ARG;
+    return guarded(s, "alva_system_pack_map_records", [&]() -> int {
+        Slam &S = *s->slam;
+        S.flush_medoids();   // the medoids of this keyframe's edits
+        if (S.last_error()) return sys_fail(S.last_error(), "alva_system_pack_map_records");
+        const int rc = s->stages->pack_map_records(S.med_log.next_slot, stream_id, capacity, d_out, h_count);
+        return rc ? sys_fail(rc, "alva_system_pack_map_records") : ALVA_OK;
+    });
+}
 extern "C" int alva_system_set_shared_ids(alva_system *s, int n, const int *local_id, const int *shared_stream, const int *shared_id) {
     if (!s || !s->slam || n < 0 || (n > 0 && (!local_id || !shared_stream || !shared_id))) return ALVA_ERR_ARG;
     return guarded(s, "alva_system_set_shared_ids", [&]() -> int {

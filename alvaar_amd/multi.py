@@ -112,6 +112,11 @@ def all_gather_map(records: torch.Tensor) -> torch.Tensor:
     if dist.get_backend() == "nccl" and not records.is_cuda:
         records = records.to(exchange_device())
     records = records.contiguous()
+    if dist.get_backend() == "gloo" and records.is_cuda:   # (two ranks on ONE GPU, tests: gloo moves host memory)
+        host = records.cpu()
+        out = torch.empty((dist.get_world_size() * host.shape[0], host.shape[1]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(records.device)
     out = torch.empty((dist.get_world_size() * records.shape[0], records.shape[1]), dtype=records.dtype, device=records.device)
     dist.all_gather_into_tensor(out, records)
     return out
@@ -151,6 +156,17 @@ def system_map_records(ar, stream_id: int, capacity: int, device: torch.device |
     """The 3-D map points of one alva::System session (alva_system_debug_map_points: id, world position, descriptor medoid) as the
     fixed-capacity record block of the exchange; points without a descriptor are skipped, the newest are dropped beyond `capacity`
     (ids are handed out consecutively, so "older absorbs newer" keeps the established part of the map).  Returns (block, n_records)."""
+    dev = device if device is not None else exchange_device()
+    if dev.type == "cuda" and hasattr(ar, "pack_map_records") and not os.environ.get("ALVA_HOST_MAP_PACK"):
+        # round 5: the block is written on the device from the resident map (records in pinned memory, descriptor tables in HBM): no
+        # per-point export to the host, no numpy packing, no upload (21 ms -> well under a millisecond for ~5 000 points)
+        block = torch.empty((capacity, RECORD_BYTES), dtype=torch.uint8, device=dev)
+        try:
+            n = ar.pack_map_records(stream_id, capacity, block)
+        except Exception:   # noqa: BLE001 -- a session without a device-resident map yet: the host export below
+            n = capacity + 1
+        if n <= capacity:
+            return block, int(n)
     ids, xyz, flags, inv, desc = ar.map_points(cap=262144)
     m = (flags[:, 0] != 0) & (flags[:, 4] > 0)   # is3d, at least one keyframe descriptor => a medoid (inspect_map_points)
     ids, xyz, desc = ids[m], xyz[m], desc[m]

@@ -233,6 +233,16 @@ class AlvaAR:
         n = lib.alva_system_debug_map_points(self.h, cap, ids.ctypes.data, xyz.ctypes.data, fl.ctypes.data, inv.ctypes.data, desc.ctypes.data)
         return ids[:n], xyz[:n], fl[:n], inv[:n], desc[:n]
 
+    def pack_map_records(self, stream_id: int, capacity: int, out):
+        """alva_system_pack_map_records: this session's 3-D map points as 64-byte exchange records written on the device into `out`
+        (cuda uint8 tensor [capacity, 64]); returns the number of points found (may exceed capacity: then `out` holds a subset)"""
+        n = C.c_int(0)
+        lib.alva_system_pack_map_records.argtypes = [_vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)]
+        rc = lib.alva_system_pack_map_records(self.h, int(stream_id), int(capacity), out.data_ptr(), C.byref(n))
+        if rc < 0:
+            raise AlvaError(lib.alva_system_last_error().decode())
+        return n.value
+
     def merge_map_points(self, prev_id: int, new_id: int) -> bool:
         """MapManager::mergeMapPoints(prev_id, new_id) on this session's map (include/alvaar_system.h); False = the reference's early return"""
         rc = lib.alva_system_merge_map_points(self.h, int(prev_id), int(new_id))

@@ -539,6 +539,14 @@ int alva_medoid_dump(alva_medoid_store *store, int mp_slot, void *h_table, size_
 /* the device array of tables (valid until the next alva_medoid_replay grows it; NULL before the first replay): kernels that read the
  * descriptors in place (alva_match_to_map_records) */
 const void *alva_medoid_tables(alva_medoid_store *store);
+/* The shared-map exchange's record block from the resident data (round 5): one thread per record slot 0 .. n_slots - 1 reads the
+ * map-point record's header (csrc/slam/mp_rec.hpp; d_record_chunks as in alva_match_to_map_records) and the descriptor medoid of the
+ * same slot's table; every 3-D point with a descriptor becomes one 64-byte row {int32 stream, int32 point id, f64 xyz[3], u8 desc[32]}
+ * of d_out [capacity][64] (device), in no particular order; unused rows get point id -1.  *h_count = points found (> capacity: only
+ * `capacity` of them were written -- an arbitrary subset).  Semantics of the exchange: MapManager::mergeMapPoints,
+ * src/slam/src/map_manager.cpp:428-513 (parity unpinned: the reference has one map).  Synchronous. */
+int alva_pack_map_records(alva_medoid_store *store, const void *const *d_record_chunks, int n_slots, int stream_id, int capacity,
+                          uint8_t *d_out, int *h_count);
 
 /* ---- §8(e) optional shared-map merge (north_star extension, PARITY UNPINNED: the reference has one map) -----------------------
  * n records sorted by (stream, point id): a record is absorbed by the earliest SURVIVING record of another stream within max_dist

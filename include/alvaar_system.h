@@ -150,6 +150,11 @@ int alva_system_debug_counters(alva_system *sys, long *out3 /* local-BA solves, 
 int alva_system_merge_map_points(alva_system *sys, int prev_id, int new_id);
 int alva_system_set_shared_ids(alva_system *sys, int n, const int *local_id, const int *shared_stream, const int *shared_id);
 int alva_system_get_shared_ids(alva_system *sys, int cap, int *local_id, int *shared_stream, int *shared_id);
+/* This session's 3-D map points as the exchange's record block, written ON THE DEVICE from the resident map (alva_pack_map_records):
+ * d_out [capacity][64] in the system's GPU memory; *h_count = 3-D points with a descriptor (when it exceeds `capacity` the block holds an
+ * arbitrary subset: export through alva_system_debug_map_points instead, which keeps the oldest).  Pending descriptor edits are replayed
+ * first.  ALVA_ERR_STATE without a device-resident map (nothing was ever mapped). */
+int alva_system_pack_map_records(alva_system *sys, int stream_id, int capacity, uint8_t *d_out, int *h_count);
 /* fb-KLT work since the last reset: out2[0] = keypoint-levels (LK passes over one pyramid level, forwards + the backward pass, from
  * the per-slot result codes), out2[1] = slots handed to the tracking steps */
 int alva_system_debug_klt_work(alva_system *sys, long *out2, int reset);
