@@ -452,6 +452,8 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
     const int ok = fbklt_value(sh, P, C, from_prior ? maxLevelPrior : maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
     int code = ok ? (from_prior ? 1 : 2) : 0;
     if (from_prior && !ok) {  // full-pyramid retry from where the forward tracker left the keypoint (:185-190)
+        // (s_setprio(3) here -- and s_setprio(2) for every full-pyramid slot -- measured in round 5: 65.6 vs 65.8 / 66.0 us, nothing: by the
+        // time the slow slots are alone on their SIMDs the crowd has left anyway)
         const int ok2 = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
         code = ok2 ? 3 : 0;
     }

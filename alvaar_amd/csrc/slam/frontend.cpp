@@ -56,6 +56,7 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     kf_flat_.clear();
     mp_flat_.clear();
     mp_rec_.clear();
+    mp_slot_.clear();
     mp_nobs_.clear();
     mp_index_.clear();
     shared_ids.clear();

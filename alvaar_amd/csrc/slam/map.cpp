@@ -217,27 +217,15 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
 
 void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid: medoid_table.hpp add_desc)
     const size_t buckets = kf_desc.bucket_count();
-    if (!kf_desc.insert_slot(kf, d).second) return;
-    note_desc(kf);
+    if (!kf_desc.insert_slot(kf).second) return;
+    note_desc(kf, d);
     r->has_desc = 1;   // desc_ is never empty again until the last observation goes
     if (kf_desc.size() > (size_t) alva_medoid::CAP || kf_desc.bucket_count() > (size_t) alva_medoid::NBKT) mlog->overflow = true;
     // the bucket count of the rehash this insert caused, if any: the table in the stages replays the list surgery, not the growth policy
     mlog->push(dev_slot, alva_medoid::OP_ADD, kf, d.b, kf_desc.bucket_count() != buckets ? (int) kf_desc.bucket_count() : 0);
 }
 
-bool MapPt::is_bad() {  // map_point.cpp:183-202
-    if (r->n_obs < 2) {
-        if (!r->observed && r->is3d) {
-            r->is3d = 0;
-            return true;
-        }
-    }
-    if (r->n_obs == 0 && !r->observed) {
-        r->is3d = 0;
-        return true;
-    }
-    return false;
-}
+bool MapPt::is_bad() { return rec_is_bad(*r); }  // map_point.cpp:183-202
 
 // ---------------------------------------------------------------------------------------------------- map (map_manager.cpp)
 std::shared_ptr<FrameRec> Slam::keyframe(int id) const {
@@ -410,6 +398,7 @@ bool Slam::ensure_rec_chunk(int slot) {
         MpRec *chunk = st->mp_arena_chunk((int) med_log.chunks.size());
         if (!chunk) return false;
         med_log.chunks.push_back(chunk);
+        med_log.desc_chunks.emplace_back(new DescBytes[(size_t) MP_CHUNK * MP_ENT_CAP]);
     }
     return true;
 }
@@ -455,19 +444,26 @@ void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
     if (mp_flat_.size() <= (size_t) next_mp_id) {
         mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
         mp_rec_.resize(mp_flat_.size(), nullptr);
+        mp_slot_.resize(mp_flat_.size(), -1);
         mp_nobs_.resize(mp_flat_.size(), 0);
     }
     mp_flat_[(size_t) next_mp_id] = mp.get();
     mp_rec_[(size_t) next_mp_id] = mp->r;
+    mp_slot_[(size_t) next_mp_id] = slot;
     sync_nobs(*mp);
     next_mp_id++;
     n_map_points++;
 }
 
 void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) {  // map_manager.cpp:366-426
-    MapPt *mpp = mp_raw(id);   // the flat mirror of mapMapPoints_ (same membership)
-    if (!mpp) return;
-    MapPt &mp = *mpp;
+    MpRec *rec = rec_raw(id);   // the flat mirror of mapMapPoints_ (same membership); the record alone in the common case
+    if (!rec) return;
+    if (rec->is3d) {
+        rec->X[0] = wpt[0]; rec->X[1] = wpt[1]; rec->X[2] = wpt[2];
+        if (anchor_inv_depth >= 0.) rec->inv_depth = anchor_inv_depth;
+        return;
+    }
+    MapPt &mp = *mp_raw(id);
     if (!mp.r->is3d) {
         const ObsList obs = mp.observers();  // getObservedKeyframeIds returns a copy; removals below edit the member
         for (int kf: obs) {
@@ -488,7 +484,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->r->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
     const ObsList next_kfs = nw->observers(), prev_kfs = prev->observers();
-    const FlatHash<Desc> prev_desc = prev->kf_desc;   // a copy (keys + bytes), in the original's order
+    const FlatHash<FlatNoValue> prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;
@@ -506,7 +502,13 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
             }
         }
     }
-    for (int se = prev_desc.first(); se != FlatHash<Desc>::END; se = prev_desc.next(se)) nw->add_desc(prev_desc.key(se), prev_desc.val(se));
+    for (int se = prev_desc.first(); se != FlatHash<FlatNoValue>::END; se = prev_desc.next(se)) {
+        const uint8_t *b = prev->desc_of(prev_desc.key(se));   // (the bytes sit beside prev's record entries)
+        if (!b) throw std::out_of_range("descriptor bytes");
+        Desc d;
+        std::memcpy(d.b, b, 32);
+        nw->add_desc(prev_desc.key(se), d);
+    }
     if (cur->observes(prev_id)) {
         if (cur->change_id(prev_id, new_id, nw->r->is3d != 0)) set_map_point_obs(new_id);
     }
@@ -520,6 +522,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     }
     mp_flat_[(size_t) prev_id] = nullptr;
     mp_rec_[(size_t) prev_id] = nullptr;
+    mp_slot_[(size_t) prev_id] = -1;
     mp_nobs_[(size_t) prev_id] = 0;
     map_points.erase(pit);
     n_merges++;
@@ -565,6 +568,7 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     if (mp->r->is3d) n_map_points--;
     mp_flat_[(size_t) id] = nullptr;
     mp_rec_[(size_t) id] = nullptr;
+    mp_slot_[(size_t) id] = -1;
     mp_nobs_[(size_t) id] = 0;
     if (defer_mp_free_) mp_graveyard_.push_back(mp);
     map_points.erase(it);

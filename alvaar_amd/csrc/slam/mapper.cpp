@@ -212,9 +212,9 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             const int id = cell_ids[ci];
             // getSurroundingKeypoints keeps ids found in mapKeypoints_ (frame.cpp:333-337); a keypoint whose map point is gone is
             // repaired by the reference on contact (:459-463) -- repaired here up front
-            const MapPt *gm = mp_raw(id);
+            const MpRec *gm = rec_raw(id);
             if (!gm) continue;
-            if (!obs_of(*gm, frame.kfid)) continue;
+            if (!(check_obs_mirror_ ? obs_of(*mp_raw(id), frame.kfid) : rec_in_kf(*gm, frame.kfid))) continue;
             cell_mp_v.push_back(intern(id));
         }
     }
@@ -269,11 +269,11 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
     }
     size_t no = 0;
     for (int m = 0; m < n_mp; m++) {
-        const MpRec &mp = *rec_raw(mp_ids[(size_t) m]);
-        mp_slot[m] = mp.dev_slot;
-        no += mp.n_obs;
+        mp_slot[m] = mp_slot_[(size_t) mp_ids[(size_t) m]];   // (the records themselves are not touched here: the stage gathers them)
+        no += mp_nobs_[(size_t) mp_ids[(size_t) m]];
         match_of_mp[m] = -1;
         if (check_obs_mirror_) {   // the records against the authoritative containers: every observer's keypoint, every descriptor key
+            const MpRec &mp = *rec_raw(mp_ids[(size_t) m]);
             const MapPt &o = *mp_raw(mp_ids[(size_t) m]);
             int n_desc = 0;
             for (int e = 0; e < mp.n_ent; e++) {
@@ -410,7 +410,7 @@ void Slam::local_ba(FrameRec &new_frame) {
     } undefer{this};
     defer_mp_free_ = true;
     // (the two big ones -- thousands of map points -- on flat arrays with libstdc++'s order, flat_hash.hpp; capacity kept between calls)
-    FlatHash<MapPt *> &local_mps = ba_scratch_.local_mps;                         // map_local_plms
+    FlatHash<MpRec *> &local_mps = ba_scratch_.local_mps;                         // map_local_plms
     local_mps.reset();
     std::pmr::unordered_map<int, std::shared_ptr<FrameRec>> local_kfs(&arena);    // map_local_pkfs
     // keyframe id -> row of the flat pose table / keyframe object: ids are small consecutive integers, so plain arrays beside the
@@ -497,13 +497,13 @@ void Slam::local_ba(FrameRec &new_frame) {
     for (size_t oi = 0; oi < ids_scratch_.size(); oi++) {
         const int lmid = ids_scratch_[oi];
         prefetch_mp(ids_scratch_.data(), oi, ids_scratch_.size());
-        MapPt *mp = mp_raw(lmid);
-        if (!mp) continue;
-        if (mp->is_bad()) {
+        MpRec *recp = rec_raw(lmid);   // (the record alone: the map point's object is not touched in this loop)
+        if (!recp) continue;
+        if (rec_is_bad(*recp)) {
             bad_mps.insert(lmid);
             continue;
         }
-        local_mps.insert_slot(lmid, mp);
+        local_mps.insert_slot(lmid, recp);
         if ((size_t) n_obs + MP_ENT_CAP > obs_cap) {
             obs_cap *= 2;
             obs_kf.resize(obs_cap);
@@ -511,8 +511,8 @@ void Slam::local_ba(FrameRec &new_frame) {
         }
         int anchor = -1;
         const int q0 = n_obs;
-        const ObsList obs = mp->observers();  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
-        const MpRec &rec = *mp->r;
+        const MpRec &rec = *recp;
+        const ObsList obs = rec_observers(rec);  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
         int si = 0;   // walks the record's entries (sorted by keyframe like obs) beside the observers; a repair below edits them: start over
         for (int kfid: obs) {
             if (kfid > max_kfid) continue;
@@ -520,7 +520,7 @@ void Slam::local_ba(FrameRec &new_frame) {
             if (!kf) {  // an observing keyframe outside the covisibility set joins as a constant one (:153-172)
                 std::shared_ptr<FrameRec> sp = keyframe(kfid);
                 if (!sp) {
-                    remove_map_point_obs(kfid, mp->id());  // sic: arguments swapped in the reference (optimizer.cpp:162)
+                    remove_map_point_obs(kfid, lmid);  // sic: arguments swapped in the reference (optimizer.cpp:162)
                     si = 0;
                     continue;
                 }
@@ -531,8 +531,8 @@ void Slam::local_ba(FrameRec &new_frame) {
             }
             while (si < rec.n_ent && rec.ent[si].kf < kfid) si++;
             const ObsEnt *kp = si < rec.n_ent && rec.ent[si].kf == kfid && (rec.ent[si].flags & MPF_INKF) ? &rec.ent[si] : nullptr;
-            if (check_obs_mirror_ && kp != obs_of(*mp, kfid)) {
-                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync in localBA (map point %d, keyframe %d)\n", mp->id(), kfid);
+            if (check_obs_mirror_ && kp != obs_of(*mp_raw(lmid), kfid)) {
+                std::fprintf(stderr, "alva_slam: sorted observation walk out of sync in localBA (map point %d, keyframe %d)\n", lmid, kfid);
                 std::abort();
             }
             if (!kp) {
@@ -675,20 +675,21 @@ void Slam::local_ba(FrameRec &new_frame) {
         const int ps = pose_slot[(size_t) e.first];
         if (ps >= 0) e.second->set_Twc(se3_from_pose7(&poses[7 * (size_t) ps]));
     }
-    for (int ls = local_mps.first(); ls != FlatHash<MapPt *>::END; ls = local_mps.next(ls)) {
+    for (int ls = local_mps.first(); ls != FlatHash<MpRec *>::END; ls = local_mps.next(ls)) {
         const int lmid = local_mps.key(ls);
-        MapPt *mp = local_mps.val(ls);
-        if (!mp) {
+        MpRec *wrp = local_mps.val(ls);
+        if (!wrp) {
             bad_mps.erase(lmid);
             continue;
         }
-        if (mp->is_bad()) {
+        MpRec &wr = *wrp;
+        if (rec_is_bad(wr)) {
             remove_map_point(lmid);
             bad_mps.erase(lmid);
             continue;
         }
-        if (mp->n_obs() < 3) {
-            if (mp->r->anchor_kf < new_frame.kfid - 3 && !mp->r->observed) {
+        if (wr.n_obs < 3) {
+            if (wr.anchor_kf < new_frame.kfid - 3 && !wr.observed) {
                 remove_map_point(lmid);
                 bad_mps.erase(lmid);
                 continue;
@@ -705,14 +706,14 @@ void Slam::local_ba(FrameRec &new_frame) {
             bad_mps.erase(lmid);
             continue;
         }
-        const FrameRec *akp = mp->r->anchor_kf >= 0 && (size_t) mp->r->anchor_kf < kf_flat.size() ? kf_flat[(size_t) mp->r->anchor_kf] : nullptr;
+        const FrameRec *akp = wr.anchor_kf >= 0 && (size_t) wr.anchor_kf < kf_flat.size() ? kf_flat[(size_t) wr.anchor_kf] : nullptr;
         if (!akp) {  // the anchor keyframe is not part of the problem (:459-463)
             bad_mps.insert(lmid);
             continue;
         }
         {
             const FrameRec &akf = *akp;
-            const ObsEnt *kp = obs_of(*mp, akf.kfid);
+            const ObsEnt *kp = check_obs_mirror_ && mp_raw(lmid) ? obs_of(*mp_raw(lmid), akf.kfid) : rec_in_kf(wr, akf.kfid);
             const float ux = kp ? kp->unpx[0] : 0.f, uy = kp ? kp->unpx[1] : 0.f;  // a default Keypoint has unpx_ = (0, 0)
             const double uv[3] = {(double) ux, (double) uy, 1.};
             double ray[3], pc[3], wpt[3];
@@ -727,12 +728,12 @@ void Slam::local_ba(FrameRec &new_frame) {
     lap_ba(t_kf[13]);
     for (int lmid: bad_mps) {  // :492-530
         const int lm = local_mps.find_slot(lmid);
-        MapPt *mp = lm == FlatHash<MapPt *>::END ? mp_raw(lmid) : local_mps.val(lm);
-        if (!mp) continue;
-        if (mp->is_bad()) {
+        MpRec *rp = lm == FlatHash<MpRec *>::END ? rec_raw(lmid) : local_mps.val(lm);
+        if (!rp) continue;
+        if (rec_is_bad(*rp)) {
             remove_map_point(lmid);
-        } else if (mp->n_obs() < 3) {
-            if (mp->r->anchor_kf < new_frame.kfid - 3 && !mp->r->observed) remove_map_point(lmid);
+        } else if (rp->n_obs < 3) {
+            if (rp->anchor_kf < new_frame.kfid - 3 && !rp->observed) remove_map_point(lmid);
         }
     }
     lap_ba(t_kf[14]);

@@ -66,8 +66,13 @@ inline int rec_find(const MpRec &r, int kf) {   // index of the entry of keyfram
     }
     return -1;
 }
+// 32 descriptor bytes per entry, parallel to MpRec::ent, HOST ONLY (the device reads descriptors from its own tables): what
+// mapKeyframeDescriptors_ holds for the entry's keyframe where MPF_DESC is set.  Kept beside the entries -- same index, shifted with them --
+// so that a merge finds the bytes it copies to the survivor without a container of its own per map point.
+typedef uint8_t DescBytes[32];
+
 // the entry of keyframe kf, created (no flags yet, positions zero) if absent; nullptr when the record is full
-inline ObsEnt *rec_slot(MpRec &r, int kf) {
+inline ObsEnt *rec_slot(MpRec &r, int kf, DescBytes *side = nullptr) {
     int i = r.n_ent;
     while (i > 0 && r.ent[i - 1].kf > kf) i--;
     if (i > 0 && r.ent[i - 1].kf == kf) return &r.ent[i - 1];
@@ -76,6 +81,7 @@ inline ObsEnt *rec_slot(MpRec &r, int kf) {
         return nullptr;
     }
     std::memmove(&r.ent[i + 1], &r.ent[i], (size_t) (r.n_ent - i) * sizeof(ObsEnt));
+    if (side) std::memmove(&side[i + 1], &side[i], (size_t) (r.n_ent - i) * sizeof(DescBytes));
     r.n_ent++;
     ObsEnt &e = r.ent[i];
     e.kf = kf;
@@ -84,14 +90,35 @@ inline ObsEnt *rec_slot(MpRec &r, int kf) {
     e.px[0] = e.px[1] = e.unpx[0] = e.unpx[1] = 0.f;
     return &e;
 }
-inline void rec_clear_flag(MpRec &r, int i, uint8_t flag) {   // clears `flag` of entry i; the entry goes with its last flag
+inline void rec_clear_flag(MpRec &r, int i, uint8_t flag, DescBytes *side = nullptr) {   // clears `flag` of entry i; the entry goes with its last flag
     ObsEnt &e = r.ent[i];
     if ((e.flags & flag) && flag == MPF_OBS) r.n_obs--;
     e.flags = (uint8_t) (e.flags & ~flag);
     if (!e.flags) {
         std::memmove(&r.ent[i], &r.ent[i + 1], (size_t) (r.n_ent - i - 1) * sizeof(ObsEnt));
+        if (side) std::memmove(&side[i], &side[i + 1], (size_t) (r.n_ent - i - 1) * sizeof(DescBytes));
         r.n_ent--;
     }
+}
+
+// MapPoint::isBad (map_point.cpp:183-202) on the record alone (the hot loops do not touch the map point's object)
+inline bool rec_is_bad(MpRec &r) {
+    if (r.n_obs < 2) {
+        if (!r.observed && r.is3d) {
+            r.is3d = 0;
+            return true;
+        }
+    }
+    if (r.n_obs == 0 && !r.observed) {
+        r.is3d = 0;
+        return true;
+    }
+    return false;
+}
+// the keypoint the map point has in keyframe kf (null: that keyframe holds none)
+inline const ObsEnt *rec_in_kf(const MpRec &r, int kf) {
+    const int i = rec_find(r, kf);
+    return i >= 0 && (r.ent[i].flags & MPF_INKF) ? &r.ent[i] : nullptr;
 }
 
 // a snapshot of the observing keyframes (MapPoint::getObservedKeyframeIds returns a COPY of the set: loops that edit while they walk)

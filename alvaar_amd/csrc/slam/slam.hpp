@@ -230,6 +230,9 @@ struct MedoidLog {
     // `s` belongs to the map point that holds descriptor-table slot `s`
     std::vector<MpRec *> chunks;
     MpRec *rec(int s) const { return chunks[(size_t) s >> MP_CHUNK_SHIFT] + (s & (MP_CHUNK - 1)); }
+    // host-only side arena: MP_ENT_CAP x 32 descriptor bytes per record slot, parallel to the record's entries (mp_rec.hpp DescBytes)
+    std::vector<std::unique_ptr<DescBytes[]>> desc_chunks;
+    DescBytes *descs(int s) const { return desc_chunks[(size_t) s >> MP_CHUNK_SHIFT].get() + (size_t) (s & (MP_CHUNK - 1)) * MP_ENT_CAP; }
     // a map point's key set outgrew what its table in the stages holds (medoid_table.hpp: CAP descriptors, NBKT buckets): the table would
     // drop the descriptor and diverge from the key set, so the frame fails instead (Slam::flush_medoids, ALVA_ERR_STATE)
     bool overflow = false;
@@ -269,14 +272,16 @@ struct MedoidLog {
 // updates the entry's MPF_INKF half, and ALVA_CHECK_OBS_MIRROR=1 compares every read with the authoritative containers.
 struct MapPt {
     MpRec *r = nullptr;
-    // mapKeyframeDescriptors_ (the reference edits it and mapDescriptorsDist_ together: same keys, same sequence => same iteration
-    // order) in libstdc++'s order (flat_hash.hpp), with the descriptor bytes (merges copy them to the survivor).  The distance sums and
-    // desc_ itself live in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`, nothing is read back
-    FlatHash<Desc> kf_desc;
+    DescBytes *dsc = nullptr;   // the record's descriptor bytes (host-only side arena, parallel to r->ent)
+    // the KEYS of mapKeyframeDescriptors_ (the reference edits it and mapDescriptorsDist_ together: same keys, same sequence => same
+    // iteration order) in libstdc++'s order (flat_hash.hpp); the bytes sit beside the record's entries (merges copy them to the survivor).
+    // The distance sums and desc_ itself live in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`,
+    // nothing is read back
+    FlatHash<FlatNoValue> kf_desc;
     MedoidLog *mlog = nullptr;
     int dev_slot = -1;
 
-    MapPt(MedoidLog *log, int slot, int id_, int kf) : r(log->rec(slot)), mlog(log), dev_slot(slot) {
+    MapPt(MedoidLog *log, int slot, int id_, int kf) : r(log->rec(slot)), dsc(log->descs(slot)), mlog(log), dev_slot(slot) {
         rec_init(*r, id_, kf, slot);
         obs_insert(kf);
     }
@@ -301,7 +306,7 @@ struct MapPt {
         return -1;
     }
     void obs_insert(int kf) {
-        ObsEnt *e = rec_slot(*r, kf);
+        ObsEnt *e = rec_slot(*r, kf, dsc);
         if (!e) {
             mlog->overflow = true;
             return;
@@ -313,7 +318,7 @@ struct MapPt {
     }
     void obs_erase(int kf) {
         const int i = rec_find(*r, kf);
-        if (i >= 0 && (r->ent[i].flags & MPF_OBS)) rec_clear_flag(*r, i, MPF_OBS);
+        if (i >= 0 && (r->ent[i].flags & MPF_OBS)) rec_clear_flag(*r, i, MPF_OBS, dsc);
     }
     ObsList observers() const { return rec_observers(*r); }   // getObservedKeyframeIds(): a copy
     void remove_obs(int kf);
@@ -326,7 +331,7 @@ struct MapPt {
         return i >= 0 && (r->ent[i].flags & MPF_INKF) ? &r->ent[i] : nullptr;
     }
     void note_px(int kf, const KeyPt &k) {
-        ObsEnt *e = rec_slot(*r, kf);
+        ObsEnt *e = rec_slot(*r, kf, dsc);
         if (!e) {
             mlog->overflow = true;
             return;
@@ -337,23 +342,28 @@ struct MapPt {
     }
     void drop_px(int kf) {
         const int i = rec_find(*r, kf);
-        if (i >= 0 && (r->ent[i].flags & MPF_INKF)) rec_clear_flag(*r, i, MPF_INKF);
+        if (i >= 0 && (r->ent[i].flags & MPF_INKF)) rec_clear_flag(*r, i, MPF_INKF, dsc);
     }
-    void note_desc(int kf) {
-        ObsEnt *e = rec_slot(*r, kf);
+    void note_desc(int kf, const Desc &d) {
+        ObsEnt *e = rec_slot(*r, kf, dsc);
         if (!e) {
             mlog->overflow = true;
             return;
         }
         e->flags |= MPF_DESC;
+        std::memcpy(dsc[e - r->ent], d.b, 32);
+    }
+    const uint8_t *desc_of(int kf) const {   // mapKeyframeDescriptors_[kf], or null
+        const int i = rec_find(*r, kf);
+        return i >= 0 && (r->ent[i].flags & MPF_DESC) ? dsc[i] : nullptr;
     }
     void drop_desc(int kf) {
         const int i = rec_find(*r, kf);
-        if (i >= 0 && (r->ent[i].flags & MPF_DESC)) rec_clear_flag(*r, i, MPF_DESC);
+        if (i >= 0 && (r->ent[i].flags & MPF_DESC)) rec_clear_flag(*r, i, MPF_DESC, dsc);
     }
     void drop_all_desc() {
         for (int i = r->n_ent; i-- > 0;)
-            if (r->ent[i].flags & MPF_DESC) rec_clear_flag(*r, i, MPF_DESC);
+            if (r->ent[i].flags & MPF_DESC) rec_clear_flag(*r, i, MPF_DESC, dsc);
     }
 };
 
@@ -506,7 +516,7 @@ private:
             const MapPt *m = mp_raw(ids[i + near_d]);
             if (m) {
                 const char *t = (const char *) m->kf_desc.slot_storage();
-                const size_t bytes = m->kf_desc.slots() * 44;
+                const size_t bytes = m->kf_desc.slots() * 12;
                 for (size_t o = 0; o < bytes && o < 1024; o += 64) __builtin_prefetch(t + o);
             }
         }
@@ -517,6 +527,7 @@ private:
     std::vector<FrameRec *> kf_flat_;
     std::vector<MapPt *> mp_flat_;
     std::vector<MpRec *> mp_rec_;
+    std::vector<int> mp_slot_;   // id -> record / descriptor-table slot (-1: no such point): a stage job names slots without touching the records
     // observer count per map point id (0 = no such point), saturated at 255: the keyframe filter of Mapper::optimize asks "more than
     // four observers?" of every 3-D keypoint of every covisible keyframe; a byte table answers without touching the map point
     std::vector<uint8_t> mp_nobs_;
@@ -528,7 +539,7 @@ private:
         std::vector<double> pt_anchor_uv, pt_inv, obs_uv, lone_inv, auv2, inv2, ouv2;
         std::vector<uint64_t> bad_bits;
         std::vector<uint8_t> kf_used, kc;
-        FlatHash<MapPt *> local_mps;
+        FlatHash<MpRec *> local_mps;   // (the RECORDS: the write-back's loops do not touch the map points' objects)
         FlatSet mps_to_opt;
     } ba_scratch_;
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns

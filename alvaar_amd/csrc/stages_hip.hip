@@ -389,7 +389,7 @@ struct HipStages::Impl {
         return hipDeviceSynchronize();
     }
     uint8_t *trk_in = nullptr;   // see track_reserve
-    bool bar_table = true;       // ALVA_NO_BAR_TABLE=1: the pinned slot table + k_track_stage_in (A/B)
+    bool bar_table = false;      // ALVA_BAR_TABLE=1: the slot table in host-written device memory (see init); default: pinned table + k_track_stage_in
     struct TrackIn {
         float *px;
         uint8_t *is3d;
@@ -567,7 +567,11 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
     m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
     m->poll = getenv("ALVA_NO_POLL") == nullptr;
-    m->bar_table = getenv("ALVA_NO_BAR_TABLE") == nullptr;
+    // OFF by default (ALVA_BAR_TABLE=1 turns it on): -4 us per frame, but with it tests/test_gpu_system.py's
+    // test_group_sessions_equal_their_solo_runs[one_lane] failed in about every second run of the file (a session's SECOND tracking frame
+    // tracked from its first frame's table) and never without it -- while 180 fresh sessions in a row (tools/probes/session_start_probe.py)
+    // and 130 000 write-then-launch rounds (tools/probes/bar_stress.cpp) reproduce nothing.  Unexplained, so not shipped.
+    m->bar_table = getenv("ALVA_BAR_TABLE") != nullptr && getenv("ALVA_NO_BAR_TABLE") == nullptr;
     int rc = hip_stream ? alva_ctx_create(device, hip_stream, 0, &m->ctx) : alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
