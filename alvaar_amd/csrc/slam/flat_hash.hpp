@@ -86,6 +86,16 @@ public:
         return {s, true};
     }
 
+    // the same for a key the caller KNOWS to be absent (it filters repeats itself, e.g. with a mark table): no look-up
+    int insert_new_slot(int k, const V &v = V(), uint8_t tag = 0) {
+        const std::pair<bool, std::size_t> grow = pol_._M_need_rehash(bkt_.size(), count_, 1);
+        if (grow.first) rehash(grow.second);
+        const int s = alloc(k, v, tag);
+        link_front_of_bucket(s);
+        count_++;
+        return s;
+    }
+
     bool erase(int k) {
         const size_t b = bucket_of(k);
         int prev = bkt_[b];
@@ -289,6 +299,7 @@ public:
     KeyIter begin() const { return KeyIter{this, first()}; }
     KeyIter end() const { return KeyIter{this, END}; }
     bool insert(int k) { return insert_slot(k).second; }
+    void insert_new(int k) { insert_new_slot(k); }   // k is known to be absent
     template <class It>
     void insert(It a, It b) {  // _M_insert_range, unique keys: one insert per element
         for (; a != b; ++a) insert_slot(*a);

@@ -263,6 +263,10 @@ void Slam::create_keyframe() {  // map_manager.cpp:12-22
     lap(t_kf[0]);
     extract_keypoints();
     add_keyframe();
+    // this keyframe's descriptor edits so far (one per tracked keypoint + the new points': the bulk of the log) go to the stages NOW: the
+    // replay runs on the device under triangulation / covisibility, and the local-map matching -- which reads the tables -- finds only the
+    // few edits made since in front of it (round 5, first form: the whole log was replayed in front of the matcher, +45 us of its wait)
+    flush_medoids();
     lap(t_kf[4]);
 }
 
@@ -658,7 +662,7 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
                 if (!mark_a_[id] && !mark_b_[id]) {
                     mark_b_[id] = 1;
                     touched_b_.push_back(kid);
-                    local_ids.insert(kid);
+                    local_ids.insert_new(kid);   // (the marks filter repeats: the key is new)
                 }
             }
         } else {

@@ -451,7 +451,7 @@ void Slam::local_ba(FrameRec &new_frame) {
                 if (!mark_a_[(size_t) kid]) {  // a repeated insert would not change the set
                     mark_a_[(size_t) kid] = 1;
                     touched_a_.push_back(kid);
-                    mps_to_opt.insert(kid);
+                    mps_to_opt.insert_new(kid);   // (the marks filter repeats: the key is new)
                 }
         } else {
             add_pose(kfid, *kf, true);

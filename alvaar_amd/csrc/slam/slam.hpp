@@ -518,6 +518,7 @@ private:
                 const char *t = (const char *) m->kf_desc.slot_storage();
                 const size_t bytes = m->kf_desc.slots() * 12;
                 for (size_t o = 0; o < bytes && o < 1024; o += 64) __builtin_prefetch(t + o);
+                __builtin_prefetch((const char *) m->dsc + (size_t) m->r->n_ent * 32, 1);   // where a new keyframe's descriptor bytes will go
             }
         }
     }
