@@ -908,7 +908,8 @@ __global__ void __launch_bounds__(256) k_results(BaResultsArgs R) {
 // over chunks of 256 observations -- per-chunk histograms, one scan, per-chunk scatter with the rank inside the chunk -- so that
 // pairPerm / pairPtr are exactly what BaHost::build's two host passes produce (ascending observation index inside a pair), and the host
 // never walks the observations for it
-constexpr int PAIR_CHUNK = 256;
+constexpr int PAIR_CHUNK = 1024;   // (256 at first: 110 chunks for 28 k observations, and the scan below -- one thread per pair walking the chunks'
+                                   // histograms through dependent global loads -- took 43 us per solve; 28 chunks, read eight at a time: a few us)
 struct PairArgs {
     const int *obsKf, *ptPtr, *ancKf;
     int nObs, nPt, nKf, nChunks;
@@ -942,11 +943,16 @@ __global__ void __launch_bounds__(1024) k_pair_scan(PairArgs A) {
     const int nPairs = A.nKf * A.nKf, k = threadIdx.x;
     int tot = 0;
     if (k < nPairs)
-        for (int c = 0; c < A.nChunks; c++) {
-            int *h = A.hist + (size_t) c * nPairs + k;
-            const int v = *h;
-            *h = tot;
-            tot += v;
+        for (int c0 = 0; c0 < A.nChunks; c0 += 8) {   // eight independent loads in flight, then their running sum
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = c0 + j < A.nChunks ? A.hist[(size_t) (c0 + j) * nPairs + k] : 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (c0 + j < A.nChunks) {
+                    A.hist[(size_t) (c0 + j) * nPairs + k] = tot;
+                    tot += v[j];
+                }
         }
     s_tot[k] = k < nPairs ? tot : 0;
     __syncthreads();
@@ -960,18 +966,23 @@ __global__ void __launch_bounds__(1024) k_pair_scan(PairArgs A) {
         const int base = s_tot[k] - tot;
         A.pairPtr[k] = base;
         if (k == nPairs - 1) A.pairPtr[nPairs] = s_tot[k];
-        for (int c = 0; c < A.nChunks; c++) A.hist[(size_t) c * nPairs + k] += base;
+        for (int c = 0; c < A.nChunks; c++) A.hist[(size_t) c * nPairs + k] += base;   // (independent read-modify-writes: they pipeline)
     }
 }
 __global__ void __launch_bounds__(PAIR_CHUNK) k_pair_fill(PairArgs A) {
-    __shared__ int s_key[PAIR_CHUNK];
+    __shared__ __attribute__((aligned(16))) int s_key[PAIR_CHUNK];
     const int q = blockIdx.x * PAIR_CHUNK + threadIdx.x, nPairs = A.nKf * A.nKf;
     const int key = q < A.nObs ? A.key[q] : -1;
     s_key[threadIdx.x] = key;
     __syncthreads();
     if (q >= A.nObs) return;
     int rank = 0;
-    for (int t = 0; t < (int) threadIdx.x; t++) rank += s_key[t] == key;
+    const int t4 = (int) threadIdx.x & ~3;
+    for (int t = 0; t < t4; t += 4) {   // the chunk's earlier observations with the same pair, four LDS words at a time
+        const int4 k4 = *reinterpret_cast<const int4 *>(&s_key[t]);
+        rank += (k4.x == key) + (k4.y == key) + (k4.z == key) + (k4.w == key);
+    }
+    for (int t = t4; t < (int) threadIdx.x; t++) rank += s_key[t] == key;
     A.pairPerm[A.hist[(size_t) blockIdx.x * nPairs + key] + rank] = q;
 }
 // the outlier sweep's per-observation test (optimizer.cpp:266-309: chi2 above the threshold, or the point behind the camera) as a bit
