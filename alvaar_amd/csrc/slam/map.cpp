@@ -396,13 +396,48 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     }
 }
 
+Slam::~Slam() {
+    if (chunk_ahead_.th.joinable()) chunk_ahead_.th.join();
+}
+
+void Slam::start_chunk_ahead(int index) {
+    static const bool off = std::getenv("ALVA_NO_CHUNK_AHEAD") != nullptr;
+    if (off || chunk_ahead_.th.joinable()) return;
+    chunk_ahead_.index = index;
+    chunk_ahead_.rec = nullptr;
+    chunk_ahead_.dsc.reset();
+    chunk_ahead_.th = std::thread([this, index] {
+        chunk_ahead_.rec = st->mp_arena_chunk(index);
+        const size_t n = (size_t) MP_CHUNK * MP_ENT_CAP;
+        std::unique_ptr<DescBytes[]> d(new DescBytes[n]);
+        std::memset(d.get(), 0, n * sizeof(DescBytes));   // the first touch of its pages happens here
+        chunk_ahead_.dsc = std::move(d);
+    });
+}
+
 bool Slam::ensure_rec_chunk(int slot) {
     const size_t c = (size_t) slot >> MP_CHUNK_SHIFT;
     while (med_log.chunks.size() <= c) {
-        MpRec *chunk = st->mp_arena_chunk((int) med_log.chunks.size());
+        const auto t0 = std::chrono::steady_clock::now();
+        const int index = (int) med_log.chunks.size();
+        MpRec *chunk = nullptr;
+        std::unique_ptr<DescBytes[]> dsc;
+        if (chunk_ahead_.th.joinable()) {
+            chunk_ahead_.th.join();
+            if (chunk_ahead_.index == index) {
+                chunk = chunk_ahead_.rec;
+                dsc = std::move(chunk_ahead_.dsc);
+            }
+        }
+        if (!chunk) chunk = st->mp_arena_chunk(index);
         if (!chunk) return false;
+        if (!dsc) dsc.reset(new DescBytes[(size_t) MP_CHUNK * MP_ENT_CAP]);
         med_log.chunks.push_back(chunk);
-        med_log.desc_chunks.emplace_back(new DescBytes[(size_t) MP_CHUNK * MP_ENT_CAP]);
+        med_log.desc_chunks.push_back(std::move(dsc));
+        static const bool timing = std::getenv("ALVA_ARENA_TIMING") != nullptr;
+        if (timing)
+            std::fprintf(stderr, "[arena] chunk %d: %.0f us\n", index, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        start_chunk_ahead(index + 1);   // the one after it, while this one fills
     }
     return true;
 }

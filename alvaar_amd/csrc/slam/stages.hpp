@@ -153,7 +153,8 @@ struct Stages {
     // Chunk `chunk` of the map layer's record arena (mp_rec.hpp): MP_CHUNK zero-filled MpRec records that stay where they are for the
     // life of the stages object.  The map layer edits them in place; an implementation whose kernels read the records hands out memory
     // they can reach (the HIP stages: pinned host memory, gathered by zero-copy reads).  nullptr = allocation failed.
-    virtual MpRec *mp_arena_chunk(int chunk) {
+    virtual MpRec *mp_arena_chunk(int chunk) {   // (may be called from the map layer's helper thread while the caller's thread READS other chunks)
+        if (arena_.capacity() < 4096) arena_.reserve(4096);   // growth inside the capacity never moves the elements a reader holds
         if ((size_t) chunk >= arena_.size()) arena_.resize((size_t) chunk + 1);
         if (!arena_[(size_t) chunk]) arena_[(size_t) chunk].reset(new MpRec[MP_CHUNK]());
         return arena_[(size_t) chunk].get();

@@ -1538,6 +1538,7 @@ MpRec *HipStages::mp_arena_chunk(int chunk) {
         if (hipMalloc((void **) &m->d_rec_tab, (size_t) Impl::REC_TAB_CAP * sizeof(void *)) != hipSuccess) return nullptr;
         if (hipMemset(m->d_rec_tab, 0, (size_t) Impl::REC_TAB_CAP * sizeof(void *)) != hipSuccess) return nullptr;
     }
+    if (m->rec_chunks.capacity() < (size_t) Impl::REC_TAB_CAP) m->rec_chunks.reserve((size_t) Impl::REC_TAB_CAP);
     while ((int) m->rec_chunks.size() <= chunk) {
         MpRec *c = nullptr;
         if (hipHostMalloc((void **) &c, (size_t) MP_CHUNK * sizeof(MpRec), hipHostMallocDefault) != hipSuccess) return nullptr;
