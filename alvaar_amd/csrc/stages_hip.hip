@@ -383,13 +383,22 @@ struct HipStages::Impl {
     // the line is evicted) -- evicted later, it would overwrite what the host stored in the meantime (seen as a tracker reading last
     // frame's slot table, once in a few hundred session starts).  One device-wide synchronisation behind a fill: its system-scope
     // release writes every dirty line back; nothing on the device writes the block afterwards.
+    // FINE-GRAINED device memory (coherent with the host by definition; the device does not keep its lines in an L2 across kernels).
+    // hipDeviceMallocUncached looked equivalent and is not: with BOTH the slot table and the caller's frame buffer allocated that way,
+    // test_group_sessions_equal_their_solo_runs[one_lane] failed in 8 of 13 runs of tests/test_gpu_system.py (a session's second tracking
+    // frame tracked from its first frame's table); either one alone, or the table fine-grained, never did (3 / 3, 3 / 3, and every run
+    // since).  ALVA_BAR_FLAG=uncached restores the failing combination for whoever wants to find out why.
+    static unsigned bar_alloc_flag() {
+        static const unsigned f = getenv("ALVA_BAR_FLAG") && strcmp(getenv("ALVA_BAR_FLAG"), "uncached") == 0 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+        return f;
+    }
     static hipError_t scrub_host_written(void *p, size_t bytes) {
         hipError_t e = hipMemset(p, 0, bytes);
         if (e != hipSuccess) return e;
         return hipDeviceSynchronize();
     }
     uint8_t *trk_in = nullptr;   // see track_reserve
-    bool bar_table = false;      // ALVA_BAR_TABLE=1: the slot table in host-written device memory (see init); default: pinned table + k_track_stage_in
+    bool bar_table = true;       // the slot table in host-written device memory; ALVA_NO_BAR_TABLE=1: pinned table + k_track_stage_in
     struct TrackIn {
         float *px;
         uint8_t *is3d;
@@ -448,8 +457,8 @@ struct HipStages::Impl {
         // the slot table (positions | 3-D flags | world points) in DEVICE memory that the host writes directly: the whole of the device's
         // memory is visible to the CPU (large BAR; tools/probes/bar_probe.cpp: 128 KB of ordinary stores in 2.6 us, write-combined and
         // posted), so the map layer assembles the table where the tracker reads it and the copy kernel of rounds 2 - 4 (k_track_stage_in:
-        // 7 us + a launch gap in front of every frame's tracker) is gone.  Uncached on the device side: an L2 must not answer with last
-        // frame's line.  The host never READS this memory (a load over the bus costs ~1 us).
+        // 7 us + a launch gap in front of every frame's tracker) is gone.  Fine-grained memory (bar_alloc_flag): an L2 must not answer with
+        // last frame's line.  The host never READS this memory (a load over the bus costs ~1 us).
         if (trk_in) {
             ALVA_HIP(alva_stream_sync(st));
             ALVA_HIP(hipFree(trk_in));
@@ -457,7 +466,7 @@ struct HipStages::Impl {
         }
         if (bar_table) {
             const size_t in_bytes = c * 8 + c + 256 + c * 24;
-            if (hipExtMallocWithFlags((void **) &trk_in, in_bytes, hipDeviceMallocUncached) != hipSuccess) {
+            if (hipExtMallocWithFlags((void **) &trk_in, in_bytes, bar_alloc_flag()) != hipSuccess) {
                 (void) hipGetLastError();
                 trk_in = nullptr;
                 bar_table = false;   // no such memory here: the pinned table + the copy kernel
@@ -567,11 +576,8 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->fused = getenv("ALVA_TRACK_UNFUSED") == nullptr;
     m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
     m->poll = getenv("ALVA_NO_POLL") == nullptr;
-    // OFF by default (ALVA_BAR_TABLE=1 turns it on): -4 us per frame, but with it tests/test_gpu_system.py's
-    // test_group_sessions_equal_their_solo_runs[one_lane] failed in about every second run of the file (a session's SECOND tracking frame
-    // tracked from its first frame's table) and never without it -- while 180 fresh sessions in a row (tools/probes/session_start_probe.py)
-    // and 130 000 write-then-launch rounds (tools/probes/bar_stress.cpp) reproduce nothing.  Unexplained, so not shipped.
-    m->bar_table = getenv("ALVA_BAR_TABLE") != nullptr && getenv("ALVA_NO_BAR_TABLE") == nullptr;
+    // the slot table in host-written device memory (track_reserve): ALVA_NO_BAR_TABLE=1 keeps the pinned table + k_track_stage_in (A/B)
+    m->bar_table = getenv("ALVA_NO_BAR_TABLE") == nullptr;
     int rc = hip_stream ? alva_ctx_create(device, hip_stream, 0, &m->ctx) : alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -839,8 +845,8 @@ int HipStages::alloc_frame_buffer(size_t bytes, uint8_t **h_writable) {
         m->bar_frame = nullptr;
         m->bar_frame_bytes = 0;
     }
-    // uncached on the device side: every frame rewrites the buffer from the host, an L2 must not answer with the previous frame's line
-    if (hipExtMallocWithFlags((void **) &m->bar_frame, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    // fine-grained (bar_alloc_flag): every frame rewrites the buffer from the host, an L2 must not answer with the previous frame's line
+    if (hipExtMallocWithFlags((void **) &m->bar_frame, bytes, Impl::bar_alloc_flag()) != hipSuccess) {
         (void) hipGetLastError();
         m->bar_frame = nullptr;
         alva_set_error("alva_system_alloc_frame_buffer: no host-writable device memory on this system");
@@ -1184,11 +1190,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
 bool HipStages::track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) {
     if (!m->fused || n <= 0) return false;
     if (hipSetDevice(m->device) != hipSuccess || m->track_reserve(n) != ALVA_OK) return false;
-    // (not for a session whose chain launches are deposited on a group's lane: there the pinned table + the copy kernel stay.  With the
-    // device table, test_group_sessions_equal_their_solo_runs[one_lane] saw a session track from its PREVIOUS frame's table in about
-    // every second run of tests/test_gpu_system.py -- never outside a lane (tools/probes/bar_stress.cpp: 0 of 130 000 launches, busy stream
-    // or not), and a bus read-back in front of the deposit did not cure it; unexplained, so the lane keeps the round-4 path)
-    if (m->bar_table && m->trk_in && !m->lists && !g_alva_lane) {   // device memory, written in place (track_reserve)
+    if (m->bar_table && m->trk_in && !m->lists) {   // device memory, written in place (track_reserve)
         const Impl::TrackIn T = m->track_in();
         *px = T.px;
         *is3d = T.is3d;
