@@ -443,6 +443,13 @@ private:
         double bv[3];
     };
     std::vector<ParPair> par_pairs_;
+    // the same pairs as separate arrays (padded to a multiple of 4): the keyframe check's rotate / project / distance loop runs four pairs
+    // per instruction (parallax_of_pairs; the check sits behind the pose with the GPU idle, every frame)
+    struct ParSoA {
+        std::vector<double> bx, by, bz;
+        std::vector<float> ku, kv;
+        std::vector<uint32_t> bits;
+    } par_soa_;
     int par_frame_ = -1, par_kfid_ = -1;   // the frame / keyframe the pairs were collected for
     void prepare_parallax();
     float parallax_of_pairs(const FrameRec &kf);
