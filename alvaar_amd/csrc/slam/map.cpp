@@ -304,14 +304,24 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
     // the reference walks a COPY of the keypoints (getKeypoints, :70) because the body may drop keypoints: a snapshot of the ids does
     ids_scratch_.clear();
     for (const auto &e: cur->kps) ids_scratch_.push_back(e.first);
-    for (int id: ids_scratch_) {
-        MapPt *mp = mp_raw(id);
-        if (!mp) {
+    for (size_t i = 0; i < ids_scratch_.size(); i++) {
+        const int id = ids_scratch_[i];
+        prefetch_mp(ids_scratch_.data(), i, ids_scratch_.size());
+        MpRec *r = rec_raw(id);   // (the record and its side arena alone: the map point's object is not touched)
+        if (!r) {
             remove_obs_from_cur(id);
             continue;
         }
-        mp->obs_insert(next_kf_id);
-        sync_nobs(*mp);
+        ObsEnt *e = rec_slot(*r, next_kf_id, med_log.descs(mp_slot_[(size_t) id]));
+        if (!e) {
+            med_log.overflow = true;
+            continue;
+        }
+        if (!(e->flags & MPF_OBS)) {
+            e->flags |= MPF_OBS;
+            r->n_obs++;
+        }
+        mp_nobs_[(size_t) id] = r->n_obs;
     }
 }
 

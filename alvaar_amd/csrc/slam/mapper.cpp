@@ -212,9 +212,10 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
             const int id = cell_ids[ci];
             // getSurroundingKeypoints keeps ids found in mapKeypoints_ (frame.cpp:333-337); a keypoint whose map point is gone is
             // repaired by the reference on contact (:459-463) -- repaired here up front
-            const MpRec *gm = rec_raw(id);
-            if (!gm) continue;
-            if (!(check_obs_mirror_ ? obs_of(*mp_raw(id), frame.kfid) : rec_in_kf(*gm, frame.kfid))) continue;
+            // (the map point exists <=> its slot of the pointer table is set; that the keyframe holds the keypoint follows from the id
+            // standing in the keyframe's own grid -- the record is not touched for it; the mirror check still asks the containers)
+            if (!rec_raw(id)) continue;
+            if (check_obs_mirror_ && !obs_of(*mp_raw(id), frame.kfid)) continue;
             cell_mp_v.push_back(intern(id));
         }
     }
@@ -512,7 +513,54 @@ void Slam::local_ba(FrameRec &new_frame) {
         int anchor = -1;
         const int q0 = n_obs;
         const MpRec &rec = *recp;
-        const ObsList obs = rec_observers(rec);  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
+        // The common case -- every observing keyframe exists and holds the keypoint -- straight over the record's entries, no snapshot.
+        // The first entry that would need a repair ends it: this point's emission is undone and the reference's own loop (below: a copy
+        // of the observer set, repairs as they come) runs from the start; keyframes that joined meanwhile stay joined, in the same order.
+        bool regular = !check_obs_mirror_;
+        if (regular) {
+            for (int e = 0; e < rec.n_ent; e++) {
+                const ObsEnt &en = rec.ent[e];
+                if (!(en.flags & MPF_OBS)) continue;
+                const int kfid = en.kf;
+                if (kfid > max_kfid) continue;
+                FrameRec *kf = kf_flat[(size_t) kfid];
+                if (!kf) {
+                    std::shared_ptr<FrameRec> sp = keyframe(kfid);
+                    if (!sp) {
+                        regular = false;
+                        break;
+                    }
+                    local_kfs.emplace(kfid, sp);
+                    kf = kf_flat[(size_t) kfid] = sp.get();
+                    add_pose(kfid, *kf, true);
+                    const_kfs.insert(kfid);
+                }
+                if (!(en.flags & MPF_INKF)) {
+                    regular = false;
+                    break;
+                }
+                const int ps = pose_slot[(size_t) kfid];
+                if (anchor < 0) {
+                    anchor = kfid;
+                    double pc[3];
+                    se3_apply(kf->Tcw, rec.X, pc);
+                    anc_slot[(size_t) n_used] = ps;
+                    anc_uv[2 * (size_t) n_used] = (double) en.unpx[0];
+                    anc_uv[2 * (size_t) n_used + 1] = (double) en.unpx[1];
+                    pinv[(size_t) n_used] = 1. / pc[2];
+                    continue;
+                }
+                obs_kf[(size_t) n_obs] = ps;
+                obs_uv[2 * (size_t) n_obs] = (double) en.unpx[0];
+                obs_uv[2 * (size_t) n_obs + 1] = (double) en.unpx[1];
+                n_obs++;
+            }
+            if (!regular) {
+                n_obs = q0;
+                anchor = -1;
+            }
+        }
+        const ObsList obs = regular ? ObsList() : rec_observers(rec);  // snapshot (getObservedKeyframeIds returns a copy): the repair branches edit the set
         int si = 0;   // walks the record's entries (sorted by keyframe like obs) beside the observers; a repair below edits them: start over
         for (int kfid: obs) {
             if (kfid > max_kfid) continue;
