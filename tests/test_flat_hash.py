@@ -23,3 +23,13 @@ def test_cell_index_floor_is_std_floor(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", str(exe), str(ROOT / "tests" / "cpp" / "cell_index_floor.cpp")])
     out = subprocess.check_output([str(exe)], text=True)
     assert out.strip().endswith(" 0 mismatches") and int(out.split()[0]) > 5000000, out
+
+
+def test_map_point_record_behaves_like_the_containers_it_stands_for(tmp_path):
+    """slam/mp_rec.hpp (round 5): one map point's observing keyframes / per-keyframe keypoint facts / descriptor keys as sorted entries of
+    a fixed record + a parallel side arena of descriptor bytes, driven side by side with std::set / std::map through random operation
+    sequences and compared after every step (tests/cpp/mp_rec_vs_std.cpp)"""
+    exe = tmp_path / "mp_rec_vs_std"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", str(exe), str(ROOT / "tests" / "cpp" / "mp_rec_vs_std.cpp")])
+    out = subprocess.check_output([str(exe), "8"], text=True)
+    assert out.startswith("ok ") and int(out.split()[1]) > 1000000, out
