@@ -11,6 +11,8 @@
 // to the reference: orc_match_to_map_flags (== Mapper::matchToMap on flattened maps) and orc_find_plane.
 #include <sys/time.h>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <sstream>
@@ -219,9 +221,227 @@ struct RefStages : Stages {
     }
 };
 
+
+// A tape of stage RESULTS (test tooling, tools/host_replay_cpu.py): the first run of a stream records what every stage call returned, a
+// second Slam over the same frames gets the recorded results back at memcpy cost -- the map layer then runs as it does over a device that
+// answers at once, with its own working set in the caches instead of OpenCV's / Ceres's, and its per-section timers (Slam::t_kf / t_fine)
+// show the HOST's share of a keyframe on a machine without a GPU.  The host logic is deterministic, so the call sequence of the second
+// run equals the first's; every record carries a tag and the sizes it was made with, and a mismatch aborts.
+struct Tape {
+    std::vector<uint8_t> bytes;
+    size_t pos = 0;
+};
+struct MemoStages : Stages {
+    Stages *in_;
+    Tape *tape_;
+    bool replay_;
+    int nest_ = 0;   // inside a composed default (track_begin, match_to_map_rec, local_ba_csr): the fine-grained calls under it just forward
+    MemoStages(Stages *inner, Tape *t, bool replay) : in_(inner), tape_(t), replay_(replay) {}
+    bool live() const { return nest_ == 0; }
+    void tag(uint32_t what, long long a = 0, long long b = 0) {
+        if (!live()) return;
+        long long rec[3] = {(long long) what, a, b};
+        if (!replay_) {
+            put(rec, sizeof(rec));
+            return;
+        }
+        long long got[3];
+        get(got, sizeof(got));
+        if (std::memcmp(rec, got, sizeof(rec))) {
+            std::fprintf(stderr, "syscpu tape: call %u (%lld, %lld) where the recording has %lld (%lld, %lld)\n", what, a, b, got[0], got[1], got[2]);
+            std::abort();
+        }
+    }
+    void put(const void *p, size_t n) {
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        tape_->bytes.insert(tape_->bytes.end(), b, b + n);
+    }
+    void get(void *p, size_t n) {
+        if (tape_->pos + n > tape_->bytes.size()) {
+            std::fprintf(stderr, "syscpu tape: read past the end\n");
+            std::abort();
+        }
+        std::memcpy(p, tape_->bytes.data() + tape_->pos, n);
+        tape_->pos += n;
+    }
+    void io(void *p, size_t n) {   // an output array: recorded after the inner call, delivered on replay
+        if (!live()) return;
+        if (replay_) get(p, n);
+        else put(p, n);
+    }
+    struct Nest {
+        MemoStages *m;
+        explicit Nest(MemoStages *s) : m(s) { m->nest_++; }
+        ~Nest() { m->nest_--; }
+    };
+    bool skip() const { return replay_ && live(); }   // the inner call is not made
+
+    int track_begin(const TrackJob &job, TrackKlt &out) override {
+        tag(1, job.n, job.want_pose);
+        int rc = 0;
+        if (!skip()) {
+            Nest n(this);
+            rc = Stages::track_begin(job, out);
+        } else {
+            out.code.resize((size_t) job.n); out.px.resize((size_t) job.n * 2); out.unpx.resize((size_t) job.n * 2); out.bv.resize((size_t) job.n * 3);
+            out.code_v = out.code.data(); out.px_v = out.px.data(); out.unpx_v = out.unpx.data(); out.bv_v = out.bv.data();
+        }
+        io(&rc, 4);
+        io(const_cast<uint8_t *>(out.code_v), (size_t) job.n);
+        io(const_cast<float *>(out.px_v), (size_t) job.n * 8);
+        io(const_cast<float *>(out.unpx_v), (size_t) job.n * 8);
+        io(const_cast<double *>(out.bv_v), (size_t) job.n * 24);
+        io(&out.p3p_req, 4);
+        io(&out.n_pose, 4);
+        n_pose_ = out.n_pose;
+        want_pose_ = job.want_pose;
+        return rc;
+    }
+    int track_pose_collect(TrackPose &out) override {
+        tag(2, n_pose_, want_pose_);
+        int rc = 0;
+        if (!skip()) {
+            Nest n(this);
+            rc = Stages::track_pose_collect(out);
+        }
+        io(&rc, 4);
+        io(&out.status, 4);
+        io(out.pose7_p3p, 56);
+        io(out.pose7, 56);
+        long long sz[2] = {(long long) out.p3p_outlier.size(), (long long) out.pnp_outlier.size()};
+        io(sz, 16);
+        out.p3p_outlier.resize((size_t) sz[0]);
+        out.pnp_outlier.resize((size_t) sz[1]);
+        io(out.p3p_outlier.data(), (size_t) sz[0]);
+        io(out.pnp_outlier.data(), (size_t) sz[1]);
+        return rc;
+    }
+    int new_frame(const uint8_t *rgba) override { return skip() ? 0 : in_->new_frame(rgba); }
+    void reset_images() override {
+        if (!skip()) in_->reset_images();
+    }
+    int fbklt(int levels, int n, const float *pts, float *prior, uint8_t *status) override {
+        tag(3, n, levels);
+        int rc = skip() ? 0 : in_->fbklt(levels, n, pts, prior, status);
+        io(&rc, 4); io(prior, (size_t) n * 8); io(status, (size_t) n);
+        return rc;
+    }
+    int compute_keypoints(int n, const float *px, float *unpx, double *bv) override {
+        tag(4, n);
+        int rc = skip() ? 0 : in_->compute_keypoints(n, px, unpx, bv);
+        io(&rc, 4); io(unpx, (size_t) n * 8); io(bv, (size_t) n * 24);
+        return rc;
+    }
+    int project_dist(int n, const double *cam_pts, float *px) override {
+        tag(5, n);
+        int rc = skip() ? 0 : in_->project_dist(n, cam_pts, px);
+        io(&rc, 4); io(px, (size_t) n * 8);
+        return rc;
+    }
+    int p3p(int n, const double *bv, const double *wpt, int do_random, double *pose7, int *outliers, int *n_outliers, int *ok) override {
+        tag(6, n);
+        int rc = skip() ? 0 : in_->p3p(n, bv, wpt, do_random, pose7, outliers, n_outliers, ok);
+        io(&rc, 4); io(ok, 4); io(pose7, 56); io(n_outliers, 4); io(outliers, (size_t) *n_outliers * 4);
+        return rc;
+    }
+    int pnp(int n, const double *uv, const double *wpt, double *pose7, int *outliers, int *n_outliers, int *ok) override {
+        tag(7, n);
+        int rc = skip() ? 0 : in_->pnp(n, uv, wpt, pose7, outliers, n_outliers, ok);
+        io(&rc, 4); io(ok, 4); io(pose7, 56); io(n_outliers, 4); io(outliers, (size_t) *n_outliers * 4);
+        return rc;
+    }
+    int five_point(int n, const double *b1, const double *b2, int do_random, double *R, double *t, int *outliers, int *n_outliers, int *ok) override {
+        tag(8, n);
+        int rc = skip() ? 0 : in_->five_point(n, b1, b2, do_random, R, t, outliers, n_outliers, ok);
+        io(&rc, 4); io(ok, 4); io(R, 72); io(t, 24); io(n_outliers, 4); io(outliers, (size_t) *n_outliers * 4);
+        return rc;
+    }
+    int detect(int cell, int n_occ, const float *occupied, int cap, float *pts, int *count) override {
+        tag(9, n_occ, cap);
+        int rc = skip() ? 0 : in_->detect(cell, n_occ, occupied, cap, pts, count);
+        io(&rc, 4); io(count, 4); io(pts, (size_t) (*count > 0 ? *count : 0) * 8);
+        return rc;
+    }
+    int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) override {
+        tag(10, n);
+        int rc = skip() ? 0 : in_->describe(n, pts, desc, valid);
+        io(&rc, 4); io(desc, (size_t) n * 32); io(valid, (size_t) n);
+        return rc;
+    }
+    int triangulate(int n, int n_groups, const double *T36, const int *group, const double *bv_l, const double *bv_r, const float *unpx_l,
+                    const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status, double *parallax) override {
+        tag(11, n, n_groups);
+        int rc = skip() ? 0 : in_->triangulate(n, n_groups, T36, group, bv_l, bv_r, unpx_l, unpx_r, wpt, inv_depth, status, parallax);
+        io(&rc, 4); io(wpt, (size_t) n * 24); io(inv_depth, (size_t) n * 8); io(status, (size_t) n); io(parallax, (size_t) n * 8);
+        return rc;
+    }
+    int match_to_map(int cell_size, int ncw, int grid_cells, const int *cell_ptr, const int *cell_mp, int n_kf, const double *kf_q,
+                     const double *kf_t, int n_mp, const double *mp_wpt, const uint8_t *mp_is3d, const uint8_t *mp_has_desc, const int *obs_ptr,
+                     const int *obs_kf, const float *obs_px, const uint8_t *obs_desc, const uint8_t *obs_has_desc, int frame_kf, int n3d,
+                     int n_local, const int *local, float max_proj_err, float dist_ratio, int *match_of_mp) override {
+        tag(12, n_mp, n_local);
+        int rc = skip() ? 0 : in_->match_to_map(cell_size, ncw, grid_cells, cell_ptr, cell_mp, n_kf, kf_q, kf_t, n_mp, mp_wpt, mp_is3d, mp_has_desc,
+                                                obs_ptr, obs_kf, obs_px, obs_desc, obs_has_desc, frame_kf, n3d, n_local, local, max_proj_err,
+                                                dist_ratio, match_of_mp);
+        io(&rc, 4); io(match_of_mp, (size_t) n_mp * 4);
+        return rc;
+    }
+    int match_to_map_rec(const MatchJob &job, int *match_of_mp) override {
+        tag(13, job.n_mp, job.n_local);
+        int rc = 0;
+        if (!skip()) {
+            Nest n(this);
+            rc = Stages::match_to_map_rec(job, match_of_mp);   // the default's flatten over THIS object's descriptor tables
+        }
+        io(&rc, 4); io(match_of_mp, (size_t) job.n_mp * 4);
+        return rc;
+    }
+    int local_ba(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_anchor_kf, const double *pt_anchor_uv,
+                 double *pt_inv_depth, int n_obs, const int *obs_kf, const int *obs_pt, const double *obs_uv, int max_iters, double *chi2,
+                 uint8_t *depth_pos) override {
+        tag(14, n_pt, n_obs);
+        int rc = skip() ? 0 : in_->local_ba(n_kf, poses7, kf_const, n_pt, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_pt, obs_uv,
+                                            max_iters, chi2, depth_pos);
+        io(&rc, 4); io(poses7, (size_t) n_kf * 56); io(pt_inv_depth, (size_t) n_pt * 8); io(chi2, (size_t) n_obs * 8); io(depth_pos, (size_t) n_obs);
+        return rc;
+    }
+    int local_ba_csr(int n_kf, double *poses7, const uint8_t *kf_const, int n_pt, const int *pt_ptr, const int *pt_anchor_kf,
+                     const double *pt_anchor_uv, double *pt_inv_depth, int n_obs, const int *obs_kf, const double *obs_uv, int max_iters,
+                     double chi2_threshold, uint64_t *bad_bits, int *n_bad) override {
+        tag(15, n_pt, n_obs);
+        int rc = 0;
+        if (!skip()) {
+            Nest n(this);
+            rc = Stages::local_ba_csr(n_kf, poses7, kf_const, n_pt, pt_ptr, pt_anchor_kf, pt_anchor_uv, pt_inv_depth, n_obs, obs_kf, obs_uv, max_iters,
+                                      chi2_threshold, bad_bits, n_bad);
+        }
+        io(&rc, 4); io(poses7, (size_t) n_kf * 56); io(pt_inv_depth, (size_t) n_pt * 8); io(bad_bits, (size_t) (n_obs / 64 + 1) * 8); io(n_bad, 4);
+        return rc;
+    }
+    // the descriptor tables: kept (host build) while recording -- the flatten above reads them; on replay the log goes nowhere, as with
+    // the HIP stages where the replay is a kernel the host only enqueues
+    int medoid_replay(int n_ops, const alva_medoid::MedoidOp *ops, int n_mp, const int *mp_slot, const int *first_op, int slots) override {
+        return replay_ ? 0 : Stages::medoid_replay(n_ops, ops, n_mp, mp_slot, first_op, slots);
+    }
+    int medoid_export(int n, const int *mp_slot, uint8_t *desc32, uint8_t *valid, int *info3) override {
+        tag(16, n, (desc32 ? 1 : 0) | (valid ? 2 : 0) | (info3 ? 4 : 0));
+        int rc = skip() ? 0 : Stages::medoid_export(n, mp_slot, desc32, valid, info3);
+        io(&rc, 4);
+        if (desc32) io(desc32, (size_t) n * 32);
+        if (valid) io(valid, (size_t) n);
+        if (info3) io(info3, (size_t) n * 12);
+        return rc;
+    }
+    int find_plane(int n, const double *pts, const double *pose7_twc, int iterations, float *pose16, int *found) override {
+        return in_->find_plane(n, pts, pose7_twc, iterations, pose16, found);
+    }
+    int n_pose_ = 0, want_pose_ = 0;
+};
+
 struct CpuSys {
     std::unique_ptr<RefStages> stages;
     std::unique_ptr<TraceStages> trace;
+    std::unique_ptr<MemoStages> memo;
     std::unique_ptr<Slam> slam;
 };
 }  // namespace
@@ -248,6 +468,20 @@ void *syscpu_create(int w, int h, double fx, double fy, double cx, double cy, do
     return s;
 }
 void syscpu_destroy(void *p) { delete static_cast<CpuSys *>(p); }
+
+// the stage-result tape (MemoStages above): attach to a FRESH system before its first frame; replay != 0 delivers the recording
+void *syscpu_tape_new() { return new Tape(); }
+void syscpu_tape_free(void *t) { delete static_cast<Tape *>(t); }
+long long syscpu_tape_bytes(void *t) { return (long long) static_cast<Tape *>(t)->bytes.size(); }
+void syscpu_attach_tape(void *p, void *t, int replay) {
+    CpuSys &s = *static_cast<CpuSys *>(p);
+    Tape *tape = static_cast<Tape *>(t);
+    if (replay) tape->pos = 0;
+    s.memo.reset(new MemoStages(s.stages.get(), tape, replay != 0));
+    s.memo->image_width_ = s.slam->st->image_width_;
+    s.memo->image_height_ = s.slam->st->image_height_;
+    s.slam->st = s.memo.get();
+}
 void syscpu_reset(void *p) { static_cast<CpuSys *>(p)->slam->reset(); }
 int syscpu_find_camera_pose(void *p, const uint8_t *rgba, double timestamp, float *pose16, double *pose7) {
     Slam &s = *static_cast<CpuSys *>(p)->slam;

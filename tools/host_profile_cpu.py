@@ -1,7 +1,8 @@
 """Where the host-side map layer spends its time, WITHOUT a GPU and without perf: the product's slam/*.cpp over the reference's CPU stages
 (oracle/_ref: syscpu_*, test infrastructure) on the bench stream under a SIGPROF sampler (tools/sampler/sampler.c).  Only samples whose
 stack passes through alva_slam:: are counted; the stage calls (CPU OpenCV / Ceres under syscpu stages) are excluded by name.
-env: FRAMES (700), WINDOW (400), HZ (2000)"""
+env: FRAMES (700), WINDOW (400), HZ (2000); REPLAY=1: the sampled pass runs over a tape of stage results recorded by a first pass (see
+tools/host_replay_cpu.py) -- the map layer with its own working set in the caches, as over a device; KF_ONLY=1 samples keyframe frames only"""
 import os, sys, time, subprocess, collections
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
@@ -23,14 +24,36 @@ if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.joi
     subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(here, "sampler", "sampler.c"), "-ldl"])
 S = C.CDLL(so)
 s = sysdiff.CpuSystem(w, h, cell)
+kf_frames = None
+if os.environ.get("REPLAY"):
+    s.L.syscpu_tape_new.restype = C.c_void_p
+    s.L.syscpu_attach_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    tape = C.c_void_p(s.L.syscpu_tape_new())
+    s.L.syscpu_attach_tape(s.h, tape, 0)
+    kf_frames, made = set(), 0
+    for k in range(n):
+        s.step(frames[idx(k)], 33.0 * k)
+        now = int(s.state()[11])
+        if now != made:
+            kf_frames.add(k)
+        made = now
+    s = sysdiff.CpuSystem(w, h, cell)
+    s.L.syscpu_attach_tape(s.h, tape, 1)
 for k in range(n - win):
     s.step(frames[idx(k)], 33.0 * k)
+kf_only = bool(os.environ.get("KF_ONLY")) and kf_frames is not None   # sample the frames that made a keyframe in the recorded pass
 S.prof_start(hz)
-cpu0 = time.perf_counter()
+cpu_s, n_sampled = 0.0, 0
 for k in range(n - win, n):
+    on = not kf_only or k in kf_frames
+    S.prof_pause(0 if on else 1)
+    c0 = time.perf_counter()
     s.step(frames[idx(k)], 33.0 * k)
-cpu_s = time.perf_counter() - cpu0
+    if on:
+        cpu_s += time.perf_counter() - c0
+        n_sampled += 1
 S.prof_stop()
+win = max(n_sampled, 1)
 cnt, depth = S.prof_count(), S.prof_depth()
 buf = (C.c_void_p * (cnt * depth))()
 S.prof_get(buf)

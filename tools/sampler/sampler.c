@@ -10,9 +10,11 @@
 #define DEPTH 24
 #define CAP 400000
 static void *g_s[CAP][DEPTH];
-static volatile int g_n;
+static volatile int g_n, g_paused;
+void prof_pause(int on) { g_paused = on; } /* ticks are dropped while paused */
 static void on_prof(int sig) {
     (void) sig;
+    if (g_paused) return;
     int i = __sync_fetch_and_add(&g_n, 1);
     if (i >= CAP) return;
     void *tmp[DEPTH + 2];
@@ -25,6 +27,7 @@ void prof_start(int hz) {
     void *w[4];
     backtrace(w, 4); /* load libgcc's unwinder outside the handler */
     g_n = 0;
+    g_paused = 0;
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
     sa.sa_handler = on_prof;
