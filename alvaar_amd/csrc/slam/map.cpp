@@ -698,17 +698,30 @@ void Slam::update_frame_covisibility(FrameRec &frame) {  // map_manager.cpp:83-1
         mark_a_[(size_t) e.first] = 1;
         touched_a_.push_back(e.first);
     }
+    kf_ptrs_.clear();
+    for (const auto &c: cov) kf_ptrs_.push_back(kf_raw(c.first));
+    FrameRec::refresh_ids3d(kf_ptrs_.data(), kf_ptrs_.size());   // the stale id lists of the keyframes walked below, together
     for (const auto &c: cov) {
         FrameRec *kf = kf_raw(c.first);
         if (kf) {
             kf->covisible[frame.kfid] = c.second;
-            for (int kid: kf->ids3d()) {  // getKeypoints3d(): container order, 3-D only
-                const size_t id = (size_t) kid;
-                if (!mark_a_[id] && !mark_b_[id]) {
-                    mark_b_[id] = 1;
-                    touched_b_.push_back(kid);
-                    local_ids.insert_new(kid);   // (the marks filter repeats: the key is new)
-                }
+            // getKeypoints3d(): container order, 3-D only.  Which of a keyframe's points are new to the set is data the branch predictor
+            // cannot learn (tracked / already listed / new, interleaved): the list is compacted without a branch first -- a keyframe holds
+            // an id once, so the marks only have to be current between keyframes -- and the new ids are inserted in a second pass
+            const std::vector<int> &ids = kf->ids3d();
+            if (fresh_ids_.size() < ids.size() + 1) fresh_ids_.resize(ids.size() + 1);
+            int *fresh = fresh_ids_.data();
+            size_t nf = 0;
+            const uint8_t *ma = mark_a_.data(), *mb = mark_b_.data();
+            for (int kid: ids) {
+                fresh[nf] = kid;
+                nf += (size_t) !(ma[(size_t) kid] | mb[(size_t) kid]);
+            }
+            for (size_t i = 0; i < nf; i++) {
+                const int kid = fresh[i];
+                mark_b_[(size_t) kid] = 1;
+                touched_b_.push_back(kid);
+                local_ids.insert_new(kid);   // (the marks filter repeats: the key is new)
             }
         } else {
             bad.insert(c.first);

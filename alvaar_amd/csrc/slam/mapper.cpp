@@ -316,6 +316,10 @@ void Slam::optimize(const std::shared_ptr<FrameRec> &kf) {  // mapper.cpp:66-142
     if (err_) return;
     if (cfg.keyframe_filtering_ratio < 1.0 && kf->kfid >= 20) {
         const std::map<int, int> cov = kf->covisible;
+        kf_ptrs_.clear();
+        for (const auto &c: cov)
+            if (c.first != 0 && c.first < kf->kfid) kf_ptrs_.push_back(kf_raw(c.first));
+        FrameRec::refresh_ids3d(kf_ptrs_.data(), kf_ptrs_.size());   // (a keyframe removed below is not walked after its removal)
         for (auto it = cov.rbegin(); it != cov.rend(); ++it) {
             const int kfid = it->first;
             if (kfid == 0) break;
@@ -436,6 +440,17 @@ void Slam::local_ba(FrameRec &new_frame) {
     touched_a_.clear();
     bool all_cst = false;
     const int max_kfid = cov.rbegin()->first;
+    {   // the keyframes whose points the loop below collects (same rule): their stale id lists are rebuilt together (FrameRec::refresh_ids3d)
+        kf_ptrs_.clear();
+        for (auto it = cov.rbegin(); it != cov.rend(); ++it) {
+            const int kfid = it->first;
+            FrameRec *kf = kf_raw(kfid);
+            if (!kf) continue;
+            if ((kfid > new_frame.kfid ? (int) new_frame.n_kps : it->second) >= min_cov && kfid > 0) kf_ptrs_.push_back(kf);
+            else break;
+        }
+        FrameRec::refresh_ids3d(kf_ptrs_.data(), kf_ptrs_.size());
+    }
     for (auto it = cov.rbegin(); it != cov.rend(); ++it) {
         const int kfid = it->first;
         int score = it->second;
@@ -448,12 +463,23 @@ void Slam::local_ba(FrameRec &new_frame) {
         if (score >= min_cov && !all_cst && kfid > 0) {
             add_pose(kfid, *kf, false);
             kfs_to_opt.insert(kfid);
-            for (int kid: kf->ids3d())
-                if (!mark_a_[(size_t) kid]) {  // a repeated insert would not change the set
+            {   // (compacted without a branch first, like update_frame_covisibility's list: a repeated insert would not change the set)
+                const std::vector<int> &ids = kf->ids3d();
+                if (fresh_ids_.size() < ids.size() + 1) fresh_ids_.resize(ids.size() + 1);
+                int *fresh = fresh_ids_.data();
+                size_t nf = 0;
+                const uint8_t *ma = mark_a_.data();
+                for (int kid: ids) {
+                    fresh[nf] = kid;
+                    nf += (size_t) !ma[(size_t) kid];
+                }
+                for (size_t i = 0; i < nf; i++) {
+                    const int kid = fresh[i];
                     mark_a_[(size_t) kid] = 1;
                     touched_a_.push_back(kid);
                     mps_to_opt.insert_new(kid);   // (the marks filter repeats: the key is new)
                 }
+            }
         } else {
             add_pose(kfid, *kf, true);
             const_kfs.insert(kfid);
@@ -504,7 +530,7 @@ void Slam::local_ba(FrameRec &new_frame) {
             bad_mps.insert(lmid);
             continue;
         }
-        local_mps.insert_slot(lmid, recp);
+        local_mps.insert_new_slot(lmid, recp);   // (ids of a set: the key is new)
         if ((size_t) n_obs + MP_ENT_CAP > obs_cap) {
             obs_cap *= 2;
             obs_kf.resize(obs_cap);

@@ -193,6 +193,46 @@ struct FrameRec {
         }
         return ids3d_;
     }
+    // The same lists for SEVERAL keyframes, the stale ones rebuilt together: a table's order is a linked list through its slots, one walk
+    // is a chain of dependent loads (≈ an L2 latency per keypoint, 2 600 of them), and the three loops above walk a dozen keyframes a
+    // merge or a triangulation has just edited.  Four chains advance in turn here, so four loads are in flight instead of one.
+    static void refresh_ids3d(FrameRec *const *kfs, size_t n) {
+        constexpr int LANES = 4;
+        typedef FlatHash<FlatNoValue> H;
+        const FrameRec *f[LANES];
+        int cur[LANES], live = 0;
+        size_t next = 0;
+        auto feed = [&](int l) {
+            while (next < n && (!kfs[next] || kfs[next]->ids3d_valid_)) next++;
+            if (next >= n) return false;
+            f[l] = kfs[next++];
+            f[l]->ids3d_.clear();
+            f[l]->ids3d_valid_ = true;   // (also keeps a keyframe named twice in kfs out of a second lane)
+            cur[l] = f[l]->kps.ids.first();
+            return true;
+        };
+        for (int l = 0; l < LANES; l++) {
+            if (!feed(live)) break;
+            live++;
+        }
+        while (live > 0) {
+            for (int l = 0; l < live;) {
+                const int sl = cur[l];
+                if (sl == H::END) {   // this chain is done: the next stale keyframe takes the lane, or the last lane moves in
+                    if (!feed(l)) {
+                        live--;
+                        f[l] = f[live];
+                        cur[l] = cur[live];
+                    }
+                    continue;
+                }
+                const H &h = f[l]->kps.ids;
+                if (h.tag(sl)) f[l]->ids3d_.push_back(h.key(sl));
+                cur[l] = h.next(sl);
+                l++;
+            }
+        }
+    }
     mutable std::vector<int> ids3d_;
     mutable bool ids3d_valid_ = false;
     bool observes(int id) const { return kps.count(id) != 0; }
@@ -531,6 +571,8 @@ private:
             }
         }
     }
+    std::vector<int> fresh_ids_;        // scratch: a keyframe's ids that are new to the set being built
+    std::vector<FrameRec *> kf_ptrs_;   // scratch: the keyframes a loop is about to walk (FrameRec::refresh_ids3d)
     FrameRec *kf_raw(int id) const { return id >= 0 && (size_t) id < kf_flat_.size() ? kf_flat_[(size_t) id] : nullptr; }
     MapPt *mp_raw(int id) const { return id >= 0 && (size_t) id < mp_flat_.size() ? mp_flat_[(size_t) id] : nullptr; }
     MpRec *rec_raw(int id) const { return id >= 0 && (size_t) id < mp_rec_.size() ? mp_rec_[(size_t) id] : nullptr; }   // the record alone (hot loops)

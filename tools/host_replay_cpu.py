@@ -4,7 +4,9 @@ and records what every stage call returned; pass 2 is a fresh map layer over the
 -- what the map layer sees from a device that answers at once.  Its section timers then hold host work only, with the map layer's own
 working set in the caches (tools/host_sections_cpu.py times the same sections with OpenCV / Ceres evicting everything in between: 3 - 4 x
 higher).  The replayed run's state is compared with the recorded run's at the end.
-env: CELL (12), FRAMES (700), WINDOW (300), REPS (3: replays, the best per section is printed too), W/H"""
+env: CELL (12), FRAMES (700), WINDOW (300), REPS (3 replays), W/H; BASE_LIB=<another build of libalva_ref.so>: its replays alternate with the
+in-tree build's over the same tape and the per-section minima of both are printed side by side (this machine's clock drifts by 10 % between
+invocations; only runs inside one invocation compare)"""
 import os, sys, time
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
@@ -26,8 +28,21 @@ names16 = ("prepare", "describe_tracked", "detect", "describe_new", "insert+copy
            "optimize", "(match stage)", "(BA stage)", "(BA build)", "(BA solves+sweep)", "(BA write-back)", "(BA culling)", "(descriptor medoids)")
 
 
-def run(tape, replay):
-    s = sysdiff.CpuSystem(w, h, cell)
+import oracles
+_libs = {}
+
+
+def run(tape, replay, lib=None):
+    if lib:   # the map layer of another build over the same tape (its own copy of every symbol: ctypes opens RTLD_LOCAL)
+        if lib not in _libs:
+            _libs[lib] = C.CDLL(lib)
+        keep, oracles._ref = oracles._ref, _libs[lib]
+        try:
+            s = sysdiff.CpuSystem(w, h, cell)
+        finally:
+            oracles._ref = keep
+    else:
+        s = sysdiff.CpuSystem(w, h, cell)
     L = s.L
     L.syscpu_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.syscpu_timing_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -63,8 +78,13 @@ tape = C.c_void_p(L0.syscpu_tape_new())
 rec = run(tape, False)
 print(f"recorded {n} frames in {rec['total']:.1f} s ({L0.syscpu_tape_bytes(tape) / 1e6:.0f} MB of stage results); last {win}: {rec['nkf']} keyframes; "
       f"keypoints {rec['state'][2]} ({rec['state'][4]} 3-D), keyframes in map {rec['state'][6]}, map points {rec['state'][7]}")
-runs = [run(tape, True) for _ in range(reps)]
-for r in runs:
+base_lib = os.environ.get("BASE_LIB")
+runs, base_runs = [], []
+for _ in range(reps):
+    if base_lib:
+        base_runs.append(run(tape, True, base_lib))
+    runs.append(run(tape, True))
+for r in runs + base_runs:
     assert r["state"] == rec["state"], ("the replayed run ended in another state", r["state"], rec["state"])
 best = lambda f, k: min(r[f][k] for r in runs)
 med = lambda f, k: float(np.median([r[f][k] for r in runs]))
@@ -79,3 +99,12 @@ host = {"prepare": d["prepare"], "create: stages' host side": d["describe_tracke
         "keyframe filter": d["optimize"] - d["(BA build)"] - d["(BA solves+sweep)"] - d["(BA write-back)"] - d["(BA culling)"]}
 print("  HOST-ONLY us per keyframe:", {a: round(b, 1) for a, b in host.items()}, "sum", round(sum(host.values()), 1))
 print("  fine, per keyframe (us | counts):", {a: round(med("fine", a), 1) for a in runs[0]["fine"]})
+if base_runs:
+    bmin = lambda f, k: min(r[f][k] for r in base_runs)
+    print(f"  A/B (minimum of {reps} alternating replays each; base = {base_lib}):")
+    print(f"    wall per frame: base {min(r['wall'] for r in base_runs) * 1e6 / win:.1f}  in-tree {min(r['wall'] for r in runs) * 1e6 / win:.1f}")
+    for f, keys in (("kf", names16), ("fine", [a for a in runs[0]["fine"] if not a.startswith("#")]), ("frame", names8)):
+        for a in keys:
+            b0, b1 = bmin(f, a), best(f, a)
+            if max(b0, b1) >= 5:
+                print(f"    {a:34s} {b0:8.1f} -> {b1:8.1f}  {b1 - b0:+7.1f}")
