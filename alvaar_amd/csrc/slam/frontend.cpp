@@ -461,61 +461,148 @@ float Slam::parallax_of_pairs(const FrameRec &kf) {
     quat_to_rot(kf.Tcw.q, Rkw);
     quat_to_rot(cur->Twc.q, Rwc);
     mat3_mul(Rkw, Rwc, Rkc);
-    std::vector<uint32_t> &all = parallax_bits_;
-    all.clear();
     const FlatHash<FlatNoValue> &cids = cur->kps.ids;
     const double fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy;
     const size_t n = par_pairs_.size();
     ParSoA &S = par_soa_;
+    if (n == 0) return 0.f;
+    S.bits.resize((n + 3) / 4 * 4);
     bool vec = false;
 #if defined(__x86_64__)
     static const bool have_avx2 = __builtin_cpu_supports("avx2") && !std::getenv("ALVA_NO_AVX2");
-    if (have_avx2 && S.bx.size() >= (n + 3) / 4 * 4 && n > 0) {
-        S.bits.resize((n + 3) / 4 * 4);
+    if (have_avx2 && S.bx.size() >= (n + 3) / 4 * 4) {
         parallax_block_avx2(Rkc, fx, fy, cx, cy, S.bx.data(), S.by.data(), S.bz.data(), S.ku.data(), S.kv.data(), (n + 3) / 4 * 4, S.bits.data());
         vec = true;
     }
 #endif
-    for (size_t i = 0; i < n; i++) {
-        const ParPair &pp = par_pairs_[i];
-        if ((size_t) pp.slot >= cids.slots() || !cids.slot_live((size_t) pp.slot) || cids.key(pp.slot) != pp.id) continue;
-        if (vec && !check_obs_mirror_) {
-            all.push_back(S.bits[i]);
-            continue;
+    if (!vec || check_obs_mirror_) {
+        for (size_t i = 0; i < n; i++) {
+            const ParPair &pp = par_pairs_[i];
+            double r[3];
+            mat3_vec(Rkc, pp.bv, r);
+            // FrameRec::project_cam_to_image (camera_calibration.cpp:25-32)
+            const double iz = 1. / r[2], x = r[0] * iz, y = r[1] * iz;
+            const float ux = (float) (fx * x + cx), uy = (float) (fy * y + cy);
+            const float dx = ux - pp.kf_unpx[0], dy = uy - pp.kf_unpx[1];
+            const float par = (float) std::sqrt((double) dx * dx + (double) dy * dy);  // cv::norm(Point2f) -> double, stored in a float
+            uint32_t b;
+            std::memcpy(&b, &par, 4);
+            if (vec && b != S.bits[i]) {   // (ALVA_CHECK_OBS_MIRROR=1: the four-wide loop against the scalar one, every pair of every frame)
+                std::fprintf(stderr, "alva_slam: vectorised parallax differs from the scalar loop (pair %zu: %08x vs %08x)\n", i, S.bits[i], b);
+                std::abort();
+            }
+            S.bits[i] = b;
         }
-        double r[3];
-        mat3_vec(Rkc, pp.bv, r);
-        // FrameRec::project_cam_to_image (camera_calibration.cpp:25-32)
-        const double iz = 1. / r[2], x = r[0] * iz, y = r[1] * iz;
-        const float ux = (float) (fx * x + cx), uy = (float) (fy * y + cy);
-        const float dx = ux - pp.kf_unpx[0], dy = uy - pp.kf_unpx[1];
-        const float par = (float) std::sqrt((double) dx * dx + (double) dy * dy);  // cv::norm(Point2f) -> double, stored in a float
-        uint32_t b;
-        std::memcpy(&b, &par, 4);
-        if (vec && b != S.bits[i]) {   // (ALVA_CHECK_OBS_MIRROR=1: the four-wide loop against the scalar one, every pair of every frame)
-            std::fprintf(stderr, "alva_slam: vectorised parallax differs from the scalar loop (pair %zu: %08x vs %08x)\n", i, S.bits[i], b);
-            std::abort();
-        }
-        all.push_back(b);
     }
-    if (all.empty()) return 0.f;
-    // The caller only COMPARES the median with minAvgRotationParallax and half of it (visual_frontend.cpp:586-593).  When every value lies
-    // on one side of both, so does the median of any subset of them: no sort (non-negative floats order like their bit patterns).
+    // The caller only COMPARES the median with minAvgRotationParallax and with half of it (visual_frontend.cpp:586-593), and the median is
+    // element size / 2 of the SET of values (:661-666).  Both tests are monotone in the value, so with L = the number of DISTINCT values
+    // that fail a test, the median passes it exactly when size / 2 >= L: counting replaces the sort (round 4: a three-pass radix sort of
+    // ~2 400 values on every frame, behind the pose, the GPU idle).  Duplicates are rare but the reference's std::set drops them, so:
+    //   pass 1 counts values and failures WITH duplicates and, in a 64 K-bit table of hashed bit patterns, how many values found their bit
+    //          set (c >= the number of duplicates).  With d duplicates, dL of them among the failing values (0 <= dL <= d <= c), the test is
+    //          (n - d) / 2 - (Ln - dL) >= 0; it lies between (n - c) / 2 - Ln and n / 2 + c - Ln -- same sign at both ends: decided;
+    //   pass 2 (the median's rank within ~2 % of a threshold) counts distinct values exactly in an open-addressed table of the bit
+    //          patterns, stamped with a generation instead of being cleared.
+    // Pairs whose keypoint the pose solve has removed since prepare_parallax are skipped.  Returned: a value of the set that passes the same
+    // tests as the median -- it stands for the median in those two comparisons only.
+    const double t_half = (double) cfg.min_avg_rot_parallax / 2., t_full = (double) cfg.min_avg_rot_parallax;   // (as the caller writes them)
+    std::vector<uint32_t> &all = parallax_bits_;   // the live pairs' values
+    all.resize(n);
+    size_t cnt = 0, coll = 0, fail_half = 0, fail_full = 0;
+    uint32_t lo = 0xffffffffu, hi = 0, lo_pass_half = 0xffffffffu;   // (non-negative floats order like their bit patterns)
     {
-        uint32_t lo = 0xffffffffu, hi = 0;
-        for (uint32_t b: all) {
+        uint64_t *bm = par_bitmap_;
+        std::memset(bm, 0, sizeof(par_bitmap_));
+        uint32_t *out = all.data();
+        for (size_t i = 0; i < n; i++) {
+            const ParPair &pp = par_pairs_[i];
+            if ((size_t) pp.slot >= cids.slots() || !cids.slot_live((size_t) pp.slot) || cids.key(pp.slot) != pp.id) continue;
+            const uint32_t b = S.bits[i];
+            out[cnt++] = b;
+            const uint32_t h = (b * 0x9E3779B1u) >> 16;
+            const uint64_t bit = 1ull << (h & 63);
+            uint64_t &w = bm[h >> 6];
+            coll += (w & bit) != 0;
+            w |= bit;
+            float v;
+            std::memcpy(&v, &b, 4);
+            const bool p_half = (double) v >= t_half, p_full = (double) v >= t_full;
+            fail_half += !p_half;
+            fail_full += !p_full;
             lo = b < lo ? b : lo;
             hi = b > hi ? b : hi;
+            const uint32_t cand = p_half ? b : 0xffffffffu;
+            lo_pass_half = cand < lo_pass_half ? cand : lo_pass_half;
         }
-        const float half = (float) (cfg.min_avg_rot_parallax / 2.), full = cfg.min_avg_rot_parallax;
-        float flo, fhi;
-        std::memcpy(&flo, &lo, 4);
-        std::memcpy(&fhi, &hi, 4);
-        // (the returned value stands for the median in the caller's two comparisons only)
-        if ((double) fhi < (double) half && (double) fhi < (double) full) return fhi;
-        if ((double) flo >= (double) half && (double) flo >= (double) full) return flo;
     }
-    return median_of_distinct(all);
+    all.resize(cnt);
+    if (!cnt) return 0.f;
+    auto decide = [&](size_t failing) -> int {   // 1 = the median passes, 0 = it fails, -1 = depends on the duplicates
+        const long f_min = (long) ((cnt - coll) / 2) - (long) failing, f_max = (long) (cnt / 2) + (long) coll - (long) failing;
+        return f_min >= 0 ? 1 : f_max < 0 ? 0 : -1;
+    };
+    int d_half = decide(fail_half), d_full = decide(fail_full);
+    if (d_half < 0 || d_full < 0 || check_obs_mirror_) {
+        size_t cap = 4096;
+        while (cap < 2 * cnt) cap *= 2;   // at most half full
+        if (par_seen_.size() != cap) {
+            par_seen_.assign(cap, 0);
+            par_gen_ = 0;
+        }
+        if (++par_gen_ == 0) {   // the stamp wrapped: old entries could look current
+            std::fill(par_seen_.begin(), par_seen_.end(), 0);
+            par_gen_ = 1;
+        }
+        const uint64_t gen = (uint64_t) par_gen_ << 32;
+        const size_t mask = cap - 1;
+        int shift = 32;
+        for (size_t c = cap; c > 1; c >>= 1) shift--;
+        uint64_t *seen = par_seen_.data();
+        size_t distinct = 0, dfail_half = 0, dfail_full = 0;
+        for (size_t i = 0; i < cnt; i++) {
+            const uint32_t b = all[i];
+            const uint64_t want = gen | b;
+            size_t h = (size_t) ((b * 0x9E3779B1u) >> shift);
+            bool dup = false;
+            while ((seen[h] >> 32) == (uint64_t) par_gen_) {
+                if (seen[h] == want) {
+                    dup = true;
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+            if (dup) continue;
+            seen[h] = want;
+            float v;
+            std::memcpy(&v, &b, 4);
+            distinct++;
+            dfail_half += !((double) v >= t_half);
+            dfail_full += !((double) v >= t_full);
+        }
+        const int e_half = distinct / 2 >= dfail_half ? 1 : 0, e_full = distinct / 2 >= dfail_full ? 1 : 0;
+        if ((d_half >= 0 && d_half != e_half) || (d_full >= 0 && d_full != e_full) || cnt - distinct > coll) {   // (only reachable in check mode)
+            std::fprintf(stderr, "alva_slam: the bounded median test differs from the exact count (%d %d vs %d %d; %zu duplicates, bound %zu)\n", d_half,
+                         d_full, e_half, e_full, cnt - distinct, coll);
+            std::abort();
+        }
+        d_half = e_half;
+        d_full = e_full;
+    }
+    const bool med_half = d_half != 0, med_full = d_full != 0;
+    // a member of the set with the median's two answers: the largest value passes whatever the median passes; the smallest fails whatever
+    // it fails; "passes half, fails full": the smallest value that passes half is <= the median, so it fails full as well
+    uint32_t pick = med_half && med_full ? hi : !med_half && !med_full ? lo : med_half ? lo_pass_half : hi;
+    float out;
+    std::memcpy(&out, &pick, 4);
+    if (med_full && !med_half) return median_of_distinct(all);   // (thresholds the other way round: not a configuration of the reference)
+    if (check_obs_mirror_) {   // the counting against the sort, every frame of the long CPU differentials
+        const float med = median_of_distinct(all);
+        if (((double) med >= t_half) != ((double) out >= t_half) || ((double) med >= t_full) != ((double) out >= t_full)) {
+            std::fprintf(stderr, "alva_slam: the counted median test differs from the sorted one (median %.9g, stand-in %.9g)\n", (double) med, (double) out);
+            std::abort();
+        }
+    }
+    return out;
 }
 
 bool Slam::check_ready_for_init() {  // visual_frontend.cpp:419-551

@@ -475,6 +475,9 @@ private:
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;
     std::vector<uint32_t> parallax_bits_, parallax_tmp_;
+    std::vector<uint64_t> par_seen_;   // parallax_of_pairs: the bit patterns seen in this call, [generation : 32 | bits : 32]
+    uint32_t par_gen_ = 0;
+    uint64_t par_bitmap_[1024];        // ... and the 64 K-bit table of the first pass (hashed bit patterns)
     // compute_parallax's pairing for the keyframe check, put together WHILE the GPU solves the pose (prepare_parallax): slot in the
     // frame's table, the frame keypoint's bearing and the reference keyframe's undistorted pixel of the same id, contiguous
     struct ParPair {
