@@ -19,3 +19,8 @@ LINES_OUT=12 tools/pmc_traffic.sh ${T}_orb720 python tools/orb_kernels.py 1280 7
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
 cat gpurun_out/${T}_pytest.log
 wc -c gpurun_out/${T}_bench_line.json
+# optional: the sustained loop under the in-tree build against every ab_variants/lib_*.so (ALVA_LIB), alternating, when AB=1
+if [ "${AB:-0}" = 1 ] && ls ab_variants/lib_*.so >/dev/null 2>&1; then
+  bash tools/variant_run.sh "python tools/system_sustained.py" > gpurun_out/${T}_ab.txt 2>&1
+  grep -n "^==\|frames/s" gpurun_out/${T}_ab.txt | cut -c1-160
+fi
