@@ -283,6 +283,142 @@ private:
     }
 };
 
+// std::unordered_set<int> of at most CAP keys on at most NBKT buckets, everything INLINE (no heap): the same state machine as FlatHash on
+// byte-sized index arrays.  For the thousands of tiny tables the map layer keeps one of per map point (the keys of a map point's
+// mapKeyframeDescriptors_: one per keyframe of the window): two heap vectors per table cost an allocation pair per new map point, a
+// copy pair per merge and two cache misses per edit; here a table is 300 bytes in an arena indexed by the map point's slot.  insert()
+// refuses (returns -1, nothing changed but the growth policy's state) what would not fit; the caller fails the frame.
+template <int CAP, int NBKT>
+class SmallFlatSet {
+    static_assert(CAP < 127 && NBKT < 32767, "index widths");
+
+public:
+    static constexpr int END = -1;
+    SmallFlatSet() { reset(); }
+    void reset() {   // a freshly constructed container: one bucket, the policy reset
+        head_ = END; free_ = END; used_ = 0; count_ = 0; nbkt_ = 1;
+        bkt_[0] = EMPTY;
+        pol_ = std::__detail::_Prime_rehash_policy();
+    }
+    size_t size() const { return (size_t) count_; }
+    bool empty() const { return count_ == 0; }
+    size_t bucket_count() const { return (size_t) nbkt_; }
+    int first() const { return head_; }
+    int next(int slot) const { return next_[slot]; }
+    int key(int slot) const { return key_[slot]; }
+    int find_slot(int k) const {
+        const int b = bucket_of(k);
+        const int p = bkt_[b];
+        if (p == EMPTY) return END;
+        for (int s = p == BEFORE_BEGIN ? head_ : next_[p]; s != END && bucket_of(key_[s]) == b; s = next_[s])
+            if (key_[s] == k) return s;
+        return END;
+    }
+    size_t count(int k) const { return find_slot(k) != END ? 1 : 0; }
+    // unordered_set::insert: 1 = inserted, 0 = already there, -1 = does not fit (CAP keys / NBKT buckets)
+    int insert(int k) {
+        if (find_slot(k) != END) return 0;
+        const std::pair<bool, std::size_t> grow = pol_._M_need_rehash((size_t) nbkt_, (size_t) count_, 1);   // _M_insert_unique_node
+        if ((grow.first && grow.second > (size_t) NBKT) || (free_ == END && used_ >= CAP)) return -1;
+        if (grow.first) rehash((int) grow.second);
+        int s = free_;
+        if (s != END) free_ = next_[s];
+        else s = used_++;
+        key_[s] = k;
+        const int b = bucket_of(k);   // _M_insert_bucket_begin
+        if (bkt_[b] != EMPTY) {
+            const int p = bkt_[b];
+            if (p == BEFORE_BEGIN) {
+                next_[s] = (int8_t) head_;
+                head_ = (int16_t) s;
+            } else {
+                next_[s] = next_[p];
+                next_[p] = (int8_t) s;
+            }
+        } else {
+            next_[s] = (int8_t) head_;
+            head_ = (int16_t) s;
+            const int nx = next_[s];
+            if (nx != END) bkt_[bucket_of(key_[nx])] = (int8_t) s;
+            bkt_[b] = BEFORE_BEGIN;
+        }
+        count_++;
+        return 1;
+    }
+    bool erase(int k) {
+        const int b = bucket_of(k);
+        int prev = bkt_[b];
+        if (prev == EMPTY) return false;
+        int s = prev == BEFORE_BEGIN ? head_ : next_[prev];
+        while (s != END && bucket_of(key_[s]) == b && key_[s] != k) {
+            prev = s;
+            s = next_[s];
+        }
+        if (s == END || bucket_of(key_[s]) != b) return false;
+        const int nx = next_[s];   // _M_erase(bkt, prev_n, n)
+        if (prev == bkt_[b]) {
+            const int nb = nx != END ? bucket_of(key_[nx]) : 0;   // _M_remove_bucket_begin
+            if (nx == END || nb != b) {
+                if (nx != END) bkt_[nb] = bkt_[b];
+                if (bkt_[b] == BEFORE_BEGIN) head_ = (int16_t) nx;
+                bkt_[b] = EMPTY;
+            }
+        } else if (nx != END) {
+            const int nb = bucket_of(key_[nx]);
+            if (nb != b) bkt_[nb] = (int8_t) prev;
+        }
+        if (prev == BEFORE_BEGIN) head_ = (int16_t) nx;
+        else next_[prev] = (int8_t) nx;
+        next_[s] = (int8_t) free_;
+        free_ = (int16_t) s;
+        count_--;
+        return true;
+    }
+    void clear() {   // keeps the bucket count and the policy state, like _Hashtable::clear
+        for (int b = 0; b < nbkt_; b++) bkt_[b] = EMPTY;
+        head_ = END; free_ = END; used_ = 0; count_ = 0;
+    }
+
+private:
+    static constexpr int EMPTY = -1, BEFORE_BEGIN = -2;
+    int bucket_of(int k) const { return (int) ((size_t) k % (size_t) nbkt_); }   // std::hash<int> = identity (sign-extended)
+    void rehash(int n) {   // _M_rehash_aux(n, unique keys)
+        int8_t nb[NBKT];
+        for (int b = 0; b < n; b++) nb[b] = EMPTY;
+        int p = head_;
+        head_ = END;
+        int bbegin_bkt = 0;
+        while (p != END) {
+            const int nx = next_[p];
+            const int b = (int) ((size_t) key_[p] % (size_t) n);
+            if (nb[b] == EMPTY) {
+                next_[p] = (int8_t) head_;
+                head_ = (int16_t) p;
+                nb[b] = BEFORE_BEGIN;
+                if (next_[p] != END) nb[bbegin_bkt] = (int8_t) p;
+                bbegin_bkt = b;
+            } else {
+                const int q = nb[b];
+                if (q == BEFORE_BEGIN) {
+                    next_[p] = (int8_t) head_;
+                    head_ = (int16_t) p;
+                } else {
+                    next_[p] = next_[q];
+                    next_[q] = (int8_t) p;
+                }
+            }
+            p = nx;
+        }
+        for (int b = 0; b < n; b++) bkt_[b] = nb[b];
+        nbkt_ = (int16_t) n;
+    }
+    int16_t head_, free_, used_, count_, nbkt_;
+    std::__detail::_Prime_rehash_policy pol_;
+    int key_[CAP];
+    int8_t next_[CAP];
+    int8_t bkt_[NBKT];
+};
+
 // std::unordered_set<int>
 class FlatSet : public FlatHash<FlatNoValue> {
 public:

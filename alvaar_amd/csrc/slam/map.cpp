@@ -217,10 +217,14 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
 
 void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid: medoid_table.hpp add_desc)
     const size_t buckets = kf_desc.bucket_count();
-    if (!kf_desc.insert_slot(kf).second) return;
+    const int ins = kf_desc.insert(kf);
+    if (ins == 0) return;
+    if (ins < 0) {   // more descriptors than a table holds (CAP keys / NBKT buckets, here and in the stages): the frame fails (flush_medoids)
+        mlog->overflow = true;
+        return;
+    }
     note_desc(kf, d);
     r->has_desc = 1;   // desc_ is never empty again until the last observation goes
-    if (kf_desc.size() > (size_t) alva_medoid::CAP || kf_desc.bucket_count() > (size_t) alva_medoid::NBKT) mlog->overflow = true;
     // the bucket count of the rehash this insert caused, if any: the table in the stages replays the list surgery, not the growth policy
     mlog->push(dev_slot, alva_medoid::OP_ADD, kf, d.b, kf_desc.bucket_count() != buckets ? (int) kf_desc.bucket_count() : 0);
 }
@@ -416,12 +420,14 @@ void Slam::start_chunk_ahead(int index) {
     chunk_ahead_.index = index;
     chunk_ahead_.rec = nullptr;
     chunk_ahead_.dsc.reset();
+    chunk_ahead_.keys.reset();
     chunk_ahead_.th = std::thread([this, index] {
         chunk_ahead_.rec = st->mp_arena_chunk(index);
         const size_t n = (size_t) MP_CHUNK * MP_ENT_CAP;
         std::unique_ptr<DescBytes[]> d(new DescBytes[n]);
         std::memset(d.get(), 0, n * sizeof(DescBytes));   // the first touch of its pages happens here
         chunk_ahead_.dsc = std::move(d);
+        chunk_ahead_.keys.reset(new DescKeys[MP_CHUNK]);   // (constructed = touched)
     });
 }
 
@@ -432,18 +438,22 @@ bool Slam::ensure_rec_chunk(int slot) {
         const int index = (int) med_log.chunks.size();
         MpRec *chunk = nullptr;
         std::unique_ptr<DescBytes[]> dsc;
+        std::unique_ptr<DescKeys[]> keys;
         if (chunk_ahead_.th.joinable()) {
             chunk_ahead_.th.join();
             if (chunk_ahead_.index == index) {
                 chunk = chunk_ahead_.rec;
                 dsc = std::move(chunk_ahead_.dsc);
+                keys = std::move(chunk_ahead_.keys);
             }
         }
         if (!chunk) chunk = st->mp_arena_chunk(index);
         if (!chunk) return false;
         if (!dsc) dsc.reset(new DescBytes[(size_t) MP_CHUNK * MP_ENT_CAP]);
+        if (!keys) keys.reset(new DescKeys[MP_CHUNK]);
         med_log.chunks.push_back(chunk);
         med_log.desc_chunks.push_back(std::move(dsc));
+        med_log.key_chunks.push_back(std::move(keys));
         static const bool timing = std::getenv("ALVA_ARENA_TIMING") != nullptr;
         if (timing)
             std::fprintf(stderr, "[arena] chunk %d: %.0f us\n", index, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -533,7 +543,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->r->is3d) return;
     std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
     const ObsList next_kfs = nw->observers(), prev_kfs = prev->observers();
-    const FlatHash<FlatNoValue> prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order
+    const DescKeys prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order (300 bytes on the stack)
     for (int pk: prev_kfs) {
         auto kf = keyframes.find(pk);
         if (kf == keyframes.end()) continue;
@@ -551,7 +561,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
             }
         }
     }
-    for (int se = prev_desc.first(); se != FlatHash<FlatNoValue>::END; se = prev_desc.next(se)) {
+    for (int se = prev_desc.first(); se != DescKeys::END; se = prev_desc.next(se)) {
         const uint8_t *b = prev->desc_of(prev_desc.key(se));   // (the bytes sit beside prev's record entries)
         if (!b) throw std::out_of_range("descriptor bytes");
         Desc d;

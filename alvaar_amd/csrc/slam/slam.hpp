@@ -261,6 +261,7 @@ struct FrameRec {
 // The operation log of the map points' descriptor tables (Stages::medoid_replay, medoid_table.hpp) + the allocator of their slots.
 // The map layer edits the KEY sets (MapPt::kf_desc) at once -- its control flow reads nothing else -- and appends what happened here;
 // Slam::flush_medoids hands the log to the stages once per keyframe.
+typedef SmallFlatSet<alva_medoid::CAP, alva_medoid::NBKT> DescKeys;
 struct MedoidLog {
     std::vector<alva_medoid::MedoidOp> ops;
     std::vector<int> touched;                 // slots with operations in `ops`, in first-touch order
@@ -274,6 +275,9 @@ struct MedoidLog {
     // host-only side arena: MP_ENT_CAP x 32 descriptor bytes per record slot, parallel to the record's entries (mp_rec.hpp DescBytes)
     std::vector<std::unique_ptr<DescBytes[]>> desc_chunks;
     DescBytes *descs(int s) const { return desc_chunks[(size_t) s >> MP_CHUNK_SHIFT].get() + (size_t) (s & (MP_CHUNK - 1)) * MP_ENT_CAP; }
+    // ... and the KEYS of mapKeyframeDescriptors_ in libstdc++'s order, one inline table per slot (flat_hash.hpp SmallFlatSet)
+    std::vector<std::unique_ptr<DescKeys[]>> key_chunks;
+    DescKeys *keys(int s) const { return key_chunks[(size_t) s >> MP_CHUNK_SHIFT].get() + (size_t) (s & (MP_CHUNK - 1)); }
     // a map point's key set outgrew what its table in the stages holds (medoid_table.hpp: CAP descriptors, NBKT buckets): the table would
     // drop the descriptor and diverge from the key set, so the frame fails instead (Slam::flush_medoids, ALVA_ERR_STATE)
     bool overflow = false;
@@ -318,12 +322,13 @@ struct MapPt {
     // iteration order) in libstdc++'s order (flat_hash.hpp); the bytes sit beside the record's entries (merges copy them to the survivor).
     // The distance sums and desc_ itself live in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`,
     // nothing is read back
-    FlatHash<FlatNoValue> kf_desc;
+    DescKeys &kf_desc;   // (in the host-side arena beside `dsc`: found from the slot number, no allocation per map point or per merge)
     MedoidLog *mlog = nullptr;
     int dev_slot = -1;
 
-    MapPt(MedoidLog *log, int slot, int id_, int kf) : r(log->rec(slot)), dsc(log->descs(slot)), mlog(log), dev_slot(slot) {
+    MapPt(MedoidLog *log, int slot, int id_, int kf) : r(log->rec(slot)), dsc(log->descs(slot)), kf_desc(*log->keys(slot)), mlog(log), dev_slot(slot) {
         rec_init(*r, id_, kf, slot);
+        kf_desc.reset();   // whoever had the slot before
         obs_insert(kf);
     }
     MapPt(MedoidLog *log, int slot, int id_, int kf, const Desc &d) : MapPt(log, slot, id_, kf) { add_desc(kf, d); }
@@ -562,16 +567,13 @@ private:
                 __builtin_prefetch(c);
                 __builtin_prefetch(c + 64);
                 __builtin_prefetch(c + 128);
+                const char *t = (const char *) &f->kf_desc;   // the descriptor keys (an address computed from the slot, nothing to chase)
+                for (size_t o = 0; o < sizeof(DescKeys); o += 64) __builtin_prefetch(t + o, 1);
             }
         }
         if (i + near_d < n) {
             const MapPt *m = mp_raw(ids[i + near_d]);
-            if (m) {
-                const char *t = (const char *) m->kf_desc.slot_storage();
-                const size_t bytes = m->kf_desc.slots() * 12;
-                for (size_t o = 0; o < bytes && o < 1024; o += 64) __builtin_prefetch(t + o);
-                __builtin_prefetch((const char *) m->dsc + (size_t) m->r->n_ent * 32, 1);   // where a new keyframe's descriptor bytes will go
-            }
+            if (m) __builtin_prefetch((const char *) m->dsc + (size_t) m->r->n_ent * 32, 1);   // where a new keyframe's descriptor bytes will go
         }
     }
     std::vector<int> fresh_ids_;        // scratch: a keyframe's ids that are new to the set being built
@@ -609,6 +611,7 @@ private:
         int index = -1;
         MpRec *rec = nullptr;
         std::unique_ptr<DescBytes[]> dsc;
+        std::unique_ptr<DescKeys[]> keys;
     } chunk_ahead_;
     void start_chunk_ahead(int index);
 

@@ -133,6 +133,52 @@ int main(int argc, char **argv) {
             }
             if (!same_order_set(sa, fa, "set a", step) || !same_order_set(sb, fb, "set b", step)) return 1;
         }
+        // ---- the inline small set (a map point's descriptor keys: keyframe ids of a sliding window, at most CAP of them): inserts of a
+        // moving key range, erases, clears (bucket count and policy state survive a clear), struct copies, a fresh reset, and inserts
+        // beyond the capacity, which must be refused without a trace
+        {
+            typedef SmallFlatSet<48, 59> Small;
+            std::unordered_set<int> ss;
+            Small fs;
+            int base = seed % 4 == 0 ? -20 : 0;
+            for (long step = 0; step < 40000; step++) {
+                const unsigned op = rng() % 100;
+                const int k = base + (int) (rng() % 70);
+                if (op < 50) {
+                    const bool fits = ss.count(k) || ss.size() < 48;
+                    const int r = fs.insert(k);
+                    if (fits) {
+                        const bool ins = ss.insert(k).second;
+                        if (r != (ins ? 1 : 0)) return std::fprintf(stderr, "small set step %ld: insert says %d\n", step, r), 1;
+                    } else if (r != -1) {   // (a refusal leaves no trace: 59 buckets hold 59 keys, the growth policy had nothing to decide)
+                        return std::fprintf(stderr, "small set step %ld: an insert beyond the capacity was not refused\n", step), 1;
+                    }
+                } else if (op < 85) {
+                    if (ss.erase(k) != (fs.erase(k) ? 1u : 0u)) return std::fprintf(stderr, "small set step %ld: erase\n", step), 1;
+                } else if (op < 88) {
+                    ss.clear();
+                    fs.clear();
+                } else if (op < 92) {   // a copy continues in place of the original (mergeMapPoints walks a copy)
+                    Small c = fs;
+                    fs = c;
+                } else if (op < 94) {   // a new map point takes the slot
+                    ss = std::unordered_set<int>();
+                    fs.reset();
+                } else {
+                    base += (int) (rng() % 3);   // the window slides
+                }
+                g_checks++;
+                if (ss.size() != fs.size() || ss.bucket_count() != fs.bucket_count())
+                    return std::fprintf(stderr, "small set step %ld: size %zu/%zu buckets %zu/%zu\n", step, ss.size(), fs.size(), ss.bucket_count(), fs.bucket_count()), 1;
+                int s2 = fs.first();
+                for (int key: ss) {
+                    if (s2 == Small::END || key != fs.key(s2)) return std::fprintf(stderr, "small set step %ld: order differs\n", step), 1;
+                    s2 = fs.next(s2);
+                }
+                if (s2 != Small::END) return std::fprintf(stderr, "small set step %ld: list too long\n", step), 1;
+                if (fs.count(k) != ss.count(k)) return std::fprintf(stderr, "small set step %ld: count\n", step), 1;
+            }
+        }
     }
     std::printf("ok %ld comparisons\n", g_checks);
     return 0;
