@@ -287,9 +287,9 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
                 size_t min_obs = std::numeric_limits<size_t>::max();
                 bool broke = false;
                 for (int lmid: ids) {
-                    auto it = map_points.find(lmid);
-                    if (it != map_points.end()) {
-                        const size_t nobs = it->second->n_obs();
+                    const MpRec *it = rec_raw(lmid);
+                    if (it) {
+                        const size_t nobs = it->n_obs;
                         if (nobs < min_obs) {
                             to_remove = lmid;
                             min_obs = nobs;
@@ -541,7 +541,8 @@ void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) 
 void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-513
     auto pit = map_points.find(prev_id), nit = map_points.find(new_id);
     if (pit == map_points.end() || nit == map_points.end() || !nit->second->r->is3d) return;
-    std::shared_ptr<MapPt> prev = pit->second, nw = nit->second;
+    std::shared_ptr<MapPt> prev = pit->second;   // (keeps the absorbed point alive to the end of the call)
+    MapPt *nw = nit->second.get();
     const ObsList next_kfs = nw->observers(), prev_kfs = prev->observers();
     const DescKeys prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order (300 bytes on the stack)
     for (int pk: prev_kfs) {
@@ -636,13 +637,13 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
 void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-647
     auto kf = keyframes.find(kfid);
     if (kf != keyframes.end()) kf->second->remove(mp_id);
-    auto m = map_points.find(mp_id);
-    if (m == map_points.end()) return;
-    m->second->drop_px(kfid);
-    m->second->remove_obs(kfid);
-    sync_nobs(*m->second);
+    MapPt *m = mp_raw(mp_id);   // (the id -> object table beside mapPoints_: one load instead of a bucket walk)
+    if (!m) return;
+    m->drop_px(kfid);
+    m->remove_obs(kfid);
+    sync_nobs(*m);
     if (kf != keyframes.end()) {
-        const ObsList obs = m->second->observers();
+        const ObsList obs = m->observers();
         for (int co: obs) {
             auto c = keyframes.find(co);
             if (c != keyframes.end()) {
@@ -661,9 +662,9 @@ void Slam::remove_obs_from_cur(int mp_id) {  // map_manager.cpp:649-679
 }
 
 bool Slam::set_map_point_obs(int mp_id) {  // map_manager.cpp:681-708
-    auto m = map_points.find(mp_id);
-    if (m == map_points.end()) return false;
-    m->second->r->observed = 1;
+    MpRec *m = rec_raw(mp_id);
+    if (!m) return false;
+    m->observed = 1;
     return true;
 }
 
