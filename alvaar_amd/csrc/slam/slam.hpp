@@ -195,9 +195,9 @@ struct FrameRec {
     }
     // The same lists for SEVERAL keyframes, the stale ones rebuilt together: a table's order is a linked list through its slots, one walk
     // is a chain of dependent loads (≈ an L2 latency per keypoint, 2 600 of them), and the three loops above walk a dozen keyframes a
-    // merge or a triangulation has just edited.  Four chains advance in turn here, so four loads are in flight instead of one.
+    // merge or a triangulation has just edited.  Eight chains advance in turn here, so eight loads are in flight instead of one.
     static void refresh_ids3d(FrameRec *const *kfs, size_t n) {
-        constexpr int LANES = 4;
+        constexpr int LANES = 8;
         typedef FlatHash<FlatNoValue> H;
         const FrameRec *f[LANES];
         int cur[LANES], live = 0;
@@ -543,9 +543,19 @@ private:
     // access.  The hash maps stay authoritative (their iteration order is behaviour); every insert / erase / clear updates the mirror.
     // software prefetch for loops that visit map points in an order the hardware cannot predict: the object `far` items ahead, its two
     // small vectors' storage `near` items ahead (their addresses are only known once the object is in cache)
+    // Three stages, because the record's address is itself a load from a table indexed by the id (8 bytes x every id ever handed out:
+    // the table misses too): 2 x far ahead the TABLE entries, far ahead the record (and the object, the key table, ...), whose addresses
+    // the tables -- by then in cache -- give without touching the map point's object.
+    void prefetch_tables(int id) const {
+        if (id >= 0 && (size_t) id < mp_rec_.size()) {
+            __builtin_prefetch(&mp_rec_[(size_t) id]);
+            __builtin_prefetch(&mp_slot_[(size_t) id]);
+        }
+    }
     void prefetch_mp(const int *ids, size_t i, size_t n, size_t far_d = 10) const {
+        if (i + 2 * far_d < n) prefetch_tables(ids[i + 2 * far_d]);
         if (i + far_d < n) {
-            const MpRec *f = rec_raw(ids[i + far_d]);   // the record's address is a table look-up away: header + the first entries
+            const MpRec *f = rec_raw(ids[i + far_d]);   // header + the first entries
             if (f) {
                 const char *c = (const char *) f;
                 __builtin_prefetch(c);
@@ -556,24 +566,34 @@ private:
         }
     }
     // the same for loops that run the descriptor-medoid update of every visited map point (addDesc / removeObservedKeyframeId edit the
-    // key table: 44 bytes per descriptor)
+    // key table and the descriptor bytes beside the record: both found from the slot number)
     void prefetch_mp_desc(const int *ids, size_t i, size_t n, size_t near_d = 4, size_t far_d = 10) const {
+        if (i + 2 * far_d < n) {
+            const int id = ids[i + 2 * far_d];
+            prefetch_tables(id);
+            if (id >= 0 && (size_t) id < mp_flat_.size()) __builtin_prefetch(&mp_flat_[(size_t) id]);
+        }
         if (i + far_d < n) {
-            const MapPt *f = mp_raw(ids[i + far_d]);
-            if (f) {
-                __builtin_prefetch(f);
-                __builtin_prefetch((const char *) f + 64);
-                const char *c = (const char *) f->r;
+            const int id = ids[i + far_d];
+            const MpRec *rc = rec_raw(id);
+            if (rc) {
+                __builtin_prefetch(mp_flat_[(size_t) id]);   // the object (40 bytes of pointers)
+                const char *c = (const char *) rc;
                 __builtin_prefetch(c);
                 __builtin_prefetch(c + 64);
                 __builtin_prefetch(c + 128);
-                const char *t = (const char *) &f->kf_desc;   // the descriptor keys (an address computed from the slot, nothing to chase)
-                for (size_t o = 0; o < sizeof(DescKeys); o += 64) __builtin_prefetch(t + o, 1);
+                const int sl = mp_slot_[(size_t) id];
+                if (sl >= 0) {
+                    const char *t = (const char *) med_log.keys(sl);
+                    for (size_t o = 0; o < sizeof(DescKeys); o += 64) __builtin_prefetch(t + o, 1);
+                }
             }
         }
         if (i + near_d < n) {
-            const MapPt *m = mp_raw(ids[i + near_d]);
-            if (m) __builtin_prefetch((const char *) m->dsc + (size_t) m->r->n_ent * 32, 1);   // where a new keyframe's descriptor bytes will go
+            const int id = ids[i + near_d];
+            const MpRec *rc = rec_raw(id);
+            if (rc && mp_slot_[(size_t) id] >= 0)   // where a new keyframe's descriptor bytes will go
+                __builtin_prefetch((const char *) med_log.descs(mp_slot_[(size_t) id]) + (size_t) rc->n_ent * 32, 1);
         }
     }
     std::vector<int> fresh_ids_;        // scratch: a keyframe's ids that are new to the set being built
