@@ -612,6 +612,8 @@ private:
     bool check_obs_mirror_ = false;
     std::vector<uint8_t> ba_arena_;                           // backing store of local_ba's function-local containers
     struct BaScratch {   // local_ba's problem arrays (see there)
+        std::vector<int> wb_ids;      // the write-back's walk of map_local_plms: ids and records in the container's order
+        std::vector<MpRec *> wb_recs;
         std::vector<int> pt_ids, pt_anchor_slot, obs_kf, pt_ptr, lone_ids, slot_ids, slot_kfid, ptr2, as2, okf2, ids2, from2;
         std::vector<double> pt_anchor_uv, pt_inv, obs_uv, lone_inv, auv2, inv2, ouv2;
         std::vector<uint64_t> bad_bits;
