@@ -263,7 +263,13 @@ void Slam::flush_medoids() {
 
 void Slam::create_keyframe() {  // map_manager.cpp:12-22
     Lap lap;
-    prepare_frame();
+    // prepareFrame (:24-81) is two things: keypoints leave the frame (thinning, map points that are gone), then the new keyframe is
+    // entered into the observer set of every remaining keypoint's map point -- 2 400 records touched, nothing the description of those
+    // keypoints (extractKeypoints' first step, :224-241) depends on.  So the description is STARTED in between and runs on the device
+    // under the second half.
+    prepare_frame_removals();
+    describe_tracked_begin();
+    prepare_frame_observers();
     lap(t_kf[0]);
     extract_keypoints();
     add_keyframe();
@@ -274,7 +280,7 @@ void Slam::create_keyframe() {  // map_manager.cpp:12-22
     lap(t_kf[4]);
 }
 
-void Slam::prepare_frame() {  // map_manager.cpp:24-81
+void Slam::prepare_frame_removals() {  // map_manager.cpp:24-81, the part that edits the frame
     cur->kfid = next_kf_id;
     if ((int) cur->n_kps > cfg.max_keypoints) {
         for (size_t ci = 0; ci < cur->grid.size(); ci++) {
@@ -305,17 +311,22 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
             }
         }
     }
-    // the reference walks a COPY of the keypoints (getKeypoints, :70) because the body may drop keypoints: a snapshot of the ids does
+    // the reference walks a COPY of the keypoints (getKeypoints, :70) because the body may drop keypoints: a snapshot of the ids does.
+    // Keypoints whose map point is gone leave the frame here (:72-76); the others get their observer in prepare_frame_observers -- the two
+    // act on different objects, so taking the removals first changes nothing
     ids_scratch_.clear();
-    for (const auto &e: cur->kps) ids_scratch_.push_back(e.first);
-    for (size_t i = 0; i < ids_scratch_.size(); i++) {
-        const int id = ids_scratch_[i];
-        prefetch_mp(ids_scratch_.data(), i, ids_scratch_.size());
+    for (const auto &e: cur->kps)
+        if (!rec_raw(e.first)) ids_scratch_.push_back(e.first);
+    for (int id: ids_scratch_) remove_obs_from_cur(id);
+}
+
+void Slam::prepare_frame_observers() {  // map_manager.cpp:70-80: addObservedKeyframeId for every keypoint's map point
+    const std::vector<int> &ids = kp_ids_;   // the frame's keypoints in container order (describe_tracked_begin's snapshot)
+    for (size_t i = 0; i < ids.size(); i++) {
+        const int id = ids[i];
+        prefetch_mp(ids.data(), i, ids.size());
         MpRec *r = rec_raw(id);   // (the record and its side arena alone: the map point's object is not touched)
-        if (!r) {
-            remove_obs_from_cur(id);
-            continue;
-        }
+        if (!r) continue;
         ObsEnt *e = rec_slot(*r, next_kf_id, med_log.descs(mp_slot_[(size_t) id]));
         if (!e) {
             med_log.overflow = true;
@@ -329,22 +340,30 @@ void Slam::prepare_frame() {  // map_manager.cpp:24-81
     }
 }
 
-void Slam::extract_keypoints() {  // map_manager.cpp:193-241
+// describeKeypoints (:224-241), first half: the frame's keypoints in container order (getKeypoints()) and the description of their
+// positions in the raw image, enqueued (Stages::describe_begin); extract_keypoints collects it
+void Slam::describe_tracked_begin() {
     const int n = (int) cur->kps.size();
-    std::vector<int> &kp_ids = ids_scratch_;
-    kp_ids.clear();
-    std::vector<float> pts((size_t) n * 2);
-    std::vector<KeyPt *> nodes((size_t) n);   // the keypoints themselves (nothing is inserted or erased before they are used)
-    {
-        size_t i = 0;
-        for (auto e: cur->kps) {  // getKeypoints(): container order
-            kp_ids.push_back(e.first);
-            nodes[i] = &e.second;
-            pts[2 * i] = e.second.px[0];
-            pts[2 * i + 1] = e.second.px[1];
-            i++;
-        }
+    kp_ids_.clear();
+    kp_pts_.resize((size_t) n * 2);
+    kp_nodes_.resize((size_t) n);   // the keypoints themselves (nothing is inserted or erased before they are used)
+    size_t i = 0;
+    for (auto e: cur->kps) {
+        kp_ids_.push_back(e.first);
+        kp_nodes_[i] = &e.second;
+        kp_pts_[2 * i] = e.second.px[0];
+        kp_pts_[2 * i + 1] = e.second.px[1];
+        i++;
     }
+    if (n) fail(st->describe_begin(n, kp_pts_.data()));
+}
+
+void Slam::extract_keypoints() {  // map_manager.cpp:193-241
+    if (err_) return;
+    const int n = (int) kp_ids_.size();
+    const std::vector<int> &kp_ids = kp_ids_;
+    const std::vector<float> &pts = kp_pts_;
+    const std::vector<KeyPt *> &nodes = kp_nodes_;
     // describeKeypoints (:224-241): refresh the descriptors of the tracked keypoints in the raw image.  The detector of :213 needs only
     // the image and the tracked positions, so it is STARTED before the descriptor medoids are updated on the host (nothing it reads
     // or writes is touched by them) and collected afterwards: the two overlap.
@@ -353,7 +372,7 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     std::vector<uint8_t> desc((size_t) n * 32), valid((size_t) n);
     if (n) {
         Lap lap;
-        if (fail(st->describe(n, pts.data(), desc.data(), valid.data()))) return;
+        if (fail(st->describe_end(desc.data(), valid.data()))) return;
         lap(t_kf[1]);
     }
     Lap lap_det;

@@ -523,7 +523,12 @@ private:
 
     // MapManager
     void create_keyframe();
-    void prepare_frame();
+    void prepare_frame_removals();   // prepareFrame, the part that edits the frame (thinning, keypoints whose map point is gone)
+    void describe_tracked_begin();   // the frame's keypoints in container order; their description enqueued
+    void prepare_frame_observers();  // prepareFrame, the observer bookkeeping (under the description)
+    std::vector<int> kp_ids_;
+    std::vector<float> kp_pts_;
+    std::vector<KeyPt *> kp_nodes_;
     void extract_keypoints();
     void add_keyframe();
     void add_map_point(const Desc *d);

@@ -138,6 +138,16 @@ struct Stages {
     // FeatureExtractor::describeFeaturePoints(imageRaw, pts) (map_manager.cpp:204, :218) on the current RAW gray image
     virtual int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) = 0;
 
+    // The same call split like detect(): describe_begin starts it, describe_end delivers what describe() would have; the caller works in
+    // between (the keyframe's observer bookkeeping, Slam::create_keyframe) and makes no other stage call.  Default: nothing happens until
+    // describe_end, which calls describe().
+    virtual int describe_begin(int n, const float *pts) {
+        dsc_n_ = n;
+        dsc_pts_.assign(pts, pts + 2 * (size_t) (n > 0 ? n : 0));
+        return 0;
+    }
+    virtual int describe_end(uint8_t *desc, uint8_t *valid) { return describe(dsc_n_, dsc_pts_.data(), desc, valid); }
+
     // describe() + compute_keypoints() of the SAME points in one call (MapManager::addKeypointsToFrame needs both for the detector's new
     // points, map_manager.cpp:166-191 / :218): the default composes the two; an implementation with a device round trip per call saves one
     virtual int describe_and_compute(int n, const float *pts, uint8_t *desc, uint8_t *valid, float *unpx, double *bv) {
@@ -262,8 +272,8 @@ protected:
     std::vector<alva_medoid::Table> med_tables_;   // (default medoid_* only)
     std::vector<std::unique_ptr<MpRec[]>> arena_;  // (default mp_arena_chunk only)
     std::vector<uint8_t> scratch_;
-    int det_cell_ = 0, det_n_occ_ = 0, det_cap_ = 0;
-    std::vector<float> det_occ_;
+    int det_cell_ = 0, det_n_occ_ = 0, det_cap_ = 0, dsc_n_ = 0;
+    std::vector<float> det_occ_, dsc_pts_;
     // hand-over from the default track_begin to the default track_pose_collect
     struct PendingPose {
         bool active = false;

@@ -490,6 +490,8 @@ struct HipStages::Impl {
     bool pose_pending = false;
     int pose_n = 0;
     alva_detect_pending det_pending{};   // detect_begin -> detect_end
+    int dsc_n = 0;                       // describe_begin -> describe_end: count, where the results will be (pinned staging)
+    const uint8_t *dsc_desc = nullptr, *dsc_valid = nullptr;
     const uint8_t *det_h = nullptr;
     int det_cap = 0;
     // a call plans its buffers first (sizes), then the arenas are grown once and carved
@@ -1384,6 +1386,14 @@ int HipStages::detect_end(float *pts, int *count) {
 }
 
 int HipStages::describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) {
+    const int rc = describe_begin(n, pts);
+    return rc ? rc : describe_end(desc, valid);
+}
+
+// the description enqueued on the stream (results land in the pinned mirror of the plan); the map layer enters the new keyframe into its
+// map points' records meanwhile (no stage call in between: the next one carves the same staging)
+int HipStages::describe_begin(int n, const float *pts) {
+    m->dsc_n = n > 0 ? n : 0;
     if (n <= 0) return ALVA_OK;
     Impl::Plan p;
     const size_t a = p.add((size_t) n * 8), b = p.add((size_t) n * 32), c = p.add((size_t) n);
@@ -1393,9 +1403,18 @@ int HipStages::describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) 
     memcpy(h[a], pts, (size_t) n * 8);
     rc = alva_describe(m->ctx, m->d_gray, (size_t) m->cam.width, m->cam.width, m->cam.height, (const float *) h[a], n, h[b], h[c]);
     if (rc) return rc;
+    m->dsc_desc = h[b];
+    m->dsc_valid = h[c];
+    return ALVA_OK;
+}
+
+int HipStages::describe_end(uint8_t *desc, uint8_t *valid) {
+    const int n = m->dsc_n;
+    m->dsc_n = 0;
+    if (n <= 0) return ALVA_OK;
     ALVA_HIP(alva_stream_sync(m->st));
-    memcpy(desc, h[b], (size_t) n * 32);
-    memcpy(valid, h[c], (size_t) n);
+    memcpy(desc, m->dsc_desc, (size_t) n * 32);
+    memcpy(valid, m->dsc_valid, (size_t) n);
     return ALVA_OK;
 }
 

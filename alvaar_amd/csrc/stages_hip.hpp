@@ -40,6 +40,8 @@ public:
     int detect_begin(int cell, int n_occ, const float *occupied, int cap) override;
     int detect_end(float *pts, int *count) override;
     int describe(int n, const float *pts, uint8_t *desc, uint8_t *valid) override;
+    int describe_begin(int n, const float *pts) override;
+    int describe_end(uint8_t *desc, uint8_t *valid) override;
     int describe_and_compute(int n, const float *pts, uint8_t *desc, uint8_t *valid, float *unpx, double *bv) override;
     int triangulate(int n, int n_groups, const double *T36, const int *group, const double *bv_l, const double *bv_r, const float *unpx_l,
                     const float *unpx_r, double *wpt, double *inv_depth, uint8_t *status, double *parallax) override;
