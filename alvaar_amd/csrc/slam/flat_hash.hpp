@@ -315,9 +315,15 @@ public:
         return END;
     }
     size_t count(int k) const { return find_slot(k) != END ? 1 : 0; }
-    // unordered_set::insert: 1 = inserted, 0 = already there, -1 = does not fit (CAP keys / NBKT buckets)
-    int insert(int k) {
-        if (find_slot(k) != END) return 0;
+    int next_slot() const { return free_ != END ? free_ : used_; }   // the slot the next new key will take (for a caller that prefetches its payload)
+    // unordered_set::insert: 1 = inserted, 0 = already there, -1 = does not fit (CAP keys / NBKT buckets); *slot = the key's slot when it
+    // is (now) in the set -- a key keeps its slot for as long as it stays (a caller may keep per-key payload in a parallel array)
+    int insert(int k, int *slot = nullptr) {
+        const int have = find_slot(k);
+        if (have != END) {
+            if (slot) *slot = have;
+            return 0;
+        }
         const std::pair<bool, std::size_t> grow = pol_._M_need_rehash((size_t) nbkt_, (size_t) count_, 1);   // _M_insert_unique_node
         if ((grow.first && grow.second > (size_t) NBKT) || (free_ == END && used_ >= CAP)) return -1;
         if (grow.first) rehash((int) grow.second);
@@ -343,6 +349,7 @@ public:
             bkt_[b] = BEFORE_BEGIN;
         }
         count_++;
+        if (slot) *slot = s;
         return 1;
     }
     bool erase(int k) {

@@ -2,6 +2,9 @@
 // src/slam/src/frame.cpp, map_point.cpp and map_manager.cpp of the reference -- including the order in which the hash
 // containers are mutated, which is what fixes their iteration order.
 #include "slam.hpp"
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -203,27 +206,26 @@ void MapPt::remove_obs(int kf) {  // map_point.cpp:73-129
     if (r->n_obs == 0) {
         r->has_desc = 0;
         kf_desc.clear();
-        drop_all_desc();
         mlog->push(dev_slot, alva_medoid::OP_CLEAR, -1, nullptr, 0);
         return;
     }
     if (kf == r->anchor_kf) r->anchor_kf = obs_first();
     // :93-128: the distances of the remaining descriptors, the new desc_ -- in the stages' table (medoid_table.hpp remove_desc)
     if (kf_desc.erase(kf)) {
-        drop_desc(kf);
         mlog->push(dev_slot, alva_medoid::OP_REMOVE, kf, nullptr, 0);
     }
 }
 
 void MapPt::add_desc(int kf, const Desc &d) {  // map_point.cpp:131-181 (the descriptor medoid: medoid_table.hpp add_desc)
     const size_t buckets = kf_desc.bucket_count();
-    const int ins = kf_desc.insert(kf);
+    int sl = DescKeys::END;
+    const int ins = kf_desc.insert(kf, &sl);
     if (ins == 0) return;
     if (ins < 0) {   // more descriptors than a table holds (CAP keys / NBKT buckets, here and in the stages): the frame fails (flush_medoids)
         mlog->overflow = true;
         return;
     }
-    note_desc(kf, d);
+    std::memcpy(dsc[sl], d.b, 32);   // mapKeyframeDescriptors_[kf] (the bytes a merge copies to the survivor)
     r->has_desc = 1;   // desc_ is never empty again until the last observation goes
     // the bucket count of the rehash this insert caused, if any: the table in the stages replays the list surgery, not the growth policy
     mlog->push(dev_slot, alva_medoid::OP_ADD, kf, d.b, kf_desc.bucket_count() != buckets ? (int) kf_desc.bucket_count() : 0);
@@ -327,7 +329,7 @@ void Slam::prepare_frame_observers() {  // map_manager.cpp:70-80: addObservedKey
         prefetch_mp(ids.data(), i, ids.size());
         MpRec *r = rec_raw(id);   // (the record and its side arena alone: the map point's object is not touched)
         if (!r) continue;
-        ObsEnt *e = rec_slot(*r, next_kf_id, med_log.descs(mp_slot_[(size_t) id]));
+        ObsEnt *e = rec_slot(*r, next_kf_id);
         if (!e) {
             med_log.overflow = true;
             continue;
@@ -429,6 +431,18 @@ void Slam::extract_keypoints() {  // map_manager.cpp:193-241
     }
 }
 
+void *alva_huge_alloc(size_t bytes) {
+    const size_t huge = (size_t) 2 << 20, sz = (bytes + huge - 1) / huge * huge;
+    void *p = std::aligned_alloc(huge, sz);
+    if (!p) return nullptr;
+#if defined(__linux__)
+    static const bool off = std::getenv("ALVA_NO_HUGE_ARENA") != nullptr;
+    if (!off) madvise(p, sz, MADV_HUGEPAGE);   // advice only: where transparent huge pages are off this is a plain allocation
+#endif
+    std::memset(p, 0, sz);   // the first touch (on the map layer's helper thread for every chunk but the first)
+    return p;
+}
+
 Slam::~Slam() {
     if (chunk_ahead_.th.joinable()) chunk_ahead_.th.join();
 }
@@ -442,11 +456,8 @@ void Slam::start_chunk_ahead(int index) {
     chunk_ahead_.keys.reset();
     chunk_ahead_.th = std::thread([this, index] {
         chunk_ahead_.rec = st->mp_arena_chunk(index);
-        const size_t n = (size_t) MP_CHUNK * MP_ENT_CAP;
-        std::unique_ptr<DescBytes[]> d(new DescBytes[n]);
-        std::memset(d.get(), 0, n * sizeof(DescBytes));   // the first touch of its pages happens here
-        chunk_ahead_.dsc = std::move(d);
-        chunk_ahead_.keys.reset(new DescKeys[MP_CHUNK]);   // (constructed = touched)
+        chunk_ahead_.dsc = HugeArray<DescBlock>(MP_CHUNK);   // (zero-filled / constructed here: the first touch of the pages)
+        chunk_ahead_.keys = HugeArray<DescKeys>(MP_CHUNK);
     });
 }
 
@@ -456,8 +467,8 @@ bool Slam::ensure_rec_chunk(int slot) {
         const auto t0 = std::chrono::steady_clock::now();
         const int index = (int) med_log.chunks.size();
         MpRec *chunk = nullptr;
-        std::unique_ptr<DescBytes[]> dsc;
-        std::unique_ptr<DescKeys[]> keys;
+        HugeArray<DescBlock> dsc;
+        HugeArray<DescKeys> keys;
         if (chunk_ahead_.th.joinable()) {
             chunk_ahead_.th.join();
             if (chunk_ahead_.index == index) {
@@ -468,8 +479,9 @@ bool Slam::ensure_rec_chunk(int slot) {
         }
         if (!chunk) chunk = st->mp_arena_chunk(index);
         if (!chunk) return false;
-        if (!dsc) dsc.reset(new DescBytes[(size_t) MP_CHUNK * MP_ENT_CAP]);
-        if (!keys) keys.reset(new DescKeys[MP_CHUNK]);
+        if (!dsc) dsc = HugeArray<DescBlock>(MP_CHUNK);
+        if (!keys) keys = HugeArray<DescKeys>(MP_CHUNK);
+        if (!dsc || !keys) return false;
         med_log.chunks.push_back(chunk);
         med_log.desc_chunks.push_back(std::move(dsc));
         med_log.key_chunks.push_back(std::move(keys));
@@ -582,8 +594,7 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
         }
     }
     for (int se = prev_desc.first(); se != DescKeys::END; se = prev_desc.next(se)) {
-        const uint8_t *b = prev->desc_of(prev_desc.key(se));   // (the bytes sit beside prev's record entries)
-        if (!b) throw std::out_of_range("descriptor bytes");
+        const uint8_t *b = prev->dsc[se];   // (the copy's slots are the original's: the bytes of key `se`)
         Desc d;
         std::memcpy(d.b, b, 32);
         nw->add_desc(prev_desc.key(se), d);

@@ -288,19 +288,13 @@ std::map<int, int> Slam::match_to_map(FrameRec &frame, float max_proj_err, float
         if (check_obs_mirror_) {   // the records against the authoritative containers: every observer's keypoint, every descriptor key
             const MpRec &mp = *rec_raw(mp_ids[(size_t) m]);
             const MapPt &o = *mp_raw(mp_ids[(size_t) m]);
-            int n_desc = 0;
             for (int e = 0; e < mp.n_ent; e++) {
                 const ObsEnt &en = mp.ent[e];
-                if (en.flags & MPF_DESC) n_desc++;
-                if (((en.flags & MPF_DESC) != 0) != (o.kf_desc.count(en.kf) != 0)) {
-                    std::fprintf(stderr, "alva_slam: descriptor mirror out of sync (map point %d, keyframe %d)\n", mp.id, en.kf);
+                if (!(en.flags & (MPF_OBS | MPF_INKF))) {
+                    std::fprintf(stderr, "alva_slam: record entry without a reason to exist (map point %d, keyframe %d)\n", mp.id, en.kf);
                     std::abort();
                 }
                 if ((en.flags & MPF_OBS) && kf_raw(en.kf)) (void) obs_of(o, en.kf);
-            }
-            if (n_desc != (int) o.kf_desc.size()) {
-                std::fprintf(stderr, "alva_slam: descriptor table of map point %d has keys without a record entry\n", mp.id);
-                std::abort();
             }
         }
     }

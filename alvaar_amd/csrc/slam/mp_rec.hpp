@@ -15,8 +15,8 @@
 //   MPF_OBS   kf is in observedKeyframeIds_                                            (map_point.hpp:60, addObservedKeyframeId / remove...)
 //   MPF_INKF  keyframe kf holds a keypoint with this map point's id; px / unpx = that keypoint's positions (a keyframe's keypoints never
 //             move after MapManager::addKeyframe's copy, map_manager.cpp:243-252)
-//   MPF_DESC  mapKeyframeDescriptors_ has key kf (the bytes live in the descriptor table: medoid_table.hpp on the stages' side,
-//             MapPt::kf_desc on the host)
+//   MPF_DESC  (free for a user of these helpers; the map layer stopped setting it at the end of round 5: the keys of
+//             mapKeyframeDescriptors_ and their bytes live in MapPt::kf_desc / the side arena indexed by the key's slot, slam.hpp)
 // Entries are sorted by keyframe id (a std::set<int> walks ascending keys whatever its history).  MP_ENT_CAP bounds them: the mapper's
 // window is 30 keyframes + keyframe 0 + the one being created; an insert beyond the capacity sets `overflow` and the frame fails.
 #pragma once
@@ -66,9 +66,9 @@ inline int rec_find(const MpRec &r, int kf) {   // index of the entry of keyfram
     }
     return -1;
 }
-// 32 descriptor bytes per entry, parallel to MpRec::ent, HOST ONLY (the device reads descriptors from its own tables): what
-// mapKeyframeDescriptors_ holds for the entry's keyframe where MPF_DESC is set.  Kept beside the entries -- same index, shifted with them --
-// so that a merge finds the bytes it copies to the survivor without a container of its own per map point.
+// 32 descriptor bytes, HOST ONLY (the device reads descriptors from its own tables).  rec_slot / rec_clear_flag can keep an array of them
+// parallel to MpRec::ent (same index, shifted with the entries) for a caller that wants per-entry payload; the map layer indexes its
+// descriptor bytes by the key's slot in its key table instead (nothing to shift) and passes no side array.
 typedef uint8_t DescBytes[32];
 
 // the entry of keyframe kf, created (no flags yet, positions zero) if absent; nullptr when the record is full

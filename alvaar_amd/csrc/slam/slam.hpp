@@ -9,6 +9,8 @@
 // receiving the same sequence of insert / erase / clear / copy operations iterate in the same order, so the state below uses
 // exactly those containers and every mutation follows the reference's sequence.
 #pragma once
+#include <cstdlib>
+#include <new>
 #include <map>
 #include <memory>
 #include <memory_resource>
@@ -262,6 +264,40 @@ struct FrameRec {
 // The map layer edits the KEY sets (MapPt::kf_desc) at once -- its control flow reads nothing else -- and appends what happened here;
 // Slam::flush_medoids hands the log to the stages once per keyframe.
 typedef SmallFlatSet<alva_medoid::CAP, alva_medoid::NBKT> DescKeys;
+// An arena chunk of n objects on 2 MB pages where the kernel grants them (MADV_HUGEPAGE; a plain allocation otherwise): the host-side
+// arenas are walked by map point, one or two objects per 4 KB page -- with small pages every touch is a TLB miss on top of the cache miss
+// (three arenas + the object: ~7 000 distinct pages per keyframe against ~2 000 second-level TLB entries).
+void *alva_huge_alloc(size_t bytes);   // (map.cpp) zero-filled, 2 MB aligned; free()
+template <class T>
+struct HugeArray {
+    T *p = nullptr;
+    HugeArray() {}
+    explicit HugeArray(size_t n) : p(static_cast<T *>(alva_huge_alloc(n * sizeof(T)))) {
+        if (p)
+            for (size_t i = 0; i < n; i++) new (p + i) T;   // (trivial for bytes; the key tables set their one-bucket state)
+    }
+    HugeArray(HugeArray &&o) : p(o.p) { o.p = nullptr; }
+    HugeArray &operator=(HugeArray &&o) {
+        if (this != &o) {
+            reset();
+            p = o.p;
+            o.p = nullptr;
+        }
+        return *this;
+    }
+    HugeArray(const HugeArray &) = delete;
+    HugeArray &operator=(const HugeArray &) = delete;
+    ~HugeArray() { reset(); }
+    void reset() {
+        std::free(p);   // (the arenas' element types have trivial destructors)
+        p = nullptr;
+    }
+    T *get() const { return p; }
+    explicit operator bool() const { return p != nullptr; }
+};
+struct DescBlock {   // the descriptor bytes of one record slot
+    DescBytes d[alva_medoid::CAP];
+};
 struct MedoidLog {
     std::vector<alva_medoid::MedoidOp> ops;
     std::vector<int> touched;                 // slots with operations in `ops`, in first-touch order
@@ -272,11 +308,12 @@ struct MedoidLog {
     // `s` belongs to the map point that holds descriptor-table slot `s`
     std::vector<MpRec *> chunks;
     MpRec *rec(int s) const { return chunks[(size_t) s >> MP_CHUNK_SHIFT] + (s & (MP_CHUNK - 1)); }
-    // host-only side arena: MP_ENT_CAP x 32 descriptor bytes per record slot, parallel to the record's entries (mp_rec.hpp DescBytes)
-    std::vector<std::unique_ptr<DescBytes[]>> desc_chunks;
-    DescBytes *descs(int s) const { return desc_chunks[(size_t) s >> MP_CHUNK_SHIFT].get() + (size_t) (s & (MP_CHUNK - 1)) * MP_ENT_CAP; }
+    // host-only side arena: the descriptor BYTES of mapKeyframeDescriptors_, alva_medoid::CAP x 32 per record slot, indexed by the key's
+    // slot in the key table below (a key keeps its slot while it stays: nothing moves when other keys come and go)
+    std::vector<HugeArray<DescBlock>> desc_chunks;
+    DescBytes *descs(int s) const { return desc_chunks[(size_t) s >> MP_CHUNK_SHIFT].get()[(size_t) (s & (MP_CHUNK - 1))].d; }
     // ... and the KEYS of mapKeyframeDescriptors_ in libstdc++'s order, one inline table per slot (flat_hash.hpp SmallFlatSet)
-    std::vector<std::unique_ptr<DescKeys[]>> key_chunks;
+    std::vector<HugeArray<DescKeys>> key_chunks;
     DescKeys *keys(int s) const { return key_chunks[(size_t) s >> MP_CHUNK_SHIFT].get() + (size_t) (s & (MP_CHUNK - 1)); }
     // a map point's key set outgrew what its table in the stages holds (medoid_table.hpp: CAP descriptors, NBKT buckets): the table would
     // drop the descriptor and diverge from the key set, so the frame fails instead (Slam::flush_medoids, ALVA_ERR_STATE)
@@ -317,7 +354,7 @@ struct MedoidLog {
 // updates the entry's MPF_INKF half, and ALVA_CHECK_OBS_MIRROR=1 compares every read with the authoritative containers.
 struct MapPt {
     MpRec *r = nullptr;
-    DescBytes *dsc = nullptr;   // the record's descriptor bytes (host-only side arena, parallel to r->ent)
+    DescBytes *dsc = nullptr;   // the descriptor bytes (host-only side arena), indexed by the key's slot in kf_desc
     // the KEYS of mapKeyframeDescriptors_ (the reference edits it and mapDescriptorsDist_ together: same keys, same sequence => same
     // iteration order) in libstdc++'s order (flat_hash.hpp); the bytes sit beside the record's entries (merges copy them to the survivor).
     // The distance sums and desc_ itself live in the stages' table `dev_slot` (medoid_table.hpp): every edit below is logged in `mlog`,
@@ -352,7 +389,7 @@ struct MapPt {
         return -1;
     }
     void obs_insert(int kf) {
-        ObsEnt *e = rec_slot(*r, kf, dsc);
+        ObsEnt *e = rec_slot(*r, kf);
         if (!e) {
             mlog->overflow = true;
             return;
@@ -364,7 +401,7 @@ struct MapPt {
     }
     void obs_erase(int kf) {
         const int i = rec_find(*r, kf);
-        if (i >= 0 && (r->ent[i].flags & MPF_OBS)) rec_clear_flag(*r, i, MPF_OBS, dsc);
+        if (i >= 0 && (r->ent[i].flags & MPF_OBS)) rec_clear_flag(*r, i, MPF_OBS);
     }
     ObsList observers() const { return rec_observers(*r); }   // getObservedKeyframeIds(): a copy
     void remove_obs(int kf);
@@ -377,7 +414,7 @@ struct MapPt {
         return i >= 0 && (r->ent[i].flags & MPF_INKF) ? &r->ent[i] : nullptr;
     }
     void note_px(int kf, const KeyPt &k) {
-        ObsEnt *e = rec_slot(*r, kf, dsc);
+        ObsEnt *e = rec_slot(*r, kf);
         if (!e) {
             mlog->overflow = true;
             return;
@@ -388,28 +425,12 @@ struct MapPt {
     }
     void drop_px(int kf) {
         const int i = rec_find(*r, kf);
-        if (i >= 0 && (r->ent[i].flags & MPF_INKF)) rec_clear_flag(*r, i, MPF_INKF, dsc);
+        if (i >= 0 && (r->ent[i].flags & MPF_INKF)) rec_clear_flag(*r, i, MPF_INKF);
     }
-    void note_desc(int kf, const Desc &d) {
-        ObsEnt *e = rec_slot(*r, kf, dsc);
-        if (!e) {
-            mlog->overflow = true;
-            return;
-        }
-        e->flags |= MPF_DESC;
-        std::memcpy(dsc[e - r->ent], d.b, 32);
-    }
-    const uint8_t *desc_of(int kf) const {   // mapKeyframeDescriptors_[kf], or null
-        const int i = rec_find(*r, kf);
-        return i >= 0 && (r->ent[i].flags & MPF_DESC) ? dsc[i] : nullptr;
-    }
-    void drop_desc(int kf) {
-        const int i = rec_find(*r, kf);
-        if (i >= 0 && (r->ent[i].flags & MPF_DESC)) rec_clear_flag(*r, i, MPF_DESC, dsc);
-    }
-    void drop_all_desc() {
-        for (int i = r->n_ent; i-- > 0;)
-            if (r->ent[i].flags & MPF_DESC) rec_clear_flag(*r, i, MPF_DESC, dsc);
+    // mapKeyframeDescriptors_[kf]'s bytes: at the key's slot of kf_desc (add_desc stores them; an erased key's bytes are simply dead)
+    const uint8_t *desc_of(int kf) const {
+        const int sl = kf_desc.find_slot(kf);
+        return sl != DescKeys::END ? dsc[sl] : nullptr;
     }
 };
 
@@ -594,11 +615,10 @@ private:
                 }
             }
         }
-        if (i + near_d < n) {
+        if (i + near_d < n) {   // where a new keyframe's descriptor bytes will go: the slot its key will take (the key table is in cache by now)
             const int id = ids[i + near_d];
-            const MpRec *rc = rec_raw(id);
-            if (rc && mp_slot_[(size_t) id] >= 0)   // where a new keyframe's descriptor bytes will go
-                __builtin_prefetch((const char *) med_log.descs(mp_slot_[(size_t) id]) + (size_t) rc->n_ent * 32, 1);
+            const int sl = id >= 0 && (size_t) id < mp_slot_.size() ? mp_slot_[(size_t) id] : -1;
+            if (sl >= 0) __builtin_prefetch((const char *) med_log.descs(sl) + (size_t) med_log.keys(sl)->next_slot() * 32, 1);
         }
     }
     std::vector<int> fresh_ids_;        // scratch: a keyframe's ids that are new to the set being built
@@ -637,8 +657,8 @@ private:
         std::thread th;
         int index = -1;
         MpRec *rec = nullptr;
-        std::unique_ptr<DescBytes[]> dsc;
-        std::unique_ptr<DescKeys[]> keys;
+        HugeArray<DescBlock> dsc;
+        HugeArray<DescKeys> keys;
     } chunk_ahead_;
     void start_chunk_ahead(int index);
 
