@@ -56,6 +56,7 @@ void Slam::reset() {  // System::reset (system.cpp:42-55)
     // MapManager::reset (map_manager.cpp:710-722)
     next_mp_id = next_kf_id = n_map_points = n_keyframes = 0;
     keyframes.clear();
+    for (auto e: map_points) destroy_map_point(e.second);   // (mapMapPoints_.clear(): every map point goes, in the container's order)
     map_points.clear();
     kf_flat_.clear();
     mp_flat_.clear();

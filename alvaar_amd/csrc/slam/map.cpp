@@ -238,10 +238,6 @@ std::shared_ptr<FrameRec> Slam::keyframe(int id) const {
     auto it = keyframes.find(id);
     return it == keyframes.end() ? nullptr : it->second;
 }
-std::shared_ptr<MapPt> Slam::map_point(int id) const {
-    auto it = map_points.find(id);
-    return it == map_points.end() ? nullptr : it->second;
-}
 
 void Slam::flush_medoids() {
     MedoidLog &L = med_log;
@@ -454,10 +450,12 @@ void Slam::start_chunk_ahead(int index) {
     chunk_ahead_.rec = nullptr;
     chunk_ahead_.dsc.reset();
     chunk_ahead_.keys.reset();
+    chunk_ahead_.objs.reset();
     chunk_ahead_.th = std::thread([this, index] {
         chunk_ahead_.rec = st->mp_arena_chunk(index);
         chunk_ahead_.dsc = HugeArray<DescBlock>(MP_CHUNK);   // (zero-filled / constructed here: the first touch of the pages)
         chunk_ahead_.keys = HugeArray<DescKeys>(MP_CHUNK);
+        chunk_ahead_.objs = HugeArray<MapPtBox>(MP_CHUNK);
     });
 }
 
@@ -469,22 +467,26 @@ bool Slam::ensure_rec_chunk(int slot) {
         MpRec *chunk = nullptr;
         HugeArray<DescBlock> dsc;
         HugeArray<DescKeys> keys;
+        HugeArray<MapPtBox> objs;
         if (chunk_ahead_.th.joinable()) {
             chunk_ahead_.th.join();
             if (chunk_ahead_.index == index) {
                 chunk = chunk_ahead_.rec;
                 dsc = std::move(chunk_ahead_.dsc);
                 keys = std::move(chunk_ahead_.keys);
+                objs = std::move(chunk_ahead_.objs);
             }
         }
         if (!chunk) chunk = st->mp_arena_chunk(index);
         if (!chunk) return false;
         if (!dsc) dsc = HugeArray<DescBlock>(MP_CHUNK);
         if (!keys) keys = HugeArray<DescKeys>(MP_CHUNK);
-        if (!dsc || !keys) return false;
+        if (!objs) objs = HugeArray<MapPtBox>(MP_CHUNK);
+        if (!dsc || !keys || !objs) return false;
         med_log.chunks.push_back(chunk);
         med_log.desc_chunks.push_back(std::move(dsc));
         med_log.key_chunks.push_back(std::move(keys));
+        mp_obj_chunks_.push_back(std::move(objs));
         static const bool timing = std::getenv("ALVA_ARENA_TIMING") != nullptr;
         if (timing)
             std::fprintf(stderr, "[arena] chunk %d: %.0f us\n", index, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -529,15 +531,15 @@ void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
         fail(-3);
         return;
     }
-    std::shared_ptr<MapPt> mp = d ? std::make_shared<MapPt>(&med_log, slot, next_mp_id, next_kf_id, *d) : std::make_shared<MapPt>(&med_log, slot, next_mp_id, next_kf_id);
-    map_points.emplace(next_mp_id, mp);
+    MapPt *mp = d ? new (mp_box_fresh(slot)) MapPt(&med_log, slot, next_mp_id, next_kf_id, *d) : new (mp_box_fresh(slot)) MapPt(&med_log, slot, next_mp_id, next_kf_id);
+    map_points.insert_slot(next_mp_id, mp);
     if (mp_flat_.size() <= (size_t) next_mp_id) {
         mp_flat_.resize((size_t) next_mp_id + 4096, nullptr);
         mp_rec_.resize(mp_flat_.size(), nullptr);
         mp_slot_.resize(mp_flat_.size(), -1);
         mp_nobs_.resize(mp_flat_.size(), 0);
     }
-    mp_flat_[(size_t) next_mp_id] = mp.get();
+    mp_flat_[(size_t) next_mp_id] = mp;
     mp_rec_[(size_t) next_mp_id] = mp->r;
     mp_slot_[(size_t) next_mp_id] = slot;
     sync_nobs(*mp);
@@ -570,10 +572,8 @@ void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) 
 }
 
 void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-513
-    auto pit = map_points.find(prev_id), nit = map_points.find(new_id);
-    if (pit == map_points.end() || nit == map_points.end() || !nit->second->r->is3d) return;
-    std::shared_ptr<MapPt> prev = pit->second;   // (keeps the absorbed point alive to the end of the call)
-    MapPt *nw = nit->second.get();
+    MapPt *prev = mp_raw(prev_id), *nw = mp_raw(new_id);   // (the id -> object table: same membership as mapMapPoints_)
+    if (!prev || !nw || !nw->r->is3d) return;
     const ObsList next_kfs = nw->observers(), prev_kfs = prev->observers();
     const DescKeys prev_desc = prev->kf_desc;   // a copy of the keys, in the original's order (300 bytes on the stack)
     for (int pk: prev_kfs) {
@@ -614,7 +614,8 @@ void Slam::merge_map_points(int prev_id, int new_id) {  // map_manager.cpp:428-5
     mp_rec_[(size_t) prev_id] = nullptr;
     mp_slot_[(size_t) prev_id] = -1;
     mp_nobs_[(size_t) prev_id] = 0;
-    map_points.erase(pit);
+    map_points.erase(prev_id);
+    destroy_map_point(prev);   // (the absorbed point lived to the end of the call, like the reference's local shared_ptr)
     n_merges++;
 }
 
@@ -643,9 +644,8 @@ void Slam::remove_keyframe(int kfid) {  // map_manager.cpp:515-557
 }
 
 void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
-    auto it = map_points.find(id);
-    if (it == map_points.end()) return;
-    std::shared_ptr<MapPt> mp = it->second;
+    MapPt *mp = mp_raw(id);
+    if (!mp) return;
     const ObsList obs = mp->observers();
     for (int kf: obs) {
         auto k = keyframes.find(kf);
@@ -660,8 +660,9 @@ void Slam::remove_map_point(int id) {  // map_manager.cpp:559-613
     mp_rec_[(size_t) id] = nullptr;
     mp_slot_[(size_t) id] = -1;
     mp_nobs_[(size_t) id] = 0;
+    map_points.erase(id);
     if (defer_mp_free_) mp_graveyard_.push_back(mp);
-    map_points.erase(it);
+    else destroy_map_point(mp);
 }
 
 void Slam::remove_map_point_obs(int mp_id, int kfid) {  // map_manager.cpp:615-647

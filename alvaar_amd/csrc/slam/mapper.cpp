@@ -416,6 +416,7 @@ void Slam::local_ba(FrameRec &new_frame) {
         Slam *s;
         ~Undefer() {
             s->defer_mp_free_ = false;
+            for (MapPt *mp: s->mp_graveyard_) s->destroy_map_point(mp);
             s->mp_graveyard_.clear();
         }
     } undefer{this};

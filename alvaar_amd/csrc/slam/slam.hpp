@@ -9,6 +9,9 @@
 // receiving the same sequence of insert / erase / clear / copy operations iterate in the same order, so the state below uses
 // exactly those containers and every mutation follows the reference's sequence.
 #pragma once
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#endif
 #include <cstdlib>
 #include <new>
 #include <map>
@@ -459,7 +462,11 @@ public:
     std::vector<int> med_firsts_;
     std::shared_ptr<FrameRec> cur;                                   // currFrame_
     std::unordered_map<int, std::shared_ptr<FrameRec>> keyframes;    // MapManager::mapKeyframes_
-    std::unordered_map<int, std::shared_ptr<MapPt>> map_points;      // MapManager::mapMapPoints_
+    // MapManager::mapMapPoints_ (std::unordered_map<int, shared_ptr<MapPoint>>): the same iteration order on flat arrays (flat_hash.hpp;
+    // getCurrentFrameMapPoints walks it), the objects constructed in place in a slot-indexed arena beside the records (mp_obj_chunks_) --
+    // no allocation per map point.  An object dies when the reference's last shared_ptr would: at the end of the call that removed it
+    // from the map, or at the end of local_ba for the ones removed inside it (mp_graveyard_).
+    FlatHash<MapPt *> map_points;
     int next_mp_id = 0, next_kf_id = 0, n_map_points = 0, n_keyframes = 0;
     bool ready_for_init = false, reset_requested = false;           // State::slamReadyForInit_ / slamResetRequested_
     bool p3p_req = false;
@@ -564,7 +571,6 @@ private:
     bool set_map_point_obs(int mp_id);
     void update_frame_covisibility(FrameRec &frame);
     std::shared_ptr<FrameRec> keyframe(int id) const;
-    std::shared_ptr<MapPt> map_point(int id) const;
     // The same look-ups through flat mirrors of the two hash maps: ids are handed out consecutively, so id -> object is an array
     // access.  The hash maps stay authoritative (their iteration order is behaviour); every insert / erase / clear updates the mirror.
     // software prefetch for loops that visit map points in an order the hardware cannot predict: the object `far` items ahead, its two
@@ -647,7 +653,26 @@ private:
         FlatSet mps_to_opt;
     } ba_scratch_;
     bool defer_mp_free_ = false;                              // remove_map_point parks the object until local_ba returns
-    std::vector<std::shared_ptr<MapPt>> mp_graveyard_;
+    std::vector<MapPt *> mp_graveyard_;
+    struct MapPtBox {
+        alignas(8) unsigned char b[64];
+    };
+    static_assert(sizeof(MapPt) <= sizeof(MapPtBox), "MapPt outgrew its arena box");
+    std::vector<HugeArray<MapPtBox>> mp_obj_chunks_;   // one box per record slot
+    MapPt *mp_box(int slot) const { return reinterpret_cast<MapPt *>(mp_obj_chunks_[(size_t) slot >> MP_CHUNK_SHIFT].get()[(size_t) (slot & (MP_CHUNK - 1))].b); }
+    void destroy_map_point(MapPt *mp) {   // (releases the slot; the box stays where it is)
+        mp->~MapPt();
+#if defined(__SANITIZE_ADDRESS__)
+        __asan_poison_memory_region(mp, sizeof(MapPtBox));   // a sanitizer build of the GPU-less harness flags any later use of the object
+#endif
+    }
+    MapPt *mp_box_fresh(int slot) const {   // where a new map point of this slot is constructed
+        MapPt *p = mp_box(slot);
+#if defined(__SANITIZE_ADDRESS__)
+        __asan_unpoison_memory_region(p, sizeof(MapPtBox));
+#endif
+        return p;
+    }
     const ObsEnt *obs_of(const MapPt &mp, int kfid) const;   // the keypoint of `mp` in keyframe `kfid` (null: that keyframe holds none)
     bool ensure_rec_chunk(int slot);                          // the arena chunk of record `slot` exists (asks the stages for it)
     // The NEXT arena chunk, prepared on a helper thread while the session goes on: a chunk is 4 MB of page-locked memory from the stages
@@ -659,6 +684,7 @@ private:
         MpRec *rec = nullptr;
         HugeArray<DescBlock> dsc;
         HugeArray<DescKeys> keys;
+        HugeArray<MapPtBox> objs;
     } chunk_ahead_;
     void start_chunk_ahead(int index);
 

@@ -325,7 +325,7 @@ extern "C" int alva_system_merge_map_points(alva_system *s, int prev_id, int new
         Slam &S = *s->slam;
         const auto ia = S.map_points.find(prev_id), ib = S.map_points.find(new_id);
         if (ia == S.map_points.end() || ib == S.map_points.end() || prev_id == new_id) return 0;
-        const std::shared_ptr<MapPt> a = ia->second, b = ib->second;
+        const MapPt *a = ia->second, *b = ib->second;
         if (S.cur->observes(prev_id) && S.cur->observes(new_id)) return 0;
         for (int kf: a->observers())
             if (b->obs_has(kf)) return 0;
