@@ -313,7 +313,7 @@ void Slam::reset_frame() {  // visual_frontend.cpp:700-714
     const KpTable copy = cur->kps;
     for (const auto &e: copy) remove_obs_from_cur(e.first);
     cur->kps.clear();
-    cur->ids3d_valid_ = false;
+    cur->note_inserted();
     cur->grid.clear();
     cur->grid.resize(cur->grid_cells);
     cur->n_kps = cur->n_2d = cur->n_3d = 0;

@@ -73,7 +73,7 @@ const KeyPt *FrameRec::find(int id_) const { return kps.find_ptr(id_); }
 
 void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
     if (!kps.emplace(k)) return;
-    ids3d_valid_ = false;
+    note_inserted();
     grid_add(k);
     n_kps++;
     if (k.is3d) n_3d++;
@@ -124,8 +124,8 @@ void FrameRec::remove(int id_) {  // :209-232
     if (k->is3d) n_3d--;
     else n_2d--;
     n_kps--;
+    note_erased_slot((int) (k - kps.kp.data()));   // (a keypoint lives at its slot's index)
     kps.erase(id_);
-    ids3d_valid_ = false;
 }
 
 void FrameRec::turn3d(int id_) {  // :234-248
@@ -188,7 +188,7 @@ void FrameRec::reset() {  // :467-489
     kfid = 0;
     timestamp = 0.;
     kps.clear();
-    ids3d_valid_ = false;
+    note_inserted();
     grid.clear();
     grid.resize(grid_cells);
     n_kps = n_2d = n_3d = 0;

@@ -187,20 +187,48 @@ struct FrameRec {
     }
     // the ids of the 3-D keypoints in mapKeypoints_ order (getKeypoints3d, frame.cpp:55-67) as ONE contiguous array, cached: three loops
     // of every keyframe step walk this list for every covisible keyframe (covisibility's local ids, the local BA's point set, the
-    // keyframe filter) and a keyframe is edited rarely (merges, culled observations); every edit of kps invalidates the cache
+    // keyframe filter).  Two levels, because most edits of a keyframe do not change the ORDER of its table:
+    //   order_  the table's slots in container order -- a walk of the linked list, ~2 600 dependent loads.  Still right after a keypoint
+    //           turned 3-D (triangulation: every observing keyframe, every keyframe step) and after an ERASE (the slot's position becomes
+    //           -1: culled observations, bad map points); only an INSERT (the id change of a merge: the newest keyframes) ends it;
+    //   ids3d_  the 3-D ids, one sequential pass over order_ (the slots' keys / flags are independent loads); any edit ends it.
     const std::vector<int> &ids3d() const {
         if (!ids3d_valid_) {
-            ids3d_.clear();
-            for_each_id([&](int kid, bool three_d) {
-                if (three_d) ids3d_.push_back(kid);
-            });
-            ids3d_valid_ = true;
+            if (!order_valid_) walk_order();
+            filter_ids3d();
         }
         return ids3d_;
     }
-    // The same lists for SEVERAL keyframes, the stale ones rebuilt together: a table's order is a linked list through its slots, one walk
-    // is a chain of dependent loads (≈ an L2 latency per keypoint, 2 600 of them), and the three loops above walk a dozen keyframes a
-    // merge or a triangulation has just edited.  Eight chains advance in turn here, so eight loads are in flight instead of one.
+    void walk_order() const {
+        const FlatHash<FlatNoValue> &h = kps.ids;
+        order_.clear();
+        pos_of_slot_.resize(h.slots());
+        for (int sl = h.first(); sl != FlatHash<FlatNoValue>::END; sl = h.next(sl)) {
+            pos_of_slot_[(size_t) sl] = (int) order_.size();
+            order_.push_back(sl);
+        }
+        order_valid_ = true;
+    }
+    void filter_ids3d() const {
+        const FlatHash<FlatNoValue> &h = kps.ids;
+        ids3d_.resize(order_.size());
+        size_t n = 0;
+        for (int sl: order_) {
+            if (sl < 0) continue;
+            ids3d_[n] = h.key(sl);
+            n += h.tag(sl) != 0;
+        }
+        ids3d_.resize(n);
+        ids3d_valid_ = true;
+    }
+    void note_erased_slot(int sl) {   // (before the table's erase)
+        ids3d_valid_ = false;
+        if (order_valid_ && (size_t) sl < pos_of_slot_.size()) order_[(size_t) pos_of_slot_[(size_t) sl]] = -1;
+    }
+    void note_inserted() { ids3d_valid_ = order_valid_ = false; }
+    // The same lists for SEVERAL keyframes, the stale ones rebuilt together: one order walk is a chain of dependent loads (≈ an L2 latency
+    // per keypoint), and the loops above walk a dozen keyframes.  Eight chains advance in turn here, so eight loads are in flight instead
+    // of one; keyframes whose order still stands only run the sequential pass.
     static void refresh_ids3d(FrameRec *const *kfs, size_t n) {
         constexpr int LANES = 8;
         typedef FlatHash<FlatNoValue> H;
@@ -208,11 +236,13 @@ struct FrameRec {
         int cur[LANES], live = 0;
         size_t next = 0;
         auto feed = [&](int l) {
-            while (next < n && (!kfs[next] || kfs[next]->ids3d_valid_)) next++;
+            while (next < n && (!kfs[next] || kfs[next]->order_valid_)) next++;
             if (next >= n) return false;
             f[l] = kfs[next++];
-            f[l]->ids3d_.clear();
-            f[l]->ids3d_valid_ = true;   // (also keeps a keyframe named twice in kfs out of a second lane)
+            f[l]->order_.clear();
+            f[l]->pos_of_slot_.resize(f[l]->kps.ids.slots());
+            f[l]->order_valid_ = true;   // (also keeps a keyframe named twice in kfs out of a second lane)
+            f[l]->ids3d_valid_ = false;
             cur[l] = f[l]->kps.ids.first();
             return true;
         };
@@ -231,13 +261,17 @@ struct FrameRec {
                     }
                     continue;
                 }
-                const H &h = f[l]->kps.ids;
-                if (h.tag(sl)) f[l]->ids3d_.push_back(h.key(sl));
-                cur[l] = h.next(sl);
+                f[l]->pos_of_slot_[(size_t) sl] = (int) f[l]->order_.size();
+                f[l]->order_.push_back(sl);
+                cur[l] = f[l]->kps.ids.next(sl);
                 l++;
             }
         }
+        for (size_t i = 0; i < n; i++)
+            if (kfs[i] && !kfs[i]->ids3d_valid_) kfs[i]->filter_ids3d();
     }
+    mutable std::vector<int> order_, pos_of_slot_;
+    mutable bool order_valid_ = false;
     mutable std::vector<int> ids3d_;
     mutable bool ids3d_valid_ = false;
     bool observes(int id) const { return kps.count(id) != 0; }
