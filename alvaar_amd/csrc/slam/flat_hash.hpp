@@ -28,6 +28,15 @@ namespace alva_slam {
 
 struct FlatNoValue {};
 
+// _Prime_rehash_policy::_M_need_rehash(buckets, elements, 1) -- the library's own function decides every growth step -- behind the test
+// it starts with (hashtable_c++0x.cc: "if (n_elt + n_ins > _M_next_resize) ... else return {false, 0}"): below the threshold the answer
+// is "no" and nothing changes, and a call into libstdc++.so per insert (17 000 per keyframe) is most of what an insert costs.
+// tests/cpp/flat_hash_vs_std.cpp compares the bucket counts with the real containers after every operation.
+inline std::pair<bool, std::size_t> need_rehash(std::__detail::_Prime_rehash_policy &pol, std::size_t buckets, std::size_t elements) {
+    if (elements + 1 <= pol._M_state()) return {false, 0};
+    return pol._M_need_rehash(buckets, elements, 1);
+}
+
 template <class V>
 class FlatHash {
 public:
@@ -78,7 +87,7 @@ public:
     std::pair<int, bool> insert_slot(int k, const V &v = V(), uint8_t tag = 0) {
         const int f = find_slot(k);
         if (f != END) return {f, false};
-        const std::pair<bool, std::size_t> grow = pol_._M_need_rehash(bkt_.size(), count_, 1);   // _M_insert_unique_node
+        const std::pair<bool, std::size_t> grow = need_rehash(pol_, bkt_.size(), count_);   // _M_insert_unique_node
         if (grow.first) rehash(grow.second);
         const int s = alloc(k, v, tag);
         link_front_of_bucket(s);
@@ -88,7 +97,7 @@ public:
 
     // the same for a key the caller KNOWS to be absent (it filters repeats itself, e.g. with a mark table): no look-up
     int insert_new_slot(int k, const V &v = V(), uint8_t tag = 0) {
-        const std::pair<bool, std::size_t> grow = pol_._M_need_rehash(bkt_.size(), count_, 1);
+        const std::pair<bool, std::size_t> grow = need_rehash(pol_, bkt_.size(), count_);
         if (grow.first) rehash(grow.second);
         const int s = alloc(k, v, tag);
         link_front_of_bucket(s);
@@ -324,7 +333,7 @@ public:
             if (slot) *slot = have;
             return 0;
         }
-        const std::pair<bool, std::size_t> grow = pol_._M_need_rehash((size_t) nbkt_, (size_t) count_, 1);   // _M_insert_unique_node
+        const std::pair<bool, std::size_t> grow = need_rehash(pol_, (size_t) nbkt_, (size_t) count_);   // _M_insert_unique_node
         if ((grow.first && grow.second > (size_t) NBKT) || (free_ == END && used_ >= CAP)) return -1;
         if (grow.first) rehash((int) grow.second);
         int s = free_;
