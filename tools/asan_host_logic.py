@@ -1,4 +1,5 @@
-"""driven by tools/asan_host_logic.sh: the GPU-less harness's sanitizer build over the bench stream, check mode, a reset half way"""
+"""driven by tools/asan_host_logic.sh: the GPU-less harness's sanitizer build over the bench stream, check mode, a reset half way
+env: CELL (12), CLAHE (0), DIST (unset: no lens distortion)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -16,7 +17,9 @@ frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) f
 period = 2 * (NF - 1)
 idx = lambda k: (k % period) if (k % period) < NF else period - (k % period)
 os.environ["ALVA_CHECK_OBS_MIRROR"] = "1"
-s = sysdiff.CpuSystem(w, h, 12)
+cell, clahe = int(os.environ.get("CELL", "12")), bool(int(os.environ.get("CLAHE", "0")))
+dist = (0.1, -0.05, 0.001, 0.0005) if os.environ.get("DIST") else (0.0, 0.0, 0.0, 0.0)
+s = sysdiff.CpuSystem(w, h, cell, clahe=clahe, dist=dist)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 for k in range(n):
     s.step(frames[idx(k)], 33.0 * k)
