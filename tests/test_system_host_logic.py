@@ -143,3 +143,40 @@ def test_explicit_reset_between_frames():
     frames = (synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h)) for k in range(110))
     statuses, cnt, _, _ = _run(frames, w, h, 40, 0, reset_at=(48,))
     assert statuses[47] == 1 and statuses[48] == 3 and statuses[-1] == 1, (statuses[44:52], statuses[-5:])
+
+
+def test_stage_result_tape_replays_to_the_same_state():
+    """tools/host_replay_cpu.py's instrument (oracle/sys_cpu.cpp MemoStages): a second map layer fed the RECORDED results of every stage
+    call of a first one must pass through the same states -- status, counters, the frame's keypoints in container order, the map-point
+    table with its medoids -- which also says that the map layer's behaviour is a function of what its stages return and nothing else"""
+    import ctypes as C
+    w, h, n = 640, 480, 90
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
+    rec, rep = sysdiff.CpuSystem(w, h, 25), sysdiff.CpuSystem(w, h, 25)
+    L = rec.L
+    L.syscpu_tape_new.restype = C.c_void_p
+    L.syscpu_tape_bytes.restype = C.c_longlong
+    L.syscpu_tape_bytes.argtypes = [C.c_void_p]
+    L.syscpu_attach_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.syscpu_tape_free.argtypes = [C.c_void_p]
+    tape = C.c_void_p(L.syscpu_tape_new())
+    try:
+        L.syscpu_attach_tape(rec.h, tape, 0)
+        seen = []
+        for k in range(n):
+            st, pose, _ = rec.step(frames[k], 33.0 * k)
+            seen.append((st, pose.copy(), [int(v) for v in rec.state()], [a.copy() for a in rec.frame_keypoints()]))
+        assert L.syscpu_tape_bytes(tape) > 1000000 and any(s[0] == 1 for s in seen)
+        L.syscpu_attach_tape(rep.h, tape, 1)
+        for k in range(n):
+            st, pose, _ = rep.step(frames[k], 33.0 * k)
+            assert st == seen[k][0] and np.array_equal(pose, seen[k][1]), k
+            assert [int(v) for v in rep.state()] == seen[k][2], k
+            for a, b in zip(rep.frame_keypoints(), seen[k][3]):
+                assert np.array_equal(a, b), k
+        sysdiff.compare(rec, rep, 0.0, what="after the replay")
+    finally:
+        rec.close()
+        rep.close()
+        L.syscpu_tape_free(tape)
