@@ -4,7 +4,11 @@ distance table in the container's iteration order and its bucket count after eve
 operations one at a time through alva_medoid_replay and dumps the table after each: medoid bytes, !desc_.empty(), the (key, distance sum)
 list IN ITERATION ORDER and the bucket count must be identical after every single operation.  Sequences are built to hit what decides
 the medoid: ties (repeated descriptors: a stream that revisits a view), keyframe 0 (never chosen by the removal, map_point.cpp:123),
-removals of absent keys, the 13 -> 29 -> 59 bucket growth, the release when the last observation goes, re-use after it."""
+removals of absent keys, the 13 -> 29 -> 59 bucket growth, the release when the last observation goes, re-use after it.
+The operation log fed to the device is written by medoid_cases.map_layer_log, a Python MODEL of what slam/map.cpp logs (which edit
+becomes which operation, the bucket count passed along with an insert that rehashes) -- not a capture of the map layer's own log.  The
+real log is exercised by every System differential (tests/test_gpu_system.py compares the medoid of every map point with the reference's
+on every frame, device path) and, without a GPU, by tests/test_system_host_logic.py through the host build of the same tables."""
 import numpy as np
 import pytest
 
