@@ -47,17 +47,9 @@ struct LkPyr {
 };
 
 struct LkShared {
-    short2 dxy[NPX + 3];  // (Ix, Iy) of the template window
-    int2 pxy[NPX + 3];    // (diff * Ix, diff * Iy) of the current iteration
-    int2 zer[NPX + 3];    // zeros (written once per kernel): the second operand of the b chains' scalar-pixel lanes -- a read of 0 instead
-                          // of a select per row (the chains' row offsets are instruction immediates, so the zeros span the rows too)
-    uint8_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level)
+    alignas(16) uint32_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level), one dword per pixel: a tap's
+                                       // two horizontal neighbours come back from ONE ds_read2_b32, ready to multiply
 };
-// once per kernel, before the first lk_level
-__device__ __forceinline__ void lk_shared_init(LkShared &sh) {
-    for (int i = threadIdx.x; i < NPX + 3; i += 64) sh.zer[i] = make_int2(0, 0);
-    __syncthreads();
-}
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
@@ -83,14 +75,62 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
 __device__ __forceinline__ int bl_u8(int s00, int s01, int s10, int s11, const Weights &w) {
     return __mul24(s00, w.w00) + __mul24(s01, w.w01) + __mul24(s10, w.w10) + __mul24(s11, w.w11);
 }
+// The same instructions by name, for the iteration of lk_level: left to itself the compiler widens some of these products to the
+// quarter-rate v_mul_lo_u32 (it cannot always prove the 24-bit range through the byte unpacking), and the iteration is the kernel.
+__device__ __forceinline__ int mul_i24(int a, int b) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// descale(bl_u8(...), 9): the rounding constant rides on the first multiply-add
+__device__ __forceinline__ int tap_u8(const uint32_t (&s)[4], const Weights &w, int half) {
+    return mad_i24((int) s[3], w.w11, mad_i24((int) s[2], w.w10, mad_i24((int) s[1], w.w01, mad_i24((int) s[0], w.w00, half)))) >> 9;
+}
 __device__ __forceinline__ int bl_i16(int s00, int s01, int s10, int s11, const Weights &w) {
     return __mul24(s00, w.w00) + __mul24(s01, w.w01) + __mul24(s10, w.w10) + __mul24(s11, w.w11);
 }
 
+// cross-lane moves of the row layout (all without LDS, all without scalar registers): the value of the lane below within the 16-lane
+// DPP row (0 into the row's first lane), and the two "last lane of a row into the next rows" broadcasts of gfx9 (lanes without a source
+// read 0; only lanes 31 / 63 of the results are used)
+__device__ __forceinline__ float dpp_shr1(float v) { return dpp_row_shr<1>(v); }
+__device__ __forceinline__ float dpp_bcast15(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_bcast31(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xf, 0xf, true));
+}
+// (q0 + q2) + (q1 + q3) of the four vector-lane chains, whose ends sit on lanes 15 (q0), 31 (q2), 47 (q1), 63 (q3): valid on lane 63
+__device__ __forceinline__ float rows_fold(float v) {
+    const float t = v + dpp_bcast15(v);   // lane 31: q2 + q0, lane 63: q3 + q1 (IEEE addition is commutative: the reference's pairs)
+    return t + dpp_bcast31(t);            // lane 63: (q3 + q1) + (q2 + q0)
+}
+
 // One point, one pyramid level (lkpyramid.cpp:199-680).  All arguments and results are wave-uniform.
+//
+// ROW LAYOUT.  The reference's SIMD128 loop keeps, per window row, running float sums for vector lane q = 0..3 (window columns q and
+// q + 4) and one scalar sum for column 8, and walks the rows top to bottom -- ten (b) / fifteen (A) SEQUENTIAL float chains over the
+// nine rows.  Here window row y lives on lane 7 + y of every 16-lane DPP row, DPP row r owns vector lane q = {0, 2, 1, 3}[r] (both of
+// its columns) and a share of column 8, and a chain is a scan along the lanes: acc = f + row_shr:1(acc), eight dependent v_add_f32_dpp
+// -- lane 15 of the row ends up with exactly the reference's sum, the lanes below 7 hold zeros and feed the scan its initial 0.  The
+// four chain ends then meet through row_bcast:15 / row_bcast:31 in the reference's (q0 + q2) + (q1 + q3) order.  No tap goes through
+// LDS and nothing waits on an LDS round trip inside the iteration (round 6; before, the 81 taps sat one per lane and reached the
+// chain lanes through LDS: two dependent LDS round trips per iteration, which for the launch's last, lonely slots -- the ones that
+// run all 30 iterations on six levels and decide the kernel time -- were a third of the iteration).  A lone wave issues one
+// instruction every four cycles whatever its type, so the iteration is also written for instruction COUNT: the template's part of
+// (J - I) * dI is folded into one constant per lane, tile bytes and bounds are revisited only when the window's integer origin moved.
 __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
                          float minEigThreshold, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
     const int lane = threadIdx.x;
+    const int row = lane >> 4, jl = lane & 15;
+    const bool act = jl >= 7;                          // lanes 7..15 of a row carry window rows 0..8
+    const int y = act ? jl - 7 : 0;
+    const int q = ((row & 1) << 1) | (row >> 1);       // rows 0, 1, 2, 3 -> vector lanes 0, 2, 1, 3
     const float halfWin = (WIN - 1) * 0.5f;
     const float lscale = 1.0f / (float) (1 << level);  // exact power of two
     float prevx = ptx * lscale, prevy = pty * lscale;
@@ -116,14 +156,11 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     }
     Weights wt = bilinear_weights(prevx - (float) ipx, prevy - (float) ipy);
 
-    // ---- patch extraction: pixel p -> lane p, pixels 64..80 -> lanes 0..16 (the other lanes redo pixel 80: no branch) ----
-    short rI[2], rIx[2], rIy[2];
-    int toff[2];
+    // ---- template: this lane's three pixels of window row y -- columns q, q + 4 and 8 (lkpyramid.cpp:440-471) ----
+    int tI[3], tIx[3], tIy[3];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int p = min(lane + 64 * r, NPX - 1);
-        const int y = p / WIN, x = p - y * WIN;
-        toff[r] = y * TW + x;
+    for (int p = 0; p < 3; p++) {
+        const int x = p == 0 ? q : (p == 1 ? q + 4 : 8);
         const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
         const int ival = descale(bl_u8(src[0], src[1], src[I.gpitch], src[I.gpitch + 1], wt), 9);
         const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
@@ -133,39 +170,40 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
         const int ixval = descale(bl_i16(d00.x, d01.x, d10.x, d11.x, wt), 14);
         const int iyval = descale(bl_i16(d00.y, d01.y, d10.y, d11.y, wt), 14);
-        rI[r] = (short) ival;
-        rIx[r] = (short) ixval;
-        rIy[r] = (short) iyval;
-        sh.dxy[p] = make_short2((short) ixval, (short) iyval);
+        tI[p] = ival;
+        tIx[p] = act ? ixval : 0;   // the lanes below a row's chain contribute exact zeros
+        tIy[p] = act ? iyval : 0;
     }
-    __syncthreads();
-    // ---- A = sum of dI dI^T in the reference's SIMD128 order: 15 chains on lanes 0..14 = (component, vector lane 0..3 |
-    // scalar pixel 8).  Branch-free: every lane runs the same 18 adds (the scalar chain adds +0.f for its missing half;
-    // lanes >= 15 repeat lane 14).  (float) ix * (float) iy == (float) (ix * iy): both round the same exact product.
-    float acc = 0.f;
-    {
-        const int l15 = min(lane, 14), comp = l15 / 5, ch = l15 - comp * 5;
-        const bool two = ch < 4;
-        const int qa = two ? ch : 8, qb = two ? ch + 4 : 8;
-#pragma unroll
-        for (int y = 0; y < WIN; y++) {
-            const short2 da = sh.dxy[y * WIN + qa], db = sh.dxy[y * WIN + qb];
-            const float fxa = (float) da.x, fya = (float) da.y, fxb = (float) db.x, fyb = (float) db.y;
-            const float p1 = (comp == 2 ? fya : fxa) * (comp == 0 ? fxa : fya);
-            float p2 = (comp == 2 ? fyb : fxb) * (comp == 0 ? fxb : fyb);
-            p2 = two ? p2 : 0.f;
-            acc = p1 + acc;
-            acc = p2 + acc;
-        }
-    }
+    // ---- A = sum of dI dI^T.  Per component (xx, xy, yy) and vector lane the reference runs acc = p(col q) + acc; acc = p(col q + 4) + acc
+    // down the rows, from acc = 0; the scalar column's chain is acc = p(col 8) + acc.  Nine scan steps from zero reproduce that,
+    // "+ 0" of the first row included.  The three scalar chains (one per component) share one scan: DPP rows 0, 1, 2.
+    // (float) ix * (float) iy == (float) (ix * iy): both round the same exact product.
     float A[3];
+    {
+        float fx[3], fy[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float q0 = lane_bcast(acc, 5 * k + 0), q1 = lane_bcast(acc, 5 * k + 1), q2 = lane_bcast(acc, 5 * k + 2),
-                    q3 = lane_bcast(acc, 5 * k + 3);
-        float sres = lane_bcast(acc, 5 * k + 4);
-        sres += (q0 + q2) + (q1 + q3);
-        A[k] = sres * (1.f / (1 << 20));
+        for (int p = 0; p < 3; p++) {
+            fx[p] = (float) tIx[p];
+            fy[p] = (float) tIy[p];
+        }
+        const float pa[3] = {fx[0] * fx[0], fx[0] * fy[0], fy[0] * fy[0]};
+        const float pb[3] = {fx[1] * fx[1], fx[1] * fy[1], fy[1] * fy[1]};
+        const float ps = row == 0 ? fx[2] * fx[2] : (row == 1 ? fx[2] * fy[2] : fy[2] * fy[2]);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, as = 0.f;
+#pragma unroll
+        for (int s = 0; s < WIN; s++) {
+            a0 = pb[0] + (pa[0] + dpp_shr1(a0));
+            a1 = pb[1] + (pa[1] + dpp_shr1(a1));
+            a2 = pb[2] + (pa[2] + dpp_shr1(a2));
+            as = ps + dpp_shr1(as);
+        }
+        const float v[3] = {rows_fold(a0), rows_fold(a1), rows_fold(a2)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float sres = lane_bcast(as, 15 + 16 * k);
+            sres += lane_bcast(v[k], 63);
+            A[k] = sres * (1.f / (1 << 20));
+        }
     }
     const float A11 = A[0], A12 = A[1], A22 = A[2];
     float D = A11 * A22 - A12 * A12;
@@ -179,91 +217,79 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         return;
     }
     D = 1.f / D;
+    const float Ds = D * (1.f / (1 << 20));
+    // ---- the iteration's per-lane constants.  (J - I) * Ix summed over the lane's two columns, an exact integer, is
+    // Ja * Ixa + Jb * Ixb - (Ia * Ixa + Ib * Ixb): two v_mad_i32_i24 on top of a constant.  (J - I fits 14 bits -- the reference's
+    // cast to short never truncates -- and the derivatives 13, so every product fits 26 bits and the sums 28.)  The scalar column's
+    // chains run on DPP rows 3 (x) and 2 (y), where their ends meet the folded vector sums.
+    const int ixa = tIx[0], iya = tIy[0], ixb = tIx[1], iyb = tIy[1];
+    const int cx = -(__mul24(tI[0], ixa) + __mul24(tI[1], ixb)), cy = -(__mul24(tI[0], iya) + __mul24(tI[1], iyb));
+    const int is = row == 3 ? tIx[2] : (row == 2 ? tIy[2] : 0);
+    const int cs = -__mul24(tI[2], is);
+    const int toff_a = y * TW + q, toff_s = y * TW + 8;
     nextx -= halfWin;
     nexty -= halfWin;
     float pdx = 0.f, pdy = 0.f;
     int tx0 = 0x40000000, ty0 = 0x40000000;  // tile origin in image coordinates (invalid: staged on first use)
-    int pinx = 0x40000000, piny = 0x40000000;   // integer window origin of the previous iteration
-    int s00[2] = {0, 0}, s01[2] = {0, 0}, s10[2] = {0, 0}, s11[2] = {0, 0};   // this lane's 2 x 4 tile bytes at that origin
+    float pfx = __int_as_float(0x7fc00000), pfy = pfx;   // floor of the previous iteration's window origin (NaN: differs from everything)
+    uint32_t sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};   // this lane's 3 x 4 tile pixels at that origin
+    const float ef = (float) epsilon, ef_hi = ef * 1.00001f, ef_lo = ef * 0.99999f;
     for (int j = 0; j < maxCount; j++) {
-        const int inx = (int) floorf(nextx), iny = (int) floorf(nexty);
-        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
-            if (level == 0) status = 0;
-            break;
-        }
-        wt = bilinear_weights(nextx - (float) inx, nexty - (float) iny);
-        if (inx < tx0 || inx > tx0 + 2 * TR || iny < ty0 || iny > ty0 + 2 * TR) {  // wave-uniform
-            tx0 = inx - TR;
-            ty0 = iny - TR;
-            __syncthreads();
-            // lane -> row lane/4, 4 consecutive columns; coordinates clamped to the padded level (the window itself
-            // never leaves it, lkpyramid.cpp:518-523, so clamped bytes are never used)
-            const int row = lane >> 2, c0 = (lane & 3) * 4;
-            const int gy = min(max(ty0 + row, -WIN), J.h + WIN - 1);
-            const uint8_t *srow = J.gray + (ptrdiff_t) gy * J.gpitch;
-#pragma unroll
-            for (int k = 0; k < 4; k++) sh.jt[row * TW + c0 + k] = srow[min(max(tx0 + c0 + k, -WIN), J.w + WIN - 1)];
-        }
-        __syncthreads();  // tile staged; previous iteration's chain reads are done before px/py are overwritten
-        const int tbase = (iny - ty0) * TW + (inx - tx0);
-        {
-            // The eight tile bytes of BOTH rounds first (one LDS latency instead of two: in program order the second round's reads sat
-            // behind the first round's store), then the arithmetic, then the two stores.  And only when the window's INTEGER origin
-            // moved: once the iteration is down to sub-pixel steps -- most iterations -- the bytes are last iteration's, only the
-            // weights change, and the LDS round trip drops out of the dependent chain altogether.
-            if (inx != pinx || iny != piny) {   // wave-uniform
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const uint8_t *src = sh.jt + toff[r] + tbase;
-                    s00[r] = src[0]; s01[r] = src[1]; s10[r] = src[TW]; s11[r] = src[TW + 1];
-                }
-                pinx = inx;
-                piny = iny;
+        const float flx = floorf(nextx), fly = floorf(nexty);
+        // bounds, tile and the twelve tile pixels only when the window's INTEGER origin moved: once the iteration is down to sub-pixel
+        // steps -- most iterations -- the pixels are last iteration's and only the weights change
+        if (flx != pfx || fly != pfy) {
+            const int inx = __builtin_amdgcn_readfirstlane((int) flx), iny = __builtin_amdgcn_readfirstlane((int) fly);
+            if ((unsigned) (inx + WIN) >= (unsigned) (J.w + WIN) || (unsigned) (iny + WIN) >= (unsigned) (J.h + WIN)) {   // inx < -WIN || inx >= J.w || ...
+                if (level == 0) status = 0;
+                break;
             }
-            int2 out[2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int jval = descale(bl_u8(s00[r], s01[r], s10[r], s11[r], wt), 9);
-                const int diff = (int) (short) (jval - rI[r]);
-                out[r] = make_int2(diff * rIx[r], diff * rIy[r]);
+            if ((unsigned) (inx - tx0) > 2u * TR || (unsigned) (iny - ty0) > 2u * TR) {
+                tx0 = inx - TR;
+                ty0 = iny - TR;
+                // lane -> row lane/4, 4 consecutive columns; coordinates clamped to the padded level (the window itself
+                // never leaves it, lkpyramid.cpp:518-523, so clamped bytes are never used)
+                const int trow = lane >> 2, c0 = (lane & 3) * 4;
+                const int gy = min(max(ty0 + trow, -WIN), J.h + WIN - 1);
+                const uint8_t *srow = J.gray + (ptrdiff_t) gy * J.gpitch;
+                uint4 px;
+                px.x = srow[min(max(tx0 + c0 + 0, -WIN), J.w + WIN - 1)];
+                px.y = srow[min(max(tx0 + c0 + 1, -WIN), J.w + WIN - 1)];
+                px.z = srow[min(max(tx0 + c0 + 2, -WIN), J.w + WIN - 1)];
+                px.w = srow[min(max(tx0 + c0 + 3, -WIN), J.w + WIN - 1)];
+                __syncthreads();   // (one wave: no barrier instruction, only the order of the LDS accesses)
+                *reinterpret_cast<uint4 *>(sh.jt + trow * TW + c0) = px;
+                __syncthreads();
             }
+            const int tbase = (iny - ty0) * TW + (inx - tx0);
+            const uint32_t *pa = sh.jt + toff_a + tbase, *ps = sh.jt + toff_s + tbase;
+            sa[0] = pa[0]; sa[1] = pa[1]; sa[2] = pa[TW]; sa[3] = pa[TW + 1];
+            sb[0] = pa[4]; sb[1] = pa[5]; sb[2] = pa[TW + 4]; sb[3] = pa[TW + 5];
+            ss[0] = ps[0]; ss[1] = ps[1]; ss[2] = ps[TW]; ss[3] = ps[TW + 1];
+            pfx = flx;
+            pfy = fly;
+        }
+        // flx == (float) (int) flx here (a saturated conversion left the loop above): the reference's a = next - cvFloor(next)
+        wt = bilinear_weights(nextx - flx, nexty - fly);
+        const int ja = tap_u8(sa, wt, 256), jb = tap_u8(sb, wt, 256), js = tap_u8(ss, wt, 256);
+        const float fx = (float) mad_i24(jb, ixb, mad_i24(ja, ixa, cx)), fy = (float) mad_i24(jb, iyb, mad_i24(ja, iya, cy)),
+                    fs = (float) mad_i24(js, is, cs);
+        // b chains (lkpyramid.cpp:553-562, 628-646): bacc += (float) (column q + column q + 4) down the rows, from 0 (0 + f == f)
+        float bx = fx, by = fy, bs = fs;
 #pragma unroll
-            for (int r = 0; r < 2; r++) sh.pxy[min(lane + 64 * r, NPX - 1)] = out[r];
+        for (int s = 1; s < WIN; s++) {
+            bx = fx + dpp_shr1(bx);
+            by = fy + dpp_shr1(by);
+            bs = fs + dpp_shr1(bs);
         }
-        __syncthreads();
-        // b chains (lkpyramid.cpp:553-562, 628-646): lanes 0..7 = (vector lane q: pixels q and q+4, component),
-        // lanes 8,9 = scalar pixel 8; branch-free like the A chains
-        float bacc = 0.f;
-        {
-            const int l10 = min(lane, 9), comp = l10 & 1, q = l10 >> 1;
-            const bool two = q < 4;
-            const int qa = two ? q : 8;
-            const int *src = reinterpret_cast<const int *>(sh.pxy) + comp;
-            // second pixel of the chain: column q + 4, or -- scalar-pixel lanes -- the zeros (va + 0 == va: same value as the select)
-            const int *srcb = two ? src + 2 * (q + 4) : reinterpret_cast<const int *>(sh.zer);
-#pragma unroll
-            for (int y = 0; y < WIN; y++) {
-                const int va = src[2 * (y * WIN + qa)];
-                const int vb = srcb[2 * (y * WIN)];
-                bacc += (float) (va + vb);
-            }
-        }
-        // The reduce of intrin_sse's v_reduce_sum + the scalar pixel, sres = b[8 + c] + ((b[0 + c] + b[4 + c]) + 0) + ((b[2 + c] + b[6 + c]) + 0),
-        // with the chains on lanes 2 q + c: three DPP row shifts bring the operands together (IEEE addition is commutative, so
-        // "upper lane + lower lane" is the reference's "lower + upper" to the last bit) and two broadcasts deliver the result -- instead
-        // of ten v_readlane and the scalar-register hazards behind them
-        float ib[2];
-        {
-            float t = bacc + dpp_row_shr<4>(bacc);   // lanes 4 + c: b[4 + c] + b[0 + c];  lanes 6 + c: b[6 + c] + b[2 + c]
-            t = t + 0.f;
-            const float u = t + dpp_row_shr<2>(t);   // lanes 6 + c: (s2 + 0) + (s0 + 0)
-            const float w = bacc + dpp_row_shr<2>(u);   // lanes 8 + c: b[8 + c] + ((s0 + 0) + (s2 + 0))
-            ib[0] = lane_bcast(w, 8);
-            ib[1] = lane_bcast(w, 9);
-        }
-        const float b1 = ib[0] * (1.f / (1 << 20)), b2 = ib[1] * (1.f / (1 << 20));
-        const float dx = (A12 * b2 - A22 * b1) * D;
-        const float dy = (A12 * b1 - A11 * b2) * D;
+        // sres = scalar + ((q0 + q2) + (q1 + q3)) on lane 63: the x scalar chain ended there (row 3), the y one on lane 47 (row 2)
+        const float wx = rows_fold(bx) + bs, wy = rows_fold(by) + dpp_bcast15(bs);
+        // b = sres * 2^-20 and delta = (A12 b2 - A22 b1, A12 b1 - A11 b2) * D (lkpyramid.cpp:660-668); the power of two commutes with
+        // every rounding on the way (nothing here is near the denormal range: a difference of two floats is zero or at least an ulp of
+        // them), so it is applied once, to D
+        const float b1 = lane_bcast(wx, 63), b2 = lane_bcast(wy, 63);
+        const float dx = (A12 * b2 - A22 * b1) * Ds;
+        const float dy = (A12 * b1 - A11 * b2) * Ds;
         nextx += dx;
         nexty += dy;
         nx = nextx + halfWin;
@@ -272,24 +298,24 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         // in double, their sum is rounded once; the same sum in float is within 3 float ulps of it, so the double arithmetic (half-rate
         // instructions on the critical path of every iteration) is only needed inside a band of +-1e-5 (relative) around epsilon.
         // (2) fabs((double) (dx + pdx)) < 0.01: the argument IS a float; no float lies between 0.01f (= 0.00999999977...) and 0.01, so
-        // "< 0.01 in double" is "<= 0.01f in float", exactly.
-        {
-            const float d2 = dx * dx + dy * dy, ef = (float) epsilon;
+        // "< 0.01 in double" is "<= 0.01f in float", exactly.  Both are rare: one test in front of them keeps them off the common path.
+        const float d2 = dx * dx + dy * dy;
+        const bool osc = (int) (j > 0) & (int) (fabsf(dx + pdx) <= 0.01f) & (int) (fabsf(dy + pdy) <= 0.01f);
+        if ((int) !(d2 > ef_hi) | (int) osc) {
             bool stop;
-            if (d2 > ef * 1.00001f) stop = false;
-            else if (d2 < ef * 0.99999f) stop = true;
+            if (d2 > ef_hi) stop = false;
+            else if (d2 < ef_lo) stop = true;
             else stop = (double) dx * (double) dx + (double) dy * (double) dy <= epsilon;
             if (stop) break;
-        }
-        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-            nx -= dx * 0.5f;
-            ny -= dy * 0.5f;
-            break;
+            if (osc) {
+                nx -= dx * 0.5f;
+                ny -= dy * 0.5f;
+                break;
+            }
         }
         pdx = dx;
         pdy = dy;
     }
-    __syncthreads();  // LDS reuse by the next level
 }
 
 // The verdict of FeatureTracker::fbKltTracking on one keypoint after its forward pass (feature_tracker.cpp:48-103): status,
@@ -359,7 +385,6 @@ __global__ void __launch_bounds__(64) k_klt(LkPyr P, LkPyr C, int mode, int maxL
                                             float *nextio, uint8_t *__restrict__ status_out, float *__restrict__ err_out,
                                             int n) {
     __shared__ LkShared sh;
-    lk_shared_init(sh);
     // XCD-aware order: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Giving every XCD one CONTIGUOUS
     // eighth of the keypoint list (callers keep keypoints in spatial / grid order) keeps an image region in one L2
     // instead of pulling the whole pyramid through all eight.
@@ -374,7 +399,6 @@ __global__ void __launch_bounds__(64) k_klt_dn(LkPyr P, LkPyr C, int mode, int m
                                                float fbDist, const float *__restrict__ pts, const float *init, float *nextio,
                                                uint8_t *__restrict__ status_out, const int *__restrict__ d_n) {
     __shared__ LkShared sh;
-    lk_shared_init(sh);
     const int per = gridDim.x >> 3;
     const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (kp >= *d_n) return;
@@ -426,7 +450,6 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
                                                const int gx) {
     __shared__ LkShared sh;
     const unsigned long long t_begin = D.dbg ? wall_clock64() : 0ull;
-    lk_shared_init(sh);
     const int per = gx >> 3;
     const int i = (bx & 7) * per + (bx >> 3);
     if (i >= D.n) return;
@@ -501,7 +524,6 @@ struct TrackKltArgs {
 __global__ void __launch_bounds__(64) k_track_klt_retry(LkPyr P, LkPyr C, TrackSlots D, int maxLevelFull, int maxCount, double epsilon,
                                                         float errThresh, float fbDist) {
     __shared__ LkShared sh;
-    lk_shared_init(sh);
     const int per = gridDim.x >> 3;
     const int i = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (i >= D.n) return;
@@ -526,7 +548,6 @@ struct KltBatchItem {
 __global__ void __launch_bounds__(64) k_klt_batch(const KltBatchItem *__restrict__ items, int maxLevel, int maxCount, double epsilon,
                                                   float errThresh, float fbDist) {
     __shared__ LkShared sh;
-    lk_shared_init(sh);
     const KltBatchItem &it = items[blockIdx.y];
     const int per = gridDim.x >> 3;
     const int kp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
