@@ -22,6 +22,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the reference's non-FMA build ("RN, no FMA contraction").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall",
          "-Wno-unused-function", f"-I{ROOT / 'include'}"]
+# one-off instrumented builds (tools/): ALVA_EXTRA_HIPFLAGS="-DALVA_KLT_COUNT" python -m alvaar_amd.build  (touch the source first)
+FLAGS += os.environ.get("ALVA_EXTRA_HIPFLAGS", "").split()
 
 
 def _newer(src: Path, dst: Path, deps: list[Path]) -> bool:

@@ -47,6 +47,9 @@ struct LkPyr {
 };
 
 struct LkShared {
+#ifdef ALVA_KLT_COUNT
+    unsigned cnt[4];
+#endif
     alignas(16) uint32_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level), one dword per pixel: a tap's
                                        // two horizontal neighbours come back from ONE ds_read2_b32, ready to multiply
 };
@@ -75,6 +78,25 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
 __device__ __forceinline__ int bl_u8(int s00, int s01, int s10, int s11, const Weights &w) {
     return __mul24(s00, w.w00) + __mul24(s01, w.w01) + __mul24(s10, w.w10) + __mul24(s11, w.w11);
 }
+// The weights of the ITERATION (bilinear_weights above, to the bit), in eleven instructions instead of twenty-one.  2^14 moves onto
+// the first factor -- a power of two commutes with every rounding here: (1 - a) 2^14 == 2^14 - a 2^14, ((1 - a)(1 - b)) 2^14 ==
+// ((1 - a) 2^14)(1 - b) -- and the round-to-nearest-even conversion is the float addition of 2^23: for 0 <= x < 2^23 the sum lies in
+// [2^23, 2^24), where floats are the integers, so its mantissa IS rint(x), and its low 24 bits -- all v_mul/mad_i32_i24 read -- are
+// that integer (bit 23 of 0x4b000000 is clear).  w11 needs the true integers once: the three biases leave through one constant.
+struct WeightsB {
+    int w00, w01, w10, w11;   // only the low 24 bits are meaningful (w11: the whole word)
+};
+__device__ __forceinline__ WeightsB bilinear_weights_i24(float a, float b) {
+    const float as = a * 16384.f, omas = 16384.f - as, omb = 1.f - b;
+    const float bias = 8388608.f;
+    WeightsB w;
+    w.w00 = __float_as_int(omas * omb + bias);
+    w.w01 = __float_as_int(as * omb + bias);
+    w.w10 = __float_as_int(omas * b + bias);
+    w.w11 = (int) ((unsigned) ((1 << 14) + 3 * 0x4b000000ll) - (unsigned) w.w00 - (unsigned) w.w01 - (unsigned) w.w10);
+    return w;
+}
+
 // The same instructions by name, for the iteration of lk_level: left to itself the compiler widens some of these products to the
 // quarter-rate v_mul_lo_u32 (it cannot always prove the 24-bit range through the byte unpacking), and the iteration is the kernel.
 __device__ __forceinline__ int mul_i24(int a, int b) {
@@ -88,12 +110,20 @@ __device__ __forceinline__ int mad_i24(int a, int b, int c) {
     return r;
 }
 // descale(bl_u8(...), 9): the rounding constant rides on the first multiply-add
-__device__ __forceinline__ int tap_u8(const uint32_t (&s)[4], const Weights &w, int half) {
+__device__ __forceinline__ int tap_u8(const uint32_t (&s)[4], const WeightsB &w, int half) {
     return mad_i24((int) s[3], w.w11, mad_i24((int) s[2], w.w10, mad_i24((int) s[1], w.w01, mad_i24((int) s[0], w.w00, half)))) >> 9;
 }
 __device__ __forceinline__ int bl_i16(int s00, int s01, int s10, int s11, const Weights &w) {
     return __mul24(s00, w.w00) + __mul24(s01, w.w01) + __mul24(s10, w.w10) + __mul24(s11, w.w11);
 }
+
+// ALVA_KLT_COUNT (a build-time switch of tools/klt_slot_stamps.py's one-off counting build; never defined in the shipped library):
+// LK iterations / window moves / tile restages / levels of a slot, reported through the stamp buffer's upper half
+#ifdef ALVA_KLT_COUNT
+#define KLT_COUNT(k) do { if (threadIdx.x == 0) sh.cnt[k]++; } while (0)
+#else
+#define KLT_COUNT(k) ((void) 0)
+#endif
 
 // cross-lane moves of the row layout (all without LDS, all without scalar registers): the value of the lane below within the 16-lane
 // DPP row (0 into the row's first lane), and the two "last lane of a row into the next rows" broadcasts of gfx9 (lanes without a source
@@ -109,6 +139,27 @@ __device__ __forceinline__ float dpp_bcast31(float v) {
 __device__ __forceinline__ float rows_fold(float v) {
     const float t = v + dpp_bcast15(v);   // lane 31: q2 + q0, lane 63: q3 + q1 (IEEE addition is commutative: the reference's pairs)
     return t + dpp_bcast31(t);            // lane 63: (q3 + q1) + (q2 + q0)
+}
+
+// The 16 x 16 tile of the searched image with origin (tx0, ty0): lane -> row lane / 4, 4 consecutive columns; coordinates clamped to
+// the padded level (the window itself never leaves it, lkpyramid.cpp:518-523, so clamped bytes are never used).  Load and LDS store
+// are separate so that the level's first tile is in flight together with the template's gathers.
+__device__ __forceinline__ uint4 tile_load(const LkLevel &J, int lane, int tx0, int ty0) {
+    const int trow = lane >> 2, c0 = (lane & 3) * 4;
+    const int gy = min(max(ty0 + trow, -WIN), J.h + WIN - 1);
+    const uint8_t *srow = J.gray + (ptrdiff_t) gy * J.gpitch;
+    uint4 px;
+    px.x = srow[min(max(tx0 + c0 + 0, -WIN), J.w + WIN - 1)];
+    px.y = srow[min(max(tx0 + c0 + 1, -WIN), J.w + WIN - 1)];
+    px.z = srow[min(max(tx0 + c0 + 2, -WIN), J.w + WIN - 1)];
+    px.w = srow[min(max(tx0 + c0 + 3, -WIN), J.w + WIN - 1)];
+    return px;
+}
+__device__ __forceinline__ void tile_store(LkShared &sh, int lane, const uint4 &px) {
+    const int trow = lane >> 2, c0 = (lane & 3) * 4;
+    __syncthreads();   // (one wave: no barrier instruction, only the order of the LDS accesses)
+    *reinterpret_cast<uint4 *>(sh.jt + trow * TW + c0) = px;
+    __syncthreads();
 }
 
 // One point, one pyramid level (lkpyramid.cpp:199-680).  All arguments and results are wave-uniform.
@@ -132,7 +183,7 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     const int y = act ? jl - 7 : 0;
     const int q = ((row & 1) << 1) | (row >> 1);       // rows 0, 1, 2, 3 -> vector lanes 0, 2, 1, 3
     const float halfWin = (WIN - 1) * 0.5f;
-    const float lscale = 1.0f / (float) (1 << level);  // exact power of two
+    const float lscale = __int_as_float((127 - level) << 23);  // 2^-level, exact (1.0f / (float) (1 << level) without the division)
     float prevx = ptx * lscale, prevy = pty * lscale;
     float nextx, nexty;
     if (level == maxLevel) {
@@ -155,6 +206,21 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         return;
     }
     Weights wt = bilinear_weights(prevx - (float) ipx, prevy - (float) ipy);
+    KLT_COUNT(3);
+    // the tile of the searched image around the initial window: its loads go out now, beside the template's, and land in LDS after the
+    // template arithmetic -- one memory latency per level instead of two
+    nextx -= halfWin;
+    nexty -= halfWin;
+    int tx0 = 0x40000000, ty0 = 0x40000000;  // tile origin in image coordinates (invalid: staged on first use)
+    uint4 tile0 = make_uint4(0, 0, 0, 0);
+    {
+        const int inx = __builtin_amdgcn_readfirstlane((int) floorf(nextx)), iny = __builtin_amdgcn_readfirstlane((int) floorf(nexty));
+        if ((unsigned) (inx + WIN) < (unsigned) (J.w + WIN) && (unsigned) (iny + WIN) < (unsigned) (J.h + WIN)) {
+            tx0 = inx - TR;
+            ty0 = iny - TR;
+            tile0 = tile_load(J, lane, tx0, ty0);
+        }
+    }
 
     // ---- template: this lane's three pixels of window row y -- columns q, q + 4 and 8 (lkpyramid.cpp:440-471) ----
     int tI[3], tIx[3], tIy[3];
@@ -188,7 +254,8 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         }
         const float pa[3] = {fx[0] * fx[0], fx[0] * fy[0], fy[0] * fy[0]};
         const float pb[3] = {fx[1] * fx[1], fx[1] * fy[1], fy[1] * fy[1]};
-        const float ps = row == 0 ? fx[2] * fx[2] : (row == 1 ? fx[2] * fy[2] : fy[2] * fy[2]);
+        const float sxx = fx[2] * fx[2], sxy = fx[2] * fy[2], syy = fy[2] * fy[2];
+        const float ps = row == 0 ? sxx : (row == 1 ? sxy : syy);   // (three products + two selects: a branch per row would cost more)
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, as = 0.f;
 #pragma unroll
         for (int s = 0; s < WIN; s++) {
@@ -227,10 +294,8 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
     const int is = row == 3 ? tIx[2] : (row == 2 ? tIy[2] : 0);
     const int cs = -__mul24(tI[2], is);
     const int toff_a = y * TW + q, toff_s = y * TW + 8;
-    nextx -= halfWin;
-    nexty -= halfWin;
+    if (tx0 != 0x40000000) tile_store(sh, lane, tile0);
     float pdx = 0.f, pdy = 0.f;
-    int tx0 = 0x40000000, ty0 = 0x40000000;  // tile origin in image coordinates (invalid: staged on first use)
     float pfx = __int_as_float(0x7fc00000), pfy = pfx;   // floor of the previous iteration's window origin (NaN: differs from everything)
     uint32_t sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};   // this lane's 3 x 4 tile pixels at that origin
     const float ef = (float) epsilon, ef_hi = ef * 1.00001f, ef_lo = ef * 0.99999f;
@@ -238,28 +303,19 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
         const float flx = floorf(nextx), fly = floorf(nexty);
         // bounds, tile and the twelve tile pixels only when the window's INTEGER origin moved: once the iteration is down to sub-pixel
         // steps -- most iterations -- the pixels are last iteration's and only the weights change
+        KLT_COUNT(0);
         if (flx != pfx || fly != pfy) {
+            KLT_COUNT(1);
             const int inx = __builtin_amdgcn_readfirstlane((int) flx), iny = __builtin_amdgcn_readfirstlane((int) fly);
             if ((unsigned) (inx + WIN) >= (unsigned) (J.w + WIN) || (unsigned) (iny + WIN) >= (unsigned) (J.h + WIN)) {   // inx < -WIN || inx >= J.w || ...
                 if (level == 0) status = 0;
                 break;
             }
             if ((unsigned) (inx - tx0) > 2u * TR || (unsigned) (iny - ty0) > 2u * TR) {
+                KLT_COUNT(2);
                 tx0 = inx - TR;
                 ty0 = iny - TR;
-                // lane -> row lane/4, 4 consecutive columns; coordinates clamped to the padded level (the window itself
-                // never leaves it, lkpyramid.cpp:518-523, so clamped bytes are never used)
-                const int trow = lane >> 2, c0 = (lane & 3) * 4;
-                const int gy = min(max(ty0 + trow, -WIN), J.h + WIN - 1);
-                const uint8_t *srow = J.gray + (ptrdiff_t) gy * J.gpitch;
-                uint4 px;
-                px.x = srow[min(max(tx0 + c0 + 0, -WIN), J.w + WIN - 1)];
-                px.y = srow[min(max(tx0 + c0 + 1, -WIN), J.w + WIN - 1)];
-                px.z = srow[min(max(tx0 + c0 + 2, -WIN), J.w + WIN - 1)];
-                px.w = srow[min(max(tx0 + c0 + 3, -WIN), J.w + WIN - 1)];
-                __syncthreads();   // (one wave: no barrier instruction, only the order of the LDS accesses)
-                *reinterpret_cast<uint4 *>(sh.jt + trow * TW + c0) = px;
-                __syncthreads();
+                tile_store(sh, lane, tile_load(J, lane, tx0, ty0));
             }
             const int tbase = (iny - ty0) * TW + (inx - tx0);
             const uint32_t *pa = sh.jt + toff_a + tbase, *ps = sh.jt + toff_s + tbase;
@@ -270,8 +326,8 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
             pfy = fly;
         }
         // flx == (float) (int) flx here (a saturated conversion left the loop above): the reference's a = next - cvFloor(next)
-        wt = bilinear_weights(nextx - flx, nexty - fly);
-        const int ja = tap_u8(sa, wt, 256), jb = tap_u8(sb, wt, 256), js = tap_u8(ss, wt, 256);
+        const WeightsB wb = bilinear_weights_i24(nextx - flx, nexty - fly);
+        const int ja = tap_u8(sa, wb, 256), jb = tap_u8(sb, wb, 256), js = tap_u8(ss, wb, 256);
         const float fx = (float) mad_i24(jb, ixb, mad_i24(ja, ixa, cx)), fy = (float) mad_i24(jb, iyb, mad_i24(ja, iya, cy)),
                     fs = (float) mad_i24(js, is, cs);
         // b chains (lkpyramid.cpp:553-562, 628-646): bacc += (float) (column q + column q + 4) down the rows, from 0 (0 + f == f)
@@ -321,21 +377,30 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int l
 // The verdict of FeatureTracker::fbKltTracking on one keypoint after its forward pass (feature_tracker.cpp:48-103): status,
 // err (min eigenvalue) <= errThresh, inBorder(level-0 size), then the backward pass on level 0 and the forward-backward distance.
 __device__ __forceinline__ int fbklt_gate(LkShared &sh, const LkPyr &P, const LkPyr &C, int maxCount, double epsilon, float errThresh,
-                                          float fbDist, float ptx, float pty, float nx, float ny, int status, float err) {
+                                          float fbDist, float ptx, float pty, float nx, float ny, int status, float err, int *why = nullptr) {
     int ok = status && !(err > errThresh);
     const float fw = (float) C.lv[0].w, fh = (float) C.lv[0].h;
-    ok = ok && (1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f);
+    if (why) *why = !status ? 1 : (err > errThresh ? 2 : 0);
+    if (ok && !(1.0f <= nx && nx < fw - 1.0f && 1.0f <= ny && ny < fh - 1.0f)) {
+        ok = 0;
+        if (why) *why = 3;
+    }
     if (ok) {
         // backward LK on level 0 only, initial flow = the original point (:84-87)
         float bx = ptx, by = pty;
         int st2 = 1;
         float err2 = 0.f;
         lk_level(sh, C.lv[0], P.lv[0], 0, 0, maxCount, epsilon, 1e-4f, nx, ny, bx, by, st2, err2);
-        if (!st2) ok = 0;
-        else {
+        if (!st2) {
+            ok = 0;
+            if (why) *why = 4;
+        } else {
             const float ddx = ptx - bx, ddy = pty - by;
             const double nrm = sqrt((double) ddx * (double) ddx + (double) ddy * (double) ddy);  // cv::norm(Point2f), :103
-            if (nrm > (double) fbDist) ok = 0;
+            if (nrm > (double) fbDist) {
+                ok = 0;
+                if (why) *why = 5;
+            }
         }
     }
     return ok;
@@ -343,12 +408,12 @@ __device__ __forceinline__ int fbklt_gate(LkShared &sh, const LkPyr &P, const Lk
 
 // fbKltTracking of one keypoint given by value: (nx, ny) is the prior on entry and the tracked position on return
 __device__ __forceinline__ int fbklt_value(LkShared &sh, const LkPyr &P, const LkPyr &C, int maxLevel, int maxCount, double epsilon,
-                                           float errThresh, float fbDist, float ptx, float pty, float &nx, float &ny) {
+                                           float errThresh, float fbDist, float ptx, float pty, float &nx, float &ny, int *why = nullptr) {
     int status = 1;
     float err = 0.f;
     for (int level = maxLevel; level >= 0; level--)
         lk_level(sh, P.lv[level], C.lv[level], level, maxLevel, maxCount, epsilon, 1e-4f, ptx, pty, nx, ny, status, err);
-    return fbklt_gate(sh, P, C, maxCount, epsilon, errThresh, fbDist, ptx, pty, nx, ny, status, err);
+    return fbklt_gate(sh, P, C, maxCount, epsilon, errThresh, fbDist, ptx, pty, nx, ny, status, err, why);
 }
 
 // One keypoint through the whole pyramid (all arguments wave-uniform).
@@ -450,6 +515,10 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
                                                const int gx) {
     __shared__ LkShared sh;
     const unsigned long long t_begin = D.dbg ? wall_clock64() : 0ull;
+#ifdef ALVA_KLT_COUNT
+    if (threadIdx.x < 4) sh.cnt[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     const int per = gx >> 3;
     const int i = (bx & 7) * per + (bx >> 3);
     if (i >= D.n) return;
@@ -472,19 +541,24 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
             ny = qv;
         }
     }
-    const int ok = fbklt_value(sh, P, C, from_prior ? maxLevelPrior : maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
+    int why = 0, why2 = 0;
+    const int ok = fbklt_value(sh, P, C, from_prior ? maxLevelPrior : maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny, D.dbg ? &why : nullptr);
     int code = ok ? (from_prior ? 1 : 2) : 0;
     if (from_prior && !ok) {  // full-pyramid retry from where the forward tracker left the keypoint (:185-190)
         // (s_setprio(3) here -- and s_setprio(2) for every full-pyramid slot -- measured in round 5: 65.6 vs 65.8 / 66.0 us, nothing: by the
         // time the slow slots are alone on their SIMDs the crowd has left anyway)
-        const int ok2 = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny);
+        const int ok2 = fbklt_value(sh, P, C, maxLevelFull, maxCount, epsilon, errThresh, fbDist, px, py, nx, ny, D.dbg ? &why2 : nullptr);
         code = ok2 ? 3 : 0;
     }
     if (threadIdx.x == 0) D.d_retried[i] = (uint8_t) (from_prior && !ok);
     track_slot_store(D, i, code, nx, ny);
-    if (D.dbg && threadIdx.x == 0 && i < 16384)
+    if (D.dbg && threadIdx.x == 0 && i < 8192)
         D.dbg[i] = ((wall_clock64() - t_begin) & 0xffffffffull) | ((unsigned long long) code << 32) | ((unsigned long long) (from_prior ? 1 : 0) << 36) |
-                   ((unsigned long long) (from_prior && !ok ? 1 : 0) << 37);
+                   ((unsigned long long) (from_prior && !ok ? 1 : 0) << 37) | ((unsigned long long) why << 40) | ((unsigned long long) why2 << 44);
+#ifdef ALVA_KLT_COUNT
+    if (D.dbg && threadIdx.x == 0 && i < 8192)
+        D.dbg[8192 + i] = (unsigned long long) sh.cnt[0] | ((unsigned long long) sh.cnt[1] << 16) | ((unsigned long long) sh.cnt[2] << 32) | ((unsigned long long) sh.cnt[3] << 48);
+#endif
     if (threadIdx.x == 0) {
         // ONE atomic per slot on a packed counter (track_slots.hpp) -- STRIPED: 2 600 atomics-with-return on one address from eight XCDs
         // queue at the memory side (k_fast_nms: 900 of them were that kernel's 50 us), so slot i arrives on stripe i % TRK_STRIPES, the
