@@ -373,8 +373,10 @@ __global__ void __launch_bounds__(256) k_match_rows(MtmRecArgs A) {
                 K = A.cellMp[cb[j] + off];
                 const MtmRow *gk = A.rows + K;
                 const int ko = gk->frame_obs, kn = gk->n_obs;
-                const float pxDist = norm2f(pu - gk->obs[ko].px[0], pv - gk->obs[ko].px[1]);
-                bool cand = !(pxDist > A.maxPxDist);
+                // (a record without the frame keyframe among its observations -- the host's guard against it runs only under
+                // ALVA_CHECK_OBS_MIRROR -- is no candidate; obs[-1] would be the row's own header bytes)
+                const float pxDist = ko >= 0 ? norm2f(pu - gk->obs[ko].px[0], pv - gk->obs[ko].px[1]) : 0.f;
+                bool cand = ko >= 0 && !(pxDist > A.maxPxDist);
                 if (!gk->has_desc) cand = false;  // kpMapPoint->desc_.empty() (:465-468)
                 if (cand)  // never both observed in one keyframe (:474-485)
                     for (int a = 0; a < kn && cand; a++)

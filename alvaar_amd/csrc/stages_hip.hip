@@ -387,10 +387,25 @@ struct HipStages::Impl {
     // hipDeviceMallocUncached looked equivalent and is not: with BOTH the slot table and the caller's frame buffer allocated that way,
     // test_group_sessions_equal_their_solo_runs[one_lane] failed in 8 of 13 runs of tests/test_gpu_system.py (a session's second tracking
     // frame tracked from its first frame's table); either one alone, or the table fine-grained, never did (3 / 3, 3 / 3, and every run
-    // since).  ALVA_BAR_FLAG=uncached restores the failing combination for whoever wants to find out why.
+    // since).  ALVA_BAR_FLAG=uncached restores the failing combination for whoever wants to find out why.  What the HIP memory model
+    // promises: fine-grained allocations are coherent between host and device at system scope WHILE kernels run; "uncached" only selects
+    // a cache policy for the device's own accesses and promises nothing about host stores that arrive over the BAR -- so the shipped flag
+    // is the documented one, and the failing one was never covered by a rule.  tests/test_gpu_bar_buffers.py starts 32 sessions (and 30
+    // one-lane groups) back to back under the shipped flag and compares every one with the first, bit for bit.
     static unsigned bar_alloc_flag() {
         static const unsigned f = getenv("ALVA_BAR_FLAG") && strcmp(getenv("ALVA_BAR_FLAG"), "uncached") == 0 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
         return f;
+    }
+    // Host stores into device memory need the whole of it mapped into the CPU's address space (a "large" / resizable BAR).  On a small-BAR
+    // host -- many passthrough VMs -- hipExtMallocWithFlags still succeeds, the pointer is simply not CPU-mapped and the first host store
+    // faults: ask the driver instead of finding out (both paths then fall back: pinned slot table + copy kernel, registered frame buffer).
+    static bool host_can_store_to_device_memory(int device) {
+        int large = 0;
+        if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device) != hipSuccess) {
+            (void) hipGetLastError();
+            return false;
+        }
+        return large != 0;
     }
     static hipError_t scrub_host_written(void *p, size_t bytes) {
         hipError_t e = hipMemset(p, 0, bytes);
@@ -579,7 +594,7 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->lists = getenv("ALVA_TRACK_LISTS") != nullptr;
     m->poll = getenv("ALVA_NO_POLL") == nullptr;
     // the slot table in host-written device memory (track_reserve): ALVA_NO_BAR_TABLE=1 keeps the pinned table + k_track_stage_in (A/B)
-    m->bar_table = getenv("ALVA_NO_BAR_TABLE") == nullptr;
+    m->bar_table = getenv("ALVA_NO_BAR_TABLE") == nullptr && Impl::host_can_store_to_device_memory(m->device);
     int rc = hip_stream ? alva_ctx_create(device, hip_stream, 0, &m->ctx) : alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -847,6 +862,10 @@ int HipStages::alloc_frame_buffer(size_t bytes, uint8_t **h_writable) {
         m->bar_frame = nullptr;
         m->bar_frame_bytes = 0;
     }
+    if (!Impl::host_can_store_to_device_memory(m->device) || getenv("ALVA_NO_BAR_FRAME")) {
+        alva_set_error("alva_system_alloc_frame_buffer: device memory is not host-writable on this system (no large BAR)");
+        return ALVA_ERR_STATE;   // the caller falls back to its registered host buffer (alvaar_amd/system.py)
+    }
     // fine-grained (bar_alloc_flag): every frame rewrites the buffer from the host, an L2 must not answer with the previous frame's line
     if (hipExtMallocWithFlags((void **) &m->bar_frame, bytes, Impl::bar_alloc_flag()) != hipSuccess) {
         (void) hipGetLastError();
@@ -890,6 +909,12 @@ int HipStages::new_frame(const uint8_t *rgba) {
         const int rc = build_from(rgba);
         if (rc) return rc;
         if (in_group) ALVA_HIP(alva_stream_sync(m->st));
+        else {
+            // the buffer is the caller's again when the call returns (frame_done waits): a frame that makes no later stream wait -- too
+            // few tracks, a reset -- must not leave the image kernels reading what the caller's next memImg.write overwrites
+            m->upload_in_flight = true;
+            ALVA_HIP(hipEventRecord(m->upload_done, m->st));
+        }
         return ALVA_OK;
     }
     if (m->registered && rgba >= m->registered && rgba + bytes <= m->registered + m->registered_bytes && (((uintptr_t) rgba) & 15) == 0) {

@@ -8,6 +8,7 @@
 #include "slam/inspect.hpp"
 #include "slam/stage_trace.hpp"
 #include "../../include/alvaar_system.h"
+#include "../../include/alvaar_system_testing.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>

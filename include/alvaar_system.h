@@ -167,10 +167,7 @@ int alva_system_debug_timing_fine(alva_system *sys, double *out32, int reset);
  * keypoints [4] map insertion + keyframe copy | [5] triangulation [6] covisibility [7] local-map matching incl. flattening and merges
  * [8] optimize (local BA + culling) ; inside them: [9] the matchToMap stage call [10] the local-BA stage calls */
 int alva_system_debug_timing_keyframe(alva_system *sys, double *out16, int reset);
-/* Test hook: the two-view initialisation adopts this pose (Twc of the initialisation frame, unit baseline) instead of its own
- * five-point result -- OpenGV's refinement sits at a rounding-noise floor of 1e-6..1e-4, so a differential
- * test against the reference either compares up to that gauge or starts both maps from the same two-view pose.  NULL disarms. */
-int alva_system_debug_set_init_pose(alva_system *sys, const double *pose7);
+/* (the differential tests' one behaviour-changing hook, alva_system_debug_set_init_pose, is declared in alvaar_system_testing.h, not here) */
 const char *alva_system_last_error(void);
 
 #ifdef __cplusplus

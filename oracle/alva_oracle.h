@@ -77,6 +77,7 @@ int orc_compute_5pt(const double *bv1, const double *bv2, int n, int maxIteratio
 
 /* f3: the INTENDED algorithm of System::processPlane (system.cpp:177-342) -- PARITY UNPINNED, see alva_oracle_plane.c. */
 int orc_find_plane(const double *pts, int n, const double *pose7_twc, const int *samples3, int numIterations, float *out16);
+int orc_find_plane_margins(const double *pts, int n, const int *samples3, int numIterations, float *out3);
 
 
 /* f2a: the numeric part of Mapper::triangulateTemporal per keypoint (mapper.cpp:246-287): OpenGV triangulate2

@@ -49,6 +49,20 @@ compile() { # src obj std
   compile "$HERE/ref_shim_map.cpp" "$OBJ/ref_shim_map.o" c++17
   compile "$HERE/ref_shim_relpose.cpp" "$OBJ/ref_shim_relpose.o" c++17
   compile "$HERE/ref_shim_system.cpp" "$OBJ/ref_shim_system.o" c++17
+  compile "$HERE/ref_shim_plane.cpp" "$OBJ/ref_shim_plane.o" c++17
+  # f3's second implementation: the reference's processPlane with its three defects repaired (ref_shim_plane.cpp, ref_plane_patch.sed).
+  # The copy is made and edited HERE, outside the repository's tracked files; every edit must hit exactly once.
+  PATCHED="$OUT/build/patched"
+  mkdir -p "$PATCHED"
+  if [ ! -f "$PATCHED/system_plane.cpp" ] || [ "$HERE/ref_plane_patch.sed" -nt "$PATCHED/system_plane.cpp" ] || [ "$REF/src/slam/src/system.cpp" -nt "$PATCHED/system_plane.cpp" ]; then
+    sed -f "$HERE/ref_plane_patch.sed" "$REF/src/slam/src/system.cpp" > "$PATCHED/system_plane.cpp"
+    for pat in 'pointWorldPos.convertTo(points\[i\], CV_32F);' 'alva_ref_plane_pick(n, indicesPicked);' 'A.col(3).setTo(1.0f);' \
+               'copyTo(A.row(i).colRange(0, 3));' 'planeCoefficientsMatrix.col(3).setTo(1.0f);' 'copyTo(planeCoefficientsMatrix.row(i).colRange(0, 3));' \
+               'copyTo(planePose.rowRange(0, 3).colRange(0, 3));' 'std::vector<float> distsSorted = dists;' 'const float medianDist = distsSorted\['; do
+      [ "$(grep -c "$pat" "$PATCHED/system_plane.cpp")" = 1 ] || { echo "ref_plane_patch.sed: edit '$pat' did not apply exactly once" >&2; exit 1; }
+    done
+  fi
+  compile "$PATCHED/system_plane.cpp" "$OBJ/system_plane_patched.o" "c++20 -DSystem=SystemPlanePatched"
   # the product's host-side map layer over the reference's L1 stages (sys_cpu.cpp): host-logic tests without a GPU
   SLAM="$HERE/../alvaar_amd/csrc/slam"
   mkdir -p "$OBJ/syscpu"
@@ -65,8 +79,17 @@ compile() { # src obj std
 if [ -s "$OBJ/cmds.txt" ]; then
   xargs -P "$J" -I{} bash -c '{}' < "$OBJ/cmds.txt"
 fi
-g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ/ref_shim_relpose.o" "$OBJ/ref_shim_system.o" "$OBJ/sys_cpu.o" "$OBJ"/syscpu/*.o "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
+g++ -shared -o "$OUT/libalva_ref.so" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ/ref_shim_relpose.o" "$OBJ/ref_shim_system.o" "$OBJ/ref_shim_plane.o" "$OBJ/system_plane_patched.o" "$OBJ/sys_cpu.o" "$OBJ"/syscpu/*.o "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
   -Wl,--start-group "$P/lib/libopencv_video.a" "$P/lib/libopencv_calib3d.a" "$P/lib/libopencv_features2d.a" \
   "$P/lib/libopencv_flann.a" "$P/lib/libopencv_imgproc.a" "$P/lib/libopencv_core.a" -Wl,--end-group \
   "$P/lib/libceres.a" "$P"/lib/opencv4/3rdparty/libzlib.a -lpthread -ldl -Wl,--exclude-libs,ALL -Wl,--wrap=gettimeofday -L"$HERE" -lalva_oracle -Wl,-rpath,'$ORIGIN/..'
 echo "built $OUT/libalva_ref.so"
+# ref_run: the same objects as a stand-alone program (tests/ref_runner.py: one reproducible run of the reference's System per process)
+if [ ! -f "$OUT/ref_run" ] || [ "$HERE/ref_run.cpp" -nt "$OUT/ref_run" ] || [ "$OUT/libalva_ref.so" -nt "$OUT/ref_run" ]; then
+  g++ -std=c++17 -O2 -Wall -c "$HERE/ref_run.cpp" -o "$OBJ/ref_run.o"
+  g++ -o "$OUT/ref_run" "$OBJ/ref_run.o" "$OBJ/ref_shim.o" "$OBJ/ref_shim_map.o" "$OBJ/ref_shim_relpose.o" "$OBJ/ref_shim_system.o" "$OBJ/ref_shim_plane.o" "$OBJ/system_plane_patched.o" "$OBJ/sys_cpu.o" "$OBJ"/syscpu/*.o "$OBJ"/slam/*.o "$OBJ"/opengv/*.o \
+    -Wl,--start-group "$P/lib/libopencv_video.a" "$P/lib/libopencv_calib3d.a" "$P/lib/libopencv_features2d.a" \
+    "$P/lib/libopencv_flann.a" "$P/lib/libopencv_imgproc.a" "$P/lib/libopencv_core.a" -Wl,--end-group \
+    "$P/lib/libceres.a" "$P"/lib/opencv4/3rdparty/libzlib.a -lpthread -ldl -Wl,--wrap=gettimeofday -L"$HERE" -lalva_oracle -Wl,-rpath,'$ORIGIN/..'
+  echo "built $OUT/ref_run"
+fi

@@ -3,10 +3,11 @@ digests:  system_long_560_cell12.npz   (640x480, cell 12, 560 frames: test_syste
           system_long_660_cell40.npz   (640x480, cell 40, 660 frames: test_system_equals_reference_long_stream)
           system_long_440_720p.npz     (1280x720, cell 15, 440 frames: test_system_equals_reference_1280x720_long_stream)
 
-Why: the reference is not run-to-run reproducible on this stream (Ceres orders parameter blocks by address: DESIGN.md section 5) -- about
-one run in five takes another discrete path -- while the HIP path is (tools/gpu_determinism_probe.py).  The GPU test compares against at
-most two LIVE runs of the reference; when both happen to be minority runs it falls back to this recording of a MAJORITY run (the path at
-least two of the runs made here agree on, frame by frame).
+Why: inside a Python process the reference is not run-to-run reproducible on these streams (Ceres orders parameter blocks by address:
+DESIGN.md section 5) -- about one run in five takes another discrete path -- while the HIP path is (tools/gpu_determinism_probe.py).
+The recording is of a MAJORITY run (the path at least two of the runs made here agree on, frame by frame); the reproducible run of
+oracle/_ref/ref_run (tests/ref_runner.py, the live reference leg of the GPU tests) walks the same path (tests/test_ref_runner.py).  The
+recordings pin the HIP path without any reference at run time: test_long_stream_equals_the_recorded_reference_run.
 
 Per frame: status, the state counters, 64-bit digests (blake2b) of the keypoint ids in container order + their flags, of the keypoint
 pixels (raw + undistorted, the float bytes), of the keyframe ids, of the map-point table (ids + flags) and of the descriptor medoids; the

@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library loads and exports every symbol include/alvaar_hip.h declares."""
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (alvaar_hip.h: the stages; alvaar_system.h: the drop-in
+surface; alvaar_system_testing.h: the test-only hook), and the public surface header does not declare the test hook."""
 import ctypes
 import re
 from pathlib import Path
@@ -6,9 +7,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def declared_symbols():
-    txt = (ROOT / "include" / "alvaar_hip.h").read_text()
+def declared_symbols(header="alvaar_hip.h"):
+    txt = (ROOT / "include" / header).read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = txt.split("#ifdef __cplusplus\n}")[0] if header == "alvaar_system.h" else txt   # (the C++ class behind the C block calls, not declares)
     return sorted(set(re.findall(r"\b(alva_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -18,6 +20,13 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 10
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in include/alvaar_hip.h but not exported: {missing}"
+    for header in ("alvaar_system.h", "alvaar_system_testing.h"):
+        syms = declared_symbols(header)
+        assert syms, header
+        missing = [s for s in syms if not hasattr(lib, s)]
+        assert not missing, f"declared in include/{header} but not exported: {missing}"
+    assert "alva_system_debug_set_init_pose" not in declared_symbols("alvaar_system.h")       # test-only: alvaar_system_testing.h
+    assert declared_symbols("alvaar_system_testing.h") == ["alva_system_debug_set_init_pose"]
 
 
 def test_no_cpu_fallback_without_device():

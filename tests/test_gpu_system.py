@@ -41,10 +41,15 @@ def _reference_run(frames, w, h, cell, reset_at=(), **kw):
     return ref, out, init_pose
 
 
-def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, reset_at=(), aligned_tol=None, min_kf_created=0, **kw):
+def _differential(frames, w, h, cell, inject, pose_tol, min_kf, min_ba, px_tol=1e-2, reset_at=(), aligned_tol=None, min_kf_created=0, reference=None, **kw):
+    """reference: (records, init_pose, final) of tests/ref_runner.py (ONE reproducible run of the reference in a process of its own: the long
+    streams); default: the reference runs here, in this process"""
     frames = list(frames)
     traj_ref, traj_gpu = [], []
-    ref, rec, init_pose = _reference_run(frames, w, h, cell, reset_at=reset_at, **kw)
+    if reference is None:
+        ref, rec, init_pose = _reference_run(frames, w, h, cell, reset_at=reset_at, **kw)
+    else:
+        rec, init_pose, ref = reference
     gpu = sysdiff.GpuSystem(w, h, cell, **kw)
     try:
         sq, cnt, worst_px, worst_x, worst_pose = 0.0, 0, 0.0, 0.0, 0.0
@@ -130,9 +135,6 @@ def test_system_equals_reference_2000_keypoints():
     _differential(frames, w, h, 12, True, 1e-5, 3, 2)
 
 
-LONG_ATTEMPTS = []   # (test, attempts needed) of this session's long-stream differentials, printed by each of them
-
-
 def _against_recording(frames, w, h, cell, recording, pose_tol):
     """The HIP path against the COMMITTED recording of one majority run of the reference on this stream
     (tests/golden/make_system_long_golden.py: per-frame status, counters, digests of keypoint ids / flags, keypoint pixels, keyframe
@@ -169,57 +171,40 @@ def _against_recording(frames, w, h, cell, recording, pose_tol):
         gpu.close()
 
 
-def _differential_long(*args, attempts=2, name="", recording=None, **kw):
-    """A long stream against the reference, allowing for the REFERENCE's own run-to-run differences.  Two runs of the reference's System on
-    the same frames in one process differ from each other from the first local BA on (pose 4e-14 ... 9e-14 at frame 37 of this stream:
-    tools/ref_determinism_probe.py; Ceres keeps its parameter blocks ordered by ADDRESS, so reduction orders follow the heap layout), and
-    the pipeline amplifies 1e-12 to a changed discrete decision within a few hundred frames.  Our path is
-    deterministic; a stream passes when it agrees frame by frame with one of at most TWO runs of the reference (observed: about one
-    reference run in five of the 560-frame, 2500-keypoint stream takes another discrete path somewhere; none of the shorter streams ever
-    did) -- the attempts needed are recorded and printed, and the first decision that differed is printed with its frame."""
-    last = None
-    for a in range(1, attempts + 1):
-        try:
-            out = _differential(*args, **kw)
-            LONG_ATTEMPTS.append((name, a))
-            print(f"\n  long-stream differential '{name}': agreed with reference run {a} of at most {attempts}; this session so far: {LONG_ATTEMPTS}")
-            return out
-        except AssertionError as e:
-            last = e
-            print(f"\n  '{name}': differs from run {a} of the reference -- first difference: {str(e).splitlines()[0][:200]}")
-    if recording is not None:
-        # Both live runs of the reference took a minority path (they differ from EACH OTHER about one time in five on this stream; the
-        # HIP path is deterministic, tools/gpu_determinism_probe.py).  The committed recording of a majority run decides: every frame's
-        # discrete state must equal it exactly.
-        frames, w, h, cell, _, pose_tol = args[:6]
-        rmse = _against_recording(list(frames), w, h, cell, recording, pose_tol)
-        LONG_ATTEMPTS.append((name, "recording"))
-        print(f"\n  long-stream differential '{name}': disagreed with {attempts} live runs of the reference, EQUAL to the committed recording of "
-              f"a majority run on every frame (pose RMSE {rmse:.2e}); this session so far: {LONG_ATTEMPTS}")
-        return rmse, None
-    raise AssertionError(f"'{name}' disagreed with {attempts} consecutive runs of the reference; last: {last}")
+def _long_stream(w, h, n, steps, canvas_seed, noise_seed):
+    """a crop sequence of n frames with noise, played forwards and backwards for `steps` steps: (base gray frames, base index per step, frames)"""
+    canvas = synth.texture_canvas(w, h, canvas_seed)
+    base = np.stack([synth.frame_gray(canvas, k, w, h, noise_seed=noise_seed) for k in range(n)])
+    period = 2 * (n - 1)
+    index = [(k % period) if (k % period) < n else period - (k % period) for k in range(steps)]
+    rgba = [synth.gray_to_rgba(g) for g in base]
+    return base, index, [rgba[i] for i in index]
+
+
+def _differential_long(base, index, frames, w, h, cell, pose_tol, min_kf, min_ba, **kw):
+    """A long stream against ONE run of the reference.  Inside this process the reference is not reproducible on these streams (Ceres keeps
+    its parameter blocks ordered by ADDRESS, so its reduction orders follow the heap layout; two runs differ from the first local BA on and
+    about one in five of the 560-frame, 2500-keypoint stream ends on another discrete path).  oracle/_ref/ref_run (tests/ref_runner.py) runs
+    it in a process that holds nothing else, without address-space randomisation: its records are a function of the frames, bit for bit,
+    and the comparison needs no second attempt."""
+    import ref_runner
+    return _differential(frames, w, h, cell, True, pose_tol, min_kf, min_ba, reference=ref_runner.run_reference(base, index, w, h, cell), **kw)
 
 
 def test_system_equals_reference_long_stream():
     """660 frames (200-frame crop sequence with noise, forwards / backwards): more than 30 keyframes -- the 30-keyframe window, the keyframe
     filter of Mapper::optimize (from keyframe 20 on), the second local-map round; >= 120 tracked frames after initialisation"""
-    w, h, n = 640, 480, 200
-    canvas = synth.texture_canvas(w, h, 7)
-    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
-    period = 2 * (n - 1)
-    frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(660)]
-    _differential_long(frames, w, h, 40, True, 1e-5, 8, 30, name="660 frames, cell 40", recording="system_long_660_cell40.npz")
+    w, h = 640, 480
+    base, index, frames = _long_stream(w, h, 200, 660, 7, 11)
+    _differential_long(base, index, frames, w, h, 40, 1e-5, 8, 30)
 
 
 def test_system_equals_reference_long_stream_2000_keypoints():
     """the same stream at BASELINE configs[1]'s geometry (cell 12 => ~2500 keypoints), 560 frames: > 30 keyframes, ~15 culled by the keyframe
     filter, ~3000 map-point merges"""
-    w, h, n = 640, 480, 200
-    canvas = synth.texture_canvas(w, h, 7)
-    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(n)]
-    period = 2 * (n - 1)
-    frames = [base[(k % period) if (k % period) < n else period - (k % period)] for k in range(560)]
-    _differential_long(frames, w, h, 12, True, 1e-5, 8, 25, name="560 frames, cell 12", recording="system_long_560_cell12.npz")
+    w, h = 640, 480
+    base, index, frames = _long_stream(w, h, 200, 560, 7, 11)
+    _differential_long(base, index, frames, w, h, 12, 1e-5, 8, 25)
 
 
 def test_system_equals_reference_rotating_camera_with_noise():
@@ -425,13 +410,9 @@ def test_system_equals_reference_1280x720_long_stream():
     """configs[4]'s geometry over a LONG stream: 1280x720, cell 15 (~5500 keypoints), 440 frames forwards / backwards => more than 20
     keyframes: the keyframe filter of Mapper::optimize (from keyframe 20 on, mapper.cpp:66-142), map-point culling and local BA over a
     full covisibility window at the size configs[4] names (reference: visual_frontend.cpp:517-552, mapper.cpp:9-64)"""
-    w, h, n = 1280, 720, 150
-    canvas = synth.texture_canvas(w, h, 9)
-    base = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=3)) for k in range(n)]
-    period = 2 * (n - 1)
-    frames = (base[(k % period) if (k % period) < n else period - (k % period)] for k in range(440))
-    _differential_long(list(frames), w, h, 15, True, 1e-5, 8, 20, min_kf_created=21, name="440 frames, 1280x720, cell 15",
-                       recording="system_long_440_720p.npz")
+    w, h = 1280, 720
+    base, index, frames = _long_stream(w, h, 150, 440, 9, 3)
+    _differential_long(base, index, frames, w, h, 15, 1e-5, 8, 20, min_kf_created=21)
 
 
 def test_concurrent_sessions_equal_their_solo_runs():
@@ -583,7 +564,8 @@ def test_next_frame_hints_do_not_change_results():
 @pytest.mark.parametrize("name", ["560_cell12", "660_cell40", "440_720p"])
 def test_long_stream_equals_the_recorded_reference_run(name):
     """Each of the three long streams against the COMMITTED recording of a majority run of the reference on it (tests/golden/
-    make_system_long_golden.py): deterministic on both sides, so this comparison never needs a second attempt -- every frame's status,
+    make_system_long_golden.py; the reproducible run of oracle/_ref/ref_run walks the same discrete path): a pin that needs no reference
+    at run time -- every frame's status,
     counters, keypoint ids / flags / pixels (digests of the bytes), keyframe ids, map-point table and descriptor medoids equal the
     recording, pose RMSE <= 1e-5 (from the recording's two-view pose: the init-pose hook, see README "pose parity")."""
     import importlib.util

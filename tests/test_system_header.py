@@ -15,7 +15,7 @@ def _compile(cmd, src, suffix):
 
 
 def test_headers_are_plain_c():
-    _compile(["gcc", "-std=c99", "-Wall", "-Werror"], '#include "alvaar_hip.h"\n#include "alvaar_system.h"\nint main(void){return 0;}\n', ".c")
+    _compile(["gcc", "-std=c99", "-Wall", "-Werror"], '#include "alvaar_hip.h"\n#include "alvaar_system.h"\n#include "alvaar_system_testing.h"\nint main(void){return 0;}\n', ".c")
 
 
 def test_system_class_signatures():
