@@ -19,6 +19,7 @@
 // are compared with the reference under a tolerance (FP64 sums in a different order anyway), not bitwise.
 #include "common.hpp"
 #include "multi_kernel.hpp"
+#include "p3p_device.hpp"   // (the fused P3P -> PnP launch below; in front of the pragma: P3P is compiled without contraction)
 #pragma clang fp contract(fast)
 #include "lm_device.hpp"
 #include "wave_utils.hpp"
@@ -678,6 +679,19 @@ struct PnpBatchItem {
 // several sessions' refinements in one launch (lane.hpp): one workgroup each, with k_pnp's completion word
 ALVA_MULTI_KERNEL(MK_PNP, k_pnp_multi, PnpBatchItem, dim3(NT), NT, pnp_body(A.A, A.active, A.chi2, A.depth, A.bad, A.out, A.p3p, A.inlier0, A.p3p_outlier));
 
+// ---- the single session's pose solve as ONE launch (round 6) ---------------------------------------------------------------------
+// VisualFrontend::computePose chains P3P-LMedS and the refinement (visual_frontend.cpp:245-417).  The P3P launch already ends in ONE
+// workgroup -- the last to arrive selects the winner and classifies its inliers -- and the refinement is one workgroup of the same 512
+// threads: that workgroup simply goes on.  Its selection record and inlier mask are its own stores (workgroup scope: a barrier orders
+// them), so the kernel boundary between k_p3p_s and k_pnp -- an agent-scope release, a dispatch, ~4 us of the frame's dependent chain --
+// disappears; every other workgroup has left long before.  Same arithmetic as the two launches (p3p_block, pnp_body).
+static_assert(NT == 512, "the fused launch runs P3P's workgroup shape");
+__global__ void __launch_bounds__(NT) k_p3p_pnp_s(P3pArgs P, P3pInlineSamples S, PnpBatchItem it) {
+    if (!p3p_block<0, NT>(P, blockIdx.x, S.v + 4 * blockIdx.x)) return;
+    __syncthreads();
+    pnp_body(it.A, it.active, it.chi2, it.depth, it.bad, it.out, it.p3p, it.inlier0, it.p3p_outlier);
+}
+
 __global__ void __launch_bounds__(NT) k_pnp_batch(const PnpBatchItem *__restrict__ items) {
     const PnpBatchItem &it = items[blockIdx.x];
     pnp_block(it.A, it.active, it.chi2, it.depth, it.bad, it.out, it.p3p, it.inlier0, it.p3p_outlier);
@@ -765,13 +779,26 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
     if (rc) return rc;
     P3pSelectOut *d_sel = (P3pSelectOut *) (base + off_sel);
     uint8_t *d_inl = base + off_inl;
-    rc = alva_p3p_enqueue(ctx, P.bearings, P.wpts, n, P.p3p_iters, P.p3p_err, P.do_random, P.seed, P.fx, P.fy, P.H, (int *) P.pin, d_sel,
-                          d_inl);
+    P3pArgs PA{};
+    rc = alva_p3p_prepare(ctx, P.bearings, P.wpts, n, P.p3p_iters, P.p3p_err, P.do_random, P.seed, P.fx, P.fy, P.H, (int *) P.pin, d_sel, d_inl, &PA);
     if (rc) return rc;
     P.A.seq = ++P.seq;
     ((PnpOut *) (P.pin + P.poff_out))->seq = 0;   // the staging may be fresh memory; every earlier user of it has completed (polled or synchronised)
     const PnpBatchItem item{P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad, (PnpOut *) (P.pin + P.poff_out),
                             (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po};
+    // ONE launch for both stages: a session of its own (no lane), samples that fit the kernel arguments, keys that fit the default
+    // dynamic-LDS limit (ALVA_POSE_UNFUSED=1: the two launches, for A/B)
+    static const bool fuse = getenv("ALVA_POSE_UNFUSED") == nullptr;
+    if (fuse && !g_alva_lane && P.H <= P3P_INLINE_H && alva_p3p_inline_samples_ok() && n <= 7168) {
+        P3pInlineSamples S;
+        memcpy(S.v, PA.samples, (size_t) P.H * 16);
+        ctx->p3p_deferred = false;
+        hipLaunchKernelGGL(k_p3p_pnp_s, dim3((unsigned) P.H), dim3(NT), (size_t) n * sizeof(double), ctx->stream, PA, S, item);
+        ALVA_LAUNCH_CHECK();
+        return ALVA_OK;
+    }
+    rc = alva_p3p_launch(ctx, PA);
+    if (rc) return rc;
     // deposited only behind a DEPOSITED P3P (same lane stream, chain order); a P3P that was launched on this context's own stream
     // (n > 7168) is followed on that stream: the lane's stream and the session's are not ordered against each other
     if (ctx->p3p_deferred && alva_lane_defer(MK_PNP, ctx, 1, 0, &item, sizeof(item))) return ALVA_OK;

@@ -16,6 +16,14 @@ int alva_p3p_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_wp
                      int do_random, uint32_t seed, float fx, float fy, int n_draws, int *pin_samples, P3pSelectOut *out,
                      uint8_t *inlier);
 
+// the same in two steps (pnp.hip's fused P3P -> PnP launch takes the prepared arguments and launches them itself): samples drawn into
+// pin_samples, scratch carved, *args filled | the launch alva_p3p_enqueue makes (lane deposit, or k_p3p_s / k_p3p on ctx->stream)
+struct P3pArgs;
+int alva_p3p_prepare(alva_ctx *ctx, const double *d_bearings, const double *d_wpts, int n, int max_iters, float err_threshold, int do_random,
+                     uint32_t seed, float fx, float fy, int n_draws, int *pin_samples, P3pSelectOut *out, uint8_t *inlier, P3pArgs *args);
+int alva_p3p_launch(alva_ctx *ctx, const P3pArgs &args);
+bool alva_p3p_inline_samples_ok();
+
 // alva_compute_pose_collect that also returns the accepted P3P pose (pnp.hip)
 int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose7_p3p, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,
                                   int *h_status);
