@@ -136,8 +136,9 @@ static int ctx_create(int device, void *hip_stream, int own_stream, int priority
         alva_set_error("hipHostMalloc: %s", hipGetErrorString(e));
         return ALVA_ERR_NOMEM;
     }
-    e = hipMalloc((void **) &c->d_counters, 64 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 64 * sizeof(int));
+    // 64 arrival counters + 8 KB behind them: the relay block of the fused pose launch (pnp.hip k_pose_all: d_counters + 64)
+    e = hipMalloc((void **) &c->d_counters, 64 * sizeof(int) + 8192);
+    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 64 * sizeof(int) + 8192);
     if (e != hipSuccess) {
         (void) hipHostFree(c->pinned);
         if (c->owns_stream) (void) hipStreamDestroy(c->stream);

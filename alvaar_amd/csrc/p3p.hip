@@ -78,6 +78,14 @@ struct Sampler {
 
 }  // namespace
 
+// the first `count` outputs of the sampler's generator -- dist(alg) of Sampler::draw, which does not depend on the number of points
+int alva_p3p_raw_draws(int count, int do_random, uint32_t seed, int *h_raw) {
+    ALVA_ARG(count >= 0 && h_raw);
+    Sampler s(0, do_random != 0, seed);
+    for (int k = 0; k < count; k++) h_raw[k] = s.dist(s.alg);
+    return ALVA_OK;
+}
+
 extern "C" int alva_p3p_draw_samples(int n_points, int count, int do_random, uint32_t seed, int *h_samples) {
     ALVA_ARG(n_points >= 4 && count >= 0 && h_samples);
     Sampler s(n_points, do_random != 0, seed);
@@ -93,7 +101,7 @@ int alva_p3p_prepare(alva_ctx *ctx, const double *d_bearings, const double *d_wp
     float focal = fx + fy;          // multi_view_geometry.cpp:72-76
     focal /= 2.f;
     const double threshold = 1.0 - std::cos(std::atan((double) (err_threshold / focal)));
-    {
+    if (pin_samples) {   // (null: the caller draws later, when it knows n -- the fused pose launch sizes everything for an upper bound)
         Sampler smp(n, do_random != 0, seed);
         for (int k = 0; k < H; k++) smp.draw(pin_samples + 4 * k);
     }

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "multi_kernel.hpp"
 #include "p3p_device.hpp"   // (the fused P3P -> PnP launch below; in front of the pragma: P3P is compiled without contraction)
+#include "track_compact_device.hpp"
 #pragma clang fp contract(fast)
 #include "lm_device.hpp"
 #include "wave_utils.hpp"
@@ -692,6 +693,110 @@ __global__ void __launch_bounds__(NT) k_p3p_pnp_s(P3pArgs P, P3pInlineSamples S,
     pnp_body(it.A, it.active, it.chi2, it.depth, it.bad, it.out, it.p3p, it.inlier0, it.p3p_outlier);
 }
 
+// ---- ... and the whole tail of the tracking frame as ONE launch: compaction -> P3P-LMedS -> refinement ---------------------------------
+// The tracking frame's chain was tracker -> compaction -> P3P -> PnP, and the compaction (13 us + a kernel boundary) sat on it for two
+// reasons: the pose solve reads the correspondences it gathers, and the host needs the tracker's counts before it can draw P3P's samples
+// -- the host did that WHILE the compaction ran.  Here the launch is queued right behind the tracker, before the host knows anything:
+//   phase A   the first G workgroups ARE the compaction (track_compact_body: per-slot results to the host, correspondences gathered,
+//             completion word published by the last one) -- meanwhile the host sees the tracker's early word, draws the samples for the
+//             now known n into the pinned PoseGo block and publishes its go word (or "abort": p3pReq_, too few correspondences);
+//   wait      every workgroup: all slices gathered (a device word the last compaction workgroup writes) and the host's word -- a few
+//             polls, bounded; an aborted launch ends here;
+//   phase B   P3P-LMedS, one workgroup per hypothesis, n / H / its four sample indices read from the PoseGo block;
+//   phase C   the selecting workgroup goes on with the refinement (as k_p3p_pnp_s).
+// No workgroup ever waits for a workgroup with a higher index (phase A's are the first ones dispatched), so the wait cannot deadlock on
+// residency; the host always writes one of the two words (HipStages::track_begin), and the poll gives up after ~1 s anyway.
+struct PoseGo {
+    long long word;   // seq = go, -seq = abort (the launch's sequence number: strictly increasing, so a stale word never matches)
+    int n, H;
+    int samples[4 * P3P_INLINE_H];
+};
+__device__ __forceinline__ int sys_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#define POSE_ALL_STAMP(k)                                                                                                                  \
+    do {                                                                                                                                   \
+        if (it.A.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || (int) blockIdx.x == G || blockIdx.x == gridDim.x - 1))                  \
+            it.A.dbg[4048 + 8 * (blockIdx.x == 0 ? 0 : ((int) blockIdx.x == G ? 1 : 2)) + (k)] = wall_clock64();                        \
+    } while (0)
+// relay: 8-byte words in DEVICE memory (ctx->d_counters + 64): [0] the word, [1] n | H << 32, [2 + h] hypothesis h's samples 0,1 | [2 +
+// P3P_INLINE_H + h] its samples 2,3.  Workgroup 0 alone talks to the host: 128 workgroups polling pinned host memory over the bus is
+// 128 reads in flight against the compaction's own traffic to the host; the others poll the relay's word in device memory.
+__global__ void __launch_bounds__(NT) k_pose_all(TrackSlots D, int G, P3pArgs P, PnpBatchItem it, const PoseGo *go, unsigned long long *relay,
+                                                 int seq) {
+    __shared__ int s_go[8];   // verdict, n, H, - | this workgroup's four sample indices
+    POSE_ALL_STAMP(0);
+    // workgroups [0, G): the compaction, nothing else (their slices' host copies and system-scope fences run beside the pose solve);
+    // workgroups [G, G + H): the hypotheses; workgroup G also relays the host's word
+    if ((int) blockIdx.x < G) {
+        (void) track_compact_body<NT, true>(D, (int) blockIdx.x, G);
+        return;
+    }
+    const int hb = (int) blockIdx.x - G;   // this workgroup's hypothesis
+    POSE_ALL_STAMP(1);
+    if (hb == 0) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            long long w = 0;
+            for (;;) {
+                w = __hip_atomic_load(&go->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (w == (long long) seq || w == -(long long) seq || ++spins > (1u << 22)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_go[0] = w == (long long) seq;
+        }
+        __syncthreads();
+        if (s_go[0]) {
+            const int t = threadIdx.x;
+            if (t == 0) agent_store(relay + 1, (unsigned long long) (unsigned) sys_load(&go->n) | ((unsigned long long) (unsigned) sys_load(&go->H) << 32));
+            else if (t <= 2 * P3P_INLINE_H) {
+                const int h = (t - 1) >> 1, half = (t - 1) & 1;
+                agent_store(relay + 2 + half * P3P_INLINE_H + h, (unsigned long long) (unsigned) sys_load(go->samples + 4 * h + 2 * half) |
+                                                                     ((unsigned long long) (unsigned) sys_load(go->samples + 4 * h + 2 * half + 1) << 32));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) agent_store(relay, (unsigned long long) (long long) (s_go[0] ? seq : -seq));
+    }
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(D.cnt + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq && ok) {
+            __builtin_amdgcn_s_sleep(8);
+            ok = ++spins < (1u << 23);
+        }
+        POSE_ALL_STAMP(2);
+        long long w = 0;
+        while (ok) {
+            w = (long long) agent_load(relay);
+            if (w == (long long) seq || w == -(long long) seq) break;
+            __builtin_amdgcn_s_sleep(8);
+            ok = ++spins < (1u << 23);
+        }
+        s_go[0] = ok && w == (long long) seq;
+    }
+    __syncthreads();
+    POSE_ALL_STAMP(3);
+    if (!s_go[0]) return;
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x, h = min(hb, P3P_INLINE_H - 1);
+        const unsigned long long v = agent_load(relay + (k == 0 ? 1 : 2 + (k - 1) * P3P_INLINE_H + h));
+        s_go[k == 0 ? 1 : 2 + 2 * k] = (int) (unsigned) v;
+        s_go[k == 0 ? 2 : 3 + 2 * k] = (int) (unsigned) (v >> 32);
+    }
+    __syncthreads();
+    if (hb >= s_go[2]) return;
+    // No agent-scope acquire here, on purpose: an L2 invalidate per workgroup, staggered over the scoring phase, has every XCD refetch the
+    // correspondences again and again (measured: the launch took 147 us instead of ~70).  It is not needed either: the kernel boundary in
+    // front of this launch left no line of the gathered arrays in any L2, nothing reads them before this point, and their writers wrote
+    // them back (system-scope fence) before they arrived -- so the first read after the wait misses and fetches what they wrote.
+    P.n = s_go[1];
+    P.H = s_go[2];
+    it.A.n = s_go[1];
+    if (!p3p_block<0, NT>(P, hb, s_go + 4)) return;
+    __syncthreads();
+    pnp_body(it.A, it.active, it.chi2, it.depth, it.bad, it.out, it.p3p, it.inlier0, it.p3p_outlier);
+}
+
 __global__ void __launch_bounds__(NT) k_pnp_batch(const PnpBatchItem *__restrict__ items) {
     const PnpBatchItem &it = items[blockIdx.x];
     pnp_block(it.A, it.active, it.chi2, it.depth, it.bad, it.out, it.p3p, it.inlier0, it.p3p_outlier);
@@ -760,6 +865,11 @@ struct alva_pose_pending {
     uint8_t *pin;
     bool active;
     int seq = 0;
+    int go_seq = 0;   // > 0: a k_pose_all is queued and waits for alva_pose_all_go / _abort (the tracker launch's sequence number)
+    // the fused launch's sampler, split: the generator's outputs do not depend on n (uniform_int_distribution<>(0, INT_MAX) over
+    // std::mt19937: SampleConsensusProblem.hpp:40-46), only "% (n - i)" and the swaps do -- so the 4 H raw draws are made when the
+    // launch is queued (the tracker is still running) and alva_pose_all_go is left with 4 H swaps on a persistent iota array
+    std::vector<int> raw, iota;
 };
 
 static void pose_pending_free(void *p) { delete (alva_pose_pending *) p; }
@@ -808,19 +918,9 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
     return ALVA_OK;
 }
 
-extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
-                                         int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx,
-                                         float fy, float cx, float cy) {
-    ALVA_ARG(ctx && n >= 0 && n <= 64 * NT && p3p_iters > 0 && pnp_iters >= 0);
-    if (!ctx->pose_pending) {
-        ctx->pose_pending = new alva_pose_pending();
-        ctx->pose_pending_free = pose_pending_free;
-    }
-    alva_pose_pending &P = *(alva_pose_pending *) ctx->pose_pending;
-    P.active = true;
-    P.n = n;
-    if (n < 4) return ALVA_OK;  // visual_frontend.cpp:249-257
-    ALVA_ARG(d_bearings && d_uv && d_wpts);
+// ---- the fused tail of the tracking frame (k_pose_all): enqueue right behind the tracker | go, once the host knows n | abort ----------
+static void pose_params(alva_pose_pending &P, const double *d_bearings, const double *d_uv, const double *d_wpts, int n, int p3p_iters, float p3p_err,
+                        int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx, float fy, float cx, float cy) {
     P.bearings = d_bearings;
     P.wpts = d_wpts;
     P.p3p_iters = p3p_iters;
@@ -844,6 +944,127 @@ extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings
     A.max_iters = pnp_iters;
     A.ftol = 1.e-3;
     A.dbg = alva_kstamp_buffer();
+}
+
+bool alva_pose_all_possible(int n_cap, int p3p_iters) {
+    static const bool on = getenv("ALVA_POSE_UNFUSED") == nullptr && getenv("ALVA_NO_POSE_ALL") == nullptr;
+    return on && !g_alva_lane && n_cap >= 4 && n_cap <= 7168 && p3p_iters + 28 <= P3P_INLINE_H && alva_p3p_inline_samples_ok();
+}
+
+int alva_pose_all_enqueue(alva_ctx *ctx, const TrackSlots &D, int G, int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters,
+                          float chi2_th, float fx, float fy, float cx, float cy) {
+    ALVA_ARG(ctx && alva_pose_all_possible(D.n, p3p_iters) && G >= 1);
+    if (!ctx->pose_pending) {
+        ctx->pose_pending = new alva_pose_pending();
+        ctx->pose_pending_free = pose_pending_free;
+    }
+    alva_pose_pending &P = *(alva_pose_pending *) ctx->pose_pending;
+    const int n_cap = D.n;
+    pose_params(P, D.Pbv, D.Puv, D.Pwpt, n_cap, p3p_iters, p3p_err, do_random, seed, pnp_iters, chi2_th, fx, fy, cx, cy);
+    P.active = false;   // until alva_pose_all_go
+    P.n = 0;
+    const size_t off_act = (size_t) n_cap * 8, off_dep = off_act + (size_t) n_cap, off_sel = (off_dep + (size_t) n_cap + 63) / 64 * 64;
+    const size_t off_inl = off_sel + 256;
+    uint8_t *base = nullptr;
+    int rc = alva_ctx_scratch(ctx, 3, off_inl + (size_t) n_cap, (void **) &base);
+    if (rc) return rc;
+    // pinned: PoseGo (samples inside) | PnpOut | bad(n) | p3p outlier(n)
+    P.poff_out = (sizeof(PoseGo) + 255) / 256 * 256;
+    P.poff_bad = P.poff_out + 256;
+    P.poff_po = P.poff_bad + (size_t) n_cap;
+    rc = alva_ctx_pinned(ctx, P.poff_po + (size_t) n_cap, (void **) &P.pin);
+    if (rc) return rc;
+    P3pSelectOut *d_sel = (P3pSelectOut *) (base + off_sel);
+    uint8_t *d_inl = base + off_inl;
+    P3pArgs PA{};
+    rc = alva_p3p_prepare(ctx, P.bearings, P.wpts, n_cap, P.p3p_iters, P.p3p_err, P.do_random, P.seed, P.fx, P.fy, P.H, nullptr, d_sel, d_inl, &PA);
+    if (rc) return rc;
+    P.A.seq = ++P.seq;
+    ((PnpOut *) (P.pin + P.poff_out))->seq = 0;
+    P.go_seq = D.seq;
+    {
+        P.raw.resize((size_t) P.H * 4);
+        rc = alva_p3p_raw_draws(P.H * 4, P.do_random, P.seed, P.raw.data());
+        if (rc) return rc;
+        const size_t have = P.iota.size();
+        if ((size_t) n_cap > have) {
+            P.iota.resize((size_t) n_cap);
+            for (size_t i = have; i < (size_t) n_cap; i++) P.iota[i] = (int) i;
+        }
+    }
+    const PnpBatchItem item{P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad, (PnpOut *) (P.pin + P.poff_out),
+                            (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po};
+    ctx->p3p_deferred = false;
+    hipLaunchKernelGGL(k_pose_all, dim3((unsigned) (P.H + G)), dim3(NT), (size_t) n_cap * sizeof(double), ctx->stream, D, G, PA, item,
+                       (const PoseGo *) P.pin, reinterpret_cast<unsigned long long *>(ctx->d_counters + 64), D.seq);
+    ALVA_LAUNCH_CHECK();
+    return ALVA_OK;
+}
+
+// the host's word to a queued k_pose_all: n correspondences (4 <= n <= the launch's slot count) -> samples drawn, go
+int alva_pose_all_go(alva_ctx *ctx, int n) {
+    alva_pose_pending *pp = (alva_pose_pending *) ctx->pose_pending;
+    ALVA_ARG(pp && pp->go_seq > 0 && n >= 4);
+    alva_pose_pending &P = *pp;
+    PoseGo *go = (PoseGo *) P.pin;
+    if ((size_t) n > P.iota.size() || P.raw.size() < (size_t) P.H * 4) {
+        (void) alva_pose_all_abort(ctx);
+        alva_set_error("alva_pose_all_go: %d correspondences, the launch was sized for %zu", n, P.iota.size());
+        return ALVA_ERR_ARG;
+    }
+    {
+        // Sampler::draw of p3p.hip (SampleConsensusProblem.hpp:65-84: a prefix Fisher-Yates on an index array that persists across the
+        // draws of one call) on the raw draws made at enqueue time; the touched entries are put back afterwards: the array stays iota
+        int *sh = P.iota.data();
+        const size_t index_size = (size_t) n;
+        static thread_local std::vector<int> touched;
+        touched.clear();
+        for (int k = 0; k < P.H; k++) {
+            for (unsigned i = 0; i < 4; ++i) {
+                const size_t j = i + ((size_t) P.raw[(size_t) 4 * k + i] % (index_size - i));
+                std::swap(sh[i], sh[j]);
+                touched.push_back((int) j);
+            }
+            for (int i = 0; i < 4; i++) go->samples[4 * k + i] = sh[i];
+        }
+        for (int i = 0; i < 4; i++) sh[i] = i;
+        for (int j: touched) sh[j] = j;
+    }
+    int rc = ALVA_OK;
+    go->n = n;
+    go->H = P.H;
+    P.n = n;
+    P.A.n = n;
+    P.active = true;
+    __atomic_store_n(&go->word, (long long) P.go_seq, __ATOMIC_RELEASE);
+    P.go_seq = 0;
+    return ALVA_OK;
+}
+
+int alva_pose_all_abort(alva_ctx *ctx) {
+    alva_pose_pending *pp = (alva_pose_pending *) ctx->pose_pending;
+    if (!pp || pp->go_seq <= 0) return ALVA_OK;
+    __atomic_store_n(&((PoseGo *) pp->pin)->word, -(long long) pp->go_seq, __ATOMIC_RELEASE);
+    pp->go_seq = 0;
+    pp->active = false;
+    return ALVA_OK;
+}
+
+extern "C" int alva_compute_pose_enqueue(alva_ctx *ctx, const double *d_bearings, const double *d_uv, const double *d_wpts, int n,
+                                         int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters, float chi2_th, float fx,
+                                         float fy, float cx, float cy) {
+    ALVA_ARG(ctx && n >= 0 && n <= 64 * NT && p3p_iters > 0 && pnp_iters >= 0);
+    if (!ctx->pose_pending) {
+        ctx->pose_pending = new alva_pose_pending();
+        ctx->pose_pending_free = pose_pending_free;
+    }
+    alva_pose_pending &P = *(alva_pose_pending *) ctx->pose_pending;
+    (void) alva_pose_all_abort(ctx);   // (a queued fused launch nobody answered: cannot happen through HipStages, cheap to be sure)
+    P.active = true;
+    P.n = n;
+    if (n < 4) return ALVA_OK;  // visual_frontend.cpp:249-257
+    ALVA_ARG(d_bearings && d_uv && d_wpts);
+    pose_params(P, d_bearings, d_uv, d_wpts, n, p3p_iters, p3p_err, do_random, seed, pnp_iters, chi2_th, fx, fy, cx, cy);
     return pose_launch(ctx, P);
 }
 

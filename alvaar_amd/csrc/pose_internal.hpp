@@ -23,6 +23,17 @@ int alva_p3p_prepare(alva_ctx *ctx, const double *d_bearings, const double *d_wp
                      uint32_t seed, float fx, float fy, int n_draws, int *pin_samples, P3pSelectOut *out, uint8_t *inlier, P3pArgs *args);
 int alva_p3p_launch(alva_ctx *ctx, const P3pArgs &args);
 bool alva_p3p_inline_samples_ok();
+int alva_p3p_raw_draws(int count, int do_random, uint32_t seed, int *h_raw);
+
+// The fused tail of the single session's tracking frame (pnp.hip k_pose_all: compaction -> P3P -> PnP in one launch, queued right behind
+// the tracker): enqueue | the host's answer once the tracker's early word gave it n (go: draws the samples; abort: the launch ends after
+// its compaction phase).  Every enqueue MUST be answered by exactly one of the two; alva_compute_pose_collect_p3p collects a "go".
+struct TrackSlots;
+bool alva_pose_all_possible(int n_slots, int p3p_iters);
+int alva_pose_all_enqueue(alva_ctx *ctx, const TrackSlots &D, int compact_workgroups, int p3p_iters, float p3p_err, int do_random, uint32_t seed,
+                          int pnp_iters, float chi2_th, float fx, float fy, float cx, float cy);
+int alva_pose_all_go(alva_ctx *ctx, int n);
+int alva_pose_all_abort(alva_ctx *ctx);
 
 // alva_compute_pose_collect that also returns the accepted P3P pose (pnp.hip)
 int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose7_p3p, uint8_t *h_p3p_outlier, uint8_t *h_pnp_outlier,

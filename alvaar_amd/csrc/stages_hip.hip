@@ -216,101 +216,9 @@ __global__ void __launch_bounds__(TRK_NT) k_track_finish(TrackDev D) {
     }
 }
 
-// The slot-wise step (track_slots.hpp): after the tracker launches every slot holds its verdict, position, undistorted position and
-// bearing; what is left is the list of the pose solve -- the tracked 3-D slots in slot order (visual_frontend.cpp:275-298) -- the
-// header, and the counters' reset for the next frame.
-constexpr int CMP_NT = 256, CMP_MAX_WG = 32;
-__device__ __forceinline__ void track_compact_body(const TrackSlots &D, const int g, const int G) {
-    // SEVERAL workgroups (one used to do all of it: 107 KB to the host + 145 KB of gathers through one compute unit took 23 us).
-    // Every workgroup owns a contiguous slice of the slots.  It counts the pose flags of the slots in front of its slice by itself
-    // (2 bytes per slot: cheaper than a cross-workgroup scan), copies its slice's results to pinned host memory and gathers its slice's
-    // correspondences.  Ordering against the completion word: every workgroup ends with a system-scope fence and an arrival on a device
-    // counter; the workgroup that arrives LAST writes the header and then the word (system-scope release) -- the host reads the word
-    // with acquire semantics, so it sees every slice.
-    __shared__ int s_cnt[CMP_NT / 64 + 1];
-    const int per = ((D.n + G - 1) / G + 63) / 64 * 64;   // slice length, a multiple of the wave size
-    const int lo = g * per, hi = min(D.n, lo + per);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // pose flags in front of the slice (and, for the header, behind it): ballot counts
-    int before = 0, total = 0;
-    for (int i0 = 0; i0 < D.n; i0 += CMP_NT) {
-        const int i = i0 + (int) threadIdx.x;
-        const bool f = i < D.n && D.d_code[i] != 0 && D.d_is3d[i] != 0;
-        const unsigned long long bal = __ballot(f);
-        const int wbase = i0 + wave * 64;
-        if (lane == 0) {
-            const int c = __popcll(bal);
-            total += c;
-            if (wbase + 64 <= lo) before += c;
-            else if (wbase < lo) before += __popcll(bal & ((1ull << (lo - wbase)) - 1ull));   // (lo is a multiple of 64: never taken)
-        }
-    }
-    if (lane == 0) s_cnt[wave] = before;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < CMP_NT / 64; w++) base += s_cnt[w];
-    __syncthreads();
-    if (lane == 0) s_cnt[wave] = total;
-    __syncthreads();
-    int n_pose = 0;
-    for (int w = 0; w < CMP_NT / 64; w++) n_pose += s_cnt[w];
-    __syncthreads();
-    for (int i0 = lo; i0 < hi; i0 += CMP_NT) {
-        const int i = i0 + (int) threadIdx.x;
-        uint8_t code = 0;
-        bool pose = false;
-        float px[2] = {0, 0}, ux[2] = {0, 0};
-        double bv[3] = {0, 0, 0};
-        if (i < hi) {   // the slot's results to the host, from THIS kernel (see track_slots.hpp)
-            const size_t j = (size_t) i;
-            code = D.d_code[i];
-            px[0] = D.d_px[2 * j]; px[1] = D.d_px[2 * j + 1];
-            ux[0] = D.d_unpx[2 * j]; ux[1] = D.d_unpx[2 * j + 1];
-            bv[0] = D.d_bv[3 * j]; bv[1] = D.d_bv[3 * j + 1]; bv[2] = D.d_bv[3 * j + 2];
-            D.o_code[i] = code;
-            D.o_px[2 * j] = px[0]; D.o_px[2 * j + 1] = px[1];
-            D.o_unpx[2 * j] = ux[0]; D.o_unpx[2 * j + 1] = ux[1];
-            D.o_bv[3 * j] = bv[0]; D.o_bv[3 * j + 1] = bv[1]; D.o_bv[3 * j + 2] = bv[2];
-            pose = code != 0 && D.d_is3d[i] != 0;
-        }
-        const unsigned long long bal = __ballot(pose);
-        if (lane == 0) s_cnt[wave] = __popcll(bal);
-        __syncthreads();
-        int wofs = 0, all = 0;
-        for (int w = 0; w < CMP_NT / 64; w++) {
-            if (w < wave) wofs += s_cnt[w];
-            all += s_cnt[w];
-        }
-        if (pose) {
-            const size_t k = (size_t) (base + wofs + __popcll(bal & ((1ull << lane) - 1ull))), j = (size_t) i;
-            D.Pbv[3 * k] = bv[0]; D.Pbv[3 * k + 1] = bv[1]; D.Pbv[3 * k + 2] = bv[2];
-            D.Puv[2 * k] = (double) ux[0]; D.Puv[2 * k + 1] = (double) ux[1];
-            D.Pwpt[3 * k] = D.d_wpt[3 * j]; D.Pwpt[3 * k + 1] = D.d_wpt[3 * j + 1]; D.Pwpt[3 * k + 2] = D.d_wpt[3 * j + 2];
-        }
-        base += all;
-        __syncthreads();
-    }
-    __threadfence_system();   // this thread's writes to the host (and the device) ...
-    __syncthreads();          // ... of every thread of the workgroup, before its arrival
-    if (threadIdx.x == 0) {
-        const int arrived = __hip_atomic_fetch_add(D.cnt + 8, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == G - 1) {   // last: every slice is out
-            const unsigned long long packed = reinterpret_cast<unsigned long long *>(D.cnt)[2];   // the tracker launch's counts (track_slots.hpp)
-            const int nA = (int) ((packed >> 16) & 0xffff), good = (int) (packed & 0xffff);
-            const bool req = nA > 0 && (double) good < 0.33 * (double) nA;
-            reinterpret_cast<unsigned long long *>(D.cnt)[2] = 0ull;
-            for (int s = 0; s < TRK_STRIPES; s++) reinterpret_cast<unsigned long long *>(D.cnt)[16 + s] = 0ull;   // the tracker's arrival stripes
-            D.cnt[8] = 0;
-            // the step's completion word carries what the host reads of the header -- [seq : 32 | p3pReq_ : 1 | n_pose : 31] at
-            // o_hdr[12..13], ONE 8-byte system-scope store: every slice's results are already behind its workgroup's fence + arrival,
-            // so no second system-scope fence (an L2 write-back, ~2.5 us of the tracking step) stands in front of it
-            const unsigned long long word = ((unsigned long long) (unsigned) D.seq << 32) | ((unsigned long long) (req ? 1 : 0) << 31) | (unsigned) n_pose;
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(D.o_hdr + 12), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-__global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) { track_compact_body(D, (int) blockIdx.x, (int) gridDim.x); }
-ALVA_MULTI_KERNEL(MK_TRACK_COMPACT, k_track_compact_multi, TrackSlots, dim3(CMP_NT), CMP_NT, track_compact_body(A, bx, (int) gx));
+#include "track_compact_device.hpp"
+__global__ void __launch_bounds__(CMP_NT) k_track_compact(TrackSlots D) { (void) track_compact_body<CMP_NT>(D, (int) blockIdx.x, (int) gridDim.x); }
+ALVA_MULTI_KERNEL(MK_TRACK_COMPACT, k_track_compact_multi, TrackSlots, dim3(CMP_NT), CMP_NT, (void) track_compact_body<CMP_NT>(A, bx, (int) gx));
 static inline int compact_grid(int n) {   // ~256 slots per workgroup
     const int g = (n + 255) / 256;
     return g < 1 ? 1 : g > CMP_MAX_WG ? CMP_MAX_WG : g;
@@ -1004,7 +912,7 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     const int *o_hdr = nullptr;
     int poll_seq = 0;
     TrackSlots slots_D{};
-    bool slots_path = false;
+    bool slots_path = false, pose_all = false;
     const Impl::TrackPin pin = m->track_pin();
     const bool staged = job.px == pin.in_px && job.is3d == pin.in_is3d && job.wpt == pin.in_wpt;   // track_slot_buffers was used
     if (in_device) {
@@ -1050,7 +958,17 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.seq = ++m->trk_seq;   // the tracker launch publishes its counts under this number too (the word at o_hdr[10])
         rc = alva_track_slots_klt(m->ctx, prev, cur, D, 1, job.klt_levels, 30.f, 0.5f, 30, 0.01f, 0);
         if (rc) return rc;
-        if (!alva_lane_defer(MK_TRACK_COMPACT, m->ctx, (unsigned) compact_grid(D.n), 0, &D, sizeof(D))) {
+        // The frame's tail -- compaction -> P3P-LMedS -> refinement -- as ONE launch queued right here, behind the tracker (pnp.hip
+        // k_pose_all): its first workgroups are the compaction, the others wait for the host's word, which goes out below as soon as
+        // the tracker's early word has told the host how many correspondences there are.  A session of its own, polling, that wants
+        // a pose; everything else keeps the compaction kernel.
+        pose_all = m->poll && job.want_pose && job.do_p3p && alva_pose_all_possible(D.n, 100);
+        if (pose_all) {
+            // (the launch has ~128 workgroups anyway: 64-slot slices -- the slice length is a multiple of the wave -- instead of 256-slot ones)
+            rc = alva_pose_all_enqueue(m->ctx, D, std::min(96, std::max(1, (D.n + 63) / 64)), 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx, (float) k.fy,
+                                       (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
+            if (rc) return rc;
+        } else if (!alva_lane_defer(MK_TRACK_COMPACT, m->ctx, (unsigned) compact_grid(D.n), 0, &D, sizeof(D))) {
             hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
             ALVA_LAUNCH_CHECK();
         }
@@ -1163,10 +1081,18 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
             word = *early;
         }
         early_n_pose = (int) (word & 0x7fffffffu);
-        if ((int) (word >> 32) == poll_seq && !((word >> 31) & 1) && early_n_pose >= 4) {
+        const bool early_ok = (int) (word >> 32) == poll_seq && !((word >> 31) & 1) && early_n_pose >= 4;
+        if (pose_all && !early_ok) {
+            (void) alva_pose_all_abort(m->ctx);   // p3pReq_, fewer than four correspondences, or no word at all: the queued launch ends after its compaction
+            pose_all = false;
+        }
+        if (early_ok) {
             m->pose_n = early_n_pose > n_pose_cap ? n_pose_cap : early_n_pose;
+            if (pose_all) rc = alva_pose_all_go(m->ctx, m->pose_n);   // the queued launch's second phase: samples for this n, go
+            else
             rc = alva_compute_pose_enqueue(m->ctx, Pbv, Puv, Pwpt, m->pose_n, 100, 3.0f, job.do_random, 12345u, 5, 5.9915f, (float) k.fx,
                                            (float) k.fy, (float) k.cx, (float) k.cy);  // state.hpp:68-69, visual_frontend.cpp:363-375
+            pose_all = false;
             if (rc) return rc;
             pose_early = true;
             rc = build_ahead();   // a hinted next frame: its images are queued behind the pose kernels
