@@ -1068,6 +1068,145 @@ __global__ void __launch_bounds__(256) k_backsub_b(const BaDev *Bs, const BaRun 
     backsub_body<1>(B, R.radius, R.xt, R.ct, R.xp, R.cp, blockIdx.x, 0);
 }
 
+// ---- the LM loop's DECISIONS on the device (round 6) -----------------------------------------------------------------------------------
+// Ceres' TrustRegionMinimizer::Minimize was restated on the host (BaHost::advance): after every candidate's evaluation the host read six
+// scalars, decided, and only then enqueued the next iteration's eight kernels -- the GPU sat idle for a bus round trip + the enqueue once
+// per LM iteration, and a rejected step cost three more launches (the Jacobian-derived state had to be restored at x).  Here
+//   * the decision is taken by the thread that has just summed the evaluation's scalars (k_assemble_lm's thread 0: lm_after_eval below --
+//     trust_region_minimizer.cc:377-451, 461-490, 781-829; levenberg_marquardt_strategy.cc:66-160 through LmState) and written to a
+//     state block in device memory that the next iteration's kernels read: radius, "refresh the diagonal", "this iteration runs";
+//   * the evaluation's outputs are DOUBLE-BUFFERED (two BaDev descriptors that differ in chi2 | depth, Jobs, rs, ptCost, Hpp, gp, Wt, M,
+//     Hcc, gc; two parameter pairs): the candidate is evaluated into the set x does not use, an accepted step flips the roles, a rejected
+//     one leaves x's set untouched -- no restore launches;
+//   * the host stays ONE ITERATION AHEAD: it enqueues iteration i + 1 when it sees that iteration i runs, so the queue never drains; when
+//     the minimiser stops, at most one enqueued iteration finds "step == 0" and returns at once.
+// Same kernels' bodies, same arithmetic, same decisions as the host loop (tests/test_gpu_ba.py: iteration and accepted-step counts and
+// chi2 classes against Ceres; ALVA_BA_HOST_LM=1 keeps the host loop for A/B).
+struct BaLmDev {
+    double radius, decrease_factor;
+    double x_cost, initial, gmax, x_norm, function_tolerance;
+    double *P[2], *T[2];   // pose / point parameter vectors: [cur] = x, [1 - cur] = the candidate
+    double *h_pub;         // pinned host, two slots ([0..7] even, [16..23] odd evaluation numbers): step, iteration, nsummaries, initial, x_cost, nsucc, ok,
+                           // cur | last << 8; [8] = evaluations published (written last, system-scope release)
+    long long evals;       // evaluations made so far (the publication's sequence number)
+    int reuse_diagonal, iteration, nsucc, invalid, nsummaries, ok, max_iters;
+    int cur;               // which descriptor / parameter pair holds x
+    int last;              // the descriptor the latest evaluation wrote (the outlier sweep reads chi2 | depth there)
+    int step;              // 1: the next iteration runs, 0: the minimiser has stopped
+    int diag;              // ... and refreshes the LM diagonal first
+    int pad;
+};
+static_assert(sizeof(BaLmDev) % 8 == 0, "BaLmDev is copied as 8-byte words");
+
+__device__ __forceinline__ void lm_after_eval(BaLmDev &L, const double *scal, const int first) {
+    LmState lm;
+    lm.radius = L.radius; lm.decrease_factor = L.decrease_factor; lm.reuse_diagonal = L.reuse_diagonal;
+    bool stop = false;
+    if (first) {
+        L.x_cost = L.initial = scal[0];
+        L.gmax = scal[3];
+        L.last = L.cur;
+    } else {
+        const int cand = 1 - L.cur;
+        L.last = cand;
+        const double cand_cost = scal[0], mcc = scal[1], step_norm = sqrt(scal[2]);
+        const bool okstep = scal[5] != 0.0 && isfinite(mcc);
+        if (!okstep || !(mcc > 0)) {  // HandleInvalidStep (:461-490)
+            if (++L.invalid >= 5) {
+                L.ok = 0;
+                stop = true;
+            } else {
+                lm.rejected();
+                L.nsummaries++;
+            }
+        } else {
+            L.invalid = 0;
+            if (step_norm <= 1e-8 * (L.x_norm + 1e-8)) stop = true;                                   // ParameterToleranceReached
+            else if (fabs(L.x_cost - cand_cost) <= L.function_tolerance * L.x_cost) stop = true;    // FunctionToleranceReached
+            else {
+                const double rel = (L.x_cost - cand_cost) / mcc;
+                if (rel > 1e-3) {
+                    L.cur = cand;
+                    L.x_cost = cand_cost;
+                    L.gmax = scal[3];
+                    L.x_norm = sqrt(scal[4]);
+                    lm.accepted(rel);
+                    L.nsucc++;
+                } else {
+                    lm.rejected();
+                }
+                L.nsummaries++;
+            }
+        }
+    }
+    L.radius = lm.radius; L.decrease_factor = lm.decrease_factor; L.reuse_diagonal = lm.reuse_diagonal;
+    // the loop's head (ba_drive): stop tests, then the next iteration's prologue
+    if (stop || L.iteration >= L.max_iters || L.gmax <= 1e-10 || L.radius <= 1e-32) {
+        L.step = 0;
+        return;
+    }
+    L.iteration++;
+    L.diag = L.reuse_diagonal ? 0 : 1;
+    L.reuse_diagonal = 1;
+    L.step = 1;
+}
+
+// the evaluation kernels: first = the evaluation at x (descriptor / parameters `cur`), otherwise the candidate's (the other set)
+#define LM_EVAL_SEL(first)                                  \
+    if (!(first) && !L->step) return;                       \
+    const int set = (first) ? L->cur : 1 - L->cur;          \
+    const BaDev &B = dB[set];
+template<bool INV>
+__global__ void __launch_bounds__(256) k_point_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L, int first) {
+    LM_EVAL_SEL(first)
+    point_body<INV, true>(B, L->P[set], L->T[set], blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(256) k_pairs_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L, int first) {
+    LM_EVAL_SEL(first)
+    pairs_body(B, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(ASM_NT) k_assemble_lm(const BaDev *__restrict__ dB, BaLmDev *L, int first) {
+    LM_EVAL_SEL(first)
+    assemble_body(B, first);   // (h_scal is null in these descriptors: the publication below replaces it)
+    if (threadIdx.x == 0) {
+        BaLmDev S = *L;
+        lm_after_eval(S, B.scal, first);
+        S.evals++;
+        *L = S;
+        // two slots, evaluation number odd / even: the host reads the slot of the number it saw while the next evaluation -- the only one that
+        // can be under way, the host being one iteration ahead -- writes the other
+        double *h = S.h_pub + ((S.evals & 1) ? 16 : 0);
+        h[0] = S.step; h[1] = S.iteration; h[2] = S.nsummaries; h[3] = S.initial; h[4] = S.x_cost; h[5] = S.nsucc; h[6] = S.ok;
+        h[7] = (double) (S.cur | (S.last << 8));
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<long long *>(S.h_pub + 8), S.evals, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// the step kernels: on x's descriptor, only while the minimiser runs
+template<int DP>
+__global__ void __launch_bounds__(256) k_prep_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L) {
+    if (!L->step) return;
+    prep_body<DP>(dB[L->cur], L->radius, L->diag, blockIdx.x, 0);
+}
+__global__ void __launch_bounds__(64) k_gemm_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L) {
+    if (!L->step) return;
+    gemm_body(dB[L->cur], blockIdx.x, blockIdx.y);
+}
+__global__ void __launch_bounds__(256) k_reduced_system_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L) {
+    if (!L->step) return;
+    reduced_system_body(dB[L->cur], L->radius, L->diag, blockIdx.x, 0);
+}
+template<bool IN_LDS>
+__global__ void __launch_bounds__(SOLVE_NT) k_solve_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L) {
+    if (!L->step) return;
+    solve_body<IN_LDS>(dB[L->cur], L->radius, 0, 0);
+}
+template<int DP>
+__global__ void __launch_bounds__(256) k_backsub_lm(const BaDev *__restrict__ dB, const BaLmDev *__restrict__ L) {
+    if (!L->step) return;
+    const int c = L->cur;
+    backsub_body<DP>(dB[c], L->radius, L->T[c], L->T[1 - c], L->P[c], L->P[1 - c], blockIdx.x, 0);
+}
 // ---- one problem on the host: sizes, the carved device block with its pinned mirror, the structure build -------------------------
 struct BaIn {
     int n_kf;
@@ -1110,6 +1249,11 @@ struct BaHost {
     int iteration = 0, nsucc = 1, invalid = 0, nsummaries = 1, ok = 1;
     bool need_restore = false, done = false;
     double *xp = nullptr, *xt = nullptr, *cp = nullptr, *ct = nullptr;
+    // the device-side LM loop (BaLmDev): its state block and the two descriptors live in the uploaded input block; B2 = the second set of
+    // the evaluation's outputs (everything else of the descriptor is shared)
+    BaLmDev *d_lm = nullptr;
+    BaDev *d_desc = nullptr;
+    BaDev B2{};
 
     int sizes(const BaIn &in, const BaCsr *csr = nullptr) {
         const int n_kf = in.n_kf, n_pt = in.n_pt, n_obs = in.n_obs, dp = in.inv_depth ? 1 : 3;
@@ -1155,6 +1299,8 @@ struct BaHost {
         }
         d_xp = carve<double>(cur, n_kf * 7);
         d_xt = carve<double>(cur, npd);
+        d_lm = carve<BaLmDev>(cur, 1);
+        d_desc = carve<BaDev>(cur, 2);
         in_bytes = (size_t) (cur - base);
         if (csr_) {
             d_pairPerm = carve<int>(cur, nObs);
@@ -1190,6 +1336,17 @@ struct BaHost {
         B.partial = carve<double>(cur, nPt * 3 + 8);   // per point: mcc, step^2, candidate^2 partials; then the camera part (3)
         d_cp = carve<double>(cur, n_kf * 7);
         d_ct = carve<double>(cur, npd);
+        B2.chi2 = carve<double>(cur, nObs);   // (chi2 | depth in the first set's order: chi_bytes() holds for both)
+        B2.depth = carve<uint8_t>(cur, nObs);
+        B2.Jobs = carve<double>(cur, nObs * 12);
+        B2.rs = carve<double>(cur, nObs * 2);
+        B2.ptCost = carve<double>(cur, nPt);
+        B2.Hpp = carve<double>(cur, npd * dp);
+        B2.gp = carve<double>(cur, npd);
+        B2.Wt = carve<double>(cur, npd * NP);
+        B2.M = carve<double>(cur, n_kf * n_kf * 27);
+        B2.Hcc = carve<double>(cur, n6 * n6);
+        B2.gc = carve<double>(cur, n6);
         return (size_t) (cur - base);
     }
     // the analogue of Ceres' program / block-structure build, written into the pinned mirror `stage` of the input arrays; then the
@@ -1299,6 +1456,25 @@ struct BaHost {
         xp = d_xp; xt = d_xt; cp = d_cp; ct = d_ct;
         return ALVA_OK;
     }
+    // the device-side LM loop's state and its two descriptors, written into the pinned mirror of the input block (uploaded with it)
+    void stage_lm(uint8_t *base, uint8_t *stage, int max_iters, double function_tolerance, double *h_pub) {
+        BaDev D0 = B, D1 = B;
+        D0.h_scal = D1.h_scal = nullptr;
+        D1.chi2 = B2.chi2; D1.depth = B2.depth; D1.Jobs = B2.Jobs; D1.rs = B2.rs; D1.ptCost = B2.ptCost; D1.Hpp = B2.Hpp; D1.gp = B2.gp;
+        D1.Wt = B2.Wt; D1.M = B2.M; D1.Hcc = B2.Hcc; D1.gc = B2.gc;
+        BaDev *h_desc = reinterpret_cast<BaDev *>(stage + ((uint8_t *) d_desc - base));
+        h_desc[0] = D0;
+        h_desc[1] = D1;
+        BaLmDev L{};
+        L.radius = lm.radius; L.decrease_factor = lm.decrease_factor; L.reuse_diagonal = lm.reuse_diagonal;
+        L.x_norm = x_norm;
+        L.function_tolerance = function_tolerance;
+        L.P[0] = d_xp; L.P[1] = d_cp; L.T[0] = d_xt; L.T[1] = d_ct;
+        L.h_pub = h_pub;
+        L.nsucc = nsucc; L.nsummaries = nsummaries; L.ok = 1; L.max_iters = max_iters;
+        L.step = 0;
+        *reinterpret_cast<BaLmDev *>(stage + ((uint8_t *) d_lm - base)) = L;
+    }
     void enqueue_pairs(hipStream_t st) {
         if (B.nObs <= 0) {
             (void) hipMemsetAsync(d_pairPtr, 0, ((size_t) B.nKf * B.nKf + 1) * 4, st);
@@ -1403,6 +1579,7 @@ static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_ite
     rc = csr ? H.build_csr(in, *csr, base, stage) : H.build(in, base, stage);
     if (rc) return rc;
     const auto t_built = std::chrono::steady_clock::now();
+    H.stage_lm(base, stage, max_iters, function_tolerance, reinterpret_cast<double *>(pin));
     ALVA_HIP(hipMemcpyAsync(base, stage, H.in_bytes, hipMemcpyHostToDevice, st));   // ONE upload from pinned memory
     if (csr) H.enqueue_pairs(st);
     // Wt: the sparsity pattern is fixed, zero once; Zt: the K padding rows stay zero -- neighbours in the layout, one fill
@@ -1454,6 +1631,77 @@ static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_ite
         return ALVA_OK;
     };
 
+    static const bool host_lm = getenv("ALVA_BA_HOST_LM") != nullptr;
+    const bool dev_lm = poll && !host_lm;
+    int last_set = 0, cur_set = 0;
+    if (dev_lm) {
+        // ---- the same minimiser with its decisions on the device (BaLmDev): the host enqueues, one iteration ahead, and watches ---------
+        ALVA_HIP(hipMemsetAsync(H.B2.Wt, 0, (size_t) B.npd * NP * 8, st));
+        const BaDev *dB = H.d_desc;
+        BaLmDev *dL = H.d_lm;
+        const int tiles = B.NP / 16, np16i = (int) np16;
+        const dim3 gBs(n_pt > 0 ? gPt.x + 1 : 1);
+        auto eval_lm = [&](int first) {
+            if (n_pt > 0) {
+                if (inv_depth) hipLaunchKernelGGL(k_point_lm<true>, gPt, blk, 0, st, dB, (const BaLmDev *) dL, first);
+                else hipLaunchKernelGGL(k_point_lm<false>, gPt, blk, 0, st, dB, (const BaLmDev *) dL, first);
+            }
+            hipLaunchKernelGGL(k_pairs_lm, dim3((unsigned) (n_kf * n_kf)), blk, 0, st, dB, (const BaLmDev *) dL, first);
+            hipLaunchKernelGGL(k_assemble_lm, dim3(1), dim3(ASM_NT), assemble_lds(n_kf), st, dB, dL, first);
+        };
+        auto step_lm = [&]() {
+            if (n_pt > 0) {
+                if (dp == 1) hipLaunchKernelGGL(k_prep_lm<1>, gPt, blk, 0, st, dB, (const BaLmDev *) dL);
+                else hipLaunchKernelGGL(k_prep_lm<3>, gPt, blk, 0, st, dB, (const BaLmDev *) dL);
+            }
+            hipLaunchKernelGGL(k_gemm_lm, dim3((unsigned) (tiles * tiles), KSPLIT), dim3(64), 0, st, dB, (const BaLmDev *) dL);
+            if (np16 > 0)
+                hipLaunchKernelGGL(k_reduced_system_lm, dim3((unsigned) alva_divup(np16i * np16i + np16i, 256)), blk, 0, st, dB, (const BaLmDev *) dL);
+            if (solve_in_lds) hipLaunchKernelGGL(k_solve_lm<true>, dim3(1), dim3(SOLVE_NT), solve_lds, st, dB, (const BaLmDev *) dL);
+            else hipLaunchKernelGGL(k_solve_lm<false>, dim3(1), dim3(SOLVE_NT), 0, st, dB, (const BaLmDev *) dL);
+            if (dp == 1) hipLaunchKernelGGL(k_backsub_lm<1>, gBs, blk, 0, st, dB, (const BaLmDev *) dL);
+            else hipLaunchKernelGGL(k_backsub_lm<3>, gBs, blk, 0, st, dB, (const BaLmDev *) dL);
+            eval_lm(0);
+        };
+        if (solve_in_lds && solve_lds > 48 * 1024)
+            ALVA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_lm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        eval_lm(1);
+        int issued = 0;
+        if (max_iters > 0) {
+            step_lm();   // iteration 0: it runs if the first evaluation says so
+            issued = 1;
+        }
+        ALVA_LAUNCH_CHECK();
+        long long seen = 0;
+        double pub[8];
+        for (;;) {
+            // publication `seen + 1`: the decision behind evaluation number `seen` (0 = the first one)
+            const volatile long long *flag = reinterpret_cast<const volatile long long *>(pin_scal + 8);
+            unsigned spins = 0;
+            while (*flag < seen + 1) {
+                if (++spins > (1u << 26)) {
+                    ALVA_HIP(alva_stream_sync(st));
+                    break;
+                }
+                alva_poll_relax(spins);
+            }
+            const long long f = *flag;
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            memcpy(pub, pin_scal + ((f & 1) ? 16 : 0), sizeof(pub));   // (the newest publication: `seen` may jump by two)
+            seen = f;
+            if (pub[0] == 0.0) break;                 // the minimiser has stopped; what is still queued returns at once
+            if (issued < max_iters) {                 // the iteration behind the one that is running now
+                step_lm();
+                issued++;
+                ALVA_LAUNCH_CHECK();
+            } else if (seen >= (long long) max_iters + 1) {
+                break;                                // (cannot happen: the last allowed iteration's evaluation publishes step = 0)
+            }
+        }
+        H.nsummaries = (int) pub[2]; H.initial = pub[3]; H.x_cost = pub[4]; H.nsucc = (int) pub[5]; H.ok = (int) pub[6];
+        cur_set = ((int) pub[7]) & 0xff;
+        last_set = ((int) pub[7]) >> 8;
+    } else {
     // ---- Ceres TrustRegionMinimizer::Minimize, restated (trust_region_minimizer.cc:67-136) -------------------
     rc = eval(H.d_xp, H.d_xt, true);
     if (rc) return rc;
@@ -1501,6 +1749,7 @@ static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_ite
         if (rc) return rc;
         if (H.advance(scal, function_tolerance)) break;
     }
+    }
     *h_ok = H.ok;
     const auto t_lm = std::chrono::steady_clock::now();
     // results: poses / points at the last accepted x; chi2 / depth flags of the LAST evaluation (what the
@@ -1508,8 +1757,15 @@ static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_ite
     // the input staging area is free again (its upload finished long ago): results land there, three DMA copies
     uint8_t *r_chi = stage;
     const size_t bad_words = csr ? (nObs + 63) / 64 : 0;
+    // (device-side loop: the last evaluation's outputs and x live in the set its final publication named)
+    const double *res_chi2 = last_set ? H.B2.chi2 : B.chi2;
+    const uint8_t *res_depth = last_set ? H.B2.depth : B.depth;
+    if (dev_lm) {
+        H.xp = cur_set ? H.d_cp : H.d_xp;
+        H.xt = cur_set ? H.d_ct : H.d_xt;
+    }
     if (csr && n_obs) {
-        hipLaunchKernelGGL(k_bad_bits, dim3((unsigned) alva_divup(n_obs, 256)), dim3(256), 0, st, (const double *) B.chi2, (const uint8_t *) B.depth, n_obs,
+        hipLaunchKernelGGL(k_bad_bits, dim3((unsigned) alva_divup(n_obs, 256)), dim3(256), 0, st, res_chi2, res_depth, n_obs,
                            csr->chi2_threshold, H.d_badBits);
     }
     const size_t chi_bytes = csr ? bad_words * 8 : H.chi_bytes();
@@ -1518,7 +1774,7 @@ static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_ite
     if (poll) {
         // (chi_bytes, the pose block and the point block are multiples of 8 bytes or are rounded up inside their 256-byte carved slots)
         BaResultsArgs R{};
-        R.src[0] = csr ? H.d_badBits : reinterpret_cast<const unsigned long long *>(B.chi2); R.dst[0] = reinterpret_cast<unsigned long long *>(r_chi);
+        R.src[0] = csr ? H.d_badBits : reinterpret_cast<const unsigned long long *>(res_chi2); R.dst[0] = reinterpret_cast<unsigned long long *>(r_chi);
         R.words[0] = n_obs ? (chi_bytes + 7) / 8 : 0;
         R.src[1] = reinterpret_cast<const unsigned long long *>(H.xp); R.dst[1] = reinterpret_cast<unsigned long long *>(r_poses);
         R.words[1] = (size_t) n_kf * 7;
@@ -1543,7 +1799,7 @@ static int ba_drive(alva_ctx *ctx, const BaIn &in, const BaCsr *csr, int max_ite
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {
-        if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, csr ? (const void *) H.d_badBits : (const void *) B.chi2, chi_bytes, hipMemcpyDeviceToHost, st));
+        if (n_obs) ALVA_HIP(hipMemcpyAsync(r_chi, csr ? (const void *) H.d_badBits : (const void *) res_chi2, chi_bytes, hipMemcpyDeviceToHost, st));
         ALVA_HIP(hipMemcpyAsync(r_poses, H.xp, (size_t) n_kf * 56, hipMemcpyDeviceToHost, st));
         if (npd) ALVA_HIP(hipMemcpyAsync(r_pts, H.xt, npd * 8, hipMemcpyDeviceToHost, st));
         ALVA_HIP(alva_stream_sync(st));
