@@ -175,8 +175,13 @@ __device__ __forceinline__ void tile_store(LkShared &sh, int lane, const uint4 &
 // run all 30 iterations on six levels and decide the kernel time -- were a third of the iteration).  A lone wave issues one
 // instruction every four cycles whatever its type, so the iteration is also written for instruction COUNT: the template's part of
 // (J - I) * dI is folded into one constant per lane, tile bytes and bounds are revisited only when the window's integer origin moved.
-__device__ void lk_level(LkShared &sh, const LkLevel &I, const LkLevel &J, int level, int maxLevel, int maxCount, double epsilon,
+__device__ void lk_level(LkShared &sh, const LkLevel &I_, const LkLevel &J_, int level, int maxLevel, int maxCount, double epsilon,
                          float minEigThreshold, float ptx, float pty, float &nx, float &ny, int &status, float &err) {
+    // Both levels' descriptors are fetched HERE, in one go: they sit in the kernel arguments behind a run-time level index, and left to
+    // itself the compiler loads each field where it is first used -- five scalar loads in a row, each waited for, on the critical path of
+    // every level of the launch's last slots.
+    const LkLevel I = I_, J = J_;
+    asm volatile("" ::"s"(I.gray), "s"(I.deriv), "s"(I.gpitch), "s"(I.dpitch), "s"(I.w), "s"(I.h), "s"(J.gray), "s"(J.gpitch), "s"(J.w), "s"(J.h));
     const int lane = threadIdx.x;
     const int row = lane >> 4, jl = lane & 15;
     const bool act = jl >= 7;                          // lanes 7..15 of a row carry window rows 0..8
