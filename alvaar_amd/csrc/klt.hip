@@ -146,9 +146,17 @@ __device__ __forceinline__ float rows_fold(float v) {
 // are separate so that the level's first tile is in flight together with the template's gathers.
 __device__ __forceinline__ uint4 tile_load(const LkLevel &J, int lane, int tx0, int ty0) {
     const int trow = lane >> 2, c0 = (lane & 3) * 4;
+    uint4 px;
+    if (tx0 >= -WIN && ty0 >= -WIN && tx0 + TW <= J.w + WIN && ty0 + TW <= J.h + WIN) {   // wave-uniform: the tile lies inside the padded level
+        // one (unaligned) dword per lane from a uniform base + a small unsigned offset: no clamps, no 64-bit address arithmetic per byte
+        const uint8_t *base = J.gray + (ptrdiff_t) ty0 * J.gpitch + tx0;
+        uint32_t v;
+        __builtin_memcpy(&v, base + (unsigned) (trow * J.gpitch + c0), 4);
+        px.x = v & 0xffu; px.y = (v >> 8) & 0xffu; px.z = (v >> 16) & 0xffu; px.w = v >> 24;
+        return px;
+    }
     const int gy = min(max(ty0 + trow, -WIN), J.h + WIN - 1);
     const uint8_t *srow = J.gray + (ptrdiff_t) gy * J.gpitch;
-    uint4 px;
     px.x = srow[min(max(tx0 + c0 + 0, -WIN), J.w + WIN - 1)];
     px.y = srow[min(max(tx0 + c0 + 1, -WIN), J.w + WIN - 1)];
     px.z = srow[min(max(tx0 + c0 + 2, -WIN), J.w + WIN - 1)];
@@ -229,16 +237,20 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I_, const LkLevel &J_, int
 
     // ---- template: this lane's three pixels of window row y -- columns q, q + 4 and 8 (lkpyramid.cpp:440-471) ----
     int tI[3], tIx[3], tIy[3];
+    // (uniform 64-bit bases + small unsigned per-lane offsets: the loads take the scalar-base addressing form)
+    const uint8_t *gbase = I.gray + (ptrdiff_t) ipy * I.gpitch + ipx;
+    const uint8_t *dbase = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) ipy * I.dpitch + (ptrdiff_t) ipx * 4;
+    const uint8_t *gbase1 = gbase + I.gpitch, *dbase1 = dbase + I.dpitch;   // the row below, as bases of their own: ONE per-lane offset serves both rows
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         const int x = p == 0 ? q : (p == 1 ? q + 4 : 8);
-        const uint8_t *src = I.gray + (ptrdiff_t) (y + ipy) * I.gpitch + (x + ipx);
-        const int ival = descale(bl_u8(src[0], src[1], src[I.gpitch], src[I.gpitch + 1], wt), 9);
-        const uint8_t *drow = reinterpret_cast<const uint8_t *>(I.deriv) + (ptrdiff_t) (y + ipy) * I.dpitch + (ptrdiff_t) (x + ipx) * 4;
-        const short2 d00 = *reinterpret_cast<const short2 *>(drow);
-        const short2 d01 = *reinterpret_cast<const short2 *>(drow + 4);
-        const short2 d10 = *reinterpret_cast<const short2 *>(drow + I.dpitch);
-        const short2 d11 = *reinterpret_cast<const short2 *>(drow + I.dpitch + 4);
+        const unsigned go = (unsigned) (y * I.gpitch + x), dof = (unsigned) (y * I.dpitch + x * 4);
+        const uint8_t *g0 = gbase + go, *g1 = gbase1 + go, *d0 = dbase + dof, *d1 = dbase1 + dof;
+        const int ival = descale(bl_u8(g0[0], g0[1], g1[0], g1[1], wt), 9);
+        const short2 d00 = *reinterpret_cast<const short2 *>(d0);
+        const short2 d01 = *reinterpret_cast<const short2 *>(d0 + 4);
+        const short2 d10 = *reinterpret_cast<const short2 *>(d1);
+        const short2 d11 = *reinterpret_cast<const short2 *>(d1 + 4);
         const int ixval = descale(bl_i16(d00.x, d01.x, d10.x, d11.x, wt), 14);
         const int iyval = descale(bl_i16(d00.y, d01.y, d10.y, d11.y, wt), 14);
         tI[p] = ival;
