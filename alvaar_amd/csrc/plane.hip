@@ -1,9 +1,11 @@
 // f3: the plane under the map points of the current frame -- the INTENDED algorithm of System::processPlane
 // (src/slam/src/system.cpp:177-342; caller System::findPlane :123-137).
 //
-// PARITY UNPINNED: the reference function has no defined behaviour (reinterpreted point matrices, a design matrix
-// that is never filled, mixed element types, a random_device-seeded generator per iteration); this is what its statements say
-// they want to compute, on float copies of the points:
+// As shipped the reference function has no defined behaviour (reinterpreted point matrices, a design matrix that is
+// never filled, distances permuted by nth_element before they are paired with the points, a random_device-seeded generator per
+// iteration).  Parity is pinned against the reference's OWN function compiled with exactly those four defects repaired
+// (oracle/ref_shim_plane.cpp, oracle/ref_plane_patch.sed; tests/test_plane.py::test_gpu_equals_the_repaired_reference).  This is what
+// its statements compute, on float copies of the points:
 //   RANSAC (:205-246)   per iteration a plane through 3 sampled points (unit 4-vector a, b, c, d), skipped unless
 //                       |(a,b,c) x (0,0,1)| <= sin 5 deg; score = k-th smallest |a x + b y + c z + d| / |(a,b,c,d)| with
 //                       k = max((int)(0.2 N), 20); the smallest score wins (the first one on ties)

@@ -39,7 +39,7 @@ from bench_common import ROOT, W, H, NKP, HBM_PEAK_GBS, STREAM_FRAMES, SYSTEM_CE
 import numpy as np
 import torch
 
-PMC_FILES = ["r5_pmc_track_klt.json", "r4_pmc_track_klt.json", "r3_pmc_track_klt.json"]   # newest first
+PMC_FILES = ["r6_pmc_track_klt.json", "r5_pmc_track_klt.json", "r4_pmc_track_klt.json", "r3_pmc_track_klt.json"]   # newest first
 
 
 def bench_ba(ctx, reps: int = 3):

@@ -282,8 +282,9 @@ int alva_relpose_hypotheses(alva_ctx *ctx, const double *d_bv1, const double *d_
  * The INTENDED algorithm of System::processPlane(mapPoints, Twc, numIterations) (src/slam/src/system.cpp:177-342, caller
  * findPlane :123-137): RANSAC over planes through 3 sampled points (orientation test, k-th smallest distance as the score),
  * inliers within 1.4 x the best score, least-squares refit, pose = [Rodrigues(...) Rodrigues((1,0,0)) | mean of the inliers]
- * in the layout of Utils::toPoseArray(cv::Mat).  PARITY UNPINNED: the reference function has no defined behaviour to compare
- * with; the CPU restatement oracle/alva_oracle_plane.c follows the same statements and is the test partner.
+ * in the layout of Utils::toPoseArray(cv::Mat).  As shipped the reference function has no defined behaviour;
+ * parity is pinned against the reference's own function compiled with its four defects repaired (oracle/ref_shim_plane.cpp) and
+ * against the CPU restatement oracle/alva_oracle_plane.c, which is pinned to the same (tests/test_plane.py).
  * d_points: n x 3 world points (device, f64); h_pose7_twc: current pose; h_samples3 (num_iterations x 3 int32, may be NULL):
  * the sample indices, otherwise drawn from std::mt19937(seed) (clock-seeded when do_random).  *h_found = 0 when n < 32 or
  * fewer than 32 inliers.  Synchronous. */

@@ -1,11 +1,11 @@
 # consolidated GPU run: tests, PMC passes (stamped), bench line (reads the fresh stamp), rocprofv3 kernel stats of the same command,
 # ORB (configs[2]) kernel times + HBM traffic.   usage (GPU box, repo root): ALVA_COMMIT=<sha> TAG=r5x tools/gpu_final_run.sh
 export ALVA_COMMIT=${ALVA_COMMIT:-unknown}
-T=${TAG:-r5}
+T=${TAG:-r6}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/${T}_pytest.log
 tools/pmc_klt.sh > gpurun_out/${T}_pmc.log 2>&1
-cp gpurun_out/r5_pmc_track_klt.json profiles/r5_pmc_track_klt.json
+cp gpurun_out/r6_pmc_track_klt.json profiles/r6_pmc_track_klt.json
 python bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err
 cp bench_detail.json gpurun_out/${T}_bench_detail.json
 tail -c 300 gpurun_out/${T}_bench.err
