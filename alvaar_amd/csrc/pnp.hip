@@ -710,6 +710,8 @@ struct PoseGo {
     long long word;   // seq = go, -seq = abort (the launch's sequence number: strictly increasing, so a stale word never matches)
     int n, H;
     int samples[4 * P3P_INLINE_H];
+    long long nack;   // written by the KERNEL: seq = "gave up waiting for the word" (a tool that makes launches synchronous -- counter
+                      // collection does -- keeps the host from answering while the kernel runs); the host then solves the pose the old way
 };
 __device__ __forceinline__ int sys_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #define POSE_ALL_STAMP(k)                                                                                                                  \
@@ -738,10 +740,12 @@ __global__ void __launch_bounds__(NT) k_pose_all(TrackSlots D, int G, P3pArgs P,
             long long w = 0;
             for (;;) {
                 w = __hip_atomic_load(&go->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (w == (long long) seq || w == -(long long) seq || ++spins > (1u << 22)) break;
+                if (w == (long long) seq || w == -(long long) seq || ++spins > 400u) break;   // ~0.6 ms of polls over the bus: the answer takes ~10 us
                 __builtin_amdgcn_s_sleep(4);
             }
             s_go[0] = w == (long long) seq;
+            if (w != (long long) seq && w != -(long long) seq)
+                __hip_atomic_store(const_cast<long long *>(&go->nack), (long long) seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __syncthreads();
         if (s_go[0]) {
@@ -762,7 +766,7 @@ __global__ void __launch_bounds__(NT) k_pose_all(TrackSlots D, int G, P3pArgs P,
         bool ok = true;
         while (__hip_atomic_load(D.cnt + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq && ok) {
             __builtin_amdgcn_s_sleep(8);
-            ok = ++spins < (1u << 23);
+            ok = ++spins < (1u << 16);
         }
         POSE_ALL_STAMP(2);
         long long w = 0;
@@ -770,7 +774,7 @@ __global__ void __launch_bounds__(NT) k_pose_all(TrackSlots D, int G, P3pArgs P,
             w = (long long) agent_load(relay);
             if (w == (long long) seq || w == -(long long) seq) break;
             __builtin_amdgcn_s_sleep(8);
-            ok = ++spins < (1u << 23);
+            ok = ++spins < (1u << 16);   // (~15 ms: far beyond the relaying workgroup's own bound)
         }
         s_go[0] = ok && w == (long long) seq;
     }
@@ -866,6 +870,7 @@ struct alva_pose_pending {
     bool active;
     int seq = 0;
     int go_seq = 0;   // > 0: a k_pose_all is queued and waits for alva_pose_all_go / _abort (the tracker launch's sequence number)
+    int went_seq = 0; // > 0: the sequence number alva_pose_all_go answered (until the result is collected): PoseGo::nack is compared with it
     // the fused launch's sampler, split: the generator's outputs do not depend on n (uniform_int_distribution<>(0, INT_MAX) over
     // std::mt19937: SampleConsensusProblem.hpp:40-46), only "% (n - i)" and the swaps do -- so the 4 H raw draws are made when the
     // launch is queued (the tracker is still running) and alva_pose_all_go is left with 4 H swaps on a persistent iota array
@@ -948,7 +953,10 @@ static void pose_params(alva_pose_pending &P, const double *d_bearings, const do
 
 bool alva_pose_all_possible(int n_cap, int p3p_iters) {
     static const bool on = getenv("ALVA_POSE_UNFUSED") == nullptr && getenv("ALVA_NO_POSE_ALL") == nullptr;
-    return on && !g_alva_lane && n_cap >= 4 && n_cap <= 7168 && p3p_iters + 28 <= P3P_INLINE_H && alva_p3p_inline_samples_ok();
+    // Not inside a session group: there the calling thread runs OTHER sessions' frames while this one's kernels fly (its polls yield to
+    // the fiber scheduler, alva_fiber_yield), so the answer the queued launch waits for could be milliseconds away -- with ~170 workgroups
+    // spinning meanwhile.  A session that owns its thread answers within ~10 us.
+    return on && !g_alva_lane && !alva_fiber_yield && n_cap >= 4 && n_cap <= 7168 && p3p_iters + 28 <= P3P_INLINE_H && alva_p3p_inline_samples_ok();
 }
 
 int alva_pose_all_enqueue(alva_ctx *ctx, const TrackSlots &D, int G, int p3p_iters, float p3p_err, int do_random, uint32_t seed, int pnp_iters,
@@ -1036,6 +1044,7 @@ int alva_pose_all_go(alva_ctx *ctx, int n) {
     P.n = n;
     P.A.n = n;
     P.active = true;
+    P.went_seq = P.go_seq;
     __atomic_store_n(&go->word, (long long) P.go_seq, __ATOMIC_RELEASE);
     P.go_seq = 0;
     return ALVA_OK;
@@ -1095,12 +1104,23 @@ int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose
             const volatile int *flag = &((const PnpOut *) (P.pin + P.poff_out))->seq;
             unsigned spins = 0;
             while (*flag != P.seq) {
+                if (P.went_seq > 0 && *reinterpret_cast<const volatile long long *>(&((const PoseGo *) P.pin)->nack) == (long long) P.went_seq) {
+                    // the fused launch gave up before the go word reached it (see PoseGo::nack): its compaction phase is done, the
+                    // correspondences are gathered -- solve the pose with the separate launches
+                    P.went_seq = 0;
+                    const int rc = pose_launch(ctx, P);
+                    if (rc) return rc;
+                    flag = &((const PnpOut *) (P.pin + P.poff_out))->seq;
+                    spins = 0;
+                    continue;
+                }
                 if (++spins > (1u << 26)) {
                     ALVA_HIP(alva_stream_sync(ctx->stream));
                     break;
                 }
                 alva_poll_relax(spins);
             }
+            P.went_seq = 0;
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         } else {
             ALVA_HIP(alva_stream_sync(ctx->stream));

@@ -14,7 +14,11 @@ namespace alva_slam {
 class TraceStages : public Stages {
 public:
     // Tracing composes the tracking step from the fine-grained stages (the default track_begin / track_pose_collect of this object),
-    // so that every stage call is visible -- a fused override of the inner implementation is bypassed while tracing.
+    // so that every stage call is visible -- a fused override of the inner implementation is bypassed while tracing.  The same holds, ON
+    // PURPOSE, for the record-level entry points added since (match_to_map_rec, local_ba_csr, describe_begin / _end, the medoid log, the
+    // record arena): they are NOT forwarded, so a traced run takes their DEFAULT forms -- the records flattened on the host and handed to
+    // the traced match_to_map / local_ba, descriptor tables kept by the host-side default -- and the log stays comparable call by call
+    // with the reference-backed stages' log.  A traced run therefore exercises the fine-grained kernels, not the fused production path.
     TraceStages(Stages *inner, const char *path) : in_(inner) { f_ = std::fopen(path, "wb"); }
     ~TraceStages() override {
         if (f_) std::fclose(f_);

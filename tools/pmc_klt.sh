@@ -9,6 +9,9 @@ repo=$(pwd)
 mkdir -p "$repo/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 export FRAMES=${FRAMES:-700} WINDOW=${WINDOW:-100}
+# counter collection makes every launch synchronous: the fused pose launch (which waits for the host's answer WHILE it runs) would only
+# ever time out into its fallback; the tracker's counters do not need it
+export ALVA_NO_POSE_ALL=1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=${c%% *}
   out=/tmp/pmc_klt_$tag; rm -rf "$out"; mkdir -p "$out"
