@@ -241,8 +241,8 @@ int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *
     return maxTiles;
 }
 
-int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles) {
-    hipLaunchKernelGGL(k_blur7_multi, dim3(alva_xcd_grid(count, total_tiles)), dim3(256), 0, ctx->stream, (const BlurBatch *) d_batches, n_levels, count,
+int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles, hipStream_t on) {
+    hipLaunchKernelGGL(k_blur7_multi, dim3(alva_xcd_grid(count, total_tiles)), dim3(256), 0, on ? on : ctx->stream, (const BlurBatch *) d_batches, n_levels, count,
                        total_tiles);
     ALVA_LAUNCH_CHECK();
     return ALVA_OK;

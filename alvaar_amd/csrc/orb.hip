@@ -26,7 +26,7 @@ int alva_blur7_batch_launch(alva_ctx *ctx, int n, const uint8_t *const *src, uin
 
 size_t alva_blur7_batch_size();
 int alva_blur7_batch_fill(void *out, int n, const uint8_t *const *src, uint8_t *const *dst, const int *w, const int *h, const int *pitch);
-int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles);
+int alva_blur7_multi_launch(alva_ctx *ctx, const void *d_batches, int count, int n_levels, int total_tiles, hipStream_t on = nullptr);
 
 namespace {
 
@@ -1226,6 +1226,9 @@ struct alva_orb {
     void *d_blur_batch = nullptr;   // the levels' BlurBatch in device memory (the pool's addresses never change)
     int blurTiles = 0;
     bool chain_resize = false;      // ALVA_ORB_PYRAMID=chain: one k_resize per level (the fused launch's check)
+    // the levels' 7x7 blur needs the pyramid only, the descriptors need it last: it runs on a stream of its own beside FAST -> Harris -> angles
+    hipStream_t side = nullptr;
+    hipEvent_t pyr_done = nullptr, blur_done = nullptr;
 };
 
 static int orb_build(alva_ctx *ctx, int width, int height, int nfeatures, float scale_factor, int nlevels, int fast_threshold, int border,
@@ -1463,11 +1466,14 @@ extern "C" void alva_orb_destroy(alva_orb *orb) {
     (void) hipSetDevice(orb->device);
     if (orb->d_block) (void) hipFree(orb->d_block);
     if (orb->D.h_n3) (void) hipHostFree(orb->D.h_n3);
+    if (orb->side) (void) hipStreamDestroy(orb->side);
+    if (orb->pyr_done) (void) hipEventDestroy(orb->pyr_done);
+    if (orb->blur_done) (void) hipEventDestroy(orb->blur_done);
     delete orb;
 }
 
 // levels -> FAST -> NMS survivors (row-major per level) with counts in n1
-static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, size_t gray_pitch, bool fused) {
+static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, size_t gray_pitch, bool fused, hipEvent_t pyramid_done = nullptr) {
     OrbDev &D = o->D;
     hipStream_t st = ctx->stream;
     const Level &L0 = D.lv[0];
@@ -1482,6 +1488,7 @@ static int run_fast_stages(alva_ctx *ctx, alva_orb *o, const uint8_t *d_gray, si
     }
     for (int l = chained; l < D.nlevels; l++)
         hipLaunchKernelGGL(k_resize, dim3(alva_divup(D.lv[l].w, 64), alva_divup(D.lv[l].h, 4)), dim3(256), 0, st, D, l);
+    if (pyramid_done) ALVA_HIP(hipEventRecord(pyramid_done, st));
     if (fused) {
         // ORB: candidate order is irrelevant downstream (k_cull_harris re-sorts by position), so FAST + NMS is one launch
         int total = 0;
@@ -1533,8 +1540,24 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     ALVA_ARG(ctx && orb && d_gray && d_kp && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
     OrbDev &D = orb->D;
     hipStream_t st = ctx->stream;
-    int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch, true);
+    // The blur beside the detector (round 6): k_blur7_multi (12 us at 1280x720) depends on the pyramid alone and only the LAST kernel reads
+    // it, so it goes on a side stream between two events -- 8 dependent launches become a chain of 7 with the blur hidden under it
+    // (ALVA_ORB_SERIAL_BLUR=1: on the main stream, as before).
+    static const bool side_blur = getenv("ALVA_ORB_SERIAL_BLUR") == nullptr;
+    const bool overlap = side_blur && d_desc != nullptr && !g_alva_prof_on;   // (the in-library profiler brackets launches on ctx->stream)
+    if (overlap && !orb->side) {
+        ALVA_HIP(hipStreamCreateWithFlags(&orb->side, hipStreamNonBlocking));
+        ALVA_HIP(hipEventCreateWithFlags(&orb->pyr_done, hipEventDisableTiming));
+        ALVA_HIP(hipEventCreateWithFlags(&orb->blur_done, hipEventDisableTiming));
+    }
+    int rc = run_fast_stages(ctx, orb, d_gray, gray_pitch, true, overlap ? orb->pyr_done : nullptr);
     if (rc) return rc;
+    if (overlap) {
+        ALVA_HIP(hipStreamWaitEvent(orb->side, orb->pyr_done, 0));
+        rc = alva_blur7_multi_launch(ctx, orb->d_blur_batch, 1, D.nlevels, orb->blurTiles, orb->side);
+        if (rc) return rc;
+        ALVA_HIP(hipEventRecord(orb->blur_done, orb->side));
+    }
     hipLaunchKernelGGL(k_cull_fast, dim3(FAST_REGIONS, D.nlevels), dim3(256), 0, st, D);
     hipLaunchKernelGGL(k_harris, dim3(256, D.nlevels), dim3(256), 0, st, D);   // wave-strided over the level's candidates
     hipLaunchKernelGGL(k_cull_harris, dim3(D.nlevels), dim3(1024), 0, st, D);
@@ -1547,8 +1570,11 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     if (d_desc) {
         // the levels' 7x7 blur: a 1-D grid over the real tiles of all levels, four pixels per thread (describe.hip; the (maxTiles, level)
         // grid of k_blur7_batch was 60 % empty workgroups at 1280x720 and byte-granular: 31 us)
-        rc = alva_blur7_multi_launch(ctx, orb->d_blur_batch, 1, D.nlevels, orb->blurTiles);
-        if (rc) return rc;
+        if (overlap) ALVA_HIP(hipStreamWaitEvent(st, orb->blur_done, 0));
+        else {
+            rc = alva_blur7_multi_launch(ctx, orb->d_blur_batch, 1, D.nlevels, orb->blurTiles);
+            if (rc) return rc;
+        }
         int nmax = 0;
         for (int l = 0; l < D.nlevels; l++) nmax += std::min(D.lv[l].candCap, std::max(4 * D.lv[l].nKeep + 64, 1024));
         nmax = std::min(nmax, cap);
