@@ -26,6 +26,7 @@
 #include "wave_utils.hpp"
 #include "pose_internal.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -903,7 +904,7 @@ static int pose_launch(alva_ctx *ctx, alva_pose_pending &P) {
                             (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po};
     // ONE launch for both stages: a session of its own (no lane), samples that fit the kernel arguments, keys that fit the default
     // dynamic-LDS limit (ALVA_POSE_UNFUSED=1: the two launches, for A/B)
-    static const bool fuse = getenv("ALVA_POSE_UNFUSED") == nullptr;
+    const bool fuse = getenv("ALVA_POSE_UNFUSED") == nullptr;
     if (fuse && !g_alva_lane && P.H <= P3P_INLINE_H && alva_p3p_inline_samples_ok() && n <= 7168) {
         P3pInlineSamples S;
         memcpy(S.v, PA.samples, (size_t) P.H * 16);
@@ -952,7 +953,7 @@ static void pose_params(alva_pose_pending &P, const double *d_bearings, const do
 }
 
 bool alva_pose_all_possible(int n_cap, int p3p_iters) {
-    static const bool on = getenv("ALVA_POSE_UNFUSED") == nullptr && getenv("ALVA_NO_POSE_ALL") == nullptr;
+    const bool on = getenv("ALVA_POSE_UNFUSED") == nullptr && getenv("ALVA_NO_POSE_ALL") == nullptr;   // (per call: tests flip them in one process)
     // Not inside a session group: there the calling thread runs OTHER sessions' frames while this one's kernels fly (its polls yield to
     // the fiber scheduler, alva_fiber_yield), so the answer the queued launch waits for could be milliseconds away -- with ~170 workgroups
     // spinning meanwhile.  A session that owns its thread answers within ~10 us.
@@ -1045,6 +1046,14 @@ int alva_pose_all_go(alva_ctx *ctx, int n) {
     P.A.n = n;
     P.active = true;
     P.went_seq = P.go_seq;
+    {   // test hook (tests/test_gpu_system.py): answer too late on purpose, so that the launch gives up and the fallback is exercised
+        const char *late = getenv("ALVA_POSE_ALL_LATE_US");   // (read per call: a test flips it inside one process)
+        const int late_us = late ? atoi(late) : 0;
+        if (late_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < late_us) {}
+        }
+    }
     __atomic_store_n(&go->word, (long long) P.go_seq, __ATOMIC_RELEASE);
     P.go_seq = 0;
     return ALVA_OK;

@@ -346,6 +346,41 @@ def test_tracking_step_variants_agree_bitwise(monkeypatch):
     print(f"\n  composed vs fused step: worst pose difference {worst:.2e}")
 
 
+def test_pose_launch_forms_agree_bitwise(monkeypatch):
+    """the frame's tail four ways: ONE launch queued behind the tracker (k_pose_all: compaction -> P3P -> PnP, the default); the compaction
+    kernel + the fused P3P -> PnP launch (ALVA_NO_POSE_ALL=1); three separate launches (ALVA_POSE_UNFUSED=1, round 5's chain); and the
+    default with the host's answer made LATE on purpose (ALVA_POSE_ALL_LATE_US: the queued launch gives up, says so, and the host
+    falls back to the separate launches -- what happens under a tool that makes launches synchronous).  Same arithmetic in all of them:
+    statuses, states, keypoints and poses equal to the last bit through initialisation, keyframes and local BA."""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(60)]
+    keys = ("ALVA_NO_POSE_ALL", "ALVA_POSE_UNFUSED", "ALVA_POSE_ALL_LATE_US")
+    runs = []
+    for env in ({}, {"ALVA_NO_POSE_ALL": "1"}, {"ALVA_POSE_UNFUSED": "1"}, {"ALVA_POSE_ALL_LATE_US": "1500"}):
+        for key in keys:
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        gpu = sysdiff.GpuSystem(w, h, 12)
+        rec = []
+        for k, f in enumerate(frames):
+            st, p7, p16 = gpu.step(f, 33.0 * k)
+            ids, px, un, i3, hd = gpu.frame_keypoints()
+            rec.append((st, list(gpu.state()), ids.copy(), px.copy(), un.copy(), i3.copy(), p7.copy()))
+        assert sum(r[0] == 1 for r in rec) >= 25
+        gpu.close()
+        runs.append(rec)
+    for key in keys:
+        monkeypatch.delenv(key, raising=False)
+    for other, name in zip(runs[1:], ("compaction + fused pose", "three launches", "late answer -> fallback")):
+        for k, (a, b) in enumerate(zip(runs[0], other)):
+            assert a[0] == b[0] and a[1] == b[1], f"{name}, frame {k}: status / state"
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[5], b[5]), f"{name}, frame {k}: keypoint ids / flags"
+            assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32)), f"{name}, frame {k}: pixels"
+            assert np.array_equal(a[6].view(np.uint64), b[6].view(np.uint64)), f"{name}, frame {k}: pose"
+
+
 def test_imu_surface_equals_reference_composition():
     """System::findCameraPoseWithIMU (system.cpp:57-104): orientation from the IMU quaternion (w, -x, y, z), inverted; translation = the
     visual translation integrated over the tracked frames (reset of the increment on every frame that is not tracked).  Expected arrays come
