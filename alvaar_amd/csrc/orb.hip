@@ -1540,10 +1540,12 @@ extern "C" int alva_orb_detect_and_compute(alva_ctx *ctx, alva_orb *orb, const u
     ALVA_ARG(ctx && orb && d_gray && d_kp && cap >= 0 && gray_pitch >= (size_t) orb->D.lv[0].w);
     OrbDev &D = orb->D;
     hipStream_t st = ctx->stream;
-    // The blur beside the detector (round 6): k_blur7_multi (12 us at 1280x720) depends on the pyramid alone and only the LAST kernel reads
-    // it, so it goes on a side stream between two events -- 8 dependent launches become a chain of 7 with the blur hidden under it
-    // (ALVA_ORB_SERIAL_BLUR=1: on the main stream, as before).
-    static const bool side_blur = getenv("ALVA_ORB_SERIAL_BLUR") == nullptr;
+    // The blur beside the detector (round 6, OFF by default): k_blur7_multi (12 us at 1280x720) depends on the pyramid alone and only the LAST
+    // kernel reads it, so it can go on a side stream between two events.  Measured: -3.5 us per call in a process of its own
+    // (tools/orb_kernels.py: 117.2 vs 120.7 us), but +80 us inside bench.py's process, where dozens of streams from the earlier sections
+    // share the hardware queues and every cross-stream dependency becomes a barrier packet + a signal round trip.  ALVA_ORB_SIDE_BLUR=1
+    // turns it on.
+    static const bool side_blur = getenv("ALVA_ORB_SIDE_BLUR") != nullptr;
     const bool overlap = side_blur && d_desc != nullptr && !g_alva_prof_on;   // (the in-library profiler brackets launches on ctx->stream)
     if (overlap && !orb->side) {
         ALVA_HIP(hipStreamCreateWithFlags(&orb->side, hipStreamNonBlocking));
