@@ -562,6 +562,9 @@ private:
     } par_soa_;
     int par_frame_ = -1, par_kfid_ = -1;   // the frame / keyframe the pairs were collected for
     void prepare_parallax();
+    // NOT the median parallax: a stand-in that compares like it against the two thresholds of the keyframe check (>= min_avg_rot_parallax / 2
+    // and >= min_avg_rot_parallax) and nowhere else -- the median's rank is COUNTED, not sorted for (ALVA_CHECK_OBS_MIRROR=1 verifies the two
+    // comparisons against the sorted median every frame).  Anything that wants the value itself calls compute_parallax().
     float parallax_of_pairs(const FrameRec &kf);
     float median_of_distinct(std::vector<uint32_t> &all);
     std::vector<int> ids_scratch_, obs_scratch_, index_scratch_, mp_index_, kf_ids_scratch_, local_scratch_, rm_ids_;
