@@ -48,7 +48,7 @@ struct LkPyr {
 
 struct LkShared {
 #ifdef ALVA_KLT_COUNT
-    unsigned cnt[4];
+    unsigned cnt[8];   // iterations, origin moves, restages, levels | level-0 failures: template out of range, min-eig / det, window out of bounds
 #endif
     alignas(16) uint32_t jt[TW * TW];  // tile of the searched image around the current window (see lk_level), one dword per pixel: a tap's
                                        // two horizontal neighbours come back from ONE ds_read2_b32, ready to multiply
@@ -215,6 +215,7 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I_, const LkLevel &J_, int
         if (level == 0) {
             status = 0;
             err = 0.f;
+            KLT_COUNT(4);
         }
         return;
     }
@@ -297,7 +298,10 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I_, const LkLevel &J_, int
     const float minEig = ((A22 + A11) - sqrtf(dA * dA + (4.f * A12) * A12)) / (float) (2 * WIN * WIN);
     err = minEig;
     if (minEig < minEigThreshold || D < 1.1920928955078125e-07f) {
-        if (level == 0) status = 0;
+        if (level == 0) {
+            status = 0;
+            KLT_COUNT(5);
+        }
         return;
     }
     D = 1.f / D;
@@ -325,7 +329,10 @@ __device__ void lk_level(LkShared &sh, const LkLevel &I_, const LkLevel &J_, int
             KLT_COUNT(1);
             const int inx = __builtin_amdgcn_readfirstlane((int) flx), iny = __builtin_amdgcn_readfirstlane((int) fly);
             if ((unsigned) (inx + WIN) >= (unsigned) (J.w + WIN) || (unsigned) (iny + WIN) >= (unsigned) (J.h + WIN)) {   // inx < -WIN || inx >= J.w || ...
-                if (level == 0) status = 0;
+                if (level == 0) {
+                    status = 0;
+                    KLT_COUNT(6);
+                }
                 break;
             }
             if ((unsigned) (inx - tx0) > 2u * TR || (unsigned) (iny - ty0) > 2u * TR) {
@@ -533,7 +540,7 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
     __shared__ LkShared sh;
     const unsigned long long t_begin = D.dbg ? wall_clock64() : 0ull;
 #ifdef ALVA_KLT_COUNT
-    if (threadIdx.x < 4) sh.cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 8) sh.cnt[threadIdx.x] = 0;
     __syncthreads();
 #endif
     const int per = gx >> 3;
@@ -574,7 +581,8 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
                    ((unsigned long long) (from_prior && !ok ? 1 : 0) << 37) | ((unsigned long long) why << 40) | ((unsigned long long) why2 << 44);
 #ifdef ALVA_KLT_COUNT
     if (D.dbg && threadIdx.x == 0 && i < 8192)
-        D.dbg[8192 + i] = (unsigned long long) sh.cnt[0] | ((unsigned long long) sh.cnt[1] << 16) | ((unsigned long long) sh.cnt[2] << 32) | ((unsigned long long) sh.cnt[3] << 48);
+        D.dbg[8192 + i] = (unsigned long long) sh.cnt[0] | ((unsigned long long) sh.cnt[1] << 16) | ((unsigned long long) sh.cnt[2] << 32) | ((unsigned long long) (sh.cnt[3] & 0xff) << 48) |
+                          ((unsigned long long) (sh.cnt[4] & 3) << 56) | ((unsigned long long) (sh.cnt[5] & 3) << 58) | ((unsigned long long) (sh.cnt[6] & 3) << 60);
 #endif
     if (threadIdx.x == 0) {
         // ONE atomic per slot on a packed counter (track_slots.hpp) -- STRIPED: 2 600 atomics-with-return on one address from eight XCDs

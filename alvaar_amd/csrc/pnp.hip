@@ -26,6 +26,7 @@
 #include "wave_utils.hpp"
 #include "pose_internal.hpp"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -952,6 +953,15 @@ static void pose_params(alva_pose_pending &P, const double *d_bearings, const do
     A.dbg = alva_kstamp_buffer();
 }
 
+// how often the fused launch was queued / answered with go / gave up waiting and was replaced by the separate launches (process-wide;
+// tools/soak.py reports them: a fallback costs ~0.7 ms once, a rate above ~1e-4 would mean the host's answer is not as prompt as assumed)
+static std::atomic<long> g_pose_all_queued{0}, g_pose_all_go{0}, g_pose_all_fallback{0};
+extern "C" void alva_debug_pose_all_stats(long *out3) {
+    out3[0] = g_pose_all_queued.load();
+    out3[1] = g_pose_all_go.load();
+    out3[2] = g_pose_all_fallback.load();
+}
+
 bool alva_pose_all_possible(int n_cap, int p3p_iters) {
     const bool on = getenv("ALVA_POSE_UNFUSED") == nullptr && getenv("ALVA_NO_POSE_ALL") == nullptr;   // (per call: tests flip them in one process)
     // Not inside a session group: there the calling thread runs OTHER sessions' frames while this one's kernels fly (its polls yield to
@@ -1004,6 +1014,7 @@ int alva_pose_all_enqueue(alva_ctx *ctx, const TrackSlots &D, int G, int p3p_ite
     const PnpBatchItem item{P.A, base + off_act, (double *) base, base + off_dep, P.pin + P.poff_bad, (PnpOut *) (P.pin + P.poff_out),
                             (const P3pSelectOut *) d_sel, (const uint8_t *) d_inl, P.pin + P.poff_po};
     ctx->p3p_deferred = false;
+    g_pose_all_queued++;
     hipLaunchKernelGGL(k_pose_all, dim3((unsigned) (P.H + G)), dim3(NT), (size_t) n_cap * sizeof(double), ctx->stream, D, G, PA, item,
                        (const PoseGo *) P.pin, reinterpret_cast<unsigned long long *>(ctx->d_counters + 64), D.seq);
     ALVA_LAUNCH_CHECK();
@@ -1046,6 +1057,7 @@ int alva_pose_all_go(alva_ctx *ctx, int n) {
     P.A.n = n;
     P.active = true;
     P.went_seq = P.go_seq;
+    g_pose_all_go++;
     {   // test hook (tests/test_gpu_system.py): answer too late on purpose, so that the launch gives up and the fallback is exercised
         const char *late = getenv("ALVA_POSE_ALL_LATE_US");   // (read per call: a test flips it inside one process)
         const int late_us = late ? atoi(late) : 0;
@@ -1117,6 +1129,7 @@ int alva_compute_pose_collect_p3p(alva_ctx *ctx, double *h_pose7, double *h_pose
                     // the fused launch gave up before the go word reached it (see PoseGo::nack): its compaction phase is done, the
                     // correspondences are gathered -- solve the pose with the separate launches
                     P.went_seq = 0;
+                    g_pose_all_fallback++;
                     const int rc = pose_launch(ctx, P);
                     if (rc) return rc;
                     flag = &((const PnpOut *) (P.pin + P.poff_out))->seq;

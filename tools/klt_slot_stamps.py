@@ -55,7 +55,10 @@ for (r_, a, b_), n in sorted(c.items(), key=lambda kv: -kv[1]):
 cnt = np.concatenate([r[6] for r in rows])
 if cnt.any():   # the counting build (hipcc -DALVA_KLT_COUNT): LK iterations, window moves, tile restages, levels per slot
     it = (cnt & np.uint64(0xffff)).astype(float); mv = ((cnt >> np.uint64(16)) & np.uint64(0xffff)).astype(float)
-    rs = ((cnt >> np.uint64(32)) & np.uint64(0xffff)).astype(float); lv = ((cnt >> np.uint64(48)) & np.uint64(0xffff)).astype(float)
+    rs = ((cnt >> np.uint64(32)) & np.uint64(0xffff)).astype(float); lv = ((cnt >> np.uint64(48)) & np.uint64(0xff)).astype(float)
+    f_tpl = ((cnt >> np.uint64(56)) & np.uint64(3)).astype(int); f_eig = ((cnt >> np.uint64(58)) & np.uint64(3)).astype(int); f_oob = ((cnt >> np.uint64(60)) & np.uint64(3)).astype(int)
+    s0 = lost & (why == 1)
+    print(f"lost with status 0 in the first attempt: {s0.sum()}; level-0 failures seen in those slots (either attempt): template out of range {int((f_tpl[s0] > 0).sum())}, min-eig / det {int((f_eig[s0] > 0).sum())}, window out of bounds during the iteration {int((f_oob[s0] > 0).sum())}")
     print(f"per slot: iterations {it.mean():.1f}, integer-origin moves {mv.mean():.1f}, tile restages {rs.mean():.2f}, levels {lv.mean():.2f}")
     slow = us > 30
     print(f"slots > 30 us: iterations {it[slow].mean():.1f}, moves {mv[slow].mean():.1f}, restages {rs[slow].mean():.1f}, levels {lv[slow].mean():.1f}, us {us[slow].mean():.1f}")
