@@ -85,6 +85,7 @@ struct BaDev {
     unsigned long long *dbg;   // phase stamps of k_solve (alva_kstamp_buffer, entries 3072..) or null
 };
 #define SOLVE_STAMP(k) do { if (B.dbg && threadIdx.x == 0) B.dbg[3072 + (k)] = wall_clock64(); } while (0)
+#define ASM_STAMP(k) do { if (B.dbg && threadIdx.x == 0) B.dbg[3072 + 48 + (k)] = wall_clock64(); } while (0)   // k_assemble's phases (tools/solve_stamps.py)
 
 constexpr int KSPLIT = 8;
 
@@ -273,6 +274,7 @@ __device__ __forceinline__ void assemble_body(const BaDev &B, int first) {
     __shared__ double s_red[5][ASM_NT / 64];
     __shared__ int s_kfof[64];   // free camera -> keyframe (a dependent global load in front of every pair-sum load otherwise)
     const int nKf = B.nKf, n6 = B.n6, tid = threadIdx.x;
+    ASM_STAMP(0);
     if (tid < B.nc && tid < 64) s_kfof[tid] = B.kfOf[tid];   // (visible after the barrier behind the row / column sums)
     double *rowsum = s_rc, *colsum = s_rc + (size_t) nKf * 27;
     for (int e = tid; e < 2 * nKf * 27; e += ASM_NT) {
@@ -292,6 +294,7 @@ __device__ __forceinline__ void assemble_body(const BaDev &B, int first) {
         s_rc[e] = acc;
     }
     __syncthreads();
+    ASM_STAMP(1);
     double gm = 0;
     {
         // H_cc row by row: wave w takes rows w, w + 16, ..., lane l the columns l, l + 64, ... -- no division by the runtime size (a
@@ -337,6 +340,7 @@ __device__ __forceinline__ void assemble_body(const BaDev &B, int first) {
             gm = fmax(gm, fabs(g));
         }
     }
+    ASM_STAMP(2);
     if (first)
         for (int i = tid; i < B.npd; i += ASM_NT) {
             const int p = i / B.dp, x = i % B.dp;
@@ -364,6 +368,7 @@ __device__ __forceinline__ void assemble_body(const BaDev &B, int first) {
         s_red[0][wave] = gm; s_red[1][wave] = cost; s_red[2][wave] = mcc; s_red[3][wave] = sn; s_red[4][wave] = xn;
     }
     __syncthreads();
+    ASM_STAMP(3);
     if (tid == 0) {
         double g2 = 0, c2 = 0, m2 = 0, s2 = 0, x2 = 0;
         for (int w = 0; w < ASM_NT / 64; w++) {

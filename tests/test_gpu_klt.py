@@ -108,3 +108,31 @@ def test_fbklt_batch_bitwise(ctx, lanes):
             op, os_ = O.fbklt(prev, curr, pts, init, 3)
             assert np.array_equal(st, os_), name
             assert np.array_equal(pr.view(np.uint32), op.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("w,h,levels,seed", [(320, 240, 3, 31), (320, 240, 0, 32), (212, 158, 2, 33)])
+def test_klt_border_windows_with_wandering_priors(ctx, w, h, levels, seed):
+    """Everything the row layout's search-tile paths can meet at once: points on, near and beyond the image border (their 16 x 16 tile
+    is read through the clamped path), priors up to 12 px off (the window leaves the tile and the level, re-stages near the border, runs
+    out of bounds on some level) on content that moved by (7, -4).  Positions bitwise, status and error exact, for plain LK and fb-KLT."""
+    import torch
+    n = 5000
+    canvas = synth.texture_canvas(w + 64, h + 64, seed)
+    prev = canvas[32:32 + h, 32:32 + w].copy()
+    curr = canvas[32 + 4:32 + 4 + h, 32 - 7:32 - 7 + w].copy()
+    rng = np.random.RandomState(seed)
+    pts = np.stack([rng.uniform(-6, w + 6, n), rng.uniform(-6, h + 6, n)], 1).astype(np.float32)
+    pts[: n // 5] = np.round(pts[: n // 5])
+    init = (pts + rng.uniform(-12, 12, pts.shape)).astype(np.float32)
+    pp, cp = _pyrs(ctx, prev, curr)
+    nx, st, er = ctx.lk_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(init).cuda(), levels)
+    nx, st, er = nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()
+    on, os_, oe = Orc.lk(prev, curr, pts, init, levels)
+    assert np.array_equal(st, os_)
+    assert np.array_equal(nx.view(np.uint32), on.view(np.uint32))
+    ok = os_.astype(bool)
+    assert np.array_equal(er[ok].view(np.uint32), oe[ok].view(np.uint32))
+    pr, fs = ctx.fbklt_track(pp, cp, torch.from_numpy(pts).cuda(), torch.from_numpy(init).cuda(), levels)
+    op, ofs = Orc.fbklt(prev, curr, pts, init, levels)
+    assert np.array_equal(fs.cpu().numpy(), ofs) and np.array_equal(pr.cpu().numpy().view(np.uint32), op.view(np.uint32))
+    assert 0.05 * n < ok.sum() < 0.98 * n and 0 < ofs.sum() < ok.sum()      # some of everything: tracked, lost, out of bounds

@@ -23,3 +23,5 @@ if os.environ.get("ALVA_KSTAMPS"):
         s = b[8 + 4 * kb: 12 + 4 * kb]
         nxt = b[8 + 4 * (kb + 1)] if kb < 6 else b[2]
         print("  block %d: diagonal %.2f  panel %.2f  trailing %.2f" % (kb, s[1] - s[0], s[2] - s[1], nxt - s[2]))
+    a = buf.astype(np.int64)[3072 + 48:3072 + 52] * 0.01
+    print("k_assemble (last launch), us: pair sums' rows / columns %.2f  camera block + gradient %.2f  points' scalars + reductions %.2f" % (a[1] - a[0], a[2] - a[1], a[3] - a[2]))
