@@ -208,6 +208,8 @@ int Stages::match_to_map_rec(const MatchJob &J, int *match_of_mp) {
     static const alva_medoid::Table fresh = [] { alva_medoid::Table t{}; alva_medoid::reset(t); return t; }();
     for (int m = 0; m < J.n_mp; m++) {
         const int slot = J.mp_slot[m];
+        // (a subclass that keeps its own arena behind mp_arena_chunk must bring its own match_to_map_rec: this one reads arena_)
+        if (slot < 0 || ((size_t) slot >> MP_CHUNK_SHIFT) >= arena_.size() || !arena_[(size_t) slot >> MP_CHUNK_SHIFT]) return -1;
         const MpRec &r = arena_[(size_t) slot >> MP_CHUNK_SHIFT][(size_t) (slot & (MP_CHUNK - 1))];
         const alva_medoid::Table &t = (size_t) slot < med_tables_.size() ? med_tables_[(size_t) slot] : fresh;
         std::memcpy(&wpt[3 * (size_t) m], r.X, 24);
