@@ -109,38 +109,23 @@ struct StageArgs {
     int down_bx;
 };
 
-__device__ __forceinline__ void scharr_tile(const StageArgs &a, int bid) {
-    int bx = bid % a.scharr_bx, by = bid / a.scharr_bx;
-    int x4 = (bx * 64 + threadIdx.x) * 4;
-    int y = by * 4 + threadIdx.y;
-    if (x4 >= a.w || y >= a.h) return;
-    // rows y-1..y+1, bytes x4-4 .. x4+7 via three aligned u32 loads per row (the padding is
-    // REFLECT_101, which is exactly the border rule of ScharrDerivInvoker, lkpyramid.cpp:83-121)
+// Scharr pair of the four pixels x4 .. x4+3 of row y from rows y-1 .. y+1, bytes x4-4 .. x4+7, as three dwords per row
+__device__ __forceinline__ void scharr_quad(const uint32_t (&r)[3][3], int16_t *d, size_t d_pitch, int x4, int y, int w) {
     int t0[6], t1[6];
-    {
-        uint32_t r[3][3];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint8_t *row = a.g + (ptrdiff_t) (y - 1 + j) * (ptrdiff_t) a.g_pitch + x4;
-            r[j][0] = *reinterpret_cast<const uint32_t *>(row - 4);
-            r[j][1] = *reinterpret_cast<const uint32_t *>(row);
-            r[j][2] = *reinterpret_cast<const uint32_t *>(row + 4);
+    for (int c = 0; c < 6; c++) {
+        // column x4-1+c
+        int p0, p1, p2;
+        if (c == 0) {
+            p0 = r[0][0] >> 24; p1 = r[1][0] >> 24; p2 = r[2][0] >> 24;
+        } else if (c == 5) {
+            p0 = r[0][2] & 0xff; p1 = r[1][2] & 0xff; p2 = r[2][2] & 0xff;
+        } else {
+            int sh = 8 * (c - 1);
+            p0 = (r[0][1] >> sh) & 0xff; p1 = (r[1][1] >> sh) & 0xff; p2 = (r[2][1] >> sh) & 0xff;
         }
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            // column x4-1+c
-            int p0, p1, p2;
-            if (c == 0) {
-                p0 = r[0][0] >> 24; p1 = r[1][0] >> 24; p2 = r[2][0] >> 24;
-            } else if (c == 5) {
-                p0 = r[0][2] & 0xff; p1 = r[1][2] & 0xff; p2 = r[2][2] & 0xff;
-            } else {
-                int sh = 8 * (c - 1);
-                p0 = (r[0][1] >> sh) & 0xff; p1 = (r[1][1] >> sh) & 0xff; p2 = (r[2][1] >> sh) & 0xff;
-            }
-            t0[c] = (p0 + p2) * 3 + p1 * 10;
-            t1[c] = p2 - p0;
-        }
+        t0[c] = (p0 + p2) * 3 + p1 * 10;
+        t1[c] = p2 - p0;
     }
     short out[8];
 #pragma unroll
@@ -148,8 +133,8 @@ __device__ __forceinline__ void scharr_tile(const StageArgs &a, int bid) {
         out[2 * k] = (short) (t0[k + 2] - t0[k]);
         out[2 * k + 1] = (short) ((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10);
     }
-    int16_t *drow = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(a.d) + (size_t) y * a.d_pitch) + 2 * x4;
-    if (x4 + 3 < a.w) {
+    int16_t *drow = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(d) + (size_t) y * d_pitch) + 2 * x4;
+    if (x4 + 3 < w) {
         uint4 v;
         v.x = (uint16_t) out[0] | ((uint32_t) (uint16_t) out[1] << 16);
         v.y = (uint16_t) out[2] | ((uint32_t) (uint16_t) out[3] << 16);
@@ -157,11 +142,29 @@ __device__ __forceinline__ void scharr_tile(const StageArgs &a, int bid) {
         v.w = (uint16_t) out[6] | ((uint32_t) (uint16_t) out[7] << 16);
         *reinterpret_cast<uint4 *>(drow) = v;
     } else {
-        for (int k = 0; k < 4 && x4 + k < a.w; k++) {
+        for (int k = 0; k < 4 && x4 + k < w; k++) {
             drow[2 * k] = out[2 * k];
             drow[2 * k + 1] = out[2 * k + 1];
         }
     }
+}
+
+__device__ __forceinline__ void scharr_tile(const StageArgs &a, int bid) {
+    int bx = bid % a.scharr_bx, by = bid / a.scharr_bx;
+    int x4 = (bx * 64 + threadIdx.x) * 4;
+    int y = by * 4 + threadIdx.y;
+    if (x4 >= a.w || y >= a.h) return;
+    // rows y-1..y+1, bytes x4-4 .. x4+7 via three aligned u32 loads per row (the padding is
+    // REFLECT_101, which is exactly the border rule of ScharrDerivInvoker, lkpyramid.cpp:83-121)
+    uint32_t r[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint8_t *row = a.g + (ptrdiff_t) (y - 1 + j) * (ptrdiff_t) a.g_pitch + x4;
+        r[j][0] = *reinterpret_cast<const uint32_t *>(row - 4);
+        r[j][1] = *reinterpret_cast<const uint32_t *>(row);
+        r[j][2] = *reinterpret_cast<const uint32_t *>(row + 4);
+    }
+    scharr_quad(r, a.d, a.d_pitch, x4, y, a.w);
 }
 
 // pyrDown of level l into level l+1: FOUR output pixels per thread.  Their 5 x 5 binomial windows span input columns
@@ -232,11 +235,14 @@ struct RestArgs {
     RestLevel lv[4];
     int nlevels, win;
     int first[4], bx[4], ntiles[4];   // deep tiles of level L: first workgroup index, tiles per row, number of tiles
+    int ts[4];                        // ... and their side (<= rest_tile(L): the LDS buffers are sized for that)
 };
 struct Span {
     int lo, hi;            // inclusive, unmirrored coordinates
 };
 __device__ __forceinline__ int mirror101(int c, int n) { return c < 0 ? -c : (c >= n ? 2 * (n - 1) - c : c); }
+// the same as an index that is safe to dereference whatever the size (a level narrower than the reach of the mirror: clamped)
+__device__ __forceinline__ int mirror_in(int c, int n) { return min(max(mirror101(c, n), 0), n - 1); }
 // the range of the level below that the entries of `s` (mirrored into [0, n)) read: 2 m - 2 .. 2 m + 2
 __device__ __forceinline__ Span below(Span s, int n) { return Span{2 * max(s.lo, 0) - 2, 2 * min(s.hi, n - 1) + 2}; }
 
@@ -259,12 +265,16 @@ __device__ __forceinline__ void down_tile(const uint8_t *src, int spitch, Span s
     }
 }
 
-__device__ __forceinline__ void deep_tile(const RestArgs &A, int L, int bid) {
+// FROM_RGBA (k_pyr_all): the level-0 footprint is converted from the RGBA frame on the way into LDS -- level 0 need not exist in memory, so
+// the tile does not wait for the launch that writes it.  Out-of-image entries: the REFLECT_101 mirror image, which is what the padding of
+// the stored level holds (store_mirrors).
+template<bool FROM_RGBA>
+__device__ __forceinline__ void deep_tile(const RestArgs &A, int L, int bid, const uint8_t *__restrict__ rgba = nullptr, size_t rgba_pitch = 0) {
     __shared__ __attribute__((aligned(16))) uint8_t b0[R0 * R0P];
     __shared__ uint8_t b1[R1 * R1], b2[R2 * R2], b3[R3 * R3];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const RestLevel &T = A.lv[L];
-    const int ts = rest_tile(L);
+    const int ts = A.ts[L];
     const int ox = (bid % A.bx[L]) * ts, oy = (bid / A.bx[L]) * ts;
     // spans per level, from the target down to level 0.  In LDS, written by one thread: as per-thread arrays indexed with the run-time
     // level they lived in scratch memory -- 80 B per thread, ~6 MB of write traffic per launch in the PMC counters against 1.75 MB of
@@ -285,7 +295,22 @@ __device__ __forceinline__ void deep_tile(const RestArgs &A, int L, int bid) {
     const int ndw = (sx[0].hi - xa) / 4 + 1, nrow = sy[0].hi - sy[0].lo + 1;
     for (int e = tid; e < ndw * nrow; e += 256) {
         const int r = e / ndw, c = e - r * ndw;
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(Z.g + (ptrdiff_t) (sy[0].lo + r) * (ptrdiff_t) Z.g_pitch + xa + 4 * c);
+        uint32_t v;
+        if (FROM_RGBA) {
+            const int yy = mirror_in(sy[0].lo + r, Z.h), x0 = xa + 4 * c;
+            const uint8_t *rowp = rgba + (size_t) yy * rgba_pitch;
+            if (x0 >= 0 && x0 + 3 < Z.w) {
+                const uint4 p = *reinterpret_cast<const uint4 *>(rowp + 4 * (size_t) x0);
+                v = gray_of(p.x) | (gray_of(p.y) << 8) | (gray_of(p.z) << 16) | (gray_of(p.w) << 24);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    v |= gray_of(*reinterpret_cast<const uint32_t *>(rowp + 4 * (size_t) mirror_in(x0 + k, Z.w))) << (8 * k);
+            }
+        } else {
+            v = *reinterpret_cast<const uint32_t *>(Z.g + (ptrdiff_t) (sy[0].lo + r) * (ptrdiff_t) Z.g_pitch + xa + 4 * c);
+        }
         *reinterpret_cast<uint32_t *>(b0 + r * R0P + 4 * c) = v;
     }
     __syncthreads();
@@ -336,10 +361,108 @@ __device__ __forceinline__ void pyr_rest_body(const RestArgs &A, const int bid) 
     const int lb = bid - A.first[L], per = (n + 7) / 8;
     const int tile = (lb & 7) * per + (lb >> 3);
     if (tile >= n) return;   // (whole workgroup: no barrier is skipped by a part of it)
-    deep_tile(A, L, tile);
+    deep_tile<false>(A, L, tile);
 }
 __global__ void __launch_bounds__(256) k_pyr_rest(RestArgs A) { pyr_rest_body(A, (int) blockIdx.x); }
 ALVA_MULTI_KERNEL(MK_PYR_REST, k_pyr_rest_multi, RestArgs, dim3(64, 4), 256, pyr_rest_body(A, bx));
+
+// ---- the whole pyramid in ONE launch (round 6) -------------------------------------------------------------------------------------------
+// k_level0 -> k_pyr_rest is a dependent pair only because the deep tiles read level 0 from memory.  Here they convert their footprint from
+// the RGBA frame themselves (deep_tile<true>: one 16-B load per four pixels instead of one dword of gray -- the frame is read ~7 times, out
+// of L2), and the level-0 role does gray + padded level 0 + the un-padded copy + Scharr of level 0 from its own pixels: a 64 x 16 tile with
+// one pixel of halo in LDS (the halo from the frame as well, REFLECT_101 at the image's edge = the padding ScharrDerivInvoker reads).  No
+// role reads anything another role writes => one launch, one launch latency in front of the tracker instead of two (k_level0 6.6 us +
+// k_pyr_rest 11.9 us + the gap between them, per frame).  Same integer arithmetic, same bytes out (tests/test_gpu_image.py).
+// Deep tiles come FIRST in the grid (deepest level first: they are the launch's critical path), the level-0 tiles behind them.
+// Deep tiles are SMALLER here than in k_pyr_rest (16 / 12 / 4 instead of 16 / 16 / 8): this launch's duration is the slowest workgroup's, and
+// a level-3 tile of 8 x 8 walks a 101 x 101 footprint (10 conversions + 235 LDS taps per thread for its level 1 alone); 4 x 4 needs 69 x 69.
+// Four times the tiles, twice the redundant arithmetic, half the critical path -- while the grid is a few workgroups per compute unit.
+// Measured (tools/pyr_times.py, event-timed launch, us): 640 x 480: 16/16/8 15.7, 16/8/4 12.0, 16/12/4 11.7, 16/8/3 11.5, 8/4/4 13.3;
+// 1280 x 720 (3.4 k workgroups: throughput counts too): 16/16/8 16.9, 16/12/6 16.5, 16/12/4 18.2, 8/8/4 21.2.
+static int env_tile(const char *name, int dflt, int most) {   // (A/B: ALVA_PYR_T1 / _T2 / _T3)
+    const char *v = getenv(name);
+    const int x = v ? atoi(v) : dflt;
+    return x >= 2 && x <= most ? x : dflt;
+}
+static int all_tile(int L, size_t pixels) {
+    static const int t[4] = {0, env_tile("ALVA_PYR_T1", 16, rest_tile(1)), env_tile("ALVA_PYR_T2", 12, rest_tile(2)), env_tile("ALVA_PYR_T3", 0, rest_tile(3))};
+    if (L == 3 && !t[3]) return pixels <= 500000 ? 4 : 6;
+    return t[L];
+}
+constexpr int L0_TW = 64, L0_TH = 16, L0_P = L0_TW + 8;   // LDS row: 4 bytes in front (the left halo is byte 3), 64 pixels, 4 behind
+struct AllArgs {
+    RestArgs R;            // (s0 unused; first[] counts from this kernel's workgroup 0, deepest level first)
+    const uint8_t *rgba;
+    size_t rgba_pitch;
+    uint8_t *gray_out;
+    size_t gray_out_pitch;
+    int l0_first, l0_bx;   // level-0 tiles: first workgroup, tiles per row
+};
+__device__ __forceinline__ uint32_t gray4(const uint8_t *p) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    return gray_of(q.x) | (gray_of(q.y) << 8) | (gray_of(q.z) << 16) | (gray_of(q.w) << 24);
+}
+__device__ __forceinline__ void level0_tile(const AllArgs &A, const int tile) {
+    __shared__ __attribute__((aligned(16))) uint8_t t[(L0_TH + 2) * L0_P];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const RestLevel &Z = A.R.lv[0];
+    const int w = Z.w, h = Z.h, win = A.R.win;
+    const int ox = (tile % A.l0_bx) * L0_TW, oy = (tile / A.l0_bx) * L0_TH;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int x4 = ox + 4 * tx, y = oy + ty;
+    const bool in = x4 < w && y < h;
+    if (in) {
+        const uint32_t packed = gray4(A.rgba + (size_t) y * A.rgba_pitch + (size_t) x4 * 4);
+        *reinterpret_cast<uint32_t *>(t + (ty + 1) * L0_P + 4 + 4 * tx) = packed;
+        *reinterpret_cast<uint32_t *>(Z.g + (size_t) y * Z.g_pitch + x4) = packed;
+        if (A.gray_out) *reinterpret_cast<uint32_t *>(A.gray_out + (size_t) y * A.gray_out_pitch + x4) = packed;
+        const bool edge_y = (y <= win) || (y >= h - 1 - win);
+        const bool edge_x = (x4 <= win) || (x4 + 3 >= w - 1 - win);
+        if (edge_x || edge_y) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) store_mirrors(Z.g, Z.g_pitch, w, h, win, x4 + k, y, (uint8_t) (packed >> (8 * k)));
+        }
+    }
+    // halo: row -1 and the row behind the tile's last (rb), column -1 and the column behind its last (cr) -- at the image's edge the mirror image
+    const int cr = min(L0_TW, w - ox), rb = min(L0_TH, h - oy);
+    if (tid < 32) {
+        const int q = tid & 15, r = tid < 16 ? -1 : rb, xx = ox + 4 * q;
+        if (xx < w)
+            *reinterpret_cast<uint32_t *>(t + (r + 1) * L0_P + 4 + 4 * q) = gray4(A.rgba + (size_t) mirror_in(oy + r, h) * A.rgba_pitch + (size_t) xx * 4);
+    } else if (tid < 32 + 2 * (L0_TH + 2)) {
+        const int k = tid - 32, side = k >= L0_TH + 2, r = (side ? k - (L0_TH + 2) : k) - 1;
+        if (r <= rb) {
+            const int c = side ? cr : -1;
+            const uint32_t px = *reinterpret_cast<const uint32_t *>(A.rgba + (size_t) mirror_in(oy + r, h) * A.rgba_pitch + (size_t) mirror_in(ox + c, w) * 4);
+            t[(r + 1) * L0_P + 4 + c] = (uint8_t) gray_of(px);
+        }
+    }
+    __syncthreads();
+    if (!in) return;
+    uint32_t r[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(t + (ty + j) * L0_P + 4 * tx);   // bytes x4-4 .. x4+7 of row y-1+j
+        r[j][0] = row[0];
+        r[j][1] = row[1];
+        r[j][2] = row[2];
+    }
+    scharr_quad(r, Z.d, Z.d_pitch, x4, y, w);
+}
+__global__ void __launch_bounds__(256) k_pyr_all(AllArgs A) {
+    const int bid = (int) blockIdx.x;
+    if (bid >= A.l0_first) {
+        level0_tile(A, bid - A.l0_first);
+        return;
+    }
+    int L = 1;
+    while (bid < A.R.first[L]) L++;   // first[] falls with the level: the deepest level owns workgroup 0
+    const int n = A.R.ntiles[L];      // XCD-aware order inside a level, as in pyr_rest_body
+    const int lb = bid - A.R.first[L], per = (n + 7) / 8;
+    const int tile = (lb & 7) * per + (lb >> 3);
+    if (tile >= n) return;
+    deep_tile<true>(A.R, L, tile, A.rgba, A.rgba_pitch);
+}
 
 __global__ void __launch_bounds__(256) k_pyr_stage(StageArgs a) {
     int bid = blockIdx.x;
@@ -482,6 +605,39 @@ static int stage_args(const alva_pyramid *p, int l, StageArgs &a) {  // returns 
     return a.scharr_blocks + down_blocks;
 }
 
+// Is the frame in device memory?  Asked per ALLOCATION, not per call: the answers are kept for the few allocations a process hands in
+// (a ring of frames inside one tensor, the wrapper's frame buffer).  A stale answer (an address range freed and handed out again as host
+// memory) costs speed, not correctness: both paths read the frame through the same pointer.
+static bool frame_in_device_memory(const void *p) {
+    struct Range {
+        uintptr_t lo, hi;
+        bool device;
+    };
+    static thread_local Range known[8];
+    static thread_local int n_known = 0, next = 0;
+    const uintptr_t a = (uintptr_t) p;
+    for (int i = 0; i < n_known; i++)
+        if (a >= known[i].lo && a < known[i].hi) return known[i].device;
+    hipPointerAttribute_t at{};
+    bool device = false;
+    uintptr_t lo = a, hi = a + 1;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) {
+        device = at.type == hipMemoryTypeDevice;
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (device && hipMemGetAddressRange(&base, &size, (hipDeviceptr_t) p) == hipSuccess && size) {
+            lo = (uintptr_t) base;
+            hi = lo + size;
+        }
+    } else {
+        (void) hipGetLastError();   // (an ordinary host pointer: not ours to launch on either way; the kernel's own error will say so)
+    }
+    known[next] = Range{lo, hi, device};
+    next = (next + 1) % 8;
+    if (n_known < 8) n_known++;
+    return device;
+}
+
 // lane_ok: level 0 was deposited on the lane too (a level 0 launched directly runs on the context's own stream: the rest must follow it there)
 static int build_rest(alva_ctx *ctx, alva_pyramid *p, bool lane_ok = false) {
     static const bool staged = getenv("ALVA_PYRAMID_STAGES") != nullptr;   // A/B: the chain of stage launches instead of the fused one
@@ -497,6 +653,7 @@ static int build_rest(alva_ctx *ctx, alva_pyramid *p, bool lane_ok = false) {
             A.lv[l] = RestLevel{L.gray, L.gray_pitch, L.deriv, L.deriv_pitch, L.w, L.h};
             if (l >= 1) {
                 A.first[l] = blocks;
+                A.ts[l] = rest_tile(l);
                 A.bx[l] = alva_divup(L.w, rest_tile(l));
                 const int tiles = A.bx[l] * alva_divup(L.h, rest_tile(l));
                 A.ntiles[l] = tiles;
@@ -535,6 +692,38 @@ extern "C" int alva_pyramid_build_from_rgba(alva_ctx *ctx, alva_pyramid *pyr, co
     ALVA_ARG(rgba_pitch >= (size_t) L.w * 4);
     if (d_gray_out) ALVA_ARG(gray_out_pitch % 4 == 0 && gray_out_pitch >= (size_t) L.w && ((uintptr_t) d_gray_out % 4) == 0);
     dim3 block(64, 4), grid(alva_divup(L.w, 256), alva_divup(L.h, 4));
+    // one launch for the whole pyramid (k_pyr_all) when the frame is in DEVICE memory -- its workgroups read the frame ~7 times, which is
+    // free out of L2 and ruinous over the bus (a registered host frame buffer) -- and the launch is this session's own (not a lane's)
+    static const bool two_launches = getenv("ALVA_PYRAMID_TWO_LAUNCHES") != nullptr || getenv("ALVA_PYRAMID_STAGES") != nullptr;   // A/B
+    if (!two_launches && !g_alva_lane && pyr->nlevels >= 2 && pyr->nlevels <= 4 && pyr->win >= 3 && L.w >= 8 && L.h >= 2 &&
+        frame_in_device_memory(d_rgba)) {
+        AllArgs A{};
+        A.R.nlevels = pyr->nlevels;
+        A.R.win = pyr->win;
+        A.rgba = d_rgba;
+        A.rgba_pitch = rgba_pitch;
+        A.gray_out = d_gray_out;
+        A.gray_out_pitch = gray_out_pitch;
+        int blocks = 0;
+        for (int l = 0; l < pyr->nlevels; l++) {
+            const alva_level &V = pyr->lv[l];
+            A.R.lv[l] = RestLevel{V.gray, V.gray_pitch, V.deriv, V.deriv_pitch, V.w, V.h};
+        }
+        for (int l = pyr->nlevels - 1; l >= 1; l--) {
+            const alva_level &V = pyr->lv[l];
+            A.R.first[l] = blocks;
+            A.R.ts[l] = all_tile(l, (size_t) L.w * (size_t) L.h);
+            A.R.bx[l] = alva_divup(V.w, A.R.ts[l]);
+            A.R.ntiles[l] = A.R.bx[l] * alva_divup(V.h, A.R.ts[l]);
+            blocks += 8 * alva_divup(A.R.ntiles[l], 8);
+        }
+        A.l0_first = blocks;
+        A.l0_bx = alva_divup(L.w, L0_TW);
+        blocks += A.l0_bx * alva_divup(L.h, L0_TH);
+        hipLaunchKernelGGL(k_pyr_all, dim3(blocks), block, 0, ctx->stream, A);
+        ALVA_LAUNCH_CHECK();
+        return ALVA_OK;
+    }
     const Level0Args LA{d_rgba, rgba_pitch, L.w, L.h, pyr->win, (int) grid.x, L.gray, L.gray_pitch, d_gray_out, gray_out_pitch};
     if (alva_lane_defer(MK_LEVEL0, ctx, grid.x * grid.y, 0, &LA, sizeof(LA))) return build_rest(ctx, pyr, true);
     hipLaunchKernelGGL(k_level0<true>, grid, block, 0, ctx->stream, d_rgba, rgba_pitch, L.w, L.h, pyr->win, L.gray, L.gray_pitch,

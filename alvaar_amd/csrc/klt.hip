@@ -533,6 +533,32 @@ __device__ __forceinline__ void track_stage_in_body(const TrackSlots &D, const i
 __global__ void __launch_bounds__(256) k_track_stage_in(TrackSlots D) { track_stage_in_body(D, (int) blockIdx.x); }
 ALVA_MULTI_KERNEL(MK_STAGE_IN, k_track_stage_in_multi, TrackSlots, dim3(256), 256, track_stage_in_body(A, bx));
 
+// the slot's row of the frame's table: written by the host (or staged by k_track_stage_in), or CARRIED from the previous frame's buffers
+// through the host's index (track_slots.hpp) -- then `writer` (one lane of the slot) also writes the row into this frame's table
+__device__ __forceinline__ void track_slot_load(const TrackSlots &D, const int i, const bool writer, float &px, float &py, int &is3, double (&X)[3]) {
+    if (D.carry) {
+        const size_t s = (size_t) D.carry[i];
+        px = D.p_px[2 * s]; py = D.p_px[2 * s + 1];
+        is3 = D.p_is3d[s];
+        X[0] = X[1] = X[2] = 0.;
+        if (is3) {
+            X[0] = D.p_wpt[3 * s]; X[1] = D.p_wpt[3 * s + 1]; X[2] = D.p_wpt[3 * s + 2];
+        }
+        if (writer) {
+            D.d_pts[2 * (size_t) i] = px; D.d_pts[2 * (size_t) i + 1] = py;
+            D.d_is3d[i] = (uint8_t) is3;
+            D.d_wpt[3 * (size_t) i] = X[0]; D.d_wpt[3 * (size_t) i + 1] = X[1]; D.d_wpt[3 * (size_t) i + 2] = X[2];
+        }
+        return;
+    }
+    px = D.d_pts[2 * i]; py = D.d_pts[2 * i + 1];
+    is3 = D.d_is3d[i];
+    X[0] = X[1] = X[2] = 0.;
+    if (is3) {
+        X[0] = D.d_wpt[3 * (size_t) i]; X[1] = D.d_wpt[3 * (size_t) i + 1]; X[2] = D.d_wpt[3 * (size_t) i + 2];
+    }
+}
+
 // gx = the launch's workgroups (a multiple of 8), bx = this one: slot i = the XCD-contiguous order of k_klt
 __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, const TrackSlots &D, const int maxLevelPrior, const int maxLevelFull,
                                                const int maxCount, const double epsilon, const float errThresh, const float fbDist, const int bx,
@@ -546,12 +572,10 @@ __device__ __forceinline__ void track_klt_body(const LkPyr &P, const LkPyr &C, c
     const int per = gx >> 3;
     const int i = (bx & 7) * per + (bx >> 3);
     if (i >= D.n) return;
-    const float px = D.d_pts[2 * i], py = D.d_pts[2 * i + 1];
-    const int is3 = D.d_is3d[i];
-    double X[3] = {0., 0., 0.};
-    if (is3) {
-        X[0] = D.d_wpt[3 * (size_t) i]; X[1] = D.d_wpt[3 * (size_t) i + 1]; X[2] = D.d_wpt[3 * (size_t) i + 2];
-    }
+    float px, py;
+    int is3;
+    double X[3];
+    track_slot_load(D, i, threadIdx.x == 0, px, py, is3, X);
     bool from_prior = false;
     float nx = px, ny = py;
     if (D.use_prior && is3) {  // visual_frontend.cpp:125-152: project under the predicted pose, keep it if it is inside the image
@@ -1211,12 +1235,13 @@ __device__ __forceinline__ void track_klt_w_body(const LkPyr &P, const LkPyr &C,
     const bool has = grp < NG && i < D.n;
     const bool leader = has && (int) threadIdx.x == grp * GL;
     const int ic = has ? i : D.n - 1;
-    const float px = D.d_pts[2 * ic], py = D.d_pts[2 * ic + 1];
-    const int is3 = D.d_is3d[ic];
+    float px, py;
+    int is3;
+    double X[3];
+    track_slot_load(D, ic, leader, px, py, is3, X);
     bool from_prior = false;
     float nx = px, ny = py;
     if (D.use_prior && is3) {  // visual_frontend.cpp:125-152: project under the predicted pose, keep it if it is inside the image
-        const double X[3] = {D.d_wpt[3 * (size_t) ic], D.d_wpt[3 * (size_t) ic + 1], D.d_wpt[3 * (size_t) ic + 2]};
         double pc[3];
         float qu, qv;
         alva_se3_apply_dev(D.q, D.t, X, pc);

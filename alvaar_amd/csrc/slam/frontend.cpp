@@ -46,9 +46,12 @@ Slam::Slam(Stages *stages, const Camera &c, const Settings &s) : st(stages), cam
     ba_arena_.assign((size_t) 4 << 20, 0);   // local_ba's arena, touched now rather than inside the first keyframe that optimises
     const char *chk = std::getenv("ALVA_CHECK_OBS_MIRROR");
     check_obs_mirror_ = chk && chk[0] == '1';
+    const char *chk_carry = std::getenv("ALVA_CHECK_CARRY");
+    check_carry_ = chk_carry && chk_carry[0] == '1';
 }
 
 void Slam::reset() {  // System::reset (system.cpp:42-55)
+    slots_dirty_ = true;
     cur->reset();
     // VisualFrontend::reset (visual_frontend.cpp:716-727): images, pyramids, the failure counter -- p3pReq_ and the motion model stay
     st->reset_images();
@@ -96,6 +99,7 @@ bool Slam::track(const uint8_t *rgba, double timestamp, bool frame_on_device) { 
         }
     }
     const bool kf_required = process(timestamp);
+    if (kf_required || reset_requested || !ready_for_init) slots_dirty_ = true;   // (the keyframe steps below add keypoints, move world points, ...)
     if (err_) return false;
     if (kf_required) {
         {
@@ -192,54 +196,142 @@ void Slam::klt_from_motion_prior() {
         t0 = t1;
     };
     const int n = (int) cur->kps.size();
-    job_ids_.resize((size_t) n);
-    job_is3d_.resize((size_t) n);
+    const FlatHash<FlatNoValue> &order = cur->kps.ids;
+    // ---- the carried table: nothing but removals since the previous tracking step => per slot, the slot it was (slam.hpp) ----------------
+    uint16_t *carry = nullptr;
+    // (only on the path that solves the pose behind the tracker with P3P: the composed step of the other configurations reads the table)
+    if (!slots_dirty_ && carry_frame_ == cur.get() && carry_table_edits_ == cur->table_edits && carry_mp_edits_ == mp_edits_ && n > 0 &&
+        n <= carry_n_prev_ && ready_for_init && (p3p_req || cfg.p3p_enabled))
+        carry = st->track_carry_buffer(carry_n_prev_, n);
     float *jpx = nullptr;
     uint8_t *j3d = nullptr;
     double *jw = nullptr;
-    if (!st->track_slot_buffers(n, &jpx, &j3d, &jw)) {
-        job_px_.resize((size_t) n * 2);
-        job_stage3d_.resize((size_t) n);
-        job_wpt_.resize((size_t) n * 3);
-        jpx = job_px_.data();
-        j3d = job_stage3d_.data();
-        jw = job_wpt_.data();
+    const bool assemble = !carry || check_carry_;
+    if (carry) {
+        job_ids_prev_.swap(job_ids_);
+        job_is3d_prev_.swap(job_is3d_);
+        job_slots_prev_.swap(job_slots_);
     }
-    int i = 0;
-    job_slots_.resize((size_t) n);
-    const FlatHash<FlatNoValue> &order = cur->kps.ids;
-    for (int sl = order.first(); sl != FlatHash<FlatNoValue>::END; sl = order.next(sl)) {
-        const KeyPt &k = cur->kps.kp[(size_t) sl];
-        job_slots_[(size_t) i] = sl;   // the table slot of tracking slot i: the results are written back without a look-up by id
-        job_ids_[(size_t) i] = k.id;
-        jpx[2 * (size_t) i] = k.px[0];
-        jpx[2 * (size_t) i + 1] = k.px[1];
-        const uint8_t is3d = order.tag(sl) != 0;   // the table's tag IS the 3-D flag (KpTable): the flag inside the 80-byte record sits on its second cache line
-        j3d[(size_t) i] = is3d;
-        job_is3d_[(size_t) i] = is3d;
-        i++;
-    }
-    // the 3-D keypoints' world points: one map point per keypoint, each behind a pointer table -- a second pass so that the objects of
-    // the next iterations can be requested ahead (this loop runs with the GPU idle, at the head of the frame's critical path)
-    for (int s = 0; s < n; s++) {
-        if (s + 16 < n && job_is3d_[(size_t) s + 16]) {
-            const MpRec *f = rec_raw(job_ids_[(size_t) s + 16]);
-            if (f) __builtin_prefetch(f);
+    job_ids_.resize((size_t) n + 1);     // (+ 1: the compaction below stores before it knows whether the row stays)
+    job_is3d_.resize((size_t) n + 1);
+    job_slots_.resize((size_t) n + 1);
+    if (carry) {
+        // The table's iteration order is the previous frame's with the erased slots taken out (an erase unlinks one node, nothing moves), so
+        // the previous frame's slot LIST is walked -- an array, no pointer chain through the table -- and the rows whose slot is still
+        // live are kept, without a branch.
+        const int np = carry_n_prev_;
+        const int *pid = job_ids_prev_.data(), *psl = job_slots_prev_.data();
+        const uint8_t *p3 = job_is3d_prev_.data();
+        int *oid = job_ids_.data(), *osl = job_slots_.data();
+        uint8_t *o3 = job_is3d_.data();
+        int i = 0;
+        for (int ip = 0; ip < np; ip++) {
+            const int sl = psl[(size_t) ip];
+            if (i > n) break;   // (more live slots than keypoints: cannot happen; caught below)
+            carry[(size_t) i] = (uint16_t) ip;   // (i <= n < the buffer's capacity, track_carry_buffer)
+            osl[(size_t) i] = sl;
+            oid[(size_t) i] = pid[(size_t) ip];
+            o3[(size_t) i] = p3[(size_t) ip];
+            i += order.slot_live((size_t) sl) ? 1 : 0;
         }
-        double *w = jw + 3 * (size_t) s;
-        if (job_is3d_[(size_t) s]) {
-            const MpRec *mp = rec_raw(job_ids_[(size_t) s]);
-            if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() throws in the reference (:131) if the map lost it
-            std::memcpy(w, mp->X, 24);
+        if (i != n) {
+            std::fprintf(stderr, "alva_slam: carried slot table: %d live slots of the previous frame's %d, %d keypoints\n", i, np, n);
+            std::abort();
+        }
+        t_fine[29] += 1.;   // #frames with a carried slot table
+    }
+    if (assemble) {
+        // (ALVA_CHECK_CARRY=1: the table in host memory -- compared and kept below, copied to the implementation's buffers when it is the one
+        // that counts; the implementation's buffers are device memory behind the bus: never read)
+        if (check_carry_ || !st->track_slot_buffers(n, &jpx, &j3d, &jw)) {
+            job_px_.resize((size_t) n * 2);
+            job_stage3d_.resize((size_t) n);
+            job_wpt_.resize((size_t) n * 3);
+            jpx = job_px_.data();
+            j3d = job_stage3d_.data();
+            jw = job_wpt_.data();
+        }
+        int i = 0;
+        for (int sl = order.first(); sl != FlatHash<FlatNoValue>::END; sl = order.next(sl)) {
+            const KeyPt &k = cur->kps.kp[(size_t) sl];
+            const uint8_t is3d = order.tag(sl) != 0;   // the table's tag IS the 3-D flag (KpTable): the flag inside the 80-byte record sits on its second cache line
+            if (carry) {
+                if (job_slots_[(size_t) i] != sl || job_ids_[(size_t) i] != k.id || job_is3d_[(size_t) i] != is3d) {
+                    std::fprintf(stderr, "alva_slam: carried slot table out of sync (slot %d: id %d / %d, 3-D %d / %d)\n", i, job_ids_[(size_t) i], k.id,
+                                 (int) job_is3d_[(size_t) i], (int) is3d);
+                    std::abort();
+                }
+            } else {
+                job_slots_[(size_t) i] = sl;   // the table slot of tracking slot i: the results are written back without a look-up by id
+                job_ids_[(size_t) i] = k.id;
+                job_is3d_[(size_t) i] = is3d;
+            }
+            jpx[2 * (size_t) i] = k.px[0];
+            jpx[2 * (size_t) i + 1] = k.px[1];
+            j3d[(size_t) i] = is3d;
+            i++;
+        }
+        // the 3-D keypoints' world points: one map point per keypoint, each behind a pointer table -- a second pass so that the objects of
+        // the next iterations can be requested ahead (this loop runs with the GPU idle, at the head of the frame's critical path)
+        for (int s = 0; s < n; s++) {
+            if (s + 16 < n && job_is3d_[(size_t) s + 16]) {
+                const MpRec *f = rec_raw(job_ids_[(size_t) s + 16]);
+                if (f) __builtin_prefetch(f);
+            }
+            double *w = jw + 3 * (size_t) s;
+            if (job_is3d_[(size_t) s]) {
+                const MpRec *mp = rec_raw(job_ids_[(size_t) s]);
+                if (!mp) throw std::out_of_range("map point");   // mapMapPoints_.at() throws in the reference (:131) if the map lost it
+                std::memcpy(w, mp->X, 24);
+            } else {
+                w[0] = w[1] = w[2] = 0.;
+            }
+        }
+        if (!carry) t_fine[30] += 1.;   // #frames with an assembled one
+    }
+    if (check_carry_) {
+        // the carried table is: positions = the previous step's tracked positions (still in its result buffers), flags and world points =
+        // the previous table's; compared here against the table assembled from the map, then kept as the next frame's "previous"
+        if (carry) {
+            const TrackKlt &pr = klt_out_;
+            for (int i = 0; i < n; i++) {
+                const size_t ip = (size_t) carry[(size_t) i];
+                const bool same = std::memcmp(&jpx[2 * (size_t) i], &pr.px_v[2 * ip], 8) == 0 && j3d[(size_t) i] == chk_is3d_[ip] &&
+                                  std::memcmp(&jw[3 * (size_t) i], &chk_wpt_[3 * ip], 24) == 0;
+                if (!same) {
+                    std::fprintf(stderr, "alva_slam: carried slot table differs from the assembled one (slot %d <- %d)\n", i, (int) ip);
+                    std::abort();
+                }
+            }
+        }
+        chk_px_.assign(jpx, jpx + 2 * (size_t) n);
+        chk_is3d_.assign(j3d, j3d + (size_t) n);
+        chk_wpt_.assign(jw, jw + 3 * (size_t) n);
+        if (carry) {   // what the stage is handed in carried mode: its own table pointers are not needed
+            jpx = nullptr; j3d = nullptr; jw = nullptr;
         } else {
-            w[0] = w[1] = w[2] = 0.;
+            float *bpx = nullptr;
+            uint8_t *b3d = nullptr;
+            double *bw = nullptr;
+            if (st->track_slot_buffers(n, &bpx, &b3d, &bw)) {
+                std::memcpy(bpx, jpx, 8 * (size_t) n);
+                std::memcpy(b3d, j3d, (size_t) n);
+                std::memcpy(bw, jw, 24 * (size_t) n);
+                jpx = bpx; j3d = b3d; jw = bw;
+            }
         }
     }
+    carry_frame_ = cur.get();
+    carry_table_edits_ = cur->table_edits;
+    carry_mp_edits_ = mp_edits_;
+    carry_n_prev_ = n;
+    slots_dirty_ = false;
     TrackJob job;
     job.n = n;
     job.px = jpx;
     job.is3d = j3d;
     job.wpt = jw;
+    job.carry = carry;
     std::memcpy(job.Tcw_q, cur->Tcw.q, 32);
     std::memcpy(job.Tcw_t, cur->Tcw.t, 24);
     se3_to_pose7(cur->Twc, job.pose7_pred);
@@ -312,6 +404,8 @@ bool Slam::compute_pose() {
 void Slam::reset_frame() {  // visual_frontend.cpp:700-714
     const KpTable copy = cur->kps;
     for (const auto &e: copy) remove_obs_from_cur(e.first);
+    slots_dirty_ = true;
+    cur->table_edits++;
     cur->kps.clear();
     cur->note_inserted();
     cur->grid.clear();

@@ -73,6 +73,7 @@ const KeyPt *FrameRec::find(int id_) const { return kps.find_ptr(id_); }
 
 void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
     if (!kps.emplace(k)) return;
+    table_edits++;
     note_inserted();
     grid_add(k);
     n_kps++;
@@ -83,6 +84,7 @@ void FrameRec::add(const KeyPt &k) {  // frame.cpp:124-143
 void FrameRec::update(int id_, const float *px, const float *unpx, const double *bv) {  // frame.cpp:160-174
     KeyPt *cur_kp = kps.find_ptr(id_);
     if (!cur_kp) return;
+    table_edits++;
     update_kp(*cur_kp, px, unpx, bv);
 }
 
@@ -133,6 +135,7 @@ void FrameRec::turn3d(int id_) {  // :234-248
     if (!k) return;
     if (!k->is3d) {
         kps.set_3d(id_);
+        table_edits++;
         ids3d_valid_ = false;
         n_3d++;
         n_2d--;
@@ -188,6 +191,7 @@ void FrameRec::reset() {  // :467-489
     kfid = 0;
     timestamp = 0.;
     kps.clear();
+    table_edits++;
     note_inserted();
     grid.clear();
     grid.resize(grid_cells);
@@ -550,6 +554,7 @@ void Slam::add_map_point(const Desc *d) {  // map_manager.cpp:254-327
 void Slam::update_map_point(int id, const double *wpt, double anchor_inv_depth) {  // map_manager.cpp:366-426
     MpRec *rec = rec_raw(id);   // the flat mirror of mapMapPoints_ (same membership); the record alone in the common case
     if (!rec) return;
+    mp_edits_++;   // (a world point moves: no carried slot table across this, frontend.cpp)
     if (rec->is3d) {
         rec->X[0] = wpt[0]; rec->X[1] = wpt[1]; rec->X[2] = wpt[2];
         if (anchor_inv_depth >= 0.) rec->inv_depth = anchor_inv_depth;

@@ -226,6 +226,9 @@ struct FrameRec {
         if (order_valid_ && (size_t) sl < pos_of_slot_.size()) order_[(size_t) pos_of_slot_[(size_t) sl]] = -1;
     }
     void note_inserted() { ids3d_valid_ = order_valid_ = false; }
+    // edits of the keypoint table other than removals and the tracker's own position updates (add, change_id, turn3d, update by id, clear):
+    // a frame whose count did not move since the previous tracking step can have its slot table carried (Slam::klt_from_motion_prior)
+    uint32_t table_edits = 0;
     // The same lists for SEVERAL keyframes, the stale ones rebuilt together: one order walk is a chain of dependent loads (≈ an L2 latency
     // per keypoint), and the loops above walk a dozen keyframes.  Eight chains advance in turn here, so eight loads are in flight instead
     // of one; keyframes whose order still stands only run the sequential pass.
@@ -538,6 +541,20 @@ private:
     std::vector<float> job_px_;
     std::vector<uint8_t> job_is3d_, job_stage3d_;
     std::vector<double> job_wpt_;
+    // The CARRIED slot table (Stages::track_carry_buffer): between two keyframes the frame's table only loses rows, and what is left is the
+    // previous frame's -- tracked positions, unchanged flags and world points -- so the walk over the keypoints and their map points is
+    // replaced by one over the table's order that names, per slot, the slot it was.  Valid while nothing but removals touched the frame
+    // (FrameRec::table_edits), no map point moved or went (mp_edits_) and the frame object is the same.
+    std::vector<int> job_slots_prev_, job_ids_prev_;   // the previous frame's table slots (in its slot order) | ids
+    std::vector<uint8_t> job_is3d_prev_;
+    const FrameRec *carry_frame_ = nullptr;
+    uint32_t carry_table_edits_ = 0, carry_mp_edits_ = 0, mp_edits_ = 0;
+    int carry_n_prev_ = -1;
+    bool slots_dirty_ = true;
+    bool check_carry_ = false;    // ALVA_CHECK_CARRY=1: every carried table against the assembled one (host side), abort on a difference
+    std::vector<float> chk_px_;
+    std::vector<uint8_t> chk_is3d_;
+    std::vector<double> chk_wpt_;
     TrackKlt klt_out_;
     TrackPose pose_out_;
     bool pose_do_p3p_ = true;

@@ -36,6 +36,9 @@ struct TrackJob {
     int want_pose = 0;                // map initialised: solve the pose behind the tracker
     int do_p3p = 1;                   // p3pReq_ || p3pEnabled_
     int do_random = 1;                // multiViewRandomEnabled_
+    // null, or the buffer track_carry_buffer handed out, filled: slot i of this frame was slot carry[i] of the PREVIOUS track_begin -- the
+    // implementation still holds that frame's table and tracked positions and builds this one from them; px / is3d / wpt are not read
+    const uint16_t *carry = nullptr;
 };
 // after the tracker: per slot  code 0 = lost, 1 = tracked from its projected prior on one level, 2 = tracked on the full pyramid,
 // 3 = tracked on the full pyramid after failing with the prior; px / unpx / bv valid where code != 0
@@ -88,6 +91,11 @@ struct Stages {
     // Where the map layer may assemble the slot table of the next track_begin (positions, 3-D flags, world points; capacity n):
     // an implementation that stages its inputs anyway hands out that staging, so the table is written once.  false = none.
     virtual bool track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) { (void) n; (void) px; (void) is3d; (void) wpt; return false; }
+    // The slot table of a frame that only LOST slots since the previous track_begin (no keyframe, no reset in between: positions are that
+    // frame's tracked positions, flags and world points unchanged) need not be assembled at all: the caller names, per slot, the slot it
+    // was (n indices into the previous frame's n_prev slots).  Non-null = the implementation can do that for the next track_begin (it
+    // still has the previous frame's table); null = assemble the table.
+    virtual uint16_t *track_carry_buffer(int n_prev, int n) { (void) n_prev; (void) n; return nullptr; }
 
     // System::findCameraPose's cvtColor(RGBA2GRAY) (system.cpp:111-112) + VisualFrontend::preprocessImage
     // (visual_frontend.cpp:672-698): the current image / pyramid become the previous ones, the new frame's gray image

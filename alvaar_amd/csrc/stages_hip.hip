@@ -327,15 +327,22 @@ struct HipStages::Impl {
         uint8_t *is3d;
         double *wpt;
     };
-    TrackIn track_in() const {
+    // TWO tables (round 6): a frame's table is either written by the host or built by the tracker from the previous frame's (the carried
+    // table, track_slots.hpp), so consecutive frames alternate between them; behind the tables the carry index the host writes instead.
+    static size_t track_in_bytes(size_t c) { return c * 8 + c + 256 + c * 24; }
+    TrackIn track_in(int par) const {
         const size_t c = (size_t) trk_cap;
         TrackIn T;
-        uint8_t *b = trk_in;
+        uint8_t *b = trk_in + (size_t) (par & 1) * track_in_bytes(c);
         T.px = (float *) b; b += c * 8;
         T.is3d = b; b += c + 256 - (c & 255);
         T.wpt = (double *) b;
         return T;
     }
+    uint16_t *track_carry() const { return (uint16_t *) (trk_in + 2 * track_in_bytes((size_t) trk_cap)); }
+    int trk_par = 0;         // the table (and d_px buffer) of the LAST tracker launch; the next one takes the other
+    int trk_valid_n = -1;    // slots of that launch if its table + tracked positions are complete on the device (a carried table may follow), else -1
+    bool carry_ok = true;    // ALVA_NO_CARRY=1: every frame's table assembled by the host (A/B)
     int trk_cap = 0;
     bool fused = true;       // ALVA_TRACK_UNFUSED=1: compose the tracking step from the fine-grained stages instead (A/B testing)
     bool poll = true;        // wait for the tracking step by polling its completion word in pinned memory (ALVA_NO_POLL=1: stream synchronisation)
@@ -371,7 +378,7 @@ struct HipStages::Impl {
         const size_t c = (size_t) cap;
         // device: cnt | slotA slotB | ptsA priorA outA ptsB priorB outB | stA stB is3d code | wpt | px | Pbv Puv Pwpt  (the list form; the
         // slot-wise form needs less)
-        const size_t dev_bytes = 1024 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64;
+        const size_t dev_bytes = 1024 + c * 8 + c * 48 + c * 4 + 256 + c * 24 + c * 8 + c * 64 + c * 8 + 256;   // (+ the second d_px of the slot-wise form)
         const size_t pin_bytes = c * 8 + c + 64 + c * 24 + 256 + c + 64 + c * 16 + c * 24 + 256;
         int rc = trk_dev.grow(dev_bytes, st);
         if (rc) return rc;
@@ -382,13 +389,14 @@ struct HipStages::Impl {
         // posted), so the map layer assembles the table where the tracker reads it and the copy kernel of rounds 2 - 4 (k_track_stage_in:
         // 7 us + a launch gap in front of every frame's tracker) is gone.  Fine-grained memory (bar_alloc_flag): an L2 must not answer with
         // last frame's line.  The host never READS this memory (a load over the bus costs ~1 us).
+        trk_valid_n = -1;   // (the buffers move)
         if (trk_in) {
             ALVA_HIP(alva_stream_sync(st));
             ALVA_HIP(hipFree(trk_in));
             trk_in = nullptr;
         }
         if (bar_table) {
-            const size_t in_bytes = c * 8 + c + 256 + c * 24;
+            const size_t in_bytes = 2 * track_in_bytes(c) + c * 2 + 256;
             if (hipExtMallocWithFlags((void **) &trk_in, in_bytes, bar_alloc_flag()) != hipSuccess) {
                 (void) hipGetLastError();
                 trk_in = nullptr;
@@ -503,6 +511,7 @@ int HipStages::init(int device, const Camera &cam, bool clahe, const double *inv
     m->poll = getenv("ALVA_NO_POLL") == nullptr;
     // the slot table in host-written device memory (track_reserve): ALVA_NO_BAR_TABLE=1 keeps the pinned table + k_track_stage_in (A/B)
     m->bar_table = getenv("ALVA_NO_BAR_TABLE") == nullptr && Impl::host_can_store_to_device_memory(m->device);
+    m->carry_ok = getenv("ALVA_NO_CARRY") == nullptr;
     int rc = hip_stream ? alva_ctx_create(device, hip_stream, 0, &m->ctx) : alva_ctx_create(device, nullptr, 1, &m->ctx);
     if (rc) return rc;
     m->st = (hipStream_t) alva_ctx_stream(m->ctx);
@@ -867,7 +876,12 @@ void HipStages::reset_images() {}  // the pyramids are rebuilt before they are r
 // by the kernels themselves: no copy commands.
 int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     if (!m->fused || (job.want_pose && !job.do_p3p)) {
-        if (m->trk_in && job.n > 0 && job.px == m->track_in().px) {
+        m->trk_valid_n = -1;
+        if (job.carry) {
+            alva_set_error("tracking step: a carried slot table on the composed path");
+            return ALVA_ERR_STATE;
+        }
+        if (m->trk_in && job.n > 0 && job.px == m->track_in(m->trk_par ^ 1).px) {
             // the composed step READS the slot table on the host, and this one was written into device memory (track_slot_buffers): one
             // copy back instead of a load over the bus per element (p3pEnabled_ off: not the shipped configuration)
             static thread_local std::vector<uint8_t> back;
@@ -894,6 +908,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     out.bv_v = nullptr;
     out.p3p_req = 0;
     out.n_pose = 0;
+    const int n_prev = m->trk_valid_n;
+    m->trk_valid_n = -1;   // (set again at the end of a launch that leaves a complete table behind)
     if (n == 0) return ALVA_OK;
     ALVA_HIP(hipSetDevice(m->device));
     int rc = m->track_reserve(n);
@@ -901,8 +917,15 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
     const size_t c = (size_t) m->trk_cap;
     const alva_pyramid *prev = m->pyr[m->prev], *cur = m->pyr[m->cur];
     const Camera &k = m->cam;
-    const bool in_device = m->bar_table && m->trk_in && !m->lists && job.px == m->track_in().px && job.is3d == m->track_in().is3d &&
-                           job.wpt == m->track_in().wpt;   // track_slot_buffers handed out the device table: it is written, never read here
+    const int par = m->trk_par ^ 1;   // this frame's table and d_px
+    // the table carried from the previous frame (track_carry_buffer said yes and the map layer filled the index): nothing to read on the host
+    const bool carried = job.carry && m->bar_table && m->trk_in && !m->lists && job.carry == m->track_carry() && n_prev >= n && !g_alva_lane;
+    if (job.carry && !carried) {
+        alva_set_error("tracking step: a carried slot table without a previous frame's table to carry it from");
+        return ALVA_ERR_STATE;
+    }
+    const bool in_device = carried || (m->bar_table && m->trk_in && !m->lists && job.px == m->track_in(par).px && job.is3d == m->track_in(par).is3d &&
+                                       job.wpt == m->track_in(par).wpt);   // track_slot_buffers handed out the device table: it is written, never read here
     int n3d = 0;
     if (!in_device)
         for (int i = 0; i < n; i++) n3d += job.is3d[i] ? 1 : 0;
@@ -938,11 +961,22 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         D.Pbv = (double *) b; b += c * 24;
         D.Puv = (double *) b; b += c * 16;
         D.Pwpt = (double *) b; b += c * 24;
+        b += 256 - ((uintptr_t) b & 255);
+        float *d_px_alt = (float *) b; b += c * 8;
+        float *const d_px2[2] = {D.d_px, d_px_alt};   // the tracked positions of consecutive frames alternate (a carried table reads the previous frame's)
+        D.d_px = d_px2[par];
         D.in_px = pin.in_px; D.in_is3d = pin.in_is3d; D.in_wpt = pin.in_wpt;
         if (in_device) {   // the table is where the tracker reads it: no copy kernel (in_px == nullptr tells alva_track_slots_klt)
-            const Impl::TrackIn T = m->track_in();
+            const Impl::TrackIn T = m->track_in(par);
             D.d_pts = T.px; D.d_is3d = T.is3d; D.d_wpt = T.wpt;
             D.in_px = nullptr; D.in_is3d = nullptr; D.in_wpt = nullptr;
+        }
+        if (carried) {
+            const Impl::TrackIn Tp = m->track_in(par ^ 1);
+            D.carry = m->track_carry();
+            D.p_px = d_px2[par ^ 1];
+            D.p_is3d = Tp.is3d;
+            D.p_wpt = Tp.wpt;
         }
         D.o_hdr = pin.o_hdr; D.o_code = pin.o_code; D.o_px = pin.o_px; D.o_unpx = pin.o_unpx; D.o_bv = pin.o_bv;
         D.n = n;
@@ -971,6 +1005,10 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
         } else if (!alva_lane_defer(MK_TRACK_COMPACT, m->ctx, (unsigned) compact_grid(D.n), 0, &D, sizeof(D))) {
             hipLaunchKernelGGL(k_track_compact, dim3(compact_grid(D.n)), dim3(CMP_NT), 0, m->st, D);
             ALVA_LAUNCH_CHECK();
+        }
+        if (in_device) {   // this frame's table and (once the launch is through) its tracked positions are complete on the device
+            m->trk_par = par;
+            m->trk_valid_n = n;
         }
         poll_seq = m->poll ? D.seq : 0;
         slots_D = D;
@@ -1143,8 +1181,8 @@ int HipStages::track_begin(const TrackJob &job, TrackKlt &out) {
 bool HipStages::track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) {
     if (!m->fused || n <= 0) return false;
     if (hipSetDevice(m->device) != hipSuccess || m->track_reserve(n) != ALVA_OK) return false;
-    if (m->bar_table && m->trk_in && !m->lists) {   // device memory, written in place (track_reserve)
-        const Impl::TrackIn T = m->track_in();
+    if (m->bar_table && m->trk_in && !m->lists) {   // device memory, written in place (track_reserve): the table the NEXT launch takes
+        const Impl::TrackIn T = m->track_in(m->trk_par ^ 1);
         *px = T.px;
         *is3d = T.is3d;
         *wpt = T.wpt;
@@ -1155,6 +1193,12 @@ bool HipStages::track_slot_buffers(int n, float **px, uint8_t **is3d, double **w
     *is3d = pin.in_is3d;
     *wpt = pin.in_wpt;
     return true;
+}
+
+uint16_t *HipStages::track_carry_buffer(int n_prev, int n) {
+    if (!m->fused || !m->carry_ok || m->lists || !m->bar_table || !m->trk_in || g_alva_lane) return nullptr;
+    if (n <= 0 || n > n_prev || n_prev != m->trk_valid_n || n_prev >= 65536 || n + 1 > m->trk_cap) return nullptr;   // (the caller may write entry n: room for n + 1)
+    return m->track_carry();
 }
 
 int HipStages::track_pose_collect(TrackPose &out) {

@@ -19,6 +19,7 @@ public:
     int track_begin(const TrackJob &job, TrackKlt &out) override;
     int track_pose_collect(TrackPose &out) override;
     bool track_slot_buffers(int n, float **px, uint8_t **is3d, double **wpt) override;
+    uint16_t *track_carry_buffer(int n_prev, int n) override;
     int new_frame(const uint8_t *rgba) override;
     int new_frame_device(const uint8_t *d_rgba) override;
     void hint_next_frame_device(const uint8_t *d_rgba) override;

@@ -49,6 +49,16 @@ struct TrackSlots {
                                // earlier and enqueues the pose solve (sample draw + two launches) while the compaction kernel runs
     double *Pbv, *Puv, *Pwpt;  // device: correspondences of the pose solve
     unsigned long long *dbg;   // null, or the per-slot stamp buffer of ALVA_KLT_STAMPS=1 (microbench.hip)
+    // The table CARRIED from the previous frame (round 6): a frame that only lost slots since the previous tracker launch -- every frame
+    // between two keyframes -- is the previous frame's table without the lost rows, with the tracked positions as the new positions.  All
+    // of that is on the device already: the host names, per slot, the slot it was (carry, 2 bytes per slot in host-written device memory
+    // instead of 33 + the walk over the map points that fetched them), the tracker's workgroup reads its row through that index from the
+    // previous frame's buffers (p_*) and writes it to this frame's (d_pts / d_is3d / d_wpt: what the retry launch, the compaction and the
+    // next frame read).  The two frames' buffers alternate.  null: d_pts / d_is3d / d_wpt were written by the host (or k_track_stage_in).
+    const uint16_t *carry;     // [n]
+    const float *p_px;         // previous frame: d_px
+    const uint8_t *p_is3d;     //                 d_is3d
+    const double *p_wpt;       //                 d_wpt
 };
 
 struct alva_ctx;

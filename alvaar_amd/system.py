@@ -295,7 +295,7 @@ class AlvaAR:
                   "window: remove kf-30", "copy: frame", "copy: order mirror", "copy: observation mirror", "new keypoints + map points",
                   "covis: counts", "covis: local ids", "covis: into local map", "parallax pairs (all frames)", "parallax (all frames)", "parallax sort (all frames)",
                   "#flattened map points", "#flattened observations", "#local candidates", "#BA points", "#BA residual blocks", "#BA keyframes",
-                  "#new keypoints", "#local ids", "#covisible keyframes", "probe 29", "probe 30", "probe 31")   # (29 - 31: scratch for measurements)
+                  "#new keypoints", "#local ids", "#covisible keyframes", "#frames: slot table carried", "#frames: slot table assembled", "probe 31")   # (31: scratch for measurements)
 
     def timing_fine(self, reset: bool = True):
         out = np.zeros(32)

@@ -431,6 +431,8 @@ def main():
         alg = {
             "k_level0<true>": 4 * P + 2 * P,                        # RGBA in; gray copy + padded level 0 out
             "k_pyr_rest": P + (P / 4 + P / 16 + P / 64) + 4 * P * PYR,   # level 0 in; levels 1-3 + every level's Scharr pair out
+            # the two above as ONE launch (round 6): RGBA in; gray copy + padded levels 0-3 + every level's Scharr pair out
+            "k_pyr_all": 4 * P + 2 * P + (P / 4 + P / 16 + P / 64) + 4 * P * PYR,
             # fb-KLT, one launch per frame over every slot: the four levels of BOTH pyramids once (gray u8 + Ix,Iy i16 = 5 B/px per level)
             # + the slot table in (33 B per slot) + per-slot results out (1 + 8 + 8 + 24 B, device memory)
             "k_track_klt": 2 * 5 * P * PYR + 33 * nkp + 41 * nkp,
@@ -447,7 +449,7 @@ def main():
         traffic, l2_hit, pmc_stamp = pmc_reference(hbm_dom, ["alvaar_amd/csrc/klt.hip", "alvaar_amd/csrc/stages_hip.hip", "alvaar_amd/csrc/track_slots.hpp"])
         klt_us_total = kt["k_track_klt"][0] * kt["k_track_klt"][1] if "k_track_klt" in kt else None
         # ---- SURVEY.md 8(d), last table row: the three end-to-end bounds of one frame next to the achieved number
-        chain = ["k_level0<true>", "k_pyr_rest", "k_track_stage_in", "k_track_klt", "k_track_compact", "k_p3p_pnp_s", "k_pose_all", "k_p3p_s", "k_p3p", "k_pnp"]
+        chain = ["k_level0<true>", "k_pyr_rest", "k_pyr_all", "k_track_stage_in", "k_track_klt", "k_track_compact", "k_p3p_pnp_s", "k_pose_all", "k_p3p_s", "k_p3p", "k_pnp"]
         chain_launches = sum(round(kt[k][0] / PROF_STEPS) for k in chain if k in kt)
         chain_kernel_us = sum(per_frame.get(k, 0.0) for k in chain)
         launches_per_frame = sum(v[0] for v in kt.values()) / PROF_STEPS

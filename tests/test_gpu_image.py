@@ -47,20 +47,60 @@ def test_pyramid_bit_exact(ctx, w, h, levels):
     pyr.close()
 
 
-def test_pyramid_from_rgba_fused(ctx):
+@pytest.mark.parametrize("w,h,levels,with_copy", [(640, 480, 3, True), (640, 480, 3, False), (1280, 720, 3, True), (100, 76, 3, True), (52, 44, 3, False),
+                                                  (332, 201, 2, True), (64, 32, 1, True), (68, 33, 1, True), (60, 31, 1, False)])
+def test_pyramid_from_rgba_fused(ctx, w, h, levels, with_copy):
+    """alva_pyramid_build_from_rgba: gray + the whole pyramid from the RGBA frame (k_pyr_all: ONE launch, every role converts its own
+    pixels from the frame) -- the un-padded gray copy, every padded level and every derivative level bit for bit, on sizes whose tiles are
+    cut by the right / bottom edge (100 x 76, 52 x 44, 332 x 201, 68 x 33, 60 x 31), and again over a second frame (stale borders)."""
     import torch
     import alvaar_amd
-    w, h = 640, 480
-    rgba = synth.gray_to_rgba(synth.frame_gray(synth.texture_canvas(w, h), 0, w, h), seed=5)
-    pyr = alvaar_amd.Pyramid(ctx, w, h, 9, 3)
-    gout = torch.empty((h, w), dtype=torch.uint8, device="cuda")
-    pyr.build_from_rgba(torch.from_numpy(rgba).cuda(), gout)
-    gray = Orc.rgba2gray(rgba)
-    assert np.array_equal(gout.cpu().numpy(), gray)
-    og, od = Orc.build_pyramid(gray, 9, 3)
-    for l in range(pyr.num_levels):
-        hg, hd = pyr.download_level(l)
-        assert np.array_equal(hg, og[l]) and np.array_equal(hd, od[l])
+    canvas = synth.texture_canvas(w, h, seed=w + 3 * h)
+    pyr = alvaar_amd.Pyramid(ctx, w, h, 9, levels)
+    for shift, seed in ((0, 5), (7, 6)):
+        rgba = synth.gray_to_rgba(synth.frame_gray(canvas, shift, w, h, noise_seed=seed), seed=seed)
+        gout = torch.zeros((h, w), dtype=torch.uint8, device="cuda") if with_copy else None
+        pyr.build_from_rgba(torch.from_numpy(rgba).cuda(), gout)
+        gray = Orc.rgba2gray(rgba)
+        if with_copy:
+            assert np.array_equal(gout.cpu().numpy(), gray)
+        og, od = Orc.build_pyramid(gray, 9, levels)
+        assert pyr.num_levels == len(og)
+        for l in range(pyr.num_levels):
+            hg, hd = pyr.download_level(l)
+            assert np.array_equal(hg, og[l]), f"gray level {l}"
+            assert np.array_equal(hd, od[l]), f"deriv level {l}"
+    pyr.close()
+
+
+def test_pyramid_one_launch_equals_two(ctx):
+    """the same call with ALVA_PYRAMID_TWO_LAUNCHES=1 (k_level0 + k_pyr_rest) in a child process: identical bytes"""
+    import os, subprocess, sys, hashlib
+    code = ("import hashlib, numpy as np, torch, alvaar_amd\n"
+            "from alvaar_amd import synth\n"
+            "ctx = alvaar_amd.Context(0)\n"
+            "hs = hashlib.sha256()\n"
+            "for w, h in ((640, 480), (100, 76), (1280, 720)):\n"
+            "    rgba = synth.gray_to_rgba(synth.frame_gray(synth.texture_canvas(w, h, seed=9), 2, w, h, noise_seed=4), seed=8)\n"
+            "    pyr = alvaar_amd.Pyramid(ctx, w, h, 9, 3)\n"
+            "    g = torch.zeros((h, w), dtype=torch.uint8, device='cuda')\n"
+            "    pyr.build_from_rgba(torch.from_numpy(rgba).cuda(), g)\n"
+            "    hs.update(g.cpu().numpy().tobytes())\n"
+            "    for l in range(pyr.num_levels):\n"
+            "        a, b = pyr.download_level(l)\n"
+            "        hs.update(a.tobytes()); hs.update(b.tobytes())\n"
+            "print('DIGEST', hs.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for two in (False, True):
+        env = dict(os.environ)
+        env.pop("ALVA_PYRAMID_TWO_LAUNCHES", None)
+        if two:
+            env["ALVA_PYRAMID_TWO_LAUNCHES"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert out[0] == out[1]
 
 
 @pytest.mark.parametrize("nq,nt,seed", [(1, 1, 0), (17, 33, 1), (300, 257, 2), (2120, 2120, 3), (64, 0, 4), (4000, 4000, 5), (4080, 4100, 6)])   # 4000 x 4000 = BASELINE configs[2]

@@ -381,6 +381,47 @@ def test_pose_launch_forms_agree_bitwise(monkeypatch):
             assert np.array_equal(a[6].view(np.uint64), b[6].view(np.uint64)), f"{name}, frame {k}: pose"
 
 
+def test_carried_slot_table_equals_assembled(monkeypatch):
+    """Between two keyframes the tracker's slot table is CARRIED on the device (the host names, per slot, the slot it was; track_slots.hpp)
+    instead of assembled from the map and written over the bus.  Three runs of one stream through initialisation, keyframes and local BA:
+    carried (the default), every frame assembled (ALVA_NO_CARRY=1), and carried with the map layer comparing every carried table against
+    the assembled one (ALVA_CHECK_CARRY=1: positions, flags, world points; it aborts on a difference).  Statuses, states, keypoints
+    and poses equal to the last bit, and the default run did carry most of its frames."""
+    w, h = 640, 480
+    canvas = synth.texture_canvas(w, h, 7)
+    frames = [synth.gray_to_rgba(synth.frame_gray(canvas, k, w, h, noise_seed=11)) for k in range(70)]
+    keys = ("ALVA_NO_CARRY", "ALVA_CHECK_CARRY")
+    runs, carried = [], []
+    for env in ({}, {"ALVA_NO_CARRY": "1"}, {"ALVA_CHECK_CARRY": "1"}):
+        for key in keys:
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        gpu = sysdiff.GpuSystem(w, h, 12)
+        gpu.ar.timing_fine()
+        rec = []
+        for k, f in enumerate(frames):
+            st, p7, p16 = gpu.step(f, 33.0 * k)
+            ids, px, un, i3, hd = gpu.frame_keypoints()
+            rec.append((st, list(gpu.state()), ids.copy(), px.copy(), un.copy(), i3.copy(), p7.copy()))
+        fine = gpu.ar.timing_fine()
+        carried.append((int(fine["#frames: slot table carried"]), int(fine["#frames: slot table assembled"])))
+        assert sum(r[0] == 1 for r in rec) >= 30
+        gpu.close()
+        runs.append(rec)
+    for key in keys:
+        monkeypatch.delenv(key, raising=False)
+    assert carried[0][0] >= 25 and carried[0][1] >= 2, carried     # most tracked frames carried; the frames behind a keyframe assembled
+    assert carried[1][0] == 0, carried
+    assert carried[2][0] == carried[0][0], carried
+    for other, name in zip(runs[1:], ("assembled every frame", "carried + checked")):
+        for k, (a, b) in enumerate(zip(runs[0], other)):
+            assert a[0] == b[0] and a[1] == b[1], f"{name}, frame {k}: status / state"
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[5], b[5]), f"{name}, frame {k}: keypoint ids / flags"
+            assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32)), f"{name}, frame {k}: pixels"
+            assert np.array_equal(a[6].view(np.uint64), b[6].view(np.uint64)), f"{name}, frame {k}: pose"
+
+
 def test_imu_surface_equals_reference_composition():
     """System::findCameraPoseWithIMU (system.cpp:57-104): orientation from the IMU quaternion (w, -x, y, z), inverted; translation = the
     visual translation integrated over the tracked frames (reset of the increment on every frame that is not tracked).  Expected arrays come
