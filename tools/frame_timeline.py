@@ -16,9 +16,8 @@ for f in range(max(1, len(klt) - 1500), len(klt) - 1):
     if any(k[2] not in chain for k in ks[a:c]):
         continue   # a keyframe's kernels before or after this tracker
     t0 = ks[b][0]
-    for s, e, name in ks[a + 1:c]:
-        tag = name + (" (previous frame)" if s < t0 and name == "k_pose_all" else "")
-        v = acc.setdefault(tag, [0.0, 0.0, 0])
+    for s, e, name in ks[b:c]:   # this frame's tracker and everything up to (not including) the next frame's tracker
+        v = acc.setdefault(name, [0.0, 0.0, 0])
         v[0] += (s - t0) / 1e3
         v[1] += (e - t0) / 1e3
         v[2] += 1
