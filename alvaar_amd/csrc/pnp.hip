@@ -1039,9 +1039,14 @@ int alva_pose_all_go(alva_ctx *ctx, int n) {
         const size_t index_size = (size_t) n;
         static thread_local std::vector<int> touched;
         touched.clear();
+        // (raw % (n - i): four divisors for the whole call -- the remainders by multiplication (Lemire's fastmod: exact for 32-bit operands)
+        // instead of 4 H hardware divisions, 2 of the answer's 2.5 us on the frame's critical path)
+        uint64_t magic[4];
+        for (unsigned i = 0; i < 4; ++i) magic[i] = UINT64_C(0xFFFFFFFFFFFFFFFF) / (uint64_t) (index_size - i) + 1;
         for (int k = 0; k < P.H; k++) {
             for (unsigned i = 0; i < 4; ++i) {
-                const size_t j = i + ((size_t) P.raw[(size_t) 4 * k + i] % (index_size - i));
+                const uint64_t low = magic[i] * (uint64_t) (uint32_t) P.raw[(size_t) 4 * k + i];
+                const size_t j = i + (size_t) (((__uint128_t) low * (uint64_t) (index_size - i)) >> 64);
                 std::swap(sh[i], sh[j]);
                 touched.push_back((int) j);
             }

@@ -26,6 +26,20 @@ __device__ __forceinline__ bool track_compact_body(const TrackSlots &D, const in
     const int per = ((D.n + G - 1) / G + 63) / 64 * 64;   // slice length, a multiple of the wave size
     const int lo = g * per, hi = min(D.n, lo + per);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // GATHER_FIRST: the slice's rows requested NOW, beside the flag bytes of the scan below (one trip to memory the tracker wrote instead
+    // of two behind each other: the scan's barriers stand between them otherwise).  One slice per workgroup: thread t owns slot lo + t.
+    uint8_t h_code = 0, h_is3d = 0;
+    float h_px[2] = {0, 0}, h_ux[2] = {0, 0};
+    double h_bv[3] = {0, 0, 0}, h_w[3] = {0, 0, 0};
+    if (GATHER_FIRST && lo + (int) threadIdx.x < hi) {
+        const size_t j = (size_t) (lo + (int) threadIdx.x);
+        h_code = D.d_code[j];
+        h_is3d = D.d_is3d[j];
+        h_px[0] = D.d_px[2 * j]; h_px[1] = D.d_px[2 * j + 1];
+        h_ux[0] = D.d_unpx[2 * j]; h_ux[1] = D.d_unpx[2 * j + 1];
+        h_bv[0] = D.d_bv[3 * j]; h_bv[1] = D.d_bv[3 * j + 1]; h_bv[2] = D.d_bv[3 * j + 2];
+        h_w[0] = D.d_wpt[3 * j]; h_w[1] = D.d_wpt[3 * j + 1]; h_w[2] = D.d_wpt[3 * j + 2];
+    }
     // pose flags in front of the slice (and, for the header, behind it): ballot counts
     int before = 0, total = 0;
     // (eight rounds' flag bytes requested before the first ballot: the rounds are dependent trips to memory another kernel wrote, and a
@@ -69,7 +83,15 @@ __device__ __forceinline__ bool track_compact_body(const TrackSlots &D, const in
         bool pose = false;
         float px[2] = {0, 0}, ux[2] = {0, 0};
         double bv[3] = {0, 0, 0};
-        if (i < hi) {   // the slot's results to the host, from THIS kernel (see track_slots.hpp)
+        if (GATHER_FIRST && i0 == lo) {   // (the rows requested at the top)
+            if (i < hi) {
+                code = h_code;
+                px[0] = h_px[0]; px[1] = h_px[1];
+                ux[0] = h_ux[0]; ux[1] = h_ux[1];
+                bv[0] = h_bv[0]; bv[1] = h_bv[1]; bv[2] = h_bv[2];
+                pose = code != 0 && h_is3d != 0;
+            }
+        } else if (i < hi) {   // the slot's results to the host, from THIS kernel (see track_slots.hpp)
             const size_t j = (size_t) i;
             code = D.d_code[i];
             px[0] = D.d_px[2 * j]; px[1] = D.d_px[2 * j + 1];
@@ -99,7 +121,9 @@ __device__ __forceinline__ bool track_compact_body(const TrackSlots &D, const in
                 };
                 put(D.Pbv + 3 * k, bv[0]); put(D.Pbv + 3 * k + 1, bv[1]); put(D.Pbv + 3 * k + 2, bv[2]);
                 put(D.Puv + 2 * k, (double) ux[0]); put(D.Puv + 2 * k + 1, (double) ux[1]);
-                put(D.Pwpt + 3 * k, D.d_wpt[3 * j]); put(D.Pwpt + 3 * k + 1, D.d_wpt[3 * j + 1]); put(D.Pwpt + 3 * k + 2, D.d_wpt[3 * j + 2]);
+                const bool first = i0 == lo;
+                put(D.Pwpt + 3 * k, first ? h_w[0] : D.d_wpt[3 * j]); put(D.Pwpt + 3 * k + 1, first ? h_w[1] : D.d_wpt[3 * j + 1]);
+                put(D.Pwpt + 3 * k + 2, first ? h_w[2] : D.d_wpt[3 * j + 2]);
             } else {
                 D.Pbv[3 * k] = bv[0]; D.Pbv[3 * k + 1] = bv[1]; D.Pbv[3 * k + 2] = bv[2];
                 D.Puv[2 * k] = (double) ux[0]; D.Puv[2 * k + 1] = (double) ux[1];
