@@ -220,6 +220,7 @@ void Slam::klt_from_motion_prior() {
         // the previous frame's slot LIST is walked -- an array, no pointer chain through the table -- and the rows whose slot is still
         // live are kept, without a branch.
         const int np = carry_n_prev_;
+        if (check_carry_) chk_carry_.resize((size_t) n + 1);
         const int *pid = job_ids_prev_.data(), *psl = job_slots_prev_.data();
         const uint8_t *p3 = job_is3d_prev_.data();
         int *oid = job_ids_.data(), *osl = job_slots_.data();
@@ -228,7 +229,8 @@ void Slam::klt_from_motion_prior() {
         for (int ip = 0; ip < np; ip++) {
             const int sl = psl[(size_t) ip];
             if (i > n) break;   // (more live slots than keypoints: cannot happen; caught below)
-            carry[(size_t) i] = (uint16_t) ip;   // (i <= n < the buffer's capacity, track_carry_buffer)
+            carry[(size_t) i] = (uint16_t) ip;   // (i <= n < the buffer's capacity, track_carry_buffer; device memory behind the bus: written, never read)
+            if (check_carry_) chk_carry_[(size_t) i] = (uint16_t) ip;
             osl[(size_t) i] = sl;
             oid[(size_t) i] = pid[(size_t) ip];
             o3[(size_t) i] = p3[(size_t) ip];
@@ -295,7 +297,7 @@ void Slam::klt_from_motion_prior() {
         if (carry) {
             const TrackKlt &pr = klt_out_;
             for (int i = 0; i < n; i++) {
-                const size_t ip = (size_t) carry[(size_t) i];
+                const size_t ip = (size_t) chk_carry_[(size_t) i];
                 const bool same = std::memcmp(&jpx[2 * (size_t) i], &pr.px_v[2 * ip], 8) == 0 && j3d[(size_t) i] == chk_is3d_[ip] &&
                                   std::memcmp(&jw[3 * (size_t) i], &chk_wpt_[3 * ip], 24) == 0;
                 if (!same) {

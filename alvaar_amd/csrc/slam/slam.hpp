@@ -554,6 +554,7 @@ private:
     bool check_carry_ = false;    // ALVA_CHECK_CARRY=1: every carried table against the assembled one (host side), abort on a difference
     std::vector<float> chk_px_;
     std::vector<uint8_t> chk_is3d_;
+    std::vector<uint16_t> chk_carry_;
     std::vector<double> chk_wpt_;
     TrackKlt klt_out_;
     TrackPose pose_out_;
